@@ -1,0 +1,513 @@
+#!/usr/bin/env python
+"""Generate the committed golden vectors by IMPORTING the reference
+(`/root/reference`, lis-epfl/apg_trajectory_tracking) in the build container.
+
+Run once, here, as:   python tests/golden/make_golden.py
+The reference never travels to the GPU box; only the `.npz` files written
+next to this script do.  They contain inputs and the reference's outputs
+(states, losses, autograd gradients) only - no reference source.
+
+Fixtures:
+  quad_step.npz      G1  FlightmareDynamics single step + VJPs, known-answer
+  quad_rollout.npz   G2  H-step unroll + quad_mpc_loss + autograd grads
+  quad_train.npz     G3  TrainDrone.train_controller_model, 2 SGD steps
+  quad_recurrent.npz G4  autoregressive / LSTM unroll (window .clone() patch)
+  wing.npz           G5  FixedWingDynamics step, 1001-step sim, rollout+grads
+  cartpole.npz       G6  CartpoleDynamics step + rollout + grads
+  features.npz       G7  state_preprocessing + VJP
+  losses.npz         G8  the three MPC losses + grads on random inputs
+"""
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _SX:  # casadi.SX is only touched in Dynamics.__init__
+    def __init__(self, *a, **k):
+        pass
+
+
+class _Any:
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, n):
+        return _Any()
+
+    def __call__(self, *a, **k):
+        return _Any()
+
+
+def install_stubs():
+    _stub("casadi", SX=_SX)
+    gym = _stub("gym")
+    gym.Env = object
+    gym.spaces = _stub("gym.spaces", Box=_Any)
+    gym.utils = _stub("gym.utils")
+    gym.utils.seeding = _stub(
+        "gym.utils.seeding", np_random=lambda seed=None: (None, seed)
+    )
+    pg = _stub("pyglet")
+    pg.gl = _stub("pyglet.gl")
+    _stub("pyquaternion", Quaternion=_Any)
+    _stub("cv2")
+
+
+install_stubs()
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "scripts"))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(1)
+
+from neural_control.dynamics.quad_dynamics_flightmare import (  # noqa: E402
+    FlightmareDynamics
+)
+from neural_control.dynamics.fixed_wing_dynamics import (  # noqa: E402
+    FixedWingDynamics
+)
+from neural_control.dynamics.cartpole_dynamics import (  # noqa: E402
+    CartpoleDynamics
+)
+from neural_control.drone_loss import (  # noqa: E402
+    quad_mpc_loss, fixed_wing_mpc_loss, cartpole_loss_mpc
+)
+from neural_control.dataset import state_preprocessing  # noqa: E402
+from neural_control.models.hutter_model import Net  # noqa: E402
+from neural_control.models.rnn import LSTM_NEW  # noqa: E402
+from neural_control.models.simple_model import Net as CartNet  # noqa: E402
+
+torch.autograd.set_detect_anomaly(False)  # drone_loss turns it on at import
+
+from apg_trajectory_tracking_amd import synthetic  # noqa: E402
+
+MOD_PARAMS = {
+    "translational_drag": [.1, .2, .3],
+    "rotational_drag": [.01, .02, .03],
+    "mass": 1.0,
+}
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB, keys={len(arrays)}")
+
+
+def rollout(dyn, loss_fn, state0, actions, ref, dt):
+    """The concurrent unroll of scripts/train_drone.py:181-194 /
+    scripts/train_fixed_wing.py:94-106, driven with leaf tensors."""
+    s0 = state0.clone().requires_grad_(True)
+    a = actions.clone().requires_grad_(True)
+    B, H = a.shape[:2]
+    inter = torch.zeros(B, H, s0.shape[1])
+    cur = s0
+    for k in range(H):
+        cur = dyn(cur, a[:, k], dt)
+        inter[:, k] = cur
+    loss = loss_fn(inter, ref, a)
+    loss.backward()
+    return npy(inter), float(loss.item()), npy(a.grad), npy(s0.grad)
+
+
+# --------------------------------------------------------------------- G1
+def g1_quad_step():
+    out = {}
+    dyn = FlightmareDynamics()
+    ka_a = torch.tensor([[0.45, 0.46, 0.3, 0.6]])
+    ka_s = torch.tensor([[
+        -0.203302, -8.12219, 0.484883, -0.15613, -0.446313, 0.25728,
+        -4.70952, 0.627684, -2.506545, -0.039999, -0.200001, 0.1
+    ]])
+    out["ka_state"], out["ka_action"] = npy(ka_s), npy(ka_a)
+    out["ka_dt"] = np.float32(0.05)
+    out["ka_next"] = npy(dyn.simulate_quadrotor(ka_a, ka_s, 0.05))
+    g = torch.Generator().manual_seed(11)
+    B = 64
+    state = torch.randn(B, 12, generator=g)
+    state[:, 3:6] *= 0.6
+    action = torch.rand(B, 4, generator=g)
+    cot = torch.randn(4, B, 12, generator=g)
+    out["state"], out["action"], out["cot"] = npy(state), npy(action), npy(cot)
+    for tag, mp in (("def", {}), ("mod", MOD_PARAMS)):
+        d = FlightmareDynamics(modified_params=dict(mp))
+        for dt in (0.05, 0.1):
+            s = state.clone().requires_grad_(True)
+            a = action.clone().requires_grad_(True)
+            nxt = d(s, a, dt)
+            key = f"{tag}_dt{int(round(dt*100)):03d}"
+            out[key + "_next"] = npy(nxt)
+            gs, ga = [], []
+            for c in cot:
+                r = torch.autograd.grad(nxt, (s, a), c, retain_graph=True)
+                gs.append(npy(r[0]))
+                ga.append(npy(r[1]))
+            out[key + "_gstate"] = np.stack(gs)
+            out[key + "_gaction"] = np.stack(ga)
+    # B = 1 (eval-time caller, neural_control/environments/drone_env.py:99)
+    out["b1_next"] = npy(dyn(state[:1], action[:1], 0.1))
+    save("quad_step.npz", **out)
+
+
+# --------------------------------------------------------------------- G2
+def g2_quad_rollout():
+    out = {}
+    B, H, dt = 64, 10, 0.1
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=3)
+    out["state0"], out["actions"], out["ref"] = (
+        npy(d["state0"]), npy(d["actions"]), npy(d["ref"])
+    )
+    out["dt"] = np.float32(dt)
+    for tag, mp in (("def", {}), ("mod", MOD_PARAMS)):
+        dyn = FlightmareDynamics(modified_params=dict(mp))
+        st, loss, ga, gs = rollout(
+            dyn, quad_mpc_loss, d["state0"], d["actions"], d["ref"], dt
+        )
+        out[tag + "_states"], out[tag + "_loss"] = st, np.float64(loss)
+        out[tag + "_gactions"], out[tag + "_gstate0"] = ga, gs
+    # a second shape: H = 5, dt = 0.05, ragged batch 37
+    d2 = synthetic.quad_polynomial_batch(37, 5, 0.05, seed=4)
+    dyn = FlightmareDynamics()
+    st, loss, ga, gs = rollout(
+        dyn, quad_mpc_loss, d2["state0"], d2["actions"], d2["ref"], 0.05
+    )
+    out.update(
+        h5_state0=npy(d2["state0"]), h5_actions=npy(d2["actions"]),
+        h5_ref=npy(d2["ref"]), h5_states=st, h5_loss=np.float64(loss),
+        h5_gactions=ga, h5_gstate0=gs, h5_dt=np.float32(0.05)
+    )
+    save("quad_rollout.npz", **out)
+
+
+# --------------------------------------------------------------------- G3
+def _state_dict_np(net, prefix):
+    return {prefix + k: npy(v) for k, v in net.state_dict().items()}
+
+
+def g3_quad_train():
+    import train_drone  # reference trainer (scripts/train_drone.py)
+    cwd = os.getcwd()
+    os.makedirs("/tmp/apg_golden_scratch", exist_ok=True)
+    os.chdir("/tmp/apg_golden_scratch")  # TrainBase.__init__ makedirs
+    try:
+        import json
+        with open(os.path.join(REF, "configs", "quad_config.json")) as f:
+            config = json.load(f)
+        B, H, dt = 64, 10, 0.1
+        config["batch_size"] = B
+        config["sample_in"] = "train_env"
+        dyn = FlightmareDynamics()
+        trainer = train_drone.TrainDrone(dyn, dyn, config)
+        torch.manual_seed(5)
+        trainer.net = Net(15, H, 9, 4 * H, conv=1)
+        trainer.optimizer_controller = torch.optim.SGD(
+            trainer.net.parameters(), lr=1e-5, momentum=0.9
+        )
+        out = _state_dict_np(trainer.net, "w0.")
+        d = synthetic.quad_polynomial_batch(B, H, dt, seed=6)
+        in_state = state_preprocessing(d["state0"])
+        out.update(
+            state0=npy(d["state0"]), in_state=npy(in_state),
+            in_ref=npy(d["in_ref"]), ref=npy(d["ref"]),
+            lr=np.float32(1e-5), momentum=np.float32(0.9), dt=np.float32(dt)
+        )
+        for step in (1, 2):
+            # body of TrainBase.run_epoch, scripts/train_base.py:202-209
+            actions = torch.sigmoid(trainer.net(in_state, d["in_ref"]))
+            action_seq = torch.reshape(actions, (-1, H, 4))
+            loss = trainer.train_controller_model(
+                d["state0"], action_seq, d["in_ref"], d["ref"]
+            )
+            out[f"loss{step}"] = np.float64(loss.item())
+            if step == 1:
+                out["actions1"] = npy(action_seq)
+                for k, p in trainer.net.named_parameters():
+                    if p.grad is not None:  # ref_in is unused when conv=1
+                        out["g1." + k] = npy(p.grad)
+            out.update(_state_dict_np(trainer.net, f"w{step}."))
+        save("quad_train.npz", **out)
+    finally:
+        os.chdir(cwd)
+
+
+# --------------------------------------------------------------------- G4
+def recurrent_unroll(net, dyn, state0, in_ref, ref, H, dt, lstm_state=None):
+    """scripts/train_drone.py:113-165 with ONE change: the reference window
+    is `.clone()`d before the relative-position subtraction (SURVEY.md §8a
+    A4 'pinned semantics'); as shipped the in-place write through the view
+    breaks autograd on torch 2.x.  Explicit (h0, c0) replace torch.randn."""
+    B = state0.shape[0]
+    inter = torch.zeros(B, H, 12)
+    action_seq = torch.zeros(B, H, 4)
+    if lstm_state is not None:
+        net.hidden_state, net.cell_state = lstm_state
+    cur = state0
+    for k in range(H):
+        rel = in_ref[:, k:k + H].clone()
+        rel[:, :, :3] = rel[:, :, :3] - torch.unsqueeze(cur[:, :3], 1)
+        in_state = state_preprocessing(cur)
+        action = torch.sigmoid(net(in_state, rel))
+        action_seq[:, k] = action
+        cur = dyn(cur, action, dt=dt)
+        inter[:, k] = cur
+    loss = quad_mpc_loss(inter, ref[:, :H], action_seq, printout=0)
+    return inter, action_seq, loss
+
+
+def g4_quad_recurrent():
+    out = {}
+    B, H, dt = 32, 10, 0.1
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=8, ref_length=2 * H)
+    out.update(
+        state0=npy(d["state0"]), in_ref=npy(d["in_ref"]), ref=npy(d["ref"]),
+        dt=np.float32(dt)
+    )
+    dyn = FlightmareDynamics()
+    for mode in ("ar", "lstm"):
+        torch.manual_seed(9)
+        if mode == "ar":
+            net = Net(15, H, 9, 4, conv=1)
+            lstm_state = None
+        else:
+            net = LSTM_NEW(15, H, 9, 4, conv=1)
+            g = torch.Generator().manual_seed(10)
+            h0 = torch.randn(B, 8, generator=g)
+            c0 = torch.randn(B, 8, generator=g)
+            out["lstm_h0"], out["lstm_c0"] = npy(h0), npy(c0)
+            lstm_state = (h0, c0)
+        out.update(_state_dict_np(net, f"{mode}.w."))
+        inter, action_seq, loss = recurrent_unroll(
+            net, dyn, d["state0"], d["in_ref"], d["ref"], H, dt, lstm_state
+        )
+        loss.backward()
+        out[f"{mode}.states"] = npy(inter)
+        out[f"{mode}.actions"] = npy(action_seq)
+        out[f"{mode}.loss"] = np.float64(loss.item())
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                out[f"{mode}.g.{k}"] = npy(p.grad)
+    save("quad_recurrent.npz", **out)
+
+
+# --------------------------------------------------------------------- G5
+def g5_wing():
+    out = {}
+    dyn = FixedWingDynamics()
+    ka_s = torch.tensor([[
+        0.6933, -0.8747, 0.9757, -0.8422, 0.5494, -1.1936, 0.0368, 0.8417,
+        -0.9412, -1.4291, 0.4538, -0.5257
+    ]])
+    ka_a = torch.tensor([[-0.5518, -2.9553, 0.0311, -0.6691]])
+    out["ka_state"], out["ka_action"] = npy(ka_s), npy(ka_a)
+    out["ka_next"] = npy(dyn.simulate_fixed_wing(ka_s, ka_a, 0.05))
+    # tests/run_wing_sim.py: 1001-step open-loop simulation
+    state = torch.zeros(1, 12)
+    state[0, 3] = 11.5
+    action = torch.tensor([[1.9 / 7, 0.5, 0.5, 35 / 40]])
+    buf = np.zeros((1001, 12), np.float32)
+    for i in range(1001):
+        buf[i] = state.numpy()[0]
+        state = dyn.simulate_fixed_wing(state, action, 1 / 100)
+    out["sim_action"] = npy(action)
+    out["sim_rows"] = np.array([0, 1, 10, 100, 250, 500, 750, 1000])
+    out["sim_states"] = buf[out["sim_rows"]]
+    # single step + VJPs, including alpha/beta beyond the +-10deg clamp
+    g = torch.Generator().manual_seed(21)
+    B = 64
+    d = synthetic.wing_batch(B, 20, 0.05, seed=22)
+    st = d["state0"].clone()
+    st[:, :3] = torch.randn(B, 3, generator=g)
+    st[:16, 5] = 4.0 * torch.randn(16, generator=g)   # large w -> alpha clamp
+    st[16:32, 4] = 4.0 * torch.randn(16, generator=g)  # large v -> beta clamp
+    st[:, 6:9] += 0.3 * torch.randn(B, 3, generator=g)
+    st[:, 9:12] += 0.5 * torch.randn(B, 3, generator=g)
+    act = torch.rand(B, 4, generator=g)
+    cot = torch.randn(4, B, 12, generator=g)
+    out["step_state"], out["step_action"], out["step_cot"] = (
+        npy(st), npy(act), npy(cot)
+    )
+    for tag, mp in (("def", {}), ("mod", {"mass": 1.4, "I_xz": -0.01,
+                                         "CL0": 0.3, "rho": 1.0})):
+        dd = FixedWingDynamics(modified_params=dict(mp))
+        s = st.clone().requires_grad_(True)
+        a = act.clone().requires_grad_(True)
+        nxt = dd(s, a, 0.05)
+        out[f"step_{tag}_next"] = npy(nxt)
+        gs, ga = [], []
+        for c in cot:
+            r = torch.autograd.grad(nxt, (s, a), c, retain_graph=True)
+            gs.append(npy(r[0]))
+            ga.append(npy(r[1]))
+        out[f"step_{tag}_gstate"] = np.stack(gs)
+        out[f"step_{tag}_gaction"] = np.stack(ga)
+    # rollout H = 20 (BASELINE config 4) and H = 10 (shipped config)
+    for H in (20, 10):
+        d = synthetic.wing_batch(B, H, 0.05, seed=23 + H)
+        s0 = d["state0"].clone()
+        s0[:8, 5] += 3.0   # some trajectories start outside the clamp
+        sts, loss, ga, gs = rollout(
+            dyn, fixed_wing_mpc_loss, s0, d["actions"], d["ref"], 0.05
+        )
+        p = f"h{H}_"
+        out.update({
+            p + "state0": npy(s0), p + "actions": npy(d["actions"]),
+            p + "ref": npy(d["ref"]), p + "target": npy(d["target"]),
+            p + "states": sts, p + "loss": np.float64(loss),
+            p + "gactions": ga, p + "gstate0": gs,
+        })
+    out["dt"] = np.float32(0.05)
+    save("wing.npz", **out)
+
+
+# --------------------------------------------------------------------- G6
+def g6_cartpole():
+    out = {}
+    dyn = CartpoleDynamics()
+    ka_s = torch.tensor([[0.5, 1.3, 0.1, 0.4]])
+    ka_a = torch.tensor([[0.4]])
+    out["ka_state"], out["ka_action"] = npy(ka_s), npy(ka_a)
+    out["ka_next"] = npy(dyn(ka_s, ka_a, 0.02))
+    B, H, dt = 64, 5, 0.05
+    d = synthetic.cartpole_batch(B, H, seed=31)
+    s0 = d["state0"].clone().requires_grad_(True)
+    a = d["actions"].clone().requires_grad_(True)
+    # make_reference, scripts/train_cartpole.py:103-110
+    ref = torch.zeros(B, H, 4)
+    for k in range(H - 1):
+        ref[:, k] = (s0 * (1 - 1 / (H - 1) * k))
+    inter = torch.zeros(B, H, 4)
+    cur = s0
+    for k in range(H):
+        cur = dyn(cur, a[:, k], dt=dt)
+        inter[:, k] = cur
+    loss = cartpole_loss_mpc(inter, ref, a)
+    loss.backward()
+    out.update(
+        state0=npy(d["state0"]), actions=npy(d["actions"]), ref=npy(ref),
+        states=npy(inter), loss=np.float64(loss.item()),
+        gactions=npy(a.grad), gstate0=npy(s0.grad), dt=np.float32(dt)
+    )
+    # same with the reference held constant (no gradient through ref):
+    s0 = d["state0"].clone().requires_grad_(True)
+    a = d["actions"].clone().requires_grad_(True)
+    cur = s0
+    inter = torch.zeros(B, H, 4)
+    for k in range(H):
+        cur = dyn(cur, a[:, k], dt=dt)
+        inter[:, k] = cur
+    loss = cartpole_loss_mpc(inter, ref.detach(), a)
+    loss.backward()
+    out.update(
+        detref_gactions=npy(a.grad), detref_gstate0=npy(s0.grad),
+        detref_loss=np.float64(loss.item())
+    )
+    # single-step VJP
+    g = torch.Generator().manual_seed(32)
+    cot = torch.randn(B, 4, generator=g)
+    s = d["state0"].clone().requires_grad_(True)
+    a1 = d["actions"][:, 0].clone().requires_grad_(True)
+    nxt = dyn(s, a1, 0.02)
+    r = torch.autograd.grad(nxt, (s, a1), cot)
+    out.update(
+        step_next=npy(nxt), step_cot=npy(cot), step_gstate=npy(r[0]),
+        step_gaction=npy(r[1])
+    )
+    # train step with the cartpole policy (simple_model.Net; tanh, no sigmoid)
+    torch.manual_seed(33)
+    net = CartNet(4, H * 1)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-4, momentum=0.9)
+    out.update(_state_dict_np(net, "w0."))
+    in_state = d["state0"].clone()
+    cur0 = d["state0"].clone()
+    # body of TrainCartpole.run_epoch, scripts/train_cartpole.py:127-155
+    actions = net(in_state)     # NB zeroes column 0 of its input in place
+    action_seq = torch.reshape(actions, (-1, H, 1))
+    opt.zero_grad()
+    ref = torch.zeros(B, H, 4)
+    for k in range(H - 1):
+        ref[:, k] = (cur0 * (1 - 1 / (H - 1) * k))
+    inter = torch.zeros(B, H, 4)
+    cur = cur0
+    for k in range(H):
+        cur = dyn(cur, action_seq[:, k], dt=dt)
+        inter[:, k] = cur
+    loss = cartpole_loss_mpc(inter, ref, action_seq)
+    loss.backward()
+    opt.step()
+    out["train_loss"] = np.float64(loss.item())
+    out["train_actions"] = npy(action_seq)
+    for k, p in net.named_parameters():
+        out["g1." + k] = npy(p.grad)
+    out.update(_state_dict_np(net, "w1."))
+    save("cartpole.npz", **out)
+
+
+# --------------------------------------------------------------------- G7
+def g7_features():
+    g = torch.Generator().manual_seed(41)
+    B = 64
+    st = torch.randn(B, 12, generator=g)
+    cot = torch.randn(B, 15, generator=g)
+    s = st.clone().requires_grad_(True)
+    f = state_preprocessing(s)
+    (gs,) = torch.autograd.grad(f, s, cot)
+    save("features.npz", state=npy(st), cot=npy(cot), feat=npy(f),
+         gstate=npy(gs))
+
+
+# --------------------------------------------------------------------- G8
+def g8_losses():
+    out = {}
+    g = torch.Generator().manual_seed(51)
+    B, H = 48, 10
+    st = torch.randn(B, H, 12, generator=g).requires_grad_(True)
+    ref = torch.randn(B, H, 9, generator=g)
+    act = torch.rand(B, H, 4, generator=g).requires_grad_(True)
+    loss = quad_mpc_loss(st, ref, act)
+    gs, ga = torch.autograd.grad(loss, (st, act))
+    out.update(q_states=npy(st), q_ref=npy(ref), q_actions=npy(act),
+               q_loss=np.float64(loss.item()), q_gstates=npy(gs),
+               q_gactions=npy(ga))
+    ref3 = torch.randn(B, H, 3, generator=g)
+    loss = fixed_wing_mpc_loss(st, ref3, act)
+    gs, ga = torch.autograd.grad(loss, (st, act))
+    out.update(w_ref=npy(ref3), w_loss=np.float64(loss.item()),
+               w_gstates=npy(gs), w_gactions=npy(ga))
+    st4 = torch.randn(B, 5, 4, generator=g).requires_grad_(True)
+    ref4 = torch.randn(B, 5, 4, generator=g)
+    act1 = torch.randn(B, 5, 1, generator=g).requires_grad_(True)
+    loss = cartpole_loss_mpc(st4, ref4, act1)
+    gs, ga = torch.autograd.grad(loss, (st4, act1))
+    out.update(c_states=npy(st4), c_ref=npy(ref4), c_actions=npy(act1),
+               c_loss=np.float64(loss.item()), c_gstates=npy(gs),
+               c_gactions=npy(ga))
+    save("losses.npz", **out)
+
+
+if __name__ == "__main__":
+    g1_quad_step()
+    g2_quad_rollout()
+    g3_quad_train()
+    g4_quad_recurrent()
+    g5_wing()
+    g6_cartpole()
+    g7_features()
+    g8_losses()

@@ -1,0 +1,187 @@
+"""Pin the PyTorch-eager oracle (oracle/torch_port.py) against the golden
+vectors generated from the real reference (tests/golden/make_golden.py).
+CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import torch_port as tp
+
+T = torch.from_numpy
+MOD = {"translational_drag": [.1, .2, .3], "rotational_drag": [.01, .02, .03],
+       "mass": 1.0}
+TOL = 2e-6   # oracle follows the reference's op order: ~fp32 rounding
+
+
+def test_quad_known_answer():
+    g = load_golden("quad_step.npz")
+    dyn = tp.QuadOracle()
+    nxt = dyn(T(g["ka_state"]), T(g["ka_action"]), float(g["ka_dt"]))
+    assert rel_err(nxt.numpy(), g["ka_next"]) < TOL
+    # value printed in SURVEY.md §4 (quad_dynamics_flightmare.py:324-341)
+    np.testing.assert_allclose(
+        nxt.numpy()[0],
+        [-0.3262, -8.1060, 0.4200, -0.1560, -0.4569, 0.2602, -4.9142, 0.6467,
+         -2.5934, -0.0400, -0.2000, 0.1000], atol=5e-5)
+
+
+@pytest.mark.parametrize("tag,mp", [("def", {}), ("mod", MOD)])
+@pytest.mark.parametrize("dt", [0.05, 0.1])
+def test_quad_step_and_vjp(tag, mp, dt):
+    g = load_golden("quad_step.npz")
+    dyn = tp.QuadOracle(mp)
+    s = T(g["state"]).requires_grad_(True)
+    a = T(g["action"]).requires_grad_(True)
+    nxt = dyn(s, a, dt)
+    key = f"{tag}_dt{int(round(dt*100)):03d}"
+    assert rel_err(nxt.detach().numpy(), g[key + "_next"]) < TOL
+    for i, c in enumerate(T(g["cot"])):
+        gs, ga = torch.autograd.grad(nxt, (s, a), c, retain_graph=True)
+        assert rel_err(gs.numpy(), g[key + "_gstate"][i]) < 1e-5
+        assert rel_err(ga.numpy(), g[key + "_gaction"][i]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,mp", [("def", {}), ("mod", MOD)])
+def test_quad_rollout(tag, mp):
+    g = load_golden("quad_rollout.npz")
+    st, loss, ga, gs = tp.rollout_fwd_bwd(
+        tp.QuadOracle(mp), tp.quad_mpc_loss, T(g["state0"]), T(g["actions"]),
+        T(g["ref"]), float(g["dt"]))
+    assert rel_err(st.numpy(), g[tag + "_states"]) < 1e-5
+    assert abs(loss.item() - g[tag + "_loss"]) / g[tag + "_loss"] < 1e-5
+    assert rel_err(ga.numpy(), g[tag + "_gactions"]) < 1e-5
+    assert rel_err(gs.numpy(), g[tag + "_gstate0"]) < 1e-5
+
+
+def test_quad_rollout_h5_ragged():
+    g = load_golden("quad_rollout.npz")
+    st, loss, ga, gs = tp.rollout_fwd_bwd(
+        tp.QuadOracle(), tp.quad_mpc_loss, T(g["h5_state0"]),
+        T(g["h5_actions"]), T(g["h5_ref"]), float(g["h5_dt"]))
+    assert rel_err(st.numpy(), g["h5_states"]) < 1e-5
+    assert rel_err(ga.numpy(), g["h5_gactions"]) < 1e-5
+    assert rel_err(gs.numpy(), g["h5_gstate0"]) < 1e-5
+
+
+def test_quad_features():
+    g = load_golden("features.npz")
+    s = T(g["state"]).requires_grad_(True)
+    f = tp.quad_state_features(s)
+    assert rel_err(f.detach().numpy(), g["feat"]) < TOL
+    (gs,) = torch.autograd.grad(f, s, T(g["cot"]))
+    assert rel_err(gs.numpy(), g["gstate"]) < 1e-5
+
+
+def test_losses():
+    g = load_golden("losses.npz")
+    st = T(g["q_states"]).requires_grad_(True)
+    act = T(g["q_actions"]).requires_grad_(True)
+    loss = tp.quad_mpc_loss(st, T(g["q_ref"]), act)
+    gs, ga = torch.autograd.grad(loss, (st, act))
+    assert abs(loss.item() - g["q_loss"]) / g["q_loss"] < 1e-6
+    assert rel_err(gs.numpy(), g["q_gstates"]) < 1e-6
+    assert rel_err(ga.numpy(), g["q_gactions"]) < 1e-6
+    loss = tp.fixed_wing_mpc_loss(st, T(g["w_ref"]), act)
+    gs, ga = torch.autograd.grad(loss, (st, act))
+    assert abs(loss.item() - g["w_loss"]) / g["w_loss"] < 1e-6
+    assert rel_err(gs.numpy(), g["w_gstates"]) < 1e-6
+    assert rel_err(ga.numpy(), g["w_gactions"]) < 1e-6
+    st4 = T(g["c_states"]).requires_grad_(True)
+    a1 = T(g["c_actions"]).requires_grad_(True)
+    loss = tp.cartpole_loss_mpc(st4, T(g["c_ref"]), a1)
+    gs, ga = torch.autograd.grad(loss, (st4, a1))
+    assert abs(loss.item() - g["c_loss"]) / g["c_loss"] < 1e-6
+    assert rel_err(gs.numpy(), g["c_gstates"]) < 1e-6
+    assert rel_err(ga.numpy(), g["c_gactions"]) < 1e-6
+
+
+def test_wing_known_answers():
+    g = load_golden("wing.npz")
+    dyn = tp.WingOracle()
+    nxt = dyn(T(g["ka_state"]), T(g["ka_action"]), 0.05)
+    assert rel_err(nxt.numpy(), g["ka_next"]) < TOL
+    # tests/run_wing_sim.py 1001-step open-loop trace
+    state = torch.zeros(1, 12)
+    state[0, 3] = 11.5
+    action = T(g["sim_action"])
+    rows = list(g["sim_rows"])
+    got = []
+    for i in range(1001):
+        if i in rows:
+            got.append(state.numpy()[0].copy())
+        state = dyn(state, action, 1 / 100)
+    got = np.stack(got)
+    assert rel_err(got, g["sim_states"]) < 2e-4   # 1000 chained fp32 steps
+    np.testing.assert_allclose(
+        got[rows.index(500)],
+        [55.06866, -10.88738, 0.46948, 11.96358, 0.08464, 0.16587, -0.52947,
+         -0.01997, -0.80656, -0.05414, 0.17649, -0.29552], rtol=2e-3,
+        atol=2e-3)
+
+
+@pytest.mark.parametrize("tag,mp", [
+    ("def", {}), ("mod", {"mass": 1.4, "I_xz": -0.01, "CL0": 0.3, "rho": 1.0})
+])
+def test_wing_step_and_vjp(tag, mp):
+    g = load_golden("wing.npz")
+    dyn = tp.WingOracle(mp)
+    s = T(g["step_state"]).requires_grad_(True)
+    a = T(g["step_action"]).requires_grad_(True)
+    nxt = dyn(s, a, 0.05)
+    assert rel_err(nxt.detach().numpy(), g[f"step_{tag}_next"]) < TOL
+    for i, c in enumerate(T(g["step_cot"])):
+        gs, ga = torch.autograd.grad(nxt, (s, a), c, retain_graph=True)
+        assert rel_err(gs.numpy(), g[f"step_{tag}_gstate"][i]) < 1e-5
+        assert rel_err(ga.numpy(), g[f"step_{tag}_gaction"][i]) < 1e-5
+
+
+@pytest.mark.parametrize("H", [20, 10])
+def test_wing_rollout(H):
+    g = load_golden("wing.npz")
+    p = f"h{H}_"
+    s0 = T(g[p + "state0"])
+    ref = T(g[p + "ref"])
+    st, loss, ga, gs = tp.rollout_fwd_bwd(
+        tp.WingOracle(), tp.fixed_wing_mpc_loss, s0, T(g[p + "actions"]), ref,
+        0.05)
+    assert rel_err(st.numpy(), g[p + "states"]) < 1e-5
+    assert abs(loss.item() - g[p + "loss"]) / g[p + "loss"] < 1e-5
+    assert rel_err(ga.numpy(), g[p + "gactions"]) < 2e-5
+    assert rel_err(gs.numpy(), g[p + "gstate0"]) < 2e-5
+
+
+def test_cartpole():
+    g = load_golden("cartpole.npz")
+    dyn = tp.CartpoleOracle()
+    nxt = dyn(T(g["ka_state"]), T(g["ka_action"]), 0.02)
+    assert rel_err(nxt.numpy(), g["ka_next"]) < TOL
+    np.testing.assert_allclose(nxt.numpy()[0], [0.5260, 1.4057, 0.1080, 0.7744],
+                               atol=5e-5)
+    H, dt = 5, float(g["dt"])
+    s0 = T(g["state0"]).requires_grad_(True)
+    a = T(g["actions"]).requires_grad_(True)
+    ref = tp.cartpole_reference(s0, H)
+    assert rel_err(ref.detach().numpy(), g["ref"]) < 1e-7
+    inter = tp.unroll(dyn, s0, a, dt)
+    loss = tp.cartpole_loss_mpc(inter, ref, a)
+    loss.backward()
+    assert rel_err(inter.detach().numpy(), g["states"]) < 1e-5
+    assert abs(loss.item() - g["loss"]) / g["loss"] < 1e-5
+    assert rel_err(a.grad.numpy(), g["gactions"]) < 1e-5
+    assert rel_err(s0.grad.numpy(), g["gstate0"]) < 1e-5
+    # step VJP
+    s = T(g["state0"]).requires_grad_(True)
+    a1 = T(g["actions"][:, 0]).requires_grad_(True)
+    nxt = dyn(s, a1, 0.02)
+    gs, ga = torch.autograd.grad(nxt, (s, a1), T(g["step_cot"]))
+    assert rel_err(nxt.detach().numpy(), g["step_next"]) < TOL
+    assert rel_err(gs.numpy(), g["step_gstate"]) < 1e-5
+    assert rel_err(ga.numpy(), g["step_gaction"]) < 1e-5
+
+
+def test_wing_linear_reference_matches_synthetic():
+    from apg_trajectory_tracking_amd import synthetic
+    d = synthetic.wing_batch(16, 20, 0.05, seed=1)
+    ref = tp.wing_linear_reference(d["state0"], d["target"], 20, 0.05)
+    assert rel_err(ref.numpy(), d["ref"].numpy()) < 1e-6
