@@ -1,0 +1,168 @@
+"""ctypes binding of libapg_hip.so (the C ABI declared in include/apg.h).
+
+There is deliberately NO fallback: if the shared library is missing or a
+tensor is not on an MI355X, the call raises.  PyTorch is used only to own
+device memory and to name the HIP stream work is enqueued on.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libapg_hip.so")
+
+LAYOUT_SOA = 0
+LAYOUT_AOS = 1
+MAX_HORIZON = 48
+ROLLOUT_BLOCK = 64
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as integers
+
+
+class ApgQuadParams(ctypes.Structure):
+    _fields_ = [
+        ("mass", ctypes.c_float),
+        ("kinv", ctypes.c_float * 3),
+        ("inertia", ctypes.c_float * 3),
+        ("gravity", ctypes.c_float * 3),
+        ("trans_drag", ctypes.c_float * 3),
+        ("rot_drag", ctypes.c_float * 3),
+    ]
+
+
+class ApgQuadLossWeights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float)
+                for n in ("pos", "vel", "av", "rates", "thrust")]
+
+
+WING_PARAM_FIELDS = (
+    "mass", "I_xx", "I_yy", "I_zz", "I_xz", "rho", "S", "c", "b", "g",
+    "CL0", "CL_alpha", "CL_q", "CL_del_e",
+    "CD0", "CD_alpha", "CD_q", "CD_del_e",
+    "CY0", "CY_beta", "CY_p", "CY_r", "CY_del_a", "CY_del_r",
+    "Cl0", "Cl_beta", "Cl_p", "Cl_r", "Cl_del_a", "Cl_del_r",
+    "Cm0", "Cm_alpha", "Cm_q", "Cm_del_e",
+    "Cn0", "Cn_beta", "Cn_p", "Cn_r", "Cn_del_a", "Cn_del_r",
+    "epsilon",
+)
+
+
+class ApgWingParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in WING_PARAM_FIELDS]
+
+
+class ApgWingLossWeights(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_float), ("action", ctypes.c_float)]
+
+
+class ApgCartpoleParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in (
+        "masscart", "masspole", "length", "max_force_mag", "friction",
+        "gravity")]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes  (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "apg_quad_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgQuadParams), _I, _I,
+                          _P, _P],
+    "apg_quad_step_bwd": [_P, _P, _F, ctypes.POINTER(ApgQuadParams), _I, _I,
+                          _P, _P, _P, _P],
+    "apg_quad_rollout_fwd_bwd": [
+        _P, _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), _I, _I, _I, _P, _P, _P, _P, _P,
+        _P],
+    "apg_quad_rollout_fwd": [_P, _P, _F, ctypes.POINTER(ApgQuadParams), _I,
+                             _I, _I, _P, _P],
+    "apg_quad_loss_fwd_bwd": [
+        _P, _P, _I, _P, ctypes.POINTER(ApgQuadLossWeights), _I, _I, _I, _P,
+        _P, _P, _P, _P],
+    "apg_quad_features_fwd": [_P, _I, _I, _P, _P],
+    "apg_quad_features_bwd": [_P, _P, _I, _I, _P, _P],
+    "apg_wing_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,
+                          _P, _P],
+    "apg_wing_step_bwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,
+                          _P, _P, _P, _P],
+    "apg_wing_rollout_fwd_bwd": [
+        _P, _P, _P, _F, ctypes.POINTER(ApgWingParams),
+        ctypes.POINTER(ApgWingLossWeights), _I, _I, _I, _P, _P, _P, _P, _P,
+        _P],
+    "apg_wing_rollout_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I,
+                             _I, _I, _P, _P],
+    "apg_cartpole_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgCartpoleParams),
+                              _I, _I, _P, _P],
+    "apg_cartpole_step_bwd": [_P, _P, _F, ctypes.POINTER(ApgCartpoleParams),
+                              _I, _I, _P, _P, _P, _P],
+    "apg_cartpole_rollout_fwd_bwd": [
+        _P, _P, _F, ctypes.POINTER(ApgCartpoleParams), _I, _I, _I, _P, _P,
+        _P, _P, _P, _P],
+    "apg_loss_partials_count": [_I],
+    "apg_version": [],
+    "apg_last_error_string": [],
+}
+_RESTYPES = {"apg_last_error_string": ctypes.c_char_p}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with "
+                "`python -m apg_trajectory_tracking_amd.build` "
+                "(there is no CPU / PyTorch fallback for the APG kernels)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a symbol is absent
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().apg_last_error_string().decode()
+        exc = ValueError if code == -1 else RuntimeError
+        raise exc(f"{what} failed ({code}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_device(*tensors):
+    """Every tensor must be a contiguous fp32 tensor on one HIP device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "apg_trajectory_tracking_amd kernels run on an MI355X only: "
+                f"got a tensor on {t.device} (no CPU fallback exists)")
+        if t.dtype != torch.float32:
+            raise TypeError(f"fp32 tensors required, got {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError("contiguous tensors required")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("all tensors must live on the same device")
+    return dev
+
+
+def loss_partials_count(B):
+    return 1 if B <= 0 else (B + ROLLOUT_BLOCK - 1) // ROLLOUT_BLOCK

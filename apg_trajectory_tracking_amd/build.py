@@ -1,0 +1,60 @@
+"""Build libapg_hip.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting .so is git-ignored but travels to the GPU box with the source tree.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libapg_hip.so")
+SOURCES = ["common.hip", "quad.hip", "wing.hip", "cartpole.hip"]
+HEADERS = [os.path.join(CSRC, "apg_device.h"),
+           os.path.join(REPO, "include", "apg.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared library; returns its path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+               "-I", os.path.join(REPO, "include"), "-I", CSRC, "-c", src,
+               "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((s, subprocess.Popen(
+            cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,689 @@
+// quad.hip - quadrotor kernels: single step (+VJP), fused horizon-unrolled
+// rollout + quad_mpc_loss + analytic adjoint, loss, policy-input features.
+//
+// Arithmetic restated from (paths relative to the reference repo):
+//   neural_control/dynamics/quad_dynamics_flightmare.py:128-216
+//   neural_control/dynamics/quad_dynamics_base.py:59-127
+//   neural_control/drone_loss.py:12-39
+//   neural_control/dataset.py:207-220
+// Closed form of one step (state = [p, att=(phi,theta,psi), v, w]):
+//   T    = 15 a0 - 7.5 + 9.81
+//   z    = third row of world_to_body(att)
+//   acc  = T z + gravity + translational_drag          (mass cancels)
+//   p'   = p + 0.5 dt^2 acc + 0.5 dt v                  (sic)
+//   v'   = v + dt acc
+//   w'   = w + dt (K (a_{1:3} - 0.5 - w) + J^-1 rotational_drag)
+//          (the w x Jw term is added and subtracted in the reference)
+//   att' = att + dt E(phi,theta) w                      (old w)
+// All of it is per-trajectory elementwise work: HBM-bound, no MFMA.
+#include "apg_device.h"
+
+namespace apg {
+namespace {
+
+struct QuadConst {  // per-launch constants, derived on the host
+  float dt, half_dt, half_dt2;
+  float g[3];    // gravity + translational drag
+  float kdt[3];  // dt * kinv
+  float wd[3];   // dt * rot_drag / inertia
+};
+
+struct Trig {
+  float sr, cr, sp, cp, sy, cy;  // roll(phi) pitch(theta) yaw(psi)
+};
+
+__device__ __forceinline__ Trig make_trig(const float att[3]) {
+  Trig t;
+  sincosf(att[0], &t.sr, &t.cr);
+  sincosf(att[1], &t.sp, &t.cp);
+  sincosf(att[2], &t.sy, &t.cy);
+  return t;
+}
+
+__device__ __forceinline__ float thrust_of(float a0) {
+  return a0 * 15.0f - 7.5f + 9.81f;  // quad_dynamics_flightmare.py:139
+}
+
+// thrust direction = third row of world_to_body (quad_dynamics_base.py:87-91)
+__device__ __forceinline__ void thrust_dir(const Trig &t, float z[3]) {
+  z[0] = t.cy * t.sp * t.cr + t.sr * t.sy;
+  z[1] = t.cr * t.sy * t.sp - t.cy * t.sr;
+  z[2] = t.cr * t.cp;
+}
+
+// s = [p(0:3), att(3:6), v(6:9), w(9:12)] updated in place.
+__device__ __forceinline__ void quad_step(float (&s)[12], const float (&a)[4],
+                                          const QuadConst &c, const Trig &t) {
+  float z[3];
+  thrust_dir(t, z);
+  const float T = thrust_of(a[0]);
+  const float w0 = s[9], w1 = s[10], w2 = s[11];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float acc = T * z[i] + c.g[i];
+    s[i] = s[i] + c.half_dt2 * acc + c.half_dt * s[6 + i];
+    s[6 + i] = s[6 + i] + c.dt * acc;
+    s[9 + i] = s[9 + i] + c.kdt[i] * ((a[1 + i] - 0.5f) - s[9 + i]) + c.wd[i];
+  }
+  // euler_rate, quad_dynamics_base.py:96-127, with the OLD angular velocity
+  s[3] += c.dt * (w0 - t.sp * w2);
+  s[4] += c.dt * (t.cr * w1 + t.cp * t.sr * w2);
+  s[5] += c.dt * (-t.sr * w1 + t.cp * t.cr * w2);
+}
+
+// Adjoint of quad_step.  lam = dL/d(next state) on entry, dL/d(state) on
+// exit; ga += dL/d(action) through the dynamics.
+__device__ __forceinline__ void quad_step_adjoint(float (&lam)[12],
+                                                  float (&ga)[4], float a0,
+                                                  const float w[3],
+                                                  const QuadConst &c,
+                                                  const Trig &t) {
+  float z[3];
+  thrust_dir(t, z);
+  const float T = thrust_of(a0);
+  float lacc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    lacc[i] = c.half_dt2 * lam[i] + c.dt * lam[6 + i];
+    lam[6 + i] += c.half_dt * lam[i];  // dL/dv
+  }
+  ga[0] += 15.0f * (lacc[0] * z[0] + lacc[1] * z[1] + lacc[2] * z[2]);
+  const float lz0 = T * lacc[0], lz1 = T * lacc[1], lz2 = T * lacc[2];
+  const float la0 = lam[3], la1 = lam[4], la2 = lam[5];
+  // dL/dw = (1 - dt K) lam_w' + dt E^T lam_att'
+  const float lw0 = lam[9], lw1 = lam[10], lw2 = lam[11];
+  ga[1] += c.kdt[0] * lw0;
+  ga[2] += c.kdt[1] * lw1;
+  ga[3] += c.kdt[2] * lw2;
+  lam[9] = lw0 - c.kdt[0] * lw0 + c.dt * la0;
+  lam[10] = lw1 - c.kdt[1] * lw1 + c.dt * (t.cr * la1 - t.sr * la2);
+  lam[11] = lw2 - c.kdt[2] * lw2 +
+            c.dt * (-t.sp * la0 + t.cp * t.sr * la1 + t.cp * t.cr * la2);
+  // dL/datt = lam_att' + dt (d(E w)/datt)^T lam_att' + (dz/datt)^T (T lacc)
+  const float dphi_e1 = -t.sr * w[1] + t.cp * t.cr * w[2];
+  const float dphi_e2 = -t.cr * w[1] - t.cp * t.sr * w[2];
+  const float dth_e0 = -t.cp * w[2];
+  const float dth_e1 = -t.sp * t.sr * w[2];
+  const float dth_e2 = -t.sp * t.cr * w[2];
+  const float dz_phi0 = -t.cy * t.sp * t.sr + t.cr * t.sy;
+  const float dz_phi1 = -t.sr * t.sy * t.sp - t.cy * t.cr;
+  const float dz_phi2 = -t.sr * t.cp;
+  const float dz_th0 = t.cy * t.cp * t.cr;
+  const float dz_th1 = t.cr * t.sy * t.cp;
+  const float dz_th2 = -t.cr * t.sp;
+  const float dz_psi0 = -t.sy * t.sp * t.cr + t.sr * t.cy;
+  const float dz_psi1 = t.cr * t.cy * t.sp + t.sy * t.sr;
+  lam[3] = la0 + c.dt * (dphi_e1 * la1 + dphi_e2 * la2) +
+           (dz_phi0 * lz0 + dz_phi1 * lz1 + dz_phi2 * lz2);
+  lam[4] = la1 + c.dt * (dth_e0 * la0 + dth_e1 * la1 + dth_e2 * la2) +
+           (dz_th0 * lz0 + dz_th1 * lz1 + dz_th2 * lz2);
+  lam[5] = la2 + (dz_psi0 * lz0 + dz_psi1 * lz1);
+}
+
+QuadConst make_const(const ApgQuadParams &p, float dt) {
+  QuadConst c;
+  c.dt = dt;
+  c.half_dt = 0.5f * dt;
+  c.half_dt2 = 0.5f * dt * dt;
+  for (int i = 0; i < 3; ++i) {
+    c.g[i] = p.gravity[i] + p.trans_drag[i];
+    c.kdt[i] = dt * p.kinv[i];
+    c.wd[i] = dt * (p.rot_drag[i] / p.inertia[i]);
+  }
+  return c;
+}
+
+// ------------------------------------------------------------ single step --
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void quad_step_fwd_kernel(
+    const float *__restrict__ state, const float *__restrict__ action,
+    QuadConst c, int B, float *__restrict__ next) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s[12], a[4];
+  load_state<LAYOUT, 12>(state, B, b, s);
+  load_state<LAYOUT, 4>(action, B, b, a);
+  Trig t = make_trig(&s[3]);
+  quad_step(s, a, c, t);
+  store_state<LAYOUT, 12>(next, B, b, s);
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void quad_step_bwd_kernel(
+    const float *__restrict__ state, const float *__restrict__ action,
+    QuadConst c, int B, const float *__restrict__ grad_next,
+    float *__restrict__ grad_state, float *__restrict__ grad_action) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s[12], a[4], lam[12];
+  load_state<LAYOUT, 12>(state, B, b, s);
+  load_state<LAYOUT, 4>(action, B, b, a);
+  load_state<LAYOUT, 12>(grad_next, B, b, lam);
+  Trig t = make_trig(&s[3]);
+  float ga[4] = {0.f, 0.f, 0.f, 0.f};
+  quad_step_adjoint(lam, ga, a[0], &s[9], c, t);
+  if (grad_state) store_state<LAYOUT, 12>(grad_state, B, b, lam);
+  if (grad_action) store_state<LAYOUT, 4>(grad_action, B, b, ga);
+}
+
+// ------------------------------------------------------------ fused rollout
+struct RolloutArgs {
+  const float *state0, *actions, *ref;
+  float *loss_partials, *grad_actions, *grad_state0, *states_out;
+  QuadConst c;
+  ApgQuadLossWeights w;
+  int B, H, ref_cols, vel_col;
+};
+
+// Compile-time horizon: the whole trajectory lives in registers.
+//   forward sweep : stashes att_k, w_k (what the adjoint of step k needs) and
+//                   the loss seeds dL/dp_{k+1}, dL/dv_{k+1}; accumulates the
+//                   loss; the action-cost gradient is written into ga[k].
+//   reverse sweep : lam <- seeds + adjoint(step k), ga[k] += dynamics part.
+// HBM traffic per trajectory: 48 + 16H + 24H read, 16H (+48) written.
+template <int LAYOUT, int HT, bool STATES_OUT>
+__global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
+    RolloutArgs A) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b < A.B;
+  const int bb = live ? b : A.B - 1;  // keep the wave convergent for the reduce
+  const QuadConst c = A.c;
+
+  float s[12];
+  float act[HT][4];
+  float rp[HT][3], rv[HT][3];
+  load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
+#pragma unroll
+  for (int k = 0; k < HT; ++k) {
+    load_seq<LAYOUT, 4>(A.actions, A.B, HT, 4, bb, k, 0, act[k]);
+    load_seq<LAYOUT, 3>(A.ref, A.B, HT, A.ref_cols, bb, k, 0, rp[k]);
+    load_seq<LAYOUT, 3>(A.ref, A.B, HT, A.ref_cols, bb, k, A.vel_col, rv[k]);
+  }
+
+  float st_att[HT][3], st_w[HT + 1][3];
+  float loss = 0.f;
+#pragma unroll
+  for (int k = 0; k < HT; ++k) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st_att[k][i] = s[3 + i], st_w[k][i] = s[9 + i];
+    Trig t = make_trig(&s[3]);
+    quad_step(s, act[k], c, t);
+    if constexpr (STATES_OUT)
+      if (live) store_seq<LAYOUT, 12>(A.states_out, A.B, HT, 12, b, k, 0, s);
+    // loss terms of step k (drone_loss.py:22-34) and their seeds
+    float lp = 0.f, lv = 0.f, lw = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float dp = s[i] - rp[k][i], dv = s[6 + i] - rv[k][i];
+      lp += dp * dp, lv += dv * dv, lw += s[9 + i] * s[9 + i];
+      rp[k][i] = 2.f * A.w.pos * dp;  // seeds overwrite the reference
+      rv[k][i] = 2.f * A.w.vel * dv;
+    }
+    const float da0 = act[k][0] - 0.5f;
+    float lr = 0.f;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      float d = act[k][i] - 0.5f;
+      lr += d * d;
+      act[k][i] = 2.f * A.w.rates * d;  // action-cost gradient
+    }
+    loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
+            A.w.thrust * da0 * da0;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) st_w[HT][i] = s[9 + i];
+
+  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+
+  float lam[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = 0.f;
+#pragma unroll
+  for (int k = HT - 1; k >= 0; --k) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      lam[i] += rp[k][i];
+      lam[6 + i] += rv[k][i];
+      lam[9 + i] += 2.f * A.w.av * st_w[k + 1][i];
+    }
+    const float a0 = act[k][0];
+    float ga[4] = {2.f * A.w.thrust * (a0 - 0.5f), act[k][1], act[k][2],
+                   act[k][3]};
+    Trig t = make_trig(st_att[k]);
+    quad_step_adjoint(lam, ga, a0, st_w[k], c, t);
+    if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, HT, 4, b, k, 0, ga);
+  }
+  if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
+}
+
+// Run-time horizon: same sweeps, the per-step stash (att, w, seeds: 12 floats)
+// is staged in LDS as [k][12][lane] (conflict-free: lane == bank).
+template <int LAYOUT, bool STATES_OUT>
+__global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_lds_kernel(
+    RolloutArgs A) {
+  extern __shared__ float stash[];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b < A.B;
+  const int bb = live ? b : A.B - 1;
+  const QuadConst c = A.c;
+  const int H = A.H;
+  auto ST = [&](int k, int i) -> float & {
+    return stash[(k * 12 + i) * APG_ROLLOUT_BLOCK + lane];
+  };
+
+  float s[12];
+  load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
+  float loss = 0.f;
+  for (int k = 0; k < H; ++k) {
+    float a[4], rp[3], rv[3];
+    load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, k, 0, a);
+    load_seq<LAYOUT, 3>(A.ref, A.B, H, A.ref_cols, bb, k, 0, rp);
+    load_seq<LAYOUT, 3>(A.ref, A.B, H, A.ref_cols, bb, k, A.vel_col, rv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ST(k, i) = s[3 + i], ST(k, 3 + i) = s[9 + i];
+    Trig t = make_trig(&s[3]);
+    quad_step(s, a, c, t);
+    if constexpr (STATES_OUT)
+      if (live) store_seq<LAYOUT, 12>(A.states_out, A.B, H, 12, b, k, 0, s);
+    float lp = 0.f, lv = 0.f, lw = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float dp = s[i] - rp[i], dv = s[6 + i] - rv[i];
+      lp += dp * dp, lv += dv * dv, lw += s[9 + i] * s[9 + i];
+      ST(k, 6 + i) = 2.f * A.w.pos * dp;
+      ST(k, 9 + i) = 2.f * A.w.vel * dv;
+    }
+    float lr = 0.f;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) lr += (a[i] - 0.5f) * (a[i] - 0.5f);
+    const float da0 = a[0] - 0.5f;
+    loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
+            A.w.thrust * da0 * da0;
+  }
+  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+
+  float lam[12], wn[3] = {s[9], s[10], s[11]};
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = 0.f;
+  for (int k = H - 1; k >= 0; --k) {
+    float a[4], att[3], w[3];
+    load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, k, 0, a);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      att[i] = ST(k, i), w[i] = ST(k, 3 + i);
+      lam[i] += ST(k, 6 + i);
+      lam[6 + i] += ST(k, 9 + i);
+      lam[9 + i] += 2.f * A.w.av * wn[i];
+    }
+    float ga[4] = {2.f * A.w.thrust * (a[0] - 0.5f),
+                   2.f * A.w.rates * (a[1] - 0.5f),
+                   2.f * A.w.rates * (a[2] - 0.5f),
+                   2.f * A.w.rates * (a[3] - 0.5f)};
+    Trig t = make_trig(att);
+    quad_step_adjoint(lam, ga, a[0], w, c, t);
+    if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, H, 4, b, k, 0, ga);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wn[i] = w[i];
+  }
+  if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void quad_rollout_fwd_kernel(
+    const float *__restrict__ state0, const float *__restrict__ actions,
+    QuadConst c, int B, int H, float *__restrict__ states_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s[12];
+  load_state<LAYOUT, 12>(state0, B, b, s);
+  for (int k = 0; k < H; ++k) {
+    float a[4];
+    load_seq<LAYOUT, 4>(actions, B, H, 4, b, k, 0, a);
+    Trig t = make_trig(&s[3]);
+    quad_step(s, a, c, t);
+    store_seq<LAYOUT, 12>(states_out, B, H, 12, b, k, 0, s);
+  }
+}
+
+// ------------------------------------------------------------- loss alone --
+template <int LAYOUT>
+__global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_loss_kernel(
+    const float *__restrict__ states, const float *__restrict__ ref,
+    int ref_cols, int vel_col, const float *__restrict__ actions,
+    ApgQuadLossWeights w, int B, int H, float *__restrict__ partials,
+    float *__restrict__ grad_states, float *__restrict__ grad_actions) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+  float loss = 0.f;
+  for (int k = 0; k < H; ++k) {
+    float s[12], a[4], rp[3], rv[3], gs[12], ga[4];
+    load_seq<LAYOUT, 12>(states, B, H, 12, bb, k, 0, s);
+    load_seq<LAYOUT, 4>(actions, B, H, 4, bb, k, 0, a);
+    load_seq<LAYOUT, 3>(ref, B, H, ref_cols, bb, k, 0, rp);
+    load_seq<LAYOUT, 3>(ref, B, H, ref_cols, bb, k, vel_col, rv);
+    float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float dp = s[i] - rp[i], dv = s[6 + i] - rv[i], d = a[1 + i] - 0.5f;
+      lp += dp * dp, lv += dv * dv, lw += s[9 + i] * s[9 + i], lr += d * d;
+      gs[i] = 2.f * w.pos * dp, gs[3 + i] = 0.f;
+      gs[6 + i] = 2.f * w.vel * dv, gs[9 + i] = 2.f * w.av * s[9 + i];
+      ga[1 + i] = 2.f * w.rates * d;
+    }
+    const float da0 = a[0] - 0.5f;
+    ga[0] = 2.f * w.thrust * da0;
+    loss += w.pos * lp + w.vel * lv + w.av * lw + w.rates * lr +
+            w.thrust * da0 * da0;
+    if (live && grad_states)
+      store_seq<LAYOUT, 12>(grad_states, B, H, 12, b, k, 0, gs);
+    if (live && grad_actions)
+      store_seq<LAYOUT, 4>(grad_actions, B, H, 4, b, k, 0, ga);
+  }
+  write_wave_partial(partials, live ? loss : 0.f);
+}
+
+// ------------------------------------------------------ policy-input features
+// features = [v_world(3), R_wb[:, :, :2] row-major (6), v_body(3), w(3)]
+struct Rot {
+  float m[3][3];
+};
+__device__ __forceinline__ Rot world_to_body(const Trig &t) {
+  Rot r;  // quad_dynamics_base.py:79-92
+  r.m[0][0] = t.cy * t.cp, r.m[0][1] = t.sy * t.cp, r.m[0][2] = -t.sp;
+  r.m[1][0] = t.cy * t.sp * t.sr - t.cr * t.sy;
+  r.m[1][1] = t.cr * t.cy + t.sr * t.sy * t.sp;
+  r.m[1][2] = t.cp * t.sr;
+  r.m[2][0] = t.cy * t.sp * t.cr + t.sr * t.sy;
+  r.m[2][1] = t.cr * t.sy * t.sp - t.cy * t.sr;
+  r.m[2][2] = t.cr * t.cp;
+  return r;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void quad_features_fwd_kernel(
+    const float *__restrict__ state, int B, float *__restrict__ feat) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s[12], f[15];
+  load_state<LAYOUT, 12>(state, B, b, s);
+  Trig t = make_trig(&s[3]);
+  Rot r = world_to_body(t);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f[i] = s[6 + i];
+    f[3 + 2 * i] = r.m[i][0], f[3 + 2 * i + 1] = r.m[i][1];
+    f[9 + i] = r.m[i][0] * s[6] + r.m[i][1] * s[7] + r.m[i][2] * s[8];
+    f[12 + i] = s[9 + i];
+  }
+  store_state<LAYOUT, 15>(feat, B, b, f);
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void quad_features_bwd_kernel(
+    const float *__restrict__ state, const float *__restrict__ gfeat, int B,
+    float *__restrict__ gstate) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s[12], gf[15], gs[12];
+  load_state<LAYOUT, 12>(state, B, b, s);
+  load_state<LAYOUT, 15>(gfeat, B, b, gf);
+  Trig t = make_trig(&s[3]);
+  Rot r = world_to_body(t);
+  // cotangent of every rotation-matrix entry
+  float gm[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    gm[i][0] = gf[3 + 2 * i] + gf[9 + i] * s[6];
+    gm[i][1] = gf[3 + 2 * i + 1] + gf[9 + i] * s[7];
+    gm[i][2] = gf[9 + i] * s[8];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    gs[j] = 0.f;
+    gs[6 + j] = gf[j] + r.m[0][j] * gf[9] + r.m[1][j] * gf[10] +
+                r.m[2][j] * gf[11];
+    gs[9 + j] = gf[12 + j];
+  }
+  // dR/droll, dR/dpitch, dR/dyaw contracted with gm
+  // roll (phi): rows 1,2 only
+  gs[3] = gm[1][0] * (t.cy * t.sp * t.cr + t.sr * t.sy) +
+          gm[1][1] * (-t.sr * t.cy + t.cr * t.sy * t.sp) +
+          gm[1][2] * (t.cp * t.cr) +
+          gm[2][0] * (-t.cy * t.sp * t.sr + t.cr * t.sy) +
+          gm[2][1] * (-t.sr * t.sy * t.sp - t.cy * t.cr) +
+          gm[2][2] * (-t.sr * t.cp);
+  // pitch (theta)
+  gs[4] = gm[0][0] * (-t.cy * t.sp) + gm[0][1] * (-t.sy * t.sp) +
+          gm[0][2] * (-t.cp) + gm[1][0] * (t.cy * t.cp * t.sr) +
+          gm[1][1] * (t.sr * t.sy * t.cp) + gm[1][2] * (-t.sp * t.sr) +
+          gm[2][0] * (t.cy * t.cp * t.cr) + gm[2][1] * (t.cr * t.sy * t.cp) +
+          gm[2][2] * (-t.cr * t.sp);
+  // yaw (psi)
+  gs[5] = gm[0][0] * (-t.sy * t.cp) + gm[0][1] * (t.cy * t.cp) +
+          gm[1][0] * (-t.sy * t.sp * t.sr - t.cr * t.cy) +
+          gm[1][1] * (-t.cr * t.sy + t.sr * t.cy * t.sp) +
+          gm[2][0] * (-t.sy * t.sp * t.cr + t.sr * t.cy) +
+          gm[2][1] * (t.cr * t.cy * t.sp + t.sy * t.sr);
+  store_state<LAYOUT, 12>(gstate, B, b, gs);
+}
+
+// ----------------------------------------------------------------- host ----
+inline int grid_for(int B, int block) { return (B + block - 1) / block; }
+
+int check_common(const void *p0, const void *p1, const void *params, int B,
+                 int layout) {
+  if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
+  if (layout != APG_LAYOUT_SOA && layout != APG_LAYOUT_AOS) {
+    set_error("unknown layout %d", layout);
+    return APG_ERR_ARG;
+  }
+  if (!params) { set_error("params is NULL"); return APG_ERR_ARG; }
+  if (B > 0 && (!p0 || !p1)) { set_error("NULL input pointer"); return APG_ERR_ARG; }
+  return APG_OK;
+}
+
+template <int LAYOUT, bool SO>
+int launch_rollout(const RolloutArgs &A, hipStream_t st) {
+  const dim3 grid(grid_for(A.B, APG_ROLLOUT_BLOCK)), block(APG_ROLLOUT_BLOCK);
+  switch (A.H) {
+#define APG_CASE(HT)                                                         \
+  case HT:                                                                   \
+    hipLaunchKernelGGL((quad_rollout_reg_kernel<LAYOUT, HT, SO>), grid, block, \
+                       0, st, A);                                            \
+    break;
+    APG_CASE(5) APG_CASE(10)  // register-resident horizons (reference configs)
+#undef APG_CASE
+    default: {
+      const size_t lds = (size_t)A.H * 12 * APG_ROLLOUT_BLOCK * sizeof(float);
+      if (lds > 64 * 1024 &&
+          hipFuncSetAttribute((const void *)quad_rollout_lds_kernel<LAYOUT, SO>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(quad_rollout_lds)");
+      hipLaunchKernelGGL((quad_rollout_lds_kernel<LAYOUT, SO>), grid, block, lds,
+                         st, A);
+    }
+  }
+  return check_launch("quad_rollout_fwd_bwd");
+}
+
+}  // namespace
+}  // namespace apg
+
+using namespace apg;
+
+extern "C" {
+
+int apg_quad_step_fwd(const float *state, const float *action, float dt,
+                      const ApgQuadParams *params, int B, int layout,
+                      float *next_state, apg_stream_t stream) {
+  if (int e = check_common(state, action, params, B, layout)) return e;
+  if (B == 0) return APG_OK;
+  if (!next_state) { set_error("next_state is NULL"); return APG_ERR_ARG; }
+  QuadConst c = make_const(*params, dt);
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == APG_LAYOUT_SOA)
+    hipLaunchKernelGGL(quad_step_fwd_kernel<APG_LAYOUT_SOA>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state, action, c, B, next_state);
+  else
+    hipLaunchKernelGGL(quad_step_fwd_kernel<APG_LAYOUT_AOS>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state, action, c, B, next_state);
+  return check_launch("quad_step_fwd");
+}
+
+int apg_quad_step_bwd(const float *state, const float *action, float dt,
+                      const ApgQuadParams *params, int B, int layout,
+                      const float *grad_next, float *grad_state,
+                      float *grad_action, apg_stream_t stream) {
+  if (int e = check_common(state, action, params, B, layout)) return e;
+  if (B == 0) return APG_OK;
+  if (!grad_next) { set_error("grad_next is NULL"); return APG_ERR_ARG; }
+  QuadConst c = make_const(*params, dt);
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == APG_LAYOUT_SOA)
+    hipLaunchKernelGGL(quad_step_bwd_kernel<APG_LAYOUT_SOA>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state, action, c, B, grad_next,
+                       grad_state, grad_action);
+  else
+    hipLaunchKernelGGL(quad_step_bwd_kernel<APG_LAYOUT_AOS>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state, action, c, B, grad_next,
+                       grad_state, grad_action);
+  return check_launch("quad_step_bwd");
+}
+
+int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
+                             const float *ref, int ref_cols, float dt,
+                             const ApgQuadParams *params,
+                             const ApgQuadLossWeights *weights, int B, int H,
+                             int layout, float *loss_partials, float *loss,
+                             float *grad_actions, float *grad_state0,
+                             float *states_out, apg_stream_t stream) {
+  if (int e = check_common(state0, actions, params, B, layout)) return e;
+  if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
+  if (H < 1 || H > APG_MAX_HORIZON) {
+    set_error("H must be in [1, %d] (got %d)", APG_MAX_HORIZON, H);
+    return APG_ERR_ARG;
+  }
+  if (ref_cols != 9 && ref_cols != 6) {
+    set_error("ref_cols must be 9 ([pos, euler, vel]) or 6 ([pos, vel])");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {  // empty batch: loss = 0, nothing else to write
+    if (loss) {
+      if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
+        return check_launch("memset(loss)");
+    }
+    return APG_OK;
+  }
+  if (!ref || !loss_partials || !grad_actions) {
+    set_error("ref / loss_partials / grad_actions must not be NULL");
+    return APG_ERR_ARG;
+  }
+  RolloutArgs A;
+  A.state0 = state0, A.actions = actions, A.ref = ref;
+  A.loss_partials = loss_partials, A.grad_actions = grad_actions;
+  A.grad_state0 = grad_state0, A.states_out = states_out;
+  A.c = make_const(*params, dt);
+  A.w = *weights;
+  A.B = B, A.H = H, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
+  int e;
+  if (layout == APG_LAYOUT_SOA)
+    e = states_out ? launch_rollout<APG_LAYOUT_SOA, true>(A, st)
+                   : launch_rollout<APG_LAYOUT_SOA, false>(A, st);
+  else
+    e = states_out ? launch_rollout<APG_LAYOUT_AOS, true>(A, st)
+                   : launch_rollout<APG_LAYOUT_AOS, false>(A, st);
+  if (e) return e;
+  if (loss) return launch_reduce_partials(loss_partials, apg_loss_partials_count(B), loss, st);
+  return APG_OK;
+}
+
+int apg_quad_rollout_fwd(const float *state0, const float *actions, float dt,
+                         const ApgQuadParams *params, int B, int H, int layout,
+                         float *states_out, apg_stream_t stream) {
+  if (int e = check_common(state0, actions, params, B, layout)) return e;
+  if (H < 1) { set_error("H must be >= 1 (got %d)", H); return APG_ERR_ARG; }
+  if (B == 0) return APG_OK;
+  if (!states_out) { set_error("states_out is NULL"); return APG_ERR_ARG; }
+  QuadConst c = make_const(*params, dt);
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == APG_LAYOUT_SOA)
+    hipLaunchKernelGGL(quad_rollout_fwd_kernel<APG_LAYOUT_SOA>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state0, actions, c, B, H, states_out);
+  else
+    hipLaunchKernelGGL(quad_rollout_fwd_kernel<APG_LAYOUT_AOS>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state0, actions, c, B, H, states_out);
+  return check_launch("quad_rollout_fwd");
+}
+
+int apg_quad_loss_fwd_bwd(const float *states, const float *ref, int ref_cols,
+                          const float *actions,
+                          const ApgQuadLossWeights *weights, int B, int H,
+                          int layout, float *loss_partials, float *loss,
+                          float *grad_states, float *grad_actions,
+                          apg_stream_t stream) {
+  if (int e = check_common(states, actions, weights, B, layout)) return e;
+  if (H < 1) { set_error("H must be >= 1 (got %d)", H); return APG_ERR_ARG; }
+  if (ref_cols != 9 && ref_cols != 6) {
+    set_error("ref_cols must be 9 or 6");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
+      return check_launch("memset(loss)");
+    return APG_OK;
+  }
+  if (!ref || !loss_partials) {
+    set_error("ref / loss_partials must not be NULL");
+    return APG_ERR_ARG;
+  }
+  const int vel_col = ref_cols == 9 ? 6 : 3;
+  const dim3 grid(grid_for(B, APG_ROLLOUT_BLOCK)), block(APG_ROLLOUT_BLOCK);
+  if (layout == APG_LAYOUT_SOA)
+    hipLaunchKernelGGL(quad_loss_kernel<APG_LAYOUT_SOA>, grid, block, 0, st, states,
+                       ref, ref_cols, vel_col, actions, *weights, B, H,
+                       loss_partials, grad_states, grad_actions);
+  else
+    hipLaunchKernelGGL(quad_loss_kernel<APG_LAYOUT_AOS>, grid, block, 0, st, states,
+                       ref, ref_cols, vel_col, actions, *weights, B, H,
+                       loss_partials, grad_states, grad_actions);
+  if (int e = check_launch("quad_loss_fwd_bwd")) return e;
+  if (loss) return launch_reduce_partials(loss_partials, apg_loss_partials_count(B), loss, st);
+  return APG_OK;
+}
+
+int apg_quad_features_fwd(const float *state, int B, int layout,
+                          float *features, apg_stream_t stream) {
+  if (int e = check_common(state, features, "", B, layout)) return e;
+  if (B == 0) return APG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == APG_LAYOUT_SOA)
+    hipLaunchKernelGGL(quad_features_fwd_kernel<APG_LAYOUT_SOA>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state, B, features);
+  else
+    hipLaunchKernelGGL(quad_features_fwd_kernel<APG_LAYOUT_AOS>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state, B, features);
+  return check_launch("quad_features_fwd");
+}
+
+int apg_quad_features_bwd(const float *state, const float *grad_features,
+                          int B, int layout, float *grad_state,
+                          apg_stream_t stream) {
+  if (int e = check_common(state, grad_features, "", B, layout)) return e;
+  if (B == 0) return APG_OK;
+  if (!grad_state) { set_error("grad_state is NULL"); return APG_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == APG_LAYOUT_SOA)
+    hipLaunchKernelGGL(quad_features_bwd_kernel<APG_LAYOUT_SOA>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state, grad_features, B, grad_state);
+  else
+    hipLaunchKernelGGL(quad_features_bwd_kernel<APG_LAYOUT_AOS>, dim3(grid_for(B, 256)),
+                       dim3(256), 0, st, state, grad_features, B, grad_state);
+  return check_launch("quad_features_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,407 @@
+"""Differentiable torch-facing wrappers over the C ABI (include/apg.h).
+
+Each `torch.autograd.Function` here stands where the reference relies on
+torch.autograd over ~60 eager ops per step: forward enqueues one HIP kernel,
+backward enqueues its hand-derived adjoint kernel.  Tensors are the
+reference's row-major ones (`layout="aos"`) unless stated; the fused rollouts
+also accept the device-native SoA layout (`layout="soa"`, batch fastest).
+"""
+import ctypes
+
+import torch
+
+from . import _capi
+from ._capi import LAYOUT_AOS, LAYOUT_SOA, check, lib, ptr, require_device, stream_of
+
+_LAYOUTS = {"aos": LAYOUT_AOS, "soa": LAYOUT_SOA}
+
+
+def _layout(layout):
+    try:
+        return _LAYOUTS[layout]
+    except KeyError:
+        raise ValueError(f"layout must be 'aos' or 'soa', got {layout!r}")
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------- parameters
+QUAD_LOSS_WEIGHTS = dict(pos=10.0, vel=1.0, av=0.1, rates=0.1, thrust=5.0)
+WING_LOSS_WEIGHTS = dict(pos=10.0, action=0.1)
+
+
+def quad_params(cfg):
+    """cfg: the dict of neural_control/dynamics/config_quad.json after
+    `update(modified_params)` -> ApgQuadParams (inertia as in
+    quad_dynamics_base.py:33-36)."""
+    p = _capi.ApgQuadParams()
+    p.mass = float(cfg["mass"])
+    scale = float(cfg["mass"]) / 12.0 * float(cfg["arm_length"])**2
+    for i in range(3):
+        p.kinv[i] = float(cfg["kinv_ang_vel_tau"][i])
+        p.inertia[i] = scale * float(cfg["frame_inertia"][i])
+        p.gravity[i] = float(cfg["gravity"][i])
+        p.trans_drag[i] = float(cfg["translational_drag"][i])
+        p.rot_drag[i] = float(cfg["rotational_drag"][i])
+    return p
+
+
+def quad_loss_weights(**kw):
+    w = dict(QUAD_LOSS_WEIGHTS)
+    w.update(kw)
+    return _capi.ApgQuadLossWeights(**{k: float(v) for k, v in w.items()})
+
+
+def wing_params(cfg):
+    p = _capi.ApgWingParams()
+    for n in _capi.WING_PARAM_FIELDS:
+        setattr(p, n, float(cfg[n]))
+    return p
+
+
+def wing_loss_weights(**kw):
+    w = dict(WING_LOSS_WEIGHTS)
+    w.update(kw)
+    return _capi.ApgWingLossWeights(**{k: float(v) for k, v in w.items()})
+
+
+def cartpole_params(cfg):
+    p = _capi.ApgCartpoleParams()
+    p.masscart = float(cfg["masscart"])
+    p.masspole = float(cfg["masspole"])
+    p.length = float(cfg["length"])
+    p.max_force_mag = float(cfg["max_force_mag"])
+    p.friction = float(cfg["friction"])
+    p.gravity = float(cfg.get("gravity", 9.81))
+    return p
+
+
+# ------------------------------------------------------- generic step op
+class _StepFn(torch.autograd.Function):
+    """next_state = dyn(state, action, dt) with an analytic VJP."""
+
+    @staticmethod
+    def forward(ctx, state, action, dt, params, fwd_name, bwd_name):
+        s, a = _f32c(state), _f32c(action)
+        require_device(s, a)
+        if s.dim() != 2 or a.dim() != 2 or s.shape[0] != a.shape[0]:
+            raise ValueError(
+                f"state [B,S] / action [B,A] expected, got {tuple(s.shape)} "
+                f"and {tuple(a.shape)}")
+        out = torch.empty_like(s)
+        check(getattr(lib(), fwd_name)(
+            ptr(s), ptr(a), float(dt), ctypes.byref(params), s.shape[0],
+            LAYOUT_AOS, ptr(out), stream_of(s)), fwd_name)
+        ctx.save_for_backward(s, a)
+        ctx.meta = (float(dt), params, bwd_name)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_next):
+        s, a = ctx.saved_tensors
+        dt, params, bwd_name = ctx.meta
+        g = _f32c(grad_next)
+        need_s, need_a = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gs = torch.empty_like(s) if need_s else None
+        ga = torch.empty_like(a) if need_a else None
+        check(getattr(lib(), bwd_name)(
+            ptr(s), ptr(a), dt, ctypes.byref(params), s.shape[0], LAYOUT_AOS,
+            ptr(g), ptr(gs), ptr(ga), stream_of(s)), bwd_name)
+        return gs, ga, None, None, None, None
+
+
+def quad_step(state, action, dt, params):
+    return _StepFn.apply(state, action, dt, params, "apg_quad_step_fwd",
+                         "apg_quad_step_bwd")
+
+
+def wing_step(state, action, dt, params):
+    return _StepFn.apply(state, action, dt, params, "apg_wing_step_fwd",
+                         "apg_wing_step_bwd")
+
+
+def cartpole_step(state, action, dt, params):
+    return _StepFn.apply(state, action, dt, params, "apg_cartpole_step_fwd",
+                         "apg_cartpole_step_bwd")
+
+
+# --------------------------------------------------- raw fused rollouts
+def _seq_shape(t, layout):
+    """-> (B, H, C) of a sequence tensor in the given layout."""
+    if t.dim() != 3:
+        raise ValueError(f"3-d sequence tensor expected, got {tuple(t.shape)}")
+    if layout == LAYOUT_AOS:
+        return t.shape[0], t.shape[1], t.shape[2]
+    return t.shape[2], t.shape[0], t.shape[1]
+
+
+def _state_batch(t, layout):
+    if t.dim() != 2:
+        raise ValueError(f"2-d state tensor expected, got {tuple(t.shape)}")
+    return t.shape[0] if layout == LAYOUT_AOS else t.shape[1]
+
+
+def quad_rollout_fwd_bwd(state0, actions, ref, dt, params, weights=None,
+                         layout="aos", want_grad_state0=True,
+                         want_states=False, want_loss=True, out=None):
+    """Fused H-step unroll + quad_mpc_loss + adjoint (apg_quad_rollout_fwd_bwd).
+
+    Returns dict(loss [1] or None, loss_partials, grad_actions, grad_state0,
+    states).  `out` may carry pre-allocated output tensors under the same
+    keys (used by bench.py to keep allocation out of the timed region).
+    """
+    lay = _layout(layout)
+    weights = weights or quad_loss_weights()
+    require_device(state0, actions, ref)
+    B, H, A = _seq_shape(actions, lay)
+    Br, Hr, ref_cols = _seq_shape(ref, lay)
+    if A != 4 or _state_batch(state0, lay) != B or Br != B or Hr != H:
+        raise ValueError("inconsistent rollout shapes")
+    out = dict(out or {})
+    dev = state0.device
+
+    def get(key, shape, wanted=True):
+        if not wanted:
+            return None
+        t = out.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=torch.float32, device=dev)
+        return t
+    partials = get("loss_partials", (_capi.loss_partials_count(B),))
+    loss = get("loss", (1,), want_loss)
+    ga = get("grad_actions", actions.shape)
+    gs = get("grad_state0", state0.shape, want_grad_state0)
+    states = get(
+        "states", (B, H, 12) if lay == LAYOUT_AOS else (H, 12, B), want_states)
+    check(lib().apg_quad_rollout_fwd_bwd(
+        ptr(state0), ptr(actions), ptr(ref), ref_cols, float(dt),
+        ctypes.byref(params), ctypes.byref(weights), B, H, lay, ptr(partials),
+        ptr(loss), ptr(ga), ptr(gs), ptr(states), stream_of(state0)),
+        "apg_quad_rollout_fwd_bwd")
+    return dict(loss=loss, loss_partials=partials, grad_actions=ga,
+                grad_state0=gs, states=states)
+
+
+def quad_rollout_fwd(state0, actions, dt, params, layout="aos"):
+    lay = _layout(layout)
+    require_device(state0, actions)
+    B, H, _ = _seq_shape(actions, lay)
+    states = torch.empty((B, H, 12) if lay == LAYOUT_AOS else (H, 12, B),
+                         dtype=torch.float32, device=state0.device)
+    check(lib().apg_quad_rollout_fwd(
+        ptr(state0), ptr(actions), float(dt), ctypes.byref(params), B, H, lay,
+        ptr(states), stream_of(state0)), "apg_quad_rollout_fwd")
+    return states
+
+
+class _QuadRolloutLoss(torch.autograd.Function):
+    """loss = quad_mpc_loss(unroll(dyn, state0, action_seq), ref, action_seq)
+    as ONE kernel; the gradients w.r.t. action_seq / state0 are produced by
+    the same launch and handed to autograd in backward()."""
+
+    @staticmethod
+    def forward(ctx, state0, action_seq, ref, dt, params, weights, layout):
+        s, a, r = _f32c(state0), _f32c(action_seq), _f32c(ref)
+        res = quad_rollout_fwd_bwd(
+            s, a, r, dt, params, weights, layout=layout,
+            want_grad_state0=ctx.needs_input_grad[0])
+        ctx.save_for_backward(res["grad_actions"], res["grad_state0"])
+        return res["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ga, gs = ctx.saved_tensors
+        ga = ga * g if ctx.needs_input_grad[1] else None
+        gs = gs * g if (gs is not None and ctx.needs_input_grad[0]) else None
+        return gs, ga, None, None, None, None, None
+
+
+def quad_rollout_loss(state0, action_seq, ref, dt, params, weights=None,
+                      layout="aos"):
+    return _QuadRolloutLoss.apply(state0, action_seq, ref, dt, params,
+                                  weights or quad_loss_weights(), layout)
+
+
+# ------------------------------------------------------------ quad loss
+class _QuadLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, states, ref, actions, weights):
+        s, r, a = _f32c(states), _f32c(ref), _f32c(actions)
+        require_device(s, r, a)
+        B, H, C = s.shape
+        if C != 12 or a.shape != (B, H, 4) or r.shape[:2] != (B, H):
+            raise ValueError("states [B,H,12], ref [B,H,9|6], actions [B,H,4]")
+        partials = torch.empty(_capi.loss_partials_count(B), device=s.device)
+        loss = torch.empty(1, device=s.device)
+        gs = torch.empty_like(s) if ctx.needs_input_grad[0] else None
+        ga = torch.empty_like(a) if ctx.needs_input_grad[2] else None
+        check(lib().apg_quad_loss_fwd_bwd(
+            ptr(s), ptr(r), r.shape[2], ptr(a), ctypes.byref(weights), B, H,
+            LAYOUT_AOS, ptr(partials), ptr(loss), ptr(gs), ptr(ga),
+            stream_of(s)), "apg_quad_loss_fwd_bwd")
+        ctx.save_for_backward(gs, ga)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gs, ga = ctx.saved_tensors
+        return (None if gs is None else gs * g, None,
+                None if ga is None else ga * g, None)
+
+
+def quad_loss(states, ref, actions, weights=None):
+    return _QuadLoss.apply(states, ref, actions, weights or quad_loss_weights())
+
+
+# -------------------------------------------------------- quad features
+class _QuadFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state):
+        s = _f32c(state)
+        require_device(s)
+        if s.dim() != 2 or s.shape[1] != 12:
+            raise ValueError(f"state [B,12] expected, got {tuple(s.shape)}")
+        f = torch.empty(s.shape[0], 15, device=s.device)
+        check(lib().apg_quad_features_fwd(
+            ptr(s), s.shape[0], LAYOUT_AOS, ptr(f), stream_of(s)),
+            "apg_quad_features_fwd")
+        ctx.save_for_backward(s)
+        return f
+
+    @staticmethod
+    def backward(ctx, gf):
+        (s,) = ctx.saved_tensors
+        g = _f32c(gf)
+        gs = torch.empty_like(s)
+        check(lib().apg_quad_features_bwd(
+            ptr(s), ptr(g), s.shape[0], LAYOUT_AOS, ptr(gs), stream_of(s)),
+            "apg_quad_features_bwd")
+        return gs
+
+
+def quad_features(state):
+    return _QuadFeatures.apply(state)
+
+
+# ------------------------------------------------------------ fixed wing
+def _alloc_outs(out, dev, B, H, S, A, lay, state0, actions, want_grad_state0,
+                want_states, want_loss):
+    out = dict(out or {})
+
+    def get(key, shape, wanted=True):
+        if not wanted:
+            return None
+        t = out.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=torch.float32, device=dev)
+        return t
+    return dict(
+        loss_partials=get("loss_partials", (_capi.loss_partials_count(B),)),
+        loss=get("loss", (1,), want_loss),
+        grad_actions=get("grad_actions", actions.shape),
+        grad_state0=get("grad_state0", state0.shape, want_grad_state0),
+        states=get("states", (B, H, S) if lay == LAYOUT_AOS else (H, S, B),
+                   want_states),
+    )
+
+
+def wing_rollout_fwd_bwd(state0, actions, ref, dt, params, weights=None,
+                         layout="aos", want_grad_state0=True,
+                         want_states=False, want_loss=True, out=None):
+    """Fused H-step unroll + fixed_wing_mpc_loss + adjoint
+    (apg_wing_rollout_fwd_bwd); ref is the [B,H,3] linear reference."""
+    lay = _layout(layout)
+    weights = weights or wing_loss_weights()
+    require_device(state0, actions, ref)
+    B, H, A = _seq_shape(actions, lay)
+    Br, Hr, C = _seq_shape(ref, lay)
+    if A != 4 or C != 3 or _state_batch(state0, lay) != B or (Br, Hr) != (B, H):
+        raise ValueError("inconsistent rollout shapes")
+    o = _alloc_outs(out, state0.device, B, H, 12, 4, lay, state0, actions,
+                    want_grad_state0, want_states, want_loss)
+    check(lib().apg_wing_rollout_fwd_bwd(
+        ptr(state0), ptr(actions), ptr(ref), float(dt), ctypes.byref(params),
+        ctypes.byref(weights), B, H, lay, ptr(o["loss_partials"]),
+        ptr(o["loss"]), ptr(o["grad_actions"]), ptr(o["grad_state0"]),
+        ptr(o["states"]), stream_of(state0)), "apg_wing_rollout_fwd_bwd")
+    return o
+
+
+def wing_rollout_fwd(state0, actions, dt, params, layout="aos"):
+    lay = _layout(layout)
+    require_device(state0, actions)
+    B, H, _ = _seq_shape(actions, lay)
+    states = torch.empty((B, H, 12) if lay == LAYOUT_AOS else (H, 12, B),
+                         dtype=torch.float32, device=state0.device)
+    check(lib().apg_wing_rollout_fwd(
+        ptr(state0), ptr(actions), float(dt), ctypes.byref(params), B, H, lay,
+        ptr(states), stream_of(state0)), "apg_wing_rollout_fwd")
+    return states
+
+
+class _WingRolloutLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state0, action_seq, ref, dt, params, weights, layout):
+        s, a, r = _f32c(state0), _f32c(action_seq), _f32c(ref)
+        res = wing_rollout_fwd_bwd(
+            s, a, r, dt, params, weights, layout=layout,
+            want_grad_state0=ctx.needs_input_grad[0])
+        ctx.save_for_backward(res["grad_actions"], res["grad_state0"])
+        return res["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ga, gs = ctx.saved_tensors
+        ga = ga * g if ctx.needs_input_grad[1] else None
+        gs = gs * g if (gs is not None and ctx.needs_input_grad[0]) else None
+        return gs, ga, None, None, None, None, None
+
+
+def wing_rollout_loss(state0, action_seq, ref, dt, params, weights=None,
+                      layout="aos"):
+    return _WingRolloutLoss.apply(state0, action_seq, ref, dt, params,
+                                  weights or wing_loss_weights(), layout)
+
+
+# -------------------------------------------------------------- cartpole
+def cartpole_rollout_fwd_bwd(state0, actions, dt, params, layout="aos",
+                             want_grad_state0=True, want_states=False,
+                             want_loss=True, out=None):
+    """Fused make_reference + H-step unroll + cartpole_loss_mpc + adjoint
+    (apg_cartpole_rollout_fwd_bwd)."""
+    lay = _layout(layout)
+    require_device(state0, actions)
+    B, H, A = _seq_shape(actions, lay)
+    if A != 1 or _state_batch(state0, lay) != B:
+        raise ValueError("inconsistent rollout shapes")
+    o = _alloc_outs(out, state0.device, B, H, 4, 1, lay, state0, actions,
+                    want_grad_state0, want_states, want_loss)
+    check(lib().apg_cartpole_rollout_fwd_bwd(
+        ptr(state0), ptr(actions), float(dt), ctypes.byref(params), B, H, lay,
+        ptr(o["loss_partials"]), ptr(o["loss"]), ptr(o["grad_actions"]),
+        ptr(o["grad_state0"]), ptr(o["states"]), stream_of(state0)),
+        "apg_cartpole_rollout_fwd_bwd")
+    return o
+
+
+class _CartpoleRolloutLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state0, action_seq, dt, params):
+        s, a = _f32c(state0), _f32c(action_seq)
+        res = cartpole_rollout_fwd_bwd(
+            s, a, dt, params, want_grad_state0=ctx.needs_input_grad[0])
+        ctx.save_for_backward(res["grad_actions"], res["grad_state0"])
+        return res["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ga, gs = ctx.saved_tensors
+        ga = ga * g if ctx.needs_input_grad[1] else None
+        gs = gs * g if (gs is not None and ctx.needs_input_grad[0]) else None
+        return gs, ga, None, None
+
+
+def cartpole_rollout_loss(state0, action_seq, dt, params):
+    return _CartpoleRolloutLoss.apply(state0, action_seq, dt, params)

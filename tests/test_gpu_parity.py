@@ -1,0 +1,382 @@
+"""Parity of the HIP kernels (through the C ABI) against the golden vectors
+generated from the reference and against the PyTorch-eager oracle.
+
+Bar (BASELINE.json north_star): states and gradients within 1e-4 relative,
+fp32.  `rel_err` = max|a-b| / max|b| over a tensor."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+MOD = {"translational_drag": [.1, .2, .3], "rotational_drag": [.01, .02, .03],
+       "mass": 1.0}
+WMOD = {"mass": 1.4, "I_xz": -0.01, "CL0": 0.3, "rho": 1.0}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda:0")
+
+
+def D(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def soa_state(x):
+    return x.t().contiguous()
+
+
+def soa_seq(x):
+    return x.permute(1, 2, 0).contiguous()
+
+
+def aos_seq(x):
+    return x.permute(2, 0, 1).contiguous()
+
+
+# ------------------------------------------------------------------ quad
+def test_quad_known_answer(dev):
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    g = load_golden("quad_step.npz")
+    dyn = FlightmareDynamics()
+    nxt = dyn.simulate_quadrotor(D(g["ka_action"], dev), D(g["ka_state"], dev),
+                                 0.05)
+    assert rel_err(N(nxt), g["ka_next"]) < 1e-6
+    # B = 1 eval-time call (neural_control/environments/drone_env.py:99)
+    nxt = dyn(D(g["state"][:1], dev), D(g["action"][:1], dev), 0.1)
+    assert rel_err(N(nxt), g["b1_next"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag,mp", [("def", {}), ("mod", MOD)])
+@pytest.mark.parametrize("dt", [0.05, 0.1])
+def test_quad_step_and_vjp(dev, tag, mp, dt):
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    g = load_golden("quad_step.npz")
+    dyn = FlightmareDynamics(modified_params=dict(mp))
+    s = D(g["state"], dev).requires_grad_(True)
+    a = D(g["action"], dev).requires_grad_(True)
+    nxt = dyn(s, a, dt)
+    key = f"{tag}_dt{int(round(dt*100)):03d}"
+    assert rel_err(N(nxt), g[key + "_next"]) < 1e-6
+    for i, c in enumerate(g["cot"]):
+        gs, ga = torch.autograd.grad(nxt, (s, a), D(c, dev), retain_graph=True)
+        assert rel_err(N(gs), g[key + "_gstate"][i]) < 1e-5
+        assert rel_err(N(ga), g[key + "_gaction"][i]) < 1e-5
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("tag,mp", [("def", {}), ("mod", MOD)])
+def test_quad_rollout_golden(dev, layout, tag, mp):
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    g = load_golden("quad_rollout.npz")
+    dyn = FlightmareDynamics(modified_params=dict(mp))
+    s0, a, r = D(g["state0"], dev), D(g["actions"], dev), D(g["ref"], dev)
+    if layout == "soa":
+        s0, a, r = soa_state(s0), soa_seq(a), soa_seq(r)
+    res = F.quad_rollout_fwd_bwd(s0, a, r, float(g["dt"]), dyn.params,
+                                 layout=layout, want_states=True)
+    st, ga, gs = res["states"], res["grad_actions"], res["grad_state0"]
+    if layout == "soa":
+        st, ga, gs = aos_seq(st), aos_seq(ga), gs.t()
+    assert rel_err(N(st), g[tag + "_states"]) < 1e-5
+    assert abs(res["loss"].item() - g[tag + "_loss"]) / g[tag + "_loss"] < 1e-5
+    assert rel_err(N(ga), g[tag + "_gactions"]) < TOL
+    assert rel_err(N(gs), g[tag + "_gstate0"]) < TOL
+    # the no-grad unroll gives the same states
+    st2 = F.quad_rollout_fwd(s0, a, float(g["dt"]), dyn.params, layout=layout)
+    if layout == "soa":
+        st2 = aos_seq(st2)
+    assert rel_err(N(st2), g[tag + "_states"]) < 1e-5
+
+
+def test_quad_rollout_h5_ragged_and_packed_ref(dev):
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    g = load_golden("quad_rollout.npz")
+    dyn = FlightmareDynamics()
+    s0, a, r = D(g["h5_state0"], dev), D(g["h5_actions"], dev), D(g["h5_ref"], dev)
+    for layout in ("aos", "soa"):
+        for packed in (False, True):
+            rr = torch.cat((r[:, :, 0:3], r[:, :, 6:9]), 2).contiguous() \
+                if packed else r
+            args = (s0, a, rr)
+            if layout == "soa":
+                args = (soa_state(s0), soa_seq(a), soa_seq(rr))
+            res = F.quad_rollout_fwd_bwd(*args, float(g["h5_dt"]), dyn.params,
+                                         layout=layout, want_states=True)
+            st, ga, gs = res["states"], res["grad_actions"], res["grad_state0"]
+            if layout == "soa":
+                st, ga, gs = aos_seq(st), aos_seq(ga), gs.t()
+            assert rel_err(N(st), g["h5_states"]) < 1e-5
+            assert abs(res["loss"].item() - g["h5_loss"]) / g["h5_loss"] < 1e-5
+            assert rel_err(N(ga), g["h5_gactions"]) < TOL
+            assert rel_err(N(gs), g["h5_gstate0"]) < TOL
+
+
+@pytest.mark.parametrize("H", [1, 7, 10, 23, 48])
+def test_quad_rollout_vs_oracle_any_horizon(dev, H):
+    """H = 10 / 5 run the register-resident kernel, the others the LDS one."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from oracle import torch_port as tp
+    B, dt = 200, 0.05
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=100 + H)
+    st, loss, ga, gs = tp.rollout_fwd_bwd(
+        tp.QuadOracle(MOD), tp.quad_mpc_loss, d["state0"], d["actions"],
+        d["ref"], dt)
+    dyn = FlightmareDynamics(modified_params=dict(MOD))
+    for layout in ("aos", "soa"):
+        s0, a, r = (d["state0"].to(dev), d["actions"].to(dev), d["ref"].to(dev))
+        if layout == "soa":
+            s0, a, r = soa_state(s0), soa_seq(a), soa_seq(r)
+        res = F.quad_rollout_fwd_bwd(s0, a, r, dt, dyn.params, layout=layout,
+                                     want_states=True)
+        rs, rga, rgs = res["states"], res["grad_actions"], res["grad_state0"]
+        if layout == "soa":
+            rs, rga, rgs = aos_seq(rs), aos_seq(rga), rgs.t()
+        assert rel_err(N(rs), st.numpy()) < TOL
+        assert abs(res["loss"].item() - loss.item()) / loss.item() < TOL
+        assert rel_err(N(rga), ga.numpy()) < TOL
+        assert rel_err(N(rgs), gs.numpy()) < TOL
+
+
+def test_quad_rollout_full_size_vs_oracle(dev):
+    """BASELINE config 2: B = 65 536, H = 10, dt = 0.1 - the whole batch is
+    checked against the CPU autograd oracle (takes ~1 s on the host)."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from oracle import torch_port as tp
+    B, H, dt = 65536, 10, 0.1
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=0)
+    st, loss, ga, gs = tp.rollout_fwd_bwd(
+        tp.QuadOracle(), tp.quad_mpc_loss, d["state0"], d["actions"], d["ref"],
+        dt)
+    dyn = FlightmareDynamics()
+    s0 = soa_state(d["state0"].to(dev))
+    a = soa_seq(d["actions"].to(dev))
+    r = soa_seq(d["ref"].to(dev))
+    res = F.quad_rollout_fwd_bwd(s0, a, r, dt, dyn.params, layout="soa",
+                                 want_states=True)
+    assert rel_err(N(aos_seq(res["states"])), st.numpy()) < TOL
+    assert abs(res["loss"].item() - loss.item()) / loss.item() < TOL
+    assert rel_err(N(aos_seq(res["grad_actions"])), ga.numpy()) < TOL
+    assert rel_err(N(res["grad_state0"].t()), gs.numpy()) < TOL
+    # per-trajectory check too (not only relative to the tensor maximum)
+    ga_dev = N(aos_seq(res["grad_actions"])).reshape(B, -1)
+    ga_ref = ga.numpy().reshape(B, -1)
+    per_traj = np.abs(ga_dev - ga_ref).max(1) / np.abs(ga_ref).max(1)
+    assert per_traj.max() < 1e-3 and np.median(per_traj) < 1e-5
+    # size-independent properties: additivity of the loss over a batch split
+    # and permutation equivariance of the gradients
+    half = B // 2
+    res_a = F.quad_rollout_fwd_bwd(
+        s0[:, :half].contiguous(), a[:, :, :half].contiguous(),
+        r[:, :, :half].contiguous(), dt, dyn.params, layout="soa")
+    res_b = F.quad_rollout_fwd_bwd(
+        s0[:, half:].contiguous(), a[:, :, half:].contiguous(),
+        r[:, :, half:].contiguous(), dt, dyn.params, layout="soa")
+    tot = res_a["loss"].item() + res_b["loss"].item()
+    assert abs(tot - res["loss"].item()) / res["loss"].item() < 1e-5
+    assert torch.equal(res_a["grad_actions"], res["grad_actions"][:, :, :half])
+    assert torch.equal(res_b["grad_actions"], res["grad_actions"][:, :, half:])
+
+
+def test_quad_empty_and_errors(dev):
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    dyn = FlightmareDynamics()
+    z = lambda *s: torch.zeros(*s, device=dev)
+    res = F.quad_rollout_fwd_bwd(z(0, 12), z(0, 10, 4), z(0, 10, 9), 0.1,
+                                 dyn.params)
+    assert res["loss"].item() == 0.0
+    assert dyn(z(0, 12), z(0, 4), 0.1).shape == (0, 12)
+    with pytest.raises(ValueError):    # H beyond APG_MAX_HORIZON
+        F.quad_rollout_fwd_bwd(z(4, 12), z(4, 49, 4), z(4, 49, 9), 0.1,
+                               dyn.params)
+    with pytest.raises(ValueError):    # bad ref_cols
+        F.quad_rollout_fwd_bwd(z(4, 12), z(4, 10, 4), z(4, 10, 7), 0.1,
+                               dyn.params)
+    with pytest.raises(RuntimeError):  # CPU tensors: no fallback
+        dyn(torch.zeros(4, 12), torch.zeros(4, 4), 0.1)
+
+
+def test_quad_features(dev):
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    g = load_golden("features.npz")
+    s = D(g["state"], dev).requires_grad_(True)
+    f = state_preprocessing(s)
+    assert rel_err(N(f), g["feat"]) < 1e-6
+    (gs,) = torch.autograd.grad(f, s, D(g["cot"], dev))
+    assert rel_err(N(gs), g["gstate"]) < 1e-5
+
+
+def test_quad_loss(dev):
+    from apg_trajectory_tracking_amd.drone_loss import quad_mpc_loss
+    g = load_golden("losses.npz")
+    st = D(g["q_states"], dev).requires_grad_(True)
+    act = D(g["q_actions"], dev).requires_grad_(True)
+    loss = quad_mpc_loss(st, D(g["q_ref"], dev), act)
+    gs, ga = torch.autograd.grad(loss, (st, act))
+    assert abs(loss.item() - g["q_loss"]) / g["q_loss"] < 1e-6
+    assert rel_err(N(gs), g["q_gstates"]) < 1e-6
+    assert rel_err(N(ga), g["q_gactions"]) < 1e-6
+
+
+def test_quad_unroll_through_step_api_matches_fused(dev):
+    """The reference's own loop (scripts/train_drone.py:181-197) written with
+    the drop-in objects gives the same loss / gradients as the fused kernel."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.drone_loss import quad_mpc_loss
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    g = load_golden("quad_rollout.npz")
+    dyn = FlightmareDynamics()
+    s0 = D(g["state0"], dev).requires_grad_(True)
+    a = D(g["actions"], dev).requires_grad_(True)
+    r = D(g["ref"], dev)
+    B, H = a.shape[:2]
+    inter = torch.zeros(B, H, 12, device=dev)
+    cur = s0
+    for k in range(H):
+        cur = dyn(cur, a[:, k], float(g["dt"]))
+        inter[:, k] = cur
+    loss = quad_mpc_loss(inter, r, a)
+    loss.backward()
+    assert rel_err(N(inter), g["def_states"]) < 1e-5
+    assert abs(loss.item() - g["def_loss"]) / g["def_loss"] < 1e-5
+    assert rel_err(N(a.grad), g["def_gactions"]) < TOL
+    assert rel_err(N(s0.grad), g["def_gstate0"]) < TOL
+    s1 = D(g["state0"], dev).requires_grad_(True)
+    a1 = D(g["actions"], dev).requires_grad_(True)
+    loss2 = F.quad_rollout_loss(s1, a1, r, float(g["dt"]), dyn.params)
+    (3.0 * loss2).backward()
+    assert abs(loss2.item() - g["def_loss"]) / g["def_loss"] < 1e-5
+    assert rel_err(N(a1.grad) / 3.0, g["def_gactions"]) < TOL
+    assert rel_err(N(s1.grad) / 3.0, g["def_gstate0"]) < TOL
+
+
+# ------------------------------------------------------------------ wing
+def test_wing_known_answers(dev):
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    g = load_golden("wing.npz")
+    dyn = FixedWingDynamics()
+    nxt = dyn.simulate_fixed_wing(D(g["ka_state"], dev), D(g["ka_action"], dev),
+                                  0.05)
+    assert rel_err(N(nxt), g["ka_next"]) < 1e-5
+    # tests/run_wing_sim.py: 1001-step open-loop trace via the rollout kernel
+    state = torch.zeros(1, 12, device=dev)
+    state[0, 3] = 11.5
+    act = D(g["sim_action"], dev).reshape(1, 1, 4).repeat(1, 1000, 1)
+    sts = dyn.rollout(state, act, 1 / 100)
+    full = torch.cat((state[:, None], sts), 1)[0]
+    got = N(full)[g["sim_rows"]]
+    assert rel_err(got, g["sim_states"]) < 5e-4   # 1000 chained fp32 steps
+
+
+@pytest.mark.parametrize("tag,mp", [("def", {}), ("mod", WMOD)])
+def test_wing_step_and_vjp(dev, tag, mp):
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    g = load_golden("wing.npz")
+    dyn = FixedWingDynamics(modified_params=dict(mp))
+    s = D(g["step_state"], dev).requires_grad_(True)
+    a = D(g["step_action"], dev).requires_grad_(True)
+    nxt = dyn(s, a, 0.05)
+    assert rel_err(N(nxt), g[f"step_{tag}_next"]) < 1e-5
+    for i, c in enumerate(g["step_cot"]):
+        gs, ga = torch.autograd.grad(nxt, (s, a), D(c, dev), retain_graph=True)
+        assert rel_err(N(gs), g[f"step_{tag}_gstate"][i]) < TOL
+        assert rel_err(N(ga), g[f"step_{tag}_gaction"][i]) < TOL
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("H", [20, 10])
+def test_wing_rollout_golden(dev, layout, H):
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    g = load_golden("wing.npz")
+    p = f"h{H}_"
+    dyn = FixedWingDynamics()
+    s0, a, r = D(g[p + "state0"], dev), D(g[p + "actions"], dev), D(g[p + "ref"], dev)
+    if layout == "soa":
+        s0, a, r = soa_state(s0), soa_seq(a), soa_seq(r)
+    res = F.wing_rollout_fwd_bwd(s0, a, r, 0.05, dyn.params, layout=layout,
+                                 want_states=True)
+    st, ga, gs = res["states"], res["grad_actions"], res["grad_state0"]
+    if layout == "soa":
+        st, ga, gs = aos_seq(st), aos_seq(ga), gs.t()
+    assert rel_err(N(st), g[p + "states"]) < 1e-5
+    assert abs(res["loss"].item() - g[p + "loss"]) / g[p + "loss"] < 1e-5
+    assert rel_err(N(ga), g[p + "gactions"]) < TOL
+    assert rel_err(N(gs), g[p + "gstate0"]) < TOL
+
+
+def test_wing_rollout_large_vs_oracle(dev):
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    from oracle import torch_port as tp
+    B, H, dt = 8192, 20, 0.05
+    d = synthetic.wing_batch(B, H, dt, seed=5)
+    st, loss, ga, gs = tp.rollout_fwd_bwd(
+        tp.WingOracle(), tp.fixed_wing_mpc_loss, d["state0"], d["actions"],
+        d["ref"], dt)
+    dyn = FixedWingDynamics()
+    res = F.wing_rollout_fwd_bwd(
+        soa_state(d["state0"].to(dev)), soa_seq(d["actions"].to(dev)),
+        soa_seq(d["ref"].to(dev)), dt, dyn.params, layout="soa",
+        want_states=True)
+    assert rel_err(N(aos_seq(res["states"])), st.numpy()) < TOL
+    assert abs(res["loss"].item() - loss.item()) / loss.item() < TOL
+    assert rel_err(N(aos_seq(res["grad_actions"])), ga.numpy()) < TOL
+    assert rel_err(N(res["grad_state0"].t()), gs.numpy()) < TOL
+
+
+# -------------------------------------------------------------- cartpole
+def test_cartpole(dev):
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.cartpole_dynamics import (
+        CartpoleDynamics)
+    g = load_golden("cartpole.npz")
+    dyn = CartpoleDynamics()
+    nxt = dyn(D(g["ka_state"], dev), D(g["ka_action"], dev), 0.02)
+    assert rel_err(N(nxt), g["ka_next"]) < 1e-6
+    s = D(g["state0"], dev).requires_grad_(True)
+    a1 = D(g["actions"][:, 0], dev).requires_grad_(True)
+    nxt = dyn(s, a1, 0.02)
+    gs, ga = torch.autograd.grad(nxt, (s, a1), D(g["step_cot"], dev))
+    assert rel_err(N(nxt), g["step_next"]) < 1e-5
+    assert rel_err(N(gs), g["step_gstate"]) < TOL
+    assert rel_err(N(ga), g["step_gaction"]) < TOL
+    for layout in ("aos", "soa"):
+        s0, a = D(g["state0"], dev), D(g["actions"], dev)
+        if layout == "soa":
+            s0, a = soa_state(s0), soa_seq(a)
+        res = F.cartpole_rollout_fwd_bwd(s0, a, float(g["dt"]), dyn.params,
+                                         layout=layout, want_states=True)
+        st, ga, gs = res["states"], res["grad_actions"], res["grad_state0"]
+        if layout == "soa":
+            st, ga, gs = aos_seq(st), aos_seq(ga), gs.t()
+        assert rel_err(N(st), g["states"]) < 1e-5
+        assert abs(res["loss"].item() - g["loss"]) / g["loss"] < 1e-5
+        assert rel_err(N(ga), g["gactions"]) < TOL
+        assert rel_err(N(gs), g["gstate0"]) < TOL
