@@ -56,6 +56,12 @@ class ApgWingLossWeights(ctypes.Structure):
     _fields_ = [("pos", ctypes.c_float), ("action", ctypes.c_float)]
 
 
+class ApgDeferredLoss(ctypes.Structure):
+    _fields_ = [("prev_partials", ctypes.c_void_p),
+                ("prev_count", ctypes.c_int),
+                ("prev_loss", ctypes.c_void_p)]
+
+
 class ApgCartpoleParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in (
         "masscart", "masspole", "length", "max_force_mag", "friction",
@@ -75,7 +81,7 @@ SIGNATURES = {
     "apg_quad_rollout_fwd_bwd": [
         _P, _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), _I, _I, _I, _P, _P, _P, _P, _P,
-        _P],
+        ctypes.POINTER(ApgDeferredLoss), _P],
     "apg_quad_rollout_fwd": [_P, _P, _F, ctypes.POINTER(ApgQuadParams), _I,
                              _I, _I, _P, _P],
     "apg_quad_loss_fwd_bwd": [
@@ -90,7 +96,7 @@ SIGNATURES = {
     "apg_wing_rollout_fwd_bwd": [
         _P, _P, _P, _F, ctypes.POINTER(ApgWingParams),
         ctypes.POINTER(ApgWingLossWeights), _I, _I, _I, _P, _P, _P, _P, _P,
-        _P],
+        ctypes.POINTER(ApgDeferredLoss), _P],
     "apg_wing_rollout_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I,
                              _I, _I, _P, _P],
     "apg_cartpole_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgCartpoleParams),
@@ -100,6 +106,7 @@ SIGNATURES = {
     "apg_cartpole_rollout_fwd_bwd": [
         _P, _P, _F, ctypes.POINTER(ApgCartpoleParams), _I, _I, _I, _P, _P,
         _P, _P, _P, _P],
+    "apg_reduce_loss_partials": [_P, _I, _P, _P],
     "apg_loss_partials_count": [_I],
     "apg_version": [],
     "apg_last_error_string": [],

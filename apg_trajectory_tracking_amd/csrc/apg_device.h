@@ -106,6 +106,61 @@ __device__ __forceinline__ void store_seq(float *__restrict__ p, int B, int H,
   }
 }
 
+// ---- buffer-addressed SoA planes --------------------------------------------
+// A SoA tensor is a stack of planes of B floats.  Addressing it through a
+// buffer resource keeps the per-lane part of the address in ONE 32-bit VGPR
+// (4*b) and the plane offset in an SGPR: no 64-bit VALU address arithmetic
+// and no address register pairs per access.  The descriptor is built from
+// kernel arguments only, so it is provably wave-uniform (no waterfall loop).
+// Requires planes * B * 4 < 2^31 (checked on the host; larger tensors take
+// the flat-address path).
+struct SoaPlanes {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff;  // 4 * trajectory index
+  int pitch; // 4 * B
+  __device__ __forceinline__ SoaPlanes(const void *base, int planes, int B, int b)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
+                                               planes * B * 4, 0x00020000)),
+        voff(b * 4), pitch(B * 4) {}
+  __device__ __forceinline__ float ld(int plane) const {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, plane * pitch, 0));
+  }
+  __device__ __forceinline__ void st(int plane, float v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc,
+                                          voff, plane * pitch, 0);
+  }
+};
+
+// ---- trigonometry ----------------------------------------------------------
+// Branch-free sin/cos pair: 3-term Cody-Waite reduction by pi/2 (exact
+// products through FMA) + degree-9 / degree-10 polynomials on [-pi/4, pi/4].
+// Max error 1.6 ulp for |x| <= 1e5 (checked against float64 on 1e7 points,
+// see DESIGN.md); beyond ~1e6 rad accuracy degrades gracefully, NaN/Inf give
+// NaN.  ~30 VALU ops and no control flow, so the three attitude angles of a
+// step interleave in the pipeline (libm's sincosf costs ~45 issued ops per
+// call plus branches that serialise them).
+__device__ __forceinline__ void sincos_fast(float x, float *sn, float *cs) {
+  const float kf = rintf(x * 0.6366197466850281f);
+  const int k = (int)kf;
+  float r = fmaf(-kf, 1.5707963705062866f, x);
+  r = fmaf(-kf, -4.371138828673793e-08f, r);
+  r = fmaf(-kf, -1.7151245100058819e-15f, r);
+  const float t = r * r;
+  float ps = fmaf(t, 2.6658919978217455e-06f, -0.0001983463589567691f);
+  ps = fmaf(t, ps, 0.008333319798111916f);
+  ps = fmaf(t, ps, -0.1666666716337204f);
+  const float s = fmaf(r * t, ps, r);
+  float pc = fmaf(t, -4.336599204179947e-07f, 2.494495674909558e-05f);
+  pc = fmaf(t, pc, -0.0013889188412576914f);
+  pc = fmaf(t, pc, 0.0416666679084301f);
+  const float c = fmaf(t * t, pc, fmaf(t, -0.5f, 1.0f));
+  const bool swap = (k & 1) != 0;
+  const float so = swap ? c : s, co = swap ? s : c;
+  *sn = __uint_as_float(__float_as_uint(so) ^ ((unsigned)(k & 2) << 30));
+  *cs = __uint_as_float(__float_as_uint(co) ^ ((unsigned)((k + 1) & 2) << 30));
+}
+
 // ---- wave64 reduction -------------------------------------------------------
 // Butterfly over the 64 lanes; every lane ends with the full sum, in an order
 // that depends only on the lane index (deterministic).
@@ -122,6 +177,56 @@ __device__ __forceinline__ void write_wave_partial(float *partials, float lane_l
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     partials[wave] = s;
   }
+}
+
+// Deferred reduction (ApgDeferredLoss): executed by ONE wave of the launch,
+// split in two so that it costs that wave no stall: `head` issues the loads
+// of the earlier launch's partials BEFORE the wave's own input loads (they
+// return first, in order), `tail` sums them at the very end of the kernel,
+// long after they have landed.  Lane l owns partials l, l+64, ...; the
+// summation order is fixed by the indices (deterministic).
+struct PrevPartials {
+  float v[16];
+  double acc;
+};
+
+__device__ __forceinline__ void reduce_prev_head(const ApgDeferredLoss &d,
+                                                 PrevPartials &pp) {
+  const int lane = threadIdx.x & (kWave - 1);
+  pp.acc = 0.0;
+  // everything beyond the first 1024 partials (batches > 65 536) is summed
+  // right away, 16 independent loads per lane and pass
+  for (int base = 16 * kWave; base < d.prev_count; base += 16 * kWave) {
+    float t[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int i = base + j * kWave + lane;
+      t[j] = i < d.prev_count ? d.prev_partials[i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pp.acc += (double)t[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = j * kWave + lane;
+    pp.v[j] = i < d.prev_count ? d.prev_partials[i] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void reduce_prev_tail(const ApgDeferredLoss &d,
+                                                 const PrevPartials &pp) {
+  double acc = pp.acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc += (double)pp.v[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) d.prev_loss[0] = (float)acc;
+}
+
+__device__ __forceinline__ void reduce_prev_partials(const ApgDeferredLoss &d) {
+  PrevPartials pp;
+  reduce_prev_head(d, pp);
+  reduce_prev_tail(d, pp);
 }
 
 // Second stage: fixed-order sum of the per-wave partials (one workgroup).

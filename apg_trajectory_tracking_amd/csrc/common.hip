@@ -24,21 +24,20 @@ int check_launch(const char *what) {
                                                                : APG_ERR_HIP;
 }
 
-// One workgroup; thread t accumulates partials[t], [t+256], ... in double,
-// then a fixed-shape LDS tree: the result does not depend on scheduling.
+// One workgroup.  Thread t sums partials[t], [t+256], ... (independent loads,
+// double accumulation), then a wave butterfly and a 4-entry LDS combine: the
+// shape is fixed, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(
     const float *__restrict__ partials, int n, float *__restrict__ out) {
-  __shared__ double sm[256];
+  __shared__ double sm[4];
   double acc = 0.0;
+#pragma unroll 4
   for (int i = threadIdx.x; i < n; i += 256) acc += (double)partials[i];
-  sm[threadIdx.x] = acc;
-  __syncthreads();
 #pragma unroll
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = (float)sm[0];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 
 int launch_reduce_partials(const float *partials, int n, float *loss,
@@ -51,6 +50,15 @@ int launch_reduce_partials(const float *partials, int n, float *loss,
 }  // namespace apg
 
 extern "C" {
+
+int apg_reduce_loss_partials(const float *partials, int n, float *loss,
+                             apg_stream_t stream) {
+  if (!partials || !loss || n < 0) {
+    apg::set_error("apg_reduce_loss_partials: bad arguments");
+    return APG_ERR_ARG;
+  }
+  return apg::launch_reduce_partials(partials, n, loss, (hipStream_t)stream);
+}
 
 int apg_loss_partials_count(int B) {
   return B <= 0 ? 1 : (B + apg::kWave - 1) / apg::kWave;

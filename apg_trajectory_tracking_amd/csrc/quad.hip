@@ -34,9 +34,9 @@ struct Trig {
 
 __device__ __forceinline__ Trig make_trig(const float att[3]) {
   Trig t;
-  sincosf(att[0], &t.sr, &t.cr);
-  sincosf(att[1], &t.sp, &t.cp);
-  sincosf(att[2], &t.sy, &t.cy);
+  sincos_fast(att[0], &t.sr, &t.cr);
+  sincos_fast(att[1], &t.sp, &t.cp);
+  sincos_fast(att[2], &t.sy, &t.cy);
   return t;
 }
 
@@ -172,88 +172,166 @@ struct RolloutArgs {
   float *loss_partials, *grad_actions, *grad_state0, *states_out;
   QuadConst c;
   ApgQuadLossWeights w;
+  ApgDeferredLoss prev;  // prev_partials == NULL: nothing deferred
   int B, H, ref_cols, vel_col;
 };
 
-// Compile-time horizon: the whole trajectory lives in registers.
-//   forward sweep : stashes att_k, w_k (what the adjoint of step k needs) and
-//                   the loss seeds dL/dp_{k+1}, dL/dv_{k+1}; accumulates the
-//                   loss; the action-cost gradient is written into ga[k].
-//   reverse sweep : lam <- seeds + adjoint(step k), ga[k] += dynamics part.
+// Compile-time horizon: the whole trajectory lives in registers and the HBM
+// stream is software-pipelined against the arithmetic (one wave per SIMD at
+// B = 65 536, so nothing else would hide the latency):
+//   prologue      : issue state0, all actions and the LAST two reference rows
+//                   (64 loads in flight - the vmcnt ceiling).
+//   forward sweep : step k needs only state0/actions; after each step one more
+//                   reference row is requested, in REVERSE step order.  Stashes
+//                   sin/cos(att_k), w_k and (p, v)_{k+1}.
+//   reverse sweep : consumes the reference rows in the order they were
+//                   requested (k = H-1 .. 0): loss terms, seeds, adjoint of
+//                   step k, store dL/da_k.  The tail of the load stream thus
+//                   overlaps the adjoint arithmetic instead of preceding it.
 // HBM traffic per trajectory: 48 + 16H + 24H read, 16H (+48) written.
-template <int LAYOUT, int HT, bool STATES_OUT>
+template <int LAYOUT, int HT, bool STATES_OUT, bool BUF>
 __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
     RolloutArgs A) {
+  static_assert(!BUF || LAYOUT == APG_LAYOUT_SOA, "buffer path is SoA only");
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = b < A.B;
   const int bb = live ? b : A.B - 1;  // keep the wave convergent for the reduce
   const QuadConst c = A.c;
+  constexpr int kPre = HT < 2 ? HT : 2;  // reference rows requested up front
+
+  // deferred loss of an earlier launch (ApgDeferredLoss): request its
+  // partials before this wave's own inputs, sum them at the very end
+  const bool reducer = blockIdx.x == 0 && A.prev.prev_partials != nullptr;
+  PrevPartials pp;
+  if (reducer) reduce_prev_head(A.prev, pp);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // accessors: buffer-addressed planes (SoA fast path) or flat addresses
+  const SoaPlanes b_s0(A.state0, 12, A.B, bb), b_act(A.actions, HT * 4, A.B, bb),
+      b_ref(A.ref, HT * A.ref_cols, A.B, bb),
+      b_ga(A.grad_actions, HT * 4, A.B, bb),
+      b_gs(A.grad_state0, 12, A.B, bb), b_so(A.states_out, HT * 12, A.B, bb);
+  auto ld_ref = [&](int k, float(&p)[3], float(&v)[3]) {
+    if constexpr (BUF) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        p[i] = b_ref.ld(k * A.ref_cols + i);
+        v[i] = b_ref.ld(k * A.ref_cols + A.vel_col + i);
+      }
+    } else {
+      load_seq<LAYOUT, 3>(A.ref, A.B, HT, A.ref_cols, bb, k, 0, p);
+      load_seq<LAYOUT, 3>(A.ref, A.B, HT, A.ref_cols, bb, k, A.vel_col, v);
+    }
+  };
 
   float s[12];
   float act[HT][4];
   float rp[HT][3], rv[HT][3];
-  load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
+  // (sched_barriers pin the request order: the memory system returns loads
+  // in order, so program order here IS the arrival order)
+  if constexpr (BUF) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = b_s0.ld(i);
+  } else {
+    load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < HT; ++k) {
-    load_seq<LAYOUT, 4>(A.actions, A.B, HT, 4, bb, k, 0, act[k]);
-    load_seq<LAYOUT, 3>(A.ref, A.B, HT, A.ref_cols, bb, k, 0, rp[k]);
-    load_seq<LAYOUT, 3>(A.ref, A.B, HT, A.ref_cols, bb, k, A.vel_col, rv[k]);
+    if constexpr (BUF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) act[k][i] = b_act.ld(k * 4 + i);
+    } else {
+      load_seq<LAYOUT, 4>(A.actions, A.B, HT, 4, bb, k, 0, act[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int k = HT - 1; k >= HT - kPre; --k) {
+    ld_ref(k, rp[k], rv[k]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
-  float st_att[HT][3], st_w[HT + 1][3];
-  float loss = 0.f;
+  Trig st_trig[HT];
+  float st_w[HT + 1][3];
+  float st_pv[HT][6];
 #pragma unroll
   for (int k = 0; k < HT; ++k) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) st_att[k][i] = s[3 + i], st_w[k][i] = s[9 + i];
-    Trig t = make_trig(&s[3]);
-    quad_step(s, act[k], c, t);
-    if constexpr (STATES_OUT)
-      if (live) store_seq<LAYOUT, 12>(A.states_out, A.B, HT, 12, b, k, 0, s);
-    // loss terms of step k (drone_loss.py:22-34) and their seeds
-    float lp = 0.f, lv = 0.f, lw = 0.f;
+    for (int i = 0; i < 3; ++i) st_w[k][i] = s[9 + i];
+    st_trig[k] = make_trig(&s[3]);
+    quad_step(s, act[k], c, st_trig[k]);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float dp = s[i] - rp[k][i], dv = s[6 + i] - rv[k][i];
-      lp += dp * dp, lv += dv * dv, lw += s[9 + i] * s[9 + i];
-      rp[k][i] = 2.f * A.w.pos * dp;  // seeds overwrite the reference
-      rv[k][i] = 2.f * A.w.vel * dv;
-    }
-    const float da0 = act[k][0] - 0.5f;
-    float lr = 0.f;
+    for (int i = 0; i < 3; ++i) st_pv[k][i] = s[i], st_pv[k][3 + i] = s[6 + i];
+    if constexpr (STATES_OUT) {
+      if (live) {
+        if constexpr (BUF) {
 #pragma unroll
-    for (int i = 1; i < 4; ++i) {
-      float d = act[k][i] - 0.5f;
-      lr += d * d;
-      act[k][i] = 2.f * A.w.rates * d;  // action-cost gradient
+          for (int i = 0; i < 12; ++i) b_so.st(k * 12 + i, s[i]);
+        } else {
+          store_seq<LAYOUT, 12>(A.states_out, A.B, HT, 12, b, k, 0, s);
+        }
+      }
     }
-    loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
-            A.w.thrust * da0 * da0;
+    const int kr = HT - 1 - kPre - k;  // next reference row to request
+    if (kr >= 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      ld_ref(kr, rp[kr], rv[kr]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) st_w[HT][i] = s[9 + i];
 
-  write_wave_partial(A.loss_partials, live ? loss : 0.f);
-
+  float loss = 0.f;
   float lam[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
 #pragma unroll
   for (int k = HT - 1; k >= 0; --k) {
+    // loss terms of step k (drone_loss.py:22-34) and their seeds
+    float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      lam[i] += rp[k][i];
-      lam[6 + i] += rv[k][i];
-      lam[9 + i] += 2.f * A.w.av * st_w[k + 1][i];
+      const float dp = st_pv[k][i] - rp[k][i];
+      const float dv = st_pv[k][3 + i] - rv[k][i];
+      const float wn = st_w[k + 1][i];
+      lp += dp * dp, lv += dv * dv, lw += wn * wn;
+      lam[i] += 2.f * A.w.pos * dp;
+      lam[6 + i] += 2.f * A.w.vel * dv;
+      lam[9 + i] += 2.f * A.w.av * wn;
     }
-    const float a0 = act[k][0];
-    float ga[4] = {2.f * A.w.thrust * (a0 - 0.5f), act[k][1], act[k][2],
-                   act[k][3]};
-    Trig t = make_trig(st_att[k]);
-    quad_step_adjoint(lam, ga, a0, st_w[k], c, t);
-    if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, HT, 4, b, k, 0, ga);
+    const float a0 = act[k][0], da0 = a0 - 0.5f;
+    float ga[4];
+    ga[0] = 2.f * A.w.thrust * da0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      const float d = act[k][i] - 0.5f;
+      lr += d * d;
+      ga[i] = 2.f * A.w.rates * d;
+    }
+    loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
+            A.w.thrust * da0 * da0;
+    quad_step_adjoint(lam, ga, a0, st_w[k], c, st_trig[k]);
+    if (live) {
+      if constexpr (BUF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b_ga.st(k * 4 + i, ga[i]);
+      } else {
+        store_seq<LAYOUT, 4>(A.grad_actions, A.B, HT, 4, b, k, 0, ga);
+      }
+    }
   }
-  if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
+  if (A.grad_state0 && live) {
+    if constexpr (BUF) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) b_gs.st(i, lam[i]);
+    } else {
+      store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
+    }
+  }
+  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+  if (reducer) reduce_prev_tail(A.prev, pp);
 }
 
 // Run-time horizon: same sweeps, the per-step stash (att, w, seeds: 12 floats)
@@ -274,6 +352,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_lds_kernel(
 
   float s[12];
   load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
+  if (blockIdx.x == 0 && threadIdx.x < kWave && A.prev.prev_partials)
+    reduce_prev_partials(A.prev);
   float loss = 0.f;
   for (int k = 0; k < H; ++k) {
     float a[4], rp[3], rv[3];
@@ -487,11 +567,18 @@ int check_common(const void *p0, const void *p1, const void *params, int B,
 template <int LAYOUT, bool SO>
 int launch_rollout(const RolloutArgs &A, hipStream_t st) {
   const dim3 grid(grid_for(A.B, APG_ROLLOUT_BLOCK)), block(APG_ROLLOUT_BLOCK);
+  // buffer addressing needs every tensor below 2 GiB (32-bit byte offsets)
+  const bool buf_ok = (long long)A.H * 12 * A.B * 4 < (1ll << 31);
   switch (A.H) {
-#define APG_CASE(HT)                                                         \
-  case HT:                                                                   \
-    hipLaunchKernelGGL((quad_rollout_reg_kernel<LAYOUT, HT, SO>), grid, block, \
-                       0, st, A);                                            \
+#define APG_CASE(HT)                                                          \
+  case HT:                                                                    \
+    if (LAYOUT == APG_LAYOUT_SOA && buf_ok)                                   \
+      hipLaunchKernelGGL(                                                     \
+          (quad_rollout_reg_kernel<LAYOUT, HT, SO, LAYOUT == APG_LAYOUT_SOA>), \
+          grid, block, 0, st, A);                                             \
+    else                                                                      \
+      hipLaunchKernelGGL((quad_rollout_reg_kernel<LAYOUT, HT, SO, false>),    \
+                         grid, block, 0, st, A);                              \
     break;
     APG_CASE(5) APG_CASE(10)  // register-resident horizons (reference configs)
 #undef APG_CASE
@@ -559,9 +646,19 @@ int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
                              const ApgQuadLossWeights *weights, int B, int H,
                              int layout, float *loss_partials, float *loss,
                              float *grad_actions, float *grad_state0,
-                             float *states_out, apg_stream_t stream) {
+                             float *states_out,
+                             const ApgDeferredLoss *deferred,
+                             apg_stream_t stream) {
   if (int e = check_common(state0, actions, params, B, layout)) return e;
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
+  if (deferred && deferred->prev_partials) {
+    if (!deferred->prev_loss || deferred->prev_count < 0 ||
+        deferred->prev_partials == loss_partials) {
+      set_error("deferred: prev_loss NULL, prev_count < 0 or prev_partials "
+                "aliases loss_partials");
+      return APG_ERR_ARG;
+    }
+  }
   if (H < 1 || H > APG_MAX_HORIZON) {
     set_error("H must be in [1, %d] (got %d)", APG_MAX_HORIZON, H);
     return APG_ERR_ARG;
@@ -571,11 +668,15 @@ int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
     return APG_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
+  const bool has_prev = deferred && deferred->prev_partials;
   if (B == 0) {  // empty batch: loss = 0, nothing else to write
     if (loss) {
       if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
         return check_launch("memset(loss)");
     }
+    if (has_prev)
+      return launch_reduce_partials(deferred->prev_partials,
+                                    deferred->prev_count, deferred->prev_loss, st);
     return APG_OK;
   }
   if (!ref || !loss_partials || !grad_actions) {
@@ -588,6 +689,7 @@ int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
   A.grad_state0 = grad_state0, A.states_out = states_out;
   A.c = make_const(*params, dt);
   A.w = *weights;
+  A.prev = has_prev ? *deferred : ApgDeferredLoss{nullptr, 0, nullptr};
   A.B = B, A.H = H, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
   int e;
   if (layout == APG_LAYOUT_SOA)

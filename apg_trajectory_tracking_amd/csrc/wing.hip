@@ -329,6 +329,7 @@ struct WingRolloutArgs {
   float *loss_partials, *grad_actions, *grad_state0, *states_out;
   WingConst k;
   ApgWingLossWeights w;
+  ApgDeferredLoss prev;
   int B, H;
 };
 
@@ -350,6 +351,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
   };
   float s[12];
   load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
+  if (blockIdx.x == 0 && threadIdx.x < kWave && A.prev.prev_partials)
+    reduce_prev_partials(A.prev);
   float loss = 0.f;
   for (int kk = 0; kk < H; ++kk) {
     float a[4], rp[3];
@@ -473,9 +476,18 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
                              const ApgWingLossWeights *weights, int B, int H,
                              int layout, float *loss_partials, float *loss,
                              float *grad_actions, float *grad_state0,
-                             float *states_out, apg_stream_t stream) {
+                             float *states_out,
+                             const ApgDeferredLoss *deferred,
+                             apg_stream_t stream) {
   if (int e = check_args(state0, actions, params, B, layout)) return e;
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
+  const bool has_prev = deferred && deferred->prev_partials;
+  if (has_prev && (!deferred->prev_loss || deferred->prev_count < 0 ||
+                   deferred->prev_partials == loss_partials)) {
+    set_error("deferred: prev_loss NULL, prev_count < 0 or prev_partials "
+              "aliases loss_partials");
+    return APG_ERR_ARG;
+  }
   if (H < 1 || H > APG_MAX_HORIZON) {
     set_error("H must be in [1, %d] (got %d)", APG_MAX_HORIZON, H);
     return APG_ERR_ARG;
@@ -484,6 +496,9 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
   if (B == 0) {
     if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
       return check_launch("memset(loss)");
+    if (has_prev)
+      return launch_reduce_partials(deferred->prev_partials,
+                                    deferred->prev_count, deferred->prev_loss, st);
     return APG_OK;
   }
   if (!ref || !loss_partials || !grad_actions) {
@@ -496,6 +511,7 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
   A.grad_state0 = grad_state0, A.states_out = states_out;
   A.k = make_const(*params, dt);
   A.w = *weights;
+  A.prev = has_prev ? *deferred : ApgDeferredLoss{nullptr, 0, nullptr};
   A.B = B, A.H = H;
   const size_t lds = (size_t)H * 12 * APG_ROLLOUT_BLOCK * sizeof(float);
   const dim3 grid(grid_for(B, APG_ROLLOUT_BLOCK)), block(APG_ROLLOUT_BLOCK);

@@ -178,7 +178,7 @@ def quad_rollout_fwd_bwd(state0, actions, ref, dt, params, weights=None,
     check(lib().apg_quad_rollout_fwd_bwd(
         ptr(state0), ptr(actions), ptr(ref), ref_cols, float(dt),
         ctypes.byref(params), ctypes.byref(weights), B, H, lay, ptr(partials),
-        ptr(loss), ptr(ga), ptr(gs), ptr(states), stream_of(state0)),
+        ptr(loss), ptr(ga), ptr(gs), ptr(states), None, stream_of(state0)),
         "apg_quad_rollout_fwd_bwd")
     return dict(loss=loss, loss_partials=partials, grad_actions=ga,
                 grad_state0=gs, states=states)
@@ -325,7 +325,7 @@ def wing_rollout_fwd_bwd(state0, actions, ref, dt, params, weights=None,
         ptr(state0), ptr(actions), ptr(ref), float(dt), ctypes.byref(params),
         ctypes.byref(weights), B, H, lay, ptr(o["loss_partials"]),
         ptr(o["loss"]), ptr(o["grad_actions"]), ptr(o["grad_state0"]),
-        ptr(o["states"]), stream_of(state0)), "apg_wing_rollout_fwd_bwd")
+        ptr(o["states"]), None, stream_of(state0)), "apg_wing_rollout_fwd_bwd")
     return o
 
 
@@ -405,3 +405,102 @@ class _CartpoleRolloutLoss(torch.autograd.Function):
 
 def cartpole_rollout_loss(state0, action_seq, dt, params):
     return _CartpoleRolloutLoss.apply(state0, action_seq, dt, params)
+
+
+# ------------------------------------------------------ pre-bound launches
+def reduce_loss_partials(partials, loss=None):
+    """loss[0] = fixed-order sum of `partials` (apg_reduce_loss_partials)."""
+    require_device(partials, loss)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=partials.device)
+    check(lib().apg_reduce_loss_partials(
+        ptr(partials), partials.numel(), ptr(loss), stream_of(partials)),
+        "apg_reduce_loss_partials")
+    return loss
+
+
+class RolloutPlan:
+    """A fused-rollout launch with every ctypes argument bound once.
+
+    `launch()` is a single foreign call that enqueues the kernel(s) on the
+    stream that was current when the plan was made - the hot loop of a
+    trainer / bench pays no per-step Python argument marshalling, no
+    allocation and no host synchronisation.  The input tensors are held by
+    reference: refill them in place (copy_) between launches.
+
+    loss_mode:
+      "eager"    the launch is followed by the small fixed-order reduction
+                 kernel; `out["loss"]` is valid after this launch.
+      "deferred" the launch only leaves per-wave partials; the NEXT launch
+                 given `after=<this plan>` folds their reduction into its own
+                 kernel (ApgDeferredLoss), `flush()` reduces the last one.
+      "none"     partials only.
+    """
+
+    def __init__(self, system, state0, actions, ref, dt, params, weights=None,
+                 layout="soa", want_grad_state0=False, want_states=False,
+                 loss_mode="eager"):
+        if loss_mode not in ("eager", "deferred", "none"):
+            raise ValueError("loss_mode must be eager, deferred or none")
+        self.system = system
+        self.layout = layout
+        self.loss_mode = loss_mode
+        self.inputs = (state0, actions, ref)
+        kw = dict(layout=layout, want_grad_state0=want_grad_state0,
+                  want_states=want_states, want_loss=True)
+        # one eager call allocates the outputs and validates the shapes
+        if system == "quad":
+            self.out = quad_rollout_fwd_bwd(state0, actions, ref, dt, params,
+                                            weights, **kw)
+            weights = weights or quad_loss_weights()
+            fn = lib().apg_quad_rollout_fwd_bwd
+        elif system == "wing":
+            self.out = wing_rollout_fwd_bwd(state0, actions, ref, dt, params,
+                                            weights, **kw)
+            weights = weights or wing_loss_weights()
+            fn = lib().apg_wing_rollout_fwd_bwd
+        else:
+            raise ValueError("system must be 'quad' or 'wing'")
+        lay = _layout(layout)
+        B, H, _ = _seq_shape(actions, lay)
+        self.B, self.H = B, H
+        self._keep = [params, weights]
+        o = self.out
+        head = [ptr(state0), ptr(actions), ptr(ref)]
+        if system == "quad":
+            head.append(_seq_shape(ref, lay)[2])
+        self._fn = fn
+        self._head = head + [
+            float(dt), ctypes.byref(params), ctypes.byref(weights), B, H, lay,
+            ptr(o["loss_partials"]),
+            ptr(o["loss"]) if loss_mode == "eager" else None,
+            ptr(o["grad_actions"]), ptr(o["grad_state0"]), ptr(o["states"])]
+        self._stream = stream_of(state0)
+        self._args = tuple(self._head + [None, self._stream])
+        self._args_after = {}
+
+    def _deferred_args(self, prev):
+        key = id(prev)
+        args = self._args_after.get(key)
+        if args is None:
+            d = _capi.ApgDeferredLoss(
+                ptr(prev.out["loss_partials"]),
+                prev.out["loss_partials"].numel(), ptr(prev.out["loss"]))
+            self._keep.append(d)
+            args = tuple(self._head + [ctypes.byref(d), self._stream])
+            self._args_after[key] = args
+        return args
+
+    def launch(self, after=None):
+        """Enqueue the rollout.  `after`: an earlier-launched *deferred* plan
+        (not this one) whose loss this launch should reduce on the side."""
+        args = self._args if after is None else self._deferred_args(after)
+        code = self._fn(*args)
+        if code != 0:
+            check(code, "fused rollout launch")
+        return self.out
+
+    def flush(self):
+        """Reduce this plan's partials now (end of a deferred chain)."""
+        reduce_loss_partials(self.out["loss_partials"], self.out["loss"])
+        return self.out["loss"]

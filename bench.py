@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""bench.py - env-steps/s of the fused APG rollout (forward + backward through
+the quadrotor dynamics + quad_mpc_loss) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (one process per
+GPU under torch.distributed.run for N > 1) prints ONE JSON line on rank 0.
+
+A "step" is one pass of the hot path over one batch: the fused kernel
+apg_quad_rollout_fwd_bwd (H x dynamics, loss, analytic adjoint down to
+dL/daction_seq) followed by the fixed-order loss reduction; inputs are
+resident in HBM.  Workload = BASELINE.json configs[1]: quadrotor, concurrent
+mode, horizon 10, batch 65 536 synthetic polynomial trajectories per GPU
+(weak scaling: every rank owns its own 65 536-trajectory shard; the
+dynamics-only metric has no cross-rank exchange).
+The timing loop rotates over --sets independent buffer sets so the working
+set (sets x 44 MB) exceeds the 256 MB Infinity Cache.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+QUAD_BYTES_PER_TRAJ = {  # state0 + actions + ref(pos,vel) + dL/dactions
+    "base": lambda H: 48 + 16 * H + 24 * H + 16 * H,
+    "grad_state0": 48,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--dt", type=float, default=0.1)
+    ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
+    ap.add_argument("--sets", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--grad-state0", action="store_true")
+    ap.add_argument("--loss-mode", choices=["deferred", "eager", "none"],
+                    default="deferred",
+                    help="how each step's scalar loss is materialised "
+                         "(DESIGN.md: deferred = folded into the next launch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_sets(args, rank, dev):
+    """--sets independent (state0, actions, ref) triples in the chosen layout.
+    ref is packed [pos, vel] (6 columns) for SoA - the 608 B/trajectory
+    algorithmic layout - and the reference's 9-column rows for AoS."""
+    from apg_trajectory_tracking_amd import synthetic
+    sets = []
+    for i in range(args.sets):
+        d = synthetic.quad_polynomial_batch(
+            args.batch, args.horizon, args.dt,
+            seed=args.seed + 1000 * i + rank)
+        if args.layout == "soa":
+            ref6 = torch.cat((d["ref"][:, :, :3], d["ref"][:, :, 6:9]), 2)
+            t = (synthetic.to_soa_state(d["state0"]),
+                 synthetic.to_soa_seq(d["actions"]), synthetic.to_soa_seq(ref6))
+        else:
+            t = (d["state0"], d["actions"], d["ref"])
+        sets.append(tuple(x.to(dev) for x in t))
+    return sets
+
+
+def cpu_baseline(args):
+    """The reference's CPU PyTorch autograd path (restated in
+    oracle/torch_port.py, pinned to the reference by tests/golden) timed on
+    this box's host cores on the same workload shape."""
+    from apg_trajectory_tracking_amd import synthetic
+    from oracle import torch_port as tp
+    threads = torch.get_num_threads()
+    d = synthetic.quad_polynomial_batch(args.batch, args.horizon, args.dt,
+                                        seed=args.seed)
+    dyn = tp.QuadOracle()
+    run = lambda: tp.rollout_fwd_bwd(dyn, tp.quad_mpc_loss, d["state0"],
+                                     d["actions"], d["ref"], args.dt)
+    run()
+    t0 = time.perf_counter()
+    run()
+    one = time.perf_counter() - t0
+    iters = max(3, min(50, int(args.cpu_seconds / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    el = time.perf_counter() - t0
+    return {
+        "value": args.batch * args.horizon * iters / el,
+        "unit": "env-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": (f"{iters} iterations of the full B={args.batch} H={args.horizon} "
+                   f"rollout fwd+bwd, PyTorch-eager CPU autograd, anomaly mode off, "
+                   f"{threads} intra-op threads of {os.cpu_count()} logical CPUs"),
+        "ms_per_iter": el / iters * 1e3,
+    }
+
+
+def load_pmc_traffic(args):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass of this very
+    command (profiles/pmc_traffic.json), or None."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        key = f"quad_B{args.batch}_H{args.horizon}_{args.layout}"
+        return table.get(key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(
+                "--gpus N > 1 must be launched with torch.distributed.run "
+                "(one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    dyn = FlightmareDynamics()
+    sets = make_sets(args, rank, dev)
+    plans = [F.RolloutPlan("quad", *s, args.dt, dyn.params, layout=args.layout,
+                           want_grad_state0=args.grad_state0,
+                           loss_mode=args.loss_mode) for s in sets]
+    nset = len(plans)
+    deferred = args.loss_mode == "deferred"
+
+    def run_steps(n):
+        """n steps; with deferred losses step i's launch also reduces step
+        i-1's partials, and the chain is flushed inside the timed region."""
+        prev = None
+        for i in range(n):
+            p = plans[i % nset]
+            p.launch(after=prev if deferred else None)
+            prev = p
+        if deferred and prev is not None:
+            prev.flush()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run_steps(args.steps)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_check = float(plans[0].out["loss"].item())
+
+    # roofline pass: the same rollout launches alone (no loss reduction
+    # kernel in between), bracketed by one HIP-event pair on the launch
+    # stream -> average launch duration of the dominant kernel including the
+    # kernel-to-kernel boundary (a per-launch event pair would add ~2.5 us of
+    # its own to a ~10 us kernel)
+    kplans = [F.RolloutPlan("quad", *s, args.dt, dyn.params, layout=args.layout,
+                            want_grad_state0=args.grad_state0, loss_mode="none")
+              for s in sets]
+    for i in range(min(args.warmup, 10)):
+        kplans[i % nset].launch()
+    torch.cuda.synchronize()
+    k0 = torch.cuda.Event(enable_timing=True)
+    k1 = torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for i in range(args.steps):
+        kplans[i % nset].launch()
+    k1.record()
+    torch.cuda.synchronize()
+    kernel_ms = k0.elapsed_time(k1) / args.steps
+
+    H, B = args.horizon, args.batch
+    bytes_per_traj = QUAD_BYTES_PER_TRAJ["base"](H) + (
+        QUAD_BYTES_PER_TRAJ["grad_state0"] if args.grad_state0 else 0)
+    algo_bytes = B * bytes_per_traj
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/sec (fwd+bwd through dynamics), quad horizon=10 batch=65536",
+        "value": world * B * H * args.steps / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("quadrotor concurrent rollout fwd+bwd (dynamics + "
+                         "quad_mpc_loss + adjoint), BASELINE configs[1]"),
+            "batch_per_gpu": B, "global_batch": world * B, "horizon": H,
+            "dt": args.dt, "layout": args.layout, "buffer_sets": nset,
+            "grad_state0": bool(args.grad_state0),
+            "loss_mode": args.loss_mode,
+            "parallelism": f"batch-sharded x{world}, no data-path collective",
+        },
+        "ms_per_step_hip_events": ev_ms / args.steps,
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "quad_rollout_reg_kernel",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": load_pmc_traffic(args),
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "kernel_us_avg": kernel_ms * 1e3,
+        },
+        "loss_check": loss_check,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,19 @@ enum {
 /* Largest horizon the fused rollout kernels accept. */
 #define APG_MAX_HORIZON 48
 
+/* Deferred loss reduction.  A fused-rollout launch can fold the fixed-order
+ * sum of the loss partials left by an EARLIER launch on the same stream into
+ * its own kernel (workgroup 0 does it while its first loads are in flight).
+ * That takes the second kernel of the `loss != NULL` mode off the per-step
+ * critical path: step i's scalar loss is materialised by step i+1's launch,
+ * the last one by apg_reduce_loss_partials().  `prev_partials` must not alias
+ * the `loss_partials` of the launch it is passed to (ping-pong two buffers). */
+typedef struct ApgDeferredLoss {
+  const float *prev_partials; /* [prev_count] written by an earlier launch */
+  int prev_count;
+  float *prev_loss;           /* [1] receives their sum */
+} ApgDeferredLoss;
+
 /* ---------------------------------------------------------------- quad --- */
 /* Parameters of neural_control/dynamics/quad_dynamics_base.py:11-57 after
  * `cfg.update(modified_params)`; `inertia` is mass/12*arm_length^2*
@@ -101,6 +114,7 @@ int apg_quad_step_bwd(const float *state, const float *action, float dt,
  *   grad_actions  [B,H,4]      dL/daction_seq
  *   grad_state0   [B,12] or NULL
  *   states_out    [B,H,12] or NULL  intermediate states
+ *   deferred      NULL, or an earlier launch's partials to reduce (see above)
  * all in `layout`. */
 int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
                              const float *ref, int ref_cols, float dt,
@@ -108,7 +122,9 @@ int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
                              const ApgQuadLossWeights *weights, int B, int H,
                              int layout, float *loss_partials, float *loss,
                              float *grad_actions, float *grad_state0,
-                             float *states_out, apg_stream_t stream);
+                             float *states_out,
+                             const ApgDeferredLoss *deferred,
+                             apg_stream_t stream);
 
 /* No-grad unroll (eval / self-play): states_out[B,H,12] only. */
 int apg_quad_rollout_fwd(const float *state0, const float *actions, float dt,
@@ -174,7 +190,9 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
                              const ApgWingLossWeights *weights, int B, int H,
                              int layout, float *loss_partials, float *loss,
                              float *grad_actions, float *grad_state0,
-                             float *states_out, apg_stream_t stream);
+                             float *states_out,
+                             const ApgDeferredLoss *deferred,
+                             apg_stream_t stream);
 int apg_wing_rollout_fwd(const float *state0, const float *actions, float dt,
                          const ApgWingParams *params, int B, int H, int layout,
                          float *states_out, apg_stream_t stream);
@@ -209,6 +227,9 @@ int apg_cartpole_rollout_fwd_bwd(const float *state0, const float *actions,
                                  float *states_out, apg_stream_t stream);
 
 /* --------------------------------------------------------------- misc --- */
+/* loss[0] = fixed-order sum of partials[0..n) (one small kernel). */
+int apg_reduce_loss_partials(const float *partials, int n, float *loss,
+                             apg_stream_t stream);
 /* Number of floats `loss_partials` must hold for a batch of B. */
 int apg_loss_partials_count(int B);
 /* APG_VERSION_MAJOR * 1000 + APG_VERSION_MINOR. */

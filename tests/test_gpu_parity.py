@@ -187,10 +187,12 @@ def test_quad_rollout_full_size_vs_oracle(dev):
     half = B // 2
     res_a = F.quad_rollout_fwd_bwd(
         s0[:, :half].contiguous(), a[:, :, :half].contiguous(),
-        r[:, :, :half].contiguous(), dt, dyn.params, layout="soa")
+        r[:, :, :half].contiguous(), dt, dyn.params, layout="soa",
+        want_states=True)   # same kernel instantiation => bit-identical
     res_b = F.quad_rollout_fwd_bwd(
         s0[:, half:].contiguous(), a[:, :, half:].contiguous(),
-        r[:, :, half:].contiguous(), dt, dyn.params, layout="soa")
+        r[:, :, half:].contiguous(), dt, dyn.params, layout="soa",
+        want_states=True)
     tot = res_a["loss"].item() + res_b["loss"].item()
     assert abs(tot - res["loss"].item()) / res["loss"].item() < 1e-5
     assert torch.equal(res_a["grad_actions"], res["grad_actions"][:, :, :half])
@@ -380,3 +382,34 @@ def test_cartpole(dev):
         assert abs(res["loss"].item() - g["loss"]) / g["loss"] < 1e-5
         assert rel_err(N(ga), g["gactions"]) < TOL
         assert rel_err(N(gs), g["gstate0"]) < TOL
+
+
+def test_deferred_loss_chain(dev):
+    """ApgDeferredLoss: step i's loss reduced inside step i+1's launch equals
+    the eager two-kernel loss (same partials, fixed summation orders)."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    dyn = FlightmareDynamics()
+    B, H, dt = 4096 + 17, 10, 0.1
+    plans, eager = [], []
+    for seed in range(3):
+        d = synthetic.quad_polynomial_batch(B, H, dt, seed=seed)
+        t = (soa_state(d["state0"].to(dev)), soa_seq(d["actions"].to(dev)),
+             soa_seq(d["ref"].to(dev)))
+        eager.append(F.quad_rollout_fwd_bwd(*t, dt, dyn.params, layout="soa"))
+        plans.append(F.RolloutPlan("quad", *t, dt, dyn.params, layout="soa",
+                                   loss_mode="deferred"))
+    for p in plans:
+        p.out["loss"].fill_(-1.0)
+    prev = None
+    for p in plans:
+        p.launch(after=prev)
+        prev = p
+    prev.flush()
+    torch.cuda.synchronize()
+    for p, e in zip(plans, eager):
+        assert abs(p.out["loss"].item() - e["loss"].item()) <= 1e-6 * abs(e["loss"].item())
+        assert torch.equal(p.out["grad_actions"], e["grad_actions"])
+    with pytest.raises(ValueError):   # a plan cannot defer onto itself
+        plans[0].launch(after=plans[0])
