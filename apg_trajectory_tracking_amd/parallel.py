@@ -1,0 +1,75 @@
+"""Multi-GPU data parallelism for the APG trainers: one process per GPU,
+trajectories sharded by contiguous batch ranges, policy replicated, ONE
+all-reduce(sum) of the flattened policy gradient (+1 slot for the loss) per
+optimizer step - `backend="nccl"` is RCCL over xGMI on MI355X.
+
+The reference is single-process; because its losses are SUMS over the batch
+(neural_control/drone_loss.py:22-34) a plain sum-reduce reproduces the
+single-device gradient of the concatenated batch exactly (up to fp32
+summation order), with no rescaling.  The message is tiny (32 729 floats =
+131 KB for the quadrotor policy): latency-bound, so everything goes in one
+bucket and one collective.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_range(n, r=None, world=None):
+    """Contiguous [lo, hi) slice of n items owned by rank r (the first
+    n % world ranks get one extra)."""
+    r = rank() if r is None else r
+    world = world_size() if world is None else world
+    base, extra = divmod(n, world)
+    lo = r * base + min(r, extra)
+    return lo, lo + base + (1 if r < extra else 0)
+
+
+class GradAllReducer:
+    """Flat bucket over the parameters that receive gradients.
+
+    sync(loss) packs every `.grad` and the scalar loss into one contiguous
+    fp32 buffer, all-reduces it (sum) and unpacks in place; returns the
+    summed loss.  With world_size == 1 it is a no-op."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self._bucket = None
+
+    def _ensure_bucket(self, like):
+        n = sum(p.numel() for p in self.params) + 1
+        if (self._bucket is None or self._bucket.numel() != n
+                or self._bucket.device != like.device):
+            self._bucket = torch.zeros(n, dtype=torch.float32, device=like.device)
+        return self._bucket
+
+    @torch.no_grad()
+    def sync(self, loss):
+        if world_size() == 1:
+            return loss
+        b = self._ensure_bucket(loss)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                b[off:off + n].zero_()
+            else:
+                b[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        b[off] = loss.detach().reshape(())
+        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is not None:
+                p.grad.copy_(b[off:off + n].view_as(p.grad))
+            off += n
+        return b[off].clone()

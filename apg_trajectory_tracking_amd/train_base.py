@@ -1,0 +1,224 @@
+"""Drop-in for scripts/train_base.py:30-375 (`TrainBase`) restricted to the
+APG hot path: constructor keywords / derived dims (:32-128), init_optimizer
+(:130-150), run_epoch (:188-218), sample_new_data (:220-231), plus a minimal
+run_control loop.  Closed-loop evaluation, curriculum, plots and the
+learnt-dynamics branch are out of scope - `evaluate_model` is a
+hook that subclasses / users may provide.
+
+Differences that matter for speed, not for results:
+  * minibatches come from whole device tensors (dataset.TensorBatches)
+    instead of per-sample DataLoader collate (:132-137);
+  * the running loss is accumulated on the device and read back ONCE per
+    epoch instead of `loss.item()` per batch (:211);
+  * with torch.distributed initialised, every rank trains on its shard and
+    the policy gradient is all-reduced once per step (parallel.GradAllReducer).
+The quirk `epoch_loss = running_loss / i` (i = last batch INDEX, :213) is kept.
+"""
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from .dataset import TensorBatches
+from .parallel import GradAllReducer
+
+
+class TrainBase:
+
+    def __init__(
+        self,
+        train_dynamics,
+        eval_dynamics,
+        sample_in="train_env",
+        delta_t=0.05,
+        delta_t_train=0.05,
+        epoch_size=500,
+        vec_std=0.15,
+        self_play=1.5,
+        self_play_every_x=2,
+        batch_size=8,
+        reset_strength=1.2,
+        max_drone_dist=0.25,
+        max_steps=1000,
+        thresh_div_start=4,
+        thresh_div_end=20,
+        thresh_stable_start=.4,
+        thresh_stable_end=.8,
+        state_size=12,
+        horizon=10,
+        ref_dim=3,
+        action_dim=4,
+        l2_lambda=0.1,
+        learning_rate_controller=0.0001,
+        learning_rate_dynamics=0.001,
+        speed_factor=.6,
+        resample_every=3,
+        suc_up_down=1,
+        train_mode="concurrent",
+        system="quad",
+        save_name="test_model",
+        **kwargs
+    ):
+        self.sample_in = sample_in
+        self.delta_t = delta_t
+        self.delta_t_train = delta_t_train
+        self.epoch_size = epoch_size
+        self.vec_std = vec_std
+        self.self_play = self_play
+        self.self_play_every_x = self_play_every_x
+        self.batch_size = batch_size
+        self.reset_strength = reset_strength
+        self.max_drone_dist = max_drone_dist
+        self.thresh_div_start = thresh_div_start
+        self.thresh_div_end = thresh_div_end
+        self.thresh_stable_start = thresh_stable_start
+        self.thresh_stable_end = thresh_stable_end
+        self.state_size = state_size
+        self.horizon = horizon
+        self.ref_dim = ref_dim
+        self.action_dim = action_dim
+        self.l2_lambda = l2_lambda
+        self.speed_factor = speed_factor
+        self.max_steps = max_steps
+        self.resample_every = resample_every
+        self.suc_up_down = suc_up_down
+        self.learning_rate_controller = learning_rate_controller
+        self.learning_rate_dynamics = learning_rate_dynamics
+        self.train_mode = train_mode
+
+        self.results_dict = defaultdict(list)
+        self.results_dict["loss"].append(0)
+
+        self.save_name = save_name
+        self.save_path = os.path.join("trained_models", system, save_name)
+        self.save_model_name = "model_" + system
+
+        self.eval_dynamics = eval_dynamics
+        self.train_dynamics = train_dynamics
+
+        self.count_finetune_data = 0
+        self.sampled_data_count = 0
+        self.current_score = 0 if suc_up_down == 1 else np.inf
+
+        self.state_data = None
+        self.net = None
+        self.trainloader = None
+        self.optimizer_controller = None
+        self.grad_sync = None
+        self.shuffle = True
+
+        # horizon / reference-window length (scripts/train_base.py:118-128)
+        if self.train_mode in ["autoregressive", "LSTM"]:
+            self.actions_out_dim = self.action_dim
+            self.ref_length = self.horizon * 2
+        elif self.train_mode == "concurrent":
+            self.actions_out_dim = self.action_dim * self.horizon
+            self.ref_length = self.horizon
+        else:
+            raise ValueError(
+                "Train mode must be one of concurrent, autoregressive, or LSTM"
+            )
+
+    # ------------------------------------------------------------ set-up
+    def dataset_tensors(self):
+        """The 4-tuple of whole-dataset tensors a minibatch is cut from
+        (neural_control/dataset.py:125-132)."""
+        d = self.state_data
+        return (d.normed_states, d.states, d.in_ref_states, d.ref_states)
+
+    def init_optimizer(self):
+        """scripts/train_base.py:130-150: shuffled minibatch loader and
+        SGD(lr, momentum 0.9) over the policy."""
+        self.trainloader = TensorBatches(
+            self.dataset_tensors(), self.batch_size, shuffle=self.shuffle)
+        self.optimizer_controller = optim.SGD(
+            self.net.parameters(),
+            lr=self.learning_rate_controller,
+            momentum=0.9
+        )
+        self.grad_sync = GradAllReducer(self.net.parameters())
+
+    def _step(self, loss):
+        """backward -> (all-reduce) -> SGD step; returns the (global) loss."""
+        loss.backward()
+        if self.grad_sync is not None:
+            loss = self.grad_sync.sync(loss.detach())
+        self.optimizer_controller.step()
+        return loss
+
+    # --------------------------------------------------------- hot loop
+    def train_controller_model(
+        self, current_state, action_seq, in_ref_state, ref_states
+    ):
+        raise NotImplementedError("implemented in the system trainers")
+
+    def train_recurrent_model(
+        self, in_state, current_state, in_ref_states, ref_states
+    ):
+        raise NotImplementedError("only the quadrotor trainer is recurrent")
+
+    def run_epoch(self, train="controller", epoch=0):
+        if train != "controller":
+            raise NotImplementedError(
+                "learnt-dynamics training is outside the APG hot path")
+        running_loss = None
+        i = -1
+        for i, data in enumerate(self.trainloader, 0):
+            in_state, current_state, in_ref_state, ref_states = data
+            if self.train_mode != "concurrent":
+                loss = self.train_recurrent_model(
+                    in_state, current_state, in_ref_state, ref_states
+                )
+            else:
+                actions = self.net(in_state, in_ref_state)
+                actions = torch.sigmoid(actions)
+                action_seq = torch.reshape(
+                    actions, (-1, self.horizon, self.action_dim)
+                )
+                loss = self.train_controller_model(
+                    current_state, action_seq, in_ref_state, ref_states
+                )
+            loss = loss.detach()
+            running_loss = loss if running_loss is None else running_loss + loss
+        # one host read-back per epoch; divides by the last index as the
+        # reference does (ZeroDivisionError with a single batch, as there)
+        epoch_loss = float(running_loss.item()) / i
+        self.results_dict["loss"].append(epoch_loss)
+        self.results_dict["trained"].append(train)
+        print(f"Loss ({train}): {round(epoch_loss, 2)}")
+        return epoch_loss
+
+    def sample_new_data(self, epoch):
+        if (epoch + 1) % self.resample_every == 0:
+            self.state_data.resample_data()
+            self.sampled_data_count += self.state_data.num_sampled_states
+
+    # -------------------------------------------------------------- cold
+    def evaluate_model(self, epoch):
+        """Hook: closed-loop evaluation is out of scope here."""
+        return None
+
+    def save_model(self, epoch, success=0.0, suc_std=0.0):
+        os.makedirs(self.save_path, exist_ok=True)
+        torch.save(self.net.state_dict(), os.path.join(
+            self.save_path, self.save_model_name + str(epoch)))
+
+    def finalize(self):
+        os.makedirs(self.save_path, exist_ok=True)
+        torch.save(self.net.state_dict(),
+                   os.path.join(self.save_path, self.save_model_name))
+        np.savetxt(os.path.join(self.save_path, "loss.csv"),
+                   self.results_dict["loss"], delimiter=",")
+
+    def run_control(self, config, sampling_based_finetune=False, curriculum=0):
+        try:
+            for epoch in range(config["nr_epochs"]):
+                self.evaluate_model(epoch)
+                self.sample_new_data(epoch)
+                print(f"\nEpoch {epoch}")
+                self.run_epoch(train="controller", epoch=epoch)
+        except KeyboardInterrupt:
+            pass
+        self.finalize()

@@ -1,0 +1,108 @@
+"""Drop-in for scripts/train_drone.py:27-257 (`TrainDrone`) restricted to the
+APG hot path: `train_controller_model` (:175-203, concurrent k-step unroll)
+and `train_recurrent_model` (:113-173, autoregressive / LSTM unroll).
+
+concurrent : one fused HIP launch does H x dynamics + quad_mpc_loss + the
+             analytic adjoint (functional.quad_rollout_loss) in place of ~600
+             eager ops + autograd.
+recurrent  : the policy runs inside the loop, so each step is
+             state_preprocessing (HIP) -> policy (PyTorch) -> dynamics (HIP),
+             all differentiable; quad_mpc_loss (HIP) closes the graph.
+             Semantics pinned in SURVEY.md §8a A4: the reference window is
+             COPIED before the current position is subtracted (as shipped,
+             the reference writes through a view, which breaks autograd on
+             torch 2.x and subtracts cumulatively).
+"""
+import torch
+
+from . import functional as F
+from .dataset import SyntheticQuadDataset, state_preprocessing
+from .drone_loss import quad_mpc_loss
+from .models.hutter_model import Net
+from .models.rnn import LSTM_NEW
+from .train_base import TrainBase
+
+
+class TrainDrone(TrainBase):
+
+    def __init__(self, train_dynamics, eval_dynamics, config):
+        self.config = config
+        super().__init__(train_dynamics, eval_dynamics, **config)
+        if self.sample_in not in ("eval_env", "train_env", "real_flightmare"):
+            raise ValueError(
+                "sample in must be one of eval_env, train_env, real_flightmare"
+            )
+        self.hidden_generator = None   # seeds LSTM (h0, c0) draws if set
+
+    def initialize_model(self, base_model=None, modified_params={},
+                         state_data=None, device=None, seed=0):
+        """Policy + dataset + optimizer.  `state_data` defaults to the seeded
+        synthetic polynomial set (the reference samples `data/traj_data_1`,
+        which upstream does not ship)."""
+        device = torch.device(device or "cuda")
+        if state_data is None:
+            n = int(self.epoch_size * (1 + self.self_play))
+            state_data = SyntheticQuadDataset(
+                n, self.horizon, self.delta_t, ref_length=self.ref_length,
+                seed=seed, device=device)
+        self.state_data = state_data
+        in_state_size = self.state_data.normed_states.size()[1]
+        if base_model is not None:
+            self.net = base_model
+        else:
+            net_class = LSTM_NEW if self.train_mode == "LSTM" else Net
+            self.net = net_class(
+                in_state_size, self.horizon, self.ref_dim,
+                self.actions_out_dim, conv=1)
+        self.net.to(device)
+        self.config["ref_length"] = self.ref_length
+        self.config["dt"] = self.delta_t
+        self.config["modified_params"] = modified_params
+        self.init_optimizer()
+
+    def train_recurrent_model(
+        self, in_state, current_state, in_ref_states, ref_states
+    ):
+        self.optimizer_controller.zero_grad()
+        batch_size = current_state.size()[0]
+        if self.train_mode == "LSTM":
+            self.net.reset_hidden_state(
+                batch_size, generator=self.hidden_generator)
+        states, actions = [], []
+        for k in range(self.horizon):
+            rel = in_ref_states[:, k:k + self.horizon].clone()
+            rel[:, :, :3] = rel[:, :, :3] - current_state[:, None, :3]
+            in_state = state_preprocessing(current_state)
+            action = torch.sigmoid(self.net(in_state, rel))
+            actions.append(action)
+            current_state = self.train_dynamics(
+                current_state, action, dt=self.delta_t)
+            states.append(current_state)
+        intermediate_states = torch.stack(states, dim=1)
+        action_seq = torch.stack(actions, dim=1)
+        loss = quad_mpc_loss(
+            intermediate_states, ref_states[:, :self.horizon], action_seq)
+        return self._step(loss)
+
+    def train_controller_model(
+        self, current_state, action_seq, in_ref_states, ref_states
+    ):
+        self.optimizer_controller.zero_grad()
+        loss = F.quad_rollout_loss(
+            current_state, action_seq, ref_states, self.delta_t,
+            self.train_dynamics.params)
+        return self._step(loss)
+
+
+def train_control(base_model, config, device=None):
+    """scripts/train_drone.py:241-257."""
+    from .dynamics.quad_dynamics_flightmare import FlightmareDynamics
+    modified_params = config["modified_params"]
+    train_dynamics = FlightmareDynamics(modified_params=modified_params)
+    eval_dynamics = FlightmareDynamics(modified_params=modified_params)
+    config["sample_in"] = "train_env"
+    trainer = TrainDrone(train_dynamics, eval_dynamics, config)
+    trainer.initialize_model(base_model, modified_params=modified_params,
+                             device=device)
+    trainer.run_control(config)
+    return trainer

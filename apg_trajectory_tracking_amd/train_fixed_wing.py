@@ -1,0 +1,54 @@
+"""Drop-in for scripts/train_fixed_wing.py:20-116 (`TrainFixedWing`)
+restricted to the APG hot path: `train_controller_model` (:90-116) as one
+fused HIP launch (H x fixed-wing dynamics at dt = delta_t_train +
+fixed_wing_mpc_loss + analytic adjoint)."""
+import torch
+
+from . import functional as F
+from .dataset import SyntheticWingDataset
+from .models.hutter_model import Net
+from .train_base import TrainBase
+
+
+class TrainFixedWing(TrainBase):
+
+    def __init__(self, train_dynamics, eval_dynamics, config):
+        self.config = config
+        super().__init__(train_dynamics, eval_dynamics, **config)
+        if self.train_mode != "concurrent":
+            raise ValueError(
+                "autoregressive / LSTM training is only implemented "
+                "for the Quadrotor! Use concurrent as train mode"
+            )
+        if self.sample_in not in ("eval_env", "train_env"):
+            raise ValueError("sample in must be one of eval_env, train_env")
+
+    def initialize_model(self, base_model=None, modified_params={},
+                         state_data=None, device=None, seed=0):
+        device = torch.device(device or "cuda")
+        if base_model is not None:
+            self.net = base_model
+        else:
+            # state without position (12 - 3) in, H x 4 actions out (:68-76)
+            self.net = Net(
+                self.state_size - self.ref_dim, 1, self.ref_dim,
+                self.action_dim * self.horizon, conv=False)
+        self.net.to(device)
+        if state_data is None:
+            n = int(self.epoch_size * (1 + self.self_play))
+            state_data = SyntheticWingDataset(
+                n, self.horizon, self.delta_t_train, seed=seed, device=device)
+        self.state_data = state_data
+        self.config["mean"] = self.state_data.mean.tolist()
+        self.config["std"] = self.state_data.std.tolist()
+        self.config["dt"] = self.delta_t
+        self.init_optimizer()
+
+    def train_controller_model(
+        self, current_state, action_seq, in_ref_state, ref_states
+    ):
+        self.optimizer_controller.zero_grad()
+        loss = F.wing_rollout_loss(
+            current_state, action_seq, ref_states, self.delta_t_train,
+            self.train_dynamics.params)
+        return self._step(loss)

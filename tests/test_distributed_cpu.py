@@ -1,0 +1,114 @@
+"""world_size-2 gloo test of the N > 1 path on CPU: batch sharding + ONE
+all-reduce(sum) of the flattened policy gradient (parallel.GradAllReducer)
+inside TrainBase._step reproduces the single-process step on the
+concatenated batch (the reference losses are sums, so no rescaling).
+
+No HIP kernel can run here, so the rollout of the trainer under test is
+replaced by the CPU oracle (test infrastructure) - what is exercised is the
+host logic: sharding, bucket packing, collective, SGD on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, rel_err
+
+H, DT, B = 10, 0.1, 48
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_trainer():
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    from oracle import torch_port as tp
+
+    class OracleBackedTrainDrone(TrainDrone):
+        def train_controller_model(self, current_state, action_seq,
+                                   in_ref_states, ref_states):
+            self.optimizer_controller.zero_grad()
+            inter = tp.unroll(tp.QuadOracle(), current_state, action_seq, DT)
+            loss = tp.quad_mpc_loss(inter, ref_states, action_seq)
+            return self._step(loss)
+
+    cfg = dict(delta_t=DT, horizon=H, batch_size=B, ref_dim=9, action_dim=4,
+               train_mode="concurrent", learning_rate_controller=1e-5,
+               system="quad")
+    trainer = OracleBackedTrainDrone(None, None, cfg)
+    torch.manual_seed(11)
+    trainer.net = Net(15, H, 9, 4 * H, conv=1)
+
+    class Data:
+        pass
+    from apg_trajectory_tracking_amd import synthetic
+    d = synthetic.quad_polynomial_batch(B, H, DT, seed=21)
+    Data.states, Data.ref_states, Data.in_ref_states = (
+        d["state0"], d["ref"], d["in_ref"])
+    Data.normed_states = tp.quad_state_features(d["state0"])
+    trainer.state_data = Data
+    trainer.shuffle = False
+    trainer.init_optimizer()
+    return trainer
+
+
+def _one_step(trainer, lo, hi):
+    d = trainer.state_data
+    acts = torch.sigmoid(trainer.net(d.normed_states[lo:hi],
+                                     d.in_ref_states[lo:hi]))
+    return trainer.train_controller_model(
+        d.states[lo:hi], acts.reshape(-1, H, 4), d.in_ref_states[lo:hi],
+        d.ref_states[lo:hi])
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from apg_trajectory_tracking_amd.parallel import shard_range
+        trainer = _make_trainer()
+        lo, hi = shard_range(B)
+        losses = [float(_one_step(trainer, lo, hi)) for _ in range(2)]
+        sd = {k: v.numpy() for k, v in trainer.net.state_dict().items()}
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"),
+                 losses=np.array(losses), **sd)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_equals_single_process(tmp_path):
+    ref = _make_trainer()
+    ref_losses = [float(_one_step(ref, 0, B)) for _ in range(2)]
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world,
+             join=True)
+    for r in range(world):
+        g = np.load(tmp_path / f"rank{r}.npz")
+        np.testing.assert_allclose(g["losses"], ref_losses, rtol=1e-5)
+        for k, v in ref.net.state_dict().items():
+            assert rel_err(g[k], v.numpy()) < 1e-5, (r, k)
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in ref.net.state_dict():
+        assert np.array_equal(a[k], b[k]), k    # replicas stay bit-identical
+
+
+def test_grad_allreducer_is_noop_single_process():
+    from apg_trajectory_tracking_amd.parallel import GradAllReducer
+    lin = torch.nn.Linear(3, 2)
+    lin(torch.ones(1, 3)).sum().backward()
+    g = lin.weight.grad.clone()
+    loss = torch.tensor(2.5)
+    assert GradAllReducer(lin.parameters()).sync(loss) is loss
+    assert torch.equal(lin.weight.grad, g)

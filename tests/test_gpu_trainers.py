@@ -1,0 +1,216 @@
+"""Trainer-level parity on the GPU: the drop-in TrainDrone / TrainFixedWing /
+TrainCartpole against the golden train steps recorded from the reference
+trainer (tests/golden/make_golden.py G3, G4, G6) and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+QUAD_CFG = dict(
+    delta_t=0.1, delta_t_train=0.1, epoch_size=1000, self_play=1,
+    batch_size=64, state_size=12, horizon=10, train_mode="concurrent",
+    ref_dim=9, action_dim=4, learning_rate_controller=1e-5, system="quad",
+    modified_params={},
+)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda:0")
+
+
+def D(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def load_weights(net, g, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files
+          if k.startswith(prefix)}
+    net.load_state_dict(sd)
+
+
+def make_trainer(cls, dyn, cfg):
+    cfg = dict(cfg)
+    return cls(dyn, dyn, cfg)
+
+
+def test_quad_train_controller_two_sgd_steps(dev):
+    """G3: scripts/train_drone.py:175-203 through run_epoch's body, twice
+    (second step exercises the SGD momentum buffer)."""
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    g = load_golden("quad_train.npz")
+    trainer = make_trainer(TrainDrone, FlightmareDynamics(), QUAD_CFG)
+    net = Net(15, 10, 9, 40, conv=1)
+    load_weights(net, g, "w0.")
+    trainer.net = net.to(dev)
+    trainer.optimizer_controller = torch.optim.SGD(
+        trainer.net.parameters(), lr=float(g["lr"]), momentum=float(g["momentum"]))
+    in_state, in_ref = D(g["in_state"], dev), D(g["in_ref"], dev)
+    state0, ref = D(g["state0"], dev), D(g["ref"], dev)
+    for step in (1, 2):
+        actions = torch.sigmoid(trainer.net(in_state, in_ref))
+        action_seq = torch.reshape(actions, (-1, 10, 4))
+        loss = trainer.train_controller_model(state0, action_seq, in_ref, ref)
+        assert abs(loss.item() - g[f"loss{step}"]) / g[f"loss{step}"] < 1e-5
+        if step == 1:
+            assert rel_err(N(action_seq), g["actions1"]) < 1e-5
+            for k, p in trainer.net.named_parameters():
+                if "g1." + k in g.files:
+                    assert rel_err(N(p.grad), g["g1." + k]) < 1e-4, k
+        for k, v in trainer.net.state_dict().items():
+            assert rel_err(N(v), g[f"w{step}.{k}"]) < 1e-5, (step, k)
+
+
+def test_quad_soa_head_matches_aos_path(dev):
+    """Net.forward_soa + layout='soa' rollout == the AoS trainer path."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    g = load_golden("quad_train.npz")
+    dyn = FlightmareDynamics()
+    net = Net(15, 10, 9, 40, conv=1)
+    load_weights(net, g, "w0.")
+    net.to(dev)
+    in_state, in_ref = D(g["in_state"], dev), D(g["in_ref"], dev)
+    state0, ref = D(g["state0"], dev), D(g["ref"], dev)
+    acts = torch.sigmoid(net.forward_soa(in_state, in_ref)).reshape(10, 4, -1)
+    loss = F.quad_rollout_loss(
+        state0.t().contiguous(), acts, ref.permute(1, 2, 0).contiguous(),
+        0.1, dyn.params, layout="soa")
+    loss.backward()
+    assert abs(loss.item() - g["loss1"]) / g["loss1"] < 1e-5
+    for k, p in net.named_parameters():
+        if "g1." + k in g.files:
+            assert rel_err(N(p.grad), g["g1." + k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("mode", ["ar", "lstm"])
+def test_quad_recurrent_unroll(dev, mode):
+    """G4: autoregressive / LSTM unroll with the pinned window semantics."""
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    g = load_golden("quad_recurrent.npz")
+    cfg = dict(QUAD_CFG, batch_size=32,
+               train_mode="LSTM" if mode == "lstm" else "autoregressive")
+    trainer = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
+    assert trainer.ref_length == 20 and trainer.actions_out_dim == 4
+    net = (LSTM_NEW if mode == "lstm" else Net)(15, 10, 9, 4, conv=1)
+    load_weights(net, g, f"{mode}.w.")
+    trainer.net = net.to(dev)
+    trainer.optimizer_controller = torch.optim.SGD(
+        trainer.net.parameters(), lr=0.0, momentum=0.9)
+    state0, in_ref, ref = (D(g["state0"], dev), D(g["in_ref"], dev),
+                           D(g["ref"], dev))
+    if mode == "lstm":
+        h0, c0 = D(g["lstm_h0"], dev), D(g["lstm_c0"], dev)
+
+        def fixed_reset(batch_size=1, generator=None):
+            net.hidden_state, net.cell_state = h0.clone(), c0.clone()
+        net.reset_hidden_state = fixed_reset
+    in_ref_before = in_ref.clone()
+    loss = trainer.train_recurrent_model(None, state0, in_ref, ref)
+    assert torch.equal(in_ref, in_ref_before)   # the window is copied
+    assert abs(loss.item() - g[f"{mode}.loss"]) / g[f"{mode}.loss"] < 2e-5
+    for k, p in trainer.net.named_parameters():
+        key = f"{mode}.g.{k}"
+        if key in g.files:
+            assert rel_err(N(p.grad), g[key]) < 2e-4, k
+
+
+def test_cartpole_train_step(dev):
+    from apg_trajectory_tracking_amd.dynamics.cartpole_dynamics import (
+        CartpoleDynamics)
+    from apg_trajectory_tracking_amd.models.simple_model import Net
+    from apg_trajectory_tracking_amd.train_cartpole import TrainCartpole
+    g = load_golden("cartpole.npz")
+    cfg = dict(delta_t=float(g["dt"]), batch_size=64, state_size=4, horizon=5,
+               action_dim=1, ref_dim=4, train_mode="concurrent",
+               learning_rate_controller=1e-4, system="cartpole")
+    trainer = TrainCartpole(CartpoleDynamics(), CartpoleDynamics(), cfg)
+    net = Net(4, 5)
+    load_weights(net, g, "w0.")
+
+    class OneBatch:
+        states = D(g["state0"], dev)
+        labels = D(g["state0"], dev)
+        num_sampled_states = 64
+    trainer.initialize_model(base_model=net, state_data=OneBatch, device=dev)
+    trainer.shuffle = False
+    trainer.init_optimizer()
+    # the reference makes the same reference trajectory
+    ref = trainer.make_reference(OneBatch.labels)
+    assert rel_err(N(ref), g["ref"]) < 1e-7
+    with pytest.raises(ZeroDivisionError):   # single batch: running_loss / 0
+        trainer.run_epoch("controller")
+    assert torch.equal(OneBatch.states, OneBatch.labels)  # dataset untouched
+    for k, p in trainer.net.named_parameters():
+        assert rel_err(N(p.grad), g["g1." + k]) < 1e-4, k
+    for k, v in trainer.net.state_dict().items():
+        assert rel_err(N(v), g["w1." + k]) < 1e-5, k
+
+
+def test_wing_train_step_vs_oracle(dev):
+    from apg_trajectory_tracking_amd.dataset import SyntheticWingDataset
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    from apg_trajectory_tracking_amd.train_fixed_wing import TrainFixedWing
+    from oracle import torch_port as tp
+    import copy
+    cfg = dict(delta_t=0.05, delta_t_train=0.05, epoch_size=256, self_play=0,
+               batch_size=256, state_size=12, horizon=20, ref_dim=3,
+               action_dim=4, train_mode="concurrent",
+               learning_rate_controller=1e-6, system="wing")
+    trainer = TrainFixedWing(FixedWingDynamics(), FixedWingDynamics(), cfg)
+    torch.manual_seed(3)
+    trainer.initialize_model(device=dev, seed=7)
+    ref_net = copy.deepcopy(trainer.net).cpu()
+    d = trainer.state_data
+    assert isinstance(d, SyntheticWingDataset) and d.ref_states.shape == (256, 20, 3)
+    actions = torch.sigmoid(trainer.net(d.normed_states, d.in_ref_states))
+    loss = trainer.train_controller_model(
+        d.states, actions.reshape(-1, 20, 4), d.in_ref_states, d.ref_states)
+    # oracle: same step with CPU autograd
+    a = torch.sigmoid(ref_net(d.normed_states.cpu(), d.in_ref_states.cpu()))
+    inter = tp.unroll(tp.WingOracle(), d.states.cpu(), a.reshape(-1, 20, 4), 0.05)
+    ref_loss = tp.fixed_wing_mpc_loss(inter, d.ref_states.cpu(), a.reshape(-1, 20, 4))
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) / ref_loss.item() < 1e-4
+    for (k, p), (_, q) in zip(trainer.net.named_parameters(),
+                              ref_net.named_parameters()):
+        if q.grad is not None:
+            assert rel_err(N(p.grad), q.grad.numpy()) < 2e-4, k
+
+
+@pytest.mark.parametrize("mode", ["concurrent", "autoregressive", "LSTM"])
+def test_quad_run_epoch_learns(dev, mode):
+    """A few epochs of the real run_epoch on the synthetic set: finite losses
+    that go down (sanity of the whole loop incl. loader, SGD, resampling)."""
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    cfg = dict(QUAD_CFG, epoch_size=512, self_play=0, batch_size=128,
+               train_mode=mode, learning_rate_controller=2e-6,
+               resample_every=100)
+    torch.manual_seed(0)
+    trainer = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), cfg)
+    trainer.initialize_model(device=dev, seed=1)
+    trainer.hidden_generator = torch.Generator().manual_seed(5)
+    losses = [trainer.run_epoch("controller", epoch=e) for e in range(4)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0]
+    assert trainer.results_dict["loss"][1:] == losses

