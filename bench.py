@@ -77,33 +77,66 @@ def make_sets(args, rank, dev):
 def cpu_baseline(args):
     """The reference's CPU PyTorch autograd path (restated in
     oracle/torch_port.py, pinned to the reference by tests/golden) timed on
-    this box's host cores on the same workload shape."""
+    this box's host cores on the same workload shape.  The intra-op thread
+    count is chosen by a short sweep (oversubscribing a 128-core host with
+    ~600 tiny eager ops per iteration is several times slower than 16-32
+    threads); the best setting is then timed on a bounded sample."""
     from apg_trajectory_tracking_amd import synthetic
     from oracle import torch_port as tp
-    threads = torch.get_num_threads()
     d = synthetic.quad_polynomial_batch(args.batch, args.horizon, args.dt,
                                         seed=args.seed)
     dyn = tp.QuadOracle()
     run = lambda: tp.rollout_fwd_bwd(dyn, tp.quad_mpc_loss, d["state0"],
                                      d["actions"], d["ref"], args.dt)
-    run()
-    t0 = time.perf_counter()
-    run()
-    one = time.perf_counter() - t0
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    for t in sorted({min(t, ncpu) for t in (8, 16, 32, 64, default_threads)}):
+        torch.set_num_threads(t)
+        run()
+        t0 = time.perf_counter()
+        run()
+        sweep[t] = time.perf_counter() - t0
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    one = sweep[threads]
     iters = max(3, min(50, int(args.cpu_seconds / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(iters):
         run()
     el = time.perf_counter() - t0
+    torch.set_num_threads(default_threads)
+    # second CPU data point: the C oracle (matrix-form restatement with a
+    # hand-written reverse sweep, OpenMP over the batch, all host cores)
+    c_port = None
+    try:
+        from oracle import c_oracle as co
+        s0, a, r = (d["state0"].numpy(), d["actions"].numpy(), d["ref"].numpy())
+        co.quad_rollout_fwd_bwd(s0, a, r, args.dt, want_states=False)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 5 or time.perf_counter() - t0 < 2.0:
+            co.quad_rollout_fwd_bwd(s0, a, r, args.dt, want_states=False)
+            n += 1
+        c_el = time.perf_counter() - t0
+        c_port = {"value": args.batch * args.horizon * n / c_el,
+                  "unit": "env-steps/s", "cores": ncpu,
+                  "what": "oracle/apg_oracle.c fp32, OpenMP, hand adjoint",
+                  "ms_per_iter": c_el / n * 1e3}
+    except Exception as e:  # the C oracle is optional equipment
+        c_port = {"error": repr(e)}
     return {
+        "c_oracle": c_port,
         "value": args.batch * args.horizon * iters / el,
         "unit": "env-steps/s",
         "cores": threads,
         "kind": "port",
         "sample": (f"{iters} iterations of the full B={args.batch} H={args.horizon} "
-                   f"rollout fwd+bwd, PyTorch-eager CPU autograd, anomaly mode off, "
-                   f"{threads} intra-op threads of {os.cpu_count()} logical CPUs"),
+                   f"rollout fwd+bwd, PyTorch-eager CPU autograd (the reference's "
+                   f"op sequence), anomaly mode off, {threads} intra-op threads "
+                   f"(best of sweep {sorted(sweep)}) on {ncpu} logical CPUs"),
         "ms_per_iter": el / iters * 1e3,
+        "thread_sweep_ms": {str(k): v * 1e3 for k, v in sorted(sweep.items())},
     }
 
 
