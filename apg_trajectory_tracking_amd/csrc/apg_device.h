@@ -45,7 +45,8 @@ __device__ __forceinline__ void store_state(float *__restrict__ p, int B, int b,
                                             const float (&v)[S]) {
   if constexpr (LAYOUT == APG_LAYOUT_SOA) {
 #pragma unroll
-    for (int i = 0; i < S; ++i) p[(size_t)i * B + b] = v[i];
+    for (int i = 0; i < S; ++i)
+      __builtin_nontemporal_store(v[i], p + (size_t)i * B + b);
   } else if constexpr (S % 4 == 0) {
     float4 *q = reinterpret_cast<float4 *>(p + (size_t)b * S);
 #pragma unroll
@@ -91,7 +92,7 @@ __device__ __forceinline__ void store_seq(float *__restrict__ p, int B, int H,
   if constexpr (LAYOUT == APG_LAYOUT_SOA) {
     float *q = p + ((size_t)k * C + c0) * B + b;
 #pragma unroll
-    for (int i = 0; i < N; ++i) q[(size_t)i * B] = v[i];
+    for (int i = 0; i < N; ++i) __builtin_nontemporal_store(v[i], q + (size_t)i * B);
   } else {
     float *q = p + ((size_t)b * H + k) * C + c0;
     if (N % 4 == 0 && (C % 4) == 0 && (c0 % 4) == 0) {
@@ -126,9 +127,13 @@ struct SoaPlanes {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, plane * pitch, 0));
   }
+  // outputs are written once and never re-read by this launch: `nt`
+  // (aux bit 1) streams them out during the kernel instead of leaving dirty
+  // L2 lines for the end-of-kernel write-back (tools/hbm_probe.hip: 8.6 ->
+  // 6.9 us per launch for the rollout-shaped stream at B = 65 536)
   __device__ __forceinline__ void st(int plane, float v) const {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc,
-                                          voff, plane * pitch, 0);
+                                          voff, plane * pitch, 2);
   }
 };
 

@@ -168,9 +168,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)
 
     from apg_trajectory_tracking_amd import functional as F

@@ -19,22 +19,22 @@ __global__ __launch_bounds__(256) void copy4(const float4* __restrict__ a, float
   for (; i < n; i += stride) b[i] = a[i];
 }
 
-template <int R, int W>
+template <int R, int W, int LAUX = 0, int SAUX = 0>
 __global__ __launch_bounds__(64) void stream_planes(const float* __restrict__ in, float* __restrict__ out, int B) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, R * B * 4, 0x00020000);
   __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, W * B * 4, 0x00020000);
   float v[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, b * 4, i * B * 4, 0));
+  for (int i = 0; i < R; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, b * 4, i * B * 4, LAUX));
   float acc = 0.f;
 #pragma unroll
   for (int i = 0; i < R; ++i) acc += v[i];
 #pragma unroll
-  for (int i = 0; i < W; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc + (float)i), ro, b * 4, i * B * 4, 0);
+  for (int i = 0; i < W; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc + (float)i), ro, b * 4, i * B * 4, SAUX);
 }
 
-template <int R, int W>
+template <int R, int W, int LAUX = 0, int SAUX = 0>
 void run_stream(int B, int nsets) {
   std::vector<float*> ins(nsets), outs(nsets);
   for (int i = 0; i < nsets; ++i) {
@@ -42,15 +42,15 @@ void run_stream(int B, int nsets) {
     CK(hipMemset(ins[i], 0, (size_t)R * B * 4));
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((stream_planes<R, W>), dim3(B / 64), dim3(64), 0, 0, ins[i % nsets], outs[i % nsets], B);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((stream_planes<R, W, LAUX, SAUX>), dim3(B / 64), dim3(64), 0, 0, ins[i % nsets], outs[i % nsets], B);
   CK(hipDeviceSynchronize());
   const int K = 400;
   CK(hipEventRecord(e0));
-  for (int i = 0; i < K; ++i) hipLaunchKernelGGL((stream_planes<R, W>), dim3(B / 64), dim3(64), 0, 0, ins[i % nsets], outs[i % nsets], B);
+  for (int i = 0; i < K; ++i) hipLaunchKernelGGL((stream_planes<R, W, LAUX, SAUX>), dim3(B / 64), dim3(64), 0, 0, ins[i % nsets], outs[i % nsets], B);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double us = ms * 1e3 / K, bytes = (double)(R + W) * B * 4;
-  printf("stream R=%d W=%d B=%d sets=%d: %.2f us/launch  %.1f GB/s\n", R, W, B, nsets, us, bytes / us / 1e3);
+  printf("stream R=%d W=%d B=%d sets=%d laux=%d saux=%d: %.2f us/launch  %.1f GB/s\n", R, W, B, nsets, LAUX, SAUX, us, bytes / us / 1e3);
   for (int i = 0; i < nsets; ++i) { CK(hipFree(ins[i])); CK(hipFree(outs[i])); }
 }
 
@@ -72,6 +72,14 @@ int main() {
   run_stream<112, 40>(65536, 1);
   run_stream<112, 40>(131072, 8);
   run_stream<112, 40>(524288, 8);
+  // cache-policy variants (aux: 1 = sc0, 2 = nt, 16 = sc1)
+  run_stream<112, 40, 0, 2>(65536, 8);
+  run_stream<112, 40, 0, 16>(65536, 8);
+  run_stream<112, 40, 0, 17>(65536, 8);
+  run_stream<112, 40, 2, 0>(65536, 8);
+  run_stream<112, 40, 2, 2>(65536, 8);
+  run_stream<112, 40, 2, 16>(65536, 8);
+  run_stream<112, 40, 16, 16>(65536, 8);
   run_stream<64, 40>(65536, 8);
   run_stream<16, 8>(65536, 8);
   run_stream<1, 1>(65536, 8);
