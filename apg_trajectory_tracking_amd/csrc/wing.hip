@@ -11,6 +11,8 @@
 // Quirks kept on purpose: all three moments scale with the chord c
 // (:170-175), gravity is rotated with psi = 0 (:195-197), alpha and beta are
 // clamped to +-10 deg so their gradient vanishes outside (:132-134).
+#include <stdlib.h>
+
 #include "apg_device.h"
 
 namespace apg {
@@ -64,13 +66,13 @@ constexpr float kPi = 3.14159265358979323846f;
 // Everything the adjoint re-uses from the forward evaluation of one step.
 struct WingAux {
   float T, de, da, dr;
-  float V, V2, r2V, tw, tb;      // tw = w/u, tb = v/V
+  float V, V2, iV, r2V, tw, tb;  // iV = 1/V, tw = w/u, tb = v/V
   float alpha, beta;
   bool alpha_free, beta_free;    // clamp passes the gradient
   float sa, ca, sb, cb;
   float CL, CD, CY, Cl, Cm, Cn, Q;
   float L, D, Y;
-  float sph, cph, sth, cth, sps, cps;
+  float sph, cph, sth, cth, sps, cps, icth;
   float R[3][3];                 // rows as assembled at :80-91
   float h0, h1, h2;              // I * omega
 };
@@ -89,15 +91,16 @@ __device__ __forceinline__ void wing_rates(const float (&s)[12],
   x.dr = kPi * (a[3] * 40.f - 20.f) / 180.f;
   // :130-134
   x.V2 = u * u + v * v + w * w;
-  x.V = sqrtf(x.V2);
-  x.tw = w / u;
-  x.tb = v / x.V;
+  x.V = __builtin_amdgcn_sqrtf(x.V2);
+  x.iV = rcp_nr(x.V);
+  x.tw = w * rcp_nr(u);
+  x.tb = v * x.iV;
   const float al = atanf(x.tw), be = atanf(x.tb);
   x.alpha_free = (al >= -k.alpha_bound) && (al <= k.alpha_bound);
   x.beta_free = (be >= -k.alpha_bound) && (be <= k.alpha_bound);
   x.alpha = fminf(fmaxf(al, -k.alpha_bound), k.alpha_bound);
   x.beta = fminf(fmaxf(be, -k.alpha_bound), k.alpha_bound);
-  x.r2V = 1.f / (2.f * x.V);
+  x.r2V = 0.5f * x.iV;
   // :139-164
   x.CL = k.CL0 + k.CL_a * x.alpha + k.CL_qc * x.r2V * q + k.CL_de * x.de;
   x.CD = k.CD0 + k.CD_a * x.alpha + k.CD_qc * x.r2V * q + k.CD_de * x.de;
@@ -113,11 +116,12 @@ __device__ __forceinline__ void wing_rates(const float (&s)[12],
   x.L = x.Q * x.CL, x.D = x.Q * x.CD, x.Y = x.Q * x.CY;
   const float l = x.Q * k.c * x.Cl, m = x.Q * k.c * x.Cm, n = x.Q * k.c * x.Cn;
   // :185-204 body forces
-  sincosf(x.alpha, &x.sa, &x.ca);
-  sincosf(x.beta, &x.sb, &x.cb);
-  sincosf(s[6], &x.sph, &x.cph);
-  sincosf(s[7], &x.sth, &x.cth);
-  sincosf(s[8], &x.sps, &x.cps);
+  sincos_fast(x.alpha, &x.sa, &x.ca);
+  sincos_fast(x.beta, &x.sb, &x.cb);
+  sincos_fast(s[6], &x.sph, &x.cph);
+  sincos_fast(s[7], &x.sth, &x.cth);
+  sincos_fast(s[8], &x.sps, &x.cps);
+  x.icth = rcp_nr(x.cth);
   const float f0 = -x.ca * x.cb * x.D - x.ca * x.sb * x.Y + x.sa * x.L -
                    k.g_m * x.sth + x.T * k.cos_eps;
   const float f1 = -x.sb * x.D + x.cb * x.Y + k.g_m * x.sph * x.cth;
@@ -139,10 +143,10 @@ __device__ __forceinline__ void wing_rates(const float (&s)[12],
   sd[4] = k.inv_mass * f1 - (r * u - p * w);
   sd[5] = k.inv_mass * f2 - (p * v - q * u);
   // :225-245
-  const float tth = x.sth / x.cth;
+  const float tth = x.sth * x.icth;
   sd[6] = p + x.sph * tth * q + x.cph * tth * r;
   sd[7] = x.cph * q - x.sph * r;
-  sd[8] = (x.sph * q + x.cph * r) / x.cth;
+  sd[8] = (x.sph * q + x.cph * r) * x.icth;
   // :250-255
   x.h0 = k.Ixx * p + k.a13 * r, x.h1 = k.Iyy * q, x.h2 = k.a13 * p + k.Izz * r;
   const float r0 = l - (q * x.h2 - r * x.h1);
@@ -194,7 +198,7 @@ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
   }
   // euler rates
   {
-    const float icth = 1.f / x.cth, tth = x.sth * icth;
+    const float icth = x.icth, tth = x.sth * icth;
     const float sq_cr = x.sph * q + x.cph * r;   // sin(phi) q + cos(phi) r
     const float cq_sr = x.cph * q - x.sph * r;
     dp += g[6];
@@ -266,17 +270,17 @@ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
   const float g_dr = k.CY_dr * gCY + k.Cl_dr * gCl + k.Cn_dr * gCn;
   dq += g_qt * x.r2V, dp += g_pt * x.r2V, dr += g_rt * x.r2V;
   const float g_r2V = g_qt * q + g_pt * p + g_rt * r;
-  const float iV = 1.f / x.V;
+  const float iV = x.iV;
   float gV = -g_r2V * x.r2V * iV;
   // alpha = clamp(atan(w/u)), beta = clamp(atan(v/V))
   if (x.alpha_free) {
-    const float gt = g_al / (1.f + x.tw * x.tw);
-    const float iu = 1.f / u;
+    const float gt = g_al * rcp_nr(1.f + x.tw * x.tw);
+    const float iu = rcp_nr(u);
     dw += gt * iu;
     du -= gt * x.tw * iu;
   }
   if (x.beta_free) {
-    const float gt = g_be / (1.f + x.tb * x.tb);
+    const float gt = g_be * rcp_nr(1.f + x.tb * x.tb);
     dv += gt * iV;
     gV -= gt * x.tb * iV;
   }
@@ -330,12 +334,19 @@ struct WingRolloutArgs {
   WingConst k;
   ApgWingLossWeights w;
   ApgDeferredLoss prev;
-  int B, H;
+  int B, H, stride;
 };
 
-// Run-time horizon.  Per-step stash in LDS as [k][12][lane]: the pre-step
-// velocity/attitude/rates (9) and the position-loss seed (3).  The aux of a
-// step is recomputed from the stash in the reverse sweep.
+// Run-time horizon, checkpointed.  The reverse sweep needs the pre-step state
+// of every step; stashing all of them ([H][12][lane] in LDS, 61 KB per wave
+// at H = 20) leaves room for only two waves per CU, i.e. half the SIMDs idle
+// on VALU-bound work.  Instead only every `stride`-th pre-step state is kept
+// ([ceil(H/stride)][12][lane]); the reverse sweep walks the horizon group by
+// group, re-integrating the (stride-1) missing states of a group from its
+// checkpoint into registers.  Costs (stride-1)/stride extra state_dot
+// evaluations, buys 3-5x the resident waves.
+constexpr int kWingMaxStride = 4;
+
 template <int LAYOUT>
 __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
     WingRolloutArgs A) {
@@ -345,21 +356,25 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
   const bool live = b < A.B;
   const int bb = live ? b : A.B - 1;
   const WingConst k = A.k;
-  const int H = A.H;
-  auto ST = [&](int kk, int i) -> float & {
-    return stash[(kk * 12 + i) * APG_ROLLOUT_BLOCK + lane];
+  const int H = A.H, S = A.stride;
+  auto ST = [&](int slot, int i) -> float & {
+    return stash[(slot * 12 + i) * APG_ROLLOUT_BLOCK + lane];
   };
   float s[12];
   load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
   if (blockIdx.x == 0 && threadIdx.x < kWave && A.prev.prev_partials)
     reduce_prev_partials(A.prev);
   float loss = 0.f;
-  for (int kk = 0; kk < H; ++kk) {
+  for (int kk = 0, slot = 0, phase = 0; kk < H; ++kk) {
     float a[4], rp[3];
     load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kk, 0, a);
     load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kk, 0, rp);
+    if (phase == 0) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) ST(kk, i) = s[3 + i];
+      for (int i = 0; i < 12; ++i) ST(slot, i) = s[i];
+      ++slot;
+    }
+    if (++phase == S) phase = 0;
     wing_step(s, a, k);
     if (A.states_out && live)
       store_seq<LAYOUT, 12>(A.states_out, A.B, H, 12, b, kk, 0, s);
@@ -368,7 +383,6 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
     for (int i = 0; i < 3; ++i) {
       float dp = s[i] - rp[i], d = a[1 + i] - 0.5f;
       lp += dp * dp, la += d * d;
-      ST(kk, 9 + i) = 2.f * A.w.pos * dp;
     }
     loss += A.w.pos * lp + A.w.action * la;
   }
@@ -377,21 +391,50 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
   float lam[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
-  for (int kk = H - 1; kk >= 0; --kk) {
-    float a[4], pre[12], sd[12];
-    load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kk, 0, a);
-    pre[0] = pre[1] = pre[2] = 0.f;  // the dynamics do not depend on position
+  float nxt[3] = {s[0], s[1], s[2]};  // position after the group's last step
+  const int G = (H + S - 1) / S;
+  for (int g = G - 1; g >= 0; --g) {
+    const int k0 = g * S;
+    const int n = (H - k0) < S ? (H - k0) : S;
+    float pre[kWingMaxStride + 1][12], act[kWingMaxStride][4];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) pre[3 + i] = ST(kk, i);
+    for (int i = 0; i < 12; ++i) pre[0][i] = ST(g, i);
+    // re-integrate the states inside the group
 #pragma unroll
-    for (int i = 0; i < 3; ++i) lam[i] += ST(kk, 9 + i);
-    float ga[4] = {0.f, 2.f * A.w.action * (a[1] - 0.5f),
-                   2.f * A.w.action * (a[2] - 0.5f),
-                   2.f * A.w.action * (a[3] - 0.5f)};
-    WingAux x;
-    wing_rates(pre, a, k, x, sd);
-    wing_step_adjoint(lam, ga, pre, x, k);
-    if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, H, 4, b, kk, 0, ga);
+    for (int j = 0; j < kWingMaxStride; ++j) {
+      if (j < n) {
+        load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, k0 + j, 0, act[j]);
+        if (j + 1 < kWingMaxStride && j + 1 < n) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) pre[j + 1][i] = pre[j][i];
+          wing_step(pre[j + 1], act[j], k);
+        }
+      }
+    }
+    // adjoint of the group's steps, last first
+#pragma unroll
+    for (int j = kWingMaxStride - 1; j >= 0; --j) {
+      if (j < n) {
+        const int kk = k0 + j;
+        float rp[3], pn[3] = {nxt[0], nxt[1], nxt[2]}, sd[12];
+        load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kk, 0, rp);
+        if (j + 1 < kWingMaxStride && j + 1 < n) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) pn[i] = pre[j + 1][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) lam[i] += 2.f * A.w.pos * (pn[i] - rp[i]);
+        float ga[4] = {0.f, 2.f * A.w.action * (act[j][1] - 0.5f),
+                       2.f * A.w.action * (act[j][2] - 0.5f),
+                       2.f * A.w.action * (act[j][3] - 0.5f)};
+        WingAux x;
+        wing_rates(pre[j], act[j], k, x, sd);
+        wing_step_adjoint(lam, ga, pre[j], x, k);
+        if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, H, 4, b, kk, 0, ga);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nxt[i] = pre[0][i];
   }
   if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
 }
@@ -513,7 +556,15 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
   A.w = *weights;
   A.prev = has_prev ? *deferred : ApgDeferredLoss{nullptr, 0, nullptr};
   A.B = B, A.H = H;
-  const size_t lds = (size_t)H * 12 * APG_ROLLOUT_BLOCK * sizeof(float);
+  // checkpoint stride: keep the stash of a wave <= 6 slots (18 KB) so that
+  // >= 8 waves fit a CU's 160 KB of LDS (APG_WING_STRIDE overrides, 1..4)
+  int stride = (H + 5) / 6;
+  if (const char *e = getenv("APG_WING_STRIDE")) stride = atoi(e);
+  if (stride < 1) stride = 1;
+  if (stride > kWingMaxStride) stride = kWingMaxStride;
+  A.stride = stride;
+  const size_t lds = (size_t)((H + stride - 1) / stride) * 12 *
+                     APG_ROLLOUT_BLOCK * sizeof(float);
   const dim3 grid(grid_for(B, APG_ROLLOUT_BLOCK)), block(APG_ROLLOUT_BLOCK);
   if (layout == APG_LAYOUT_SOA) {
     if (lds > 64 * 1024 &&
