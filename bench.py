@@ -50,6 +50,9 @@ def parse():
                     help="how each step's scalar loss is materialised "
                          "(DESIGN.md: deferred = folded into the next launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=20,
+                    help="steps of the secondary full-training-step "
+                         "measurement (0 disables it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -137,6 +140,61 @@ def cpu_baseline(args):
                    f"(best of sweep {sorted(sweep)}) on {ncpu} logical CPUs"),
         "ms_per_iter": el / iters * 1e3,
         "thread_sweep_ms": {str(k): v * 1e3 for k, v in sorted(sweep.items())},
+    }
+
+
+def train_step_probe(args, dev, dyn, dist):
+    """Secondary, informational: a FULL concurrent-mode training step per rank
+    (policy forward with the SoA head, fused rollout, policy backward, ONE
+    RCCL all-reduce of the flattened gradient + loss when world > 1, SGD) -
+    reported next to, never instead of, the dynamics-only metric."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.parallel import GradAllReducer
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    H, B = args.horizon, args.batch
+    rank = dist.get_rank() if dist is not None else 0
+    torch.manual_seed(1234)                     # identical replicas
+    net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-9, momentum=0.9)
+    sync = GradAllReducer(net.parameters())
+    d = synthetic.quad_polynomial_batch(B, H, args.dt, seed=args.seed + rank)
+    state0 = d["state0"].to(dev)
+    in_ref = d["in_ref"].to(dev)
+    with torch.no_grad():
+        in_state = state_preprocessing(state0)
+    s0_soa = synthetic.to_soa_state(d["state0"]).to(dev)
+    ref_soa = synthetic.to_soa_seq(d["ref"]).to(dev)
+
+    def step():
+        opt.zero_grad()
+        acts = torch.sigmoid(net.forward_soa(in_state, in_ref)).reshape(H, 4, -1)
+        loss = F.quad_rollout_loss(s0_soa, acts, ref_soa, args.dt, dyn.params,
+                                   layout="soa")
+        loss.backward()
+        total = sync.sync(loss.detach())
+        opt.step()
+        return total
+    for _ in range(3):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        total = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    world = dist.get_world_size() if dist is not None else 1
+    return {
+        "ms_per_step": el / args.train_steps * 1e3,
+        "env_steps_per_s": world * B * H * args.train_steps / el,
+        "allreduce_floats": sum(p.numel() for p in net.parameters()) + 1,
+        "global_loss": float(total.item()),
+        "what": "policy fwd (PyTorch-ROCm, SoA head) + fused rollout + policy "
+                "bwd + RCCL all-reduce(sum) + SGD, per rank batch %d" % B,
     }
 
 
@@ -279,6 +337,11 @@ def main():
         },
         "loss_check": loss_check,
     }
+    if args.train_steps > 0:
+        try:
+            out["train_step"] = train_step_probe(args, dev, dyn, dist)
+        except Exception as e:      # informational only
+            out["train_step"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     elif rank == 0:
