@@ -334,6 +334,144 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
   if (reducer) reduce_prev_tail(A.prev, pp);
 }
 
+// Reference (AoS, row-major) tensors, compile-time horizon.  A wave owns 64
+// consecutive trajectories, i.e. ONE contiguous slab of each tensor
+// (state0 3 KB, actions 16H*64 B, ref 4*RC*H*64 B).  The slabs are pulled
+// into LDS with direct-to-LDS buffer loads (`buffer_load_dwordx4 ... lds`,
+// 1 KB per wave instruction, fully coalesced, no VGPR staging); every lane
+// then reads ITS row from LDS (row strides 48 / 160 / 360 B: at most 2-way
+// bank conflicts).  dL/dactions rows are written back into the action slab
+// and leave through the same coalesced 16-byte-per-lane pattern.  Compared
+// with per-lane row loads straight from HBM this turns 64 partial cache
+// lines per wave instruction into one full KB, and frees the ~100 VGPRs the
+// SoA kernel spends on in-flight inputs.
+template <int HT, int RC, bool STATES_OUT>
+__global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_aos_kernel(
+    RolloutArgs A) {
+  constexpr int kS0 = 64 * 12, kAct = 64 * 4 * HT;
+  constexpr int kRefChunks = (64 * RC * HT * 4 + 1023) / 1024;
+  constexpr int kVel = RC == 9 ? 6 : 3;
+  __shared__ __attribute__((aligned(16))) float l_s0[kS0];
+  __shared__ __attribute__((aligned(16))) float l_act[kAct];
+  __shared__ __attribute__((aligned(16))) float l_ref[kRefChunks * 256];
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < A.B;
+  const QuadConst c = A.c;
+
+  const bool reducer = blockIdx.x == 0 && A.prev.prev_partials != nullptr;
+  PrevPartials pp;
+  if (reducer) reduce_prev_head(A.prev, pp);
+
+  // slabs -> LDS (out-of-range rows of the last workgroup read as zero)
+  const auto r_s0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(A.state0), 0, A.B * 12 * 4, 0x00020000);
+  const auto r_act = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(A.actions), 0, A.B * HT * 4 * 4, 0x00020000);
+  const auto r_ref = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(A.ref), 0, A.B * HT * RC * 4, 0x00020000);
+  const auto r_ga = __builtin_amdgcn_make_buffer_rsrc(
+      A.grad_actions, 0, A.B * HT * 4 * 4, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        r_s0, (lds_ptr)(l_s0 + i * 256), 16, lane * 16,
+        blockIdx.x * (kS0 * 4) + i * 1024, 0, 0);
+#pragma unroll
+  for (int i = 0; i < HT; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        r_act, (lds_ptr)(l_act + i * 256), 16, lane * 16,
+        blockIdx.x * (kAct * 4) + i * 1024, 0, 0);
+#pragma unroll
+  for (int i = 0; i < kRefChunks; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        r_ref, (lds_ptr)(l_ref + i * 256), 16, lane * 16,
+        blockIdx.x * (64 * RC * HT * 4) + i * 1024, 0, 0);
+  // state0 + actions have landed once only the reference chunks are pending
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRefChunks) : "memory");
+
+  float s[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 v = *reinterpret_cast<const float4 *>(&l_s0[lane * 12 + 4 * i]);
+    s[4 * i] = v.x, s[4 * i + 1] = v.y, s[4 * i + 2] = v.z, s[4 * i + 3] = v.w;
+  }
+  Trig st_trig[HT];
+  float st_w[HT + 1][3];
+  float st_pv[HT][6];
+#pragma unroll
+  for (int k = 0; k < HT; ++k) {
+    const float4 a4 =
+        *reinterpret_cast<const float4 *>(&l_act[lane * 4 * HT + 4 * k]);
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st_w[k][i] = s[9 + i];
+    st_trig[k] = make_trig(&s[3]);
+    quad_step(s, a, c, st_trig[k]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st_pv[k][i] = s[i], st_pv[k][3 + i] = s[6 + i];
+    if constexpr (STATES_OUT)
+      if (live)
+        store_seq<APG_LAYOUT_AOS, 12>(A.states_out, A.B, HT, 12, b, k, 0, s);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) st_w[HT][i] = s[9 + i];
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // reference slab landed
+
+  float loss = 0.f;
+  float lam[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = 0.f;
+#pragma unroll
+  for (int k = HT - 1; k >= 0; --k) {
+    const float *rrow = &l_ref[lane * RC * HT + k * RC];
+    float4 a4 = *reinterpret_cast<const float4 *>(&l_act[lane * 4 * HT + 4 * k]);
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float dp = st_pv[k][i] - rrow[i];
+      const float dv = st_pv[k][3 + i] - rrow[kVel + i];
+      const float wn = st_w[k + 1][i];
+      lp += dp * dp, lv += dv * dv, lw += wn * wn;
+      lam[i] += 2.f * A.w.pos * dp;
+      lam[6 + i] += 2.f * A.w.vel * dv;
+      lam[9 + i] += 2.f * A.w.av * wn;
+    }
+    const float a0 = act[0], da0 = a0 - 0.5f;
+    float ga[4];
+    ga[0] = 2.f * A.w.thrust * da0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      const float d = act[i] - 0.5f;
+      lr += d * d;
+      ga[i] = 2.f * A.w.rates * d;
+    }
+    loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
+            A.w.thrust * da0 * da0;
+    quad_step_adjoint(lam, ga, a0, st_w[k], c, st_trig[k]);
+    *reinterpret_cast<float4 *>(&l_act[lane * 4 * HT + 4 * k]) =
+        make_float4(ga[0], ga[1], ga[2], ga[3]);
+  }
+  // dL/dactions slab: LDS -> HBM, 1 KB per wave instruction, streaming
+  // stores; rows past B fall outside the buffer and are dropped
+#pragma unroll
+  for (int i = 0; i < HT; ++i) {
+    const float4 v = *reinterpret_cast<const float4 *>(&l_act[i * 256 + lane * 4]);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(
+        __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned,
+                           (v4f){v.x, v.y, v.z, v.w}),
+        r_ga, lane * 16, blockIdx.x * (kAct * 4) + i * 1024, 2);
+  }
+  if (A.grad_state0 && live)
+    store_state<APG_LAYOUT_AOS, 12>(A.grad_state0, A.B, b, lam);
+  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+  if (reducer) reduce_prev_tail(A.prev, pp);
+}
+
 // Run-time horizon: same sweeps, the per-step stash (att, w, seeds: 12 floats)
 // is staged in LDS as [k][12][lane] (conflict-free: lane == bank).
 template <int LAYOUT, bool STATES_OUT>
@@ -569,6 +707,20 @@ int launch_rollout(const RolloutArgs &A, hipStream_t st) {
   const dim3 grid(grid_for(A.B, APG_ROLLOUT_BLOCK)), block(APG_ROLLOUT_BLOCK);
   // buffer addressing needs every tensor below 2 GiB (32-bit byte offsets)
   const bool buf_ok = (long long)A.H * 12 * A.B * 4 < (1ll << 31);
+  if constexpr (LAYOUT == APG_LAYOUT_AOS) {
+    // slab path: every tensor below 2 GiB and a register-resident horizon
+    if (buf_ok && (A.H == 5 || A.H == 10)) {
+#define APG_AOS(HT, RC)                                                       \
+  hipLaunchKernelGGL((quad_rollout_aos_kernel<HT, RC, SO>), grid, block, 0,  \
+                     st, A)
+      if (A.H == 10 && A.ref_cols == 9) APG_AOS(10, 9);
+      else if (A.H == 10) APG_AOS(10, 6);
+      else if (A.ref_cols == 9) APG_AOS(5, 9);
+      else APG_AOS(5, 6);
+#undef APG_AOS
+      return check_launch("quad_rollout_fwd_bwd");
+    }
+  }
   switch (A.H) {
 #define APG_CASE(HT)                                                          \
   case HT:                                                                    \
