@@ -12,6 +12,12 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libapg_hip.so")
 SOURCES = ["common.hip", "quad.hip", "wing.hip", "cartpole.hip"]
+# -fno-slp-vectorize: hipcc's SLP pass packs neighbouring f32 ops into
+# v_pk_fma/mul/add_f32; on gfx950 a packed op issues no faster than two plain
+# ones here and needs v_mov shuffles to form register pairs - measured on
+# MI355X: quad rollout 9.7 -> 9.0 us, wing rollout 126 -> 94 us
+COMMON_FLAGS = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {}
 HEADERS = [os.path.join(CSRC, "apg_device.h"),
            os.path.join(REPO, "include", "apg.h")]
 
@@ -37,6 +43,8 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+               *COMMON_FLAGS, *EXTRA_FLAGS.get(s, []),
+               *os.environ.get("APG_HIPCC_FLAGS", "").split(),
                "-I", os.path.join(REPO, "include"), "-I", CSRC, "-c", src,
                "-o", obj]
         if verbose:

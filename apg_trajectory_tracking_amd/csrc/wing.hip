@@ -11,6 +11,7 @@
 // Quirks kept on purpose: all three moments scale with the chord c
 // (:170-175), gravity is rotated with psi = 0 (:195-197), alpha and beta are
 // clamped to +-10 deg so their gradient vanishes outside (:132-134).
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "apg_device.h"
@@ -78,10 +79,11 @@ struct WingAux {
 };
 
 // Evaluates state_dot (12) and fills aux.
+// (KT = const WingConst, possibly qualified with the constant address space)
+template <typename KT>
 __device__ __forceinline__ void wing_rates(const float (&s)[12],
-                                           const float (&a)[4],
-                                           const WingConst &k, WingAux &x,
-                                           float (&sd)[12]) {
+                                           const float (&a)[4], KT &k,
+                                           WingAux &x, float (&sd)[12]) {
   const float u = s[3], v = s[4], w = s[5];
   const float p = s[9], q = s[10], r = s[11];
   // normalize_action :41-46
@@ -157,8 +159,9 @@ __device__ __forceinline__ void wing_rates(const float (&s)[12],
   sd[11] = k.i02 * r0 + k.i22 * r2;
 }
 
+template <typename KT>
 __device__ __forceinline__ void wing_step(float (&s)[12], const float (&a)[4],
-                                          const WingConst &k) {
+                                          KT &k) {
   WingAux x;
   float sd[12];
   wing_rates(s, a, k, x, sd);
@@ -168,11 +171,11 @@ __device__ __forceinline__ void wing_step(float (&s)[12], const float (&a)[4],
 
 // lam: dL/dnext on entry -> dL/dstate on exit; ga += dL/daction.
 // `s`, `a` are the PRE-step state and the action; x the matching aux.
+template <typename KT>
 __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
                                                   float (&ga)[4],
                                                   const float (&s)[12],
-                                                  const WingAux &x,
-                                                  const WingConst &k) {
+                                                  const WingAux &x, KT &k) {
   const float u = s[3], v = s[4], w = s[5];
   const float p = s[9], q = s[10], r = s[11];
   float g[12];  // cotangent of state_dot
@@ -355,7 +358,17 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = b < A.B;
   const int bb = live ? b : A.B - 1;
-  const WingConst k = A.k;
+  // The ~70 coefficients do not fit the SGPR file next to everything else:
+  // kept live for the whole kernel they are spilled to VGPR lanes
+  // (v_writelane / v_readlane, ~10 % of the issued instructions).  Reading
+  // them from the kernel-argument segment where they are used (scalar loads,
+  // scalar-cache hits) is cheaper; `launder` stops the compiler from hoisting
+  // those loads back out of the step loops.
+  typedef __attribute__((address_space(4))) const WingConst *const_ptr;
+  typedef __attribute__((address_space(4))) const char *const_bytes;
+  const_ptr kp = (const_ptr)((const_bytes)__builtin_amdgcn_kernarg_segment_ptr() +
+                             offsetof(WingRolloutArgs, k));
+#define APG_LAUNDER(p) asm volatile("" : "+s"(p))
   const int H = A.H, S = A.stride;
   auto ST = [&](int slot, int i) -> float & {
     return stash[(slot * 12 + i) * APG_ROLLOUT_BLOCK + lane];
@@ -375,7 +388,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
       ++slot;
     }
     if (++phase == S) phase = 0;
-    wing_step(s, a, k);
+    APG_LAUNDER(kp);
+    wing_step(s, a, *kp);
     if (A.states_out && live)
       store_seq<LAYOUT, 12>(A.states_out, A.B, H, 12, b, kk, 0, s);
     float lp = 0.f, la = 0.f;
@@ -407,7 +421,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
         if (j + 1 < kWingMaxStride && j + 1 < n) {
 #pragma unroll
           for (int i = 0; i < 12; ++i) pre[j + 1][i] = pre[j][i];
-          wing_step(pre[j + 1], act[j], k);
+          APG_LAUNDER(kp);
+          wing_step(pre[j + 1], act[j], *kp);
         }
       }
     }
@@ -428,8 +443,9 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
                        2.f * A.w.action * (act[j][2] - 0.5f),
                        2.f * A.w.action * (act[j][3] - 0.5f)};
         WingAux x;
-        wing_rates(pre[j], act[j], k, x, sd);
-        wing_step_adjoint(lam, ga, pre[j], x, k);
+        APG_LAUNDER(kp);
+        wing_rates(pre[j], act[j], *kp, x, sd);
+        wing_step_adjoint(lam, ga, pre[j], x, *kp);
         if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, H, 4, b, kk, 0, ga);
       }
     }
@@ -437,6 +453,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
     for (int i = 0; i < 3; ++i) nxt[i] = pre[0][i];
   }
   if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
+#undef APG_LAUNDER
 }
 
 template <int LAYOUT>
