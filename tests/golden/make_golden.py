@@ -16,6 +16,7 @@ Fixtures:
   cartpole.npz       G6  CartpoleDynamics step + rollout + grads
   features.npz       G7  state_preprocessing + VJP
   losses.npz         G8  the three MPC losses + grads on random inputs
+  checkpoints.npz    G9  state_dicts of the shipped controllers + outputs
 """
 import os
 import sys
@@ -511,3 +512,36 @@ if __name__ == "__main__":
     g6_cartpole()
     g7_features()
     g8_losses()
+    g9_checkpoints()
+
+
+# --------------------------------------------------------------------- G9
+def g9_checkpoints():
+    """N4: the controllers the reference ships are whole-module
+    pickles (`torch.save(net)`, scripts/train_base.py:233-259).  Record their
+    state_dicts (data) + the reference module's output on a fixed input, so
+    that the package's model classes can be checked to load and reproduce
+    them.  Written to tests/golden/checkpoints.npz."""
+    out = {}
+    specs = {
+        "quad": ("model_quad", lambda g: (torch.randn(16, 15, generator=g),
+                                          torch.randn(16, 10, 9, generator=g))),
+        "wing": ("model_wing", lambda g: (torch.randn(16, 9, generator=g),
+                                          torch.randn(16, 3, generator=g))),
+        "cartpole": ("model_cartpole", lambda g: (torch.randn(16, 4, generator=g),)),
+    }
+    for system, (fname, make_in) in specs.items():
+        path = os.path.join(REF, "trained_models", system, "current_model", fname)
+        net = torch.load(path, weights_only=False)
+        net.eval()
+        for k, v in net.state_dict().items():
+            out[f"{system}.w.{k}"] = npy(v)
+        g = torch.Generator().manual_seed(77)
+        inputs = make_in(g)
+        for i, x in enumerate(inputs):
+            out[f"{system}.in{i}"] = npy(x)
+        with torch.no_grad():
+            y = net(*[x.clone() for x in inputs])
+        out[f"{system}.out"] = npy(y)
+        out[f"{system}.class"] = np.array(type(net).__module__ + "." + type(net).__name__)
+    save("checkpoints.npz", **out)

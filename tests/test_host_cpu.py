@@ -183,3 +183,28 @@ def test_shard_range_partitions():
         assert all(got[i][1] == got[i + 1][0] for i in range(w - 1))
         sizes = [hi - lo for lo, hi in got]
         assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("system", ["quad", "wing", "cartpole"])
+def test_shipped_reference_controllers_load_and_reproduce(system):
+    """N4: the state_dicts of the controllers the reference ships
+    (trained_models/*/current_model, recorded by make_golden.py G9) load into
+    the package's model classes and give the reference module's outputs."""
+    from apg_trajectory_tracking_amd.checkpoint import build_policy
+    g = load_golden("checkpoints.npz")
+    pre = f"{system}.w."
+    sd = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+    net = build_policy(system, sd)
+    net.eval()
+    inputs = [torch.from_numpy(g[f"{system}.in{i}"]).clone()
+              for i in range(2) if f"{system}.in{i}" in g.files]
+    with torch.no_grad():
+        y = net(*inputs)
+    assert rel_err(y.numpy(), g[f"{system}.out"]) < 1e-6
+    if system == "quad":
+        assert net.conv and net.horizon == 10 and y.shape == (16, 40)
+        with torch.no_grad():
+            y2 = net.forward_soa(*inputs)
+        assert rel_err(y2.t().numpy(), g["quad.out"]) < 1e-6
+    if system == "wing":
+        assert not net.conv
