@@ -413,3 +413,153 @@ def test_deferred_loss_chain(dev):
         assert torch.equal(p.out["grad_actions"], e["grad_actions"])
     with pytest.raises(ValueError):   # a plan cannot defer onto itself
         plans[0].launch(after=plans[0])
+
+
+# ------------------------------------------------------- edge / size cases
+def test_quad_large_angles_and_rates(dev):
+    """Attitudes of tens of radians and fast body rates: the branch-free
+    sincos (Cody-Waite reduction) must stay within tolerance far outside the
+    training distribution."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from oracle import torch_port as tp
+    B, H, dt = 512, 10, 0.1
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=77)
+    g = torch.Generator().manual_seed(78)
+    s0 = d["state0"].clone()
+    s0[:, 3:6] = 30.0 * torch.randn(B, 3, generator=g)
+    s0[:, 9:12] = 8.0 * torch.randn(B, 3, generator=g)
+    s0[:64, 3:6] *= 100.0                       # |att| up to ~1e4 rad
+    st, loss, ga, gs = tp.rollout_fwd_bwd(
+        tp.QuadOracle(), tp.quad_mpc_loss, s0, d["actions"], d["ref"], dt)
+    dyn = FlightmareDynamics()
+    for layout in ("soa", "aos"):
+        a = (s0.to(dev), d["actions"].to(dev), d["ref"].to(dev))
+        if layout == "soa":
+            a = (soa_state(a[0]), soa_seq(a[1]), soa_seq(a[2]))
+        res = F.quad_rollout_fwd_bwd(*a, dt, dyn.params, layout=layout,
+                                     want_states=True)
+        rs, rga, rgs = res["states"], res["grad_actions"], res["grad_state0"]
+        if layout == "soa":
+            rs, rga, rgs = aos_seq(rs), aos_seq(rga), rgs.t()
+        assert torch.isfinite(rs).all()
+        assert rel_err(N(rs), st.numpy()) < TOL
+        assert abs(res["loss"].item() - loss.item()) / loss.item() < TOL
+        assert rel_err(N(rga), ga.numpy()) < TOL
+        assert rel_err(N(rgs), gs.numpy()) < TOL
+
+
+def test_quad_rollout_max_batch_chunk_additivity(dev):
+    """B = 524 288 (BASELINE config 3's global batch on ONE GPU): the result
+    equals the concatenation of eight independent 65 536-trajectory launches
+    bit for bit (trajectories are independent; what N-GPU sharding relies on),
+    and the loss is the sum of the shard losses."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    dyn = FlightmareDynamics()
+    B, H, dt, n = 524288, 10, 0.1, 8
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=9)
+    s0 = soa_state(d["state0"]).to(dev)
+    a = soa_seq(d["actions"]).to(dev)
+    r = soa_seq(d["ref"][:, :, [0, 1, 2, 6, 7, 8]]).to(dev)
+    full = F.quad_rollout_fwd_bwd(s0, a, r, dt, dyn.params, layout="soa")
+    assert torch.isfinite(full["grad_actions"]).all()
+    total, c = 0.0, B // n
+    for i in range(n):
+        part = F.quad_rollout_fwd_bwd(
+            s0[:, i * c:(i + 1) * c].contiguous(),
+            a[:, :, i * c:(i + 1) * c].contiguous(),
+            r[:, :, i * c:(i + 1) * c].contiguous(), dt, dyn.params,
+            layout="soa")
+        total += part["loss"].item()
+        assert torch.equal(part["grad_actions"],
+                           full["grad_actions"][:, :, i * c:(i + 1) * c])
+        assert torch.equal(part["grad_state0"],
+                           full["grad_state0"][:, i * c:(i + 1) * c])
+    assert abs(total - full["loss"].item()) / full["loss"].item() < 1e-5
+
+
+@pytest.mark.parametrize("B,H", [(100, 7), (1, 20), (333, 13)])
+def test_wing_ragged_any_horizon_vs_oracle(dev, B, H):
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    from oracle import torch_port as tp
+    dt = 0.05
+    d = synthetic.wing_batch(B, H, dt, seed=B + H)
+    st, loss, ga, gs = tp.rollout_fwd_bwd(
+        tp.WingOracle(WMOD), tp.fixed_wing_mpc_loss, d["state0"], d["actions"],
+        d["ref"], dt)
+    dyn = FixedWingDynamics(modified_params=dict(WMOD))
+    for layout in ("aos", "soa"):
+        a = (d["state0"].to(dev), d["actions"].to(dev), d["ref"].to(dev))
+        if layout == "soa":
+            a = (soa_state(a[0]), soa_seq(a[1]), soa_seq(a[2]))
+        res = F.wing_rollout_fwd_bwd(*a, dt, dyn.params, layout=layout,
+                                     want_states=True)
+        rs, rga, rgs = res["states"], res["grad_actions"], res["grad_state0"]
+        if layout == "soa":
+            rs, rga, rgs = aos_seq(rs), aos_seq(rga), rgs.t()
+        assert rel_err(N(rs), st.numpy()) < TOL
+        assert abs(res["loss"].item() - loss.item()) / loss.item() < TOL
+        assert rel_err(N(rga), ga.numpy()) < 2 * TOL
+        assert rel_err(N(rgs), gs.numpy()) < 2 * TOL
+
+
+def test_cartpole_ragged_longer_horizon_vs_oracle(dev):
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.cartpole_dynamics import (
+        CartpoleDynamics)
+    from oracle import torch_port as tp
+    B, H, dt = 70, 10, 0.02
+    d = synthetic.cartpole_batch(B, H, seed=3)
+    dyn_o = tp.CartpoleOracle()
+    s0 = d["state0"].clone().requires_grad_(True)
+    a = d["actions"].clone().requires_grad_(True)
+    inter = tp.unroll(dyn_o, s0, a, dt)
+    loss = tp.cartpole_loss_mpc(inter, tp.cartpole_reference(s0, H), a)
+    loss.backward()
+    dyn = CartpoleDynamics()
+    res = F.cartpole_rollout_fwd_bwd(d["state0"].to(dev), d["actions"].to(dev),
+                                     dt, dyn.params, want_states=True)
+    assert rel_err(N(res["states"]), inter.detach().numpy()) < TOL
+    assert abs(res["loss"].item() - loss.item()) / loss.item() < TOL
+    assert rel_err(N(res["grad_actions"]), a.grad.numpy()) < TOL
+    assert rel_err(N(res["grad_state0"]), s0.grad.numpy()) < TOL
+
+
+def test_step_kernels_soa_layout_through_c_abi(dev):
+    """The single-step entry points in the device-native SoA layout (the
+    drop-in classes use AoS): same numbers as the golden AoS results."""
+    import ctypes
+    from apg_trajectory_tracking_amd import _capi, functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    g = load_golden("quad_step.npz")
+    dyn = FlightmareDynamics()
+    lib = _capi.lib()
+    s = D(g["state"], dev).t().contiguous()
+    a = D(g["action"], dev).t().contiguous()
+    out = torch.empty_like(s)
+    st = torch.cuda.current_stream().cuda_stream
+    _capi.check(lib.apg_quad_step_fwd(s.data_ptr(), a.data_ptr(), 0.1,
+                                      ctypes.byref(dyn.params), s.shape[1],
+                                      _capi.LAYOUT_SOA, out.data_ptr(), st),
+                "apg_quad_step_fwd")
+    assert rel_err(N(out.t()), g["def_dt010_next"]) < 1e-6
+    cot = D(g["cot"][0], dev).t().contiguous()
+    gs, ga = torch.empty_like(s), torch.empty_like(a)
+    _capi.check(lib.apg_quad_step_bwd(s.data_ptr(), a.data_ptr(), 0.1,
+                                      ctypes.byref(dyn.params), s.shape[1],
+                                      _capi.LAYOUT_SOA, cot.data_ptr(),
+                                      gs.data_ptr(), ga.data_ptr(), st),
+                "apg_quad_step_bwd")
+    assert rel_err(N(gs.t()), g["def_dt010_gstate"][0]) < 1e-5
+    assert rel_err(N(ga.t()), g["def_dt010_gaction"][0]) < 1e-5
+    f = torch.empty(15, s.shape[1], device=dev)
+    _capi.check(lib.apg_quad_features_fwd(s.data_ptr(), s.shape[1],
+                                          _capi.LAYOUT_SOA, f.data_ptr(), st),
+                "apg_quad_features_fwd")
+    assert torch.allclose(f.t(), F.quad_features(s.t().contiguous()), atol=0, rtol=0)
