@@ -62,6 +62,11 @@ class ApgDeferredLoss(ctypes.Structure):
                 ("prev_loss", ctypes.c_void_p)]
 
 
+class ApgLstmPolicy(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "conv_w", "conv_b", "w_ih_t", "w_hh_t", "b_gates", "w_out", "b_out")]
+
+
 class ApgCartpoleParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in (
         "masscart", "masspole", "length", "max_force_mag", "friction",
@@ -89,6 +94,16 @@ SIGNATURES = {
         _P, _P, _P, _P],
     "apg_quad_features_fwd": [_P, _I, _I, _P, _P],
     "apg_quad_features_bwd": [_P, _P, _I, _I, _P, _P],
+    "apg_quad_lstm_rollout_fwd": [
+        _P, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgLstmPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_rollout_bwd": [
+        _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgLstmPolicy),
+        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_planes_gemm_workspace_floats": [_I, _I, _I],
+    "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, ctypes.c_longlong, _P,
+                        _I, _P, _P],
     "apg_wing_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,
                           _P, _P],
     "apg_wing_step_bwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,

@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libapg_hip.so")
-SOURCES = ["common.hip", "quad.hip", "wing.hip", "cartpole.hip"]
+SOURCES = ["common.hip", "quad.hip", "wing.hip", "cartpole.hip", "lstm.hip",
+           "planes_gemm.hip"]
 # -fno-slp-vectorize: hipcc's SLP pass packs neighbouring f32 ops into
 # v_pk_fma/mul/add_f32; on gfx950 a packed op issues no faster than two plain
 # ones here and needs v_mov shuffles to form register pairs - measured on
@@ -19,6 +20,7 @@ SOURCES = ["common.hip", "quad.hip", "wing.hip", "cartpole.hip"]
 COMMON_FLAGS = ["-fno-slp-vectorize"]
 EXTRA_FLAGS = {}
 HEADERS = [os.path.join(CSRC, "apg_device.h"),
+           os.path.join(CSRC, "quad_math.h"),
            os.path.join(REPO, "include", "apg.h")]
 
 

@@ -504,3 +504,131 @@ class RolloutPlan:
         """Reduce this plan's partials now (end of a deferred chain)."""
         reduce_loss_partials(self.out["loss_partials"], self.out["loss"])
         return self.out["loss"]
+
+
+# ----------------------------------------- fused LSTM-policy unroll (K7)
+_GEMM_WGS = 512
+_boff_cache = {}
+
+
+def _boff(dev, key, values):
+    k = (str(dev), key)
+    if k not in _boff_cache:
+        _boff_cache[k] = torch.tensor(values, dtype=torch.int32, device=dev)
+    return _boff_cache[k]
+
+
+def planes_gemm(A, M, S, Bp, boff, bstride=0, with_ones=True):
+    """C[m][j] = sum_{s,n} A[m*S+s][n] * Bp[boff[j] + s*bstride][n] on the
+    matrix cores (apg_planes_gemm); A, Bp are [planes, N] fp32 tensors."""
+    require_device(A, Bp)
+    N = A.shape[1]
+    J = boff.numel()
+    ws = torch.empty(lib().apg_planes_gemm_workspace_floats(
+        J, int(with_ones), _GEMM_WGS), dtype=torch.float32, device=A.device)
+    C = torch.empty(M, J + int(with_ones), dtype=torch.float32, device=A.device)
+    check(lib().apg_planes_gemm(
+        ptr(A), M, S, ptr(Bp), boff.data_ptr(), J, bstride, int(with_ones), N,
+        ptr(ws), _GEMM_WGS, ptr(C), stream_of(A)), "apg_planes_gemm")
+    return C
+
+
+class _QuadLstmRolloutLoss(torch.autograd.Function):
+    """loss of the LSTM-mode unroll with the policy inside the kernel.
+
+    forward : apg_quad_lstm_rollout_fwd then apg_quad_lstm_rollout_bwd (the
+              reverse sweep runs right away - the loss only exists after it).
+    backward: turns the saved per-(step, trajectory) cotangent planes into the
+              parameter gradients with three matrix-core reduction GEMMs over
+              the H*B rows (apg_planes_gemm).
+    Inputs are the reference's tensors: state0 [B,12], in_ref [B,2H,9],
+    ref [B,>=H,9], h0 / c0 [B,8] and the LSTM_NEW parameters."""
+
+    @staticmethod
+    def forward(ctx, state0, in_ref, ref, h0, c0, conv_w, conv_b, w_ih, w_hh,
+                b_ih, b_hh, w_out, b_out, dt, params, weights):
+        B = state0.shape[0]
+        H = 10
+        if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
+            raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
+        if w_ih.shape != (32, 175) or conv_w.shape != (20, 9, 3):
+            raise ValueError("fused path needs LSTM_NEW(15, 10, 9, 4, conv=1)")
+        dev = state0.device
+        s0 = _f32c(state0).t().contiguous()
+        inr = _f32c(in_ref[:, :2 * H]).permute(1, 2, 0).contiguous()
+        rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
+        h0s, c0s = _f32c(h0).t().contiguous(), _f32c(c0).t().contiguous()
+        pw = dict(
+            conv_w=_f32c(conv_w), conv_b=_f32c(conv_b),
+            w_ih_t=_f32c(w_ih).t().contiguous(),
+            w_hh_t=_f32c(w_hh).t().contiguous(),
+            b_gates=(_f32c(b_ih) + _f32c(b_hh)).contiguous(),
+            w_out=_f32c(w_out), b_out=_f32c(b_out))
+        require_device(s0, inr, rf, h0s, c0s, *pw.values())
+        pol = _capi.ApgLstmPolicy(**{k: ptr(v) for k, v in pw.items()})
+        N = H * B
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        states, actions = new(H, 12, B), new(H, 4, B)
+        # one buffer for everything the weight-gradient GEMMs read as B
+        # operand: x (175 planes), h_prev / c_prev (16), h_new (8)
+        acts = new(199, N)
+        x, hc, hnew = acts[:175], acts[175:191], acts[191:199]
+        gates = new(32, N)
+        st = stream_of(s0)
+        check(lib().apg_quad_lstm_rollout_fwd(
+            ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
+            ctypes.byref(params), ctypes.byref(pol), B, H, ptr(states),
+            ptr(actions), ptr(x), ptr(gates), ptr(hc), ptr(hnew), st),
+            "apg_quad_lstm_rollout_fwd")
+        partials = new(2 * ((B + 127) // 128))
+        loss = new(1)
+        d_gates, d_zout, d_conv = new(32, N), new(4, N), new(160, N)
+        check(lib().apg_quad_lstm_rollout_bwd(
+            ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1], ptr(x),
+            ptr(gates), ptr(hc), float(dt), ctypes.byref(params),
+            ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
+            ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), None, None,
+            None, st), "apg_quad_lstm_rollout_bwd")
+        ctx.save_for_backward(s0, inr, states, acts, d_gates, d_zout, d_conv)
+        ctx.mark_non_differentiable(states, actions)
+        ctx.dims = (B, H)
+        return loss.reshape(()), states, actions
+
+    @staticmethod
+    def backward(ctx, g, _gs, _ga):
+        s0, inr, states, acts, d_gates, d_zout, d_conv = ctx.saved_tensors
+        B, H = ctx.dims
+        N = H * B
+        dev = s0.device
+        # [dW_ih | dW_hh | db] = d_gates . [x ; h_prev ; 1]^T
+        c1 = planes_gemm(d_gates, 32, 1, acts,
+                         _boff(dev, "ih_hh", list(range(183))))
+        d_w_ih, d_w_hh, d_b = c1[:, :175], c1[:, 175:183], c1[:, 183]
+        # [dW_out | db_out] = d_zout . [h_new ; 1]^T
+        c2 = planes_gemm(d_zout, 4, 1, acts,
+                         _boff(dev, "out", list(range(191, 199))))
+        d_w_out, d_b_out = c2[:, :8], c2[:, 8]
+        # conv weight: windows made relative to the position BEFORE each step;
+        # dW[ch][c][t] = sum_{pos,n} d_conv[ch*8+pos][n] * win[(pos+t)*9+c][n]
+        pos = torch.cat((s0[None, :3], states[:-1, :3]), 0)        # [H,3,B]
+        win = inr.unfold(0, H, 1)[:H].permute(3, 1, 0, 2).clone()  # [r,9,k,B]
+        win[:, :3] -= pos.permute(1, 0, 2)[None]
+        c3 = planes_gemm(d_conv, 20, 8, win.reshape(90, N),
+                         _boff(dev, "conv", [t * 9 + c for c in range(9)
+                                             for t in range(3)]), bstride=9)
+        d_conv_w, d_conv_b = c3[:, :27].reshape(20, 9, 3), c3[:, 27]
+        grads = [d_conv_w, d_conv_b, d_w_ih, d_w_hh, d_b, d_b, d_w_out, d_b_out]
+        grads = [gr * g for gr in grads]
+        return (None, None, None, None, None, *grads, None, None, None)
+
+
+def quad_lstm_rollout_loss(net, state0, in_ref, ref, dt, params, h0, c0,
+                           weights=None):
+    """Fused LSTM-mode unroll for an `LSTM_NEW(15, 10, 9, 4, conv=1)` policy.
+    Returns (loss, states [H,12,B], actions [H,4,B]); `loss.backward()` fills
+    the gradients of net.conv_ref / net.lstm / net.fc_out."""
+    return _QuadLstmRolloutLoss.apply(
+        state0, in_ref, ref, h0, c0, net.conv_ref.weight, net.conv_ref.bias,
+        net.lstm.weight_ih, net.lstm.weight_hh, net.lstm.bias_ih,
+        net.lstm.bias_hh, net.fc_out.weight, net.fc_out.bias, dt, params,
+        weights or quad_loss_weights())

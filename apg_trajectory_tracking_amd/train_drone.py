@@ -33,6 +33,9 @@ class TrainDrone(TrainBase):
                 "sample in must be one of eval_env, train_env, real_flightmare"
             )
         self.hidden_generator = None   # seeds LSTM (h0, c0) draws if set
+        # LSTM mode: run the policy INSIDE the rollout kernel (K7) when the
+        # network is the reference architecture LSTM_NEW(15, 10, 9, 4, conv=1)
+        self.fused_policy = True
 
     def initialize_model(self, base_model=None, modified_params={},
                          state_data=None, device=None, seed=0):
@@ -68,6 +71,12 @@ class TrainDrone(TrainBase):
         if self.train_mode == "LSTM":
             self.net.reset_hidden_state(
                 batch_size, generator=self.hidden_generator)
+            if self.fused_policy and self._fusable():
+                loss, _, _ = F.quad_lstm_rollout_loss(
+                    self.net, current_state, in_ref_states, ref_states,
+                    self.delta_t, self.train_dynamics.params,
+                    self.net.hidden_state, self.net.cell_state)
+                return self._step(loss)
         states, actions = [], []
         for k in range(self.horizon):
             rel = in_ref_states[:, k:k + self.horizon].clone()
@@ -83,6 +92,13 @@ class TrainDrone(TrainBase):
         loss = quad_mpc_loss(
             intermediate_states, ref_states[:, :self.horizon], action_seq)
         return self._step(loss)
+
+    def _fusable(self):
+        n = self.net
+        return (isinstance(n, LSTM_NEW) and n.conv and self.horizon == 10
+                and n.lstm.weight_ih.shape == (32, 175)
+                and n.conv_ref.weight.shape == (20, 9, 3)
+                and n.fc_out.weight.shape == (4, 8))
 
     def train_controller_model(
         self, current_state, action_seq, in_ref_states, ref_states

@@ -563,3 +563,31 @@ def test_step_kernels_soa_layout_through_c_abi(dev):
                                           _capi.LAYOUT_SOA, f.data_ptr(), st),
                 "apg_quad_features_fwd")
     assert torch.allclose(f.t(), F.quad_features(s.t().contiguous()), atol=0, rtol=0)
+
+
+def test_planes_gemm_mfma_vs_torch(dev):
+    """apg_planes_gemm (v_mfma_f32_32x32x2_f32 reduction GEMM) against
+    torch.matmul in float64, incl. segment strides, the ones column, ragged
+    N and an asymmetric operand (catches row/column swaps)."""
+    from apg_trajectory_tracking_amd import functional as F
+    g = torch.Generator().manual_seed(0)
+    for (M, S, P, J, bstride, N) in ((32, 1, 199, 183, 0, 6400),
+                                     (4, 1, 16, 8, 0, 777),
+                                     (20, 8, 90, 27, 9, 1300)):
+        A = torch.randn(M * S, N, generator=g).to(dev)
+        Bp = (torch.randn(P, N, generator=g) + torch.arange(P)[:, None] * 0.01).to(dev)
+        if bstride:
+            offs = [t * 9 + c for c in range(9) for t in range(3)]
+        else:
+            offs = list(range(P - J, P))
+        boff = torch.tensor(offs, dtype=torch.int32, device=dev)
+        C = F.planes_gemm(A, M, S, Bp, boff, bstride=bstride, with_ones=True)
+        A64, B64 = A.double().cpu(), Bp.double().cpu()
+        ref = torch.zeros(M, J + 1, dtype=torch.float64)
+        for m in range(M):
+            for s in range(S):
+                a = A64[m * S + s]
+                rows = torch.stack([B64[o + s * bstride] for o in offs])
+                ref[m, :J] += rows @ a
+                ref[m, J] += a.sum()
+        assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5

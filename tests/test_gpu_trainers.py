@@ -123,13 +123,15 @@ def test_quad_recurrent_unroll(dev, mode):
             net.hidden_state, net.cell_state = h0.clone(), c0.clone()
         net.reset_hidden_state = fixed_reset
     in_ref_before = in_ref.clone()
-    loss = trainer.train_recurrent_model(None, state0, in_ref, ref)
-    assert torch.equal(in_ref, in_ref_before)   # the window is copied
-    assert abs(loss.item() - g[f"{mode}.loss"]) / g[f"{mode}.loss"] < 2e-5
-    for k, p in trainer.net.named_parameters():
-        key = f"{mode}.g.{k}"
-        if key in g.files:
-            assert rel_err(N(p.grad), g[key]) < 2e-4, k
+    for fused in ((False, True) if mode == "lstm" else (False,)):
+        trainer.fused_policy = fused   # K7 (policy in-kernel) vs per-step kernels
+        loss = trainer.train_recurrent_model(None, state0, in_ref, ref)
+        assert torch.equal(in_ref, in_ref_before)   # the window is copied
+        assert abs(loss.item() - g[f"{mode}.loss"]) / g[f"{mode}.loss"] < 2e-5
+        for k, p in trainer.net.named_parameters():
+            key = f"{mode}.g.{k}"
+            if key in g.files:
+                assert rel_err(N(p.grad), g[key]) < 2e-4, (fused, k)
 
 
 def test_cartpole_train_step(dev):
@@ -214,3 +216,31 @@ def test_quad_run_epoch_learns(dev, mode):
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0]
     assert trainer.results_dict["loss"][1:] == losses
+
+
+def test_fused_lstm_rollout_matches_reference_unroll(dev):
+    """K7: policy-in-kernel LSTM unroll vs the golden LSTM unroll (G4):
+    states, actions, loss and every parameter gradient."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    g = load_golden("quad_recurrent.npz")
+    net = LSTM_NEW(15, 10, 9, 4, conv=1)
+    load_weights(net, g, "lstm.w.")
+    net.to(dev)
+    dyn = FlightmareDynamics()
+    state0, in_ref, ref = (D(g["state0"], dev), D(g["in_ref"], dev),
+                           D(g["ref"], dev))
+    h0, c0 = D(g["lstm_h0"], dev), D(g["lstm_c0"], dev)
+    loss, states, actions = F.quad_lstm_rollout_loss(
+        net, state0, in_ref, ref, float(g["dt"]), dyn.params, h0, c0)
+    loss.backward()
+    assert rel_err(N(states.permute(2, 0, 1)), g["lstm.states"]) < 2e-5
+    assert rel_err(N(actions.permute(2, 0, 1)), g["lstm.actions"]) < 2e-5
+    assert abs(loss.item() - g["lstm.loss"]) / g["lstm.loss"] < 2e-5
+    for k, p in net.named_parameters():
+        key = f"lstm.g.{k}"
+        if key in g.files:
+            assert p.grad is not None, k
+            assert rel_err(N(p.grad), g[key]) < 2e-4, k

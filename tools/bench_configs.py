@@ -132,9 +132,12 @@ def main():
             t._step(loss)
         emit("quad_train_step_soa_head", B, H, timed(step_soa, 30, 5))
 
-    for mode, name in (("autoregressive", "quad_ar"), ("LSTM", "quad_lstm")):
+    for mode, name, fused in (("autoregressive", "quad_ar", False),
+                              ("LSTM", "quad_lstm_unfused", False),
+                              ("LSTM", "quad_lstm_fused", True)):
         if want(name):
             t = make_trainer(mode)
+            t.fused_policy = fused
             d = t.state_data
             emit(name, B, H, timed(lambda: t.train_recurrent_model(
                 None, d.states, d.in_ref_states, d.ref_states), 10, 2))
