@@ -34,7 +34,7 @@ struct GemmArgs {
   const float *A, *Bp;
   const int *boff;
   float *part;  // [gridDim.x][32][NB*32]
-  long long N;
+  long long N, a_bytes, b_bytes;
   int M, S, J, bstride, with_ones, NB, tiles_per_seg;
 };
 
@@ -42,40 +42,77 @@ template <int NB>
 __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
   extern __shared__ float lds[];  // (32 + NB*32) rows of kLd floats
   float *la = lds, *lb = lds + 32 * kLd;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index is wave-uniform; tell the compiler, so that everything
+  // derived from it (row numbers, plane offsets) lives in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane;  // column of the tile this lane stages
   const int Jt = G.J + G.with_ones;
+  constexpr int RA = 8, RB = NB * 8;  // rows staged per wave (row = wave + 4 i)
   f32x16 acc[NB];
 #pragma unroll
   for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[jb][i] = 0.f;
 
-  const long long total_tiles = (long long)G.S * G.tiles_per_seg;
-  for (long long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+  // Branch-free staging through buffer resources: per-lane column offset in a
+  // VGPR, the row's plane offset in an SGPR (row numbers are wave-uniform).
+  // EVERY row is loaded unconditionally - padding rows and the ones row read
+  // plane 0 - and is turned into what it should be by one FMA when it is
+  // written to LDS:   real row: v*1 + 0   padding: v*0 + 0   ones: v*0 + 1.
+  // No conditional touches a loaded value before that point, so all loads of
+  // a tile are in flight together and overlap the previous tile's MFMAs.
+  const unsigned plane_bytes = (unsigned)(G.N * 4);
+  const auto rA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(G.A), 0, (unsigned)G.a_bytes, 0x00020000);
+  const auto rB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(G.Bp), 0, (unsigned)G.b_bytes, 0x00020000);
+
+  float va[RA], vb[RB];
+  float keep = 1.f;  // 0 for the lanes of a ragged last tile beyond N
+  auto fetch = [&](long long tile) {  // issue every load of a tile, no waits
     const int s = (int)(tile / G.tiles_per_seg);
-    const long long n0 = (tile % G.tiles_per_seg) * kKT;
-    // stage: thread t loads column (t & 63) of rows (t >> 6) + 4 i
-    const int col = tid & 63;
-    const long long n = n0 + col;
-    const bool in_n = n < G.N;
-#pragma unroll 4
-    for (int r = wave; r < 32; r += 4) {
-      float v = 0.f;
-      if (r < G.M && in_n) v = G.A[((long long)r * G.S + s) * G.N + n];
-      la[r * kLd + col] = v;
+    const long long n = (tile % G.tiles_per_seg) * kKT + col;
+    keep = n < G.N ? 1.f : 0.f;
+    const int voff = (int)((n < G.N ? n : G.N - 1) * 4);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int r = wave + 4 * i;
+      const int plane = r < G.M ? r * G.S + s : 0;
+      va[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                  rA, voff, (unsigned)plane * plane_bytes, 0));
     }
-#pragma unroll 4
-    for (int r = wave; r < NB * 32; r += 4) {
-      float v = 0.f;
-      if (in_n) {
-        if (r < G.J)
-          v = G.Bp[((long long)G.boff[r] + (long long)s * G.bstride) * G.N + n];
-        else if (r < Jt)
-          v = 1.0f;  // the ones column: row sums of A
-      }
-      lb[r * kLd + col] = v;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int r = wave + 4 * i;
+      const int plane = r < G.J ? G.boff[r] + s * G.bstride : 0;
+      vb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                  rB, voff, (unsigned)plane * plane_bytes, 0));
+    }
+  };
+
+  const long long total_tiles = (long long)G.S * G.tiles_per_seg;
+  long long tile = blockIdx.x;
+  if (tile < total_tiles) fetch(tile);
+  for (; tile < total_tiles; tile += gridDim.x) {
+    // registers -> LDS ([row][kLd]: conflict-free for the stores and for the
+    // MFMA fragment reads below)
+    const float kp_ = keep;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int r = wave + 4 * i;
+      la[r * kLd + col] = va[i] * (r < G.M ? kp_ : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int r = wave + 4 * i;
+      const float mul = r < G.J ? kp_ : 0.f;
+      const float add = (r >= G.J && r < Jt) ? kp_ : 0.f;  // ones column
+      lb[r * kLd + col] = fmaf(vb[i], mul, add);
     }
     __syncthreads();
+    // software pipeline: the next tile's loads fly while this one multiplies
+    if (tile + gridDim.x < total_tiles) fetch(tile + gridDim.x);
     // wave w owns k-pairs [8w, 8w+8) of the tile
 #pragma unroll
     for (int kp = 0; kp < 8; ++kp) {
@@ -111,16 +148,25 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
   for (int i = tid; i < 32 * W; i += kThreads) out[i] = red[i];
 }
 
-// C[m][j] = sum over workgroups of part[wg][m][j], fixed order
+// C[m][j] = sum over workgroups of part[wg][m][j].  Fixed order: eight
+// interleaved double accumulators (loads in flight), combined pairwise.
 __global__ __launch_bounds__(256) void planes_gemm_reduce_kernel(
     const float *__restrict__ part, int num_wg, int W, int M, int Jt,
     float *__restrict__ C) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * Jt) return;
   const int m = idx / Jt, j = idx % Jt;
-  double acc = 0.0;
-  for (int w = 0; w < num_wg; ++w) acc += (double)part[((size_t)w * 32 + m) * W + j];
-  C[idx] = (float)acc;
+  const float *p = part + (size_t)m * W + j;
+  const size_t stride = (size_t)32 * W;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int w = 0;
+  for (; w + 8 <= num_wg; w += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += (double)p[(size_t)(w + u) * stride];
+  }
+  for (; w < num_wg; ++w) acc[0] += (double)p[(size_t)w * stride];
+  C[idx] = (float)(((acc[0] + acc[1]) + (acc[2] + acc[3])) +
+                   ((acc[4] + acc[5]) + (acc[6] + acc[7])));
 }
 
 template <int NB>
@@ -153,8 +199,8 @@ int apg_planes_gemm_workspace_floats(int J, int with_ones, int num_wg) {
 
 int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
                     const int *boff, int J, int bstride, int with_ones,
-                    long long N, float *workspace, int num_wg, float *C,
-                    apg_stream_t stream) {
+                    int b_planes, long long N, float *workspace, int num_wg,
+                    float *C, apg_stream_t stream) {
   const int Jt = J + (with_ones ? 1 : 0);
   if (!A || !Bp || !boff || !workspace || !C) {
     set_error("apg_planes_gemm: NULL pointer");
@@ -166,8 +212,16 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
               "num_wg >= 1", kMaxNB * 32);
     return APG_ERR_ARG;
   }
+  const long long a_bytes = (long long)M * S * N * 4;
+  const long long b_bytes = (long long)b_planes * N * 4;
+  if (b_planes < 1 || a_bytes >= (1ll << 32) || b_bytes >= (1ll << 32)) {
+    set_error("apg_planes_gemm: operands must be smaller than 4 GiB each "
+              "(32-bit buffer offsets); split the batch");
+    return APG_ERR_ARG;
+  }
   GemmArgs G;
   G.A = A, G.Bp = Bp, G.boff = boff, G.part = workspace;
+  G.a_bytes = a_bytes, G.b_bytes = b_bytes;
   G.N = N, G.M = M, G.S = S, G.J = J, G.bstride = bstride;
   G.with_ones = with_ones ? 1 : 0;
   G.NB = (Jt + 31) / 32;

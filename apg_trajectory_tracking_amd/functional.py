@@ -528,8 +528,9 @@ def planes_gemm(A, M, S, Bp, boff, bstride=0, with_ones=True):
         J, int(with_ones), _GEMM_WGS), dtype=torch.float32, device=A.device)
     C = torch.empty(M, J + int(with_ones), dtype=torch.float32, device=A.device)
     check(lib().apg_planes_gemm(
-        ptr(A), M, S, ptr(Bp), boff.data_ptr(), J, bstride, int(with_ones), N,
-        ptr(ws), _GEMM_WGS, ptr(C), stream_of(A)), "apg_planes_gemm")
+        ptr(A), M, S, ptr(Bp), boff.data_ptr(), J, bstride, int(with_ones),
+        Bp.shape[0], N, ptr(ws), _GEMM_WGS, ptr(C), stream_of(A)),
+        "apg_planes_gemm")
     return C
 
 

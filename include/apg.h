@@ -215,12 +215,13 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
  * of apg_quad_lstm_rollout_bwd into weight gradients - the role torch.autograd
  * plays for the parameters in scripts/train_drone.py:168.  `boff` is a DEVICE
  * int array [J]; `workspace` holds apg_planes_gemm_workspace_floats(J,
- * with_ones, num_wg) floats; C is [M][J + with_ones] row-major. */
+ * with_ones, num_wg) floats; C is [M][J + with_ones] row-major.  B holds
+ * `b_planes` planes; A (M*S planes) and B must each stay below 4 GiB. */
 int apg_planes_gemm_workspace_floats(int J, int with_ones, int num_wg);
 int apg_planes_gemm(const float *A, int M, int S, const float *B,
                     const int *boff, int J, int bstride, int with_ones,
-                    long long N, float *workspace, int num_wg, float *C,
-                    apg_stream_t stream);
+                    int b_planes, long long N, float *workspace, int num_wg,
+                    float *C, apg_stream_t stream);
 
 /* ---------------------------------------------------------- fixed wing --- */
 /* Parameters of neural_control/dynamics/fixed_wing_dynamics.py:18-39 +
