@@ -139,6 +139,13 @@ class TrainBase:
             momentum=0.9
         )
         self.grad_sync = GradAllReducer(self.net.parameters())
+        # a learnable simulator gets its own optimizer (:144-150)
+        if isinstance(self.train_dynamics, torch.nn.Module):
+            self.optimizer_dynamics = optim.SGD(
+                self.train_dynamics.parameters(),
+                lr=self.learning_rate_dynamics,
+                momentum=0.9
+            )
 
     def _step(self, loss):
         """backward -> (all-reduce) -> SGD step; returns the (global) loss."""
@@ -159,15 +166,51 @@ class TrainBase:
     ):
         raise NotImplementedError("only the quadrotor trainer is recurrent")
 
+    def train_dynamics_model(self, current_state, action_seq):
+        """scripts/train_base.py:160-186: one SGD step fitting the learnable
+        train dynamics to the eval dynamics on the first action of the
+        sequence (sum of squared next-state differences + l2 on the residual
+        network)."""
+        self.optimizer_dynamics.zero_grad()
+        next_state_d1 = self.train_dynamics(
+            current_state, action_seq[:, 0], dt=self.delta_t
+        )
+        with torch.no_grad():
+            next_state_d2 = self.eval_dynamics(
+                current_state, action_seq[:, 0], dt=self.delta_t
+            )
+        l2_loss = 0
+        if self.l2_lambda > 0:
+            l2_loss = (
+                torch.norm(self.train_dynamics.linear_state_2.weight) +
+                torch.norm(self.train_dynamics.linear_state_2.bias) +
+                torch.norm(self.train_dynamics.linear_state_1.weight) +
+                torch.norm(self.train_dynamics.linear_state_1.bias)
+            )
+        loss = torch.sum(
+            (next_state_d1 - next_state_d2)**2
+        ) + self.l2_lambda * l2_loss
+        loss.backward()
+        self.optimizer_dynamics.step()
+        self.results_dict["loss_dyn_per_step"].append(loss.detach())
+        return loss
+
     def run_epoch(self, train="controller", epoch=0):
-        if train != "controller":
-            raise NotImplementedError(
-                "learnt-dynamics training is outside the APG hot path")
+        if train not in ("controller", "dynamics"):
+            raise ValueError("train must be 'controller' or 'dynamics'")
         running_loss = None
         i = -1
         for i, data in enumerate(self.trainloader, 0):
             in_state, current_state, in_ref_state, ref_states = data
-            if self.train_mode != "concurrent":
+            if train == "dynamics":
+                with torch.no_grad():
+                    actions = torch.sigmoid(self.net(in_state, in_ref_state))
+                action_seq = torch.reshape(
+                    actions, (-1, self.actions_out_dim // self.action_dim,
+                              self.action_dim))
+                loss = self.train_dynamics_model(current_state, action_seq)
+                self.count_finetune_data += len(current_state)
+            elif self.train_mode != "concurrent":
                 loss = self.train_recurrent_model(
                     in_state, current_state, in_ref_state, ref_states
                 )

@@ -58,6 +58,8 @@ class TrainDrone(TrainBase):
                 in_state_size, self.horizon, self.ref_dim,
                 self.actions_out_dim, conv=1)
         self.net.to(device)
+        if isinstance(self.train_dynamics, torch.nn.Module):
+            self.train_dynamics.to(device)     # learnable simulator (N3)
         self.config["ref_length"] = self.ref_length
         self.config["dt"] = self.delta_t
         self.config["modified_params"] = modified_params

@@ -17,6 +17,7 @@ Fixtures:
   features.npz       G7  state_preprocessing + VJP
   losses.npz         G8  the three MPC losses + grads on random inputs
   checkpoints.npz    G9  state_dicts of the shipped controllers + outputs
+  learnt_dynamics.npz G10 LearntDynamics forward + parameter gradients
 """
 import os
 import sys
@@ -513,6 +514,7 @@ if __name__ == "__main__":
     g7_features()
     g8_losses()
     g9_checkpoints()
+    g10_learnt_dynamics()
 
 
 # --------------------------------------------------------------------- G9
@@ -545,3 +547,41 @@ def g9_checkpoints():
         out[f"{system}.out"] = npy(y)
         out[f"{system}.class"] = np.array(type(net).__module__ + "." + type(net).__name__)
     save("checkpoints.npz", **out)
+
+
+# -------------------------------------------------------------------- G10
+def g10_learnt_dynamics():
+    """N3: LearntDynamics (quad_dynamics_trained.py:10-69) -
+    action transform + residual MLP + learnable kinv / inertia around the
+    Flightmare step - and the loss of TrainBase.train_dynamics_model
+    (scripts/train_base.py:160-186, l2 term off).  Records one forward value
+    and the autograd gradients of every parameter."""
+    from neural_control.dynamics.quad_dynamics_trained import LearntDynamics
+    init = {"rotational_drag": [.01, .02, .03]}
+    torch.manual_seed(61)
+    dyn = LearntDynamics(initial_params=dict(init))
+    with torch.no_grad():
+        dyn.linear_at.add_(0.05 * torch.randn(4, 4))
+        dyn.linear_state_1.weight.normal_(0, 0.05)
+        dyn.linear_state_1.bias.normal_(0, 0.05)
+        dyn.linear_state_2.weight.normal_(0, 0.02)
+        dyn.linear_state_2.bias.normal_(0, 0.02)
+    target = FlightmareDynamics(modified_params=dict(MOD_PARAMS))
+    g = torch.Generator().manual_seed(62)
+    B = 64
+    state = torch.randn(B, 12, generator=g)
+    state[:, 3:6] *= 0.4
+    action = torch.rand(B, 4, generator=g)
+    out = {"state": npy(state), "action": npy(action), "dt": np.float32(0.1)}
+    for k, v in dyn.state_dict().items():
+        out["w." + k] = npy(v)
+    d1 = dyn(state, action, 0.1)
+    d2 = target(state, action, 0.1)
+    loss = torch.sum((d1 - d2)**2)
+    loss.backward()
+    out["next"] = npy(d1)
+    out["target_next"] = npy(d2)
+    out["loss"] = np.float64(loss.item())
+    for k, p in dyn.named_parameters():
+        out["g." + k] = npy(p.grad) if p.grad is not None else np.zeros(1)
+    save("learnt_dynamics.npz", **out)
