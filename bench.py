@@ -49,6 +49,9 @@ def parse():
                     default="deferred",
                     help="how each step's scalar loss is materialised "
                          "(DESIGN.md: deferred = folded into the next launch)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every step from Python instead of replaying "
+                         "one captured HIP graph of the K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=20,
                     help="steps of the secondary full-training-step "
@@ -235,13 +238,25 @@ def main():
     from apg_trajectory_tracking_amd import functional as F
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
+    import gc
     dyn = FlightmareDynamics()
     sets = make_sets(args, rank, dev)
-    plans = [F.RolloutPlan("quad", *s, args.dt, dyn.params, layout=args.layout,
-                           want_grad_state0=args.grad_state0,
-                           loss_mode=args.loss_mode) for s in sets]
-    nset = len(plans)
+    # all launches of the timed loops go to ONE non-default stream, so that the
+    # K steps can be captured into a HIP graph: the GPU then runs them back to
+    # back and a host hiccup (a descheduled Python process costs tens of ms)
+    # cannot leak into the measurement
+    side = torch.cuda.Stream(device=dev)
+    nset = len(sets)
     deferred = args.loss_mode == "deferred"
+    with torch.cuda.stream(side):
+        plans = [F.RolloutPlan("quad", *s, args.dt, dyn.params,
+                               layout=args.layout,
+                               want_grad_state0=args.grad_state0,
+                               loss_mode=args.loss_mode) for s in sets]
+        kplans = [F.RolloutPlan("quad", *s, args.dt, dyn.params,
+                                layout=args.layout,
+                                want_grad_state0=args.grad_state0,
+                                loss_mode="none") for s in sets]
 
     def run_steps(n):
         """n steps; with deferred losses step i's launch also reduces step
@@ -254,55 +269,78 @@ def main():
         if deferred and prev is not None:
             prev.flush()
 
+    def run_kernel_only(n):
+        for i in range(n):
+            kplans[i % nset].launch()
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup)
-    barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run_steps(args.steps)
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    def graph_of(fn, n):
+        if args.no_graph:
+            return None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fn(n)
+        return g
+
+    def timed(fn, n, graph):
+        """(host seconds, HIP-event ms) for exactly n steps, bracketed by
+        barrier + synchronize on both sides."""
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            e0.record()
+            if graph is not None:
+                graph.replay()
+            else:
+                fn(n)
+            e1.record()
+        barrier()
+        return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+    gc.collect()
+    gc.disable()
+    with torch.cuda.stream(side):
+        run_steps(args.warmup)
+    torch.cuda.synchronize()
+    g_steps = graph_of(run_steps, args.steps)
+    g_kernel = graph_of(run_kernel_only, args.steps)
+    if g_steps is not None:      # one untimed replay: graph upload, clocks
+        with torch.cuda.stream(side):
+            g_steps.replay()
+    elapsed, ev_ms = timed(run_steps, args.steps, g_steps)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_check = float(plans[0].out["loss"].item())
 
-    # roofline pass: the same rollout launches alone (no loss reduction
-    # kernel in between), bracketed by one HIP-event pair on the launch
-    # stream -> average launch duration of the dominant kernel including the
-    # kernel-to-kernel boundary (a per-launch event pair would add ~2.5 us of
-    # its own to a ~10 us kernel)
-    kplans = [F.RolloutPlan("quad", *s, args.dt, dyn.params, layout=args.layout,
-                            want_grad_state0=args.grad_state0, loss_mode="none")
-              for s in sets]
-    for i in range(min(args.warmup, 10)):
-        kplans[i % nset].launch()
+    # roofline pass: the same rollout launches alone (no loss reduction),
+    # bracketed by one HIP-event pair on the launch stream -> average launch
+    # duration of the dominant kernel including the kernel-to-kernel boundary
+    # (a per-launch event pair would add ~2.5 us of its own to a ~9 us kernel)
+    with torch.cuda.stream(side):
+        run_kernel_only(min(args.warmup, 10))
+    _, k_ms = timed(run_kernel_only, args.steps, g_kernel)
+    kernel_ms = k_ms / args.steps
+    # the same launch on ONE buffer set: inputs stay in the 256 MB Infinity
+    # Cache - reported, labelled, never used for `value` or the roofline
     torch.cuda.synchronize()
     k0 = torch.cuda.Event(enable_timing=True)
     k1 = torch.cuda.Event(enable_timing=True)
-    k0.record()
-    for i in range(args.steps):
-        kplans[i % nset].launch()
-    k1.record()
-    torch.cuda.synchronize()
-    kernel_ms = k0.elapsed_time(k1) / args.steps
-    # the same launch on ONE buffer set: inputs stay in the 256 MB Infinity
-    # Cache - reported, labelled, never used for `value` or the roofline
-    k0.record()
-    for i in range(args.steps):
-        kplans[0].launch()
-    k1.record()
+    with torch.cuda.stream(side):
+        k0.record()
+        for i in range(args.steps):
+            kplans[0].launch()
+        k1.record()
     torch.cuda.synchronize()
     resident_ms = k0.elapsed_time(k1) / args.steps
+    gc.enable()
 
     H, B = args.horizon, args.batch
     bytes_per_traj = QUAD_BYTES_PER_TRAJ["base"](H) + (
@@ -329,6 +367,7 @@ def main():
             "dt": args.dt, "layout": args.layout, "buffer_sets": nset,
             "grad_state0": bool(args.grad_state0),
             "loss_mode": args.loss_mode,
+            "launch": "python" if args.no_graph else "hip-graph replay of the K steps",
             "parallelism": f"batch-sharded x{world}, no data-path collective",
         },
         "ms_per_step_hip_events": ev_ms / args.steps,
