@@ -96,7 +96,7 @@ SIGNATURES = {
     "apg_quad_features_bwd": [_P, _P, _I, _I, _P, _P],
     "apg_quad_lstm_rollout_fwd": [
         _P, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
-        ctypes.POINTER(ApgLstmPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P],
+        ctypes.POINTER(ApgLstmPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_quad_lstm_rollout_bwd": [
         _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgLstmPolicy),

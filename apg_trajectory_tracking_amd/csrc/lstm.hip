@@ -85,22 +85,33 @@ __device__ __forceinline__ void axpy32(float (&acc)[kNG], const float *row, floa
   }
 }
 
-__device__ __forceinline__ float dot32(const float *row, const float (&d)[kNG]) {
-  float acc = 0.f;
+// four independent partial sums: a single accumulator would make the 32 FMAs
+// one dependent chain (latency-, not issue-bound, with one wave per SIMD)
+__device__ __forceinline__ float dot32(const float4 (&w)[kNG / 4],
+                                       const float (&d)[kNG]) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
   for (int q = 0; q < kNG / 4; ++q) {
-    const float4 w = *reinterpret_cast<const float4 *>(row + 4 * q);
-    acc = fmaf(w.x, d[4 * q + 0], acc);
-    acc = fmaf(w.y, d[4 * q + 1], acc);
-    acc = fmaf(w.z, d[4 * q + 2], acc);
-    acc = fmaf(w.w, d[4 * q + 3], acc);
+    a0 = fmaf(w[q].x, d[4 * q + 0], a0);
+    a1 = fmaf(w[q].y, d[4 * q + 1], a1);
+    a2 = fmaf(w[q].z, d[4 * q + 2], a2);
+    a3 = fmaf(w[q].w, d[4 * q + 3], a3);
   }
-  return acc;
+  return (a0 + a1) + (a2 + a3);
+}
+
+__device__ __forceinline__ float dot32(const float *row, const float (&d)[kNG]) {
+  float4 w[kNG / 4];
+#pragma unroll
+  for (int q = 0; q < kNG / 4; ++q)
+    w[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
+  return dot32(w, d);
 }
 
 struct FwdArgs {
   const float *state0, *in_ref, *h0, *c0;
   float *states, *actions, *x, *gates, *hc, *hnew;
+  unsigned *mask;  // [5][N] relu mask bits of the conv outputs
   ApgLstmPolicy pol;
   QuadConst c;
   int B;
@@ -152,26 +163,52 @@ __global__ __launch_bounds__(kBlock) void lstm_rollout_fwd_kernel(FwdArgs A) {
     for (int r = 0; r < kH; ++r)
 #pragma unroll
       for (int q = 0; q < 3; ++q) wr[r][q] = w[r][q] - s[q];
+    unsigned mask[5] = {0u, 0u, 0u, 0u, 0u};  // relu mask of the 160 conv outputs
+    float4 wrow[kNG / 4];                      // W_ih row of the next element
+#pragma unroll
+    for (int q = 0; q < kNG / 4; ++q)
+      wrow[q] = *reinterpret_cast<const float4 *>(&lds[oWih + kNF * kNG + 4 * q]);
 #pragma unroll 1
     for (int ch = 0; ch < kNC; ++ch) {
       float wc[27];
 #pragma unroll
       for (int i = 0; i < 27; ++i) wc[i] = lds[oWc + ch * 27 + i];
       const float bias = lds[oBc + ch];
+      unsigned bits = 0u;
 #pragma unroll
       for (int pos = 0; pos < kNP; ++pos) {
+        const int j = kNF + ch * kNP + pos;
+        // this element's weights were requested one element ago; request the
+        // next row now so that its LDS latency hides behind 59 FMAs
+        float4 wcur[kNG / 4];
+#pragma unroll
+        for (int q = 0; q < kNG / 4; ++q) wcur[q] = wrow[q];
+        const int jn = j + 1 < kNX ? j + 1 : j;
+#pragma unroll
+        for (int q = 0; q < kNG / 4; ++q)
+          wrow[q] = *reinterpret_cast<const float4 *>(&lds[oWih + jn * kNG + 4 * q]);
         float v = bias;
 #pragma unroll
         for (int q = 0; q < kRD; ++q)
 #pragma unroll
           for (int tt = 0; tt < 3; ++tt)
             v = fmaf(wc[q * 3 + tt], q < 3 ? wr[pos + tt][q] : w[pos + tt][q], v);
+        bits |= (v > 0.f ? 1u : 0u) << pos;
         v = fmaxf(v, 0.f);
-        const int j = kNF + ch * kNP + pos;
         A.x[(size_t)j * N + n] = v;
-        axpy32(g, &lds[oWih + j * kNG], v);
+#pragma unroll
+        for (int q = 0; q < kNG / 4; ++q) {
+          g[4 * q + 0] = fmaf(wcur[q].x, v, g[4 * q + 0]);
+          g[4 * q + 1] = fmaf(wcur[q].y, v, g[4 * q + 1]);
+          g[4 * q + 2] = fmaf(wcur[q].z, v, g[4 * q + 2]);
+          g[4 * q + 3] = fmaf(wcur[q].w, v, g[4 * q + 3]);
+        }
       }
+      mask[ch >> 2] |= bits << (8 * (ch & 3));
     }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      A.mask[(size_t)i * N + n] = mask[i];
     // LSTMCell (torch gate order i, f, g, o)
     float hn[kNH];
 #pragma unroll
@@ -213,7 +250,8 @@ __global__ __launch_bounds__(kBlock) void lstm_rollout_fwd_kernel(FwdArgs A) {
 }
 
 struct BwdArgs {
-  const float *state0, *states, *actions, *ref, *x, *gates, *hc;
+  const float *state0, *states, *actions, *ref, *gates, *hc;
+  const unsigned *mask;
   float *loss_partials, *d_gates, *d_zout, *d_conv;
   float *grad_state0, *grad_h0, *grad_c0;
   ApgLstmPolicy pol;
@@ -322,15 +360,29 @@ __global__ __launch_bounds__(kBlock) void lstm_rollout_bwd_kernel(BwdArgs A) {
     for (int i = 0; i < 12; ++i) lam[i] += gs[i];
     // conv branch: relu mask from the saved activations; only the position
     // columns of the window carry a gradient (rel = ref - pos)
+    unsigned mask[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) mask[i] = A.mask[(size_t)i * N + n];
+    float4 wrow[kNG / 4];  // W_ih row of the next conv element (prefetched)
+#pragma unroll
+    for (int q = 0; q < kNG / 4; ++q)
+      wrow[q] = *reinterpret_cast<const float4 *>(&lds[oWih + kNF * kNG + 4 * q]);
 #pragma unroll 1
     for (int ch = 0; ch < kNC; ++ch) {
       float sum = 0.f;
+      const unsigned bits = (mask[ch >> 2] >> (8 * (ch & 3))) & 0xffu;
 #pragma unroll
       for (int pos = 0; pos < kNP; ++pos) {
         const int j = kNF + ch * kNP + pos;
-        const float xe = A.x[(size_t)j * N + n];
-        const float dxe = dot32(&lds[oWih + j * kNG], dG);
-        const float dcp = xe > 0.f ? dxe : 0.f;
+        float4 wcur[kNG / 4];
+#pragma unroll
+        for (int q = 0; q < kNG / 4; ++q) wcur[q] = wrow[q];
+        const int jn = j + 1 < kNX ? j + 1 : j;
+#pragma unroll
+        for (int q = 0; q < kNG / 4; ++q)
+          wrow[q] = *reinterpret_cast<const float4 *>(&lds[oWih + jn * kNG + 4 * q]);
+        const float dxe = dot32(wcur, dG);
+        const float dcp = ((bits >> pos) & 1u) ? dxe : 0.f;
         if (live) A.d_conv[(size_t)(ch * kNP + pos) * N + n] = dcp;
         sum += dcp;
       }
@@ -381,11 +433,11 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
                               const ApgLstmPolicy *policy, int B, int H,
                               float *states, float *actions, float *x,
                               float *gates, float *hc, float *hnew,
-                              apg_stream_t stream) {
+                              unsigned *relu_mask, apg_stream_t stream) {
   if (int e = check_lstm(params, policy, B, H)) return e;
   if (B == 0) return APG_OK;
   if (!state0 || !in_ref || !h0 || !c0 || !states || !actions || !x || !gates ||
-      !hc || !hnew) {
+      !hc || !hnew || !relu_mask) {
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
@@ -393,6 +445,7 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
   A.state0 = state0, A.in_ref = in_ref, A.h0 = h0, A.c0 = c0;
   A.states = states, A.actions = actions, A.x = x, A.gates = gates, A.hc = hc;
   A.hnew = hnew;
+  A.mask = relu_mask;
   A.pol = *policy;
   A.c = make_const(*params, dt);
   A.B = B;
@@ -403,8 +456,8 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
 
 int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const float *actions, const float *ref,
-                              int ref_cols, const float *x, const float *gates,
-                              const float *hc, float dt,
+                              int ref_cols, const unsigned *relu_mask,
+                              const float *gates, const float *hc, float dt,
                               const ApgQuadParams *params,
                               const ApgQuadLossWeights *weights,
                               const ApgLstmPolicy *policy, int B, int H,
@@ -424,14 +477,14 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
       return check_launch("memset(loss)");
     return APG_OK;
   }
-  if (!state0 || !states || !actions || !ref || !x || !gates || !hc ||
+  if (!state0 || !states || !actions || !ref || !relu_mask || !gates || !hc ||
       !loss_partials || !d_gates || !d_zout || !d_conv) {
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
   BwdArgs A;
   A.state0 = state0, A.states = states, A.actions = actions, A.ref = ref;
-  A.x = x, A.gates = gates, A.hc = hc;
+  A.mask = relu_mask, A.gates = gates, A.hc = hc;
   A.loss_partials = loss_partials, A.d_gates = d_gates, A.d_zout = d_zout;
   A.d_conv = d_conv, A.grad_state0 = grad_state0, A.grad_h0 = grad_h0;
   A.grad_c0 = grad_c0;

@@ -575,18 +575,20 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         acts = new(199, N)
         x, hc, hnew = acts[:175], acts[175:191], acts[191:199]
         gates = new(32, N)
+        relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
         st = stream_of(s0)
         check(lib().apg_quad_lstm_rollout_fwd(
             ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
             ctypes.byref(params), ctypes.byref(pol), B, H, ptr(states),
-            ptr(actions), ptr(x), ptr(gates), ptr(hc), ptr(hnew), st),
-            "apg_quad_lstm_rollout_fwd")
+            ptr(actions), ptr(x), ptr(gates), ptr(hc), ptr(hnew),
+            relu_mask.data_ptr(), st), "apg_quad_lstm_rollout_fwd")
         partials = new(2 * ((B + 127) // 128))
         loss = new(1)
         d_gates, d_zout, d_conv = new(32, N), new(4, N), new(160, N)
         check(lib().apg_quad_lstm_rollout_bwd(
-            ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1], ptr(x),
-            ptr(gates), ptr(hc), float(dt), ctypes.byref(params),
+            ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1],
+            relu_mask.data_ptr(), ptr(gates), ptr(hc), float(dt),
+            ctypes.byref(params),
             ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
             ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), None, None,
             None, st), "apg_quad_lstm_rollout_bwd")
@@ -603,11 +605,11 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         dev = s0.device
         # [dW_ih | dW_hh | db] = d_gates . [x ; h_prev ; 1]^T
         c1 = planes_gemm(d_gates, 32, 1, acts,
-                         _boff(dev, "ih_hh", list(range(183))))
+                         _boff(dev, "ih_hh", list(range(183)))) * g
         d_w_ih, d_w_hh, d_b = c1[:, :175], c1[:, 175:183], c1[:, 183]
         # [dW_out | db_out] = d_zout . [h_new ; 1]^T
         c2 = planes_gemm(d_zout, 4, 1, acts,
-                         _boff(dev, "out", list(range(191, 199))))
+                         _boff(dev, "out", list(range(191, 199)))) * g
         d_w_out, d_b_out = c2[:, :8], c2[:, 8]
         # conv weight: windows made relative to the position BEFORE each step;
         # dW[ch][c][t] = sum_{pos,n} d_conv[ch*8+pos][n] * win[(pos+t)*9+c][n]
@@ -616,10 +618,9 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         win[:, :3] -= pos.permute(1, 0, 2)[None]
         c3 = planes_gemm(d_conv, 20, 8, win.reshape(90, N),
                          _boff(dev, "conv", [t * 9 + c for c in range(9)
-                                             for t in range(3)]), bstride=9)
+                                             for t in range(3)]), bstride=9) * g
         d_conv_w, d_conv_b = c3[:, :27].reshape(20, 9, 3), c3[:, 27]
         grads = [d_conv_w, d_conv_b, d_w_ih, d_w_hh, d_b, d_b, d_w_out, d_b_out]
-        grads = [gr * g for gr in grads]
         return (None, None, None, None, None, *grads, None, None, None)
 
 

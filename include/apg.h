@@ -176,14 +176,14 @@ typedef struct ApgLstmPolicy {
  *   states [H][12][B], actions [H][4][B],
  *   x [175][N]   LSTM inputs (features, relu(conv)),
  *   gates [32][N] activated gates (i, f, g, o), hc [16][N] = h_prev, c_prev,
- *   hnew [8][N]. */
+ *   hnew [8][N], relu_mask [5][N] (bit ch*8+pos = conv output > 0). */
 int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
                               const float *h0, const float *c0, float dt,
                               const ApgQuadParams *params,
                               const ApgLstmPolicy *policy, int B, int H,
                               float *states, float *actions, float *x,
                               float *gates, float *hc, float *hnew,
-                              apg_stream_t stream);
+                              unsigned *relu_mask, apg_stream_t stream);
 
 /* Reverse sweep (BPTT) of the above + quad_mpc_loss on ref[:, :H]
  * (scripts/train_drone.py:159-168).  ref [H][ref_cols][B].  Writes the loss
@@ -197,8 +197,8 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
  *   dconv_w[ch][c][t] = sum_{pos,n} d_conv[ch][pos][n] window[n][pos+t][c]. */
 int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const float *actions, const float *ref,
-                              int ref_cols, const float *x, const float *gates,
-                              const float *hc, float dt,
+                              int ref_cols, const unsigned *relu_mask,
+                              const float *gates, const float *hc, float dt,
                               const ApgQuadParams *params,
                               const ApgQuadLossWeights *weights,
                               const ApgLstmPolicy *policy, int B, int H,
