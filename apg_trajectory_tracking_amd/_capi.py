@@ -67,6 +67,12 @@ class ApgLstmPolicy(ctypes.Structure):
         "conv_w", "conv_b", "w_ih_t", "w_hh_t", "b_gates", "w_out", "b_out")]
 
 
+class ApgMlpPolicy(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
+        "w_3", "b_3", "w_out", "b_out")]
+
+
 class ApgCartpoleParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in (
         "masscart", "masspole", "length", "max_force_mag", "friction",
@@ -101,9 +107,18 @@ SIGNATURES = {
         _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgLstmPolicy),
         _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "apg_planes_gemm_workspace_floats": [_I, _I, _I],
-    "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I, ctypes.c_longlong,
-                        _P, _I, _P, _P],
+    "apg_quad_mlp_rollout_fwd": [
+        _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgMlpPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_mlp_workspace_floats": [],
+    "apg_quad_mlp_loss_partials_count": [_I],
+    "apg_quad_mlp_rollout_bwd": [
+        _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy),
+        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
+    "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I,
+                        ctypes.c_longlong, _P, _I, _P, _I, _P],
     "apg_wing_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,
                           _P, _P],
     "apg_wing_step_bwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,

@@ -1,0 +1,802 @@
+// mlp.hip - the AUTOREGRESSIVE quadrotor unroll with the MLP policy inside the
+// kernel, on the matrix cores (BASELINE config 3 per GPU: quadrotor,
+// autoregressive, H = 10).
+//
+// Replaces, for train_mode == "autoregressive", the loop of
+//   TrainDrone.train_recurrent_model       scripts/train_drone.py:113-173
+//   hutter_model.Net.forward (conv branch) neural_control/models/hutter_model.py:35-49
+//   state_preprocessing                    neural_control/dataset.py:207-220
+//   FlightmareDynamics / quad_mpc_loss     (see quad.hip)
+// by a forward sweep and a reverse sweep (pinned window semantics of
+// SURVEY.md §8a A4).  Network Net(15, 10, 9, 4, conv=1):
+//   s1 = tanh(W_s feat + b_s)                      15 -> 64
+//   cv = relu(conv1d(window^T; 9 -> 20, k = 3))    90 -> 160
+//   h1 = tanh(W_1 [s1, cv] + b_1)                  224 -> 64
+//   h2 = tanh(W_2 h1 + b_2),  h3 = tanh(W_3 h2 + b_3)
+//   a  = sigmoid(W_o h3 + b_o)                     64 -> 4
+// ~28 k FMA per env-step: this IS GEMM-shaped, with the batch as the N
+// dimension, so the layers run on v_mfma_f32_32x32x2_f32 (exact fp32).
+//
+// Mapping.  A wave owns 32 trajectories: lane l works for trajectory l & 31,
+// both half-waves carry the same state / window registers (the ~600-op
+// dynamics are computed twice, which is cheaper than any exchange).  For
+// D = A B + C with A = weights [32 outputs x 2 k], B = activations
+// [2 k x 32 trajectories]:
+//   A operand: lane l supplies A[l & 31][l >> 5]
+//   B operand: lane l supplies B[l >> 5][l & 31]
+//   C / D    : register i of lane l is row r(i) + 4 (l >> 5), column l & 31,
+//              with r(i) = (i & 3) + 8 (i >> 2).
+// Hence accumulator register i of a layer's output IS the B operand of the
+// next layer for the k-pair (r(i), r(i) + 4) - layers chain with no shuffles;
+// tanh / relu are applied to the accumulator registers in place.  The weights
+// are gathered once per workgroup into LDS in A-operand order
+// ([row block][k pair][lane], conflict-free ds_read_b32 per MFMA), so the
+// C ABI takes the plain row-major torch parameters.
+// One workgroup = 8 waves = 256 trajectories per CU; while one wave of a SIMD
+// multiplies, the other runs dynamics / tanh on the VALU.
+//
+// Parameter gradients: the reverse sweep writes the pre-activation cotangent
+// planes; the host reduces them against the saved activation planes with
+// apg_planes_gemm.
+#include "apg_device.h"
+#include "quad_math.h"
+
+namespace apg {
+namespace {
+
+constexpr int kH = 10, kRD = 9, kNF = 15, kNC = 20, kNP = kH - 2;
+constexpr int kW = 64;               // width of s1, h1, h2, h3
+constexpr int kN1 = kW + kNC * kNP;  // fc1 input width (224)
+constexpr int kThreads = 512;
+constexpr int kTrajPerBlock = kThreads / 2;
+constexpr unsigned kDead = 0xFFFFFFFCu;  // buffer offset beyond any tensor
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int rrow(int i) { return (i & 3) + 8 * (i >> 2); }
+// input index fed by accumulator register c & 15 of row block c >> 4
+__host__ __device__ constexpr int kchain(int c, int hi) {
+  return (c >> 4) * 32 + rrow(c & 15) + 4 * hi;
+}
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// tanh: 1 - 2 / (exp(2|x|) + 1), odd Taylor polynomial below 0.15 where the
+// subtraction would cancel.  <= ~1e-6 relative.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(2.f * ax);
+  float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  const float x2 = ax * ax;
+  const float p = ax * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f),
+                                     -1.f / 3.f), 1.f);
+  t = ax < 0.15f ? p : t;
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return 1.0f / (1.0f + expf(-x));
+}
+
+__device__ __forceinline__ float other_half(float v) {
+  return __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------ forward sweep
+// LDS map (floats).  The small tables indexed by the half-wave come first,
+// the A-operand tables (indexed by the lane) after them; see LdsView.
+constexpr int fTo = 0;                      // [4][2][16][2]
+constexpr int fTbs = fTo + 256;             // [2][16][2] x 4 layers
+constexpr int fTb1 = fTbs + 64, fTb2 = fTb1 + 64, fTb3 = fTb2 + 64;
+constexpr int fTbc = fTb3 + 64;             // [16][2]
+constexpr int fBo = fTbc + 32;              // [4]
+constexpr int fAs = 576;                    // [2][8][64]
+constexpr int fAc = fAs + 2 * 8 * 64;       // [15][64]
+constexpr int fA1s = fAc + 15 * 64;         // [2][32][64]
+constexpr int fA1c = fA1s + 2 * 32 * 64;    // [2][8 pos][12 regs][64]
+constexpr int fA2 = fA1c + 2 * 8 * 12 * 64; // [2][32][64]
+constexpr int fA3 = fA2 + 2 * 32 * 64;      // [2][32][64]
+constexpr int kFwdLds = fA3 + 2 * 32 * 64;  // 27 136 floats = 108 544 B
+static_assert(fBo + 4 <= fAs, "LDS map");
+
+// LDS reads with compile-time table offsets.  ds_read has a 16-bit immediate
+// byte offset, the tables span > 64 KB: three opaque per-lane bases (half-wave
+// index, lane, lane + kSplit) keep every access "base VGPR + immediate";
+// without them the compiler materialises one address VGPR per distinct
+// offset, hoists all of them out of the step loop and spills them.
+constexpr int kSplit = 255 * 64;
+struct LdsView {
+  const float *lds;
+  int o_0, o_hi, o_l0, o_l1;
+  __device__ __forceinline__ LdsView(const float *l, int lane) : lds(l) {
+    o_0 = 0, o_hi = lane >> 5, o_l0 = lane, o_l1 = lane + kSplit;
+    asm volatile("" : "+v"(o_0), "+v"(o_hi), "+v"(o_l0), "+v"(o_l1));
+  }
+  // wave-uniform entry [off]
+  __device__ __forceinline__ float U(int off) const { return lds[o_0 + off]; }
+  // table entry [off + hi] (off even: [..][2] tables)
+  __device__ __forceinline__ float T(int off) const { return lds[o_hi + off]; }
+  // A operand [off + lane]
+  __device__ __forceinline__ float A(int off) const {
+    return off < kSplit ? lds[o_l0 + off] : lds[o_l1 + (off - kSplit)];
+  }
+};
+
+__device__ __forceinline__ void pack_forward(float *lds, const ApgMlpPolicy &p,
+                                             int tid, int T) {
+  for (int idx = tid; idx < 2 * 8 * 64; idx += T) {
+    const int l = idx & 63, pp = (idx >> 6) & 7, rb = idx >> 9;
+    const int k = 2 * pp + (l >> 5);
+    lds[fAs + idx] = k < kNF ? p.w_s[(rb * 32 + (l & 31)) * kNF + k] : 0.f;
+  }
+  // conv k-pair (j, tap): the lower half multiplies reference column j (< 4),
+  // the upper half column 4 + j, so a lane only keeps 5 of the 9 columns
+  for (int idx = tid; idx < 15 * 64; idx += T) {
+    const int l = idx & 63, pp = idx >> 6, ch = l & 31;
+    const int j = pp / 3, tap = pp % 3, hi = l >> 5;
+    const int q = hi ? 4 + j : j;
+    lds[fAc + idx] = (ch < kNC && (hi || j < 4)) ? p.conv_w[ch * 27 + q * 3 + tap] : 0.f;
+  }
+  for (int idx = tid; idx < 2 * 32 * 64; idx += T) {
+    const int l = idx & 63, c = (idx >> 6) & 31, rb = idx >> 11;
+    const int m = rb * 32 + (l & 31), k = kchain(c, l >> 5);
+    lds[fA1s + idx] = p.w_1[m * kN1 + k];
+    lds[fA2 + idx] = p.w_2[m * kW + k];
+    lds[fA3 + idx] = p.w_3[m * kW + k];
+  }
+  for (int idx = tid; idx < 2 * 8 * 12 * 64; idx += T) {
+    const int l = idx & 63, q = idx >> 6;
+    const int i = q % 12, pos = (q / 12) & 7, rb = q / 96;
+    const int ch = rrow(i) + 4 * (l >> 5);
+    lds[fA1c + idx] =
+        ch < kNC ? p.w_1[(rb * 32 + (l & 31)) * kN1 + kW + ch * kNP + pos] : 0.f;
+  }
+  for (int idx = tid; idx < 256; idx += T) {
+    const int hi = idx & 1, i = (idx >> 1) & 15, rb = (idx >> 5) & 1, j = idx >> 6;
+    lds[fTo + idx] = p.w_out[j * kW + rb * 32 + rrow(i) + 4 * hi];
+  }
+  for (int idx = tid; idx < 64; idx += T) {
+    const int hi = idx & 1, i = (idx >> 1) & 15, rb = idx >> 5;
+    const int row = rb * 32 + rrow(i) + 4 * hi;
+    lds[fTbs + idx] = p.b_s[row];
+    lds[fTb1 + idx] = p.b_1[row];
+    lds[fTb2 + idx] = p.b_2[row];
+    lds[fTb3 + idx] = p.b_3[row];
+  }
+  for (int idx = tid; idx < 32; idx += T) {
+    const int hi = idx & 1, i = idx >> 1, ch = rrow(i) + 4 * hi;
+    lds[fTbc + idx] = ch < kNC ? p.conv_b[ch] : 0.f;
+  }
+  for (int idx = tid; idx < 4; idx += T) lds[fBo + idx] = p.b_out[idx];
+}
+
+// Plane-addressed global memory through a buffer resource: the per-lane part
+// of the address is ONE 32-bit VGPR, the plane offset a scalar - no 64-bit
+// address pairs per access (the kernels touch ~450 planes per step).
+struct Planes {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ Planes(const void *base, unsigned planes, unsigned pitch)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
+                                               (int)(planes * pitch), 0x00020000)) {}
+  // voff: per-lane byte offset (VGPR), soff: plane * pitch (scalar)
+  __device__ __forceinline__ float ld(unsigned voff, unsigned soff) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                         rsrc, (int)voff, (int)soff, 0));
+  }
+  __device__ __forceinline__ unsigned ldu(unsigned voff, unsigned soff) const {
+    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0);
+  }
+  __device__ __forceinline__ void st(unsigned voff, unsigned soff, float v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc,
+                                          (int)voff, (int)soff, 2);
+  }
+  __device__ __forceinline__ void stu(unsigned voff, unsigned soff, unsigned v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)voff, (int)soff, 2);
+  }
+};
+
+// acc[rb] (row block rb of a 64-wide layer) = bias table at `tab`
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[2], const LdsView &L, int tab) {
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[rb][i] = L.T(tab + (rb * 16 + i) * 2);
+}
+
+// out[rb_out] += W[rb_out rows][64 inputs] . in    ([2][32][64] A table at `tab`)
+__device__ __forceinline__ void dense64(f32x16 (&out)[2], const f32x16 (&in)[2],
+                                        const LdsView &L, int tab) {
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float b = in[c >> 4][c & 15];
+    out[0] = mfma(L.A(tab + (0 * 32 + c) * 64), b, out[0]);
+    out[1] = mfma(L.A(tab + (1 * 32 + c) * 64), b, out[1]);
+  }
+}
+
+// The operand tables are gathered ONCE per launch into a global workspace
+// (52 k elements, one small kernel); every workgroup then fills its LDS with a
+// linear, fully coalesced copy instead of 27 k scattered loads of its own.
+struct PackArgs {
+  ApgMlpPolicy pol;
+  float *dst;
+};
+__global__ __launch_bounds__(256) void mlp_pack_fwd_kernel(PackArgs A) {
+  pack_forward(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
+               gridDim.x * blockDim.x);
+}
+
+__device__ __forceinline__ void fill_lds(float *lds, const float *src, int floats) {
+  const float4 *s4 = reinterpret_cast<const float4 *>(src);
+  float4 *d4 = reinterpret_cast<float4 *>(lds);
+  for (int i = threadIdx.x; i < floats / 4; i += blockDim.x) d4[i] = s4[i];
+  __syncthreads();
+}
+
+// The plane pitch as the loop body sees it: opaque per iteration, so that the
+// ~450 `plane * pitch` scalar offsets of a step are computed where they are
+// used (one s_mul each on the idle SALU) instead of being hoisted out of the
+// step loop into several hundred live SGPRs.
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// dense64 with the previous layer's tanh applied where the input is consumed
+// (and the activation written to its plane): the VALU work of element c sits
+// between the MFMAs of elements c - 1 and c, under the matrix pipe's shadow.
+__device__ __forceinline__ void dense64_tanh(f32x16 (&out)[2], f32x16 (&in)[2],
+                                             const LdsView &L, int tab,
+                                             const Planes &P, int plane0,
+                                             unsigned vr, unsigned pN) {
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float b = tanh_fast(in[c >> 4][c & 15]);
+    in[c >> 4][c & 15] = b;
+    P.st(vr, (plane0 + (c >> 4) * 32 + rrow(c & 15)) * pN, b);
+    out[0] = mfma(L.A(tab + (0 * 32 + c) * 64), b, out[0]);
+    out[1] = mfma(L.A(tab + (1 * 32 + c) * 64), b, out[1]);
+  }
+}
+
+struct FwdArgs {
+  const float *state0, *in_ref;
+  float *states, *actions;
+  float *feat, *x1, *h;  // [15][N], [224][N], [192][N] (h1, h2, h3)
+  unsigned *mask;        // [5][N]
+  const float *tables;  // packed operand tables (mlp_pack_fwd_kernel)
+  QuadConst c;
+  int B;
+};
+
+__global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds(lds, A.tables, kFwdLds);
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const LdsView L(lds, lane);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = (blockIdx.x * (kThreads / 64) + wave) * 32 + (lane & 31);
+  const int B = A.B;
+  // lanes beyond the batch (and the upper half for per-trajectory stores)
+  // get an out-of-range buffer offset: their loads return 0, their stores are
+  // dropped by the range check - no branch anywhere in the step loop
+  const bool live = b < B;
+  const bool st_lo = live && hi == 0;  // per-trajectory stores: lower half only
+  const unsigned pitchB = (unsigned)B * 4u, pitchN = pitchB * kH;
+  const QuadConst c = A.c;
+  const Planes Ps0(A.state0, 12, pitchB), Pin(A.in_ref, 2 * kH * kRD, pitchB);
+  const Planes Pst(A.states, kH * 12, pitchB), Pac(A.actions, kH * 4, pitchB);
+  const Planes Pfe(A.feat, kNF, pitchN), Px1(A.x1, kN1, pitchN);
+  const Planes Ph(A.h, 3 * kW, pitchN), Pmk(A.mask, 5, pitchN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  const unsigned vb_lo = st_lo ? vb : kDead;
+
+  float s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = Ps0.ld(vb, i * pitchB);
+  // sliding reference window, raw values: columns 0..4 in the lower half,
+  // 4..8 in the upper half (see pack_forward)
+  const unsigned vwin = live ? vb + (hi ? 4u * pitchB : 0u) : kDead;
+  float w[kH][5];
+#pragma unroll
+  for (int r = 0; r < kH; ++r)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vwin, (r * kRD + j) * pitchB);
+
+#pragma unroll 1
+  for (int k = 0; k < kH; ++k) {
+    const unsigned pB = opaque(pitchB), pN = opaque(pitchN);
+    const unsigned col = (unsigned)b * 4u + (unsigned)k * pitchB;  // column k*B + b
+    const unsigned vn = live ? col : kDead;
+    const unsigned vn_lo = st_lo ? col : kDead;
+    const unsigned vr = live ? col + (hi ? 4u * pitchN : 0u) : kDead;   // + row 4 hi
+    const unsigned vc = live ? col + (hi ? 32u * pitchN : 0u) : kDead;  // + channel 4 hi
+    const unsigned vm = live ? col + (hi ? pitchN : 0u) : kDead;        // + mask word hi
+    const Trig t = make_trig(&s[3]);
+    float feat[kNF];
+    quad_features(s, t, feat);
+#pragma unroll
+    for (int j = 0; j < kNF; ++j) Pfe.st(vn_lo, j * pN, feat[j]);
+
+    f32x16 u[2], a[2];
+    // state branch: 8 k-pairs of the 15 features
+    init_bias(u, L, fTbs);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
+      const float bv = hi ? odd : feat[2 * p];
+      u[0] = mfma(L.A(fAs + (0 * 8 + p) * 64), bv, u[0]);
+      u[1] = mfma(L.A(fAs + (1 * 8 + p) * 64), bv, u[1]);
+    }
+    // conv (one 32-row block per window position) feeding fc1 directly; the
+    // tanh of the state branch (independent work) is spread over the
+    // positions so that it runs under the conv MFMAs
+    init_bias(a, L, fTb1);
+    unsigned mbits[3] = {0u, 0u, 0u};
+    const float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
+#pragma unroll
+    for (int pos = 0; pos < kNP; ++pos) {
+      f32x16 cv;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2);
+#pragma unroll
+      for (int p = 0; p < 15; ++p) {
+        const int j = p / 3, tap = p % 3;
+        const float x = j < 3 ? w[pos + tap][j] - sub[j] : w[pos + tap][j];
+        cv = mfma(L.A(fAc + p * 64), x, cv);
+        if (p % 4 == 3 || p == 14) {  // 4 state-branch activations per position
+          const int c = pos * 4 + (p == 14 ? 3 : p / 4);
+          const float tv = tanh_fast(u[c >> 4][c & 15]);
+          u[c >> 4][c & 15] = tv;
+          Px1.st(vr, ((c >> 4) * 32 + rrow(c & 15)) * pN, tv);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {  // rows r(i) + 4 hi < 20 are real channels
+        float v = cv[i];
+        mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
+        v = fmaxf(v, 0.f);
+        // plane 64 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
+        Px1.st(i < 8 ? vc : vn_lo, (kW + rrow(i) * kNP + pos) * pN, v);
+        a[0] = mfma(L.A(fA1c + ((0 * 8 + pos) * 12 + i) * 64), v, a[0]);
+        a[1] = mfma(L.A(fA1c + ((1 * 8 + pos) * 12 + i) * 64), v, a[1]);
+      }
+    }
+    // relu mask, trajectory-indexed: bit e = ch*8 + pos of word e >> 5
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      Pmk.stu(g < 2 ? vm : vn_lo, 2 * g * pN, mbits[g]);
+    // fc1, state part
+    dense64(a, u, L, fA1s);
+    // h1 -> h2 -> h3 (tanh of a layer applied inside the next layer's loop)
+    init_bias(u, L, fTb2);
+    dense64_tanh(u, a, L, fA2, Ph, 0, vr, pN);
+    init_bias(a, L, fTb3);
+    dense64_tanh(a, u, L, fA3, Ph, kW, vr, pN);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        a[rb][i] = tanh_fast(a[rb][i]);
+        Ph.st(vr, (2 * kW + rb * 32 + rrow(i)) * pN, a[rb][i]);
+      }
+    // head on the VALU: each half sums its 32 of the 64 inputs
+    float act[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        z0 = fmaf(L.T(fTo + ((j * 2 + 0) * 16 + i) * 2), a[0][i], z0);
+        z1 = fmaf(L.T(fTo + ((j * 2 + 1) * 16 + i) * 2), a[1][i], z1);
+      }
+      float z = z0 + z1;
+      z += other_half(z);
+      act[j] = sigmoidf_(z + L.U(fBo + j));
+      Pac.st(vb_lo, (k * 4 + j) * pB, act[j]);
+    }
+    quad_step(s, act, c, t);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Pst.st(vb_lo, (k * 12 + i) * pB, s[i]);
+    if (k + 1 < kH) {
+#pragma unroll
+      for (int r = 0; r + 1 < kH; ++r)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w[r][j] = w[r + 1][j];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) w[kH - 1][j] = Pin.ld(vwin, ((k + kH) * kRD + j) * pB);
+    }
+  }
+}
+
+// ------------------------------------------------------------ reverse sweep
+constexpr int rTo = 0;                    // [4][2][16][2]
+constexpr int rAq = rTo + 256;            // [20][3] sum over taps of conv_w
+constexpr int rA3 = 320;                  // [2][32][64]  fc3^T
+constexpr int rA2 = rA3 + 2 * 32 * 64;    // [2][32][64]  fc2^T
+constexpr int rA1s = rA2 + 2 * 32 * 64;   // [2][32][64]  fc1^T, state inputs
+constexpr int rA1c = rA1s + 2 * 32 * 64;  // [5][32][64]  fc1^T, conv inputs
+constexpr int rAs = rA1c + 5 * 32 * 64;   // [32][64]     states_in^T
+constexpr int kBwdLds = rAs + 32 * 64;    // 24 896 floats = 99 584 B
+static_assert(rAq + kNC * 3 <= rA3, "LDS map");
+
+__device__ __forceinline__ void pack_reverse(float *lds, const ApgMlpPolicy &p,
+                                             int tid, int T) {
+  for (int idx = tid; idx < 2 * 32 * 64; idx += T) {
+    const int l = idx & 63, c = (idx >> 6) & 31, rb = idx >> 11;
+    const int m = rb * 32 + (l & 31), k = kchain(c, l >> 5);
+    lds[rA3 + idx] = p.w_3[k * kW + m];
+    lds[rA2 + idx] = p.w_2[k * kW + m];
+    lds[rA1s + idx] = p.w_1[k * kN1 + m];
+  }
+  for (int idx = tid; idx < 5 * 32 * 64; idx += T) {
+    const int l = idx & 63, c = (idx >> 6) & 31, eb = idx >> 11;
+    lds[rA1c + idx] = p.w_1[kchain(c, l >> 5) * kN1 + kW + eb * 32 + (l & 31)];
+  }
+  for (int idx = tid; idx < 32 * 64; idx += T) {
+    const int l = idx & 63, c = idx >> 6, m = l & 31;
+    lds[rAs + idx] = m < kNF ? p.w_s[kchain(c, l >> 5) * kNF + m] : 0.f;
+  }
+  for (int idx = tid; idx < 256; idx += T) {
+    const int hi = idx & 1, i = (idx >> 1) & 15, rb = (idx >> 5) & 1, j = idx >> 6;
+    lds[rTo + idx] = p.w_out[j * kW + rb * 32 + rrow(i) + 4 * hi];
+  }
+  for (int idx = tid; idx < kNC * 3; idx += T) {
+    const int ch = idx / 3, q = idx % 3;
+    lds[rAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
+                     p.conv_w[ch * 27 + q * 3 + 2];
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_bwd_kernel(PackArgs A) {
+  pack_reverse(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
+               gridDim.x * blockDim.x);
+}
+
+struct BwdArgs {
+  const float *state0, *states, *actions, *ref, *x1, *h;
+  const unsigned *mask;
+  float *loss_partials;
+  float *d_pre;   // [256][N]: d_pre1, d_pre2, d_pre3, d_pre_s (64 each)
+  float *d_zout;  // [4][N]
+  float *d_conv;  // [160][N]
+  float *grad_state0;
+  const float *tables;  // packed operand tables (mlp_pack_bwd_kernel)
+  QuadConst c;
+  ApgQuadLossWeights w;
+  int B, ref_cols, vel_col;
+};
+
+__device__ __forceinline__ void zero(f32x16 (&v)[2]) {
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[rb][i] = 0.f;
+}
+
+// The saved activations of a layer (planes [base, base + 64), accumulator
+// layout) are requested one matrix product ahead of their use ...
+__device__ __forceinline__ void load_acts(float (&hv)[2][16], const Planes &act,
+                                          int base, unsigned vr, unsigned pN) {
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hv[rb][i] = act.ld(vr, (base + rb * 32 + rrow(i)) * pN);
+}
+
+// ... and applied here: v *= 1 - act^2 (tanh'), result written to the
+// cotangent planes [out_base, out_base + 64)
+__device__ __forceinline__ void tanh_adjoint(f32x16 (&v)[2], const float (&hv)[2][16],
+                                             const Planes &out, int out_base,
+                                             unsigned vr, unsigned pN) {
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[rb][i] *= 1.f - hv[rb][i] * hv[rb][i];
+      out.st(vr, (out_base + rb * 32 + rrow(i)) * pN, v[rb][i]);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds(lds, A.tables, kBwdLds);
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const LdsView L(lds, lane);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = (blockIdx.x * (kThreads / 64) + wave) * 32 + (lane & 31);
+  const int B = A.B;
+  const bool live = b < B;  // dead lanes: out-of-range offsets, see forward
+  const bool st_lo = live && hi == 0;
+  const unsigned pitchB = (unsigned)B * 4u, pitchN = pitchB * kH;
+  const QuadConst c = A.c;
+  const Planes Ps0(A.state0, 12, pitchB), Pst(A.states, kH * 12, pitchB);
+  const Planes Pac(A.actions, kH * 4, pitchB), Prf(A.ref, kH * A.ref_cols, pitchB);
+  const Planes Px1(A.x1, kN1, pitchN), Ph(A.h, 3 * kW, pitchN);
+  const Planes Pmk(A.mask, 5, pitchN), Pdp(A.d_pre, 4 * kW, pitchN);
+  const Planes Pdz(A.d_zout, 4, pitchN), Pdc(A.d_conv, kNC * kNP, pitchN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+
+  float lam[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = 0.f;
+  float loss = 0.f;
+
+#pragma unroll 1
+  for (int k = kH - 1; k >= 0; --k) {
+    const unsigned pB = opaque(pitchB), pN = opaque(pitchN);
+    const unsigned col = (unsigned)b * 4u + (unsigned)k * pitchB;
+    const unsigned vn = live ? col : kDead;
+    const unsigned vn_lo = st_lo ? col : kDead;
+    const unsigned vr = live ? col + (hi ? 4u * pitchN : 0u) : kDead;
+    float sn[12], sc[12], a[4], rp[3], rv[3];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      sn[i] = Pst.ld(vb, (k * 12 + i) * pB);
+      sc[i] = k > 0 ? Pst.ld(vb, ((k - 1) * 12 + i) * pB) : Ps0.ld(vb, i * pB);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = Pac.ld(vb, (k * 4 + j) * pB);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      rp[i] = Prf.ld(vb, (k * A.ref_cols + i) * pB);
+      rv[i] = Prf.ld(vb, (k * A.ref_cols + A.vel_col + i) * pB);
+    }
+    unsigned mw[5];
+#pragma unroll
+    for (int eb = 0; eb < 5; ++eb) mw[eb] = Pmk.ldu(vn, eb * pN);
+    float hv[2][16];
+    load_acts(hv, Ph, 2 * kW, vr, pN);  // h3
+    __builtin_amdgcn_sched_barrier(0);
+    float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float dp = sn[i] - rp[i], dv = sn[6 + i] - rv[i], wn = sn[9 + i];
+      lp += dp * dp, lv += dv * dv, lw += wn * wn;
+      lam[i] += 2.f * A.w.pos * dp;
+      lam[6 + i] += 2.f * A.w.vel * dv;
+      lam[9 + i] += 2.f * A.w.av * wn;
+    }
+    const float da0 = a[0] - 0.5f;
+    float ga[4];
+    ga[0] = 2.f * A.w.thrust * da0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      const float d = a[j] - 0.5f;
+      lr += d * d;
+      ga[j] = 2.f * A.w.rates * d;
+    }
+    loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
+            A.w.thrust * da0 * da0;
+    const Trig t = make_trig(&sc[3]);
+    quad_step_adjoint(lam, ga, a[0], &sc[9], c, t);
+
+    // head (VALU): d/dh3 in accumulator layout
+    float dz[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dz[j] = ga[j] * a[j] * (1.f - a[j]);
+      Pdz.st(vn_lo, j * pN, dz[j]);
+    }
+    f32x16 d[2], e[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v = fmaf(L.T(rTo + ((j * 2 + rb) * 16 + i) * 2), dz[j], v);
+        d[rb][i] = v;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    tanh_adjoint(d, hv, Pdp, 2 * kW, vr, pN);  // d_pre3
+    load_acts(hv, Ph, kW, vr, pN);             // h2, lands under the product
+    __builtin_amdgcn_sched_barrier(0);
+    zero(e);
+    dense64(e, d, L, rA3);
+    __builtin_amdgcn_sched_barrier(0);
+    tanh_adjoint(e, hv, Pdp, kW, vr, pN);      // d_pre2
+    load_acts(hv, Ph, 0, vr, pN);              // h1
+    __builtin_amdgcn_sched_barrier(0);
+    zero(d);
+    dense64(d, e, L, rA2);
+    __builtin_amdgcn_sched_barrier(0);
+    tanh_adjoint(d, hv, Pdp, 0, vr, pN);       // d_pre1
+    load_acts(hv, Px1, 0, vr, pN);             // s1
+    __builtin_amdgcn_sched_barrier(0);
+    // fc1 inputs, state branch
+    zero(e);
+    dense64(e, d, L, rA1s);
+    __builtin_amdgcn_sched_barrier(0);
+    tanh_adjoint(e, hv, Pdp, 3 * kW, vr, pN);  // d_pre_s
+    // features: one 32-row block (15 real rows), then both halves need all
+    f32x16 f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) f[i] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc)
+      f = mfma(L.A(rAs + cc * 64), e[cc >> 4][cc & 15], f);
+    float dfeat[kNF], gs[12];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float own = f[i], oth = other_half(own);
+      dfeat[rrow(i)] = hi ? oth : own;
+      if (rrow(i) + 4 < kNF) dfeat[rrow(i) + 4 < kNF ? rrow(i) + 4 : 0] = hi ? own : oth;
+    }
+    quad_features_adjoint(sc, t, dfeat, gs);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) lam[i] += gs[i];
+    // fc1 inputs, conv outputs: five 32-row blocks over e = ch*8 + pos
+    float dpos[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int eb = 0; eb < 5; ++eb) {
+      f32x16 y;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y[i] = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 32; ++cc)
+        y = mfma(L.A(rA1c + (eb * 32 + cc) * 64), d[cc >> 4][cc & 15], y);
+      const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];  // bit r(i) + 4 hi -> bit r(i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g
+        float sum = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = 4 * g + ii;
+          const float dcp = ((mws >> rrow(i)) & 1u) ? y[i] : 0.f;
+          Pdc.st(vr, (eb * 32 + rrow(i)) * pN, dcp);
+          sum += dcp;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          dpos[q] = fmaf(L.U(rAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) lam[q] -= dpos[q] + other_half(dpos[q]);
+  }
+  if (st_lo && A.grad_state0)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) A.grad_state0[(size_t)i * B + b] = lam[i];
+  write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
+}
+
+
+int check_mlp(const ApgQuadParams *params, const ApgMlpPolicy *pol, int B, int H) {
+  if (!params || !pol) { set_error("params / policy is NULL"); return APG_ERR_ARG; }
+  if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
+  if ((long long)B * kH * 4 * 256 >= (1ll << 32) - 64) {
+    set_error("B too large for 32-bit plane offsets (max %d); split the batch",
+              (int)(((1ll << 32) - 64) / (kH * 4 * 256)));
+    return APG_ERR_ARG;
+  }
+  if (H != kH) {
+    set_error("the fused autoregressive rollout is built for horizon %d (got %d)",
+              kH, H);
+    return APG_ERR_ARG;
+  }
+  if (!pol->w_s || !pol->b_s || !pol->conv_w || !pol->conv_b || !pol->w_1 ||
+      !pol->b_1 || !pol->w_2 || !pol->b_2 || !pol->w_3 || !pol->b_3 ||
+      !pol->w_out || !pol->b_out) {
+    set_error("policy weight pointer is NULL");
+    return APG_ERR_ARG;
+  }
+  return APG_OK;
+}
+
+template <typename K>
+int raise_lds(K kernel, int floats) {
+  if (hipFuncSetAttribute((const void *)kernel,
+                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(floats * sizeof(float))) != hipSuccess)
+    return check_launch("hipFuncSetAttribute(mlp_rollout)");
+  return APG_OK;
+}
+
+}  // namespace
+}  // namespace apg
+
+using namespace apg;
+
+extern "C" {
+
+int apg_quad_mlp_workspace_floats(void) { return kFwdLds > kBwdLds ? kFwdLds : kBwdLds; }
+
+int apg_quad_mlp_loss_partials_count(int B) {
+  return B <= 0 ? 0 : ((B + kTrajPerBlock - 1) / kTrajPerBlock) * (kThreads / kWave);
+}
+
+int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
+                             const ApgQuadParams *params,
+                             const ApgMlpPolicy *policy, int B, int H,
+                             float *states, float *actions, float *feat,
+                             float *x1, float *h, unsigned *relu_mask,
+                             float *workspace, apg_stream_t stream) {
+  if (int e = check_mlp(params, policy, B, H)) return e;
+  if (B == 0) return APG_OK;
+  if (!state0 || !in_ref || !states || !actions || !feat || !x1 || !h ||
+      !relu_mask || !workspace) {
+    set_error("NULL buffer");
+    return APG_ERR_ARG;
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (int e = raise_lds(mlp_rollout_fwd_kernel, kFwdLds)) return e;
+    attr = true;
+  }
+  FwdArgs A;
+  A.state0 = state0, A.in_ref = in_ref, A.states = states, A.actions = actions;
+  A.feat = feat, A.x1 = x1, A.h = h, A.mask = relu_mask;
+  A.tables = workspace;
+  A.c = make_const(*params, dt);
+  A.B = B;
+  PackArgs P;
+  P.pol = *policy, P.dst = workspace;
+  hipLaunchKernelGGL(mlp_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256),
+                     0, (hipStream_t)stream, P);
+  hipLaunchKernelGGL(mlp_rollout_fwd_kernel,
+                     dim3((B + kTrajPerBlock - 1) / kTrajPerBlock),
+                     dim3(kThreads), kFwdLds * sizeof(float), (hipStream_t)stream,
+                     A);
+  return check_launch("quad_mlp_rollout_fwd");
+}
+
+int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
+                             const float *actions, const float *ref,
+                             int ref_cols, const float *x1, const float *h,
+                             const unsigned *relu_mask, float dt,
+                             const ApgQuadParams *params,
+                             const ApgQuadLossWeights *weights,
+                             const ApgMlpPolicy *policy, int B, int H,
+                             float *loss_partials, float *loss, float *d_pre,
+                             float *d_zout, float *d_conv, float *grad_state0,
+                             float *workspace, apg_stream_t stream) {
+  if (int e = check_mlp(params, policy, B, H)) return e;
+  if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
+  if (ref_cols != 9 && ref_cols != 6) {
+    set_error("ref_cols must be 9 or 6");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
+      return check_launch("memset(loss)");
+    return APG_OK;
+  }
+  if (!state0 || !states || !actions || !ref || !x1 || !h || !relu_mask ||
+      !loss_partials || !d_pre || !d_zout || !d_conv || !workspace) {
+    set_error("NULL buffer");
+    return APG_ERR_ARG;
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (int e = raise_lds(mlp_rollout_bwd_kernel, kBwdLds)) return e;
+    attr = true;
+  }
+  BwdArgs A;
+  A.state0 = state0, A.states = states, A.actions = actions, A.ref = ref;
+  A.x1 = x1, A.h = h, A.mask = relu_mask;
+  A.loss_partials = loss_partials, A.d_pre = d_pre, A.d_zout = d_zout;
+  A.d_conv = d_conv, A.grad_state0 = grad_state0;
+  A.tables = workspace;
+  A.c = make_const(*params, dt);
+  A.w = *weights;
+  PackArgs P;
+  P.pol = *policy, P.dst = workspace;
+  hipLaunchKernelGGL(mlp_pack_bwd_kernel, dim3((kBwdLds + 255) / 256), dim3(256),
+                     0, st, P);
+  A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
+  const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
+  hipLaunchKernelGGL(mlp_rollout_bwd_kernel, dim3(blocks), dim3(kThreads),
+                     kBwdLds * sizeof(float), st, A);
+  if (int e = check_launch("quad_mlp_rollout_bwd")) return e;
+  if (loss)
+    return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave),
+                                  loss, st);
+  return APG_OK;
+}
+
+}  // extern "C"

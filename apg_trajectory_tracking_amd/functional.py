@@ -518,20 +518,47 @@ def _boff(dev, key, values):
     return _boff_cache[k]
 
 
-def planes_gemm(A, M, S, Bp, boff, bstride=0, with_ones=True):
-    """C[m][j] = sum_{s,n} A[m*S+s][n] * Bp[boff[j] + s*bstride][n] on the
-    matrix cores (apg_planes_gemm); A, Bp are [planes, N] fp32 tensors."""
+def planes_gemm(A, M, S, Bp, boff, bstride=0, with_ones=True, sdiv=1,
+                bstride2=0, N=None, out=None):
+    """C[m][j] = sum_{s,n} A[m*S+s][n] * Bp[boff[j] + (s//sdiv)*bstride +
+    (s%sdiv)*bstride2][n] on the matrix cores (apg_planes_gemm).  A, Bp are
+    fp32 tensors whose rows ("planes") hold N contiguous floats; `N` defaults
+    to A.shape[1] (pass it to re-interpret a buffer as shorter planes).
+    `out`: optional [M, >= J+ones] view (row stride = out.stride(0)) written
+    in place; returns the [M, J+ones] result."""
     require_device(A, Bp)
-    N = A.shape[1]
+    N = A.shape[1] if N is None else N
     J = boff.numel()
+    Jt = J + int(with_ones)
     ws = torch.empty(lib().apg_planes_gemm_workspace_floats(
-        J, int(with_ones), _GEMM_WGS), dtype=torch.float32, device=A.device)
-    C = torch.empty(M, J + int(with_ones), dtype=torch.float32, device=A.device)
+        M, J, int(with_ones), _GEMM_WGS), dtype=torch.float32, device=A.device)
+    if out is None:
+        out = torch.empty(M, Jt, dtype=torch.float32, device=A.device)
+    if out.stride(1) != 1 or out.shape[0] < M or out.shape[1] < Jt:
+        raise ValueError("planes_gemm: out must be [>=M, >=J+ones], unit column stride")
     check(lib().apg_planes_gemm(
-        ptr(A), M, S, ptr(Bp), boff.data_ptr(), J, bstride, int(with_ones),
-        Bp.shape[0], N, ptr(ws), _GEMM_WGS, ptr(C), stream_of(A)),
-        "apg_planes_gemm")
-    return C
+        ptr(A), M, S, ptr(Bp), boff.data_ptr(), J, bstride, sdiv, bstride2,
+        int(with_ones), Bp.numel() // N, N, ptr(ws), _GEMM_WGS,
+        out.data_ptr(), out.stride(0), stream_of(A)), "apg_planes_gemm")
+    return out[:M, :Jt]
+
+
+def _conv_weight_grad(d_conv, inr, s0, states, B, H, out=None):
+    """d conv_ref.weight / bias from the conv cotangent planes d_conv
+    [160][H*B] (plane = ch*8 + pos): the windows are read in place from the
+    reference tensor inr [2H][9][B] with segment = (pos, step); the
+    relative-position shift of columns 0..2 is a second small product with
+    the positions before each step.  Returns [20, 28] = [dW (c-major, tap) | db]."""
+    dev = d_conv.device
+    boff = _boff(dev, "conv", [t * 9 + c for c in range(9) for t in range(3)])
+    c1 = planes_gemm(d_conv, 20, 8 * H, inr.reshape(2 * H * 9, B), boff,
+                     bstride=9, sdiv=H, bstride2=9, N=B, out=out)
+    prev = torch.cat((s0[None], states[:-1]), 0)                # [H,12,B]
+    c2 = planes_gemm(d_conv, 20, 8 * H, prev.reshape(H * 12, B),
+                     _boff(dev, "pos", [0, 1, 2]), bstride=0, sdiv=H,
+                     bstride2=12, N=B, with_ones=False)
+    c1[:, :9].view(20, 3, 3).sub_(c2[:, :, None])
+    return c1
 
 
 class _QuadLstmRolloutLoss(torch.autograd.Function):
@@ -611,14 +638,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         c2 = planes_gemm(d_zout, 4, 1, acts,
                          _boff(dev, "out", list(range(191, 199)))) * g
         d_w_out, d_b_out = c2[:, :8], c2[:, 8]
-        # conv weight: windows made relative to the position BEFORE each step;
-        # dW[ch][c][t] = sum_{pos,n} d_conv[ch*8+pos][n] * win[(pos+t)*9+c][n]
-        pos = torch.cat((s0[None, :3], states[:-1, :3]), 0)        # [H,3,B]
-        win = inr.unfold(0, H, 1)[:H].permute(3, 1, 0, 2).clone()  # [r,9,k,B]
-        win[:, :3] -= pos.permute(1, 0, 2)[None]
-        c3 = planes_gemm(d_conv, 20, 8, win.reshape(90, N),
-                         _boff(dev, "conv", [t * 9 + c for c in range(9)
-                                             for t in range(3)]), bstride=9) * g
+        c3 = _conv_weight_grad(d_conv, inr, s0, states, B, H) * g
         d_conv_w, d_conv_b = c3[:, :27].reshape(20, 9, 3), c3[:, 27]
         grads = [d_conv_w, d_conv_b, d_w_ih, d_w_hh, d_b, d_b, d_w_out, d_b_out]
         return (None, None, None, None, None, *grads, None, None, None)
@@ -633,4 +653,104 @@ def quad_lstm_rollout_loss(net, state0, in_ref, ref, dt, params, h0, c0,
         state0, in_ref, ref, h0, c0, net.conv_ref.weight, net.conv_ref.bias,
         net.lstm.weight_ih, net.lstm.weight_hh, net.lstm.bias_ih,
         net.lstm.bias_hh, net.fc_out.weight, net.fc_out.bias, dt, params,
+        weights or quad_loss_weights())
+
+
+# ------------------------------- fused autoregressive MLP-policy unroll (K8)
+class _QuadMlpRolloutLoss(torch.autograd.Function):
+    """loss of the autoregressive unroll with the MLP policy inside the
+    kernel (apg_quad_mlp_rollout_fwd / _bwd, matrix cores).  Same contract as
+    _QuadLstmRolloutLoss; the network is hutter_model.Net(15, 10, 9, 4,
+    conv=1)."""
+
+    @staticmethod
+    def forward(ctx, state0, in_ref, ref, w_s, b_s, conv_w, conv_b, w_1, b_1,
+                w_2, b_2, w_3, b_3, w_out, b_out, dt, params, weights):
+        B = state0.shape[0]
+        H = 10
+        if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
+            raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
+        if (w_s.shape != (64, 15) or conv_w.shape != (20, 9, 3)
+                or w_1.shape != (64, 224) or w_out.shape != (4, 64)):
+            raise ValueError("fused path needs Net(15, 10, 9, 4, conv=1)")
+        N = H * B
+        if 256 * N * 4 >= 2 ** 32:
+            raise ValueError("batch too large for one fused launch "
+                             "(B <= 400 000); split it")
+        dev = state0.device
+        s0 = _f32c(state0).t().contiguous()
+        inr = _f32c(in_ref[:, :2 * H]).permute(1, 2, 0).contiguous()
+        rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
+        names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
+                 "w_3", "b_3", "w_out", "b_out")
+        pw = dict(zip(names, (_f32c(v).contiguous() for v in (
+            w_s, b_s, conv_w, conv_b, w_1, b_1, w_2, b_2, w_3, b_3, w_out,
+            b_out))))
+        require_device(s0, inr, rf, *pw.values())
+        pol = _capi.ApgMlpPolicy(**{k: ptr(v) for k, v in pw.items()})
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        states, actions = new(H, 12, B), new(H, 4, B)
+        # everything the weight-gradient GEMMs read as B operand:
+        # feat (15 planes) | x1 (224) | h1, h2, h3 (192)
+        acts = new(431, N)
+        feat, x1, h = acts[:15], acts[15:239], acts[239:431]
+        relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
+        st = stream_of(s0)
+        ws = new(lib().apg_quad_mlp_workspace_floats())
+        check(lib().apg_quad_mlp_rollout_fwd(
+            ptr(s0), ptr(inr), float(dt), ctypes.byref(params),
+            ctypes.byref(pol), B, H, ptr(states), ptr(actions), ptr(feat),
+            ptr(x1), ptr(h), relu_mask.data_ptr(), ptr(ws), st),
+            "apg_quad_mlp_rollout_fwd")
+        partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
+        loss = new(1)
+        d_pre, d_zout, d_conv = new(256, N), new(4, N), new(160, N)
+        check(lib().apg_quad_mlp_rollout_bwd(
+            ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1], ptr(x1),
+            ptr(h), relu_mask.data_ptr(), float(dt), ctypes.byref(params),
+            ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
+            ptr(loss), ptr(d_pre), ptr(d_zout), ptr(d_conv), None, ptr(ws),
+            st), "apg_quad_mlp_rollout_bwd")
+        ctx.save_for_backward(s0, inr, states, acts, d_pre, d_zout, d_conv)
+        ctx.mark_non_differentiable(states, actions)
+        ctx.dims = (B, H)
+        return loss.reshape(()), states, actions
+
+    @staticmethod
+    def backward(ctx, g, _gs, _ga):
+        s0, inr, states, acts, d_pre, d_zout, d_conv = ctx.saved_tensors
+        B, H = ctx.dims
+        N = H * B
+        dev = s0.device
+        # every gradient is a view of ONE flat buffer, scaled by g once
+        sizes = [64 * 225, 64 * 65, 64 * 65, 64 * 16, 4 * 65, 20 * 28]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        c1, c2, c3, cs, co, cc = (
+            v.view(r, -1) for v, r in zip(flat.split(sizes), (64, 64, 64, 64, 4, 20)))
+        R = lambda lo, hi_: _boff(dev, ("mlp", lo, hi_), list(range(lo, hi_)))
+        # acts planes: feat 0..14 | x1 15..238 | h1 239.. | h2 303.. | h3 367..
+        planes_gemm(d_pre[0:64], 64, 1, acts, R(15, 127), with_ones=False, out=c1)
+        planes_gemm(d_pre[0:64], 64, 1, acts, R(127, 239), out=c1[:, 112:])
+        planes_gemm(d_pre[64:128], 64, 1, acts, R(239, 303), out=c2)
+        planes_gemm(d_pre[128:192], 64, 1, acts, R(303, 367), out=c3)
+        planes_gemm(d_pre[192:256], 64, 1, acts, R(0, 15), out=cs)
+        planes_gemm(d_zout, 4, 1, acts, R(367, 431), out=co)
+        _conv_weight_grad(d_conv, inr, s0, states, B, H, out=cc)
+        flat *= g
+        grads = [cs[:, :15], cs[:, 15], cc[:, :27].reshape(20, 9, 3), cc[:, 27],
+                 c1[:, :224], c1[:, 224], c2[:, :64], c2[:, 64],
+                 c3[:, :64], c3[:, 64], co[:, :64], co[:, 64]]
+        return (None, None, None, *grads, None, None, None)
+
+
+def quad_mlp_rollout_loss(net, state0, in_ref, ref, dt, params, weights=None):
+    """Fused autoregressive unroll for a `Net(15, 10, 9, 4, conv=1)` policy
+    (train_mode "autoregressive", scripts/train_drone.py:113-173).  Returns
+    (loss, states [H,12,B], actions [H,4,B]); `loss.backward()` fills the
+    gradients of every used parameter of `net`."""
+    return _QuadMlpRolloutLoss.apply(
+        state0, in_ref, ref, net.states_in.weight, net.states_in.bias,
+        net.conv_ref.weight, net.conv_ref.bias, net.fc1.weight, net.fc1.bias,
+        net.fc2.weight, net.fc2.bias, net.fc3.weight, net.fc3.bias,
+        net.fc_out.weight, net.fc_out.bias, dt, params,
         weights or quad_loss_weights())

@@ -79,6 +79,11 @@ class TrainDrone(TrainBase):
                     self.delta_t, self.train_dynamics.params,
                     self.net.hidden_state, self.net.cell_state)
                 return self._step(loss)
+        elif self.fused_policy and self._fusable_mlp():
+            loss, _, _ = F.quad_mlp_rollout_loss(
+                self.net, current_state, in_ref_states, ref_states,
+                self.delta_t, self.train_dynamics.params)
+            return self._step(loss)
         states, actions = [], []
         for k in range(self.horizon):
             rel = in_ref_states[:, k:k + self.horizon].clone()
@@ -101,6 +106,16 @@ class TrainDrone(TrainBase):
                 and n.lstm.weight_ih.shape == (32, 175)
                 and n.conv_ref.weight.shape == (20, 9, 3)
                 and n.fc_out.weight.shape == (4, 8))
+
+    def _fusable_mlp(self):
+        n = self.net
+        return (isinstance(n, Net) and n.conv and self.horizon == 10
+                and self.train_mode == "autoregressive"
+                and hasattr(self.train_dynamics, "params")
+                and n.states_in.weight.shape == (64, 15)
+                and n.conv_ref.weight.shape == (20, 9, 3)
+                and n.fc1.weight.shape == (64, 224)
+                and n.fc_out.weight.shape == (4, 64))
 
     def train_controller_model(
         self, current_state, action_seq, in_ref_states, ref_states

@@ -207,21 +207,88 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               float *grad_h0, float *grad_c0,
                               apg_stream_t stream);
 
+/* ------------------------------------------- quad, MLP policy in-kernel ---- */
+/* hutter_model.Net with the conv branch (neural_control/models/
+ * hutter_model.py:6-49) for state_dim 15, horizon 10, ref_dim 9, 4 actions:
+ * Linear(15 -> 64), conv1d(9 -> 20, k = 3), fc1 (224 -> 64), fc2, fc3
+ * (64 -> 64), fc_out (64 -> 4).  Device pointers to the plain row-major
+ * torch parameters (the kernels gather them into matrix-core operand order
+ * themselves). */
+typedef struct ApgMlpPolicy {
+  const float *w_s;    /* [64][15]   states_in.weight */
+  const float *b_s;    /* [64] */
+  const float *conv_w; /* [20][9][3] conv_ref.weight */
+  const float *conv_b; /* [20] */
+  const float *w_1;    /* [64][224]  fc1.weight (inputs: s1, then conv ch-major) */
+  const float *b_1;    /* [64] */
+  const float *w_2;    /* [64][64]   fc2.weight */
+  const float *b_2;    /* [64] */
+  const float *w_3;    /* [64][64]   fc3.weight */
+  const float *b_3;    /* [64] */
+  const float *w_out;  /* [4][64]    fc_out.weight */
+  const float *b_out;  /* [4] */
+} ApgMlpPolicy;
+
+/* Fused AUTOREGRESSIVE unroll, forward sweep: the loop of
+ * TrainDrone.train_recurrent_model (scripts/train_drone.py:134-157) for
+ * train_mode "autoregressive" - per step: window relative to the current
+ * position (copied), state_preprocessing, Net.forward,
+ * sigmoid, FlightmareDynamics.  SoA only: state0 [12][B], in_ref [2H][9][B].
+ * Outputs (N = H*B, plane index = step*B + trajectory):
+ *   states [H][12][B], actions [H][4][B], feat [15][N],
+ *   x1 [224][N] (tanh state branch, relu conv), h [192][N] (h1, h2, h3),
+ *   relu_mask [5][N].
+ * `workspace`: apg_quad_mlp_workspace_floats() floats of scratch (the weights
+ * re-ordered into matrix-core operand order by a small pre-kernel); the
+ * forward and the reverse call may share it (same stream).  B <= 419 430. */
+int apg_quad_mlp_workspace_floats(void);
+int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
+                             const ApgQuadParams *params,
+                             const ApgMlpPolicy *policy, int B, int H,
+                             float *states, float *actions, float *feat,
+                             float *x1, float *h, unsigned *relu_mask,
+                             float *workspace, apg_stream_t stream);
+
+/* Reverse sweep of the above + quad_mpc_loss on ref[:, :H]
+ * (scripts/train_drone.py:159-168).  loss_partials:
+ * apg_quad_mlp_loss_partials_count(B) floats.
+ * Cotangent planes for the weight gradients (apg_planes_gemm):
+ *   d_pre [256][N] = pre-activation cotangents of fc1, fc2, fc3, states_in
+ *   (64 planes each, in this order), d_zout [4][N], d_conv [160][N];
+ *   dW_1 = d_pre1 x1^T, dW_2 = d_pre2 h1^T, dW_3 = d_pre3 h2^T,
+ *   dW_s = d_pre_s feat^T, dW_out = d_zout h3^T, biases = row sums,
+ *   dconv_w as for the LSTM policy.  Optional grad_state0 [12][B]. */
+int apg_quad_mlp_loss_partials_count(int B);
+int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
+                             const float *actions, const float *ref,
+                             int ref_cols, const float *x1, const float *h,
+                             const unsigned *relu_mask, float dt,
+                             const ApgQuadParams *params,
+                             const ApgQuadLossWeights *weights,
+                             const ApgMlpPolicy *policy, int B, int H,
+                             float *loss_partials, float *loss, float *d_pre,
+                             float *d_zout, float *d_conv, float *grad_state0,
+                             float *workspace, apg_stream_t stream);
+
 /* "Planes x planes" reduction GEMM on the matrix cores
  * (v_mfma_f32_32x32x2_f32, exact fp32):
- *   C[m][j] = sum_{s<S} sum_{n<N} A[(m*S + s)*N + n] * B[(boff[j] + s*bstride)*N + n]
- * for m < M <= 32, j < J (J + with_ones <= 192); with_ones appends one
- * column C[m][J] = sum_{s,n} A[...] (row sums).  Turns the cotangent planes
- * of apg_quad_lstm_rollout_bwd into weight gradients - the role torch.autograd
- * plays for the parameters in scripts/train_drone.py:168.  `boff` is a DEVICE
- * int array [J]; `workspace` holds apg_planes_gemm_workspace_floats(J,
- * with_ones, num_wg) floats; C is [M][J + with_ones] row-major.  B holds
- * `b_planes` planes; A (M*S planes) and B must each stay below 4 GiB. */
-int apg_planes_gemm_workspace_floats(int J, int with_ones, int num_wg);
+ *   C[m*ldc + j] = sum_{s<S} sum_{n<N} A[(m*S + s)*N + n] * B[bplane(j,s)*N + n]
+ *   bplane(j, s) = boff[j] + (s / sdiv) * bstride + (s % sdiv) * bstride2
+ * for m < M <= 64, j < J (J + with_ones <= 192, <= 128 when M > 32);
+ * with_ones appends one column C[m][J] = sum_{s,n} A[...] (row sums).  Turns
+ * the cotangent planes of apg_quad_lstm_rollout_bwd / apg_quad_mlp_rollout_bwd
+ * into weight gradients - the role torch.autograd plays for the parameters in
+ * scripts/train_drone.py:168.  The two-level segment stride reads the sliding
+ * reference windows of the conv branch in place (segment = (window position,
+ * step), sdiv = H).  `boff` is a DEVICE int array [J]; `workspace` holds
+ * apg_planes_gemm_workspace_floats(M, J, with_ones, num_wg) floats; C has row
+ * stride ldc >= J + with_ones.  B holds `b_planes` planes; A (M*S planes) and
+ * B must each stay below 4 GiB. */
+int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg);
 int apg_planes_gemm(const float *A, int M, int S, const float *B,
-                    const int *boff, int J, int bstride, int with_ones,
-                    int b_planes, long long N, float *workspace, int num_wg,
-                    float *C, apg_stream_t stream);
+                    const int *boff, int J, int bstride, int sdiv, int bstride2,
+                    int with_ones, int b_planes, long long N, float *workspace,
+                    int num_wg, float *C, int ldc, apg_stream_t stream);
 
 /* ---------------------------------------------------------- fixed wing --- */
 /* Parameters of neural_control/dynamics/fixed_wing_dynamics.py:18-39 +

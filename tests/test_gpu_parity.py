@@ -573,6 +573,8 @@ def test_planes_gemm_mfma_vs_torch(dev):
     g = torch.Generator().manual_seed(0)
     for (M, S, P, J, bstride, N) in ((32, 1, 199, 183, 0, 6400),
                                      (4, 1, 16, 8, 0, 777),
+                                     (64, 1, 140, 112, 0, 3000),
+                                     (64, 1, 20, 15, 0, 515),
                                      (20, 8, 90, 27, 9, 1300)):
         A = torch.randn(M * S, N, generator=g).to(dev)
         Bp = (torch.randn(P, N, generator=g) + torch.arange(P)[:, None] * 0.01).to(dev)
@@ -591,3 +593,21 @@ def test_planes_gemm_mfma_vs_torch(dev):
                 ref[m, :J] += rows @ a
                 ref[m, J] += a.sum()
         assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
+    # two-level segment stride (segment = (pos, step)) into a strided output
+    H, Bn = 5, 200
+    A = torch.randn(20 * 8 * H, Bn, generator=g).to(dev)       # [ch][pos][k] planes
+    inr = torch.randn((H + 9) * 9, Bn, generator=g).to(dev)     # [row][9] planes
+    offs = [t * 9 + c for c in range(9) for t in range(3)]
+    boff = torch.tensor(offs, dtype=torch.int32, device=dev)
+    out = torch.zeros(20, 40, device=dev)
+    C = F.planes_gemm(A, 20, 8 * H, inr, boff, bstride=9, sdiv=H, bstride2=9,
+                      out=out[:, 5:])
+    assert C.data_ptr() == out[:, 5:].data_ptr() and float(out[:, :5].abs().sum()) == 0
+    A64, B64 = A.double().cpu().view(20, 8, H, Bn), inr.double().cpu()
+    ref = torch.zeros(20, 28, dtype=torch.float64)
+    for pos in range(8):
+        for k in range(H):
+            rows = torch.stack([B64[o + (pos + k) * 9] for o in offs])   # [27,Bn]
+            ref[:, :27] += A64[:, pos, k] @ rows.t()
+            ref[:, 27] += A64[:, pos, k].sum(1)
+    assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5

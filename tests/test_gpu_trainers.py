@@ -123,8 +123,8 @@ def test_quad_recurrent_unroll(dev, mode):
             net.hidden_state, net.cell_state = h0.clone(), c0.clone()
         net.reset_hidden_state = fixed_reset
     in_ref_before = in_ref.clone()
-    for fused in ((False, True) if mode == "lstm" else (False,)):
-        trainer.fused_policy = fused   # K7 (policy in-kernel) vs per-step kernels
+    for fused in (False, True):
+        trainer.fused_policy = fused   # K7/K8 (policy in-kernel) vs per-step kernels
         loss = trainer.train_recurrent_model(None, state0, in_ref, ref)
         assert torch.equal(in_ref, in_ref_before)   # the window is copied
         assert abs(loss.item() - g[f"{mode}.loss"]) / g[f"{mode}.loss"] < 2e-5
@@ -244,6 +244,65 @@ def test_fused_lstm_rollout_matches_reference_unroll(dev):
         if key in g.files:
             assert p.grad is not None, k
             assert rel_err(N(p.grad), g[key]) < 2e-4, k
+
+
+def test_fused_mlp_rollout_matches_reference_unroll(dev):
+    """K8: policy-in-kernel autoregressive unroll (MFMA) vs the golden
+    autoregressive unroll (G4): states, actions, loss, parameter gradients."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    g = load_golden("quad_recurrent.npz")
+    net = Net(15, 10, 9, 4, conv=1)
+    load_weights(net, g, "ar.w.")
+    net.to(dev)
+    dyn = FlightmareDynamics()
+    state0, in_ref, ref = (D(g["state0"], dev), D(g["in_ref"], dev),
+                           D(g["ref"], dev))
+    loss, states, actions = F.quad_mlp_rollout_loss(
+        net, state0, in_ref, ref, float(g["dt"]), dyn.params)
+    loss.backward()
+    assert rel_err(N(actions.permute(2, 0, 1)), g["ar.actions"]) < 2e-5
+    assert rel_err(N(states.permute(2, 0, 1)), g["ar.states"]) < 2e-5
+    assert abs(loss.item() - g["ar.loss"]) / g["ar.loss"] < 2e-5
+    for k, p in net.named_parameters():
+        key = f"ar.g.{k}"
+        if key in g.files:
+            assert p.grad is not None, k
+            assert rel_err(N(p.grad), g[key]) < 2e-4, k
+
+
+@pytest.mark.parametrize("B", [1, 100, 300])
+def test_fused_mlp_ragged_batches_match_unfused(dev, B):
+    """K8 on batch sizes that do not fill a wave / workgroup."""
+    import copy
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    cfg = dict(QUAD_CFG, batch_size=B, train_mode="autoregressive")
+    d = synthetic.quad_polynomial_batch(B, 10, 0.1, seed=70 + B, ref_length=20)
+    state0, in_ref, ref = (d["state0"].to(dev), d["in_ref"].to(dev),
+                           d["ref"].to(dev))
+    torch.manual_seed(9)
+    base = Net(15, 10, 9, 4, conv=1)
+    results = []
+    for fused in (False, True):
+        trainer = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), dict(cfg))
+        net = copy.deepcopy(base).to(dev)
+        trainer.net = net
+        trainer.fused_policy = fused
+        trainer.optimizer_controller = torch.optim.SGD(net.parameters(), lr=0.0)
+        loss = trainer.train_recurrent_model(None, state0, in_ref, ref)
+        results.append((loss.item(), {k: N(p.grad) for k, p in
+                                      net.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = results
+    assert abs(l0 - l1) / abs(l0) < 1e-5
+    assert set(g0) == set(g1)
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 2e-4, k
 
 
 def test_wing_and_cartpole_run_epoch(dev):

@@ -6,7 +6,8 @@ on one MI355X for DESIGN.md).  Prints one JSON object per line.
   wing      config 4: fixed-wing concurrent, H = 20, B = 131 072 (fused kernel)
   cartpole  config 1: B = 64, H = 5 (fused kernel; launch-latency bound)
   quad_aos  config 2 through the reference's row-major tensors
-  quad_ar   config 3 shape per GPU: autoregressive unroll, policy in the loop
+  quad_ar_* config 3 shape per GPU: autoregressive unroll, policy in the loop
+            (unfused: torch policy + step kernels; fused: mlp.hip)
   quad_lstm config 5: LSTM unroll
   quad_train config 2 as a FULL training step (policy fwd/bwd + rollout + SGD)
 """
@@ -108,7 +109,7 @@ def main():
         t = TrainDrone(qdyn, qdyn, cfg)
         torch.manual_seed(0)
         t.initialize_model(device=dev, seed=0)
-        t.hidden_generator = torch.Generator().manual_seed(1)
+        t.hidden_generator = torch.Generator(device=dev).manual_seed(1)  # draw on the GPU
         return t
 
     if want("quad_train"):
@@ -132,7 +133,8 @@ def main():
             t._step(loss)
         emit("quad_train_step_soa_head", B, H, timed(step_soa, 30, 5))
 
-    for mode, name, fused in (("autoregressive", "quad_ar", False),
+    for mode, name, fused in (("autoregressive", "quad_ar_unfused", False),
+                              ("autoregressive", "quad_ar_fused", True),
                               ("LSTM", "quad_lstm_unfused", False),
                               ("LSTM", "quad_lstm_fused", True)):
         if want(name):
