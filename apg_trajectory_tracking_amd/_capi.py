@@ -117,7 +117,7 @@ SIGNATURES = {
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy),
         _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
-    "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I,
+    "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I,
                         ctypes.c_longlong, _P, _I, _P, _I, _P],
     "apg_wing_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,
                           _P, _P],

@@ -2,147 +2,177 @@
 //
 // The weight gradients of the in-kernel policies (lstm.hip, mlp.hip) are
 //   C[m][j] = sum_{s < S} sum_{n < N} A[(m*S + s)][n] * B[bplane(j, s)][n]
-//   bplane(j, s) = boff[j] + (s / sdiv) * bstride + (s % sdiv) * bstride2
+//   bplane(j, s) = bdesc[0][j] + (s / sdiv) * bdesc[1][j] + (s % sdiv) * bdesc[2][j]
 // with small M (<= 64), small J (<= 192) and an enormous reduction length
 // (S * N = 655 360 ... 5 242 880 at the benchmark batch).  Every operand row is
 // a plane of N contiguous floats ("NT" layout: the reduction index is the
 // contiguous one).  rocBLAS picks a 16x16 macro-tile without split-K for this
 // shape and takes 1.5 ms per call; this kernel streams both operands from HBM
-// once and is bound by that stream.  The two-level segment stride lets the
-// conv-weight gradient read the sliding reference windows straight from the
-// [2H][9][B] reference tensor (segment = (window position, step)) instead of
-// from a materialised [90][H*B] copy.
+// once and is bound by that stream.  The per-column two-level segment stride
+// lets the conv-weight gradient read the sliding reference windows straight
+// from the [2H][9][B] reference tensor (segment = (window position, step))
+// and the positions before each step from the state planes in the same pass,
+// instead of from a materialised [90][H*B] copy.
 //
-// Structure: the S*N reduction range is cut into tiles of 64; workgroups take
-// tiles grid-strided.  A tile is staged in LDS as [row][64 (+1 pad)] with
-// coalesced dword row-segment loads, then each of the 4 waves multiplies 8 of
-// the tile's 32 k-pairs for ALL row / column blocks with
-// v_mfma_f32_32x32x2_f32 (exact f32, 16 accumulator registers per 32x32
-// block; an A fragment is reused by every column block, a B fragment by both
-// row blocks).  Accumulators stay in registers across tiles; at the end the 4
-// waves are summed through LDS and the workgroup writes one partial C; a
-// second kernel adds the partials in a fixed order (deterministic, no float
-// atomics).  An optional extra column of ones yields the row sums (bias
-// gradients) for free.
+// Structure: the S*N reduction range is cut into tiles of 64 columns;
+// workgroups take tiles grid-strided.  A tile ((MB + NB) * 32 operand rows x
+// 64 columns) goes global -> LDS by direct-to-LDS DMA, 16 bytes per lane: one
+// wave instruction moves a GROUP of 4 rows x 64 columns (1 KiB; 256 contiguous
+// bytes per plane), so the big shape needs 12 instructions per wave and tile,
+// no staging registers, no ds_write and no VALU.  Inside a group the 16-byte
+// chunk of (row r, columns 4c..4c+3) sits in slot r*16 + (c ^ 4r): the source
+// address per lane is free, so the swizzle costs nothing and spreads the
+// MFMA fragment reads over the banks.  LDS is double-buffered: the DMA of
+// tile t+1 is in flight while tile t is multiplied, ONE barrier per tile.
+// Each of the 4 waves multiplies 8 of the tile's 32 k-pairs for ALL row /
+// column blocks with v_mfma_f32_32x32x2_f32 (exact f32; an A fragment is
+// reused by every column block, a B fragment by both row blocks).
+// Accumulators stay in registers across tiles; at the end the 4 waves are
+// summed through LDS and the workgroup writes one partial C; a second kernel
+// adds the partials in a fixed order (deterministic, no float atomics).  The
+// optional extra column of row sums (bias gradients) is accumulated on the
+// VALU from the A fragments the lanes read anyway.
 #include "apg_device.h"
 
 namespace apg {
 namespace {
 
 constexpr int kKT = 64;        // reduction elements per tile
-constexpr int kLd = kKT + 1;   // padded LDS row
+constexpr int kGS = 4 * kKT + 4;  // floats per 4-row group in LDS (16 B pad)
 constexpr int kMaxNB = 6;      // column blocks of 32 (J + ones <= 192)
 constexpr int kThreads = 256;
+constexpr unsigned kDeadOff = 0x80000000u;  // beyond any operand (< 2 GiB each)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void *lds_ptr;
 
 struct GemmArgs {
   const float *A, *Bp;
-  const int *boff;
+  const int *bdesc;  // [3][J]: plane offset, stride per s / sdiv, stride per s % sdiv
   float *part;  // [gridDim.x][MB*32][NB*32]
   long long N, a_bytes, b_bytes;
-  int M, S, J, bstride, sdiv, bstride2, with_ones, tiles_per_seg;
+  int M, S, J, sdiv, with_ones, tiles_per_seg;
 };
+
+// LDS float index of element (row, col) of a tile buffer
+__device__ __forceinline__ int tile_index(int row, int col) {
+  const int r = row & 3;
+  return (row >> 2) * kGS + (r << 6) + ((((col >> 2) ^ (r << 2))) << 2) + (col & 3);
+}
 
 template <int MB, int NB>
 __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
-  extern __shared__ float lds[];  // (MB*32 + NB*32) rows of kLd floats
-  float *la = lds, *lb = lds + MB * 32 * kLd;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NG = (MB + NB) * 8;  // 4-row groups per tile
+  constexpr int GI = NG / 4;         // groups (= DMA instructions) per wave
+  constexpr int BUF = NG * kGS;      // floats per tile buffer
+  constexpr int W = NB * 32;
   const int tid = threadIdx.x, lane = tid & 63;
-  // the wave index is wave-uniform; tell the compiler, so that everything
-  // derived from it (row numbers, plane offsets) lives in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane;  // column of the tile this lane stages
-  const int Jt = G.J + G.with_ones;
-  constexpr int RA = MB * 8, RB = NB * 8;  // rows staged per wave (row = wave + 4 i)
   f32x16 acc[MB][NB];
+  float rsum[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+  for (int mb = 0; mb < MB; ++mb) {
+    rsum[mb] = 0.f;
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][jb][i] = 0.f;
+  }
+  // padding rows are never written by the DMA: zero both buffers once
+  for (int i = tid; i < 2 * BUF; i += kThreads) lds[i] = 0.f;
 
-  // Branch-free staging through buffer resources: per-lane column offset in a
-  // VGPR, the row's plane offset in an SGPR (row numbers are wave-uniform).
-  // EVERY row is loaded unconditionally - padding rows and the ones row read
-  // plane 0 - and is turned into what it should be by one FMA when it is
-  // written to LDS:   real row: v*1 + 0   padding: v*0 + 0   ones: v*0 + 1.
-  // No conditional touches a loaded value before that point, so all loads of
-  // a tile are in flight together and overlap the previous tile's MFMAs.
   const unsigned plane_bytes = (unsigned)(G.N * 4);
   const auto rA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(G.A), 0, (unsigned)G.a_bytes, 0x00020000);
   const auto rB = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(G.Bp), 0, (unsigned)G.b_bytes, 0x00020000);
-
-  float va[RA], vb[RB];
-  float keep = 1.f;  // 0 for the lanes of a ragged last tile beyond N
-  auto fetch = [&](long long tile) {  // issue every load of a tile, no waits
-    const int s = (int)(tile / G.tiles_per_seg);
-    const int sb = (s / G.sdiv) * G.bstride + (s % G.sdiv) * G.bstride2;
-    const long long n = (tile % G.tiles_per_seg) * kKT + col;
-    keep = n < G.N ? 1.f : 0.f;
-    const int voff = (int)((n < G.N ? n : G.N - 1) * 4);
+  // this lane's slot of a group: row (lane >> 4), source column chunk cgs
+  const int r_in = lane >> 4, cgs = (lane & 15) ^ (r_in << 2);
+  unsigned rowoff[GI];  // byte offset of the lane's row + chunk (segment 0)
+  unsigned bs1[NB * 2], bs2[NB * 2];  // B rows: bytes per s / sdiv, per s % sdiv
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int r = wave + 4 * i;
-      const int plane = r < G.M ? r * G.S + s : 0;
-      va[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                  rA, voff, (unsigned)plane * plane_bytes, 0));
+  for (int i = 0; i < GI; ++i) {
+    const int row = (wave + 4 * i) * 4 + r_in;
+    if (i < MB * 2) {
+      rowoff[i] = row < G.M ? (unsigned)(row * G.S) * plane_bytes + cgs * 16 : kDeadOff;
+    } else {
+      const int j = row - MB * 32, jc = j < G.J ? j : 0;
+      rowoff[i] = j < G.J ? (unsigned)G.bdesc[jc] * plane_bytes + cgs * 16 : kDeadOff;
+      bs1[i - MB * 2] = j < G.J ? (unsigned)G.bdesc[G.J + jc] * plane_bytes : 0u;
+      bs2[i - MB * 2] = j < G.J ? (unsigned)G.bdesc[2 * G.J + jc] * plane_bytes : 0u;
     }
+  }
+  __syncthreads();
+
+  auto issue = [&](long long tile, int p) {  // DMA of one tile into buffer p
+    const int s = (int)(tile / G.tiles_per_seg);
+    const unsigned colb = (unsigned)(tile % G.tiles_per_seg) * (kKT * 4);
+    const unsigned sa = (unsigned)s * plane_bytes;
+    const unsigned s1 = (unsigned)(s / G.sdiv), s2 = (unsigned)(s % G.sdiv);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int r = wave + 4 * i;
-      const int plane = r < G.J ? G.boff[r] + sb : 0;
-      vb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                  rB, voff, (unsigned)plane * plane_bytes, 0));
+    for (int i = 0; i < GI; ++i) {
+      const int gi = wave + 4 * i;
+      const bool isA = i < MB * 2;
+      const int first = isA ? gi * 4 : gi * 4 - MB * 32;  // first row of the group
+      if (first < (isA ? G.M : G.J)) {                    // wave-uniform
+        if (isA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rA, (lds_ptr)(lds + p * BUF + gi * kGS), 16, (int)(rowoff[i] + colb),
+              (int)sa, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rB, (lds_ptr)(lds + p * BUF + gi * kGS), 16,
+              (int)(rowoff[i] + colb + s1 * bs1[i < MB * 2 ? 0 : i - MB * 2] +
+                    s2 * bs2[i < MB * 2 ? 0 : i - MB * 2]),
+              0, 0, 0);
+      }
     }
   };
 
+  const int lr = lane & 31, kh = lane >> 5;
+  const int lane_base =
+      (lr >> 2) * kGS + ((lr & 3) << 6) + ((wave ^ (lr & 3)) << 4) + kh;
   const long long total_tiles = (long long)G.S * G.tiles_per_seg;
   long long tile = blockIdx.x;
-  if (tile < total_tiles) fetch(tile);
-  for (; tile < total_tiles; tile += gridDim.x) {
-    // registers -> LDS ([row][kLd]: conflict-free for the stores and for the
-    // MFMA fragment reads below)
-    const float kp_ = keep;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int r = wave + 4 * i;
-      la[r * kLd + col] = va[i] * (r < G.M ? kp_ : 0.f);
+  int p = 0;
+  if (tile < total_tiles) issue(tile, 0);
+  for (; tile < total_tiles; tile += gridDim.x, p ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile landed (all waves); buffer p^1 is free again
+    const long long n0 = (tile % G.tiles_per_seg) * kKT;
+    if (G.N - n0 < kKT) {  // ragged last tile of a segment: zero A beyond N
+      const int rem = (int)(G.N - n0);
+      for (int e = tid; e < MB * 32 * kKT; e += kThreads)
+        if ((e & 63) >= rem) lds[p * BUF + tile_index(e >> 6, e & 63)] = 0.f;
+      __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int r = wave + 4 * i;
-      const float mul = r < G.J ? kp_ : 0.f;
-      const float add = (r >= G.J && r < Jt) ? kp_ : 0.f;  // ones column
-      lb[r * kLd + col] = fmaf(vb[i], mul, add);
-    }
-    __syncthreads();
-    // software pipeline: the next tile's loads fly while this one multiplies
-    if (tile + gridDim.x < total_tiles) fetch(tile + gridDim.x);
+    if (tile + gridDim.x < total_tiles) issue(tile + gridDim.x, p ^ 1);
+    const float *bp = lds + p * BUF + lane_base;
     // wave w owns k-pairs [8w, 8w+8) of the tile
 #pragma unroll
     for (int kp = 0; kp < 8; ++kp) {
-      const int kcol = 2 * (wave * 8 + kp) + (lane >> 5);
       float a[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) a[mb] = la[(mb * 32 + (lane & 31)) * kLd + kcol];
+      for (int mb = 0; mb < MB; ++mb) {
+        a[mb] = bp[mb * 8 * kGS + 2 * kp];
+        rsum[mb] += a[mb];
+      }
 #pragma unroll
       for (int jb = 0; jb < NB; ++jb) {
-        const float b = lb[(jb * 32 + (lane & 31)) * kLd + kcol];
+        const float b = bp[(MB + jb) * 8 * kGS + 2 * kp];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
           acc[mb][jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b, acc[mb][jb], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
   // sum the 4 waves through LDS (reuse the tile buffers): [MB*32][NB*32]
   // C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float *red = lds;
-  constexpr int W = NB * 32;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) rsum[mb] += __shfl_xor(rsum[mb], 32, 64);
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -156,6 +186,11 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
             if (w == 0) red[row * W + cc] = acc[mb][jb][i];
             else red[row * W + cc] += acc[mb][jb][i];
           }
+    }
+    __syncthreads();
+    if (wave == w && G.with_ones && lane < 32) {  // row sums -> column J
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) red[(mb * 32 + lane) * W + G.J] += rsum[mb];
     }
     __syncthreads();
   }
@@ -194,7 +229,7 @@ __global__ __launch_bounds__(256) void planes_gemm_reduce_kernel(
 
 template <int MB, int NB>
 int launch(const GemmArgs &G, int num_wg, hipStream_t st) {
-  const size_t lds = (size_t)(MB * 32 + NB * 32) * kLd * sizeof(float);
+  const size_t lds = (size_t)2 * (MB + NB) * 8 * kGS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)planes_gemm_kernel<MB, NB>,
@@ -233,11 +268,11 @@ int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg) {
 }
 
 int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
-                    const int *boff, int J, int bstride, int sdiv, int bstride2,
-                    int with_ones, int b_planes, long long N, float *workspace,
-                    int num_wg, float *C, int ldc, apg_stream_t stream) {
+                    const int *bdesc, int J, int sdiv, int with_ones,
+                    int b_planes, long long N, float *workspace, int num_wg,
+                    float *C, int ldc, apg_stream_t stream) {
   const int Jt = J + (with_ones ? 1 : 0);
-  if (!A || !Bp || !boff || !workspace || !C) {
+  if (!A || !Bp || !bdesc || !workspace || !C) {
     set_error("apg_planes_gemm: NULL pointer");
     return APG_ERR_ARG;
   }
@@ -250,16 +285,16 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
   }
   const long long a_bytes = (long long)M * S * N * 4;
   const long long b_bytes = (long long)b_planes * N * 4;
-  if (b_planes < 1 || a_bytes >= (1ll << 32) || b_bytes >= (1ll << 32)) {
-    set_error("apg_planes_gemm: operands must be smaller than 4 GiB each "
+  if (b_planes < 1 || a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) {
+    set_error("apg_planes_gemm: operands must be smaller than 2 GiB each "
               "(32-bit buffer offsets); split the batch");
     return APG_ERR_ARG;
   }
   GemmArgs G;
-  G.A = A, G.Bp = Bp, G.boff = boff, G.part = workspace;
+  G.A = A, G.Bp = Bp, G.bdesc = bdesc, G.part = workspace;
   G.a_bytes = a_bytes, G.b_bytes = b_bytes;
   G.N = N, G.M = M, G.S = S, G.J = J;
-  G.bstride = bstride, G.sdiv = sdiv, G.bstride2 = bstride2;
+  G.sdiv = sdiv;
   G.with_ones = with_ones ? 1 : 0;
   G.tiles_per_seg = (int)((N + kKT - 1) / kKT);
   hipStream_t st = (hipStream_t)stream;

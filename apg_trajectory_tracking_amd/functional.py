@@ -507,58 +507,85 @@ class RolloutPlan:
 
 
 # ----------------------------------------- fused LSTM-policy unroll (K7)
-_GEMM_WGS = 512
-_boff_cache = {}
+_GEMM_WGS = None   # None: sized from the LDS footprint (workgroups per CU x 256)
+_bdesc_cache = {}
 
 
-def _boff(dev, key, values):
+def make_bdesc(dev, offsets, stride1=0, stride2=0, key=None):
+    """Column descriptor of apg_planes_gemm: int32 [3, J] = plane offset and
+    the two segment strides of every column (scalars broadcast).  Cached per
+    device when a `key` is given (building it is a host-to-device copy)."""
     k = (str(dev), key)
-    if k not in _boff_cache:
-        _boff_cache[k] = torch.tensor(values, dtype=torch.int32, device=dev)
-    return _boff_cache[k]
+    if key is not None and k in _bdesc_cache:
+        return _bdesc_cache[k]
+    J = len(offsets)
+    bc = lambda v: list(v) if hasattr(v, "__len__") else [int(v)] * J
+    t = torch.tensor([list(offsets), bc(stride1), bc(stride2)],
+                     dtype=torch.int32, device=dev)
+    if key is not None:
+        _bdesc_cache[k] = t
+    return t
 
 
-def planes_gemm(A, M, S, Bp, boff, bstride=0, with_ones=True, sdiv=1,
-                bstride2=0, N=None, out=None):
-    """C[m][j] = sum_{s,n} A[m*S+s][n] * Bp[boff[j] + (s//sdiv)*bstride +
-    (s%sdiv)*bstride2][n] on the matrix cores (apg_planes_gemm).  A, Bp are
-    fp32 tensors whose rows ("planes") hold N contiguous floats; `N` defaults
-    to A.shape[1] (pass it to re-interpret a buffer as shorter planes).
-    `out`: optional [M, >= J+ones] view (row stride = out.stride(0)) written
-    in place; returns the [M, J+ones] result."""
+def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None):
+    """C[m][j] = sum_{s,n} A[m*S+s][n] * Bp[bdesc[0][j] + (s//sdiv)*bdesc[1][j]
+    + (s%sdiv)*bdesc[2][j]][n] on the matrix cores (apg_planes_gemm).  A, Bp
+    are fp32 tensors whose rows ("planes") hold N contiguous floats; `N`
+    defaults to A.shape[1] (pass it to re-interpret a buffer as shorter
+    planes).  `bdesc`: make_bdesc(...).  `out`: optional [M, >= J+ones] view
+    (row stride = out.stride(0)) written in place; returns [M, J+ones]."""
     require_device(A, Bp)
     N = A.shape[1] if N is None else N
-    J = boff.numel()
+    J = bdesc.shape[1]
     Jt = J + int(with_ones)
+    wgs = _GEMM_WGS
+    if wgs is None:   # double-buffered tiles: 16.6 KB of LDS per 32-row block
+        blocks = (M + 31) // 32 + (Jt + 31) // 32
+        wgs = 256 * max(1, min(2, 9 // blocks))
     ws = torch.empty(lib().apg_planes_gemm_workspace_floats(
-        M, J, int(with_ones), _GEMM_WGS), dtype=torch.float32, device=A.device)
+        M, J, int(with_ones), wgs), dtype=torch.float32, device=A.device)
     if out is None:
         out = torch.empty(M, Jt, dtype=torch.float32, device=A.device)
     if out.stride(1) != 1 or out.shape[0] < M or out.shape[1] < Jt:
         raise ValueError("planes_gemm: out must be [>=M, >=J+ones], unit column stride")
     check(lib().apg_planes_gemm(
-        ptr(A), M, S, ptr(Bp), boff.data_ptr(), J, bstride, sdiv, bstride2,
-        int(with_ones), Bp.numel() // N, N, ptr(ws), _GEMM_WGS,
-        out.data_ptr(), out.stride(0), stream_of(A)), "apg_planes_gemm")
+        ptr(A), M, S, ptr(Bp), bdesc.data_ptr(), J, sdiv, int(with_ones),
+        Bp.numel() // N, N, ptr(ws), wgs, out.data_ptr(), out.stride(0),
+        stream_of(A)), "apg_planes_gemm")
     return out[:M, :Jt]
 
 
-def _conv_weight_grad(d_conv, inr, s0, states, B, H, out=None):
+def _ref_and_states(in_ref, state0, B, H):
+    """One buffer for everything the conv-weight product reads as B operand:
+    planes [0, 2H*9) = the reference tensor [2H][9][B], planes [2H*9, +(H+1)*12)
+    = [state0; states of the rollout] ([H+1][12][B], the kernels write the H
+    new states in place).  Returns (buffer, in_ref view, state0 view, states view)."""
+    buf = torch.empty(2 * H * 9 + (H + 1) * 12, B, dtype=torch.float32,
+                      device=state0.device)
+    inr = buf[:2 * H * 9].view(2 * H, 9, B)
+    inr.copy_(in_ref[:, :2 * H].permute(1, 2, 0))
+    st_all = buf[2 * H * 9:].view(H + 1, 12, B)
+    st_all[0].copy_(state0.t())
+    return buf, inr, st_all[0], st_all[1:]
+
+
+def _conv_weight_grad(d_conv, refbuf, B, H, out=None):
     """d conv_ref.weight / bias from the conv cotangent planes d_conv
-    [160][H*B] (plane = ch*8 + pos): the windows are read in place from the
-    reference tensor inr [2H][9][B] with segment = (pos, step); the
-    relative-position shift of columns 0..2 is a second small product with
-    the positions before each step.  Returns [20, 28] = [dW (c-major, tap) | db]."""
+    [160][H*B] (plane = ch*8 + pos) in ONE product: the windows are read in
+    place from the reference planes of `refbuf` with segment = (pos, step),
+    the relative-position shift of columns 0..2 comes from three extra
+    columns over the position planes before each step.
+    Returns [20, 28] = [dW (c-major, tap) | db]."""
     dev = d_conv.device
-    boff = _boff(dev, "conv", [t * 9 + c for c in range(9) for t in range(3)])
-    c1 = planes_gemm(d_conv, 20, 8 * H, inr.reshape(2 * H * 9, B), boff,
-                     bstride=9, sdiv=H, bstride2=9, N=B, out=out)
-    prev = torch.cat((s0[None], states[:-1]), 0)                # [H,12,B]
-    c2 = planes_gemm(d_conv, 20, 8 * H, prev.reshape(H * 12, B),
-                     _boff(dev, "pos", [0, 1, 2]), bstride=0, sdiv=H,
-                     bstride2=12, N=B, with_ones=False)
-    c1[:, :9].view(20, 3, 3).sub_(c2[:, :, None])
-    return c1
+    offs = [t * 9 + c for c in range(9) for t in range(3)] + [2 * H * 9 + q for q in range(3)]
+    desc = make_bdesc(dev, offs, [9] * 27 + [0] * 3, [9] * 27 + [12] * 3,
+                      key=("conv", H))
+    c = planes_gemm(d_conv, 20, 8 * H, refbuf, desc, sdiv=H, N=B)   # [20, 31]
+    res = torch.empty(20, 28, dtype=torch.float32, device=dev) if out is None else out
+    res[:, :27] = c[:, :27]
+    res[:, :9].view(20, 3, 3).sub_(c[:, 27:30, None])
+    res[:, 27] = c[:, 30]
+    return res
 
 
 class _QuadLstmRolloutLoss(torch.autograd.Function):
@@ -582,8 +609,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         if w_ih.shape != (32, 175) or conv_w.shape != (20, 9, 3):
             raise ValueError("fused path needs LSTM_NEW(15, 10, 9, 4, conv=1)")
         dev = state0.device
-        s0 = _f32c(state0).t().contiguous()
-        inr = _f32c(in_ref[:, :2 * H]).permute(1, 2, 0).contiguous()
+        refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H)
         rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
         h0s, c0s = _f32c(h0).t().contiguous(), _f32c(c0).t().contiguous()
         pw = dict(
@@ -596,7 +622,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         pol = _capi.ApgLstmPolicy(**{k: ptr(v) for k, v in pw.items()})
         N = H * B
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        states, actions = new(H, 12, B), new(H, 4, B)
+        actions = new(H, 4, B)
         # one buffer for everything the weight-gradient GEMMs read as B
         # operand: x (175 planes), h_prev / c_prev (16), h_new (8)
         acts = new(199, N)
@@ -619,26 +645,30 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
             ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), None, None,
             None, st), "apg_quad_lstm_rollout_bwd")
-        ctx.save_for_backward(s0, inr, states, acts, d_gates, d_zout, d_conv)
+        ctx.save_for_backward(refbuf, acts, d_gates, d_zout, d_conv)
         ctx.mark_non_differentiable(states, actions)
         ctx.dims = (B, H)
         return loss.reshape(()), states, actions
 
     @staticmethod
     def backward(ctx, g, _gs, _ga):
-        s0, inr, states, acts, d_gates, d_zout, d_conv = ctx.saved_tensors
+        refbuf, acts, d_gates, d_zout, d_conv = ctx.saved_tensors
         B, H = ctx.dims
-        N = H * B
-        dev = s0.device
+        dev = acts.device
+        # every gradient is a view of ONE flat buffer, scaled by g once
+        sizes = [32 * 184, 4 * 9, 20 * 28]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        c1, c2, c3 = (v.view(r, -1) for v, r in zip(flat.split(sizes), (32, 4, 20)))
         # [dW_ih | dW_hh | db] = d_gates . [x ; h_prev ; 1]^T
-        c1 = planes_gemm(d_gates, 32, 1, acts,
-                         _boff(dev, "ih_hh", list(range(183)))) * g
+        planes_gemm(d_gates, 32, 1, acts,
+                    make_bdesc(dev, range(183), key="ih_hh"), out=c1)
         d_w_ih, d_w_hh, d_b = c1[:, :175], c1[:, 175:183], c1[:, 183]
         # [dW_out | db_out] = d_zout . [h_new ; 1]^T
-        c2 = planes_gemm(d_zout, 4, 1, acts,
-                         _boff(dev, "out", list(range(191, 199)))) * g
+        planes_gemm(d_zout, 4, 1, acts,
+                    make_bdesc(dev, range(191, 199), key="out"), out=c2)
         d_w_out, d_b_out = c2[:, :8], c2[:, 8]
-        c3 = _conv_weight_grad(d_conv, inr, s0, states, B, H) * g
+        _conv_weight_grad(d_conv, refbuf, B, H, out=c3)
+        flat *= g
         d_conv_w, d_conv_b = c3[:, :27].reshape(20, 9, 3), c3[:, 27]
         grads = [d_conv_w, d_conv_b, d_w_ih, d_w_hh, d_b, d_b, d_w_out, d_b_out]
         return (None, None, None, None, None, *grads, None, None, None)
@@ -678,8 +708,7 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
             raise ValueError("batch too large for one fused launch "
                              "(B <= 400 000); split it")
         dev = state0.device
-        s0 = _f32c(state0).t().contiguous()
-        inr = _f32c(in_ref[:, :2 * H]).permute(1, 2, 0).contiguous()
+        refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H)
         rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
@@ -689,7 +718,7 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
         require_device(s0, inr, rf, *pw.values())
         pol = _capi.ApgMlpPolicy(**{k: ptr(v) for k, v in pw.items()})
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        states, actions = new(H, 12, B), new(H, 4, B)
+        actions = new(H, 4, B)
         # everything the weight-gradient GEMMs read as B operand:
         # feat (15 planes) | x1 (224) | h1, h2, h3 (192)
         acts = new(431, N)
@@ -711,23 +740,22 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
             ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
             ptr(loss), ptr(d_pre), ptr(d_zout), ptr(d_conv), None, ptr(ws),
             st), "apg_quad_mlp_rollout_bwd")
-        ctx.save_for_backward(s0, inr, states, acts, d_pre, d_zout, d_conv)
+        ctx.save_for_backward(refbuf, acts, d_pre, d_zout, d_conv)
         ctx.mark_non_differentiable(states, actions)
         ctx.dims = (B, H)
         return loss.reshape(()), states, actions
 
     @staticmethod
     def backward(ctx, g, _gs, _ga):
-        s0, inr, states, acts, d_pre, d_zout, d_conv = ctx.saved_tensors
+        refbuf, acts, d_pre, d_zout, d_conv = ctx.saved_tensors
         B, H = ctx.dims
-        N = H * B
-        dev = s0.device
+        dev = acts.device
         # every gradient is a view of ONE flat buffer, scaled by g once
         sizes = [64 * 225, 64 * 65, 64 * 65, 64 * 16, 4 * 65, 20 * 28]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
         c1, c2, c3, cs, co, cc = (
             v.view(r, -1) for v, r in zip(flat.split(sizes), (64, 64, 64, 64, 4, 20)))
-        R = lambda lo, hi_: _boff(dev, ("mlp", lo, hi_), list(range(lo, hi_)))
+        R = lambda lo, hi_: make_bdesc(dev, range(lo, hi_), key=("mlp", lo, hi_))
         # acts planes: feat 0..14 | x1 15..238 | h1 239.. | h2 303.. | h3 367..
         planes_gemm(d_pre[0:64], 64, 1, acts, R(15, 127), with_ones=False, out=c1)
         planes_gemm(d_pre[0:64], 64, 1, acts, R(127, 239), out=c1[:, 112:])
@@ -735,7 +763,7 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
         planes_gemm(d_pre[128:192], 64, 1, acts, R(303, 367), out=c3)
         planes_gemm(d_pre[192:256], 64, 1, acts, R(0, 15), out=cs)
         planes_gemm(d_zout, 4, 1, acts, R(367, 431), out=co)
-        _conv_weight_grad(d_conv, inr, s0, states, B, H, out=cc)
+        _conv_weight_grad(d_conv, refbuf, B, H, out=cc)
         flat *= g
         grads = [cs[:, :15], cs[:, 15], cc[:, :27].reshape(20, 9, 3), cc[:, 27],
                  c1[:, :224], c1[:, 224], c2[:, :64], c2[:, 64],

@@ -273,22 +273,22 @@ int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
 /* "Planes x planes" reduction GEMM on the matrix cores
  * (v_mfma_f32_32x32x2_f32, exact fp32):
  *   C[m*ldc + j] = sum_{s<S} sum_{n<N} A[(m*S + s)*N + n] * B[bplane(j,s)*N + n]
- *   bplane(j, s) = boff[j] + (s / sdiv) * bstride + (s % sdiv) * bstride2
+ *   bplane(j, s) = bdesc[j] + (s / sdiv) * bdesc[J + j] + (s % sdiv) * bdesc[2J + j]
  * for m < M <= 64, j < J (J + with_ones <= 192, <= 128 when M > 32);
  * with_ones appends one column C[m][J] = sum_{s,n} A[...] (row sums).  Turns
  * the cotangent planes of apg_quad_lstm_rollout_bwd / apg_quad_mlp_rollout_bwd
  * into weight gradients - the role torch.autograd plays for the parameters in
- * scripts/train_drone.py:168.  The two-level segment stride reads the sliding
- * reference windows of the conv branch in place (segment = (window position,
- * step), sdiv = H).  `boff` is a DEVICE int array [J]; `workspace` holds
- * apg_planes_gemm_workspace_floats(M, J, with_ones, num_wg) floats; C has row
- * stride ldc >= J + with_ones.  B holds `b_planes` planes; A (M*S planes) and
- * B must each stay below 4 GiB. */
+ * scripts/train_drone.py:168.  The per-column two-level segment stride reads
+ * the sliding reference windows of the conv branch in place (segment =
+ * (window position, step), sdiv = H).  `bdesc` is a DEVICE int array [3][J];
+ * `workspace` holds apg_planes_gemm_workspace_floats(M, J, with_ones, num_wg)
+ * floats; C has row stride ldc >= J + with_ones.  B holds `b_planes` planes;
+ * A (M*S planes) and B must each stay below 2 GiB. */
 int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg);
 int apg_planes_gemm(const float *A, int M, int S, const float *B,
-                    const int *boff, int J, int bstride, int sdiv, int bstride2,
-                    int with_ones, int b_planes, long long N, float *workspace,
-                    int num_wg, float *C, int ldc, apg_stream_t stream);
+                    const int *bdesc, int J, int sdiv, int with_ones,
+                    int b_planes, long long N, float *workspace, int num_wg,
+                    float *C, int ldc, apg_stream_t stream);
 
 /* ---------------------------------------------------------- fixed wing --- */
 /* Parameters of neural_control/dynamics/fixed_wing_dynamics.py:18-39 +

@@ -582,8 +582,8 @@ def test_planes_gemm_mfma_vs_torch(dev):
             offs = [t * 9 + c for c in range(9) for t in range(3)]
         else:
             offs = list(range(P - J, P))
-        boff = torch.tensor(offs, dtype=torch.int32, device=dev)
-        C = F.planes_gemm(A, M, S, Bp, boff, bstride=bstride, with_ones=True)
+        C = F.planes_gemm(A, M, S, Bp, F.make_bdesc(dev, offs, bstride),
+                          with_ones=True)
         A64, B64 = A.double().cpu(), Bp.double().cpu()
         ref = torch.zeros(M, J + 1, dtype=torch.float64)
         for m in range(M):
@@ -593,21 +593,22 @@ def test_planes_gemm_mfma_vs_torch(dev):
                 ref[m, :J] += rows @ a
                 ref[m, J] += a.sum()
         assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
-    # two-level segment stride (segment = (pos, step)) into a strided output
-    H, Bn = 5, 200
-    A = torch.randn(20 * 8 * H, Bn, generator=g).to(dev)       # [ch][pos][k] planes
-    inr = torch.randn((H + 9) * 9, Bn, generator=g).to(dev)     # [row][9] planes
-    offs = [t * 9 + c for c in range(9) for t in range(3)]
-    boff = torch.tensor(offs, dtype=torch.int32, device=dev)
+    # per-column two-level segment strides (segment = (pos, step)), strided output
+    H, Bn = 5, 203
+    A = torch.randn(20 * 8 * H, Bn, generator=g).to(dev)        # [ch][pos][k] planes
+    inr = torch.randn((H + 9) * 9 + H * 12, Bn, generator=g).to(dev)
+    P0 = (H + 9) * 9                                             # "position" planes
+    offs = [t * 9 + c for c in range(9) for t in range(3)] + [P0, P0 + 1, P0 + 2]
+    s1, s2 = [9] * 27 + [0] * 3, [9] * 27 + [12] * 3
     out = torch.zeros(20, 40, device=dev)
-    C = F.planes_gemm(A, 20, 8 * H, inr, boff, bstride=9, sdiv=H, bstride2=9,
+    C = F.planes_gemm(A, 20, 8 * H, inr, F.make_bdesc(dev, offs, s1, s2), sdiv=H,
                       out=out[:, 5:])
     assert C.data_ptr() == out[:, 5:].data_ptr() and float(out[:, :5].abs().sum()) == 0
     A64, B64 = A.double().cpu().view(20, 8, H, Bn), inr.double().cpu()
-    ref = torch.zeros(20, 28, dtype=torch.float64)
+    ref = torch.zeros(20, 31, dtype=torch.float64)
     for pos in range(8):
         for k in range(H):
-            rows = torch.stack([B64[o + (pos + k) * 9] for o in offs])   # [27,Bn]
-            ref[:, :27] += A64[:, pos, k] @ rows.t()
-            ref[:, 27] += A64[:, pos, k].sum(1)
+            rows = torch.stack([B64[o + pos * a + k * b] for o, a, b in zip(offs, s1, s2)])
+            ref[:, :30] += A64[:, pos, k] @ rows.t()
+            ref[:, 30] += A64[:, pos, k].sum(1)
     assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5

@@ -11,22 +11,23 @@ acts = torch.randn(431, N, device=dev)
 d_pre = torch.randn(256, N, device=dev)
 inr = torch.randn(2 * H * 9, B, device=dev)
 d_conv = d_pre[:160]
-R = lambda lo, hi: torch.arange(lo, hi, dtype=torch.int32, device=dev)
-conv_off = torch.tensor([t * 9 + c for c in range(9) for t in range(3)],
-                        dtype=torch.int32, device=dev)
+R = lambda lo, hi: F.make_bdesc(dev, range(lo, hi))
+refbuf = torch.randn(2 * H * 9 + (H + 1) * 12, B, device=dev)
+conv_desc = F.make_bdesc(dev, [t * 9 + c for c in range(9) for t in range(3)] + [180, 181, 182],
+                         [9] * 27 + [0] * 3, [9] * 27 + [12] * 3)
 shapes = {
     "fc1a M64 J112": lambda: F.planes_gemm(d_pre[0:64], 64, 1, acts, R(15, 127), with_ones=False),
     "fc2  M64 J64+1": lambda: F.planes_gemm(d_pre[64:128], 64, 1, acts, R(239, 303)),
     "st   M64 J15+1": lambda: F.planes_gemm(d_pre[192:256], 64, 1, acts, R(0, 15)),
     "out  M4  J64+1": lambda: F.planes_gemm(d_pre[:4], 4, 1, acts, R(367, 431)),
     "lstm M32 J183+1": lambda: F.planes_gemm(d_pre[:32], 32, 1, acts, R(0, 183)),
-    "conv M20 S80 J27+1": lambda: F.planes_gemm(d_conv, 20, 8 * H, inr, conv_off, bstride=9,
-                                                 sdiv=H, bstride2=9, N=B),
+    "conv M20 S80 J30+1": lambda: F.planes_gemm(d_conv, 20, 8 * H, refbuf, conv_desc,
+                                                 sdiv=H, N=B),
 }
 planes = {"fc1a M64 J112": 176, "fc2  M64 J64+1": 128, "st   M64 J15+1": 79,
-          "out  M4  J64+1": 68, "lstm M32 J183+1": 215, "conv M20 S80 J27+1": 160}
-for wgs in [int(x) for x in os.environ.get("WGS", "256,512,1024,2048").split(",")]:
-    F._GEMM_WGS = wgs
+          "out  M4  J64+1": 68, "lstm M32 J183+1": 215, "conv M20 S80 J30+1": 160}
+for wgs in [int(x) for x in os.environ.get("WGS", "0,256,512,1024").split(",")]:
+    F._GEMM_WGS = wgs or None
     for name, fn in shapes.items():
         for _ in range(3):
             fn()

@@ -46,7 +46,7 @@ R = {k: torch.stack(v, 0) for k, v in R.items()}   # [H,B,*]
 
 loss, states, actions = F.quad_mlp_rollout_loss(net, state0, in_ref, ref, 0.1, dyn.params)
 fn = loss.grad_fn
-s0, inr, states_s, acts, d_pre, d_zout, d_conv = fn.saved_tensors
+refbuf, acts, d_pre, d_zout, d_conv = fn.saved_tensors
 N = H * B
 pl = lambda t, lo, hi: t[lo:hi].reshape(hi - lo, H, B).permute(1, 2, 0)
 print("feat", rel(pl(acts, 0, 15), R["feat"]))
