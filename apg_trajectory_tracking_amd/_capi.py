@@ -64,7 +64,7 @@ class ApgDeferredLoss(ctypes.Structure):
 
 class ApgLstmPolicy(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "conv_w", "conv_b", "w_ih_t", "w_hh_t", "b_gates", "w_out", "b_out")]
+        "conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")]
 
 
 class ApgMlpPolicy(ctypes.Structure):
@@ -102,11 +102,14 @@ SIGNATURES = {
     "apg_quad_features_bwd": [_P, _P, _I, _I, _P, _P],
     "apg_quad_lstm_rollout_fwd": [
         _P, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
-        ctypes.POINTER(ApgLstmPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+        ctypes.POINTER(ApgLstmPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P,
+        _P],
+    "apg_quad_lstm_workspace_floats": [],
+    "apg_quad_lstm_loss_partials_count": [_I],
     "apg_quad_lstm_rollout_bwd": [
         _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgLstmPolicy),
-        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_quad_mlp_rollout_fwd": [
         _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgMlpPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],

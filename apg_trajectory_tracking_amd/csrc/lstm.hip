@@ -1,32 +1,35 @@
 // lstm.hip - K7: the LSTM-policy quadrotor unroll with the policy INSIDE the
-// kernel (BASELINE config 5: quadrotor, LSTM recurrent mode, H = 10).
+// kernel, on the matrix cores (BASELINE config 5: quadrotor, LSTM recurrent
+// mode, H = 10).
 //
 // Replaces, for train_mode == "LSTM", the loop of
 //   TrainDrone.train_recurrent_model       scripts/train_drone.py:113-173
 //   LSTM_NEW.forward (conv branch)         neural_control/models/rnn.py:35-51
 //   state_preprocessing                    neural_control/dataset.py:207-220
 //   FlightmareDynamics / quad_mpc_loss     (see quad.hip)
-// with two launches: a forward sweep that runs policy + dynamics for all H
-// steps of a trajectory in one lane, and a reverse sweep (BPTT through LSTM
-// cell, conv window, feature construction and dynamics).  Pinned window
-// semantics: window_k = in_ref[k : k+H], its position
-// columns made relative to the CURRENT position, copied - never in place.
+// with two launches: a forward sweep (policy + dynamics for all H steps) and a
+// reverse sweep (BPTT through head, LSTM cell, conv window, feature
+// construction and dynamics).  Pinned window semantics:
+// window_k = in_ref[k : k+H], its position columns made relative to the
+// CURRENT position, copied - never in place.
 //
-// One lane = one trajectory.  The 6.5 k policy weights (26 KB) live in LDS;
-// every lane of a wave reads the same weight at the same time (LDS broadcast,
-// conflict-free); hidden / cell state, the sliding reference window (90
-// floats, one new row per step) and the 32 gate accumulators stay in
-// registers.  ~10.3 k FMA per env-step forward: VALU-bound, no MFMA (a
-// 64 x 183 x 32 per-wave GEMM per step would fit MFMA, but the recurrence
-// serialises the steps and the conv/relu producer is elementwise; left for a
-// later round).
+// LSTM_NEW(15, 10, 9, 4, conv=1): x = [15 state features, relu(conv1d(9 -> 20,
+// k = 3)) (160)], gates = W_ih x + W_hh h + b (32 = i, f, g, o x 8 units),
+// c' = sig(f) c + sig(i) tanh(g), h' = sig(o) tanh(c'), a = sig(W_out h' + b).
+// The 32 x 183 gate projection and the conv are GEMM-shaped with the batch as
+// N: they run on v_mfma_f32_32x32x2_f32 in the layout of policy_mfma.h (one
+// wave = 32 trajectories, lane l works for trajectory l & 31).  The gate
+// accumulator puts (i, f, g, o) of hidden unit u = r + 4 (l >> 5) into
+// registers r, 4 + r, 8 + r, 12 + r of ONE lane, so the cell update is
+// lane-local, and h' (4 registers per lane) is directly the B operand of the
+// next step's W_hh product: the recurrence needs no data movement at all.
+// 228 MFMAs per step and wave forward, 112 in the reverse sweep.
 //
-// Weight gradients are NOT accumulated per lane: the reverse sweep writes the
-// per-(step, trajectory) cotangents (gate pre-activations, head
-// pre-activations, conv pre-activations) next to the forward's saved inputs,
-// all as [feature][H*B] planes, and the host turns them into dW with a few
-// plain GEMMs over the H*B rows (rocBLAS through torch.matmul).
+// Weight gradients: the reverse sweep writes the per-(step, trajectory)
+// cotangent planes (gate / head / conv pre-activations) next to the forward's
+// saved inputs, all as [feature][H*B] planes; apg_planes_gemm reduces them.
 #include "apg_device.h"
+#include "policy_mfma.h"
 #include "quad_math.h"
 
 namespace apg {
@@ -40,260 +43,320 @@ constexpr int kNP = kH - 2;       // conv output positions (kernel 3)
 constexpr int kNX = kNF + kNC * kNP;  // LSTM input width (175)
 constexpr int kNH = 8;            // hidden units
 constexpr int kNG = 4 * kNH;      // gate pre-activations (i, f, g, o)
-constexpr int kBlock = 128;
+constexpr int kThreads = 256;
+constexpr int kTrajPerBlock = kThreads / 2;
 
-// LDS image of the policy (floats)
-constexpr int oWc = 0;                       // [20][27]
-constexpr int oBc = oWc + kNC * 27;          // [20]
-constexpr int oWih = oBc + kNC;              // [175][32]  (transposed)
-constexpr int oWhh = oWih + kNX * kNG;       // [8][32]    (transposed)
-constexpr int oBg = oWhh + kNH * kNG;        // [32] = b_ih + b_hh
-constexpr int oWo = oBg + kNG;               // [4][8]
-constexpr int oBo = oWo + 4 * kNH;           // [4]
-constexpr int oA = oBo + 4;                  // [20][3] = sum_t Wc[ch][c][t], c < 3
-constexpr int kLdsFloats = oA + kNC * 3;
+__device__ __forceinline__ float sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+}
 
-__device__ __forceinline__ void load_policy(float *lds, const ApgLstmPolicy &p) {
-  for (int i = threadIdx.x; i < kNC * 27; i += blockDim.x) lds[oWc + i] = p.conv_w[i];
-  for (int i = threadIdx.x; i < kNC; i += blockDim.x) lds[oBc + i] = p.conv_b[i];
-  for (int i = threadIdx.x; i < kNX * kNG; i += blockDim.x) lds[oWih + i] = p.w_ih_t[i];
-  for (int i = threadIdx.x; i < kNH * kNG; i += blockDim.x) lds[oWhh + i] = p.w_hh_t[i];
-  for (int i = threadIdx.x; i < kNG; i += blockDim.x) lds[oBg + i] = p.b_gates[i];
-  for (int i = threadIdx.x; i < 4 * kNH; i += blockDim.x) lds[oWo + i] = p.w_out[i];
-  for (int i = threadIdx.x; i < 4; i += blockDim.x) lds[oBo + i] = p.b_out[i];
-  for (int i = threadIdx.x; i < kNC * 3; i += blockDim.x) {
-    const int ch = i / 3, c = i % 3;
-    lds[oA + i] = p.conv_w[ch * 27 + c * 3] + p.conv_w[ch * 27 + c * 3 + 1] +
-                  p.conv_w[ch * 27 + c * 3 + 2];
+// ------------------------------------------------------------ forward sweep
+constexpr int fTo = 0;               // [4 j][4 r][2]   W_out[j][r + 4 hi]
+constexpr int fTbg = fTo + 32;       // [16][2]         b_ih + b_hh
+constexpr int fTbc = fTbg + 32;      // [16][2]         conv bias
+constexpr int fBo = fTbc + 32;       // [4]
+constexpr int fAf = 128;             // [8][64]         W_ih, feature k-pairs
+constexpr int fAh = fAf + 8 * 64;    // [4][64]         W_hh, k-pair (r, r + 4)
+constexpr int fAc = fAh + 4 * 64;    // [15][64]        conv
+constexpr int fAg = fAc + 15 * 64;   // [8 pos][12][64] W_ih, conv inputs
+constexpr int kFwdLds = fAg + 8 * 12 * 64;  // 8 000 floats
+
+__device__ __forceinline__ void pack_forward(float *dst, const ApgLstmPolicy &p,
+                                             int tid, int T) {
+  for (int idx = tid; idx < 8 * 64; idx += T) {
+    const int l = idx & 63, pp = idx >> 6, k = 2 * pp + (l >> 5);
+    dst[fAf + idx] = k < kNF ? p.w_ih[(l & 31) * kNX + k] : 0.f;
   }
-  __syncthreads();
-}
-
-__device__ __forceinline__ float sigmoidf_(float x) {
-  return 1.0f / (1.0f + expf(-x));
-}
-
-// acc[0..31] += row[0..31] * v   (row is wave-uniform: LDS broadcast reads)
-__device__ __forceinline__ void axpy32(float (&acc)[kNG], const float *row, float v) {
-#pragma unroll
-  for (int q = 0; q < kNG / 4; ++q) {
-    const float4 w = *reinterpret_cast<const float4 *>(row + 4 * q);
-    acc[4 * q + 0] = fmaf(w.x, v, acc[4 * q + 0]);
-    acc[4 * q + 1] = fmaf(w.y, v, acc[4 * q + 1]);
-    acc[4 * q + 2] = fmaf(w.z, v, acc[4 * q + 2]);
-    acc[4 * q + 3] = fmaf(w.w, v, acc[4 * q + 3]);
+  for (int idx = tid; idx < 4 * 64; idx += T) {
+    const int l = idx & 63, r = idx >> 6;
+    dst[fAh + idx] = p.w_hh[(l & 31) * kNH + r + 4 * (l >> 5)];
   }
-}
-
-// four independent partial sums: a single accumulator would make the 32 FMAs
-// one dependent chain (latency-, not issue-bound, with one wave per SIMD)
-__device__ __forceinline__ float dot32(const float4 (&w)[kNG / 4],
-                                       const float (&d)[kNG]) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-  for (int q = 0; q < kNG / 4; ++q) {
-    a0 = fmaf(w[q].x, d[4 * q + 0], a0);
-    a1 = fmaf(w[q].y, d[4 * q + 1], a1);
-    a2 = fmaf(w[q].z, d[4 * q + 2], a2);
-    a3 = fmaf(w[q].w, d[4 * q + 3], a3);
+  // conv k-pair (j, tap): the lower half multiplies reference column j (< 4),
+  // the upper half column 4 + j, so a lane only keeps 5 of the 9 columns
+  for (int idx = tid; idx < 15 * 64; idx += T) {
+    const int l = idx & 63, pp = idx >> 6, ch = l & 31;
+    const int j = pp / 3, tap = pp % 3, hi = l >> 5;
+    const int q = hi ? 4 + j : j;
+    dst[fAc + idx] = (ch < kNC && (hi || j < 4)) ? p.conv_w[ch * 27 + q * 3 + tap] : 0.f;
   }
-  return (a0 + a1) + (a2 + a3);
+  for (int idx = tid; idx < 8 * 12 * 64; idx += T) {
+    const int l = idx & 63, q = idx >> 6, i = q % 12, pos = q / 12;
+    const int ch = rrow(i) + 4 * (l >> 5);
+    dst[fAg + idx] = ch < kNC ? p.w_ih[(l & 31) * kNX + kNF + ch * kNP + pos] : 0.f;
+  }
+  for (int idx = tid; idx < 32; idx += T) {
+    const int hi = idx & 1, r = (idx >> 1) & 3, j = idx >> 3;
+    dst[fTo + idx] = p.w_out[j * kNH + r + 4 * hi];
+    const int i = idx >> 1, row = rrow(i) + 4 * hi;
+    dst[fTbg + idx] = p.b_ih[row] + p.b_hh[row];
+    dst[fTbc + idx] = row < kNC ? p.conv_b[row] : 0.f;
+  }
+  for (int idx = tid; idx < 4; idx += T) dst[fBo + idx] = p.b_out[idx];
 }
 
-__device__ __forceinline__ float dot32(const float *row, const float (&d)[kNG]) {
-  float4 w[kNG / 4];
-#pragma unroll
-  for (int q = 0; q < kNG / 4; ++q)
-    w[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
-  return dot32(w, d);
+struct PackArgs {
+  ApgLstmPolicy pol;
+  float *dst;
+};
+__global__ __launch_bounds__(256) void lstm_pack_fwd_kernel(PackArgs A) {
+  pack_forward(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
+               gridDim.x * blockDim.x);
 }
 
 struct FwdArgs {
   const float *state0, *in_ref, *h0, *c0;
   float *states, *actions, *x, *gates, *hc, *hnew;
-  unsigned *mask;  // [5][N] relu mask bits of the conv outputs
-  ApgLstmPolicy pol;
+  unsigned *mask;        // [5][N] relu bits of the conv outputs
+  const float *tables;   // packed operand tables (lstm_pack_fwd_kernel)
   QuadConst c;
   int B;
 };
 
-__global__ __launch_bounds__(kBlock) void lstm_rollout_fwd_kernel(FwdArgs A) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
-  load_policy(lds, A.pol);
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= A.B) return;
+__global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds(lds, A.tables, kFwdLds);
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const LdsView L(lds, lane);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = (blockIdx.x * (kThreads / 64) + wave) * 32 + (lane & 31);
   const int B = A.B;
-  const size_t N = (size_t)kH * B;
+  const bool live = b < B;             // see Planes: dead lanes never branch
+  const bool st_lo = live && hi == 0;  // per-trajectory stores: lower half only
+  const unsigned pitchB = (unsigned)B * 4u, pitchN = pitchB * kH;
   const QuadConst c = A.c;
+  const Planes Ps0(A.state0, 12, pitchB), Pin(A.in_ref, 2 * kH * kRD, pitchB);
+  const Planes Ph0(A.h0, kNH, pitchB), Pc0(A.c0, kNH, pitchB);
+  const Planes Pst(A.states, kH * 12, pitchB), Pac(A.actions, kH * 4, pitchB);
+  const Planes Px(A.x, kNX, pitchN), Pg(A.gates, kNG, pitchN);
+  const Planes Phc(A.hc, 2 * kNH, pitchN), Phn(A.hnew, kNH, pitchN);
+  const Planes Pmk(A.mask, 5, pitchN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  const unsigned vb_lo = st_lo ? vb : kDead;
+  const unsigned vb_u = live ? vb + (hi ? 4u * pitchB : 0u) : kDead;  // unit r + 4 hi
 
-  float s[12], h[kNH], cell[kNH];
+  float s[12], h[4], cell[4];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = A.state0[(size_t)i * B + b];
+  for (int i = 0; i < 12; ++i) s[i] = Ps0.ld(vb, i * pitchB);
 #pragma unroll
-  for (int m = 0; m < kNH; ++m) h[m] = A.h0[(size_t)m * B + b], cell[m] = A.c0[(size_t)m * B + b];
-  float w[kH][kRD];  // sliding reference window, raw (absolute) values
+  for (int r = 0; r < 4; ++r) {
+    h[r] = Ph0.ld(vb_u, r * pitchB);
+    cell[r] = Pc0.ld(vb_u, r * pitchB);
+  }
+  // sliding reference window, raw values: columns 0..4 in the lower half,
+  // 4..8 in the upper half (see pack_forward)
+  float w[kH][5];
 #pragma unroll
   for (int r = 0; r < kH; ++r)
 #pragma unroll
-    for (int q = 0; q < kRD; ++q) w[r][q] = A.in_ref[((size_t)r * kRD + q) * B + b];
+    for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vb_u, (r * kRD + j) * pitchB);
 
 #pragma unroll 1
   for (int k = 0; k < kH; ++k) {
-    const size_t n = (size_t)k * B + b;
+    const unsigned pB = opaque(pitchB), pN = opaque(pitchN);
+    const unsigned col = (unsigned)b * 4u + (unsigned)k * pitchB;  // column k*B + b
+    const unsigned vn_lo = st_lo ? col : kDead;
+    const unsigned vr = live ? col + (hi ? 4u * pitchN : 0u) : kDead;   // + row 4 hi
+    const unsigned vc = live ? col + (hi ? 32u * pitchN : 0u) : kDead;  // + channel 4 hi
+    const unsigned vm = live ? col + (hi ? pitchN : 0u) : kDead;        // + mask word hi
     const Trig t = make_trig(&s[3]);
     float feat[kNF];
     quad_features(s, t, feat);
-    float g[kNG];
 #pragma unroll
-    for (int q = 0; q < kNG; ++q) g[q] = lds[oBg + q];
+    for (int j = 0; j < kNF; ++j) Px.st(vn_lo, j * pN, feat[j]);
 #pragma unroll
-    for (int j = 0; j < kNF; ++j) {
-      A.x[(size_t)j * N + n] = feat[j];
-      axpy32(g, &lds[oWih + j * kNG], feat[j]);
+    for (int r = 0; r < 4; ++r) {
+      Phc.st(vr, r * pN, h[r]);
+      Phc.st(vr, (kNH + r) * pN, cell[r]);
+    }
+    // gates: two accumulators (even / odd k-pairs) keep the MFMAs independent
+    f32x16 g0, g1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g0[i] = L.T(fTbg + i * 2), g1[i] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
+      const float bv = hi ? odd : feat[2 * p];
+      if (p & 1) g1 = mfma(L.A(fAf + p * 64), bv, g1);
+      else g0 = mfma(L.A(fAf + p * 64), bv, g0);
     }
 #pragma unroll
-    for (int m = 0; m < kNH; ++m) {
-      A.hc[(size_t)m * N + n] = h[m];
-      A.hc[(size_t)(kNH + m) * N + n] = cell[m];
-      axpy32(g, &lds[oWhh + m * kNG], h[m]);
+    for (int r = 0; r < 4; ++r) {
+      if (r & 1) g1 = mfma(L.A(fAh + r * 64), h[r], g1);
+      else g0 = mfma(L.A(fAh + r * 64), h[r], g0);
     }
-    // position columns relative to the current position
-    float wr[kH][3];
+    // conv (one 32-row block per window position) feeding the gates directly
+    unsigned mbits[3] = {0u, 0u, 0u};
+    const float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
 #pragma unroll
-    for (int r = 0; r < kH; ++r)
+    for (int pos = 0; pos < kNP; ++pos) {
+      f32x16 cv, cw;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) wr[r][q] = w[r][q] - s[q];
-    unsigned mask[5] = {0u, 0u, 0u, 0u, 0u};  // relu mask of the 160 conv outputs
-    float4 wrow[kNG / 4];                      // W_ih row of the next element
+      for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2), cw[i] = 0.f;
 #pragma unroll
-    for (int q = 0; q < kNG / 4; ++q)
-      wrow[q] = *reinterpret_cast<const float4 *>(&lds[oWih + kNF * kNG + 4 * q]);
-#pragma unroll 1
-    for (int ch = 0; ch < kNC; ++ch) {
-      float wc[27];
-#pragma unroll
-      for (int i = 0; i < 27; ++i) wc[i] = lds[oWc + ch * 27 + i];
-      const float bias = lds[oBc + ch];
-      unsigned bits = 0u;
-#pragma unroll
-      for (int pos = 0; pos < kNP; ++pos) {
-        const int j = kNF + ch * kNP + pos;
-        // this element's weights were requested one element ago; request the
-        // next row now so that its LDS latency hides behind 59 FMAs
-        float4 wcur[kNG / 4];
-#pragma unroll
-        for (int q = 0; q < kNG / 4; ++q) wcur[q] = wrow[q];
-        const int jn = j + 1 < kNX ? j + 1 : j;
-#pragma unroll
-        for (int q = 0; q < kNG / 4; ++q)
-          wrow[q] = *reinterpret_cast<const float4 *>(&lds[oWih + jn * kNG + 4 * q]);
-        float v = bias;
-#pragma unroll
-        for (int q = 0; q < kRD; ++q)
-#pragma unroll
-          for (int tt = 0; tt < 3; ++tt)
-            v = fmaf(wc[q * 3 + tt], q < 3 ? wr[pos + tt][q] : w[pos + tt][q], v);
-        bits |= (v > 0.f ? 1u : 0u) << pos;
-        v = fmaxf(v, 0.f);
-        A.x[(size_t)j * N + n] = v;
-#pragma unroll
-        for (int q = 0; q < kNG / 4; ++q) {
-          g[4 * q + 0] = fmaf(wcur[q].x, v, g[4 * q + 0]);
-          g[4 * q + 1] = fmaf(wcur[q].y, v, g[4 * q + 1]);
-          g[4 * q + 2] = fmaf(wcur[q].z, v, g[4 * q + 2]);
-          g[4 * q + 3] = fmaf(wcur[q].w, v, g[4 * q + 3]);
-        }
+      for (int p = 0; p < 15; ++p) {
+        const int j = p / 3, tap = p % 3;
+        const float xv = j < 3 ? w[pos + tap][j] - sub[j] : w[pos + tap][j];
+        if (p & 1) cw = mfma(L.A(fAc + p * 64), xv, cw);
+        else cv = mfma(L.A(fAc + p * 64), xv, cv);
       }
-      mask[ch >> 2] |= bits << (8 * (ch & 3));
-    }
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
-      A.mask[(size_t)i * N + n] = mask[i];
-    // LSTMCell (torch gate order i, f, g, o)
-    float hn[kNH];
-#pragma unroll
-    for (int m = 0; m < kNH; ++m) {
-      const float gi = sigmoidf_(g[m]), gf = sigmoidf_(g[kNH + m]);
-      const float gg = tanhf(g[2 * kNH + m]), go = sigmoidf_(g[3 * kNH + m]);
-      A.gates[(size_t)m * N + n] = gi;
-      A.gates[(size_t)(kNH + m) * N + n] = gf;
-      A.gates[(size_t)(2 * kNH + m) * N + n] = gg;
-      A.gates[(size_t)(3 * kNH + m) * N + n] = go;
-      cell[m] = gf * cell[m] + gi * gg;
-      hn[m] = go * tanhf(cell[m]);
-      h[m] = hn[m];
-      A.hnew[(size_t)m * N + n] = hn[m];
+      for (int i = 0; i < 12; ++i) {  // rows r(i) + 4 hi < 20 are real channels
+        float v = cv[i] + cw[i];
+        mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
+        v = fmaxf(v, 0.f);
+        // plane 15 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
+        Px.st(i < 8 ? vc : vn_lo, (kNF + rrow(i) * kNP + pos) * pN, v);
+        if (i & 1) g1 = mfma(L.A(fAg + (pos * 12 + i) * 64), v, g1);
+        else g0 = mfma(L.A(fAg + (pos * 12 + i) * 64), v, g0);
+      }
     }
-    float a[4];
+    // relu mask, trajectory-indexed: bit e = ch*8 + pos of word e >> 5
+#pragma unroll
+    for (int g = 0; g < 3; ++g) Pmk.stu(g < 2 ? vm : vn_lo, 2 * g * pN, mbits[g]);
+    // cell update: (i, f, g, o) of unit r + 4 hi are registers r, 4+r, 8+r, 12+r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = sigmoid_fast(g0[r] + g1[r]);
+      const float gf = sigmoid_fast(g0[4 + r] + g1[4 + r]);
+      const float gg = tanh_fast(g0[8 + r] + g1[8 + r]);
+      const float go = sigmoid_fast(g0[12 + r] + g1[12 + r]);
+      Pg.st(vr, r * pN, gi);
+      Pg.st(vr, (kNH + r) * pN, gf);
+      Pg.st(vr, (2 * kNH + r) * pN, gg);
+      Pg.st(vr, (3 * kNH + r) * pN, go);
+      cell[r] = fmaf(gf, cell[r], gi * gg);
+      h[r] = go * tanh_fast(cell[r]);
+      Phn.st(vr, r * pN, h[r]);
+    }
+    // head on the VALU: each half sums its 4 of the 8 units
+    float act[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float z = lds[oBo + j];
+      float z = 0.f;
 #pragma unroll
-      for (int m = 0; m < kNH; ++m) z = fmaf(lds[oWo + j * kNH + m], hn[m], z);
-      a[j] = sigmoidf_(z);
-      A.actions[((size_t)k * 4 + j) * B + b] = a[j];
+      for (int r = 0; r < 4; ++r) z = fmaf(L.T(fTo + (j * 4 + r) * 2), h[r], z);
+      z += other_half(z);
+      act[j] = sigmoidf_(z + L.U(fBo + j));
+      Pac.st(vb_lo, (k * 4 + j) * pB, act[j]);
     }
-    quad_step(s, a, c, t);
+    quad_step(s, act, c, t);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) A.states[((size_t)k * 12 + i) * B + b] = s[i];
-    // slide the window: drop row 0, fetch in_ref row k + H
-    if (k + 1 < kH) {
+    for (int i = 0; i < 12; ++i) Pst.st(vb_lo, (k * 12 + i) * pB, s[i]);
+    if (k + 1 < kH) {  // slide the window: drop row 0, fetch in_ref row k + H
 #pragma unroll
       for (int r = 0; r + 1 < kH; ++r)
 #pragma unroll
-        for (int q = 0; q < kRD; ++q) w[r][q] = w[r + 1][q];
+        for (int j = 0; j < 5; ++j) w[r][j] = w[r + 1][j];
 #pragma unroll
-      for (int q = 0; q < kRD; ++q)
-        w[kH - 1][q] = A.in_ref[((size_t)(k + kH) * kRD + q) * B + b];
+      for (int j = 0; j < 5; ++j) w[kH - 1][j] = Pin.ld(vb_u, ((k + kH) * kRD + j) * pB);
     }
   }
 }
 
+// ------------------------------------------------------------ reverse sweep
+constexpr int rTo = 0;               // [4 j][4 r][2]
+constexpr int rAq = rTo + 32;        // [20][3] sum over taps of conv_w
+constexpr int rAf = 128;             // [16][64]     W_ih^T, feature rows
+constexpr int rAh = rAf + 16 * 64;   // [16][64]     W_hh^T
+constexpr int rAc = rAh + 16 * 64;   // [5][16][64]  W_ih^T, conv rows
+constexpr int kBwdLds = rAc + 5 * 16 * 64;  // 7 296 floats
+
+__device__ __forceinline__ void pack_reverse(float *dst, const ApgLstmPolicy &p,
+                                             int tid, int T) {
+  for (int idx = tid; idx < 16 * 64; idx += T) {
+    const int l = idx & 63, cc = idx >> 6, m = l & 31, k = kchain(cc, l >> 5);
+    dst[rAf + idx] = m < kNF ? p.w_ih[k * kNX + m] : 0.f;
+    dst[rAh + idx] = m < kNH ? p.w_hh[k * kNH + m] : 0.f;
+  }
+  for (int idx = tid; idx < 5 * 16 * 64; idx += T) {
+    const int l = idx & 63, cc = (idx >> 6) & 15, eb = idx >> 10;
+    dst[rAc + idx] = p.w_ih[kchain(cc, l >> 5) * kNX + kNF + eb * 32 + (l & 31)];
+  }
+  for (int idx = tid; idx < 32; idx += T) {
+    const int hi = idx & 1, r = (idx >> 1) & 3, j = idx >> 3;
+    dst[rTo + idx] = p.w_out[j * kNH + r + 4 * hi];
+  }
+  for (int idx = tid; idx < kNC * 3; idx += T) {
+    const int ch = idx / 3, q = idx % 3;
+    dst[rAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
+                     p.conv_w[ch * 27 + q * 3 + 2];
+  }
+}
+__global__ __launch_bounds__(256) void lstm_pack_bwd_kernel(PackArgs A) {
+  pack_reverse(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
+               gridDim.x * blockDim.x);
+}
+
 struct BwdArgs {
-  const float *state0, *states, *actions, *ref, *gates, *hc;
+  const float *state0, *states, *actions, *ref;
   const unsigned *mask;
-  float *loss_partials, *d_gates, *d_zout, *d_conv;
+  const float *gates, *hc;
+  float *loss_partials;
+  float *d_gates;  // [32][N]  dL/d gate pre-activations
+  float *d_zout;   // [4][N]   dL/d head pre-activations
+  float *d_conv;   // [160][N] dL/d conv pre-activations (relu applied)
   float *grad_state0, *grad_h0, *grad_c0;
-  ApgLstmPolicy pol;
+  const float *tables;
   QuadConst c;
   ApgQuadLossWeights w;
   int B, ref_cols, vel_col;
 };
 
-__global__ __launch_bounds__(kBlock) void lstm_rollout_bwd_kernel(BwdArgs A) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
-  load_policy(lds, A.pol);
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = b < A.B;
-  const int bb = live ? b : A.B - 1;
+__global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds(lds, A.tables, kBwdLds);
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const LdsView L(lds, lane);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = (blockIdx.x * (kThreads / 64) + wave) * 32 + (lane & 31);
   const int B = A.B;
-  const size_t N = (size_t)kH * B;
+  const bool live = b < B;
+  const bool st_lo = live && hi == 0;
+  const unsigned pitchB = (unsigned)B * 4u, pitchN = pitchB * kH;
   const QuadConst c = A.c;
+  const Planes Ps0(A.state0, 12, pitchB), Pst(A.states, kH * 12, pitchB);
+  const Planes Pac(A.actions, kH * 4, pitchB), Prf(A.ref, kH * A.ref_cols, pitchB);
+  const Planes Pg(A.gates, kNG, pitchN), Phc(A.hc, 2 * kNH, pitchN);
+  const Planes Pmk(A.mask, 5, pitchN), Pdg(A.d_gates, kNG, pitchN);
+  const Planes Pdz(A.d_zout, 4, pitchN), Pdc(A.d_conv, kNC * kNP, pitchN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
 
-  float lam[12], dh[kNH], dc[kNH];
+  float lam[12], dh[4], dc[4];
 #pragma unroll
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
 #pragma unroll
-  for (int m = 0; m < kNH; ++m) dh[m] = 0.f, dc[m] = 0.f;
+  for (int r = 0; r < 4; ++r) dh[r] = 0.f, dc[r] = 0.f;
   float loss = 0.f;
 
 #pragma unroll 1
   for (int k = kH - 1; k >= 0; --k) {
-    const size_t n = (size_t)k * B + bb;
+    const unsigned pB = opaque(pitchB), pN = opaque(pitchN);
+    const unsigned col = (unsigned)b * 4u + (unsigned)k * pitchB;
+    const unsigned vn = live ? col : kDead;
+    const unsigned vn_lo = st_lo ? col : kDead;
+    const unsigned vr = live ? col + (hi ? 4u * pitchN : 0u) : kDead;
     float sn[12], sc[12], a[4], rp[3], rv[3];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-      sn[i] = A.states[((size_t)k * 12 + i) * B + bb];
-      sc[i] = k > 0 ? A.states[((size_t)(k - 1) * 12 + i) * B + bb]
-                    : A.state0[(size_t)i * B + bb];
+      sn[i] = Pst.ld(vb, (k * 12 + i) * pB);
+      sc[i] = k > 0 ? Pst.ld(vb, ((k - 1) * 12 + i) * pB) : Ps0.ld(vb, i * pB);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = A.actions[((size_t)k * 4 + j) * B + bb];
+    for (int j = 0; j < 4; ++j) a[j] = Pac.ld(vb, (k * 4 + j) * pB);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      rp[i] = A.ref[((size_t)k * A.ref_cols + i) * B + bb];
-      rv[i] = A.ref[((size_t)k * A.ref_cols + A.vel_col + i) * B + bb];
+      rp[i] = Prf.ld(vb, (k * A.ref_cols + i) * pB);
+      rv[i] = Prf.ld(vb, (k * A.ref_cols + A.vel_col + i) * pB);
     }
+    unsigned mw[5];
+#pragma unroll
+    for (int eb = 0; eb < 5; ++eb) mw[eb] = Pmk.ldu(vn, eb * pN);
+    float gt[16], cp[4];  // activated gates and c_prev of units r + 4 hi
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gt[i] = Pg.ld(vr, ((i >> 2) * kNH + (i & 3)) * pN);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cp[r] = Phc.ld(vr, (kNH + r) * pN);
+    __builtin_amdgcn_sched_barrier(0);
     // loss terms of step k and their seeds (drone_loss.py:22-34)
     float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
 #pragma unroll
@@ -323,97 +386,105 @@ __global__ __launch_bounds__(kBlock) void lstm_rollout_bwd_kernel(BwdArgs A) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       dz[j] = ga[j] * a[j] * (1.f - a[j]);
-      if (live) A.d_zout[(size_t)j * N + n] = dz[j];
+      Pdz.st(vn_lo, j * pN, dz[j]);
     }
-    // LSTM cell
-    float dG[kNG];
+    // LSTM cell, lane-local for the units r + 4 hi
+    f32x16 dG;
 #pragma unroll
-    for (int m = 0; m < kNH; ++m) {
-      const float gi = A.gates[(size_t)m * N + n];
-      const float gf = A.gates[(size_t)(kNH + m) * N + n];
-      const float gg = A.gates[(size_t)(2 * kNH + m) * N + n];
-      const float go = A.gates[(size_t)(3 * kNH + m) * N + n];
-      const float cp = A.hc[(size_t)(kNH + m) * N + n];
-      const float tc = tanhf(gf * cp + gi * gg);
-      float dht = dh[m];
+    for (int r = 0; r < 4; ++r) {
+      const float gi = gt[r], gf = gt[4 + r], gg = gt[8 + r], go = gt[12 + r];
+      const float tc = tanh_fast(fmaf(gf, cp[r], gi * gg));
+      float dht = dh[r];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dht = fmaf(lds[oWo + j * kNH + m], dz[j], dht);
-      const float dct = dc[m] + dht * go * (1.f - tc * tc);
-      dG[m] = dct * gg * gi * (1.f - gi);
-      dG[kNH + m] = dct * cp * gf * (1.f - gf);
-      dG[2 * kNH + m] = dct * gi * (1.f - gg * gg);
-      dG[3 * kNH + m] = dht * tc * go * (1.f - go);
-      dc[m] = dct * gf;
-    }
-    if (live) {
-#pragma unroll
-      for (int q = 0; q < kNG; ++q) A.d_gates[(size_t)q * N + n] = dG[q];
+      for (int j = 0; j < 4; ++j) dht = fmaf(L.T(rTo + (j * 4 + r) * 2), dz[j], dht);
+      const float dct = dc[r] + dht * go * (1.f - tc * tc);
+      dG[r] = dct * gg * gi * (1.f - gi);
+      dG[4 + r] = dct * cp[r] * gf * (1.f - gf);
+      dG[8 + r] = dct * gi * (1.f - gg * gg);
+      dG[12 + r] = dht * tc * go * (1.f - go);
+      dc[r] = dct * gf;
     }
 #pragma unroll
-    for (int m = 0; m < kNH; ++m) dh[m] = dot32(&lds[oWhh + m * kNG], dG);
-    // state features
+    for (int i = 0; i < 16; ++i) Pdg.st(vr, ((i >> 2) * kNH + (i & 3)) * pN, dG[i]);
+    // dL/dh_prev = W_hh^T dG and dL/dfeatures = W_ih[:, :15]^T dG
+    f32x16 yh, yf;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) yh[i] = 0.f, yf[i] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      yh = mfma(L.A(rAh + cc * 64), dG[cc], yh);
+      yf = mfma(L.A(rAf + cc * 64), dG[cc], yf);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[r] = yh[r];  // rows r + 4 hi = the lane's units
     float dfeat[kNF], gs[12];
 #pragma unroll
-    for (int j = 0; j < kNF; ++j) dfeat[j] = dot32(&lds[oWih + j * kNG], dG);
+    for (int i = 0; i < 8; ++i) {
+      const float own = yf[i], oth = other_half(own);
+      dfeat[rrow(i)] = hi ? oth : own;
+      if (rrow(i) + 4 < kNF) dfeat[rrow(i) + 4 < kNF ? rrow(i) + 4 : 0] = hi ? own : oth;
+    }
     quad_features_adjoint(sc, t, dfeat, gs);
 #pragma unroll
     for (int i = 0; i < 12; ++i) lam[i] += gs[i];
-    // conv branch: relu mask from the saved activations; only the position
+    // conv outputs: five 32-row blocks over e = ch*8 + pos; only the position
     // columns of the window carry a gradient (rel = ref - pos)
-    unsigned mask[5];
+    float dpos[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 5; ++i) mask[i] = A.mask[(size_t)i * N + n];
-    float4 wrow[kNG / 4];  // W_ih row of the next conv element (prefetched)
+    for (int eb = 0; eb < 5; ++eb) {
+      f32x16 y0, y1;
 #pragma unroll
-    for (int q = 0; q < kNG / 4; ++q)
-      wrow[q] = *reinterpret_cast<const float4 *>(&lds[oWih + kNF * kNG + 4 * q]);
-#pragma unroll 1
-    for (int ch = 0; ch < kNC; ++ch) {
-      float sum = 0.f;
-      const unsigned bits = (mask[ch >> 2] >> (8 * (ch & 3))) & 0xffu;
+      for (int i = 0; i < 16; ++i) y0[i] = 0.f, y1[i] = 0.f;
 #pragma unroll
-      for (int pos = 0; pos < kNP; ++pos) {
-        const int j = kNF + ch * kNP + pos;
-        float4 wcur[kNG / 4];
-#pragma unroll
-        for (int q = 0; q < kNG / 4; ++q) wcur[q] = wrow[q];
-        const int jn = j + 1 < kNX ? j + 1 : j;
-#pragma unroll
-        for (int q = 0; q < kNG / 4; ++q)
-          wrow[q] = *reinterpret_cast<const float4 *>(&lds[oWih + jn * kNG + 4 * q]);
-        const float dxe = dot32(wcur, dG);
-        const float dcp = ((bits >> pos) & 1u) ? dxe : 0.f;
-        if (live) A.d_conv[(size_t)(ch * kNP + pos) * N + n] = dcp;
-        sum += dcp;
+      for (int cc = 0; cc < 16; cc += 2) {
+        y0 = mfma(L.A(rAc + (eb * 16 + cc) * 64), dG[cc], y0);
+        y1 = mfma(L.A(rAc + (eb * 16 + cc + 1) * 64), dG[cc + 1], y1);
       }
+      const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];  // bit r(i) + 4 hi -> bit r(i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) lam[q] -= lds[oA + ch * 3 + q] * sum;
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g
+        float sum = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = 4 * g + ii;
+          const float dcp = ((mws >> rrow(i)) & 1u) ? y0[i] + y1[i] : 0.f;
+          Pdc.st(vr, (eb * 32 + rrow(i)) * pN, dcp);
+          sum += dcp;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          dpos[q] = fmaf(L.U(rAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
+      }
     }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) lam[q] -= dpos[q] + other_half(dpos[q]);
   }
-  if (live) {
-    if (A.grad_state0)
+  if (st_lo && A.grad_state0)
 #pragma unroll
-      for (int i = 0; i < 12; ++i) A.grad_state0[(size_t)i * B + b] = lam[i];
-    if (A.grad_h0)
+    for (int i = 0; i < 12; ++i) A.grad_state0[(size_t)i * B + b] = lam[i];
+  if (live && A.grad_h0)
 #pragma unroll
-      for (int m = 0; m < kNH; ++m) A.grad_h0[(size_t)m * B + b] = dh[m];
-    if (A.grad_c0)
+    for (int r = 0; r < 4; ++r) A.grad_h0[(size_t)(r + 4 * hi) * B + b] = dh[r];
+  if (live && A.grad_c0)
 #pragma unroll
-      for (int m = 0; m < kNH; ++m) A.grad_c0[(size_t)m * B + b] = dc[m];
-  }
-  // one loss partial per wave (kBlock / 64 waves per workgroup)
-  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+    for (int r = 0; r < 4; ++r) A.grad_c0[(size_t)(r + 4 * hi) * B + b] = dc[r];
+  write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
 }
 
 int check_lstm(const ApgQuadParams *params, const ApgLstmPolicy *pol, int B, int H) {
   if (!params || !pol) { set_error("params / policy is NULL"); return APG_ERR_ARG; }
   if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
+  if ((long long)B * kH * 4 * kNX >= (1ll << 32) - 64) {
+    set_error("B too large for 32-bit plane offsets (max %d); split the batch",
+              (int)(((1ll << 32) - 64) / (kH * 4 * kNX)));
+    return APG_ERR_ARG;
+  }
   if (H != kH) {
     set_error("the fused LSTM rollout is built for horizon %d (got %d)", kH, H);
     return APG_ERR_ARG;
   }
-  if (!pol->conv_w || !pol->conv_b || !pol->w_ih_t || !pol->w_hh_t ||
-      !pol->b_gates || !pol->w_out || !pol->b_out) {
+  if (!pol->conv_w || !pol->conv_b || !pol->w_ih || !pol->w_hh || !pol->b_ih ||
+      !pol->b_hh || !pol->w_out || !pol->b_out) {
     set_error("policy weight pointer is NULL");
     return APG_ERR_ARG;
   }
@@ -427,17 +498,26 @@ using namespace apg;
 
 extern "C" {
 
+int apg_quad_lstm_workspace_floats(void) {
+  return kFwdLds > kBwdLds ? kFwdLds : kBwdLds;
+}
+
+int apg_quad_lstm_loss_partials_count(int B) {
+  return B <= 0 ? 0 : ((B + kTrajPerBlock - 1) / kTrajPerBlock) * (kThreads / kWave);
+}
+
 int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
                               const float *h0, const float *c0, float dt,
                               const ApgQuadParams *params,
                               const ApgLstmPolicy *policy, int B, int H,
                               float *states, float *actions, float *x,
                               float *gates, float *hc, float *hnew,
-                              unsigned *relu_mask, apg_stream_t stream) {
+                              unsigned *relu_mask, float *workspace,
+                              apg_stream_t stream) {
   if (int e = check_lstm(params, policy, B, H)) return e;
   if (B == 0) return APG_OK;
   if (!state0 || !in_ref || !h0 || !c0 || !states || !actions || !x || !gates ||
-      !hc || !hnew || !relu_mask) {
+      !hc || !hnew || !relu_mask || !workspace) {
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
@@ -446,11 +526,17 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
   A.states = states, A.actions = actions, A.x = x, A.gates = gates, A.hc = hc;
   A.hnew = hnew;
   A.mask = relu_mask;
-  A.pol = *policy;
+  A.tables = workspace;
   A.c = make_const(*params, dt);
   A.B = B;
-  hipLaunchKernelGGL(lstm_rollout_fwd_kernel, dim3((B + kBlock - 1) / kBlock),
-                     dim3(kBlock), 0, (hipStream_t)stream, A);
+  PackArgs P;
+  P.pol = *policy, P.dst = workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(lstm_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256),
+                     0, st, P);
+  hipLaunchKernelGGL(lstm_rollout_fwd_kernel,
+                     dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
+                     kFwdLds * sizeof(float), st, A);
   return check_launch("quad_lstm_rollout_fwd");
 }
 
@@ -463,7 +549,7 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const ApgLstmPolicy *policy, int B, int H,
                               float *loss_partials, float *loss, float *d_gates,
                               float *d_zout, float *d_conv, float *grad_state0,
-                              float *grad_h0, float *grad_c0,
+                              float *grad_h0, float *grad_c0, float *workspace,
                               apg_stream_t stream) {
   if (int e = check_lstm(params, policy, B, H)) return e;
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
@@ -478,7 +564,7 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
     return APG_OK;
   }
   if (!state0 || !states || !actions || !ref || !relu_mask || !gates || !hc ||
-      !loss_partials || !d_gates || !d_zout || !d_conv) {
+      !loss_partials || !d_gates || !d_zout || !d_conv || !workspace) {
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
@@ -488,15 +574,20 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
   A.loss_partials = loss_partials, A.d_gates = d_gates, A.d_zout = d_zout;
   A.d_conv = d_conv, A.grad_state0 = grad_state0, A.grad_h0 = grad_h0;
   A.grad_c0 = grad_c0;
-  A.pol = *policy;
+  A.tables = workspace;
   A.c = make_const(*params, dt);
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
-  const int blocks = (B + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(lstm_rollout_bwd_kernel, dim3(blocks), dim3(kBlock), 0, st, A);
+  PackArgs P;
+  P.pol = *policy, P.dst = workspace;
+  hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3((kBwdLds + 255) / 256), dim3(256),
+                     0, st, P);
+  const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
+  hipLaunchKernelGGL(lstm_rollout_bwd_kernel, dim3(blocks), dim3(kThreads),
+                     kBwdLds * sizeof(float), st, A);
   if (int e = check_launch("quad_lstm_rollout_bwd")) return e;
   if (loss)
-    return launch_reduce_partials(loss_partials, blocks * (kBlock / kWave), loss, st);
+    return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave), loss, st);
   return APG_OK;
 }
 

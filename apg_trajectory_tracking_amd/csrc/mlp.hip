@@ -39,6 +39,7 @@
 // planes; the host reduces them against the saved activation planes with
 // apg_planes_gemm.
 #include "apg_device.h"
+#include "policy_mfma.h"
 #include "quad_math.h"
 
 namespace apg {
@@ -49,41 +50,6 @@ constexpr int kW = 64;               // width of s1, h1, h2, h3
 constexpr int kN1 = kW + kNC * kNP;  // fc1 input width (224)
 constexpr int kThreads = 512;
 constexpr int kTrajPerBlock = kThreads / 2;
-constexpr unsigned kDead = 0xFFFFFFFCu;  // buffer offset beyond any tensor
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__host__ __device__ constexpr int rrow(int i) { return (i & 3) + 8 * (i >> 2); }
-// input index fed by accumulator register c & 15 of row block c >> 4
-__host__ __device__ constexpr int kchain(int c, int hi) {
-  return (c >> 4) * 32 + rrow(c & 15) + 4 * hi;
-}
-
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// tanh: 1 - 2 / (exp(2|x|) + 1), odd Taylor polynomial below 0.15 where the
-// subtraction would cancel.  <= ~1e-6 relative.
-__device__ __forceinline__ float tanh_fast(float x) {
-  const float ax = fabsf(x);
-  const float e = __expf(2.f * ax);
-  float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-  const float x2 = ax * ax;
-  const float p = ax * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f),
-                                     -1.f / 3.f), 1.f);
-  t = ax < 0.15f ? p : t;
-  return copysignf(t, x);
-}
-
-__device__ __forceinline__ float sigmoidf_(float x) {
-  return 1.0f / (1.0f + expf(-x));
-}
-
-__device__ __forceinline__ float other_half(float v) {
-  return __shfl_xor(v, 32, 64);
-}
-
 // ------------------------------------------------------------ forward sweep
 // LDS map (floats).  The small tables indexed by the half-wave come first,
 // the A-operand tables (indexed by the lane) after them; see LdsView.
@@ -100,29 +66,6 @@ constexpr int fA2 = fA1c + 2 * 8 * 12 * 64; // [2][32][64]
 constexpr int fA3 = fA2 + 2 * 32 * 64;      // [2][32][64]
 constexpr int kFwdLds = fA3 + 2 * 32 * 64;  // 27 136 floats = 108 544 B
 static_assert(fBo + 4 <= fAs, "LDS map");
-
-// LDS reads with compile-time table offsets.  ds_read has a 16-bit immediate
-// byte offset, the tables span > 64 KB: three opaque per-lane bases (half-wave
-// index, lane, lane + kSplit) keep every access "base VGPR + immediate";
-// without them the compiler materialises one address VGPR per distinct
-// offset, hoists all of them out of the step loop and spills them.
-constexpr int kSplit = 255 * 64;
-struct LdsView {
-  const float *lds;
-  int o_0, o_hi, o_l0, o_l1;
-  __device__ __forceinline__ LdsView(const float *l, int lane) : lds(l) {
-    o_0 = 0, o_hi = lane >> 5, o_l0 = lane, o_l1 = lane + kSplit;
-    asm volatile("" : "+v"(o_0), "+v"(o_hi), "+v"(o_l0), "+v"(o_l1));
-  }
-  // wave-uniform entry [off]
-  __device__ __forceinline__ float U(int off) const { return lds[o_0 + off]; }
-  // table entry [off + hi] (off even: [..][2] tables)
-  __device__ __forceinline__ float T(int off) const { return lds[o_hi + off]; }
-  // A operand [off + lane]
-  __device__ __forceinline__ float A(int off) const {
-    return off < kSplit ? lds[o_l0 + off] : lds[o_l1 + (off - kSplit)];
-  }
-};
 
 __device__ __forceinline__ void pack_forward(float *lds, const ApgMlpPolicy &p,
                                              int tid, int T) {
@@ -172,31 +115,6 @@ __device__ __forceinline__ void pack_forward(float *lds, const ApgMlpPolicy &p,
   for (int idx = tid; idx < 4; idx += T) lds[fBo + idx] = p.b_out[idx];
 }
 
-// Plane-addressed global memory through a buffer resource: the per-lane part
-// of the address is ONE 32-bit VGPR, the plane offset a scalar - no 64-bit
-// address pairs per access (the kernels touch ~450 planes per step).
-struct Planes {
-  __amdgpu_buffer_rsrc_t rsrc;
-  __device__ __forceinline__ Planes(const void *base, unsigned planes, unsigned pitch)
-      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
-                                               (int)(planes * pitch), 0x00020000)) {}
-  // voff: per-lane byte offset (VGPR), soff: plane * pitch (scalar)
-  __device__ __forceinline__ float ld(unsigned voff, unsigned soff) const {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                         rsrc, (int)voff, (int)soff, 0));
-  }
-  __device__ __forceinline__ unsigned ldu(unsigned voff, unsigned soff) const {
-    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0);
-  }
-  __device__ __forceinline__ void st(unsigned voff, unsigned soff, float v) const {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc,
-                                          (int)voff, (int)soff, 2);
-  }
-  __device__ __forceinline__ void stu(unsigned voff, unsigned soff, unsigned v) const {
-    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)voff, (int)soff, 2);
-  }
-};
-
 // acc[rb] (row block rb of a 64-wide layer) = bias table at `tab`
 __device__ __forceinline__ void init_bias(f32x16 (&acc)[2], const LdsView &L, int tab) {
 #pragma unroll
@@ -226,22 +144,6 @@ struct PackArgs {
 __global__ __launch_bounds__(256) void mlp_pack_fwd_kernel(PackArgs A) {
   pack_forward(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
                gridDim.x * blockDim.x);
-}
-
-__device__ __forceinline__ void fill_lds(float *lds, const float *src, int floats) {
-  const float4 *s4 = reinterpret_cast<const float4 *>(src);
-  float4 *d4 = reinterpret_cast<float4 *>(lds);
-  for (int i = threadIdx.x; i < floats / 4; i += blockDim.x) d4[i] = s4[i];
-  __syncthreads();
-}
-
-// The plane pitch as the loop body sees it: opaque per iteration, so that the
-// ~450 `plane * pitch` scalar offsets of a step are computed where they are
-// used (one s_mul each on the idle SALU) instead of being hoisted out of the
-// step loop into several hundred live SGPRs.
-__device__ __forceinline__ unsigned opaque(unsigned v) {
-  asm volatile("" : "+s"(v));
-  return v;
 }
 
 // dense64 with the previous layer's tanh applied where the input is consumed

@@ -1,0 +1,120 @@
+// policy_mfma.h - building blocks shared by the in-kernel policies (mlp.hip,
+// lstm.hip): the policy layers of a trajectory batch on
+// v_mfma_f32_32x32x2_f32 with one wave = 32 trajectories.
+//
+// For D = A B + C with A = weights [32 outputs x 2 k], B = activations
+// [2 k x 32 trajectories]:
+//   A operand: lane l supplies A[l & 31][l >> 5]
+//   B operand: lane l supplies B[l >> 5][l & 31]
+//   C / D    : register i of lane l is row r(i) + 4 (l >> 5), column l & 31,
+//              with r(i) = (i & 3) + 8 (i >> 2).
+// Hence accumulator register i of a layer's output IS the B operand of the
+// next layer for the k-pair (r(i), r(i) + 4) - layers chain with no shuffles.
+#pragma once
+#include "apg_device.h"
+
+namespace apg {
+
+constexpr unsigned kDead = 0xFFFFFFFCu;  // buffer offset beyond any tensor
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int rrow(int i) { return (i & 3) + 8 * (i >> 2); }
+// input index fed by accumulator register c & 15 of row block c >> 4
+__host__ __device__ constexpr int kchain(int c, int hi) {
+  return (c >> 4) * 32 + rrow(c & 15) + 4 * hi;
+}
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// tanh: 1 - 2 / (exp(2|x|) + 1), odd Taylor polynomial below 0.15 where the
+// subtraction would cancel.  <= ~1e-6 relative.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(2.f * ax);
+  float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  const float x2 = ax * ax;
+  const float p = ax * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f),
+                                     -1.f / 3.f), 1.f);
+  t = ax < 0.15f ? p : t;
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return 1.0f / (1.0f + expf(-x));
+}
+
+__device__ __forceinline__ float other_half(float v) {
+  return __shfl_xor(v, 32, 64);
+}
+
+// LDS reads with compile-time table offsets.  ds_read has a 16-bit immediate
+// byte offset, the tables may span > 64 KB: opaque per-lane bases (zero,
+// half-wave index, lane, lane + kSplit) keep every access "base VGPR +
+// immediate"; without them the compiler materialises one address VGPR per
+// distinct offset, hoists all of them out of the step loop and spills them.
+constexpr int kSplit = 255 * 64;
+struct LdsView {
+  const float *lds;
+  int o_0, o_hi, o_l0, o_l1;
+  __device__ __forceinline__ LdsView(const float *l, int lane) : lds(l) {
+    o_0 = 0, o_hi = lane >> 5, o_l0 = lane, o_l1 = lane + kSplit;
+    asm volatile("" : "+v"(o_0), "+v"(o_hi), "+v"(o_l0), "+v"(o_l1));
+  }
+  // wave-uniform entry [off]
+  __device__ __forceinline__ float U(int off) const { return lds[o_0 + off]; }
+  // table entry [off + hi] (off even: [..][2] tables)
+  __device__ __forceinline__ float T(int off) const { return lds[o_hi + off]; }
+  // A operand [off + lane]
+  __device__ __forceinline__ float A(int off) const {
+    return off < kSplit ? lds[o_l0 + off] : lds[o_l1 + (off - kSplit)];
+  }
+};
+
+// Plane-addressed global memory through a buffer resource: the per-lane part
+// of the address is ONE 32-bit VGPR, the plane offset a scalar - no 64-bit
+// address pairs per access (the kernels touch hundreds of planes per step).
+// Lanes that must not touch memory get the offset kDead: their loads return
+// 0 and their stores are dropped by the range check - no branches.
+struct Planes {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ Planes(const void *base, unsigned planes, unsigned pitch)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
+                                               (int)(planes * pitch), 0x00020000)) {}
+  // voff: per-lane byte offset (VGPR), soff: plane * pitch (scalar)
+  __device__ __forceinline__ float ld(unsigned voff, unsigned soff) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                         rsrc, (int)voff, (int)soff, 0));
+  }
+  __device__ __forceinline__ unsigned ldu(unsigned voff, unsigned soff) const {
+    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0);
+  }
+  __device__ __forceinline__ void st(unsigned voff, unsigned soff, float v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc,
+                                          (int)voff, (int)soff, 2);
+  }
+  __device__ __forceinline__ void stu(unsigned voff, unsigned soff, unsigned v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)voff, (int)soff, 2);
+  }
+};
+
+// The plane pitch as the loop body sees it: opaque per iteration, so that the
+// `plane * pitch` scalar offsets of a step are computed where they are used
+// (one s_mul each on the idle SALU) instead of being hoisted out of the step
+// loop into several hundred live SGPRs.
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// workgroup copy of the packed operand tables into LDS (linear, coalesced)
+__device__ __forceinline__ void fill_lds(float *lds, const float *src, int floats) {
+  const float4 *s4 = reinterpret_cast<const float4 *>(src);
+  float4 *d4 = reinterpret_cast<float4 *>(lds);
+  for (int i = threadIdx.x; i < floats / 4; i += blockDim.x) d4[i] = s4[i];
+  __syncthreads();
+}
+
+}  // namespace apg

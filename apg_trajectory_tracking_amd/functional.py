@@ -613,11 +613,10 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
         h0s, c0s = _f32c(h0).t().contiguous(), _f32c(c0).t().contiguous()
         pw = dict(
-            conv_w=_f32c(conv_w), conv_b=_f32c(conv_b),
-            w_ih_t=_f32c(w_ih).t().contiguous(),
-            w_hh_t=_f32c(w_hh).t().contiguous(),
-            b_gates=(_f32c(b_ih) + _f32c(b_hh)).contiguous(),
+            conv_w=_f32c(conv_w), conv_b=_f32c(conv_b), w_ih=_f32c(w_ih),
+            w_hh=_f32c(w_hh), b_ih=_f32c(b_ih), b_hh=_f32c(b_hh),
             w_out=_f32c(w_out), b_out=_f32c(b_out))
+        pw = {k: v.contiguous() for k, v in pw.items()}
         require_device(s0, inr, rf, h0s, c0s, *pw.values())
         pol = _capi.ApgLstmPolicy(**{k: ptr(v) for k, v in pw.items()})
         N = H * B
@@ -630,12 +629,13 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         gates = new(32, N)
         relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
         st = stream_of(s0)
+        ws = new(lib().apg_quad_lstm_workspace_floats())
         check(lib().apg_quad_lstm_rollout_fwd(
             ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
             ctypes.byref(params), ctypes.byref(pol), B, H, ptr(states),
             ptr(actions), ptr(x), ptr(gates), ptr(hc), ptr(hnew),
-            relu_mask.data_ptr(), st), "apg_quad_lstm_rollout_fwd")
-        partials = new(2 * ((B + 127) // 128))
+            relu_mask.data_ptr(), ptr(ws), st), "apg_quad_lstm_rollout_fwd")
+        partials = new(max(1, lib().apg_quad_lstm_loss_partials_count(B)))
         loss = new(1)
         d_gates, d_zout, d_conv = new(32, N), new(4, N), new(160, N)
         check(lib().apg_quad_lstm_rollout_bwd(
@@ -644,7 +644,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             ctypes.byref(params),
             ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
             ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), None, None,
-            None, st), "apg_quad_lstm_rollout_bwd")
+            None, ptr(ws), st), "apg_quad_lstm_rollout_bwd")
         ctx.save_for_backward(refbuf, acts, d_gates, d_zout, d_conv)
         ctx.mark_non_differentiable(states, actions)
         ctx.dims = (B, H)

@@ -153,14 +153,15 @@ int apg_quad_features_bwd(const float *state, const float *grad_features,
 /* LSTM_NEW with the conv branch (neural_control/models/rnn.py:8-51) for
  * state_dim 15, horizon 10, ref_dim 9, 4 actions: conv1d(9 -> 20, k = 3) over
  * the 10-row reference window, LSTMCell(15 + 160 -> 8), Linear(8 -> 4).
- * Device pointers; `w_ih_t` / `w_hh_t` are the TRANSPOSED weight matrices
- * (input index major), `b_gates` = bias_ih + bias_hh. */
+ * Device pointers to the plain row-major torch parameters (the kernels
+ * gather them into matrix-core operand order themselves). */
 typedef struct ApgLstmPolicy {
   const float *conv_w;  /* [20][9][3] conv_ref.weight */
   const float *conv_b;  /* [20]       conv_ref.bias   */
-  const float *w_ih_t;  /* [175][32]  lstm.weight_ih^T (gate order i,f,g,o) */
-  const float *w_hh_t;  /* [8][32]    lstm.weight_hh^T */
-  const float *b_gates; /* [32]       lstm.bias_ih + lstm.bias_hh */
+  const float *w_ih;    /* [32][175]  lstm.weight_ih (gate order i,f,g,o) */
+  const float *w_hh;    /* [32][8]    lstm.weight_hh */
+  const float *b_ih;    /* [32]       lstm.bias_ih */
+  const float *b_hh;    /* [32]       lstm.bias_hh */
   const float *w_out;   /* [4][8]     fc_out.weight */
   const float *b_out;   /* [4]        fc_out.bias */
 } ApgLstmPolicy;
@@ -169,32 +170,38 @@ typedef struct ApgLstmPolicy {
  * TrainDrone.train_recurrent_model (scripts/train_drone.py:134-157) for
  * train_mode "LSTM" - per step: window made relative to the current position
  * (copied), state_preprocessing, LSTM_NEW.forward, sigmoid,
- * FlightmareDynamics - all H = 10 steps of a trajectory in one lane, policy
- * weights in LDS, hidden / cell state and the sliding window in registers.
+ * FlightmareDynamics - all H = 10 steps in one launch, gate projection and
+ * conv on the matrix cores (one wave = 32 trajectories), hidden / cell state
+ * and the sliding window in registers.
  * SoA only:  state0 [12][B], in_ref [2H][9][B], h0 / c0 [8][B].
  * Outputs (caller-allocated, N = H*B, plane index = step*B + trajectory):
  *   states [H][12][B], actions [H][4][B],
  *   x [175][N]   LSTM inputs (features, relu(conv)),
  *   gates [32][N] activated gates (i, f, g, o), hc [16][N] = h_prev, c_prev,
- *   hnew [8][N], relu_mask [5][N] (bit ch*8+pos = conv output > 0). */
+ *   hnew [8][N], relu_mask [5][N] (bit ch*8+pos = conv output > 0).
+ * `workspace`: apg_quad_lstm_workspace_floats() floats of scratch (weights in
+ * operand order); forward and reverse call may share it (same stream). */
+int apg_quad_lstm_workspace_floats(void);
 int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
                               const float *h0, const float *c0, float dt,
                               const ApgQuadParams *params,
                               const ApgLstmPolicy *policy, int B, int H,
                               float *states, float *actions, float *x,
                               float *gates, float *hc, float *hnew,
-                              unsigned *relu_mask, apg_stream_t stream);
+                              unsigned *relu_mask, float *workspace,
+                              apg_stream_t stream);
 
 /* Reverse sweep (BPTT) of the above + quad_mpc_loss on ref[:, :H]
  * (scripts/train_drone.py:159-168).  ref [H][ref_cols][B].  Writes the loss
- * (loss_partials needs 2 * ceil(B / 128) floats) and the per-(step,
- * trajectory) cotangents the weight gradients are built from with plain GEMMs:
+ * (loss_partials: apg_quad_lstm_loss_partials_count(B) floats) and the
+ * cotangent planes from which the host forms the weight gradients:
  *   d_gates [32][N] (gate pre-activations), d_zout [4][N] (head
  *   pre-activations), d_conv [160][N] (conv pre-activations, ch-major);
  * optional grad_state0 [12][B], grad_h0 / grad_c0 [8][B].
  *   dW_ih = d_gates x^T, dW_hh = d_gates h_prev^T, db_ih = db_hh = sum d_gates,
  *   dW_out = d_zout hnew^T, db_out = sum d_zout,
  *   dconv_w[ch][c][t] = sum_{pos,n} d_conv[ch][pos][n] window[n][pos+t][c]. */
+int apg_quad_lstm_loss_partials_count(int B);
 int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const float *actions, const float *ref,
                               int ref_cols, const unsigned *relu_mask,
@@ -204,7 +211,7 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const ApgLstmPolicy *policy, int B, int H,
                               float *loss_partials, float *loss, float *d_gates,
                               float *d_zout, float *d_conv, float *grad_state0,
-                              float *grad_h0, float *grad_c0,
+                              float *grad_h0, float *grad_c0, float *workspace,
                               apg_stream_t stream);
 
 /* ------------------------------------------- quad, MLP policy in-kernel ---- */
