@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libapg_hip.so")
+# APG_LIB: load an alternative build of the same ABI (kernel experiments)
+LIB_PATH = os.environ.get("APG_LIB") or os.path.join(_HERE, "csrc", "libapg_hip.so")
 
 LAYOUT_SOA = 0
 LAYOUT_AOS = 1

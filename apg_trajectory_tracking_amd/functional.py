@@ -638,14 +638,19 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         partials = new(max(1, lib().apg_quad_lstm_loss_partials_count(B)))
         loss = new(1)
         d_gates, d_zout, d_conv = new(32, N), new(4, N), new(160, N)
+        # optional input gradients (state0, h0, c0)
+        g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
+        g_h0 = new(8, B) if ctx.needs_input_grad[3] else None
+        g_c0 = new(8, B) if ctx.needs_input_grad[4] else None
         check(lib().apg_quad_lstm_rollout_bwd(
             ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1],
             relu_mask.data_ptr(), ptr(gates), ptr(hc), float(dt),
             ctypes.byref(params),
             ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
-            ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), None, None,
-            None, ptr(ws), st), "apg_quad_lstm_rollout_bwd")
+            ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), ptr(g_s0),
+            ptr(g_h0), ptr(g_c0), ptr(ws), st), "apg_quad_lstm_rollout_bwd")
         ctx.save_for_backward(refbuf, acts, d_gates, d_zout, d_conv)
+        ctx.input_grads = (g_s0, g_h0, g_c0)
         ctx.mark_non_differentiable(states, actions)
         ctx.dims = (B, H)
         return loss.reshape(()), states, actions
@@ -671,7 +676,8 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         flat *= g
         d_conv_w, d_conv_b = c3[:, :27].reshape(20, 9, 3), c3[:, 27]
         grads = [d_conv_w, d_conv_b, d_w_ih, d_w_hh, d_b, d_b, d_w_out, d_b_out]
-        return (None, None, None, None, None, *grads, None, None, None)
+        g_s0, g_h0, g_c0 = (None if v is None else v.t() * g for v in ctx.input_grads)
+        return (g_s0, None, None, g_h0, g_c0, *grads, None, None, None)
 
 
 def quad_lstm_rollout_loss(net, state0, in_ref, ref, dt, params, h0, c0,
@@ -734,13 +740,15 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
         partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
         loss = new(1)
         d_pre, d_zout, d_conv = new(256, N), new(4, N), new(160, N)
+        g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
         check(lib().apg_quad_mlp_rollout_bwd(
             ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1], ptr(x1),
             ptr(h), relu_mask.data_ptr(), float(dt), ctypes.byref(params),
             ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
-            ptr(loss), ptr(d_pre), ptr(d_zout), ptr(d_conv), None, ptr(ws),
+            ptr(loss), ptr(d_pre), ptr(d_zout), ptr(d_conv), ptr(g_s0), ptr(ws),
             st), "apg_quad_mlp_rollout_bwd")
         ctx.save_for_backward(refbuf, acts, d_pre, d_zout, d_conv)
+        ctx.input_grads = (g_s0,)
         ctx.mark_non_differentiable(states, actions)
         ctx.dims = (B, H)
         return loss.reshape(()), states, actions
@@ -768,7 +776,8 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
         grads = [cs[:, :15], cs[:, 15], cc[:, :27].reshape(20, 9, 3), cc[:, 27],
                  c1[:, :224], c1[:, 224], c2[:, :64], c2[:, 64],
                  c3[:, :64], c3[:, 64], co[:, :64], co[:, 64]]
-        return (None, None, None, *grads, None, None, None)
+        g_s0 = None if ctx.input_grads[0] is None else ctx.input_grads[0].t() * g
+        return (g_s0, None, None, *grads, None, None, None)
 
 
 def quad_mlp_rollout_loss(net, state0, in_ref, ref, dt, params, weights=None):

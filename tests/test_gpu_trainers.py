@@ -305,6 +305,59 @@ def test_fused_mlp_ragged_batches_match_unfused(dev, B):
         assert rel_err(g1[k], g0[k]) < 2e-4, k
 
 
+@pytest.mark.parametrize("mode", ["lstm", "mlp"])
+def test_fused_policy_input_gradients(dev, mode):
+    """dL/dstate0 (and dL/dh0, dL/dc0 for the LSTM) of the in-kernel policies
+    against autograd through the per-step path - checks the carried adjoints
+    (lambda, dh, dc) of the reverse sweeps end to end."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.drone_loss import quad_mpc_loss
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    B, H = 77, 10
+    d = synthetic.quad_polynomial_batch(B, H, 0.1, seed=11, ref_length=20)
+    in_ref, ref = d["in_ref"].to(dev), d["ref"].to(dev)
+    torch.manual_seed(3)
+    net = (LSTM_NEW if mode == "lstm" else Net)(15, 10, 9, 4, conv=1).to(dev)
+    dyn = FlightmareDynamics()
+    gen = torch.Generator().manual_seed(8)
+    h0, c0 = (torch.randn(B, 8, generator=gen).to(dev) for _ in range(2))
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in
+                ((d["state0"].to(dev), h0, c0) if mode == "lstm"
+                 else (d["state0"].to(dev),))]
+
+    # per-step path
+    ins = leaves()
+    cur = ins[0]
+    if mode == "lstm":
+        net.hidden_state, net.cell_state = ins[1], ins[2]
+    sts, acs = [], []
+    for k in range(H):
+        rel = in_ref[:, k:k + H].clone()
+        rel[:, :, :3] = rel[:, :, :3] - cur[:, None, :3]
+        a = torch.sigmoid(net(state_preprocessing(cur), rel))
+        cur = dyn(cur, a, dt=0.1)
+        sts.append(cur), acs.append(a)
+    quad_mpc_loss(torch.stack(sts, 1), ref[:, :H], torch.stack(acs, 1)).backward()
+    want = [t.grad for t in ins]
+    # fused
+    ins = leaves()
+    if mode == "lstm":
+        loss, _, _ = F.quad_lstm_rollout_loss(net, ins[0], in_ref, ref, 0.1,
+                                              dyn.params, ins[1], ins[2])
+    else:
+        loss, _, _ = F.quad_mlp_rollout_loss(net, ins[0], in_ref, ref, 0.1, dyn.params)
+    (2.0 * loss).backward()
+    for t, w in zip(ins, want):
+        assert t.grad is not None
+        assert rel_err(N(t.grad), 2.0 * N(w)) < 1e-4
+
+
 def test_wing_and_cartpole_run_epoch(dev):
     """Multi-batch epochs of the other two systems through the real loader /
     SGD path: finite, decreasing losses; `epoch_loss = running_loss / i`."""
