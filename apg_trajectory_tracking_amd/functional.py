@@ -791,3 +791,50 @@ def quad_mlp_rollout_loss(net, state0, in_ref, ref, dt, params, weights=None):
         net.fc2.weight, net.fc2.bias, net.fc3.weight, net.fc3.bias,
         net.fc_out.weight, net.fc_out.bias, dt, params,
         weights or quad_loss_weights())
+
+
+# ------------------------------------------ batched closed-loop evaluation (N2)
+def quad_mlp_closed_loop(net, traj, dt, params, max_steps=251, thresh_div=1.0,
+                         thresh_stable=1.0, test_time=0, want_trajectory=False):
+    """`QuadEvaluator.follow_trajectory("rand")` (scripts/evaluate_drone.py:
+    81-194) for a batch of reference trajectories in one launch
+    (apg_quad_mlp_closed_loop).  net: hutter_model.Net(15, 10, 9, 4 or 40,
+    conv=1) - a concurrent-mode net uses its first action, as the reference
+    does.  traj [B, L, 9] = (position, euler, velocity) rows, used as given
+    (the reference's Random adds 3 to z: do that before the call).
+    Returns dict(div [T,B], steps [B] int32, and with want_trajectory: drone
+    [T+1,12,B], actions [T,4,B], start_states [T,12,B])."""
+    B, L, _ = traj.shape
+    H = 10
+    dev = traj.device
+    tr = _f32c(traj).permute(1, 2, 0).contiguous()
+    names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
+             "w_3", "b_3", "w_out", "b_out")
+    vals = (net.states_in.weight, net.states_in.bias, net.conv_ref.weight,
+            net.conv_ref.bias, net.fc1.weight, net.fc1.bias, net.fc2.weight,
+            net.fc2.bias, net.fc3.weight, net.fc3.bias, net.fc_out.weight,
+            net.fc_out.bias)
+    pw = {k: _f32c(v.detach()).contiguous() for k, v in zip(names, vals)}
+    if (pw["w_s"].shape != (64, 15) or pw["conv_w"].shape != (20, 9, 3)
+            or pw["w_1"].shape != (64, 224) or pw["w_out"].shape[1] != 64
+            or pw["w_out"].shape[0] < 4):
+        raise ValueError("closed loop needs Net(15, 10, 9, 4*k, conv=1)")
+    require_device(tr, *pw.values())
+    pol = _capi.ApgMlpPolicy(**{k: ptr(v) for k, v in pw.items()})
+    T = min(int(max_steps), L + 1)
+    new = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    div = new(T, B)
+    steps = torch.zeros(B, dtype=torch.int32, device=dev)
+    drone = new(T + 1, 12, B) if want_trajectory else None
+    actions = new(T, 4, B) if want_trajectory else None
+    start = new(T, 12, B) if want_trajectory else None
+    ws = new(lib().apg_quad_mlp_workspace_floats())
+    check(lib().apg_quad_mlp_closed_loop(
+        ptr(tr), L, float(dt), ctypes.byref(params), ctypes.byref(pol), B, H,
+        int(max_steps), float(thresh_div), float(thresh_stable), int(test_time),
+        ptr(div), steps.data_ptr(), ptr(drone), ptr(actions), ptr(start),
+        ptr(ws), stream_of(tr)), "apg_quad_mlp_closed_loop")
+    out = dict(div=div, steps=steps)
+    if want_trajectory:
+        out.update(drone=drone, actions=actions, start_states=start)
+    return out

@@ -115,3 +115,28 @@ def from_soa_state(x):
 def from_soa_seq(x):
     """[H,C,B] -> [B,H,C] contiguous."""
     return x.permute(2, 0, 1).contiguous()
+
+
+def quad_eval_trajectories(batch, length, dt, seed=42, speed=1.0):
+    """Long smooth reference trajectories for the closed-loop evaluation, in the
+    row format of `load_prepare_trajectory` (neural_control/trajectory/
+    generate_trajectory.py:566-605): [position(3), euler(3), velocity(3)] per
+    time step, [B, L, 9].  The reference reads min-snap trajectories from
+    data/traj_data_1 (not shipped); here each axis is a sum of three sinusoids
+    with random amplitude / frequency / phase (bounded, smooth, velocity = the
+    exact derivative), starting at the origin; euler columns are zero."""
+    g = _gen(seed)
+    B, L = batch, length
+    t = torch.arange(L, dtype=torch.float32) * dt
+    amp = torch.rand(B, 3, 3, generator=g) * torch.tensor([1.5, 0.6, 0.2]) + 0.05
+    freq = (torch.rand(B, 3, 3, generator=g) * torch.tensor([0.5, 0.8, 1.0])
+            + torch.tensor([0.2, 0.7, 1.5])) * speed
+    phase = torch.rand(B, 3, 3, generator=g) * (2 * math.pi)
+    arg = freq[..., None] * t + phase[..., None]                  # [B,3,3,L]
+    pos = (amp[..., None] * torch.sin(arg)).sum(2)                # [B,3,L]
+    vel = (amp[..., None] * freq[..., None] * torch.cos(arg)).sum(2)
+    pos = pos - pos[:, :, :1]
+    traj = torch.zeros(B, L, 9)
+    traj[:, :, 0:3] = pos.transpose(1, 2)
+    traj[:, :, 6:9] = vel.transpose(1, 2)
+    return traj

@@ -1,9 +1,9 @@
 """Drop-in for scripts/train_base.py:30-375 (`TrainBase`) restricted to the
 APG hot path: constructor keywords / derived dims (:32-128), init_optimizer
 (:130-150), run_epoch (:188-218), sample_new_data (:220-231), plus a minimal
-run_control loop.  Closed-loop evaluation, curriculum, plots and the
-learnt-dynamics branch are out of scope - `evaluate_model` is a
-hook that subclasses / users may provide.
+run_control loop.  `evaluate_model` is a hook: TrainDrone provides the batched
+closed-loop evaluation (evaluate_drone.py); the speed
+curriculum and plots are out of scope.
 
 Differences that matter for speed, not for results:
   * minibatches come from whole device tensors (dataset.TensorBatches)
@@ -240,7 +240,7 @@ class TrainBase:
 
     # -------------------------------------------------------------- cold
     def evaluate_model(self, epoch):
-        """Hook: closed-loop evaluation is out of scope here."""
+        """Hook (scripts/train_base.py:298): TrainDrone evaluates in closed loop."""
         return None
 
     def save_model(self, epoch, success=0.0, suc_std=0.0):
@@ -258,8 +258,8 @@ class TrainBase:
     def run_control(self, config, sampling_based_finetune=False, curriculum=0):
         try:
             for epoch in range(config["nr_epochs"]):
-                self.evaluate_model(epoch)
-                self.sample_new_data(epoch)
+                if self.evaluate_model(epoch) is None:   # hook not provided:
+                    self.sample_new_data(epoch)          # it resamples itself
                 print(f"\nEpoch {epoch}")
                 self.run_epoch(train="controller", epoch=epoch)
         except KeyboardInterrupt:

@@ -117,6 +117,39 @@ class TrainDrone(TrainBase):
                 and n.fc1.weight.shape == (64, 224)
                 and n.fc_out.weight.shape == (4, 64))
 
+    def evaluate_model(self, epoch):
+        """scripts/train_drone.py:205-238: closed-loop evaluation on "rand"
+        references (all runs in one launch, evaluate_drone.QuadEvaluator),
+        resampling, divergence-threshold curriculum, checkpoint, statistics."""
+        from .evaluate_drone import QuadEvaluator
+        n = self.net
+        if not (isinstance(n, Net) and n.conv and self.horizon == 10
+                and hasattr(self.eval_dynamics, "params")):
+            return None          # e.g. LSTM controller: no fused evaluator yet
+        self.config.setdefault("thresh_div", self.thresh_div_start)
+        self.config.setdefault("thresh_stable", self.thresh_stable_start)
+        evaluator = QuadEvaluator(n, self.eval_dynamics, **{
+            k: v for k, v in self.config.items()
+            if k in ("ref_length", "dt", "speed_factor", "train_mode")})
+        with torch.no_grad():
+            (suc_mean, suc_std, div_full_mean, div_full_std, div_mean,
+             div_std) = evaluator.run_eval(
+                "rand", nr_test=self.config.get("nr_test", 10),
+                max_steps=self.config.get("max_steps", 251),
+                thresh_div=self.config["thresh_div"],
+                thresh_stable=self.config["thresh_stable"])
+        self.sample_new_data(epoch)
+        if epoch % 5 == 0 and self.config["thresh_div"] < self.thresh_div_end:
+            self.config["thresh_div"] += .05
+        self.save_model(epoch, suc_mean, suc_std)
+        for key, val in (("mean_divergence_full", div_full_mean),
+                         ("std_divergence_full", div_full_std),
+                         ("mean_divergence", div_mean), ("std_divergence", div_std),
+                         ("mean_success", suc_mean), ("std_success", suc_std),
+                         ("thresh_div", self.config["thresh_div"])):
+            self.results_dict[key].append(val)
+        return suc_mean, suc_std
+
     def train_controller_model(
         self, current_state, action_seq, in_ref_states, ref_states
     ):

@@ -277,6 +277,29 @@ int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
                              float *d_zout, float *d_conv, float *grad_state0,
                              float *workspace, apg_stream_t stream);
 
+/* Batched closed-loop evaluation: the loop of
+ * QuadEvaluator.follow_trajectory("rand") (scripts/evaluate_drone.py:81-194)
+ * for B reference trajectories in one launch - per step the H-row reference
+ * window (Random.get_ref_traj, neural_control/trajectory/random_traj.py:60-79),
+ * QuadDataset.prepare_data (dataset.py:155-204), the policy (first 4 outputs of
+ * `policy->w_out`, so a concurrent-mode Net works unchanged), sigmoid, clip,
+ * FlightmareDynamics, the divergence from the projected reference and the
+ * attitude check (drone_env.py:59-72); on failure either stop (test_time) or
+ * reset to the reference state.  traj [L][9][B] = (position, euler, velocity)
+ * rows, L > H.  T = min(max_steps, L + 1) iterations.
+ * Outputs: div [T][B] (rows >= steps[b] are not written), steps [B];
+ * optional (NULL to skip) drone [T+1][12][B] (state after each step, row 0 =
+ * start), actions [T][4][B], start_states [T][12][B] (state the policy saw,
+ * i.e. after a reset).  workspace: apg_quad_mlp_workspace_floats(). */
+int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
+                             const ApgQuadParams *params,
+                             const ApgMlpPolicy *policy, int B, int H,
+                             int max_steps, float thresh_div,
+                             float thresh_stable, int test_time, float *div,
+                             int *steps, float *drone, float *actions,
+                             float *start_states, float *workspace,
+                             apg_stream_t stream);
+
 /* "Planes x planes" reduction GEMM on the matrix cores
  * (v_mfma_f32_32x32x2_f32, exact fp32):
  *   C[m*ldc + j] = sum_{s<S} sum_{n<N} A[(m*S + s)*N + n] * B[bplane(j,s)*N + n]

@@ -379,3 +379,66 @@ def quad_recurrent_unroll(net, dyn, state0, in_ref, ref, horizon, dt):
         inter[:, k] = cur
     loss = quad_mpc_loss(inter, ref[:, :horizon], acts)
     return inter, acts, loss
+
+
+def quad_closed_loop(net, dyn, traj, dt, horizon, max_steps, thresh_div,
+                     thresh_stable, test_time, hidden=None):
+    """Batched restatement of `QuadEvaluator.follow_trajectory("rand")`
+    (scripts/evaluate_drone.py:81-194) with
+      Random.get_ref_traj / project_on_ref / get_current_full_state
+        (neural_control/trajectory/random_traj.py:60-92; +3 on z :34),
+      NetworkWrapper.predict_actions (controllers/network_wrapper.py:42-72),
+      QuadDataset.prepare_data (neural_control/dataset.py:155-204),
+      QuadRotorEnvBase.step / get_is_stable / zero_reset
+        (neural_control/environments/drone_env.py:59-117,129-142).
+    traj [B, L, 9] = (position, euler, velocity) rows; every trajectory runs
+    its own loop (break / reset are per trajectory).  Returns dict with
+    drone [B, T+1, 12], ref [B, T, 3], div [B, T], actions [B, T, 4] and
+    steps [B] (iterations executed; entries beyond are left at zero)."""
+    B, L, _ = traj.shape
+    H = horizon
+    ref = traj.clone()
+    ref[:, :, 2] += 3.0
+    T = min(max_steps, L + 1)
+    state = torch.zeros(B, 12, dtype=traj.dtype)
+    state[:, :3] = ref[:, 0, :3]
+    cur = 0
+    alive = torch.ones(B, dtype=torch.bool)
+    out = dict(drone=torch.zeros(B, T + 1, 12), ref=torch.zeros(B, T, 3),
+               div=torch.zeros(B, T), actions=torch.zeros(B, T, 4),
+               steps=torch.zeros(B, dtype=torch.long))
+    out["drone"][:, 0] = state
+    last = ref[:, -1, :3]
+    with torch.no_grad():
+        for i in range(T):
+            if cur >= L - H:
+                left = ref[:, cur:]
+                pad = torch.zeros(B, H - (L - cur), 9, dtype=traj.dtype)
+                pad[:, :, :3] = last[:, None]
+                window = torch.cat((left, pad), 1)
+            else:
+                window = ref[:, cur + 1:cur + H + 1]
+                cur += 1
+            rel = torch.cat((window[:, :, :3] - state[:, None, :3],
+                             window[:, :, 6:9],
+                             window[:, :, 6:9] - state[:, None, 6:9]), 2)
+            raw = net(quad_state_features(state), rel)
+            action = torch.sigmoid(raw)[:, :4].clamp(0.0, 1.0)
+            new = dyn(state, action, dt)
+            on_line = ref[:, cur, :3]
+            div = torch.linalg.norm(on_line - new[:, :3], dim=1)
+            stable = (new[:, 3:5].abs() < thresh_stable).all(1)
+            rec = alive.clone()
+            out["drone"][rec, i + 1] = new[rec]
+            out["ref"][rec, i] = on_line[rec]
+            out["div"][rec, i] = div[rec]
+            out["actions"][rec, i] = action[rec]
+            out["steps"][rec] = i + 1
+            failed = (div > thresh_div) | ~stable
+            if test_time:
+                alive = alive & ~failed
+            reset = torch.cat((ref[:, cur], torch.zeros(B, 3, dtype=traj.dtype)), 1)
+            state = torch.where((failed & (not test_time))[:, None], reset, new)
+            if i >= L:
+                break
+    return out

@@ -18,6 +18,10 @@ Fixtures:
   losses.npz         G8  the three MPC losses + grads on random inputs
   checkpoints.npz    G9  state_dicts of the shipped controllers + outputs
   learnt_dynamics.npz G10 LearntDynamics forward + parameter gradients
+  closed_loop.npz    G11 QuadEvaluator.follow_trajectory with the shipped quad
+                         controller on injected reference trajectories
+
+`python tests/golden/make_golden.py g11` regenerates selected fixtures only.
 """
 import os
 import sys
@@ -504,19 +508,6 @@ def g8_losses():
     save("losses.npz", **out)
 
 
-if __name__ == "__main__":
-    g1_quad_step()
-    g2_quad_rollout()
-    g3_quad_train()
-    g4_quad_recurrent()
-    g5_wing()
-    g6_cartpole()
-    g7_features()
-    g8_losses()
-    g9_checkpoints()
-    g10_learnt_dynamics()
-
-
 # --------------------------------------------------------------------- G9
 def g9_checkpoints():
     """N4: the controllers the reference ships are whole-module
@@ -585,3 +576,93 @@ def g10_learnt_dynamics():
     for k, p in dyn.named_parameters():
         out["g." + k] = npy(p.grad) if p.grad is not None else np.zeros(1)
     save("learnt_dynamics.npz", **out)
+
+
+# -------------------------------------------------------------------- G11
+def g11_closed_loop():
+    """N2: the closed-loop evaluation of
+    scripts/evaluate_drone.py:81-194 (`QuadEvaluator.follow_trajectory`, "rand"
+    reference) with the controller the reference ships
+    (trained_models/quad, concurrent Net, horizon 10, dt 0.1) through
+    NetworkWrapper.predict_actions -> QuadDataset.prepare_data ->
+    QuadRotorEnvBase.step.  The reference reads its trajectories from
+    data/traj_data_1 (not in the repository); `load_prepare_trajectory` is
+    replaced by a function returning an injected [L, 9] array (position,
+    euler, velocity).  Recorded: the drone trajectory, the projected reference,
+    divergences and actions, with and without `test_time`, and with a tight
+    divergence threshold that triggers the reset-to-reference branch."""
+    import evaluate_drone
+    from neural_control.environments.drone_env import QuadRotorEnvBase
+    from neural_control.environments.helper_simple_env import DynamicsState
+    from neural_control.controllers.network_wrapper import NetworkWrapper
+    from neural_control.dataset import QuadDataset
+    from neural_control.trajectory import random_traj
+
+    net = torch.load(os.path.join(REF, "trained_models", "quad", "current_model",
+                                  "model_quad"), weights_only=False)
+    net.eval()
+    dt, H, L, n_traj, steps = 0.1, 10, 64, 4, 75
+
+    # smooth synthetic references: sums of two sinusoids per axis, z around 3
+    rng = np.random.default_rng(2024)
+    t = np.arange(L) * dt
+    trajs = np.zeros((n_traj, L, 9), dtype=np.float64)
+    for i in range(n_traj):
+        for ax in range(3):
+            a1, a2 = rng.uniform(0.3, 1.0), rng.uniform(0.05, 0.3)
+            w1, w2 = rng.uniform(0.3, 0.9), rng.uniform(1.0, 2.0)
+            p1, p2 = rng.uniform(0, 2 * np.pi, 2)
+            trajs[i, :, ax] = a1 * np.sin(w1 * t + p1) + a2 * np.sin(w2 * t + p2)
+            trajs[i, :, 6 + ax] = a1 * w1 * np.cos(w1 * t + p1) + a2 * w2 * np.cos(w2 * t + p2)
+        trajs[i, :, :3] -= trajs[i, 0, :3]
+        trajs[i, :, 3:6] = 0.02 * rng.standard_normal((L, 3))   # "euler" columns
+    trajs = trajs.astype(np.float32).astype(np.float64)          # fp32-exact inputs
+
+    class Env(QuadRotorEnvBase):      # no renderer, deterministic reset
+        def __init__(self, dynamics, dt):
+            self._state = DynamicsState()
+            self.dt, self.dynamics, self.renderer = dt, dynamics, None
+
+        def reset(self, strength=.8):
+            self._state = DynamicsState()
+
+    dataset = QuadDataset.__new__(QuadDataset)
+    dataset.num_self_play = 0
+    out = {"dt": np.float32(dt), "horizon": np.int64(H), "trajs": trajs.astype(np.float32)}
+    cases = {"train": dict(test_time=0, thresh_div=1.0, thresh_stable=1.0),
+             "test": dict(test_time=1, thresh_div=1.0, thresh_stable=1.0),
+             "tight": dict(test_time=0, thresh_div=0.12, thresh_stable=1.0),
+             "tight_test": dict(test_time=1, thresh_div=0.12, thresh_stable=1.0)}
+    for name, c in cases.items():
+        for i in range(n_traj):
+            random_traj.load_prepare_trajectory = (
+                lambda *a, _r=trajs[i], **k: _r.copy())     # +3 on z is applied inside
+            env = Env(FlightmareDynamics(), dt)
+            ctrl = NetworkWrapper(net, dataset, horizon=H, dt=dt)
+            ev = evaluate_drone.QuadEvaluator(
+                ctrl, env, ref_length=H, dt=dt, test_time=c["test_time"],
+                speed_factor=0.4, train_mode="concurrent")
+            ref_tr, drone_tr, divs, acts = ev.follow_trajectory(
+                "rand", max_nr_steps=steps, thresh_div=c["thresh_div"],
+                thresh_stable=c["thresh_stable"])
+            out[f"{name}.{i}.ref"] = np.asarray(ref_tr, dtype=np.float32)
+            out[f"{name}.{i}.drone"] = np.asarray(drone_tr, dtype=np.float32)
+            out[f"{name}.{i}.div"] = np.asarray(divs, dtype=np.float32)
+            out[f"{name}.{i}.actions"] = np.asarray(acts, dtype=np.float32)
+        out[f"{name}.thresh_div"] = np.float32(c["thresh_div"])
+        out[f"{name}.thresh_stable"] = np.float32(c["thresh_stable"])
+        out[f"{name}.test_time"] = np.int64(c["test_time"])
+        print(name, [len(out[f"{name}.{i}.div"]) for i in range(n_traj)],
+              [float(out[f"{name}.{i}.div"].max()) for i in range(n_traj)])
+    out["max_steps"] = np.int64(steps)
+    save("closed_loop.npz", **out)
+
+
+FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
+                g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
+                g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
+                g11=g11_closed_loop)
+
+if __name__ == "__main__":
+    for key in (sys.argv[1:] or FIXTURES):
+        FIXTURES[key]()

@@ -477,3 +477,80 @@ def test_fused_lstm_ragged_batches_match_unfused(dev, B):
     assert set(g0) == set(g1)
     for k in g0:
         assert rel_err(g1[k], g0[k]) < 2e-4, k
+
+
+@pytest.mark.parametrize("case", ["train", "test", "tight", "tight_test"])
+def test_closed_loop_matches_reference_evaluator(dev, case):
+    """N2 / G11: the batched closed-loop kernel against the reference's
+    QuadEvaluator.follow_trajectory with the shipped quad controller: drone
+    states, projected reference, divergences, actions and the number of steps
+    - tracking, break (test_time) and reset-to-reference branches."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.checkpoint import build_policy
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    g = load_golden("closed_loop.npz")
+    ck = load_golden("checkpoints.npz")
+    sd = {k[len("quad.w."):]: torch.from_numpy(ck[k]) for k in ck.files
+          if k.startswith("quad.w.")}
+    net = build_policy("quad", sd).to(dev)
+    traj = D(g["trajs"], dev).clone()
+    traj[:, :, 2] += 3          # Random.__init__, random_traj.py:34
+    out = F.quad_mlp_closed_loop(
+        net, traj, float(g["dt"]), FlightmareDynamics().params,
+        max_steps=int(g["max_steps"]), thresh_div=float(g[f"{case}.thresh_div"]),
+        thresh_stable=float(g[f"{case}.thresh_stable"]),
+        test_time=int(g[f"{case}.test_time"]), want_trajectory=True)
+    for i in range(traj.shape[0]):
+        n = len(g[f"{case}.{i}.div"])
+        assert int(out["steps"][i]) == n, (case, i)
+        assert rel_err(N(out["drone"][:n + 1, :, i]), g[f"{case}.{i}.drone"]) < 1e-4
+        assert np.abs(N(out["div"][:n, i]) - g[f"{case}.{i}.div"]).max() < 2e-4
+        assert rel_err(N(out["actions"][:n, :, i]), g[f"{case}.{i}.actions"][:, 0]) < 1e-4
+
+
+def test_closed_loop_evaluator_and_oracle_large_batch(dev):
+    """N2 at a batch that spans several workgroups with a ragged tail: the
+    kernel against the batched oracle loop (same net, random smooth
+    trajectories), and QuadEvaluator.run_eval statistics against the same
+    statistics computed from the oracle's divergences."""
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.checkpoint import build_policy
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.evaluate_drone import QuadEvaluator
+    from oracle import torch_port as tp
+    ck = load_golden("checkpoints.npz")
+    sd = {k[len("quad.w."):]: torch.from_numpy(ck[k]) for k in ck.files
+          if k.startswith("quad.w.")}
+    B, L, steps = 300, 40, 30
+    traj = synthetic.quad_eval_trajectories(B, L, 0.1, seed=5)
+    traj[:, :, 2] += 3
+    for test_time, td in ((0, 0.25), (1, 0.25)):
+        net_cpu = build_policy("quad", sd)
+        ref = tp.quad_closed_loop(net_cpu, tp.QuadOracle(), traj, 0.1, 10, steps,
+                                  td, 1.0, test_time)
+        ev = QuadEvaluator(build_policy("quad", sd).to(dev), FlightmareDynamics(),
+                           ref_length=10, dt=0.1, test_time=test_time)
+        _, drone, divs, acts = ev.follow_trajectory(
+            "rand", max_nr_steps=steps, thresh_stable=1.0, thresh_div=td,
+            trajectories=traj)
+        # a divergence within rounding of the threshold may flip a branch:
+        # compare the trajectories that took the same branches
+        same = [i for i in range(B) if len(divs[i]) == int(ref["steps"][i])]
+        assert len(same) > 0.97 * B
+        worst = 0.0
+        for i in same:
+            n = len(divs[i])
+            worst = max(worst, float(np.abs(N(divs[i]) - ref["div"][i, :n].numpy()).max()))
+        # resets re-synchronise both sides, a flipped reset shows up as one
+        # large difference: allow a handful of trajectories to disagree
+        bad = [i for i in same
+               if np.abs(N(divs[i]) - ref["div"][i, :len(divs[i])].numpy()).max() > 2e-3]
+        assert len(bad) <= 0.03 * B, (len(bad), worst)
+        stats = ev.run_eval("rand", nr_test=B, max_steps=steps, thresh_div=td,
+                            thresh_stable=1.0, trajectories=traj)
+        assert all(np.isfinite(stats[k]) for k in (0, 1, 4, 5))
+        st = np.array([int((ref["div"][i, :int(ref["steps"][i])] < td).sum())
+                       for i in range(B)])
+        assert abs(stats[0] - st.mean()) < 0.05 * max(1.0, st.mean())

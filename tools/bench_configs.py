@@ -145,5 +145,21 @@ def main():
                 None, d.states, d.in_ref_states, d.ref_states), 10, 2))
 
 
+    if want("quad_closed_loop"):
+        # N2: batched closed-loop evaluation (251 steps each) with an untrained
+        # AR policy; resets keep every run alive for all steps
+        from apg_trajectory_tracking_amd.models.hutter_model import Net
+        torch.manual_seed(0)
+        net = Net(15, 10, 9, 4, conv=1).to(dev)
+        nt, L, steps = 16384, 501, 251
+        traj = synthetic.quad_eval_trajectories(nt, L, dt, seed=2).to(dev)
+        traj[:, :, 2] += 3
+
+        def step():
+            F.quad_mlp_closed_loop(net, traj, dt, qdyn.params, max_steps=steps,
+                                   thresh_div=1.0, thresh_stable=1.0, test_time=0)
+        emit("quad_closed_loop", nt, steps, timed(step, 5, 2))
+
+
 if __name__ == "__main__":
     main()
