@@ -58,37 +58,88 @@ class TensorBatches:
 # the hot path and not shipped upstream.
 # ---------------------------------------------------------------------------
 class SyntheticQuadDataset:
-    """Counterpart of QuadDataset (neural_control/dataset.py:135-204):
-    `normed_states` are the 15 policy features (state_preprocessing),
+    """Counterpart of QuadDataset / DroneDataset (neural_control/dataset.py:
+    46-204): `normed_states` are the 15 policy features (state_preprocessing),
     `in_ref_states` = [rel. pos, vel, vel - v_drone], `ref_states` the 9-column
-    reference rows the loss reads."""
+    reference rows the loss reads.  As in the reference the set has
+    `num_sampled_states` sampled entries, refreshed by `resample_data`, followed
+    by `num_self_play = int(self_play * num_states)` slots that the closed-loop
+    evaluation overwrites cyclically with the states it visited
+    (`add_eval_data`, the batched form of get_and_add_eval_data :103-119)."""
 
     def __init__(self, num_states, horizon, dt, ref_length=None, seed=0,
-                 device="cuda"):
+                 device="cuda", self_play=0.0):
         self.num_sampled_states = int(num_states)
+        self.num_self_play = int(self_play * num_states)
+        self.total_dataset_size = self.num_sampled_states + self.num_self_play
         self.horizon, self.dt = horizon, dt
         self.ref_length = ref_length or horizon
         self.device = torch.device(device)
         self.seed = seed
         self._epoch = 0
-        self._fill()
-
-    def _fill(self):
-        from . import synthetic
-        d = synthetic.quad_polynomial_batch(
-            self.num_sampled_states, self.horizon, self.dt,
-            seed=self.seed + self._epoch, ref_length=self.ref_length)
-        self.states = d["state0"].to(self.device)
-        self.ref_states = d["ref"].to(self.device)
-        self.in_ref_states = d["in_ref"].to(self.device)
-        with torch.no_grad():
-            self.normed_states = state_preprocessing(self.states)
+        self.eval_counter = 0
         self.mean = torch.zeros(12)
         self.std = torch.ones(12)
+        (self.normed_states, self.states, self.in_ref_states,
+         self.ref_states) = self._sample(self.total_dataset_size)
+
+    def _sample(self, n):
+        from . import synthetic
+        d = synthetic.quad_polynomial_batch(
+            n, self.horizon, self.dt, seed=self.seed + self._epoch,
+            ref_length=self.ref_length)
+        states = d["state0"].to(self.device)
+        with torch.no_grad():
+            normed = state_preprocessing(states)
+        return (normed, states, d["in_ref"].to(self.device),
+                d["ref"].to(self.device))
 
     def resample_data(self):
+        """:87-101 - only the sampled part is renewed."""
         self._epoch += 1
-        self._fill()
+        n = self.num_sampled_states
+        for dst, src in zip((self.normed_states, self.states,
+                             self.in_ref_states, self.ref_states), self._sample(n)):
+            dst[:n] = src
+
+    def prepare_data(self, states, ref_states):
+        """QuadDataset.prepare_data (:155-204) on device tensors: states [n,12],
+        ref_states [n,R,9] (position, euler, velocity rows) -> (policy
+        features, states with the position zeroed, policy reference input,
+        reference rows relative to the drone position)."""
+        states = states.to(self.device, torch.float32).clone()
+        ref = ref_states.to(self.device, torch.float32).clone()
+        pos, vel = states[:, None, :3].clone(), states[:, None, 6:9].clone()
+        ref[:, :, :3] -= pos
+        states[:, :3] = 0
+        with torch.no_grad():
+            normed = state_preprocessing(states)
+        in_ref = torch.cat((ref[:, :, :3], ref[:, :, 6:9], ref[:, :, 6:9] - vel), 2)
+        return normed, states, in_ref, ref
+
+    def get_eval_index(self):
+        if self.num_self_play > 0:
+            return self.eval_counter % self.num_self_play + self.num_sampled_states
+
+    def add_eval_data(self, states, ref_states):
+        """Overwrite the next self-play slots with n visited (state, reference
+        window) pairs, in order, wrapping around like repeated
+        get_and_add_eval_data(..., add_to_dataset=True) calls."""
+        n = states.shape[0]
+        if self.num_self_play == 0 or n == 0:
+            return 0
+        if ref_states.shape[1] != self.ref_length:
+            raise ValueError("reference window length != data set ref_length")
+        prepared = self.prepare_data(states, ref_states)
+        # only the last num_self_play entries survive a wrap-around
+        keep = min(n, self.num_self_play)
+        idx = ((self.eval_counter + torch.arange(n - keep, n, device=self.device))
+               % self.num_self_play + self.num_sampled_states)
+        for dst, src in zip((self.normed_states, self.states,
+                             self.in_ref_states, self.ref_states), prepared):
+            dst[idx] = src[n - keep:]
+        self.eval_counter += n
+        return n
 
     def __len__(self):
         return self.states.shape[0]

@@ -76,10 +76,30 @@ class QuadEvaluator:
                 [divs[i, :n] for i, n in enumerate(steps)],
                 [acts[i, :n] for i, n in enumerate(steps)])
 
+    def add_self_play_data(self, dataset, traj, out, steps, take_every_x):
+        """The (state, window) pairs of every take_every_x-th policy call."""
+        dev = traj.device
+        T, L, H = out["div"].shape[0], traj.shape[1], self.horizon
+        first = torch.cumsum(steps, 0) - steps               # calls before run i
+        k = torch.arange(T, device=dev)[:, None]             # [T,1]
+        pick = ((first[None] + k + 1) % take_every_x == 0) & (k < steps[None])
+        kk, ii = torch.nonzero(pick.t(), as_tuple=True)[::-1]  # run-major order
+        if kk.numel() == 0:
+            return 0
+        states = out["start_states"][kk, :, ii]              # [n,12]
+        ws = torch.clamp(kk + 1, max=L - H)                  # get_ref_traj window
+        rows = ws[:, None] + torch.arange(H, device=dev)[None]
+        windows = traj[ii[:, None], rows]                    # [n,H,9]
+        return dataset.add_eval_data(states, windows)
+
     def run_eval(self, reference="rand", nr_test=10, max_steps=251,
                  thresh_div=1, thresh_stable=1, return_dict=False,
-                 trajectories=None, **kwargs):
-        """scripts/evaluate_drone.py:237-300, all runs in one launch."""
+                 trajectories=None, dataset=None, take_every_x=1000, **kwargs):
+        """scripts/evaluate_drone.py:237-300, all runs in one launch.
+        `dataset` (optional, with `add_eval_data`): self play - every
+        take_every_x-th policy call, counted through the runs in order like
+        NetworkWrapper.action_counter (network_wrapper.py:47-71), hands its
+        (state, reference window) to the data set."""
         if nr_test == 0:
             return 0, 0
         if reference != "rand":
@@ -91,9 +111,12 @@ class QuadEvaluator:
             out = F.quad_mlp_closed_loop(
                 self.net, traj, self.dt, self.dynamics.params,
                 max_steps=max_steps, thresh_div=thresh_div,
-                thresh_stable=thresh_stable, test_time=self.test_time)
+                thresh_stable=thresh_stable, test_time=self.test_time,
+                want_trajectory=dataset is not None)
         steps = out["steps"].to(torch.int64)
         T = out["div"].shape[0]
+        if dataset is not None:
+            self.add_self_play_data(dataset, traj, out, steps, take_every_x)
         valid = torch.arange(T, device=dev)[:, None] < steps[None]
         divs = torch.where(valid, out["div"], torch.zeros_like(out["div"]))
         div = (divs.sum(0) / steps.clamp(min=1)).cpu().numpy().astype(np.float64)

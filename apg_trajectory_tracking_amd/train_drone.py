@@ -44,10 +44,10 @@ class TrainDrone(TrainBase):
         which upstream does not ship)."""
         device = torch.device(device or "cuda")
         if state_data is None:
-            n = int(self.epoch_size * (1 + self.self_play))
             state_data = SyntheticQuadDataset(
-                n, self.horizon, self.delta_t, ref_length=self.ref_length,
-                seed=seed, device=device)
+                self.epoch_size, self.horizon, self.delta_t,
+                ref_length=self.ref_length, seed=seed, device=device,
+                self_play=self.self_play)
         self.state_data = state_data
         in_state_size = self.state_data.normed_states.size()[1]
         if base_model is not None:
@@ -131,13 +131,20 @@ class TrainDrone(TrainBase):
         evaluator = QuadEvaluator(n, self.eval_dynamics, **{
             k: v for k, v in self.config.items()
             if k in ("ref_length", "dt", "speed_factor", "train_mode")})
+        # self play (NetworkWrapper.predict_actions, take_every_x): visited
+        # states go into the data set's self-play slots (concurrent mode: the
+        # reference windows have the data set's length only there)
+        self_play = (self.state_data
+                     if getattr(self.state_data, "num_self_play", 0) > 0
+                     and self.ref_length == self.horizon else None)
         with torch.no_grad():
             (suc_mean, suc_std, div_full_mean, div_full_std, div_mean,
              div_std) = evaluator.run_eval(
                 "rand", nr_test=self.config.get("nr_test", 10),
                 max_steps=self.config.get("max_steps", 251),
                 thresh_div=self.config["thresh_div"],
-                thresh_stable=self.config["thresh_stable"])
+                thresh_stable=self.config["thresh_stable"],
+                dataset=self_play, take_every_x=self.self_play_every_x)
         self.sample_new_data(epoch)
         if epoch % 5 == 0 and self.config["thresh_div"] < self.thresh_div_end:
             self.config["thresh_div"] += .05

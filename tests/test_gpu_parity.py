@@ -612,3 +612,42 @@ def test_planes_gemm_mfma_vs_torch(dev):
             ref[:, :30] += A64[:, pos, k] @ rows.t()
             ref[:, 30] += A64[:, pos, k].sum(1)
     assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_fused_policy_argument_errors(dev):
+    """Argument validation of the in-kernel-policy entry points: wrong network
+    shape, wrong horizon, short reference trajectory, oversized GEMM operands
+    -> ValueError (APG_ERR_ARG), nothing launched."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    dyn = FlightmareDynamics()
+    d = synthetic.quad_polynomial_batch(8, 10, 0.1, seed=1, ref_length=20)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    with pytest.raises(ValueError):     # linear reference branch: not fusable
+        F.quad_mlp_rollout_loss(Net(15, 10, 9, 4, conv=0).to(dev), s0, in_ref, ref,
+                                0.1, dyn.params)
+    with pytest.raises(ValueError):     # in_ref shorter than 2H
+        F.quad_mlp_rollout_loss(Net(15, 10, 9, 4, conv=1).to(dev), s0,
+                                in_ref[:, :12], ref, 0.1, dyn.params)
+    h0 = torch.zeros(8, 8, device=dev)
+    with pytest.raises(ValueError):     # horizon-5 LSTM
+        F.quad_lstm_rollout_loss(LSTM_NEW(15, 5, 9, 4, conv=1).to(dev), s0, in_ref,
+                                 ref, 0.1, dyn.params, h0, h0)
+    with pytest.raises(ValueError):     # reference trajectory not longer than H
+        F.quad_mlp_closed_loop(Net(15, 10, 9, 4, conv=1).to(dev),
+                               torch.zeros(4, 10, 9, device=dev), 0.1, dyn.params)
+    A = torch.zeros(65, 64, device=dev)
+    with pytest.raises(ValueError):     # M > 64
+        F.planes_gemm(A, 65, 1, A, F.make_bdesc(dev, range(8)))
+    with pytest.raises(ValueError):     # M > 32 with more than 128 columns
+        F.planes_gemm(A[:64], 64, 1, torch.zeros(200, 64, device=dev),
+                      F.make_bdesc(dev, range(150)))
+    # B = 0 is a no-op with a zero loss
+    e = torch.zeros(0, 12, device=dev)
+    loss, st, ac = F.quad_mlp_rollout_loss(
+        Net(15, 10, 9, 4, conv=1).to(dev), e, torch.zeros(0, 20, 9, device=dev),
+        torch.zeros(0, 20, 9, device=dev), 0.1, dyn.params)
+    assert float(loss.detach()) == 0.0 and st.shape == (10, 12, 0)

@@ -554,3 +554,60 @@ def test_closed_loop_evaluator_and_oracle_large_batch(dev):
         st = np.array([int((ref["div"][i, :int(ref["steps"][i])] < td).sum())
                        for i in range(B)])
         assert abs(stats[0] - st.mean()) < 0.05 * max(1.0, st.mean())
+
+
+def test_self_play_slots_and_evaluate_model(dev):
+    """N1/N2: the data set's self-play slots (DroneDataset.get_eval_index /
+    get_and_add_eval_data semantics, vectorised) and TrainDrone.evaluate_model
+    (closed-loop statistics, slot replacement, threshold curriculum)."""
+    from apg_trajectory_tracking_amd.dataset import SyntheticQuadDataset
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    from oracle import torch_port as tp
+    ds = SyntheticQuadDataset(40, 10, 0.1, seed=3, device=dev, self_play=0.5)
+    assert (ds.num_sampled_states, ds.num_self_play, len(ds)) == (40, 20, 60)
+    before = ds.states.clone()
+    g = torch.Generator().manual_seed(1)
+    st = torch.randn(7, 12, generator=g) * 0.3
+    win = torch.randn(7, 10, 9, generator=g)
+    assert ds.add_eval_data(st.to(dev), win.to(dev)) == 7
+    sl = slice(40, 47)
+    z = st.clone()
+    z[:, :3] = 0
+    assert torch.equal(ds.states[sl].cpu(), z)
+    assert rel_err(N(ds.normed_states[sl]), tp.quad_state_features(z).numpy()) < 1e-6
+    rel = win.clone()
+    rel[:, :, :3] -= st[:, None, :3]
+    want_in = torch.cat((rel[:, :, :3], rel[:, :, 6:9], rel[:, :, 6:9] - st[:, None, 6:9]), 2)
+    assert rel_err(N(ds.in_ref_states[sl]), want_in.numpy()) < 1e-6
+    assert rel_err(N(ds.ref_states[sl]), rel.numpy()) < 1e-6
+    assert torch.equal(ds.states[:40], before[:40]) and torch.equal(ds.states[47:], before[47:])
+    # wrap-around: 30 more entries, counter 7 -> 37; the last 20 survive
+    st2 = torch.randn(30, 12, generator=g) * 0.3
+    ds.add_eval_data(st2.to(dev), torch.randn(30, 10, 9, generator=g).to(dev))
+    assert ds.eval_counter == 37 and ds.get_eval_index() == 40 + 17
+    for j in range(10, 30):
+        slot = 40 + (7 + j) % 20
+        assert torch.equal(ds.states[slot, 3:].cpu(), st2[j, 3:])
+    ds.resample_data()      # renews the sampled part only
+    assert not torch.equal(ds.states[:40], before[:40])
+    assert torch.equal(ds.states[slot, 3:].cpu(), st2[29, 3:])
+
+    cfg = dict(QUAD_CFG, batch_size=32, epoch_size=64, self_play=0.5,
+               self_play_every_x=5, train_mode="concurrent", nr_test=6,
+               max_steps=40, thresh_div_start=1.0, thresh_div_end=2.0,
+               thresh_stable_start=1.0)
+    trainer = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), cfg)
+    trainer.initialize_model(device=dev, seed=2)
+    trainer.save_path = "/tmp/apg_eval_test"
+    data = trainer.state_data
+    assert data.num_self_play == 32
+    old = data.states[64:].clone()
+    res = trainer.evaluate_model(0)
+    assert res is not None and np.isfinite(res[0])
+    assert data.eval_counter == 6 * 40 // 5          # every 5th policy call
+    assert not torch.equal(data.states[64:], old)
+    assert abs(trainer.config["thresh_div"] - 1.05) < 1e-9
+    for key in ("mean_success", "std_success", "mean_divergence", "thresh_div"):
+        assert len(trainer.results_dict[key]) == 1
