@@ -123,6 +123,10 @@ SIGNATURES = {
     "apg_quad_mlp_closed_loop": [
         _P, _I, _F, ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgMlpPolicy),
         _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_closed_loop": [
+        _P, _I, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgLstmPolicy), _I, _I, _I, _F, _F, _I, _P, _P, _P, _P,
+        _P, _P, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
     "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I,
                         ctypes.c_longlong, _P, _I, _P, _I, _P],

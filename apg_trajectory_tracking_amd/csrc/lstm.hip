@@ -253,6 +253,179 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   }
 }
 
+// ------------------------------------------------------ closed-loop evaluation
+// N2 for the LSTM controller: QuadEvaluator.follow_trajectory
+// ("rand", scripts/evaluate_drone.py:81-194) for a batch of reference
+// trajectories - see mlp_closed_loop_kernel (mlp.hip) for the loop; here the
+// hidden / cell state is carried through all steps (it is reset once per
+// evaluator, evaluate_drone.py:56-58, never on a divergence).
+struct LoopArgs {
+  const float *traj;  // [L][9][B] (position, euler, velocity) rows
+  const float *h0, *c0;  // [8][B]
+  float *div;         // [T][B]
+  int *steps;         // [B] iterations executed
+  float *drone;       // [T+1][12][B] or NULL: states after each step
+  float *actions;     // [T][4][B] or NULL
+  float *start;       // [T][12][B] or NULL: states the policy saw
+  const float *tables;
+  QuadConst c;
+  int B, L, T, test_time;
+  float thresh_div, thresh_stable;
+};
+
+__global__ __launch_bounds__(kThreads) void lstm_closed_loop_kernel(LoopArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds(lds, A.tables, kFwdLds);
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const LdsView L(lds, lane);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = (blockIdx.x * (kThreads / 64) + wave) * 32 + (lane & 31);
+  const int B = A.B, T = A.T;
+  const bool live = b < B;
+  const bool st_lo = live && hi == 0;
+  const unsigned pitchB = (unsigned)B * 4u;
+  const QuadConst c = A.c;
+  // a NULL output becomes an empty buffer: every store to it is dropped
+  const Planes Ptr(A.traj, A.L * 9, pitchB), Pdv(A.div, T, pitchB);
+  const Planes Ph0(A.h0, kNH, pitchB), Pc0(A.c0, kNH, pitchB);
+  const Planes Pdr(A.drone, A.drone ? (T + 1) * 12 : 0, pitchB);
+  const Planes Pac(A.actions, A.actions ? T * 4 : 0, pitchB);
+  const Planes Pss(A.start, A.start ? T * 12 : 0, pitchB);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  const unsigned vb_u = live ? vb + (hi ? 4u * pitchB : 0u) : kDead;
+  // window columns of this half-wave: lower (x, y, z, vx, -), upper (vy, vz,
+  // vx, vy, vz) - policy channels 0-3 / 4-8; trajectory columns 6..8 = velocity
+  unsigned vcol[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int lo = j < 3 ? j : 6, up = j < 2 ? 7 + j : 4 + j;
+    vcol[j] = live ? vb + (unsigned)(hi ? up : lo) * pitchB : kDead;
+  }
+  float s[12], h[4], cell[4];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = i < 3 ? Ptr.ld(vb, i * pitchB) : 0.f;  // zero_reset
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    h[r] = Ph0.ld(vb_u, r * pitchB);
+    cell[r] = Pc0.ld(vb_u, r * pitchB);
+  }
+  float w[kH][5];  // rows cur + 1 .. cur + H of the trajectory
+#pragma unroll
+  for (int r = 0; r < kH; ++r)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w[r][j] = Ptr.ld(vcol[j], ((1 + r) * 9) * pitchB);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Pdr.st(st_lo ? vb : kDead, i * pitchB, s[i]);
+  bool alive = live;
+  int steps = 0;
+
+#pragma unroll 1
+  for (int k = 0; k < T; ++k) {
+    const unsigned pB = opaque(pitchB);
+    const unsigned vrec = (alive && hi == 0) ? vb : kDead;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Pss.st(vrec, (k * 12 + i) * pB, s[i]);
+    const Trig t = make_trig(&s[3]);
+    float feat[kNF];
+    quad_features(s, t, feat);
+    f32x16 g0, g1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g0[i] = L.T(fTbg + i * 2), g1[i] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
+      const float bv = hi ? odd : feat[2 * p];
+      if (p & 1) g1 = mfma(L.A(fAf + p * 64), bv, g1);
+      else g0 = mfma(L.A(fAf + p * 64), bv, g0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r & 1) g1 = mfma(L.A(fAh + r * 64), h[r], g1);
+      else g0 = mfma(L.A(fAh + r * 64), h[r], g0);
+    }
+    // lower: position columns relative to the drone; upper: the last three
+    // columns are reference velocity minus drone velocity (prepare_data)
+    const float sub[5] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? s[6] : s[2],
+                          hi ? s[7] : 0.f, hi ? s[8] : 0.f};
+#pragma unroll
+    for (int pos = 0; pos < kNP; ++pos) {
+      f32x16 cv, cw;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2), cw[i] = 0.f;
+#pragma unroll
+      for (int p = 0; p < 15; ++p) {
+        const int j = p / 3, tap = p % 3;
+        const float xv = w[pos + tap][j] - sub[j];
+        if (p & 1) cw = mfma(L.A(fAc + p * 64), xv, cw);
+        else cv = mfma(L.A(fAc + p * 64), xv, cv);
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const float v = fmaxf(cv[i] + cw[i], 0.f);
+        if (i & 1) g1 = mfma(L.A(fAg + (pos * 12 + i) * 64), v, g1);
+        else g0 = mfma(L.A(fAg + (pos * 12 + i) * 64), v, g0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = sigmoid_fast(g0[r] + g1[r]);
+      const float gf = sigmoid_fast(g0[4 + r] + g1[4 + r]);
+      const float gg = tanh_fast(g0[8 + r] + g1[8 + r]);
+      const float go = sigmoid_fast(g0[12 + r] + g1[12 + r]);
+      cell[r] = fmaf(gf, cell[r], gi * gg);
+      h[r] = go * tanh_fast(cell[r]);
+    }
+    float act[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float z = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z = fmaf(L.T(fTo + (j * 4 + r) * 2), h[r], z);
+      z += other_half(z);
+      act[j] = fminf(fmaxf(sigmoidf_(z + L.U(fBo + j)), 0.f), 1.f);  // np.clip
+      Pac.st(vrec, (k * 4 + j) * pB, act[j]);
+    }
+    quad_step(s, act, c, t);
+    // window row 0 is reference[cur] after get_ref_traj: project_on_ref
+    float d2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float oth = other_half(w[0][q]);
+      const float e = (hi ? oth : w[0][q]) - s[q];
+      d2 = fmaf(e, e, d2);
+    }
+    const float dv = sqrtf(d2);
+    const bool stable = fabsf(s[3]) < A.thresh_stable && fabsf(s[4]) < A.thresh_stable;
+    const bool failed = dv > A.thresh_div || !stable;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Pdr.st(vrec, ((k + 1) * 12 + i) * pB, s[i]);
+    Pdv.st(vrec, k * pB, dv);
+    if (alive) steps = k + 1;
+    if (A.test_time) {
+      alive = alive && !failed;
+      if (!__any(alive)) break;
+    } else if (__any(failed)) {  // get_current_full_state: row cur, zero rates
+      const int cur = k + 1 < A.L - kH ? k + 1 : A.L - kH;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float rv = Ptr.ld(vb, (cur * 9 + i) * pB);
+        s[i] = failed ? rv : s[i];
+      }
+#pragma unroll
+      for (int i = 9; i < 12; ++i) s[i] = failed ? 0.f : s[i];
+    }
+    if (k + 2 <= A.L - kH) {  // get_ref_traj advanced: slide, fetch row k+1+H
+#pragma unroll
+      for (int r = 0; r + 1 < kH; ++r)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w[r][j] = w[r + 1][j];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) w[kH - 1][j] = Ptr.ld(vcol[j], ((k + 1 + kH) * 9) * pB);
+    }
+  }
+  if (st_lo) A.steps[b] = steps;
+}
+
 // ------------------------------------------------------------ reverse sweep
 constexpr int rTo = 0;               // [4 j][4 r][2]
 constexpr int rAq = rTo + 32;        // [20][3] sum over taps of conv_w
@@ -589,6 +762,50 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
   if (loss)
     return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave), loss, st);
   return APG_OK;
+}
+
+int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
+                              const float *c0, float dt,
+                              const ApgQuadParams *params,
+                              const ApgLstmPolicy *policy, int B, int H,
+                              int max_steps, float thresh_div,
+                              float thresh_stable, int test_time, float *div,
+                              int *steps, float *drone, float *actions,
+                              float *start_states, float *workspace,
+                              apg_stream_t stream) {
+  if (int e = check_lstm(params, policy, B, H)) return e;
+  if (L <= kH || max_steps < 1) {
+    set_error("closed loop needs L > %d reference rows and max_steps >= 1", kH);
+    return APG_ERR_ARG;
+  }
+  const int T = max_steps < L + 1 ? max_steps : L + 1;
+  const long long planes = (long long)(T + 1) * 12 > (long long)L * 9
+                               ? (long long)(T + 1) * 12 : (long long)L * 9;
+  if ((long long)B * 4 * planes >= (1ll << 32) - 64) {
+    set_error("B * steps too large for 32-bit plane offsets; split the batch");
+    return APG_ERR_ARG;
+  }
+  if (B == 0) return APG_OK;
+  if (!traj || !h0 || !c0 || !div || !steps || !workspace) {
+    set_error("NULL buffer");
+    return APG_ERR_ARG;
+  }
+  LoopArgs A;
+  A.traj = traj, A.h0 = h0, A.c0 = c0, A.div = div, A.steps = steps;
+  A.drone = drone, A.actions = actions, A.start = start_states;
+  A.tables = workspace;
+  A.c = make_const(*params, dt);
+  A.B = B, A.L = L, A.T = T, A.test_time = test_time;
+  A.thresh_div = thresh_div, A.thresh_stable = thresh_stable;
+  PackArgs P;
+  P.pol = *policy, P.dst = workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(lstm_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256),
+                     0, st, P);
+  hipLaunchKernelGGL(lstm_closed_loop_kernel,
+                     dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
+                     kFwdLds * sizeof(float), st, A);
+  return check_launch("quad_lstm_closed_loop");
 }
 
 }  // extern "C"

@@ -26,8 +26,8 @@ class QuadEvaluator:
     def __init__(self, controller, environment, ref_length=10, dt=0.1,
                  test_time=0, speed_factor=.6, train_mode="concurrent",
                  trajectory_length=501, **kwargs):
-        """controller: the policy (hutter_model.Net, conv branch) or an
-        object with a `.net`; environment: the FlightmareDynamics the
+        """controller: the policy (hutter_model.Net or rnn.LSTM_NEW, conv
+        branch) or an object with a `.net`; environment: the FlightmareDynamics the
         reference's eval_env steps with (its `.params` are used)."""
         self.net = getattr(controller, "net", controller)
         self.dynamics = getattr(environment, "dynamics", environment)
@@ -39,6 +39,21 @@ class QuadEvaluator:
         self.speed_factor = speed_factor
         self.train_mode = train_mode
         self.trajectory_length = trajectory_length
+        self.hidden = None     # (h0, c0) [B,8] for an LSTM controller
+
+    def _closed_loop(self, traj, **kw):
+        """One launch for the whole batch; MLP or LSTM controller."""
+        if hasattr(self.net, "lstm"):
+            B, dev = traj.shape[0], traj.device
+            if self.hidden is None or self.hidden[0].shape[0] != B:
+                # reset_hidden_state (rnn.py:30-33): standard normal draws
+                self.hidden = (torch.randn(B, 8, device=dev),
+                               torch.randn(B, 8, device=dev))
+            return F.quad_lstm_closed_loop(
+                self.net, traj, self.dt, self.dynamics.params, self.hidden[0],
+                self.hidden[1], **kw)
+        return F.quad_mlp_closed_loop(self.net, traj, self.dt,
+                                      self.dynamics.params, **kw)
 
     def reference_batch(self, nr_test, seed=42):
         """Counterpart of `Random.__init__` (random_traj.py:28-35): nr_test
@@ -57,9 +72,8 @@ class QuadEvaluator:
         dev = next(self.net.parameters()).device
         traj = (self.reference_batch(nr_test) if trajectories is None
                 else trajectories).to(dev)
-        out = F.quad_mlp_closed_loop(
-            self.net, traj, self.dt, self.dynamics.params,
-            max_steps=max_nr_steps, thresh_div=thresh_div,
+        out = self._closed_loop(
+            traj, max_steps=max_nr_steps, thresh_div=thresh_div,
             thresh_stable=thresh_stable, test_time=self.test_time,
             want_trajectory=True)
         steps = out["steps"].cpu().numpy()
@@ -108,9 +122,8 @@ class QuadEvaluator:
         traj = (self.reference_batch(nr_test) if trajectories is None
                 else trajectories).to(dev)
         with torch.no_grad():
-            out = F.quad_mlp_closed_loop(
-                self.net, traj, self.dt, self.dynamics.params,
-                max_steps=max_steps, thresh_div=thresh_div,
+            out = self._closed_loop(
+                traj, max_steps=max_steps, thresh_div=thresh_div,
                 thresh_stable=thresh_stable, test_time=self.test_time,
                 want_trajectory=dataset is not None)
         steps = out["steps"].to(torch.int64)

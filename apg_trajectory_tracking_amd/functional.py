@@ -838,3 +838,44 @@ def quad_mlp_closed_loop(net, traj, dt, params, max_steps=251, thresh_div=1.0,
     if want_trajectory:
         out.update(drone=drone, actions=actions, start_states=start)
     return out
+
+
+def quad_lstm_closed_loop(net, traj, dt, params, h0, c0, max_steps=251,
+                          thresh_div=1.0, thresh_stable=1.0, test_time=0,
+                          want_trajectory=False):
+    """quad_mlp_closed_loop for an `LSTM_NEW(15, 10, 9, 4, conv=1)` controller;
+    h0 / c0 [B, 8]: the hidden / cell state at the start of every run (the
+    reference resets it once per evaluator and carries it through the run)."""
+    B, L, _ = traj.shape
+    H = 10
+    dev = traj.device
+    tr = _f32c(traj).permute(1, 2, 0).contiguous()
+    h0s, c0s = _f32c(h0).t().contiguous(), _f32c(c0).t().contiguous()
+    pw = dict(conv_w=net.conv_ref.weight, conv_b=net.conv_ref.bias,
+              w_ih=net.lstm.weight_ih, w_hh=net.lstm.weight_hh,
+              b_ih=net.lstm.bias_ih, b_hh=net.lstm.bias_hh,
+              w_out=net.fc_out.weight, b_out=net.fc_out.bias)
+    pw = {k: _f32c(v.detach()).contiguous() for k, v in pw.items()}
+    if pw["w_ih"].shape != (32, 175) or pw["conv_w"].shape != (20, 9, 3) \
+            or pw["w_out"].shape != (4, 8) or h0s.shape != (8, B):
+        raise ValueError("closed loop needs LSTM_NEW(15, 10, 9, 4, conv=1), h0/c0 [B,8]")
+    require_device(tr, h0s, c0s, *pw.values())
+    pol = _capi.ApgLstmPolicy(**{k: ptr(v) for k, v in pw.items()})
+    T = min(int(max_steps), L + 1)
+    new = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    div = new(T, B)
+    steps = torch.zeros(B, dtype=torch.int32, device=dev)
+    drone = new(T + 1, 12, B) if want_trajectory else None
+    actions = new(T, 4, B) if want_trajectory else None
+    start = new(T, 12, B) if want_trajectory else None
+    ws = new(lib().apg_quad_lstm_workspace_floats())
+    check(lib().apg_quad_lstm_closed_loop(
+        ptr(tr), L, ptr(h0s), ptr(c0s), float(dt), ctypes.byref(params),
+        ctypes.byref(pol), B, H, int(max_steps), float(thresh_div),
+        float(thresh_stable), int(test_time), ptr(div), steps.data_ptr(),
+        ptr(drone), ptr(actions), ptr(start), ptr(ws), stream_of(tr)),
+        "apg_quad_lstm_closed_loop")
+    out = dict(div=div, steps=steps)
+    if want_trajectory:
+        out.update(drone=drone, actions=actions, start_states=start)
+    return out

@@ -123,9 +123,9 @@ class TrainDrone(TrainBase):
         resampling, divergence-threshold curriculum, checkpoint, statistics."""
         from .evaluate_drone import QuadEvaluator
         n = self.net
-        if not (isinstance(n, Net) and n.conv and self.horizon == 10
+        if not (isinstance(n, (Net, LSTM_NEW)) and n.conv and self.horizon == 10
                 and hasattr(self.eval_dynamics, "params")):
-            return None          # e.g. LSTM controller: no fused evaluator yet
+            return None          # no fused evaluator for this architecture
         self.config.setdefault("thresh_div", self.thresh_div_start)
         self.config.setdefault("thresh_stable", self.thresh_stable_start)
         evaluator = QuadEvaluator(n, self.eval_dynamics, **{

@@ -300,6 +300,20 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
                              float *start_states, float *workspace,
                              apg_stream_t stream);
 
+/* The same closed loop for the LSTM controller (LSTM_NEW): hidden / cell
+ * state h0 / c0 [8][B] carried through all steps (QuadEvaluator resets it once,
+ * scripts/evaluate_drone.py:56-58).  workspace:
+ * apg_quad_lstm_workspace_floats(). */
+int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
+                              const float *c0, float dt,
+                              const ApgQuadParams *params,
+                              const ApgLstmPolicy *policy, int B, int H,
+                              int max_steps, float thresh_div,
+                              float thresh_stable, int test_time, float *div,
+                              int *steps, float *drone, float *actions,
+                              float *start_states, float *workspace,
+                              apg_stream_t stream);
+
 /* "Planes x planes" reduction GEMM on the matrix cores
  * (v_mfma_f32_32x32x2_f32, exact fp32):
  *   C[m*ldc + j] = sum_{s<S} sum_{n<N} A[(m*S + s)*N + n] * B[bplane(j,s)*N + n]

@@ -654,6 +654,44 @@ def g11_closed_loop():
         out[f"{name}.test_time"] = np.int64(c["test_time"])
         print(name, [len(out[f"{name}.{i}.div"]) for i in range(n_traj)],
               [float(out[f"{name}.{i}.div"].max()) for i in range(n_traj)])
+    # the same loop with an LSTM controller (random weights, given h0 / c0;
+    # QuadEvaluator resets the hidden state once, evaluate_drone.py:56-58)
+    torch.manual_seed(1234)
+    lstm = LSTM_NEW(15, 10, 9, 4, conv=1)
+    lstm.eval()
+    for k, v in lstm.state_dict().items():
+        out["lstm.w." + k] = npy(v)
+    gen = torch.Generator().manual_seed(99)
+    h0 = torch.randn(n_traj, 8, generator=gen)
+    c0 = torch.randn(n_traj, 8, generator=gen)
+    out["lstm.h0"], out["lstm.c0"] = npy(h0), npy(c0)
+    for name, c in (("lstm_train", dict(test_time=0, thresh_div=0.6, thresh_stable=1.0)),
+                    ("lstm_test", dict(test_time=1, thresh_div=0.6, thresh_stable=1.0))):
+        for i in range(n_traj):
+            random_traj.load_prepare_trajectory = (
+                lambda *a, _r=trajs[i], **k: _r.copy())
+
+            def fixed_reset(batch_size=1, _i=i):
+                lstm.hidden_state = h0[_i:_i + 1].clone()
+                lstm.cell_state = c0[_i:_i + 1].clone()
+            lstm.reset_hidden_state = fixed_reset
+            env = Env(FlightmareDynamics(), dt)
+            ctrl = NetworkWrapper(lstm, dataset, horizon=H, dt=dt)
+            ev = evaluate_drone.QuadEvaluator(
+                ctrl, env, ref_length=H, dt=dt, test_time=c["test_time"],
+                speed_factor=0.4, train_mode="LSTM")
+            ref_tr, drone_tr, divs, acts = ev.follow_trajectory(
+                "rand", max_nr_steps=steps, thresh_div=c["thresh_div"],
+                thresh_stable=c["thresh_stable"])
+            out[f"{name}.{i}.ref"] = np.asarray(ref_tr, dtype=np.float32)
+            out[f"{name}.{i}.drone"] = np.asarray(drone_tr, dtype=np.float32)
+            out[f"{name}.{i}.div"] = np.asarray(divs, dtype=np.float32)
+            out[f"{name}.{i}.actions"] = np.asarray(acts, dtype=np.float32)
+        out[f"{name}.thresh_div"] = np.float32(c["thresh_div"])
+        out[f"{name}.thresh_stable"] = np.float32(c["thresh_stable"])
+        out[f"{name}.test_time"] = np.int64(c["test_time"])
+        print(name, [len(out[f"{name}.{i}.div"]) for i in range(n_traj)],
+              [float(out[f"{name}.{i}.div"].max()) for i in range(n_traj)])
     out["max_steps"] = np.int64(steps)
     save("closed_loop.npz", **out)
 

@@ -611,3 +611,30 @@ def test_self_play_slots_and_evaluate_model(dev):
     assert abs(trainer.config["thresh_div"] - 1.05) < 1e-9
     for key in ("mean_success", "std_success", "mean_divergence", "thresh_div"):
         assert len(trainer.results_dict[key]) == 1
+
+
+@pytest.mark.parametrize("case", ["lstm_train", "lstm_test"])
+def test_closed_loop_lstm_matches_reference_evaluator(dev, case):
+    """N2 / G11 with the LSTM controller (hidden state carried through the run)."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    g = load_golden("closed_loop.npz")
+    net = LSTM_NEW(15, 10, 9, 4, conv=1)
+    load_weights(net, g, "lstm.w.")
+    net.to(dev)
+    traj = D(g["trajs"], dev).clone()
+    traj[:, :, 2] += 3
+    out = F.quad_lstm_closed_loop(
+        net, traj, float(g["dt"]), FlightmareDynamics().params,
+        D(g["lstm.h0"], dev), D(g["lstm.c0"], dev), max_steps=int(g["max_steps"]),
+        thresh_div=float(g[f"{case}.thresh_div"]),
+        thresh_stable=float(g[f"{case}.thresh_stable"]),
+        test_time=int(g[f"{case}.test_time"]), want_trajectory=True)
+    for i in range(traj.shape[0]):
+        n = len(g[f"{case}.{i}.div"])
+        assert int(out["steps"][i]) == n, (case, i)
+        assert rel_err(N(out["drone"][:n + 1, :, i]), g[f"{case}.{i}.drone"]) < 1e-4
+        assert np.abs(N(out["div"][:n, i]) - g[f"{case}.{i}.div"]).max() < 2e-4
+        assert rel_err(N(out["actions"][:n, :, i]), g[f"{case}.{i}.actions"]) < 1e-4
