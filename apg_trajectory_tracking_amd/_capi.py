@@ -120,6 +120,11 @@ SIGNATURES = {
         _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy),
         _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_mlp_concurrent_workspace_floats": [],
+    "apg_quad_mlp_concurrent_fwd_bwd": [
+        _P, _P, _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
+        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_quad_mlp_closed_loop": [
         _P, _I, _F, ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgMlpPolicy),
         _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -129,7 +134,7 @@ SIGNATURES = {
         _P, _P, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
     "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I,
-                        ctypes.c_longlong, _P, _I, _P, _I, _P],
+                        ctypes.c_longlong, _P, _I, _P, _I, _P, _P],
     "apg_wing_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,
                           _P, _P],
     "apg_wing_step_bwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,

@@ -82,7 +82,8 @@ constexpr int kFwdLds = fA3 + 2 * 32 * 64;  // 27 136 floats = 108 544 B
 static_assert(fBo + 4 <= fAs, "LDS map");
 
 __device__ __forceinline__ void pack_forward(float *lds, const ApgMlpPolicy &p,
-                                             int tid, int T) {
+                                             int tid, int T, bool head4 = true) {
+  (void)head4;  // w_out rows 0..3 / b_out 0..3 are read either way
   for (int idx = tid; idx < 2 * 8 * 64; idx += T) {
     const int l = idx & 63, pp = (idx >> 6) & 7, rb = idx >> 9;
     const int k = 2 * pp + (l >> 5);
@@ -523,7 +524,8 @@ constexpr int kBwdLds = rAs + 32 * 64;    // 24 896 floats = 99 584 B
 static_assert(rAq + kNC * 3 <= rA3, "LDS map");
 
 __device__ __forceinline__ void pack_reverse(float *lds, const ApgMlpPolicy &p,
-                                             int tid, int T) {
+                                             int tid, int T, bool head4 = true) {
+  (void)head4;
   for (int idx = tid; idx < 2 * 32 * 64; idx += T) {
     const int l = idx & 63, c = (idx >> 6) & 31, rb = idx >> 11;
     const int m = rb * 32 + (l & 31), k = kchain(c, l >> 5);
@@ -765,6 +767,303 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
 }
 
 
+// ---------------------------------------------- concurrent mode, policy fused
+// The concurrent training step (BASELINE config 2, the headline workload) with
+// the policy inside: TrainBase.run_epoch's concurrent branch
+// (scripts/train_base.py:198-204: actions = sigmoid(net(in_state, in_ref)),
+// reshape [B, H, 4]) + TrainDrone.train_controller_model
+// (scripts/train_drone.py:175-203: H x dynamics, quad_mpc_loss, backward).
+// The network runs ONCE per trajectory (40 outputs = H x 4 actions), then the
+// register-resident rollout and its adjoint (as quad.hip), then - second
+// kernel - the reverse pass of the network from dL/d(head pre-activations).
+// Planes are [feature][B]; the weight gradients come from apg_planes_gemm.
+constexpr int kNA = kH * 4;                       // head width (40)
+constexpr int cAo = kFwdLds;                      // [2][33][64] head A table
+constexpr int kCfLds = cAo + 2 * 33 * 64;         // 31 360 floats = 125 440 B
+constexpr int cAoT = kBwdLds;                     // [2][20][64] head^T A table
+constexpr int kCbLds = cAoT + 2 * 20 * 64;        // 27 456 floats = 109 824 B
+
+// k index of head-output k-pair c (accumulator layout of the 40 outputs:
+// row block 0 registers 0..15, row block 1 registers 0..3)
+__host__ __device__ constexpr int khead(int c, int hi) {
+  return (c < 16 ? rrow(c) : 32 + rrow(c - 16)) + 4 * hi;
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_cfwd_kernel(PackArgs A) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+  pack_forward(A.dst, A.pol, tid, T, /*head4=*/false);
+  for (int idx = tid; idx < 2 * 33 * 64; idx += T) {
+    const int l = idx & 63, c = (idx >> 6) % 33, rb = idx / (33 * 64);
+    const int m = rb * 32 + (l & 31);
+    float v = 0.f;
+    if (m < kNA) v = c < 32 ? A.pol.w_out[m * kW + kchain(c, l >> 5)]
+                            : (l < 32 ? A.pol.b_out[m] : 0.f);  // bias pair (1, 0)
+    A.dst[cAo + idx] = v;
+  }
+}
+__global__ __launch_bounds__(256) void mlp_pack_cbwd_kernel(PackArgs A) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+  pack_reverse(A.dst, A.pol, tid, T, /*head4=*/false);
+  for (int idx = tid; idx < 2 * 20 * 64; idx += T) {
+    const int l = idx & 63, c = (idx >> 6) % 20, rb = idx / (20 * 64);
+    A.dst[cAoT + idx] = A.pol.w_out[khead(c, l >> 5) * kW + rb * 32 + (l & 31)];
+  }
+}
+
+struct ConcArgs {
+  const float *feat, *in_ref, *state0, *ref;  // [15][B], [H][9][B], [12][B], [H][C][B]
+  float *x1, *h;        // [224][B], [192][B]
+  unsigned *mask;       // [5][B]
+  float *d_zout;        // [40][B]
+  float *d_pre, *d_conv;  // [256][B], [160][B] (second kernel)
+  float *states;        // [H][12][B] or NULL
+  float *loss_partials;
+  const float *tables;
+  QuadConst c;
+  ApgQuadLossWeights w;
+  int B, ref_cols, vel_col;
+};
+
+__global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds(lds, A.tables, kCfLds);
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const LdsView L(lds, lane);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = (blockIdx.x * (kThreads / 64) + wave) * 32 + (lane & 31);
+  const int B = A.B;
+  const bool live = b < B;
+  const bool st_lo = live && hi == 0;
+  const unsigned pN = (unsigned)B * 4u;  // every plane here is [..][B]
+  const QuadConst c = A.c;
+  const Planes Pfe(A.feat, kNF, pN), Pin(A.in_ref, kH * kRD, pN);
+  const Planes Ps0(A.state0, 12, pN), Prf(A.ref, kH * A.ref_cols, pN);
+  const Planes Px1(A.x1, kN1, pN), Ph(A.h, 3 * kW, pN), Pmk(A.mask, 5, pN);
+  const Planes Pdz(A.d_zout, kNA, pN);
+  const Planes Pst(A.states, A.states ? kH * 12 : 0, pN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  const unsigned vb_lo = st_lo ? vb : kDead;
+  const unsigned vr = live ? vb + (hi ? 4u * pN : 0u) : kDead;   // + row 4 hi
+  const unsigned vc = live ? vb + (hi ? 32u * pN : 0u) : kDead;  // + channel 4 hi
+  const unsigned vm = live ? vb + (hi ? pN : 0u) : kDead;        // + mask word hi
+
+  float feat[kNF];
+#pragma unroll
+  for (int j = 0; j < kNF; ++j) feat[j] = Pfe.ld(vb, j * pN);
+  float w[kH][5];  // policy reference input, columns 0..4 / 4..8 per half
+#pragma unroll
+  for (int r = 0; r < kH; ++r)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vr, (r * kRD + j) * pN);
+
+  // ---- policy forward (as mlp_rollout_fwd_kernel, window used as given)
+  f32x16 u[2], a[2];
+  init_bias(u, L, fTbs);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
+    const float bv = hi ? odd : feat[2 * p];
+    u[0] = mfma(L.A(fAs + (0 * 8 + p) * 64), bv, u[0]);
+    u[1] = mfma(L.A(fAs + (1 * 8 + p) * 64), bv, u[1]);
+  }
+  init_bias(a, L, fTb1);
+  unsigned mbits[3] = {0u, 0u, 0u};
+#pragma unroll
+  for (int pos = 0; pos < kNP; ++pos) {
+    f32x16 cv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2);
+#pragma unroll
+    for (int p = 0; p < 15; ++p) {
+      cv = mfma(L.A(fAc + p * 64), w[pos + p % 3][p / 3], cv);
+      if (p % 4 == 3 || p == 14) {
+        const int cc = pos * 4 + (p == 14 ? 3 : p / 4);
+        const float tv = tanh_fast(u[cc >> 4][cc & 15]);
+        u[cc >> 4][cc & 15] = tv;
+        Px1.st(vr, ((cc >> 4) * 32 + rrow(cc & 15)) * pN, tv);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      float v = cv[i];
+      mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
+      v = fmaxf(v, 0.f);
+      Px1.st(i < 8 ? vc : vb_lo, (kW + rrow(i) * kNP + pos) * pN, v);
+      a[0] = mfma(L.A(fA1c + ((0 * 8 + pos) * 12 + i) * 64), v, a[0]);
+      a[1] = mfma(L.A(fA1c + ((1 * 8 + pos) * 12 + i) * 64), v, a[1]);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) Pmk.stu(g < 2 ? vm : vb_lo, 2 * g * pN, mbits[g]);
+  dense64(a, u, L, fA1s);
+  init_bias(u, L, fTb2);
+  dense64_tanh(u, a, L, fA2, Ph, 0, vr, pN);
+  init_bias(a, L, fTb3);
+  dense64_tanh(a, u, L, fA3, Ph, kW, vr, pN);
+  // head: 40 outputs = row block 0 + rows 0..7 of row block 1, bias as an
+  // extra k-pair with the B operand (1, 0)
+  zero(u);
+#pragma unroll
+  for (int cc = 0; cc < 32; ++cc) {
+    const float bv = tanh_fast(a[cc >> 4][cc & 15]);
+    Ph.st(vr, (2 * kW + (cc >> 4) * 32 + rrow(cc & 15)) * pN, bv);
+    u[0] = mfma(L.A(cAo + (0 * 33 + cc) * 64), bv, u[0]);
+    u[1] = mfma(L.A(cAo + (1 * 33 + cc) * 64), bv, u[1]);
+  }
+  u[0] = mfma(L.A(cAo + (0 * 33 + 32) * 64), hi ? 0.f : 1.f, u[0]);
+  u[1] = mfma(L.A(cAo + (1 * 33 + 32) * 64), hi ? 0.f : 1.f, u[1]);
+  // every lane needs all 40 actions (both halves run the same rollout)
+  float act[kH][4];
+#pragma unroll
+  for (int cc = 0; cc < 20; ++cc) {
+    const float own = cc < 16 ? u[0][cc] : u[1][cc - 16], oth = other_half(own);
+    const int row = khead(cc, 0);
+    act[row >> 2][row & 3] = sigmoidf_(hi ? oth : own);
+    act[(row + 4) >> 2][(row + 4) & 3] = sigmoidf_(hi ? own : oth);
+  }
+
+  // ---- rollout + adjoint in registers (quad_rollout_reg_kernel's structure)
+  float s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = Ps0.ld(vb, i * pN);
+  Trig st_trig[kH];
+  float st_w[kH + 1][3], st_pv[kH][6];
+#pragma unroll
+  for (int k = 0; k < kH; ++k) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st_w[k][i] = s[9 + i];
+    st_trig[k] = make_trig(&s[3]);
+    quad_step(s, act[k], c, st_trig[k]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st_pv[k][i] = s[i], st_pv[k][3 + i] = s[6 + i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Pst.st(vb_lo, (k * 12 + i) * pN, s[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) st_w[kH][i] = s[9 + i];
+  float loss = 0.f, lam[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = 0.f;
+  float rp[3], rv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    rp[i] = Prf.ld(vb, ((kH - 1) * A.ref_cols + i) * pN);
+    rv[i] = Prf.ld(vb, ((kH - 1) * A.ref_cols + A.vel_col + i) * pN);
+  }
+#pragma unroll
+  for (int k = kH - 1; k >= 0; --k) {
+    float np_[3], nv_[3];  // next iteration's reference row, one step ahead
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      np_[i] = k > 0 ? Prf.ld(vb, ((k - 1) * A.ref_cols + i) * pN) : 0.f;
+      nv_[i] = k > 0 ? Prf.ld(vb, ((k - 1) * A.ref_cols + A.vel_col + i) * pN) : 0.f;
+    }
+    float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float dp = st_pv[k][i] - rp[i], dv = st_pv[k][3 + i] - rv[i];
+      const float wn = st_w[k + 1][i];
+      lp += dp * dp, lv += dv * dv, lw += wn * wn;
+      lam[i] += 2.f * A.w.pos * dp;
+      lam[6 + i] += 2.f * A.w.vel * dv;
+      lam[9 + i] += 2.f * A.w.av * wn;
+    }
+    const float a0 = act[k][0], da0 = a0 - 0.5f;
+    float ga[4];
+    ga[0] = 2.f * A.w.thrust * da0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      const float d = act[k][i] - 0.5f;
+      lr += d * d;
+      ga[i] = 2.f * A.w.rates * d;
+    }
+    loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
+            A.w.thrust * da0 * da0;
+    quad_step_adjoint(lam, ga, a0, st_w[k], c, st_trig[k]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // dL/d(head pre-activation), in place
+      act[k][i] = ga[i] * act[k][i] * (1.f - act[k][i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rp[i] = np_[i], rv[i] = nv_[i];
+  }
+  // own rows of dL/dz in accumulator layout: rows khead(c, hi)
+#pragma unroll
+  for (int cc = 0; cc < 20; ++cc) {
+    const int row = khead(cc, 0);
+    const float v = hi ? act[(row + 4) >> 2][(row + 4) & 3] : act[row >> 2][row & 3];
+    Pdz.st(vr, row * pN, v);
+  }
+  write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
+}
+
+__global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds(lds, A.tables, kCbLds);
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const LdsView L(lds, lane);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = (blockIdx.x * (kThreads / 64) + wave) * 32 + (lane & 31);
+  const int B = A.B;
+  const bool live = b < B;
+  const unsigned pN = (unsigned)B * 4u;
+  const Planes Px1(A.x1, kN1, pN), Ph(A.h, 3 * kW, pN), Pmk(A.mask, 5, pN);
+  const Planes Pdz(A.d_zout, kNA, pN), Pdp(A.d_pre, 4 * kW, pN);
+  const Planes Pdc(A.d_conv, kNC * kNP, pN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  const unsigned vr = live ? vb + (hi ? 4u * pN : 0u) : kDead;
+
+  float dzr[20];
+#pragma unroll
+  for (int cc = 0; cc < 20; ++cc) dzr[cc] = Pdz.ld(vr, khead(cc, 0) * pN);
+  unsigned mw[5];
+#pragma unroll
+  for (int eb = 0; eb < 5; ++eb) mw[eb] = Pmk.ldu(vb, eb * pN);
+  float hv[2][16];
+  load_acts(hv, Ph, 2 * kW, vr, pN);  // h3
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 d[2], e[2];
+  zero(d);
+#pragma unroll
+  for (int cc = 0; cc < 20; ++cc) {  // dL/dh3 = W_out^T dL/dz
+    d[0] = mfma(L.A(cAoT + (0 * 20 + cc) * 64), dzr[cc], d[0]);
+    d[1] = mfma(L.A(cAoT + (1 * 20 + cc) * 64), dzr[cc], d[1]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  tanh_adjoint(d, hv, Pdp, 2 * kW, vr, pN);  // d_pre3
+  load_acts(hv, Ph, kW, vr, pN);             // h2
+  __builtin_amdgcn_sched_barrier(0);
+  zero(e);
+  dense64(e, d, L, rA3);
+  __builtin_amdgcn_sched_barrier(0);
+  tanh_adjoint(e, hv, Pdp, kW, vr, pN);      // d_pre2
+  load_acts(hv, Ph, 0, vr, pN);              // h1
+  __builtin_amdgcn_sched_barrier(0);
+  zero(d);
+  dense64(d, e, L, rA2);
+  __builtin_amdgcn_sched_barrier(0);
+  tanh_adjoint(d, hv, Pdp, 0, vr, pN);       // d_pre1
+  load_acts(hv, Px1, 0, vr, pN);             // s1
+  __builtin_amdgcn_sched_barrier(0);
+  zero(e);
+  dense64(e, d, L, rA1s);
+  __builtin_amdgcn_sched_barrier(0);
+  tanh_adjoint(e, hv, Pdp, 3 * kW, vr, pN);  // d_pre_s
+  // conv outputs (the network inputs carry no gradient in this mode)
+#pragma unroll
+  for (int eb = 0; eb < 5; ++eb) {
+    f32x16 y;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) y[i] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc)
+      y = mfma(L.A(rA1c + (eb * 32 + cc) * 64), d[cc >> 4][cc & 15], y);
+    const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      Pdc.st(vr, (eb * 32 + rrow(i)) * pN, ((mws >> rrow(i)) & 1u) ? y[i] : 0.f);
+  }
+}
+
 int check_mlp(const ApgQuadParams *params, const ApgMlpPolicy *pol, int B, int H) {
   if (!params || !pol) { set_error("params / policy is NULL"); return APG_ERR_ARG; }
   if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
@@ -944,6 +1243,65 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
                      kFwdLds * sizeof(float), st, A);
   return check_launch("quad_mlp_closed_loop");
+}
+
+int apg_quad_mlp_concurrent_workspace_floats(void) {
+  return kCfLds > kCbLds ? kCfLds : kCbLds;
+}
+
+int apg_quad_mlp_concurrent_fwd_bwd(
+    const float *feat, const float *in_ref, const float *state0, const float *ref,
+    int ref_cols, float dt, const ApgQuadParams *params,
+    const ApgQuadLossWeights *weights, const ApgMlpPolicy *policy, int B, int H,
+    float *x1, float *h, unsigned *relu_mask, float *d_zout, float *d_pre,
+    float *d_conv, float *loss_partials, float *loss, float *states,
+    float *workspace, apg_stream_t stream) {
+  if (int e = check_mlp(params, policy, B, H)) return e;
+  if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
+  if (ref_cols != 9 && ref_cols != 6) {
+    set_error("ref_cols must be 9 or 6");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
+      return check_launch("memset(loss)");
+    return APG_OK;
+  }
+  if (!feat || !in_ref || !state0 || !ref || !x1 || !h || !relu_mask || !d_zout ||
+      !d_pre || !d_conv || !loss_partials || !workspace) {
+    set_error("NULL buffer");
+    return APG_ERR_ARG;
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (int e = raise_lds(mlp_concurrent_fwd_kernel, kCfLds)) return e;
+    if (int e = raise_lds(mlp_concurrent_bwd_kernel, kCbLds)) return e;
+    attr = true;
+  }
+  ConcArgs A;
+  A.feat = feat, A.in_ref = in_ref, A.state0 = state0, A.ref = ref;
+  A.x1 = x1, A.h = h, A.mask = relu_mask, A.d_zout = d_zout, A.d_pre = d_pre;
+  A.d_conv = d_conv, A.states = states, A.loss_partials = loss_partials;
+  A.tables = workspace;
+  A.c = make_const(*params, dt);
+  A.w = *weights;
+  A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
+  PackArgs P;
+  P.pol = *policy, P.dst = workspace;
+  const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
+  hipLaunchKernelGGL(mlp_pack_cfwd_kernel, dim3((kCfLds + 255) / 256), dim3(256),
+                     0, st, P);
+  hipLaunchKernelGGL(mlp_concurrent_fwd_kernel, dim3(blocks), dim3(kThreads),
+                     kCfLds * sizeof(float), st, A);
+  hipLaunchKernelGGL(mlp_pack_cbwd_kernel, dim3((kCbLds + 255) / 256), dim3(256),
+                     0, st, P);
+  hipLaunchKernelGGL(mlp_concurrent_bwd_kernel, dim3(blocks), dim3(kThreads),
+                     kCbLds * sizeof(float), st, A);
+  if (int e = check_launch("quad_mlp_concurrent_fwd_bwd")) return e;
+  if (loss)
+    return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave), loss, st);
+  return APG_OK;
 }
 
 }  // extern "C"

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
 // slices are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void planes_gemm_reduce_kernel(
     const float *__restrict__ part, int num_wg, int W, int rows, int M, int Jt,
-    float *__restrict__ C, int ldc) {
+    float *__restrict__ C, int ldc, int J, float *__restrict__ bias_out) {
   __shared__ double sh[4][64];
   const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + x;
@@ -223,8 +223,11 @@ __global__ __launch_bounds__(256) void planes_gemm_reduce_kernel(
   for (; w < w1; ++w) acc[0] += (double)p[(size_t)w * stride];
   sh[y][x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   __syncthreads();
-  if (y == 0 && ok)
-    C[(size_t)m * ldc + j] = (float)((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x]));
+  if (y == 0 && ok) {
+    const float v = (float)((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x]));
+    if (j == J && bias_out) bias_out[m] = v;  // row sums to their own vector
+    else C[(size_t)m * ldc + j] = v;
+  }
 }
 
 template <int MB, int NB>
@@ -270,7 +273,7 @@ int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg) {
 int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
                     const int *bdesc, int J, int sdiv, int with_ones,
                     int b_planes, long long N, float *workspace, int num_wg,
-                    float *C, int ldc, apg_stream_t stream) {
+                    float *C, int ldc, float *bias_out, apg_stream_t stream) {
   const int Jt = J + (with_ones ? 1 : 0);
   if (!A || !Bp || !bdesc || !workspace || !C) {
     set_error("apg_planes_gemm: NULL pointer");
@@ -278,7 +281,7 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
   }
   const int MB = (M + 31) / 32, NB = (Jt + 31) / 32;
   if (M < 1 || M > 64 || S < 1 || J < 1 || Jt > kMaxNB * 32 || N < 1 ||
-      num_wg < 1 || sdiv < 1 || ldc < Jt || (MB == 2 && NB > 4)) {
+      num_wg < 1 || sdiv < 1 || ldc < (bias_out ? J : Jt) || (MB == 2 && NB > 4)) {
     set_error("apg_planes_gemm: need 1 <= M <= 64, J + ones <= %d (<= 128 when "
               "M > 32), S, N, num_wg, sdiv >= 1, ldc >= J + ones", kMaxNB * 32);
     return APG_ERR_ARG;
@@ -312,7 +315,7 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
   if (e) return e;
   hipLaunchKernelGGL(planes_gemm_reduce_kernel, dim3((M * Jt + 63) / 64),
                      dim3(256), 0, st, workspace, num_wg, NB * 32, MB * 32, M, Jt,
-                     C, ldc);
+                     C, ldc, J, with_ones ? bias_out : nullptr);
   return check_launch("planes_gemm_reduce");
 }
 

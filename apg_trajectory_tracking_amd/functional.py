@@ -527,13 +527,16 @@ def make_bdesc(dev, offsets, stride1=0, stride2=0, key=None):
     return t
 
 
-def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None):
+def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None,
+                bias_out=None):
     """C[m][j] = sum_{s,n} A[m*S+s][n] * Bp[bdesc[0][j] + (s//sdiv)*bdesc[1][j]
     + (s%sdiv)*bdesc[2][j]][n] on the matrix cores (apg_planes_gemm).  A, Bp
     are fp32 tensors whose rows ("planes") hold N contiguous floats; `N`
     defaults to A.shape[1] (pass it to re-interpret a buffer as shorter
     planes).  `bdesc`: make_bdesc(...).  `out`: optional [M, >= J+ones] view
-    (row stride = out.stride(0)) written in place; returns [M, J+ones]."""
+    (row stride = out.stride(0)) written in place; returns [M, J+ones].
+    `bias_out` [M] (with_ones): the row sums go there instead of column J, so
+    weight and bias gradients are separate contiguous tensors; returns [M, J]."""
     require_device(A, Bp)
     N = A.shape[1] if N is None else N
     J = bdesc.shape[1]
@@ -544,15 +547,25 @@ def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None):
         wgs = 256 * max(1, min(2, 9 // blocks))
     ws = torch.empty(lib().apg_planes_gemm_workspace_floats(
         M, J, int(with_ones), wgs), dtype=torch.float32, device=A.device)
+    Jc = J if (bias_out is not None and with_ones) else Jt   # columns of C
     if out is None:
-        out = torch.empty(M, Jt, dtype=torch.float32, device=A.device)
-    if out.stride(1) != 1 or out.shape[0] < M or out.shape[1] < Jt:
+        out = torch.empty(M, Jc, dtype=torch.float32, device=A.device)
+    if out.stride(1) != 1 or out.shape[0] < M or out.shape[1] < Jc:
         raise ValueError("planes_gemm: out must be [>=M, >=J+ones], unit column stride")
     check(lib().apg_planes_gemm(
         ptr(A), M, S, ptr(Bp), bdesc.data_ptr(), J, sdiv, int(with_ones),
         Bp.numel() // N, N, ptr(ws), wgs, out.data_ptr(), out.stride(0),
-        stream_of(A)), "apg_planes_gemm")
-    return out[:M, :Jt]
+        ptr(bias_out), stream_of(A)), "apg_planes_gemm")
+    return out[:M, :Jc]
+
+
+def _flat_grads(dev, shapes):
+    """One flat fp32 buffer holding a contiguous gradient tensor per entry of
+    `shapes` (name -> shape); returns (flat, {name: view})."""
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes.values()]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    views = {k: v.view(sh) for (k, sh), v in zip(shapes.items(), flat.split(sizes))}
+    return flat, views
 
 
 def _ref_and_states(in_ref, state0, B, H):
@@ -569,23 +582,22 @@ def _ref_and_states(in_ref, state0, B, H):
     return buf, inr, st_all[0], st_all[1:]
 
 
-def _conv_weight_grad(d_conv, refbuf, B, H, out=None):
-    """d conv_ref.weight / bias from the conv cotangent planes d_conv
-    [160][H*B] (plane = ch*8 + pos) in ONE product: the windows are read in
-    place from the reference planes of `refbuf` with segment = (pos, step),
-    the relative-position shift of columns 0..2 comes from three extra
-    columns over the position planes before each step.
-    Returns [20, 28] = [dW (c-major, tap) | db]."""
+def _conv_weight_grad(d_conv, refbuf, B, H, w_out, b_out):
+    """d conv_ref.weight [20,9,3] / bias [20] (written into w_out / b_out) from
+    the conv cotangent planes d_conv [160][H*B] (plane = ch*8 + pos) in ONE
+    product: the windows are read in place from the reference planes of
+    `refbuf` with segment = (pos, step), the relative-position shift of
+    columns 0..2 comes from three extra columns over the position planes
+    before each step."""
     dev = d_conv.device
     offs = [t * 9 + c for c in range(9) for t in range(3)] + [2 * H * 9 + q for q in range(3)]
     desc = make_bdesc(dev, offs, [9] * 27 + [0] * 3, [9] * 27 + [12] * 3,
                       key=("conv", H))
-    c = planes_gemm(d_conv, 20, 8 * H, refbuf, desc, sdiv=H, N=B)   # [20, 31]
-    res = torch.empty(20, 28, dtype=torch.float32, device=dev) if out is None else out
-    res[:, :27] = c[:, :27]
-    res[:, :9].view(20, 3, 3).sub_(c[:, 27:30, None])
-    res[:, 27] = c[:, 30]
-    return res
+    c = planes_gemm(d_conv, 20, 8 * H, refbuf, desc, sdiv=H, N=B,
+                    bias_out=b_out)                                  # [20, 30]
+    w = w_out.view(20, 27)
+    w.copy_(c[:, :27])
+    w[:, :9].view(20, 3, 3).sub_(c[:, 27:30, None])
 
 
 class _QuadLstmRolloutLoss(torch.autograd.Function):
@@ -657,27 +669,35 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gs, _ga):
-        refbuf, acts, d_gates, d_zout, d_conv = ctx.saved_tensors
-        B, H = ctx.dims
-        dev = acts.device
-        # every gradient is a view of ONE flat buffer, scaled by g once
-        sizes = [32 * 184, 4 * 9, 20 * 28]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        c1, c2, c3 = (v.view(r, -1) for v, r in zip(flat.split(sizes), (32, 4, 20)))
-        # [dW_ih | dW_hh | db] = d_gates . [x ; h_prev ; 1]^T
-        planes_gemm(d_gates, 32, 1, acts,
-                    make_bdesc(dev, range(183), key="ih_hh"), out=c1)
-        d_w_ih, d_w_hh, d_b = c1[:, :175], c1[:, 175:183], c1[:, 183]
-        # [dW_out | db_out] = d_zout . [h_new ; 1]^T
-        planes_gemm(d_zout, 4, 1, acts,
-                    make_bdesc(dev, range(191, 199), key="out"), out=c2)
-        d_w_out, d_b_out = c2[:, :8], c2[:, 8]
-        _conv_weight_grad(d_conv, refbuf, B, H, out=c3)
+        flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
         flat *= g
-        d_conv_w, d_conv_b = c3[:, :27].reshape(20, 9, 3), c3[:, 27]
-        grads = [d_conv_w, d_conv_b, d_w_ih, d_w_hh, d_b, d_b, d_w_out, d_b_out]
+        grads = [gr[k] for k in ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
+                                 "lstm.weight_hh", "lstm.bias_ih", "lstm.bias_hh",
+                                 "fc_out.weight", "fc_out.bias")]
         g_s0, g_h0, g_c0 = (None if v is None else v.t() * g for v in ctx.input_grads)
         return (g_s0, None, None, g_h0, g_c0, *grads, None, None, None)
+
+
+def _lstm_param_grads(saved, dims):
+    """Weight gradients of the fused LSTM unroll from the saved planes: three
+    matrix-core products; every gradient is a contiguous view of one flat
+    buffer (returned first), keyed by LSTM_NEW parameter name."""
+    refbuf, acts, d_gates, d_zout, d_conv = saved
+    B, H = dims
+    dev = acts.device
+    flat, gr = _flat_grads(dev, {
+        "ih_hh": (32, 183), "lstm.bias_ih": (32,), "fc_out.weight": (4, 8),
+        "fc_out.bias": (4,), "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,)})
+    # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T, db = row sums
+    planes_gemm(d_gates, 32, 1, acts, make_bdesc(dev, range(183), key="ih_hh"),
+                out=gr["ih_hh"], bias_out=gr["lstm.bias_ih"])
+    planes_gemm(d_zout, 4, 1, acts, make_bdesc(dev, range(191, 199), key="out"),
+                out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])
+    _conv_weight_grad(d_conv, refbuf, B, H, gr["conv_ref.weight"], gr["conv_ref.bias"])
+    ih_hh = gr.pop("ih_hh")
+    gr["lstm.weight_ih"], gr["lstm.weight_hh"] = ih_hh[:, :175], ih_hh[:, 175:]
+    gr["lstm.bias_hh"] = gr["lstm.bias_ih"]
+    return flat, gr
 
 
 def quad_lstm_rollout_loss(net, state0, in_ref, ref, dt, params, h0, c0,
@@ -755,29 +775,52 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gs, _ga):
-        refbuf, acts, d_pre, d_zout, d_conv = ctx.saved_tensors
-        B, H = ctx.dims
-        dev = acts.device
-        # every gradient is a view of ONE flat buffer, scaled by g once
-        sizes = [64 * 225, 64 * 65, 64 * 65, 64 * 16, 4 * 65, 20 * 28]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        c1, c2, c3, cs, co, cc = (
-            v.view(r, -1) for v, r in zip(flat.split(sizes), (64, 64, 64, 64, 4, 20)))
-        R = lambda lo, hi_: make_bdesc(dev, range(lo, hi_), key=("mlp", lo, hi_))
-        # acts planes: feat 0..14 | x1 15..238 | h1 239.. | h2 303.. | h3 367..
-        planes_gemm(d_pre[0:64], 64, 1, acts, R(15, 127), with_ones=False, out=c1)
-        planes_gemm(d_pre[0:64], 64, 1, acts, R(127, 239), out=c1[:, 112:])
-        planes_gemm(d_pre[64:128], 64, 1, acts, R(239, 303), out=c2)
-        planes_gemm(d_pre[128:192], 64, 1, acts, R(303, 367), out=c3)
-        planes_gemm(d_pre[192:256], 64, 1, acts, R(0, 15), out=cs)
-        planes_gemm(d_zout, 4, 1, acts, R(367, 431), out=co)
-        _conv_weight_grad(d_conv, refbuf, B, H, out=cc)
+        flat, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
         flat *= g
-        grads = [cs[:, :15], cs[:, 15], cc[:, :27].reshape(20, 9, 3), cc[:, 27],
-                 c1[:, :224], c1[:, 224], c2[:, :64], c2[:, 64],
-                 c3[:, :64], c3[:, 64], co[:, :64], co[:, 64]]
         g_s0 = None if ctx.input_grads[0] is None else ctx.input_grads[0].t() * g
-        return (g_s0, None, None, *grads, None, None, None)
+        return (g_s0, None, None, *[gr[k] for k in _MLP_PARAMS], None, None, None)
+
+
+_MLP_PARAMS = ("states_in.weight", "states_in.bias", "conv_ref.weight",
+               "conv_ref.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+               "fc3.weight", "fc3.bias", "fc_out.weight", "fc_out.bias")
+
+
+def _mlp_param_grads(saved, dims, n_out, conv=None):
+    """Weight gradients of the fused MLP-policy kernels from the saved planes
+    (acts = feat 0..14 | x1 15..238 | h1 239.. | h2 303.. | h3 367..; d_pre =
+    fc1, fc2, fc3, states_in cotangents): matrix-core products over the plane
+    length; every gradient is a contiguous view of one flat buffer (returned
+    first), keyed by hutter_model.Net parameter name.  `conv`: how the conv
+    weight gradient reads its windows (default: the autoregressive unroll)."""
+    refbuf, acts, d_pre, d_zout, d_conv = saved
+    B, H = dims
+    dev = acts.device
+    flat, gr = _flat_grads(dev, {
+        "states_in.weight": (64, 15), "states_in.bias": (64,),
+        "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,),
+        "fc1.weight": (64, 224), "fc1.bias": (64,), "fc2.weight": (64, 64),
+        "fc2.bias": (64,), "fc3.weight": (64, 64), "fc3.bias": (64,),
+        "fc_out.weight": (n_out, 64), "fc_out.bias": (n_out,)})
+    R = lambda lo, hi_: make_bdesc(dev, range(lo, hi_), key=("mlp", lo, hi_))
+    planes_gemm(d_pre[0:64], 64, 1, acts, R(15, 127), with_ones=False,
+                out=gr["fc1.weight"])
+    planes_gemm(d_pre[0:64], 64, 1, acts, R(127, 239), out=gr["fc1.weight"][:, 112:],
+                bias_out=gr["fc1.bias"])
+    planes_gemm(d_pre[64:128], 64, 1, acts, R(239, 303), out=gr["fc2.weight"],
+                bias_out=gr["fc2.bias"])
+    planes_gemm(d_pre[128:192], 64, 1, acts, R(303, 367), out=gr["fc3.weight"],
+                bias_out=gr["fc3.bias"])
+    planes_gemm(d_pre[192:256], 64, 1, acts, R(0, 15), out=gr["states_in.weight"],
+                bias_out=gr["states_in.bias"])
+    planes_gemm(d_zout, n_out, 1, acts, R(367, 431), out=gr["fc_out.weight"],
+                bias_out=gr["fc_out.bias"])
+    if conv is None:
+        _conv_weight_grad(d_conv, refbuf, B, H, gr["conv_ref.weight"],
+                          gr["conv_ref.bias"])
+    else:
+        conv(d_conv, gr["conv_ref.weight"], gr["conv_ref.bias"])
+    return flat, gr
 
 
 def quad_mlp_rollout_loss(net, state0, in_ref, ref, dt, params, weights=None):
@@ -879,3 +922,154 @@ def quad_lstm_closed_loop(net, traj, dt, params, h0, c0, max_steps=251,
     if want_trajectory:
         out.update(drone=drone, actions=actions, start_states=start)
     return out
+
+
+# --------------------------- concurrent mode with the policy inside (config 2)
+class _QuadConcurrentPolicyLoss(torch.autograd.Function):
+    """loss of the concurrent training step with `Net(15, 10, 9, 40, conv=1)`
+    inside the kernels (apg_quad_mlp_concurrent_fwd_bwd): policy once per
+    trajectory, rollout + quad_mpc_loss + adjoint, policy reverse pass;
+    backward() = the weight-gradient products over the batch."""
+
+    @staticmethod
+    def forward(ctx, normed, state0, in_ref, ref, w_s, b_s, conv_w, conv_b, w_1,
+                b_1, w_2, b_2, w_3, b_3, w_out, b_out, dt, params, weights):
+        B, H = state0.shape[0], 10
+        if in_ref.shape[1] < H or in_ref.shape[2] != 9 or ref.shape[1] < H \
+                or normed.shape[1] != 15:
+            raise ValueError("normed [B,15], in_ref [B,>=H,9], ref [B,>=H,9|6], H = 10")
+        if (w_s.shape != (64, 15) or conv_w.shape != (20, 9, 3)
+                or w_1.shape != (64, 224) or w_out.shape != (40, 64)):
+            raise ValueError("fused path needs Net(15, 10, 9, 40, conv=1)")
+        dev = state0.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        # one buffer for the B operands of the weight products:
+        # feat (15) | x1 (224) | h1, h2, h3 (192) | in_ref rows (H*9)
+        acts = new(431 + H * 9, B)
+        feat, x1, h, inr = acts[:15], acts[15:239], acts[239:431], acts[431:]
+        feat.copy_(_f32c(normed).t())
+        inr.view(H, 9, B).copy_(_f32c(in_ref)[:, :H].permute(1, 2, 0))
+        s0 = _f32c(state0).t().contiguous()
+        rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
+        names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
+                 "w_3", "b_3", "w_out", "b_out")
+        pw = dict(zip(names, (_f32c(v).contiguous() for v in (
+            w_s, b_s, conv_w, conv_b, w_1, b_1, w_2, b_2, w_3, b_3, w_out,
+            b_out))))
+        require_device(acts, s0, rf, *pw.values())
+        pol = _capi.ApgMlpPolicy(**{k: ptr(v) for k, v in pw.items()})
+        relu_mask = torch.empty(5, B, dtype=torch.int32, device=dev)
+        cot = new(40 + 256 + 160, B)      # d_zout | d_pre | d_conv
+        d_zout, d_pre, d_conv = cot[:40], cot[40:296], cot[296:]
+        partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
+        loss = new(1)
+        ws = new(lib().apg_quad_mlp_concurrent_workspace_floats())
+        check(lib().apg_quad_mlp_concurrent_fwd_bwd(
+            ptr(feat), ptr(inr), ptr(s0), ptr(rf), rf.shape[1], float(dt),
+            ctypes.byref(params), ctypes.byref(weights), ctypes.byref(pol), B, H,
+            ptr(x1), ptr(h), relu_mask.data_ptr(), ptr(d_zout), ptr(d_pre),
+            ptr(d_conv), ptr(partials), ptr(loss), None, ptr(ws),
+            stream_of(s0)), "apg_quad_mlp_concurrent_fwd_bwd")
+        ctx.save_for_backward(acts, cot)
+        ctx.dims = (B, H)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, gr = _conc_param_grads(ctx.saved_tensors, ctx.dims)
+        flat *= g
+        return (None, None, None, None, *[gr[k] for k in _MLP_PARAMS], None, None, None)
+
+
+def _conc_param_grads(saved, dims):
+    acts, cot = saved
+    B, H = dims
+    dev = acts.device
+
+    def conv(d_conv, w_out, b_out):
+        # window rows are the in_ref planes behind the activations, segment = position
+        desc = make_bdesc(dev, [431 + t * 9 + c for c in range(9) for t in range(3)],
+                          9, 0, key=("conc_conv", H))
+        planes_gemm(d_conv, 20, 8, acts, desc, out=w_out.view(20, 27), bias_out=b_out)
+
+    return _mlp_param_grads((None, acts, cot[40:296], cot[:40], cot[296:]), dims, 40,
+                            conv=conv)
+
+
+def quad_concurrent_policy_loss(net, normed, state0, in_ref, ref, dt, params,
+                                weights=None):
+    """The concurrent training step's loss for a `Net(15, 10, 9, 40, conv=1)`:
+    quad_mpc_loss(unroll(dyn, state0, sigmoid(net(normed, in_ref))), ref) with
+    the policy inside the kernels; `loss.backward()` fills the parameter
+    gradients (the inputs carry none, as in scripts/train_base.py:198-204)."""
+    return _QuadConcurrentPolicyLoss.apply(
+        normed, state0, in_ref, ref, net.states_in.weight, net.states_in.bias,
+        net.conv_ref.weight, net.conv_ref.bias, net.fc1.weight, net.fc1.bias,
+        net.fc2.weight, net.fc2.bias, net.fc3.weight, net.fc3.bias,
+        net.fc_out.weight, net.fc_out.bias, dt, params,
+        weights or quad_loss_weights())
+
+
+# ------------------------------------- fused policies without the autograd tape
+class _DirectCtx:
+    """Stand-in for the autograd context when a fused loss is evaluated for its
+    parameter gradients only (trainers): no input gradients, nothing taped."""
+    needs_input_grad = (False,) * 8
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def _net_params(net, names):
+    out = []
+    for n in names:
+        mod, attr = n.rsplit(".", 1)
+        out.append(getattr(net.get_submodule(mod), attr).detach())
+    return out
+
+
+def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
+                                 weights=None):
+    """quad_concurrent_policy_loss + its parameter gradients, without autograd:
+    returns (loss, {parameter name: gradient}); the gradients are contiguous
+    views of one flat buffer (no per-parameter clone as `loss.backward()`
+    does)."""
+    ctx = _DirectCtx()
+    with torch.no_grad():
+        loss = _QuadConcurrentPolicyLoss.forward(
+            ctx, normed, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt,
+            params, weights or quad_loss_weights())
+        _, gr = _conc_param_grads(ctx.saved_tensors, ctx.dims)
+    return loss, gr
+
+
+def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None):
+    """quad_mlp_rollout_loss (autoregressive unroll) + parameter gradients,
+    without autograd; see quad_concurrent_policy_grads."""
+    ctx = _DirectCtx()
+    with torch.no_grad():
+        loss, _, _ = _QuadMlpRolloutLoss.forward(
+            ctx, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt, params,
+            weights or quad_loss_weights())
+        _, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
+    return loss, gr
+
+
+_LSTM_PARAMS = ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
+                "lstm.weight_hh", "lstm.bias_ih", "lstm.bias_hh", "fc_out.weight",
+                "fc_out.bias")
+
+
+def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
+                            weights=None):
+    """quad_lstm_rollout_loss + parameter gradients, without autograd."""
+    ctx = _DirectCtx()
+    with torch.no_grad():
+        loss, _, _ = _QuadLstmRolloutLoss.forward(
+            ctx, state0, in_ref, ref, h0, c0, *_net_params(net, _LSTM_PARAMS), dt,
+            params, weights or quad_loss_weights())
+        _, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
+    return loss, gr

@@ -155,6 +155,18 @@ class TrainBase:
         self.optimizer_controller.step()
         return loss
 
+    def _step_direct(self, loss, named_grads):
+        """_step for the fused-policy paths: the kernels already produced the
+        parameter gradients (contiguous views of one flat buffer), so they are
+        attached as `.grad` directly - no autograd tape, no per-parameter
+        clone - then (all-reduce) -> optimizer step."""
+        for name, p in self.net.named_parameters():
+            p.grad = named_grads.get(name)
+        if self.grad_sync is not None:
+            loss = self.grad_sync.sync(loss.detach())
+        self.optimizer_controller.step()
+        return loss
+
     # --------------------------------------------------------- hot loop
     def train_controller_model(
         self, current_state, action_seq, in_ref_state, ref_states
@@ -165,6 +177,13 @@ class TrainBase:
         self, in_state, current_state, in_ref_states, ref_states
     ):
         raise NotImplementedError("only the quadrotor trainer is recurrent")
+
+    def train_concurrent_fused(
+        self, in_state, current_state, in_ref_states, ref_states
+    ):
+        """Optional: the whole concurrent step (policy forward, rollout, loss,
+        backward, optimizer) in fused kernels; None = not available."""
+        return None
 
     def train_dynamics_model(self, current_state, action_seq):
         """scripts/train_base.py:160-186: one SGD step fitting the learnable
@@ -214,6 +233,9 @@ class TrainBase:
                 loss = self.train_recurrent_model(
                     in_state, current_state, in_ref_state, ref_states
                 )
+            elif (loss := self.train_concurrent_fused(
+                    in_state, current_state, in_ref_state, ref_states)) is not None:
+                pass        # policy + rollout + backward in the fused kernels
             else:
                 actions = self.net(in_state, in_ref_state)
                 actions = torch.sigmoid(actions)

@@ -74,16 +74,16 @@ class TrainDrone(TrainBase):
             self.net.reset_hidden_state(
                 batch_size, generator=self.hidden_generator)
             if self.fused_policy and self._fusable():
-                loss, _, _ = F.quad_lstm_rollout_loss(
+                loss, grads = F.quad_lstm_rollout_grads(
                     self.net, current_state, in_ref_states, ref_states,
                     self.delta_t, self.train_dynamics.params,
                     self.net.hidden_state, self.net.cell_state)
-                return self._step(loss)
+                return self._step_direct(loss, grads)
         elif self.fused_policy and self._fusable_mlp():
-            loss, _, _ = F.quad_mlp_rollout_loss(
+            loss, grads = F.quad_mlp_rollout_grads(
                 self.net, current_state, in_ref_states, ref_states,
                 self.delta_t, self.train_dynamics.params)
-            return self._step(loss)
+            return self._step_direct(loss, grads)
         states, actions = [], []
         for k in range(self.horizon):
             rel = in_ref_states[:, k:k + self.horizon].clone()
@@ -106,6 +106,24 @@ class TrainDrone(TrainBase):
                 and n.lstm.weight_ih.shape == (32, 175)
                 and n.conv_ref.weight.shape == (20, 9, 3)
                 and n.fc_out.weight.shape == (4, 8))
+
+    def train_concurrent_fused(
+        self, in_state, current_state, in_ref_states, ref_states
+    ):
+        """scripts/train_base.py:198-204 + scripts/train_drone.py:175-203 with
+        the policy inside the kernels (apg_quad_mlp_concurrent_fwd_bwd)."""
+        n = self.net
+        if not (self.fused_policy and isinstance(n, Net) and n.conv
+                and self.horizon == 10 and hasattr(self.train_dynamics, "params")
+                and n.states_in.weight.shape == (64, 15)
+                and n.conv_ref.weight.shape == (20, 9, 3)
+                and n.fc1.weight.shape == (64, 224)
+                and n.fc_out.weight.shape == (40, 64)):
+            return None
+        loss, grads = F.quad_concurrent_policy_grads(
+            n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
+            self.train_dynamics.params)
+        return self._step_direct(loss, grads)
 
     def _fusable_mlp(self):
         n = self.net

@@ -277,6 +277,30 @@ int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
                              float *d_zout, float *d_conv, float *grad_state0,
                              float *workspace, apg_stream_t stream);
 
+/* Concurrent-mode training step with the policy inside (BASELINE config 2):
+ * TrainBase.run_epoch's concurrent branch (scripts/train_base.py:198-204:
+ * actions = sigmoid(net(in_state, in_ref)) reshaped [B, H, 4]) +
+ * TrainDrone.train_controller_model (scripts/train_drone.py:175-203) in two
+ * launches: network forward once per trajectory + register-resident rollout,
+ * quad_mpc_loss and adjoint; then the network's reverse pass.  `policy` is a
+ * Net(15, 10, 9, 40, conv=1): w_out [40][64], b_out [40].
+ * In (SoA): feat [15][B] (the data set's normed_states), in_ref [H][9][B],
+ * state0 [12][B], ref [H][ref_cols][B].
+ * Out: planes for apg_planes_gemm - x1 [224][B], h [192][B], relu_mask [5][B],
+ * d_zout [40][B] (head pre-activation cotangents), d_pre [256][B], d_conv
+ * [160][B]; loss_partials (apg_quad_mlp_loss_partials_count(B)), loss [1] or
+ * NULL, states [H][12][B] or NULL.
+ *   dW_out = d_zout h3^T, the rest as for apg_quad_mlp_rollout_bwd with N = B.
+ * workspace: apg_quad_mlp_concurrent_workspace_floats(). */
+int apg_quad_mlp_concurrent_workspace_floats(void);
+int apg_quad_mlp_concurrent_fwd_bwd(
+    const float *feat, const float *in_ref, const float *state0, const float *ref,
+    int ref_cols, float dt, const ApgQuadParams *params,
+    const ApgQuadLossWeights *weights, const ApgMlpPolicy *policy, int B, int H,
+    float *x1, float *h, unsigned *relu_mask, float *d_zout, float *d_pre,
+    float *d_conv, float *loss_partials, float *loss, float *states,
+    float *workspace, apg_stream_t stream);
+
 /* Batched closed-loop evaluation: the loop of
  * QuadEvaluator.follow_trajectory("rand") (scripts/evaluate_drone.py:81-194)
  * for B reference trajectories in one launch - per step the H-row reference
@@ -326,13 +350,15 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
  * the sliding reference windows of the conv branch in place (segment =
  * (window position, step), sdiv = H).  `bdesc` is a DEVICE int array [3][J];
  * `workspace` holds apg_planes_gemm_workspace_floats(M, J, with_ones, num_wg)
- * floats; C has row stride ldc >= J + with_ones.  B holds `b_planes` planes;
- * A (M*S planes) and B must each stay below 2 GiB. */
+ * floats; C has row stride ldc >= J + with_ones.  With `bias_out` (and
+ * with_ones) the row sums go to bias_out[M] instead of column J, so that
+ * weight and bias gradients are both contiguous (ldc >= J then).  B holds
+ * `b_planes` planes; A (M*S planes) and B must each stay below 2 GiB. */
 int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg);
 int apg_planes_gemm(const float *A, int M, int S, const float *B,
                     const int *bdesc, int J, int sdiv, int with_ones,
                     int b_planes, long long N, float *workspace, int num_wg,
-                    float *C, int ldc, apg_stream_t stream);
+                    float *C, int ldc, float *bias_out, apg_stream_t stream);
 
 /* ---------------------------------------------------------- fixed wing --- */
 /* Parameters of neural_control/dynamics/fixed_wing_dynamics.py:18-39 +

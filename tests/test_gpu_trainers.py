@@ -72,6 +72,71 @@ def test_quad_train_controller_two_sgd_steps(dev):
             assert rel_err(N(v), g[f"w{step}.{k}"]) < 1e-5, (step, k)
 
 
+def test_quad_concurrent_fused_policy_two_sgd_steps(dev):
+    """G3 again, with policy forward, rollout, loss, adjoint and policy
+    backward inside the fused kernels (apg_quad_mlp_concurrent_fwd_bwd):
+    loss, every parameter gradient, post-SGD weights of two steps."""
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    g = load_golden("quad_train.npz")
+    trainer = make_trainer(TrainDrone, FlightmareDynamics(), QUAD_CFG)
+    net = Net(15, 10, 9, 40, conv=1)
+    load_weights(net, g, "w0.")
+    trainer.net = net.to(dev)
+    trainer.optimizer_controller = torch.optim.SGD(
+        trainer.net.parameters(), lr=float(g["lr"]), momentum=float(g["momentum"]))
+    in_state, in_ref = D(g["in_state"], dev), D(g["in_ref"], dev)
+    state0, ref = D(g["state0"], dev), D(g["ref"], dev)
+    for step in (1, 2):
+        loss = trainer.train_concurrent_fused(in_state, state0, in_ref, ref)
+        assert loss is not None
+        assert abs(loss.item() - g[f"loss{step}"]) / g[f"loss{step}"] < 1e-5
+        if step == 1:
+            for k, p in trainer.net.named_parameters():
+                if "g1." + k in g.files:
+                    assert rel_err(N(p.grad), g["g1." + k]) < 1e-4, k
+        for k, v in trainer.net.state_dict().items():
+            assert rel_err(N(v), g[f"w{step}.{k}"]) < 1e-5, (step, k)
+
+
+@pytest.mark.parametrize("B", [1, 77, 600])
+def test_quad_concurrent_fused_matches_unfused(dev, B):
+    """Ragged batches: fused concurrent step == torch policy + fused rollout."""
+    import copy
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    d = synthetic.quad_polynomial_batch(B, 10, 0.1, seed=90 + B)
+    state0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    with torch.no_grad():
+        normed = state_preprocessing(state0)
+    torch.manual_seed(4)
+    base = Net(15, 10, 9, 40, conv=1)
+    res = []
+    for fused in (False, True):
+        trainer = TrainDrone(FlightmareDynamics(), FlightmareDynamics(),
+                             dict(QUAD_CFG, batch_size=B))
+        trainer.net = copy.deepcopy(base).to(dev)
+        trainer.optimizer_controller = torch.optim.SGD(trainer.net.parameters(), lr=0.0)
+        if fused:
+            loss = trainer.train_concurrent_fused(normed, state0, in_ref, ref)
+        else:
+            acts = torch.sigmoid(trainer.net(normed, in_ref)).reshape(-1, 10, 4)
+            loss = trainer.train_controller_model(state0, acts, in_ref, ref)
+        res.append((loss.item(), {k: N(p.grad) for k, p in
+                                  trainer.net.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) / abs(l0) < 1e-5
+    assert set(g0) == set(g1)
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 2e-4, k
+
+
 def test_quad_soa_head_matches_aos_path(dev):
     """Net.forward_soa + layout='soa' rollout == the AoS trainer path."""
     from apg_trajectory_tracking_amd import functional as F

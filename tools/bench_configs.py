@@ -133,6 +133,11 @@ def main():
             t._step(loss)
         emit("quad_train_step_soa_head", B, H, timed(step_soa, 30, 5))
 
+        def step_fused():      # policy inside the kernels
+            t.train_concurrent_fused(d.normed_states, d.states, d.in_ref_states,
+                                     d.ref_states)
+        emit("quad_train_step_fused_policy", B, H, timed(step_fused, 30, 5))
+
     for mode, name, fused in (("autoregressive", "quad_ar_unfused", False),
                               ("autoregressive", "quad_ar_fused", True),
                               ("LSTM", "quad_lstm_unfused", False),
