@@ -74,6 +74,15 @@ class ApgMlpPolicy(ctypes.Structure):
         "w_3", "b_3", "w_out", "b_out")]
 
 
+class ApgGemmProblem(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p),
+                ("bdesc", ctypes.c_void_p), ("C", ctypes.c_void_p),
+                ("bias_out", ctypes.c_void_p), ("N", ctypes.c_longlong),
+                ("M", ctypes.c_int), ("S", ctypes.c_int), ("J", ctypes.c_int),
+                ("sdiv", ctypes.c_int), ("with_ones", ctypes.c_int),
+                ("b_planes", ctypes.c_int), ("ldc", ctypes.c_int)]
+
+
 class ApgCartpoleParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in (
         "masscart", "masspole", "length", "max_force_mag", "friction",
@@ -132,6 +141,7 @@ SIGNATURES = {
         _P, _I, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgLstmPolicy), _I, _I, _I, _F, _F, _I, _P, _P, _P, _P,
         _P, _P, _P],
+    "apg_planes_gemm_grouped": [ctypes.POINTER(ApgGemmProblem), _I, _P, _I, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
     "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I,
                         ctypes.c_longlong, _P, _I, _P, _I, _P, _P],

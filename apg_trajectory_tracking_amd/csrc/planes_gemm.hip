@@ -60,9 +60,11 @@ __device__ __forceinline__ int tile_index(int row, int col) {
   return (row >> 2) * kGS + (r << 6) + ((((col >> 2) ^ (r << 2))) << 2) + (col & 3);
 }
 
+// One workgroup's share of a product: tiles bid, bid + nb, ... of `G`; the
+// partial C ([MB*32][NB*32]) goes to `out`.
 template <int MB, int NB>
-__global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
+                                          float *out, float *lds) {
   constexpr int NG = (MB + NB) * 8;  // 4-row groups per tile
   constexpr int GI = NG / 4;         // groups (= DMA instructions) per wave
   constexpr int BUF = NG * kGS;      // floats per tile buffer
@@ -134,10 +136,10 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
   const int lane_base =
       (lr >> 2) * kGS + ((lr & 3) << 6) + ((wave ^ (lr & 3)) << 4) + kh;
   const long long total_tiles = (long long)G.S * G.tiles_per_seg;
-  long long tile = blockIdx.x;
+  long long tile = bid;
   int p = 0;
   if (tile < total_tiles) issue(tile, 0);
-  for (; tile < total_tiles; tile += gridDim.x, p ^= 1) {
+  for (; tile < total_tiles; tile += nb, p ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile landed (all waves); buffer p^1 is free again
     const long long n0 = (tile % G.tiles_per_seg) * kKT;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
         if ((e & 63) >= rem) lds[p * BUF + tile_index(e >> 6, e & 63)] = 0.f;
       __syncthreads();
     }
-    if (tile + gridDim.x < total_tiles) issue(tile + gridDim.x, p ^ 1);
+    if (tile + nb < total_tiles) issue(tile + nb, p ^ 1);
     const float *bp = lds + p * BUF + lane_base;
     // wave w owns k-pairs [8w, 8w+8) of the tile
 #pragma unroll
@@ -194,8 +196,35 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
     }
     __syncthreads();
   }
-  float *out = G.part + (size_t)blockIdx.x * MB * 32 * W;
   for (int i = tid; i < MB * 32 * W; i += kThreads) out[i] = red[i];
+}
+
+template <int MB, int NB>
+__global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  gemm_body<MB, NB>(G, blockIdx.x, gridDim.x,
+                    G.part + (size_t)blockIdx.x * MB * 32 * NB * 32, lds);
+}
+
+// Several products in ONE launch (the weight gradients of a training step):
+// every workgroup belongs to one problem (range [wg0[p], wg0[p+1])), all
+// problems use the 64 x 128 accumulator shape.  A second launch reduces every
+// problem's partials.
+constexpr int kMaxGroup = 8;
+struct GroupArgs {
+  GemmArgs g[kMaxGroup];
+  int wg0[kMaxGroup + 1];
+  float *C[kMaxGroup], *bias[kMaxGroup];
+  int ldc[kMaxGroup];
+  int n;
+};
+
+__global__ __launch_bounds__(kThreads) void planes_gemm_grouped_kernel(GroupArgs GA) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int p = 0;
+  while (p + 1 < GA.n && (int)blockIdx.x >= GA.wg0[p + 1]) ++p;
+  gemm_body<2, 4>(GA.g[p], blockIdx.x - GA.wg0[p], GA.wg0[p + 1] - GA.wg0[p],
+                  GA.g[0].part + (size_t)blockIdx.x * 64 * 128, lds);
 }
 
 // C[m*ldc + j] = sum over workgroups of part[wg][m][j].  64 outputs x 4
@@ -227,6 +256,30 @@ __global__ __launch_bounds__(256) void planes_gemm_reduce_kernel(
     const float v = (float)((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x]));
     if (j == J && bias_out) bias_out[m] = v;  // row sums to their own vector
     else C[(size_t)m * ldc + j] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void planes_gemm_grouped_reduce_kernel(GroupArgs GA) {
+  __shared__ double sh[4][64];
+  const int p = blockIdx.y;
+  const GemmArgs &G = GA.g[p];
+  const int Jt = G.J + G.with_ones;
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + x;
+  const bool ok = idx < G.M * Jt;
+  const int m = ok ? idx / Jt : 0, j = ok ? idx % Jt : 0;
+  const float *part = GA.g[0].part + (size_t)GA.wg0[p] * 64 * 128 + (size_t)m * 128 + j;
+  const int num_wg = GA.wg0[p + 1] - GA.wg0[p];
+  const int per = (num_wg + 3) / 4;
+  const int w0 = y * per, w1 = w0 + per < num_wg ? w0 + per : num_wg;
+  double acc = 0;
+  for (int w = w0; w < w1; ++w) acc += (double)part[(size_t)w * 64 * 128];
+  sh[y][x] = acc;
+  __syncthreads();
+  if (y == 0 && ok) {
+    const float v = (float)((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x]));
+    if (j == G.J && GA.bias[p]) GA.bias[p][m] = v;
+    else GA.C[p][(size_t)m * GA.ldc[p] + j] = v;
   }
 }
 
@@ -317,6 +370,70 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
                      dim3(256), 0, st, workspace, num_wg, NB * 32, MB * 32, M, Jt,
                      C, ldc, J, with_ones ? bias_out : nullptr);
   return check_launch("planes_gemm_reduce");
+}
+
+int apg_planes_gemm_grouped(const ApgGemmProblem *problems, int n,
+                            float *workspace, int num_wg, apg_stream_t stream) {
+  if (!problems || !workspace || n < 1 || n > kMaxGroup || num_wg < n) {
+    set_error("apg_planes_gemm_grouped: need 1 <= n <= %d problems, num_wg >= n",
+              kMaxGroup);
+    return APG_ERR_ARG;
+  }
+  GroupArgs GA;
+  GA.n = n;
+  double cost[kMaxGroup], total = 0;
+  for (int p = 0; p < n; ++p) {
+    const ApgGemmProblem &q = problems[p];
+    const int Jt = q.J + (q.with_ones ? 1 : 0);
+    if (!q.A || !q.B || !q.bdesc || !q.C || q.M < 1 || q.M > 64 || q.S < 1 ||
+        q.J < 1 || Jt > 128 || q.N < 1 || q.sdiv < 1 ||
+        q.ldc < (q.bias_out && q.with_ones ? q.J : Jt)) {
+      set_error("apg_planes_gemm_grouped: problem %d: need M <= 64, J + ones <= "
+                "128, valid pointers and ldc", p);
+      return APG_ERR_ARG;
+    }
+    const long long a_bytes = (long long)q.M * q.S * q.N * 4;
+    const long long b_bytes = (long long)q.b_planes * q.N * 4;
+    if (q.b_planes < 1 || a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) {
+      set_error("apg_planes_gemm_grouped: problem %d: operands must be < 2 GiB", p);
+      return APG_ERR_ARG;
+    }
+    GemmArgs &G = GA.g[p];
+    G.A = q.A, G.Bp = q.B, G.bdesc = q.bdesc, G.part = workspace;
+    G.a_bytes = a_bytes, G.b_bytes = b_bytes;
+    G.N = q.N, G.M = q.M, G.S = q.S, G.J = q.J, G.sdiv = q.sdiv;
+    G.with_ones = q.with_ones ? 1 : 0;
+    G.tiles_per_seg = (int)((q.N + kKT - 1) / kKT);
+    GA.C[p] = q.C, GA.ldc[p] = q.ldc;
+    GA.bias[p] = q.with_ones ? q.bias_out : nullptr;
+    // measured per workgroup and tile: ~0.6 us fixed + 12.5 ns per operand row
+    cost[p] = (double)q.S * G.tiles_per_seg * (q.M + Jt + 48);
+    total += cost[p];
+  }
+  // workgroups in proportion to the time each problem needs
+  int given = 0;
+  for (int p = 0; p < n; ++p) {
+    int w = (int)(cost[p] / total * (num_wg - n)) + 1;
+    GA.wg0[p] = given;
+    given += w;
+  }
+  GA.wg0[n] = given;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * (2 + 4) * 8 * kGS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)planes_gemm_grouped_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(planes_gemm_grouped)");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(planes_gemm_grouped_kernel, dim3(given), dim3(kThreads), lds, st,
+                     GA);
+  if (int e = check_launch("planes_gemm_grouped")) return e;
+  hipLaunchKernelGGL(planes_gemm_grouped_reduce_kernel, dim3((64 * 128 + 63) / 64, n),
+                     dim3(256), 0, st, GA);
+  return check_launch("planes_gemm_grouped_reduce");
 }
 
 }  // extern "C"

@@ -559,6 +559,55 @@ def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None,
     return out[:M, :Jc]
 
 
+_GROUP_WGS = 256
+
+
+def planes_gemm_grouped(problems):
+    """Several planes_gemm products in one launch pair
+    (apg_planes_gemm_grouped).  `problems`: dicts with the planes_gemm
+    arguments A, M, S, Bp, bdesc, out and optionally with_ones (True), sdiv
+    (1), N, bias_out; each M <= 64 and J + ones <= 128, at most 8."""
+    probs = (_capi.ApgGemmProblem * len(problems))()
+    for q, d in zip(probs, problems):
+        A, Bp, out = d["A"], d["Bp"], d["out"]
+        require_device(A, Bp)
+        N = d.get("N") or A.shape[1]
+        ones = int(d.get("with_ones", True))
+        bias = d.get("bias_out") if ones else None
+        J = d["bdesc"].shape[1]
+        if out.stride(1) != 1 or out.shape[0] < d["M"] \
+                or out.shape[1] < (J if bias is not None else J + ones):
+            raise ValueError("planes_gemm_grouped: bad `out` view")
+        q.A, q.B, q.bdesc, q.C = ptr(A), ptr(Bp), d["bdesc"].data_ptr(), out.data_ptr()
+        q.bias_out = ptr(bias)
+        q.N, q.M, q.S, q.J = N, d["M"], d["S"], J
+        q.sdiv, q.with_ones = d.get("sdiv", 1), ones
+        q.b_planes, q.ldc = Bp.numel() // N, out.stride(0)
+    A0 = problems[0]["A"]
+    ws = torch.empty(_GROUP_WGS * 64 * 128, dtype=torch.float32, device=A0.device)
+    check(lib().apg_planes_gemm_grouped(probs, len(problems), ptr(ws), _GROUP_WGS,
+                                        stream_of(A0)), "apg_planes_gemm_grouped")
+
+
+def _run_products(problems):
+    """A training step's weight-gradient products.  Short planes (one column
+    per trajectory, the concurrent mode): launch latency dominates, so all
+    products share one launch pair.  Long planes (H columns per trajectory):
+    each product gets its own launch with the tile shape and occupancy that
+    fit it - a shared launch would run the small ones at one workgroup per
+    CU."""
+    n_max = max(d.get("N") or d["A"].shape[1] for d in problems)
+    total = sum((d.get("N") or d["A"].shape[1]) * d["S"] for d in problems)
+    fits = all(d["bdesc"].shape[1] + int(d.get("with_ones", True)) <= 128
+               for d in problems) and len(problems) <= 8
+    if fits and total <= 8 * 131072 and n_max <= 131072:
+        return planes_gemm_grouped(problems)
+    for d in problems:
+        planes_gemm(d["A"], d["M"], d["S"], d["Bp"], d["bdesc"],
+                    with_ones=d.get("with_ones", True), sdiv=d.get("sdiv", 1),
+                    N=d.get("N"), out=d["out"], bias_out=d.get("bias_out"))
+
+
 def _flat_grads(dev, shapes):
     """One flat fp32 buffer holding a contiguous gradient tensor per entry of
     `shapes` (name -> shape); returns (flat, {name: view})."""
@@ -582,22 +631,26 @@ def _ref_and_states(in_ref, state0, B, H):
     return buf, inr, st_all[0], st_all[1:]
 
 
-def _conv_weight_grad(d_conv, refbuf, B, H, w_out, b_out):
-    """d conv_ref.weight [20,9,3] / bias [20] (written into w_out / b_out) from
-    the conv cotangent planes d_conv [160][H*B] (plane = ch*8 + pos) in ONE
-    product: the windows are read in place from the reference planes of
-    `refbuf` with segment = (pos, step), the relative-position shift of
-    columns 0..2 comes from three extra columns over the position planes
-    before each step."""
+def _conv_weight_problem(d_conv, refbuf, B, H, b_out):
+    """The conv-weight product of the recurrent unrolls as a planes_gemm
+    problem: d_conv [160][H*B] (plane = ch*8 + pos) against the windows read in
+    place from the reference planes of `refbuf` (segment = (pos, step)) plus
+    three columns over the position planes before each step (the
+    relative-position shift of columns 0..2).  Returns (problem, finish):
+    finish(w_out) writes d conv_ref.weight [20,9,3] once the product ran."""
     dev = d_conv.device
     offs = [t * 9 + c for c in range(9) for t in range(3)] + [2 * H * 9 + q for q in range(3)]
     desc = make_bdesc(dev, offs, [9] * 27 + [0] * 3, [9] * 27 + [12] * 3,
                       key=("conv", H))
-    c = planes_gemm(d_conv, 20, 8 * H, refbuf, desc, sdiv=H, N=B,
-                    bias_out=b_out)                                  # [20, 30]
-    w = w_out.view(20, 27)
-    w.copy_(c[:, :27])
-    w[:, :9].view(20, 3, 3).sub_(c[:, 27:30, None])
+    c = torch.empty(20, 30, dtype=torch.float32, device=dev)
+    prob = dict(A=d_conv, M=20, S=8 * H, Bp=refbuf, bdesc=desc, sdiv=H, N=B, out=c,
+                bias_out=b_out)
+
+    def finish(w_out):
+        w = w_out.view(20, 27)
+        w.copy_(c[:, :27])
+        w[:, :9].view(20, 3, 3).sub_(c[:, 27:30, None])
+    return prob, finish
 
 
 class _QuadLstmRolloutLoss(torch.autograd.Function):
@@ -688,12 +741,16 @@ def _lstm_param_grads(saved, dims):
     flat, gr = _flat_grads(dev, {
         "ih_hh": (32, 183), "lstm.bias_ih": (32,), "fc_out.weight": (4, 8),
         "fc_out.bias": (4,), "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,)})
-    # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T, db = row sums
-    planes_gemm(d_gates, 32, 1, acts, make_bdesc(dev, range(183), key="ih_hh"),
-                out=gr["ih_hh"], bias_out=gr["lstm.bias_ih"])
-    planes_gemm(d_zout, 4, 1, acts, make_bdesc(dev, range(191, 199), key="out"),
-                out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])
-    _conv_weight_grad(d_conv, refbuf, B, H, gr["conv_ref.weight"], gr["conv_ref.bias"])
+    # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T (two column chunks), db = row
+    # sums; dW_out = d_zout . h_new^T; conv - all in one launch pair
+    conv, finish = _conv_weight_problem(d_conv, refbuf, B, H, gr["conv_ref.bias"])
+    _run_products([
+        dict(A=d_gates, M=32, S=1, Bp=acts, bdesc=make_bdesc(dev, range(183), key="ih_hh"),
+             out=gr["ih_hh"], bias_out=gr["lstm.bias_ih"]),
+        dict(A=d_zout, M=4, S=1, Bp=acts, bdesc=make_bdesc(dev, range(191, 199), key="out"),
+             out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"]),
+        conv])
+    finish(gr["conv_ref.weight"])
     ih_hh = gr.pop("ih_hh")
     gr["lstm.weight_ih"], gr["lstm.weight_hh"] = ih_hh[:, :175], ih_hh[:, 175:]
     gr["lstm.bias_hh"] = gr["lstm.bias_ih"]
@@ -803,23 +860,26 @@ def _mlp_param_grads(saved, dims, n_out, conv=None):
         "fc2.bias": (64,), "fc3.weight": (64, 64), "fc3.bias": (64,),
         "fc_out.weight": (n_out, 64), "fc_out.bias": (n_out,)})
     R = lambda lo, hi_: make_bdesc(dev, range(lo, hi_), key=("mlp", lo, hi_))
-    planes_gemm(d_pre[0:64], 64, 1, acts, R(15, 127), with_ones=False,
-                out=gr["fc1.weight"])
-    planes_gemm(d_pre[0:64], 64, 1, acts, R(127, 239), out=gr["fc1.weight"][:, 112:],
-                bias_out=gr["fc1.bias"])
-    planes_gemm(d_pre[64:128], 64, 1, acts, R(239, 303), out=gr["fc2.weight"],
-                bias_out=gr["fc2.bias"])
-    planes_gemm(d_pre[128:192], 64, 1, acts, R(303, 367), out=gr["fc3.weight"],
-                bias_out=gr["fc3.bias"])
-    planes_gemm(d_pre[192:256], 64, 1, acts, R(0, 15), out=gr["states_in.weight"],
-                bias_out=gr["states_in.bias"])
-    planes_gemm(d_zout, n_out, 1, acts, R(367, 431), out=gr["fc_out.weight"],
-                bias_out=gr["fc_out.bias"])
+    probs = [
+        dict(A=d_pre[0:64], M=64, S=1, Bp=acts, bdesc=R(15, 127), with_ones=False,
+             out=gr["fc1.weight"]),
+        dict(A=d_pre[0:64], M=64, S=1, Bp=acts, bdesc=R(127, 239),
+             out=gr["fc1.weight"][:, 112:], bias_out=gr["fc1.bias"]),
+        dict(A=d_pre[64:128], M=64, S=1, Bp=acts, bdesc=R(239, 303),
+             out=gr["fc2.weight"], bias_out=gr["fc2.bias"]),
+        dict(A=d_pre[128:192], M=64, S=1, Bp=acts, bdesc=R(303, 367),
+             out=gr["fc3.weight"], bias_out=gr["fc3.bias"]),
+        dict(A=d_pre[192:256], M=64, S=1, Bp=acts, bdesc=R(0, 15),
+             out=gr["states_in.weight"], bias_out=gr["states_in.bias"]),
+        dict(A=d_zout, M=n_out, S=1, Bp=acts, bdesc=R(367, 431),
+             out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])]
     if conv is None:
-        _conv_weight_grad(d_conv, refbuf, B, H, gr["conv_ref.weight"],
-                          gr["conv_ref.bias"])
+        cp, finish = _conv_weight_problem(d_conv, refbuf, B, H, gr["conv_ref.bias"])
     else:
-        conv(d_conv, gr["conv_ref.weight"], gr["conv_ref.bias"])
+        cp, finish = conv(d_conv, gr["conv_ref.weight"], gr["conv_ref.bias"]), None
+    _run_products(probs + [cp])
+    if finish is not None:
+        finish(gr["conv_ref.weight"])
     return flat, gr
 
 
@@ -990,7 +1050,8 @@ def _conc_param_grads(saved, dims):
         # window rows are the in_ref planes behind the activations, segment = position
         desc = make_bdesc(dev, [431 + t * 9 + c for c in range(9) for t in range(3)],
                           9, 0, key=("conc_conv", H))
-        planes_gemm(d_conv, 20, 8, acts, desc, out=w_out.view(20, 27), bias_out=b_out)
+        return dict(A=d_conv, M=20, S=8, Bp=acts, bdesc=desc, out=w_out.view(20, 27),
+                    bias_out=b_out)
 
     return _mlp_param_grads((None, acts, cot[40:296], cot[:40], cot[296:]), dims, 40,
                             conv=conv)

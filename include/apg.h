@@ -360,6 +360,22 @@ int apg_planes_gemm(const float *A, int M, int S, const float *B,
                     int b_planes, long long N, float *workspace, int num_wg,
                     float *C, int ldc, float *bias_out, apg_stream_t stream);
 
+/* Several of the products above in one launch pair (all weight gradients of a
+ * training step): n <= 8 problems, each M <= 64 and J + with_ones <= 128.
+ * workspace: num_wg * 64 * 128 floats; num_wg >= n workgroups are divided
+ * among the problems in proportion to the planes they stream. */
+typedef struct ApgGemmProblem {
+  const float *A;
+  const float *B;
+  const int *bdesc;   /* device int [3][J] */
+  float *C;
+  float *bias_out;    /* or NULL */
+  long long N;
+  int M, S, J, sdiv, with_ones, b_planes, ldc;
+} ApgGemmProblem;
+int apg_planes_gemm_grouped(const ApgGemmProblem *problems, int n,
+                            float *workspace, int num_wg, apg_stream_t stream);
+
 /* ---------------------------------------------------------- fixed wing --- */
 /* Parameters of neural_control/dynamics/fixed_wing_dynamics.py:18-39 +
  * config_fixed_wing.json after `cfg.update(modified_params)`. */

@@ -651,3 +651,41 @@ def test_fused_policy_argument_errors(dev):
         Net(15, 10, 9, 4, conv=1).to(dev), e, torch.zeros(0, 20, 9, device=dev),
         torch.zeros(0, 20, 9, device=dev), 0.1, dyn.params)
     assert float(loss.detach()) == 0.0 and st.shape == (10, 12, 0)
+
+
+def test_planes_gemm_grouped_vs_torch(dev):
+    """apg_planes_gemm_grouped: several products of different shape in one
+    launch pair, strided outputs, separate bias vectors, ragged N."""
+    from apg_trajectory_tracking_amd import functional as F
+    g = torch.Generator().manual_seed(3)
+    N = 5000 + 37
+    Bp = torch.randn(150, N, generator=g).to(dev)
+    A1 = torch.randn(64, N, generator=g).to(dev)
+    A2 = torch.randn(4, N, generator=g).to(dev)
+    A3 = torch.randn(20 * 8, N, generator=g).to(dev)
+    o1 = torch.zeros(64, 120, device=dev)
+    b1 = torch.zeros(64, device=dev)
+    o2 = torch.zeros(4, 9, device=dev)
+    o3, b3 = torch.zeros(20, 27, device=dev), torch.zeros(20, device=dev)
+    offs3 = [t * 9 + c for c in range(9) for t in range(3)]
+    F.planes_gemm_grouped([
+        dict(A=A1, M=64, S=1, Bp=Bp, bdesc=F.make_bdesc(dev, range(10, 122)),
+             out=o1[:, 4:], bias_out=b1),
+        dict(A=A2, M=4, S=1, Bp=Bp, bdesc=F.make_bdesc(dev, range(140, 148)), out=o2),
+        dict(A=A3, M=20, S=8, Bp=Bp, bdesc=F.make_bdesc(dev, offs3, 9), out=o3,
+             bias_out=b3)])
+    B64 = Bp.double().cpu()
+    r1 = A1.double().cpu() @ B64[10:122].t()
+    assert rel_err(o1[:, 4:116].cpu().numpy(), r1.numpy()) < 1e-5
+    assert float(o1[:, :4].abs().sum()) == 0 and float(o1[:, 116:].abs().sum()) == 0
+    assert rel_err(b1.cpu().numpy(), A1.double().cpu().sum(1).numpy()) < 1e-5
+    r2 = torch.cat((A2.double().cpu() @ B64[140:148].t(),
+                    A2.double().cpu().sum(1, keepdim=True)), 1)
+    assert rel_err(o2.cpu().numpy(), r2.numpy()) < 1e-5
+    A3d = A3.double().cpu().view(20, 8, N)
+    r3 = torch.zeros(20, 27, dtype=torch.float64)
+    for s_ in range(8):
+        rows = torch.stack([B64[o + 9 * s_] for o in offs3])
+        r3 += A3d[:, s_] @ rows.t()
+    assert rel_err(o3.cpu().numpy(), r3.numpy()) < 1e-5
+    assert rel_err(b3.cpu().numpy(), A3d.sum((1, 2)).numpy()) < 1e-5
