@@ -148,7 +148,7 @@ def cpu_baseline(args):
 
 def train_step_probe(args, dev, dyn, dist):
     """Secondary, informational: a FULL concurrent-mode training step per rank
-    (policy forward with the SoA head, fused rollout, policy backward, ONE
+    (policy forward, rollout, loss, backward through dynamics and policy, ONE
     RCCL all-reduce of the flattened gradient + loss when world > 1, SGD) -
     reported next to, never instead of, the dynamics-only metric."""
     from apg_trajectory_tracking_amd import functional as F, synthetic
@@ -169,12 +169,21 @@ def train_step_probe(args, dev, dyn, dist):
     s0_soa = synthetic.to_soa_state(d["state0"]).to(dev)
     ref_soa = synthetic.to_soa_seq(d["ref"]).to(dev)
 
+    ref = d["ref"].to(dev)
+    fused = H == 10          # policy inside the kernels (mlp.hip) for H = 10
+
     def step():
-        opt.zero_grad()
-        acts = torch.sigmoid(net.forward_soa(in_state, in_ref)).reshape(H, 4, -1)
-        loss = F.quad_rollout_loss(s0_soa, acts, ref_soa, args.dt, dyn.params,
-                                   layout="soa")
-        loss.backward()
+        if fused:
+            loss, grads = F.quad_concurrent_policy_grads(
+                net, in_state, state0, in_ref, ref, args.dt, dyn.params)
+            for name, p in net.named_parameters():
+                p.grad = grads.get(name)
+        else:
+            opt.zero_grad()
+            acts = torch.sigmoid(net.forward_soa(in_state, in_ref)).reshape(H, 4, -1)
+            loss = F.quad_rollout_loss(s0_soa, acts, ref_soa, args.dt, dyn.params,
+                                       layout="soa")
+            loss.backward()
         total = sync.sync(loss.detach())
         opt.step()
         return total
@@ -196,8 +205,11 @@ def train_step_probe(args, dev, dyn, dist):
         "env_steps_per_s": world * B * H * args.train_steps / el,
         "allreduce_floats": sum(p.numel() for p in net.parameters()) + 1,
         "global_loss": float(total.item()),
-        "what": "policy fwd (PyTorch-ROCm, SoA head) + fused rollout + policy "
-                "bwd + RCCL all-reduce(sum) + SGD, per rank batch %d" % B,
+        "what": ("policy fwd + rollout + loss + adjoint + policy bwd in the fused "
+                 "kernels (matrix cores), weight-gradient products"
+                 if fused else
+                 "policy fwd (PyTorch-ROCm, SoA head) + fused rollout + policy bwd")
+                + " + RCCL all-reduce(sum) + SGD, per rank batch %d" % B,
     }
 
 
