@@ -610,10 +610,13 @@ def _run_products(problems):
 
 def _flat_grads(dev, shapes):
     """One flat fp32 buffer holding a contiguous gradient tensor per entry of
-    `shapes` (name -> shape); returns (flat, {name: view})."""
+    `shapes` (name -> shape) plus ONE trailing slot (for the loss: the whole
+    buffer is then the message of the data-parallel all-reduce); returns
+    (flat, {name: view})."""
     sizes = [int(torch.Size(sh).numel()) for sh in shapes.values()]
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-    views = {k: v.view(sh) for (k, sh), v in zip(shapes.items(), flat.split(sizes))}
+    flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=dev)
+    views = {k: v.view(sh) for (k, sh), v in
+             zip(shapes.items(), flat[:-1].split(sizes))}
     return flat, views
 
 
@@ -1095,16 +1098,17 @@ def _net_params(net, names):
 def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
                                  weights=None):
     """quad_concurrent_policy_loss + its parameter gradients, without autograd:
-    returns (loss, {parameter name: gradient}); the gradients are contiguous
-    views of one flat buffer (no per-parameter clone as `loss.backward()`
-    does)."""
+    returns (loss, {parameter name: gradient}, flat); the gradients are
+    contiguous views of the flat buffer (no per-parameter clone as
+    `loss.backward()` does), whose last element is a free slot for the loss -
+    so the buffer itself is the all-reduce message."""
     ctx = _DirectCtx()
     with torch.no_grad():
         loss = _QuadConcurrentPolicyLoss.forward(
             ctx, normed, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt,
             params, weights or quad_loss_weights())
-        _, gr = _conc_param_grads(ctx.saved_tensors, ctx.dims)
-    return loss, gr
+        flat, gr = _conc_param_grads(ctx.saved_tensors, ctx.dims)
+    return loss, gr, flat
 
 
 def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None):
@@ -1115,8 +1119,8 @@ def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None):
         loss, _, _ = _QuadMlpRolloutLoss.forward(
             ctx, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt, params,
             weights or quad_loss_weights())
-        _, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
-    return loss, gr
+        flat, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
+    return loss, gr, flat
 
 
 _LSTM_PARAMS = ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
@@ -1132,5 +1136,5 @@ def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
         loss, _, _ = _QuadLstmRolloutLoss.forward(
             ctx, state0, in_ref, ref, h0, c0, *_net_params(net, _LSTM_PARAMS), dt,
             params, weights or quad_loss_weights())
-        _, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
-    return loss, gr
+        flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
+    return loss, gr, flat

@@ -22,6 +22,7 @@ import torch
 import torch.optim as optim
 
 from .dataset import TensorBatches
+from . import parallel
 from .parallel import GradAllReducer
 
 
@@ -155,15 +156,22 @@ class TrainBase:
         self.optimizer_controller.step()
         return loss
 
-    def _step_direct(self, loss, named_grads):
+    def _step_direct(self, loss, named_grads, flat=None):
         """_step for the fused-policy paths: the kernels already produced the
         parameter gradients (contiguous views of one flat buffer), so they are
         attached as `.grad` directly - no autograd tape, no per-parameter
-        clone - then (all-reduce) -> optimizer step."""
+        clone - then (all-reduce) -> optimizer step.  With more than one rank
+        the flat buffer (gradients + loss in its last slot) is the message of
+        the ONE all-reduce: nothing is packed or unpacked."""
         for name, p in self.net.named_parameters():
             p.grad = named_grads.get(name)
-        if self.grad_sync is not None:
-            loss = self.grad_sync.sync(loss.detach())
+        if parallel.world_size() > 1:
+            if flat is not None:
+                flat[-1] = loss.detach().reshape(())
+                parallel.dist.all_reduce(flat, op=parallel.dist.ReduceOp.SUM)
+                loss = flat[-1].clone()
+            elif self.grad_sync is not None:
+                loss = self.grad_sync.sync(loss.detach())
         self.optimizer_controller.step()
         return loss
 

@@ -74,16 +74,16 @@ class TrainDrone(TrainBase):
             self.net.reset_hidden_state(
                 batch_size, generator=self.hidden_generator)
             if self.fused_policy and self._fusable():
-                loss, grads = F.quad_lstm_rollout_grads(
+                loss, grads, flat = F.quad_lstm_rollout_grads(
                     self.net, current_state, in_ref_states, ref_states,
                     self.delta_t, self.train_dynamics.params,
                     self.net.hidden_state, self.net.cell_state)
-                return self._step_direct(loss, grads)
+                return self._step_direct(loss, grads, flat)
         elif self.fused_policy and self._fusable_mlp():
-            loss, grads = F.quad_mlp_rollout_grads(
+            loss, grads, flat = F.quad_mlp_rollout_grads(
                 self.net, current_state, in_ref_states, ref_states,
                 self.delta_t, self.train_dynamics.params)
-            return self._step_direct(loss, grads)
+            return self._step_direct(loss, grads, flat)
         states, actions = [], []
         for k in range(self.horizon):
             rel = in_ref_states[:, k:k + self.horizon].clone()
@@ -120,10 +120,10 @@ class TrainDrone(TrainBase):
                 and n.fc1.weight.shape == (64, 224)
                 and n.fc_out.weight.shape == (40, 64)):
             return None
-        loss, grads = F.quad_concurrent_policy_grads(
+        loss, grads, flat = F.quad_concurrent_policy_grads(
             n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
             self.train_dynamics.params)
-        return self._step_direct(loss, grads)
+        return self._step_direct(loss, grads, flat)
 
     def _fusable_mlp(self):
         n = self.net

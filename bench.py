@@ -174,16 +174,23 @@ def train_step_probe(args, dev, dyn, dist):
 
     def step():
         if fused:
-            loss, grads = F.quad_concurrent_policy_grads(
+            loss, grads, flat = F.quad_concurrent_policy_grads(
                 net, in_state, state0, in_ref, ref, args.dt, dyn.params)
             for name, p in net.named_parameters():
                 p.grad = grads.get(name)
-        else:
-            opt.zero_grad()
-            acts = torch.sigmoid(net.forward_soa(in_state, in_ref)).reshape(H, 4, -1)
-            loss = F.quad_rollout_loss(s0_soa, acts, ref_soa, args.dt, dyn.params,
-                                       layout="soa")
-            loss.backward()
+            if dist is not None and dist.get_world_size() > 1:
+                flat[-1] = loss       # gradients + loss: one all-reduce, in place
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                total = flat[-1].clone()
+            else:
+                total = loss
+            opt.step()
+            return total
+        opt.zero_grad()
+        acts = torch.sigmoid(net.forward_soa(in_state, in_ref)).reshape(H, 4, -1)
+        loss = F.quad_rollout_loss(s0_soa, acts, ref_soa, args.dt, dyn.params,
+                                   layout="soa")
+        loss.backward()
         total = sync.sync(loss.detach())
         opt.step()
         return total

@@ -39,6 +39,24 @@ def _make_trainer():
             loss = tp.quad_mpc_loss(inter, ref_states, action_seq)
             return self._step(loss)
 
+        def train_concurrent_fused(self, in_state, current_state, in_ref_states,
+                                   ref_states):
+            """Emulates the fused-policy path: parameter gradients arrive as
+            contiguous views of one flat buffer with a trailing loss slot."""
+            acts = torch.sigmoid(self.net(in_state, in_ref_states)).reshape(-1, H, 4)
+            inter = tp.unroll(tp.QuadOracle(), current_state, acts, DT)
+            loss = tp.quad_mpc_loss(inter, ref_states, acts)
+            named = [(k, p) for k, p in self.net.named_parameters()]
+            grads = torch.autograd.grad(loss, [p for _, p in named], allow_unused=True)
+            used = [(k, g) for (k, _), g in zip(named, grads) if g is not None]
+            flat = torch.empty(sum(g.numel() for _, g in used) + 1)
+            views, off = {}, 0
+            for k, g in used:
+                views[k] = flat[off:off + g.numel()].view_as(g)
+                views[k].copy_(g)
+                off += g.numel()
+            return self._step_direct(loss.detach(), views, flat)
+
     cfg = dict(delta_t=DT, horizon=H, batch_size=B, ref_dim=9, action_dim=4,
                train_mode="concurrent", learning_rate_controller=1e-5,
                system="quad")
@@ -68,6 +86,13 @@ def _one_step(trainer, lo, hi):
         d.ref_states[lo:hi])
 
 
+def _one_step_direct(trainer, lo, hi):
+    d = trainer.state_data
+    return trainer.train_concurrent_fused(
+        d.normed_states[lo:hi], d.states[lo:hi], d.in_ref_states[lo:hi],
+        d.ref_states[lo:hi])
+
+
 def _worker(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, REPO)
@@ -83,6 +108,12 @@ def _worker(rank, world, port, out_dir):
         losses = [float(_one_step(trainer, lo, hi)) for _ in range(2)]
         sd = {k: v.numpy() for k, v in trainer.net.state_dict().items()}
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"),
+                 losses=np.array(losses), **sd)
+        # the fused-policy path: flat gradient buffer all-reduced in place
+        trainer = _make_trainer()
+        losses = [float(_one_step_direct(trainer, lo, hi)) for _ in range(2)]
+        sd = {k: v.numpy() for k, v in trainer.net.state_dict().items()}
+        np.savez(os.path.join(out_dir, f"direct_rank{rank}.npz"),
                  losses=np.array(losses), **sd)
     finally:
         dist.destroy_process_group()
@@ -102,6 +133,11 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
     a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in ref.net.state_dict():
         assert np.array_equal(a[k], b[k]), k    # replicas stay bit-identical
+    for r in range(world):                      # _step_direct, flat all-reduce
+        g = np.load(tmp_path / f"direct_rank{r}.npz")
+        np.testing.assert_allclose(g["losses"], ref_losses, rtol=1e-5)
+        for k, v in ref.net.state_dict().items():
+            assert rel_err(g[k], v.numpy()) < 1e-5, (r, k)
 
 
 def test_grad_allreducer_is_noop_single_process():
