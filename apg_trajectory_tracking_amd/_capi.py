@@ -142,6 +142,7 @@ SIGNATURES = {
         ctypes.POINTER(ApgLstmPolicy), _I, _I, _I, _F, _F, _I, _P, _P, _P, _P,
         _P, _P, _P],
     "apg_planes_gemm_grouped": [ctypes.POINTER(ApgGemmProblem), _I, _P, _I, _P],
+    "apg_to_soa": [_P, _I, _I, _I, _P, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
     "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I,
                         ctypes.c_longlong, _P, _I, _P, _I, _P, _P],

@@ -47,9 +47,44 @@ int launch_reduce_partials(const float *partials, int n, float *loss,
   return check_launch("reduce_partials");
 }
 
+// [B][R] row-major (the reference's batch-major tensors) -> [R][B] planes:
+// 64 x 64 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void to_soa_kernel(const float *__restrict__ src,
+                                                     int B, int R, int ld,
+                                                     float *__restrict__ dst) {
+  __shared__ float tile[64][65];
+  const int b0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  for (int i = y; i < 64; i += 4) {  // row b0 + i, columns r0 + x
+    const int b = b0 + i, r = r0 + x;
+    if (b < B && r < R) tile[i][x] = src[(size_t)b * ld + r];
+  }
+  __syncthreads();
+  for (int i = y; i < 64; i += 4) {  // plane r0 + i, trajectories b0 + x
+    const int r = r0 + i, b = b0 + x;
+    if (r < R && b < B) dst[(size_t)r * B + b] = tile[x][i];
+  }
+}
+
 }  // namespace apg
 
 extern "C" {
+
+int apg_to_soa(const float *src, int B, int R, int ld, float *dst,
+               apg_stream_t stream) {
+  if (B < 0 || R < 1 || ld < R) {
+    apg::set_error("apg_to_soa: need B >= 0, R >= 1, ld >= R");
+    return APG_ERR_ARG;
+  }
+  if (B == 0) return APG_OK;
+  if (!src || !dst) {
+    apg::set_error("apg_to_soa: NULL pointer");
+    return APG_ERR_ARG;
+  }
+  hipLaunchKernelGGL(apg::to_soa_kernel, dim3((B + 63) / 64, (R + 63) / 64),
+                     dim3(256), 0, (hipStream_t)stream, src, B, R, ld, dst);
+  return apg::check_launch("to_soa");
+}
 
 int apg_reduce_loss_partials(const float *partials, int n, float *loss,
                              apg_stream_t stream) {

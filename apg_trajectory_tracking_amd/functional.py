@@ -620,6 +620,28 @@ def _flat_grads(dev, shapes):
     return flat, views
 
 
+def to_soa(t, out=None):
+    """[B, ...] fp32 -> [..., B] planes (apg_to_soa: tiled transpose, both sides
+    coalesced).  A leading slice of longer rows (e.g. ref[:, :H]) is read in
+    place through its row stride.  `out`: optional contiguous destination."""
+    B = t.shape[0]
+    inner = torch.Size(t.shape[1:])
+    R = int(inner.numel())
+    t = _f32c(t)
+    dense_rows = all(t.stride(i + 1) == s_ for i, s_ in
+                     enumerate(torch.empty(inner, device="meta").stride()))
+    if not dense_rows or (B > 1 and t.stride(0) < R):
+        t = t.contiguous()
+    ld = t.stride(0) if B > 1 else R
+    if out is None:
+        out = torch.empty(*inner, B, dtype=torch.float32, device=t.device)
+    if not (t.is_cuda and out.is_cuda and out.is_contiguous()):
+        raise ValueError("to_soa: device tensors, contiguous destination "
+                         "(there is no CPU fallback)")
+    check(lib().apg_to_soa(ptr(t), B, R, ld, ptr(out), stream_of(t)), "apg_to_soa")
+    return out
+
+
 def _ref_and_states(in_ref, state0, B, H):
     """One buffer for everything the conv-weight product reads as B operand:
     planes [0, 2H*9) = the reference tensor [2H][9][B], planes [2H*9, +(H+1)*12)
@@ -628,9 +650,9 @@ def _ref_and_states(in_ref, state0, B, H):
     buf = torch.empty(2 * H * 9 + (H + 1) * 12, B, dtype=torch.float32,
                       device=state0.device)
     inr = buf[:2 * H * 9].view(2 * H, 9, B)
-    inr.copy_(in_ref[:, :2 * H].permute(1, 2, 0))
+    to_soa(in_ref[:, :2 * H], out=inr)
     st_all = buf[2 * H * 9:].view(H + 1, 12, B)
-    st_all[0].copy_(state0.t())
+    to_soa(state0, out=st_all[0])
     return buf, inr, st_all[0], st_all[1:]
 
 
@@ -678,8 +700,8 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             raise ValueError("fused path needs LSTM_NEW(15, 10, 9, 4, conv=1)")
         dev = state0.device
         refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H)
-        rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
-        h0s, c0s = _f32c(h0).t().contiguous(), _f32c(c0).t().contiguous()
+        rf = to_soa(ref[:, :H])
+        h0s, c0s = to_soa(h0), to_soa(c0)
         pw = dict(
             conv_w=_f32c(conv_w), conv_b=_f32c(conv_b), w_ih=_f32c(w_ih),
             w_hh=_f32c(w_hh), b_ih=_f32c(b_ih), b_hh=_f32c(b_hh),
@@ -742,20 +764,23 @@ def _lstm_param_grads(saved, dims):
     B, H = dims
     dev = acts.device
     flat, gr = _flat_grads(dev, {
-        "ih_hh": (32, 183), "lstm.bias_ih": (32,), "fc_out.weight": (4, 8),
-        "fc_out.bias": (4,), "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,)})
-    # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T (two column chunks), db = row
-    # sums; dW_out = d_zout . h_new^T; conv - all in one launch pair
+        "lstm.weight_ih": (32, 175), "lstm.weight_hh": (32, 8),
+        "lstm.bias_ih": (32,), "fc_out.weight": (4, 8), "fc_out.bias": (4,),
+        "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,)})
+    ih_hh = torch.empty(32, 183, dtype=torch.float32, device=dev)
+    # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T, db = row sums;
+    # dW_out = d_zout . h_new^T; conv
     conv, finish = _conv_weight_problem(d_conv, refbuf, B, H, gr["conv_ref.bias"])
     _run_products([
         dict(A=d_gates, M=32, S=1, Bp=acts, bdesc=make_bdesc(dev, range(183), key="ih_hh"),
-             out=gr["ih_hh"], bias_out=gr["lstm.bias_ih"]),
+             out=ih_hh, bias_out=gr["lstm.bias_ih"]),
         dict(A=d_zout, M=4, S=1, Bp=acts, bdesc=make_bdesc(dev, range(191, 199), key="out"),
              out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"]),
         conv])
     finish(gr["conv_ref.weight"])
-    ih_hh = gr.pop("ih_hh")
-    gr["lstm.weight_ih"], gr["lstm.weight_hh"] = ih_hh[:, :175], ih_hh[:, 175:]
+    # contiguous per-parameter gradients (the fused optimizer path wants them)
+    gr["lstm.weight_ih"].copy_(ih_hh[:, :175])
+    gr["lstm.weight_hh"].copy_(ih_hh[:, 175:])
     gr["lstm.bias_hh"] = gr["lstm.bias_ih"]
     return flat, gr
 
@@ -795,7 +820,7 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
                              "(B <= 400 000); split it")
         dev = state0.device
         refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H)
-        rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
+        rf = to_soa(ref[:, :H])
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -956,7 +981,7 @@ def quad_lstm_closed_loop(net, traj, dt, params, h0, c0, max_steps=251,
     H = 10
     dev = traj.device
     tr = _f32c(traj).permute(1, 2, 0).contiguous()
-    h0s, c0s = _f32c(h0).t().contiguous(), _f32c(c0).t().contiguous()
+    h0s, c0s = to_soa(h0), to_soa(c0)
     pw = dict(conv_w=net.conv_ref.weight, conv_b=net.conv_ref.bias,
               w_ih=net.lstm.weight_ih, w_hh=net.lstm.weight_hh,
               b_ih=net.lstm.bias_ih, b_hh=net.lstm.bias_hh,
@@ -1010,10 +1035,10 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         # feat (15) | x1 (224) | h1, h2, h3 (192) | in_ref rows (H*9)
         acts = new(431 + H * 9, B)
         feat, x1, h, inr = acts[:15], acts[15:239], acts[239:431], acts[431:]
-        feat.copy_(_f32c(normed).t())
-        inr.view(H, 9, B).copy_(_f32c(in_ref)[:, :H].permute(1, 2, 0))
-        s0 = _f32c(state0).t().contiguous()
-        rf = _f32c(ref[:, :H]).permute(1, 2, 0).contiguous()
+        to_soa(normed, out=feat)
+        to_soa(in_ref[:, :H], out=inr.view(H, 9, B))
+        s0 = to_soa(state0)
+        rf = to_soa(ref[:, :H])
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (

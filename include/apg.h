@@ -457,6 +457,12 @@ int apg_cartpole_rollout_fwd_bwd(const float *state0, const float *actions,
 /* loss[0] = fixed-order sum of partials[0..n) (one small kernel). */
 int apg_reduce_loss_partials(const float *partials, int n, float *loss,
                              apg_stream_t stream);
+/* Layout change at the boundary: src [B][R] row-major with row stride ld >= R
+ * (the reference's batch-major tensors, trailing dims flattened into R; ld > R
+ * reads the leading part of longer rows) -> dst [R][B], the plane layout every
+ * APG_LAYOUT_SOA entry point reads. */
+int apg_to_soa(const float *src, int B, int R, int ld, float *dst,
+               apg_stream_t stream);
 /* Number of floats `loss_partials` must hold for a batch of B. */
 int apg_loss_partials_count(int B);
 /* APG_VERSION_MAJOR * 1000 + APG_VERSION_MINOR. */

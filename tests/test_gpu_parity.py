@@ -689,3 +689,19 @@ def test_planes_gemm_grouped_vs_torch(dev):
         r3 += A3d[:, s_] @ rows.t()
     assert rel_err(o3.cpu().numpy(), r3.numpy()) < 1e-5
     assert rel_err(b3.cpu().numpy(), A3d.sum((1, 2)).numpy()) < 1e-5
+
+
+def test_to_soa_matches_permute(dev):
+    """apg_to_soa: tiled transpose at the boundary, incl. ragged sizes and a
+    leading slice of longer rows read in place."""
+    from apg_trajectory_tracking_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    for shape in ((1, 12), (77, 15), (300, 20, 9), (4097, 10, 9)):
+        t = torch.randn(*shape, generator=g).to(dev)
+        want = t.permute(*range(1, t.dim()), 0).contiguous()
+        assert torch.equal(F.to_soa(t), want)
+    t = torch.randn(130, 20, 9, generator=g).to(dev)
+    assert torch.equal(F.to_soa(t[:, :10]), t[:, :10].permute(1, 2, 0).contiguous())
+    out = torch.zeros(4, 9, 130, device=dev)
+    F.to_soa(t[:, 3:7], out=out)           # not a leading slice: copied first
+    assert torch.equal(out, t[:, 3:7].permute(1, 2, 0).contiguous())
