@@ -74,6 +74,12 @@ class ApgMlpPolicy(ctypes.Structure):
         "w_3", "b_3", "w_out", "b_out")]
 
 
+class ApgWingPolicy(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "w_s", "b_s", "w_r", "b_r", "w_1", "b_1", "w_2", "b_2", "w_3", "b_3",
+        "w_out", "b_out")]
+
+
 class ApgGemmProblem(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p),
                 ("bdesc", ctypes.c_void_p), ("C", ctypes.c_void_p),
@@ -143,6 +149,11 @@ SIGNATURES = {
         _P, _P, _P],
     "apg_planes_gemm_grouped": [ctypes.POINTER(ApgGemmProblem), _I, _P, _I, _P],
     "apg_to_soa": [_P, _I, _I, _I, _P, _P],
+    "apg_wing_policy_workspace_floats": [],
+    "apg_wing_policy_fwd": [_P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P, _P, _P,
+                            _P, _P],
+    "apg_wing_policy_bwd": [_P, _P, _P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P,
+                            _P, _P, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
     "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I,
                         ctypes.c_longlong, _P, _I, _P, _I, _P, _P],

@@ -1163,3 +1163,79 @@ def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
             params, weights or quad_loss_weights())
         flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
     return loss, gr, flat
+
+
+# ------------------------------ fixed wing: concurrent step, policy in-kernel
+_WING_PARAMS = ("states_in.weight", "states_in.bias", "ref_in.weight", "ref_in.bias",
+                "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight",
+                "fc3.bias", "fc_out.weight", "fc_out.bias")
+
+
+def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
+                                 weights=None):
+    """The fixed-wing concurrent training step without the autograd tape:
+    loss = fixed_wing_mpc_loss(unroll(dyn, state0, sigmoid(net(normed,
+    in_ref))), ref) for `Net(9, 1, 3, 80, conv=False)` with the policy on the
+    matrix cores (apg_wing_policy_fwd / _bwd) around the fused rollout
+    (apg_wing_rollout_fwd_bwd).  normed [B,9], in_ref [B,3], state0 [B,12],
+    ref [B,20,3].  Returns (loss, {parameter name: gradient}, flat) like
+    quad_concurrent_policy_grads."""
+    B, H = state0.shape[0], 20
+    pw = dict(zip(("w_s", "b_s", "w_r", "b_r", "w_1", "b_1", "w_2", "b_2", "w_3",
+                   "b_3", "w_out", "b_out"),
+                  (_f32c(v).contiguous() for v in _net_params(net, _WING_PARAMS))))
+    if (pw["w_s"].shape != (64, 9) or pw["w_r"].shape != (64, 3)
+            or pw["w_1"].shape != (64, 128) or pw["w_out"].shape != (80, 64)
+            or normed.shape[1] != 9 or in_ref.reshape(B, -1).shape[1] != 3
+            or ref.shape[1:] != (H, 3)):
+        raise ValueError("fused path needs Net(9, 1, 3, 80, conv=False), H = 20")
+    dev = state0.device
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        # B operands of the weight products: feat 0..8 | ref 9..11 | x1 12..139 |
+        # h1 140.. | h2 204.. | h3 268..
+        acts = new(332, B)
+        feat, rin, x1, h = acts[:9], acts[9:12], acts[12:140], acts[140:]
+        to_soa(normed, out=feat)
+        to_soa(in_ref.reshape(B, 3), out=rin)
+        require_device(acts, *pw.values())
+        pol = _capi.ApgWingPolicy(**{k: ptr(v) for k, v in pw.items()})
+        actions = new(H, 4, B)
+        ws = new(lib().apg_wing_policy_workspace_floats())
+        st = stream_of(acts)
+        check(lib().apg_wing_policy_fwd(ptr(feat), ptr(rin), ctypes.byref(pol), B,
+                                        ptr(actions), ptr(x1), ptr(h), ptr(ws), st),
+              "apg_wing_policy_fwd")
+        res = wing_rollout_fwd_bwd(to_soa(state0), actions, to_soa(ref), dt, params,
+                                   weights, layout="soa", want_grad_state0=False)
+        cot = new(80 + 320, B)
+        d_zout, d_pre = cot[:80], cot[80:]
+        check(lib().apg_wing_policy_bwd(
+            ptr(actions), ptr(res["grad_actions"]), ptr(x1), ptr(h),
+            ctypes.byref(pol), B, ptr(d_zout), ptr(d_pre), ptr(ws), st),
+            "apg_wing_policy_bwd")
+        flat, gr = _flat_grads(dev, {
+            "states_in.weight": (64, 9), "states_in.bias": (64,),
+            "ref_in.weight": (64, 3), "ref_in.bias": (64,),
+            "fc1.weight": (64, 128), "fc1.bias": (64,), "fc2.weight": (64, 64),
+            "fc2.bias": (64,), "fc3.weight": (64, 64), "fc3.bias": (64,),
+            "fc_out.weight": (80, 64), "fc_out.bias": (80,)})
+        R = lambda lo, hi_: make_bdesc(dev, range(lo, hi_), key=("wing", lo, hi_))
+        _run_products([
+            dict(A=d_zout[:64], M=64, S=1, Bp=acts, bdesc=R(268, 332),
+                 out=gr["fc_out.weight"][:64], bias_out=gr["fc_out.bias"][:64]),
+            dict(A=d_zout[64:], M=16, S=1, Bp=acts, bdesc=R(268, 332),
+                 out=gr["fc_out.weight"][64:], bias_out=gr["fc_out.bias"][64:]),
+            dict(A=d_pre[128:192], M=64, S=1, Bp=acts, bdesc=R(204, 268),
+                 out=gr["fc3.weight"], bias_out=gr["fc3.bias"]),
+            dict(A=d_pre[64:128], M=64, S=1, Bp=acts, bdesc=R(140, 204),
+                 out=gr["fc2.weight"], bias_out=gr["fc2.bias"]),
+            dict(A=d_pre[0:64], M=64, S=1, Bp=acts, bdesc=R(12, 76), with_ones=False,
+                 out=gr["fc1.weight"]),
+            dict(A=d_pre[0:64], M=64, S=1, Bp=acts, bdesc=R(76, 140),
+                 out=gr["fc1.weight"][:, 64:], bias_out=gr["fc1.bias"]),
+            dict(A=d_pre[192:256], M=64, S=1, Bp=acts, bdesc=R(0, 9),
+                 out=gr["states_in.weight"], bias_out=gr["states_in.bias"]),
+            dict(A=d_pre[256:320], M=64, S=1, Bp=acts, bdesc=R(9, 12),
+                 out=gr["ref_in.weight"], bias_out=gr["ref_in.bias"])])
+    return res["loss"].reshape(()), gr, flat

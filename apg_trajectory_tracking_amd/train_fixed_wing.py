@@ -44,6 +44,26 @@ class TrainFixedWing(TrainBase):
         self.config["dt"] = self.delta_t
         self.init_optimizer()
 
+    fused_policy = True   # policy on the matrix cores around the fused rollout
+
+    def train_concurrent_fused(
+        self, in_state, current_state, in_ref_states, ref_states
+    ):
+        """scripts/train_base.py:198-204 + scripts/train_fixed_wing.py:90-116
+        with the policy inside HIP kernels (functional.wing_concurrent_policy_grads)."""
+        n = self.net
+        if not (self.fused_policy and isinstance(n, Net) and not n.conv
+                and self.horizon == 20 and hasattr(self.train_dynamics, "params")
+                and n.states_in.weight.shape == (64, 9)
+                and n.ref_in.weight.shape == (64, 3)
+                and n.fc1.weight.shape == (64, 128)
+                and n.fc_out.weight.shape == (80, 64)):
+            return None
+        loss, grads, flat = F.wing_concurrent_policy_grads(
+            n, in_state, in_ref_states, current_state, ref_states,
+            self.delta_t_train, self.train_dynamics.params)
+        return self._step_direct(loss, grads, flat)
+
     def train_controller_model(
         self, current_state, action_seq, in_ref_state, ref_states
     ):

@@ -390,6 +390,43 @@ typedef struct ApgWingParams {
   float epsilon;
 } ApgWingParams;
 
+/* The fixed-wing controller hutter_model.Net(9, 1, 3, 80, conv=False)
+ * (neural_control/models/hutter_model.py:6-49; scripts/train_fixed_wing.py:
+ * 68-76): device pointers to the plain row-major torch parameters. */
+typedef struct ApgWingPolicy {
+  const float *w_s;    /* [64][9]   states_in.weight */
+  const float *b_s;    /* [64] */
+  const float *w_r;    /* [64][3]   ref_in.weight */
+  const float *b_r;    /* [64] */
+  const float *w_1;    /* [64][128] fc1.weight (inputs: state branch, ref branch) */
+  const float *b_1;    /* [64] */
+  const float *w_2;    /* [64][64]  fc2.weight */
+  const float *b_2;    /* [64] */
+  const float *w_3;    /* [64][64]  fc3.weight */
+  const float *b_3;    /* [64] */
+  const float *w_out;  /* [80][64]  fc_out.weight */
+  const float *b_out;  /* [80] */
+} ApgWingPolicy;
+
+/* Policy part of the fixed-wing concurrent step on the matrix cores
+ * (scripts/train_base.py:198-204: actions = sigmoid(net(in_state,
+ * in_ref_state))).  Forward: feat [9][B] (normed_states), ref_in [3][B] ->
+ * actions [80][B] = [H = 20][4][B], the SoA action sequence of
+ * apg_wing_rollout_fwd_bwd; saved x1 [128][B], h [192][B] (h1, h2, h3).
+ * Reverse: from grad_actions [80][B] (that kernel's dL/dactions) -> d_zout
+ * [80][B] and d_pre [320][B] (fc1, fc2, fc3 pre-activation cotangents, 64
+ * planes each, then the first layer's 128); weight gradients by
+ * apg_planes_gemm(_grouped).  workspace: apg_wing_policy_workspace_floats(). */
+int apg_wing_policy_workspace_floats(void);
+int apg_wing_policy_fwd(const float *feat, const float *ref_in,
+                        const ApgWingPolicy *policy, int B, float *actions,
+                        float *x1, float *h, float *workspace,
+                        apg_stream_t stream);
+int apg_wing_policy_bwd(const float *actions, const float *grad_actions,
+                        const float *x1, const float *h,
+                        const ApgWingPolicy *policy, int B, float *d_zout,
+                        float *d_pre, float *workspace, apg_stream_t stream);
+
 /* Weights of fixed_wing_mpc_loss, neural_control/drone_loss.py:72-82
  * (reference values: pos 10, action 0.1). */
 typedef struct ApgWingLossWeights {
