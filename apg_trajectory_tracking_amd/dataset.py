@@ -40,7 +40,13 @@ class TensorBatches:
         n = self.tensors[0].shape[0]
         dev = self.tensors[0].device
         if self.shuffle:
-            perm = torch.randperm(n, generator=self.generator).to(dev)
+            # drawn on the device unless a (CPU) generator pins the order: a
+            # host permutation of 5e5 indices + its upload costs more than a
+            # whole fused training step
+            if self.generator is None:
+                perm = torch.randperm(n, device=dev)
+            else:
+                perm = torch.randperm(n, generator=self.generator).to(dev)
         for lo in range(0, n, self.batch_size):
             if self.shuffle:
                 idx = perm[lo:lo + self.batch_size]

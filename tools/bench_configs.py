@@ -162,6 +162,25 @@ def main():
                                      d.ref_states)
         emit("quad_train_step_fused_policy", B, H, timed(step_fused, 30, 5))
 
+    if want("quad_run_epoch"):
+        # the real epoch loop (whole-tensor shuffled batches + fused step)
+        from apg_trajectory_tracking_amd.train_drone import TrainDrone
+        nb = 8
+        cfg = dict(delta_t=dt, delta_t_train=dt, epoch_size=nb * B, self_play=0,
+                   batch_size=B, state_size=12, horizon=H, train_mode="concurrent",
+                   ref_dim=9, action_dim=4, learning_rate_controller=1e-9,
+                   system="quad", modified_params={})
+        te = TrainDrone(qdyn, qdyn, cfg)
+        te.initialize_model(device=dev, seed=0)
+        te.run_epoch("controller", 0)
+        torch.cuda.synchronize()
+        import time as _t
+        t0 = _t.perf_counter()
+        for e in range(3):
+            te.run_epoch("controller", e + 1)
+        torch.cuda.synchronize()
+        emit("quad_run_epoch_per_batch", B, H, (_t.perf_counter() - t0) / (3 * nb) * 1e3)
+
     for mode, name, fused in (("autoregressive", "quad_ar_unfused", False),
                               ("autoregressive", "quad_ar_fused", True),
                               ("LSTM", "quad_lstm_unfused", False),
