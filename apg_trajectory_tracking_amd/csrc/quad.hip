@@ -96,7 +96,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
 
   // deferred loss of an earlier launch (ApgDeferredLoss): request its
   // partials before this wave's own inputs, sum them at the very end
-  const bool reducer = blockIdx.x == 0 && A.prev.prev_partials != nullptr;
+  const bool reducer = blockIdx.x == 0 && threadIdx.x < kWave &&
+                       A.prev.prev_partials != nullptr;
   PrevPartials pp;
   if (reducer) reduce_prev_head(A.prev, pp);
   __builtin_amdgcn_sched_barrier(0);
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_aos_kernel(
   const bool live = b < A.B;
   const QuadConst c = A.c;
 
-  const bool reducer = blockIdx.x == 0 && A.prev.prev_partials != nullptr;
+  const bool reducer = blockIdx.x == 0 && threadIdx.x < kWave &&
+                       A.prev.prev_partials != nullptr;
   PrevPartials pp;
   if (reducer) reduce_prev_head(A.prev, pp);
 

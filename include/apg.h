@@ -48,7 +48,9 @@ enum {
 
 /* Threads per workgroup of the fused rollout kernels; one loss partial is
  * produced per workgroup.  apg_loss_partials_count(B) = ceil(B / 64). */
+#ifndef APG_ROLLOUT_BLOCK
 #define APG_ROLLOUT_BLOCK 64
+#endif
 /* Largest horizon the fused rollout kernels accept. */
 #define APG_MAX_HORIZON 48
 
