@@ -1136,9 +1136,29 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
     return loss, gr, flat
 
 
+_MAX_FUSED_AR_BATCH = 98304   # saved planes stay below planes_gemm's 2 GiB per operand
+
+
 def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None):
     """quad_mlp_rollout_loss (autoregressive unroll) + parameter gradients,
-    without autograd; see quad_concurrent_policy_grads."""
+    without autograd; see quad_concurrent_policy_grads.  Batches beyond
+    98 304 trajectories are processed in chunks (losses and gradients are sums
+    over trajectories, so the chunks simply add up)."""
+    B = state0.shape[0]
+    if B > _MAX_FUSED_AR_BATCH:
+        n = -(-B // _MAX_FUSED_AR_BATCH)
+        step = -(-B // n)
+        loss, gr, flat = None, None, None
+        for lo in range(0, B, step):
+            sl = slice(lo, lo + step)
+            l, g, f = quad_mlp_rollout_grads(net, state0[sl], in_ref[sl], ref[sl], dt,
+                                             params, weights)
+            if flat is None:
+                loss, gr, flat = l, g, f
+            else:
+                flat += f
+                loss = loss + l
+        return loss, gr, flat
     ctx = _DirectCtx()
     with torch.no_grad():
         loss, _, _ = _QuadMlpRolloutLoss.forward(

@@ -749,3 +749,26 @@ def test_wing_concurrent_fused_policy_matches_unfused(dev, B):
         assert rel_err(g1[k], g0[k]) < 2e-4, k
     for k in w0:
         assert rel_err(w1[k], w0[k]) < 1e-5, k
+
+
+def test_fused_ar_large_batch_is_chunked(dev, monkeypatch):
+    """Beyond the per-launch batch limit of the fused autoregressive path the
+    direct-gradient function processes chunks and adds them up."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    B = 1000
+    d = synthetic.quad_polynomial_batch(B, 10, 0.1, seed=8, ref_length=20)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    torch.manual_seed(2)
+    net = Net(15, 10, 9, 4, conv=1).to(dev)
+    dyn = FlightmareDynamics()
+    l0, g0, _ = F.quad_mlp_rollout_grads(net, s0, in_ref, ref, 0.1, dyn.params)
+    g0 = {k: v.clone() for k, v in g0.items()}
+    monkeypatch.setattr(F, "_MAX_FUSED_AR_BATCH", 384)     # 3 ragged chunks
+    l1, g1, flat = F.quad_mlp_rollout_grads(net, s0, in_ref, ref, 0.1, dyn.params)
+    assert abs(l0.item() - l1.item()) / l0.item() < 1e-5
+    for k in g0:
+        assert g1[k].data_ptr() >= flat.data_ptr()          # still views of `flat`
+        assert rel_err(N(g1[k]), N(g0[k])) < 1e-4, k
