@@ -148,7 +148,7 @@ SIGNATURES = {
         ctypes.POINTER(ApgLstmPolicy), _I, _I, _I, _F, _F, _I, _P, _P, _P, _P,
         _P, _P, _P],
     "apg_planes_gemm_grouped": [ctypes.POINTER(ApgGemmProblem), _I, _P, _I, _P],
-    "apg_to_soa": [_P, _I, _I, _I, _P, _P],
+    "apg_to_soa": [_P, _P, _I, _I, _I, _P, _P],
     "apg_wing_policy_workspace_floats": [],
     "apg_wing_policy_fwd": [_P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P, _P, _P,
                             _P, _P],

@@ -49,7 +49,10 @@ int launch_reduce_partials(const float *partials, int n, float *loss,
 
 // [B][R] row-major (the reference's batch-major tensors) -> [R][B] planes:
 // 64 x 64 tiles through LDS, both sides coalesced.
+// With `index` the rows are gathered: dst[r][b] = src[index[b]][r] - the
+// minibatch selection of the training loop folded into the layout change.
 __global__ __launch_bounds__(256) void to_soa_kernel(const float *__restrict__ src,
+                                                     const long long *__restrict__ index,
                                                      int B, int R, int ld,
                                                      float *__restrict__ dst) {
   __shared__ float tile[64][65];
@@ -57,7 +60,10 @@ __global__ __launch_bounds__(256) void to_soa_kernel(const float *__restrict__ s
   const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
   for (int i = y; i < 64; i += 4) {  // row b0 + i, columns r0 + x
     const int b = b0 + i, r = r0 + x;
-    if (b < B && r < R) tile[i][x] = src[(size_t)b * ld + r];
+    if (b < B && r < R) {
+      const size_t row = index ? (size_t)index[b] : (size_t)b;
+      tile[i][x] = src[row * ld + r];
+    }
   }
   __syncthreads();
   for (int i = y; i < 64; i += 4) {  // plane r0 + i, trajectories b0 + x
@@ -70,8 +76,8 @@ __global__ __launch_bounds__(256) void to_soa_kernel(const float *__restrict__ s
 
 extern "C" {
 
-int apg_to_soa(const float *src, int B, int R, int ld, float *dst,
-               apg_stream_t stream) {
+int apg_to_soa(const float *src, const long long *index, int B, int R, int ld,
+               float *dst, apg_stream_t stream) {
   if (B < 0 || R < 1 || ld < R) {
     apg::set_error("apg_to_soa: need B >= 0, R >= 1, ld >= R");
     return APG_ERR_ARG;
@@ -82,7 +88,7 @@ int apg_to_soa(const float *src, int B, int R, int ld, float *dst,
     return APG_ERR_ARG;
   }
   hipLaunchKernelGGL(apg::to_soa_kernel, dim3((B + 63) / 64, (R + 63) / 64),
-                     dim3(256), 0, (hipStream_t)stream, src, B, R, ld, dst);
+                     dim3(256), 0, (hipStream_t)stream, src, index, B, R, ld, dst);
   return apg::check_launch("to_soa");
 }
 

@@ -36,17 +36,29 @@ class TensorBatches:
         n = self.tensors[0].shape[0]
         return (n + self.batch_size - 1) // self.batch_size
 
+    def iter_indices(self):
+        """The same batches as __iter__, as index tensors (int64, on the data's
+        device) into `self.tensors`: lets a consumer fold the row gather into
+        its own first pass over the data (functional.to_soa(index=...))."""
+        n = self.tensors[0].shape[0]
+        dev = self.tensors[0].device
+        order = self._permutation(n, dev) if self.shuffle else torch.arange(n, device=dev)
+        for lo in range(0, n, self.batch_size):
+            yield order[lo:lo + self.batch_size]
+
+    def _permutation(self, n, dev):
+        # drawn on the device unless a (CPU) generator pins the order: a host
+        # permutation of 5e5 indices + its upload costs more than a whole
+        # fused training step
+        if self.generator is None:
+            return torch.randperm(n, device=dev)
+        return torch.randperm(n, generator=self.generator).to(dev)
+
     def __iter__(self):
         n = self.tensors[0].shape[0]
         dev = self.tensors[0].device
         if self.shuffle:
-            # drawn on the device unless a (CPU) generator pins the order: a
-            # host permutation of 5e5 indices + its upload costs more than a
-            # whole fused training step
-            if self.generator is None:
-                perm = torch.randperm(n, device=dev)
-            else:
-                perm = torch.randperm(n, generator=self.generator).to(dev)
+            perm = self._permutation(n, dev)
         for lo in range(0, n, self.batch_size):
             if self.shuffle:
                 idx = perm[lo:lo + self.batch_size]

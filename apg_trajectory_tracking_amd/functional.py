@@ -620,25 +620,31 @@ def _flat_grads(dev, shapes):
     return flat, views
 
 
-def to_soa(t, out=None):
+def to_soa(t, out=None, index=None):
     """[B, ...] fp32 -> [..., B] planes (apg_to_soa: tiled transpose, both sides
     coalesced).  A leading slice of longer rows (e.g. ref[:, :H]) is read in
-    place through its row stride.  `out`: optional contiguous destination."""
-    B = t.shape[0]
+    place through its row stride.  `index` (int64 device tensor [B]): gather
+    rows t[index] in the same pass (t is then the whole data set).
+    `out`: optional contiguous destination."""
     inner = torch.Size(t.shape[1:])
     R = int(inner.numel())
     t = _f32c(t)
     dense_rows = all(t.stride(i + 1) == s_ for i, s_ in
                      enumerate(torch.empty(inner, device="meta").stride()))
-    if not dense_rows or (B > 1 and t.stride(0) < R):
+    if not dense_rows or (t.shape[0] > 1 and t.stride(0) < R):
         t = t.contiguous()
-    ld = t.stride(0) if B > 1 else R
+    ld = t.stride(0) if t.shape[0] > 1 else R
+    B = t.shape[0] if index is None else index.numel()
+    if index is not None and (index.dtype != torch.int64 or not index.is_cuda
+                              or not index.is_contiguous()):
+        raise ValueError("to_soa: index must be a contiguous int64 device tensor")
     if out is None:
         out = torch.empty(*inner, B, dtype=torch.float32, device=t.device)
     if not (t.is_cuda and out.is_cuda and out.is_contiguous()):
         raise ValueError("to_soa: device tensors, contiguous destination "
                          "(there is no CPU fallback)")
-    check(lib().apg_to_soa(ptr(t), B, R, ld, ptr(out), stream_of(t)), "apg_to_soa")
+    check(lib().apg_to_soa(ptr(t), None if index is None else index.data_ptr(), B, R,
+                           ld, ptr(out), stream_of(t)), "apg_to_soa")
     return out
 
 
@@ -1021,8 +1027,9 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, normed, state0, in_ref, ref, w_s, b_s, conv_w, conv_b, w_1,
-                b_1, w_2, b_2, w_3, b_3, w_out, b_out, dt, params, weights):
-        B, H = state0.shape[0], 10
+                b_1, w_2, b_2, w_3, b_3, w_out, b_out, dt, params, weights,
+                index=None):
+        B, H = (state0.shape[0] if index is None else index.numel()), 10
         if in_ref.shape[1] < H or in_ref.shape[2] != 9 or ref.shape[1] < H \
                 or normed.shape[1] != 15:
             raise ValueError("normed [B,15], in_ref [B,>=H,9], ref [B,>=H,9|6], H = 10")
@@ -1035,10 +1042,10 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         # feat (15) | x1 (224) | h1, h2, h3 (192) | in_ref rows (H*9)
         acts = new(431 + H * 9, B)
         feat, x1, h, inr = acts[:15], acts[15:239], acts[239:431], acts[431:]
-        to_soa(normed, out=feat)
-        to_soa(in_ref[:, :H], out=inr.view(H, 9, B))
-        s0 = to_soa(state0)
-        rf = to_soa(ref[:, :H])
+        to_soa(normed, out=feat, index=index)
+        to_soa(in_ref[:, :H], out=inr.view(H, 9, B), index=index)
+        s0 = to_soa(state0, index=index)
+        rf = to_soa(ref[:, :H], index=index)
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -1121,17 +1128,19 @@ def _net_params(net, names):
 
 
 def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
-                                 weights=None):
+                                 weights=None, index=None):
     """quad_concurrent_policy_loss + its parameter gradients, without autograd:
     returns (loss, {parameter name: gradient}, flat); the gradients are
     contiguous views of the flat buffer (no per-parameter clone as
     `loss.backward()` does), whose last element is a free slot for the loss -
-    so the buffer itself is the all-reduce message."""
+    so the buffer itself is the all-reduce message.  `index` (int64 device
+    tensor): the four tensors are the whole data set and the minibatch
+    rows are gathered while they are brought into the plane layout."""
     ctx = _DirectCtx()
     with torch.no_grad():
         loss = _QuadConcurrentPolicyLoss.forward(
             ctx, normed, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt,
-            params, weights or quad_loss_weights())
+            params, weights or quad_loss_weights(), index)
         flat, gr = _conc_param_grads(ctx.saved_tensors, ctx.dims)
     return loss, gr, flat
 

@@ -187,11 +187,15 @@ class TrainBase:
         raise NotImplementedError("only the quadrotor trainer is recurrent")
 
     def train_concurrent_fused(
-        self, in_state, current_state, in_ref_states, ref_states
+        self, in_state, current_state, in_ref_states, ref_states, index=None,
+        probe=False
     ):
         """Optional: the whole concurrent step (policy forward, rollout, loss,
-        backward, optimizer) in fused kernels; None = not available."""
-        return None
+        backward, optimizer) in fused kernels; None = not available.
+        `index`: the four tensors are the whole data set, the batch is
+        rows `index`.  `probe=True` only asks whether the indexed form is
+        available (returns a bool, runs nothing)."""
+        return False if probe else None
 
     def train_dynamics_model(self, current_state, action_seq):
         """scripts/train_base.py:160-186: one SGD step fitting the learnable
@@ -227,6 +231,16 @@ class TrainBase:
             raise ValueError("train must be 'controller' or 'dynamics'")
         running_loss = None
         i = -1
+        if (train == "controller" and self.train_mode == "concurrent"
+                and hasattr(self.trainloader, "iter_indices")
+                and self.train_concurrent_fused(None, None, None, None,
+                                                probe=True)):
+            # fused step with the minibatch gather folded into its first pass
+            tensors = self.trainloader.tensors
+            for i, index in enumerate(self.trainloader.iter_indices(), 0):
+                loss = self.train_concurrent_fused(*tensors, index=index).detach()
+                running_loss = loss if running_loss is None else running_loss + loss
+            return self._finish_epoch(running_loss, i, train)
         for i, data in enumerate(self.trainloader, 0):
             in_state, current_state, in_ref_state, ref_states = data
             if train == "dynamics":
@@ -255,6 +269,9 @@ class TrainBase:
                 )
             loss = loss.detach()
             running_loss = loss if running_loss is None else running_loss + loss
+        return self._finish_epoch(running_loss, i, train)
+
+    def _finish_epoch(self, running_loss, i, train):
         # one host read-back per epoch; divides by the last index as the
         # reference does (ZeroDivisionError with a single batch, as there)
         epoch_loss = float(running_loss.item()) / i

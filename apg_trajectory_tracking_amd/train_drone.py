@@ -108,21 +108,25 @@ class TrainDrone(TrainBase):
                 and n.fc_out.weight.shape == (4, 8))
 
     def train_concurrent_fused(
-        self, in_state, current_state, in_ref_states, ref_states
+        self, in_state, current_state, in_ref_states, ref_states, index=None,
+        probe=False
     ):
         """scripts/train_base.py:198-204 + scripts/train_drone.py:175-203 with
         the policy inside the kernels (apg_quad_mlp_concurrent_fwd_bwd)."""
         n = self.net
-        if not (self.fused_policy and isinstance(n, Net) and n.conv
+        ok = (self.fused_policy and isinstance(n, Net) and n.conv
                 and self.horizon == 10 and hasattr(self.train_dynamics, "params")
                 and n.states_in.weight.shape == (64, 15)
                 and n.conv_ref.weight.shape == (20, 9, 3)
                 and n.fc1.weight.shape == (64, 224)
-                and n.fc_out.weight.shape == (40, 64)):
+                and n.fc_out.weight.shape == (40, 64))
+        if probe:
+            return ok
+        if not ok:
             return None
         loss, grads, flat = F.quad_concurrent_policy_grads(
             n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
-            self.train_dynamics.params)
+            self.train_dynamics.params, index=index)
         return self._step_direct(loss, grads, flat)
 
     def _fusable_mlp(self):

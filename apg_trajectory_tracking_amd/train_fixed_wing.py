@@ -47,7 +47,8 @@ class TrainFixedWing(TrainBase):
     fused_policy = True   # policy on the matrix cores around the fused rollout
 
     def train_concurrent_fused(
-        self, in_state, current_state, in_ref_states, ref_states
+        self, in_state, current_state, in_ref_states, ref_states, index=None,
+        probe=False
     ):
         """scripts/train_base.py:198-204 + scripts/train_fixed_wing.py:90-116
         with the policy inside HIP kernels (functional.wing_concurrent_policy_grads)."""
@@ -58,7 +59,9 @@ class TrainFixedWing(TrainBase):
                 and n.ref_in.weight.shape == (64, 3)
                 and n.fc1.weight.shape == (64, 128)
                 and n.fc_out.weight.shape == (80, 64)):
-            return None
+            return False if probe else None
+        if probe:
+            return False      # no indexed form yet: batches come from the loader
         loss, grads, flat = F.wing_concurrent_policy_grads(
             n, in_state, in_ref_states, current_state, ref_states,
             self.delta_t_train, self.train_dynamics.params)

@@ -499,9 +499,11 @@ int apg_reduce_loss_partials(const float *partials, int n, float *loss,
 /* Layout change at the boundary: src [B][R] row-major with row stride ld >= R
  * (the reference's batch-major tensors, trailing dims flattened into R; ld > R
  * reads the leading part of longer rows) -> dst [R][B], the plane layout every
- * APG_LAYOUT_SOA entry point reads. */
-int apg_to_soa(const float *src, int B, int R, int ld, float *dst,
-               apg_stream_t stream);
+ * APG_LAYOUT_SOA entry point reads.  With `index` (device int64 [B], or NULL)
+ * row b of the result is src row index[b]: the minibatch gather of the
+ * training loop (scripts/train_base.py:132-137, 191-194) in the same pass. */
+int apg_to_soa(const float *src, const long long *index, int B, int R, int ld,
+               float *dst, apg_stream_t stream);
 /* Number of floats `loss_partials` must hold for a batch of B. */
 int apg_loss_partials_count(int B);
 /* APG_VERSION_MAJOR * 1000 + APG_VERSION_MINOR. */

@@ -772,3 +772,38 @@ def test_fused_ar_large_batch_is_chunked(dev, monkeypatch):
     for k in g0:
         assert g1[k].data_ptr() >= flat.data_ptr()          # still views of `flat`
         assert rel_err(N(g1[k]), N(g0[k])) < 1e-4, k
+
+
+def test_run_epoch_indexed_fused_path_equals_batch_path(dev):
+    """run_epoch's fast path (fused concurrent step with the minibatch gather
+    folded into the layout change, functional.to_soa(index=...)) against the
+    same fused step fed with materialised batches."""
+    import copy
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    t = torch.randn(50, 4, 3, device=dev)
+    idx = torch.tensor([7, 0, 49, 7, 13], device=dev)
+    assert torch.equal(F.to_soa(t, index=idx), t[idx].permute(1, 2, 0).contiguous())
+    cfg = dict(QUAD_CFG, batch_size=96, epoch_size=300, self_play=0,
+               learning_rate_controller=1e-7)
+    a = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), dict(cfg))
+    a.shuffle = False
+    a.initialize_model(device=dev, seed=3)
+    b = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), dict(cfg))
+    b.shuffle = False
+    b.initialize_model(device=dev, seed=3)
+    b.net.load_state_dict(copy.deepcopy(a.net.state_dict()))
+    assert a.train_concurrent_fused(None, None, None, None, probe=True)
+    la = a.run_epoch("controller", 0)
+    losses = []
+    d = b.state_data
+    for lo in range(0, 300, 96):
+        sl = slice(lo, lo + 96)
+        losses.append(b.train_concurrent_fused(
+            d.normed_states[sl], d.states[sl], d.in_ref_states[sl],
+            d.ref_states[sl]).item())
+    assert abs(la - sum(losses) / (len(losses) - 1)) / abs(la) < 1e-5
+    for (k, va), (_, vb) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
+        assert rel_err(N(va), N(vb)) < 1e-6, k
