@@ -1201,21 +1201,22 @@ _WING_PARAMS = ("states_in.weight", "states_in.bias", "ref_in.weight", "ref_in.b
 
 
 def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
-                                 weights=None):
+                                 weights=None, index=None):
     """The fixed-wing concurrent training step without the autograd tape:
     loss = fixed_wing_mpc_loss(unroll(dyn, state0, sigmoid(net(normed,
     in_ref))), ref) for `Net(9, 1, 3, 80, conv=False)` with the policy on the
     matrix cores (apg_wing_policy_fwd / _bwd) around the fused rollout
     (apg_wing_rollout_fwd_bwd).  normed [B,9], in_ref [B,3], state0 [B,12],
     ref [B,20,3].  Returns (loss, {parameter name: gradient}, flat) like
-    quad_concurrent_policy_grads."""
-    B, H = state0.shape[0], 20
+    quad_concurrent_policy_grads; `index` selects the batch rows out of whole
+    data-set tensors in the same way."""
+    B, H = (state0.shape[0] if index is None else index.numel()), 20
     pw = dict(zip(("w_s", "b_s", "w_r", "b_r", "w_1", "b_1", "w_2", "b_2", "w_3",
                    "b_3", "w_out", "b_out"),
                   (_f32c(v).contiguous() for v in _net_params(net, _WING_PARAMS))))
     if (pw["w_s"].shape != (64, 9) or pw["w_r"].shape != (64, 3)
             or pw["w_1"].shape != (64, 128) or pw["w_out"].shape != (80, 64)
-            or normed.shape[1] != 9 or in_ref.reshape(B, -1).shape[1] != 3
+            or normed.shape[1] != 9 or in_ref.reshape(in_ref.shape[0], -1).shape[1] != 3
             or ref.shape[1:] != (H, 3)):
         raise ValueError("fused path needs Net(9, 1, 3, 80, conv=False), H = 20")
     dev = state0.device
@@ -1225,8 +1226,8 @@ def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
         # h1 140.. | h2 204.. | h3 268..
         acts = new(332, B)
         feat, rin, x1, h = acts[:9], acts[9:12], acts[12:140], acts[140:]
-        to_soa(normed, out=feat)
-        to_soa(in_ref.reshape(B, 3), out=rin)
+        to_soa(normed, out=feat, index=index)
+        to_soa(in_ref.reshape(-1, 3), out=rin, index=index)
         require_device(acts, *pw.values())
         pol = _capi.ApgWingPolicy(**{k: ptr(v) for k, v in pw.items()})
         actions = new(H, 4, B)
@@ -1235,8 +1236,9 @@ def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
         check(lib().apg_wing_policy_fwd(ptr(feat), ptr(rin), ctypes.byref(pol), B,
                                         ptr(actions), ptr(x1), ptr(h), ptr(ws), st),
               "apg_wing_policy_fwd")
-        res = wing_rollout_fwd_bwd(to_soa(state0), actions, to_soa(ref), dt, params,
-                                   weights, layout="soa", want_grad_state0=False)
+        res = wing_rollout_fwd_bwd(to_soa(state0, index=index), actions,
+                                   to_soa(ref, index=index), dt, params, weights,
+                                   layout="soa", want_grad_state0=False)
         cot = new(80 + 320, B)
         d_zout, d_pre = cot[:80], cot[80:]
         check(lib().apg_wing_policy_bwd(

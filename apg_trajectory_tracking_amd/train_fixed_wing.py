@@ -61,10 +61,10 @@ class TrainFixedWing(TrainBase):
                 and n.fc_out.weight.shape == (80, 64)):
             return False if probe else None
         if probe:
-            return False      # no indexed form yet: batches come from the loader
+            return True
         loss, grads, flat = F.wing_concurrent_policy_grads(
             n, in_state, in_ref_states, current_state, ref_states,
-            self.delta_t_train, self.train_dynamics.params)
+            self.delta_t_train, self.train_dynamics.params, index=index)
         return self._step_direct(loss, grads, flat)
 
     def train_controller_model(

@@ -807,3 +807,33 @@ def test_run_epoch_indexed_fused_path_equals_batch_path(dev):
     assert abs(la - sum(losses) / (len(losses) - 1)) / abs(la) < 1e-5
     for (k, va), (_, vb) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
         assert rel_err(N(va), N(vb)) < 1e-6, k
+
+
+def test_wing_run_epoch_indexed_fused_path(dev):
+    """Fixed-wing run_epoch at H = 20: the indexed fused path (gather folded
+    into the layout change) == the fused step on materialised batches."""
+    import copy
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    from apg_trajectory_tracking_amd.train_fixed_wing import TrainFixedWing
+    cfg = dict(delta_t=0.05, delta_t_train=0.05, epoch_size=200, self_play=0,
+               batch_size=64, state_size=12, horizon=20, ref_dim=3, action_dim=4,
+               learning_rate_controller=1e-7, system="fixed_wing", modified_params={})
+    a = TrainFixedWing(FixedWingDynamics(), FixedWingDynamics(), dict(cfg))
+    a.shuffle = False
+    a.initialize_model(device=dev, seed=5)
+    b = TrainFixedWing(FixedWingDynamics(), FixedWingDynamics(), dict(cfg))
+    b.shuffle = False
+    b.initialize_model(device=dev, seed=5)
+    b.net.load_state_dict(copy.deepcopy(a.net.state_dict()))
+    assert a.train_concurrent_fused(None, None, None, None, probe=True)
+    la = a.run_epoch("controller", 0)
+    d, losses = b.state_data, []
+    for lo in range(0, 200, 64):
+        sl = slice(lo, lo + 64)
+        losses.append(b.train_concurrent_fused(
+            d.normed_states[sl], d.states[sl], d.in_ref_states[sl],
+            d.ref_states[sl]).item())
+    assert abs(la - sum(losses) / (len(losses) - 1)) / abs(la) < 1e-5
+    for (k, va), (_, vb) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
+        assert rel_err(N(va), N(vb)) < 1e-6, k
