@@ -648,7 +648,7 @@ def to_soa(t, out=None, index=None):
     return out
 
 
-def _ref_and_states(in_ref, state0, B, H):
+def _ref_and_states(in_ref, state0, B, H, index=None):
     """One buffer for everything the conv-weight product reads as B operand:
     planes [0, 2H*9) = the reference tensor [2H][9][B], planes [2H*9, +(H+1)*12)
     = [state0; states of the rollout] ([H+1][12][B], the kernels write the H
@@ -656,9 +656,9 @@ def _ref_and_states(in_ref, state0, B, H):
     buf = torch.empty(2 * H * 9 + (H + 1) * 12, B, dtype=torch.float32,
                       device=state0.device)
     inr = buf[:2 * H * 9].view(2 * H, 9, B)
-    to_soa(in_ref[:, :2 * H], out=inr)
+    to_soa(in_ref[:, :2 * H], out=inr, index=index)
     st_all = buf[2 * H * 9:].view(H + 1, 12, B)
-    to_soa(state0, out=st_all[0])
+    to_soa(state0, out=st_all[0], index=index)
     return buf, inr, st_all[0], st_all[1:]
 
 
@@ -697,16 +697,17 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, state0, in_ref, ref, h0, c0, conv_w, conv_b, w_ih, w_hh,
-                b_ih, b_hh, w_out, b_out, dt, params, weights):
-        B = state0.shape[0]
+                b_ih, b_hh, w_out, b_out, dt, params, weights, index=None):
+        B = state0.shape[0] if index is None else index.numel()
         H = 10
         if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
             raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
         if w_ih.shape != (32, 175) or conv_w.shape != (20, 9, 3):
             raise ValueError("fused path needs LSTM_NEW(15, 10, 9, 4, conv=1)")
         dev = state0.device
-        refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H)
-        rf = to_soa(ref[:, :H])
+        refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H,
+                                                  index)
+        rf = to_soa(ref[:, :H], index=index)
         h0s, c0s = to_soa(h0), to_soa(c0)
         pw = dict(
             conv_w=_f32c(conv_w), conv_b=_f32c(conv_b), w_ih=_f32c(w_ih),
@@ -812,8 +813,8 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, state0, in_ref, ref, w_s, b_s, conv_w, conv_b, w_1, b_1,
-                w_2, b_2, w_3, b_3, w_out, b_out, dt, params, weights):
-        B = state0.shape[0]
+                w_2, b_2, w_3, b_3, w_out, b_out, dt, params, weights, index=None):
+        B = state0.shape[0] if index is None else index.numel()
         H = 10
         if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
             raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
@@ -825,8 +826,9 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
             raise ValueError("batch too large for one fused launch "
                              "(B <= 400 000); split it")
         dev = state0.device
-        refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H)
-        rf = to_soa(ref[:, :H])
+        refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H,
+                                                  index)
+        rf = to_soa(ref[:, :H], index=index)
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -1148,20 +1150,22 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
 _MAX_FUSED_AR_BATCH = 98304   # saved planes stay below planes_gemm's 2 GiB per operand
 
 
-def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None):
+def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
+                           index=None):
     """quad_mlp_rollout_loss (autoregressive unroll) + parameter gradients,
     without autograd; see quad_concurrent_policy_grads.  Batches beyond
     98 304 trajectories are processed in chunks (losses and gradients are sums
     over trajectories, so the chunks simply add up)."""
-    B = state0.shape[0]
+    B = state0.shape[0] if index is None else index.numel()
     if B > _MAX_FUSED_AR_BATCH:
         n = -(-B // _MAX_FUSED_AR_BATCH)
         step = -(-B // n)
+        if index is None:
+            index = torch.arange(B, device=state0.device)
         loss, gr, flat = None, None, None
         for lo in range(0, B, step):
-            sl = slice(lo, lo + step)
-            l, g, f = quad_mlp_rollout_grads(net, state0[sl], in_ref[sl], ref[sl], dt,
-                                             params, weights)
+            l, g, f = quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params,
+                                             weights, index[lo:lo + step].contiguous())
             if flat is None:
                 loss, gr, flat = l, g, f
             else:
@@ -1172,7 +1176,7 @@ def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None):
     with torch.no_grad():
         loss, _, _ = _QuadMlpRolloutLoss.forward(
             ctx, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt, params,
-            weights or quad_loss_weights())
+            weights or quad_loss_weights(), index)
         flat, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
     return loss, gr, flat
 
@@ -1183,13 +1187,13 @@ _LSTM_PARAMS = ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
 
 
 def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
-                            weights=None):
+                            weights=None, index=None):
     """quad_lstm_rollout_loss + parameter gradients, without autograd."""
     ctx = _DirectCtx()
     with torch.no_grad():
         loss, _, _ = _QuadLstmRolloutLoss.forward(
             ctx, state0, in_ref, ref, h0, c0, *_net_params(net, _LSTM_PARAMS), dt,
-            params, weights or quad_loss_weights())
+            params, weights or quad_loss_weights(), index)
         flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
     return loss, gr, flat
 

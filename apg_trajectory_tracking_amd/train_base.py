@@ -241,6 +241,14 @@ class TrainBase:
                 loss = self.train_concurrent_fused(*tensors, index=index).detach()
                 running_loss = loss if running_loss is None else running_loss + loss
             return self._finish_epoch(running_loss, i, train)
+        if (train == "controller" and self.train_mode != "concurrent"
+                and hasattr(self.trainloader, "iter_indices")
+                and getattr(self, "recurrent_indexed_ok", lambda: False)()):
+            tensors = self.trainloader.tensors
+            for i, index in enumerate(self.trainloader.iter_indices(), 0):
+                loss = self.train_recurrent_model(*tensors, index=index).detach()
+                running_loss = loss if running_loss is None else running_loss + loss
+            return self._finish_epoch(running_loss, i, train)
         for i, data in enumerate(self.trainloader, 0):
             in_state, current_state, in_ref_state, ref_states = data
             if train == "dynamics":

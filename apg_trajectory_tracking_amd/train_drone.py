@@ -66,10 +66,12 @@ class TrainDrone(TrainBase):
         self.init_optimizer()
 
     def train_recurrent_model(
-        self, in_state, current_state, in_ref_states, ref_states
+        self, in_state, current_state, in_ref_states, ref_states, index=None
     ):
+        """`index` (fused paths only): the tensors are the whole data set, the
+        batch is rows `index` (gathered inside the kernels' layout change)."""
         self.optimizer_controller.zero_grad()
-        batch_size = current_state.size()[0]
+        batch_size = current_state.size()[0] if index is None else index.numel()
         if self.train_mode == "LSTM":
             self.net.reset_hidden_state(
                 batch_size, generator=self.hidden_generator)
@@ -77,13 +79,17 @@ class TrainDrone(TrainBase):
                 loss, grads, flat = F.quad_lstm_rollout_grads(
                     self.net, current_state, in_ref_states, ref_states,
                     self.delta_t, self.train_dynamics.params,
-                    self.net.hidden_state, self.net.cell_state)
+                    self.net.hidden_state, self.net.cell_state, index=index)
                 return self._step_direct(loss, grads, flat)
         elif self.fused_policy and self._fusable_mlp():
             loss, grads, flat = F.quad_mlp_rollout_grads(
                 self.net, current_state, in_ref_states, ref_states,
-                self.delta_t, self.train_dynamics.params)
+                self.delta_t, self.train_dynamics.params, index=index)
             return self._step_direct(loss, grads, flat)
+        if index is not None:     # per-step path: materialise the batch
+            current_state, in_ref_states, ref_states = (
+                t.index_select(0, index) for t in
+                (current_state, in_ref_states, ref_states))
         states, actions = [], []
         for k in range(self.horizon):
             rel = in_ref_states[:, k:k + self.horizon].clone()
@@ -99,6 +105,11 @@ class TrainDrone(TrainBase):
         loss = quad_mpc_loss(
             intermediate_states, ref_states[:, :self.horizon], action_seq)
         return self._step(loss)
+
+    def recurrent_indexed_ok(self):
+        """run_epoch may hand index batches to train_recurrent_model."""
+        return self.fused_policy and (
+            self._fusable() if self.train_mode == "LSTM" else self._fusable_mlp())
 
     def _fusable(self):
         n = self.net

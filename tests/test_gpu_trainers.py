@@ -837,3 +837,35 @@ def test_wing_run_epoch_indexed_fused_path(dev):
     assert abs(la - sum(losses) / (len(losses) - 1)) / abs(la) < 1e-5
     for (k, va), (_, vb) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
         assert rel_err(N(va), N(vb)) < 1e-6, k
+
+
+@pytest.mark.parametrize("mode", ["autoregressive", "LSTM"])
+def test_recurrent_run_epoch_indexed_path(dev, mode):
+    """run_epoch for the recurrent modes: index batches handed to the fused
+    unroll (gather inside the layout change) == materialised batches."""
+    import copy
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    cfg = dict(QUAD_CFG, batch_size=80, epoch_size=250, self_play=0,
+               train_mode=mode, learning_rate_controller=1e-7)
+    a = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), dict(cfg))
+    a.shuffle = False
+    a.initialize_model(device=dev, seed=4)
+    b = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), dict(cfg))
+    b.shuffle = False
+    b.initialize_model(device=dev, seed=4)
+    b.net.load_state_dict(copy.deepcopy(a.net.state_dict()))
+    a.hidden_generator = torch.Generator().manual_seed(5)
+    b.hidden_generator = torch.Generator().manual_seed(5)
+    assert a.recurrent_indexed_ok()
+    la = a.run_epoch("controller", 0)
+    d, losses = b.state_data, []
+    for lo in range(0, 250, 80):
+        sl = slice(lo, lo + 80)
+        losses.append(b.train_recurrent_model(
+            d.normed_states[sl], d.states[sl], d.in_ref_states[sl],
+            d.ref_states[sl]).item())
+    assert abs(la - sum(losses) / (len(losses) - 1)) / abs(la) < 1e-5
+    for (k, va), (_, vb) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
+        assert rel_err(N(va), N(vb)) < 1e-6, k
