@@ -869,3 +869,57 @@ def test_recurrent_run_epoch_indexed_path(dev, mode):
     assert abs(la - sum(losses) / (len(losses) - 1)) / abs(la) < 1e-5
     for (k, va), (_, vb) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
         assert rel_err(N(va), N(vb)) < 1e-6, k
+
+
+@pytest.mark.parametrize("mode", ["concurrent", "autoregressive", "LSTM"])
+def test_fused_policy_paths_at_baseline_batch(dev, mode):
+    """BASELINE.json size (65 536 trajectories, H = 10): the fused-policy
+    training step of every mode against the per-step / torch-policy path on the
+    same data - loss and every parameter gradient (sums over the batch)."""
+    import copy
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    B = 65536
+    conc = mode == "concurrent"
+    d = synthetic.quad_polynomial_batch(B, 10, 0.1, seed=17,
+                                        ref_length=10 if conc else 20)
+    state0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    with torch.no_grad():
+        normed = state_preprocessing(state0)
+    torch.manual_seed(12)
+    base = (LSTM_NEW(15, 10, 9, 4, conv=1) if mode == "LSTM"
+            else Net(15, 10, 9, 40 if conc else 4, conv=1))
+    gen = torch.Generator().manual_seed(3)
+    h0, c0 = (torch.randn(B, 8, generator=gen).to(dev) for _ in range(2))
+    res = []
+    for fused in (False, True):
+        t = TrainDrone(FlightmareDynamics(), FlightmareDynamics(),
+                       dict(QUAD_CFG, batch_size=B, train_mode=mode))
+        t.net = copy.deepcopy(base).to(dev)
+        if mode == "LSTM":
+            def fixed_reset(batch_size=1, generator=None, net=t.net):
+                net.hidden_state, net.cell_state = h0.clone(), c0.clone()
+            t.net.reset_hidden_state = fixed_reset
+        t.fused_policy = fused
+        t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=0.0)
+        if conc and fused:
+            loss = t.train_concurrent_fused(normed, state0, in_ref, ref)
+        elif conc:
+            acts = torch.sigmoid(t.net(normed, in_ref)).reshape(-1, 10, 4)
+            loss = t.train_controller_model(state0, acts, in_ref, ref)
+        else:
+            loss = t.train_recurrent_model(normed, state0, in_ref, ref)
+        res.append((loss.item(), {k: N(p.grad) for k, p in
+                                  t.net.named_parameters() if p.grad is not None}))
+        del t
+        torch.cuda.empty_cache()
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) / abs(l0) < 2e-5
+    assert set(g0) == set(g1)
+    for k in g0:      # 655 360-term fp32 sums in different orders
+        assert rel_err(g1[k], g0[k]) < 1e-3, k
