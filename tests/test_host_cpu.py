@@ -208,3 +208,48 @@ def test_shipped_reference_controllers_load_and_reproduce(system):
         assert rel_err(y2.t().numpy(), g["quad.out"]) < 1e-6
     if system == "wing":
         assert not net.conv
+
+
+def test_tensor_batches_index_batches_match_tensor_batches():
+    """iter_indices yields the index form of the batches __iter__ materialises
+    (same generator state -> same permutation)."""
+    from apg_trajectory_tracking_amd.dataset import TensorBatches
+    a = torch.arange(23.)[:, None].repeat(1, 2)
+    tb1 = TensorBatches((a,), 5, shuffle=True, generator=torch.Generator().manual_seed(4))
+    tb2 = TensorBatches((a,), 5, shuffle=True, generator=torch.Generator().manual_seed(4))
+    idx = list(tb2.iter_indices())
+    assert [i.dtype for i in idx] == [torch.int64] * 5
+    for (x,), i in zip(tb1, idx):
+        assert torch.equal(x, a[i])
+    seq = list(TensorBatches((a,), 10, shuffle=False).iter_indices())
+    assert torch.equal(torch.cat(seq), torch.arange(23))
+
+
+def test_flat_gradient_layout_and_new_argument_errors():
+    """Host logic of the fused-policy paths that needs no GPU: the flat
+    gradient buffer (contiguous per-parameter views + one loss slot), the
+    column descriptor of planes_gemm, struct sizes, and argument validation of
+    the new entry points (happens before any HIP call)."""
+    from apg_trajectory_tracking_amd import _capi, functional as F
+    flat, views = F._flat_grads("cpu", {"a.weight": (4, 3), "a.bias": (4,), "c": (2, 2, 2)})
+    assert flat.numel() == 12 + 4 + 8 + 1
+    assert [tuple(v.shape) for v in views.values()] == [(4, 3), (4,), (2, 2, 2)]
+    assert all(v.is_contiguous() for v in views.values())
+    views["c"].fill_(2.0)
+    assert float(flat[16:24].sum()) == 16.0 and views["a.bias"].data_ptr() == flat[12:].data_ptr()
+    d = F.make_bdesc("cpu", [5, 6, 7], 9, [0, 1, 2])
+    assert d.dtype == torch.int32 and d.tolist() == [[5, 6, 7], [9, 9, 9], [0, 1, 2]]
+    assert ctypes.sizeof(_capi.ApgMlpPolicy) == 12 * 8
+    assert ctypes.sizeof(_capi.ApgLstmPolicy) == 8 * 8
+    assert ctypes.sizeof(_capi.ApgWingPolicy) == 12 * 8
+    assert ctypes.sizeof(_capi.ApgGemmProblem) == 5 * 8 + 8 + 7 * 4 + 4
+    lib = _capi.lib()
+    assert lib.apg_to_soa(None, None, 4, 0, 0, None, None) == -1
+    assert b"apg_to_soa" in lib.apg_last_error_string()
+    assert lib.apg_planes_gemm(1, 65, 1, 1, 1, 8, 1, 1, 8, 64, 1, 16, 1, 9, None, None) == -1
+    assert b"M <= 64" in lib.apg_last_error_string()
+    assert lib.apg_planes_gemm_grouped(None, 0, None, 4, None) == -1
+    assert lib.apg_quad_mlp_workspace_floats() > 0 and lib.apg_quad_lstm_workspace_floats() > 0
+    assert lib.apg_quad_mlp_loss_partials_count(300) == 16
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        F.to_soa(torch.zeros(4, 3))
