@@ -20,6 +20,7 @@ Fixtures:
   learnt_dynamics.npz G10 LearntDynamics forward + parameter gradients
   closed_loop.npz    G11 QuadEvaluator.follow_trajectory with the shipped quad
                          controller on injected reference trajectories
+  wing_train.npz     G12 TrainFixedWing.train_controller_model, 2 SGD steps
 
 `python tests/golden/make_golden.py g11` regenerates selected fixtures only.
 """
@@ -696,10 +697,62 @@ def g11_closed_loop():
     save("closed_loop.npz", **out)
 
 
+# -------------------------------------------------------------------- G12
+def g12_wing_train():
+    """The fixed-wing counterpart of G3: the body of TrainBase.run_epoch
+    (scripts/train_base.py:198-209) + TrainFixedWing.train_controller_model
+    (scripts/train_fixed_wing.py:90-116) with fixed Net(9, 1, 3, 80,
+    conv=False) weights, two momentum-SGD steps: losses, the gradients of the
+    first step, the weights after each step."""
+    import json
+    import train_fixed_wing as tfw
+    cwd = os.getcwd()
+    os.makedirs("/tmp/apg_golden_scratch", exist_ok=True)
+    os.chdir("/tmp/apg_golden_scratch")
+    try:
+        with open(os.path.join(REF, "configs", "wing_config.json")) as f:
+            config = json.load(f)
+        B, H = 48, 20
+        config.update(batch_size=B, sample_in="train_env", horizon=H)
+        dt = config.get("delta_t_train", config["delta_t"])
+        dyn = FixedWingDynamics()
+        trainer = tfw.TrainFixedWing(dyn, dyn, config)
+        assert trainer.horizon == H and trainer.delta_t_train == dt
+        torch.manual_seed(15)
+        trainer.net = Net(9, 1, 3, 4 * H, conv=False)
+        trainer.optimizer_controller = torch.optim.SGD(
+            trainer.net.parameters(), lr=1e-7, momentum=0.9)
+        out = _state_dict_np(trainer.net, "w0.")
+        from apg_trajectory_tracking_amd import synthetic as syn
+        d = syn.wing_batch(B, H, dt, seed=16)
+        g = torch.Generator().manual_seed(17)
+        in_state = 0.5 * torch.randn(B, 9, generator=g)      # normed state features
+        in_ref = torch.randn(B, 3, generator=g)
+        in_ref = in_ref / in_ref.norm(dim=1, keepdim=True)   # unit target direction
+        out.update(state0=npy(d["state0"]), ref=npy(d["ref"]), in_state=npy(in_state),
+                   in_ref=npy(in_ref), lr=np.float32(1e-7), momentum=np.float32(0.9),
+                   dt=np.float32(dt))
+        for step in (1, 2):
+            actions = torch.sigmoid(trainer.net(in_state, in_ref))
+            action_seq = torch.reshape(actions, (-1, H, 4))
+            loss = trainer.train_controller_model(d["state0"], action_seq, in_ref,
+                                                  d["ref"])
+            out[f"loss{step}"] = np.float64(loss.item())
+            if step == 1:
+                out["actions1"] = npy(action_seq)
+                for k, p in trainer.net.named_parameters():
+                    if p.grad is not None:
+                        out["g1." + k] = npy(p.grad)
+            out.update(_state_dict_np(trainer.net, f"w{step}."))
+        save("wing_train.npz", **out)
+    finally:
+        os.chdir(cwd)
+
+
 FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
                 g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
                 g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
-                g11=g11_closed_loop)
+                g11=g11_closed_loop, g12=g12_wing_train)
 
 if __name__ == "__main__":
     for key in (sys.argv[1:] or FIXTURES):

@@ -923,3 +923,41 @@ def test_fused_policy_paths_at_baseline_batch(dev, mode):
     assert set(g0) == set(g1)
     for k in g0:      # 655 360-term fp32 sums in different orders
         assert rel_err(g1[k], g0[k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_wing_train_controller_two_sgd_steps(dev, fused):
+    """G12: the fixed-wing training step against the reference trainer's
+    recording - torch policy around the fused rollout, and the policy on the
+    matrix cores (apg_wing_policy_fwd/_bwd)."""
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_fixed_wing import TrainFixedWing
+    g = load_golden("wing_train.npz")
+    cfg = dict(delta_t=float(g["dt"]), delta_t_train=float(g["dt"]), epoch_size=48,
+               self_play=0, batch_size=48, state_size=12, horizon=20, ref_dim=3,
+               action_dim=4, learning_rate_controller=float(g["lr"]),
+               system="fixed_wing", modified_params={})
+    t = TrainFixedWing(FixedWingDynamics(), FixedWingDynamics(), cfg)
+    net = Net(9, 1, 3, 80, conv=False)
+    load_weights(net, g, "w0.")
+    t.net = net.to(dev)
+    t.optimizer_controller = torch.optim.SGD(
+        t.net.parameters(), lr=float(g["lr"]), momentum=float(g["momentum"]))
+    in_state, in_ref = D(g["in_state"], dev), D(g["in_ref"], dev)
+    state0, ref = D(g["state0"], dev), D(g["ref"], dev)
+    for step in (1, 2):
+        if fused:
+            loss = t.train_concurrent_fused(in_state, state0, in_ref, ref)
+            assert loss is not None
+        else:
+            acts = torch.sigmoid(t.net(in_state, in_ref)).reshape(-1, 20, 4)
+            loss = t.train_controller_model(state0, acts, in_ref, ref)
+        assert abs(loss.item() - g[f"loss{step}"]) / g[f"loss{step}"] < 1e-5
+        if step == 1:
+            for k, p in t.net.named_parameters():
+                if "g1." + k in g.files:
+                    assert rel_err(N(p.grad), g["g1." + k]) < 1e-4, k
+        for k, v in t.net.state_dict().items():
+            assert rel_err(N(v), g[f"w{step}.{k}"]) < 1e-5, (step, k)
