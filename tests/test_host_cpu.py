@@ -253,3 +253,83 @@ def test_flat_gradient_layout_and_new_argument_errors():
     assert lib.apg_quad_mlp_loss_partials_count(300) == 16
     with pytest.raises(ValueError, match="no CPU fallback"):
         F.to_soa(torch.zeros(4, 3))
+
+
+@pytest.mark.filterwarnings("ignore::RuntimeWarning")   # mean of no complete run
+def test_evaluator_statistics_and_self_play_selection(monkeypatch):
+    """Host logic of evaluate_drone.QuadEvaluator on CPU: the kernel call is
+    replaced by the batched oracle loop (test infrastructure); checked are
+    run_eval's statistics against the reference's formulas
+    (scripts/evaluate_drone.py:250-299) applied run by run, and which (state,
+    window) pairs self play hands to the data set (every take_every_x-th policy
+    call, counted through the runs, network_wrapper.py:47-71)."""
+    from apg_trajectory_tracking_amd import evaluate_drone, functional as F, synthetic
+    from apg_trajectory_tracking_amd.checkpoint import build_policy
+    from conftest import load_golden
+    from oracle import torch_port as tp
+    ck = load_golden("checkpoints.npz")
+    sd = {k[len("quad.w."):]: torch.from_numpy(ck[k]) for k in ck.files
+          if k.startswith("quad.w.")}
+    net = build_policy("quad", sd)
+    B, L, steps, td = 7, 30, 24, 0.12
+
+    def fake_closed_loop(net_, traj, dt, params, max_steps=251, thresh_div=1.0,
+                         thresh_stable=1.0, test_time=0, want_trajectory=False):
+        o = tp.quad_closed_loop(net_, tp.QuadOracle(), traj, dt, 10, max_steps,
+                                thresh_div, thresh_stable, test_time)
+        T_ = min(max_steps, traj.shape[1] + 1)
+        out = dict(div=o["div"][:, :T_].t().contiguous(), steps=o["steps"].int())
+        if want_trajectory:
+            # the state the policy saw: previous state, or the reference row
+            # after a failed step (train mode)
+            start = torch.zeros(T_, 12, traj.shape[0])
+            start[0] = o["drone"][:, 0].t()
+            for k in range(1, T_):
+                cur = min(k, traj.shape[1] - 10)
+                unstable = ~(o["drone"][:, k, 3:5].abs() < thresh_stable).all(1)
+                failed = (o["div"][:, k - 1] > thresh_div) | unstable
+                reset = torch.cat((traj[:, cur], torch.zeros(traj.shape[0], 3)), 1)
+                start[k] = torch.where(failed[:, None] & (not test_time), reset,
+                                       o["drone"][:, k]).t()
+            out.update(drone=o["drone"][:, :T_ + 1].permute(1, 2, 0),
+                       actions=o["actions"][:, :T_].permute(1, 2, 0), start_states=start)
+        return out
+    monkeypatch.setattr(F, "quad_mlp_closed_loop", fake_closed_loop)
+
+    class Dyn:
+        params = None
+    traj = synthetic.quad_eval_trajectories(B, L, 0.1, seed=9)
+    traj[:, :, 2] += 3
+    for test_time in (0, 1):
+        ev = evaluate_drone.QuadEvaluator(net, Dyn(), ref_length=10, dt=0.1,
+                                          test_time=test_time)
+        got = ev.run_eval("rand", nr_test=B, max_steps=steps, thresh_div=td,
+                          thresh_stable=1.0, trajectories=traj)
+        o = tp.quad_closed_loop(net, tp.QuadOracle(), traj, 0.1, 10, steps, td, 1.0,
+                                test_time)
+        div, stable = [], []
+        for i in range(B):                  # the reference's per-run bookkeeping
+            d_i = o["div"][i, :int(o["steps"][i])].numpy()
+            div.append(np.mean(d_i))
+            stable.append(np.sum(d_i < td))
+        div, stable = np.array(div), np.array(stable)
+        full = div[stable == int(o["steps"][-1])]
+        want = (np.mean(stable), np.std(stable), np.mean(full), np.std(full),
+                np.mean(div), np.std(div))
+        np.testing.assert_allclose(got, want, rtol=1e-5, equal_nan=True)
+
+    class Recorder:
+        def add_eval_data(self, states, windows):
+            self.states, self.windows = states, windows
+            return states.shape[0]
+    rec = Recorder()
+    ev = evaluate_drone.QuadEvaluator(net, Dyn(), ref_length=10, dt=0.1, test_time=0)
+    ev.run_eval("rand", nr_test=B, max_steps=steps, thresh_div=td, thresh_stable=1.0,
+                trajectories=traj, dataset=rec, take_every_x=5)
+    T_ = min(steps, L + 1)
+    calls = [(i, k) for i in range(B) for k in range(T_)]          # run-major order
+    picked = [c for n, c in enumerate(calls) if (n + 1) % 5 == 0]
+    assert rec.states.shape == (len(picked), 12) and rec.windows.shape[1:] == (10, 9)
+    i, k = picked[3]
+    ws = min(k + 1, L - 10)
+    assert torch.equal(rec.windows[3], traj[i, ws:ws + 10])
