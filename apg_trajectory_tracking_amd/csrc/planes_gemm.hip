@@ -108,8 +108,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
   __syncthreads();
 
   auto issue = [&](long long tile, int p) {  // DMA of one tile into buffer p
-    const int s = (int)(tile / G.tiles_per_seg);
-    const unsigned colb = (unsigned)(tile % G.tiles_per_seg) * (kKT * 4);
+    // segment fastest: the workgroups running at the same time then work on a
+    // few column tiles across ALL segments, so B rows shared by segments (the
+    // sliding windows of the conv product) are fetched from HBM once
+    const int s = (int)(tile % G.S);
+    const unsigned colb = (unsigned)(tile / G.S) * (kKT * 4);
     const unsigned sa = (unsigned)s * plane_bytes;
     const unsigned s1 = (unsigned)(s / G.sdiv), s2 = (unsigned)(s % G.sdiv);
 #pragma unroll
@@ -142,7 +145,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
   for (; tile < total_tiles; tile += nb, p ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile landed (all waves); buffer p^1 is free again
-    const long long n0 = (tile % G.tiles_per_seg) * kKT;
+    const long long n0 = (tile / G.S) * kKT;
     if (G.N - n0 < kKT) {  // ragged last tile of a segment: zero A beyond N
       const int rem = (int)(G.N - n0);
       for (int e = tid; e < MB * 32 * kKT; e += kThreads)
