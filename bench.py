@@ -114,13 +114,14 @@ def cpu_baseline(args):
     # the reference turns autograd anomaly detection on at import
     # (neural_control/drone_loss.py:6): its as-shipped path pays for it
     import warnings
-    with warnings.catch_warnings(), torch.autograd.detect_anomaly(check_nan=True):
+    with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        run()
-        t0 = time.perf_counter()
-        for _ in range(2):
+        with torch.autograd.detect_anomaly(check_nan=True):
             run()
-        anomaly_ms = (time.perf_counter() - t0) / 2 * 1e3
+            t0 = time.perf_counter()
+            for _ in range(2):
+                run()
+            anomaly_ms = (time.perf_counter() - t0) / 2 * 1e3
     torch.set_num_threads(default_threads)
     # second CPU data point: the C oracle (matrix-form restatement with a
     # hand-written reverse sweep, OpenMP over the batch, all host cores)
