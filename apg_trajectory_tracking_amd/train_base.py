@@ -175,6 +175,15 @@ class TrainBase:
         self.optimizer_controller.step()
         return loss
 
+    def analytic_train_dynamics(self):
+        """The fused rollouts integrate the ANALYTIC simulator described by
+        `train_dynamics.params`.  A learnable simulator (an nn.Module such as
+        LearntDynamics: action transform + residual network on top of the
+        physics) must be called step by step instead, as the reference does
+        (scripts/train_drone.py:185-191)."""
+        d = self.train_dynamics
+        return hasattr(d, "params") and not isinstance(d, torch.nn.Module)
+
     # --------------------------------------------------------- hot loop
     def train_controller_model(
         self, current_state, action_seq, in_ref_state, ref_states
@@ -299,24 +308,85 @@ class TrainBase:
         return None
 
     def save_model(self, epoch, success=0.0, suc_std=0.0):
-        os.makedirs(self.save_path, exist_ok=True)
-        torch.save(self.net.state_dict(), os.path.join(
-            self.save_path, self.save_model_name + str(epoch)))
+        """scripts/train_base.py:233-251: a checkpoint per evaluated epoch
+        (not for epoch 0) and the score bookkeeping; a state_dict is written
+        instead of the pickled module (checkpoint.py reads both)."""
+        if epoch > 0:
+            self.current_score = success
+            os.makedirs(self.save_path, exist_ok=True)
+            torch.save(self.net.state_dict(), os.path.join(
+                self.save_path, self.save_model_name + str(epoch)))
 
     def finalize(self):
+        """scripts/train_base.py:253-287 without the plots: final weights and
+        the per-epoch statistics as csv."""
         os.makedirs(self.save_path, exist_ok=True)
         torch.save(self.net.state_dict(),
                    os.path.join(self.save_path, self.save_model_name))
         np.savetxt(os.path.join(self.save_path, "loss.csv"),
                    self.results_dict["loss"], delimiter=",")
+        if self.results_dict["mean_success"]:
+            np.savetxt(os.path.join(self.save_path, "mean_successes.csv"),
+                       self.results_dict["mean_success"], delimiter=",")
+
+    def _speed_curriculum(self, epoch, track):
+        """The speed ladder of run_control (scripts/train_base.py:300-313):
+        once the last five evaluations all flew longer than a full reference
+        at the current speed - or after 100 epochs at it - the references get
+        0.1 faster (up to 0.4) and the divergence threshold restarts at 0.1."""
+        cfg = self.config
+        full_length = 1000 / (cfg["speed_factor"] / cfg.get("delta_t", self.delta_t))
+        track["successes"].append(self.results_dict["mean_success"][-1])
+        recent = track["successes"][-5:]
+        mastered = len(track["successes"]) > 5 and min(recent) > full_length
+        if (mastered or epoch - track["since"] > 100) and cfg["speed_factor"] < 0.4:
+            cfg["speed_factor"] += 0.1
+            cfg["thresh_div"] = 0.1
+            track["successes"] = []
+            track["since"] = epoch + 1
+            self.current_score = 0 if self.suc_up_down == 1 else np.inf
 
     def run_control(self, config, sampling_based_finetune=False, curriculum=0):
+        """scripts/train_base.py:289-332.  `curriculum` (off by default here;
+        the reference's default is on) needs the closed-loop statistics of
+        evaluate_model, i.e. a trainer that provides the hook."""
+        track = {"successes": [], "since": 0}
+        if curriculum:
+            self.config["speed_factor"] = 0.2
         try:
             for epoch in range(config["nr_epochs"]):
-                if self.evaluate_model(epoch) is None:   # hook not provided:
-                    self.sample_new_data(epoch)          # it resamples itself
+                evaluated = self.evaluate_model(epoch)
+                if evaluated is None:          # hook not provided:
+                    self.sample_new_data(epoch)  # it resamples itself
+                elif curriculum:
+                    self._speed_curriculum(epoch, track)
                 print(f"\nEpoch {epoch}")
                 self.run_epoch(train="controller", epoch=epoch)
+                if sampling_based_finetune:
+                    self.results_dict["samples_in_d2"].append(
+                        getattr(self.state_data, "eval_counter", 0))
+        except KeyboardInterrupt:
+            pass
+        self.finalize()
+
+    def run_dynamics(self, config):
+        """scripts/train_base.py:334-375: fit the learnable
+        train dynamics for the first `train_dyn_for_epochs` epochs (every
+        `train_dyn_every`-th), then train the controller through it."""
+        until = config.get("train_dyn_for_epochs", 10)
+        every = config.get("train_dyn_every", 1)
+        try:
+            for epoch in range(config["nr_epochs"]):
+                if self.evaluate_model(epoch) is None:
+                    self.sample_new_data(epoch)
+                fit = epoch <= until and epoch % every == 0
+                print(f"\nEpoch {epoch}")
+                self.run_epoch(train="dynamics" if fit else "controller",
+                               epoch=epoch)
+                self.results_dict["samples_in_d2"].append(
+                    self.count_finetune_data)
+                if epoch == until:   # the controller phase starts from scratch
+                    self.current_score = 0 if self.suc_up_down == 1 else np.inf
         except KeyboardInterrupt:
             pass
         self.finalize()

@@ -114,6 +114,7 @@ class TrainDrone(TrainBase):
     def _fusable(self):
         n = self.net
         return (isinstance(n, LSTM_NEW) and n.conv and self.horizon == 10
+                and self.analytic_train_dynamics()
                 and n.lstm.weight_ih.shape == (32, 175)
                 and n.conv_ref.weight.shape == (20, 9, 3)
                 and n.fc_out.weight.shape == (4, 8))
@@ -126,7 +127,7 @@ class TrainDrone(TrainBase):
         the policy inside the kernels (apg_quad_mlp_concurrent_fwd_bwd)."""
         n = self.net
         ok = (self.fused_policy and isinstance(n, Net) and n.conv
-                and self.horizon == 10 and hasattr(self.train_dynamics, "params")
+                and self.horizon == 10 and self.analytic_train_dynamics()
                 and n.states_in.weight.shape == (64, 15)
                 and n.conv_ref.weight.shape == (20, 9, 3)
                 and n.fc1.weight.shape == (64, 224)
@@ -144,7 +145,7 @@ class TrainDrone(TrainBase):
         n = self.net
         return (isinstance(n, Net) and n.conv and self.horizon == 10
                 and self.train_mode == "autoregressive"
-                and hasattr(self.train_dynamics, "params")
+                and self.analytic_train_dynamics()
                 and n.states_in.weight.shape == (64, 15)
                 and n.conv_ref.weight.shape == (20, 9, 3)
                 and n.fc1.weight.shape == (64, 224)
@@ -156,12 +157,22 @@ class TrainDrone(TrainBase):
         resampling, divergence-threshold curriculum, checkpoint, statistics."""
         from .evaluate_drone import QuadEvaluator
         n = self.net
+        # the environment flown in: `sample_in` (scripts/train_drone.py:39-49).
+        # The batched loop integrates an analytic simulator; when the chosen
+        # one is a learnt nn.Module, the analytic evaluation dynamics is flown
+        # instead (statistics and self-play states then come from the system
+        # the learnt model is fitted to).
+        env = (self.eval_dynamics if self.sample_in == "eval_env"
+               else self.train_dynamics)
+        if isinstance(env, torch.nn.Module):
+            env = self.eval_dynamics
         if not (isinstance(n, (Net, LSTM_NEW)) and n.conv and self.horizon == 10
-                and hasattr(self.eval_dynamics, "params")):
+                and hasattr(env, "params")
+                and not isinstance(env, torch.nn.Module)):
             return None          # no fused evaluator for this architecture
         self.config.setdefault("thresh_div", self.thresh_div_start)
         self.config.setdefault("thresh_stable", self.thresh_stable_start)
-        evaluator = QuadEvaluator(n, self.eval_dynamics, **{
+        evaluator = QuadEvaluator(n, env, **{
             k: v for k, v in self.config.items()
             if k in ("ref_length", "dt", "speed_factor", "train_mode")})
         # self play (NetworkWrapper.predict_actions, take_every_x): visited
@@ -194,6 +205,15 @@ class TrainDrone(TrainBase):
         self, current_state, action_seq, in_ref_states, ref_states
     ):
         self.optimizer_controller.zero_grad()
+        if not self.analytic_train_dynamics():
+            # learnt simulator: unroll through its own forward (:185-191)
+            states = []
+            for k in range(action_seq.size()[1]):
+                current_state = self.train_dynamics(
+                    current_state, action_seq[:, k], dt=self.delta_t)
+                states.append(current_state)
+            loss = quad_mpc_loss(torch.stack(states, dim=1), ref_states, action_seq)
+            return self._step(loss)
         loss = F.quad_rollout_loss(
             current_state, action_seq, ref_states, self.delta_t,
             self.train_dynamics.params)
@@ -211,4 +231,35 @@ def train_control(base_model, config, device=None):
     trainer.initialize_model(base_model, modified_params=modified_params,
                              device=device)
     trainer.run_control(config)
+    return trainer
+
+
+def train_dynamics(base_model, config, device=None):
+    """scripts/train_drone.py:260-278: fit LearntDynamics
+    to the (modified) evaluation simulator, then train the controller through
+    the learnt one."""
+    from .dynamics.quad_dynamics_flightmare import FlightmareDynamics
+    from .dynamics.quad_dynamics_trained import LearntDynamics
+    modified_params = config["modified_params"]
+    config["sample_in"] = "train_env"
+    trainer = TrainDrone(LearntDynamics(), FlightmareDynamics(modified_params),
+                         config)
+    trainer.initialize_model(base_model, modified_params=modified_params,
+                             device=device)
+    trainer.run_dynamics(config)
+    return trainer
+
+
+def train_sampling_finetune(base_model, config, device=None):
+    """scripts/train_drone.py:281-300: train in the nominal simulator on
+    states visited in the modified one (self play samples from `eval_env`)."""
+    from .dynamics.quad_dynamics_flightmare import FlightmareDynamics
+    modified_params = config["modified_params"]
+    config["sample_in"] = "eval_env"
+    trainer = TrainDrone(FlightmareDynamics(),
+                         FlightmareDynamics(modified_params=modified_params),
+                         config)
+    trainer.initialize_model(base_model, modified_params=modified_params,
+                             device=device)
+    trainer.run_control(config, sampling_based_finetune=True)
     return trainer

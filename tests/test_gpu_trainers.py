@@ -504,6 +504,57 @@ def test_learnt_dynamics_matches_reference(dev):
     assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0]
 
 
+def test_controller_through_learnt_dynamics_is_not_fused(dev):
+    """N3, controller phase of run_dynamics: with a learnable simulator the
+    step-by-step unroll runs (the fused analytic rollout would ignore the
+    action transform and the residual network).  A freshly initialised
+    LearntDynamics IS the analytic simulator (identity transform, zero
+    residual), so loss and policy gradients must equal the fused step's; after
+    perturbing the learnt parts they must differ, and the learnt parameters
+    receive gradients."""
+    import copy
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_trained import (
+        LearntDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    B = 96
+    d = synthetic.quad_polynomial_batch(B, 10, 0.1, seed=77)
+    state0, in_ref, ref = (d["state0"].to(dev), d["in_ref"].to(dev),
+                           d["ref"].to(dev))
+    torch.manual_seed(5)
+    base = Net(15, 10, 9, 40, conv=1)
+    learnt = LearntDynamics().to(dev)
+
+    def one_step(train_dynamics):
+        t = TrainDrone(train_dynamics, FlightmareDynamics(), dict(QUAD_CFG))
+        t.net = copy.deepcopy(base).to(dev)
+        t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=0.0)
+        in_state = state_preprocessing(state0)
+        fused = t.train_concurrent_fused(in_state, state0, in_ref, ref)
+        if fused is not None:
+            return float(fused), {k: N(p.grad) for k, p in t.net.named_parameters()}
+        actions = torch.sigmoid(t.net(in_state, in_ref)).reshape(B, 10, 4)
+        loss = t.train_controller_model(state0, actions, in_ref, ref)
+        return float(loss), {k: N(p.grad) for k, p in t.net.named_parameters()}
+
+    l_fused, g_fused = one_step(FlightmareDynamics())
+    l_learnt, g_learnt = one_step(learnt)
+    assert abs(l_fused - l_learnt) <= 1e-4 * abs(l_fused)
+    for k in g_fused:
+        assert rel_err(g_learnt[k], g_fused[k]) < 2e-4, k
+    assert learnt.linear_at.grad is not None
+    assert float(learnt.linear_state_2.bias.grad.abs().sum()) > 0
+    with torch.no_grad():
+        learnt.linear_at.add_(0.05 * torch.randn(4, 4, device=dev))
+        learnt.linear_state_2.bias.add_(0.01)
+    l_pert, _ = one_step(learnt)
+    assert abs(l_pert - l_fused) > 1e-3 * abs(l_fused)
+
+
 @pytest.mark.parametrize("B", [1, 100, 129])
 def test_fused_lstm_ragged_batches_match_unfused(dev, B):
     """K7 on batch sizes that do not fill a workgroup: loss and parameter

@@ -333,3 +333,128 @@ def test_evaluator_statistics_and_self_play_selection(monkeypatch):
     i, k = picked[3]
     ws = min(k + 1, L - 10)
     assert torch.equal(rec.windows[3], traj[i, ws:ws + 10])
+
+
+def _loop_trainer(tmp_path, **cfg):
+    """A TrainDrone whose epoch / evaluation are recorded stubs: only the
+    scheduling logic of run_control / run_dynamics runs."""
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    config = dict(delta_t=0.1, speed_factor=0.6, thresh_div_start=1, **cfg)
+    t = TrainDrone(None, None, config)
+    t.save_path = str(tmp_path)
+    t.net = torch.nn.Linear(2, 2)
+    t.log = []
+
+    class Data:
+        num_sampled_states, resampled = 11, 0
+        def resample_data(self):
+            self.resampled += 1
+    t.state_data = Data()
+    t.run_epoch = lambda train="controller", epoch=0: t.log.append((epoch, train))
+    return t
+
+
+def test_run_dynamics_schedule_and_outputs(tmp_path):
+    """scripts/train_base.py:334-375: dynamics epochs first (every
+    train_dyn_every-th up to train_dyn_for_epochs), then the controller; the
+    score restarts when the controller phase begins; finalize writes weights
+    and the loss table."""
+    t = _loop_trainer(tmp_path)
+    t.current_score = 123
+    t.count_finetune_data = 40
+    t.run_dynamics(dict(nr_epochs=7, train_dyn_for_epochs=3, train_dyn_every=2))
+    assert t.log == [(0, "dynamics"), (1, "controller"), (2, "dynamics"),
+                     (3, "controller"), (4, "controller"), (5, "controller"),
+                     (6, "controller")]
+    assert t.current_score == 0
+    assert t.results_dict["samples_in_d2"] == [40] * 7
+    # no evaluation hook for this net: the loop resamples itself (every 3rd epoch)
+    assert t.state_data.resampled == 2 and t.sampled_data_count == 22
+    assert os.path.exists(tmp_path / "model_quad")
+    assert os.path.exists(tmp_path / "loss.csv")
+    assert not os.path.exists(tmp_path / "mean_successes.csv")   # nothing evaluated
+
+
+def test_speed_curriculum_and_checkpoints(tmp_path):
+    """run_control with curriculum (scripts/train_base.py:289-332): speed
+    starts at 0.2 and rises by 0.1 (below 0.4) once more than five
+    evaluations are in and the last five all exceed a full reference's steps
+    (1000 / (speed / dt)); thresh_div restarts at 0.1; checkpoints are
+    written for every evaluated epoch but the first (:233-243)."""
+    t = _loop_trainer(tmp_path)
+    t.config["thresh_div"] = 1.0
+    speeds = []
+
+    def evaluate(epoch):
+        speeds.append(round(t.config["speed_factor"], 2))
+        t.results_dict["mean_success"].append(1e4)   # always flies to the end
+        t.save_model(epoch, 1e4, 0.0)
+        return 1e4, 0.0
+    t.evaluate_model = evaluate
+    t.run_control(dict(nr_epochs=16), curriculum=1)
+    # epochs 0-5 at 0.2 (six successes needed), 6-11 at 0.3, then 0.4 stays
+    assert speeds == [0.2] * 6 + [0.3] * 6 + [0.4] * 4
+    assert t.config["thresh_div"] == 0.1
+    assert not os.path.exists(tmp_path / "model_quad0")
+    assert all(os.path.exists(tmp_path / f"model_quad{e}") for e in range(1, 16))
+    assert os.path.exists(tmp_path / "mean_successes.csv")
+    assert [e for e, _ in t.log] == list(range(16))
+    # a controller that never masters the speed keeps it (no 100-epoch timeout yet)
+    t2 = _loop_trainer(tmp_path)
+
+    def evaluate_bad(epoch):
+        t2.results_dict["mean_success"].append(3.0)
+        return 3.0, 0.0
+    t2.evaluate_model = evaluate_bad
+    t2.run_control(dict(nr_epochs=8), curriculum=1)
+    assert round(t2.config["speed_factor"], 2) == 0.2
+
+
+def test_learnt_train_dynamics_is_unrolled_step_by_step(monkeypatch):
+    """A learnable simulator (nn.Module) must not be replaced by the fused
+    analytic rollout: train_controller_model unrolls through its forward
+    (scripts/train_drone.py:185-191) and none of the fused paths is offered."""
+    from apg_trajectory_tracking_amd import train_drone
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from oracle import torch_port as tp
+
+    class Learnt(torch.nn.Module):
+        params = object()            # inherited analytic block, as LearntDynamics has
+        def __init__(self):
+            super().__init__()
+            self.gain = torch.nn.Parameter(torch.tensor(0.5))
+            self.calls = 0
+        def forward(self, state, action, dt):
+            self.calls += 1
+            return state + dt * self.gain * action.sum(1, keepdim=True)
+
+    monkeypatch.setattr(train_drone, "quad_mpc_loss", tp.quad_mpc_loss)
+    dyn = Learnt()
+    t = train_drone.TrainDrone(dyn, None, dict(delta_t=0.1, horizon=10,
+                                               train_mode="concurrent"))
+    t.net = Net(15, 10, 9, 40, conv=1)
+    assert not t.analytic_train_dynamics()
+    assert t.train_concurrent_fused(None, None, None, None, probe=True) is False
+    t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=0.0)
+    g = torch.Generator().manual_seed(0)
+    state0 = torch.randn(5, 12, generator=g)
+    ref = torch.randn(5, 10, 9, generator=g)
+    in_state = torch.randn(5, 15, generator=g)
+    actions = torch.sigmoid(t.net(in_state, ref)).reshape(5, 10, 4)
+    loss = t.train_controller_model(state0, actions, ref, ref)
+    assert dyn.calls == 10
+    # the same unroll written out
+    s, states = state0, []
+    a = actions.detach()
+    for k in range(10):
+        s = s + 0.1 * 0.5 * a[:, k].sum(1, keepdim=True)
+        states.append(s)
+    want = tp.quad_mpc_loss(torch.stack(states, 1), ref, a)
+    assert abs(float(loss.detach()) - float(want)) <= 1e-5 * abs(float(want))
+    assert dyn.gain.grad is not None and t.net.fc_out.weight.grad is not None
+
+    for mode in ("autoregressive", "LSTM"):
+        t = train_drone.TrainDrone(dyn, None, dict(horizon=10, train_mode=mode))
+        t.net = (Net(15, 10, 9, 4, conv=1) if mode == "autoregressive" else
+                 train_drone.LSTM_NEW(15, 10, 9, 4, conv=1))
+        assert not t.recurrent_indexed_ok()
