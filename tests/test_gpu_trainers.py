@@ -536,14 +536,17 @@ def test_controller_through_learnt_dynamics_is_not_fused(dev):
         in_state = state_preprocessing(state0)
         fused = t.train_concurrent_fused(in_state, state0, in_ref, ref)
         if fused is not None:
-            return float(fused), {k: N(p.grad) for k, p in t.net.named_parameters()}
+            return float(fused), {k: N(p.grad) for k, p in
+                                  t.net.named_parameters() if p.grad is not None}
         actions = torch.sigmoid(t.net(in_state, in_ref)).reshape(B, 10, 4)
         loss = t.train_controller_model(state0, actions, in_ref, ref)
-        return float(loss), {k: N(p.grad) for k, p in t.net.named_parameters()}
+        return float(loss.detach()), {k: N(p.grad) for k, p in
+                             t.net.named_parameters() if p.grad is not None}
 
     l_fused, g_fused = one_step(FlightmareDynamics())
     l_learnt, g_learnt = one_step(learnt)
     assert abs(l_fused - l_learnt) <= 1e-4 * abs(l_fused)
+    assert set(g_fused) == set(g_learnt) and len(g_fused) >= 12
     for k in g_fused:
         assert rel_err(g_learnt[k], g_fused[k]) < 2e-4, k
     assert learnt.linear_at.grad is not None
