@@ -55,9 +55,14 @@ class QuadEvaluator:
         return F.quad_mlp_closed_loop(self.net, traj, self.dt,
                                       self.dynamics.params, **kw)
 
-    def reference_batch(self, nr_test, seed=42):
+    def reference_batch(self, nr_test, seed=None):
         """Counterpart of `Random.__init__` (random_traj.py:28-35): nr_test
-        trajectories, lifted by 3 m."""
+        trajectories, lifted by 3 m.  Like the reference (unseeded numpy
+        draws per run) every call gives NEW trajectories: `seed=None` takes
+        the seed from torch's global generator, so `torch.manual_seed` makes
+        an evaluation reproducible."""
+        if seed is None:
+            seed = int(torch.randint(2**31 - 1, (1,)))
         traj = synthetic.quad_eval_trajectories(
             nr_test, self.trajectory_length, self.dt, seed=seed,
             speed=self.speed_factor / .6)
@@ -66,11 +71,11 @@ class QuadEvaluator:
 
     def follow_trajectory(self, traj_type="rand", max_nr_steps=200,
                           thresh_stable=.4, thresh_div=3, trajectories=None,
-                          nr_test=1, **traj_args):
+                          nr_test=1, seed=None, **traj_args):
         if traj_type != "rand":
             raise ValueError("only the 'rand' reference is evaluated on the GPU")
         dev = next(self.net.parameters()).device
-        traj = (self.reference_batch(nr_test) if trajectories is None
+        traj = (self.reference_batch(nr_test, seed) if trajectories is None
                 else trajectories).to(dev)
         out = self._closed_loop(
             traj, max_steps=max_nr_steps, thresh_div=thresh_div,
@@ -108,7 +113,8 @@ class QuadEvaluator:
 
     def run_eval(self, reference="rand", nr_test=10, max_steps=251,
                  thresh_div=1, thresh_stable=1, return_dict=False,
-                 trajectories=None, dataset=None, take_every_x=1000, **kwargs):
+                 trajectories=None, dataset=None, take_every_x=1000, seed=None,
+                 **kwargs):
         """scripts/evaluate_drone.py:237-300, all runs in one launch.
         `dataset` (optional, with `add_eval_data`): self play - every
         take_every_x-th policy call, counted through the runs in order like
@@ -119,7 +125,7 @@ class QuadEvaluator:
         if reference != "rand":
             raise ValueError("only the 'rand' reference is evaluated on the GPU")
         dev = next(self.net.parameters()).device
-        traj = (self.reference_batch(nr_test) if trajectories is None
+        traj = (self.reference_batch(nr_test, seed) if trajectories is None
                 else trajectories).to(dev)
         with torch.no_grad():
             out = self._closed_loop(
