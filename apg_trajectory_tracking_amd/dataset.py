@@ -198,11 +198,15 @@ class SyntheticWingDataset:
         d = synthetic.wing_batch(self.num_sampled_states, self.horizon,
                                  self.dt, seed=self.seed + self._epoch)
         states = d["state0"]
-        self.normed_states = (
-            ((states - self.mean) / self.std)[:, 3:]).to(self.device)
-        self.states = states.to(self.device)
-        self.ref_states = d["ref"].to(self.device)
-        self.in_ref_states = (d["ref"][:, -1] - states[:, :3]).to(self.device)
+        fresh = dict(
+            normed_states=((states - self.mean) / self.std)[:, 3:],
+            states=states, ref_states=d["ref"],
+            in_ref_states=d["ref"][:, -1] - states[:, :3])
+        for name, t in fresh.items():
+            if hasattr(self, name):    # renew IN PLACE: the trainer's loader
+                getattr(self, name).copy_(t)   # holds these very tensors
+            else:
+                setattr(self, name, t.to(self.device))
 
     def resample_data(self):
         self._epoch += 1

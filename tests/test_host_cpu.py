@@ -458,3 +458,21 @@ def test_learnt_train_dynamics_is_unrolled_step_by_step(monkeypatch):
         t.net = (Net(15, 10, 9, 4, conv=1) if mode == "autoregressive" else
                  train_drone.LSTM_NEW(15, 10, 9, 4, conv=1))
         assert not t.recurrent_indexed_ok()
+
+
+def test_wing_resample_reaches_the_loader():
+    """resample_data must renew the tensors the trainer's TensorBatches holds
+    (scripts/train_base.py:220-231 resamples the data set the DataLoader
+    wraps), not rebind new ones."""
+    from apg_trajectory_tracking_amd.dataset import SyntheticWingDataset, TensorBatches
+    ds = SyntheticWingDataset(32, 20, 0.05, seed=1, device="cpu")
+    loader = TensorBatches((ds.normed_states, ds.states, ds.in_ref_states,
+                            ds.ref_states), 16, shuffle=False)
+    before = [t.clone() for t in loader.tensors]
+    ds.resample_data()
+    for old, now, attr in zip(before, loader.tensors,
+                              (ds.normed_states, ds.states, ds.in_ref_states,
+                               ds.ref_states)):
+        assert now is attr and not torch.equal(old, now)
+    first = next(iter(loader))
+    assert torch.equal(first[1], ds.states[:16])
