@@ -147,6 +147,8 @@ class TrainBase:
                 lr=self.learning_rate_dynamics,
                 momentum=0.9
             )
+            self.grad_sync_dynamics = GradAllReducer(
+                self.train_dynamics.parameters())
 
     def _step(self, loss):
         """backward -> (all-reduce) -> SGD step; returns the (global) loss."""
@@ -231,6 +233,8 @@ class TrainBase:
             (next_state_d1 - next_state_d2)**2
         ) + self.l2_lambda * l2_loss
         loss.backward()
+        if getattr(self, "grad_sync_dynamics", None) is not None:
+            loss = self.grad_sync_dynamics.sync(loss.detach())  # replicas stay equal
         self.optimizer_dynamics.step()
         self.results_dict["loss_dyn_per_step"].append(loss.detach())
         return loss
