@@ -1,6 +1,7 @@
 """Trainer-level parity on the GPU: the drop-in TrainDrone / TrainFixedWing /
 TrainCartpole against the golden train steps recorded from the reference
 trainer (tests/golden/make_golden.py G3, G4, G6) and against the oracle."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -1015,3 +1016,39 @@ def test_wing_train_controller_two_sgd_steps(dev, fused):
                     assert rel_err(N(p.grad), g["g1." + k]) < 1e-4, k
         for k, v in t.net.state_dict().items():
             assert rel_err(N(v), g[f"w{step}.{k}"]) < 1e-5, (step, k)
+
+
+@pytest.mark.filterwarnings("ignore::RuntimeWarning")   # mean of no complete run
+def test_train_control_and_train_dynamics_end_to_end(dev, tmp_path, monkeypatch):
+    """The reference's entry points (scripts/train_drone.py:241-278) run
+    through: evaluation (closed loop + self play) -> resampling -> epoch, for a
+    few epochs; run_dynamics fits the learnt simulator first and then trains the
+    controller through it, step by step."""
+    from apg_trajectory_tracking_amd import train_drone
+    monkeypatch.chdir(tmp_path)
+    cfg = dict(QUAD_CFG, epoch_size=256, batch_size=64, self_play=0.5,
+               self_play_every_x=3, nr_test=4, max_steps=30, nr_epochs=4,
+               resample_every=2, thresh_div_start=1.0, thresh_div_end=2.0,
+               thresh_stable_start=1.0, learning_rate_controller=1e-6,
+               save_name="e2e")
+    torch.manual_seed(0)
+    t = train_drone.train_control(None, dict(cfg), device=dev)
+    assert len(t.results_dict["loss"]) == 1 + 4
+    assert all(np.isfinite(t.results_dict["loss"]))
+    assert len(t.results_dict["mean_success"]) == 4
+    assert t.state_data.eval_counter == 4 * (4 * 30 // 3)
+    assert t.sampled_data_count == 2 * 256
+    out = tmp_path / "trained_models" / "quad" / "e2e"
+    assert sorted(os.listdir(out)) == ["loss.csv", "mean_successes.csv", "model_quad",
+                                       "model_quad1", "model_quad2", "model_quad3"]
+    sd = torch.load(out / "model_quad", map_location="cpu")
+    assert sd["fc_out.weight"].shape == (40, 64)
+
+    cfg2 = dict(cfg, nr_epochs=3, train_dyn_for_epochs=1, save_name="e2e_dyn",
+                learning_rate_dynamics=1e-5, l2_lambda=0.01,
+                modified_params={"rotational_drag": [.01, .02, .03]})
+    t2 = train_drone.train_dynamics(None, dict(cfg2), device=dev)
+    assert t2.results_dict["trained"] == ["dynamics", "dynamics", "controller"]
+    assert all(np.isfinite(t2.results_dict["loss"]))
+    assert t2.count_finetune_data == 2 * 384
+    assert len(t2.results_dict["mean_success"]) == 3     # flown in the analytic env
