@@ -50,3 +50,21 @@ def build_policy(system, state_dict, conv=True):
                   conv=conv)
     net.load_state_dict(sd)
     return net
+
+
+def load_policy(path, system="quad", conv=True):
+    """Policy from a checkpoint FILE holding a state_dict (what this package
+    writes; a reference pickle converted by reference_pickle_to_state_dict).
+    A reference whole-module pickle is refused with a pointer to the
+    converter rather than unpickled blindly."""
+    try:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:
+        raise ValueError(
+            f"{path} is not a state_dict checkpoint ({type(e).__name__}); "
+            "convert reference pickles with "
+            "checkpoint.reference_pickle_to_state_dict where the reference "
+            "is importable") from e
+    if not isinstance(sd, dict):
+        raise ValueError(f"{path}: expected a state_dict, got {type(sd).__name__}")
+    return build_policy(system, sd, conv=conv)

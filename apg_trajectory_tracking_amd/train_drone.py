@@ -13,6 +13,9 @@ recurrent  : the policy runs inside the loop, so each step is
              the reference writes through a view, which breaks autograd on
              torch 2.x and subtracts cumulatively).
 """
+import json
+import os
+
 import torch
 
 from . import functional as F
@@ -38,11 +41,20 @@ class TrainDrone(TrainBase):
         self.fused_policy = True
 
     def initialize_model(self, base_model=None, modified_params={},
-                         state_data=None, device=None, seed=0):
-        """Policy + dataset + optimizer.  `state_data` defaults to the seeded
-        synthetic polynomial set (the reference samples `data/traj_data_1`,
-        which upstream does not ship)."""
+                         state_data=None, device=None, seed=0,
+                         base_model_name="model_quad"):
+        """Policy + dataset + optimizer (scripts/train_drone.py:51-112).
+        `base_model`: a module, or - as in the reference - the directory of a
+        trained model (`<dir>/model_quad`, here a state_dict checkpoint, see
+        checkpoint.py).  `state_data` defaults to the seeded synthetic
+        polynomial set (the reference samples `data/traj_data_1`, which
+        upstream does not ship).  The run's parameters are written to
+        `<save_path>/config.json` like the reference does."""
         device = torch.device(device or "cuda")
+        if isinstance(base_model, (str, os.PathLike)):
+            from .checkpoint import load_policy
+            base_model = load_policy(os.path.join(base_model, base_model_name),
+                                     conv=True)
         if state_data is None:
             state_data = SyntheticQuadDataset(
                 self.epoch_size, self.horizon, self.delta_t,
@@ -62,7 +74,17 @@ class TrainDrone(TrainBase):
             self.train_dynamics.to(device)     # learnable simulator (N3)
         self.config["ref_length"] = self.ref_length
         self.config["dt"] = self.delta_t
-        self.config["modified_params"] = modified_params
+        self.config["take_every_x"] = self.self_play_every_x
+        self.config["thresh_div"] = self.thresh_div_start
+        self.config["thresh_stable"] = self.thresh_stable_start
+        self.config["mean"] = torch.as_tensor(self.state_data.mean).tolist()
+        self.config["std"] = torch.as_tensor(self.state_data.std).tolist()
+        self.config["modified_params"] = {
+            k: (v.tolist() if hasattr(v, "tolist") else v)
+            for k, v in modified_params.items()}
+        os.makedirs(self.save_path, exist_ok=True)
+        with open(os.path.join(self.save_path, "config.json"), "w") as f:
+            json.dump(self.config, f, default=str)
         self.init_optimizer()
 
     def train_recurrent_model(

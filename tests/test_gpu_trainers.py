@@ -1039,8 +1039,9 @@ def test_train_control_and_train_dynamics_end_to_end(dev, tmp_path, monkeypatch)
     assert t.state_data.eval_counter == 4 * (4 * 30 // 3)
     assert t.sampled_data_count == 2 * 256
     out = tmp_path / "trained_models" / "quad" / "e2e"
-    assert sorted(os.listdir(out)) == ["loss.csv", "mean_successes.csv", "model_quad",
-                                       "model_quad1", "model_quad2", "model_quad3"]
+    assert sorted(os.listdir(out)) == ["config.json", "loss.csv", "mean_successes.csv",
+                                       "model_quad", "model_quad1", "model_quad2",
+                                       "model_quad3"]
     sd = torch.load(out / "model_quad", map_location="cpu")
     assert sd["fc_out.weight"].shape == (40, 64)
 
