@@ -4,35 +4,33 @@ Linear over the flattened window), three 64-wide tanh layers, linear head."""
 import torch
 import torch.nn as nn
 
+from .common import (CONV_CHANNELS, CONV_KERNEL, DENSE_WIDTH, encode_window,
+                     window_feature_count)
+
 
 class Net(nn.Module):
 
     def __init__(self, state_dim, horizon, ref_dim, nr_actions_predict,
                  conv=True):
         super().__init__()
-        self.horizon = horizon
-        self.conv = conv
-        self.reshape_len = 20 * (horizon - 2) if conv else 64
-        self.states_in = nn.Linear(state_dim, 64)
-        self.conv_ref = nn.Conv1d(ref_dim, 20, kernel_size=3)
-        self.ref_in = nn.Linear(horizon * ref_dim, 64)  # used when conv=False
-        self.fc1 = nn.Linear(64 + self.reshape_len, 64)
-        self.fc2 = nn.Linear(64, 64)
-        self.fc3 = nn.Linear(64, 64)
-        self.fc_out = nn.Linear(64, nr_actions_predict)
+        W = DENSE_WIDTH
+        self.horizon, self.conv = horizon, conv
+        self.reshape_len = window_feature_count(horizon, conv)
+        # registration order = the reference's state_dict order
+        self.states_in = nn.Linear(state_dim, W)
+        self.conv_ref = nn.Conv1d(ref_dim, CONV_CHANNELS, kernel_size=CONV_KERNEL)
+        self.ref_in = nn.Linear(horizon * ref_dim, W)     # conv=False branch
+        self.fc1 = nn.Linear(W + self.reshape_len, W)
+        self.fc2, self.fc3 = nn.Linear(W, W), nn.Linear(W, W)
+        self.fc_out = nn.Linear(W, nr_actions_predict)
 
     def trunk(self, state, ref):
         """Everything up to (not including) the output layer: [B,64]."""
-        s = torch.tanh(self.states_in(state))
-        if self.conv:
-            r = torch.relu(self.conv_ref(ref.transpose(1, 2)))
-            r = r.reshape(-1, self.reshape_len)
-        else:
-            r = torch.tanh(self.ref_in(ref))
-        x = torch.cat((s, r), dim=1)
-        x = torch.tanh(self.fc1(x))
-        x = torch.tanh(self.fc2(x))
-        return torch.tanh(self.fc3(x))
+        x = torch.cat((torch.tanh(self.states_in(state)),
+                       encode_window(self, ref)), dim=1)
+        for layer in (self.fc1, self.fc2, self.fc3):
+            x = torch.tanh(layer(x))
+        return x
 
     def forward(self, state, ref):
         """state [B,state_dim], ref [B,horizon,ref_dim] -> [B,nr_actions]."""

@@ -7,44 +7,40 @@ the steps of one unroll and re-drawn from N(0,1) by reset_hidden_state()
 import torch
 import torch.nn as nn
 
+from .common import (CONV_CHANNELS, CONV_KERNEL, DENSE_WIDTH, encode_window,
+                     window_feature_count)
+
+HIDDEN = 8     # LSTM units
+
 
 class LSTM_NEW(nn.Module):
 
     def __init__(self, state_dim, horizon, ref_dim, nr_actions_predict,
                  conv=True):
         super().__init__()
-        self.state_dim = state_dim
-        self.ref_dim = ref_dim
-        self.horizon = horizon
-        self.conv = conv
-        self.reshape_len = 20 * (horizon - 2) if conv else 64
-        self.conv_ref = nn.Conv1d(ref_dim, 20, kernel_size=3)
-        self.ref_in = nn.Linear(horizon * ref_dim, 64)
-        self.fc_out = nn.Linear(8, nr_actions_predict)
-        self.lstm = nn.LSTMCell(state_dim + self.reshape_len, 8)
-        self.hidden_state = None
-        self.cell_state = None
+        self.state_dim, self.ref_dim = state_dim, ref_dim
+        self.horizon, self.conv = horizon, conv
+        self.reshape_len = window_feature_count(horizon, conv)
+        # registration order = the reference's state_dict order
+        self.conv_ref = nn.Conv1d(ref_dim, CONV_CHANNELS, kernel_size=CONV_KERNEL)
+        self.ref_in = nn.Linear(horizon * ref_dim, DENSE_WIDTH)
+        self.fc_out = nn.Linear(HIDDEN, nr_actions_predict)
+        self.lstm = nn.LSTMCell(state_dim + self.reshape_len, HIDDEN)
+        self.hidden_state = self.cell_state = None
         self.reset_hidden_state(1)
 
     def reset_hidden_state(self, batch_size=1, generator=None):
+        """Fresh (h, c) ~ N(0, 1), [batch_size, 8] each, h drawn first."""
         dev = self.fc_out.weight.device
-        if generator is None:
-            self.hidden_state = torch.randn(batch_size, 8, device=dev)
-            self.cell_state = torch.randn(batch_size, 8, device=dev)
-        else:  # draw on the generator's device, then move
-            gdev = generator.device
-            self.hidden_state = torch.randn(
-                batch_size, 8, generator=generator, device=gdev).to(dev)
-            self.cell_state = torch.randn(
-                batch_size, 8, generator=generator, device=gdev).to(dev)
+        # with a generator: draw on ITS device, then move
+        where = dev if generator is None else generator.device
+        draw = lambda: torch.randn(batch_size, HIDDEN, generator=generator,
+                                   device=where).to(dev)
+        self.hidden_state = draw()
+        self.cell_state = draw()
 
     def forward(self, state, ref):
-        if self.conv:
-            r = torch.relu(self.conv_ref(ref.transpose(1, 2)))
-            r = r.reshape(-1, self.reshape_len)
-        else:
-            r = torch.tanh(self.ref_in(ref))
-        x = torch.cat((state, r), dim=1)
-        self.hidden_state, self.cell_state = self.lstm(
-            x, (self.hidden_state, self.cell_state))
+        x = torch.cat((state, encode_window(self, ref)), dim=1)
+        carry = self.lstm(x, (self.hidden_state, self.cell_state))
+        self.hidden_state, self.cell_state = carry
         return self.fc_out(self.hidden_state)
