@@ -516,3 +516,43 @@ def test_initialize_model_from_checkpoint_directory(tmp_path, monkeypatch):
     torch.save(src, tmp_path / "pretrained" / "model_pickled")
     with pytest.raises(ValueError, match="not a state_dict checkpoint"):
         checkpoint.load_policy(tmp_path / "pretrained" / "model_pickled")
+
+
+def test_bench_line_contract():
+    """The committed bench lines (profiles/) carry every field the driver's
+    contract names, with consistent arithmetic; bench.py refuses to run
+    without a GPU or with --gpus N outside torch.distributed.run."""
+    import json
+    import subprocess
+    import sys
+    for name in ("r01_bench.json", "r01_bench_anomaly.json"):
+        d = json.load(open(os.path.join(REPO, "profiles", name)))
+        for key, typ in (("metric", str), ("value", float), ("unit", str),
+                         ("n_gpus", int), ("steps", int), ("warmup", int),
+                         ("ms_per_step", float), ("higher_is_better", bool),
+                         ("scaling", str), ("dtype", str), ("data", str),
+                         ("config", dict), ("roofline", dict),
+                         ("cpu_baseline", dict)):
+            assert isinstance(d[key], typ), (name, key)
+        assert "vs_baseline" in d and d["vs_baseline"] is None
+        assert d["dtype"] == "f32" and d["scaling"] == "weak"
+        assert "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        B, H = d["config"]["batch_per_gpu"], d["config"]["horizon"]
+        assert r["algorithmic_bytes_per_launch"] == B * (48 + 56 * H)   # SURVEY §8(d)
+        assert abs(d["value"] - d["n_gpus"] * B * H / (d["ms_per_step"] * 1e-3)) \
+            < 1e-6 * d["value"]
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1
+        assert isinstance(c["sample"], str) and c["value"] > 0
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
