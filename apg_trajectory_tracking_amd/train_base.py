@@ -229,9 +229,12 @@ class TrainBase:
                 torch.norm(self.train_dynamics.linear_state_1.weight) +
                 torch.norm(self.train_dynamics.linear_state_1.bias)
             )
+        # data parallel: the data term is a sum over the shard, the weight
+        # penalty is not - each rank carries 1/world of it so that the summed
+        # gradient equals the single-process one
         loss = torch.sum(
             (next_state_d1 - next_state_d2)**2
-        ) + self.l2_lambda * l2_loss
+        ) + self.l2_lambda * l2_loss / parallel.world_size()
         loss.backward()
         if getattr(self, "grad_sync_dynamics", None) is not None:
             loss = self.grad_sync_dynamics.sync(loss.detach())  # replicas stay equal

@@ -93,6 +93,39 @@ def _one_step_direct(trainer, lo, hi):
         d.ref_states[lo:hi])
 
 
+class _ToyLearntDynamics(torch.nn.Module):
+    """Stand-in for LearntDynamics on CPU: learnable, with the two residual
+    layers train_dynamics_model penalises."""
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.linear_state_1 = torch.nn.Linear(16, 8)
+        self.linear_state_2 = torch.nn.Linear(8, 12)
+
+    def forward(self, state, action, dt):
+        x = torch.cat((state, action), 1)
+        return state + dt * self.linear_state_2(torch.tanh(self.linear_state_1(x)))
+
+
+def _dynamics_steps(lo, hi):
+    """Two train_dynamics_model steps on rows [lo, hi) of the data set."""
+    from oracle import torch_port as tp
+    trainer = _make_trainer()
+    trainer.train_dynamics = _ToyLearntDynamics()
+    trainer.eval_dynamics = tp.QuadOracle()
+    trainer.l2_lambda = 0.1
+    trainer.learning_rate_dynamics = 1e-3
+    trainer.init_optimizer()
+    d = trainer.state_data
+    with torch.no_grad():
+        acts = torch.sigmoid(trainer.net(d.normed_states[lo:hi],
+                                         d.in_ref_states[lo:hi])).reshape(-1, H, 4)
+    losses = [float(trainer.train_dynamics_model(d.states[lo:hi], acts))
+              for _ in range(2)]
+    return losses, {k: v.numpy() for k, v in
+                    trainer.train_dynamics.state_dict().items()}
+
+
 def _worker(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, REPO)
@@ -114,6 +147,10 @@ def _worker(rank, world, port, out_dir):
         losses = [float(_one_step_direct(trainer, lo, hi)) for _ in range(2)]
         sd = {k: v.numpy() for k, v in trainer.net.state_dict().items()}
         np.savez(os.path.join(out_dir, f"direct_rank{rank}.npz"),
+                 losses=np.array(losses), **sd)
+        # the simulator fit (N3): its gradients are all-reduced too
+        losses, sd = _dynamics_steps(lo, hi)
+        np.savez(os.path.join(out_dir, f"dyn_rank{rank}.npz"),
                  losses=np.array(losses), **sd)
     finally:
         dist.destroy_process_group()
@@ -138,6 +175,14 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
         np.testing.assert_allclose(g["losses"], ref_losses, rtol=1e-5)
         for k, v in ref.net.state_dict().items():
             assert rel_err(g[k], v.numpy()) < 1e-5, (r, k)
+
+
+    ref_losses, ref_sd = _dynamics_steps(0, B)      # train_dynamics_model
+    for r in range(world):
+        g = np.load(tmp_path / f"dyn_rank{r}.npz")
+        np.testing.assert_allclose(g["losses"], ref_losses, rtol=1e-5)
+        for k, v in ref_sd.items():
+            assert rel_err(g[k], v) < 1e-5, (r, k)
 
 
 def test_grad_allreducer_is_noop_single_process():
