@@ -23,7 +23,6 @@ EXTRA_FLAGS = {}
 HEADERS = [os.path.join(CSRC, "apg_device.h"),
            os.path.join(CSRC, "quad_math.h"),
            os.path.join(CSRC, "policy_mfma.h"),
-           os.path.join(CSRC, "quad_lane_pk.h"),
            os.path.join(REPO, "include", "apg.h")]
 
 

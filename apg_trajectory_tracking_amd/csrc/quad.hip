@@ -18,7 +18,6 @@
 // All of it is per-trajectory elementwise work: HBM-bound, no MFMA.
 #include "apg_device.h"
 #include "quad_math.h"
-#include "quad_lane_pk.h"
 
 namespace apg {
 namespace {
@@ -226,64 +225,6 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
       store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
     }
   }
-  write_wave_partial(A.loss_partials, live ? loss : 0.f);
-  if (reducer) reduce_prev_tail(A.prev, pp);
-}
-
-// The same launch with the per-trajectory work written on float pairs
-// (quad_lane_pk.h: packed fp32 instructions, regrouped adjoint): SoA planes
-// through buffer resources only.  Selected by launch_rollout when the
-// library is built with -DAPG_QUAD_PK.
-struct PlaneIO {
-  SoaPlanes s0_, act_, ref_, ga_, gs_, so_;
-  int ref_cols, vel_col;
-  bool live;
-  __device__ __forceinline__ float s0(int i) const { return s0_.ld(i); }
-  __device__ __forceinline__ float act(int k, int i) const {
-    return act_.ld(k * 4 + i);
-  }
-  __device__ __forceinline__ float ref_p(int k, int i) const {
-    return ref_.ld(k * ref_cols + i);
-  }
-  __device__ __forceinline__ float ref_v(int k, int i) const {
-    return ref_.ld(k * ref_cols + vel_col + i);
-  }
-  __device__ __forceinline__ void ga(int k, int i, float v) const {
-    if (live) ga_.st(k * 4 + i, v);
-  }
-  __device__ __forceinline__ void gs(int i, float v) const {
-    if (live) gs_.st(i, v);
-  }
-  __device__ __forceinline__ void state(int k, int i, float v) const {
-    if (live) so_.st(k * 12 + i, v);
-  }
-};
-
-template <int HT, bool STATES_OUT>
-__global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_pk_kernel(
-    RolloutArgs A) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = b < A.B;
-  const int bb = live ? b : A.B - 1;  // keep the wave convergent for the reduce
-  pk::Const c;
-  c.dt = A.c.dt, c.hd = A.c.half_dt, c.hd2 = A.c.half_dt2;
-  c.g01 = (pk::f2){A.c.g[0], A.c.g[1]}, c.g2 = A.c.g[2];
-  c.kdt01 = (pk::f2){A.c.kdt[0], A.c.kdt[1]}, c.kdt2 = A.c.kdt[2];
-  c.wd01 = (pk::f2){A.c.wd[0], A.c.wd[1]}, c.wd2 = A.c.wd[2];
-  const bool reducer = blockIdx.x == 0 && threadIdx.x < kWave &&
-                       A.prev.prev_partials != nullptr;
-  PrevPartials pp;
-  if (reducer) reduce_prev_head(A.prev, pp);
-  __builtin_amdgcn_sched_barrier(0);
-  PlaneIO io{SoaPlanes(A.state0, 12, A.B, bb),
-             SoaPlanes(A.actions, HT * 4, A.B, bb),
-             SoaPlanes(A.ref, HT * A.ref_cols, A.B, bb),
-             SoaPlanes(A.grad_actions, HT * 4, A.B, bb),
-             SoaPlanes(A.grad_state0, 12, A.B, bb),
-             SoaPlanes(A.states_out, HT * 12, A.B, bb),
-             A.ref_cols, A.vel_col, live};
-  const float loss =
-      pk::rollout_lane<HT, STATES_OUT>(io, c, A.w, A.grad_state0 != nullptr);
   write_wave_partial(A.loss_partials, live ? loss : 0.f);
   if (reducer) reduce_prev_tail(A.prev, pp);
 }
@@ -616,27 +557,19 @@ int launch_rollout(const RolloutArgs &A, hipStream_t st) {
       return check_launch("quad_rollout_fwd_bwd");
     }
   }
-#ifdef APG_QUAD_PK
-#define APG_SOA_ROLLOUT(HT) \
-  hipLaunchKernelGGL((quad_rollout_pk_kernel<HT, SO>), grid, block, 0, st, A)
-#else
-#define APG_SOA_ROLLOUT(HT)                                                   \
-  hipLaunchKernelGGL(                                                         \
-      (quad_rollout_reg_kernel<LAYOUT, HT, SO, LAYOUT == APG_LAYOUT_SOA>),    \
-      grid, block, 0, st, A)
-#endif
   switch (A.H) {
 #define APG_CASE(HT)                                                          \
   case HT:                                                                    \
     if (LAYOUT == APG_LAYOUT_SOA && buf_ok)                                   \
-      APG_SOA_ROLLOUT(HT);                                                    \
+      hipLaunchKernelGGL(                                                     \
+          (quad_rollout_reg_kernel<LAYOUT, HT, SO, LAYOUT == APG_LAYOUT_SOA>), \
+          grid, block, 0, st, A);                                             \
     else                                                                      \
       hipLaunchKernelGGL((quad_rollout_reg_kernel<LAYOUT, HT, SO, false>),    \
                          grid, block, 0, st, A);                              \
     break;
     APG_CASE(5) APG_CASE(10)  // register-resident horizons (reference configs)
 #undef APG_CASE
-#undef APG_SOA_ROLLOUT
     default: {
       const size_t lds = (size_t)A.H * 12 * APG_ROLLOUT_BLOCK * sizeof(float);
       if (lds > 64 * 1024 &&
