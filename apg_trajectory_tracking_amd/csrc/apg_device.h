@@ -144,8 +144,9 @@ struct SoaPlanes {
 // see DESIGN.md); beyond ~1e6 rad accuracy degrades gracefully, NaN/Inf give
 // NaN.  ~30 VALU ops and no control flow, so the three attitude angles of a
 // step interleave in the pipeline (libm's sincosf costs ~45 issued ops per
-// call plus branches that serialise them).
-__device__ __forceinline__ void sincos_fast(float x, float *sn, float *cs) {
+// call plus branches that serialise them).  Host-callable as well: tests/
+// compiles this arithmetic for the CPU (tests/host_math).
+__host__ __device__ __forceinline__ void sincos_fast(float x, float *sn, float *cs) {
   const float kf = rintf(x * 0.6366197466850281f);
   const int k = (int)kf;
   float r = fmaf(-kf, 1.5707963705062866f, x);
@@ -162,8 +163,10 @@ __device__ __forceinline__ void sincos_fast(float x, float *sn, float *cs) {
   const float c = fmaf(t * t, pc, fmaf(t, -0.5f, 1.0f));
   const bool swap = (k & 1) != 0;
   const float so = swap ? c : s, co = swap ? s : c;
-  *sn = __uint_as_float(__float_as_uint(so) ^ ((unsigned)(k & 2) << 30));
-  *cs = __uint_as_float(__float_as_uint(co) ^ ((unsigned)((k + 1) & 2) << 30));
+  *sn = __builtin_bit_cast(
+      float, __builtin_bit_cast(unsigned, so) ^ ((unsigned)(k & 2) << 30));
+  *cs = __builtin_bit_cast(
+      float, __builtin_bit_cast(unsigned, co) ^ ((unsigned)((k + 1) & 2) << 30));
 }
 
 // 1/x: hardware v_rcp_f32 (1 ulp) + one Newton step (~0.5 ulp) in 3 VALU ops

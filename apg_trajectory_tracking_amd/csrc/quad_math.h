@@ -1,6 +1,8 @@
 // quad_math.h - per-trajectory quadrotor arithmetic shared by the kernels of
-// quad.hip and lstm.hip (device functions only; see quad.hip for the closed
-// form and the reference lines it restates).
+// quad.hip, lstm.hip and mlp.hip (see quad.hip for the closed form and the
+// reference lines it restates).  The functions are host-callable too, so that
+// tests/host_math can run this very arithmetic on the CPU against the golden
+// vectors.
 #pragma once
 #include "apg_device.h"
 
@@ -18,7 +20,7 @@ struct Trig {
   float sr, cr, sp, cp, sy, cy;  // roll(phi) pitch(theta) yaw(psi)
 };
 
-__device__ __forceinline__ Trig make_trig(const float att[3]) {
+__host__ __device__ __forceinline__ Trig make_trig(const float att[3]) {
   Trig t;
   sincos_fast(att[0], &t.sr, &t.cr);
   sincos_fast(att[1], &t.sp, &t.cp);
@@ -26,19 +28,19 @@ __device__ __forceinline__ Trig make_trig(const float att[3]) {
   return t;
 }
 
-__device__ __forceinline__ float thrust_of(float a0) {
+__host__ __device__ __forceinline__ float thrust_of(float a0) {
   return a0 * 15.0f - 7.5f + 9.81f;  // quad_dynamics_flightmare.py:139
 }
 
 // thrust direction = third row of world_to_body (quad_dynamics_base.py:87-91)
-__device__ __forceinline__ void thrust_dir(const Trig &t, float z[3]) {
+__host__ __device__ __forceinline__ void thrust_dir(const Trig &t, float z[3]) {
   z[0] = t.cy * t.sp * t.cr + t.sr * t.sy;
   z[1] = t.cr * t.sy * t.sp - t.cy * t.sr;
   z[2] = t.cr * t.cp;
 }
 
 // s = [p(0:3), att(3:6), v(6:9), w(9:12)] updated in place.
-__device__ __forceinline__ void quad_step(float (&s)[12], const float (&a)[4],
+__host__ __device__ __forceinline__ void quad_step(float (&s)[12], const float (&a)[4],
                                           const QuadConst &c, const Trig &t) {
   float z[3];
   thrust_dir(t, z);
@@ -59,7 +61,7 @@ __device__ __forceinline__ void quad_step(float (&s)[12], const float (&a)[4],
 
 // Adjoint of quad_step.  lam = dL/d(next state) on entry, dL/d(state) on
 // exit; ga += dL/d(action) through the dynamics.
-__device__ __forceinline__ void quad_step_adjoint(float (&lam)[12],
+__host__ __device__ __forceinline__ void quad_step_adjoint(float (&lam)[12],
                                                   float (&ga)[4], float a0,
                                                   const float w[3],
                                                   const QuadConst &c,
@@ -124,7 +126,7 @@ QuadConst make_const(const ApgQuadParams &p, float dt) {
 struct Rot {
   float m[3][3];
 };
-__device__ __forceinline__ Rot world_to_body(const Trig &t) {
+__host__ __device__ __forceinline__ Rot world_to_body(const Trig &t) {
   Rot r;  // quad_dynamics_base.py:79-92
   r.m[0][0] = t.cy * t.cp, r.m[0][1] = t.sy * t.cp, r.m[0][2] = -t.sp;
   r.m[1][0] = t.cy * t.sp * t.sr - t.cr * t.sy;
@@ -137,7 +139,7 @@ __device__ __forceinline__ Rot world_to_body(const Trig &t) {
 }
 
 // state_preprocessing (neural_control/dataset.py:207-220) for one trajectory
-__device__ __forceinline__ void quad_features(const float (&s)[12], const Trig &t,
+__host__ __device__ __forceinline__ void quad_features(const float (&s)[12], const Trig &t,
                                               float (&f)[15]) {
   Rot r = world_to_body(t);
 #pragma unroll
@@ -150,7 +152,7 @@ __device__ __forceinline__ void quad_features(const float (&s)[12], const Trig &
 }
 
 // its VJP: gs = (d features / d state)^T gf  (position gets zero)
-__device__ __forceinline__ void quad_features_adjoint(const float (&s)[12],
+__host__ __device__ __forceinline__ void quad_features_adjoint(const float (&s)[12],
                                                       const Trig &t,
                                                       const float (&gf)[15],
                                                       float (&gs)[12]) {
