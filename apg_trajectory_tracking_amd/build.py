@@ -23,6 +23,8 @@ EXTRA_FLAGS = {}
 HEADERS = [os.path.join(CSRC, "apg_device.h"),
            os.path.join(CSRC, "quad_math.h"),
            os.path.join(CSRC, "policy_mfma.h"),
+           os.path.join(CSRC, "wing_math.h"),
+           os.path.join(CSRC, "cartpole_math.h"),
            os.path.join(REPO, "include", "apg.h")]
 
 

@@ -170,10 +170,24 @@ __host__ __device__ __forceinline__ void sincos_fast(float x, float *sn, float *
 }
 
 // 1/x: hardware v_rcp_f32 (1 ulp) + one Newton step (~0.5 ulp) in 3 VALU ops
-// instead of the ~10-op IEEE division sequence.
-__device__ __forceinline__ float rcp_nr(float x) {
+// instead of the ~10-op IEEE division sequence.  (Host builds - tests only -
+// start the same Newton step from the correctly rounded quotient.)
+__host__ __device__ __forceinline__ float rcp_nr(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
   const float r = __builtin_amdgcn_rcpf(x);
+#else
+  const float r = 1.0f / x;
+#endif
   return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
+// hardware v_sqrt_f32 (1 ulp); sqrtf on the host
+__host__ __device__ __forceinline__ float sqrt_fast(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
 }
 
 // ---- wave64 reduction -------------------------------------------------------

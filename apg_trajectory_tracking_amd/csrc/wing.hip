@@ -15,289 +15,11 @@
 #include <stdlib.h>
 
 #include "apg_device.h"
+#include "wing_math.h"
 
 namespace apg {
 namespace {
 
-struct WingConst {
-  float dt;
-  float half_rho, S, c, inv_mass, g_m;
-  float cos_eps, sin_eps, alpha_bound;
-  // coefficient tables; the rate derivatives are pre-multiplied by c or b as
-  // the reference does in double before touching a tensor (:139-164)
-  float CL0, CL_a, CL_qc, CL_de;
-  float CD0, CD_a, CD_qc, CD_de;
-  float CY0, CY_b, CY_pb, CY_rb, CY_da, CY_dr;
-  float Cl0, Cl_b, Cl_pb, Cl_rb, Cl_da, Cl_dr;
-  float Cm0, Cm_a, Cm_qc, Cm_de;
-  float Cn0, Cn_b, Cn_pb, Cn_rb, Cn_da, Cn_dr;
-  float Ixx, Iyy, Izz, a13;       // inertia matrix entries (a13 = -I_xz)
-  float i00, i02, i11, i22;       // its inverse
-};
-
-WingConst make_const(const ApgWingParams &p, float dt) {
-  WingConst k;
-  k.dt = dt;
-  k.half_rho = (float)(0.5 * (double)p.rho);
-  k.S = p.S, k.c = p.c;
-  k.inv_mass = (float)(1.0 / (double)p.mass);
-  k.g_m = (float)((double)p.g * (double)p.mass);
-  k.cos_eps = cosf(p.epsilon), k.sin_eps = sinf(p.epsilon);
-  k.alpha_bound = (float)(10.0 / 180.0 * 3.14159265358979323846);
-  const double c = p.c, b = p.b;
-  k.CL0 = p.CL0, k.CL_a = p.CL_alpha, k.CL_qc = (float)(p.CL_q * c), k.CL_de = p.CL_del_e;
-  k.CD0 = p.CD0, k.CD_a = p.CD_alpha, k.CD_qc = (float)(p.CD_q * c), k.CD_de = p.CD_del_e;
-  k.CY0 = p.CY0, k.CY_b = p.CY_beta, k.CY_pb = (float)(p.CY_p * b);
-  k.CY_rb = (float)(p.CY_r * b), k.CY_da = p.CY_del_a, k.CY_dr = p.CY_del_r;
-  k.Cl0 = p.Cl0, k.Cl_b = p.Cl_beta, k.Cl_pb = (float)(p.Cl_p * b);
-  k.Cl_rb = (float)(p.Cl_r * b), k.Cl_da = p.Cl_del_a, k.Cl_dr = p.Cl_del_r;
-  k.Cm0 = p.Cm0, k.Cm_a = p.Cm_alpha, k.Cm_qc = (float)(p.Cm_q * c), k.Cm_de = p.Cm_del_e;
-  k.Cn0 = p.Cn0, k.Cn_b = p.Cn_beta, k.Cn_pb = (float)(p.Cn_p * b);
-  k.Cn_rb = (float)(p.Cn_r * b), k.Cn_da = p.Cn_del_a, k.Cn_dr = p.Cn_del_r;
-  k.Ixx = p.I_xx, k.Iyy = p.I_yy, k.Izz = p.I_zz, k.a13 = -p.I_xz;
-  const double det = (double)p.I_xx * p.I_zz - (double)p.I_xz * p.I_xz;
-  k.i00 = (float)(p.I_zz / det), k.i22 = (float)(p.I_xx / det);
-  k.i02 = (float)((double)p.I_xz / det);  // -a13 / det
-  k.i11 = (float)(1.0 / (double)p.I_yy);
-  return k;
-}
-
-constexpr float kPi = 3.14159265358979323846f;
-
-// Everything the adjoint re-uses from the forward evaluation of one step.
-struct WingAux {
-  float T, de, da, dr;
-  float V, V2, iV, r2V, tw, tb;  // iV = 1/V, tw = w/u, tb = v/V
-  float alpha, beta;
-  bool alpha_free, beta_free;    // clamp passes the gradient
-  float sa, ca, sb, cb;
-  float CL, CD, CY, Cl, Cm, Cn, Q;
-  float L, D, Y;
-  float sph, cph, sth, cth, sps, cps, icth;
-  float R[3][3];                 // rows as assembled at :80-91
-  float h0, h1, h2;              // I * omega
-};
-
-// Evaluates state_dot (12) and fills aux.
-// (KT = const WingConst, possibly qualified with the constant address space)
-template <typename KT>
-__device__ __forceinline__ void wing_rates(const float (&s)[12],
-                                           const float (&a)[4], KT &k,
-                                           WingAux &x, float (&sd)[12]) {
-  const float u = s[3], v = s[4], w = s[5];
-  const float p = s[9], q = s[10], r = s[11];
-  // normalize_action :41-46
-  x.T = a[0] * 7.f;
-  x.de = kPi * (a[1] * 40.f - 20.f) / 180.f;
-  x.da = kPi * (a[2] * 5.f - 2.5f) / 180.f;
-  x.dr = kPi * (a[3] * 40.f - 20.f) / 180.f;
-  // :130-134
-  x.V2 = u * u + v * v + w * w;
-  x.V = __builtin_amdgcn_sqrtf(x.V2);
-  x.iV = rcp_nr(x.V);
-  x.tw = w * rcp_nr(u);
-  x.tb = v * x.iV;
-  const float al = atanf(x.tw), be = atanf(x.tb);
-  x.alpha_free = (al >= -k.alpha_bound) && (al <= k.alpha_bound);
-  x.beta_free = (be >= -k.alpha_bound) && (be <= k.alpha_bound);
-  x.alpha = fminf(fmaxf(al, -k.alpha_bound), k.alpha_bound);
-  x.beta = fminf(fmaxf(be, -k.alpha_bound), k.alpha_bound);
-  x.r2V = 0.5f * x.iV;
-  // :139-164
-  x.CL = k.CL0 + k.CL_a * x.alpha + k.CL_qc * x.r2V * q + k.CL_de * x.de;
-  x.CD = k.CD0 + k.CD_a * x.alpha + k.CD_qc * x.r2V * q + k.CD_de * x.de;
-  x.CY = k.CY0 + k.CY_b * x.beta + k.CY_pb * x.r2V * p + k.CY_rb * x.r2V * r +
-         k.CY_da * x.da + k.CY_dr * x.dr;
-  x.Cl = k.Cl0 + k.Cl_b * x.beta + k.Cl_pb * x.r2V * p + k.Cl_rb * x.r2V * r +
-         k.Cl_da * x.da + k.Cl_dr * x.dr;
-  x.Cm = k.Cm0 + k.Cm_a * x.alpha + k.Cm_qc * x.r2V * q + k.Cm_de * x.de;
-  x.Cn = k.Cn0 + k.Cn_b * x.beta + k.Cn_pb * x.r2V * p + k.Cn_rb * x.r2V * r +
-         k.Cn_da * x.da + k.Cn_dr * x.dr;
-  // :167-175
-  x.Q = k.half_rho * x.V2 * k.S;
-  x.L = x.Q * x.CL, x.D = x.Q * x.CD, x.Y = x.Q * x.CY;
-  const float l = x.Q * k.c * x.Cl, m = x.Q * k.c * x.Cm, n = x.Q * k.c * x.Cn;
-  // :185-204 body forces
-  sincos_fast(x.alpha, &x.sa, &x.ca);
-  sincos_fast(x.beta, &x.sb, &x.cb);
-  sincos_fast(s[6], &x.sph, &x.cph);
-  sincos_fast(s[7], &x.sth, &x.cth);
-  sincos_fast(s[8], &x.sps, &x.cps);
-  x.icth = rcp_nr(x.cth);
-  const float f0 = -x.ca * x.cb * x.D - x.ca * x.sb * x.Y + x.sa * x.L -
-                   k.g_m * x.sth + x.T * k.cos_eps;
-  const float f1 = -x.sb * x.D + x.cb * x.Y + k.g_m * x.sph * x.cth;
-  const float f2 = -x.sa * x.cb * x.D - x.sa * x.sb * x.Y - x.ca * x.L +
-                   k.g_m * x.cph * x.cth + x.T * k.sin_eps;
-  // :213-216 position rate: R^T vel with R rows as at :80-91
-  x.R[0][0] = x.cth * x.cps, x.R[0][1] = x.cth * x.sps, x.R[0][2] = -x.sth;
-  x.R[1][0] = -x.cph * x.sps + x.sph * x.sth * x.cps;
-  x.R[1][1] = x.cph * x.cps + x.sph * x.sth * x.sps;
-  x.R[1][2] = x.sph * x.cth;
-  x.R[2][0] = x.sph * x.sps + x.cph * x.sth * x.cps;
-  x.R[2][1] = -x.sph * x.cps + x.cph * x.sth * x.sps;
-  x.R[2][2] = x.cph * x.cth;
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-    sd[j] = x.R[0][j] * u + x.R[1][j] * v + x.R[2][j] * w;
-  // :220-221
-  sd[3] = k.inv_mass * f0 - (q * w - r * v);
-  sd[4] = k.inv_mass * f1 - (r * u - p * w);
-  sd[5] = k.inv_mass * f2 - (p * v - q * u);
-  // :225-245
-  const float tth = x.sth * x.icth;
-  sd[6] = p + x.sph * tth * q + x.cph * tth * r;
-  sd[7] = x.cph * q - x.sph * r;
-  sd[8] = (x.sph * q + x.cph * r) * x.icth;
-  // :250-255
-  x.h0 = k.Ixx * p + k.a13 * r, x.h1 = k.Iyy * q, x.h2 = k.a13 * p + k.Izz * r;
-  const float r0 = l - (q * x.h2 - r * x.h1);
-  const float r1 = m - (r * x.h0 - p * x.h2);
-  const float r2 = n - (p * x.h1 - q * x.h0);
-  sd[9] = k.i00 * r0 + k.i02 * r2;
-  sd[10] = k.i11 * r1;
-  sd[11] = k.i02 * r0 + k.i22 * r2;
-}
-
-template <typename KT>
-__device__ __forceinline__ void wing_step(float (&s)[12], const float (&a)[4],
-                                          KT &k) {
-  WingAux x;
-  float sd[12];
-  wing_rates(s, a, k, x, sd);
-#pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = s[i] + k.dt * sd[i];
-}
-
-// lam: dL/dnext on entry -> dL/dstate on exit; ga += dL/daction.
-// `s`, `a` are the PRE-step state and the action; x the matching aux.
-template <typename KT>
-__device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
-                                                  float (&ga)[4],
-                                                  const float (&s)[12],
-                                                  const WingAux &x, KT &k) {
-  const float u = s[3], v = s[4], w = s[5];
-  const float p = s[9], q = s[10], r = s[11];
-  float g[12];  // cotangent of state_dot
-#pragma unroll
-  for (int i = 0; i < 12; ++i) g[i] = k.dt * lam[i];
-  float du = 0.f, dv = 0.f, dw = 0.f, dph = 0.f, dth = 0.f, dps = 0.f;
-  float dp = 0.f, dq = 0.f, dr = 0.f;
-
-  // omega_dot = I^-1 (M - omega x I omega)
-  const float gr0 = k.i00 * g[9] + k.i02 * g[11];
-  const float gr1 = k.i11 * g[10];
-  const float gr2 = k.i02 * g[9] + k.i22 * g[11];
-  {
-    const float c0 = -gr0, c1 = -gr1, c2 = -gr2;  // cotangent of the cross
-    dp += -c1 * x.h2 + c2 * x.h1;
-    dq += c0 * x.h2 - c2 * x.h0;
-    dr += -c0 * x.h1 + c1 * x.h0;
-    const float gh0 = c1 * r - c2 * q, gh1 = -c0 * r + c2 * p,
-                gh2 = c0 * q - c1 * p;
-    dp += k.Ixx * gh0 + k.a13 * gh2;
-    dq += k.Iyy * gh1;
-    dr += k.a13 * gh0 + k.Izz * gh2;
-  }
-  // euler rates
-  {
-    const float icth = x.icth, tth = x.sth * icth;
-    const float sq_cr = x.sph * q + x.cph * r;   // sin(phi) q + cos(phi) r
-    const float cq_sr = x.cph * q - x.sph * r;
-    dp += g[6];
-    dq += g[6] * x.sph * tth + g[7] * x.cph + g[8] * x.sph * icth;
-    dr += g[6] * x.cph * tth - g[7] * x.sph + g[8] * x.cph * icth;
-    dph += g[6] * tth * cq_sr - g[7] * sq_cr + g[8] * cq_sr * icth;
-    dth += g[6] * sq_cr * icth * icth + g[8] * sq_cr * x.sth * icth * icth;
-  }
-  // uvw_dot = f/m - omega x vel
-  const float gf0 = k.inv_mass * g[3], gf1 = k.inv_mass * g[4],
-              gf2 = k.inv_mass * g[5];
-  {
-    const float x0 = -g[3], x1 = -g[4], x2 = -g[5];
-    dq += x0 * w, dw += x0 * q, dr -= x0 * v, dv -= x0 * r;
-    dr += x1 * u, du += x1 * r, dp -= x1 * w, dw -= x1 * p;
-    dp += x2 * v, dv += x2 * p, dq -= x2 * u, du -= x2 * q;
-  }
-  // pos_dot_j = sum_i R[i][j] vel_i
-  {
-    const float vel[3] = {u, v, w};
-    float dvel[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      dvel[i] = x.R[i][0] * g[0] + x.R[i][1] * g[1] + x.R[i][2] * g[2];
-    du += dvel[0], dv += dvel[1], dw += dvel[2];
-    // gR[i][j] = vel_i * g_j
-    auto GR = [&](int i, int j) { return vel[i] * g[j]; };
-    // d/dphi: row1' = row2, row2' = -row1
-    dph += GR(1, 0) * x.R[2][0] + GR(1, 1) * x.R[2][1] + GR(1, 2) * x.R[2][2] -
-           GR(2, 0) * x.R[1][0] - GR(2, 1) * x.R[1][1] - GR(2, 2) * x.R[1][2];
-    // d/dtheta
-    dth += GR(0, 0) * (-x.sth * x.cps) + GR(0, 1) * (-x.sth * x.sps) +
-           GR(0, 2) * (-x.cth) + GR(1, 0) * (x.sph * x.cth * x.cps) +
-           GR(1, 1) * (x.sph * x.cth * x.sps) + GR(1, 2) * (-x.sph * x.sth) +
-           GR(2, 0) * (x.cph * x.cth * x.cps) +
-           GR(2, 1) * (x.cph * x.cth * x.sps) + GR(2, 2) * (-x.cph * x.sth);
-    // d/dpsi: col0' = -col1, col1' = col0
-    dps += -GR(0, 0) * x.R[0][1] + GR(0, 1) * x.R[0][0] -
-           GR(1, 0) * x.R[1][1] + GR(1, 1) * x.R[1][0] -
-           GR(2, 0) * x.R[2][1] + GR(2, 1) * x.R[2][0];
-  }
-  // f = R_bw [-D, Y, -L] + gravity(phi, theta) + thrust
-  const float gT = gf0 * k.cos_eps + gf2 * k.sin_eps;
-  dth += k.g_m * (-x.cth * gf0 - x.sph * x.sth * gf1 - x.cph * x.sth * gf2);
-  dph += k.g_m * (x.cph * x.cth * gf1 - x.sph * x.cth * gf2);
-  const float gD = -x.ca * x.cb * gf0 - x.sb * gf1 - x.sa * x.cb * gf2;
-  const float gY = -x.ca * x.sb * gf0 + x.cb * gf1 - x.sa * x.sb * gf2;
-  const float gL = x.sa * gf0 - x.ca * gf2;
-  float g_al = gf0 * (x.sa * x.cb * x.D + x.sa * x.sb * x.Y + x.ca * x.L) +
-               gf2 * (-x.ca * x.cb * x.D - x.ca * x.sb * x.Y + x.sa * x.L);
-  float g_be = gf0 * (x.ca * x.sb * x.D - x.ca * x.cb * x.Y) +
-               gf1 * (-x.cb * x.D - x.sb * x.Y) +
-               gf2 * (x.sa * x.sb * x.D - x.sa * x.cb * x.Y);
-  // forces and moments
-  const float Qc = x.Q * k.c;
-  const float gCL = x.Q * gL, gCD = x.Q * gD, gCY = x.Q * gY;
-  const float gCl = Qc * gr0, gCm = Qc * gr1, gCn = Qc * gr2;
-  const float gQ = gL * x.CL + gD * x.CD + gY * x.CY +
-                   k.c * (gr0 * x.Cl + gr1 * x.Cm + gr2 * x.Cn);
-  float gV2 = k.half_rho * k.S * gQ;
-  // coefficients
-  g_al += k.CL_a * gCL + k.CD_a * gCD + k.Cm_a * gCm;
-  g_be += k.CY_b * gCY + k.Cl_b * gCl + k.Cn_b * gCn;
-  const float g_qt = k.CL_qc * gCL + k.CD_qc * gCD + k.Cm_qc * gCm;
-  const float g_pt = k.CY_pb * gCY + k.Cl_pb * gCl + k.Cn_pb * gCn;
-  const float g_rt = k.CY_rb * gCY + k.Cl_rb * gCl + k.Cn_rb * gCn;
-  const float g_de = k.CL_de * gCL + k.CD_de * gCD + k.Cm_de * gCm;
-  const float g_da = k.CY_da * gCY + k.Cl_da * gCl + k.Cn_da * gCn;
-  const float g_dr = k.CY_dr * gCY + k.Cl_dr * gCl + k.Cn_dr * gCn;
-  dq += g_qt * x.r2V, dp += g_pt * x.r2V, dr += g_rt * x.r2V;
-  const float g_r2V = g_qt * q + g_pt * p + g_rt * r;
-  const float iV = x.iV;
-  float gV = -g_r2V * x.r2V * iV;
-  // alpha = clamp(atan(w/u)), beta = clamp(atan(v/V))
-  if (x.alpha_free) {
-    const float gt = g_al * rcp_nr(1.f + x.tw * x.tw);
-    const float iu = rcp_nr(u);
-    dw += gt * iu;
-    du -= gt * x.tw * iu;
-  }
-  if (x.beta_free) {
-    const float gt = g_be * rcp_nr(1.f + x.tb * x.tb);
-    dv += gt * iV;
-    gV -= gt * x.tb * iV;
-  }
-  gV2 += gV * 0.5f * iV;
-  du += 2.f * u * gV2, dv += 2.f * v * gV2, dw += 2.f * w * gV2;
-  // actions
-  ga[0] += 7.f * gT;
-  ga[1] += g_de * (kPi * 40.f / 180.f);
-  ga[2] += g_da * (kPi * 5.f / 180.f);
-  ga[3] += g_dr * (kPi * 40.f / 180.f);
-  lam[3] += du, lam[4] += dv, lam[5] += dw;
-  lam[6] += dph, lam[7] += dth, lam[8] += dps;
-  lam[9] += dp, lam[10] += dq, lam[11] += dr;
-}
 
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void wing_step_fwd_kernel(

@@ -1,9 +1,10 @@
-"""The SHIPPED per-trajectory quadrotor arithmetic (csrc/quad_math.h and
-sincos_fast of csrc/apg_device.h - what every quad kernel executes per lane)
-compiled for the HOST and pinned to the golden vectors recorded from the
-reference: single step + VJPs (G1), the rollout composition with gradients
-(G2), state_preprocessing + VJP (G7), and the accuracy claim of the
-branch-free sin-cos.  No GPU needed: the same source, the CPU's fma / rint."""
+"""The SHIPPED per-trajectory arithmetic (csrc/quad_math.h, csrc/wing_math.h,
+sincos_fast of csrc/apg_device.h - what the quadrotor / fixed-wing kernels
+execute per lane) compiled for the HOST and pinned to the golden vectors
+recorded from the reference: single steps + VJPs (G1, G5), the rollout
+compositions with gradients (G2, G5), state_preprocessing + VJP (G7), the
+reference's 1 001-step wing trace, and the accuracy claim of the branch-free
+sin-cos.  No GPU needed: the same source with the CPU's fma / rint / sqrt."""
 import ctypes
 import os
 import subprocess
@@ -13,29 +14,42 @@ import pytest
 
 from conftest import REPO, load_golden, rel_err
 
-SRC = os.path.join(REPO, "tests", "host_math", "quad_math_host.hip")
-OUT = os.path.join(REPO, "tests", "host_math", "_build")
-LIB = os.path.join(OUT, "libquad_math_host.so")
+HERE = os.path.join(REPO, "tests", "host_math")
+OUT = os.path.join(HERE, "_build")
 CSRC = os.path.join(REPO, "apg_trajectory_tracking_amd", "csrc")
-DEPS = [SRC, os.path.join(CSRC, "quad_math.h"), os.path.join(CSRC, "apg_device.h")]
 MOD = {"translational_drag": [.1, .2, .3], "rotational_drag": [.01, .02, .03],
        "mass": 1.0}
 
 
-@pytest.fixture(scope="module")
-def hm():
-    if not os.path.exists("/opt/rocm/bin/hipcc") and not os.path.exists(LIB):
+def _host_lib(name, headers):
+    """hipcc --cuda-host-only build of tests/host_math/<name>.hip."""
+    src = os.path.join(HERE, name + ".hip")
+    lib = os.path.join(OUT, f"lib{name}.so")
+    deps = [src] + [os.path.join(CSRC, h) for h in headers]
+    if not os.path.exists("/opt/rocm/bin/hipcc") and not os.path.exists(lib):
         pytest.skip("no hipcc to compile the host harness")
     os.makedirs(OUT, exist_ok=True)
-    if (not os.path.exists(LIB)
-            or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in DEPS)):
+    if (not os.path.exists(lib)
+            or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps)):
         subprocess.run(
             ["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared",
              "--cuda-host-only", "-I", os.path.join(REPO, "include"), "-I", CSRC,
-             "-o", LIB, SRC], check=True, stdout=subprocess.DEVNULL,
+             "-o", lib, src], check=True, stdout=subprocess.DEVNULL,
             stderr=subprocess.DEVNULL)
-    lib = ctypes.CDLL(LIB)
+    return ctypes.CDLL(lib)
+
+
+@pytest.fixture(scope="module")
+def hm():
+    lib = _host_lib("quad_math_host", ["quad_math.h", "apg_device.h"])
     lib.hm_quad_rollout.restype = ctypes.c_double
+    return lib
+
+
+@pytest.fixture(scope="module")
+def hw():
+    lib = _host_lib("wing_math_host", ["wing_math.h", "apg_device.h"])
+    lib.hm_wing_rollout.restype = ctypes.c_double
     return lib
 
 
@@ -117,3 +131,106 @@ def test_shipped_features_and_vjp(hm):
     hm.hm_quad_features(_p(s), s.shape[0], _p(cot), _p(feat), _p(gs))
     assert rel_err(feat, g["feat"]) < 2e-6
     assert rel_err(gs, g["gstate"]) < 1e-5
+
+
+# ------------------------------------------------------------- fixed wing
+def _wing_params(mp):
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    return FixedWingDynamics(modified_params=mp).params
+
+
+def _wing_step(hw, s, a, dt, mp, steps=1, cot=None):
+    s, a = _f(s), _f(a)
+    nxt = np.empty_like(s)
+    gs, ga = (np.empty_like(s), np.empty_like(a)) if cot is not None else (None, None)
+    hw.hm_wing_step(_p(s), _p(a), ctypes.c_float(dt), ctypes.byref(_wing_params(mp)),
+                    s.shape[0], int(steps), _p(None if cot is None else _f(cot)), _p(nxt),
+                    _p(gs), _p(ga))
+    return nxt, gs, ga
+
+
+def test_shipped_wing_known_answers(hw):
+    g = load_golden("wing.npz")
+    nxt, _, _ = _wing_step(hw, g["ka_state"], g["ka_action"], 0.05, {})
+    assert rel_err(nxt, g["ka_next"]) < 2e-6
+    # tests/run_wing_sim.py: 1001-step open-loop trace, rows recorded on the way
+    state = np.zeros((1, 12), np.float32)
+    state[0, 3] = 11.5
+    rows = list(g["sim_rows"])
+    got, done = [], 0
+    for r in rows:
+        state, _, _ = _wing_step(hw, state, g["sim_action"], 1 / 100, {}, steps=r - done)
+        done = r
+        got.append(state[0].copy())
+    assert rel_err(np.stack(got), g["sim_states"]) < 2e-4   # 1000 chained fp32 steps
+
+
+@pytest.mark.parametrize("tag,mp", [
+    ("def", {}), ("mod", {"mass": 1.4, "I_xz": -0.01, "CL0": 0.3, "rho": 1.0})
+])
+def test_shipped_wing_step_and_vjp(hw, tag, mp):
+    g = load_golden("wing.npz")
+    for i, c in enumerate(g["step_cot"]):
+        nxt, gs, ga = _wing_step(hw, g["step_state"], g["step_action"], 0.05, mp, cot=c)
+        assert rel_err(nxt, g[f"step_{tag}_next"]) < 2e-6
+        assert rel_err(gs, g[f"step_{tag}_gstate"][i]) < 1e-5
+        assert rel_err(ga, g[f"step_{tag}_gaction"][i]) < 1e-5
+
+
+@pytest.mark.parametrize("H", [20, 10])
+def test_shipped_wing_rollout_composition(hw, H):
+    from apg_trajectory_tracking_amd import functional as F
+    g = load_golden("wing.npz")
+    p = f"h{H}_"
+    s0, act, ref = _f(g[p + "state0"]), _f(g[p + "actions"]), _f(g[p + "ref"])
+    B = s0.shape[0]
+    st = np.empty((B, H, 12), np.float32)
+    ga, gs = np.empty_like(act), np.empty_like(s0)
+    w = F.wing_loss_weights()
+    loss = hw.hm_wing_rollout(_p(s0), _p(act), _p(ref), ctypes.c_float(0.05),
+                              ctypes.byref(_wing_params({})), ctypes.byref(w), B, H,
+                              _p(st), _p(ga), _p(gs))
+    assert rel_err(st, g[p + "states"]) < 1e-5
+    assert abs(loss - g[p + "loss"]) / g[p + "loss"] < 1e-5
+    assert rel_err(ga, g[p + "gactions"]) < 2e-5
+    assert rel_err(gs, g[p + "gstate0"]) < 2e-5
+
+
+# --------------------------------------------------------------- cart-pole
+@pytest.fixture(scope="module")
+def hc():
+    lib = _host_lib("cartpole_math_host", ["cartpole_math.h", "apg_device.h"])
+    lib.hm_cart_rollout.restype = ctypes.c_double
+    return lib
+
+
+def test_shipped_cartpole(hc):
+    from apg_trajectory_tracking_amd.dynamics.cartpole_dynamics import CartpoleDynamics
+    g = load_golden("cartpole.npz")
+    par = CartpoleDynamics().params
+    s, a = _f(g["ka_state"]), _f(g["ka_action"])
+    nxt = np.empty_like(s)
+    hc.hm_cart_step(_p(s), _p(a), ctypes.c_float(0.02), ctypes.byref(par), 1, None,
+                    _p(nxt), None, None)
+    assert rel_err(nxt, g["ka_next"]) < 2e-6
+    np.testing.assert_allclose(nxt[0], [0.5260, 1.4057, 0.1080, 0.7744], atol=5e-5)
+    # step + VJP
+    s, a, cot = _f(g["state0"]), _f(g["actions"][:, 0]), _f(g["step_cot"])
+    nxt, gs, ga = np.empty_like(s), np.empty_like(s), np.empty_like(a)
+    hc.hm_cart_step(_p(s), _p(a), ctypes.c_float(0.02), ctypes.byref(par), s.shape[0],
+                    _p(cot), _p(nxt), _p(gs), _p(ga))
+    assert rel_err(nxt, g["step_next"]) < 2e-6
+    assert rel_err(gs, g["step_gstate"]) < 1e-5
+    assert rel_err(ga, g["step_gaction"]) < 1e-5
+    # rollout with the reference derived from the start state
+    act = _f(g["actions"])
+    B, H = act.shape[:2]
+    st = np.empty((B, H, 4), np.float32)
+    gact, gs0 = np.empty_like(act), np.empty_like(s)
+    loss = hc.hm_cart_rollout(_p(s), _p(act), ctypes.c_float(float(g["dt"])),
+                              ctypes.byref(par), B, H, _p(st), _p(gact), _p(gs0))
+    assert rel_err(st, g["states"]) < 1e-5
+    assert abs(loss - g["loss"]) / g["loss"] < 1e-5
+    assert rel_err(gact, g["gactions"]) < 1e-5
+    assert rel_err(gs0, g["gstate0"]) < 1e-5
