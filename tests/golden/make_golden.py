@@ -749,7 +749,82 @@ def g12_wing_train():
         os.chdir(cwd)
 
 
-FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
+# -------------------------------------------------------------------- G13
+def g13_self_play():
+    """N1/N2: self play during the evaluation, as TrainDrone.evaluate_model runs
+    it (scripts/train_drone.py:205-217): ONE NetworkWrapper (its action counter
+    runs through all test flights, network_wrapper.py:42-72) drives the real
+    QuadEvaluator.run_eval (scripts/evaluate_drone.py:237-300) over injected
+    trajectories; every take_every_x-th policy call puts its (state, window)
+    into the next self-play slot of a real QuadDataset
+    (DroneDataset.get_and_add_eval_data, dataset.py:103-119), wrapping around.
+    Recorded: run_eval's six statistics, the self-play part of the four data
+    set tensors and the slot counter."""
+    import evaluate_drone
+    from neural_control.environments.drone_env import QuadRotorEnvBase
+    from neural_control.environments.helper_simple_env import DynamicsState
+    from neural_control.controllers.network_wrapper import NetworkWrapper
+    from neural_control.dataset import QuadDataset
+    from neural_control.trajectory import random_traj
+
+    g = np.load(os.path.join(HERE, "closed_loop.npz"))
+    trajs = g["trajs"].astype(np.float64)          # the G11 references
+    net = torch.load(os.path.join(REF, "trained_models", "quad", "current_model",
+                                  "model_quad"), weights_only=False)
+    net.eval()
+    dt, H, steps = 0.1, 10, 60
+    n_sampled, n_self, every = 6, 10, 7
+
+    class Env(QuadRotorEnvBase):
+        def __init__(self, dynamics, dt):
+            self._state = DynamicsState()
+            self.dt, self.dynamics, self.renderer = dt, dynamics, None
+
+        def reset(self, strength=.8):
+            self._state = DynamicsState()
+
+    out = {"take_every_x": np.int64(every), "num_sampled": np.int64(n_sampled),
+           "num_self_play": np.int64(n_self), "max_steps": np.int64(steps)}
+    for name, c in (("train", dict(test_time=0, thresh_div=0.12)),
+                    ("test", dict(test_time=1, thresh_div=0.2))):
+        ds = QuadDataset.__new__(QuadDataset)
+        ds.num_sampled_states, ds.num_self_play = n_sampled, n_self
+        ds.total_dataset_size = n_sampled + n_self
+        ds.eval_counter = 0
+        ds.normed_states = torch.zeros(ds.total_dataset_size, 15)
+        ds.states = torch.zeros(ds.total_dataset_size, 12)
+        ds.in_ref_states = torch.zeros(ds.total_dataset_size, H, 9)
+        ds.ref_states = torch.zeros(ds.total_dataset_size, H, 9)
+        served = [0]
+
+        def next_traj(*a, **k):
+            r = trajs[served[0] % len(trajs)].copy()
+            served[0] += 1
+            return r
+        random_traj.load_prepare_trajectory = next_traj
+        env = Env(FlightmareDynamics(), dt)
+        ctrl = NetworkWrapper(net, ds, horizon=H, dt=dt, take_every_x=every)
+        ev = evaluate_drone.QuadEvaluator(
+            ctrl, env, ref_length=H, dt=dt, test_time=c["test_time"],
+            speed_factor=0.4, train_mode="concurrent")
+        with torch.no_grad():
+            stats = ev.run_eval("rand", nr_test=len(trajs), max_steps=steps,
+                                thresh_div=c["thresh_div"], thresh_stable=1.0)
+        out[f"{name}.stats"] = np.asarray(stats, dtype=np.float64)
+        out[f"{name}.thresh_div"] = np.float32(c["thresh_div"])
+        out[f"{name}.test_time"] = np.int64(c["test_time"])
+        out[f"{name}.eval_counter"] = np.int64(ds.eval_counter)
+        out[f"{name}.action_counter"] = np.int64(ctrl.action_counter)
+        sl = slice(n_sampled, None)
+        out[f"{name}.normed"] = npy(ds.normed_states[sl])
+        out[f"{name}.states"] = npy(ds.states[sl])
+        out[f"{name}.in_ref"] = npy(ds.in_ref_states[sl])
+        out[f"{name}.ref"] = npy(ds.ref_states[sl])
+        print(name, stats, ds.eval_counter, ctrl.action_counter)
+    save("self_play.npz", **out)
+
+
+FIXTURES = dict(g13=g13_self_play, g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
                 g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
                 g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
                 g11=g11_closed_loop, g12=g12_wing_train)

@@ -255,6 +255,34 @@ def test_flat_gradient_layout_and_new_argument_errors():
         F.to_soa(torch.zeros(4, 3))
 
 
+def _oracle_closed_loop(net_, traj, dt, params, max_steps=251, thresh_div=1.0,
+                        thresh_stable=1.0, test_time=0, want_trajectory=False):
+    """Stand-in for functional.quad_mlp_closed_loop on CPU: the batched oracle
+    loop (test infrastructure) in the kernel's output format."""
+    from oracle import torch_port as tp
+    flat = traj.clone()       # the kernel takes the lifted reference, the oracle
+    flat[:, :, 2] -= 3        # lifts it itself (random_traj.py:34)
+    o = tp.quad_closed_loop(net_, tp.QuadOracle(), flat, dt, 10, max_steps,
+                            thresh_div, thresh_stable, test_time)
+    T_ = min(max_steps, traj.shape[1] + 1)
+    out = dict(div=o["div"][:, :T_].t().contiguous(), steps=o["steps"].int())
+    if want_trajectory:
+        # the state the policy saw: previous state, or the reference row
+        # after a failed step (train mode)
+        start = torch.zeros(T_, 12, traj.shape[0])
+        start[0] = o["drone"][:, 0].t()
+        for k in range(1, T_):
+            cur = min(k, traj.shape[1] - 10)
+            unstable = ~(o["drone"][:, k, 3:5].abs() < thresh_stable).all(1)
+            failed = (o["div"][:, k - 1] > thresh_div) | unstable
+            reset = torch.cat((traj[:, cur], torch.zeros(traj.shape[0], 3)), 1)
+            start[k] = torch.where(failed[:, None] & (not test_time), reset,
+                                   o["drone"][:, k]).t()
+        out.update(drone=o["drone"][:, :T_ + 1].permute(1, 2, 0),
+                   actions=o["actions"][:, :T_].permute(1, 2, 0), start_states=start)
+    return out
+
+
 @pytest.mark.filterwarnings("ignore::RuntimeWarning")   # mean of no complete run
 def test_evaluator_statistics_and_self_play_selection(monkeypatch):
     """Host logic of evaluate_drone.QuadEvaluator on CPU: the kernel call is
@@ -273,28 +301,7 @@ def test_evaluator_statistics_and_self_play_selection(monkeypatch):
     net = build_policy("quad", sd)
     B, L, steps, td = 7, 30, 24, 0.12
 
-    def fake_closed_loop(net_, traj, dt, params, max_steps=251, thresh_div=1.0,
-                         thresh_stable=1.0, test_time=0, want_trajectory=False):
-        o = tp.quad_closed_loop(net_, tp.QuadOracle(), traj, dt, 10, max_steps,
-                                thresh_div, thresh_stable, test_time)
-        T_ = min(max_steps, traj.shape[1] + 1)
-        out = dict(div=o["div"][:, :T_].t().contiguous(), steps=o["steps"].int())
-        if want_trajectory:
-            # the state the policy saw: previous state, or the reference row
-            # after a failed step (train mode)
-            start = torch.zeros(T_, 12, traj.shape[0])
-            start[0] = o["drone"][:, 0].t()
-            for k in range(1, T_):
-                cur = min(k, traj.shape[1] - 10)
-                unstable = ~(o["drone"][:, k, 3:5].abs() < thresh_stable).all(1)
-                failed = (o["div"][:, k - 1] > thresh_div) | unstable
-                reset = torch.cat((traj[:, cur], torch.zeros(traj.shape[0], 3)), 1)
-                start[k] = torch.where(failed[:, None] & (not test_time), reset,
-                                       o["drone"][:, k]).t()
-            out.update(drone=o["drone"][:, :T_ + 1].permute(1, 2, 0),
-                       actions=o["actions"][:, :T_].permute(1, 2, 0), start_states=start)
-        return out
-    monkeypatch.setattr(F, "quad_mlp_closed_loop", fake_closed_loop)
+    monkeypatch.setattr(F, "quad_mlp_closed_loop", _oracle_closed_loop)
 
     class Dyn:
         params = None
@@ -305,7 +312,9 @@ def test_evaluator_statistics_and_self_play_selection(monkeypatch):
                                           test_time=test_time)
         got = ev.run_eval("rand", nr_test=B, max_steps=steps, thresh_div=td,
                           thresh_stable=1.0, trajectories=traj)
-        o = tp.quad_closed_loop(net, tp.QuadOracle(), traj, 0.1, 10, steps, td, 1.0,
+        flat = traj.clone()
+        flat[:, :, 2] -= 3
+        o = tp.quad_closed_loop(net, tp.QuadOracle(), flat, 0.1, 10, steps, td, 1.0,
                                 test_time)
         div, stable = [], []
         for i in range(B):                  # the reference's per-run bookkeeping
@@ -556,3 +565,52 @@ def test_bench_line_contract():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+@pytest.mark.filterwarnings("ignore::RuntimeWarning")   # mean of no complete run
+@pytest.mark.parametrize("case", ["train", "test"])
+def test_self_play_matches_the_reference_evaluator(monkeypatch, case):
+    """Golden G13: the REAL QuadEvaluator.run_eval + NetworkWrapper + QuadDataset
+    of the reference flew the G11 trajectories with self play on; the six
+    statistics, the slot counter and the self-play part of the four data-set
+    tensors must come out of evaluate_drone.QuadEvaluator.run_eval +
+    SyntheticQuadDataset.add_eval_data.  On CPU the closed-loop kernel is
+    replaced by the batched oracle loop and the feature kernel by the oracle's
+    features (both pinned themselves); the GPU twin of this test runs the
+    kernels."""
+    from apg_trajectory_tracking_amd import dataset as ds_mod
+    from apg_trajectory_tracking_amd import evaluate_drone, functional as F
+    from apg_trajectory_tracking_amd.checkpoint import build_policy
+    from oracle import torch_port as tp
+    g, traj_g = load_golden("self_play.npz"), load_golden("closed_loop.npz")
+    ck = load_golden("checkpoints.npz")
+    net = build_policy("quad", {k[len("quad.w."):]: torch.from_numpy(ck[k])
+                                for k in ck.files if k.startswith("quad.w.")})
+    monkeypatch.setattr(F, "quad_mlp_closed_loop", _oracle_closed_loop)
+    monkeypatch.setattr(ds_mod, "state_preprocessing", tp.quad_state_features)
+    n_s, n_p = int(g["num_sampled"]), int(g["num_self_play"])
+    data = ds_mod.SyntheticQuadDataset.__new__(ds_mod.SyntheticQuadDataset)
+    data.num_sampled_states, data.num_self_play = n_s, n_p
+    data.ref_length, data.device, data.eval_counter = 10, torch.device("cpu"), 0
+    data.normed_states = torch.zeros(n_s + n_p, 15)
+    data.states = torch.zeros(n_s + n_p, 12)
+    data.in_ref_states = torch.zeros(n_s + n_p, 10, 9)
+    data.ref_states = torch.zeros(n_s + n_p, 10, 9)
+    traj = torch.from_numpy(traj_g["trajs"]).clone()
+    traj[:, :, 2] += 3                      # Random.__init__ lifts the reference
+
+    class Dyn:
+        params = None
+    ev = evaluate_drone.QuadEvaluator(net, Dyn(), ref_length=10, dt=0.1,
+                                      test_time=int(g[f"{case}.test_time"]))
+    stats = ev.run_eval("rand", nr_test=traj.shape[0], max_steps=int(g["max_steps"]),
+                        thresh_div=float(g[f"{case}.thresh_div"]), thresh_stable=1.0,
+                        trajectories=traj, dataset=data,
+                        take_every_x=int(g["take_every_x"]))
+    np.testing.assert_allclose(stats, g[f"{case}.stats"], rtol=2e-4, equal_nan=True)
+    assert data.eval_counter == int(g[f"{case}.eval_counter"])
+    sl = slice(n_s, None)
+    for name, got in (("states", data.states), ("normed", data.normed_states),
+                      ("in_ref", data.in_ref_states), ("ref", data.ref_states)):
+        assert rel_err(got[sl].numpy(), g[f"{case}.{name}"]) < 2e-4, name
+    assert torch.count_nonzero(data.states[:n_s]) == 0     # sampled part untouched
