@@ -21,6 +21,8 @@ Fixtures:
   closed_loop.npz    G11 QuadEvaluator.follow_trajectory with the shipped quad
                          controller on injected reference trajectories
   wing_train.npz     G12 TrainFixedWing.train_controller_model, 2 SGD steps
+  self_play.npz      G13 QuadEvaluator.run_eval + NetworkWrapper + QuadDataset
+                         with self play on (needs closed_loop.npz)
 
 `python tests/golden/make_golden.py g11` regenerates selected fixtures only.
 """
@@ -824,10 +826,11 @@ def g13_self_play():
     save("self_play.npz", **out)
 
 
-FIXTURES = dict(g13=g13_self_play, g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
+FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
                 g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
                 g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
-                g11=g11_closed_loop, g12=g12_wing_train)
+                g11=g11_closed_loop, g12=g12_wing_train,
+                g13=g13_self_play)
 
 if __name__ == "__main__":
     for key in (sys.argv[1:] or FIXTURES):
