@@ -23,6 +23,8 @@ Fixtures:
   wing_train.npz     G12 TrainFixedWing.train_controller_model, 2 SGD steps
   self_play.npz      G13 QuadEvaluator.run_eval + NetworkWrapper + QuadDataset
                          with self play on (needs closed_loop.npz)
+  schedules.npz      G14 TrainBase.run_control (speed curriculum) and
+                         run_dynamics with scripted evaluation results
 
 `python tests/golden/make_golden.py g11` regenerates selected fixtures only.
 """
@@ -826,11 +828,84 @@ def g13_self_play():
     save("self_play.npz", **out)
 
 
+# -------------------------------------------------------------------- G14
+def g14_schedules():
+    """Host loops of the trainer: the REAL TrainBase.run_control with the speed
+    curriculum (scripts/train_base.py:289-332) and run_dynamics (:334-375) of a
+    reference TrainDrone whose evaluate_model / run_epoch / finalize are stubs
+    fed with a scripted success sequence.  Recorded per epoch: speed factor,
+    divergence threshold and score as evaluate_model sees them, and which model
+    each epoch trains."""
+    import json
+    import train_drone
+    cwd = os.getcwd()
+    os.makedirs("/tmp/apg_golden_scratch", exist_ok=True)
+    os.chdir("/tmp/apg_golden_scratch")
+    try:
+        with open(os.path.join(REF, "configs", "quad_config.json")) as f:
+            base = json.load(f)
+        rng = np.random.default_rng(7)
+        n = 260
+        # full-length flights most of the time, with streaks of failures and a
+        # long plateau that only the 100-epoch rule ends
+        success = np.where(rng.uniform(size=n) < 0.8, 1e4, 5.0)
+        success[:6] = 1e4
+        success[6:130] = 5.0
+        out = {"success": success, "delta_t": np.float64(base["delta_t"])}
+
+        def make(config, learnt=False):
+            dyn = FlightmareDynamics()
+            if learnt:
+                from neural_control.dynamics.quad_dynamics_trained import (
+                    LearntDynamics)
+                t = train_drone.TrainDrone(LearntDynamics(), dyn, config)
+            else:
+                t = train_drone.TrainDrone(dyn, dyn, config)
+            t.log = []
+            t.net = torch.nn.Linear(1, 1)
+
+            def evaluate(epoch):
+                t.log.append((epoch, t.config["speed_factor"],
+                              t.config.get("thresh_div", -1.0), t.current_score))
+                t.results_dict["mean_success"].append(success[epoch])
+                t.current_score = success[epoch]
+                # the divergence-threshold ladder of evaluate_model (:219-224)
+                if epoch % 5 == 0 and t.config["thresh_div"] < t.thresh_div_end:
+                    t.config["thresh_div"] += .05
+                return success[epoch], 0.0
+            t.evaluate_model = evaluate
+            t.trained = []
+            t.run_epoch = lambda train="controller", epoch=0: t.trained.append(train)
+            t.finalize = lambda: None
+            return t
+        cfg = dict(base, sample_in="train_env", speed_factor=0.6, thresh_div=1.0,
+                   nr_epochs=n)
+        t = make(cfg)
+        t.run_control(cfg, curriculum=1)
+        out["control.log"] = np.asarray(t.log, dtype=np.float64)
+        out["control.final"] = np.asarray(
+            [t.config["speed_factor"], t.config["thresh_div"]], dtype=np.float64)
+        out["thresh_div_end"] = np.float64(t.thresh_div_end)
+        cfg = dict(base, sample_in="train_env", thresh_div=1.0, nr_epochs=12,
+                   train_dyn_for_epochs=5, train_dyn_every=2)
+        t = make(cfg, learnt=True)
+        t.count_finetune_data = 0
+        t.run_dynamics(cfg)
+        out["dynamics.trained"] = np.asarray(
+            [int(x == "dynamics") for x in t.trained], dtype=np.int64)
+        out["dynamics.for_epochs"], out["dynamics.every"] = np.int64(5), np.int64(2)
+        print(out["control.log"][[0, 5, 6, 7, 106, 107, 108, 259]], out["control.final"],
+              out["dynamics.trained"])
+        save("schedules.npz", **out)
+    finally:
+        os.chdir(cwd)
+
+
 FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
                 g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
                 g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
                 g11=g11_closed_loop, g12=g12_wing_train,
-                g13=g13_self_play)
+                g13=g13_self_play, g14=g14_schedules)
 
 if __name__ == "__main__":
     for key in (sys.argv[1:] or FIXTURES):

@@ -614,3 +614,44 @@ def test_self_play_matches_the_reference_evaluator(monkeypatch, case):
                       ("in_ref", data.in_ref_states), ("ref", data.ref_states)):
         assert rel_err(got[sl].numpy(), g[f"{case}.{name}"]) < 2e-4, name
     assert torch.count_nonzero(data.states[:n_s]) == 0     # sampled part untouched
+
+
+def test_schedules_match_the_reference_loops(tmp_path):
+    """Golden G14: the reference's REAL run_control (speed curriculum) and
+    run_dynamics loops were driven with a scripted success sequence; the
+    package's loops, driven with the same sequence, must show the same speed
+    factor / divergence threshold / score to every evaluation and train the
+    same model in every epoch."""
+    g = load_golden("schedules.npz")
+    success = g["success"]
+    n = len(success)
+
+    def make(**cfg):
+        t = _loop_trainer(tmp_path, **cfg)
+        t.config["delta_t"] = float(g["delta_t"])
+        t.config["thresh_div"] = 1.0
+        t.thresh_div_end = float(g["thresh_div_end"])
+        t.seen = []
+
+        def evaluate(epoch):
+            t.seen.append((epoch, t.config["speed_factor"], t.config["thresh_div"],
+                           t.current_score))
+            t.results_dict["mean_success"].append(success[epoch])
+            t.current_score = success[epoch]
+            if epoch % 5 == 0 and t.config["thresh_div"] < t.thresh_div_end:
+                t.config["thresh_div"] += .05
+            return success[epoch], 0.0
+        t.evaluate_model = evaluate
+        return t
+    t = make()
+    t.run_control(dict(nr_epochs=n), curriculum=1)
+    np.testing.assert_allclose(np.asarray(t.seen, dtype=np.float64),
+                               g["control.log"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(
+        [t.config["speed_factor"], t.config["thresh_div"]], g["control.final"],
+        rtol=1e-12)
+    t = make()
+    t.run_dynamics(dict(nr_epochs=len(g["dynamics.trained"]),
+                        train_dyn_for_epochs=int(g["dynamics.for_epochs"]),
+                        train_dyn_every=int(g["dynamics.every"])))
+    assert [int(m == "dynamics") for _, m in t.log] == list(g["dynamics.trained"])
