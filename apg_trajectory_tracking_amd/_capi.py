@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("APG_LIB") or os.path.join(_HERE, "csrc", "libapg_hip.
 
 LAYOUT_SOA = 0
 LAYOUT_AOS = 1
+LAYOUT_PACKED = 2   # rows [rows][B][C]: fused quad rollout only
 MAX_HORIZON = 48
 ROLLOUT_BLOCK = 64
 

@@ -19,7 +19,10 @@ SOURCES = ["common.hip", "quad.hip", "wing.hip", "cartpole.hip", "lstm.hip",
 # ones here and needs v_mov shuffles to form register pairs - measured on
 # MI355X: quad rollout 9.7 -> 9.0 us, wing rollout 126 -> 94 us
 COMMON_FLAGS = ["-fno-slp-vectorize"]
-EXTRA_FLAGS = {}
+# kernarg preload: the leading scalar arguments of a kernel arrive in SGPRs
+# with the wave (gfx950 firmware feature) - the packed-rows rollout issues its
+# first loads without waiting for an s_load round trip
+EXTRA_FLAGS = {"quad.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
 HEADERS = [os.path.join(CSRC, "apg_device.h"),
            os.path.join(CSRC, "quad_math.h"),
            os.path.join(CSRC, "policy_mfma.h"),

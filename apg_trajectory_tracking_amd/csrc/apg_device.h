@@ -169,6 +169,29 @@ __host__ __device__ __forceinline__ void sincos_fast(float x, float *sn, float *
       float, __builtin_bit_cast(unsigned, co) ^ ((unsigned)((k + 1) & 2) << 30));
 }
 
+// Hardware pair: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS and
+// reduce it themselves (valid for |u| <= 256), so the work left to the VALU
+// is x / 2pi to better than one fp32 rounding: the product with 1/2pi as a
+// two-word constant, split as fract(hi) + lo so that many revolutions cost no
+// precision (5 plain ops + 2 quarter-rate ops instead of ~30).  Absolute error
+// of the results ~1.5e-7 (measured against float64, tools/ab_quad.cpp runs
+// the rollout parity with it).  Host builds (tests only) use libm.
+__host__ __device__ __forceinline__ void sincos_hw(float x, float *sn, float *cs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float kHi = 0.15915494f;          // fl(1 / 2pi)
+  const float kLo = 6.4206382e-09f;       // 1 / 2pi - kHi
+  const float u = x * kHi;
+  float e = fmaf(x, kHi, -u);             // exact low word of the product
+  e = fmaf(x, kLo, e);
+  const float f = __builtin_amdgcn_fractf(u) + e;
+  *sn = __builtin_amdgcn_sinf(f);
+  *cs = __builtin_amdgcn_cosf(f);
+#else
+  *sn = (float)sin((double)x);
+  *cs = (float)cos((double)x);
+#endif
+}
+
 // 1/x: hardware v_rcp_f32 (1 ulp) + one Newton step (~0.5 ulp) in 3 VALU ops
 // instead of the ~10-op IEEE division sequence.  (Host builds - tests only -
 // start the same Newton step from the correctly rounded quotient.)

@@ -19,8 +19,70 @@
 #include "apg_device.h"
 #include "quad_math.h"
 
+#ifndef APG_QX
+#define APG_QX 0  // experiment bits (tools/exp builds): 1 loss accumulators,
+                  // 4 attitude-first request order
+#endif
+
 namespace apg {
 namespace {
+
+#ifdef APG_STAMP
+// timing experiments only (tools/ab_quad.cpp): per-wave s_memtime stamps.  They
+// are parked in the lanes of ONE VGPR (v_writelane) and written out once at the
+// end of the kernel, so that a stamp costs the s_memtime round trip and two
+// VALU slots - no stores, no loads of the buffer pointer in between.
+__device__ unsigned long long *g_stamps = nullptr;
+#define APG_STAMP_DECL unsigned apg_stv = 0
+#define APG_STAMP_PUT(i, t_)                                                   \
+  asm volatile("v_writelane_b32 %0, %1, %3\nv_writelane_b32 %0, %2, %4"        \
+               : "+v"(apg_stv)                                                 \
+               : "s"((unsigned)(t_)), "s"((unsigned)((t_) >> 32)), "n"(2 * (i)), \
+                 "n"(2 * (i) + 1))
+#define APG_STAMP_AT(i)                                                        \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    unsigned long long t_;                                                     \
+    asm volatile("s_memtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
+    APG_STAMP_PUT(i, t_);                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+// same, but not before the scalar value `dep` (a kernel argument) has arrived
+#define APG_STAMP_DEP(i, dep)                                                  \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    unsigned long long t_;                                                     \
+    asm volatile("s_memtime %0\ns_waitcnt lgkmcnt(0)"                          \
+                 : "=s"(t_)                                                    \
+                 : "s"(dep)                                                    \
+                 : "memory");                                                  \
+    APG_STAMP_PUT(i, t_);                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+// s_memrealtime: the constant 100 MHz clock all XCDs share (s_memtime is per XCD)
+#define APG_STAMP_REAL(i)                                                      \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    unsigned long long t_;                                                     \
+    asm volatile("s_memrealtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    APG_STAMP_PUT(i, t_);                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+#define APG_STAMP_FLUSH()                                                      \
+  do {                                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
+    APG_STAMP_AT(4);                                                           \
+    APG_STAMP_REAL(5);                                                         \
+    if (g_stamps && threadIdx.x < 16)                                          \
+      ((unsigned *)g_stamps)[blockIdx.x * 16 + threadIdx.x] = apg_stv;         \
+  } while (0)
+#else
+#define APG_STAMP_DECL
+#define APG_STAMP_AT(i)
+#define APG_STAMP_DEP(i, dep)
+#define APG_STAMP_REAL(i)
+#define APG_STAMP_FLUSH()
+#endif
 
 // ------------------------------------------------------------ single step --
 template <int LAYOUT>
@@ -82,6 +144,8 @@ template <int LAYOUT, int HT, bool STATES_OUT, bool BUF>
 __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
     RolloutArgs A) {
   static_assert(!BUF || LAYOUT == APG_LAYOUT_SOA, "buffer path is SoA only");
+  APG_STAMP_DECL;
+  APG_STAMP_AT(0);
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = b < A.B;
   const int bb = live ? b : A.B - 1;  // keep the wave convergent for the reduce
@@ -92,7 +156,14 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
   // burst per wave); each forward step requests one more action row and one
   // reference row (reverse order), so everything is in flight by the end of
   // the forward sweep.
-  constexpr int kActPre = HT < 3 ? HT : 3;
+#ifndef APG_REG_ACT_PRE
+#define APG_REG_ACT_PRE 3
+#endif
+#ifndef APG_REG_REF_PER_STEP
+#define APG_REG_REF_PER_STEP 1
+#endif
+  constexpr int kActPre = HT < (APG_REG_ACT_PRE) ? HT : (APG_REG_ACT_PRE);
+  constexpr int kRefPerStep = APG_REG_REF_PER_STEP;
 
   // deferred loss of an earlier launch (ApgDeferredLoss): request its
   // partials before this wave's own inputs, sum them at the very end
@@ -120,6 +191,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
     }
   };
 
+  APG_STAMP_REAL(7);
   float s[12];
   float act[HT][4];
   float rp[HT][3], rv[HT][3];
@@ -133,17 +205,40 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
       load_seq<LAYOUT, 4>(A.actions, A.B, HT, 4, bb, k, 0, act[k]);
     }
   };
-  if constexpr (BUF) {
+  if constexpr (BUF && (APG_QX & 4)) {
+    // attitude and body rates first: the sin/cos of step 0 (the long pole of
+    // a step) starts as soon as three planes have landed
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = b_s0.ld(i);
-  } else {
-    load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k = 0; k < kActPre; ++k) {
-    ld_act(k);
+    for (int i = 3; i < 6; ++i) s[i] = b_s0.ld(i);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 9; i < 12; ++i) s[i] = b_s0.ld(i);
+    __builtin_amdgcn_sched_barrier(0);
+    ld_act(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 6; i < 9; ++i) s[i] = b_s0.ld(i);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i] = b_s0.ld(i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 1; k < kActPre; ++k) {
+      ld_act(k);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    if constexpr (BUF) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s[i] = b_s0.ld(i);
+    } else {
+      load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < kActPre; ++k) {
+      ld_act(k);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   Trig st_trig[HT];
@@ -151,10 +246,14 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
   float st_pv[HT][6];
 #pragma unroll
   for (int k = 0; k < HT; ++k) {
-    {  // requests of this step: action row k + kActPre, reference row H-1-k
-      const int kr = HT - 1 - k;
+    {  // requests of this step: action row k + kActPre, reference rows in
+       // reverse step order
       if (k + kActPre < HT) ld_act(k + kActPre);
-      ld_ref(kr, rp[kr], rv[kr]);
+#pragma unroll
+      for (int j = 0; j < kRefPerStep; ++j) {
+        const int kr = HT - 1 - (k * kRefPerStep + j);
+        if (kr >= 0) ld_ref(kr, rp[kr], rv[kr]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -173,40 +272,43 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
         }
       }
     }
-
+    if (k == 0) APG_STAMP_AT(1);
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) st_w[HT][i] = s[9 + i];
+  APG_STAMP_AT(2);
 
-  float loss = 0.f;
+  // loss terms (drone_loss.py:22-34): the five sums run over the whole
+  // horizon and meet their weights once at the end
+  float sum_p = 0.f, sum_v = 0.f, sum_w = 0.f, sum_r = 0.f, sum_t = 0.f;
+  const float wp2 = 2.f * A.w.pos, wv2 = 2.f * A.w.vel, ww2 = 2.f * A.w.av,
+              wr2 = 2.f * A.w.rates, wt2 = 2.f * A.w.thrust;
   float lam[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
 #pragma unroll
   for (int k = HT - 1; k >= 0; --k) {
-    // loss terms of step k (drone_loss.py:22-34) and their seeds
-    float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const float dp = st_pv[k][i] - rp[k][i];
       const float dv = st_pv[k][3 + i] - rv[k][i];
       const float wn = st_w[k + 1][i];
-      lp += dp * dp, lv += dv * dv, lw += wn * wn;
-      lam[i] += 2.f * A.w.pos * dp;
-      lam[6 + i] += 2.f * A.w.vel * dv;
-      lam[9 + i] += 2.f * A.w.av * wn;
+      sum_p = fmaf(dp, dp, sum_p), sum_v = fmaf(dv, dv, sum_v);
+      sum_w = fmaf(wn, wn, sum_w);
+      lam[i] = fmaf(wp2, dp, lam[i]);
+      lam[6 + i] = fmaf(wv2, dv, lam[6 + i]);
+      lam[9 + i] = fmaf(ww2, wn, lam[9 + i]);
     }
     const float a0 = act[k][0], da0 = a0 - 0.5f;
     float ga[4];
-    ga[0] = 2.f * A.w.thrust * da0;
+    ga[0] = wt2 * da0;
+    sum_t = fmaf(da0, da0, sum_t);
 #pragma unroll
     for (int i = 1; i < 4; ++i) {
       const float d = act[k][i] - 0.5f;
-      lr += d * d;
-      ga[i] = 2.f * A.w.rates * d;
+      sum_r = fmaf(d, d, sum_r);
+      ga[i] = wr2 * d;
     }
-    loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
-            A.w.thrust * da0 * da0;
     quad_step_adjoint(lam, ga, a0, st_w[k], c, st_trig[k]);
     if (live) {
       if constexpr (BUF) {
@@ -216,6 +318,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
         store_seq<LAYOUT, 4>(A.grad_actions, A.B, HT, 4, b, k, 0, ga);
       }
     }
+    if (k == HT / 2) APG_STAMP_AT(6);
   }
   if (A.grad_state0 && live) {
     if constexpr (BUF) {
@@ -225,8 +328,245 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
       store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
     }
   }
+  APG_STAMP_AT(3);
+  const float loss = A.w.pos * sum_p + A.w.vel * sum_v + A.w.av * sum_w +
+                     A.w.rates * sum_r + A.w.thrust * sum_t;
   write_wave_partial(A.loss_partials, live ? loss : 0.f);
   if (reducer) reduce_prev_tail(A.prev, pp);
+  APG_STAMP_FLUSH();
+}
+
+// ---------------------------------------------- fused rollout, packed rows --
+// APG_LAYOUT_PACKED.  Same sweeps as quad_rollout_reg_kernel, but every tensor
+// is a stack of ROWS - the consecutive floats one trajectory needs at one
+// step - with the batch as the next-faster dimension:
+//   state0 [3][B][4]   actions [H][B][4]   ref [H][B][6] = [pos, vel]
+//   grad_actions [H][B][4]   grad_state0 [3][B][4]   states_out [H][3][B][4]
+// so a lane moves its action row with ONE 16-byte access and a wave
+// instruction covers 1 KiB of contiguous memory.  Why it matters (measured,
+// tools/issue_probe.hip, one wave per SIMD, all four waves of a CU active):
+// a dword-per-lane buffer load occupies the issuing wave for ~38 cycles, a
+// dword store for ~33 - the 112 loads + 40 stores of the plane layout cost a
+// wave ~5 600 cycles (2.4 us) of pure issue time on top of ~2 000 VALU slots
+// of 4.3 cycles; the row layout needs 33 loads + 10 stores.
+// The first 16 dwords of the argument list are scalars so that they can be
+// PRELOADED into SGPRs (-mllvm -amdgpu-kernarg-preload-count=16): the wave
+// issues its first loads without waiting ~0.35 us for an s_load round trip.
+struct RowArgs {
+  float wd[3];  // dt * rot_drag / inertia
+  ApgQuadLossWeights w;
+  float *loss_partials, *grad_actions, *grad_state0, *states_out;
+  ApgDeferredLoss prev;
+};
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
+
+template <int HT, bool STATES_OUT>
+__global__ __launch_bounds__(64) void quad_rollout_rows_kernel(
+    const float *state0, const float *actions, const float *ref, int B, float dt,
+    float half_dt, float half_dt2, float g0, float g1, float g2, float k0,
+    float k1, float k2, RowArgs R) {
+  APG_STAMP_DECL;
+  APG_STAMP_AT(0);
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;  // keep the wave convergent for the reduce
+  // Request schedule.  Loads return in order, so the order of the requests IS
+  // the order of arrival; the memory system delivers ~11 B / cycle / CU, i.e.
+  // one 1 KiB row per wave every ~370 cycles - more than a forward step
+  // computes in.  The forward sweep needs state0 and the action rows only:
+  // they are requested first, all of them; the reference rows follow in
+  // REVERSE step order, kRefPerStep per forward step, so that the reverse
+  // sweep consumes them while they are still streaming in.
+#ifndef APG_ROWS_ACT_PRE
+#define APG_ROWS_ACT_PRE 3
+#endif
+#ifndef APG_ROWS_REF_PER_STEP
+#define APG_ROWS_REF_PER_STEP 1
+#endif
+  constexpr int kActPre = HT < (APG_ROWS_ACT_PRE) ? HT : (APG_ROWS_ACT_PRE);
+  constexpr int kRefPerStep = APG_ROWS_REF_PER_STEP;
+#ifndef APG_ROWS_REF_LOOK
+#define APG_ROWS_REF_LOOK 3
+#endif
+#ifndef APG_ROWS_ST_AUX
+#define APG_ROWS_ST_AUX 2  // nt
+#endif
+#ifndef APG_ROWS_REF_TOP
+#define APG_ROWS_REF_TOP 0  // 1: rows below H - kRefLook all requested before
+#endif                      //    the first store (top of the reverse sweep)
+  // kRefLook > 0: just-in-time reference rows - the last kRefLook forward
+  // steps request rows H-1 .. H-kRefLook, reverse step k requests row
+  // k - kRefLook, so that the reverse sweep reads while it computes
+  constexpr int kRefLook = APG_ROWS_REF_LOOK > HT ? HT : APG_ROWS_REF_LOOK;
+  const auto r_s0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(state0), 0, 3 * B * 16, 0x00020000);
+  const auto r_act = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(actions), 0, HT * B * 16, 0x00020000);
+  const auto r_ref = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(ref), 0, HT * B * 24, 0x00020000);
+  const int v16 = bb * 16, v24 = bb * 24, p16 = B * 16, p24 = B * 24;
+  APG_STAMP_REAL(7);
+
+  u4v s4[3], a4[HT], rA[HT];
+  u2v rB[HT];
+  auto ld_ref = [&](int kr) {
+    rA[kr] = __builtin_amdgcn_raw_buffer_load_b128(r_ref, v24, kr * p24, 0);
+    rB[kr] = __builtin_amdgcn_raw_buffer_load_b64(r_ref, v24 + 16, kr * p24, 0);
+  };
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+    s4[g] = __builtin_amdgcn_raw_buffer_load_b128(r_s0, v16, g * p16, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < kActPre; ++k)
+    a4[k] = __builtin_amdgcn_raw_buffer_load_b128(r_act, v16, k * p16, 0);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // everything below the first requests can wait for the rest of the arguments
+  QuadConst c;
+  c.dt = dt, c.half_dt = half_dt, c.half_dt2 = half_dt2;
+  c.g[0] = g0, c.g[1] = g1, c.g[2] = g2;
+  c.kdt[0] = k0, c.kdt[1] = k1, c.kdt[2] = k2;
+  c.wd[0] = R.wd[0], c.wd[1] = R.wd[1], c.wd[2] = R.wd[2];
+  const auto r_ga = __builtin_amdgcn_make_buffer_rsrc(R.grad_actions, 0,
+                                                      HT * B * 16, 0x00020000);
+  // dead lanes store out of range (dropped by the buffer range check): no
+  // exec-mask branches around the stores
+  const int st16 = live ? b * 16 : (int)0x80000000;
+
+  const bool reducer = blockIdx.x == 0 && R.prev.prev_partials != nullptr;
+  PrevPartials pp;
+  if (reducer) reduce_prev_head(R.prev, pp);
+  __builtin_amdgcn_sched_barrier(0);
+
+  float s[12];
+  Trig st_trig[HT];
+  float st_w[HT + 1][3];
+  float st_pv[HT][6];
+#pragma unroll
+  for (int k = 0; k < HT; ++k) {
+    {  // requests of this step
+      if (k + kActPre < HT)
+        a4[k + kActPre] = __builtin_amdgcn_raw_buffer_load_b128(
+            r_act, v16, (k + kActPre) * p16, 0);
+      if constexpr (kRefLook == 0) {
+#pragma unroll
+        for (int j = 0; j < kRefPerStep; ++j) {
+          const int kr = HT - 1 - (k * kRefPerStep + j);
+          if (kr >= 0) ld_ref(kr);
+        }
+      } else if (k >= HT - kRefLook) {
+        ld_ref(HT - 1 - (k - (HT - kRefLook)));  // rows H-1 .. H-kRefLook
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (k == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        s[4 * g] = u2f(s4[g].x), s[4 * g + 1] = u2f(s4[g].y);
+        s[4 * g + 2] = u2f(s4[g].z), s[4 * g + 3] = u2f(s4[g].w);
+      }
+    }
+    const float act[4] = {u2f(a4[k].x), u2f(a4[k].y), u2f(a4[k].z), u2f(a4[k].w)};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st_w[k][i] = s[9 + i];
+    st_trig[k] = make_trig(&s[3]);
+    quad_step(s, act, c, st_trig[k]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st_pv[k][i] = s[i], st_pv[k][3 + i] = s[6 + i];
+    if constexpr (STATES_OUT) {
+      const auto r_so = __builtin_amdgcn_make_buffer_rsrc(
+          R.states_out, 0, HT * 3 * B * 16, 0x00020000);
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+        __builtin_amdgcn_raw_buffer_store_b128(
+            (u4v){f2u(s[4 * g]), f2u(s[4 * g + 1]), f2u(s[4 * g + 2]),
+                  f2u(s[4 * g + 3])},
+            r_so, st16, (k * 3 + g) * p16, 2);
+    }
+    if (k == 0) APG_STAMP_AT(1);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) st_w[HT][i] = s[9 + i];
+  APG_STAMP_AT(2);
+
+  float sum_p = 0.f, sum_v = 0.f, sum_w = 0.f, sum_r = 0.f, sum_t = 0.f;
+  const float wp2 = 2.f * R.w.pos, wv2 = 2.f * R.w.vel, ww2 = 2.f * R.w.av,
+              wr2 = 2.f * R.w.rates, wt2 = 2.f * R.w.thrust;
+  float lam[12];
+#ifdef APG_EXP_NO_STORES
+  float exp_keep = 0.f;
+#endif
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = 0.f;
+#pragma unroll
+  for (int k = HT - 1; k >= 0; --k) {
+    if constexpr (kRefLook > 0 && APG_ROWS_REF_TOP) {
+      if (k == HT - 1) {
+#pragma unroll
+        for (int kr = HT - 1 - kRefLook; kr >= 0; --kr) ld_ref(kr);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (kRefLook > 0) {
+      if (k - kRefLook >= 0) ld_ref(k - kRefLook);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float rp[3] = {u2f(rA[k].x), u2f(rA[k].y), u2f(rA[k].z)};
+    const float rv[3] = {u2f(rA[k].w), u2f(rB[k].x), u2f(rB[k].y)};
+    const float act[4] = {u2f(a4[k].x), u2f(a4[k].y), u2f(a4[k].z), u2f(a4[k].w)};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float dp = st_pv[k][i] - rp[i];
+      const float dv = st_pv[k][3 + i] - rv[i];
+      const float wn = st_w[k + 1][i];
+      sum_p = fmaf(dp, dp, sum_p), sum_v = fmaf(dv, dv, sum_v);
+      sum_w = fmaf(wn, wn, sum_w);
+      lam[i] = fmaf(wp2, dp, lam[i]);
+      lam[6 + i] = fmaf(wv2, dv, lam[6 + i]);
+      lam[9 + i] = fmaf(ww2, wn, lam[9 + i]);
+    }
+    const float a0 = act[0], da0 = a0 - 0.5f;
+    float ga[4];
+    ga[0] = wt2 * da0;
+    sum_t = fmaf(da0, da0, sum_t);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      const float d = act[i] - 0.5f;
+      sum_r = fmaf(d, d, sum_r);
+      ga[i] = wr2 * d;
+    }
+    quad_step_adjoint(lam, ga, a0, st_w[k], c, st_trig[k]);
+#ifdef APG_EXP_NO_STORES  // timing experiment: only the last row is written
+    exp_keep += (ga[0] + ga[1]) + (ga[2] + ga[3]);
+    if (k == 0) ga[0] += exp_keep;
+    if (k == 0)
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(
+        (u4v){f2u(ga[0]), f2u(ga[1]), f2u(ga[2]), f2u(ga[3])}, r_ga, st16, k * p16,
+        APG_ROWS_ST_AUX);
+    if (k == HT / 2) APG_STAMP_AT(6);
+  }
+  if (R.grad_state0) {
+    const auto r_gs = __builtin_amdgcn_make_buffer_rsrc(R.grad_state0, 0,
+                                                        3 * B * 16, 0x00020000);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      __builtin_amdgcn_raw_buffer_store_b128(
+          (u4v){f2u(lam[4 * g]), f2u(lam[4 * g + 1]), f2u(lam[4 * g + 2]),
+                f2u(lam[4 * g + 3])},
+          r_gs, st16, g * p16, 2);
+  }
+  APG_STAMP_AT(3);
+  const float loss = R.w.pos * sum_p + R.w.vel * sum_v + R.w.av * sum_w +
+                     R.w.rates * sum_r + R.w.thrust * sum_t;
+  write_wave_partial(R.loss_partials, live ? loss : 0.f);
+  if (reducer) reduce_prev_tail(R.prev, pp);
+  APG_STAMP_FLUSH();
 }
 
 // Reference (AoS, row-major) tensors, compile-time horizon.  A wave owns 64
@@ -527,9 +867,10 @@ __global__ __launch_bounds__(256) void quad_features_bwd_kernel(
 inline int grid_for(int B, int block) { return (B + block - 1) / block; }
 
 int check_common(const void *p0, const void *p1, const void *params, int B,
-                 int layout) {
+                 int layout, bool packed_ok = false) {
   if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
-  if (layout != APG_LAYOUT_SOA && layout != APG_LAYOUT_AOS) {
+  if (layout != APG_LAYOUT_SOA && layout != APG_LAYOUT_AOS &&
+      !(packed_ok && layout == APG_LAYOUT_PACKED)) {
     set_error("unknown layout %d", layout);
     return APG_ERR_ARG;
   }
@@ -584,12 +925,52 @@ int launch_rollout(const RolloutArgs &A, hipStream_t st) {
   return check_launch("quad_rollout_fwd_bwd");
 }
 
+// APG_LAYOUT_PACKED: register-resident horizons only (the reference configs)
+template <bool SO>
+int launch_rollout_rows(const RolloutArgs &A, hipStream_t st) {
+  if (A.H != 5 && A.H != 10) {
+    set_error("APG_LAYOUT_PACKED: H must be 5 or 10 (got %d)", A.H);
+    return APG_ERR_ARG;
+  }
+  if (A.ref_cols != 6) {
+    set_error("APG_LAYOUT_PACKED: ref rows are [pos, vel] (ref_cols = 6)");
+    return APG_ERR_ARG;
+  }
+  if ((long long)A.H * 3 * A.B * 16 >= (1ll << 31)) {
+    set_error("APG_LAYOUT_PACKED: H * B too large for 32-bit buffer offsets");
+    return APG_ERR_ARG;
+  }
+  RowArgs R;
+  for (int i = 0; i < 3; ++i) R.wd[i] = A.c.wd[i];
+  R.w = A.w;
+  R.loss_partials = A.loss_partials, R.grad_actions = A.grad_actions;
+  R.grad_state0 = A.grad_state0, R.states_out = A.states_out;
+  R.prev = A.prev;
+  const dim3 grid(grid_for(A.B, 64)), block(64);
+  const QuadConst &c = A.c;
+#define APG_ROWS(HT)                                                          \
+  hipLaunchKernelGGL((quad_rollout_rows_kernel<HT, SO>), grid, block, 0, st,  \
+                     A.state0, A.actions, A.ref, A.B, c.dt, c.half_dt,        \
+                     c.half_dt2, c.g[0], c.g[1], c.g[2], c.kdt[0], c.kdt[1],  \
+                     c.kdt[2], R)
+  if (A.H == 10) APG_ROWS(10);
+  else APG_ROWS(5);
+#undef APG_ROWS
+  return check_launch("quad_rollout_fwd_bwd(packed)");
+}
+
 }  // namespace
 }  // namespace apg
 
 using namespace apg;
 
 extern "C" {
+
+#ifdef APG_STAMP
+int apg_debug_set_stamps(unsigned long long *dev) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev, sizeof(dev));
+}
+#endif
 
 int apg_quad_step_fwd(const float *state, const float *action, float dt,
                       const ApgQuadParams *params, int B, int layout,
@@ -637,7 +1018,7 @@ int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
                              float *states_out,
                              const ApgDeferredLoss *deferred,
                              apg_stream_t stream) {
-  if (int e = check_common(state0, actions, params, B, layout)) return e;
+  if (int e = check_common(state0, actions, params, B, layout, true)) return e;
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
   if (deferred && deferred->prev_partials) {
     if (!deferred->prev_loss || deferred->prev_count < 0 ||
@@ -680,7 +1061,10 @@ int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
   A.prev = has_prev ? *deferred : ApgDeferredLoss{nullptr, 0, nullptr};
   A.B = B, A.H = H, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
   int e;
-  if (layout == APG_LAYOUT_SOA)
+  if (layout == APG_LAYOUT_PACKED)
+    e = states_out ? launch_rollout_rows<true>(A, st)
+                   : launch_rollout_rows<false>(A, st);
+  else if (layout == APG_LAYOUT_SOA)
     e = states_out ? launch_rollout<APG_LAYOUT_SOA, true>(A, st)
                    : launch_rollout<APG_LAYOUT_SOA, false>(A, st);
   else

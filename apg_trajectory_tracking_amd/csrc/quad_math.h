@@ -22,9 +22,18 @@ struct Trig {
 
 __host__ __device__ __forceinline__ Trig make_trig(const float att[3]) {
   Trig t;
+  // device code: the hardware pair (7 issue slots per angle instead of ~30);
+  // host builds (tests/host_math) and -DAPG_SW_TRIG: the branch-free software
+  // pair, which stays the fixed-wing kernels' sin/cos as well
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(APG_SW_TRIG)
+  sincos_hw(att[0], &t.sr, &t.cr);
+  sincos_hw(att[1], &t.sp, &t.cp);
+  sincos_hw(att[2], &t.sy, &t.cy);
+#else
   sincos_fast(att[0], &t.sr, &t.cr);
   sincos_fast(att[1], &t.sp, &t.cp);
   sincos_fast(att[2], &t.sy, &t.cy);
+#endif
   return t;
 }
 
@@ -61,13 +70,26 @@ __host__ __device__ __forceinline__ void quad_step(float (&s)[12], const float (
 
 // Adjoint of quad_step.  lam = dL/d(next state) on entry, dL/d(state) on
 // exit; ga += dL/d(action) through the dynamics.
+//   lacc   = 1/2 dt^2 lam_p' + dt lam_v'          (cotangent of acc)
+//   lam_v  = lam_v' + 1/2 dt lam_p'
+//   ga0   += 15 (lacc . z),  ga_{1:3} += dt K lam_w'
+//   lam_w  = (1 - dt K) lam_w' + dt E^T lam_att'
+//   lam_att= lam_att' + dt (d(E w)/d att)^T lam_att' + (dz/d att)^T (T lacc)
+// The last product is contracted through two scalars instead of forming the
+// nine partials of z: with lz = T lacc, m = cy lz0 + sy lz1, n = sy lz0 - cy lz1
+//   (dz/dphi)^T lz   = cr n - sr (sp m + cp lz2)
+//   (dz/dtheta)^T lz = cr (cp m - sp lz2)
+//   (dz/dpsi)^T lz   = sr m - sp cr n
+// and d(E w)/d att shares r = sr la1 + cr la2 with E^T lam_att'.
 __host__ __device__ __forceinline__ void quad_step_adjoint(float (&lam)[12],
                                                   float (&ga)[4], float a0,
                                                   const float w[3],
                                                   const QuadConst &c,
                                                   const Trig &t) {
-  float z[3];
-  thrust_dir(t, z);
+  const float spcr = t.sp * t.cr;
+  const float z0 = fmaf(t.cy, spcr, t.sr * t.sy);
+  const float z1 = fmaf(t.sy, spcr, -(t.cy * t.sr));
+  const float z2 = t.cr * t.cp;
   const float T = thrust_of(a0);
   float lacc[3];
 #pragma unroll
@@ -75,37 +97,31 @@ __host__ __device__ __forceinline__ void quad_step_adjoint(float (&lam)[12],
     lacc[i] = c.half_dt2 * lam[i] + c.dt * lam[6 + i];
     lam[6 + i] += c.half_dt * lam[i];  // dL/dv
   }
-  ga[0] += 15.0f * (lacc[0] * z[0] + lacc[1] * z[1] + lacc[2] * z[2]);
+  ga[0] += 15.0f * (lacc[0] * z0 + lacc[1] * z1 + lacc[2] * z2);
   const float lz0 = T * lacc[0], lz1 = T * lacc[1], lz2 = T * lacc[2];
   const float la0 = lam[3], la1 = lam[4], la2 = lam[5];
-  // dL/dw = (1 - dt K) lam_w' + dt E^T lam_att'
   const float lw0 = lam[9], lw1 = lam[10], lw2 = lam[11];
   ga[1] += c.kdt[0] * lw0;
   ga[2] += c.kdt[1] * lw1;
   ga[3] += c.kdt[2] * lw2;
+  const float r = t.sr * la1 + t.cr * la2;
   lam[9] = lw0 - c.kdt[0] * lw0 + c.dt * la0;
   lam[10] = lw1 - c.kdt[1] * lw1 + c.dt * (t.cr * la1 - t.sr * la2);
-  lam[11] = lw2 - c.kdt[2] * lw2 +
-            c.dt * (-t.sp * la0 + t.cp * t.sr * la1 + t.cp * t.cr * la2);
-  // dL/datt = lam_att' + dt (d(E w)/datt)^T lam_att' + (dz/datt)^T (T lacc)
-  const float dphi_e1 = -t.sr * w[1] + t.cp * t.cr * w[2];
-  const float dphi_e2 = -t.cr * w[1] - t.cp * t.sr * w[2];
-  const float dth_e0 = -t.cp * w[2];
-  const float dth_e1 = -t.sp * t.sr * w[2];
-  const float dth_e2 = -t.sp * t.cr * w[2];
-  const float dz_phi0 = -t.cy * t.sp * t.sr + t.cr * t.sy;
-  const float dz_phi1 = -t.sr * t.sy * t.sp - t.cy * t.cr;
-  const float dz_phi2 = -t.sr * t.cp;
-  const float dz_th0 = t.cy * t.cp * t.cr;
-  const float dz_th1 = t.cr * t.sy * t.cp;
-  const float dz_th2 = -t.cr * t.sp;
-  const float dz_psi0 = -t.sy * t.sp * t.cr + t.sr * t.cy;
-  const float dz_psi1 = t.cr * t.cy * t.sp + t.sy * t.sr;
-  lam[3] = la0 + c.dt * (dphi_e1 * la1 + dphi_e2 * la2) +
-           (dz_phi0 * lz0 + dz_phi1 * lz1 + dz_phi2 * lz2);
-  lam[4] = la1 + c.dt * (dth_e0 * la0 + dth_e1 * la1 + dth_e2 * la2) +
-           (dz_th0 * lz0 + dz_th1 * lz1 + dz_th2 * lz2);
-  lam[5] = la2 + (dz_psi0 * lz0 + dz_psi1 * lz1);
+  lam[11] = lw2 - c.kdt[2] * lw2 + c.dt * (t.cp * r - t.sp * la0);
+  // attitude rates e1, e2 of the step: d(E w)/dphi = (0, e2, -e1)
+  const float cpw2 = t.cp * w[2];
+  const float e1 = fmaf(t.cr, w[1], t.sr * cpw2);
+  const float e2 = fmaf(t.cr, cpw2, -(t.sr * w[1]));
+  const float gphi_e = la1 * e2 - la2 * e1;
+  const float gth_e = -w[2] * (t.cp * la0 + t.sp * r);
+  const float m = t.cy * lz0 + t.sy * lz1;
+  const float n = t.sy * lz0 - t.cy * lz1;
+  const float gphi_z = t.cr * n - t.sr * (t.sp * m + t.cp * lz2);
+  const float gth_z = t.cr * (t.cp * m - t.sp * lz2);
+  const float gpsi_z = t.sr * m - spcr * n;
+  lam[3] = la0 + c.dt * gphi_e + gphi_z;
+  lam[4] = la1 + c.dt * gth_e + gth_z;
+  lam[5] = la2 + gpsi_z;
 }
 
 QuadConst make_const(const ApgQuadParams &p, float dt) {

@@ -11,16 +11,20 @@ import ctypes
 import torch
 
 from . import _capi
-from ._capi import LAYOUT_AOS, LAYOUT_SOA, check, lib, ptr, require_device, stream_of
+from ._capi import (LAYOUT_AOS, LAYOUT_PACKED, LAYOUT_SOA, check, lib, ptr,
+                    require_device, stream_of)
 
-_LAYOUTS = {"aos": LAYOUT_AOS, "soa": LAYOUT_SOA}
+# "packed" (rows [rows][B][C], include/apg.h) is understood by the fused
+# quadrotor rollout only
+_LAYOUTS = {"aos": LAYOUT_AOS, "soa": LAYOUT_SOA, "packed": LAYOUT_PACKED}
 
 
 def _layout(layout):
     try:
         return _LAYOUTS[layout]
     except KeyError:
-        raise ValueError(f"layout must be 'aos' or 'soa', got {layout!r}")
+        raise ValueError(
+            f"layout must be 'aos', 'soa' or 'packed', got {layout!r}")
 
 
 def _f32c(t):
@@ -134,13 +138,28 @@ def _seq_shape(t, layout):
         raise ValueError(f"3-d sequence tensor expected, got {tuple(t.shape)}")
     if layout == LAYOUT_AOS:
         return t.shape[0], t.shape[1], t.shape[2]
+    if layout == LAYOUT_PACKED:
+        return t.shape[1], t.shape[0], t.shape[2]
     return t.shape[2], t.shape[0], t.shape[1]
 
 
 def _state_batch(t, layout):
+    if layout == LAYOUT_PACKED:
+        if t.dim() != 3 or t.shape[2] != 4:
+            raise ValueError(
+                f"packed state tensor [S/4, B, 4] expected, got {tuple(t.shape)}")
+        return t.shape[1]
     if t.dim() != 2:
         raise ValueError(f"2-d state tensor expected, got {tuple(t.shape)}")
     return t.shape[0] if layout == LAYOUT_AOS else t.shape[1]
+
+
+def _states_shape(B, H, S, lay):
+    if lay == LAYOUT_AOS:
+        return (B, H, S)
+    if lay == LAYOUT_PACKED:
+        return (H, S // 4, B, 4)
+    return (H, S, B)
 
 
 def quad_rollout_fwd_bwd(state0, actions, ref, dt, params, weights=None,
@@ -173,8 +192,7 @@ def quad_rollout_fwd_bwd(state0, actions, ref, dt, params, weights=None,
     loss = get("loss", (1,), want_loss)
     ga = get("grad_actions", actions.shape)
     gs = get("grad_state0", state0.shape, want_grad_state0)
-    states = get(
-        "states", (B, H, 12) if lay == LAYOUT_AOS else (H, 12, B), want_states)
+    states = get("states", _states_shape(B, H, 12, lay), want_states)
     check(lib().apg_quad_rollout_fwd_bwd(
         ptr(state0), ptr(actions), ptr(ref), ref_cols, float(dt),
         ctypes.byref(params), ctypes.byref(weights), B, H, lay, ptr(partials),

@@ -117,6 +117,33 @@ def from_soa_seq(x):
     return x.permute(2, 0, 1).contiguous()
 
 
+# APG_LAYOUT_PACKED (include/apg.h): rows of one trajectory's floats, batch as
+# the next-faster dimension - state [S/4][B][4], sequences [H][B][C]
+def to_packed_state(x):
+    """[B, S] -> [S/4, B, 4]"""
+    B, S = x.shape
+    return x.reshape(B, S // 4, 4).permute(1, 0, 2).contiguous()
+
+
+def to_packed_seq(x):
+    """[B, H, C] -> [H, B, C]"""
+    return x.permute(1, 0, 2).contiguous()
+
+
+def from_packed_state(x):
+    """[S/4, B, 4] -> [B, S]"""
+    G, B, W = x.shape
+    return x.permute(1, 0, 2).reshape(B, G * W).contiguous()
+
+
+def from_packed_seq(x):
+    """[H, B, C] -> [B, H, C]; states [H, 3, B, 4] -> [B, H, 12]"""
+    if x.dim() == 4:
+        H, G, B, W = x.shape
+        return x.permute(2, 0, 1, 3).reshape(B, H, G * W).contiguous()
+    return x.permute(1, 0, 2).contiguous()
+
+
 def quad_eval_trajectories(batch, length, dt, seed=42, speed=1.0):
     """Long smooth reference trajectories for the closed-loop evaluation, in the
     row format of `load_prepare_trajectory` (neural_control/trajectory/

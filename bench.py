@@ -13,7 +13,12 @@ mode, horizon 10, batch 65 536 synthetic polynomial trajectories per GPU
 (weak scaling: every rank owns its own 65 536-trajectory shard; the
 dynamics-only metric has no cross-rank exchange).
 The timing loop rotates over --sets independent buffer sets so the working
-set (sets x 44 MB) exceeds the 256 MB Infinity Cache.
+set (sets x 40 MB) exceeds the 256 MB Infinity Cache (SURVEY.md §8d: 8 sets);
+the same launches over 16 sets (640 MB - the read-only inputs alone no longer
+fit) and over ONE set (cache resident) are reported next to it, labelled.
+The K steps are captured into one HIP graph; the graph is replayed R times so
+that the timed region is >= --min-ms (a 20-step region of 0.15 ms would be
+dominated by the replay call itself); `steps` stays K, `config.replays` = R.
 """
 import argparse
 import json
@@ -41,7 +46,14 @@ def parse():
     ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--dt", type=float, default=0.1)
-    ap.add_argument("--layout", choices=["soa", "aos"], default="soa")
+    ap.add_argument("--layout", choices=["packed", "soa", "aos"],
+                    default="packed",
+                    help="packed: rows [rows][B][C] (16-byte accesses per lane, "
+                         "the fast path); soa: planes [C][B]; aos: the "
+                         "reference's row-major tensors")
+    ap.add_argument("--min-ms", type=float, default=5.0,
+                    help="replay the K-step graph until the timed region is "
+                         "at least this long")
     ap.add_argument("--sets", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--grad-state0", action="store_true")
@@ -53,6 +65,8 @@ def parse():
                     help="launch every step from Python instead of replaying "
                          "one captured HIP graph of the K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wide-sets", action="store_true",
+                    help="skip the informational 2 x --sets measurement")
     ap.add_argument("--train-steps", type=int, default=20,
                     help="steps of the secondary full-training-step "
                          "measurement (0 disables it)")
@@ -60,18 +74,22 @@ def parse():
     return ap.parse_args()
 
 
-def make_sets(args, rank, dev):
+def make_sets(args, rank, dev, nsets=None, first=0):
     """--sets independent (state0, actions, ref) triples in the chosen layout.
     ref is packed [pos, vel] (6 columns) for SoA - the 608 B/trajectory
     algorithmic layout - and the reference's 9-column rows for AoS."""
     from apg_trajectory_tracking_amd import synthetic
     sets = []
-    for i in range(args.sets):
+    for i in range(first, first + (nsets or args.sets)):
         d = synthetic.quad_polynomial_batch(
             args.batch, args.horizon, args.dt,
             seed=args.seed + 1000 * i + rank)
-        if args.layout == "soa":
-            ref6 = torch.cat((d["ref"][:, :, :3], d["ref"][:, :, 6:9]), 2)
+        ref6 = torch.cat((d["ref"][:, :, :3], d["ref"][:, :, 6:9]), 2)
+        if args.layout == "packed":
+            t = (synthetic.to_packed_state(d["state0"]),
+                 synthetic.to_packed_seq(d["actions"]),
+                 synthetic.to_packed_seq(ref6))
+        elif args.layout == "soa":
             t = (synthetic.to_soa_state(d["state0"]),
                  synthetic.to_soa_seq(d["actions"]), synthetic.to_soa_seq(ref6))
         else:
@@ -232,17 +250,39 @@ def train_step_probe(args, dev, dyn, dist):
     }
 
 
+KERNEL_SOURCES = ("quad.hip", "quad_math.h", "apg_device.h")
+
+
+def kernel_build_id():
+    """sha256 of the sources the dominant kernel is compiled from: PMC numbers
+    measured on another build of the kernel must not be reported for this one."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "apg_trajectory_tracking_amd", "csrc")
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc_traffic(args):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass of this very
-    command (profiles/pmc_traffic.json), or None."""
+    """(HBM bytes per launch, note): the committed rocprofv3 PMC pass of this
+    very command (profiles/pmc_traffic.json) - only if it was taken on THIS
+    build of the kernel (entry["kernel_build"] == kernel_build_id())."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    key = f"quad_B{args.batch}_H{args.horizon}_{args.layout}"
     try:
         with open(path) as f:
-            table = json.load(f)
-        key = f"quad_B{args.batch}_H{args.horizon}_{args.layout}"
-        return table.get(key, {}).get("hbm_bytes_per_launch")
+            entry = json.load(f).get(key)
     except (OSError, ValueError):
-        return None
+        entry = None
+    if not entry:
+        return None, f"no PMC entry {key} in profiles/pmc_traffic.json"
+    build = kernel_build_id()
+    if entry.get("kernel_build") != build:
+        return None, (f"PMC entry is for kernel build {entry.get('kernel_build')}, "
+                      f"this is {build}: stale, not reported")
+    return entry.get("hbm_bytes_per_launch"), f"PMC pass on kernel build {build}"
 
 
 def main():
@@ -317,23 +357,6 @@ def main():
             fn(n)
         return g
 
-    def timed(fn, n, graph):
-        """(host seconds, HIP-event ms) for exactly n steps, bracketed by
-        barrier + synchronize on both sides."""
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        barrier()
-        t0 = time.perf_counter()
-        with torch.cuda.stream(side):
-            e0.record()
-            if graph is not None:
-                graph.replay()
-            else:
-                fn(n)
-            e1.record()
-        barrier()
-        return time.perf_counter() - t0, e0.elapsed_time(e1)
-
     gc.collect()
     gc.disable()
     with torch.cuda.stream(side):
@@ -341,36 +364,81 @@ def main():
     torch.cuda.synchronize()
     g_steps = graph_of(run_steps, args.steps)
     g_kernel = graph_of(run_kernel_only, args.steps)
-    if g_steps is not None:      # one untimed replay: graph upload, clocks
+
+    def timed(fn, n, graph, replays):
+        """(host seconds, HIP-event ms) for `replays` x n steps, bracketed by
+        barrier + synchronize on both sides."""
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
         with torch.cuda.stream(side):
-            g_steps.replay()
-    elapsed, ev_ms = timed(run_steps, args.steps, g_steps)
+            e0.record()
+            for _ in range(replays):
+                if graph is not None:
+                    graph.replay()
+                else:
+                    fn(n)
+            e1.record()
+        barrier()
+        return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+    # one untimed pass (graph upload, clocks) that also sizes the region
+    _, probe_ms = timed(run_steps, args.steps, g_steps, 1)
+    replays = max(1, int(-(-args.min_ms // max(probe_ms, 1e-3))))
+    if dist is not None:     # every rank must run the same number of replays
+        t = torch.tensor([replays], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        replays = int(t.item())
+    elapsed, ev_ms = timed(run_steps, args.steps, g_steps, replays)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_check = float(plans[0].out["loss"].item())
+    nsteps = args.steps * replays
 
     # roofline pass: the same rollout launches alone (no loss reduction),
     # bracketed by one HIP-event pair on the launch stream -> average launch
     # duration of the dominant kernel including the kernel-to-kernel boundary
-    # (a per-launch event pair would add ~2.5 us of its own to a ~9 us kernel)
+    # (a per-launch event pair would add ~2.5 us of its own to a ~8 us kernel)
     with torch.cuda.stream(side):
         run_kernel_only(min(args.warmup, 10))
-    _, k_ms = timed(run_kernel_only, args.steps, g_kernel)
-    kernel_ms = k_ms / args.steps
+    _, k_ms = timed(run_kernel_only, args.steps, g_kernel, replays)
+    kernel_ms = k_ms / nsteps
     # the same launch on ONE buffer set: inputs stay in the 256 MB Infinity
     # Cache - reported, labelled, never used for `value` or the roofline
-    torch.cuda.synchronize()
-    k0 = torch.cuda.Event(enable_timing=True)
-    k1 = torch.cuda.Event(enable_timing=True)
-    with torch.cuda.stream(side):
-        k0.record()
-        for i in range(args.steps):
-            kplans[0].launch()
-        k1.record()
-    torch.cuda.synchronize()
-    resident_ms = k0.elapsed_time(k1) / args.steps
+    def events_over(launches):
+        torch.cuda.synchronize()
+        k0 = torch.cuda.Event(enable_timing=True)
+        k1 = torch.cuda.Event(enable_timing=True)
+        n = max(nsteps, 200)
+        with torch.cuda.stream(side):
+            for i in range(20):
+                launches[i % len(launches)].launch()
+            k0.record()
+            for i in range(n):
+                launches[i % len(launches)].launch()
+            k1.record()
+        torch.cuda.synchronize()
+        return k0.elapsed_time(k1) / n
+    resident_ms = events_over(kplans[:1])
+    # ... and over twice as many sets (the read-only inputs of 8 sets, 235 MB,
+    # still fit the Infinity Cache; those of 16 do not)
+    wide_ms = None
+    if not args.no_wide_sets:
+        try:
+            more = make_sets(args, rank, dev, nsets=nset, first=nset)
+            with torch.cuda.stream(side):
+                wplans = kplans + [
+                    F.RolloutPlan("quad", *s, args.dt, dyn.params,
+                                  layout=args.layout,
+                                  want_grad_state0=args.grad_state0,
+                                  loss_mode="none") for s in more]
+            wide_ms = events_over(wplans)
+            del wplans, more
+        except Exception as e:     # informational only (e.g. out of memory)
+            wide_ms = None
     gc.enable()
 
     H, B = args.horizon, args.batch
@@ -378,14 +446,15 @@ def main():
         QUAD_BYTES_PER_TRAJ["grad_state0"] if args.grad_state0 else 0)
     algo_bytes = B * bytes_per_traj
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_note = load_pmc_traffic(args)
     out = {
         "metric": "env-steps/sec (fwd+bwd through dynamics), quad horizon=10 batch=65536",
-        "value": world * B * H * args.steps / elapsed,
+        "value": world * B * H * nsteps / elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": elapsed / nsteps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -399,20 +468,27 @@ def main():
             "grad_state0": bool(args.grad_state0),
             "loss_mode": args.loss_mode,
             "launch": "python" if args.no_graph else "hip-graph replay of the K steps",
+            "replays": replays, "timed_steps": nsteps,
             "parallelism": f"batch-sharded x{world}, no data-path collective",
         },
-        "ms_per_step_hip_events": ev_ms / args.steps,
+        "ms_per_step_hip_events": ev_ms / nsteps,
         "roofline": {
             "bound": "hbm",
-            "kernel": "quad_rollout_reg_kernel",
+            "kernel": {"packed": "quad_rollout_rows_kernel",
+                       "soa": "quad_rollout_reg_kernel",
+                       "aos": "quad_rollout_aos_kernel"}[args.layout],
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(args),
+            "traffic": traffic, "traffic_note": traffic_note,
+            "kernel_build": kernel_build_id(),
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_us_avg": kernel_ms * 1e3,
             "kernel_us_avg_cache_resident": resident_ms * 1e3,
+            "kernel_us_avg_2x_sets": None if wide_ms is None else wide_ms * 1e3,
+            "frac_2x_sets": (None if wide_ms is None else
+                             algo_bytes / (wide_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
         },
         "loss_check": loss_check,
     }

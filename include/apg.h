@@ -22,8 +22,16 @@
  *                      state[B][S], seq[B][H][C]   (C = A, or ref columns)
  *      APG_LAYOUT_SOA  device-native, batch fastest:
  *                      state[S][B], seq[H][C][B]
+ *      APG_LAYOUT_PACKED  device-native, rows of one trajectory's floats with
+ *                      the batch as the next-faster dimension (accepted by
+ *                      apg_quad_rollout_fwd_bwd only, H = 5 or 10):
+ *                      state[S/4][B][4], seq[H][B][C]  (actions C = 4, packed
+ *                      reference rows C = 6, states_out [H][3][B][4])
  *    The fused rollout kernels read one trajectory per lane; with SOA every
- *    wave-wide load/store is one fully coalesced 256-byte transaction.
+ *    wave-wide load/store is one fully coalesced 256-byte transaction, with
+ *    PACKED a lane moves a whole row with one 16-byte access (1 KiB per wave
+ *    instruction) - a quarter of the memory instructions, which is what the
+ *    one-wave-per-SIMD rollout kernel is paced by.
  */
 #ifndef APG_H_
 #define APG_H_
@@ -37,7 +45,7 @@ extern "C" {
 
 typedef void *apg_stream_t; /* hipStream_t */
 
-enum { APG_LAYOUT_SOA = 0, APG_LAYOUT_AOS = 1 };
+enum { APG_LAYOUT_SOA = 0, APG_LAYOUT_AOS = 1, APG_LAYOUT_PACKED = 2 };
 
 enum {
   APG_OK = 0,

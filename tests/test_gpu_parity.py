@@ -199,6 +199,113 @@ def test_quad_rollout_full_size_vs_oracle(dev):
     assert torch.equal(res_b["grad_actions"], res["grad_actions"][:, :, half:])
 
 
+def _packed_inputs(d, dev):
+    from apg_trajectory_tracking_amd import synthetic as sy
+    ref6 = torch.cat((d["ref"][:, :, :3], d["ref"][:, :, 6:9]), 2)
+    return (sy.to_packed_state(d["state0"]).to(dev),
+            sy.to_packed_seq(d["actions"]).to(dev),
+            sy.to_packed_seq(ref6).to(dev))
+
+
+@pytest.mark.parametrize("tag,mp", [("def", {}), ("mod", MOD)])
+def test_quad_rollout_golden_packed_layout(dev, tag, mp):
+    """G2 through APG_LAYOUT_PACKED (rows [rows][B][C], 16-byte accesses per
+    lane - the layout bench.py measures), H = 10 and the ragged H = 5 case."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic as sy
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    g = load_golden("quad_rollout.npz")
+    dyn = FlightmareDynamics(modified_params=dict(mp))
+    cases = [("", tag + "_", float(g["dt"]))]
+    if tag == "def":
+        cases.append(("h5_", "h5_", float(g["h5_dt"])))
+    for pre, out, dt in cases:
+        d = {k: torch.from_numpy(np.ascontiguousarray(g[pre + k]))
+             for k in ("state0", "actions", "ref")}
+        s0, a, r = _packed_inputs(d, dev)
+        res = F.quad_rollout_fwd_bwd(s0, a, r, dt, dyn.params, layout="packed",
+                                     want_states=True)
+        assert res["states"].shape == (a.shape[0], 3, a.shape[1], 4)
+        assert rel_err(N(sy.from_packed_seq(res["states"])), g[out + "states"]) < 1e-5
+        assert abs(res["loss"].item() - g[out + "loss"]) / g[out + "loss"] < 1e-5
+        assert rel_err(N(sy.from_packed_seq(res["grad_actions"])),
+                       g[out + "gactions"]) < TOL
+        assert rel_err(N(sy.from_packed_state(res["grad_state0"])),
+                       g[out + "gstate0"]) < TOL
+
+
+def test_quad_rollout_packed_full_size_vs_oracle(dev):
+    """BASELINE config 2 through the packed layout: B = 65 536, H = 10 against
+    the CPU autograd oracle, a ragged batch (dead lanes store out of range),
+    and bit-identity with the plane-layout kernel's arithmetic is NOT asked
+    for - only the 1e-4 bar."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic as sy
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from oracle import torch_port as tp
+    H, dt = 10, 0.1
+    dyn = FlightmareDynamics()
+    for B, seed in ((65536, 0), (65536 - 37, 3), (1, 4), (63, 5), (65, 6)):
+        d = sy.quad_polynomial_batch(B, H, dt, seed=seed)
+        st, loss, ga, gs = tp.rollout_fwd_bwd(
+            tp.QuadOracle(), tp.quad_mpc_loss, d["state0"], d["actions"],
+            d["ref"], dt)
+        s0, a, r = _packed_inputs(d, dev)
+        # canaries behind every output: a dead lane must not write
+        out = {"grad_actions": torch.full((H + 1, B, 4), 7.0, device=dev)[:H],
+               "grad_state0": torch.full((4, B, 4), 7.0, device=dev)[:3],
+               "states": torch.full((H + 1, 3, B, 4), 7.0, device=dev)[:H]}
+        res = F.quad_rollout_fwd_bwd(s0, a, r, dt, dyn.params, layout="packed",
+                                     want_states=True, out=out)
+        for k in out:       # the row after the last one is untouched
+            assert torch.all(out[k]._base[-1] == 7.0), k
+        assert rel_err(N(sy.from_packed_seq(res["states"])), st.numpy()) < TOL
+        assert abs(res["loss"].item() - loss.item()) / loss.item() < TOL
+        dev_ga = N(sy.from_packed_seq(res["grad_actions"]))
+        assert rel_err(dev_ga, ga.numpy()) < TOL
+        assert rel_err(N(sy.from_packed_state(res["grad_state0"])), gs.numpy()) < TOL
+        per_traj = (np.abs(dev_ga - ga.numpy()).reshape(B, -1).max(1)
+                    / np.abs(ga.numpy()).reshape(B, -1).max(1))
+        assert per_traj.max() < 1e-3 and np.median(per_traj) < 1e-5
+    # additivity over a batch split / per-trajectory independence (B = 65 536)
+    B = 65536
+    d = sy.quad_polynomial_batch(B, H, dt, seed=0)
+    s0, a, r = _packed_inputs(d, dev)
+    res = F.quad_rollout_fwd_bwd(s0, a, r, dt, dyn.params, layout="packed")
+    half = B // 2
+    parts = [F.quad_rollout_fwd_bwd(
+        s0[:, sl].contiguous(), a[:, sl].contiguous(), r[:, sl].contiguous(),
+        dt, dyn.params, layout="packed")
+        for sl in (slice(0, half), slice(half, B))]
+    tot = parts[0]["loss"].item() + parts[1]["loss"].item()
+    assert abs(tot - res["loss"].item()) / res["loss"].item() < 1e-5
+    assert torch.equal(parts[0]["grad_actions"], res["grad_actions"][:, :half])
+    assert torch.equal(parts[1]["grad_actions"], res["grad_actions"][:, half:])
+
+
+def test_quad_packed_layout_errors(dev):
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    dyn = FlightmareDynamics()
+    z = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(ValueError):   # only the register-resident horizons
+        F.quad_rollout_fwd_bwd(z(3, 8, 4), z(7, 8, 4), z(7, 8, 6), 0.1,
+                               dyn.params, layout="packed")
+    with pytest.raises(ValueError):   # packed reference rows are [pos, vel]
+        F.quad_rollout_fwd_bwd(z(3, 8, 4), z(10, 8, 4), z(10, 8, 9), 0.1,
+                               dyn.params, layout="packed")
+    with pytest.raises(ValueError):   # state must be [3, B, 4]
+        F.quad_rollout_fwd_bwd(z(8, 12), z(10, 8, 4), z(10, 8, 6), 0.1,
+                               dyn.params, layout="packed")
+    with pytest.raises(ValueError):   # no packed variant of the no-grad unroll
+        F.quad_rollout_fwd(z(3, 8, 4), z(10, 8, 4), 0.1, dyn.params,
+                           layout="packed")
+    res = F.quad_rollout_fwd_bwd(z(3, 0, 4), z(10, 0, 4), z(10, 0, 6), 0.1,
+                                 dyn.params, layout="packed")
+    assert res["loss"].item() == 0.0
+
+
 def test_quad_empty_and_errors(dev):
     from apg_trajectory_tracking_amd import functional as F
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
@@ -384,7 +491,8 @@ def test_cartpole(dev):
         assert rel_err(N(gs), g["gstate0"]) < TOL
 
 
-def test_deferred_loss_chain(dev):
+@pytest.mark.parametrize("layout", ["soa", "packed"])
+def test_deferred_loss_chain(dev, layout):
     """ApgDeferredLoss: step i's loss reduced inside step i+1's launch equals
     the eager two-kernel loss (same partials, fixed summation orders)."""
     from apg_trajectory_tracking_amd import functional as F, synthetic
@@ -395,10 +503,13 @@ def test_deferred_loss_chain(dev):
     plans, eager = [], []
     for seed in range(3):
         d = synthetic.quad_polynomial_batch(B, H, dt, seed=seed)
-        t = (soa_state(d["state0"].to(dev)), soa_seq(d["actions"].to(dev)),
-             soa_seq(d["ref"].to(dev)))
-        eager.append(F.quad_rollout_fwd_bwd(*t, dt, dyn.params, layout="soa"))
-        plans.append(F.RolloutPlan("quad", *t, dt, dyn.params, layout="soa",
+        if layout == "packed":
+            t = _packed_inputs(d, dev)
+        else:
+            t = (soa_state(d["state0"].to(dev)), soa_seq(d["actions"].to(dev)),
+                 soa_seq(d["ref"].to(dev)))
+        eager.append(F.quad_rollout_fwd_bwd(*t, dt, dyn.params, layout=layout))
+        plans.append(F.RolloutPlan("quad", *t, dt, dyn.params, layout=layout,
                                    loss_mode="deferred"))
     for p in plans:
         p.out["loss"].fill_(-1.0)
