@@ -173,17 +173,25 @@ __host__ __device__ __forceinline__ void sincos_fast(float x, float *sn, float *
 // reduce it themselves (valid for |u| <= 256), so the work left to the VALU
 // is x / 2pi to better than one fp32 rounding: the product with 1/2pi as a
 // two-word constant, split as fract(hi) + lo so that many revolutions cost no
-// precision (5 plain ops + 2 quarter-rate ops instead of ~30).  Absolute error
-// of the results ~1.5e-7 (measured against float64, tools/ab_quad.cpp runs
-// the rollout parity with it).  Host builds (tests only) use libm.
+// precision (5 plain + 2 quarter-rate instructions instead of ~30; absolute
+// error of the results ~1.5e-7).  A single rounded product (APG_TRIG_1WORD,
+// 3 instructions fewer per angle) leaves a phase error of 1.2e-7 |x| rad:
+// fine for attitudes within a few revolutions, but it fails the 1e-4 parity
+// bar at |x| ~ 1e4 rad (tests/test_gpu_parity.py::test_quad_large_angles_and_
+// rates) and measured no faster on the bench kernel (profiles/r02_ab_trig.json).
+// Host builds (tests only) use libm.
 __host__ __device__ __forceinline__ void sincos_hw(float x, float *sn, float *cs) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const float kHi = 0.15915494f;          // fl(1 / 2pi)
-  const float kLo = 6.4206382e-09f;       // 1 / 2pi - kHi
   const float u = x * kHi;
+#if defined(APG_TRIG_1WORD)
+  const float f = __builtin_amdgcn_fractf(u);
+#else
+  const float kLo = 6.4206382e-09f;       // 1 / 2pi - kHi
   float e = fmaf(x, kHi, -u);             // exact low word of the product
   e = fmaf(x, kLo, e);
   const float f = __builtin_amdgcn_fractf(u) + e;
+#endif
   *sn = __builtin_amdgcn_sinf(f);
   *cs = __builtin_amdgcn_cosf(f);
 #else

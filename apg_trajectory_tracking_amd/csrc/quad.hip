@@ -164,6 +164,15 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
 #endif
   constexpr int kActPre = HT < (APG_REG_ACT_PRE) ? HT : (APG_REG_ACT_PRE);
   constexpr int kRefPerStep = APG_REG_REF_PER_STEP;
+#ifndef APG_REG_REF_LOOK
+#define APG_REG_REF_LOOK 3
+#endif
+  // kRefLook > 0 (measured faster, profiles/r02_ab_jit.json): the reference
+  // rows are requested just in time - the last kRefLook forward steps ask for
+  // rows H-1 .. H-kRefLook, reverse step k for row k - kRefLook - so that the
+  // forward sweep is not paced by the reference stream (loads return in order)
+  // and the reverse sweep reads while it computes
+  constexpr int kRefLook = APG_REG_REF_LOOK > HT ? HT : APG_REG_REF_LOOK;
 
   // deferred loss of an earlier launch (ApgDeferredLoss): request its
   // partials before this wave's own inputs, sum them at the very end
@@ -249,10 +258,15 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
     {  // requests of this step: action row k + kActPre, reference rows in
        // reverse step order
       if (k + kActPre < HT) ld_act(k + kActPre);
+      if constexpr (kRefLook == 0) {
 #pragma unroll
-      for (int j = 0; j < kRefPerStep; ++j) {
-        const int kr = HT - 1 - (k * kRefPerStep + j);
-        if (kr >= 0) ld_ref(kr, rp[kr], rv[kr]);
+        for (int j = 0; j < kRefPerStep; ++j) {
+          const int kr = HT - 1 - (k * kRefPerStep + j);
+          if (kr >= 0) ld_ref(kr, rp[kr], rv[kr]);
+        }
+      } else if (k >= HT - kRefLook) {
+        const int kr = HT - 1 - (k - (HT - kRefLook));
+        ld_ref(kr, rp[kr], rv[kr]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -288,6 +302,10 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
 #pragma unroll
   for (int k = HT - 1; k >= 0; --k) {
+    if constexpr (kRefLook > 0) {
+      if (k - kRefLook >= 0) ld_ref(k - kRefLook, rp[k - kRefLook], rv[k - kRefLook]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const float dp = st_pv[k][i] - rp[k][i];

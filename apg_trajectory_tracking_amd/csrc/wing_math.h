@@ -55,13 +55,58 @@ WingConst make_const(const ApgWingParams &p, float dt) {
 }
 
 constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTanBound = 0.17632698070846498f;  // tan(10 deg)
+
+// alpha = clamp(atan(t), +-10 deg) needs the arc tangent on |t| <= tan(10 deg)
+// only: outside, the clamp returns the bound and kills the gradient.  With t
+// clamped FIRST, atan is its Taylor polynomial to t^9 (next term 4.6e-10) -
+// 6 instructions instead of libm's ~40 with their selects - and
+// atan(tan(bound)) reproduces the bound to 3e-9.  `free` = 1 where the clamp
+// was inactive, computed arithmetically (a compare + v_cndmask pair costs ~5
+// issue slots on gfx950, tools/issue_probe.hip).
+__host__ __device__ __forceinline__ float atan_clamped(float t, float *tc_out,
+                                                       float *free_out) {
+  const float tc = fminf(fmaxf(t, -kTanBound), kTanBound);
+  *tc_out = tc;
+  // (|t| - bound, not t - tc: the compiler contracts `w * (1/u) - tc` into an
+  // fma whose exact product differs from the rounded t by its rounding error)
+  *free_out = 1.f - fminf(1.f, fmaxf(fabsf(t) - kTanBound, 0.f) * 1e30f);
+  const float z = tc * tc;
+  float p = fmaf(z, 1.f / 9.f, -1.f / 7.f);
+  p = fmaf(z, p, 1.f / 5.f);
+  p = fmaf(z, p, -1.f / 3.f);
+  return fmaf(tc * z, p, tc);
+}
+
+// sin / cos on |x| <= 10 deg (the clamped alpha, beta): Taylor to x^7 / x^6,
+// truncation < 3e-11
+__host__ __device__ __forceinline__ void sincos_small(float x, float *sn, float *cs) {
+  const float z = x * x;
+  float ps = fmaf(z, -1.f / 5040.f, 1.f / 120.f);
+  ps = fmaf(z, ps, -1.f / 6.f);
+  *sn = fmaf(x * z, ps, x);
+  float pc = fmaf(z, -1.f / 720.f, 1.f / 24.f);
+  pc = fmaf(z, pc, -0.5f);
+  *cs = fmaf(z, pc, 1.f);
+}
+
+// attitude angles: the hardware pair on the device (apg_device.h), the
+// branch-free software pair on the host (tests/host_math)
+__host__ __device__ __forceinline__ void sincos_att(float x, float *sn, float *cs) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(APG_SW_TRIG)
+  sincos_hw(x, sn, cs);
+#else
+  sincos_fast(x, sn, cs);
+#endif
+}
 
 // Everything the adjoint re-uses from the forward evaluation of one step.
 struct WingAux {
   float T, de, da, dr;
-  float V, V2, iV, r2V, tw, tb;  // iV = 1/V, tw = w/u, tb = v/V
+  float V, V2, iV, r2V, tw, tb;  // iV = 1/V; tw = w/u, tb = v/V, both CLAMPED
+                                 // to +-tan(10 deg)
   float alpha, beta;
-  bool alpha_free, beta_free;    // clamp passes the gradient
+  float alpha_free, beta_free;   // 1: clamp passes the gradient, 0: it does not
   float sa, ca, sb, cb;
   float CL, CD, CY, Cl, Cm, Cn, Q;
   float L, D, Y;
@@ -78,22 +123,18 @@ __host__ __device__ __forceinline__ void wing_rates(const float (&s)[12],
                                            WingAux &x, float (&sd)[12]) {
   const float u = s[3], v = s[4], w = s[5];
   const float p = s[9], q = s[10], r = s[11];
-  // normalize_action :41-46
+  // normalize_action :41-46 (pi (40 a - 20) / 180 with the constants folded:
+  // no IEEE division sequence per control surface)
   x.T = a[0] * 7.f;
-  x.de = kPi * (a[1] * 40.f - 20.f) / 180.f;
-  x.da = kPi * (a[2] * 5.f - 2.5f) / 180.f;
-  x.dr = kPi * (a[3] * 40.f - 20.f) / 180.f;
+  x.de = fmaf(a[1], kPi * 40.f / 180.f, -kPi * 20.f / 180.f);
+  x.da = fmaf(a[2], kPi * 5.f / 180.f, -kPi * 2.5f / 180.f);
+  x.dr = fmaf(a[3], kPi * 40.f / 180.f, -kPi * 20.f / 180.f);
   // :130-134
   x.V2 = u * u + v * v + w * w;
   x.V = sqrt_fast(x.V2);
   x.iV = rcp_nr(x.V);
-  x.tw = w * rcp_nr(u);
-  x.tb = v * x.iV;
-  const float al = atanf(x.tw), be = atanf(x.tb);
-  x.alpha_free = (al >= -k.alpha_bound) && (al <= k.alpha_bound);
-  x.beta_free = (be >= -k.alpha_bound) && (be <= k.alpha_bound);
-  x.alpha = fminf(fmaxf(al, -k.alpha_bound), k.alpha_bound);
-  x.beta = fminf(fmaxf(be, -k.alpha_bound), k.alpha_bound);
+  x.alpha = atan_clamped(w * rcp_nr(u), &x.tw, &x.alpha_free);
+  x.beta = atan_clamped(v * x.iV, &x.tb, &x.beta_free);
   x.r2V = 0.5f * x.iV;
   // :139-164
   x.CL = k.CL0 + k.CL_a * x.alpha + k.CL_qc * x.r2V * q + k.CL_de * x.de;
@@ -110,11 +151,11 @@ __host__ __device__ __forceinline__ void wing_rates(const float (&s)[12],
   x.L = x.Q * x.CL, x.D = x.Q * x.CD, x.Y = x.Q * x.CY;
   const float l = x.Q * k.c * x.Cl, m = x.Q * k.c * x.Cm, n = x.Q * k.c * x.Cn;
   // :185-204 body forces
-  sincos_fast(x.alpha, &x.sa, &x.ca);
-  sincos_fast(x.beta, &x.sb, &x.cb);
-  sincos_fast(s[6], &x.sph, &x.cph);
-  sincos_fast(s[7], &x.sth, &x.cth);
-  sincos_fast(s[8], &x.sps, &x.cps);
+  sincos_small(x.alpha, &x.sa, &x.ca);
+  sincos_small(x.beta, &x.sb, &x.cb);
+  sincos_att(s[6], &x.sph, &x.cph);
+  sincos_att(s[7], &x.sth, &x.cth);
+  sincos_att(s[8], &x.sps, &x.cps);
   x.icth = rcp_nr(x.cth);
   const float f0 = -x.ca * x.cb * x.D - x.ca * x.sb * x.Y + x.sa * x.L -
                    k.g_m * x.sth + x.T * k.cos_eps;
@@ -267,15 +308,16 @@ __host__ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
   const float g_r2V = g_qt * q + g_pt * p + g_rt * r;
   const float iV = x.iV;
   float gV = -g_r2V * x.r2V * iV;
-  // alpha = clamp(atan(w/u)), beta = clamp(atan(v/V))
-  if (x.alpha_free) {
-    const float gt = g_al * rcp_nr(1.f + x.tw * x.tw);
+  // alpha = clamp(atan(w/u)), beta = clamp(atan(v/V)): where the clamp is
+  // active the mask is 0 and tw / tb hold the (finite) bound
+  {
+    const float gt = x.alpha_free * g_al * rcp_nr(1.f + x.tw * x.tw);
     const float iu = rcp_nr(u);
     dw += gt * iu;
     du -= gt * x.tw * iu;
   }
-  if (x.beta_free) {
-    const float gt = g_be * rcp_nr(1.f + x.tb * x.tb);
+  {
+    const float gt = x.beta_free * g_be * rcp_nr(1.f + x.tb * x.tb);
     dv += gt * iV;
     gV -= gt * x.tb * iV;
   }
@@ -283,7 +325,7 @@ __host__ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
   du += 2.f * u * gV2, dv += 2.f * v * gV2, dw += 2.f * w * gV2;
   // actions
   ga[0] += 7.f * gT;
-  ga[1] += g_de * (kPi * 40.f / 180.f);
+  ga[1] += g_de * (kPi * 40.f / 180.f);   // (constant-folded)
   ga[2] += g_da * (kPi * 5.f / 180.f);
   ga[3] += g_dr * (kPi * 40.f / 180.f);
   lam[3] += du, lam[4] += dv, lam[5] += dw;
