@@ -99,11 +99,29 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
   load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
   if (blockIdx.x == 0 && threadIdx.x < kWave && A.prev.prev_partials)
     reduce_prev_partials(A.prev);
+  // The loads are software-pipelined against the arithmetic: with two waves
+  // per SIMD a step's own loads would expose most of the ~1 us HBM latency
+  // twice per step.  Forward sweep: the rows of step kk + 2 are requested
+  // while step kk computes.
   float loss = 0.f;
+  float a_q[2][4], r_q[2][3];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int kq = d < H ? d : H - 1;
+    load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kq, 0, a_q[d]);
+    load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kq, 0, r_q[d]);
+  }
   for (int kk = 0, slot = 0, phase = 0; kk < H; ++kk) {
     float a[4], rp[3];
-    load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kk, 0, a);
-    load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kk, 0, rp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = a_q[0][i], a_q[0][i] = a_q[1][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rp[i] = r_q[0][i], r_q[0][i] = r_q[1][i];
+    {
+      const int kq = kk + 2 < H ? kk + 2 : H - 1;
+      load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kq, 0, a_q[1]);
+      load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kq, 0, r_q[1]);
+    }
     if (phase == 0) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) ST(slot, i) = s[i];
@@ -129,17 +147,32 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
   float nxt[3] = {s[0], s[1], s[2]};  // position after the group's last step
   const int G = (H + S - 1) / S;
+  // reverse sweep: the action and reference rows of group g - 1 are requested
+  // while group g is re-integrated and differentiated
+  float act[kWingMaxStride][4], rpg[kWingMaxStride][3];
+  float act_n[kWingMaxStride][4], rpg_n[kWingMaxStride][3];
+  auto load_group = [&](int g, float(&ga_)[kWingMaxStride][4],
+                        float(&gr_)[kWingMaxStride][3]) {
+#pragma unroll
+    for (int j = 0; j < kWingMaxStride; ++j) {
+      int kq = g * S + j;           // rows past the group / horizon: any valid row
+      kq = (j < S && kq < H) ? kq : H - 1;
+      load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kq, 0, ga_[j]);
+      load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kq, 0, gr_[j]);
+    }
+  };
+  load_group(G - 1, act, rpg);
   for (int g = G - 1; g >= 0; --g) {
     const int k0 = g * S;
     const int n = (H - k0) < S ? (H - k0) : S;
-    float pre[kWingMaxStride + 1][12], act[kWingMaxStride][4];
+    load_group(g > 0 ? g - 1 : 0, act_n, rpg_n);
+    float pre[kWingMaxStride + 1][12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) pre[0][i] = ST(g, i);
     // re-integrate the states inside the group
 #pragma unroll
     for (int j = 0; j < kWingMaxStride; ++j) {
       if (j < n) {
-        load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, k0 + j, 0, act[j]);
         if (j + 1 < kWingMaxStride && j + 1 < n) {
 #pragma unroll
           for (int i = 0; i < 12; ++i) pre[j + 1][i] = pre[j][i];
@@ -153,14 +186,13 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
     for (int j = kWingMaxStride - 1; j >= 0; --j) {
       if (j < n) {
         const int kk = k0 + j;
-        float rp[3], pn[3] = {nxt[0], nxt[1], nxt[2]}, sd[12];
-        load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kk, 0, rp);
+        float pn[3] = {nxt[0], nxt[1], nxt[2]}, sd[12];
         if (j + 1 < kWingMaxStride && j + 1 < n) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) pn[i] = pre[j + 1][i];
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) lam[i] += 2.f * A.w.pos * (pn[i] - rp[i]);
+        for (int i = 0; i < 3; ++i) lam[i] += 2.f * A.w.pos * (pn[i] - rpg[j][i]);
         float ga[4] = {0.f, 2.f * A.w.action * (act[j][1] - 0.5f),
                        2.f * A.w.action * (act[j][2] - 0.5f),
                        2.f * A.w.action * (act[j][3] - 0.5f)};
@@ -173,6 +205,13 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) nxt[i] = pre[0][i];
+#pragma unroll
+    for (int j = 0; j < kWingMaxStride; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) act[j][i] = act_n[j][i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rpg[j][i] = rpg_n[j][i];
+    }
   }
   if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
 #undef APG_LAUNDER
