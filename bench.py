@@ -65,6 +65,8 @@ def parse():
                     help="launch every step from Python instead of replaying "
                          "one captured HIP graph of the K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the fixed-wing dual-roofline block")
     ap.add_argument("--no-wide-sets", action="store_true",
                     help="skip the informational 2 x --sets measurement")
     ap.add_argument("--train-steps", type=int, default=20,
@@ -160,8 +162,30 @@ def cpu_baseline(args):
                   "ms_per_iter": c_el / n * 1e3}
     except Exception as e:  # the C oracle is optional equipment
         c_port = {"error": repr(e)}
+    # config 4 (fixed wing, B = 131 072, H = 20) on the host cores: the C
+    # restatement with its hand reverse sweep (oracle/apg_oracle_wing.c)
+    c_wing = None
+    try:
+        from oracle import c_oracle as co
+        wb, wh, wdt = 131072, 20, 0.05
+        w = synthetic.wing_batch(wb, wh, wdt, seed=args.seed)
+        ws, wa, wr = (w["state0"].numpy(), w["actions"].numpy(), w["ref"].numpy())
+        co.wing_rollout_fwd_bwd(ws, wa, wr, wdt, want_states=False)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or time.perf_counter() - t0 < 2.0:
+            co.wing_rollout_fwd_bwd(ws, wa, wr, wdt, want_states=False)
+            n += 1
+        w_el = time.perf_counter() - t0
+        c_wing = {"value": wb * wh * n / w_el, "unit": "env-steps/s",
+                  "cores": ncpu, "batch": wb, "horizon": wh,
+                  "what": "oracle/apg_oracle_wing.c fp32, OpenMP, hand adjoint",
+                  "ms_per_iter": w_el / n * 1e3}
+    except Exception as e:
+        c_wing = {"error": repr(e)}
     return {
         "c_oracle": c_port,
+        "c_oracle_wing": c_wing,
         "value": args.batch * args.horizon * iters / el,
         "unit": "env-steps/s",
         "cores": threads,
@@ -251,15 +275,18 @@ def train_step_probe(args, dev, dyn, dist):
 
 
 KERNEL_SOURCES = ("quad.hip", "quad_math.h", "apg_device.h")
+WING_SOURCES = ("wing.hip", "wing_math.h", "apg_device.h")
+FP32_VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2   # 157.3 TFLOP/s spec = one
+# wave64 fma per SIMD every 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
 
 
-def kernel_build_id():
+def kernel_build_id(sources=KERNEL_SOURCES):
     """sha256 of the sources the dominant kernel is compiled from: PMC numbers
     measured on another build of the kernel must not be reported for this one."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "apg_trajectory_tracking_amd", "csrc")
-    for name in KERNEL_SOURCES:
+    for name in sources:
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -283,6 +310,65 @@ def load_pmc_traffic(args):
         return None, (f"PMC entry is for kernel build {entry.get('kernel_build')}, "
                       f"this is {build}: stale, not reported")
     return entry.get("hbm_bytes_per_launch"), f"PMC pass on kernel build {build}"
+
+
+def wing_secondary(args, dev):
+    """BASELINE configs[3] (fixed wing, H = 20, B = 131 072) is
+    VALU-bound, so BOTH fractions are reported: algorithmic HBM bytes (928 B /
+    trajectory) per second against 8 TB/s, and issued fp32 VALU
+    wave-instructions per second against the vector peak (the instruction
+    count per launch is a PMC figure, SQ_INSTS_VALU, committed in
+    profiles/pmc_traffic.json and only used for the build it was taken on)."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    B, H, dt = 131072, 20, 0.05
+    dyn = FixedWingDynamics()
+    plans = []
+    for i in range(4):
+        d = synthetic.wing_batch(B, H, dt, seed=args.seed + i)
+        plans.append(F.RolloutPlan(
+            "wing", synthetic.to_soa_state(d["state0"]).to(dev),
+            synthetic.to_soa_seq(d["actions"]).to(dev),
+            synthetic.to_soa_seq(d["ref"]).to(dev), dt, dyn.params,
+            layout="soa", loss_mode="none"))
+    for i in range(8):
+        plans[i % 4].launch()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    n = 60
+    e0.record()
+    for i in range(n):
+        plans[i % 4].launch()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / n * 1e-3
+    algo = B * (48 + 16 * H + 12 * H + 16 * H)
+    out = {"workload": "fixed-wing concurrent rollout fwd+bwd, BASELINE configs[3]",
+           "batch": B, "horizon": H, "us_per_launch": sec * 1e6,
+           "env_steps_per_s": B * H / sec,
+           "hbm": {"algorithmic_bytes_per_launch": algo,
+                   "achieved_GBps": algo / sec / 1e9,
+                   "frac": algo / sec / 1e9 / HBM_PEAK_GBS},
+           "fp32_valu": None}
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+            entry = json.load(f).get(f"wing_B{B}_H{H}_soa")
+    except (OSError, ValueError):
+        entry = None
+    build = kernel_build_id(WING_SOURCES)
+    if entry and entry.get("kernel_build") == build:
+        n_valu = entry["valu_wave_instructions_per_launch"]
+        out["fp32_valu"] = {
+            "wave_instructions_per_launch": n_valu,
+            "achieved_wave_instr_per_s": n_valu / sec,
+            "peak_wave_instr_per_s": FP32_VALU_WAVE_INSTR_PER_S,
+            "frac": n_valu / sec / FP32_VALU_WAVE_INSTR_PER_S,
+            "kernel_build": build}
+    else:
+        out["fp32_valu_note"] = f"no PMC entry for wing kernel build {build}"
+    return out
 
 
 def main():
@@ -497,6 +583,11 @@ def main():
             out["train_step"] = train_step_probe(args, dev, dyn, dist)
         except Exception as e:      # informational only
             out["train_step"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        try:
+            out["secondary"] = {"wing_rollout": wing_secondary(args, dev)}
+        except Exception as e:      # informational only
+            out["secondary"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     elif rank == 0:

@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line(
         "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)"
     )
+    # the CPU oracles are ~600 tiny eager ops per unroll: on a 256-CPU host the
+    # default intra-op thread count makes them 10x SLOWER than 16 threads
+    # (bench.py's thread sweep: 137 ms at 16 threads, 1 995 ms at 128)
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except ImportError:
+        pass
 
 
 def load_golden(name):

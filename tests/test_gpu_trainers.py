@@ -135,7 +135,7 @@ def test_quad_concurrent_fused_matches_unfused(dev, B):
     assert abs(l0 - l1) / abs(l0) < 1e-5
     assert set(g0) == set(g1)
     for k in g0:
-        assert rel_err(g1[k], g0[k]) < 2e-4, k
+        assert rel_err(g1[k], g0[k]) < 1e-4, k
 
 
 def test_quad_soa_head_matches_aos_path(dev):
@@ -197,7 +197,7 @@ def test_quad_recurrent_unroll(dev, mode):
         for k, p in trainer.net.named_parameters():
             key = f"{mode}.g.{k}"
             if key in g.files:
-                assert rel_err(N(p.grad), g[key]) < 2e-4, (fused, k)
+                assert rel_err(N(p.grad), g[key]) < 1e-4, (fused, k)
 
 
 def test_cartpole_train_step(dev):
@@ -261,7 +261,7 @@ def test_wing_train_step_vs_oracle(dev):
     for (k, p), (_, q) in zip(trainer.net.named_parameters(),
                               ref_net.named_parameters()):
         if q.grad is not None:
-            assert rel_err(N(p.grad), q.grad.numpy()) < 2e-4, k
+            assert rel_err(N(p.grad), q.grad.numpy()) < 1e-4, k
 
 
 @pytest.mark.parametrize("mode", ["concurrent", "autoregressive", "LSTM"])
@@ -309,7 +309,7 @@ def test_fused_lstm_rollout_matches_reference_unroll(dev):
         key = f"lstm.g.{k}"
         if key in g.files:
             assert p.grad is not None, k
-            assert rel_err(N(p.grad), g[key]) < 2e-4, k
+            assert rel_err(N(p.grad), g[key]) < 1e-4, k
 
 
 def test_fused_mlp_rollout_matches_reference_unroll(dev):
@@ -336,7 +336,7 @@ def test_fused_mlp_rollout_matches_reference_unroll(dev):
         key = f"ar.g.{k}"
         if key in g.files:
             assert p.grad is not None, k
-            assert rel_err(N(p.grad), g[key]) < 2e-4, k
+            assert rel_err(N(p.grad), g[key]) < 1e-4, k
 
 
 @pytest.mark.parametrize("B", [1, 100, 300])
@@ -368,7 +368,7 @@ def test_fused_mlp_ragged_batches_match_unfused(dev, B):
     assert abs(l0 - l1) / abs(l0) < 1e-5
     assert set(g0) == set(g1)
     for k in g0:
-        assert rel_err(g1[k], g0[k]) < 2e-4, k
+        assert rel_err(g1[k], g0[k]) < 1e-4, k
 
 
 @pytest.mark.parametrize("mode", ["lstm", "mlp"])
@@ -549,7 +549,7 @@ def test_controller_through_learnt_dynamics_is_not_fused(dev):
     assert abs(l_fused - l_learnt) <= 1e-4 * abs(l_fused)
     assert set(g_fused) == set(g_learnt) and len(g_fused) >= 12
     for k in g_fused:
-        assert rel_err(g_learnt[k], g_fused[k]) < 2e-4, k
+        assert rel_err(g_learnt[k], g_fused[k]) < 1e-4, k
     assert learnt.linear_at.grad is not None
     assert float(learnt.linear_state_2.bias.grad.abs().sum()) > 0
     with torch.no_grad():
@@ -596,7 +596,7 @@ def test_fused_lstm_ragged_batches_match_unfused(dev, B):
     assert abs(l0 - l1) / abs(l0) < 1e-5
     assert set(g0) == set(g1)
     for k in g0:
-        assert rel_err(g1[k], g0[k]) < 2e-4, k
+        assert rel_err(g1[k], g0[k]) < 1e-4, k
 
 
 @pytest.mark.parametrize("case", ["train", "test", "tight", "tight_test"])
@@ -801,7 +801,7 @@ def test_wing_concurrent_fused_policy_matches_unfused(dev, B):
     assert np.allclose(l0, l1, rtol=1e-5)
     assert set(g0) == set(g1)
     for k in g0:
-        assert rel_err(g1[k], g0[k]) < 2e-4, k
+        assert rel_err(g1[k], g0[k]) < 1e-4, k
     for k in w0:
         assert rel_err(w1[k], w0[k]) < 1e-5, k
 
