@@ -230,12 +230,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// One loss partial per wave, indexed by the global wave number.
-__device__ __forceinline__ void write_wave_partial(float *partials, float lane_loss) {
+// One loss partial per WAVE, indexed by the global wave number.  `count` =
+// number of partials the buffer holds (apg_loss_partials_count(B) =
+// ceil(B / 64)): with workgroups of more than one wave (-DAPG_ROLLOUT_BLOCK=128
+// / 256 builds) the fully dead tail waves of the last workgroup stay
+// convergent for the reductions and reach this point - they must not write.
+__device__ __forceinline__ void write_wave_partial(float *partials, float lane_loss,
+                                                   int count = 0x7fffffff) {
   float s = wave_sum(lane_loss);
   if ((threadIdx.x & (kWave - 1)) == 0) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    partials[wave] = s;
+    if (wave < count) partials[wave] = s;
   }
 }
 

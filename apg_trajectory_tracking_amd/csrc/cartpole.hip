@@ -87,7 +87,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void cart_rollout_kernel(
     }
     loss += 0.01f * a[0] * a[0];
   }
-  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+  write_wave_partial(A.loss_partials, live ? loss : 0.f, (A.B + kWave - 1) / kWave);
 
   float lam[4] = {0.f, 0.f, 0.f, 0.f}, g0[4] = {0.f, 0.f, 0.f, 0.f};
   float nxt[4] = {s[0], s[1], s[2], s[3]};

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_reg_kernel(
   APG_STAMP_AT(3);
   const float loss = A.w.pos * sum_p + A.w.vel * sum_v + A.w.av * sum_w +
                      A.w.rates * sum_r + A.w.thrust * sum_t;
-  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+  write_wave_partial(A.loss_partials, live ? loss : 0.f, (A.B + kWave - 1) / kWave);
   if (reducer) reduce_prev_tail(A.prev, pp);
   APG_STAMP_FLUSH();
 }
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_aos_kernel(
   }
   if (A.grad_state0 && live)
     store_state<APG_LAYOUT_AOS, 12>(A.grad_state0, A.B, b, lam);
-  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+  write_wave_partial(A.loss_partials, live ? loss : 0.f, (A.B + kWave - 1) / kWave);
   if (reducer) reduce_prev_tail(A.prev, pp);
 }
 
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_lds_kernel(
     loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
             A.w.thrust * da0 * da0;
   }
-  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+  write_wave_partial(A.loss_partials, live ? loss : 0.f, (A.B + kWave - 1) / kWave);
 
   float lam[12], wn[3] = {s[9], s[10], s[11]};
 #pragma unroll
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_loss_kernel(
     if (live && grad_actions)
       store_seq<LAYOUT, 4>(grad_actions, B, H, 4, b, k, 0, ga);
   }
-  write_wave_partial(partials, live ? loss : 0.f);
+  write_wave_partial(partials, live ? loss : 0.f, (B + kWave - 1) / kWave);
 }
 
 // ------------------------------------------------------ policy-input features

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
     }
     loss += A.w.pos * lp + A.w.action * la;
   }
-  write_wave_partial(A.loss_partials, live ? loss : 0.f);
+  write_wave_partial(A.loss_partials, live ? loss : 0.f, (A.B + kWave - 1) / kWave);
 
   float lam[12];
 #pragma unroll

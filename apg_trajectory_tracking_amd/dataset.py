@@ -21,9 +21,17 @@ class TensorBatches:
     shuffle=True, num_workers=0) over a Dataset whose __getitem__ returns
     `tuple(t[i] for t in tensors)` (scripts/train_base.py:132-137,
     neural_control/dataset.py:125-132) - but one index_select per tensor per
-    batch instead of O(B) Python collate calls."""
+    batch instead of O(B) Python collate calls.
 
-    def __init__(self, tensors, batch_size, shuffle=True, generator=None):
+    Data parallel (`shard=(rank, world)`, world > 1): `batch_size` stays the
+    GLOBAL minibatch; every rank holds the same data set, draws the SAME
+    permutation (a generator seeded with `shard_seed`, advanced once per
+    epoch on every rank) and takes its contiguous slice of each global batch
+    (parallel.shard_range) - so all ranks see the same number of batches and
+    the union of their slices is exactly the single-process batch."""
+
+    def __init__(self, tensors, batch_size, shuffle=True, generator=None,
+                 shard=None, shard_seed=0):
         n = tensors[0].shape[0]
         if any(t.shape[0] != n for t in tensors):
             raise ValueError("all tensors must share the first dimension")
@@ -31,6 +39,17 @@ class TensorBatches:
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
         self.generator = generator
+        self.shard = shard if shard and shard[1] > 1 else None
+        if self.shard and self.generator is None:
+            self.generator = torch.Generator().manual_seed(int(shard_seed))
+
+    def _slice(self, idx):
+        """This rank's part of one global batch of indices."""
+        if self.shard is None:
+            return idx
+        from .parallel import shard_range
+        lo, hi = shard_range(idx.shape[0], *self.shard)
+        return idx[lo:hi]
 
     def __len__(self):
         n = self.tensors[0].shape[0]
@@ -44,7 +63,7 @@ class TensorBatches:
         dev = self.tensors[0].device
         order = self._permutation(n, dev) if self.shuffle else torch.arange(n, device=dev)
         for lo in range(0, n, self.batch_size):
-            yield order[lo:lo + self.batch_size]
+            yield self._slice(order[lo:lo + self.batch_size])
 
     def _permutation(self, n, dev):
         # drawn on the device unless a (CPU) generator pins the order: a host
@@ -61,8 +80,13 @@ class TensorBatches:
             perm = self._permutation(n, dev)
         for lo in range(0, n, self.batch_size):
             if self.shuffle:
-                idx = perm[lo:lo + self.batch_size]
+                idx = self._slice(perm[lo:lo + self.batch_size])
                 yield tuple(t.index_select(0, idx) for t in self.tensors)
+            elif self.shard is not None:
+                idx = self._slice(torch.arange(
+                    lo, min(lo + self.batch_size, n), device=dev))
+                yield tuple(t[idx[0]:idx[-1] + 1] if idx.numel() else t[:0]
+                            for t in self.tensors)
             else:
                 yield tuple(t[lo:lo + self.batch_size] for t in self.tensors)
 

@@ -12,6 +12,15 @@ the reference too):
     w'_i = w_i + dt (K_i (a_i - 1/2 - w_i) + d_r,i / J_i)
     dL/dK_i = sum_b lam_w'_i dt (a_i - 1/2 - w_i),
     dL/dJ_i = -sum_b lam_w'_i dt d_r,i / J_i^2.
+
+Reference quirk kept on purpose (pinned by golden G10 `steps.*`): the matrices
+the simulated step multiplies with, `torch_inertia_J` / `torch_kinv_ang_vel_tau`,
+are `torch.diag(...)` COPIES made once in `__init__`
+(quad_dynamics_trained.py:48-50).  `torch_inertia_vector` / `torch_kinv_vector`
+receive gradients and are moved by the optimizer (and by `load_state_dict`),
+but the step keeps integrating with the kinv / inertia of construction time.
+The kernel's parameter block is therefore filled once, in `__init__`, and the
+closed-form gradients above are evaluated at those initial values.
 """
 import ctypes
 
@@ -26,7 +35,8 @@ from .quad_dynamics_flightmare import FlightmareDynamics
 
 class _LearntStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, state, action, kinv, inertia, mass, dt, params, rot_drag):
+    def forward(ctx, state, action, kinv, inertia, mass, dt, params, rot_drag,
+                inertia0):
         s, a = F._f32c(state), F._f32c(action)
         _capi.require_device(s, a)
         out = torch.empty_like(s)
@@ -34,7 +44,9 @@ class _LearntStep(torch.autograd.Function):
             _capi.ptr(s), _capi.ptr(a), float(dt), ctypes.byref(params),
             s.shape[0], _capi.LAYOUT_AOS, _capi.ptr(out), _capi.stream_of(s)),
             "apg_quad_step_fwd")
-        ctx.save_for_backward(s, a, inertia.detach())
+        # `inertia` here is the value the step was simulated with (the
+        # construction-time copy), not the live parameter
+        ctx.save_for_backward(s, a, inertia0.detach().to(s.device))
         ctx.meta = (float(dt), params, rot_drag)
         return out
 
@@ -52,7 +64,7 @@ class _LearntStep(torch.autograd.Function):
         g_kinv = (lam_w * (dt * ((a[:, 1:] - 0.5) - s[:, 9:12]))).sum(0)
         g_inertia = -(lam_w.sum(0)) * dt * rot_drag.to(s.device) / inertia**2
         g_mass = torch.zeros(1, device=s.device)
-        return gs, ga, g_kinv, g_inertia, g_mass, None, None, None
+        return gs, ga, g_kinv, g_inertia, g_mass, None, None, None, None
 
 
 class LearntDynamics(nn.Module, FlightmareDynamics):
@@ -75,10 +87,14 @@ class LearntDynamics(nn.Module, FlightmareDynamics):
             torch.tensor(np.asarray(self.kinv_ang_vel_tau)).float())
         self._rot_drag = torch.tensor(
             [float(v) for v in self.cfg["rotational_drag"]])
+        # the reference's torch.diag copies (:48-50): what the step uses from
+        # now on, whatever happens to the parameters above
+        self._inertia0 = self.torch_inertia_vector.detach().clone()
+        self._snapshot_params()
 
-    def _refresh_params(self):
-        """Copy the current learnable physical parameters into the kernel's
-        parameter block (one small device->host read per call)."""
+    def _snapshot_params(self):
+        """Fill the kernel's parameter block from the (initial) physical
+        parameters - called once, from __init__."""
         kinv = self.torch_kinv_vector.detach().cpu().tolist()
         inertia = self.torch_inertia_vector.detach().cpu().tolist()
         self.params.mass = float(self.mass.detach().cpu())
@@ -94,11 +110,10 @@ class LearntDynamics(nn.Module, FlightmareDynamics):
     def forward(self, state, action, dt):
         action_transformed = torch.matmul(
             self.linear_at, torch.unsqueeze(action, 2))[:, :, 0]
-        self._refresh_params()
         new_state = _LearntStep.apply(
             state, action_transformed, self.torch_kinv_vector,
             self.torch_inertia_vector, self.mass, dt, self.params,
-            self._rot_drag)
+            self._rot_drag, self._inertia0)
         return new_state + self.state_transformer(state, action_transformed)
 
     def __call__(self, *args, **kwargs):        # nn.Module.__call__, not the

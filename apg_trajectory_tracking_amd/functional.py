@@ -646,7 +646,12 @@ def to_soa(t, out=None, index=None):
     `out`: optional contiguous destination."""
     inner = torch.Size(t.shape[1:])
     R = int(inner.numel())
-    t = _f32c(t)
+    # no .contiguous() up front: a leading slice of longer rows (the whole
+    # data set's ref[:, :H] in the indexed paths) must be read IN PLACE
+    # through its row stride, not copied per minibatch
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
     dense_rows = all(t.stride(i + 1) == s_ for i, s_ in
                      enumerate(torch.empty(inner, device="meta").stride()))
     if not dense_rows or (t.shape[0] > 1 and t.stride(0) < R):

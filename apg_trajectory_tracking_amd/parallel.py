@@ -32,6 +32,30 @@ def shard_range(n, r=None, world=None):
     return lo, lo + base + (1 if r < extra else 0)
 
 
+def is_main():
+    """True on the rank that writes checkpoints / logs (rank 0)."""
+    return rank() == 0
+
+
+@torch.no_grad()
+def broadcast_module(module, src=0):
+    """Make every replica start from rank `src`'s parameters and buffers (one
+    flat fp32 message).  No-op for a single process."""
+    if world_size() == 1 or module is None:
+        return
+    tensors = [p.data for p in module.parameters()] + list(module.buffers())
+    tensors = [t for t in tensors if t.is_floating_point()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
 class GradAllReducer:
     """Flat bucket over the parameters that receive gradients.
 

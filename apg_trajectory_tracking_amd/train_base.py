@@ -10,8 +10,12 @@ Differences that matter for speed, not for results:
     instead of per-sample DataLoader collate (:132-137);
   * the running loss is accumulated on the device and read back ONCE per
     epoch instead of `loss.item()` per batch (:211);
-  * with torch.distributed initialised, every rank trains on its shard and
-    the policy gradient is all-reduced once per step (parallel.GradAllReducer).
+  * with torch.distributed initialised (one process per GPU): init_optimizer
+    broadcasts rank 0's policy (and learnable simulator) to every replica,
+    the loader hands each rank its slice of every GLOBAL minibatch (same
+    permutation on all ranks, dataset.TensorBatches), the gradients are
+    all-reduced once per step (parallel.GradAllReducer / the flat buffer of
+    the fused paths) and only rank 0 writes checkpoints and result files.
 The quirk `epoch_loss = running_loss / i` (i = last batch INDEX, :213) is kept.
 """
 import os
@@ -133,7 +137,13 @@ class TrainBase:
         """scripts/train_base.py:130-150: shuffled minibatch loader and
         SGD(lr, momentum 0.9) over the policy."""
         self.trainloader = TensorBatches(
-            self.dataset_tensors(), self.batch_size, shuffle=self.shuffle)
+            self.dataset_tensors(), self.batch_size, shuffle=self.shuffle,
+            shard=(parallel.rank(), parallel.world_size()),
+            shard_seed=getattr(self, "shard_seed", 0))
+        # replicas must start equal: the sum all-reduce keeps them equal
+        parallel.broadcast_module(self.net)
+        if isinstance(self.train_dynamics, torch.nn.Module):
+            parallel.broadcast_module(self.train_dynamics)
         self.optimizer_controller = optim.SGD(
             self.net.parameters(),
             lr=self.learning_rate_controller,
@@ -208,33 +218,34 @@ class TrainBase:
         available (returns a bool, runs nothing)."""
         return False if probe else None
 
+    def _residual_weight_norm(self):
+        """The regulariser of the simulator fit: 2-norms of the residual
+        network's four tensors, summed (scripts/train_base.py:171-178)."""
+        net = self.train_dynamics
+        return sum(torch.norm(t) for t in (
+            net.linear_state_2.weight, net.linear_state_2.bias,
+            net.linear_state_1.weight, net.linear_state_1.bias))
+
     def train_dynamics_model(self, current_state, action_seq):
-        """scripts/train_base.py:160-186: one SGD step fitting the learnable
-        train dynamics to the eval dynamics on the first action of the
-        sequence (sum of squared next-state differences + l2 on the residual
-        network)."""
+        """One optimizer step of the simulator fit (scripts/train_base.py:
+        160-186): the learnable train dynamics is pulled towards the eval
+        dynamics on (state, first action of the sequence) - squared error of
+        the two predicted next states, summed over the batch, plus
+        l2_lambda x the residual network's weight norms."""
+        first_action = action_seq[:, 0]
         self.optimizer_dynamics.zero_grad()
-        next_state_d1 = self.train_dynamics(
-            current_state, action_seq[:, 0], dt=self.delta_t
-        )
+        predicted = self.train_dynamics(current_state, first_action,
+                                        dt=self.delta_t)
         with torch.no_grad():
-            next_state_d2 = self.eval_dynamics(
-                current_state, action_seq[:, 0], dt=self.delta_t
-            )
-        l2_loss = 0
+            target = self.eval_dynamics(current_state, first_action,
+                                        dt=self.delta_t)
+        loss = torch.sum((predicted - target)**2)
         if self.l2_lambda > 0:
-            l2_loss = (
-                torch.norm(self.train_dynamics.linear_state_2.weight) +
-                torch.norm(self.train_dynamics.linear_state_2.bias) +
-                torch.norm(self.train_dynamics.linear_state_1.weight) +
-                torch.norm(self.train_dynamics.linear_state_1.bias)
-            )
-        # data parallel: the data term is a sum over the shard, the weight
-        # penalty is not - each rank carries 1/world of it so that the summed
-        # gradient equals the single-process one
-        loss = torch.sum(
-            (next_state_d1 - next_state_d2)**2
-        ) + self.l2_lambda * l2_loss / parallel.world_size()
+            # data parallel: the data term is a sum over the shard, the
+            # penalty is not - every rank carries 1 / world of it so that the
+            # all-reduced gradient equals the single-process one
+            loss = loss + (self.l2_lambda / parallel.world_size()
+                           ) * self._residual_weight_norm()
         loss.backward()
         if getattr(self, "grad_sync_dynamics", None) is not None:
             loss = self.grad_sync_dynamics.sync(loss.detach())  # replicas stay equal
@@ -283,14 +294,12 @@ class TrainBase:
                     in_state, current_state, in_ref_state, ref_states)) is not None:
                 pass        # policy + rollout + backward in the fused kernels
             else:
-                actions = self.net(in_state, in_ref_state)
-                actions = torch.sigmoid(actions)
-                action_seq = torch.reshape(
-                    actions, (-1, self.horizon, self.action_dim)
-                )
+                # policy -> (0, 1) actions for the whole horizon -> [B, H, A]
+                # (scripts/train_base.py:199-208), then the fused rollout step
+                plan = torch.sigmoid(self.net(in_state, in_ref_state))
                 loss = self.train_controller_model(
-                    current_state, action_seq, in_ref_state, ref_states
-                )
+                    current_state, plan.view(-1, self.horizon, self.action_dim),
+                    in_ref_state, ref_states)
             loss = loss.detach()
             running_loss = loss if running_loss is None else running_loss + loss
         return self._finish_epoch(running_loss, i, train)
@@ -301,7 +310,8 @@ class TrainBase:
         epoch_loss = float(running_loss.item()) / i
         self.results_dict["loss"].append(epoch_loss)
         self.results_dict["trained"].append(train)
-        print(f"Loss ({train}): {round(epoch_loss, 2)}")
+        if parallel.is_main():
+            print(f"Loss ({train}): {round(epoch_loss, 2)}")
         return epoch_loss
 
     def sample_new_data(self, epoch):
@@ -316,25 +326,52 @@ class TrainBase:
 
     def save_model(self, epoch, success=0.0, suc_std=0.0):
         """scripts/train_base.py:233-251: a checkpoint per evaluated epoch
-        (not for epoch 0) and the score bookkeeping; a state_dict is written
-        instead of the pickled module (checkpoint.py reads both)."""
+        (not for epoch 0) and the score bookkeeping.  A state_dict is written
+        instead of the pickled module; checkpoint.load_policy reads those
+        (whole-module pickles of the reference are converted once, see
+        checkpoint.py).  Rank 0 writes."""
         if epoch > 0:
             self.current_score = success
-            os.makedirs(self.save_path, exist_ok=True)
-            torch.save(self.net.state_dict(), os.path.join(
-                self.save_path, self.save_model_name + str(epoch)))
+            if parallel.is_main():
+                os.makedirs(self.save_path, exist_ok=True)
+                torch.save(self.net.state_dict(), os.path.join(
+                    self.save_path, self.save_model_name + str(epoch)))
 
     def finalize(self):
-        """scripts/train_base.py:253-287 without the plots: final weights and
-        the per-epoch statistics as csv."""
+        """scripts/train_base.py:253-287 without the plots: final weights,
+        the per-epoch statistics as csv, results.json and - for a learnable
+        simulator - its state_dict as `dynamics_model`.  Rank 0 writes."""
+        if not parallel.is_main():
+            return
+        import json
         os.makedirs(self.save_path, exist_ok=True)
         torch.save(self.net.state_dict(),
                    os.path.join(self.save_path, self.save_model_name))
-        np.savetxt(os.path.join(self.save_path, "loss.csv"),
-                   self.results_dict["loss"], delimiter=",")
-        if self.results_dict["mean_success"]:
-            np.savetxt(os.path.join(self.save_path, "mean_successes.csv"),
-                       self.results_dict["mean_success"], delimiter=",")
+        res = self.results_dict
+        for key, fname in (("mean_success", "mean_successes.csv"),
+                           ("std_success", "std_success.csv"),
+                           ("loss", "loss.csv"),
+                           ("mean_divergence_full", "mean_divergence_full.csv"),
+                           ("std_divergence_full", "std_divergence_full.csv"),
+                           ("mean_divergence", "mean_divergence.csv"),
+                           ("std_divergence", "std_divergence.csv")):
+            np.savetxt(os.path.join(self.save_path, fname),
+                       np.asarray([float(v) for v in res[key]]), delimiter=",")
+
+        def plain(v):
+            if isinstance(v, torch.Tensor):
+                return v.detach().cpu().tolist()
+            if isinstance(v, (np.floating, np.integer)):
+                return v.item()
+            if isinstance(v, np.ndarray):
+                return v.tolist()
+            return v
+        with open(os.path.join(self.save_path, "results.json"), "w") as f:
+            json.dump({k: [plain(x) for x in v] for k, v in res.items()}, f)
+        if isinstance(self.train_dynamics, torch.nn.Module):
+            torch.save(self.train_dynamics.state_dict(),
+                       os.path.join(self.save_path, "dynamics_model"))
+        print("finished and saved.")
 
     def _speed_curriculum(self, epoch, track):
         """The speed ladder of run_control (scripts/train_base.py:300-313):

@@ -82,9 +82,11 @@ class TrainDrone(TrainBase):
         self.config["modified_params"] = {
             k: (v.tolist() if hasattr(v, "tolist") else v)
             for k, v in modified_params.items()}
-        os.makedirs(self.save_path, exist_ok=True)
-        with open(os.path.join(self.save_path, "config.json"), "w") as f:
-            json.dump(self.config, f, default=str)
+        from . import parallel
+        if parallel.is_main():       # one writer under torch.distributed
+            os.makedirs(self.save_path, exist_ok=True)
+            with open(os.path.join(self.save_path, "config.json"), "w") as f:
+                json.dump(self.config, f, default=str)
         self.init_optimizer()
 
     def train_recurrent_model(

@@ -54,8 +54,9 @@ enum {
   APG_ERR_NO_DEVICE = -3 /* no gfx950 device visible                          */
 };
 
-/* Threads per workgroup of the fused rollout kernels; one loss partial is
- * produced per workgroup.  apg_loss_partials_count(B) = ceil(B / 64). */
+/* Threads per workgroup of the fused rollout kernels.  One loss partial is
+ * produced per WAVE (64 trajectories): apg_loss_partials_count(B) =
+ * ceil(B / 64) independently of this value. */
 #ifndef APG_ROLLOUT_BLOCK
 #define APG_ROLLOUT_BLOCK 64
 #endif
@@ -118,7 +119,8 @@ int apg_quad_step_bwd(const float *state, const float *action, float dt,
  *   ref      [B,H,ref_cols]    ref_cols = 9: reference rows
  *                              [pos, euler, vel] (cols 3:6 never read);
  *                              ref_cols = 6: packed [pos, vel]
- *   loss_partials [apg_loss_partials_count(B)]  per-workgroup loss sums
+ *   loss_partials [apg_loss_partials_count(B)]  per-WAVE loss sums (one per
+ *                 64 trajectories, whatever the workgroup size)
  *   loss          [1] or NULL; if given, a second tiny kernel sums the
  *                 partials in a fixed order (deterministic)
  *   grad_actions  [B,H,4]      dL/daction_seq

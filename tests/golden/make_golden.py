@@ -580,6 +580,24 @@ def g10_learnt_dynamics():
     out["loss"] = np.float64(loss.item())
     for k, p in dyn.named_parameters():
         out["g." + k] = npy(p.grad) if p.grad is not None else np.zeros(1)
+    # four optimizer steps of the train_dynamics_model loss (momentum SGD as
+    # in TrainBase.init_optimizer): torch_inertia_J / torch_kinv_ang_vel_tau
+    # are torch.diag COPIES made in __init__ (quad_dynamics_trained.py:48-50),
+    # so the parameters drift while the simulated step keeps the initial
+    # kinv / inertia - the recorded losses pin that behaviour
+    opt = torch.optim.SGD(dyn.parameters(), lr=1e-4, momentum=0.9)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        l = torch.sum((dyn(state, action, 0.1) - d2)**2)
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    out["steps.loss"] = np.asarray(losses, np.float64)
+    for k, v in dyn.state_dict().items():
+        out["steps.w." + k] = npy(v)
+    with torch.no_grad():
+        out["steps.next"] = npy(dyn(state, action, 0.1))
     save("learnt_dynamics.npz", **out)
 
 

@@ -126,6 +126,25 @@ def _dynamics_steps(lo, hi):
                     trainer.train_dynamics.state_dict().items()}
 
 
+def _epoch_run(world_sharded):
+    """Two epochs of the REAL run_epoch loop (shuffled loader) on a trainer
+    whose global minibatch is 16 of the 48 trajectories."""
+    trainer = _make_trainer()
+    trainer.batch_size = 16
+    trainer.shuffle = True
+    trainer.shard_seed = 123
+    with torch.no_grad():           # replicas start DIFFERENT on purpose
+        for p in trainer.net.parameters():
+            p.add_(0.01 * (dist.get_rank() if dist.is_initialized() else 0))
+    trainer.init_optimizer()        # broadcast + sharded loader
+    if not world_sharded:           # single process: same permutation stream
+        trainer.trainloader.generator = torch.Generator().manual_seed(123)
+    trainer.train_concurrent_fused = lambda *a, **k: (False if k.get("probe")
+                                                      else None)
+    losses = [trainer.run_epoch("controller", epoch=e) for e in range(2)]
+    return losses, {k: v.numpy() for k, v in trainer.net.state_dict().items()}
+
+
 def _worker(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, REPO)
@@ -152,6 +171,11 @@ def _worker(rank, world, port, out_dir):
         losses, sd = _dynamics_steps(lo, hi)
         np.savez(os.path.join(out_dir, f"dyn_rank{rank}.npz"),
                  losses=np.array(losses), **sd)
+        # the epoch loop itself: parameter broadcast, shared permutation,
+        # per-rank slices of every global minibatch
+        losses, sd = _epoch_run(True)
+        np.savez(os.path.join(out_dir, f"epoch_rank{rank}.npz"),
+                 losses=np.array(losses), **sd)
     finally:
         dist.destroy_process_group()
 
@@ -177,6 +201,16 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
             assert rel_err(g[k], v.numpy()) < 1e-5, (r, k)
 
 
+    ref_losses, ref_sd = _epoch_run(False)          # run_epoch, sharded loader
+    for r in range(world):
+        g = np.load(tmp_path / f"epoch_rank{r}.npz")
+        np.testing.assert_allclose(g["losses"], ref_losses, rtol=1e-5)
+        for k, v in ref_sd.items():
+            assert rel_err(g[k], v) < 1e-5, (r, k)
+    a, b = (np.load(tmp_path / f"epoch_rank{r}.npz") for r in range(2))
+    for k in ref_sd:
+        assert np.array_equal(a[k], b[k]), k
+
     ref_losses, ref_sd = _dynamics_steps(0, B)      # train_dynamics_model
     for r in range(world):
         g = np.load(tmp_path / f"dyn_rank{r}.npz")
@@ -193,3 +227,27 @@ def test_grad_allreducer_is_noop_single_process():
     loss = torch.tensor(2.5)
     assert GradAllReducer(lin.parameters()).sync(loss) is loss
     assert torch.equal(lin.weight.grad, g)
+
+
+def test_tensor_batches_shards_partition_every_global_batch():
+    """Every rank's slices of a global minibatch are disjoint, contiguous in
+    the shared permutation and cover it; all ranks see the same batch count."""
+    from apg_trajectory_tracking_amd.dataset import TensorBatches
+    data = (torch.arange(103),)
+    single = TensorBatches(data, 16, shuffle=True,
+                           generator=torch.Generator().manual_seed(7))
+    want = [b.tolist() for b in single.iter_indices()]
+    world = 3
+    parts = [list(TensorBatches(data, 16, shuffle=True, shard=(r, world),
+                                shard_seed=7).iter_indices()) for r in range(world)]
+    assert all(len(p) == len(want) for p in parts)
+    for i, w in enumerate(want):
+        got = sum((parts[r][i].tolist() for r in range(world)), [])
+        assert got == w
+    # __iter__ (materialised batches) agrees with iter_indices, unshuffled too
+    for shuffle in (True, False):
+        for r in range(world):
+            a = TensorBatches(data, 16, shuffle=shuffle, shard=(r, world), shard_seed=3)
+            b = TensorBatches(data, 16, shuffle=shuffle, shard=(r, world), shard_seed=3)
+            for (x,), idx in zip(a, b.iter_indices()):
+                assert x.tolist() == idx.tolist()

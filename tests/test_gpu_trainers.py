@@ -491,6 +491,23 @@ def test_learnt_dynamics_matches_reference(dev):
             assert rel_err(N(p.grad), ref) < 2e-3, k
         else:
             assert rel_err(N(p.grad), ref) < 1e-4, k
+    # four momentum-SGD steps (golden G10 `steps.*`): the reference keeps
+    # simulating with the kinv / inertia of construction time while the
+    # parameters drift (its torch.diag copies, quad_dynamics_trained.py:48-50;
+    # the inertia parameter even changes sign here) - the loss sequence only
+    # matches if the drop-in does the same
+    opt = torch.optim.SGD(dyn.parameters(), lr=1e-4, momentum=0.9)
+    for want in g["steps.loss"]:
+        opt.zero_grad()
+        l = torch.sum((dyn(state, action, float(g["dt"])) - d2.detach())**2)
+        l.backward()
+        opt.step()
+        assert abs(l.item() - want) / want < 2e-5, (l.item(), want)
+    with torch.no_grad():
+        assert rel_err(N(dyn(state, action, float(g["dt"]))), g["steps.next"]) < 1e-5
+    for k, v in dyn.state_dict().items():
+        tol = 5e-3 if k == "torch_inertia_vector" else 1e-4
+        assert rel_err(N(v), g["steps.w." + k]) < tol, k
     # trainer-level: fitting reduces the one-step model error
     cfg = dict(delta_t=0.1, delta_t_train=0.1, epoch_size=512, self_play=0,
                batch_size=128, state_size=12, horizon=10,
