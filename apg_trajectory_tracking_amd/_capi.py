@@ -175,6 +175,8 @@ SIGNATURES = {
     "apg_cartpole_rollout_fwd_bwd": [
         _P, _P, _F, ctypes.POINTER(ApgCartpoleParams), _I, _I, _I, _P, _P,
         _P, _P, _P, _P],
+    "apg_cartpole_rollout_fwd": [_P, _P, _F, ctypes.POINTER(ApgCartpoleParams),
+                                 _I, _I, _I, _P, _P],
     "apg_reduce_loss_partials": [_P, _I, _P, _P],
     "apg_loss_partials_count": [_I],
     "apg_version": [],

@@ -117,6 +117,23 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void cart_rollout_kernel(
   }
 }
 
+// no-grad unroll (evaluation): states only
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void cart_rollout_fwd_kernel(
+    const float *__restrict__ state0, const float *__restrict__ actions,
+    CartConst c, int B, int H, float *__restrict__ states_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s[4];
+  load_state<LAYOUT, 4>(state0, B, b, s);
+  for (int k = 0; k < H; ++k) {
+    float a[1];
+    load_seq<LAYOUT, 1>(actions, B, H, 1, b, k, 0, a);
+    cart_step(s, a[0], c);
+    store_seq<LAYOUT, 4>(states_out, B, H, 4, b, k, 0, s);
+  }
+}
+
 inline int grid_for(int B, int block) { return (B + block - 1) / block; }
 
 int check_args(const void *p0, const void *p1, const void *params, int B,
@@ -212,6 +229,26 @@ int apg_cartpole_rollout_fwd_bwd(const float *state0, const float *actions,
   if (loss)
     return launch_reduce_partials(loss_partials, apg_loss_partials_count(B), loss, st);
   return APG_OK;
+}
+
+int apg_cartpole_rollout_fwd(const float *state0, const float *actions, float dt,
+                             const ApgCartpoleParams *params, int B, int H,
+                             int layout, float *states_out, apg_stream_t stream) {
+  if (int e = check_args(state0, actions, params, B, layout)) return e;
+  if (H < 1) { set_error("H must be >= 1 (got %d)", H); return APG_ERR_ARG; }
+  if (B == 0) return APG_OK;
+  if (!states_out) { set_error("states_out is NULL"); return APG_ERR_ARG; }
+  const CartConst c = make_const(*params, dt);
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == APG_LAYOUT_SOA)
+    hipLaunchKernelGGL(cart_rollout_fwd_kernel<APG_LAYOUT_SOA>,
+                       dim3(grid_for(B, 256)), dim3(256), 0, st, state0, actions,
+                       c, B, H, states_out);
+  else
+    hipLaunchKernelGGL(cart_rollout_fwd_kernel<APG_LAYOUT_AOS>,
+                       dim3(grid_for(B, 256)), dim3(256), 0, st, state0, actions,
+                       c, B, H, states_out);
+  return check_launch("cartpole_rollout_fwd");
 }
 
 }  // extern "C"

@@ -34,3 +34,9 @@ class CartpoleDynamics:
         next state [B,4]."""
         self.timestamp += .05          # side effect kept (:57)
         return F.cartpole_step(state, action, delta_t, self.params)
+
+    def rollout(self, state0, action_seq, dt):
+        """H-step no-grad unroll in one kernel: states [B, H, 4]."""
+        self.timestamp += .05 * action_seq.shape[1]
+        return F.cartpole_rollout_fwd(F._f32c(state0), F._f32c(action_seq), dt,
+                                      self.params)

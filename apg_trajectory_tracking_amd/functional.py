@@ -404,6 +404,21 @@ def cartpole_rollout_fwd_bwd(state0, actions, dt, params, layout="aos",
     return o
 
 
+def cartpole_rollout_fwd(state0, actions, dt, params, layout="aos"):
+    """No-grad H-step unroll (apg_cartpole_rollout_fwd): states [B,H,4]."""
+    lay = _layout(layout)
+    require_device(state0, actions)
+    B, H, A = _seq_shape(actions, lay)
+    if A != 1 or _state_batch(state0, lay) != B:
+        raise ValueError("inconsistent rollout shapes")
+    states = torch.empty(_states_shape(B, H, 4, lay), dtype=torch.float32,
+                         device=state0.device)
+    check(lib().apg_cartpole_rollout_fwd(
+        ptr(state0), ptr(actions), float(dt), ctypes.byref(params), B, H, lay,
+        ptr(states), stream_of(state0)), "apg_cartpole_rollout_fwd")
+    return states
+
+
 class _CartpoleRolloutLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, state0, action_seq, dt, params):

@@ -65,6 +65,9 @@ def parse():
                     help="launch every step from Python instead of replaying "
                          "one captured HIP graph of the K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["dynamics", "ar"], default="dynamics",
+                    help="ar: also report the autoregressive training step "
+                         "(BASELINE configs[2] shape; automatic for --gpus > 1)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the fixed-wing dual-roofline block")
     ap.add_argument("--no-wide-sets", action="store_true",
@@ -272,6 +275,78 @@ def train_step_probe(args, dev, dyn, dist):
                  "policy fwd (PyTorch-ROCm, SoA head) + fused rollout + policy bwd")
                 + " + RCCL all-reduce(sum) + SGD, per rank batch %d" % B,
     }
+
+
+def ar_train_step_probe(args, dev, dyn, dist):
+    """BASELINE configs[2] shape: the AUTOREGRESSIVE training step per rank
+    (65 536 trajectories per GPU; 524 288 over 8) through the REAL trainer
+    method - TrainDrone.train_recurrent_model: fused policy-in-kernel unroll
+    (mlp.hip), weight-gradient products, then TrainBase._step_direct = ONE
+    in-place all-reduce(sum) of the flat gradient buffer (30 389 floats + the
+    loss slot = 122 KB, RCCL over xGMI when world > 1) and momentum SGD on
+    every replica.  With world > 1 the collective alone is timed as well
+    (it is on the critical path: the next forward needs the updated weights,
+    so there is nothing legal to overlap a single-bucket all-reduce with)."""
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    H, B = args.horizon, args.batch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    cfg = dict(delta_t=args.dt, horizon=H, batch_size=B * world, ref_dim=9,
+               action_dim=4, train_mode="autoregressive",
+               learning_rate_controller=1e-9, system="quad")
+    t = TrainDrone(dyn, dyn, cfg)
+    torch.manual_seed(4321 + rank)       # init_optimizer broadcasts rank 0's
+    t.net = Net(15, H, 9, 4, conv=1).to(dev)
+    d = synthetic.quad_polynomial_batch(B, H, args.dt, seed=args.seed + rank,
+                                        ref_length=2 * H)
+
+    class Shard:     # this rank's shard, resident on the device
+        states, in_ref_states, ref_states = (
+            d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+        normed_states = states
+    t.state_data = Shard
+    t.init_optimizer()
+
+    def step():
+        return t.train_recurrent_model(None, Shard.states, Shard.in_ref_states,
+                                       Shard.ref_states)
+    for _ in range(3):
+        total = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        total = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    n_msg = sum(p.numel() for p in t.net.parameters() if p.requires_grad) + 1
+    out = {
+        "ms_per_step": el / args.train_steps * 1e3,
+        "env_steps_per_s": world * B * H * args.train_steps / el,
+        "batch_per_gpu": B, "global_batch": world * B,
+        "allreduce_floats": n_msg,
+        "fused": bool(t.fused_policy and t._fusable_mlp()),
+        "global_loss": float(total.item()),
+        "what": "TrainDrone.train_recurrent_model (autoregressive, policy inside "
+                "the kernels) + flat-buffer all-reduce(sum) + SGD",
+    }
+    if world > 1:
+        buf = torch.zeros(n_msg, device=dev)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        out["allreduce_us_alone"] = (time.perf_counter() - t0) / 50 * 1e6
+    return out
 
 
 KERNEL_SOURCES = ("quad.hip", "quad_math.h", "apg_device.h")
@@ -583,6 +658,13 @@ def main():
             out["train_step"] = train_step_probe(args, dev, dyn, dist)
         except Exception as e:      # informational only
             out["train_step"] = {"error": repr(e)}
+    # the configs[2]-shaped block: always with more than one GPU, on request
+    # (--mode ar) on one
+    if args.train_steps > 0 and (world > 1 or args.mode == "ar"):
+        try:
+            out["train_step_ar"] = ar_train_step_probe(args, dev, dyn, dist)
+        except Exception as e:      # informational only
+            out["train_step_ar"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_secondary:
         try:
             out["secondary"] = {"wing_rollout": wing_secondary(args, dev)}

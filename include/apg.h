@@ -502,6 +502,12 @@ int apg_cartpole_rollout_fwd_bwd(const float *state0, const float *actions,
                                  float *grad_actions, float *grad_state0,
                                  float *states_out, apg_stream_t stream);
 
+/* No-grad unroll (evaluation: CartPoleEnv._step in a loop,
+ * neural_control/environments/cartpole_env.py:72-74): states_out[B,H,4]. */
+int apg_cartpole_rollout_fwd(const float *state0, const float *actions, float dt,
+                             const ApgCartpoleParams *params, int B, int H,
+                             int layout, float *states_out, apg_stream_t stream);
+
 /* --------------------------------------------------------------- misc --- */
 /* loss[0] = fixed-order sum of partials[0..n) (one small kernel). */
 int apg_reduce_loss_partials(const float *partials, int n, float *loss,

@@ -491,6 +491,28 @@ def test_cartpole(dev):
         assert rel_err(N(gs), g["gstate0"]) < TOL
 
 
+def test_cartpole_rollout_fwd_matches_stepwise(dev):
+    """apg_cartpole_rollout_fwd (no-grad unroll) = the golden states (G6) =
+    the per-step kernel in a loop, both layouts."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.cartpole_dynamics import (
+        CartpoleDynamics)
+    g = load_golden("cartpole.npz")
+    dyn = CartpoleDynamics()
+    s0, a = D(g["state0"], dev), D(g["actions"], dev)
+    dt = float(g["dt"])
+    st = dyn.rollout(s0, a, dt)
+    assert rel_err(N(st), g["states"]) < 1e-5
+    st_soa = F.cartpole_rollout_fwd(soa_state(s0), soa_seq(a), dt, dyn.params,
+                                    layout="soa")
+    assert torch.equal(aos_seq(st_soa), st)
+    cur = s0
+    for k in range(a.shape[1]):
+        cur = dyn(cur, a[:, k], dt)
+        assert torch.equal(cur, st[:, k])
+    assert F.cartpole_rollout_fwd(s0[:0], a[:0], dt, dyn.params).shape == (0, 5, 4)
+
+
 @pytest.mark.parametrize("layout", ["soa", "packed"])
 def test_deferred_loss_chain(dev, layout):
     """ApgDeferredLoss: step i's loss reduced inside step i+1's launch equals

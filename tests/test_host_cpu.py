@@ -379,9 +379,23 @@ def test_run_dynamics_schedule_and_outputs(tmp_path):
     assert t.results_dict["samples_in_d2"] == [40] * 7
     # no evaluation hook for this net: the loop resamples itself (every 3rd epoch)
     assert t.state_data.resampled == 2 and t.sampled_data_count == 22
-    assert os.path.exists(tmp_path / "model_quad")
-    assert os.path.exists(tmp_path / "loss.csv")
-    assert not os.path.exists(tmp_path / "mean_successes.csv")   # nothing evaluated
+    # finalize (scripts/train_base.py:253-287): weights, every statistics
+    # table (empty ones included, as np.savetxt writes them there), results.json
+    import json
+    for name in ("model_quad", "loss.csv", "mean_successes.csv", "std_success.csv",
+                 "mean_divergence.csv", "std_divergence.csv",
+                 "mean_divergence_full.csv", "std_divergence_full.csv",
+                 "results.json"):
+        assert os.path.exists(tmp_path / name), name
+    assert not os.path.exists(tmp_path / "dynamics_model")   # analytic simulator
+    res = json.load(open(tmp_path / "results.json"))
+    assert res["samples_in_d2"] == [40] * 7
+    # a learnable simulator is saved next to the policy (:279-285)
+    t2 = _loop_trainer(tmp_path / "learnt")
+    t2.train_dynamics = torch.nn.Linear(3, 3)
+    t2.finalize()
+    sd = torch.load(tmp_path / "learnt" / "dynamics_model")
+    assert set(sd) == {"weight", "bias"}
 
 
 def test_speed_curriculum_and_checkpoints(tmp_path):
