@@ -1056,9 +1056,14 @@ def test_train_control_and_train_dynamics_end_to_end(dev, tmp_path, monkeypatch)
     assert t.state_data.eval_counter == 4 * (4 * 30 // 3)
     assert t.sampled_data_count == 2 * 256
     out = tmp_path / "trained_models" / "quad" / "e2e"
-    assert sorted(os.listdir(out)) == ["config.json", "loss.csv", "mean_successes.csv",
-                                       "model_quad", "model_quad1", "model_quad2",
-                                       "model_quad3"]
+    # scripts/train_base.py:253-287: weights, every statistics table,
+    # results.json; a checkpoint per evaluated epoch but the first
+    assert sorted(os.listdir(out)) == sorted([
+        "config.json", "loss.csv", "mean_successes.csv", "std_success.csv",
+        "mean_divergence.csv", "std_divergence.csv", "mean_divergence_full.csv",
+        "std_divergence_full.csv", "results.json", "model_quad", "model_quad1",
+        "model_quad2", "model_quad3"])
+    assert len(np.loadtxt(out / "mean_successes.csv", delimiter=",")) == 4
     sd = torch.load(out / "model_quad", map_location="cpu")
     assert sd["fc_out.weight"].shape == (40, 64)
 
@@ -1070,6 +1075,10 @@ def test_train_control_and_train_dynamics_end_to_end(dev, tmp_path, monkeypatch)
     assert all(np.isfinite(t2.results_dict["loss"]))
     assert t2.count_finetune_data == 2 * 384
     assert len(t2.results_dict["mean_success"]) == 3     # flown in the analytic env
+    # the fitted simulator is saved next to the policy (:279-285)
+    dyn_sd = torch.load(tmp_path / "trained_models" / "quad" / "e2e_dyn" /
+                        "dynamics_model", map_location="cpu")
+    assert "linear_at" in dyn_sd and "torch_kinv_vector" in dyn_sd
 
 
 @pytest.mark.filterwarnings("ignore::RuntimeWarning")   # mean of no complete run
