@@ -64,6 +64,11 @@ class ApgDeferredLoss(ctypes.Structure):
                 ("prev_loss", ctypes.c_void_p)]
 
 
+class ApgLearntResidual(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "linear_at", "w1", "b1", "w2", "b2")]
+
+
 class ApgLstmPolicy(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")]
@@ -112,6 +117,10 @@ SIGNATURES = {
         ctypes.POINTER(ApgDeferredLoss), _P],
     "apg_quad_rollout_fwd": [_P, _P, _F, ctypes.POINTER(ApgQuadParams), _I,
                              _I, _I, _P, _P],
+    "apg_quad_learnt_rollout_fwd_bwd": [
+        _P, _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgLearntResidual), ctypes.POINTER(ApgQuadLossWeights),
+        _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "apg_quad_loss_fwd_bwd": [
         _P, _P, _I, _P, ctypes.POINTER(ApgQuadLossWeights), _I, _I, _I, _P,
         _P, _P, _P, _P],

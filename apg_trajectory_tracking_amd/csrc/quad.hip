@@ -73,8 +73,9 @@ __device__ unsigned long long *g_stamps = nullptr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
     APG_STAMP_AT(4);                                                           \
     APG_STAMP_REAL(5);                                                         \
-    if (g_stamps && threadIdx.x < 16)                                          \
-      ((unsigned *)g_stamps)[blockIdx.x * 16 + threadIdx.x] = apg_stv;         \
+    if (g_stamps && (threadIdx.x & 63) < 16)                                   \
+      ((unsigned *)g_stamps)[(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 16 + \
+                             (threadIdx.x & 63)] = apg_stv;                    \
   } while (0)
 #else
 #define APG_STAMP_DECL
@@ -383,14 +384,17 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
 
+#ifndef APG_ROWS_BLOCK
+#define APG_ROWS_BLOCK 64   // threads per workgroup (64 / 128 / 256)
+#endif
 template <int HT, bool STATES_OUT>
-__global__ __launch_bounds__(64) void quad_rollout_rows_kernel(
+__global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
     const float *state0, const float *actions, const float *ref, int B, float dt,
     float half_dt, float half_dt2, float g0, float g1, float g2, float k0,
     float k1, float k2, RowArgs R) {
   APG_STAMP_DECL;
   APG_STAMP_AT(0);
-  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int b = blockIdx.x * APG_ROWS_BLOCK + threadIdx.x;
   const bool live = b < B;
   const int bb = live ? b : B - 1;  // keep the wave convergent for the reduce
   // Request schedule.  Loads return in order, so the order of the requests IS
@@ -457,7 +461,8 @@ __global__ __launch_bounds__(64) void quad_rollout_rows_kernel(
   // exec-mask branches around the stores
   const int st16 = live ? b * 16 : (int)0x80000000;
 
-  const bool reducer = blockIdx.x == 0 && R.prev.prev_partials != nullptr;
+  const bool reducer = blockIdx.x == 0 && threadIdx.x < kWave &&
+                       R.prev.prev_partials != nullptr;
   PrevPartials pp;
   if (reducer) reduce_prev_head(R.prev, pp);
   __builtin_amdgcn_sched_barrier(0);
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(64) void quad_rollout_rows_kernel(
   APG_STAMP_AT(3);
   const float loss = R.w.pos * sum_p + R.w.vel * sum_v + R.w.av * sum_w +
                      R.w.rates * sum_r + R.w.thrust * sum_t;
-  write_wave_partial(R.loss_partials, live ? loss : 0.f);
+  write_wave_partial(R.loss_partials, live ? loss : 0.f, (B + kWave - 1) / kWave);
   if (reducer) reduce_prev_tail(R.prev, pp);
   APG_STAMP_FLUSH();
 }
@@ -801,6 +806,239 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void quad_rollout_lds_kernel(
   if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
 }
 
+// ------------------------------------------- rollout through LearntDynamics --
+// Controller phase of TrainBase.run_dynamics (scripts/train_base.py:334-375):
+// the simulator is neural_control/dynamics/quad_dynamics_trained.py:61-69,
+//   a' = linear_at a;  s' = simulate_quadrotor(a', s) + W2 relu(W1 [s; a'] + b1) + b2
+// (4x4 action transform, 16 -> 64 -> 12 residual network), unrolled H steps
+// with quad_mpc_loss and differentiated back to the policy's actions and
+// state0 - the simulator's own parameters are frozen in this phase, so no
+// parameter gradient leaves the kernel.  One lane = one trajectory; the
+// weights are wave-uniform and arrive as scalar operands (s_load from the
+// module's own tensors); the pre-step states of the reverse sweep are stashed
+// in LDS as [k][12][lane]; the hidden layer is recomputed in the reverse sweep.
+// ~4 600 fma per env-step fwd + bwd against ~175 for the analytic simulator:
+// VALU-issue bound (run-time horizon, loops over k are not unrolled).
+struct LearntArgs {
+  const float *state0, *actions, *ref;
+  float *loss_partials, *grad_actions, *grad_state0, *states_out;
+  ApgLearntResidual m;
+  QuadConst c;
+  ApgQuadLossWeights w;
+  int B, H, ref_cols, vel_col;
+};
+
+// the module's tensors seen through the constant address space: wave-uniform
+// indices then become scalar loads (s_load_dwordxN) and the weights scalar
+// operands of the v_fmac - no VGPR, no vector memory instruction per weight
+typedef __attribute__((address_space(4))) const float *cfloat_ptr;
+struct LearntWeights {
+  cfloat_ptr linear_at, w1, b1, w2, b2;
+  __device__ explicit LearntWeights(const ApgLearntResidual &m)
+      : linear_at((cfloat_ptr)m.linear_at), w1((cfloat_ptr)m.w1),
+        b1((cfloat_ptr)m.b1), w2((cfloat_ptr)m.w2), b2((cfloat_ptr)m.b2) {}
+};
+
+// (APG_OPAQUE: without it the compiler hoists hundreds of weight loads, runs
+// out of SGPRs and spills them through v_writelane / v_readlane - 16 000 extra
+// instructions per step body; with it a row of weights is loaded where it is
+// used)
+// The asm is tied to a VALUE of the running computation too: an asm that only
+// touches the pointer is free to float to the top of the block with its loads.
+#define APG_OPAQUE(p, v) asm volatile("" : "+s"(p), "+v"(v))
+// ... and to all sixteen accumulators of a row, where a row has sixteen
+#define APG_OPAQUE16(p, v, o)                                                   \
+  asm volatile(""                                                              \
+               : "+s"(p), "+v"(v[o + 0]), "+v"(v[o + 1]), "+v"(v[o + 2]),      \
+                 "+v"(v[o + 3]), "+v"(v[o + 4]), "+v"(v[o + 5]), "+v"(v[o + 6]), \
+                 "+v"(v[o + 7]), "+v"(v[o + 8]), "+v"(v[o + 9]), "+v"(v[o + 10]), \
+                 "+v"(v[o + 11]), "+v"(v[o + 12]), "+v"(v[o + 13]),            \
+                 "+v"(v[o + 14]), "+v"(v[o + 15]))
+__device__ __forceinline__ void learnt_hidden(const LearntWeights &m,
+                                              const float (&x)[16], float (&z)[64]) {
+  cfloat_ptr w1 = m.w1, b1 = m.b1;
+  float x0 = x[0];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    // row j's loads may start once row j-2 is accumulated: one row of scalar
+    // loads in flight behind the row being multiplied
+    if (j < 2) APG_OPAQUE(w1, x0);
+    else APG_OPAQUE(w1, z[j - 2]);
+    if (j % 16 == 0) APG_OPAQUE(b1, x0);   // (biases too: loop-invariant loads
+    float acc = b1[j];                     //  get hoisted and spilled)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = fmaf(w1[j * 16 + i], i == 0 ? x0 : x[i], acc);
+    z[j] = acc;
+  }
+}
+
+__device__ __forceinline__ void learnt_transform(const LearntWeights &m,
+                                                 const float (&a)[4], float (&ap)[4]) {
+  cfloat_ptr L = m.linear_at;
+  float a0 = a[0];
+  asm volatile("" : "+s"(L), "+v"(a0));
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    ap[r] = L[r * 4] * a0 + L[r * 4 + 1] * a[1] + L[r * 4 + 2] * a[2] +
+            L[r * 4 + 3] * a[3];
+}
+
+// s <- LearntDynamics.forward(s, a)
+__device__ __forceinline__ void learnt_step(float (&s)[12], const float (&a)[4],
+                                            const LearntWeights &m,
+                                            const QuadConst &c) {
+  float ap[4], x[16], z[64], r[12];
+  learnt_transform(m, a, ap);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x[i] = s[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[12 + i] = ap[i];
+  learnt_hidden(m, x, z);
+#pragma unroll
+  for (int j = 0; j < 64; ++j) z[j] = fmaxf(z[j], 0.f);
+  cfloat_ptr w2 = m.w2, b2 = m.b2;
+  APG_OPAQUE(b2, z[0]);
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    float acc[2] = {b2[q], 0.f};   // alternating chunks: one chunk of loads ahead
+#pragma unroll
+    for (int jb = 0; jb < 64; jb += 16) {
+      float &ac = acc[(jb >> 4) & 1];
+      APG_OPAQUE(w2, ac);
+#pragma unroll
+      for (int j = jb; j < jb + 16; ++j) ac = fmaf(w2[q * 64 + j], z[j], ac);
+    }
+    r[q] = acc[0] + acc[1];
+  }
+  const Trig t = make_trig(&s[3]);
+  quad_step(s, ap, c, t);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] += r[i];
+}
+
+// lam: dL/d(next state) -> dL/d(state); ga += dL/d(action); `pre` = the state
+// the step started from
+__device__ __forceinline__ void learnt_step_adjoint(float (&lam)[12], float (&ga)[4],
+                                                    const float (&pre)[12],
+                                                    const float (&a)[4],
+                                                    const LearntWeights &m,
+                                                    const QuadConst &c) {
+  float ap[4], x[16], z[64], gx[16];
+  learnt_transform(m, a, ap);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x[i] = pre[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[12 + i] = ap[i];
+  learnt_hidden(m, x, z);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gx[i] = 0.f;
+  // through W2 (row by row: contiguous scalar loads), the relu and W1
+  cfloat_ptr w1 = m.w1, w2 = m.w2;
+  float gh[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) gh[j] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+#pragma unroll
+    for (int jb = 0; jb < 64; jb += 16) {
+      APG_OPAQUE16(w2, gh, (jb + 32) % 64);   // after the chunk before the previous one
+#pragma unroll
+      for (int j = jb; j < jb + 16; ++j) gh[j] = fmaf(w2[q * 64 + j], lam[q], gh[j]);
+    }
+  }
+  float gx2[32];   // even / odd rows accumulate apart: one row of loads ahead
+#pragma unroll
+  for (int i = 0; i < 32; ++i) gx2[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    constexpr int kZero = 0;
+    const int o = (j & 1) * 16 + kZero;
+    if (j & 1) APG_OPAQUE16(w1, gx2, 16);   // after ALL fmas of row j - 2
+    else APG_OPAQUE16(w1, gx2, 0);
+    const float g = z[j] > 0.f ? gh[j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gx2[o + i] = fmaf(w1[j * 16 + i], g, gx2[o + i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gx[i] = gx2[i] + gx2[16 + i];
+  const Trig t = make_trig(&pre[3]);
+  float gap[4] = {0.f, 0.f, 0.f, 0.f};
+  const float w[3] = {pre[9], pre[10], pre[11]};
+  quad_step_adjoint(lam, gap, ap[0], w, c, t);   // analytic part, lam in place
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] += gx[i];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) gap[r] += gx[12 + r];
+  cfloat_ptr L = m.linear_at;
+  asm volatile("" : "+s"(L), "+v"(gap[0]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i)     // linear_at^T
+    ga[i] += L[i] * gap[0] + L[4 + i] * gap[1] + L[8 + i] * gap[2] +
+             L[12 + i] * gap[3];
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(64) void quad_learnt_rollout_kernel(LearntArgs A) {
+  extern __shared__ float stash[];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < A.B;
+  const int bb = live ? b : A.B - 1;
+  const QuadConst c = A.c;
+  const int H = A.H;
+  const LearntWeights W(A.m);
+  auto ST = [&](int k, int i) -> float & { return stash[(k * 12 + i) * 64 + lane]; };
+  float s[12];
+  load_state<LAYOUT, 12>(A.state0, A.B, bb, s);
+  float sum_p = 0.f, sum_v = 0.f, sum_w = 0.f, sum_r = 0.f, sum_t = 0.f;
+  for (int k = 0; k < H; ++k) {
+    float a[4], rp[3], rv[3];
+    load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, k, 0, a);
+    load_seq<LAYOUT, 3>(A.ref, A.B, H, A.ref_cols, bb, k, 0, rp);
+    load_seq<LAYOUT, 3>(A.ref, A.B, H, A.ref_cols, bb, k, A.vel_col, rv);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ST(k, i) = s[i];
+    learnt_step(s, a, W, c);
+    if (A.states_out && live)
+      store_seq<LAYOUT, 12>(A.states_out, A.B, H, 12, b, k, 0, s);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float dp = s[i] - rp[i], dv = s[6 + i] - rv[i], d = a[1 + i] - 0.5f;
+      sum_p = fmaf(dp, dp, sum_p), sum_v = fmaf(dv, dv, sum_v);
+      sum_w = fmaf(s[9 + i], s[9 + i], sum_w), sum_r = fmaf(d, d, sum_r);
+    }
+    sum_t = fmaf(a[0] - 0.5f, a[0] - 0.5f, sum_t);
+  }
+  const float loss = A.w.pos * sum_p + A.w.vel * sum_v + A.w.av * sum_w +
+                     A.w.rates * sum_r + A.w.thrust * sum_t;
+  write_wave_partial(A.loss_partials, live ? loss : 0.f, (A.B + kWave - 1) / kWave);
+
+  float lam[12], nxt[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = 0.f, nxt[i] = s[i];
+  for (int k = H - 1; k >= 0; --k) {
+    float a[4], rp[3], rv[3], pre[12];
+    load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, k, 0, a);
+    load_seq<LAYOUT, 3>(A.ref, A.B, H, A.ref_cols, bb, k, 0, rp);
+    load_seq<LAYOUT, 3>(A.ref, A.B, H, A.ref_cols, bb, k, A.vel_col, rv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      lam[i] += 2.f * A.w.pos * (nxt[i] - rp[i]);
+      lam[6 + i] += 2.f * A.w.vel * (nxt[6 + i] - rv[i]);
+      lam[9 + i] += 2.f * A.w.av * nxt[9 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pre[i] = ST(k, i);
+    float ga[4] = {2.f * A.w.thrust * (a[0] - 0.5f), 2.f * A.w.rates * (a[1] - 0.5f),
+                   2.f * A.w.rates * (a[2] - 0.5f), 2.f * A.w.rates * (a[3] - 0.5f)};
+    learnt_step_adjoint(lam, ga, pre, a, W, c);
+    if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, H, 4, b, k, 0, ga);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) nxt[i] = pre[i];
+  }
+  if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void quad_rollout_fwd_kernel(
     const float *__restrict__ state0, const float *__restrict__ actions,
@@ -964,7 +1202,7 @@ int launch_rollout_rows(const RolloutArgs &A, hipStream_t st) {
   R.loss_partials = A.loss_partials, R.grad_actions = A.grad_actions;
   R.grad_state0 = A.grad_state0, R.states_out = A.states_out;
   R.prev = A.prev;
-  const dim3 grid(grid_for(A.B, 64)), block(64);
+  const dim3 grid(grid_for(A.B, APG_ROWS_BLOCK)), block(APG_ROWS_BLOCK);
   const QuadConst &c = A.c;
 #define APG_ROWS(HT)                                                          \
   hipLaunchKernelGGL((quad_rollout_rows_kernel<HT, SO>), grid, block, 0, st,  \
@@ -1089,6 +1327,65 @@ int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
     e = states_out ? launch_rollout<APG_LAYOUT_AOS, true>(A, st)
                    : launch_rollout<APG_LAYOUT_AOS, false>(A, st);
   if (e) return e;
+  if (loss) return launch_reduce_partials(loss_partials, apg_loss_partials_count(B), loss, st);
+  return APG_OK;
+}
+
+int apg_quad_learnt_rollout_fwd_bwd(const float *state0, const float *actions,
+                                    const float *ref, int ref_cols, float dt,
+                                    const ApgQuadParams *params,
+                                    const ApgLearntResidual *model,
+                                    const ApgQuadLossWeights *weights, int B, int H,
+                                    int layout, float *loss_partials, float *loss,
+                                    float *grad_actions, float *grad_state0,
+                                    float *states_out, apg_stream_t stream) {
+  if (int e = check_common(state0, actions, params, B, layout)) return e;
+  if (!weights || !model || !model->linear_at || !model->w1 || !model->b1 ||
+      !model->w2 || !model->b2) {
+    set_error("weights / model tensors must not be NULL");
+    return APG_ERR_ARG;
+  }
+  if (H < 1 || H > APG_MAX_HORIZON) {
+    set_error("H must be in [1, %d] (got %d)", APG_MAX_HORIZON, H);
+    return APG_ERR_ARG;
+  }
+  if (ref_cols != 9 && ref_cols != 6) {
+    set_error("ref_cols must be 9 ([pos, euler, vel]) or 6 ([pos, vel])");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
+      return check_launch("memset(loss)");
+    return APG_OK;
+  }
+  if (!ref || !loss_partials || !grad_actions) {
+    set_error("ref / loss_partials / grad_actions must not be NULL");
+    return APG_ERR_ARG;
+  }
+  LearntArgs A;
+  A.state0 = state0, A.actions = actions, A.ref = ref;
+  A.loss_partials = loss_partials, A.grad_actions = grad_actions;
+  A.grad_state0 = grad_state0, A.states_out = states_out;
+  A.m = *model;
+  A.c = make_const(*params, dt);
+  A.w = *weights;
+  A.B = B, A.H = H, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
+  const size_t lds = (size_t)H * 12 * 64 * sizeof(float);
+  const dim3 grid(grid_for(B, 64)), block(64);
+#define APG_LEARNT(L)                                                          \
+  do {                                                                         \
+    if (lds > 64 * 1024 &&                                                     \
+        hipFuncSetAttribute((const void *)quad_learnt_rollout_kernel<L>,       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                            (int)lds) != hipSuccess)                           \
+      return check_launch("hipFuncSetAttribute(quad_learnt_rollout)");         \
+    hipLaunchKernelGGL((quad_learnt_rollout_kernel<L>), grid, block, lds, st, A); \
+  } while (0)
+  if (layout == APG_LAYOUT_SOA) APG_LEARNT(APG_LAYOUT_SOA);
+  else APG_LEARNT(APG_LAYOUT_AOS);
+#undef APG_LEARNT
+  if (int e = check_launch("quad_learnt_rollout_fwd_bwd")) return e;
   if (loss) return launch_reduce_partials(loss_partials, apg_loss_partials_count(B), loss, st);
   return APG_OK;
 }

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void wing_step_bwd_kernel(
   WingAux x;
   wing_rates(s, a, k, x, sd);
   float ga[4] = {0.f, 0.f, 0.f, 0.f};
-  wing_step_adjoint(lam, ga, s, x, k);
+  wing_step_adjoint(lam, ga, s, x, sd, k);
   if (grad_state) store_state<LAYOUT, 12>(grad_state, B, b, lam);
   if (grad_action) store_state<LAYOUT, 4>(grad_action, B, b, ga);
 }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
         WingAux x;
         APG_LAUNDER(kp);
         wing_rates(pre[j], act[j], *kp, x, sd);
-        wing_step_adjoint(lam, ga, pre[j], x, *kp);
+        wing_step_adjoint(lam, ga, pre[j], x, sd, *kp);
         if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, H, 4, b, kk, 0, ga);
       }
     }

@@ -204,11 +204,14 @@ __host__ __device__ __forceinline__ void wing_step(float (&s)[12], const float (
 
 // lam: dL/dnext on entry -> dL/dstate on exit; ga += dL/daction.
 // `s`, `a` are the PRE-step state and the action; x the matching aux.
+// `sd`: the state_dot wing_rates returned for (s, a) (its position part is
+// re-used by the yaw cotangent).
 template <typename KT>
 __host__ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
                                                   float (&ga)[4],
                                                   const float (&s)[12],
-                                                  const WingAux &x, KT &k) {
+                                                  const WingAux &x,
+                                                  const float (&sd)[12], KT &k) {
   const float u = s[3], v = s[4], w = s[5];
   const float p = s[9], q = s[10], r = s[11];
   float g[12];  // cotangent of state_dot
@@ -252,42 +255,40 @@ __host__ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
     dr += x1 * u, du += x1 * r, dp -= x1 * w, dw -= x1 * p;
     dp += x2 * v, dv += x2 * p, dq -= x2 * u, du -= x2 * q;
   }
-  // pos_dot_j = sum_i R[i][j] vel_i
+  // pos_dot_j = sum_i R[i][j] vel_i.  With Rg_i = R[i] . g (needed for the
+  // velocity cotangent anyway) the attitude cotangents contract to a few
+  // products, because every derivative of a row of R is another row:
+  //   dR1/dphi = R2, dR2/dphi = -R1          => dphi   = v Rg_2 - w Rg_1
+  //   dR1/dth = sph R0, dR2/dth = cph R0     => dtheta = u (g . dR0/dth)
+  //                                                      + (v sph + w cph) Rg_0
+  //   dcol0/dpsi = -col1, dcol1/dpsi = col0  => dpsi   = g1 pd0 - g0 pd1
   {
-    const float vel[3] = {u, v, w};
-    float dvel[3];
+    float Rg[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-      dvel[i] = x.R[i][0] * g[0] + x.R[i][1] * g[1] + x.R[i][2] * g[2];
-    du += dvel[0], dv += dvel[1], dw += dvel[2];
-    // gR[i][j] = vel_i * g_j
-    auto GR = [&](int i, int j) { return vel[i] * g[j]; };
-    // d/dphi: row1' = row2, row2' = -row1
-    dph += GR(1, 0) * x.R[2][0] + GR(1, 1) * x.R[2][1] + GR(1, 2) * x.R[2][2] -
-           GR(2, 0) * x.R[1][0] - GR(2, 1) * x.R[1][1] - GR(2, 2) * x.R[1][2];
-    // d/dtheta
-    dth += GR(0, 0) * (-x.sth * x.cps) + GR(0, 1) * (-x.sth * x.sps) +
-           GR(0, 2) * (-x.cth) + GR(1, 0) * (x.sph * x.cth * x.cps) +
-           GR(1, 1) * (x.sph * x.cth * x.sps) + GR(1, 2) * (-x.sph * x.sth) +
-           GR(2, 0) * (x.cph * x.cth * x.cps) +
-           GR(2, 1) * (x.cph * x.cth * x.sps) + GR(2, 2) * (-x.cph * x.sth);
-    // d/dpsi: col0' = -col1, col1' = col0
-    dps += -GR(0, 0) * x.R[0][1] + GR(0, 1) * x.R[0][0] -
-           GR(1, 0) * x.R[1][1] + GR(1, 1) * x.R[1][0] -
-           GR(2, 0) * x.R[2][1] + GR(2, 1) * x.R[2][0];
+      Rg[i] = x.R[i][0] * g[0] + x.R[i][1] * g[1] + x.R[i][2] * g[2];
+    du += Rg[0], dv += Rg[1], dw += Rg[2];
+    dph += v * Rg[2] - w * Rg[1];
+    const float g_dr0 = -x.sth * (x.cps * g[0] + x.sps * g[1]) - x.cth * g[2];
+    dth += u * g_dr0 + (v * x.sph + w * x.cph) * Rg[0];
+    dps += g[1] * sd[0] - g[0] * sd[1];
   }
   // f = R_bw [-D, Y, -L] + gravity(phi, theta) + thrust
   const float gT = gf0 * k.cos_eps + gf2 * k.sin_eps;
   dth += k.g_m * (-x.cth * gf0 - x.sph * x.sth * gf1 - x.cph * x.sth * gf2);
   dph += k.g_m * (x.cph * x.cth * gf1 - x.sph * x.cth * gf2);
-  const float gD = -x.ca * x.cb * gf0 - x.sb * gf1 - x.sa * x.cb * gf2;
-  const float gY = -x.ca * x.sb * gf0 + x.cb * gf1 - x.sa * x.sb * gf2;
+  // f_aero = R_bw(alpha, beta) [-D, Y, -L], contracted through
+  //   m = ca gf0 + sa gf2,  t = cb D + sb Y,  q = sb D - cb Y:
+  //   d f_aero0 / dalpha = -f_aero2,  d f_aero2 / dalpha = f_aero0
+  const float m_ = x.ca * gf0 + x.sa * gf2;
+  const float t_ = x.cb * x.D + x.sb * x.Y;
+  const float q_ = x.sb * x.D - x.cb * x.Y;
+  const float gD = -x.cb * m_ - x.sb * gf1;
+  const float gY = -x.sb * m_ + x.cb * gf1;
   const float gL = x.sa * gf0 - x.ca * gf2;
-  float g_al = gf0 * (x.sa * x.cb * x.D + x.sa * x.sb * x.Y + x.ca * x.L) +
-               gf2 * (-x.ca * x.cb * x.D - x.ca * x.sb * x.Y + x.sa * x.L);
-  float g_be = gf0 * (x.ca * x.sb * x.D - x.ca * x.cb * x.Y) +
-               gf1 * (-x.cb * x.D - x.sb * x.Y) +
-               gf2 * (x.sa * x.sb * x.D - x.sa * x.cb * x.Y);
+  const float fa0 = x.sa * x.L - x.ca * t_, fa2 = -x.sa * t_ - x.ca * x.L;
+  float g_al = gf2 * fa0 - gf0 * fa2;
+  float g_be = q_ * m_ - gf1 * t_;
   // forces and moments
   const float Qc = x.Q * k.c;
   const float gCL = x.Q * gL, gCD = x.Q * gD, gCY = x.Q * gY;

@@ -243,6 +243,85 @@ def quad_rollout_loss(state0, action_seq, ref, dt, params, weights=None,
 
 
 # ------------------------------------------------------------ quad loss
+# ------------------------------------------- rollout through LearntDynamics
+def _learnt_model(dyn):
+    """ApgLearntResidual over a LearntDynamics module's own tensors."""
+    tensors = [dyn.linear_at, dyn.linear_state_1.weight, dyn.linear_state_1.bias,
+               dyn.linear_state_2.weight, dyn.linear_state_2.bias]
+    for t in tensors:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("LearntDynamics tensors must be contiguous fp32 "
+                               "device tensors (module.to('cuda'))")
+    if tuple(tensors[1].shape) != (64, 16) or tuple(tensors[3].shape) != (12, 64):
+        raise ValueError("fused rollout expects the 16 -> 64 -> 12 residual network")
+    return _capi.ApgLearntResidual(*[t.data_ptr() for t in tensors])
+
+
+def quad_learnt_rollout_fwd_bwd(dyn, state0, actions, ref, dt, weights=None,
+                                layout="aos", want_grad_state0=True,
+                                want_states=False, out=None):
+    """Fused H-step unroll through `dyn` (a LearntDynamics module: action
+    transform + analytic step + residual network) + quad_mpc_loss + adjoint
+    down to dL/dactions and dL/dstate0 (apg_quad_learnt_rollout_fwd_bwd).  The
+    module's parameters are read, never differentiated."""
+    lay = _layout(layout)
+    if lay == LAYOUT_PACKED:
+        raise ValueError("the learnt-dynamics rollout takes 'aos' or 'soa' tensors")
+    weights = weights or quad_loss_weights()
+    require_device(state0, actions, ref)
+    B, H, A = _seq_shape(actions, lay)
+    Br, Hr, ref_cols = _seq_shape(ref, lay)
+    if A != 4 or _state_batch(state0, lay) != B or Br != B or Hr != H:
+        raise ValueError("inconsistent rollout shapes")
+    out = dict(out or {})
+    dev = state0.device
+
+    def get(key, shape, wanted=True):
+        if not wanted:
+            return None
+        t = out.get(key)
+        return t if t is not None else torch.empty(shape, dtype=torch.float32,
+                                                   device=dev)
+    partials = get("loss_partials", (_capi.loss_partials_count(B),))
+    loss = get("loss", (1,))
+    ga = get("grad_actions", actions.shape)
+    gs = get("grad_state0", state0.shape, want_grad_state0)
+    states = get("states", _states_shape(B, H, 12, lay), want_states)
+    model = _learnt_model(dyn)
+    check(lib().apg_quad_learnt_rollout_fwd_bwd(
+        ptr(state0), ptr(actions), ptr(ref), ref_cols, float(dt),
+        ctypes.byref(dyn.params), ctypes.byref(model), ctypes.byref(weights), B, H,
+        lay, ptr(partials), ptr(loss), ptr(ga), ptr(gs), ptr(states),
+        stream_of(state0)), "apg_quad_learnt_rollout_fwd_bwd")
+    return dict(loss=loss, loss_partials=partials, grad_actions=ga,
+                grad_state0=gs, states=states)
+
+
+class _QuadLearntRolloutLoss(torch.autograd.Function):
+    """loss = quad_mpc_loss(unroll(learnt_dyn, state0, action_seq), ref,
+    action_seq) as ONE kernel; gradients w.r.t. action_seq / state0 only."""
+
+    @staticmethod
+    def forward(ctx, state0, action_seq, ref, dt, dyn, weights):
+        s, a, r = _f32c(state0), _f32c(action_seq), _f32c(ref)
+        res = quad_learnt_rollout_fwd_bwd(
+            dyn, s, a, r, dt, weights, want_grad_state0=ctx.needs_input_grad[0])
+        ctx.save_for_backward(res["grad_actions"], res["grad_state0"])
+        return res["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ga, gs = ctx.saved_tensors
+        ga = ga * g if ctx.needs_input_grad[1] else None
+        gs = gs * g if (gs is not None and ctx.needs_input_grad[0]) else None
+        return gs, ga, None, None, None, None
+
+
+def quad_learnt_rollout_loss(dyn, state0, action_seq, ref, dt, weights=None):
+    return _QuadLearntRolloutLoss.apply(state0, action_seq, ref, dt, dyn,
+                                        weights or quad_loss_weights())
+
+
 class _QuadLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, states, ref, actions, weights):

@@ -39,6 +39,7 @@ class TrainDrone(TrainBase):
         # LSTM mode: run the policy INSIDE the rollout kernel (K7) when the
         # network is the reference architecture LSTM_NEW(15, 10, 9, 4, conv=1)
         self.fused_policy = True
+        self.fused_learnt = True    # controller phase through LearntDynamics
 
     def initialize_model(self, base_model=None, modified_params={},
                          state_data=None, device=None, seed=0,
@@ -165,6 +166,15 @@ class TrainDrone(TrainBase):
             self.train_dynamics.params, index=index)
         return self._step_direct(loss, grads, flat)
 
+    def _fusable_learnt(self):
+        from .dynamics.quad_dynamics_trained import LearntDynamics
+        d = self.train_dynamics
+        return (isinstance(d, LearntDynamics)
+                and self.horizon <= 48
+                and tuple(d.linear_state_1.weight.shape) == (64, 16)
+                and tuple(d.linear_state_2.weight.shape) == (12, 64)
+                and d.linear_at.is_cuda)
+
     def _fusable_mlp(self):
         n = self.net
         return (isinstance(n, Net) and n.conv and self.horizon == 10
@@ -229,6 +239,16 @@ class TrainDrone(TrainBase):
         self, current_state, action_seq, in_ref_states, ref_states
     ):
         self.optimizer_controller.zero_grad()
+        if self.fused_learnt and self._fusable_learnt():
+            # learnt simulator, frozen in this phase: the whole unroll through
+            # LearntDynamics.forward + loss + backward to the actions in ONE
+            # kernel (apg_quad_learnt_rollout_fwd_bwd); the simulator's own
+            # parameters get no gradient here (optimizer_controller does not
+            # own them, scripts/train_base.py:140-143)
+            loss = F.quad_learnt_rollout_loss(
+                self.train_dynamics, current_state, action_seq, ref_states,
+                self.delta_t)
+            return self._step(loss)
         if not self.analytic_train_dynamics():
             # learnt simulator: unroll through its own forward (:185-191)
             states = []

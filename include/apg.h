@@ -138,6 +138,30 @@ int apg_quad_rollout_fwd_bwd(const float *state0, const float *actions,
                              const ApgDeferredLoss *deferred,
                              apg_stream_t stream);
 
+/* The same fused unroll through the LEARNT simulator of
+ * neural_control/dynamics/quad_dynamics_trained.py:10-69 (LearntDynamics):
+ *   a' = linear_at a;  s' = simulate_quadrotor(a', s) + W2 relu(W1 [s; a'] + b1) + b2
+ * for the controller phase of TrainBase.run_dynamics (scripts/train_base.py:
+ * 334-375, scripts/train_drone.py:185-191): H x LearntDynamics.forward,
+ * quad_mpc_loss, backward down to dL/daction_seq and dL/dstate0.  The
+ * simulator's parameters are frozen in that phase: no parameter gradient is
+ * produced.  `params` = the physical parameters the module simulates with (its
+ * construction-time kinv / inertia); the tensors of `model` are the module's
+ * own (row-major, device memory): linear_at [4,4], linear_state_1.weight
+ * [64,16] / .bias [64], linear_state_2.weight [12,64] / .bias [12].
+ * Layouts: APG_LAYOUT_AOS or APG_LAYOUT_SOA. */
+typedef struct ApgLearntResidual {
+  const float *linear_at, *w1, *b1, *w2, *b2;
+} ApgLearntResidual;
+int apg_quad_learnt_rollout_fwd_bwd(const float *state0, const float *actions,
+                                    const float *ref, int ref_cols, float dt,
+                                    const ApgQuadParams *params,
+                                    const ApgLearntResidual *model,
+                                    const ApgQuadLossWeights *weights, int B, int H,
+                                    int layout, float *loss_partials, float *loss,
+                                    float *grad_actions, float *grad_state0,
+                                    float *states_out, apg_stream_t stream);
+
 /* No-grad unroll (eval / self-play): states_out[B,H,12] only. */
 int apg_quad_rollout_fwd(const float *state0, const float *actions, float dt,
                          const ApgQuadParams *params, int B, int H, int layout,

@@ -24,7 +24,7 @@ extern "C" void hm_wing_step(const float *state, const float *action, float dt,
     float sd[12], lam[12], ga[4] = {0.f, 0.f, 0.f, 0.f};
     wing_rates(s0, a, k, x, sd);
     for (int i = 0; i < 12; ++i) lam[i] = cot[b * 12 + i];
-    wing_step_adjoint(lam, ga, s0, x, k);
+    wing_step_adjoint(lam, ga, s0, x, sd, k);
     for (int i = 0; i < 12; ++i) gstate[b * 12 + i] = lam[i];
     for (int i = 0; i < 4; ++i) gaction[b * 4 + i] = ga[i];
   }
@@ -68,7 +68,7 @@ extern "C" double hm_wing_rollout(const float *state0, const float *actions,
       WingAux x;
       float sd[12];
       wing_rates(pre[n], a, k, x, sd);
-      wing_step_adjoint(lam, ga, pre[n], x, k);
+      wing_step_adjoint(lam, ga, pre[n], x, sd, k);
       for (int i = 0; i < 4; ++i) gactions[((size_t)b * H + n) * 4 + i] = ga[i];
     }
     for (int i = 0; i < 12; ++i) gstate0[b * 12 + i] = lam[i];
