@@ -165,6 +165,9 @@ SIGNATURES = {
     "apg_wing_policy_bwd": [_P, _P, _P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P,
                             _P, _P, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
+    "apg_planes_gemm_default_wgs": [_I, _I, _I],
+    "apg_planes_gemm_multi_workspace_floats": [ctypes.POINTER(ApgGemmProblem), _I],
+    "apg_planes_gemm_multi": [ctypes.POINTER(ApgGemmProblem), _I, _P, _P],
     "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I,
                         ctypes.c_longlong, _P, _I, _P, _I, _P, _P],
     "apg_wing_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I, _I,
@@ -191,7 +194,8 @@ SIGNATURES = {
     "apg_version": [],
     "apg_last_error_string": [],
 }
-_RESTYPES = {"apg_last_error_string": ctypes.c_char_p}
+_RESTYPES = {"apg_last_error_string": ctypes.c_char_p,
+             "apg_planes_gemm_multi_workspace_floats": ctypes.c_longlong}
 
 _lib = None
 

@@ -22,26 +22,52 @@
 // no staging registers, no ds_write and no VALU.  Inside a group the 16-byte
 // chunk of (row r, columns 4c..4c+3) sits in slot r*16 + (c ^ 4r): the source
 // address per lane is free, so the swizzle costs nothing and spreads the
-// MFMA fragment reads over the banks.  LDS is double-buffered: the DMA of
-// tile t+1 is in flight while tile t is multiplied, ONE barrier per tile.
+// MFMA fragment reads over the banks.  LDS is a ring of ST = 2 tile buffers:
+// while tile t is multiplied the DMA of tile t+1 is in flight; every wave
+// issues the same number of DMA instructions per tile (rows that do not exist
+// get an out-of-range offset, which costs an issue slot and no memory
+// traffic), so "the oldest tile has landed" is a vmcnt immediate followed by
+// ONE barrier per tile (a bare s_barrier, no fence).
 // Each of the 4 waves multiplies 8 of the tile's 32 k-pairs for ALL row /
 // column blocks with v_mfma_f32_32x32x2_f32 (exact f32; an A fragment is
 // reused by every column block, a B fragment by both row blocks).
 // Accumulators stay in registers across tiles; at the end the 4 waves are
 // summed through LDS and the workgroup writes one partial C; a second kernel
-// adds the partials in a fixed order (deterministic, no float atomics).  The
+// adds the partials in a fixed order (deterministic, no float atomics) - one
+// launch for all products of a training step (apg_planes_gemm_multi).  The
 // optional extra column of row sums (bias gradients) is accumulated on the
 // VALU from the A fragments the lanes read anyway.
+// Operand offsets are unsigned 32-bit buffer offsets: each operand (for B:
+// the span of planes the caller passes) must stay below 4 GiB.
 #include "apg_device.h"
 
 namespace apg {
 namespace {
 
+// Depth of the LDS tile ring.  A third buffer (two tiles in flight during a
+// multiply, where 160 KB hold it) measured no faster than two on MI355X - the
+// waves that multiply are also the ones whose DMA issue blocks on the CU's
+// request queue, and a separate loader wave was slower still - so 2 is built.
+#ifndef APG_GEMM_ST_MAX
+#define APG_GEMM_ST_MAX 2
+#endif
+
 constexpr int kKT = 64;        // reduction elements per tile
 constexpr int kGS = 4 * kKT + 4;  // floats per 4-row group in LDS (16 B pad)
 constexpr int kMaxNB = 6;      // column blocks of 32 (J + ones <= 192)
 constexpr int kThreads = 256;
-constexpr unsigned kDeadOff = 0x80000000u;  // beyond any operand (< 2 GiB each)
+constexpr unsigned kDeadOff = 0xfffffff0u;  // beyond any operand (< 4 GiB - 16 each)
+constexpr long long kMaxOperandBytes = 0xfffffff0ll;
+constexpr int kLdsBytes = 160 * 1024;
+
+// ring depth of a tile shape: 3 buffers where the LDS holds them
+template <int MB, int NB>
+struct Shape {
+  static constexpr int NG = (MB + NB) * 8;  // 4-row groups per tile
+  static constexpr int BUF = NG * kGS;      // floats per tile buffer
+  static constexpr int ST = (APG_GEMM_ST_MAX >= 3 && 3 * BUF * 4 <= kLdsBytes) ? 3 : 2;
+  static constexpr int lds_bytes = ST * BUF * 4;
+};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -65,9 +91,10 @@ __device__ __forceinline__ int tile_index(int row, int col) {
 template <int MB, int NB>
 __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
                                           float *out, float *lds) {
-  constexpr int NG = (MB + NB) * 8;  // 4-row groups per tile
+  constexpr int NG = Shape<MB, NB>::NG;
   constexpr int GI = NG / 4;         // groups (= DMA instructions) per wave
-  constexpr int BUF = NG * kGS;      // floats per tile buffer
+  constexpr int BUF = Shape<MB, NB>::BUF;
+  constexpr int ST = Shape<MB, NB>::ST;
   constexpr int W = NB * 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,8 +108,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][jb][i] = 0.f;
   }
-  // padding rows are never written by the DMA: zero both buffers once
-  for (int i = tid; i < 2 * BUF; i += kThreads) lds[i] = 0.f;
+  // padding rows only ever receive out-of-range (zero) data: zero the ring once
+  for (int i = tid; i < ST * BUF; i += kThreads) lds[i] = 0.f;
 
   const unsigned plane_bytes = (unsigned)(G.N * 4);
   const auto rA = __builtin_amdgcn_make_buffer_rsrc(
@@ -107,52 +134,71 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
   }
   __syncthreads();
 
-  auto issue = [&](long long tile, int p) {  // DMA of one tile into buffer p
-    // segment fastest: the workgroups running at the same time then work on a
-    // few column tiles across ALL segments, so B rows shared by segments (the
-    // sliding windows of the conv product) are fetched from HBM once
-    const int s = (int)(tile % G.S);
-    const unsigned colb = (unsigned)(tile / G.S) * (kKT * 4);
-    const unsigned sa = (unsigned)s * plane_bytes;
-    const unsigned s1 = (unsigned)(s / G.sdiv), s2 = (unsigned)(s % G.sdiv);
+  // tile t = (segment s, column tile ct), t = ct * S + s: segment fastest, so
+  // the workgroups running at the same time work on a few column tiles across
+  // ALL segments and B rows shared by segments (the sliding windows of the
+  // conv product) are fetched from HBM once.  The DMA front and the multiply
+  // walk their own (s, ct) by the grid stride.
+  const int ds = nb % G.S, dc = nb / G.S;
+  auto advance = [&](int &s_, int &ct_) {
+    s_ += ds, ct_ += dc;
+    if (s_ >= G.S) s_ -= G.S, ++ct_;
+  };
+  // Every wave issues GI instructions per tile (rows that do not exist and
+  // tiles past the end get an out-of-range offset: zeros, no traffic), so
+  // "the oldest tile has landed" is a vmcnt immediate.
+  auto issue = [&](int s_, int ct_, int q) {  // DMA of one tile into buffer q
+    const bool live = ct_ < G.tiles_per_seg;
+    const unsigned colb = (unsigned)ct_ * (kKT * 4);
+    const unsigned sa = (unsigned)s_ * plane_bytes;
+    const unsigned s1 = (unsigned)(s_ / G.sdiv), s2 = (unsigned)(s_ % G.sdiv);
 #pragma unroll
     for (int i = 0; i < GI; ++i) {
       const int gi = wave + 4 * i;
-      const bool isA = i < MB * 2;
-      const int first = isA ? gi * 4 : gi * 4 - MB * 32;  // first row of the group
-      if (first < (isA ? G.M : G.J)) {                    // wave-uniform
-        if (isA)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(
-              rA, (lds_ptr)(lds + p * BUF + gi * kGS), 16, (int)(rowoff[i] + colb),
-              (int)sa, 0, 0);
-        else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(
-              rB, (lds_ptr)(lds + p * BUF + gi * kGS), 16,
-              (int)(rowoff[i] + colb + s1 * bs1[i < MB * 2 ? 0 : i - MB * 2] +
-                    s2 * bs2[i < MB * 2 ? 0 : i - MB * 2]),
-              0, 0, 0);
+      unsigned off;
+      if (i < MB * 2) {
+        off = rowoff[i] + colb + sa;
+      } else {
+        const int ib = i < MB * 2 ? 0 : i - MB * 2;
+        off = rowoff[i] + colb + s1 * bs1[ib] + s2 * bs2[ib];
       }
+      off = (live && rowoff[i] != kDeadOff) ? off : kDeadOff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          i < MB * 2 ? rA : rB, (lds_ptr)(lds + q * BUF + gi * kGS), 16, (int)off, 0,
+          0, 0);
     }
   };
 
   const int lr = lane & 31, kh = lane >> 5;
   const int lane_base =
       (lr >> 2) * kGS + ((lr & 3) << 6) + ((wave ^ (lr & 3)) << 4) + kh;
-  const long long total_tiles = (long long)G.S * G.tiles_per_seg;
-  long long tile = bid;
+  int s_m = bid % G.S, ct_m = bid / G.S;  // the tile being multiplied
+  int s_i = s_m, ct_i = ct_m;             // the DMA front
+#pragma unroll
+  for (int q = 0; q < ST - 1; ++q) {
+    issue(s_i, ct_i, q);
+    advance(s_i, ct_i);
+  }
   int p = 0;
-  if (tile < total_tiles) issue(tile, 0);
-  for (; tile < total_tiles; tile += nb, p ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile landed (all waves); buffer p^1 is free again
-    const long long n0 = (tile / G.S) * kKT;
+  for (; ct_m < G.tiles_per_seg; advance(s_m, ct_m)) {
+    // the oldest of the ST-1 tiles in flight has landed (this wave's part) ...
+    if (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and everybody's; the buffer multiplied last is free.  A bare
+    // s_barrier: __syncthreads() carries a fence that makes the compiler wait
+    // for ALL outstanding DMAs.  Nothing else needs the fence: the LDS reads
+    // of the last multiply have been consumed by its MFMAs.
+    __builtin_amdgcn_s_barrier();
+    const long long n0 = (long long)ct_m * kKT;
     if (G.N - n0 < kKT) {  // ragged last tile of a segment: zero A beyond N
       const int rem = (int)(G.N - n0);
       for (int e = tid; e < MB * 32 * kKT; e += kThreads)
         if ((e & 63) >= rem) lds[p * BUF + tile_index(e >> 6, e & 63)] = 0.f;
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-    if (tile + nb < total_tiles) issue(tile + nb, p ^ 1);
+    issue(s_i, ct_i, p == 0 ? ST - 1 : p - 1);
+    advance(s_i, ct_i);
     const float *bp = lds + p * BUF + lane_base;
     // wave w owns k-pairs [8w, 8w+8) of the tile
 #pragma unroll
@@ -171,7 +217,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
           acc[mb][jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b, acc[mb][jb], 0, 0, 0);
       }
     }
+    p = p + 1 == ST ? 0 : p + 1;
   }
+  // the DMAs issued past the end (zeros) must be done before the ring is reused
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // sum the 4 waves through LDS (reuse the tile buffers): [MB*32][NB*32]
   // C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -230,22 +279,32 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_grouped_kernel(GroupArgs
                   GA.g[0].part + (size_t)blockIdx.x * 64 * 128, lds);
 }
 
-// C[m*ldc + j] = sum over workgroups of part[wg][m][j].  64 outputs x 4
-// slices of the workgroup range per block: the loads of a slice are coalesced
-// over the outputs; every slice is summed in index order in double, the four
-// slices are combined in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void planes_gemm_reduce_kernel(
-    const float *__restrict__ part, int num_wg, int W, int rows, int M, int Jt,
-    float *__restrict__ C, int ldc, int J, float *__restrict__ bias_out) {
-  __shared__ double sh[4][64];
-  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + x;
-  const bool ok = idx < M * Jt;
-  const int m = ok ? idx / Jt : 0, j = ok ? idx % Jt : 0;
-  const float *p = part + (size_t)m * W + j;
-  const size_t stride = (size_t)rows * W;
-  const int per = (num_wg + 3) / 4;
-  const int w0 = y * per, w1 = w0 + per < num_wg ? w0 + per : num_wg;
+// C[m*ldc + j] = sum over workgroups of part[wg][m][j], for up to kMaxGroup
+// products per launch (blockIdx.y).  A block owns 32 outputs and cuts the
+// workgroup range into 32 slices: the loads of a slice are coalesced over the
+// outputs, every slice is summed in index order in double and the slices are
+// combined in index order (deterministic).
+struct ReduceItem {
+  const float *part;
+  float *C, *bias;
+  int num_wg, W, rows, M, Jt, J, ldc;
+};
+struct ReduceArgs {
+  ReduceItem it[kMaxGroup];
+};
+
+__global__ __launch_bounds__(1024) void planes_gemm_reduce_kernel(ReduceArgs R) {
+  __shared__ double sh[32][33];
+  const ReduceItem &q = R.it[blockIdx.y];
+  if ((int)blockIdx.x * 32 >= q.M * q.Jt) return;
+  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + x;
+  const bool ok = idx < q.M * q.Jt;
+  const int m = ok ? idx / q.Jt : 0, j = ok ? idx % q.Jt : 0;
+  const float *p = q.part + (size_t)m * q.W + j;
+  const size_t stride = (size_t)q.rows * q.W;
+  const int per = (q.num_wg + 31) / 32;
+  const int w0 = y * per, w1 = w0 + per < q.num_wg ? w0 + per : q.num_wg;
   double acc[4] = {0, 0, 0, 0};
   int w = w0;
   for (; w + 4 <= w1; w += 4) {
@@ -256,9 +315,11 @@ __global__ __launch_bounds__(256) void planes_gemm_reduce_kernel(
   sh[y][x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   __syncthreads();
   if (y == 0 && ok) {
-    const float v = (float)((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x]));
-    if (j == J && bias_out) bias_out[m] = v;  // row sums to their own vector
-    else C[(size_t)m * ldc + j] = v;
+    double t = 0;
+    for (int k = 0; k < 32; ++k) t += sh[k][x];
+    const float v = (float)t;
+    if (j == q.J && q.bias) q.bias[m] = v;  // row sums to their own vector
+    else q.C[(size_t)m * q.ldc + j] = v;
   }
 }
 
@@ -288,7 +349,7 @@ __global__ __launch_bounds__(256) void planes_gemm_grouped_reduce_kernel(GroupAr
 
 template <int MB, int NB>
 int launch(const GemmArgs &G, int num_wg, hipStream_t st) {
-  const size_t lds = (size_t)2 * (MB + NB) * 8 * kGS * sizeof(float);
+  const size_t lds = Shape<MB, NB>::lds_bytes;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)planes_gemm_kernel<MB, NB>,
@@ -302,16 +363,83 @@ int launch(const GemmArgs &G, int num_wg, hipStream_t st) {
   return check_launch("planes_gemm");
 }
 
-template <int MB>
-int launch_nb(const GemmArgs &G, int NB, int num_wg, hipStream_t st) {  // MB == 1
-  switch (NB) {
-    case 1: return launch<MB, 1>(G, num_wg, st);
-    case 2: return launch<MB, 2>(G, num_wg, st);
-    case 3: return launch<MB, 3>(G, num_wg, st);
-    case 4: return launch<MB, 4>(G, num_wg, st);
-    case 5: return launch<MB, 5>(G, num_wg, st);
-    default: return launch<MB, 6>(G, num_wg, st);
+int launch_shape(const GemmArgs &G, int MB, int NB, int num_wg, hipStream_t st) {
+  if (MB == 1) {
+    switch (NB) {
+      case 1: return launch<1, 1>(G, num_wg, st);
+      case 2: return launch<1, 2>(G, num_wg, st);
+      case 3: return launch<1, 3>(G, num_wg, st);
+      case 4: return launch<1, 4>(G, num_wg, st);
+      case 5: return launch<1, 5>(G, num_wg, st);
+      default: return launch<1, 6>(G, num_wg, st);
+    }
   }
+  switch (NB) {
+    case 1: return launch<2, 1>(G, num_wg, st);
+    case 2: return launch<2, 2>(G, num_wg, st);
+    case 3: return launch<2, 3>(G, num_wg, st);
+    default: return launch<2, 4>(G, num_wg, st);
+  }
+}
+
+// LDS bytes of a tile shape's ring (Shape<MB, NB>::lds_bytes at run time)
+int shape_lds_bytes(int MB, int NB) {
+  const int buf = (MB + NB) * 8 * kGS * 4;
+  return ((APG_GEMM_ST_MAX >= 3 && 3 * buf <= kLdsBytes) ? 3 : 2) * buf;
+}
+
+int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) ==
+            hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+    (void)hipGetLastError();
+  }
+  return n;
+}
+
+// workgroups per CU as measured best (tools/bench_gemm.py, WGS sweep): what the
+// LDS holds, but at most 2 - except the 32 x 32 shape, whose tiles are so
+// small that 4 rings per CU are needed to keep enough bytes in flight
+int default_wgs(int MB, int NB) {
+  int per_cu = kLdsBytes / shape_lds_bytes(MB, NB);
+  const int cap = MB + NB <= 2 ? 4 : 2;
+  per_cu = per_cu < 1 ? 1 : per_cu > cap ? cap : per_cu;
+  return cu_count() * per_cu;
+}
+
+const char *check_problem(const float *A, const float *Bp, const int *bdesc,
+                          const float *C, int M, int S, int J, int Jt, int sdiv,
+                          int b_planes, long long N, int ldc, bool own_bias) {
+  if (!A || !Bp || !bdesc || !C) return "NULL pointer";
+  const int MB = (M + 31) / 32, NB = (Jt + 31) / 32;
+  if (M < 1 || M > 64 || S < 1 || J < 1 || Jt > kMaxNB * 32 || N < 1 || sdiv < 1 ||
+      ldc < (own_bias ? J : Jt) || (MB == 2 && NB > 4))
+    return "need 1 <= M <= 64, J + ones <= 192 (<= 128 when M > 32), S, N, sdiv >= 1, "
+           "ldc >= J + ones";
+  if (b_planes < 1 || (long long)M * S * N * 4 >= kMaxOperandBytes ||
+      (long long)b_planes * N * 4 >= kMaxOperandBytes)
+    return "operands must be smaller than 4 GiB each (32-bit buffer offsets): pass "
+           "B from the first plane the product uses, or split the batch";
+  if ((long long)S * ((N + kKT - 1) / kKT) >= (1ll << 31)) return "too many tiles";
+  return nullptr;
+}
+
+void fill_args(GemmArgs &G, const float *A, const float *Bp, const int *bdesc,
+               float *part, int M, int S, int J, int sdiv, int with_ones,
+               int b_planes, long long N) {
+  G.A = A, G.Bp = Bp, G.bdesc = bdesc, G.part = part;
+  G.a_bytes = (long long)M * S * N * 4;
+  G.b_bytes = (long long)b_planes * N * 4;
+  G.N = N, G.M = M, G.S = S, G.J = J;
+  G.sdiv = sdiv;
+  G.with_ones = with_ones ? 1 : 0;
+  G.tiles_per_seg = (int)((N + kKT - 1) / kKT);
 }
 
 }  // namespace
@@ -326,52 +454,86 @@ int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg) {
   return num_wg * MB * 32 * NB * 32;
 }
 
+int apg_planes_gemm_default_wgs(int M, int J, int with_ones) {
+  return default_wgs((M + 31) / 32, (J + (with_ones ? 1 : 0) + 31) / 32);
+}
+
 int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
                     const int *bdesc, int J, int sdiv, int with_ones,
                     int b_planes, long long N, float *workspace, int num_wg,
                     float *C, int ldc, float *bias_out, apg_stream_t stream) {
   const int Jt = J + (with_ones ? 1 : 0);
-  if (!A || !Bp || !bdesc || !workspace || !C) {
-    set_error("apg_planes_gemm: NULL pointer");
+  if (!workspace || num_wg < 1) {
+    set_error("apg_planes_gemm: workspace is NULL or num_wg < 1");
+    return APG_ERR_ARG;
+  }
+  if (const char *why = check_problem(A, Bp, bdesc, C, M, S, J, Jt, sdiv, b_planes, N,
+                                      ldc, bias_out != nullptr)) {
+    set_error("apg_planes_gemm: %s", why);
     return APG_ERR_ARG;
   }
   const int MB = (M + 31) / 32, NB = (Jt + 31) / 32;
-  if (M < 1 || M > 64 || S < 1 || J < 1 || Jt > kMaxNB * 32 || N < 1 ||
-      num_wg < 1 || sdiv < 1 || ldc < (bias_out ? J : Jt) || (MB == 2 && NB > 4)) {
-    set_error("apg_planes_gemm: need 1 <= M <= 64, J + ones <= %d (<= 128 when "
-              "M > 32), S, N, num_wg, sdiv >= 1, ldc >= J + ones", kMaxNB * 32);
-    return APG_ERR_ARG;
-  }
-  const long long a_bytes = (long long)M * S * N * 4;
-  const long long b_bytes = (long long)b_planes * N * 4;
-  if (b_planes < 1 || a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) {
-    set_error("apg_planes_gemm: operands must be smaller than 2 GiB each "
-              "(32-bit buffer offsets); split the batch");
-    return APG_ERR_ARG;
-  }
   GemmArgs G;
-  G.A = A, G.Bp = Bp, G.bdesc = bdesc, G.part = workspace;
-  G.a_bytes = a_bytes, G.b_bytes = b_bytes;
-  G.N = N, G.M = M, G.S = S, G.J = J;
-  G.sdiv = sdiv;
-  G.with_ones = with_ones ? 1 : 0;
-  G.tiles_per_seg = (int)((N + kKT - 1) / kKT);
+  fill_args(G, A, Bp, bdesc, workspace, M, S, J, sdiv, with_ones, b_planes, N);
   hipStream_t st = (hipStream_t)stream;
-  int e;
-  if (MB == 1) {
-    e = launch_nb<1>(G, NB, num_wg, st);
-  } else {
-    switch (NB) {
-      case 1: e = launch<2, 1>(G, num_wg, st); break;
-      case 2: e = launch<2, 2>(G, num_wg, st); break;
-      case 3: e = launch<2, 3>(G, num_wg, st); break;
-      default: e = launch<2, 4>(G, num_wg, st); break;
+  if (int e = launch_shape(G, MB, NB, num_wg, st)) return e;
+  ReduceArgs R;
+  R.it[0] = ReduceItem{workspace, C, with_ones ? bias_out : nullptr, num_wg, NB * 32,
+                       MB * 32, M, Jt, J, ldc};
+  hipLaunchKernelGGL(planes_gemm_reduce_kernel, dim3((M * Jt + 31) / 32, 1),
+                     dim3(1024), 0, st, R);
+  return check_launch("planes_gemm_reduce");
+}
+
+long long apg_planes_gemm_multi_workspace_floats(const ApgGemmProblem *problems,
+                                                 int n) {
+  long long total = 0;
+  for (int p = 0; problems && p < n; ++p) {
+    const int Jt = problems[p].J + (problems[p].with_ones ? 1 : 0);
+    const int MB = (problems[p].M + 31) / 32, NB = (Jt + 31) / 32;
+    total += (long long)default_wgs(MB, NB) * MB * 32 * NB * 32;
+  }
+  return total;
+}
+
+int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspace,
+                          apg_stream_t stream) {
+  if (!problems || !workspace || n < 1 || n > kMaxGroup) {
+    set_error("apg_planes_gemm_multi: need 1 <= n <= %d problems and a workspace",
+              kMaxGroup);
+    return APG_ERR_ARG;
+  }
+  for (int p = 0; p < n; ++p) {
+    const ApgGemmProblem &q = problems[p];
+    const int Jt = q.J + (q.with_ones ? 1 : 0);
+    if (const char *why = check_problem(q.A, q.B, q.bdesc, q.C, q.M, q.S, q.J, Jt,
+                                        q.sdiv, q.b_planes, q.N, q.ldc,
+                                        q.bias_out && q.with_ones)) {
+      set_error("apg_planes_gemm_multi: problem %d: %s", p, why);
+      return APG_ERR_ARG;
     }
   }
-  if (e) return e;
-  hipLaunchKernelGGL(planes_gemm_reduce_kernel, dim3((M * Jt + 63) / 64),
-                     dim3(256), 0, st, workspace, num_wg, NB * 32, MB * 32, M, Jt,
-                     C, ldc, J, with_ones ? bias_out : nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  ReduceArgs R;
+  float *part = workspace;
+  int max_blocks = 1;
+  for (int p = 0; p < n; ++p) {
+    const ApgGemmProblem &q = problems[p];
+    const int Jt = q.J + (q.with_ones ? 1 : 0);
+    const int MB = (q.M + 31) / 32, NB = (Jt + 31) / 32;
+    const int wgs = default_wgs(MB, NB);
+    GemmArgs G;
+    fill_args(G, q.A, q.B, q.bdesc, part, q.M, q.S, q.J, q.sdiv, q.with_ones,
+              q.b_planes, q.N);
+    if (int e = launch_shape(G, MB, NB, wgs, st)) return e;
+    R.it[p] = ReduceItem{part, q.C, q.with_ones ? q.bias_out : nullptr, wgs, NB * 32,
+                         MB * 32, q.M, Jt, q.J, q.ldc};
+    part += (size_t)wgs * MB * 32 * NB * 32;
+    const int blocks = (q.M * Jt + 31) / 32;
+    max_blocks = blocks > max_blocks ? blocks : max_blocks;
+  }
+  hipLaunchKernelGGL(planes_gemm_reduce_kernel, dim3(max_blocks, n), dim3(1024), 0, st,
+                     R);
   return check_launch("planes_gemm_reduce");
 }
 
@@ -397,8 +559,8 @@ int apg_planes_gemm_grouped(const ApgGemmProblem *problems, int n,
     }
     const long long a_bytes = (long long)q.M * q.S * q.N * 4;
     const long long b_bytes = (long long)q.b_planes * q.N * 4;
-    if (q.b_planes < 1 || a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) {
-      set_error("apg_planes_gemm_grouped: problem %d: operands must be < 2 GiB", p);
+    if (q.b_planes < 1 || a_bytes >= kMaxOperandBytes || b_bytes >= kMaxOperandBytes) {
+      set_error("apg_planes_gemm_grouped: problem %d: operands must be < 4 GiB", p);
       return APG_ERR_ARG;
     }
     GemmArgs &G = GA.g[p];
@@ -422,7 +584,7 @@ int apg_planes_gemm_grouped(const ApgGemmProblem *problems, int n,
   }
   GA.wg0[n] = given;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)2 * (2 + 4) * 8 * kGS * sizeof(float);
+  const size_t lds = Shape<2, 4>::lds_bytes;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)planes_gemm_grouped_kernel,

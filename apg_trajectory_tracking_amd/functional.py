@@ -623,20 +623,61 @@ _GEMM_WGS = None   # None: sized from the LDS footprint (workgroups per CU x 256
 _bdesc_cache = {}
 
 
+class _BDesc:
+    """Column descriptor of apg_planes_gemm: device int32 [3, J] = plane offset
+    and the two segment strides of every column, the offsets RELATIVE to
+    `base_plane` (the first plane the product touches): the kernel addresses
+    its operands with unsigned 32-bit byte offsets, so B is handed over from
+    that plane on and only the span the product really uses has to stay below
+    4 GiB."""
+    __slots__ = ("tensor", "base_plane", "J", "host")
+
+    def __init__(self, tensor, base_plane, J, host):
+        self.tensor, self.base_plane, self.J, self.host = tensor, base_plane, J, host
+
+    def span(self, S, sdiv):
+        """Planes from base_plane up to the last one segment s < S touches."""
+        q, r = (S - 1) // sdiv, min(S, sdiv) - 1
+        return 1 + max(o + q * a + r * b for o, a, b in zip(*self.host))
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    def data_ptr(self):
+        return self.tensor.data_ptr()
+
+
 def make_bdesc(dev, offsets, stride1=0, stride2=0, key=None):
-    """Column descriptor of apg_planes_gemm: int32 [3, J] = plane offset and
-    the two segment strides of every column (scalars broadcast).  Cached per
-    device when a `key` is given (building it is a host-to-device copy)."""
+    """Descriptor for the columns `offsets` (plane indices into B) with the
+    per-column strides per s // sdiv and s % sdiv (scalars broadcast, >= 0).
+    Cached per device when a `key` is given (building it is a host-to-device
+    copy)."""
     k = (str(dev), key)
     if key is not None and k in _bdesc_cache:
         return _bdesc_cache[k]
+    offsets = [int(o) for o in offsets]
     J = len(offsets)
-    bc = lambda v: list(v) if hasattr(v, "__len__") else [int(v)] * J
-    t = torch.tensor([list(offsets), bc(stride1), bc(stride2)],
-                     dtype=torch.int32, device=dev)
+    bc = lambda v: [int(x) for x in v] if hasattr(v, "__len__") else [int(v)] * J
+    s1, s2 = bc(stride1), bc(stride2)
+    if min(s1) < 0 or min(s2) < 0 or min(offsets) < 0:
+        raise ValueError("make_bdesc: plane offsets and strides must be >= 0")
+    base = min(offsets)
+    host = ([o - base for o in offsets], s1, s2)
+    t = torch.tensor(list(host), dtype=torch.int32, device=dev)
+    d = _BDesc(t, base, J, host)
     if key is not None:
-        _bdesc_cache[k] = t
-    return t
+        _bdesc_cache[k] = d
+    return d
+
+
+def _b_operand(Bp, bdesc, N, S, sdiv):
+    """(pointer, plane count) of B as the kernel gets it: the planes the
+    product touches, from the descriptor's base plane on."""
+    planes = bdesc.span(S, sdiv)
+    if bdesc.base_plane + planes > Bp.numel() // N:
+        raise ValueError("planes_gemm: descriptor points beyond B")
+    return Bp.data_ptr() + bdesc.base_plane * N * 4, planes
 
 
 def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None,
@@ -651,12 +692,9 @@ def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None,
     weight and bias gradients are separate contiguous tensors; returns [M, J]."""
     require_device(A, Bp)
     N = A.shape[1] if N is None else N
-    J = bdesc.shape[1]
+    J = bdesc.J
     Jt = J + int(with_ones)
-    wgs = _GEMM_WGS
-    if wgs is None:   # double-buffered tiles: 16.6 KB of LDS per 32-row block
-        blocks = (M + 31) // 32 + (Jt + 31) // 32
-        wgs = 256 * max(1, min(2, 9 // blocks))
+    wgs = _GEMM_WGS or lib().apg_planes_gemm_default_wgs(M, J, int(with_ones))
     ws = torch.empty(lib().apg_planes_gemm_workspace_floats(
         M, J, int(with_ones), wgs), dtype=torch.float32, device=A.device)
     Jc = J if (bias_out is not None and with_ones) else Jt   # columns of C
@@ -664,9 +702,10 @@ def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None,
         out = torch.empty(M, Jc, dtype=torch.float32, device=A.device)
     if out.stride(1) != 1 or out.shape[0] < M or out.shape[1] < Jc:
         raise ValueError("planes_gemm: out must be [>=M, >=J+ones], unit column stride")
+    b_ptr, b_planes = _b_operand(Bp, bdesc, N, S, sdiv)
     check(lib().apg_planes_gemm(
-        ptr(A), M, S, ptr(Bp), bdesc.data_ptr(), J, sdiv, int(with_ones),
-        Bp.numel() // N, N, ptr(ws), wgs, out.data_ptr(), out.stride(0),
+        ptr(A), M, S, b_ptr, bdesc.data_ptr(), J, sdiv, int(with_ones),
+        b_planes, N, ptr(ws), wgs, out.data_ptr(), out.stride(0),
         ptr(bias_out), stream_of(A)), "apg_planes_gemm")
     return out[:M, :Jc]
 
@@ -674,11 +713,7 @@ def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None,
 _GROUP_WGS = 256
 
 
-def planes_gemm_grouped(problems):
-    """Several planes_gemm products in one launch pair
-    (apg_planes_gemm_grouped).  `problems`: dicts with the planes_gemm
-    arguments A, M, S, Bp, bdesc, out and optionally with_ones (True), sdiv
-    (1), N, bias_out; each M <= 64 and J + ones <= 128, at most 8."""
+def _gemm_problems(problems):
     probs = (_capi.ApgGemmProblem * len(problems))()
     for q, d in zip(probs, problems):
         A, Bp, out = d["A"], d["Bp"], d["out"]
@@ -686,19 +721,41 @@ def planes_gemm_grouped(problems):
         N = d.get("N") or A.shape[1]
         ones = int(d.get("with_ones", True))
         bias = d.get("bias_out") if ones else None
-        J = d["bdesc"].shape[1]
+        J = d["bdesc"].J
         if out.stride(1) != 1 or out.shape[0] < d["M"] \
                 or out.shape[1] < (J if bias is not None else J + ones):
-            raise ValueError("planes_gemm_grouped: bad `out` view")
-        q.A, q.B, q.bdesc, q.C = ptr(A), ptr(Bp), d["bdesc"].data_ptr(), out.data_ptr()
+            raise ValueError("planes_gemm: bad `out` view")
+        q.A, q.bdesc, q.C = ptr(A), d["bdesc"].data_ptr(), out.data_ptr()
+        q.B, q.b_planes = _b_operand(Bp, d["bdesc"], N, d["S"], d.get("sdiv", 1))
         q.bias_out = ptr(bias)
         q.N, q.M, q.S, q.J = N, d["M"], d["S"], J
         q.sdiv, q.with_ones = d.get("sdiv", 1), ones
-        q.b_planes, q.ldc = Bp.numel() // N, out.stride(0)
+        q.ldc = out.stride(0)
+    return probs
+
+
+def planes_gemm_grouped(problems):
+    """Several planes_gemm products in one launch pair
+    (apg_planes_gemm_grouped).  `problems`: dicts with the planes_gemm
+    arguments A, M, S, Bp, bdesc, out and optionally with_ones (True), sdiv
+    (1), N, bias_out; each M <= 64 and J + ones <= 128, at most 8."""
+    probs = _gemm_problems(problems)
     A0 = problems[0]["A"]
     ws = torch.empty(_GROUP_WGS * 64 * 128, dtype=torch.float32, device=A0.device)
     check(lib().apg_planes_gemm_grouped(probs, len(problems), ptr(ws), _GROUP_WGS,
                                         stream_of(A0)), "apg_planes_gemm_grouped")
+
+
+def planes_gemm_multi(problems):
+    """The same products, one launch each (own tile shape and occupancy) and
+    ONE second-stage launch for all (apg_planes_gemm_multi); at most 8."""
+    probs = _gemm_problems(problems)
+    A0 = problems[0]["A"]
+    n = len(problems)
+    ws = torch.empty(lib().apg_planes_gemm_multi_workspace_floats(probs, n),
+                     dtype=torch.float32, device=A0.device)
+    check(lib().apg_planes_gemm_multi(probs, n, ptr(ws), stream_of(A0)),
+          "apg_planes_gemm_multi")
 
 
 def _run_products(problems):
@@ -707,17 +764,15 @@ def _run_products(problems):
     products share one launch pair.  Long planes (H columns per trajectory):
     each product gets its own launch with the tile shape and occupancy that
     fit it - a shared launch would run the small ones at one workgroup per
-    CU."""
+    CU - and they share the second-stage launch."""
     n_max = max(d.get("N") or d["A"].shape[1] for d in problems)
     total = sum((d.get("N") or d["A"].shape[1]) * d["S"] for d in problems)
-    fits = all(d["bdesc"].shape[1] + int(d.get("with_ones", True)) <= 128
+    fits = all(d["bdesc"].J + int(d.get("with_ones", True)) <= 128
                for d in problems) and len(problems) <= 8
     if fits and total <= 8 * 131072 and n_max <= 131072:
         return planes_gemm_grouped(problems)
-    for d in problems:
-        planes_gemm(d["A"], d["M"], d["S"], d["Bp"], d["bdesc"],
-                    with_ones=d.get("with_ones", True), sdiv=d.get("sdiv", 1),
-                    N=d.get("N"), out=d["out"], bias_out=d.get("bias_out"))
+    for lo in range(0, len(problems), 8):
+        planes_gemm_multi(problems[lo:lo + 8])
 
 
 def _flat_grads(dev, shapes):
@@ -1264,14 +1319,16 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
     return loss, gr, flat
 
 
-_MAX_FUSED_AR_BATCH = 98304   # saved planes stay below planes_gemm's 2 GiB per operand
+# the sweeps address every plane tensor with unsigned 32-bit byte offsets: the
+# largest (256 cotangent planes of H*B floats) stays below 4 GiB up to 419 430
+_MAX_FUSED_AR_BATCH = 393216
 
 
 def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
                            index=None):
     """quad_mlp_rollout_loss (autoregressive unroll) + parameter gradients,
     without autograd; see quad_concurrent_policy_grads.  Batches beyond
-    98 304 trajectories are processed in chunks (losses and gradients are sums
+    393 216 trajectories are processed in chunks (losses and gradients are sums
     over trajectories, so the chunks simply add up)."""
     B = state0.shape[0] if index is None else index.numel()
     if B > _MAX_FUSED_AR_BATCH:

@@ -389,8 +389,13 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
  * floats; C has row stride ldc >= J + with_ones.  With `bias_out` (and
  * with_ones) the row sums go to bias_out[M] instead of column J, so that
  * weight and bias gradients are both contiguous (ldc >= J then).  B holds
- * `b_planes` planes; A (M*S planes) and B must each stay below 2 GiB. */
+ * `b_planes` planes; A (M*S planes) and B must each stay below 4 GiB (unsigned
+ * 32-bit buffer offsets): hand B over from the first plane the product uses
+ * (bdesc relative to it) when the tensor behind it is larger.
+ * apg_planes_gemm_default_wgs: the num_wg that fills every CU's LDS with this
+ * shape's tile rings (what apg_planes_gemm_multi uses). */
 int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg);
+int apg_planes_gemm_default_wgs(int M, int J, int with_ones);
 int apg_planes_gemm(const float *A, int M, int S, const float *B,
                     const int *bdesc, int J, int sdiv, int with_ones,
                     int b_planes, long long N, float *workspace, int num_wg,
@@ -411,6 +416,16 @@ typedef struct ApgGemmProblem {
 } ApgGemmProblem;
 int apg_planes_gemm_grouped(const ApgGemmProblem *problems, int n,
                             float *workspace, int num_wg, apg_stream_t stream);
+
+/* The same n <= 8 products as n launches, each with the tile shape and
+ * occupancy that fit it (long planes: H columns per trajectory), followed by
+ * ONE second-stage launch for all of them.  J + with_ones <= 192 (<= 128 when
+ * M > 32) as for apg_planes_gemm.  workspace:
+ * apg_planes_gemm_multi_workspace_floats(problems, n) floats. */
+long long apg_planes_gemm_multi_workspace_floats(const ApgGemmProblem *problems,
+                                                 int n);
+int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspace,
+                          apg_stream_t stream);
 
 /* ---------------------------------------------------------- fixed wing --- */
 /* Parameters of neural_control/dynamics/fixed_wing_dynamics.py:18-39 +

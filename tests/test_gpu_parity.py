@@ -824,6 +824,102 @@ def test_planes_gemm_grouped_vs_torch(dev):
     assert rel_err(b3.cpu().numpy(), A3d.sum((1, 2)).numpy()) < 1e-5
 
 
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def test_planes_gemm_multi_vs_torch(dev):
+    """apg_planes_gemm_multi: the products of a recurrent training step, one
+    launch each with its own tile shape (3-deep DMA ring where the LDS holds
+    it, 2-deep for the 32 x 192 shape) and ONE second-stage launch; strided
+    outputs, separate bias vectors, ragged N, two-level segment strides."""
+    from apg_trajectory_tracking_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    N = 9000 + 21
+    Bp = torch.randn(240, N, generator=g).to(dev)
+    A1 = torch.randn(64, N, generator=g).to(dev)
+    A2 = torch.randn(4, N, generator=g).to(dev)
+    A3 = torch.randn(20 * 8 * 3, N, generator=g).to(dev)
+    A4 = torch.randn(32, N, generator=g).to(dev)
+    o1, b1 = torch.zeros(64, 120, device=dev), torch.zeros(64, device=dev)
+    o2 = torch.zeros(4, 65, device=dev)
+    o3, b3 = torch.zeros(20, 30, device=dev), torch.zeros(20, device=dev)
+    o4, b4 = torch.zeros(32, 183, device=dev), torch.zeros(32, device=dev)
+    o5 = torch.zeros(64, 16, device=dev)
+    offs3 = [t * 9 + c for c in range(9) for t in range(3)] + [200, 201, 202]
+    s1, s2 = [9] * 27 + [0] * 3, [9] * 27 + [12] * 3
+    F.planes_gemm_multi([
+        dict(A=A1, M=64, S=1, Bp=Bp, bdesc=F.make_bdesc(dev, range(10, 122)),
+             out=o1[:, 4:], bias_out=b1),
+        dict(A=A2, M=4, S=1, Bp=Bp, bdesc=F.make_bdesc(dev, range(140, 204)), out=o2),
+        dict(A=A3, M=20, S=8 * 3, Bp=Bp, bdesc=F.make_bdesc(dev, offs3, s1, s2),
+             sdiv=3, out=o3, bias_out=b3),
+        dict(A=A4, M=32, S=1, Bp=Bp, bdesc=F.make_bdesc(dev, range(57, 240)),
+             out=o4, bias_out=b4),
+        dict(A=A1, M=64, S=1, Bp=Bp, bdesc=F.make_bdesc(dev, range(225, 240)),
+             out=o5)])
+    B64 = Bp.double().cpu()
+    A1d = A1.double().cpu()
+    assert rel_err(o1[:, 4:116].cpu().numpy(), (A1d @ B64[10:122].t()).numpy()) < 1e-5
+    assert float(o1[:, :4].abs().sum()) == 0 and float(o1[:, 116:].abs().sum()) == 0
+    assert rel_err(b1.cpu().numpy(), A1d.sum(1).numpy()) < 1e-5
+    r2 = torch.cat((A2.double().cpu() @ B64[140:204].t(),
+                    A2.double().cpu().sum(1, keepdim=True)), 1)
+    assert rel_err(o2.cpu().numpy(), r2.numpy()) < 1e-5
+    A3d = A3.double().cpu().view(20, 8, 3, N)
+    r3 = torch.zeros(20, 30, dtype=torch.float64)
+    for pos in range(8):
+        for k in range(3):
+            rows = torch.stack([B64[o + pos * a + k * b]
+                                for o, a, b in zip(offs3, s1, s2)])
+            r3 += A3d[:, pos, k] @ rows.t()
+    assert rel_err(o3.cpu().numpy(), r3.numpy()) < 1e-5
+    assert rel_err(b3.cpu().numpy(), A3d.sum((1, 2, 3)).numpy()) < 1e-5
+    A4d = A4.double().cpu()
+    assert rel_err(o4.cpu().numpy(), (A4d @ B64[57:240].t()).numpy()) < 1e-5
+    assert rel_err(b4.cpu().numpy(), A4d.sum(1).numpy()) < 1e-5
+    r5 = torch.cat((A1d @ B64[225:240].t(), A1d.sum(1, keepdim=True)), 1)
+    assert rel_err(o5.cpu().numpy(), r5.numpy()) < 1e-5
+    # tiny reduction lengths: fewer tiles than workgroups, one ragged tile
+    for n in (1, 63, 64, 65, 200):
+        C = F.planes_gemm(A1[:, :n].contiguous(), 64, 1, Bp[:, :n].contiguous(),
+                          F.make_bdesc(dev, range(100, 164)))
+        r = torch.cat((A1d[:, :n] @ B64[100:164, :n].t(),
+                       A1d[:, :n].sum(1, keepdim=True)), 1)
+        assert rel_err(C.cpu().numpy(), r.numpy()) < 1e-5, n
+
+
+def test_planes_gemm_operands_beyond_2gib(dev):
+    """Operand offsets are unsigned 32-bit and B is addressed from the first
+    plane a product uses: a 3.2 GB B tensor (planes of 1 Mi floats) works for
+    products over its last planes as well as its first (2.7 GB span)."""
+    from apg_trajectory_tracking_amd import functional as F
+    N = 1 << 20
+    Bp = torch.empty(760, N, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    for lo in range(0, 760, 40):
+        Bp[lo:lo + 40].normal_(generator=g)
+    A = torch.randn(32, N, device=dev, generator=g)
+    for lo, hi in ((728, 760), (0, 32), (620, 652)):
+        C = F.planes_gemm(A, 32, 1, Bp, F.make_bdesc(dev, range(lo, hi)),
+                          with_ones=False)
+        ref = A.double() @ Bp[lo:hi].double().t()
+        assert rel_err(N_(C), N_(ref)) < 1e-5, (lo, hi)
+    # columns 0 and 650: the span (651 planes x 4 MiB = 2.7 GB) is what counts
+    C = F.planes_gemm(A, 32, 1, Bp, F.make_bdesc(dev, [0, 650]), with_ones=False)
+    ref = A.double() @ Bp[[0, 650]].double().t()
+    assert rel_err(N_(C), N_(ref)) < 1e-5
+    big = torch.empty(1100, N, device=dev)      # 4.6 GB
+    big[1060:1092].copy_(Bp[:32])
+    C = F.planes_gemm(A, 32, 1, big, F.make_bdesc(dev, range(1060, 1092)),
+                      with_ones=False)           # a narrow product anywhere in it
+    assert rel_err(N_(C), N_(A.double() @ Bp[:32].double().t())) < 1e-5
+    with pytest.raises(ValueError):              # span beyond 32 bits
+        F.planes_gemm(A, 32, 1, big, F.make_bdesc(dev, [0, 1090]), with_ones=False)
+    with pytest.raises(ValueError):              # descriptor beyond the tensor
+        F.planes_gemm(A, 32, 1, Bp, F.make_bdesc(dev, [759, 760]), with_ones=False)
+
+
 def test_to_soa_matches_permute(dev):
     """apg_to_soa: tiled transpose at the boundary, incl. ragged sizes and a
     leading slice of longer rows read in place."""

@@ -238,7 +238,13 @@ def test_flat_gradient_layout_and_new_argument_errors():
     views["c"].fill_(2.0)
     assert float(flat[16:24].sum()) == 16.0 and views["a.bias"].data_ptr() == flat[12:].data_ptr()
     d = F.make_bdesc("cpu", [5, 6, 7], 9, [0, 1, 2])
-    assert d.dtype == torch.int32 and d.tolist() == [[5, 6, 7], [9, 9, 9], [0, 1, 2]]
+    # offsets relative to the first plane the product touches (B is handed to
+    # the kernel from there: only the span has to fit 32-bit byte offsets)
+    assert d.tensor.dtype == torch.int32 and d.base_plane == 5 and d.J == 3
+    assert d.tensor.tolist() == [[0, 1, 2], [9, 9, 9], [0, 1, 2]]
+    assert d.span(1, 1) == 3 and d.span(8, 4) == 3 + 9 + 3 * 2
+    with pytest.raises(ValueError):
+        F.make_bdesc("cpu", [1, 2], -1)
     assert ctypes.sizeof(_capi.ApgMlpPolicy) == 12 * 8
     assert ctypes.sizeof(_capi.ApgLstmPolicy) == 8 * 8
     assert ctypes.sizeof(_capi.ApgWingPolicy) == 12 * 8

@@ -6,13 +6,14 @@ from apg_trajectory_tracking_amd import functional as F
 
 dev = torch.device("cuda:0")
 B, H = 65536, 10
-N = B * H
+N = B * H + int(os.environ.get('NPAD', '0'))   # NPAD: plane pitch experiment
 acts = torch.randn(431, N, device=dev)
 d_pre = torch.randn(256, N, device=dev)
 inr = torch.randn(2 * H * 9, B, device=dev)
+Bc = B + int(os.environ.get('NPAD', '0')) // 8
 d_conv = d_pre[:160]
 R = lambda lo, hi: F.make_bdesc(dev, range(lo, hi))
-refbuf = torch.randn(2 * H * 9 + (H + 1) * 12, B, device=dev)
+refbuf = torch.randn(2 * H * 9 + (H + 1) * 12, Bc, device=dev)
 conv_desc = F.make_bdesc(dev, [t * 9 + c for c in range(9) for t in range(3)] + [180, 181, 182],
                          [9] * 27 + [0] * 3, [9] * 27 + [12] * 3)
 shapes = {
@@ -22,7 +23,7 @@ shapes = {
     "out  M4  J64+1": lambda: F.planes_gemm(d_pre[:4], 4, 1, acts, R(367, 431)),
     "lstm M32 J183+1": lambda: F.planes_gemm(d_pre[:32], 32, 1, acts, R(0, 183)),
     "conv M20 S80 J30+1": lambda: F.planes_gemm(d_conv, 20, 8 * H, refbuf, conv_desc,
-                                                 sdiv=H, N=B),
+                                                 sdiv=H, N=Bc),
 }
 planes = {"fc1a M64 J112": 176, "fc2  M64 J64+1": 128, "st   M64 J15+1": 79,
           "out  M4  J64+1": 68, "lstm M32 J183+1": 215, "conv M20 S80 J30+1": 160}
