@@ -165,7 +165,7 @@ SIGNATURES = {
     "apg_wing_policy_bwd": [_P, _P, _P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P,
                             _P, _P, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
-    "apg_planes_gemm_default_wgs": [_I, _I, _I],
+    "apg_planes_gemm_default_wgs": [_I, _I, _I, _I],
     "apg_planes_gemm_multi_workspace_floats": [ctypes.POINTER(ApgGemmProblem), _I],
     "apg_planes_gemm_multi": [ctypes.POINTER(ApgGemmProblem), _I, _P, _P],
     "apg_planes_gemm": [_P, _I, _I, _P, _P, _I, _I, _I, _I,

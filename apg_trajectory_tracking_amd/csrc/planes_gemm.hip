@@ -51,6 +51,12 @@ namespace {
 #ifndef APG_GEMM_ST_MAX
 #define APG_GEMM_ST_MAX 2
 #endif
+// 1: apg_planes_gemm / apg_planes_gemm_multi run the register-streaming kernel
+// (stream_body); 0: the LDS-tile kernel (experiments; the grouped entry point
+// for short planes always uses the LDS-tile kernel).
+#ifndef APG_GEMM_STREAM
+#define APG_GEMM_STREAM 1
+#endif
 
 constexpr int kKT = 64;        // reduction elements per tile
 constexpr int kGS = 4 * kKT + 4;  // floats per 4-row group in LDS (16 B pad)
@@ -251,6 +257,163 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
   for (int i = tid; i < MB * 32 * W; i += kThreads) out[i] = red[i];
 }
 
+// ---------------------------------------------------------------------------
+// The long-plane kernel: operands go global -> registers -> matrix core, no
+// LDS tile and no barrier in the main loop.  With v_mfma_f32_16x16x4_f32 lane
+// l supplies A[l & 15][k = l >> 4] and B[k = l >> 4][l & 15]; the reduction
+// index may be permuted freely as long as A and B agree, so lane (i, g) loads
+// 8 CONSECUTIVE floats of its row's plane (two 16-byte loads at column
+// 32 c + 8 g) and the m-th of them is its operand of the m-th MFMA of the
+// chunk: 16 rows x 128 contiguous bytes per load pair, every operand element
+// is fetched exactly once, and each wave streams its own chunks of 32 columns
+// (split-K over all waves of the grid) with the next chunk's loads in flight
+// while this one multiplies (S = 1 products only: the segmented conv product
+// re-reads its windows per segment and is faster through the LDS tiles).
+// One wave holds ALL MB x NB accumulator tiles of
+// 16 x 16 (4 registers each); the 4 waves of a workgroup are summed through
+// LDS at the end and the partial C goes to the same second stage as above.
+// Row sums (bias gradients) are accumulated from the A operands on the VALU.
+constexpr unsigned kDeadOff2 = 0xffffff00u;  // + the 16-byte immediate: still out of range
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MB, int NB>
+__device__ __forceinline__ void stream_body(const GemmArgs &G, int bid, int nb,
+                                            float *out, float *red) {
+  constexpr int W = NB * 16 + 1;  // partial row pitch; column J holds the row sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+  f32x4 acc[MB][NB];
+  float rsum[MB];
+#pragma unroll
+  for (int rb = 0; rb < MB; ++rb) {
+    rsum[rb] = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const unsigned plane_bytes = (unsigned)(G.N * 4);
+  const auto rA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(G.A), 0, (unsigned)G.a_bytes, 0x00020000);
+  const auto rB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(G.Bp), 0, (unsigned)G.b_bytes, 0x00020000);
+  unsigned offA[MB], offB[NB];
+#pragma unroll
+  for (int rb = 0; rb < MB; ++rb) {
+    const int row = rb * 16 + i16;
+    offA[rb] = row < G.M ? (unsigned)row * plane_bytes + g * 32 : kDeadOff2;
+  }
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) {
+    const int j = cb * 16 + i16, jc = j < G.J ? j : 0;
+    offB[cb] = j < G.J ? (unsigned)G.bdesc[jc] * plane_bytes + g * 32 : kDeadOff2;
+  }
+  // the waves of the grid take chunks of 32 columns wave-strided: at any time
+  // the grid reads one contiguous stretch of every plane
+  const int cps = (int)((G.N + 31) / 32);
+  const int nw = nb * 4;
+  int cc = bid * 4 + wave;
+  auto load = [&](u32x4 (&fa)[MB][2], u32x4 (&fb)[NB][2]) {
+    const bool live = cc < cps;
+    const unsigned colb = (unsigned)cc * 128u;
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) {
+      const unsigned off = (live && offA[rb] != kDeadOff2) ? offA[rb] + colb : kDeadOff2;
+      fa[rb][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)off, 0, 0);
+      fa[rb][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)off + 16, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const unsigned off = (live && offB[cb] != kDeadOff2) ? offB[cb] + colb : kDeadOff2;
+      fb[cb][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)off, 0, 0);
+      fb[cb][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)off + 16, 0, 0);
+    }
+  };
+  auto multiply = [&](u32x4 (&fa)[MB][2], u32x4 (&fb)[NB][2], int cc_) {
+    const int n0 = cc_ * 32 + g * 8;  // this lane's first column of the chunk
+    if ((long long)cc_ * 32 + 32 > G.N) {  // ragged last chunk: zero A beyond N
+#pragma unroll
+      for (int rb = 0; rb < MB; ++rb)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          if (n0 + m >= G.N) fa[rb][m >> 2][m & 3] = 0u;
+    }
+    // (whole-vector bit casts: __builtin_bit_cast of a single vector ELEMENT
+    // reads element 0 whatever the index - clang 19 / ROCm 7.2)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 va[MB], vb[NB];
+#pragma unroll
+      for (int rb = 0; rb < MB; ++rb) va[rb] = __builtin_bit_cast(f32x4, fa[rb][h]);
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) vb[cb] = __builtin_bit_cast(f32x4, fb[cb][h]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) {
+          const float a = va[rb][e];
+          rsum[rb] += a;
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb[cb][e],
+                                                               acc[rb][cb], 0, 0, 0);
+        }
+    }
+  };
+  // two register sets: the loads of chunk c+1 are in flight while chunk c
+  // multiplies (the compiler places the vmcnt waits)
+  u32x4 fa0[MB][2], fb0[NB][2], fa1[MB][2], fb1[NB][2];
+  load(fa0, fb0);
+  while (cc < cps) {
+    const int c0 = cc;
+    cc += nw;
+    load(fa1, fb1);
+    multiply(fa0, fb0, c0);
+    if (cc >= cps) break;
+    const int c1 = cc;
+    cc += nw;
+    load(fa0, fb0);
+    multiply(fa1, fb1, c1);
+  }
+  // sum the 4 waves through LDS: red [MB*16][W]
+  // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+  for (int rb = 0; rb < MB; ++rb) {
+    rsum[rb] += __shfl_xor(rsum[rb], 16, 64);
+    rsum[rb] += __shfl_xor(rsum[rb], 32, 64);
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int rb = 0; rb < MB; ++rb) {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int idx = (rb * 16 + 4 * g + r) * W + cb * 16 + i16;
+            if (w == 0) red[idx] = acc[rb][cb][r];
+            else red[idx] += acc[rb][cb][r];
+          }
+        if (w == 0 && lane < 16) red[(rb * 16 + lane) * W + NB * 16] = 0.f;
+      }
+    }
+    __syncthreads();
+    if (wave == w && G.with_ones && lane < 16) {  // row sums -> column J
+#pragma unroll
+      for (int rb = 0; rb < MB; ++rb) red[(rb * 16 + lane) * W + G.J] += rsum[rb];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < MB * 16 * W; i += kThreads) out[i] = red[i];
+}
+
+template <int MB, int NB>
+__global__ __launch_bounds__(kThreads) void planes_gemm_stream_kernel(GemmArgs G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stream_body<MB, NB>(G, blockIdx.x, gridDim.x,
+                      G.part + (size_t)blockIdx.x * MB * 16 * (NB * 16 + 1), lds);
+}
+
 template <int MB, int NB>
 __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -363,6 +526,57 @@ int launch(const GemmArgs &G, int num_wg, hipStream_t st) {
   return check_launch("planes_gemm");
 }
 
+// ---- the long-plane (stream) kernel: instantiated block shapes ------------
+// row blocks of 16: 1, 2 or 4; column blocks of 16: 1, 2, 4, 7, 8 or 12
+int stream_mb(int M) { const int b = (M + 15) / 16; return b <= 1 ? 1 : b <= 2 ? 2 : 4; }
+int stream_nb(int J) {
+  const int b = (J + 15) / 16;
+  return b <= 1 ? 1 : b <= 2 ? 2 : b <= 4 ? 4 : b <= 7 ? 7 : b <= 8 ? 8 : 12;
+}
+long long stream_partial_floats(int M, int J) {
+  return (long long)stream_mb(M) * 16 * (stream_nb(J) * 16 + 1);
+}
+
+template <int MB, int NB>
+int launch_stream(const GemmArgs &G, int num_wg, hipStream_t st) {
+  const size_t lds = (size_t)MB * 16 * (NB * 16 + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    if (hipFuncSetAttribute((const void *)planes_gemm_stream_kernel<MB, NB>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(planes_gemm_stream)");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((planes_gemm_stream_kernel<MB, NB>), dim3(num_wg),
+                     dim3(kThreads), lds, st, G);
+  return check_launch("planes_gemm_stream");
+}
+
+template <int MB>
+int launch_stream_nb(const GemmArgs &G, int NB, int num_wg, hipStream_t st) {
+  switch (NB) {
+    case 1: return launch_stream<MB, 1>(G, num_wg, st);
+    case 2: return launch_stream<MB, 2>(G, num_wg, st);
+    case 4: return launch_stream<MB, 4>(G, num_wg, st);
+    case 7: return launch_stream<MB, 7>(G, num_wg, st);
+    case 8: return launch_stream<MB, 8>(G, num_wg, st);
+    default:
+      if constexpr (MB <= 2) return launch_stream<MB, 12>(G, num_wg, st);
+      set_error("planes_gemm: J > 128 needs M <= 32");
+      return APG_ERR_ARG;
+  }
+}
+
+int launch_stream_shape(const GemmArgs &G, int num_wg, hipStream_t st) {
+  const int NB = stream_nb(G.J);
+  switch (stream_mb(G.M)) {
+    case 1: return launch_stream_nb<1>(G, NB, num_wg, st);
+    case 2: return launch_stream_nb<2>(G, NB, num_wg, st);
+    default: return launch_stream_nb<4>(G, NB, num_wg, st);
+  }
+}
+
 int launch_shape(const GemmArgs &G, int MB, int NB, int num_wg, hipStream_t st) {
   if (MB == 1) {
     switch (NB) {
@@ -413,6 +627,10 @@ int default_wgs(int MB, int NB) {
   return cu_count() * per_cu;
 }
 
+// one workgroup (4 waves, one per SIMD) per CU: a wave holds all accumulator
+// tiles and two sets of operand registers
+int stream_default_wgs(int, int) { return cu_count(); }
+
 const char *check_problem(const float *A, const float *Bp, const int *bdesc,
                           const float *C, int M, int S, int J, int Jt, int sdiv,
                           int b_planes, long long N, int ldc, bool own_bias) {
@@ -449,12 +667,25 @@ using namespace apg;
 
 extern "C" {
 
-int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg) {
+// which kernel runs a product: the register-streaming one for plain (S = 1)
+// products, the LDS-tile one for segmented products
+static bool use_stream(int S) { return APG_GEMM_STREAM && S == 1; }
+
+static long long partial_floats(int M, int S, int J, int with_ones) {
+  if (use_stream(S)) return stream_partial_floats(M, J);
   const int MB = (M + 31) / 32, NB = (J + (with_ones ? 1 : 0) + 31) / 32;
-  return num_wg * MB * 32 * NB * 32;
+  return (long long)MB * 32 * NB * 32;
 }
 
-int apg_planes_gemm_default_wgs(int M, int J, int with_ones) {
+int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg) {
+  // enough for either kernel (the segment count is not known here)
+  const long long a = partial_floats(M, 1, J, with_ones);
+  const long long b = partial_floats(M, 2, J, with_ones);
+  return (int)(num_wg * (a > b ? a : b));
+}
+
+int apg_planes_gemm_default_wgs(int M, int S, int J, int with_ones) {
+  if (use_stream(S)) return stream_default_wgs(M, J);
   return default_wgs((M + 31) / 32, (J + (with_ones ? 1 : 0) + 31) / 32);
 }
 
@@ -472,14 +703,20 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
     set_error("apg_planes_gemm: %s", why);
     return APG_ERR_ARG;
   }
-  const int MB = (M + 31) / 32, NB = (Jt + 31) / 32;
   GemmArgs G;
   fill_args(G, A, Bp, bdesc, workspace, M, S, J, sdiv, with_ones, b_planes, N);
   hipStream_t st = (hipStream_t)stream;
-  if (int e = launch_shape(G, MB, NB, num_wg, st)) return e;
   ReduceArgs R;
-  R.it[0] = ReduceItem{workspace, C, with_ones ? bias_out : nullptr, num_wg, NB * 32,
-                       MB * 32, M, Jt, J, ldc};
+  if (use_stream(S)) {
+    if (int e = launch_stream_shape(G, num_wg, st)) return e;
+    R.it[0] = ReduceItem{workspace, C, with_ones ? bias_out : nullptr, num_wg,
+                         stream_nb(J) * 16 + 1, stream_mb(M) * 16, M, Jt, J, ldc};
+  } else {
+    const int MB = (M + 31) / 32, NB = (Jt + 31) / 32;
+    if (int e = launch_shape(G, MB, NB, num_wg, st)) return e;
+    R.it[0] = ReduceItem{workspace, C, with_ones ? bias_out : nullptr, num_wg, NB * 32,
+                         MB * 32, M, Jt, J, ldc};
+  }
   hipLaunchKernelGGL(planes_gemm_reduce_kernel, dim3((M * Jt + 31) / 32, 1),
                      dim3(1024), 0, st, R);
   return check_launch("planes_gemm_reduce");
@@ -489,9 +726,9 @@ long long apg_planes_gemm_multi_workspace_floats(const ApgGemmProblem *problems,
                                                  int n) {
   long long total = 0;
   for (int p = 0; problems && p < n; ++p) {
-    const int Jt = problems[p].J + (problems[p].with_ones ? 1 : 0);
-    const int MB = (problems[p].M + 31) / 32, NB = (Jt + 31) / 32;
-    total += (long long)default_wgs(MB, NB) * MB * 32 * NB * 32;
+    const ApgGemmProblem &q = problems[p];
+    total += (long long)apg_planes_gemm_default_wgs(q.M, q.S, q.J, q.with_ones) *
+             partial_floats(q.M, q.S, q.J, q.with_ones);
   }
   return total;
 }
@@ -520,15 +757,22 @@ int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspac
   for (int p = 0; p < n; ++p) {
     const ApgGemmProblem &q = problems[p];
     const int Jt = q.J + (q.with_ones ? 1 : 0);
-    const int MB = (q.M + 31) / 32, NB = (Jt + 31) / 32;
-    const int wgs = default_wgs(MB, NB);
+    const int wgs = apg_planes_gemm_default_wgs(q.M, q.S, q.J, q.with_ones);
     GemmArgs G;
     fill_args(G, q.A, q.B, q.bdesc, part, q.M, q.S, q.J, q.sdiv, q.with_ones,
               q.b_planes, q.N);
-    if (int e = launch_shape(G, MB, NB, wgs, st)) return e;
-    R.it[p] = ReduceItem{part, q.C, q.with_ones ? q.bias_out : nullptr, wgs, NB * 32,
-                         MB * 32, q.M, Jt, q.J, q.ldc};
-    part += (size_t)wgs * MB * 32 * NB * 32;
+    int rows, W;
+    if (use_stream(q.S)) {
+      if (int e = launch_stream_shape(G, wgs, st)) return e;
+      rows = stream_mb(q.M) * 16, W = stream_nb(q.J) * 16 + 1;
+    } else {
+      const int MB = (q.M + 31) / 32, NB = (Jt + 31) / 32;
+      if (int e = launch_shape(G, MB, NB, wgs, st)) return e;
+      rows = MB * 32, W = NB * 32;
+    }
+    R.it[p] = ReduceItem{part, q.C, q.with_ones ? q.bias_out : nullptr, wgs, W, rows,
+                         q.M, Jt, q.J, q.ldc};
+    part += (size_t)wgs * rows * W;
     const int blocks = (q.M * Jt + 31) / 32;
     max_blocks = blocks > max_blocks ? blocks : max_blocks;
   }

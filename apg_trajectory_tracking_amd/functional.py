@@ -694,7 +694,7 @@ def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None,
     N = A.shape[1] if N is None else N
     J = bdesc.J
     Jt = J + int(with_ones)
-    wgs = _GEMM_WGS or lib().apg_planes_gemm_default_wgs(M, J, int(with_ones))
+    wgs = _GEMM_WGS or lib().apg_planes_gemm_default_wgs(M, S, J, int(with_ones))
     ws = torch.empty(lib().apg_planes_gemm_workspace_floats(
         M, J, int(with_ones), wgs), dtype=torch.float32, device=A.device)
     Jc = J if (bias_out is not None and with_ones) else Jt   # columns of C

@@ -392,10 +392,13 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
  * `b_planes` planes; A (M*S planes) and B must each stay below 4 GiB (unsigned
  * 32-bit buffer offsets): hand B over from the first plane the product uses
  * (bdesc relative to it) when the tensor behind it is larger.
- * apg_planes_gemm_default_wgs: the num_wg that fills every CU's LDS with this
- * shape's tile rings (what apg_planes_gemm_multi uses). */
+ * Two kernels behind it: plain products (S = 1) stream their operands global ->
+ * registers -> v_mfma_f32_16x16x4_f32 (split-K over all waves, no LDS tile);
+ * segmented products (S > 1, the conv windows) go through LDS tiles filled by
+ * direct-to-LDS DMA.  apg_planes_gemm_default_wgs: the num_wg measured best for
+ * the shape (what apg_planes_gemm_multi uses). */
 int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg);
-int apg_planes_gemm_default_wgs(int M, int J, int with_ones);
+int apg_planes_gemm_default_wgs(int M, int S, int J, int with_ones);
 int apg_planes_gemm(const float *A, int M, int S, const float *B,
                     const int *bdesc, int J, int sdiv, int with_ones,
                     int b_planes, long long N, float *workspace, int num_wg,
