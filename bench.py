@@ -600,6 +600,42 @@ def main():
             del wplans, more
         except Exception as e:     # informational only (e.g. out of memory)
             wide_ms = None
+    # informational: the same launches as TWO independent chains of one graph
+    # (even / odd buffer sets on two streams).  The batches are independent, so
+    # the next launch's waves can move into SIMDs the current launch's early
+    # finishers have left: the tail of one launch and the kernel boundary
+    # overlap the head of the next.  Never used for `value` or the roofline
+    # (those stay one launch after the other, as rocprof sees them).
+    overlap_ms = None
+    if not args.no_graph and nset >= 2:
+        try:
+            side2 = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side2):
+                oplans = [F.RolloutPlan("quad", *s, args.dt, dyn.params,
+                                        layout=args.layout,
+                                        want_grad_state0=args.grad_state0,
+                                        loss_mode="none") for s in sets[1::2]]
+            eplans = kplans[0::2]
+
+            def run_two_chains(n):
+                fork = torch.cuda.Event()
+                fork.record(side)
+                side2.wait_event(fork)
+                for i in range(n):
+                    (eplans if i % 2 == 0 else oplans)[(i // 2) % len(eplans)].launch()
+                join = torch.cuda.Event()
+                join.record(side2)
+                side.wait_event(join)
+
+            with torch.cuda.stream(side):
+                run_two_chains(4)
+            torch.cuda.synchronize()
+            g_two = graph_of(run_two_chains, args.steps)
+            _, o_ms = timed(run_two_chains, args.steps, g_two, replays)
+            overlap_ms = o_ms / nsteps
+            del g_two
+        except Exception:        # informational only
+            overlap_ms = None
     gc.enable()
 
     H, B = args.horizon, args.batch
@@ -653,6 +689,14 @@ def main():
         },
         "loss_check": loss_check,
     }
+    if overlap_ms is not None:
+        out["overlapped_launches"] = {
+            "streams": 2, "ms_per_step": overlap_ms,
+            "env_steps_per_s": world * B * H / (overlap_ms * 1e-3),
+            "algorithmic_GBps": algo_bytes / (overlap_ms * 1e-3) / 1e9,
+            "what": "informational: the K kernel-only launches as two independent "
+                    "chains of one graph (even / odd buffer sets); `value` and "
+                    "`roofline` are the serial launches"}
     if args.train_steps > 0:
         try:
             out["train_step"] = train_step_probe(args, dev, dyn, dist)
