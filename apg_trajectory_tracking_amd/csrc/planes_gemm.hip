@@ -8,13 +8,19 @@
 // a plane of N contiguous floats ("NT" layout: the reduction index is the
 // contiguous one).  rocBLAS picks a 16x16 macro-tile without split-K for this
 // shape and takes 1.5 ms per call; this kernel streams both operands from HBM
-// once and is bound by that stream.  The per-column two-level segment stride
-// lets the conv-weight gradient read the sliding reference windows straight
-// from the [2H][9][B] reference tensor (segment = (window position, step))
-// and the positions before each step from the state planes in the same pass,
-// instead of from a materialised [90][H*B] copy.
+// once and is bound by that stream.  Two kernels:
+//  * plain products (S = 1; six of the seven of an autoregressive step):
+//    planes_gemm_stream_kernel - global -> registers -> v_mfma_f32_16x16x4_f32,
+//    split-K over all waves, no LDS tile (described at stream_body below);
+//  * segmented products (S > 1) and the grouped launch for short planes:
+//    planes_gemm_kernel, the LDS-tile kernel described next.  Its per-column
+//    two-level segment stride lets the conv-weight gradient read the sliding
+//    reference windows straight from the [2H][9][B] reference tensor (segment
+//    = (window position, step)) and the positions before each step from the
+//    state planes in the same pass, instead of from a materialised
+//    [90][H*B] copy.
 //
-// Structure: the S*N reduction range is cut into tiles of 64 columns;
+// LDS-tile kernel: the S*N reduction range is cut into tiles of 64 columns;
 // workgroups take tiles grid-strided.  A tile ((MB + NB) * 32 operand rows x
 // 64 columns) goes global -> LDS by direct-to-LDS DMA, 16 bytes per lane: one
 // wave instruction moves a GROUP of 4 rows x 64 columns (1 KiB; 256 contiguous
@@ -62,11 +68,11 @@ constexpr int kKT = 64;        // reduction elements per tile
 constexpr int kGS = 4 * kKT + 4;  // floats per 4-row group in LDS (16 B pad)
 constexpr int kMaxNB = 6;      // column blocks of 32 (J + ones <= 192)
 constexpr int kThreads = 256;
-constexpr unsigned kDeadOff = 0xfffffff0u;  // beyond any operand (< 4 GiB - 16 each)
-constexpr long long kMaxOperandBytes = 0xfffffff0ll;
+constexpr unsigned kDeadOff = 0xfffffff0u;  // beyond any operand
+constexpr long long kMaxOperandBytes = 0xffffff00ll;  // < both kernels' dead offsets
 constexpr int kLdsBytes = 160 * 1024;
 
-// ring depth of a tile shape: 3 buffers where the LDS holds them
+// LDS footprint of a tile shape (ring depth: see APG_GEMM_ST_MAX)
 template <int MB, int NB>
 struct Shape {
   static constexpr int NG = (MB + NB) * 8;  // 4-row groups per tile
@@ -165,8 +171,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
       if (i < MB * 2) {
         off = rowoff[i] + colb + sa;
       } else {
-        const int ib = i < MB * 2 ? 0 : i - MB * 2;
-        off = rowoff[i] + colb + s1 * bs1[ib] + s2 * bs2[ib];
+        off = rowoff[i] + colb + s1 * bs1[i - MB * 2] + s2 * bs2[i - MB * 2];
       }
       off = (live && rowoff[i] != kDeadOff) ? off : kDeadOff;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(

@@ -254,6 +254,13 @@ def test_flat_gradient_layout_and_new_argument_errors():
     assert b"apg_to_soa" in lib.apg_last_error_string()
     assert lib.apg_planes_gemm(1, 65, 1, 1, 1, 8, 1, 1, 8, 64, 1, 16, 1, 9, None, None) == -1
     assert b"M <= 64" in lib.apg_last_error_string()
+    assert lib.apg_planes_gemm_multi(None, 0, None, None) == -1
+    assert b"apg_planes_gemm_multi" in lib.apg_last_error_string()
+    # shape -> workgroups / workspace helpers are pure host functions
+    assert lib.apg_planes_gemm_default_wgs(64, 1, 112, 0) > 0
+    assert lib.apg_planes_gemm_default_wgs(20, 80, 30, 1) > 0
+    one = lib.apg_planes_gemm_workspace_floats(64, 112, 1, 1)
+    assert one >= 64 * 113 and lib.apg_planes_gemm_workspace_floats(64, 112, 1, 3) == 3 * one
     assert lib.apg_planes_gemm_grouped(None, 0, None, 4, None) == -1
     assert lib.apg_quad_mlp_workspace_floats() > 0 and lib.apg_quad_lstm_workspace_floats() > 0
     assert lib.apg_quad_mlp_loss_partials_count(300) == 16
