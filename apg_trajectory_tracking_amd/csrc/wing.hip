@@ -71,9 +71,20 @@ struct WingRolloutArgs {
 // checkpoint into registers.  Costs (stride-1)/stride extra state_dot
 // evaluations, buys 3-5x the resident waves.
 constexpr int kWingMaxStride = 4;
+// Experiments (tools/exp): waves per SIMD the register allocator must leave
+// room for, and whether the reverse sweep requests a group's rows one group
+// ahead (28 more live registers).
+#ifdef APG_WING_WAVES
+#define APG_WING_OCCUPANCY __attribute__((amdgpu_waves_per_eu(APG_WING_WAVES, APG_WING_WAVES)))
+#else
+#define APG_WING_OCCUPANCY   /* 227 registers: two waves per SIMD */
+#endif
+#ifndef APG_WING_GROUP_PREFETCH
+#define APG_WING_GROUP_PREFETCH 1
+#endif
 
 template <int LAYOUT>
-__global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
+__global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rollout_lds_kernel(
     WingRolloutArgs A) {
   extern __shared__ float stash[];
   const int lane = threadIdx.x;
@@ -161,11 +172,17 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
       load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kq, 0, gr_[j]);
     }
   };
+#if APG_WING_GROUP_PREFETCH
   load_group(G - 1, act, rpg);
+#endif
   for (int g = G - 1; g >= 0; --g) {
     const int k0 = g * S;
     const int n = (H - k0) < S ? (H - k0) : S;
+#if APG_WING_GROUP_PREFETCH
     load_group(g > 0 ? g - 1 : 0, act_n, rpg_n);
+#else
+    load_group(g, act, rpg);
+#endif
     float pre[kWingMaxStride + 1][12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) pre[0][i] = ST(g, i);
@@ -205,6 +222,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) nxt[i] = pre[0][i];
+#if APG_WING_GROUP_PREFETCH
 #pragma unroll
     for (int j = 0; j < kWingMaxStride; ++j) {
 #pragma unroll
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) void wing_rollout_lds_kernel(
 #pragma unroll
       for (int i = 0; i < 3; ++i) rpg[j][i] = rpg_n[j][i];
     }
+#endif
   }
   if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
 #undef APG_LAUNDER

@@ -440,6 +440,13 @@ def wing_secondary(args, dev):
             "achieved_wave_instr_per_s": n_valu / sec,
             "peak_wave_instr_per_s": FP32_VALU_WAVE_INSTR_PER_S,
             "frac": n_valu / sec / FP32_VALU_WAVE_INSTR_PER_S,
+            # the peak above needs two waves of a SIMD issuing in each other's
+            # gaps, which the hardware only does for VALU ops whose operands
+            # are all VGPRs / literals: an op with an SGPR operand (every
+            # aerodynamic coefficient here) or a transcendental takes the SIMD
+            # alone (profiles/r02_issue_probe_coissue.jsonl) - one wave
+            # instruction per 4 cycles is the rate this instruction mix can get
+            "frac_of_single_issue_rate": n_valu / sec / (FP32_VALU_WAVE_INSTR_PER_S / 2),
             "kernel_build": build}
     else:
         out["fp32_valu_note"] = f"no PMC entry for wing kernel build {build}"

@@ -414,6 +414,14 @@ int main() {
     run<P_CNDMASK>(d_out, w, 0, 256, 128);
     run<P_CNDMASK64>(d_out, w, 0, 256, 128);
     run<P_DSR_MIX>(d_out, w, 0, 256, 128);
+    // which instruction classes of a second wave issue in the first wave's gaps
+    run<P_FMA_SGPR_IND4>(d_out, w, 0, 256, 128);
+    run<P_FMAAK_IND4>(d_out, w, 0, 256, 128);
+    run<P_FMAC_IND4>(d_out, w, 0, 256, 128);
+    run<P_MUL_DEP>(d_out, w, 0, 256, 128);
+    run<P_MOV_IND4>(d_out, w, 0, 256, 128);
+    run<P_SIN_MIX>(d_out, w, 0, 256, 128);
+    run<P_ACC_MIX>(d_out, w, 0, 256, 128);
   }
   run<P_FMA_DEP>(d_out, 1, 1, 256);
   run<P_FMA_IND4>(d_out, 1, 1, 256);
