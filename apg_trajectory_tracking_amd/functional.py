@@ -711,6 +711,10 @@ def planes_gemm(A, M, S, Bp, bdesc, with_ones=True, sdiv=1, N=None, out=None,
 
 
 _GROUP_WGS = 256
+# the grouped launch pair wins while launch latency dominates; from ~8 k columns
+# per product on, one register-streaming launch per product is faster (B =
+# 65 536: 0.42 -> 0.36 ms per concurrent training step)
+_GROUPED_MAX_COLUMNS = 8 * 8192
 
 
 def _gemm_problems(problems):
@@ -759,17 +763,16 @@ def planes_gemm_multi(problems):
 
 
 def _run_products(problems):
-    """A training step's weight-gradient products.  Short planes (one column
-    per trajectory, the concurrent mode): launch latency dominates, so all
-    products share one launch pair.  Long planes (H columns per trajectory):
-    each product gets its own launch with the tile shape and occupancy that
-    fit it - a shared launch would run the small ones at one workgroup per
-    CU - and they share the second-stage launch."""
+    """A training step's weight-gradient products.  Few columns (small
+    batches in the concurrent mode, one column per trajectory): launch latency
+    dominates, so all products share one launch pair.  Otherwise each product
+    gets its own launch with the kernel, tile shape and occupancy that fit it,
+    and they share the second-stage launch."""
     n_max = max(d.get("N") or d["A"].shape[1] for d in problems)
     total = sum((d.get("N") or d["A"].shape[1]) * d["S"] for d in problems)
     fits = all(d["bdesc"].J + int(d.get("with_ones", True)) <= 128
                for d in problems) and len(problems) <= 8
-    if fits and total <= 8 * 131072 and n_max <= 131072:
+    if fits and total <= _GROUPED_MAX_COLUMNS and n_max <= 131072:
         return planes_gemm_grouped(problems)
     for lo in range(0, len(problems), 8):
         planes_gemm_multi(problems[lo:lo + 8])
