@@ -419,6 +419,42 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_stream_kernel(GemmArgs G
                       G.part + (size_t)blockIdx.x * MB * 16 * (NB * 16 + 1), lds);
 }
 
+// All plain products of a training step in ONE launch: every workgroup belongs
+// to one product (range [wg0[p], wg0[p+1]), sized by the bytes the product
+// streams) and runs that product's block shape.  For short planes (one column
+// per trajectory) seven separate launches are mostly launch ramp and tail.
+constexpr int kMaxGroup = 8;
+struct StreamGroupArgs {
+  GemmArgs g[kMaxGroup];   // .part = the product's own partial region
+  int wg0[kMaxGroup + 1];
+  int shape[kMaxGroup];    // MB * 16 + NB (blocks of 16)
+  int n;
+};
+
+__global__ __launch_bounds__(kThreads) void planes_gemm_stream_grouped_kernel(
+    StreamGroupArgs GA) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int p = 0;
+  while (p + 1 < GA.n && (int)blockIdx.x >= GA.wg0[p + 1]) ++p;
+  const GemmArgs &G = GA.g[p];
+  const int bid = blockIdx.x - GA.wg0[p], nb = GA.wg0[p + 1] - GA.wg0[p];
+#define APG_STREAM_CASE(MB, NB)                                                  \
+  case MB * 16 + NB:                                                             \
+    stream_body<MB, NB>(G, bid, nb,                                              \
+                        G.part + (size_t)bid * MB * 16 * (NB * 16 + 1), lds);    \
+    break;
+  switch (GA.shape[p]) {
+    APG_STREAM_CASE(1, 1) APG_STREAM_CASE(1, 2) APG_STREAM_CASE(1, 4)
+    APG_STREAM_CASE(1, 7) APG_STREAM_CASE(1, 8) APG_STREAM_CASE(1, 12)
+    APG_STREAM_CASE(2, 1) APG_STREAM_CASE(2, 2) APG_STREAM_CASE(2, 4)
+    APG_STREAM_CASE(2, 7) APG_STREAM_CASE(2, 8) APG_STREAM_CASE(2, 12)
+    APG_STREAM_CASE(4, 1) APG_STREAM_CASE(4, 2) APG_STREAM_CASE(4, 4)
+    APG_STREAM_CASE(4, 7) APG_STREAM_CASE(4, 8)
+    default: break;
+  }
+#undef APG_STREAM_CASE
+}
+
 template <int MB, int NB>
 __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -430,7 +466,6 @@ __global__ __launch_bounds__(kThreads) void planes_gemm_kernel(GemmArgs G) {
 // every workgroup belongs to one problem (range [wg0[p], wg0[p+1])), all
 // problems use the 64 x 128 accumulator shape.  A second launch reduces every
 // problem's partials.
-constexpr int kMaxGroup = 8;
 struct GroupArgs {
   GemmArgs g[kMaxGroup];
   int wg0[kMaxGroup + 1];
@@ -727,14 +762,52 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
   return check_launch("planes_gemm_reduce");
 }
 
+// Workgroups of every product of an apg_planes_gemm_multi call.  Short planes
+// (<= kGroupMaxN columns: one column per trajectory, the concurrent mode): the
+// plain (S = 1) products share ONE launch of cu_count() workgroups, divided in
+// proportion to the planes they stream (at least one each) - seven separate
+// launches would be mostly ramp and tail (fixed-wing step 0.53 -> 0.46 ms).
+// Long planes: every product its own launch (sharing one made the LSTM step
+// slower, 0.82 -> 0.93 ms).  A segmented product always gets its own launch.
+constexpr long long kGroupMaxN = 262144;
+static bool multi_grouped(const ApgGemmProblem *problems, int n) {
+  int plain = 0;
+  for (int p = 0; p < n; ++p)
+    if (use_stream(problems[p].S)) {
+      if (problems[p].N > kGroupMaxN) return false;
+      ++plain;
+    }
+  return plain > 1;
+}
+
+static void multi_wgs(const ApgGemmProblem *problems, int n, int *wgs) {
+  const bool grouped = multi_grouped(problems, n);
+  double total = 0;
+  int plain = 0;
+  for (int p = 0; p < n; ++p)
+    if (use_stream(problems[p].S)) {
+      total += (double)(problems[p].M + problems[p].J) * (double)problems[p].N;
+      ++plain;
+    }
+  const int pool = cu_count() > plain ? cu_count() - plain : 0;
+  for (int p = 0; p < n; ++p) {
+    const ApgGemmProblem &q = problems[p];
+    if (grouped && use_stream(q.S))
+      wgs[p] = 1 + (int)(pool * ((double)(q.M + q.J) * (double)q.N / total));
+    else
+      wgs[p] = apg_planes_gemm_default_wgs(q.M, q.S, q.J, q.with_ones);
+  }
+}
+
 long long apg_planes_gemm_multi_workspace_floats(const ApgGemmProblem *problems,
                                                  int n) {
+  if (!problems || n < 1 || n > kMaxGroup) return 0;
+  int wgs[kMaxGroup];
+  multi_wgs(problems, n, wgs);
   long long total = 0;
-  for (int p = 0; problems && p < n; ++p) {
-    const ApgGemmProblem &q = problems[p];
-    total += (long long)apg_planes_gemm_default_wgs(q.M, q.S, q.J, q.with_ones) *
-             partial_floats(q.M, q.S, q.J, q.with_ones);
-  }
+  for (int p = 0; p < n; ++p)
+    total += (long long)wgs[p] * partial_floats(problems[p].M, problems[p].S,
+                                                problems[p].J, problems[p].with_ones);
   return total;
 }
 
@@ -756,30 +829,58 @@ int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspac
     }
   }
   hipStream_t st = (hipStream_t)stream;
+  int wgs[kMaxGroup];
+  multi_wgs(problems, n, wgs);
+  const bool grouped = multi_grouped(problems, n);
   ReduceArgs R;
+  StreamGroupArgs SG;
+  SG.n = 0;
+  SG.wg0[0] = 0;
+  size_t group_lds = 0;
   float *part = workspace;
   int max_blocks = 1;
   for (int p = 0; p < n; ++p) {
     const ApgGemmProblem &q = problems[p];
     const int Jt = q.J + (q.with_ones ? 1 : 0);
-    const int wgs = apg_planes_gemm_default_wgs(q.M, q.S, q.J, q.with_ones);
     GemmArgs G;
     fill_args(G, q.A, q.B, q.bdesc, part, q.M, q.S, q.J, q.sdiv, q.with_ones,
               q.b_planes, q.N);
     int rows, W;
-    if (use_stream(q.S)) {
-      if (int e = launch_stream_shape(G, wgs, st)) return e;
+    if (use_stream(q.S) && !grouped) {
+      if (int e = launch_stream_shape(G, wgs[p], st)) return e;
       rows = stream_mb(q.M) * 16, W = stream_nb(q.J) * 16 + 1;
+    } else if (use_stream(q.S)) {
+      const int mb = stream_mb(q.M), nb = stream_nb(q.J);
+      rows = mb * 16, W = nb * 16 + 1;
+      SG.g[SG.n] = G;
+      SG.shape[SG.n] = mb * 16 + nb;
+      SG.wg0[SG.n + 1] = SG.wg0[SG.n] + wgs[p];
+      ++SG.n;
+      const size_t lds = (size_t)rows * W * sizeof(float);
+      group_lds = lds > group_lds ? lds : group_lds;
     } else {
       const int MB = (q.M + 31) / 32, NB = (Jt + 31) / 32;
-      if (int e = launch_shape(G, MB, NB, wgs, st)) return e;
+      if (int e = launch_shape(G, MB, NB, wgs[p], st)) return e;
       rows = MB * 32, W = NB * 32;
     }
-    R.it[p] = ReduceItem{part, q.C, q.with_ones ? q.bias_out : nullptr, wgs, W, rows,
-                         q.M, Jt, q.J, q.ldc};
-    part += (size_t)wgs * rows * W;
+    R.it[p] = ReduceItem{part, q.C, q.with_ones ? q.bias_out : nullptr, wgs[p], W,
+                         rows, q.M, Jt, q.J, q.ldc};
+    part += (size_t)wgs[p] * rows * W;
     const int blocks = (q.M * Jt + 31) / 32;
     max_blocks = blocks > max_blocks ? blocks : max_blocks;
+  }
+  if (SG.n > 0) {
+    static bool attr_set = false;
+    if (!attr_set) {  // room for the largest partial any shape can have
+      if (hipFuncSetAttribute((const void *)planes_gemm_stream_grouped_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              64 * 1024) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(planes_gemm_stream_grouped)");
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(planes_gemm_stream_grouped_kernel, dim3(SG.wg0[SG.n]),
+                       dim3(kThreads), group_lds, st, SG);
+    if (int e = check_launch("planes_gemm_stream_grouped")) return e;
   }
   hipLaunchKernelGGL(planes_gemm_reduce_kernel, dim3(max_blocks, n), dim3(1024), 0, st,
                      R);
