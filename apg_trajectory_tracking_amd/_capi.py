@@ -95,6 +95,11 @@ class ApgGemmProblem(ctypes.Structure):
                 ("b_planes", ctypes.c_int), ("ldc", ctypes.c_int)]
 
 
+class ApgSoaItem(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("index", ctypes.c_void_p),
+                ("dst", ctypes.c_void_p), ("R", ctypes.c_int), ("ld", ctypes.c_int)]
+
+
 class ApgCartpoleParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in (
         "masscart", "masspole", "length", "max_force_mag", "friction",
@@ -159,6 +164,7 @@ SIGNATURES = {
         _P, _P, _P],
     "apg_planes_gemm_grouped": [ctypes.POINTER(ApgGemmProblem), _I, _P, _I, _P],
     "apg_to_soa": [_P, _P, _I, _I, _I, _P, _P],
+    "apg_to_soa_multi": [ctypes.POINTER(ApgSoaItem), _I, _I, _P],
     "apg_wing_policy_workspace_floats": [],
     "apg_wing_policy_fwd": [_P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P, _P, _P,
                             _P, _P],

@@ -47,49 +47,85 @@ int launch_reduce_partials(const float *partials, int n, float *loss,
   return check_launch("reduce_partials");
 }
 
-// [B][R] row-major (the reference's batch-major tensors) -> [R][B] planes:
-// 64 x 64 tiles through LDS, both sides coalesced.
-// With `index` the rows are gathered: dst[r][b] = src[index[b]][r] - the
-// minibatch selection of the training loop folded into the layout change.
-__global__ __launch_bounds__(256) void to_soa_kernel(const float *__restrict__ src,
-                                                     const long long *__restrict__ index,
-                                                     int B, int R, int ld,
-                                                     float *__restrict__ dst) {
-  __shared__ float tile[64][65];
-  const int b0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-  for (int i = y; i < 64; i += 4) {  // row b0 + i, columns r0 + x
-    const int b = b0 + i, r = r0 + x;
-    if (b < B && r < R) {
-      const size_t row = index ? (size_t)index[b] : (size_t)b;
-      tile[i][x] = src[row * ld + r];
-    }
+// [B][R] row-major (the reference's batch-major tensors) -> [R][B] planes, for
+// up to APG_SOA_MAX_ITEMS tensors of the same batch in ONE launch (blockIdx.y =
+// tensor).  A block owns 64 trajectories and up to 128 columns (blockIdx.z =
+// column chunk): the row segments are read with consecutive lanes on
+// consecutive floats whatever R is (a whole [64][R] block is one contiguous
+// stretch when ld == R, no index and R <= 128), staged in LDS and written out
+// plane by plane, 64 lanes per plane segment - both sides coalesced, also for
+// the narrow tensors (12, 15 columns) a 64 x 64 tiling would waste 3/4 of its
+// lanes on.  With `index` the rows are gathered: dst[r][b] = src[index[b]][r] -
+// the minibatch selection of the training loop folded into the layout change.
+constexpr int kSoaChunk = 128;
+struct SoaArgs {
+  ApgSoaItem it[APG_SOA_MAX_ITEMS];
+  int B;
+};
+
+__global__ __launch_bounds__(256) void to_soa_kernel(SoaArgs A) {
+  __shared__ float tile[64 * (kSoaChunk + 1)];
+  const ApgSoaItem &q = A.it[blockIdx.y];
+  const int c0 = blockIdx.z * kSoaChunk;
+  if (c0 >= q.R) return;
+  const int RC = q.R - c0 < kSoaChunk ? q.R - c0 : kSoaChunk, P = RC + 1;
+  const int B = A.B, b0 = blockIdx.x * 64;
+  const int nb = B - b0 < 64 ? B - b0 : 64;
+  const float *__restrict__ src = q.src + c0;
+  float *__restrict__ dst = q.dst + (size_t)c0 * B;
+  // element e of the block: trajectory e / RC, column e % RC
+  for (int e = threadIdx.x; e < nb * RC; e += 256) {
+    const int i = e / RC, r = e - i * RC;
+    const size_t row = q.index ? (size_t)q.index[b0 + i] : (size_t)(b0 + i);
+    tile[i * P + r] = src[row * q.ld + r];
   }
   __syncthreads();
-  for (int i = y; i < 64; i += 4) {  // plane r0 + i, trajectories b0 + x
-    const int r = r0 + i, b = b0 + x;
-    if (r < R && b < B) dst[(size_t)r * B + b] = tile[x][i];
-  }
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  if (x < nb)
+    for (int r = y; r < RC; r += 4) dst[(size_t)r * B + b0 + x] = tile[x * P + r];
 }
 
 }  // namespace apg
 
 extern "C" {
 
-int apg_to_soa(const float *src, const long long *index, int B, int R, int ld,
-               float *dst, apg_stream_t stream) {
-  if (B < 0 || R < 1 || ld < R) {
-    apg::set_error("apg_to_soa: need B >= 0, R >= 1, ld >= R");
+int apg_to_soa_multi(const ApgSoaItem *items, int n, int B, apg_stream_t stream) {
+  if (!items || n < 1 || n > APG_SOA_MAX_ITEMS || B < 0) {
+    apg::set_error("apg_to_soa_multi: need 1 <= n <= %d items, B >= 0",
+                   APG_SOA_MAX_ITEMS);
     return APG_ERR_ARG;
+  }
+  apg::SoaArgs A;
+  A.B = B;
+  int max_r = 0;
+  for (int i = 0; i < n; ++i) {
+    const ApgSoaItem &q = items[i];
+    if (q.R < 1 || q.ld < q.R) {
+      apg::set_error("apg_to_soa: need B >= 0, R >= 1, ld >= R (item %d)", i);
+      return APG_ERR_ARG;
+    }
+    if (B > 0 && (!q.src || !q.dst)) {
+      apg::set_error("apg_to_soa: NULL pointer (item %d)", i);
+      return APG_ERR_ARG;
+    }
+    A.it[i] = q;
+    max_r = q.R > max_r ? q.R : max_r;
   }
   if (B == 0) return APG_OK;
-  if (!src || !dst) {
-    apg::set_error("apg_to_soa: NULL pointer");
+  const int chunks = (max_r + apg::kSoaChunk - 1) / apg::kSoaChunk;
+  if (chunks > 65535) {
+    apg::set_error("apg_to_soa: R too large");
     return APG_ERR_ARG;
   }
-  hipLaunchKernelGGL(apg::to_soa_kernel, dim3((B + 63) / 64, (R + 63) / 64),
-                     dim3(256), 0, (hipStream_t)stream, src, index, B, R, ld, dst);
+  hipLaunchKernelGGL(apg::to_soa_kernel, dim3((B + 63) / 64, n, chunks), dim3(256), 0,
+                     (hipStream_t)stream, A);
   return apg::check_launch("to_soa");
+}
+
+int apg_to_soa(const float *src, const long long *index, int B, int R, int ld,
+               float *dst, apg_stream_t stream) {
+  const ApgSoaItem item = {src, index, dst, R, ld};
+  return apg_to_soa_multi(&item, 1, B, stream);
 }
 
 int apg_reduce_loss_partials(const float *partials, int n, float *loss,

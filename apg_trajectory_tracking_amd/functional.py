@@ -790,12 +790,8 @@ def _flat_grads(dev, shapes):
     return flat, views
 
 
-def to_soa(t, out=None, index=None):
-    """[B, ...] fp32 -> [..., B] planes (apg_to_soa: tiled transpose, both sides
-    coalesced).  A leading slice of longer rows (e.g. ref[:, :H]) is read in
-    place through its row stride.  `index` (int64 device tensor [B]): gather
-    rows t[index] in the same pass (t is then the whole data set).
-    `out`: optional contiguous destination."""
+def _soa_source(t, out, index):
+    """(tensor kept alive, R, ld, B, out) of one to_soa conversion."""
     inner = torch.Size(t.shape[1:])
     R = int(inner.numel())
     # no .contiguous() up front: a leading slice of longer rows (the whole
@@ -818,23 +814,55 @@ def to_soa(t, out=None, index=None):
     if not (t.is_cuda and out.is_cuda and out.is_contiguous()):
         raise ValueError("to_soa: device tensors, contiguous destination "
                          "(there is no CPU fallback)")
+    return t, R, ld, B, out
+
+
+def to_soa(t, out=None, index=None):
+    """[B, ...] fp32 -> [..., B] planes (apg_to_soa: both sides coalesced).  A
+    leading slice of longer rows (e.g. ref[:, :H]) is read in place through its
+    row stride.  `index` (int64 device tensor [B]): gather rows t[index] in the
+    same pass (t is then the whole data set).  `out`: optional contiguous
+    destination."""
+    t, R, ld, B, out = _soa_source(t, out, index)
     check(lib().apg_to_soa(ptr(t), None if index is None else index.data_ptr(), B, R,
                            ld, ptr(out), stream_of(t)), "apg_to_soa")
     return out
 
 
-def _ref_and_states(in_ref, state0, B, H, index=None):
+def to_soa_multi(items, index=None):
+    """Several to_soa conversions of the same batch in ONE launch
+    (apg_to_soa_multi): `items` = [(tensor, out-or-None), ...]; returns the
+    list of outputs."""
+    prepared = [_soa_source(t, out, index) for t, out in items]
+    B = prepared[0][3]
+    if any(p[3] != B for p in prepared):
+        raise ValueError("to_soa_multi: all tensors must have the same batch")
+    outs = [p[4] for p in prepared]
+    for lo in range(0, len(prepared), 6):        # APG_SOA_MAX_ITEMS
+        part = prepared[lo:lo + 6]
+        arr = (_capi.ApgSoaItem * len(part))()
+        for q, (t, R, ld, _, out) in zip(arr, part):
+            q.src, q.dst, q.R, q.ld = ptr(t), ptr(out), R, ld
+            q.index = None if index is None else index.data_ptr()
+        check(lib().apg_to_soa_multi(arr, len(part), B, stream_of(part[0][0])),
+              "apg_to_soa_multi")
+    return outs
+
+
+def _ref_and_states(in_ref, state0, B, H, index=None, also=()):
     """One buffer for everything the conv-weight product reads as B operand:
     planes [0, 2H*9) = the reference tensor [2H][9][B], planes [2H*9, +(H+1)*12)
     = [state0; states of the rollout] ([H+1][12][B], the kernels write the H
-    new states in place).  Returns (buffer, in_ref view, state0 view, states view)."""
+    new states in place).  `also`: further [B, ...] tensors of the same
+    (indexed) batch converted by the same launch.  Returns (buffer, in_ref
+    view, state0 view, states view, *planes of `also`)."""
     buf = torch.empty(2 * H * 9 + (H + 1) * 12, B, dtype=torch.float32,
                       device=state0.device)
     inr = buf[:2 * H * 9].view(2 * H, 9, B)
-    to_soa(in_ref[:, :2 * H], out=inr, index=index)
     st_all = buf[2 * H * 9:].view(H + 1, 12, B)
-    to_soa(state0, out=st_all[0], index=index)
-    return buf, inr, st_all[0], st_all[1:]
+    outs = to_soa_multi([(in_ref[:, :2 * H], inr), (state0, st_all[0])] +
+                        [(t, None) for t in also], index=index)
+    return (buf, inr, st_all[0], st_all[1:], *outs[2:])
 
 
 def _conv_weight_problem(d_conv, refbuf, B, H, b_out):
@@ -880,10 +908,9 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         if w_ih.shape != (32, 175) or conv_w.shape != (20, 9, 3):
             raise ValueError("fused path needs LSTM_NEW(15, 10, 9, 4, conv=1)")
         dev = state0.device
-        refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H,
-                                                  index)
-        rf = to_soa(ref[:, :H], index=index)
-        h0s, c0s = to_soa(h0), to_soa(c0)
+        refbuf, inr, s0, states, rf = _ref_and_states(
+            _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
+        h0s, c0s = to_soa_multi([(h0, None), (c0, None)])
         pw = dict(
             conv_w=_f32c(conv_w), conv_b=_f32c(conv_b), w_ih=_f32c(w_ih),
             w_hh=_f32c(w_hh), b_ih=_f32c(b_ih), b_hh=_f32c(b_hh),
@@ -1001,9 +1028,8 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
             raise ValueError("batch too large for one fused launch "
                              "(B <= 400 000); split it")
         dev = state0.device
-        refbuf, inr, s0, states = _ref_and_states(_f32c(in_ref), _f32c(state0), B, H,
-                                                  index)
-        rf = to_soa(ref[:, :H], index=index)
+        refbuf, inr, s0, states, rf = _ref_and_states(
+            _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -1219,10 +1245,9 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         # feat (15) | x1 (224) | h1, h2, h3 (192) | in_ref rows (H*9)
         acts = new(431 + H * 9, B)
         feat, x1, h, inr = acts[:15], acts[15:239], acts[239:431], acts[431:]
-        to_soa(normed, out=feat, index=index)
-        to_soa(in_ref[:, :H], out=inr.view(H, 9, B), index=index)
-        s0 = to_soa(state0, index=index)
-        rf = to_soa(ref[:, :H], index=index)
+        _, _, s0, rf = to_soa_multi(
+            [(normed, feat), (in_ref[:, :H], inr.view(H, 9, B)), (state0, None),
+             (ref[:, :H], None)], index=index)
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -1407,8 +1432,9 @@ def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
         # h1 140.. | h2 204.. | h3 268..
         acts = new(332, B)
         feat, rin, x1, h = acts[:9], acts[9:12], acts[12:140], acts[140:]
-        to_soa(normed, out=feat, index=index)
-        to_soa(in_ref.reshape(-1, 3), out=rin, index=index)
+        _, _, s0_planes, ref_planes = to_soa_multi(
+            [(normed, feat), (in_ref.reshape(-1, 3), rin), (state0, None),
+             (ref, None)], index=index)
         require_device(acts, *pw.values())
         pol = _capi.ApgWingPolicy(**{k: ptr(v) for k, v in pw.items()})
         actions = new(H, 4, B)
@@ -1417,9 +1443,8 @@ def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
         check(lib().apg_wing_policy_fwd(ptr(feat), ptr(rin), ctypes.byref(pol), B,
                                         ptr(actions), ptr(x1), ptr(h), ptr(ws), st),
               "apg_wing_policy_fwd")
-        res = wing_rollout_fwd_bwd(to_soa(state0, index=index), actions,
-                                   to_soa(ref, index=index), dt, params, weights,
-                                   layout="soa", want_grad_state0=False)
+        res = wing_rollout_fwd_bwd(s0_planes, actions, ref_planes, dt, params,
+                                   weights, layout="soa", want_grad_state0=False)
         cot = new(80 + 320, B)
         d_zout, d_pre = cot[:80], cot[80:]
         check(lib().apg_wing_policy_bwd(

@@ -562,6 +562,17 @@ int apg_reduce_loss_partials(const float *partials, int n, float *loss,
  * training loop (scripts/train_base.py:132-137, 191-194) in the same pass. */
 int apg_to_soa(const float *src, const long long *index, int B, int R, int ld,
                float *dst, apg_stream_t stream);
+/* The same for up to APG_SOA_MAX_ITEMS tensors of one batch in ONE launch (a
+ * training step converts 3-5 of them: features, reference windows, state,
+ * reference, hidden state). */
+#define APG_SOA_MAX_ITEMS 6
+typedef struct ApgSoaItem {
+  const float *src;
+  const long long *index;   /* device int64 [B] or NULL */
+  float *dst;
+  int R, ld;
+} ApgSoaItem;
+int apg_to_soa_multi(const ApgSoaItem *items, int n, int B, apg_stream_t stream);
 /* Number of floats `loss_partials` must hold for a batch of B. */
 int apg_loss_partials_count(int B);
 /* APG_VERSION_MAJOR * 1000 + APG_VERSION_MINOR. */

@@ -934,3 +934,22 @@ def test_to_soa_matches_permute(dev):
     out = torch.zeros(4, 9, 130, device=dev)
     F.to_soa(t[:, 3:7], out=out)           # not a leading slice: copied first
     assert torch.equal(out, t[:, 3:7].permute(1, 2, 0).contiguous())
+    # wide rows (several 128-column chunks), gathered rows, and several tensors
+    # of one batch in ONE launch (apg_to_soa_multi)
+    wide = torch.randn(200, 261, 9, generator=g).to(dev)
+    assert torch.equal(F.to_soa(wide), wide.permute(1, 2, 0).contiguous())
+    idx = torch.randperm(4097, generator=g)[:1000].to(dev)
+    a = torch.randn(4097, 15, generator=g).to(dev)
+    b = torch.randn(4097, 20, 9, generator=g).to(dev)
+    c = torch.randn(4097, 12, generator=g).to(dev)
+    pre = torch.zeros(10, 9, 1000, device=dev)
+    oa, ob, oc = F.to_soa_multi([(a, None), (b[:, :10], pre), (c, None)], index=idx)
+    assert ob.data_ptr() == pre.data_ptr()
+    assert torch.equal(oa, a[idx].t().contiguous())
+    assert torch.equal(ob, b[idx][:, :10].permute(1, 2, 0).contiguous())
+    assert torch.equal(oc, c[idx].t().contiguous())
+    many = [(torch.randn(70, 3 + i, generator=g).to(dev), None) for i in range(8)]
+    for (t_, _), o in zip(many, F.to_soa_multi(many)):     # more than one launch
+        assert torch.equal(o, t_.t().contiguous())
+    with pytest.raises(ValueError):
+        F.to_soa_multi([(a, None), (c[:100], None)])
