@@ -8,7 +8,7 @@ batch index (:163)."""
 import torch
 
 from . import functional as F
-from .dataset import SyntheticCartpoleDataset, TensorBatches
+from .dataset import SyntheticCartpoleDataset
 from .models.simple_model import Net
 from .train_base import TrainBase
 

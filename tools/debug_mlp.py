@@ -3,11 +3,8 @@ a plain torch evaluation of the same network: prints the relative error of
 every saved plane, so a layout bug is localised in one GPU run."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import ctypes
-import numpy as np
 import torch
-from apg_trajectory_tracking_amd import _capi, functional as F, synthetic
-from apg_trajectory_tracking_amd._capi import lib, check, ptr, stream_of
+from apg_trajectory_tracking_amd import functional as F, synthetic
 from apg_trajectory_tracking_amd.dataset import state_preprocessing
 from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import FlightmareDynamics
 from apg_trajectory_tracking_amd.models.hutter_model import Net
