@@ -951,8 +951,7 @@ __device__ __forceinline__ void learnt_step_adjoint(float (&lam)[12], float (&ga
   for (int i = 0; i < 32; ++i) gx2[i] = 0.f;
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
-    constexpr int kZero = 0;
-    const int o = (j & 1) * 16 + kZero;
+    const int o = (j & 1) * 16;
     if (j & 1) APG_OPAQUE16(w1, gx2, 16);   // after ALL fmas of row j - 2
     else APG_OPAQUE16(w1, gx2, 0);
     const float g = z[j] > 0.f ? gh[j] : 0.f;
