@@ -149,17 +149,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
   // tile t = (segment s, column tile ct), t = ct * S + s: segment fastest, so
   // the workgroups running at the same time work on a few column tiles across
   // ALL segments and B rows shared by segments (the sliding windows of the
-  // conv product) are fetched from HBM once.  The DMA front and the multiply
-  // walk their own (s, ct) by the grid stride.
-  const int ds = nb % G.S, dc = nb / G.S;
-  auto advance = [&](int &s_, int &ct_) {
-    s_ += ds, ct_ += dc;
-    if (s_ >= G.S) s_ -= G.S, ++ct_;
+  // conv product) are fetched once.  "Once" per L2: workgroup b runs on XCD
+  // b % 8, so a segmented product gives XCD x the column tiles ct = 8 c + x -
+  // all segments of a column tile then share ONE XCD's L2 instead of pulling
+  // the windows into all eight (737 -> 5xx MB fetched for the conv product).
+  // The DMA front and the multiply walk their own (s, c) by the stride of the
+  // XCD's share of the grid.
+  const int X = (G.S > 1 && nb % 8 == 0) ? 8 : 1;
+  const int xcd = bid % X, lnb = nb / X;
+  const int ds = lnb % G.S, dc = lnb / G.S;
+  auto advance = [&](int &s_, int &c_) {
+    s_ += ds, c_ += dc;
+    if (s_ >= G.S) s_ -= G.S, ++c_;
   };
+  auto col_tile = [&](int c_) { return c_ * X + xcd; };
   // Every wave issues GI instructions per tile (rows that do not exist and
   // tiles past the end get an out-of-range offset: zeros, no traffic), so
   // "the oldest tile has landed" is a vmcnt immediate.
-  auto issue = [&](int s_, int ct_, int q) {  // DMA of one tile into buffer q
+  auto issue = [&](int s_, int c_, int q) {  // DMA of one tile into buffer q
+    const int ct_ = col_tile(c_);
     const bool live = ct_ < G.tiles_per_seg;
     const unsigned colb = (unsigned)ct_ * (kKT * 4);
     const unsigned sa = (unsigned)s_ * plane_bytes;
@@ -183,15 +191,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
   const int lr = lane & 31, kh = lane >> 5;
   const int lane_base =
       (lr >> 2) * kGS + ((lr & 3) << 6) + ((wave ^ (lr & 3)) << 4) + kh;
-  int s_m = bid % G.S, ct_m = bid / G.S;  // the tile being multiplied
-  int s_i = s_m, ct_i = ct_m;             // the DMA front
+  int s_m = (bid / X) % G.S, ct_m = (bid / X) / G.S;  // the tile being multiplied
+  int s_i = s_m, ct_i = ct_m;                         // the DMA front
 #pragma unroll
   for (int q = 0; q < ST - 1; ++q) {
     issue(s_i, ct_i, q);
     advance(s_i, ct_i);
   }
   int p = 0;
-  for (; ct_m < G.tiles_per_seg; advance(s_m, ct_m)) {
+  for (; col_tile(ct_m) < G.tiles_per_seg; advance(s_m, ct_m)) {
     // the oldest of the ST-1 tiles in flight has landed (this wave's part) ...
     if (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -200,7 +208,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
     // for ALL outstanding DMAs.  Nothing else needs the fence: the LDS reads
     // of the last multiply have been consumed by its MFMAs.
     __builtin_amdgcn_s_barrier();
-    const long long n0 = (long long)ct_m * kKT;
+    const long long n0 = (long long)col_tile(ct_m) * kKT;
     if (G.N - n0 < kKT) {  // ragged last tile of a segment: zero A beyond N
       const int rem = (int)(G.N - n0);
       for (int e = tid; e < MB * 32 * kKT; e += kThreads)
