@@ -887,6 +887,39 @@ def _conv_weight_problem(d_conv, refbuf, B, H, b_out):
     return prob, finish
 
 
+_CONV_DIAG_PLANES = 720      # 20 ch x 2 half-waves x 13 diagonals + 20 ch x H
+
+
+def _conv_diag_problems(cv, refbuf, B, H, b_out):
+    """The conv-weight gradient of the recurrent unrolls from the DIAGONAL sums
+    the reverse sweep leaves (csrc/lstm.hip kConvP): cv [720][B] =
+    G[ch][hi][tau] (tau = k + pos - 4 hi; the window of (step, position, tap) is
+    reference row k + pos + tap) followed by P[ch][k] = sum_pos d[ch][pos][k].
+      dW[ch][c][t] = sum G[ch][hi][tau] . ref[4 hi + tau + t][c]
+                     - (c < 3) sum_k P[ch][k] . pos_k[c]
+    as two segmented planes_gemm problems reading the reference windows and the
+    position planes of `refbuf` in place.  Returns (problems, finish)."""
+    assert H == 10
+    dev = cv.device
+    offs = [t * 9 + c for c in range(9) for t in range(3)]
+    g_desc = make_bdesc(dev, offs, 36, 9, key=("conv_diag", H))
+    p_desc = make_bdesc(dev, [2 * H * 9 + q for q in range(3)], 12, 0,
+                        key=("conv_pos", H))
+    cg = torch.empty(20, 27, dtype=torch.float32, device=dev)
+    cp = torch.empty(20, 3, dtype=torch.float32, device=dev)
+    probs = [
+        dict(A=cv[:520], M=20, S=26, Bp=refbuf, bdesc=g_desc, sdiv=13, N=B, out=cg,
+             with_ones=False),
+        dict(A=cv[520:], M=20, S=H, Bp=refbuf, bdesc=p_desc, sdiv=1, N=B, out=cp,
+             bias_out=b_out)]
+
+    def finish(w_out):
+        w = w_out.view(20, 27)
+        w.copy_(cg)
+        w[:, :9].view(20, 3, 3).sub_(cp[:, :, None])
+    return probs, finish
+
+
 class _QuadLstmRolloutLoss(torch.autograd.Function):
     """loss of the LSTM-mode unroll with the policy inside the kernel.
 
@@ -936,7 +969,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             relu_mask.data_ptr(), ptr(ws), st), "apg_quad_lstm_rollout_fwd")
         partials = new(max(1, lib().apg_quad_lstm_loss_partials_count(B)))
         loss = new(1)
-        d_gates, d_zout, d_conv = new(32, N), new(4, N), new(160, N)
+        d_gates, d_zout, d_conv = new(32, N), new(4, N), new(_CONV_DIAG_PLANES, B)
         # optional input gradients (state0, h0, c0)
         g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
         g_h0 = new(8, B) if ctx.needs_input_grad[3] else None
@@ -979,13 +1012,12 @@ def _lstm_param_grads(saved, dims):
     ih_hh = torch.empty(32, 183, dtype=torch.float32, device=dev)
     # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T, db = row sums;
     # dW_out = d_zout . h_new^T; conv
-    conv, finish = _conv_weight_problem(d_conv, refbuf, B, H, gr["conv_ref.bias"])
+    conv, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.bias"])
     _run_products([
         dict(A=d_gates, M=32, S=1, Bp=acts, bdesc=make_bdesc(dev, range(183), key="ih_hh"),
              out=ih_hh, bias_out=gr["lstm.bias_ih"]),
         dict(A=d_zout, M=4, S=1, Bp=acts, bdesc=make_bdesc(dev, range(191, 199), key="out"),
-             out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"]),
-        conv])
+             out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])] + conv)
     finish(gr["conv_ref.weight"])
     # contiguous per-parameter gradients (the fused optimizer path wants them)
     gr["lstm.weight_ih"].copy_(ih_hh[:, :175])

@@ -232,11 +232,20 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
  * (loss_partials: apg_quad_lstm_loss_partials_count(B) floats) and the
  * cotangent planes from which the host forms the weight gradients:
  *   d_gates [32][N] (gate pre-activations), d_zout [4][N] (head
- *   pre-activations), d_conv [160][N] (conv pre-activations, ch-major);
+ *   pre-activations), d_conv [720][B]: the conv pre-activation cotangents
+ *   d[ch][pos][k] summed along the window diagonals - the window of (step k,
+ *   position pos, tap t) is reference row k + pos + t, so 17 diagonal sums per
+ *   channel carry what 80 (pos, k) planes would:
+ *     planes [0, 520):   G[ch][hi][tau] = sum_{k + pos - 4 hi = tau} d[ch][pos][k]
+ *                        (hi = pos / 4: the half-wave that holds the position;
+ *                        tau in [0, 13)), plane = ch * 26 + hi * 13 + tau
+ *     planes [520, 720): P[ch][k] = sum_pos d[ch][pos][k], plane = 520 + ch*10 + k
  * optional grad_state0 [12][B], grad_h0 / grad_c0 [8][B].
  *   dW_ih = d_gates x^T, dW_hh = d_gates h_prev^T, db_ih = db_hh = sum d_gates,
  *   dW_out = d_zout hnew^T, db_out = sum d_zout,
- *   dconv_w[ch][c][t] = sum_{pos,n} d_conv[ch][pos][n] window[n][pos+t][c]. */
+ *   dconv_w[ch][c][t] = sum_{hi,tau,n} G[ch][hi][tau][n] ref[n][4 hi + tau + t][c]
+ *                       - (c < 3) sum_{k,n} P[ch][k][n] pos_k[n][c],
+ *   dconv_b[ch] = sum_{k,n} P[ch][k][n]. */
 int apg_quad_lstm_loss_partials_count(int B);
 int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const float *actions, const float *ref,
