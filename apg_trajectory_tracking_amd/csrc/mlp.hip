@@ -62,6 +62,20 @@ namespace {
 constexpr int kH = 10, kRD = 9, kNF = 15, kNC = 20, kNP = kH - 2;
 constexpr int kW = 64;               // width of s1, h1, h2, h3
 constexpr int kN1 = kW + kNC * kNP;  // fc1 input width (224)
+// What the autoregressive reverse sweep leaves for the conv weight gradient
+// (same as lstm.hip): the window of (step k, position pos, tap t) is reference
+// row k + pos + t, so dW[ch][c][t] = sum_{sigma,n} G[ch][sigma][n] R[sigma+t][c][n]
+// with G[ch][sigma] = sum_{k+pos=sigma} d[ch][pos][k] - 17 diagonal sums per
+// channel instead of 80 (pos, k) planes.  A lane holds the positions
+// pos = 4 hi + ii of a channel: each half-wave keeps its own diagonals
+// tau = k + ii (13 of them, sigma = tau + 4 hi) in four sliding registers per
+// channel and stores a diagonal when its last term is in.
+//   planes [0, kConvP):        G[ch][hi][tau]  (kNC x 2 x 13, B floats each)
+//   planes [kConvP, +kNC*kH):  P[ch][k] = sum_pos d[ch][pos][k] (relative-
+//                              position shift of window columns 0..2, bias)
+constexpr int kTau = kH + 3;
+constexpr int kConvP = kNC * 2 * kTau;          // 520
+constexpr int kConvPlanes = kConvP + kNC * kH;  // 720
 constexpr int kThreads = 512;
 constexpr int kTrajPerBlock = kThreads / 2;
 // ------------------------------------------------------------ forward sweep
@@ -563,7 +577,7 @@ struct BwdArgs {
   float *loss_partials;
   float *d_pre;   // [256][N]: d_pre1, d_pre2, d_pre3, d_pre_s (64 each)
   float *d_zout;  // [4][N]
-  float *d_conv;  // [160][N]
+  float *d_conv;  // [720][B]: window-diagonal sums of the conv cotangents (kConvP)
   float *grad_state0;
   const float *tables;  // packed operand tables (mlp_pack_bwd_kernel)
   QuadConst c;
@@ -618,13 +632,22 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
   const Planes Pac(A.actions, kH * 4, pitchB), Prf(A.ref, kH * A.ref_cols, pitchB);
   const Planes Px1(A.x1, kN1, pitchN), Ph(A.h, 3 * kW, pitchN);
   const Planes Pmk(A.mask, 5, pitchN), Pdp(A.d_pre, 4 * kW, pitchN);
-  const Planes Pdz(A.d_zout, 4, pitchN), Pdc(A.d_conv, kNC * kNP, pitchN);
+  const Planes Pdz(A.d_zout, 4, pitchN), Pdc(A.d_conv, kConvPlanes, pitchB);
   const unsigned vb = live ? (unsigned)b * 4u : kDead;
 
   float lam[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
   float loss = 0.f;
+  // sliding diagonal sums of the conv cotangents: dgn[ch][ii] = diagonal
+  // tau = k + ii of this half-wave's positions (see kConvP)
+  float dgn[kNC][4];
+#pragma unroll
+  for (int ch = 0; ch < kNC; ++ch)
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) dgn[ch][ii] = 0.f;
+  const unsigned vg = live ? (unsigned)b * 4u + (hi ? kTau * pitchB : 0u) : kDead;
+  const unsigned vb_lo = st_lo ? (unsigned)b * 4u : kDead;
 
 #pragma unroll 1
   for (int k = kH - 1; k >= 0; --k) {
@@ -743,15 +766,21 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
         y = mfma(L.A(rA1c + (eb * 32 + cc) * 64), d[cc >> 4][cc & 15], y);
       const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];  // bit r(i) + 4 hi -> bit r(i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g,
+        const int ch = eb * 4 + g;     // positions ii + 4 hi
         float sum = 0.f;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = 4 * g + ii;
           const float dcp = ((mws >> rrow(i)) & 1u) ? y[i] : 0.f;
-          Pdc.st(vr, (eb * 32 + rrow(i)) * pN, dcp);
+          dgn[ch][ii] += dcp;
           sum += dcp;
         }
+        // diagonal tau = k + 3 is complete; the others move up one position
+        Pdc.st(vg, (unsigned)(ch * 2 * kTau + k + 3) * pB, dgn[ch][3]);
+        dgn[ch][3] = dgn[ch][2], dgn[ch][2] = dgn[ch][1], dgn[ch][1] = dgn[ch][0];
+        dgn[ch][0] = 0.f;
+        Pdc.st(vb_lo, (unsigned)(kConvP + ch * kH + k) * pB, sum + other_half(sum));
 #pragma unroll
         for (int q = 0; q < 3; ++q)
           dpos[q] = fmaf(L.U(rAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
@@ -760,6 +789,12 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) lam[q] -= dpos[q] + other_half(dpos[q]);
   }
+  // the diagonals tau = 0..2 (after the last shift they sit in slots 1..3)
+#pragma unroll
+  for (int ch = 0; ch < kNC; ++ch)
+#pragma unroll
+    for (int tau = 0; tau < 3; ++tau)
+      Pdc.st(vg, (unsigned)(ch * 2 * kTau + tau) * pitchB, dgn[ch][tau + 1]);
   if (st_lo && A.grad_state0)
 #pragma unroll
     for (int i = 0; i < 12; ++i) A.grad_state0[(size_t)i * B + b] = lam[i];

@@ -865,28 +865,6 @@ def _ref_and_states(in_ref, state0, B, H, index=None, also=()):
     return (buf, inr, st_all[0], st_all[1:], *outs[2:])
 
 
-def _conv_weight_problem(d_conv, refbuf, B, H, b_out):
-    """The conv-weight product of the recurrent unrolls as a planes_gemm
-    problem: d_conv [160][H*B] (plane = ch*8 + pos) against the windows read in
-    place from the reference planes of `refbuf` (segment = (pos, step)) plus
-    three columns over the position planes before each step (the
-    relative-position shift of columns 0..2).  Returns (problem, finish):
-    finish(w_out) writes d conv_ref.weight [20,9,3] once the product ran."""
-    dev = d_conv.device
-    offs = [t * 9 + c for c in range(9) for t in range(3)] + [2 * H * 9 + q for q in range(3)]
-    desc = make_bdesc(dev, offs, [9] * 27 + [0] * 3, [9] * 27 + [12] * 3,
-                      key=("conv", H))
-    c = torch.empty(20, 30, dtype=torch.float32, device=dev)
-    prob = dict(A=d_conv, M=20, S=8 * H, Bp=refbuf, bdesc=desc, sdiv=H, N=B, out=c,
-                bias_out=b_out)
-
-    def finish(w_out):
-        w = w_out.view(20, 27)
-        w.copy_(c[:, :27])
-        w[:, :9].view(20, 3, 3).sub_(c[:, 27:30, None])
-    return prob, finish
-
-
 _CONV_DIAG_PLANES = 720      # 20 ch x 2 half-waves x 13 diagonals + 20 ch x H
 
 
@@ -1085,7 +1063,7 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
             "apg_quad_mlp_rollout_fwd")
         partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
         loss = new(1)
-        d_pre, d_zout, d_conv = new(256, N), new(4, N), new(160, N)
+        d_pre, d_zout, d_conv = new(256, N), new(4, N), new(_CONV_DIAG_PLANES, B)
         g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
         check(lib().apg_quad_mlp_rollout_bwd(
             ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1], ptr(x1),
@@ -1143,10 +1121,10 @@ def _mlp_param_grads(saved, dims, n_out, conv=None):
         dict(A=d_zout, M=n_out, S=1, Bp=acts, bdesc=R(367, 431),
              out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])]
     if conv is None:
-        cp, finish = _conv_weight_problem(d_conv, refbuf, B, H, gr["conv_ref.bias"])
+        cp, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.bias"])
     else:
-        cp, finish = conv(d_conv, gr["conv_ref.weight"], gr["conv_ref.bias"]), None
-    _run_products(probs + [cp])
+        cp, finish = [conv(d_conv, gr["conv_ref.weight"], gr["conv_ref.bias"])], None
+    _run_products(probs + cp)
     if finish is not None:
         finish(gr["conv_ref.weight"])
     return flat, gr

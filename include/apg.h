@@ -306,7 +306,8 @@ int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
  * apg_quad_mlp_loss_partials_count(B) floats.
  * Cotangent planes for the weight gradients (apg_planes_gemm):
  *   d_pre [256][N] = pre-activation cotangents of fc1, fc2, fc3, states_in
- *   (64 planes each, in this order), d_zout [4][N], d_conv [160][N];
+ *   (64 planes each, in this order), d_zout [4][N], d_conv [720][B] (the
+ *   window-diagonal sums G / P described at apg_quad_lstm_rollout_bwd);
  *   dW_1 = d_pre1 x1^T, dW_2 = d_pre2 h1^T, dW_3 = d_pre3 h2^T,
  *   dW_s = d_pre_s feat^T, dW_out = d_zout h3^T, biases = row sums,
  *   dconv_w as for the LSTM policy.  Optional grad_state0 [12][B]. */

@@ -29,7 +29,7 @@ feat, x1, h = acts[:15], acts[15:239], acts[239:431]
 mask = torch.empty(5, N, dtype=torch.int32, device=dev)
 ws = new(lib().apg_quad_mlp_workspace_floats())
 partials, loss = new(lib().apg_quad_mlp_loss_partials_count(B)), new(1)
-d_pre, d_zout, d_conv = new(256, N), new(4, N), new(160, N)
+d_pre, d_zout, d_conv = new(256, N), new(4, N), new(720, B)   # d_conv: diagonal sums
 st = stream_of(s0)
 wts = F.quad_loss_weights()
 
