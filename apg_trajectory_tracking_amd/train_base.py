@@ -30,6 +30,16 @@ from . import parallel
 from .parallel import GradAllReducer
 
 
+def momentum_sgd(params, lr):
+    """optim.SGD(params, lr, momentum=0.9) as the reference builds it
+    (scripts/train_base.py:140-150); with every parameter on the GPU the fused
+    implementation does the whole step in ONE launch instead of three
+    (same arithmetic: buf = 0.9 buf + grad, p -= lr buf)."""
+    params = list(params)
+    fused = bool(params) and all(p.is_cuda for p in params)
+    return optim.SGD(params, lr=lr, momentum=0.9, fused=fused)
+
+
 class TrainBase:
 
     def __init__(
@@ -144,19 +154,13 @@ class TrainBase:
         parallel.broadcast_module(self.net)
         if isinstance(self.train_dynamics, torch.nn.Module):
             parallel.broadcast_module(self.train_dynamics)
-        self.optimizer_controller = optim.SGD(
-            self.net.parameters(),
-            lr=self.learning_rate_controller,
-            momentum=0.9
-        )
+        self.optimizer_controller = momentum_sgd(
+            self.net.parameters(), self.learning_rate_controller)
         self.grad_sync = GradAllReducer(self.net.parameters())
         # a learnable simulator gets its own optimizer (:144-150)
         if isinstance(self.train_dynamics, torch.nn.Module):
-            self.optimizer_dynamics = optim.SGD(
-                self.train_dynamics.parameters(),
-                lr=self.learning_rate_dynamics,
-                momentum=0.9
-            )
+            self.optimizer_dynamics = momentum_sgd(
+                self.train_dynamics.parameters(), self.learning_rate_dynamics)
             self.grad_sync_dynamics = GradAllReducer(
                 self.train_dynamics.parameters())
 
