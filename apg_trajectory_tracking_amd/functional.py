@@ -868,7 +868,7 @@ def _ref_and_states(in_ref, state0, B, H, index=None, also=()):
 _CONV_DIAG_PLANES = 720      # 20 ch x 2 half-waves x 13 diagonals + 20 ch x H
 
 
-def _conv_diag_problems(cv, refbuf, B, H, b_out):
+def _conv_diag_problems(cv, refbuf, B, H, w_out, b_out):
     """The conv-weight gradient of the recurrent unrolls from the DIAGONAL sums
     the reverse sweep leaves (csrc/lstm.hip kConvP): cv [720][B] =
     G[ch][hi][tau] (tau = k + pos - 4 hi; the window of (step, position, tap) is
@@ -876,14 +876,16 @@ def _conv_diag_problems(cv, refbuf, B, H, b_out):
       dW[ch][c][t] = sum G[ch][hi][tau] . ref[4 hi + tau + t][c]
                      - (c < 3) sum_k P[ch][k] . pos_k[c]
     as two segmented planes_gemm problems reading the reference windows and the
-    position planes of `refbuf` in place.  Returns (problems, finish)."""
+    position planes of `refbuf` in place; the first one writes straight into
+    `w_out` (d conv_ref.weight [20,9,3]), finish() subtracts the second.
+    Returns (problems, finish)."""
     assert H == 10
     dev = cv.device
     offs = [t * 9 + c for c in range(9) for t in range(3)]
     g_desc = make_bdesc(dev, offs, 36, 9, key=("conv_diag", H))
     p_desc = make_bdesc(dev, [2 * H * 9 + q for q in range(3)], 12, 0,
                         key=("conv_pos", H))
-    cg = torch.empty(20, 27, dtype=torch.float32, device=dev)
+    cg = w_out.view(20, 27)
     cp = torch.empty(20, 3, dtype=torch.float32, device=dev)
     probs = [
         dict(A=cv[:520], M=20, S=26, Bp=refbuf, bdesc=g_desc, sdiv=13, N=B, out=cg,
@@ -891,10 +893,8 @@ def _conv_diag_problems(cv, refbuf, B, H, b_out):
         dict(A=cv[520:], M=20, S=H, Bp=refbuf, bdesc=p_desc, sdiv=1, N=B, out=cp,
              bias_out=b_out)]
 
-    def finish(w_out):
-        w = w_out.view(20, 27)
-        w.copy_(cg)
-        w[:, :9].view(20, 3, 3).sub_(cp[:, :, None])
+    def finish():
+        cg[:, :9].view(20, 3, 3).sub_(cp[:, :, None])
     return probs, finish
 
 
@@ -990,13 +990,14 @@ def _lstm_param_grads(saved, dims):
     ih_hh = torch.empty(32, 183, dtype=torch.float32, device=dev)
     # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T, db = row sums;
     # dW_out = d_zout . h_new^T; conv
-    conv, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.bias"])
+    conv, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.weight"],
+                                       gr["conv_ref.bias"])
     _run_products([
         dict(A=d_gates, M=32, S=1, Bp=acts, bdesc=make_bdesc(dev, range(183), key="ih_hh"),
              out=ih_hh, bias_out=gr["lstm.bias_ih"]),
         dict(A=d_zout, M=4, S=1, Bp=acts, bdesc=make_bdesc(dev, range(191, 199), key="out"),
              out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])] + conv)
-    finish(gr["conv_ref.weight"])
+    finish()
     # contiguous per-parameter gradients (the fused optimizer path wants them)
     gr["lstm.weight_ih"].copy_(ih_hh[:, :175])
     gr["lstm.weight_hh"].copy_(ih_hh[:, 175:])
@@ -1121,12 +1122,13 @@ def _mlp_param_grads(saved, dims, n_out, conv=None):
         dict(A=d_zout, M=n_out, S=1, Bp=acts, bdesc=R(367, 431),
              out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])]
     if conv is None:
-        cp, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.bias"])
+        cp, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.weight"],
+                                         gr["conv_ref.bias"])
     else:
         cp, finish = [conv(d_conv, gr["conv_ref.weight"], gr["conv_ref.bias"])], None
     _run_products(probs + cp)
     if finish is not None:
-        finish(gr["conv_ref.weight"])
+        finish()
     return flat, gr
 
 
