@@ -551,7 +551,9 @@ class RolloutPlan:
 
     def __init__(self, system, state0, actions, ref, dt, params, weights=None,
                  layout="soa", want_grad_state0=False, want_states=False,
-                 loss_mode="eager"):
+                 loss_mode="eager", out=None):
+        """`out`: optional pre-allocated output tensors (keys as returned by
+        quad_/wing_rollout_fwd_bwd) - e.g. slices of one large allocation."""
         if loss_mode not in ("eager", "deferred", "none"):
             raise ValueError("loss_mode must be eager, deferred or none")
         self.system = system
@@ -559,7 +561,7 @@ class RolloutPlan:
         self.loss_mode = loss_mode
         self.inputs = (state0, actions, ref)
         kw = dict(layout=layout, want_grad_state0=want_grad_state0,
-                  want_states=want_states, want_loss=True)
+                  want_states=want_states, want_loss=True, out=out)
         # one eager call allocates the outputs and validates the shapes
         if system == "quad":
             self.out = quad_rollout_fwd_bwd(state0, actions, ref, dt, params,

@@ -104,6 +104,26 @@ static std::vector<float> to_planes(const std::vector<float> &r, int G, int W, i
   return pl;
 }
 
+// AB_ARENA=1: the per-set tensors come out of ONE hipMalloc (2 MiB-aligned
+// slices) instead of one hipMalloc each - page-table fragment experiment.
+static char *g_arena = nullptr;
+static size_t g_arena_off = 0, g_arena_size = 0;
+static hipError_t arena_alloc(void **p, size_t bytes) {
+  static const bool on = std::getenv("AB_ARENA") && std::atoi(std::getenv("AB_ARENA"));
+  if (!on) return hipMalloc(p, bytes);
+  if (!g_arena) {
+    g_arena_size = (size_t)3 << 30;
+    hipError_t e = hipMalloc((void **)&g_arena, g_arena_size);
+    if (e != hipSuccess) return e;
+  }
+  const size_t al = (size_t)2 << 20;
+  g_arena_off = (g_arena_off + al - 1) / al * al;
+  if (g_arena_off + bytes > g_arena_size) return hipErrorOutOfMemory;
+  *p = g_arena + g_arena_off;
+  g_arena_off += bytes;
+  return hipSuccess;
+}
+
 int main(int argc, char **argv) {
   if (argc < 3) {
     std::printf("usage: ab_quad lib0[:p] lib1[:p] [lib2 ...]\n");
@@ -159,9 +179,9 @@ int main(int argc, char **argv) {
       hr[i] = (urand() - 0.5f) * 0.3f * (k + 1);
     }
     for (int lay = 0; lay < (any_packed ? 2 : 1); ++lay) {
-      CK(hipMalloc(&s0[lay][s], nS * 4));
-      CK(hipMalloc(&act[lay][s], nA * 4));
-      CK(hipMalloc(&ref[lay][s], nR * 4));
+      CK(arena_alloc((void **)&s0[lay][s], nS * 4));
+      CK(arena_alloc((void **)&act[lay][s], nA * 4));
+      CK(arena_alloc((void **)&ref[lay][s], nR * 4));
       const std::vector<float> a = lay ? to_rows(hs, 3, 4, B) : hs,
                                b = lay ? to_rows(ha, H, 4, B) : ha,
                                c = lay ? to_rows(hr, H, 6, B) : hr;
@@ -169,7 +189,7 @@ int main(int argc, char **argv) {
       CK(hipMemcpy(act[lay][s], b.data(), nA * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(ref[lay][s], c.data(), nR * 4, hipMemcpyHostToDevice));
     }
-    CK(hipMalloc(&ga[s], nA * 4));
+    CK(arena_alloc((void **)&ga[s], nA * 4));
     if (s == 0) h_s0 = hs, h_act = ha, h_ref = hr;
   }
   CK(hipMalloc(&gs, nS * 4));
