@@ -254,6 +254,11 @@ def test_flat_gradient_layout_and_new_argument_errors():
     assert b"apg_to_soa" in lib.apg_last_error_string()
     assert lib.apg_planes_gemm(1, 65, 1, 1, 1, 8, 1, 1, 8, 64, 1, 16, 1, 9, None, None) == -1
     assert b"M <= 64" in lib.apg_last_error_string()
+    assert lib.apg_to_soa_multi(None, 0, 4, None) == -1
+    assert b"apg_to_soa_multi" in lib.apg_last_error_string()
+    item = _capi.ApgSoaItem(None, None, None, 0, 0)
+    assert lib.apg_to_soa_multi(ctypes.byref(item), 1, 4, None) == -1   # R < 1
+    assert ctypes.sizeof(_capi.ApgSoaItem) == 3 * 8 + 2 * 4
     assert lib.apg_planes_gemm_multi(None, 0, None, None) == -1
     assert b"apg_planes_gemm_multi" in lib.apg_last_error_string()
     # shape -> workgroups / workspace helpers are pure host functions
