@@ -687,3 +687,46 @@ def test_schedules_match_the_reference_loops(tmp_path):
                         train_dyn_for_epochs=int(g["dynamics.for_epochs"]),
                         train_dyn_every=int(g["dynamics.every"])))
     assert [int(m == "dynamics") for _, m in t.log] == list(g["dynamics.trained"])
+
+
+def test_conv_gradient_from_window_diagonals():
+    """The algebra behind the reverse sweeps' conv cotangent format
+    (csrc/lstm.hip kConvP, functional._conv_diag_problems): the window of
+    (step k, position pos, tap t) is reference row k + pos + t, so the weight
+    gradient of the 3-tap conv over all steps follows from 13 diagonal sums per
+    channel and half-wave (G) plus the per-step sums over positions (P) -
+    checked against autograd through torch's conv1d on the windows the unroll
+    builds (relative position in columns 0..2)."""
+    import torch.nn.functional as Fn
+    g = torch.Generator().manual_seed(0)
+    H, B, NC = 10, 5, 20
+    ref = torch.randn(B, 2 * H, 9, generator=g, dtype=torch.float64)
+    pos = torch.randn(B, H, 3, generator=g, dtype=torch.float64)   # position before step k
+    w = torch.randn(NC, 9, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(NC, dtype=torch.float64, requires_grad=True)
+    d = torch.randn(B, H, NC, 8, generator=g, dtype=torch.float64)  # dL/d conv out [n][k][ch][pos]
+    total = 0.0
+    for k in range(H):
+        win = ref[:, k:k + H].clone()                   # [B, 10, 9]
+        win[:, :, :3] = win[:, :, :3] - pos[:, k, None, :]
+        out = Fn.conv1d(win.transpose(1, 2), w, bias)     # [B, 20, 8]
+        total = total + (out * d[:, k]).sum()
+    total.backward()
+    # what the kernel leaves: G[ch][hi][tau], tau = k + pos - 4 hi; P[ch][k]
+    G = torch.zeros(NC, 2, 13, B, dtype=torch.float64)
+    P = torch.zeros(NC, H, B, dtype=torch.float64)
+    for k in range(H):
+        for p_ in range(8):
+            hi = p_ // 4
+            G[:, hi, k + p_ - 4 * hi] += d[:, k, :, p_].t()
+            P[:, k] += d[:, k, :, p_].t()
+    dw = torch.zeros(NC, 9, 3, dtype=torch.float64)
+    for hi in range(2):
+        for tau in range(13):
+            for t in range(3):
+                row = ref[:, 4 * hi + tau + t]            # [B, 9]
+                dw[:, :, t] += G[:, hi, tau] @ row
+    shift = torch.einsum("ckn,nkq->cq", P, pos)           # [20, 3]
+    dw[:, :3, :] -= shift[:, :, None]
+    assert torch.allclose(dw, w.grad, rtol=1e-10, atol=1e-10)
+    assert torch.allclose(P.sum((1, 2)), bias.grad, rtol=1e-10, atol=1e-10)
