@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: build_gemm_variant.sh <name> [flags...]  -> tools/exp/libapg_gemm_<name>.so
-cd /root/repo
-name=$1; shift
+cd "$(dirname "$0")/.."
+name=$1; shift; mkdir -p tools/exp
 C=apg_trajectory_tracking_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -Iinclude -I$C -c $C/planes_gemm.hip -o tools/exp/planes_gemm_$name.o || exit 1
 objs=$(ls $C/*.o | grep -v planes_gemm.o)

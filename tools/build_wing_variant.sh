@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: build_wing_variant.sh <name> [flags...]  -> tools/exp/libapg_wing_<name>.so
-cd /root/repo
-name=$1; shift
+cd "$(dirname "$0")/.."
+name=$1; shift; mkdir -p tools/exp
 C=apg_trajectory_tracking_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize "$@" -Iinclude -I$C -c $C/wing.hip -o tools/exp/wing_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A12 "wing_rollout_lds_kernelILi0" | grep -E "VGPRs|AGPRs|Scratch|Occupancy" | tr '\n' ' '; echo
 objs=$(ls $C/*.o | grep -v "/wing.o")
