@@ -39,10 +39,26 @@ def _stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _extra_flags():
+    """APG_HIPCC_FLAGS: extra compiler flags for the product build (-g,
+    -save-temps ...).  Kernel-variant macros are refused here - they belong to
+    tools/build_variant.py, which builds a SEPARATE library - so that a stray
+    -DAPG_... in the environment cannot change the shipped kernels (the
+    sources #error on them as well, apg_device.h)."""
+    flags = os.environ.get("APG_HIPCC_FLAGS", "").split()
+    bad = [f for f in flags if f.startswith(("-DAPG_", "-UAPG_"))]
+    if bad:
+        raise RuntimeError(
+            f"APG_HIPCC_FLAGS must not define kernel macros ({' '.join(bad)}): "
+            "build variants with tools/build_variant.py")
+    return flags
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source into one shared library; returns its path."""
     if not force and not _stale():
         return LIB
+    extra = _extra_flags()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -53,7 +69,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                *COMMON_FLAGS, *EXTRA_FLAGS.get(s, []),
-               *os.environ.get("APG_HIPCC_FLAGS", "").split(),
+               *extra,
                "-I", os.path.join(REPO, "include"), "-I", CSRC, "-c", src,
                "-o", obj]
         if verbose:

@@ -10,6 +10,26 @@
 
 #include "apg.h"
 
+// Tuning knobs and instrumentation (request schedules, stamps, occupancy
+// overrides ...) are compile-time macros so that tools/build_variant.py can
+// A/B them.  A PRODUCT build must not carry any of them: one stray -D in the
+// environment would ship a different kernel.  Variant builds say so
+// explicitly (-DAPG_EXPERIMENT_BUILD); forks that produce wrong results on
+// purpose live in tools/patches/, not here.
+#if !defined(APG_EXPERIMENT_BUILD) &&                                          \
+    (defined(APG_STAMP) || defined(APG_QX) || defined(APG_EXP_NO_STORES) ||    \
+     defined(APG_TRIG_1WORD) || defined(APG_SW_TRIG) || defined(APG_MLP_EXP) || \
+     defined(APG_ROWS_BLOCK) || defined(APG_ROWS_ACT_PRE) ||                   \
+     defined(APG_ROWS_REF_PER_STEP) || defined(APG_ROWS_REF_LOOK) ||           \
+     defined(APG_ROWS_ST_AUX) || defined(APG_ROWS_REF_TOP) ||                  \
+     defined(APG_ROWS_LD_AUX) ||                                               \
+     defined(APG_REG_ACT_PRE) || defined(APG_REG_REF_PER_STEP) ||              \
+     defined(APG_REG_REF_LOOK) || defined(APG_GEMM_ST_MAX) ||                  \
+     defined(APG_GEMM_STREAM) || defined(APG_WING_WAVES) ||                    \
+     defined(APG_WING_GROUP_PREFETCH) || defined(APG_WING_LITERALS))
+#error "experiment macro in a product build (variants: -DAPG_EXPERIMENT_BUILD, tools/build_variant.py)"
+#endif
+
 namespace apg {
 
 constexpr int kWave = 64;  // CDNA wavefront
@@ -210,6 +230,23 @@ __host__ __device__ __forceinline__ float rcp_nr(float x) {
   const float r = 1.0f / x;
 #endif
   return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
+// rcp_nr that stays usable at x = 0 (+-FLT_MAX instead of inf / NaN: the
+// Newton step of rcp_nr turns 1 / 0 into 0 * inf).  Identical bits for every
+// x whose reciprocal is finite; used where a mask multiplies the result
+// (0 * FLT_MAX = 0, 0 * inf = NaN).  Two v_med3_f32 more than rcp_nr.
+__host__ __device__ __forceinline__ float rcp_nr_finite(float x) {
+  const float kMax = 3.402823466e+38f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(x), -kMax, kMax);
+  r = fmaf(fmaf(-x, r, 1.0f), r, r);
+  return __builtin_amdgcn_fmed3f(r, -kMax, kMax);
+#else
+  float r = fminf(fmaxf(1.0f / x, -kMax), kMax);
+  r = fmaf(fmaf(-x, r, 1.0f), r, r);
+  return fminf(fmaxf(r, -kMax), kMax);
+#endif
 }
 
 // hardware v_sqrt_f32 (1 ulp); sqrtf on the host

@@ -42,22 +42,8 @@
 #include "policy_mfma.h"
 #include "quad_math.h"
 
-// Timing experiments only (tools/exp_mlp.sh): bit 0 drops the plane stores of
-// the forward sweep, bit 1 replaces tanh by a 1-op stand-in, bit 2 skips the
-// dynamics, bit 3 replaces the MFMAs by one VALU op.  0 in every real build.
-#ifndef APG_MLP_EXP
-#define APG_MLP_EXP 0
-#endif
-
 namespace apg {
 namespace {
-
-#if APG_MLP_EXP & 2
-#define tanh_fast(x) ((x) * 0.5f)
-#endif
-#if APG_MLP_EXP & 8
-#define mfma(a, b, c) ((c) + (a) * (b))
-#endif
 
 constexpr int kH = 10, kRD = 9, kNF = 15, kNC = 20, kNP = kH - 2;
 constexpr int kW = 64;               // width of s1, h1, h2, h3
@@ -186,9 +172,7 @@ __device__ __forceinline__ void dense64_tanh(f32x16 (&out)[2], f32x16 (&in)[2],
   for (int c = 0; c < 32; ++c) {
     const float b = tanh_fast(in[c >> 4][c & 15]);
     in[c >> 4][c & 15] = b;
-#if !(APG_MLP_EXP & 1)
     P.st(vr, (plane0 + (c >> 4) * 32 + rrow(c & 15)) * pN, b);
-#endif
     out[0] = mfma(L.A(tab + (0 * 32 + c) * 64), b, out[0]);
     out[1] = mfma(L.A(tab + (1 * 32 + c) * 64), b, out[1]);
   }
@@ -204,11 +188,6 @@ struct FwdArgs {
   int B;
 };
 
-#if APG_MLP_EXP & 1
-#define FWD_STORE if (false)
-#else
-#define FWD_STORE
-#endif
 __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds(lds, A.tables, kFwdLds);
@@ -256,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
     float feat[kNF];
     quad_features(s, t, feat);
 #pragma unroll
-    for (int j = 0; j < kNF; ++j) FWD_STORE Pfe.st(vn_lo, j * pN, feat[j]);
+    for (int j = 0; j < kNF; ++j) Pfe.st(vn_lo, j * pN, feat[j]);
 
     f32x16 u[2], a[2];
     // state branch: 8 k-pairs of the 15 features
@@ -288,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
           const int c = pos * 4 + (p == 14 ? 3 : p / 4);
           const float tv = tanh_fast(u[c >> 4][c & 15]);
           u[c >> 4][c & 15] = tv;
-          FWD_STORE Px1.st(vr, ((c >> 4) * 32 + rrow(c & 15)) * pN, tv);
+          Px1.st(vr, ((c >> 4) * 32 + rrow(c & 15)) * pN, tv);
         }
       }
 #pragma unroll
@@ -297,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
         mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
         v = fmaxf(v, 0.f);
         // plane 64 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
-        FWD_STORE Px1.st(i < 8 ? vc : vn_lo, (kW + rrow(i) * kNP + pos) * pN, v);
+        Px1.st(i < 8 ? vc : vn_lo, (kW + rrow(i) * kNP + pos) * pN, v);
         a[0] = mfma(L.A(fA1c + ((0 * 8 + pos) * 12 + i) * 64), v, a[0]);
         a[1] = mfma(L.A(fA1c + ((1 * 8 + pos) * 12 + i) * 64), v, a[1]);
       }
@@ -305,7 +284,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
     // relu mask, trajectory-indexed: bit e = ch*8 + pos of word e >> 5
 #pragma unroll
     for (int g = 0; g < 3; ++g)
-      FWD_STORE Pmk.stu(g < 2 ? vm : vn_lo, 2 * g * pN, mbits[g]);
+      Pmk.stu(g < 2 ? vm : vn_lo, 2 * g * pN, mbits[g]);
     // fc1, state part
     dense64(a, u, L, fA1s);
     // h1 -> h2 -> h3 (tanh of a layer applied inside the next layer's loop)
@@ -318,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         a[rb][i] = tanh_fast(a[rb][i]);
-        FWD_STORE Ph.st(vr, (2 * kW + rb * 32 + rrow(i)) * pN, a[rb][i]);
+        Ph.st(vr, (2 * kW + rb * 32 + rrow(i)) * pN, a[rb][i]);
       }
     // head on the VALU: each half sums its 32 of the 64 inputs
     float act[4];
@@ -335,9 +314,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
       act[j] = sigmoidf_(z + L.U(fBo + j));
       Pac.st(vb_lo, (k * 4 + j) * pB, act[j]);
     }
-#if !(APG_MLP_EXP & 4)
     quad_step(s, act, c, t);
-#endif
 #pragma unroll
     for (int i = 0; i < 12; ++i) Pst.st(vb_lo, (k * 12 + i) * pB, s[i]);
     if (k + 1 < kH) {

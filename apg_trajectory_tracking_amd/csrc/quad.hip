@@ -418,6 +418,9 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
 #ifndef APG_ROWS_ST_AUX
 #define APG_ROWS_ST_AUX 2  // nt
 #endif
+#ifndef APG_ROWS_LD_AUX
+#define APG_ROWS_LD_AUX 0  // default cache policy for the input rows
+#endif
 #ifndef APG_ROWS_REF_TOP
 #define APG_ROWS_REF_TOP 0  // 1: rows below H - kRefLook all requested before
 #endif                      //    the first store (top of the reverse sweep)
@@ -437,16 +440,16 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
   u4v s4[3], a4[HT], rA[HT];
   u2v rB[HT];
   auto ld_ref = [&](int kr) {
-    rA[kr] = __builtin_amdgcn_raw_buffer_load_b128(r_ref, v24, kr * p24, 0);
-    rB[kr] = __builtin_amdgcn_raw_buffer_load_b64(r_ref, v24 + 16, kr * p24, 0);
+    rA[kr] = __builtin_amdgcn_raw_buffer_load_b128(r_ref, v24, kr * p24, APG_ROWS_LD_AUX);
+    rB[kr] = __builtin_amdgcn_raw_buffer_load_b64(r_ref, v24 + 16, kr * p24, APG_ROWS_LD_AUX);
   };
 #pragma unroll
   for (int g = 0; g < 3; ++g)
-    s4[g] = __builtin_amdgcn_raw_buffer_load_b128(r_s0, v16, g * p16, 0);
+    s4[g] = __builtin_amdgcn_raw_buffer_load_b128(r_s0, v16, g * p16, APG_ROWS_LD_AUX);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < kActPre; ++k)
-    a4[k] = __builtin_amdgcn_raw_buffer_load_b128(r_act, v16, k * p16, 0);
+    a4[k] = __builtin_amdgcn_raw_buffer_load_b128(r_act, v16, k * p16, APG_ROWS_LD_AUX);
   __builtin_amdgcn_sched_barrier(0);
 
   // everything below the first requests can wait for the rest of the arguments
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
     {  // requests of this step
       if (k + kActPre < HT)
         a4[k + kActPre] = __builtin_amdgcn_raw_buffer_load_b128(
-            r_act, v16, (k + kActPre) * p16, 0);
+            r_act, v16, (k + kActPre) * p16, APG_ROWS_LD_AUX);
       if constexpr (kRefLook == 0) {
 #pragma unroll
         for (int j = 0; j < kRefPerStep; ++j) {
@@ -522,9 +525,6 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
   const float wp2 = 2.f * R.w.pos, wv2 = 2.f * R.w.vel, ww2 = 2.f * R.w.av,
               wr2 = 2.f * R.w.rates, wt2 = 2.f * R.w.thrust;
   float lam[12];
-#ifdef APG_EXP_NO_STORES
-  float exp_keep = 0.f;
-#endif
 #pragma unroll
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
 #pragma unroll
@@ -564,11 +564,6 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
       ga[i] = wr2 * d;
     }
     quad_step_adjoint(lam, ga, a0, st_w[k], c, st_trig[k]);
-#ifdef APG_EXP_NO_STORES  // timing experiment: only the last row is written
-    exp_keep += (ga[0] + ga[1]) + (ga[2] + ga[3]);
-    if (k == 0) ga[0] += exp_keep;
-    if (k == 0)
-#endif
     __builtin_amdgcn_raw_buffer_store_b128(
         (u4v){f2u(ga[0]), f2u(ga[1]), f2u(ga[2]), f2u(ga[3])}, r_ga, st16, k * p16,
         APG_ROWS_ST_AUX);
@@ -1201,9 +1196,9 @@ int launch_rollout_rows(const RolloutArgs &A, hipStream_t st) {
   R.loss_partials = A.loss_partials, R.grad_actions = A.grad_actions;
   R.grad_state0 = A.grad_state0, R.states_out = A.states_out;
   R.prev = A.prev;
-  const dim3 grid(grid_for(A.B, APG_ROWS_BLOCK)), block(APG_ROWS_BLOCK);
   const QuadConst &c = A.c;
-#define APG_ROWS(HT)                                                          \
+  const dim3 grid(grid_for(A.B, APG_ROWS_BLOCK)), block(APG_ROWS_BLOCK);
+#define APG_ROWS(HT)                                                        \
   hipLaunchKernelGGL((quad_rollout_rows_kernel<HT, SO>), grid, block, 0, st,  \
                      A.state0, A.actions, A.ref, A.B, c.dt, c.half_dt,        \
                      c.half_dt2, c.g[0], c.g[1], c.g[2], c.kdt[0], c.kdt[1],  \

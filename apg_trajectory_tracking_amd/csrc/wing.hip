@@ -71,6 +71,7 @@ struct WingRolloutArgs {
 // checkpoint into registers.  Costs (stride-1)/stride extra state_dot
 // evaluations, buys 3-5x the resident waves.
 constexpr int kWingMaxStride = 4;
+constexpr float kWingDefaultPosWeight = 10.f, kWingDefaultActionWeight = 0.1f;
 // Experiments (tools/exp): waves per SIMD the register allocator must leave
 // room for, and whether the reverse sweep requests a group's rows one group
 // ahead (28 more live registers).
@@ -83,14 +84,41 @@ constexpr int kWingMaxStride = 4;
 #define APG_WING_GROUP_PREFETCH 1
 #endif
 
-template <int LAYOUT>
+// LIT: the default parameter set as instruction literals (WingDefaultK) -
+// selected by the host when make_const(params, dt) equals that table.
+// BUF (plane layout, every tensor below 2 GiB): rows are addressed through
+// buffer resources - per-lane offset in one VGPR, plane offset in an SGPR -
+// instead of 64-bit per-lane address arithmetic on the VALU; dead lanes store
+// through an out-of-range offset instead of an exec-mask branch.
+template <int LAYOUT, bool LIT, bool BUF>
 __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rollout_lds_kernel(
     WingRolloutArgs A) {
+  static_assert(!BUF || LAYOUT == APG_LAYOUT_SOA, "buffer path is SoA only");
   extern __shared__ float stash[];
   const int lane = threadIdx.x;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = b < A.B;
   const int bb = live ? b : A.B - 1;
+  const SoaPlanes b_act(A.actions, A.H * 4, A.B, bb), b_ref(A.ref, A.H * 3, A.B, bb);
+  SoaPlanes b_ga(A.grad_actions, A.H * 4, A.B, bb),
+      b_so(A.states_out, A.H * 12, A.B, bb), b_gs(A.grad_state0, 12, A.B, bb);
+  if (!live) b_ga.voff = b_so.voff = b_gs.voff = (int)0x80000000;
+  auto ld_act = [&](int kq, float(&o)[4]) {
+    if constexpr (BUF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = b_act.ld(kq * 4 + i);
+    } else {
+      load_seq<LAYOUT, 4>(A.actions, A.B, A.H, 4, bb, kq, 0, o);
+    }
+  };
+  auto ld_ref = [&](int kq, float(&o)[3]) {
+    if constexpr (BUF) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o[i] = b_ref.ld(kq * 3 + i);
+    } else {
+      load_seq<LAYOUT, 3>(A.ref, A.B, A.H, 3, bb, kq, 0, o);
+    }
+  };
   // The ~70 coefficients do not fit the SGPR file next to everything else:
   // kept live for the whole kernel they are spilled to VGPR lanes
   // (v_writelane / v_readlane, ~10 % of the issued instructions).  Reading
@@ -102,6 +130,20 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
   const_ptr kp = (const_ptr)((const_bytes)__builtin_amdgcn_kernarg_segment_ptr() +
                              offsetof(WingRolloutArgs, k));
 #define APG_LAUNDER(p) asm volatile("" : "+s"(p))
+  const WingDefaultK kl;
+  // (the literal instance is selected for the default loss weights only:
+  // fixed_wing_mpc_loss, neural_control/drone_loss.py:72-82)
+  const float w_pos = LIT ? kWingDefaultPosWeight : A.w.pos,
+              w_act = LIT ? kWingDefaultActionWeight : A.w.action;
+  // one step / one evaluation on whichever constant table this instance uses
+  auto step = [&](float(&s_)[12], const float(&a_)[4]) {
+    if constexpr (LIT) {
+      wing_step(s_, a_, kl);
+    } else {
+      APG_LAUNDER(kp);
+      wing_step(s_, a_, *kp);
+    }
+  };
   const int H = A.H, S = A.stride;
   auto ST = [&](int slot, int i) -> float & {
     return stash[(slot * 12 + i) * APG_ROLLOUT_BLOCK + lane];
@@ -119,8 +161,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     const int kq = d < H ? d : H - 1;
-    load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kq, 0, a_q[d]);
-    load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kq, 0, r_q[d]);
+    ld_act(kq, a_q[d]);
+    ld_ref(kq, r_q[d]);
   }
   for (int kk = 0, slot = 0, phase = 0; kk < H; ++kk) {
     float a[4], rp[3];
@@ -130,8 +172,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
     for (int i = 0; i < 3; ++i) rp[i] = r_q[0][i], r_q[0][i] = r_q[1][i];
     {
       const int kq = kk + 2 < H ? kk + 2 : H - 1;
-      load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kq, 0, a_q[1]);
-      load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kq, 0, r_q[1]);
+      ld_act(kq, a_q[1]);
+      ld_ref(kq, r_q[1]);
     }
     if (phase == 0) {
 #pragma unroll
@@ -139,17 +181,22 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
       ++slot;
     }
     if (++phase == S) phase = 0;
-    APG_LAUNDER(kp);
-    wing_step(s, a, *kp);
-    if (A.states_out && live)
-      store_seq<LAYOUT, 12>(A.states_out, A.B, H, 12, b, kk, 0, s);
+    step(s, a);
+    if (A.states_out) {
+      if constexpr (BUF) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b_so.st(kk * 12 + i, s[i]);
+      } else if (live) {
+        store_seq<LAYOUT, 12>(A.states_out, A.B, H, 12, b, kk, 0, s);
+      }
+    }
     float lp = 0.f, la = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float dp = s[i] - rp[i], d = a[1 + i] - 0.5f;
       lp += dp * dp, la += d * d;
     }
-    loss += A.w.pos * lp + A.w.action * la;
+    loss += w_pos * lp + w_act * la;
   }
   write_wave_partial(A.loss_partials, live ? loss : 0.f, (A.B + kWave - 1) / kWave);
 
@@ -168,8 +215,8 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
     for (int j = 0; j < kWingMaxStride; ++j) {
       int kq = g * S + j;           // rows past the group / horizon: any valid row
       kq = (j < S && kq < H) ? kq : H - 1;
-      load_seq<LAYOUT, 4>(A.actions, A.B, H, 4, bb, kq, 0, ga_[j]);
-      load_seq<LAYOUT, 3>(A.ref, A.B, H, 3, bb, kq, 0, gr_[j]);
+      ld_act(kq, ga_[j]);
+      ld_ref(kq, gr_[j]);
     }
   };
 #if APG_WING_GROUP_PREFETCH
@@ -193,8 +240,7 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
         if (j + 1 < kWingMaxStride && j + 1 < n) {
 #pragma unroll
           for (int i = 0; i < 12; ++i) pre[j + 1][i] = pre[j][i];
-          APG_LAUNDER(kp);
-          wing_step(pre[j + 1], act[j], *kp);
+          step(pre[j + 1], act[j]);
         }
       }
     }
@@ -209,15 +255,25 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
           for (int i = 0; i < 3; ++i) pn[i] = pre[j + 1][i];
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) lam[i] += 2.f * A.w.pos * (pn[i] - rpg[j][i]);
-        float ga[4] = {0.f, 2.f * A.w.action * (act[j][1] - 0.5f),
-                       2.f * A.w.action * (act[j][2] - 0.5f),
-                       2.f * A.w.action * (act[j][3] - 0.5f)};
+        for (int i = 0; i < 3; ++i) lam[i] += 2.f * w_pos * (pn[i] - rpg[j][i]);
+        float ga[4] = {0.f, 2.f * w_act * (act[j][1] - 0.5f),
+                       2.f * w_act * (act[j][2] - 0.5f),
+                       2.f * w_act * (act[j][3] - 0.5f)};
         WingAux x;
-        APG_LAUNDER(kp);
-        wing_rates(pre[j], act[j], *kp, x, sd);
-        wing_step_adjoint(lam, ga, pre[j], x, sd, *kp);
-        if (live) store_seq<LAYOUT, 4>(A.grad_actions, A.B, H, 4, b, kk, 0, ga);
+        if constexpr (LIT) {
+          wing_rates(pre[j], act[j], kl, x, sd);
+          wing_step_adjoint(lam, ga, pre[j], x, sd, kl);
+        } else {
+          APG_LAUNDER(kp);
+          wing_rates(pre[j], act[j], *kp, x, sd);
+          wing_step_adjoint(lam, ga, pre[j], x, sd, *kp);
+        }
+        if constexpr (BUF) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) b_ga.st(kk * 4 + i, ga[i]);
+        } else if (live) {
+          store_seq<LAYOUT, 4>(A.grad_actions, A.B, H, 4, b, kk, 0, ga);
+        }
       }
     }
 #pragma unroll
@@ -232,7 +288,14 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
     }
 #endif
   }
-  if (A.grad_state0 && live) store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
+  if (A.grad_state0) {
+    if constexpr (BUF) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) b_gs.st(i, lam[i]);
+    } else if (live) {
+      store_state<LAYOUT, 12>(A.grad_state0, A.B, b, lam);
+    }
+  }
 #undef APG_LAUNDER
 }
 
@@ -363,21 +426,38 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
   const size_t lds = (size_t)((H + stride - 1) / stride) * 12 *
                      APG_ROLLOUT_BLOCK * sizeof(float);
   const dim3 grid(grid_for(B, APG_ROLLOUT_BLOCK)), block(APG_ROLLOUT_BLOCK);
-  if (layout == APG_LAYOUT_SOA) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)wing_rollout_lds_kernel<APG_LAYOUT_SOA>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return check_launch("hipFuncSetAttribute(wing_rollout)");
-    hipLaunchKernelGGL(wing_rollout_lds_kernel<APG_LAYOUT_SOA>, grid, block, lds, st, A);
+  // default parameter set and dt: the instance with the coefficients as
+  // instruction literals; anything else (modified_params, another dt): the
+  // table in the kernel-argument segment
+#ifndef APG_WING_LITERALS
+#define APG_WING_LITERALS 1
+#endif
+  const bool lit = APG_WING_LITERALS && is_default(A.k) &&
+                   A.w.pos == kWingDefaultPosWeight &&
+                   A.w.action == kWingDefaultActionWeight;
+  // buffer addressing needs every tensor below 2 GiB (32-bit byte offsets)
+  const bool buf_ok = (long long)H * 12 * B * 4 < (1ll << 31);
+#define APG_WING_LAUNCH(L, LIT, BUF)                                          \
+  do {                                                                        \
+    if (lds > 64 * 1024 &&                                                    \
+        hipFuncSetAttribute(                                                  \
+            (const void *)wing_rollout_lds_kernel<L, LIT, BUF>,               \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return check_launch("hipFuncSetAttribute(wing_rollout)");               \
+    hipLaunchKernelGGL((wing_rollout_lds_kernel<L, LIT, BUF>), grid, block,   \
+                       lds, st, A);                                           \
+  } while (0)
+  if (layout == APG_LAYOUT_SOA && buf_ok) {
+    if (lit) APG_WING_LAUNCH(APG_LAYOUT_SOA, true, true);
+    else APG_WING_LAUNCH(APG_LAYOUT_SOA, false, true);
+  } else if (layout == APG_LAYOUT_SOA) {
+    if (lit) APG_WING_LAUNCH(APG_LAYOUT_SOA, true, false);
+    else APG_WING_LAUNCH(APG_LAYOUT_SOA, false, false);
   } else {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)wing_rollout_lds_kernel<APG_LAYOUT_AOS>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return check_launch("hipFuncSetAttribute(wing_rollout)");
-    hipLaunchKernelGGL(wing_rollout_lds_kernel<APG_LAYOUT_AOS>, grid, block, lds, st, A);
+    if (lit) APG_WING_LAUNCH(APG_LAYOUT_AOS, true, false);
+    else APG_WING_LAUNCH(APG_LAYOUT_AOS, false, false);
   }
+#undef APG_WING_LAUNCH
   if (int e = check_launch("wing_rollout_fwd_bwd")) return e;
   if (loss)
     return launch_reduce_partials(loss_partials, apg_loss_partials_count(B), loss, st);

@@ -730,3 +730,34 @@ def test_conv_gradient_from_window_diagonals():
     dw[:, :3, :] -= shift[:, :, None]
     assert torch.allclose(dw, w.grad, rtol=1e-10, atol=1e-10)
     assert torch.allclose(P.sum((1, 2)), bias.grad, rtol=1e-10, atol=1e-10)
+
+
+def test_product_build_refuses_experiment_macros(monkeypatch):
+    """Kernel-variant macros cannot reach the shipped library: build.py
+    refuses them in APG_HIPCC_FLAGS, the sources #error on them unless the
+    variant builder says -DAPG_EXPERIMENT_BUILD, and no fork that produces
+    wrong results on purpose is left in the product sources."""
+    import subprocess
+    from apg_trajectory_tracking_amd import build as B
+    monkeypatch.setenv("APG_HIPCC_FLAGS", "-g -DAPG_ROWS_REF_LOOK=5")
+    with pytest.raises(RuntimeError, match="must not define kernel macros"):
+        B.build(force=True)
+    monkeypatch.setenv("APG_HIPCC_FLAGS", "-g")
+    assert B._extra_flags() == ["-g"]
+    hdr = os.path.join(B.CSRC, "apg_device.h")
+    base = ["/opt/rocm/bin/hipcc", "--cuda-host-only", "-x", "hip", "-E", "-I",
+            os.path.join(REPO, "include"), hdr, "-o", os.devnull]
+    for macro in ("-DAPG_STAMP", "-DAPG_QX=4", "-DAPG_WING_WAVES=1",
+                  "-DAPG_ROWS_LD_AUX=2"):
+        r = subprocess.run(base + [macro], capture_output=True, text=True)
+        assert r.returncode != 0 and "experiment macro" in r.stderr, macro
+        r = subprocess.run(base + [macro, "-DAPG_EXPERIMENT_BUILD"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    for name in os.listdir(B.CSRC):
+        if name.endswith((".hip", ".h")):
+            text = open(os.path.join(B.CSRC, name)).read()
+            assert "APG_EXP_NO_STORES" not in text.replace(
+                "defined(APG_EXP_NO_STORES)", ""), name
+            assert "APG_MLP_EXP &" not in text, name
+    assert not os.path.exists(os.path.join(REPO, "tools", "exp_mlp.sh"))

@@ -135,6 +135,9 @@ int main(int argc, char **argv) {
   };
   const int B = env("AB_B", 65536), H = env("AB_H", 10), sets = env("AB_SETS", 8),
             iters = env("AB_ITERS", 200);
+  // AB_NO_STATES=1: the comparison runs ask for no states_out (the two-role
+  // packed kernel is only selected then); the states column compares zeros
+  const bool no_states = env("AB_NO_STATES", 0) != 0;
   const int nl = argc - 1;
   std::vector<Lib> L(nl);
   bool any_packed = false;
@@ -226,7 +229,7 @@ int main(int argc, char **argv) {
         CK(hipMemset(so, 0, nO * 4));
         const int rc = L[l].run(x_s0, x_act, x_ref, 6, dt, &par[m], &w, Bq, H,
                                 pk ? APG_LAYOUT_PACKED : APG_LAYOUT_SOA, part, loss,
-                                ga[0], gs, so, nullptr, nullptr);
+                                ga[0], gs, no_states ? nullptr : so, nullptr, nullptr);
         if (rc != 0) {
           std::printf("], \"error\": \"lib %d rc %d: %s\"}\n", l, rc,
                       L[l].err ? L[l].err() : "?");

@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from apg_trajectory_tracking_amd import build as B  # noqa: E402
 
-KERNELS = ["quad_rollout_reg_kernelILi0ELi10ELb0ELb1E",
+KERNELS = ["quad_rollout_reg_kernelILi0ELi10ELb0ELb1E", 
            "quad_rollout_rows_kernelILi10ELb0E"]
 
 
@@ -23,7 +23,7 @@ def main():
     src = os.path.join(B.CSRC, "quad.hip")
     obj = os.path.join(out, f"quad_{name}.o")
     base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
-            "-fPIC", *B.COMMON_FLAGS, *flags, "-I",
+            "-fPIC", *B.COMMON_FLAGS, "-DAPG_EXPERIMENT_BUILD", *flags, "-I",
             os.path.join(REPO, "include"), "-I", B.CSRC]
     subprocess.run(base + ["-c", src, "-o", obj], check=True)
     objs = [os.path.join(B.CSRC, s.replace(".hip", ".o")) for s in B.SOURCES

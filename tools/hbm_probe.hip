@@ -134,6 +134,9 @@ int main() {
   run_rows<28, 10, 0>(65536, 8);
   run_rows<28, 10, 2>(65536, 8);
   run_rows<28, 10, 2>(65536, 16);
+  run_rows<28, 10, 2>(65536, 20);  // bench.py's round-3 protocol (inputs 588 MB)
+  run_rows<28, 0, 2>(65536, 20);   // reads only, from HBM
+  run_rows<1, 10, 2>(65536, 20);
   run_rows<28, 10, 2>(65536, 1);
   run_stream<112, 40, 0, 2>(65536, 16);
   run_stream<112, 40>(65536, 8);
