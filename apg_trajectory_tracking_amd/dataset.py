@@ -27,8 +27,13 @@ class TensorBatches:
     GLOBAL minibatch; every rank holds the same data set, draws the SAME
     permutation (a generator seeded with `shard_seed`, advanced once per
     epoch on every rank) and takes its contiguous slice of each global batch
-    (parallel.shard_range) - so all ranks see the same number of batches and
-    the union of their slices is exactly the single-process batch."""
+    (parallel.shard_range) - so all ranks see the same number of batches and,
+    PROVIDED every rank holds the same data set (same seed / a broadcast: the
+    loader does not check), the union of their slices is the single-process
+    batch.  A ragged last batch with fewer rows than ranks would leave some
+    ranks an EMPTY slice (kernels and the all-reduce expect >= 1 row each): it
+    is dropped on every rank alike (at most world - 1 samples per epoch; the
+    single-process loader keeps it, like the reference's drop_last=False)."""
 
     def __init__(self, tensors, batch_size, shuffle=True, generator=None,
                  shard=None, shard_seed=0):
@@ -51,9 +56,14 @@ class TensorBatches:
         lo, hi = shard_range(idx.shape[0], *self.shard)
         return idx[lo:hi]
 
+    def _too_small(self, rows):
+        """A global batch with fewer rows than ranks (see the class docstring)."""
+        return self.shard is not None and rows < self.shard[1]
+
     def __len__(self):
         n = self.tensors[0].shape[0]
-        return (n + self.batch_size - 1) // self.batch_size
+        full, tail = divmod(n, self.batch_size)
+        return full + (1 if tail and not self._too_small(tail) else 0)
 
     def iter_indices(self):
         """The same batches as __iter__, as index tensors (int64, on the data's
@@ -63,6 +73,8 @@ class TensorBatches:
         dev = self.tensors[0].device
         order = self._permutation(n, dev) if self.shuffle else torch.arange(n, device=dev)
         for lo in range(0, n, self.batch_size):
+            if self._too_small(min(self.batch_size, n - lo)):
+                continue
             yield self._slice(order[lo:lo + self.batch_size])
 
     def _permutation(self, n, dev):
@@ -79,6 +91,8 @@ class TensorBatches:
         if self.shuffle:
             perm = self._permutation(n, dev)
         for lo in range(0, n, self.batch_size):
+            if self._too_small(min(self.batch_size, n - lo)):
+                continue
             if self.shuffle:
                 idx = self._slice(perm[lo:lo + self.batch_size])
                 yield tuple(t.index_select(0, idx) for t in self.tensors)
@@ -108,6 +122,9 @@ class SyntheticQuadDataset:
     by `num_self_play = int(self_play * num_states)` slots that the closed-loop
     evaluation overwrites cyclically with the states it visited
     (`add_eval_data`, the batched form of get_and_add_eval_data :103-119)."""
+
+    _version = 0     # bumped by every in-place change of the tensors
+    _packed = None   # (version, state0 rows, reference rows), see packed()
 
     def __init__(self, num_states, horizon, dt, ref_length=None, seed=0,
                  device="cuda", self_play=0.0):
@@ -143,6 +160,7 @@ class SyntheticQuadDataset:
         for dst, src in zip((self.normed_states, self.states,
                              self.in_ref_states, self.ref_states), self._sample(n)):
             dst[:n] = src
+        self._version += 1
 
     def prepare_data(self, states, ref_states):
         """QuadDataset.prepare_data (:155-204) on device tensors: states [n,12],
@@ -181,7 +199,25 @@ class SyntheticQuadDataset:
                              self.in_ref_states, self.ref_states), prepared):
             dst[idx] = src[n - keep:]
         self.eval_counter += n
+        self._version += 1
         return n
+
+    def packed(self):
+        """The simulation inputs of the whole set as ROWS (`APG_LAYOUT_PACKED`,
+        include/apg.h): state0 [3, N, 4] and the reference's [pos, vel]
+        columns [R, N, 6] - what the fused quadrotor rollout reads with one
+        16-byte access per lane.  Built once per version of the data
+        (resample_data / add_eval_data invalidate it); a minibatch is
+        `index_select(1, index)` of these, the identity batch is the tensors
+        themselves."""
+        if self._packed is None or self._packed[0] != self._version:
+            from . import synthetic
+            r = self.ref_states
+            ref6 = torch.cat((r[:, :, :3], r[:, :, 6:9]), 2)
+            self._packed = (self._version,
+                            synthetic.to_packed_state(self.states),
+                            synthetic.to_packed_seq(ref6))
+        return self._packed[1], self._packed[2]
 
     def __len__(self):
         return self.states.shape[0]

@@ -44,3 +44,18 @@ class Net(nn.Module):
         fully coalesced - no transpose pass in either direction."""
         h = self.trunk(state, ref)
         return torch.addmm(self.fc_out.bias[:, None], self.fc_out.weight, h.t())
+
+    def forward_packed(self, state, ref):
+        """Same network, output as action ROWS: [H, B, nr_actions // H] - the
+        `APG_LAYOUT_PACKED` action tensor of the fused rollout
+        (include/apg.h), i.e. what `forward(...).view(B, H, A).transpose(0, 1)`
+        would give after a copy.  The head is evaluated with the horizon as
+        the BATCH of the GEMM (out[h] = x W_h^T + b_h, W_h = rows h*A..h*A+A of
+        fc_out.weight), so the rows leave rocBLAS in the kernel's layout and
+        dL/dactions comes back the same way: no transpose pass either way."""
+        H = self.horizon
+        A = self.fc_out.out_features // H
+        x = self.trunk(state, ref)                          # [B, 64]
+        w = self.fc_out.weight.view(H, A, -1).transpose(1, 2)   # [H, 64, A]
+        return torch.baddbmm(self.fc_out.bias.view(H, 1, A),
+                             x.unsqueeze(0).expand(H, -1, -1), w)

@@ -272,6 +272,29 @@ class TrainBase:
                 loss = self.train_concurrent_fused(*tensors, index=index).detach()
                 running_loss = loss if running_loss is None else running_loss + loss
             return self._finish_epoch(running_loss, i, train)
+        if (train == "controller" and self.train_mode == "concurrent"
+                and hasattr(self.trainloader, "iter_indices")
+                and getattr(self, "use_packed_path", True)
+                and getattr(self, "packed_path_ok", lambda: False)()):
+            # any PyTorch policy on the row-layout tensors of the fastest
+            # rollout kernel (TrainDrone.train_controller_packed); the
+            # minibatch is a gather of rows out of the data set's cached
+            # packed tensors, the whole-set batch is those tensors themselves
+            normed, _, in_ref, _ = self.trainloader.tensors
+            s0_rows, ref_rows = self.state_data.packed()
+            n = normed.shape[0]
+            for i, index in enumerate(self.trainloader.iter_indices(), 0):
+                whole = (not self.shuffle and index.numel() == n)
+                if whole:
+                    batch = (normed, in_ref, s0_rows, ref_rows)
+                else:
+                    batch = (normed.index_select(0, index),
+                             in_ref.index_select(0, index),
+                             s0_rows.index_select(1, index),
+                             ref_rows.index_select(1, index))
+                loss = self.train_controller_packed(*batch).detach()
+                running_loss = loss if running_loss is None else running_loss + loss
+            return self._finish_epoch(running_loss, i, train)
         if (train == "controller" and self.train_mode != "concurrent"
                 and hasattr(self.trainloader, "iter_indices")
                 and getattr(self, "recurrent_indexed_ok", lambda: False)()):

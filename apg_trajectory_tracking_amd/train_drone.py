@@ -166,6 +166,44 @@ class TrainDrone(TrainBase):
             self.train_dynamics.params, index=index)
         return self._step_direct(loss, grads, flat)
 
+    # ------------------------------------------- packed (row-layout) path --
+    # scripts/train_base.py:198-209 + scripts/train_drone.py:175-203 for ANY
+    # PyTorch policy, on the tensors the fastest rollout kernel reads
+    # (quad_rollout_rows_kernel, APG_LAYOUT_PACKED): the data set keeps its
+    # state0 / reference rows in that layout (SyntheticQuadDataset.packed),
+    # the policy's action sequence is produced as [H, B, 4] rows - by
+    # `forward_packed` when the network has one (the head GEMM batched over
+    # the horizon, no transpose), otherwise by one transposing copy of the
+    # network's [B, 4H] output - and dL/dactions returns to autograd in the
+    # same layout.
+    def packed_path_ok(self):
+        return (self.train_mode == "concurrent" and self.horizon in (5, 10)
+                and self.analytic_train_dynamics()
+                and hasattr(self.state_data, "packed")
+                and self.ref_length == self.horizon)
+
+    def policy_action_rows(self, in_state, in_ref_states):
+        """sigmoid(policy) as action rows [H, B, action_dim]."""
+        net = self.net
+        if hasattr(net, "forward_packed"):
+            return torch.sigmoid(net.forward_packed(in_state, in_ref_states))
+        plan = torch.sigmoid(net(in_state, in_ref_states))
+        return plan.view(-1, self.horizon, self.action_dim).transpose(
+            0, 1).contiguous()
+
+    def train_controller_packed(self, in_state, in_ref_states, state0_rows,
+                                ref_rows):
+        """One optimizer step of the concurrent mode on packed tensors:
+        state0_rows [3, B, 4], ref_rows [H, B, 6] = [pos, vel]; policy inputs
+        in the reference's layout.  Same arithmetic as run_epoch's concurrent
+        body followed by train_controller_model."""
+        self.optimizer_controller.zero_grad()
+        action_rows = self.policy_action_rows(in_state, in_ref_states)
+        loss = F.quad_rollout_loss(
+            state0_rows, action_rows, ref_rows, self.delta_t,
+            self.train_dynamics.params, layout="packed")
+        return self._step(loss)
+
     def _fusable_learnt(self):
         from .dynamics.quad_dynamics_trained import LearntDynamics
         d = self.train_dynamics

@@ -12,13 +12,19 @@ resident in HBM.  Workload = BASELINE.json configs[1]: quadrotor, concurrent
 mode, horizon 10, batch 65 536 synthetic polynomial trajectories per GPU
 (weak scaling: every rank owns its own 65 536-trajectory shard; the
 dynamics-only metric has no cross-rank exchange).
-The timing loop rotates over --sets independent buffer sets so the working
-set (sets x 40 MB) exceeds the 256 MB Infinity Cache (SURVEY.md §8d: 8 sets);
-the same launches over 16 sets (640 MB - the read-only inputs alone no longer
-fit) and over ONE set (cache resident) are reported next to it, labelled.
+The timing loop rotates over --sets independent buffer sets.  Round 3: the
+default is 20 sets, so that the READ-ONLY inputs alone (29.4 MB per set) are
+588 MB > 2 x the 256 MiB Infinity Cache and every launch reads them from HBM
+(with SURVEY.md §8d's 8 sets the 235 MB of inputs stay cache resident: that
+protocol, and the one-set cache-resident launch, are reported next to the
+headline, labelled, never as `value`).
 The K steps are captured into one HIP graph; the graph is replayed R times so
-that the timed region is >= --min-ms (a 20-step region of 0.15 ms would be
-dominated by the replay call itself); `steps` stays K, `config.replays` = R.
+that the timed region is >= --min-ms (1 s: long enough for the driver's
+GPU-activity sampling to see it); `steps` stays K, `config.replays` = R.
+`--dry-run-cpu` executes the rank logic of this file (process group, replay
+agreement, barriers, max over ranks, rank-0 print) under gloo on the CPU with
+a stub in place of the kernels - tests/test_distributed_cpu.py runs it with
+two ranks so that the first multi-GPU run cannot die on plumbing.
 """
 import argparse
 import json
@@ -51,10 +57,12 @@ def parse():
                     help="packed: rows [rows][B][C] (16-byte accesses per lane, "
                          "the fast path); soa: planes [C][B]; aos: the "
                          "reference's row-major tensors")
-    ap.add_argument("--min-ms", type=float, default=5.0,
+    ap.add_argument("--min-ms", type=float, default=1000.0,
                     help="replay the K-step graph until the timed region is "
                          "at least this long")
-    ap.add_argument("--sets", type=int, default=8)
+    ap.add_argument("--sets", type=int, default=20,
+                    help="rotating buffer sets of the headline (20: the read-only "
+                         "inputs alone are 588 MB > 2 x the Infinity Cache)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--grad-state0", action="store_true")
     ap.add_argument("--loss-mode", choices=["deferred", "eager", "none"],
@@ -65,13 +73,13 @@ def parse():
                     help="launch every step from Python instead of replaying "
                          "one captured HIP graph of the K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["dynamics", "ar"], default="dynamics",
-                    help="ar: also report the autoregressive training step "
-                         "(BASELINE configs[2] shape; automatic for --gpus > 1)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline launches (for the rocprofv3 pass whose "
+                         "per-kernel average must not mix protocols)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="rank logic only, gloo on the CPU, stub kernels")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the fixed-wing dual-roofline block")
-    ap.add_argument("--no-wide-sets", action="store_true",
-                    help="skip the informational 2 x --sets measurement")
     ap.add_argument("--train-steps", type=int, default=20,
                     help="steps of the secondary full-training-step "
                          "measurement (0 disables it)")
@@ -189,8 +197,15 @@ def cpu_baseline(args):
     return {
         "c_oracle": c_port,
         "c_oracle_wing": c_wing,
+        # the same two numbers as flat, named fields (all host CPUs, OpenMP)
+        "c_oracle_quad_env_steps_per_s": (c_port or {}).get("value"),
+        "c_oracle_wing_env_steps_per_s": (c_wing or {}).get("value"),
+        "c_oracle_cores": ncpu,
+        "host_logical_cpus": ncpu,
         "value": args.batch * args.horizon * iters / el,
         "unit": "env-steps/s",
+        # threads of THIS (PyTorch-eager) number: the best of the sweep below,
+        # not the size of the host - see host_logical_cpus
         "cores": threads,
         "kind": "port",
         "sample": (f"{iters} iterations of the full B={args.batch} H={args.horizon} "
@@ -203,141 +218,163 @@ def cpu_baseline(args):
     }
 
 
-def train_step_probe(args, dev, dyn, dist):
-    """Secondary, informational: a FULL concurrent-mode training step per rank
-    (policy forward, rollout, loss, backward through dynamics and policy, ONE
-    RCCL all-reduce of the flattened gradient + loss when world > 1, SGD) -
-    reported next to, never instead of, the dynamics-only metric."""
-    from apg_trajectory_tracking_amd import functional as F, synthetic
-    from apg_trajectory_tracking_amd.models.hutter_model import Net
-    from apg_trajectory_tracking_amd.parallel import GradAllReducer
-    from apg_trajectory_tracking_amd.dataset import state_preprocessing
-    from apg_trajectory_tracking_amd.train_base import momentum_sgd
-    H, B = args.horizon, args.batch
-    rank = dist.get_rank() if dist is not None else 0
-    torch.manual_seed(1234)                     # identical replicas
-    net = Net(15, H, 9, 4 * H, conv=1).to(dev)
-    opt = momentum_sgd(net.parameters(), 1e-9)
-    sync = GradAllReducer(net.parameters())
-    d = synthetic.quad_polynomial_batch(B, H, args.dt, seed=args.seed + rank)
-    state0 = d["state0"].to(dev)
-    in_ref = d["in_ref"].to(dev)
-    with torch.no_grad():
-        in_state = state_preprocessing(state0)
-    s0_soa = synthetic.to_soa_state(d["state0"]).to(dev)
-    ref_soa = synthetic.to_soa_seq(d["ref"]).to(dev)
+# ----------------------------------------------------------------------------
+# Training steps (secondary blocks of the line).  Each is the REAL trainer
+# method on this rank's shard and carries its own roofline: the step's MFMA
+# work (policy sweeps in exact fp32 on v_mfma_f32_32x32x2_f32 + the
+# weight-gradient products) against the 157.3 TFLOP/s fp32 matrix peak, its
+# algorithmic plane traffic against 8 TB/s, and the achieved fraction of the
+# LARGER of the two floors.  Per-wave MFMA counts are the kernels' static
+# instruction counts (hipcc -S of csrc/mlp.hip, lstm.hip; one wave = 32
+# trajectories, one MFMA = 32 x 32 x 2 x 2 flop); plane bytes are the planes
+# the sweeps write / read once plus one more read by the products
+# (measured FETCH / WRITE equal these counts).
+FP32_MFMA_PEAK_TFLOPS = 157.3
+STEP_MODELS = {
+    # mode: MFMAs per wave (forward, reverse; per step for the unrolled modes),
+    # plane bytes per env-step and per trajectory
+    "concurrent": dict(mfma_once=586 + 392, mfma_per_step=0,
+                       # 431 + 456 planes of B floats written, read once more
+                       # by the products; inputs: features 60 + in_ref 360 +
+                       # state0 48 + ref 360
+                       bytes_per_traj=(431 + 456) * 4 * 2 + 828, bytes_per_step=0),
+    "autoregressive": dict(mfma_once=0, mfma_per_step=520 + 384,
+                           # fwd 436 planes + states/actions written, reverse
+                           # reads 1 153 B and writes 260 planes per env-step +
+                           # 720 planes per trajectory, products read the 431
+                           # activation + 260 cotangent planes once
+                           bytes_per_step=1808 + 1153 + 1040 + (431 + 260) * 4,
+                           bytes_per_traj=2880 * 2 + 48 + 20 * 72),
+    "LSTM": dict(mfma_once=0, mfma_per_step=228 + 112,
+                 # x 700 + gates 128 + h/c 96 + states/actions 64 written and
+                 # re-read by the reverse sweep, cotangents 144 written, the
+                 # products read x, gates' cotangents and h once more
+                 bytes_per_step=(988 + 924 + 144) + (700 + 128 + 32),
+                 bytes_per_traj=288 * 2 + 48 + 20 * 72),
+}
 
-    ref = d["ref"].to(dev)
-    fused = H == 10          # policy inside the kernels (mlp.hip) for H = 10
 
-    def step():
-        if fused:
-            loss, grads, flat = F.quad_concurrent_policy_grads(
-                net, in_state, state0, in_ref, ref, args.dt, dyn.params)
-            for name, p in net.named_parameters():
-                p.grad = grads.get(name)
-            if dist is not None and dist.get_world_size() > 1:
-                flat[-1] = loss       # gradients + loss: one all-reduce, in place
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                total = flat[-1].clone()
-            else:
-                total = loss
-            opt.step()
-            return total
-        opt.zero_grad()
-        acts = torch.sigmoid(net.forward_soa(in_state, in_ref)).reshape(H, 4, -1)
-        loss = F.quad_rollout_loss(s0_soa, acts, ref_soa, args.dt, dyn.params,
-                                   layout="soa")
-        loss.backward()
-        total = sync.sync(loss.detach())
-        opt.step()
-        return total
+def step_roofline(mode, B, H, n_params, ms):
+    m = STEP_MODELS[mode]
+    waves = (B + 31) // 32
+    sweep_flops = (m["mfma_once"] + m["mfma_per_step"] * H) * 4096.0 * waves
+    cols = B * (H if m["mfma_per_step"] else 1)      # columns of the products
+    product_flops = 2.0 * n_params * cols
+    flops = sweep_flops + product_flops
+    nbytes = float(B) * (m["bytes_per_traj"] + m["bytes_per_step"] * H)
+    mfma_ms = flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+    hbm_ms = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
+    floor = max(mfma_ms, hbm_ms)
+    return {
+        "bound": "mfma" if mfma_ms >= hbm_ms else "hbm",
+        "mfma_fp32": {"flops_per_step": flops, "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS,
+                      "floor_ms": mfma_ms,
+                      "achieved_TFLOPs": flops / (ms * 1e-3) / 1e12},
+        "hbm": {"plane_bytes_per_step": nbytes, "peak_GBps": HBM_PEAK_GBS,
+                "floor_ms": hbm_ms, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9},
+        "frac": floor / ms,
+        "what": "larger of (MFMA flops / 157.3 TF, plane bytes / 8 TB/s) over the "
+                "measured step; exact fp32 throughout",
+    }
+
+
+def timed_steps(step, n, dist):
+    """ms per step of `n` calls, bracketed by barrier + synchronize."""
     for _ in range(3):
-        step()
+        out = step()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.train_steps):
-        total = step()
+    for _ in range(n):
+        out = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    el = time.perf_counter() - t0
-    world = dist.get_world_size() if dist is not None else 1
-    return {
-        "ms_per_step": el / args.train_steps * 1e3,
-        "env_steps_per_s": world * B * H * args.train_steps / el,
-        "allreduce_floats": sum(p.numel() for p in net.parameters()) + 1,
-        "global_loss": float(total.item()),
-        "what": ("policy fwd + rollout + loss + adjoint + policy bwd in the fused "
-                 "kernels (matrix cores), weight-gradient products"
-                 if fused else
-                 "policy fwd (PyTorch-ROCm, SoA head) + fused rollout + policy bwd")
-                + " + RCCL all-reduce(sum) + SGD, per rank batch %d" % B,
-    }
+    return (time.perf_counter() - t0) / n * 1e3, out
 
 
-def ar_train_step_probe(args, dev, dyn, dist):
-    """BASELINE configs[2] shape: the AUTOREGRESSIVE training step per rank
-    (65 536 trajectories per GPU; 524 288 over 8) through the REAL trainer
-    method - TrainDrone.train_recurrent_model: fused policy-in-kernel unroll
-    (mlp.hip), weight-gradient products, then TrainBase._step_direct = ONE
-    in-place all-reduce(sum) of the flat gradient buffer (30 389 floats + the
-    loss slot = 122 KB, RCCL over xGMI when world > 1) and momentum SGD on
-    every replica.  With world > 1 the collective alone is timed as well
-    (it is on the critical path: the next forward needs the updated weights,
-    so there is nothing legal to overlap a single-bucket all-reduce with)."""
+def trainer_step_probe(args, dev, dyn, dist, mode):
+    """One training step per rank through the REAL trainer method
+    (TrainDrone): policy inside the fused kernels (matrix cores), weight-
+    gradient products, ONE in-place all-reduce(sum) of the flat gradient buffer
+    + loss slot when world > 1 (RCCL over xGMI), momentum SGD.
+      concurrent      BASELINE configs[1] as a full step (train_concurrent_fused)
+      autoregressive  configs[2] shape: 65 536 per GPU (train_recurrent_model)
+      LSTM            configs[4] (train_recurrent_model, carried state in-kernel)
+      packed          configs[1] with a policy that is NOT the reference
+                      architecture, through run_epoch's row-layout path
+                      (train_controller_packed -> quad_rollout_rows_kernel)"""
     from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
     from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
     from apg_trajectory_tracking_amd.train_drone import TrainDrone
     H, B = args.horizon, args.batch
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
+    tmode = "concurrent" if mode == "packed" else mode
     cfg = dict(delta_t=args.dt, horizon=H, batch_size=B * world, ref_dim=9,
-               action_dim=4, train_mode="autoregressive",
+               action_dim=4, train_mode=tmode,
                learning_rate_controller=1e-9, system="quad")
     t = TrainDrone(dyn, dyn, cfg)
     torch.manual_seed(4321 + rank)       # init_optimizer broadcasts rank 0's
-    t.net = Net(15, H, 9, 4, conv=1).to(dev)
+    if mode == "LSTM":
+        t.net = LSTM_NEW(15, H, 9, 4, conv=1).to(dev)
+    elif mode == "packed":
+        t.net = PlainPolicy(H).to(dev)
+    else:
+        t.net = Net(15, H, 9, 4 * H if mode == "concurrent" else 4, conv=1).to(dev)
     d = synthetic.quad_polynomial_batch(B, H, args.dt, seed=args.seed + rank,
-                                        ref_length=2 * H)
+                                        ref_length=t.ref_length)
 
     class Shard:     # this rank's shard, resident on the device
         states, in_ref_states, ref_states = (
             d[k].to(dev) for k in ("state0", "in_ref", "ref"))
-        normed_states = states
+    with torch.no_grad():
+        Shard.normed_states = state_preprocessing(Shard.states)
     t.state_data = Shard
     t.init_optimizer()
-
-    def step():
-        return t.train_recurrent_model(None, Shard.states, Shard.in_ref_states,
-                                       Shard.ref_states)
-    for _ in range(3):
-        total = step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.train_steps):
-        total = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    n_msg = sum(p.numel() for p in t.net.parameters() if p.requires_grad) + 1
+    if mode == "packed":
+        ref6 = torch.cat((d["ref"][:, :, :3], d["ref"][:, :, 6:9]), 2)
+        rows = (synthetic.to_packed_state(d["state0"]).to(dev),
+                synthetic.to_packed_seq(ref6).to(dev))
+        step = lambda: t.train_controller_packed(
+            Shard.normed_states, Shard.in_ref_states, *rows)
+    elif mode == "concurrent":
+        step = lambda: t.train_concurrent_fused(
+            Shard.normed_states, Shard.states, Shard.in_ref_states, Shard.ref_states)
+    else:
+        step = lambda: t.train_recurrent_model(
+            None, Shard.states, Shard.in_ref_states, Shard.ref_states)
+    ms, total = timed_steps(step, args.train_steps, dist)
+    n_params = sum(p.numel() for p in t.net.parameters() if p.requires_grad)
     out = {
-        "ms_per_step": el / args.train_steps * 1e3,
-        "env_steps_per_s": world * B * H * args.train_steps / el,
+        "ms_per_step": ms,
+        "env_steps_per_s": world * B * H / (ms * 1e-3),
         "batch_per_gpu": B, "global_batch": world * B,
-        "allreduce_floats": n_msg,
-        "fused": bool(t.fused_policy and t._fusable_mlp()),
+        "allreduce_floats": n_params + 1,
         "global_loss": float(total.item()),
-        "what": "TrainDrone.train_recurrent_model (autoregressive, policy inside "
-                "the kernels) + flat-buffer all-reduce(sum) + SGD",
     }
-    if world > 1:
-        buf = torch.zeros(n_msg, device=dev)
+    if mode == "packed":
+        out["what"] = ("TrainDrone.train_controller_packed: PyTorch policy (not the "
+                       "reference architecture) -> [H, B, 4] action rows -> "
+                       "quad_rollout_rows_kernel -> policy backward (rocBLAS) + SGD")
+    else:
+        fused = {"concurrent": t.train_concurrent_fused(None, None, None, None, probe=True),
+                 "autoregressive": t.fused_policy and t._fusable_mlp(),
+                 "LSTM": t.fused_policy and t._fusable()}[mode]
+        out["fused"] = bool(fused)
+        out["what"] = {
+            "concurrent": "TrainDrone.train_concurrent_fused",
+            "autoregressive": "TrainDrone.train_recurrent_model (autoregressive)",
+            "LSTM": "TrainDrone.train_recurrent_model (LSTM)"}[mode] + (
+            ": policy inside the kernels + weight-gradient products + flat-buffer "
+            "all-reduce(sum) + SGD")
+        if fused and H == 10:
+            out["roofline"] = step_roofline(mode, B, H, n_params, ms)
+    if world > 1 and mode == "autoregressive":
+        buf = torch.zeros(n_params + 1, device=dev)
         for _ in range(5):
             dist.all_reduce(buf)
         torch.cuda.synchronize()
@@ -348,6 +385,20 @@ def ar_train_step_probe(args, dev, dyn, dist):
         torch.cuda.synchronize()
         out["allreduce_us_alone"] = (time.perf_counter() - t0) / 50 * 1e6
     return out
+
+
+class PlainPolicy(torch.nn.Module):
+    """A policy that is not the reference architecture (for `train_step_packed`)."""
+
+    def __init__(self, horizon):
+        super().__init__()
+        self.a = torch.nn.Linear(15 + horizon * 9, 64)
+        self.b = torch.nn.Linear(64, 64)
+        self.c = torch.nn.Linear(64, 4 * horizon)
+
+    def forward(self, state, ref):
+        x = torch.cat((state, ref.flatten(1)), 1)
+        return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
 
 
 KERNEL_SOURCES = ("quad.hip", "quad_math.h", "apg_device.h")
@@ -369,9 +420,13 @@ def kernel_build_id(sources=KERNEL_SOURCES):
 
 
 def load_pmc_traffic(args):
-    """(HBM bytes per launch, note): the committed rocprofv3 PMC pass of this
-    very command (profiles/pmc_traffic.json) - only if it was taken on THIS
-    build of the kernel (entry["kernel_build"] == kernel_build_id())."""
+    """(L2 <-> fabric bytes per launch, note): the committed rocprofv3 PMC pass
+    of this very command (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE,
+    calibrated) - only if it was taken on THIS build of the kernel and on this
+    buffer-set protocol.  These counters sit on the L2's memory side, so
+    Infinity-Cache hits are counted too (MI355X_MICROARCH.md §HBM): the number
+    shows over-fetch (ratio to the algorithmic bytes), not where the bytes
+    came from - the buffer-set protocol takes care of that."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     key = f"quad_B{args.batch}_H{args.horizon}_{args.layout}"
     try:
@@ -385,7 +440,8 @@ def load_pmc_traffic(args):
     if entry.get("kernel_build") != build:
         return None, (f"PMC entry is for kernel build {entry.get('kernel_build')}, "
                       f"this is {build}: stale, not reported")
-    return entry.get("hbm_bytes_per_launch"), f"PMC pass on kernel build {build}"
+    return (entry.get("l2_fabric_bytes_per_launch"),
+            f"PMC pass on kernel build {build}, {entry.get('buffer_sets')} buffer sets")
 
 
 def wing_secondary(args, dev):
@@ -441,17 +497,100 @@ def wing_secondary(args, dev):
             "achieved_wave_instr_per_s": n_valu / sec,
             "peak_wave_instr_per_s": FP32_VALU_WAVE_INSTR_PER_S,
             "frac": n_valu / sec / FP32_VALU_WAVE_INSTR_PER_S,
-            # the peak above needs two waves of a SIMD issuing in each other's
-            # gaps, which the hardware only does for VALU ops whose operands
-            # are all VGPRs / literals: an op with an SGPR operand (every
-            # aerodynamic coefficient here) or a transcendental takes the SIMD
-            # alone (profiles/r02_issue_probe_coissue.jsonl) - one wave
-            # instruction per 4 cycles is the rate this instruction mix can get
             "frac_of_single_issue_rate": n_valu / sec / (FP32_VALU_WAVE_INSTR_PER_S / 2),
             "kernel_build": build}
     else:
         out["fp32_valu_note"] = f"no PMC entry for wing kernel build {build}"
     return out
+
+
+# ----------------------------------------------------------------------------
+# Rank plumbing shared by the real run and --dry-run-cpu
+def agree_replays(replays, dist, dev):
+    """Every rank must run the same number of graph replays."""
+    if dist is None:
+        return replays
+    t = torch.tensor([replays], device=dev, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def max_over_ranks(seconds, dist, dev):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def headline_fields(args, world, nsteps, elapsed, replays, nset):
+    """The contract's top-level fields (BASELINE.json metric / config)."""
+    H, B = args.horizon, args.batch
+    return {
+        "metric": "env-steps/sec (fwd+bwd through dynamics), quad horizon=10 batch=65536",
+        "value": world * B * H * nsteps / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / nsteps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("quadrotor concurrent rollout fwd+bwd (dynamics + "
+                         "quad_mpc_loss + adjoint), BASELINE configs[1]"),
+            "batch_per_gpu": B, "global_batch": world * B, "horizon": H,
+            "dt": args.dt, "layout": args.layout, "buffer_sets": nset,
+            "input_bytes_all_sets": nset * B * (48 + 40 * H),
+            "grad_state0": bool(args.grad_state0),
+            "loss_mode": args.loss_mode,
+            "launch": "python" if args.no_graph else "hip-graph replay of the K steps",
+            "replays": replays, "timed_steps": nsteps,
+            "parallelism": f"batch-sharded x{world}, no data-path collective",
+        },
+    }
+
+
+def dry_run_cpu(args, dist, rank, world):
+    """The rank logic of main() without a GPU: same process-group calls, same
+    replay agreement, barriers and max over ranks; the 'step' is a stub that
+    sleeps.  The line is marked `dry_run` - its numbers mean nothing."""
+    dev = torch.device("cpu")
+    stub = lambda n: time.sleep(2e-5 * n * (1 + rank))   # ranks differ on purpose
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def timed(n, replays):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            stub(n)
+        barrier()
+        return time.perf_counter() - t0
+    stub(args.warmup)
+    probe = timed(args.steps, 1)
+    replays = max(1, min(50, int(-(-min(args.min_ms, 20.0) // max(probe * 1e3, 1e-3)))))
+    replays = agree_replays(replays + rank, dist, dev)   # unequal proposals
+    elapsed = max_over_ranks(timed(args.steps, replays), dist, dev)
+    nsteps = args.steps * replays
+    out = headline_fields(args, world, nsteps, elapsed, replays, args.sets)
+    out["dry_run"] = True
+    out["roofline"] = None
+    out["cpu_baseline"] = None
+    if dist is not None:
+        # the collective of the training steps: flat gradient buffer + loss slot
+        flat = torch.full((30389 + 1,), float(rank + 1))
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        out["allreduce_check"] = float(flat[-1]) == world * (world + 1) / 2
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def main():
@@ -464,15 +603,23 @@ def main():
             raise SystemExit(
                 "--gpus N > 1 must be launched with torch.distributed.run "
                 "(one process per GPU)")
+    launched = world > 1 or "RANK" in os.environ   # by torch.distributed.run
+    if launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+    if args.dry_run_cpu:
+        dist = None
+        if launched:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        return dry_run_cpu(args, dist, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run
+    if launched:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)
 
     from apg_trajectory_tracking_amd import functional as F
@@ -555,15 +702,9 @@ def main():
     # one untimed pass (graph upload, clocks) that also sizes the region
     _, probe_ms = timed(run_steps, args.steps, g_steps, 1)
     replays = max(1, int(-(-args.min_ms // max(probe_ms, 1e-3))))
-    if dist is not None:     # every rank must run the same number of replays
-        t = torch.tensor([replays], device=dev, dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        replays = int(t.item())
+    replays = agree_replays(replays, dist, dev)
     elapsed, ev_ms = timed(run_steps, args.steps, g_steps, replays)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist, dev)
     loss_check = float(plans[0].out["loss"].item())
     nsteps = args.steps * replays
 
@@ -575,15 +716,15 @@ def main():
         run_kernel_only(min(args.warmup, 10))
     _, k_ms = timed(run_kernel_only, args.steps, g_kernel, replays)
     kernel_ms = k_ms / nsteps
-    # the same launch on ONE buffer set: inputs stay in the 256 MB Infinity
-    # Cache - reported, labelled, never used for `value` or the roofline
+
     def events_over(launches):
+        """average launch duration over a SUBSET of the buffer sets"""
         torch.cuda.synchronize()
         k0 = torch.cuda.Event(enable_timing=True)
         k1 = torch.cuda.Event(enable_timing=True)
-        n = max(nsteps, 200)
+        n = 2000
         with torch.cuda.stream(side):
-            for i in range(20):
+            for i in range(40):
                 launches[i % len(launches)].launch()
             k0.record()
             for i in range(n):
@@ -591,59 +732,52 @@ def main():
             k1.record()
         torch.cuda.synchronize()
         return k0.elapsed_time(k1) / n
-    resident_ms = events_over(kplans[:1])
-    # ... and over twice as many sets (the read-only inputs of 8 sets, 235 MB,
-    # still fit the Infinity Cache; those of 16 do not)
-    wide_ms = None
-    if not args.no_wide_sets:
-        try:
-            more = make_sets(args, rank, dev, nsets=nset, first=nset)
-            with torch.cuda.stream(side):
-                wplans = kplans + [
-                    F.RolloutPlan("quad", *s, args.dt, dyn.params,
-                                  layout=args.layout,
-                                  want_grad_state0=args.grad_state0,
-                                  loss_mode="none") for s in more]
-            wide_ms = events_over(wplans)
-            del wplans, more
-        except Exception as e:     # informational only (e.g. out of memory)
-            wide_ms = None
-    # informational: the same launches as TWO independent chains of one graph
-    # (even / odd buffer sets on two streams).  The batches are independent, so
-    # the next launch's waves can move into SIMDs the current launch's early
-    # finishers have left: the tail of one launch and the kernel boundary
-    # overlap the head of the next.  Never used for `value` or the roofline
-    # (those stay one launch after the other, as rocprof sees them).
+    other_protocols = {}
     overlap_ms = None
-    if not args.no_graph and nset >= 2:
-        try:
-            side2 = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(side2):
-                oplans = [F.RolloutPlan("quad", *s, args.dt, dyn.params,
-                                        layout=args.layout,
-                                        want_grad_state0=args.grad_state0,
-                                        loss_mode="none") for s in sets[1::2]]
-            eplans = kplans[0::2]
+    if not args.headline_only:
+        # labelled secondaries: SURVEY §8d's 8 sets (read-only inputs 235 MB:
+        # Infinity-Cache resident) and ONE set (everything cache resident)
+        for k in (8, 1):
+            if k < nset:
+                ms = events_over(kplans[:k])
+                other_protocols[f"{k}_sets"] = {
+                    "kernel_us_avg": ms * 1e3, "launch": "python, HIP events",
+                    "input_bytes_all_sets": k * args.batch * (48 + 40 * args.horizon),
+                    "note": "inputs (partly) Infinity-Cache resident: NOT an HBM number"}
+        # informational: the same launches as TWO independent chains of one
+        # graph (even / odd buffer sets on two streams): the tail of one launch
+        # and the kernel boundary overlap the head of the next.  Never used
+        # for `value` or the roofline.
+        if not args.no_graph and nset >= 2:
+            try:
+                side2 = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(side2):
+                    oplans = [F.RolloutPlan("quad", *s, args.dt, dyn.params,
+                                            layout=args.layout,
+                                            want_grad_state0=args.grad_state0,
+                                            loss_mode="none") for s in sets[1::2]]
+                eplans = kplans[0::2]
 
-            def run_two_chains(n):
-                fork = torch.cuda.Event()
-                fork.record(side)
-                side2.wait_event(fork)
-                for i in range(n):
-                    (eplans if i % 2 == 0 else oplans)[(i // 2) % len(eplans)].launch()
-                join = torch.cuda.Event()
-                join.record(side2)
-                side.wait_event(join)
+                def run_two_chains(n):
+                    fork = torch.cuda.Event()
+                    fork.record(side)
+                    side2.wait_event(fork)
+                    for i in range(n):
+                        (eplans if i % 2 == 0 else oplans)[(i // 2) % len(oplans)].launch()
+                    join = torch.cuda.Event()
+                    join.record(side2)
+                    side.wait_event(join)
 
-            with torch.cuda.stream(side):
-                run_two_chains(4)
-            torch.cuda.synchronize()
-            g_two = graph_of(run_two_chains, args.steps)
-            _, o_ms = timed(run_two_chains, args.steps, g_two, replays)
-            overlap_ms = o_ms / nsteps
-            del g_two
-        except Exception:        # informational only
-            overlap_ms = None
+                with torch.cuda.stream(side):
+                    run_two_chains(4)
+                torch.cuda.synchronize()
+                g_two = graph_of(run_two_chains, args.steps)
+                o_replays = max(1, replays // 10)
+                _, o_ms = timed(run_two_chains, args.steps, g_two, o_replays)
+                overlap_ms = o_ms / (args.steps * o_replays)
+                del g_two
+            except Exception:        # informational only
+                overlap_ms = None
     gc.enable()
 
     H, B = args.horizon, args.batch
@@ -652,51 +786,29 @@ def main():
     algo_bytes = B * bytes_per_traj
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_note = load_pmc_traffic(args)
-    out = {
-        "metric": "env-steps/sec (fwd+bwd through dynamics), quad horizon=10 batch=65536",
-        "value": world * B * H * nsteps / elapsed,
-        "unit": "env-steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / nsteps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": ("quadrotor concurrent rollout fwd+bwd (dynamics + "
-                         "quad_mpc_loss + adjoint), BASELINE configs[1]"),
-            "batch_per_gpu": B, "global_batch": world * B, "horizon": H,
-            "dt": args.dt, "layout": args.layout, "buffer_sets": nset,
-            "grad_state0": bool(args.grad_state0),
-            "loss_mode": args.loss_mode,
-            "launch": "python" if args.no_graph else "hip-graph replay of the K steps",
-            "replays": replays, "timed_steps": nsteps,
-            "parallelism": f"batch-sharded x{world}, no data-path collective",
-        },
-        "ms_per_step_hip_events": ev_ms / nsteps,
-        "roofline": {
-            "bound": "hbm",
-            "kernel": {"packed": "quad_rollout_rows_kernel",
-                       "soa": "quad_rollout_reg_kernel",
-                       "aos": "quad_rollout_aos_kernel"}[args.layout],
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_note": traffic_note,
-            "kernel_build": kernel_build_id(),
-            "algorithmic_bytes_per_launch": algo_bytes,
-            "kernel_us_avg": kernel_ms * 1e3,
-            "kernel_us_avg_cache_resident": resident_ms * 1e3,
-            "kernel_us_avg_2x_sets": None if wide_ms is None else wide_ms * 1e3,
-            "frac_2x_sets": (None if wide_ms is None else
-                             algo_bytes / (wide_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
-        },
-        "loss_check": loss_check,
+    out = headline_fields(args, world, nsteps, elapsed, replays, nset)
+    out["ms_per_step_hip_events"] = ev_ms / nsteps
+    out["roofline"] = {
+        "bound": "hbm",
+        "kernel": {"packed": "quad_rollout_rows_kernel",
+                   "soa": "quad_rollout_reg_kernel",
+                   "aos": "quad_rollout_aos_kernel"}[args.layout],
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_what": ("L2 <-> fabric bytes per launch (rocprofv3 FETCH_SIZE + "
+                         "WRITE_SIZE, calibrated; Infinity-Cache hits are counted "
+                         "too): over-fetch check, not a residency proof"),
+        "traffic_note": traffic_note,
+        "kernel_build": kernel_build_id(),
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "kernel_us_avg": kernel_ms * 1e3,
+        "buffer_sets": nset,
+        "other_protocols": other_protocols,
     }
+    out["loss_check"] = loss_check
     if overlap_ms is not None:
         out["overlapped_launches"] = {
             "streams": 2, "ms_per_step": overlap_ms,
@@ -705,24 +817,24 @@ def main():
             "what": "informational: the K kernel-only launches as two independent "
                     "chains of one graph (even / odd buffer sets); `value` and "
                     "`roofline` are the serial launches"}
-    if args.train_steps > 0:
-        try:
-            out["train_step"] = train_step_probe(args, dev, dyn, dist)
-        except Exception as e:      # informational only
-            out["train_step"] = {"error": repr(e)}
-    # the configs[2]-shaped block: always with more than one GPU, on request
-    # (--mode ar) on one
-    if args.train_steps > 0 and (world > 1 or args.mode == "ar"):
-        try:
-            out["train_step_ar"] = ar_train_step_probe(args, dev, dyn, dist)
-        except Exception as e:      # informational only
-            out["train_step_ar"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_secondary:
+    del plans, kplans, sets, g_steps, g_kernel
+    gc.collect()
+    torch.cuda.empty_cache()
+    if args.train_steps > 0 and not args.headline_only:
+        for key, mode in (("train_step", "concurrent"),
+                          ("train_step_packed", "packed"),
+                          ("train_step_ar", "autoregressive"),
+                          ("train_step_lstm", "LSTM")):
+            try:
+                out[key] = trainer_step_probe(args, dev, dyn, dist, mode)
+            except Exception as e:      # secondary blocks must not kill the line
+                out[key] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not (args.no_secondary or args.headline_only):
         try:
             out["secondary"] = {"wing_rollout": wing_secondary(args, dev)}
         except Exception as e:      # informational only
             out["secondary"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.headline_only):
         out["cpu_baseline"] = cpu_baseline(args)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -314,3 +314,34 @@ def test_tensor_batches_shards_partition_every_global_batch():
             b = TensorBatches(data, 16, shuffle=shuffle, shard=(r, world), shard_seed=3)
             for (x,), idx in zip(a, b.iter_indices()):
                 assert x.tolist() == idx.tolist()
+
+
+def test_bench_rank_logic_under_gloo_with_two_ranks():
+    """`bench.py --gpus 2 --dry-run-cpu` under torch.distributed.run: the file's
+    own rank plumbing (process group from the launcher's environment, replay
+    agreement, barriers, max over ranks, the flat-buffer all-reduce, rank-0
+    print) runs on two CPU ranks and yields exactly ONE contract line."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(_free_port()), os.path.join(repo, "bench.py"),
+         "--gpus", "2", "--dry-run-cpu", "--steps", "5", "--warmup", "2"],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 5
+    assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"]
+    # rank 1 proposed one replay more than rank 0: the maximum was agreed on
+    assert d["config"]["replays"] >= 2
+    assert d["config"]["timed_steps"] == 5 * d["config"]["replays"]
+    assert abs(d["value"] - 2 * 65536 * 10 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["allreduce_check"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None

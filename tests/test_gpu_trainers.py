@@ -1215,3 +1215,105 @@ def test_self_play_matches_the_reference_evaluator_gpu(dev, case):
         assert got.is_cuda
         assert rel_err(N(got[sl]), g[f"{case}.{name}"]) < 2e-4, name
     assert torch.count_nonzero(data.states[:n_s]) == 0     # sampled part untouched
+
+
+def test_quad_packed_path_two_sgd_steps(dev):
+    """G3 (scripts/train_drone.py:175-203 recorded from the real TrainDrone)
+    through the row-layout path: Net.forward_packed -> [H, B, 4] action rows ->
+    quad_rollout_rows_kernel (APG_LAYOUT_PACKED) -> dL/dactions rows back into
+    the head's backward.  Loss, every gradient, post-SGD weights of two steps."""
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    g = load_golden("quad_train.npz")
+    trainer = make_trainer(TrainDrone, FlightmareDynamics(), QUAD_CFG)
+    net = Net(15, 10, 9, 40, conv=1)
+    load_weights(net, g, "w0.")
+    trainer.net = net.to(dev)
+    trainer.optimizer_controller = torch.optim.SGD(
+        trainer.net.parameters(), lr=float(g["lr"]), momentum=float(g["momentum"]))
+    in_state, in_ref = D(g["in_state"], dev), D(g["in_ref"], dev)
+    s0_rows = synthetic.to_packed_state(D(g["state0"], dev))
+    ref = D(g["ref"], dev)
+    ref_rows = synthetic.to_packed_seq(torch.cat((ref[:, :, :3], ref[:, :, 6:9]), 2))
+    for step in (1, 2):
+        loss = trainer.train_controller_packed(in_state, in_ref, s0_rows, ref_rows)
+        assert abs(loss.item() - g[f"loss{step}"]) / g[f"loss{step}"] < 1e-5
+        if step == 1:
+            for k, p in trainer.net.named_parameters():
+                if "g1." + k in g.files:
+                    assert rel_err(N(p.grad), g["g1." + k]) < 1e-4, k
+        for k, v in trainer.net.state_dict().items():
+            assert rel_err(N(v), g[f"w{step}.{k}"]) < 1e-5, (step, k)
+
+
+class _PlainPolicy(torch.nn.Module):
+    """Not the reference architecture (no conv branch, relu, other widths):
+    what `run_epoch` must still drive through the fast kernel."""
+
+    def __init__(self, horizon=10):
+        super().__init__()
+        self.a = torch.nn.Linear(15 + horizon * 9, 48)
+        self.b = torch.nn.Linear(48, 4 * horizon)
+
+    def forward(self, state, ref):
+        x = torch.cat((state, ref.flatten(1)), 1)
+        return self.b(torch.relu(self.a(x)))
+
+
+def test_run_epoch_packed_path_with_an_arbitrary_policy(dev):
+    """run_epoch with a PyTorch policy that is NOT the reference architecture:
+    the epoch goes through TrainDrone.train_controller_packed (row-layout
+    tensors, quad_rollout_rows_kernel) and reproduces - epoch loss and every
+    weight after three optimizer steps - the reference-layout (AoS) path."""
+    from apg_trajectory_tracking_amd.dataset import SyntheticQuadDataset
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    import apg_trajectory_tracking_amd.functional as F
+    cfg = dict(QUAD_CFG, batch_size=256, learning_rate_controller=1e-7)
+    torch.manual_seed(5)
+    proto = _PlainPolicy()
+    results = []
+    for packed in (True, False):
+        t = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
+        t.state_data = SyntheticQuadDataset(700, 10, 0.1, seed=11, device=dev)
+        t.net = _PlainPolicy().to(dev)
+        t.net.load_state_dict(proto.state_dict())
+        t.shuffle = False
+        t.use_packed_path = packed
+        t.init_optimizer()
+        assert t.packed_path_ok()
+        calls = []
+        real = F.quad_rollout_fwd_bwd
+
+        def spy(*a, **kw):
+            calls.append(kw.get("layout", "aos"))
+            return real(*a, **kw)
+        F.quad_rollout_fwd_bwd = spy
+        try:
+            loss = t.run_epoch(train="controller", epoch=0)
+        finally:
+            F.quad_rollout_fwd_bwd = real
+        assert calls == (["packed"] * 3 if packed else ["aos"] * 3), calls
+        results.append((loss, {k: N(v) for k, v in t.net.state_dict().items()}))
+    (l_p, w_p), (l_a, w_a) = results
+    assert abs(l_p - l_a) / abs(l_a) < 1e-5
+    for k in w_a:
+        assert rel_err(w_p[k], w_a[k]) < 1e-5, k
+    # the whole-set batch is the cached packed tensors themselves (no gather)
+    t = make_trainer(TrainDrone, FlightmareDynamics(), dict(cfg, batch_size=700))
+    t.state_data = SyntheticQuadDataset(700, 10, 0.1, seed=11, device=dev)
+    t.net = _PlainPolicy().to(dev)
+    t.shuffle = False
+    t.init_optimizer()
+    seen = []
+    real = t.train_controller_packed
+    t.train_controller_packed = lambda *a: (seen.append(a), real(*a))[1]
+    with pytest.raises(ZeroDivisionError):   # one batch: running_loss / 0, as upstream
+        t.run_epoch(train="controller", epoch=0)
+    s0_rows, ref_rows = t.state_data.packed()
+    assert seen[0][2].data_ptr() == s0_rows.data_ptr()
+    assert seen[0][3].data_ptr() == ref_rows.data_ptr()

@@ -761,3 +761,62 @@ def test_product_build_refuses_experiment_macros(monkeypatch):
                 "defined(APG_EXP_NO_STORES)", ""), name
             assert "APG_MLP_EXP &" not in text, name
     assert not os.path.exists(os.path.join(REPO, "tools", "exp_mlp.sh"))
+
+
+def test_sharded_loader_drops_a_tail_smaller_than_the_world():
+    """a ragged last global batch with fewer rows than ranks would
+    hand some rank an empty slice; it is dropped on every rank alike, larger
+    tails are split as before."""
+    from apg_trajectory_tracking_amd.dataset import TensorBatches
+    a = torch.arange(18.)[:, None]
+    for world, expect in ((4, [8, 8]), (2, [8, 8, 2])):
+        per_rank = []
+        for r in range(world):
+            tb = TensorBatches((a,), 8, shuffle=True, shard=(r, world), shard_seed=3)
+            assert len(tb) == len(expect)
+            per_rank.append([i for i in tb.iter_indices()])
+            assert all(i.numel() > 0 for i in per_rank[-1])
+        sizes = [sum(p[b].numel() for p in per_rank) for b in range(len(expect))]
+        assert sizes == expect
+    # single process: nothing is dropped
+    assert [i.numel() for i in TensorBatches((a,), 8, shuffle=False).iter_indices()] \
+        == [8, 8, 2]
+
+
+def test_packed_rows_of_policy_and_dataset():
+    """Host side of the row-layout training path: Net.forward_packed equals the
+    transposed forward (values and gradients), the data set's packed cache
+    follows in-place changes."""
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd import dataset as ds, synthetic
+    torch.manual_seed(3)
+    net = Net(15, 10, 9, 40, conv=1)
+    s, r = torch.randn(9, 15), torch.randn(9, 10, 9)
+    a = net(s, r).view(9, 10, 4).transpose(0, 1)
+    b = net.forward_packed(s, r)
+    assert b.shape == (10, 9, 4) and b.is_contiguous()
+    assert torch.allclose(a, b, atol=1e-6)
+    g = torch.randn(10, 9, 4)
+    ga = torch.autograd.grad((a * g).sum(), list(net.parameters()), allow_unused=True)
+    gb = torch.autograd.grad((b * g).sum(), list(net.parameters()), allow_unused=True)
+    for x, y in zip(ga, gb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert torch.allclose(x, y, atol=1e-5)
+
+    class Cpu(ds.SyntheticQuadDataset):      # the features need no kernel here
+        def _sample(self, n):
+            d = synthetic.quad_polynomial_batch(
+                n, self.horizon, self.dt, seed=self.seed + self._epoch,
+                ref_length=self.ref_length)
+            return (torch.zeros(n, 15), d["state0"], d["in_ref"], d["ref"])
+    d = Cpu(32, 10, 0.1, seed=1, device="cpu")
+    s0, ref = d.packed()
+    assert s0.shape == (3, 32, 4) and ref.shape == (10, 32, 6)
+    assert torch.equal(synthetic.from_packed_state(s0), d.states)
+    assert torch.equal(ref[:, :, :3], d.ref_states[:, :, :3].transpose(0, 1))
+    assert torch.equal(ref[:, :, 3:], d.ref_states[:, :, 6:9].transpose(0, 1))
+    assert d.packed()[0] is s0               # cached
+    d.resample_data()
+    s1, _ = d.packed()
+    assert s1 is not s0 and torch.equal(synthetic.from_packed_state(s1), d.states)

@@ -156,6 +156,15 @@ def main():
             t._step(loss)
         emit("quad_train_step_soa_head", B, H, timed(step_soa, 30, 5))
 
+        # row-layout path (run_epoch's branch for ANY PyTorch policy): the data
+        # set's cached packed tensors, Net.forward_packed -> [H, B, 4] rows ->
+        # quad_rollout_rows_kernel
+        rows = d.packed()
+
+        def step_packed():
+            t.train_controller_packed(d.normed_states, d.in_ref_states, *rows)
+        emit("quad_train_step_packed_rows", B, H, timed(step_packed, 30, 5))
+
         def step_fused():      # policy inside the kernels
             t.train_concurrent_fused(d.normed_states, d.states, d.in_ref_states,
                                      d.ref_states)

@@ -108,7 +108,11 @@ void run_floor(int grid, int block) {
   CK(hipFree(out));
 }
 
-int main() {
+int main(int argc, char **argv) {
+  if (argc > 1) {  // "calib": only the stream the PMC passes are calibrated on
+    run_rows<28, 10, 2>(65536, 20);
+    return 0;
+  }
   run_floor(1024, 64); run_floor(512, 128); run_floor(256, 256); run_floor(256, 64);
   run_floor(2048, 64); run_floor(64, 64); run_floor(1, 64); run_floor(1024, 256);
   {
