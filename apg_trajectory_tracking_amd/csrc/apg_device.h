@@ -26,7 +26,8 @@
      defined(APG_REG_ACT_PRE) || defined(APG_REG_REF_PER_STEP) ||              \
      defined(APG_REG_REF_LOOK) || defined(APG_GEMM_ST_MAX) ||                  \
      defined(APG_GEMM_STREAM) || defined(APG_WING_WAVES) ||                    \
-     defined(APG_WING_GROUP_PREFETCH) || defined(APG_WING_LITERALS))
+     defined(APG_WING_GROUP_PREFETCH) || defined(APG_WING_LITERALS) ||        \
+     defined(APG_WING_PK) || defined(APG_WING_PK_KMODE))
 #error "experiment macro in a product build (variants: -DAPG_EXPERIMENT_BUILD, tools/build_variant.py)"
 #endif
 
@@ -256,6 +257,20 @@ __host__ __device__ __forceinline__ float sqrt_fast(float x) {
 #else
   return sqrtf(x);
 #endif
+}
+
+// Two values per lane (the fixed-wing kernels' two-trajectories-per-lane
+// form, wing_math.h): component-wise forms of the helpers above, in THIS
+// namespace so that overload resolution sees them next to the scalar ones.
+typedef float fx2 __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ fx2 rcp_nr(fx2 x) {
+  return (fx2){rcp_nr(x.x), rcp_nr(x.y)};
+}
+__host__ __device__ __forceinline__ fx2 rcp_nr_finite(fx2 x) {
+  return (fx2){rcp_nr_finite(x.x), rcp_nr_finite(x.y)};
+}
+__host__ __device__ __forceinline__ fx2 sqrt_fast(fx2 x) {
+  return (fx2){sqrt_fast(x.x), sqrt_fast(x.y)};
 }
 
 // ---- wave64 reduction -------------------------------------------------------

@@ -29,8 +29,6 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// tanh: 1 - 2 / (exp(2|x|) + 1), odd Taylor polynomial below 0.15 where the
-// subtraction would cancel.  <= ~1e-6 relative.
 // tanh(x) = 1 - 2 / (1 + e^(2x)): one v_exp and one v_rcp, no select.  Exact
 // limits (e -> inf: 1, e -> 0: -1); absolute error <= 2e-7 everywhere (near 0
 // the subtraction cancels, so the RELATIVE error of tiny outputs is larger -

@@ -299,6 +299,211 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
 #undef APG_LAUNDER
 }
 
+// ------------------------------------------------ two trajectories per lane --
+// The same rollout with T = fx2 (wing_math.h): lane l of wave w integrates
+// trajectories 128 w + 2 l and + 1.  Plane layout ([C][B], B even): the two
+// floats of a lane are adjacent, so every load / store is one 8-byte buffer
+// access per lane (512 B per wave instruction, fully coalesced).  B = 131 072
+// is then 1 024 waves = ONE wave per SIMD: packed fp32 issues at the single-
+// wave rate, transcendentals cost 8 cycles instead of the ~23 they cost each
+// of two co-resident waves (profiles/r03_issue_probe2.jsonl), and up to 512
+// registers per lane hold what the two trajectories keep live.
+// KMODE: where the ~70 coefficients come from.  0: the kernel-argument table,
+// read with scalar loads where used (as the one-per-lane kernel does);
+// 1: instruction literals of the default parameter set (a packed op cannot
+// encode a literal, so each becomes an s_mov into an SGPR operand);
+// 2: VGPR-resident for the whole kernel (no scalar traffic, but with two
+// trajectories per lane the 256 architectural VGPRs are full: the table ends
+// up in AGPRs and every use costs a v_accvgpr_read - measured, not shipped).
+template <int KMODE>
+__global__ __launch_bounds__(64) void wing_rollout_pk_kernel(WingRolloutArgs A) {
+  extern __shared__ fx2 stash2[];
+  typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x;
+  const int pr = blockIdx.x * 64 + lane;     // pair of trajectories
+  const int npairs = A.B >> 1;
+  const bool live = pr < npairs;
+  const int vld = (live ? pr : npairs - 1) * 8;
+  const int vst = live ? pr * 8 : (int)0x80000000;   // dead lanes: out of range
+  const int pitch = A.B * 4;
+  const auto rs = [&](const void *p, int planes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0,
+                                             planes * A.B * 4, 0x00020000);
+  };
+  const auto r_s0 = rs(A.state0, 12), r_act = rs(A.actions, A.H * 4),
+             r_ref = rs(A.ref, A.H * 3), r_ga = rs(A.grad_actions, A.H * 4),
+             r_so = rs(A.states_out, A.H * 12), r_gs = rs(A.grad_state0, 12);
+  auto ld2 = [&](__amdgpu_buffer_rsrc_t r, int plane) {
+    return __builtin_bit_cast(
+        fx2, __builtin_amdgcn_raw_buffer_load_b64(r, vld, plane * pitch, 0));
+  };
+  auto st2 = [&](__amdgpu_buffer_rsrc_t r, int plane, fx2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v_, v), r, vst,
+                                          plane * pitch, 2);
+  };
+  auto ld_act = [&](int kq, fx2(&o)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = ld2(r_act, kq * 4 + i);
+  };
+  auto ld_ref = [&](int kq, fx2(&o)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = ld2(r_ref, kq * 3 + i);
+  };
+  typedef __attribute__((address_space(4))) const WingConst *const_ptr;
+  typedef __attribute__((address_space(4))) const char *const_bytes;
+  const_ptr kp = (const_ptr)((const_bytes)__builtin_amdgcn_kernarg_segment_ptr() +
+                             offsetof(WingRolloutArgs, k));
+#define APG_LAUNDER(p) asm volatile("" : "+s"(p))
+  const WingDefaultK kl;
+  WingConst kv = A.k;
+  float w_pos = KMODE == 1 ? kWingDefaultPosWeight : A.w.pos,
+        w_act = KMODE == 1 ? kWingDefaultActionWeight : A.w.action;
+  if constexpr (KMODE == 2) {
+    float *f = reinterpret_cast<float *>(&kv);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(WingConst) / sizeof(float)); ++i)
+      asm volatile("" : "+v"(f[i]));
+    asm volatile("" : "+v"(w_pos), "+v"(w_act));
+  }
+  auto step = [&](fx2(&s_)[12], const fx2(&a_)[4]) {
+    if constexpr (KMODE == 1) {
+      wing_step(s_, a_, kl);
+    } else if constexpr (KMODE == 2) {
+      wing_step(s_, a_, kv);
+    } else {
+      APG_LAUNDER(kp);
+      wing_step(s_, a_, *kp);
+    }
+  };
+  const int H = A.H, S = A.stride;
+  auto ST = [&](int slot, int i) -> fx2 & { return stash2[(slot * 12 + i) * 64 + lane]; };
+  fx2 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = ld2(r_s0, i);
+  if (blockIdx.x == 0 && A.prev.prev_partials) reduce_prev_partials(A.prev);
+  fx2 loss = {0.f, 0.f};
+  fx2 a_q[2][4], r_q[2][3];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int kq = d < H ? d : H - 1;
+    ld_act(kq, a_q[d]);
+    ld_ref(kq, r_q[d]);
+  }
+  for (int kk = 0, slot = 0, phase = 0; kk < H; ++kk) {
+    fx2 a[4], rp[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = a_q[0][i], a_q[0][i] = a_q[1][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rp[i] = r_q[0][i], r_q[0][i] = r_q[1][i];
+    {
+      const int kq = kk + 2 < H ? kk + 2 : H - 1;
+      ld_act(kq, a_q[1]);
+      ld_ref(kq, r_q[1]);
+    }
+    if (phase == 0) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) ST(slot, i) = s[i];
+      ++slot;
+    }
+    if (++phase == S) phase = 0;
+    step(s, a);
+    if (A.states_out) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) st2(r_so, kk * 12 + i, s[i]);
+    }
+    fx2 lp = {0.f, 0.f}, la = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const fx2 dp = s[i] - rp[i], d = a[1 + i] - 0.5f;
+      lp += dp * dp, la += d * d;
+    }
+    loss += w_pos * lp + w_act * la;
+  }
+  {  // the host reduces ceil(B / 64) partials (one per 64 trajectories): this
+     // wave's 128 trajectories fill two of them (even / odd trajectories), or
+     // one when the second lies beyond the batch's partial count
+    const int count = (A.B + kWave - 1) / kWave;
+    const float s0 = wave_sum(live ? loss.x : 0.f), s1 = wave_sum(live ? loss.y : 0.f);
+    if (lane == 0) {
+      const int j = 2 * blockIdx.x;
+      if (j + 1 < count) A.loss_partials[j] = s0, A.loss_partials[j + 1] = s1;
+      else if (j < count) A.loss_partials[j] = s0 + s1;
+    }
+  }
+
+  fx2 lam[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = (fx2){0.f, 0.f};
+  fx2 nxt[3] = {s[0], s[1], s[2]};  // position after the group's last step
+  const int G = (H + S - 1) / S;
+  fx2 act[kWingMaxStride][4], rpg[kWingMaxStride][3];
+  auto load_group = [&](int g, fx2(&ga_)[kWingMaxStride][4],
+                        fx2(&gr_)[kWingMaxStride][3]) {
+#pragma unroll
+    for (int j = 0; j < kWingMaxStride; ++j) {
+      int kq = g * S + j;           // rows past the group / horizon: any valid row
+      kq = (j < S && kq < H) ? kq : H - 1;
+      ld_act(kq, ga_[j]);
+      ld_ref(kq, gr_[j]);
+    }
+  };
+  for (int g = G - 1; g >= 0; --g) {
+    const int k0 = g * S;
+    const int n = (H - k0) < S ? (H - k0) : S;
+    load_group(g, act, rpg);
+    fx2 pre[kWingMaxStride + 1][12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pre[0][i] = ST(g, i);
+#pragma unroll
+    for (int j = 0; j < kWingMaxStride; ++j) {
+      if (j < n) {
+        if (j + 1 < kWingMaxStride && j + 1 < n) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) pre[j + 1][i] = pre[j][i];
+          step(pre[j + 1], act[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = kWingMaxStride - 1; j >= 0; --j) {
+      if (j < n) {
+        const int kk = k0 + j;
+        fx2 pn[3] = {nxt[0], nxt[1], nxt[2]}, sd[12];
+        if (j + 1 < kWingMaxStride && j + 1 < n) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) pn[i] = pre[j + 1][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) lam[i] += 2.f * w_pos * (pn[i] - rpg[j][i]);
+        fx2 ga[4] = {(fx2){0.f, 0.f}, 2.f * w_act * (act[j][1] - 0.5f),
+                     2.f * w_act * (act[j][2] - 0.5f),
+                     2.f * w_act * (act[j][3] - 0.5f)};
+        WingAuxT<fx2> x;
+        if constexpr (KMODE == 1) {
+          wing_rates(pre[j], act[j], kl, x, sd);
+          wing_step_adjoint(lam, ga, pre[j], x, sd, kl);
+        } else if constexpr (KMODE == 2) {
+          wing_rates(pre[j], act[j], kv, x, sd);
+          wing_step_adjoint(lam, ga, pre[j], x, sd, kv);
+        } else {
+          APG_LAUNDER(kp);
+          wing_rates(pre[j], act[j], *kp, x, sd);
+          wing_step_adjoint(lam, ga, pre[j], x, sd, *kp);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st2(r_ga, kk * 4 + i, ga[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nxt[i] = pre[0][i];
+  }
+  if (A.grad_state0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st2(r_gs, i, lam[i]);
+  }
+#undef APG_LAUNDER
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void wing_rollout_fwd_kernel(
     const float *__restrict__ state0, const float *__restrict__ actions,
@@ -437,6 +642,53 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
                    A.w.action == kWingDefaultActionWeight;
   // buffer addressing needs every tensor below 2 GiB (32-bit byte offsets)
   const bool buf_ok = (long long)H * 12 * B * 4 < (1ll << 31);
+  // Two trajectories per lane (packed fp32, one wave per SIMD) as soon as the
+  // one-per-lane kernel would put more than one wave on a SIMD; needs the
+  // plane layout, an even batch and 8-byte aligned tensors.
+#ifndef APG_WING_PK
+#define APG_WING_PK 2   // 0 never, 1 whenever possible, 2 by batch size
+#endif
+  static int simds = 0;
+  if (!simds) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) !=
+            hipSuccess || cus <= 0)
+      cus = 256;
+    simds = 4 * cus;
+  }
+  const auto al8 = [](const void *q) { return ((size_t)q & 7) == 0; };
+  const bool pk_ok = layout == APG_LAYOUT_SOA && buf_ok && (B & 1) == 0 &&
+                     al8(state0) && al8(actions) && al8(ref) && al8(grad_actions) &&
+                     al8(grad_state0) && al8(states_out);
+  // APG_WING_PK in the environment (tests): 1 = whenever possible, 0 = never
+  int pk_mode = APG_WING_PK;
+  if (const char *e = getenv("APG_WING_PK")) pk_mode = atoi(e);
+  if (pk_ok && (pk_mode == 1 || (pk_mode == 2 && grid_for(B, 64) > simds))) {
+    const size_t lds2 = 2 * lds;
+    const dim3 grid2(grid_for(B / 2, 64)), block2(64);
+#define APG_WING_PK_LAUNCH(KM)                                                \
+  do {                                                                        \
+    if (lds2 > 64 * 1024 &&                                                   \
+        hipFuncSetAttribute((const void *)wing_rollout_pk_kernel<KM>,         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                            (int)lds2) != hipSuccess)                         \
+      return check_launch("hipFuncSetAttribute(wing_rollout_pk)");            \
+    hipLaunchKernelGGL((wing_rollout_pk_kernel<KM>), grid2, block2, lds2, st, A); \
+  } while (0)
+#ifdef APG_WING_PK_KMODE     /* experiment builds: force one constant source */
+    if (APG_WING_PK_KMODE == 1 && !lit) APG_WING_PK_LAUNCH(0);
+    else APG_WING_PK_LAUNCH(APG_WING_PK_KMODE);
+#else
+    if (lit) APG_WING_PK_LAUNCH(1);
+    else APG_WING_PK_LAUNCH(0);
+#endif
+#undef APG_WING_PK_LAUNCH
+    if (int e = check_launch("wing_rollout_fwd_bwd(two per lane)")) return e;
+    if (loss)
+      return launch_reduce_partials(loss_partials, apg_loss_partials_count(B), loss, st);
+    return APG_OK;
+  }
 #define APG_WING_LAUNCH(L, LIT, BUF)                                          \
   do {                                                                        \
     if (lds > 64 * 1024 &&                                                    \

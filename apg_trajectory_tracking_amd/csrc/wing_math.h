@@ -123,6 +123,27 @@ inline bool is_default(const WingConst &k) {
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kTanBound = 0.17632698070846498f;  // tan(10 deg)
 
+// ---- one trajectory per lane (float) or TWO (fx2) ---------------------------
+// The per-trajectory arithmetic below is written once on a value type T:
+// float, or fx2 = two trajectories per lane.  With fx2 every multiply / add /
+// fma is ONE v_pk_*_f32 for both trajectories (5.1 cycles of issue for a lone
+// wave against 2 x 4.1-5.1 for two scalar ops, profiles/r03_issue_probe2.jsonl)
+// and the quarter-rate ops (sin, cos, rcp, sqrt) are issued per component by
+// a wave that has its SIMD to itself (8 cycles each) - in the two-waves-per-
+// SIMD regime of the scalar kernel a transcendental costs each wave ~23
+// cycles (same probe), which is what held that kernel at 1.2 x one wave.
+__host__ __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+__host__ __device__ __forceinline__ float min_(float a, float b) { return fminf(a, b); }
+__host__ __device__ __forceinline__ float max_(float a, float b) { return fmaxf(a, b); }
+__host__ __device__ __forceinline__ float abs_(float a) { return fabsf(a); }
+__host__ __device__ __forceinline__ fx2 fma_(fx2 a, fx2 b, fx2 c) { return __builtin_elementwise_fma(a, b, c); }
+__host__ __device__ __forceinline__ fx2 min_(fx2 a, fx2 b) { return (fx2){fminf(a.x, b.x), fminf(a.y, b.y)}; }
+__host__ __device__ __forceinline__ fx2 max_(fx2 a, fx2 b) { return (fx2){fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__host__ __device__ __forceinline__ fx2 abs_(fx2 a) { return (fx2){fabsf(a.x), fabsf(a.y)}; }
+__host__ __device__ __forceinline__ fx2 splat(fx2, float v) { return (fx2){v, v}; }
+__host__ __device__ __forceinline__ float splat(float, float v) { return v; }
+#define APG_T(v) splat(T{}, (v))   // a constant of the value type
+
 // alpha = clamp(atan(t), +-10 deg) needs the arc tangent on |t| <= tan(10 deg)
 // only: outside, the clamp returns the bound and kills the gradient.  With t
 // clamped FIRST, atan is its Taylor polynomial to t^9 (next term 4.6e-10) -
@@ -130,30 +151,32 @@ constexpr float kTanBound = 0.17632698070846498f;  // tan(10 deg)
 // atan(tan(bound)) reproduces the bound to 3e-9.  `free` = 1 where the clamp
 // was inactive, computed arithmetically (a compare + v_cndmask pair costs ~5
 // issue slots on gfx950, tools/issue_probe.hip).
-__host__ __device__ __forceinline__ float atan_clamped(float t, float *tc_out,
-                                                       float *free_out) {
-  const float tc = fminf(fmaxf(t, -kTanBound), kTanBound);
+template <typename T>
+__host__ __device__ __forceinline__ T atan_clamped(T t, T *tc_out, T *free_out) {
+  const T tc = min_(max_(t, APG_T(-kTanBound)), APG_T(kTanBound));
   *tc_out = tc;
   // (|t| - bound, not t - tc: the compiler contracts `w * (1/u) - tc` into an
   // fma whose exact product differs from the rounded t by its rounding error)
-  *free_out = 1.f - fminf(1.f, fmaxf(fabsf(t) - kTanBound, 0.f) * 1e30f);
-  const float z = tc * tc;
-  float p = fmaf(z, 1.f / 9.f, -1.f / 7.f);
-  p = fmaf(z, p, 1.f / 5.f);
-  p = fmaf(z, p, -1.f / 3.f);
-  return fmaf(tc * z, p, tc);
+  *free_out = 1.f - min_(APG_T(1.f),
+                         max_(abs_(t) - kTanBound, APG_T(0.f)) * 1e30f);
+  const T z = tc * tc;
+  T p = fma_(z, APG_T(1.f / 9.f), APG_T(-1.f / 7.f));
+  p = fma_(z, p, APG_T(1.f / 5.f));
+  p = fma_(z, p, APG_T(-1.f / 3.f));
+  return fma_(tc * z, p, tc);
 }
 
 // sin / cos on |x| <= 10 deg (the clamped alpha, beta): Taylor to x^7 / x^6,
 // truncation < 3e-11
-__host__ __device__ __forceinline__ void sincos_small(float x, float *sn, float *cs) {
-  const float z = x * x;
-  float ps = fmaf(z, -1.f / 5040.f, 1.f / 120.f);
-  ps = fmaf(z, ps, -1.f / 6.f);
-  *sn = fmaf(x * z, ps, x);
-  float pc = fmaf(z, -1.f / 720.f, 1.f / 24.f);
-  pc = fmaf(z, pc, -0.5f);
-  *cs = fmaf(z, pc, 1.f);
+template <typename T>
+__host__ __device__ __forceinline__ void sincos_small(T x, T *sn, T *cs) {
+  const T z = x * x;
+  T ps = fma_(z, APG_T(-1.f / 5040.f), APG_T(1.f / 120.f));
+  ps = fma_(z, ps, APG_T(-1.f / 6.f));
+  *sn = fma_(x * z, ps, x);
+  T pc = fma_(z, APG_T(-1.f / 720.f), APG_T(1.f / 24.f));
+  pc = fma_(z, pc, APG_T(-0.5f));
+  *cs = fma_(z, pc, APG_T(1.f));
 }
 
 // attitude angles: the hardware pair on the device (apg_device.h), the
@@ -165,36 +188,44 @@ __host__ __device__ __forceinline__ void sincos_att(float x, float *sn, float *c
   sincos_fast(x, sn, cs);
 #endif
 }
+__host__ __device__ __forceinline__ void sincos_att(fx2 x, fx2 *sn, fx2 *cs) {
+  float s0, c0, s1, c1;
+  sincos_att(x.x, &s0, &c0);
+  sincos_att(x.y, &s1, &c1);
+  *sn = (fx2){s0, s1}, *cs = (fx2){c0, c1};
+}
 
 // Everything the adjoint re-uses from the forward evaluation of one step.
-struct WingAux {
-  float T, de, da, dr;
-  float V, V2, iV, r2V, tw, tb;  // iV = 1/V; tw = w/u, tb = v/V, both CLAMPED
+template <typename T>
+struct WingAuxT {
+  T Tt, de, da, dr;
+  T V, V2, iV, r2V, tw, tb;      // iV = 1/V; tw = w/u, tb = v/V, both CLAMPED
                                  // to +-tan(10 deg)
-  float alpha, beta;
-  float alpha_free, beta_free;   // 1: clamp passes the gradient, 0: it does not
-  float sa, ca, sb, cb;
-  float CL, CD, CY, Cl, Cm, Cn, Q;
-  float L, D, Y;
-  float sph, cph, sth, cth, sps, cps, icth;
-  float R[3][3];                 // rows as assembled at :80-91
-  float h0, h1, h2;              // I * omega
+  T alpha, beta;
+  T alpha_free, beta_free;       // 1: clamp passes the gradient, 0: it does not
+  T sa, ca, sb, cb;
+  T CL, CD, CY, Cl, Cm, Cn, Q;
+  T L, D, Y;
+  T sph, cph, sth, cth, sps, cps, icth;
+  T R[3][3];                     // rows as assembled at :80-91
+  T h0, h1, h2;                  // I * omega
 };
+typedef WingAuxT<float> WingAux;
 
 // Evaluates state_dot (12) and fills aux.
-// (KT = const WingConst, possibly qualified with the constant address space)
-template <typename KT>
-__host__ __device__ __forceinline__ void wing_rates(const float (&s)[12],
-                                           const float (&a)[4], KT &k,
-                                           WingAux &x, float (&sd)[12]) {
-  const float u = s[3], v = s[4], w = s[5];
-  const float p = s[9], q = s[10], r = s[11];
+// (KT = const WingConst, possibly qualified with the constant address space,
+// or WingDefaultK)
+template <typename T, typename KT>
+__host__ __device__ __forceinline__ void wing_rates(const T (&s)[12], const T (&a)[4],
+                                           KT &k, WingAuxT<T> &x, T (&sd)[12]) {
+  const T u = s[3], v = s[4], w = s[5];
+  const T p = s[9], q = s[10], r = s[11];
   // normalize_action :41-46 (pi (40 a - 20) / 180 with the constants folded:
   // no IEEE division sequence per control surface)
-  x.T = a[0] * 7.f;
-  x.de = fmaf(a[1], kPi * 40.f / 180.f, -kPi * 20.f / 180.f);
-  x.da = fmaf(a[2], kPi * 5.f / 180.f, -kPi * 2.5f / 180.f);
-  x.dr = fmaf(a[3], kPi * 40.f / 180.f, -kPi * 20.f / 180.f);
+  x.Tt = a[0] * 7.f;
+  x.de = fma_(a[1], APG_T(kPi * 40.f / 180.f), APG_T(-kPi * 20.f / 180.f));
+  x.da = fma_(a[2], APG_T(kPi * 5.f / 180.f), APG_T(-kPi * 2.5f / 180.f));
+  x.dr = fma_(a[3], APG_T(kPi * 40.f / 180.f), APG_T(-kPi * 20.f / 180.f));
   // :130-134
   x.V2 = u * u + v * v + w * w;
   x.V = sqrt_fast(x.V2);
@@ -217,7 +248,7 @@ __host__ __device__ __forceinline__ void wing_rates(const float (&s)[12],
   // :167-175
   x.Q = k.half_rho * x.V2 * k.S;
   x.L = x.Q * x.CL, x.D = x.Q * x.CD, x.Y = x.Q * x.CY;
-  const float l = x.Q * k.c * x.Cl, m = x.Q * k.c * x.Cm, n = x.Q * k.c * x.Cn;
+  const T l = x.Q * k.c * x.Cl, m = x.Q * k.c * x.Cm, n = x.Q * k.c * x.Cn;
   // :185-204 body forces
   sincos_small(x.alpha, &x.sa, &x.ca);
   sincos_small(x.beta, &x.sb, &x.cb);
@@ -225,11 +256,11 @@ __host__ __device__ __forceinline__ void wing_rates(const float (&s)[12],
   sincos_att(s[7], &x.sth, &x.cth);
   sincos_att(s[8], &x.sps, &x.cps);
   x.icth = rcp_nr(x.cth);
-  const float f0 = -x.ca * x.cb * x.D - x.ca * x.sb * x.Y + x.sa * x.L -
-                   k.g_m * x.sth + x.T * k.cos_eps;
-  const float f1 = -x.sb * x.D + x.cb * x.Y + k.g_m * x.sph * x.cth;
-  const float f2 = -x.sa * x.cb * x.D - x.sa * x.sb * x.Y - x.ca * x.L +
-                   k.g_m * x.cph * x.cth + x.T * k.sin_eps;
+  const T f0 = -x.ca * x.cb * x.D - x.ca * x.sb * x.Y + x.sa * x.L -
+               k.g_m * x.sth + x.Tt * k.cos_eps;
+  const T f1 = -x.sb * x.D + x.cb * x.Y + k.g_m * x.sph * x.cth;
+  const T f2_ = -x.sa * x.cb * x.D - x.sa * x.sb * x.Y - x.ca * x.L +
+                k.g_m * x.cph * x.cth + x.Tt * k.sin_eps;
   // :213-216 position rate: R^T vel with R rows as at :80-91
   x.R[0][0] = x.cth * x.cps, x.R[0][1] = x.cth * x.sps, x.R[0][2] = -x.sth;
   x.R[1][0] = -x.cph * x.sps + x.sph * x.sth * x.cps;
@@ -244,27 +275,26 @@ __host__ __device__ __forceinline__ void wing_rates(const float (&s)[12],
   // :220-221
   sd[3] = k.inv_mass * f0 - (q * w - r * v);
   sd[4] = k.inv_mass * f1 - (r * u - p * w);
-  sd[5] = k.inv_mass * f2 - (p * v - q * u);
+  sd[5] = k.inv_mass * f2_ - (p * v - q * u);
   // :225-245
-  const float tth = x.sth * x.icth;
+  const T tth = x.sth * x.icth;
   sd[6] = p + x.sph * tth * q + x.cph * tth * r;
   sd[7] = x.cph * q - x.sph * r;
   sd[8] = (x.sph * q + x.cph * r) * x.icth;
   // :250-255
   x.h0 = k.Ixx * p + k.a13 * r, x.h1 = k.Iyy * q, x.h2 = k.a13 * p + k.Izz * r;
-  const float r0 = l - (q * x.h2 - r * x.h1);
-  const float r1 = m - (r * x.h0 - p * x.h2);
-  const float r2 = n - (p * x.h1 - q * x.h0);
+  const T r0 = l - (q * x.h2 - r * x.h1);
+  const T r1 = m - (r * x.h0 - p * x.h2);
+  const T r2 = n - (p * x.h1 - q * x.h0);
   sd[9] = k.i00 * r0 + k.i02 * r2;
   sd[10] = k.i11 * r1;
   sd[11] = k.i02 * r0 + k.i22 * r2;
 }
 
-template <typename KT>
-__host__ __device__ __forceinline__ void wing_step(float (&s)[12], const float (&a)[4],
-                                          KT &k) {
-  WingAux x;
-  float sd[12];
+template <typename T, typename KT>
+__host__ __device__ __forceinline__ void wing_step(T (&s)[12], const T (&a)[4], KT &k) {
+  WingAuxT<T> x;
+  T sd[12];
   wing_rates(s, a, k, x, sd);
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = s[i] + k.dt * sd[i];
@@ -274,40 +304,39 @@ __host__ __device__ __forceinline__ void wing_step(float (&s)[12], const float (
 // `s`, `a` are the PRE-step state and the action; x the matching aux.
 // `sd`: the state_dot wing_rates returned for (s, a) (its position part is
 // re-used by the yaw cotangent).
-template <typename KT>
-__host__ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
-                                                  float (&ga)[4],
-                                                  const float (&s)[12],
-                                                  const WingAux &x,
-                                                  const float (&sd)[12], KT &k) {
-  const float u = s[3], v = s[4], w = s[5];
-  const float p = s[9], q = s[10], r = s[11];
-  float g[12];  // cotangent of state_dot
+template <typename T, typename KT>
+__host__ __device__ __forceinline__ void wing_step_adjoint(T (&lam)[12], T (&ga)[4],
+                                                  const T (&s)[12],
+                                                  const WingAuxT<T> &x,
+                                                  const T (&sd)[12], KT &k) {
+  const T u = s[3], v = s[4], w = s[5];
+  const T p = s[9], q = s[10], r = s[11];
+  const T zero = APG_T(0.f);
+  T g[12];  // cotangent of state_dot
 #pragma unroll
   for (int i = 0; i < 12; ++i) g[i] = k.dt * lam[i];
-  float du = 0.f, dv = 0.f, dw = 0.f, dph = 0.f, dth = 0.f, dps = 0.f;
-  float dp = 0.f, dq = 0.f, dr = 0.f;
+  T du = zero, dv = zero, dw = zero, dph = zero, dth = zero, dps = zero;
+  T dp = zero, dq = zero, dr = zero;
 
   // omega_dot = I^-1 (M - omega x I omega)
-  const float gr0 = k.i00 * g[9] + k.i02 * g[11];
-  const float gr1 = k.i11 * g[10];
-  const float gr2 = k.i02 * g[9] + k.i22 * g[11];
+  const T gr0 = k.i00 * g[9] + k.i02 * g[11];
+  const T gr1 = k.i11 * g[10];
+  const T gr2 = k.i02 * g[9] + k.i22 * g[11];
   {
-    const float c0 = -gr0, c1 = -gr1, c2 = -gr2;  // cotangent of the cross
+    const T c0 = -gr0, c1 = -gr1, c2 = -gr2;  // cotangent of the cross
     dp += -c1 * x.h2 + c2 * x.h1;
     dq += c0 * x.h2 - c2 * x.h0;
     dr += -c0 * x.h1 + c1 * x.h0;
-    const float gh0 = c1 * r - c2 * q, gh1 = -c0 * r + c2 * p,
-                gh2 = c0 * q - c1 * p;
+    const T gh0 = c1 * r - c2 * q, gh1 = -c0 * r + c2 * p, gh2 = c0 * q - c1 * p;
     dp += k.Ixx * gh0 + k.a13 * gh2;
     dq += k.Iyy * gh1;
     dr += k.a13 * gh0 + k.Izz * gh2;
   }
   // euler rates
   {
-    const float icth = x.icth, tth = x.sth * icth;
-    const float sq_cr = x.sph * q + x.cph * r;   // sin(phi) q + cos(phi) r
-    const float cq_sr = x.cph * q - x.sph * r;
+    const T icth = x.icth, tth = x.sth * icth;
+    const T sq_cr = x.sph * q + x.cph * r;   // sin(phi) q + cos(phi) r
+    const T cq_sr = x.cph * q - x.sph * r;
     dp += g[6];
     dq += g[6] * x.sph * tth + g[7] * x.cph + g[8] * x.sph * icth;
     dr += g[6] * x.cph * tth - g[7] * x.sph + g[8] * x.cph * icth;
@@ -315,10 +344,9 @@ __host__ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
     dth += g[6] * sq_cr * icth * icth + g[8] * sq_cr * x.sth * icth * icth;
   }
   // uvw_dot = f/m - omega x vel
-  const float gf0 = k.inv_mass * g[3], gf1 = k.inv_mass * g[4],
-              gf2 = k.inv_mass * g[5];
+  const T gf0 = k.inv_mass * g[3], gf1 = k.inv_mass * g[4], gf2 = k.inv_mass * g[5];
   {
-    const float x0 = -g[3], x1 = -g[4], x2 = -g[5];
+    const T x0 = -g[3], x1 = -g[4], x2 = -g[5];
     dq += x0 * w, dw += x0 * q, dr -= x0 * v, dv -= x0 * r;
     dr += x1 * u, du += x1 * r, dp -= x1 * w, dw -= x1 * p;
     dp += x2 * v, dv += x2 * p, dq -= x2 * u, du -= x2 * q;
@@ -331,63 +359,63 @@ __host__ __device__ __forceinline__ void wing_step_adjoint(float (&lam)[12],
   //                                                      + (v sph + w cph) Rg_0
   //   dcol0/dpsi = -col1, dcol1/dpsi = col0  => dpsi   = g1 pd0 - g0 pd1
   {
-    float Rg[3];
+    T Rg[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       Rg[i] = x.R[i][0] * g[0] + x.R[i][1] * g[1] + x.R[i][2] * g[2];
     du += Rg[0], dv += Rg[1], dw += Rg[2];
     dph += v * Rg[2] - w * Rg[1];
-    const float g_dr0 = -x.sth * (x.cps * g[0] + x.sps * g[1]) - x.cth * g[2];
+    const T g_dr0 = -x.sth * (x.cps * g[0] + x.sps * g[1]) - x.cth * g[2];
     dth += u * g_dr0 + (v * x.sph + w * x.cph) * Rg[0];
     dps += g[1] * sd[0] - g[0] * sd[1];
   }
   // f = R_bw [-D, Y, -L] + gravity(phi, theta) + thrust
-  const float gT = gf0 * k.cos_eps + gf2 * k.sin_eps;
+  const T gT = gf0 * k.cos_eps + gf2 * k.sin_eps;
   dth += k.g_m * (-x.cth * gf0 - x.sph * x.sth * gf1 - x.cph * x.sth * gf2);
   dph += k.g_m * (x.cph * x.cth * gf1 - x.sph * x.cth * gf2);
   // f_aero = R_bw(alpha, beta) [-D, Y, -L], contracted through
   //   m = ca gf0 + sa gf2,  t = cb D + sb Y,  q = sb D - cb Y:
   //   d f_aero0 / dalpha = -f_aero2,  d f_aero2 / dalpha = f_aero0
-  const float m_ = x.ca * gf0 + x.sa * gf2;
-  const float t_ = x.cb * x.D + x.sb * x.Y;
-  const float q_ = x.sb * x.D - x.cb * x.Y;
-  const float gD = -x.cb * m_ - x.sb * gf1;
-  const float gY = -x.sb * m_ + x.cb * gf1;
-  const float gL = x.sa * gf0 - x.ca * gf2;
-  const float fa0 = x.sa * x.L - x.ca * t_, fa2 = -x.sa * t_ - x.ca * x.L;
-  float g_al = gf2 * fa0 - gf0 * fa2;
-  float g_be = q_ * m_ - gf1 * t_;
+  const T m_ = x.ca * gf0 + x.sa * gf2;
+  const T t_ = x.cb * x.D + x.sb * x.Y;
+  const T q_ = x.sb * x.D - x.cb * x.Y;
+  const T gD = -x.cb * m_ - x.sb * gf1;
+  const T gY = -x.sb * m_ + x.cb * gf1;
+  const T gL = x.sa * gf0 - x.ca * gf2;
+  const T fa0 = x.sa * x.L - x.ca * t_, fa2 = -x.sa * t_ - x.ca * x.L;
+  T g_al = gf2 * fa0 - gf0 * fa2;
+  T g_be = q_ * m_ - gf1 * t_;
   // forces and moments
-  const float Qc = x.Q * k.c;
-  const float gCL = x.Q * gL, gCD = x.Q * gD, gCY = x.Q * gY;
-  const float gCl = Qc * gr0, gCm = Qc * gr1, gCn = Qc * gr2;
-  const float gQ = gL * x.CL + gD * x.CD + gY * x.CY +
-                   k.c * (gr0 * x.Cl + gr1 * x.Cm + gr2 * x.Cn);
-  float gV2 = k.half_rho * k.S * gQ;
+  const T Qc = x.Q * k.c;
+  const T gCL = x.Q * gL, gCD = x.Q * gD, gCY = x.Q * gY;
+  const T gCl = Qc * gr0, gCm = Qc * gr1, gCn = Qc * gr2;
+  const T gQ = gL * x.CL + gD * x.CD + gY * x.CY +
+               k.c * (gr0 * x.Cl + gr1 * x.Cm + gr2 * x.Cn);
+  T gV2 = k.half_rho * k.S * gQ;
   // coefficients
   g_al += k.CL_a * gCL + k.CD_a * gCD + k.Cm_a * gCm;
   g_be += k.CY_b * gCY + k.Cl_b * gCl + k.Cn_b * gCn;
-  const float g_qt = k.CL_qc * gCL + k.CD_qc * gCD + k.Cm_qc * gCm;
-  const float g_pt = k.CY_pb * gCY + k.Cl_pb * gCl + k.Cn_pb * gCn;
-  const float g_rt = k.CY_rb * gCY + k.Cl_rb * gCl + k.Cn_rb * gCn;
-  const float g_de = k.CL_de * gCL + k.CD_de * gCD + k.Cm_de * gCm;
-  const float g_da = k.CY_da * gCY + k.Cl_da * gCl + k.Cn_da * gCn;
-  const float g_dr = k.CY_dr * gCY + k.Cl_dr * gCl + k.Cn_dr * gCn;
+  const T g_qt = k.CL_qc * gCL + k.CD_qc * gCD + k.Cm_qc * gCm;
+  const T g_pt = k.CY_pb * gCY + k.Cl_pb * gCl + k.Cn_pb * gCn;
+  const T g_rt = k.CY_rb * gCY + k.Cl_rb * gCl + k.Cn_rb * gCn;
+  const T g_de = k.CL_de * gCL + k.CD_de * gCD + k.Cm_de * gCm;
+  const T g_da = k.CY_da * gCY + k.Cl_da * gCl + k.Cn_da * gCn;
+  const T g_dr = k.CY_dr * gCY + k.Cl_dr * gCl + k.Cn_dr * gCn;
   dq += g_qt * x.r2V, dp += g_pt * x.r2V, dr += g_rt * x.r2V;
-  const float g_r2V = g_qt * q + g_pt * p + g_rt * r;
-  const float iV = x.iV;
-  float gV = -g_r2V * x.r2V * iV;
+  const T g_r2V = g_qt * q + g_pt * p + g_rt * r;
+  const T iV = x.iV;
+  T gV = -g_r2V * x.r2V * iV;
   // alpha = clamp(atan(w/u)), beta = clamp(atan(v/V)): where the clamp is
   // active the mask is 0 and tw / tb hold the (finite) bound
   {
-    const float gt = x.alpha_free * g_al * rcp_nr(1.f + x.tw * x.tw);
-    const float iu = rcp_nr_finite(u);   // gt = 0 where the clamp is active:
-                                         // 0 * FLT_MAX = 0, never 0 * inf
+    const T gt = x.alpha_free * g_al * rcp_nr(1.f + x.tw * x.tw);
+    const T iu = rcp_nr_finite(u);   // gt = 0 where the clamp is active:
+                                     // 0 * FLT_MAX = 0, never 0 * inf
     dw += gt * iu;
     du -= gt * x.tw * iu;
   }
   {
-    const float gt = x.beta_free * g_be * rcp_nr(1.f + x.tb * x.tb);
+    const T gt = x.beta_free * g_be * rcp_nr(1.f + x.tb * x.tb);
     dv += gt * iV;
     gV -= gt * x.tb * iV;
   }

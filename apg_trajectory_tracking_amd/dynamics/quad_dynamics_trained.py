@@ -85,11 +85,16 @@ class LearntDynamics(nn.Module, FlightmareDynamics):
             torch.from_numpy(np.asarray(self.inertia_vector)).float())
         self.torch_kinv_vector = nn.Parameter(
             torch.tensor(np.asarray(self.kinv_ang_vel_tau)).float())
-        self._rot_drag = torch.tensor(
-            [float(v) for v in self.cfg["rotational_drag"]])
+        # constants of the step, as NON-persistent buffers: they follow
+        # module.to(device) (no host-to-device copy per forward) and stay out
+        # of the state_dict (the reference's has no such keys)
+        self.register_buffer("_rot_drag", torch.tensor(
+            [float(v) for v in self.cfg["rotational_drag"]]), persistent=False)
         # the reference's torch.diag copies (:48-50): what the step uses from
         # now on, whatever happens to the parameters above
-        self._inertia0 = self.torch_inertia_vector.detach().clone()
+        self.register_buffer("_inertia0",
+                             self.torch_inertia_vector.detach().clone(),
+                             persistent=False)
         self._snapshot_params()
 
     def _snapshot_params(self):

@@ -851,6 +851,40 @@ def to_soa_multi(items, index=None):
     return outs
 
 
+class _StaticPlanes:
+    """Plane-layout copies of WHOLE input tensors that have not changed since
+    the last step (a trainer stepping on its resident shard, bench.py): the
+    layout change (apg_to_soa, 45-70 us at B = 65 536) is then done once, not
+    per step.  Opt-in by the direct-gradient entry points only (no autograd
+    tape holds the buffers), keyed on the identity of the caller's tensor
+    OBJECTS (weak references) and their in-place version counters - a fresh
+    minibatch tensor, or `t[:n] = ...` on the data set, can never hit."""
+
+    def __init__(self, slots=4):
+        self.slots, self.entries = slots, []
+
+    def _match(self, e, tag, tensors):
+        return (e[0] == tag and len(e[1]) == len(tensors) and all(
+            r() is t and v == t._version for r, v, t in zip(e[1], e[2], tensors)))
+
+    def lookup(self, tag, tensors):
+        for e in self.entries:
+            if self._match(e, tag, tensors):
+                return e[3]
+        return None
+
+    def store(self, tag, tensors, value):
+        import weakref
+        self.entries = [e for e in self.entries
+                        if not self._match(e, tag, tensors)][-(self.slots - 1):]
+        self.entries.append((tag, [weakref.ref(t) for t in tensors],
+                             [t._version for t in tensors], value))
+        return value
+
+
+_STATIC_PLANES = _StaticPlanes()
+
+
 def _ref_and_states(in_ref, state0, B, H, index=None, also=()):
     """One buffer for everything the conv-weight product reads as B operand:
     planes [0, 2H*9) = the reference tensor [2H][9][B], planes [2H*9, +(H+1)*12)
@@ -921,8 +955,12 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         if w_ih.shape != (32, 175) or conv_w.shape != (20, 9, 3):
             raise ValueError("fused path needs LSTM_NEW(15, 10, 9, 4, conv=1)")
         dev = state0.device
-        refbuf, inr, s0, states, rf = _ref_and_states(
+        src = getattr(ctx, "static_src", None) if index is None else None
+        hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
+        refbuf, inr, s0, states, rf = hit or _ref_and_states(
             _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
+        if src and hit is None:
+            _STATIC_PLANES.store("recurrent", src, (refbuf, inr, s0, states, rf))
         h0s, c0s = to_soa_multi([(h0, None), (c0, None)])
         pw = dict(
             conv_w=_f32c(conv_w), conv_b=_f32c(conv_b), w_ih=_f32c(w_ih),
@@ -1041,8 +1079,12 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
             raise ValueError("batch too large for one fused launch "
                              "(B <= 400 000); split it")
         dev = state0.device
-        refbuf, inr, s0, states, rf = _ref_and_states(
+        src = getattr(ctx, "static_src", None) if index is None else None
+        hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
+        refbuf, inr, s0, states, rf = hit or _ref_and_states(
             _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
+        if src and hit is None:
+            _STATIC_PLANES.store("recurrent", src, (refbuf, inr, s0, states, rf))
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -1257,11 +1299,19 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         # one buffer for the B operands of the weight products:
         # feat (15) | x1 (224) | h1, h2, h3 (192) | in_ref rows (H*9)
-        acts = new(431 + H * 9, B)
+        src = getattr(ctx, "static_src", None) if index is None else None
+        hit = _STATIC_PLANES.lookup("concurrent", src) if src else None
+        if hit is not None:
+            acts, s0, rf = hit       # feat / in_ref planes still valid, the
+        else:                        # kernels rewrite x1 and h every step
+            acts = new(431 + H * 9, B)
         feat, x1, h, inr = acts[:15], acts[15:239], acts[239:431], acts[431:]
-        _, _, s0, rf = to_soa_multi(
-            [(normed, feat), (in_ref[:, :H], inr.view(H, 9, B)), (state0, None),
-             (ref[:, :H], None)], index=index)
+        if hit is None:
+            _, _, s0, rf = to_soa_multi(
+                [(normed, feat), (in_ref[:, :H], inr.view(H, 9, B)), (state0, None),
+                 (ref[:, :H], None)], index=index)
+            if src:
+                _STATIC_PLANES.store("concurrent", src, (acts, s0, rf))
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -1344,15 +1394,20 @@ def _net_params(net, names):
 
 
 def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
-                                 weights=None, index=None):
+                                 weights=None, index=None, static_inputs=False):
     """quad_concurrent_policy_loss + its parameter gradients, without autograd:
     returns (loss, {parameter name: gradient}, flat); the gradients are
     contiguous views of the flat buffer (no per-parameter clone as
     `loss.backward()` does), whose last element is a free slot for the loss -
     so the buffer itself is the all-reduce message.  `index` (int64 device
     tensor): the four tensors are the whole data set and the minibatch
-    rows are gathered while they are brought into the plane layout."""
+    rows are gathered while they are brought into the plane layout.
+    `static_inputs` (index None): the caller steps repeatedly on these very
+    tensor objects (its resident shard) - their plane-layout copies are kept
+    while the tensors stay unchanged (_StaticPlanes)."""
     ctx = _DirectCtx()
+    if static_inputs and index is None:
+        ctx.static_src = (normed, state0, in_ref, ref)
     with torch.no_grad():
         loss = _QuadConcurrentPolicyLoss.forward(
             ctx, normed, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt,
@@ -1367,7 +1422,7 @@ _MAX_FUSED_AR_BATCH = 393216
 
 
 def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
-                           index=None):
+                           index=None, static_inputs=False):
     """quad_mlp_rollout_loss (autoregressive unroll) + parameter gradients,
     without autograd; see quad_concurrent_policy_grads.  Batches beyond
     393 216 trajectories are processed in chunks (losses and gradients are sums
@@ -1389,6 +1444,8 @@ def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
                 loss = loss + l
         return loss, gr, flat
     ctx = _DirectCtx()
+    if static_inputs and index is None:
+        ctx.static_src = (state0, in_ref, ref)
     with torch.no_grad():
         loss, _, _ = _QuadMlpRolloutLoss.forward(
             ctx, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt, params,
@@ -1403,9 +1460,11 @@ _LSTM_PARAMS = ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
 
 
 def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
-                            weights=None, index=None):
+                            weights=None, index=None, static_inputs=False):
     """quad_lstm_rollout_loss + parameter gradients, without autograd."""
     ctx = _DirectCtx()
+    if static_inputs and index is None:
+        ctx.static_src = (state0, in_ref, ref)
     with torch.no_grad():
         loss, _, _ = _QuadLstmRolloutLoss.forward(
             ctx, state0, in_ref, ref, h0, c0, *_net_params(net, _LSTM_PARAMS), dt,

@@ -47,15 +47,13 @@ class Net(nn.Module):
 
     def forward_packed(self, state, ref):
         """Same network, output as action ROWS: [H, B, nr_actions // H] - the
-        `APG_LAYOUT_PACKED` action tensor of the fused rollout
-        (include/apg.h), i.e. what `forward(...).view(B, H, A).transpose(0, 1)`
-        would give after a copy.  The head is evaluated with the horizon as
-        the BATCH of the GEMM (out[h] = x W_h^T + b_h, W_h = rows h*A..h*A+A of
-        fc_out.weight), so the rows leave rocBLAS in the kernel's layout and
-        dL/dactions comes back the same way: no transpose pass either way."""
+        `APG_LAYOUT_PACKED` action tensor of the fused rollout (include/apg.h).
+        Plain head GEMM + ONE transposing copy (10 MB at B = 65 536, ~15 us;
+        its backward is the same copy).  Evaluating the head with the horizon
+        as the batch of the GEMM (`baddbmm`, no copy) was measured and dropped:
+        rocBLAS runs the ten [B x 64] x [64 x 4] products and their weight
+        gradients 250 us slower than the one wide GEMM
+        (profiles/r03_packed_step_timeline.txt)."""
         H = self.horizon
-        A = self.fc_out.out_features // H
-        x = self.trunk(state, ref)                          # [B, 64]
-        w = self.fc_out.weight.view(H, A, -1).transpose(1, 2)   # [H, 64, A]
-        return torch.baddbmm(self.fc_out.bias.view(H, 1, A),
-                             x.unsqueeze(0).expand(H, -1, -1), w)
+        out = self.forward(state, ref)
+        return out.view(out.shape[0], H, -1).transpose(0, 1).contiguous()

@@ -40,6 +40,10 @@ class TrainDrone(TrainBase):
         # network is the reference architecture LSTM_NEW(15, 10, 9, 4, conv=1)
         self.fused_policy = True
         self.fused_learnt = True    # controller phase through LearntDynamics
+        # True: the fused steps are called (index=None) on the SAME resident
+        # tensors step after step - their plane-layout copies are then kept
+        # instead of being rebuilt per step (functional._StaticPlanes)
+        self.static_shard = False
 
     def initialize_model(self, base_model=None, modified_params={},
                          state_data=None, device=None, seed=0,
@@ -104,12 +108,14 @@ class TrainDrone(TrainBase):
                 loss, grads, flat = F.quad_lstm_rollout_grads(
                     self.net, current_state, in_ref_states, ref_states,
                     self.delta_t, self.train_dynamics.params,
-                    self.net.hidden_state, self.net.cell_state, index=index)
+                    self.net.hidden_state, self.net.cell_state, index=index,
+                    static_inputs=self.static_shard)
                 return self._step_direct(loss, grads, flat)
         elif self.fused_policy and self._fusable_mlp():
             loss, grads, flat = F.quad_mlp_rollout_grads(
                 self.net, current_state, in_ref_states, ref_states,
-                self.delta_t, self.train_dynamics.params, index=index)
+                self.delta_t, self.train_dynamics.params, index=index,
+                static_inputs=self.static_shard)
             return self._step_direct(loss, grads, flat)
         if index is not None:     # per-step path: materialise the batch
             current_state, in_ref_states, ref_states = (
@@ -163,7 +169,8 @@ class TrainDrone(TrainBase):
             return None
         loss, grads, flat = F.quad_concurrent_policy_grads(
             n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
-            self.train_dynamics.params, index=index)
+            self.train_dynamics.params, index=index,
+            static_inputs=self.static_shard)
         return self._step_direct(loss, grads, flat)
 
     # ------------------------------------------- packed (row-layout) path --

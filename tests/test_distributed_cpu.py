@@ -157,7 +157,7 @@ def _ar_steps(lo, hi):
     from oracle import torch_port as tp
 
     def oracle_grads(net, state0, in_ref, ref, dt, params, weights=None,
-                     index=None):
+                     index=None, static_inputs=False):
         _, _, loss = tp.quad_recurrent_unroll(net, tp.QuadOracle(), state0,
                                               in_ref, ref, H, dt)
         named = list(net.named_parameters())

@@ -97,17 +97,23 @@ def test_recurrent_fused_full_size_vs_fp64_oracle(dev, mode):
 
 
 def test_wing_rollout_full_size_vs_oracles(dev):
-    """BASELINE configs[3]: 131 072 x 20 (2 048 workgroups, two waves per
-    SIMD, five checkpoint groups) against the torch oracle on the whole batch
-    and the C oracle in float64; ragged variant for the grid logic."""
+    """BASELINE configs[3]: 131 072 x 20 against the torch oracle on the whole
+    batch and the C oracle in float64.  At this size the even batches run the
+    two-trajectories-per-lane kernel (packed fp32, one wave per SIMD): the
+    default parameter set with its literal coefficients, a ragged even batch
+    (dead lanes, partial last wave) and MODIFIED parameters (the coefficient
+    table read from the kernel arguments); the odd ragged batch runs the
+    one-per-lane kernel at two waves per SIMD."""
     from apg_trajectory_tracking_amd import functional as F, synthetic
     from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
         FixedWingDynamics)
     from oracle import c_oracle as co
     from oracle import torch_port as tp
     H, dt = 20, 0.05
-    dyn = FixedWingDynamics()
-    for B, seed, full in ((131072, 0, True), (131072 - 77, 1, False)):
+    WMOD = {"mass": 1.4, "I_xz": -0.01, "CL0": 0.3, "rho": 1.0}
+    for B, seed, full, mp in ((131072, 0, True, {}), (131072 - 77, 1, False, {}),
+                              (131072 - 78, 2, False, {}), (131072, 3, False, WMOD)):
+        dyn = FixedWingDynamics(modified_params=dict(mp))
         d = synthetic.wing_batch(B, H, dt, seed=seed)
         s0 = synthetic.to_soa_state(d["state0"]).to(dev)
         a = synthetic.to_soa_seq(d["actions"]).to(dev)
@@ -120,7 +126,7 @@ def test_wing_rollout_full_size_vs_oracles(dev):
         # independent C restatement, float64, OpenMP (seconds)
         cst, closs, cga, cgs = co.wing_rollout_fwd_bwd(
             d["state0"].numpy(), d["actions"].numpy(), d["ref"].numpy(), dt,
-            dtype=np.float64)
+            modified_params=mp, dtype=np.float64)
         assert rel_err(st, cst) < TOL
         assert abs(res["loss"].item() - closs) / closs < 1e-5
         assert rel_err(ga, cga) < TOL
@@ -173,3 +179,33 @@ def test_quad_concurrent_fused_full_size_vs_fp64_oracle(dev):
         if p.grad is not None:
             e = rel_err(N(grads[k]), p.grad.numpy())
             assert e < TOL, (k, e)
+
+
+def test_fused_ar_sweeps_beyond_two_gib_of_planes(dev, monkeypatch):
+    """`_MAX_FUSED_AR_BATCH` = 393 216 lets the autoregressive
+    sweeps address plane tensors of up to ~4 GiB through 32-bit buffer offsets.
+    At B = 262 144 the cotangent planes (260 x H x B floats = 2.7 GB) and the
+    fc1 input planes (224 x H x B = 2.3 GB) are past 2 GiB in ONE launch; the
+    same batch in four chunks of 65 536 (planes well below 2 GiB, the
+    configuration every other test exercises) must give the same loss and
+    parameter gradients."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    B = 262144
+    assert 260 * 10 * B * 4 > 2**31 and B <= F._MAX_FUSED_AR_BATCH
+    d = synthetic.quad_polynomial_batch(B, 10, 0.1, seed=21, ref_length=20)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    torch.manual_seed(6)
+    net = Net(15, 10, 9, 4, conv=1).to(dev)
+    dyn = FlightmareDynamics()
+    l0, g0, _ = F.quad_mlp_rollout_grads(net, s0, in_ref, ref, 0.1, dyn.params)
+    l0 = l0.item()
+    g0 = {k: v.double().cpu() for k, v in g0.items()}
+    torch.cuda.empty_cache()
+    monkeypatch.setattr(F, "_MAX_FUSED_AR_BATCH", 65536)
+    l1, g1, _ = F.quad_mlp_rollout_grads(net, s0, in_ref, ref, 0.1, dyn.params)
+    assert abs(l0 - l1.item()) / abs(l0) < 1e-5
+    for k in g0:
+        assert rel_err(g1[k].double().cpu().numpy(), g0[k].numpy()) < 1e-4, k

@@ -416,9 +416,12 @@ def test_wing_step_and_vjp(dev, tag, mp):
         assert rel_err(N(ga), g[f"step_{tag}_gaction"][i]) < TOL
 
 
-@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("layout", ["aos", "soa", "soa_two_per_lane"])
 @pytest.mark.parametrize("H", [20, 10])
-def test_wing_rollout_golden(dev, layout, H):
+def test_wing_rollout_golden(dev, layout, H, monkeypatch):
+    """G5 rollouts (incl. samples beyond the alpha / beta clamp).
+    soa_two_per_lane: the packed-fp32 kernel (two trajectories per lane) that
+    large batches use, forced here on the 64-trajectory golden batch."""
     from apg_trajectory_tracking_amd import functional as F
     from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
         FixedWingDynamics)
@@ -426,6 +429,11 @@ def test_wing_rollout_golden(dev, layout, H):
     p = f"h{H}_"
     dyn = FixedWingDynamics()
     s0, a, r = D(g[p + "state0"], dev), D(g[p + "actions"], dev), D(g[p + "ref"], dev)
+    if layout == "soa_two_per_lane":
+        monkeypatch.setenv("APG_WING_PK", "1")
+        layout = "soa"
+    else:
+        monkeypatch.setenv("APG_WING_PK", "0")
     if layout == "soa":
         s0, a, r = soa_state(s0), soa_seq(a), soa_seq(r)
     res = F.wing_rollout_fwd_bwd(s0, a, r, 0.05, dyn.params, layout=layout,
@@ -614,8 +622,8 @@ def test_quad_rollout_max_batch_chunk_additivity(dev):
     assert abs(total - full["loss"].item()) / full["loss"].item() < 1e-5
 
 
-@pytest.mark.parametrize("B,H", [(100, 7), (1, 20), (333, 13)])
-def test_wing_ragged_any_horizon_vs_oracle(dev, B, H):
+@pytest.mark.parametrize("B,H", [(100, 7), (1, 20), (333, 13), (258, 13)])
+def test_wing_ragged_any_horizon_vs_oracle(dev, B, H, monkeypatch):
     from apg_trajectory_tracking_amd import functional as F, synthetic
     from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
         FixedWingDynamics)
@@ -626,7 +634,12 @@ def test_wing_ragged_any_horizon_vs_oracle(dev, B, H):
         tp.WingOracle(WMOD), tp.fixed_wing_mpc_loss, d["state0"], d["actions"],
         d["ref"], dt)
     dyn = FixedWingDynamics(modified_params=dict(WMOD))
-    for layout in ("aos", "soa"):
+    # (even batches also through the two-trajectories-per-lane kernel, with the
+    # modified coefficient table read from the kernel arguments)
+    for layout in ("aos", "soa") + (("two_per_lane",) if B % 2 == 0 else ()):
+        monkeypatch.setenv("APG_WING_PK", "1" if layout == "two_per_lane" else "0")
+        if layout == "two_per_lane":
+            layout = "soa"
         a = (d["state0"].to(dev), d["actions"].to(dev), d["ref"].to(dev))
         if layout == "soa":
             a = (soa_state(a[0]), soa_seq(a[1]), soa_seq(a[2]))

@@ -1317,3 +1317,54 @@ def test_run_epoch_packed_path_with_an_arbitrary_policy(dev):
     s0_rows, ref_rows = t.state_data.packed()
     assert seen[0][2].data_ptr() == s0_rows.data_ptr()
     assert seen[0][3].data_ptr() == ref_rows.data_ptr()
+
+
+@pytest.mark.parametrize("mode", ["concurrent", "autoregressive", "LSTM"])
+def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
+    """TrainDrone.static_shard: stepping on the same resident tensors re-uses
+    their plane-layout copies (functional._StaticPlanes) - results equal the
+    uncached trainer's step by step, and an in-place change of the data
+    (`resample_data` style) is seen by the next step."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    B, H = 300, 10
+    cfg = dict(QUAD_CFG, train_mode=mode, batch_size=B, learning_rate_controller=1e-7)
+    R = H if mode == "concurrent" else 2 * H
+    d = synthetic.quad_polynomial_batch(B, H, 0.1, seed=9, ref_length=R)
+    torch.manual_seed(1)
+    proto = (LSTM_NEW(15, H, 9, 4, conv=1) if mode == "LSTM" else
+             Net(15, H, 9, 40 if mode == "concurrent" else 4, conv=1))
+    losses = []
+    for static in (False, True):
+        F._STATIC_PLANES.entries.clear()
+        t = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
+        t.net = type(proto)(15, H, 9, proto.fc_out.out_features, conv=1).to(dev)
+        t.net.load_state_dict(proto.state_dict())
+        t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=1e-7,
+                                                 momentum=0.9)
+        t.static_shard = static
+        t.hidden_generator = torch.Generator(device=dev).manual_seed(3)
+        s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+        normed = state_preprocessing(s0)
+        out = []
+        for step in range(4):
+            if step == 2:            # the data changes in place
+                s0[:, 6:9] += 0.25
+                normed.copy_(state_preprocessing(s0))
+            if mode == "concurrent":
+                loss = t.train_concurrent_fused(normed, s0, in_ref, ref)
+            else:
+                loss = t.train_recurrent_model(None, s0, in_ref, ref)
+            out.append(loss.item())
+        losses.append(out)
+        assert (len(F._STATIC_PLANES.entries) > 0) == static
+    a, b = losses
+    assert abs(a[1] - a[2]) / abs(a[1]) > 1e-4       # the change matters
+    for x, y in zip(a, b):
+        assert abs(x - y) / abs(x) < 1e-6, (a, b)
+    F._STATIC_PLANES.entries.clear()

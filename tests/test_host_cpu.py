@@ -588,6 +588,41 @@ def test_bench_line_contract():
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1
         assert isinstance(c["sample"], str) and c["value"] > 0
+    # round 3: HBM-honest buffer-set protocol, per-step rooflines
+    d = json.load(open(os.path.join(REPO, "profiles", "r03_bench.json")))
+    cfg, r = d["config"], d["roofline"]
+    B, H = cfg["batch_per_gpu"], cfg["horizon"]
+    assert cfg["buffer_sets"] >= 16 and r["buffer_sets"] == cfg["buffer_sets"]
+    # the read-only inputs alone exceed twice the 256 MiB Infinity Cache
+    assert cfg["input_bytes_all_sets"] == cfg["buffer_sets"] * B * (48 + 40 * H)
+    assert cfg["input_bytes_all_sets"] > 2 * 256 * 2**20
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"]
+               / (r["kernel_us_avg"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert r["algorithmic_bytes_per_launch"] == B * (48 + 56 * H)
+    assert "traffic" in r and "fabric" in r["traffic_what"]
+    for k, v in r["other_protocols"].items():       # labelled, never the headline
+        assert "NOT an HBM number" in v["note"] and v["kernel_us_avg"] > 0
+        assert v["input_bytes_all_sets"] < 256 * 2**20
+    assert abs(d["value"] - d["n_gpus"] * B * H / (d["ms_per_step"] * 1e-3)) \
+        < 1e-6 * d["value"]
+    assert cfg["timed_steps"] == d["steps"] * cfg["replays"]
+    assert cfg["timed_steps"] * d["ms_per_step"] >= 900      # >= ~1 s timed region
+    for key, mode in (("train_step", "concurrent"), ("train_step_ar", "autoregressive"),
+                      ("train_step_lstm", "LSTM")):
+        t = d[key]
+        assert t["fused"] is True and t["ms_per_step"] > 0, key
+        q = t["roofline"]
+        assert q["bound"] in ("mfma", "hbm")
+        floor = max(q["mfma_fp32"]["floor_ms"], q["hbm"]["floor_ms"])
+        assert abs(q["frac"] - floor / t["ms_per_step"]) < 1e-9 and 0 < q["frac"] < 1
+        assert q["mfma_fp32"]["peak_TFLOPs"] == 157.3 and q["hbm"]["peak_GBps"] == 8000.0
+    assert d["train_step_packed"]["ms_per_step"] > 0
+    assert "quad_rollout_rows_kernel" in d["train_step_packed"]["what"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["host_logical_cpus"] >= c["cores"] >= 1
+    assert c["c_oracle_quad_env_steps_per_s"] > 0 and c["c_oracle_wing_env_steps_per_s"] > 0
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")],
                            capture_output=True, text=True, timeout=300)
