@@ -40,6 +40,47 @@ def momentum_sgd(params, lr):
     return optim.SGD(params, lr=lr, momentum=0.9, fused=fused)
 
 
+class _GraphedStep:
+    """One optimizer step captured into a HIP graph (kernels of the fused
+    paths, the weight-gradient products, the fused SGD update) and replayed:
+    the ~12 launches of a step cost the host ~0.25 ms of Python and launch
+    overhead, more than the GPU needs for the concurrent step.  Valid while
+    the step's input tensors are the same objects with the same in-place
+    version (TrainBase._graphed re-captures otherwise); allocations made
+    during capture live in the graph's private pool, so the gradient views the
+    optimizer reads keep their addresses across replays."""
+
+    def __init__(self, fn, signature, keep, net, optimizer):
+        self.signature, self.keep = signature, keep
+        # the warm-up steps (allocator, momentum buffers, lazy inits, plane
+        # caches - all outside the capture) must not train: parameters and
+        # momentum are put back afterwards (a missing momentum buffer is a
+        # zero one: SGD's first step sets buf = grad = 0.9 * 0 + grad)
+        params = [p for p in net.parameters()]
+        saved = [p.detach().clone() for p in params]
+        bufs = [optimizer.state.get(p, {}).get("momentum_buffer") for p in params]
+        bufs = [None if b is None else b.detach().clone() for b in bufs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for p, v, b in zip(params, saved, bufs):
+                p.copy_(v)
+                now = optimizer.state.get(p, {}).get("momentum_buffer")
+                if now is not None:
+                    now.zero_() if b is None else now.copy_(b)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
+
+
 class TrainBase:
 
     def __init__(
@@ -123,6 +164,11 @@ class TrainBase:
         self.optimizer_controller = None
         self.grad_sync = None
         self.shuffle = True
+        # True: steps on unchanged resident tensors are replayed from a
+        # captured HIP graph (single process only: the data-parallel
+        # all-reduce stays an eager call between the kernels and the update)
+        self.graph_steps = False
+        self._graphs = {}
 
         # horizon / reference-window length (scripts/train_base.py:118-128)
         if self.train_mode in ["autoregressive", "LSTM"]:
@@ -190,6 +236,21 @@ class TrainBase:
                 loss = self.grad_sync.sync(loss.detach())
         self.optimizer_controller.step()
         return loss
+
+    def _graphed(self, key, inputs, fn):
+        """fn() - through a captured graph when `graph_steps` is on and the
+        inputs are the same tensor objects, unchanged, as at capture time."""
+        if not self.graph_steps or parallel.world_size() > 1 \
+                or not torch.cuda.is_available():
+            return fn()
+        sig = tuple((id(t), t._version, tuple(t.shape)) for t in inputs)
+        g = self._graphs.get(key)
+        if g is None or g.signature != sig:
+            g = self._graphs[key] = _GraphedStep(fn, sig, list(inputs), self.net,
+                                                 self.optimizer_controller)
+            # the capture's own warm-up steps may have bumped nothing; re-read
+            g.signature = tuple((id(t), t._version, tuple(t.shape)) for t in inputs)
+        return g()
 
     def analytic_train_dynamics(self):
         """The fused rollouts integrate the ANALYTIC simulator described by

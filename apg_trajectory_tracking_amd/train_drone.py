@@ -101,22 +101,36 @@ class TrainDrone(TrainBase):
         batch is rows `index` (gathered inside the kernels' layout change)."""
         self.optimizer_controller.zero_grad()
         batch_size = current_state.size()[0] if index is None else index.numel()
+        static = index is None and self.static_shard
+        tensors = (current_state, in_ref_states, ref_states)
         if self.train_mode == "LSTM":
+            if self.fused_policy and self._fusable():
+                def step():
+                    self.net.reset_hidden_state(
+                        batch_size, generator=self.hidden_generator)
+                    loss, grads, flat = F.quad_lstm_rollout_grads(
+                        self.net, current_state, in_ref_states, ref_states,
+                        self.delta_t, self.train_dynamics.params,
+                        self.net.hidden_state, self.net.cell_state, index=index,
+                        static_inputs=self.static_shard)
+                    return self._step_direct(loss, grads, flat)
+                # (a private hidden-state generator is not registered with the
+                # graph: those runs step eagerly)
+                if static and self.hidden_generator is None:
+                    return self._graphed("lstm", tensors, step)
+                return step()
             self.net.reset_hidden_state(
                 batch_size, generator=self.hidden_generator)
-            if self.fused_policy and self._fusable():
-                loss, grads, flat = F.quad_lstm_rollout_grads(
+        elif self.fused_policy and self._fusable_mlp():
+            def step():
+                loss, grads, flat = F.quad_mlp_rollout_grads(
                     self.net, current_state, in_ref_states, ref_states,
-                    self.delta_t, self.train_dynamics.params,
-                    self.net.hidden_state, self.net.cell_state, index=index,
+                    self.delta_t, self.train_dynamics.params, index=index,
                     static_inputs=self.static_shard)
                 return self._step_direct(loss, grads, flat)
-        elif self.fused_policy and self._fusable_mlp():
-            loss, grads, flat = F.quad_mlp_rollout_grads(
-                self.net, current_state, in_ref_states, ref_states,
-                self.delta_t, self.train_dynamics.params, index=index,
-                static_inputs=self.static_shard)
-            return self._step_direct(loss, grads, flat)
+            if static:
+                return self._graphed("autoregressive", tensors, step)
+            return step()
         if index is not None:     # per-step path: materialise the batch
             current_state, in_ref_states, ref_states = (
                 t.index_select(0, index) for t in
@@ -167,11 +181,16 @@ class TrainDrone(TrainBase):
             return ok
         if not ok:
             return None
-        loss, grads, flat = F.quad_concurrent_policy_grads(
-            n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
-            self.train_dynamics.params, index=index,
-            static_inputs=self.static_shard)
-        return self._step_direct(loss, grads, flat)
+        def step():
+            loss, grads, flat = F.quad_concurrent_policy_grads(
+                n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
+                self.train_dynamics.params, index=index,
+                static_inputs=self.static_shard)
+            return self._step_direct(loss, grads, flat)
+        if index is None and self.static_shard:
+            return self._graphed("concurrent", (in_state, current_state,
+                                                in_ref_states, ref_states), step)
+        return step()
 
     # ------------------------------------------- packed (row-layout) path --
     # scripts/train_base.py:198-209 + scripts/train_drone.py:175-203 for ANY

@@ -334,7 +334,8 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
     with torch.no_grad():
         Shard.normed_states = state_preprocessing(Shard.states)
     t.state_data = Shard
-    t.static_shard = True        # every step is on this resident shard
+    t.static_shard = True        # every step is on this resident shard:
+    t.graph_steps = world == 1   # plane copies kept, the step replayed as a graph
     t.init_optimizer()
     if mode == "packed":
         ref6 = torch.cat((d["ref"][:, :, :3], d["ref"][:, :, 6:9]), 2)
