@@ -22,7 +22,7 @@
      defined(APG_ROWS_BLOCK) || defined(APG_ROWS_ACT_PRE) ||                   \
      defined(APG_ROWS_REF_PER_STEP) || defined(APG_ROWS_REF_LOOK) ||           \
      defined(APG_ROWS_ST_AUX) || defined(APG_ROWS_REF_TOP) ||                  \
-     defined(APG_ROWS_LD_AUX) ||                                               \
+     defined(APG_ROWS_LD_AUX) || defined(APG_ROWS_STORE_AT_END) || defined(APG_ROWS_STORE_FLUSH_AT) ||                                               \
      defined(APG_REG_ACT_PRE) || defined(APG_REG_REF_PER_STEP) ||              \
      defined(APG_REG_REF_LOOK) || defined(APG_GEMM_ST_MAX) ||                  \
      defined(APG_GEMM_STREAM) || defined(APG_WING_WAVES) ||                    \

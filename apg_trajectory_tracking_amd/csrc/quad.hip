@@ -421,6 +421,12 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
 #ifndef APG_ROWS_LD_AUX
 #define APG_ROWS_LD_AUX 0  // default cache policy for the input rows
 #endif
+#ifndef APG_ROWS_STORE_AT_END
+#define APG_ROWS_STORE_AT_END 1  // dL/dactions rows wait in registers (the
+#endif                            // action rows' own) and are written AFTER the
+#ifndef APG_ROWS_STORE_FLUSH_AT   // reverse sweep: once the inputs come from
+#define APG_ROWS_STORE_FLUSH_AT (-1)  // HBM, writes in flight slow the reads
+#endif                            // (8.63 -> 8.39 us at 20 buffer sets)
 #ifndef APG_ROWS_REF_TOP
 #define APG_ROWS_REF_TOP 0  // 1: rows below H - kRefLook all requested before
 #endif                      //    the first store (top of the reverse sweep)
@@ -564,11 +570,37 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
       ga[i] = wr2 * d;
     }
     quad_step_adjoint(lam, ga, a0, st_w[k], c, st_trig[k]);
+#if APG_ROWS_STORE_AT_END
+    // rows k > kFlush are kept in registers and written when step kFlush is
+    // done (kFlush = -1, shipped: all of them after the sweep), later rows at
+    // once (profiles/r03_ab_quad.json `store_timing`)
+    constexpr int kFlush = APG_ROWS_STORE_FLUSH_AT;
+    a4[k] = (u4v){f2u(ga[0]), f2u(ga[1]), f2u(ga[2]), f2u(ga[3])};
+    if (k <= kFlush) {
+      if (k == kFlush) {
+#pragma unroll
+        for (int j = HT - 1; j > kFlush; --j)
+          __builtin_amdgcn_raw_buffer_store_b128(a4[j], r_ga, st16, j * p16,
+                                                 APG_ROWS_ST_AUX);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(a4[k], r_ga, st16, k * p16,
+                                             APG_ROWS_ST_AUX);
+    }
+#else
     __builtin_amdgcn_raw_buffer_store_b128(
         (u4v){f2u(ga[0]), f2u(ga[1]), f2u(ga[2]), f2u(ga[3])}, r_ga, st16, k * p16,
         APG_ROWS_ST_AUX);
+#endif
     if (k == HT / 2) APG_STAMP_AT(6);
   }
+#if APG_ROWS_STORE_AT_END
+  if constexpr (APG_ROWS_STORE_FLUSH_AT < 0) {
+#pragma unroll
+    for (int k = HT - 1; k >= 0; --k)
+      __builtin_amdgcn_raw_buffer_store_b128(a4[k], r_ga, st16, k * p16,
+                                             APG_ROWS_ST_AUX);
+  }
+#endif
   if (R.grad_state0) {
     const auto r_gs = __builtin_amdgcn_make_buffer_rsrc(R.grad_state0, 0,
                                                         3 * B * 16, 0x00020000);
