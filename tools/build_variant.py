@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from apg_trajectory_tracking_amd import build as B  # noqa: E402
 
-KERNELS = ["quad_rollout_reg_kernelILi0ELi10ELb0ELb1E", 
+KERNELS = ["quad_rollout_reg_kernelILi0ELi10ELb0ELb1E",
            "quad_rollout_rows_kernelILi10ELb0E"]
 
 

@@ -30,8 +30,8 @@
   "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v40",  \
       "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",     \
       "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",     \
-      "v61", "v62", "v63", "v64", "v65", "v66", "v67", "s40", "s41", "s42",     \
-      "s43", "memory"
+      "v61", "v62", "v63", "v64", "v65", "v66", "v67", "a0", "a1", "a2", "a3",    \
+      "s40", "s41", "s42", "s43", "memory"
 
 // 8 instructions per block, sources in three different register banks
 #define FMA_DIST3                                                              \
@@ -109,14 +109,57 @@
   "v_rcp_f32_e32 v16, v45\nv_rcp_f32_e32 v17, v44\n"
 #define PLAIN16 PLAIN15 "v_add_f32_e32 v17, v47, v56\n"
 
+// ---- round 3b: which FORM of a packed op is slow?  (the rollout kernel with
+// packed arithmetic ran 2.4 x slower than the scalar one although it issues
+// 10 % fewer instructions)
+#define PK8(x) x x x x x x x x
+#define PK_PLAIN PK8("v_pk_fma_f32 v[10:11], v[40:41], v[50:51], v[60:61]\n")
+#define PK_BCAST PK8("v_pk_fma_f32 v[10:11], v[40:41], v[50:51], v[60:61] op_sel_hi:[0,1,1]\n")
+#define PK_OPSEL PK8("v_pk_fma_f32 v[10:11], v[40:41], v[50:51], v[60:61] op_sel:[0,1,0] op_sel_hi:[0,0,1]\n")
+#define PK_LIT PK8("v_pk_mul_f32 v[10:11], v[40:41], 0.15915494 op_sel_hi:[1,0]\n")
+#define PK_INLINE PK8("v_pk_add_f32 v[10:11], v[40:41], -0.5 op_sel_hi:[1,0]\n")
+#define PK_NEG PK8("v_pk_add_f32 v[10:11], v[40:41], v[50:51] neg_lo:[0,1] neg_hi:[0,1]\n")
+#define PK_SGPR_BCAST PK8("v_pk_fma_f32 v[10:11], v[40:41], v[50:51], s[40:41] op_sel_hi:[0,1,1]\n")
+// a packed op reading a pair whose LOW half a scalar op has just written
+#define PK_AFTER_SCALAR                                                        \
+  "v_mul_f32_e32 v40, v42, v43\nv_pk_fma_f32 v[10:11], v[40:41], v[50:51], v[60:61]\n"  \
+  "v_mul_f32_e32 v44, v46, v47\nv_pk_fma_f32 v[12:13], v[44:45], v[52:53], v[62:63]\n"  \
+  "v_mul_f32_e32 v48, v42, v43\nv_pk_fma_f32 v[14:15], v[48:49], v[54:55], v[64:65]\n"  \
+  "v_mul_f32_e32 v56, v46, v47\nv_pk_fma_f32 v[16:17], v[56:57], v[58:59], v[66:67]\n"
+// a scalar op reading one half of a pair a packed op has just written
+#define SCALAR_AFTER_PK                                                        \
+  "v_pk_fma_f32 v[10:11], v[40:41], v[50:51], v[60:61]\nv_mul_f32_e32 v18, v10, v43\n"  \
+  "v_pk_fma_f32 v[12:13], v[44:45], v[52:53], v[62:63]\nv_mul_f32_e32 v19, v13, v43\n"  \
+  "v_pk_fma_f32 v[14:15], v[48:49], v[54:55], v[64:65]\nv_mul_f32_e32 v18, v14, v43\n"  \
+  "v_pk_fma_f32 v[16:17], v[56:57], v[58:59], v[66:67]\nv_mul_f32_e32 v19, v17, v43\n"
+// packed op right after a transcendental that wrote one of its halves
+#define PK_AFTER_TRANS                                                         \
+  "v_sin_f32_e32 v40, v42\nv_cos_f32_e32 v41, v42\nv_pk_mul_f32 v[10:11], v[40:41], v[50:51]\n"  \
+  "v_sin_f32_e32 v44, v46\nv_cos_f32_e32 v45, v46\nv_pk_mul_f32 v[12:13], v[44:45], v[52:53]\n"  \
+  "v_mov_b32_e32 v18, v10\nv_mov_b32_e32 v19, v12\n"
+// AGPR round trips around packed ops
+#define PK_ACC                                                                 \
+  "v_accvgpr_write_b32 a0, v10\nv_accvgpr_write_b32 a1, v11\n"                 \
+  "v_pk_fma_f32 v[10:11], v[40:41], v[50:51], v[60:61]\n"                       \
+  "v_accvgpr_read_b32 v40, a0\nv_accvgpr_read_b32 v41, a1\n"                   \
+  "v_pk_fma_f32 v[12:13], v[40:41], v[52:53], v[62:63]\n"                       \
+  "v_accvgpr_write_b32 a2, v12\nv_accvgpr_read_b32 v44, a2\n"
+
 enum { P_FMA_DIST3, P_FMA_SAMEBANK, P_MUL_DIST2, P_FMAC_DIST, P_FMA_CHAIN_DIST,
        P_PKFMA_DIST, P_PKMUL_DIST, P_PKFMA_SGPR, P_WING_MIX, P_WING_CLUSTER,
-       P_PLAIN16, P_COUNT };
+       P_PLAIN16, P_PK_PLAIN, P_PK_BCAST, P_PK_OPSEL, P_PK_LIT, P_PK_INLINE, P_PK_NEG,
+       P_PK_SGPR_BCAST, P_PK_AFTER_SCALAR, P_SCALAR_AFTER_PK, P_PK_AFTER_TRANS,
+       P_PK_ACC, P_COUNT };
 static const char *kNames[P_COUNT] = {
     "fma_dist3", "fma_samebank", "mul_dist2", "fmac_dist", "fma_chain_dist",
     "pk_fma_dist", "pk_mul_dist", "pk_fma_sgpr", "wing_mix_15plain_1rcp",
-    "wing_mix_60plain_4rcp_clustered", "plain16_no_transcendental"};
-static const int kInstr[P_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 16, 64, 16};
+    "wing_mix_60plain_4rcp_clustered", "plain16_no_transcendental",
+    "pk_plain_dep", "pk_bcast_src0", "pk_op_sel_mixed", "pk_mul_literal",
+    "pk_add_inline_const", "pk_add_neg", "pk_fma_sgpr_src2_bcast",
+    "pk_after_scalar_halfwrite", "scalar_after_pk_halfread", "pk_after_sincos",
+    "pk_with_agpr_roundtrips"};
+static const int kInstr[P_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 16, 64, 16,
+                                    8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
 
 template <int P>
 __global__ __launch_bounds__(64) void probe(unsigned long long *out, int reps) {
@@ -151,6 +194,17 @@ __global__ __launch_bounds__(64) void probe(unsigned long long *out, int reps) {
     if constexpr (P == P_WING_MIX) asm volatile(R32(WING_MIX) ::: VCLOB);
     if constexpr (P == P_WING_CLUSTER) asm volatile(R32(WING_MIX_CLUSTER) ::: VCLOB);
     if constexpr (P == P_PLAIN16) asm volatile(R32(PLAIN16) ::: VCLOB);
+    if constexpr (P == P_PK_PLAIN) asm volatile(R32(PK_PLAIN) ::: VCLOB);
+    if constexpr (P == P_PK_BCAST) asm volatile(R32(PK_BCAST) ::: VCLOB);
+    if constexpr (P == P_PK_OPSEL) asm volatile(R32(PK_OPSEL) ::: VCLOB);
+    if constexpr (P == P_PK_LIT) asm volatile(R32(PK_LIT) ::: VCLOB);
+    if constexpr (P == P_PK_INLINE) asm volatile(R32(PK_INLINE) ::: VCLOB);
+    if constexpr (P == P_PK_NEG) asm volatile(R32(PK_NEG) ::: VCLOB);
+    if constexpr (P == P_PK_SGPR_BCAST) asm volatile(R32(PK_SGPR_BCAST) ::: VCLOB);
+    if constexpr (P == P_PK_AFTER_SCALAR) asm volatile(R32(PK_AFTER_SCALAR) ::: VCLOB);
+    if constexpr (P == P_SCALAR_AFTER_PK) asm volatile(R32(SCALAR_AFTER_PK) ::: VCLOB);
+    if constexpr (P == P_PK_AFTER_TRANS) asm volatile(R32(PK_AFTER_TRANS) ::: VCLOB);
+    if constexpr (P == P_PK_ACC) asm volatile(R32(PK_ACC) ::: VCLOB);
   }
   asm volatile("s_memtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
   float sink;
@@ -186,6 +240,19 @@ void run(unsigned long long *d_out, int waves_per_simd, int reps = 64) {
 int main() {
   unsigned long long *d_out;
   CK(hipMalloc(&d_out, 8192 * 8));
+  if (true) {   // the packed-form probes: one wave per SIMD
+    run<P_PK_PLAIN>(d_out, 1);
+    run<P_PK_BCAST>(d_out, 1);
+    run<P_PK_OPSEL>(d_out, 1);
+    run<P_PK_LIT>(d_out, 1);
+    run<P_PK_INLINE>(d_out, 1);
+    run<P_PK_NEG>(d_out, 1);
+    run<P_PK_SGPR_BCAST>(d_out, 1);
+    run<P_PK_AFTER_SCALAR>(d_out, 1);
+    run<P_SCALAR_AFTER_PK>(d_out, 1);
+    run<P_PK_AFTER_TRANS>(d_out, 1);
+    run<P_PK_ACC>(d_out, 1);
+  }
   for (int w = 1; w <= 2; ++w) {
     run<P_FMA_DIST3>(d_out, w);
     run<P_FMA_SAMEBANK>(d_out, w);
