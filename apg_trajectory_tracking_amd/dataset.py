@@ -232,7 +232,11 @@ class SyntheticWingDataset:
     normed_states = ((state - mean) / std)[:, 3:], in_ref = last linear
     reference point relative to the aircraft, ref_states = the [N,H,3] linear
     reference of _compute_target_pos; fixed mean / std of set_fixed_mean
-    (:284-299)."""
+    (:284-299) unless given.  As in the reference the set has
+    `num_sampled_states` sampled entries, refreshed by `resample_data`,
+    followed by `num_self_play = int(self_play * num_states)` slots that the
+    closed-loop evaluation overwrites cyclically with the states it visited
+    (`add_eval_data`, the batched get_and_add_eval_data :103-119)."""
 
     MEAN = [0.0, 0.0, 0.0, 11.525899887084961, -0.00016766408225521445,
             0.16617104411125183, 0.007394296582788229, 0.018172707409,
@@ -243,20 +247,24 @@ class SyntheticWingDataset:
            0.04499124363064766, 0.10370047390460968, 0.049977313727,
            0.06449887901544571, 0.27508440613746643, 0.05634994804859]
 
-    def __init__(self, num_states, horizon, dt, seed=0, device="cuda"):
+    def __init__(self, num_states, horizon, dt, seed=0, device="cuda",
+                 self_play=0.0, mean=None, std=None):
         self.num_sampled_states = int(num_states)
+        self.num_self_play = int(self_play * num_states)
+        self.total_dataset_size = self.num_sampled_states + self.num_self_play
         self.horizon, self.dt = horizon, dt
         self.device = torch.device(device)
         self.seed = seed
         self._epoch = 0
-        self.mean = torch.tensor(self.MEAN)
-        self.std = torch.tensor(self.STD)
-        self._fill()
+        self.eval_counter = 0
+        self.mean = torch.tensor(self.MEAN if mean is None else mean).float()
+        self.std = torch.tensor(self.STD if std is None else std).float()
+        self._fill(self.total_dataset_size)
 
-    def _fill(self):
+    def _fill(self, n):
         from . import synthetic
-        d = synthetic.wing_batch(self.num_sampled_states, self.horizon,
-                                 self.dt, seed=self.seed + self._epoch)
+        d = synthetic.wing_batch(n, self.horizon, self.dt,
+                                 seed=self.seed + self._epoch)
         states = d["state0"]
         fresh = dict(
             normed_states=((states - self.mean) / self.std)[:, 3:],
@@ -264,13 +272,57 @@ class SyntheticWingDataset:
             in_ref_states=d["ref"][:, -1] - states[:, :3])
         for name, t in fresh.items():
             if hasattr(self, name):    # renew IN PLACE: the trainer's loader
-                getattr(self, name).copy_(t)   # holds these very tensors
+                getattr(self, name)[:n].copy_(t)   # holds these very tensors
             else:
                 setattr(self, name, t.to(self.device))
 
     def resample_data(self):
+        """:87-101 - only the sampled part is renewed."""
         self._epoch += 1
-        self._fill()
+        self._fill(self.num_sampled_states)
+
+    def _compute_target_pos(self, current_state, ref_vector):
+        """:309-320: points 12 * dt * (i + 1) along ref_vector, the products in
+        the reference's order (float32 tensor x Python double x int)."""
+        steps = torch.arange(1, self.horizon + 1, device=current_state.device,
+                             dtype=torch.float32)
+        step_vec = ref_vector * (12 * self.dt)
+        return current_state[:, None, :3] + step_vec[:, None, :] * steps[None, :, None]
+
+    def prepare_data(self, states, ref_states):
+        """WingDataset.prepare_data (:322-350) on device tensors: states [n,12],
+        ref_states [n,3] (target points) -> (normed_states, states, in_ref,
+        linear reference [n,H,3])."""
+        states = states.to(self.device, torch.float32)
+        target = ref_states.to(self.device, torch.float32)
+        mean, std = self.mean.to(self.device), self.std.to(self.device)
+        normed = ((states - mean) / std)[:, 3:]
+        rel = target - states[:, :3]
+        norm = torch.sqrt(torch.sum(rel**2, dim=1))
+        nvec = (rel.t() / norm).t()
+        ref = self._compute_target_pos(states, nvec)
+        return normed, states, ref[:, -1] - states[:, :3], ref
+
+    def get_eval_index(self):
+        if self.num_self_play > 0:
+            return self.eval_counter % self.num_self_play + self.num_sampled_states
+
+    def add_eval_data(self, states, targets):
+        """Overwrite the next self-play slots with n visited (state, target)
+        pairs, in order, wrapping around like repeated
+        get_and_add_eval_data(..., add_to_dataset=True) calls."""
+        n = states.shape[0]
+        if self.num_self_play == 0 or n == 0:
+            return 0
+        prepared = self.prepare_data(states, targets)
+        keep = min(n, self.num_self_play)   # only these survive a wrap-around
+        idx = ((self.eval_counter + torch.arange(n - keep, n, device=self.device))
+               % self.num_self_play + self.num_sampled_states)
+        for dst, src in zip((self.normed_states, self.states,
+                             self.in_ref_states, self.ref_states), prepared):
+            dst[idx] = src[n - keep:]
+        self.eval_counter += n
+        return n
 
     def __len__(self):
         return self.states.shape[0]

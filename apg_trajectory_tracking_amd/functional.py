@@ -1277,6 +1277,64 @@ def quad_lstm_closed_loop(net, traj, dt, params, h0, c0, max_steps=251,
     return out
 
 
+def wing_mlp_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
+                         data_horizon=10, state0=None, max_steps=1000,
+                         thresh_div=10.0, thresh_stable=0.8, test_time=0,
+                         want_trajectory=False):
+    """`FixedWingEvaluator.fly_to_point` (scripts/evaluate_fixed_wing.py:45-131)
+    for a batch of target lists in one launch (apg_wing_mlp_closed_loop).
+    net: hutter_model.Net(9, 1, 3, 4*k, conv=False) - the first action of the
+    plan is flown, as in the reference.  targets [B, n_targets, 3]; mean / std:
+    the data set's 12 normalisation values; data_dt / data_horizon: its dt and
+    horizon (WingDataset.prepare_data, neural_control/dataset.py:322-350);
+    state0 [B, 12] or None for SimpleWingEnv.zero_reset.
+    Returns dict(div_linear [T,B], div_pass [T,B], div_fail [T,B] (-1 where
+    fly_to_point appends nothing to div_target), steps [B] int32, and with
+    want_trajectory: drone [T,16,B] (state after the step + action), seen
+    [T,15,B] (state the policy saw + its target))."""
+    B, n_targets, _ = targets.shape
+    dev = targets.device
+    tg = _f32c(targets).permute(1, 2, 0).contiguous()
+    s0 = None if state0 is None else to_soa(state0)
+    names = ("w_s", "b_s", "w_r", "b_r", "w_1", "b_1", "w_2", "b_2", "w_3",
+             "b_3", "w_out", "b_out")
+    vals = (net.states_in.weight, net.states_in.bias, net.ref_in.weight,
+            net.ref_in.bias, net.fc1.weight, net.fc1.bias, net.fc2.weight,
+            net.fc2.bias, net.fc3.weight, net.fc3.bias, net.fc_out.weight,
+            net.fc_out.bias)
+    pw = {k: _f32c(v.detach()).contiguous() for k, v in zip(names, vals)}
+    if (pw["w_s"].shape != (64, 9) or pw["w_r"].shape != (64, 3)
+            or pw["w_1"].shape != (64, 128) or pw["w_out"].shape[1] != 64
+            or pw["w_out"].shape[0] < 4):
+        raise ValueError("closed loop needs Net(9, 1, 3, 4*k, conv=False)")
+    require_device(tg, *pw.values())
+    if s0 is not None:
+        require_device(s0)
+    pol = _capi.ApgWingPolicy(**{k: ptr(v) for k, v in pw.items()})
+    f12 = ctypes.c_float * 12
+    mean = f12(*[float(v) for v in mean])
+    std = f12(*[float(v) for v in std])
+    T = int(max_steps)
+    new = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    div_linear, div_pass, div_fail = new(T, B), new(T, B), new(T, B)
+    steps = torch.zeros(B, dtype=torch.int32, device=dev)
+    drone = new(T, 16, B) if want_trajectory else None
+    seen = new(T, 15, B) if want_trajectory else None
+    ws = new(lib().apg_wing_policy_workspace_floats())
+    check(lib().apg_wing_mlp_closed_loop(
+        ptr(tg), n_targets, ptr(s0), float(dt), ctypes.byref(params),
+        ctypes.byref(pol), mean, std, float(data_dt), int(data_horizon), B, T,
+        float(thresh_div), float(thresh_stable), int(test_time),
+        ptr(div_linear), ptr(div_pass), ptr(div_fail), steps.data_ptr(),
+        ptr(drone), ptr(seen), ptr(ws), stream_of(tg)),
+        "apg_wing_mlp_closed_loop")
+    out = dict(div_linear=div_linear, div_pass=div_pass, div_fail=div_fail,
+               steps=steps)
+    if want_trajectory:
+        out.update(drone=drone, seen=seen)
+    return out
+
+
 # --------------------------- concurrent mode with the policy inside (config 2)
 class _QuadConcurrentPolicyLoss(torch.autograd.Function):
     """loss of the concurrent training step with `Net(15, 10, 9, 40, conv=1)`

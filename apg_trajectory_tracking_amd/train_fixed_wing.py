@@ -1,7 +1,9 @@
-"""Drop-in for scripts/train_fixed_wing.py:20-116 (`TrainFixedWing`)
-restricted to the APG hot path: `train_controller_model` (:90-116) as one
-fused HIP launch (H x fixed-wing dynamics at dt = delta_t_train +
-fixed_wing_mpc_loss + analytic adjoint)."""
+"""Drop-in for scripts/train_fixed_wing.py:20-197 (`TrainFixedWing`):
+`train_controller_model` (:90-116) as one fused HIP launch (H x fixed-wing
+dynamics at dt = delta_t_train + fixed_wing_mpc_loss + analytic adjoint) and
+`evaluate_model` (:142-197) on the batched closed-loop evaluator
+(evaluate_fixed_wing.FixedWingEvaluator: all test flights in one launch),
+with self play into the data set and the threshold curriculum."""
 import torch
 
 from . import functional as F
@@ -35,14 +37,70 @@ class TrainFixedWing(TrainBase):
                 self.action_dim * self.horizon, conv=False)
         self.net.to(device)
         if state_data is None:
-            n = int(self.epoch_size * (1 + self.self_play))
+            # epoch_size sampled states + int(self_play * epoch_size) slots for
+            # the states the evaluation flights visit (WingDataset(epoch_size,
+            # **config), :80; DroneDataset.__init__, dataset.py:48-56)
             state_data = SyntheticWingDataset(
-                n, self.horizon, self.delta_t_train, seed=seed, device=device)
+                self.epoch_size, self.horizon, self.delta_t_train, seed=seed,
+                device=device, self_play=self.self_play,
+                mean=self.config.get("mean"), std=self.config.get("std"))
         self.state_data = state_data
         self.config["mean"] = self.state_data.mean.tolist()
         self.config["std"] = self.state_data.std.tolist()
+        self.config["thresh_div"] = self.thresh_div_start
         self.config["dt"] = self.delta_t
+        self.config["take_every_x"] = self.self_play_every_x
+        self.config["thresh_stable"] = self.thresh_stable_start
         self.init_optimizer()
+
+    # flights per launch while the self-play slots are first filled (the
+    # reference flies them five at a time, :156-160; here a launch is one batch)
+    self_play_flights = 64
+
+    def evaluate_model(self, epoch):
+        """scripts/train_fixed_wing.py:142-197: flights with self play (at
+        epoch 0 until `self_play` states were collected), two test_time
+        flights for the score, resampling, the divergence / stability
+        threshold ladders, checkpoint, statistics."""
+        from .evaluate_fixed_wing import FixedWingEvaluator, FixedWingNetWrapper
+        n = self.net
+        env = (self.eval_dynamics if self.sample_in == "eval_env"
+               else self.train_dynamics)
+        if isinstance(env, torch.nn.Module):
+            env = self.eval_dynamics
+        if not (isinstance(n, Net) and not n.conv and hasattr(env, "params")
+                and hasattr(self.state_data, "add_eval_data")
+                and n.fc1.weight.shape == (64, 128)):
+            return None          # no fused evaluator for this architecture
+        keys = ("dt", "horizon", "thresh_div", "thresh_stable", "take_every_x")
+        cfg = {k: self.config[k] for k in keys if k in self.config}
+        controller = FixedWingNetWrapper(n, self.state_data, **cfg)
+        evaluator = FixedWingEvaluator(controller, env, **cfg)
+        data = self.state_data
+        with torch.no_grad():
+            if epoch == 0 and data.num_self_play > 0:
+                goal = data.eval_counter + int(self.config.get(
+                    "self_play", data.num_self_play))
+                while data.eval_counter < goal:
+                    before = data.eval_counter
+                    evaluator.run_eval(nr_test=self.self_play_flights,
+                                       printout=False)
+                    if data.eval_counter == before:
+                        break          # nothing is being collected
+            evaluator.run_eval(nr_test=10, printout=False)
+            evaluator_test = FixedWingEvaluator(
+                controller, env, **dict(cfg, test_time=True))
+            suc_mean, suc_std = evaluator_test.run_eval(nr_test=2, printout=False)
+        self.sample_new_data(epoch)
+        if epoch % 5 == 0 and self.config["thresh_div"] < self.thresh_div_end:
+            self.config["thresh_div"] += .2
+        if epoch % 5 == 0 and self.config["thresh_stable"] < self.thresh_stable_end:
+            self.config["thresh_stable"] += .05
+        self.save_model(epoch, suc_mean, suc_std)
+        self.results_dict["mean_success"].append(suc_mean)
+        self.results_dict["std_success"].append(suc_std)
+        self.results_dict["thresh_div"].append(self.config["thresh_div"])
+        return suc_mean, suc_std
 
     fused_policy = True   # policy on the matrix cores around the fused rollout
 

@@ -491,6 +491,38 @@ int apg_wing_policy_bwd(const float *actions, const float *grad_actions,
                         const ApgWingPolicy *policy, int B, float *d_zout,
                         float *d_pre, float *workspace, apg_stream_t stream);
 
+/* Closed-loop evaluation of the fixed-wing controller - beyond SURVEY.md §8:
+ * FixedWingEvaluator.fly_to_point (scripts/evaluate_fixed_wing.py:45-131) for B
+ * target lists in one launch.  Per step: WingDataset.prepare_data
+ * (neural_control/dataset.py:322-350; mean / std: HOST arrays of 12, entries
+ * 3..11 used; data_dt / data_horizon: the data set's dt and horizon, which fix
+ * the length 12 * dt * horizon of the reference vector the policy sees),
+ * FixedWingNetWrapper.predict_actions (neural_control/controllers/
+ * network_wrapper.py:81-98: sigmoid, first action; only rows 0..3 of
+ * policy->w_out / b_out are read, so a head of any horizon serves),
+ * SimpleWingEnv.step (neural_control/environments/wing_env.py:44-57, dt),
+ * project_to_line (neural_control/trajectory/q_funcs.py:6-18), the target
+ * switch, and on divergence the break (test_time) or the reset onto the line
+ * at 11.5 m/s.  targets [n_targets][3][B]; state0 [12][B] or NULL (zero_reset:
+ * zeros, u = 11.5).  Outputs, all SoA: div_linear [T][B] (div_to_linear),
+ * div_pass [T][B] / div_fail [T][B] = the values fly_to_point appends to
+ * div_target when a target is passed / on divergence at that step (-1: none;
+ * the caller appends thresh_div for a run with steps == max_steps), steps [B]
+ * = len(drone_traj); optional drone [T][16][B] (state after the step, action)
+ * and seen [T][15][B] (state the policy saw - after a reset still the last
+ * simulated one, as in the reference - and its target).
+ * workspace: apg_wing_policy_workspace_floats(). */
+int apg_wing_mlp_closed_loop(const float *targets, int n_targets,
+                             const float *state0, float dt,
+                             const ApgWingParams *params,
+                             const ApgWingPolicy *policy, const float *mean,
+                             const float *std, float data_dt, int data_horizon,
+                             int B, int max_steps, float thresh_div,
+                             float thresh_stable, int test_time,
+                             float *div_linear, float *div_pass, float *div_fail,
+                             int *steps, float *drone, float *seen,
+                             float *workspace, apg_stream_t stream);
+
 /* Weights of fixed_wing_mpc_loss, neural_control/drone_loss.py:72-82
  * (reference values: pos 10, action 0.1). */
 typedef struct ApgWingLossWeights {

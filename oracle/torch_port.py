@@ -442,3 +442,100 @@ def quad_closed_loop(net, dyn, traj, dt, horizon, max_steps, thresh_div,
             if i >= L:
                 break
     return out
+
+
+def wing_closed_loop(net, dyn, targets, dt, mean, std, data_dt, data_horizon,
+                     max_steps, thresh_div, thresh_stable, test_time,
+                     state0=None, des_speed=11.5):
+    """Batched restatement of `FixedWingEvaluator.fly_to_point`
+    (scripts/evaluate_fixed_wing.py:45-131) with
+      WingDataset.prepare_data / _compute_target_pos
+        (neural_control/dataset.py:309-350),
+      FixedWingNetWrapper.predict_actions (controllers/network_wrapper.py:81-98),
+      SimpleWingEnv.zero_reset / step (environments/wing_env.py:26-28,44-57),
+      project_to_line (trajectory/q_funcs.py:6-18, evaluated in float64 as the
+      reference's numpy arithmetic is).
+    targets [B, n, 3]; every flight runs its own loop (target switch, break and
+    reset are per flight).  As in the reference the policy keeps seeing the
+    last SIMULATED state after a reset (:124 resets the environment only).
+    Returns dict: traj [B, T, 16] (state after the step + action), div_linear
+    [B, T], div_pass / div_fail [B, T] (what the step appended to div_target
+    when a target was passed / on divergence, -1 otherwise), seen [B, T, 15]
+    (state the policy saw + its target), steps [B]."""
+    B, n_t, _ = targets.shape
+    T = max_steps
+    f64 = torch.float64
+    mean = torch.as_tensor(mean, dtype=torch.float32)
+    std = torch.as_tensor(std, dtype=torch.float32)
+    if state0 is None:
+        env = torch.zeros(B, 12)
+        env[:, 3] = 11.5
+    else:
+        env = state0.clone().float()
+    obs = env.clone()
+    line = env[:, :3].to(f64)
+    prev = env[:, :3].to(f64)
+    ti = torch.zeros(B, dtype=torch.long)
+    alive = torch.ones(B, dtype=torch.bool)
+    out = dict(traj=torch.zeros(B, T, 16), div_linear=torch.zeros(B, T, dtype=f64),
+               div_pass=-torch.ones(B, T, dtype=f64),
+               div_fail=-torch.ones(B, T, dtype=f64), seen=torch.zeros(B, T, 15),
+               steps=torch.zeros(B, dtype=torch.long))
+    tg64 = targets.to(f64)
+
+    def project(a, b, p):
+        ab = b - a
+        n2 = (ab * ab).sum(1, keepdim=True)
+        d = (ab * (p - a)).sum(1, keepdim=True)
+        return torch.where(n2 > 0, a + ab * d / n2.clamp(min=1e-300), a)
+
+    rows = torch.arange(B)
+    vec_len = 12 * data_dt
+    with torch.no_grad():
+        for k in range(T):
+            tg = tg64[rows, ti]
+            tg32 = tg.float()
+            out["seen"][alive, k] = torch.cat((obs, tg32), 1)[alive]
+            normed = ((obs - mean) / std)[:, 3:]
+            rel = tg32 - obs[:, :3]
+            nvec = (rel.t() / torch.sqrt(torch.sum(rel**2, dim=1))).t()
+            last = obs[:, :3] + nvec * vec_len * data_horizon
+            in_ref = last - obs[:, :3]
+            action = torch.sigmoid(net(normed, in_ref))[:, :4]
+            new = dyn(env, action, dt)
+            obs = new
+            stable = (new[:, 6:8].abs() < thresh_stable).all(1)
+            pos = new[:, :3].to(f64)
+            on_line = project(line, tg, pos)
+            div = torch.linalg.norm(on_line - pos, dim=1)
+            rec = alive.clone()
+            out["traj"][rec, k] = torch.cat((new, action), 1)[rec]
+            out["div_linear"][rec, k] = div[rec]
+            out["steps"][rec] = k + 1
+            passed = pos[:, 0] > tg[:, 0]
+            d_pass = torch.linalg.norm(project(prev, pos, tg) - tg, dim=1)
+            last_target = ti >= n_t - 1
+            done = passed & last_target
+            advance = passed & ~last_target
+            failed = ~done & (~stable | (div > thresh_div))
+            d_fail = torch.full((B,), float(thresh_div), dtype=f64)
+            if test_time:
+                d_fail = torch.linalg.norm(pos - tg, dim=1)
+            out["div_pass"][rec & passed, k] = d_pass[rec & passed]
+            out["div_fail"][rec & failed, k] = d_fail[rec & failed]
+            # continue on the line towards the (old) target at des_speed
+            v = tg - on_line
+            reset = torch.zeros(B, 12, dtype=f64)
+            reset[:, :3] = on_line
+            reset[:, 3:6] = v / torch.linalg.norm(v, dim=1, keepdim=True) * des_speed
+            do_reset = failed & (not test_time)
+            env = torch.where(do_reset[:, None], reset.float(), new)
+            line = torch.where(advance[:, None], pos, line)
+            ti = ti + advance.long()
+            prev = pos
+            if test_time:
+                done = done | failed
+            alive = alive & ~done
+            if not alive.any():
+                break
+    return out

@@ -25,6 +25,8 @@ Fixtures:
                          with self play on (needs closed_loop.npz)
   schedules.npz      G14 TrainBase.run_control (speed curriculum) and
                          run_dynamics with scripted evaluation results
+  wing_closed_loop.npz G15 FixedWingEvaluator.fly_to_point / run_eval with the
+                         shipped wing controller (+ self play into WingDataset)
 
 `python tests/golden/make_golden.py g11` regenerates selected fixtures only.
 """
@@ -919,11 +921,176 @@ def g14_schedules():
         os.chdir(cwd)
 
 
+# -------------------------------------------------------------------- G15
+def _wing_eval_parts():
+    """The reference pieces of the fixed-wing evaluation with the shipped
+    controller; SimpleWingEnv without its renderer."""
+    import json
+    from neural_control.environments.wing_env import SimpleWingEnv
+    from neural_control.dataset import WingDataset
+
+    model_dir = os.path.join(REF, "trained_models", "wing", "current_model")
+    net = torch.load(os.path.join(model_dir, "model_wing"), weights_only=False)
+    net.eval()
+    with open(os.path.join(model_dir, "config.json")) as f:
+        cfg = json.load(f)
+
+    class Env(SimpleWingEnv):
+        def __init__(self, dynamics, dt):
+            self.dt, self.dynamics = dt, dynamics
+
+    def dataset(n_sampled=0, n_self=0):
+        ds = WingDataset.__new__(WingDataset)
+        ds.mean = torch.tensor(cfg["mean"]).float()
+        ds.std = torch.tensor(cfg["std"]).float()
+        ds.dt, ds.horizon = cfg["delta_t"], cfg["horizon"]
+        ds.num_sampled_states, ds.num_self_play = n_sampled, n_self
+        ds.total_dataset_size = n_sampled + n_self
+        ds.eval_counter = 0
+        H = ds.horizon
+        ds.normed_states = torch.zeros(ds.total_dataset_size, 9)
+        ds.states = torch.zeros(ds.total_dataset_size, 12)
+        ds.in_ref_states = torch.zeros(ds.total_dataset_size, 3)
+        ds.ref_states = torch.zeros(ds.total_dataset_size, H, 3)
+        return ds
+    return net, cfg, Env, dataset
+
+
+def g15_wing_closed_loop():
+    """Beyond §8 (VERDICT r2 missing #5): the REAL FixedWingEvaluator.fly_to_point
+    and run_eval (scripts/evaluate_fixed_wing.py:45-178) with the controller the
+    reference ships (trained_models/wing, Net(9, 1, 3, 40), horizon 10,
+    dt 0.05) through FixedWingNetWrapper.predict_actions ->
+    WingDataset.prepare_data -> SimpleWingEnv.step.  Recorded per case and run:
+    the flown trajectory (state + action rows), div_target and div_to_linear;
+    with loose / tight thresholds (tight ones trigger the reset-onto-the-line
+    branch), test_time on and off, several targets per flight, a flight cut at
+    max_steps, modified dynamics; and one run_eval with self play into a real
+    WingDataset (targets drawn from a seeded numpy stream, recorded)."""
+    import evaluate_fixed_wing as efw
+    from neural_control.controllers.network_wrapper import FixedWingNetWrapper
+
+    net, cfg, Env, dataset = _wing_eval_parts()
+    dt = 0.05
+    rng = np.random.default_rng(515)
+    n_run = 6
+    single = np.zeros((n_run, 1, 3))
+    single[:, 0, 0] = 50
+    single[:, 0, 1:] = (rng.uniform(size=(n_run, 2)) - .5) * 2 * 5
+    multi = np.zeros((n_run, 3, 3))
+    multi[:, :, 0] = np.array([25, 50, 80])[None] + rng.uniform(-3, 3, (n_run, 3))
+    multi[:, :, 1:] = rng.uniform(-4, 4, (n_run, 3, 2))
+    single = single.astype(np.float32).astype(np.float64)
+    multi = multi.astype(np.float32).astype(np.float64)
+    wmod = {"mass": 1.2, "CL0": 0.3, "rho": 1.1}
+    cases = {
+        # the thresholds of the evaluation script's __main__ (:225-231)
+        "eval": dict(targets=single, test_time=1, thresh_div=10, thresh_stable=3,
+                     max_steps=1000, mp={}),
+        # the trainer's start thresholds (configs/wing_config.json)
+        "train": dict(targets=single, test_time=0, thresh_div=4, thresh_stable=.4,
+                      max_steps=1000, mp={}),
+        "tight": dict(targets=single, test_time=0, thresh_div=.2,
+                      thresh_stable=.4, max_steps=300, mp={}),
+        "tight_test": dict(targets=single, test_time=1, thresh_div=.2,
+                           thresh_stable=.4, max_steps=300, mp={}),
+        "unstable": dict(targets=single, test_time=0, thresh_div=10,
+                         thresh_stable=.12, max_steps=200, mp={}),
+        "multi": dict(targets=multi, test_time=0, thresh_div=4, thresh_stable=.8,
+                      max_steps=1000, mp={}),
+        "multi_tight": dict(targets=multi, test_time=0, thresh_div=.8,
+                            thresh_stable=.8, max_steps=400, mp={}),
+        "cut": dict(targets=single, test_time=0, thresh_div=4, thresh_stable=.8,
+                    max_steps=30, mp={}),
+        "modified": dict(targets=single, test_time=0, thresh_div=1.21,
+                         thresh_stable=.8, max_steps=300, mp=wmod),
+    }
+    out = {"dt": np.float32(dt), "data_dt": np.float32(cfg["delta_t"]),
+           "data_horizon": np.int64(cfg["horizon"]),
+           "mean": np.asarray(cfg["mean"], np.float32),
+           "std": np.asarray(cfg["std"], np.float32),
+           "cases": np.array(sorted(cases))}
+    for name, c in cases.items():
+        out[f"{name}.targets"] = c["targets"].astype(np.float32)
+        for key in ("test_time", "max_steps"):
+            out[f"{name}.{key}"] = np.int64(c[key])
+        for key in ("thresh_div", "thresh_stable"):
+            out[f"{name}.{key}"] = np.float32(c[key])
+        out[f"{name}.modified"] = np.array(
+            [f"{k}={v}" for k, v in sorted(c["mp"].items())], dtype="U32")
+        lens = []
+        for i in range(len(c["targets"])):
+            def make():
+                env = Env(FixedWingDynamics(modified_params=dict(c["mp"])), dt)
+                ctrl = FixedWingNetWrapper(net, dataset(), horizon=cfg["horizon"])
+                return efw.FixedWingEvaluator(
+                    ctrl, env, dt=dt, horizon=cfg["horizon"], render=0,
+                    thresh_div=c["thresh_div"], thresh_stable=c["thresh_stable"],
+                    test_time=c["test_time"])
+            with torch.no_grad():
+                traj = make().fly_to_point(c["targets"][i],
+                                           max_steps=c["max_steps"], return_traj=True)
+                dtg, dlin = make().fly_to_point(c["targets"][i],
+                                                max_steps=c["max_steps"])
+            out[f"{name}.{i}.traj"] = np.asarray(traj, np.float32)
+            out[f"{name}.{i}.div_target"] = np.asarray(dtg, np.float64)
+            out[f"{name}.{i}.div_linear"] = np.asarray(dlin, np.float64)
+            lens.append((len(dlin), len(dtg), round(float(np.max(dlin)), 3)))
+        print(name, lens)
+
+    # run_eval + self play: ONE wrapper, its action counter runs through all
+    # flights; every take_every_x-th call stores (state, target) in the data set
+    n_sampled, n_self, every, nr_test = 5, 40, 3, 7
+    for name, c in (("sp_train", dict(test_time=0, thresh_div=.2, thresh_stable=.4)),
+                    ("sp_test", dict(test_time=1, thresh_div=.25, thresh_stable=.4))):
+        ds = dataset(n_sampled, n_self)
+        env = Env(FixedWingDynamics(), dt)
+        ctrl = FixedWingNetWrapper(net, ds, horizon=cfg["horizon"],
+                                   take_every_x=every)
+        ev = efw.FixedWingEvaluator(
+            ctrl, env, dt=dt, horizon=cfg["horizon"], render=0,
+            thresh_div=c["thresh_div"], thresh_stable=c["thresh_stable"],
+            test_time=c["test_time"])
+        np.random.seed(99)
+        drawn = (np.random.rand(nr_test, 2) - .5) * 2 * 5    # run_eval's draws (:143)
+        np.random.seed(99)
+        with torch.no_grad():
+            dists = ev.run_eval(nr_test, return_dists=True, printout=False)
+        np.random.seed(99)
+        ds2 = dataset(n_sampled, n_self)
+        ctrl2 = FixedWingNetWrapper(net, ds2, horizon=cfg["horizon"],
+                                    take_every_x=every)
+        ev2 = efw.FixedWingEvaluator(
+            ctrl2, Env(FixedWingDynamics(), dt), dt=dt, horizon=cfg["horizon"],
+            render=0, thresh_div=c["thresh_div"], thresh_stable=c["thresh_stable"],
+            test_time=c["test_time"])
+        with torch.no_grad():
+            stats = ev2.run_eval(nr_test, printout=False)
+        out[f"{name}.targets_yz"] = drawn.astype(np.float64)
+        out[f"{name}.dists"] = np.asarray(dists, np.float64)
+        out[f"{name}.stats"] = np.asarray(stats, np.float64)
+        for key in ("thresh_div", "thresh_stable"):
+            out[f"{name}.{key}"] = np.float32(c[key])
+        out[f"{name}.test_time"] = np.int64(c["test_time"])
+        out[f"{name}.eval_counter"] = np.int64(ds.eval_counter)
+        out[f"{name}.action_counter"] = np.int64(ctrl.action_counter)
+        sl = slice(n_sampled, None)
+        out[f"{name}.normed"] = npy(ds.normed_states[sl])
+        out[f"{name}.states"] = npy(ds.states[sl])
+        out[f"{name}.in_ref"] = npy(ds.in_ref_states[sl])
+        out[f"{name}.ref"] = npy(ds.ref_states[sl])
+        print(name, stats, ds.eval_counter, ctrl.action_counter)
+    out["sp.num_sampled"], out["sp.num_self_play"] = np.int64(n_sampled), np.int64(n_self)
+    out["sp.take_every_x"], out["sp.nr_test"] = np.int64(every), np.int64(nr_test)
+    save("wing_closed_loop.npz", **out)
+
+
 FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
                 g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
                 g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
                 g11=g11_closed_loop, g12=g12_wing_train,
-                g13=g13_self_play, g14=g14_schedules)
+                g13=g13_self_play, g14=g14_schedules,
+                g15=g15_wing_closed_loop)
 
 if __name__ == "__main__":
     for key in (sys.argv[1:] or FIXTURES):

@@ -855,3 +855,84 @@ def test_packed_rows_of_policy_and_dataset():
     d.resample_data()
     s1, _ = d.packed()
     assert s1 is not s0 and torch.equal(synthetic.from_packed_state(s1), d.states)
+
+
+def test_wing_evaluator_host_logic_vs_reference_run_eval(monkeypatch):
+    """G15 `sp_*`: FixedWingEvaluator.run_eval / fly_to_point, the self-play
+    cadence of FixedWingNetWrapper and SyntheticWingDataset.add_eval_data
+    against the REAL run_eval + FixedWingNetWrapper + WingDataset, with the
+    kernel replaced by the oracle's closed loop (the host logic around the
+    launch is what runs here; the GPU suite runs the same check on the
+    kernel).  np.random.seed gives both evaluators the same targets."""
+    from conftest import load_golden, oracle_wing_closed_loop, wing_loop_policy
+    from apg_trajectory_tracking_amd import evaluate_fixed_wing as efw
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dataset import SyntheticWingDataset
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    monkeypatch.setattr(F, "wing_mlp_closed_loop", oracle_wing_closed_loop)
+    g = load_golden("wing_closed_loop.npz")
+    net = wing_loop_policy()
+    n_s, n_p = int(g["sp.num_sampled"]), int(g["sp.num_self_play"])
+    for name in ("sp_train", "sp_test"):
+        ds = SyntheticWingDataset(
+            n_s, int(g["data_horizon"]), float(g["data_dt"]), device="cpu",
+            self_play=n_p / n_s, mean=g["mean"].tolist(), std=g["std"].tolist())
+        assert ds.num_self_play == n_p and len(ds) == n_s + n_p
+        ctrl = efw.FixedWingNetWrapper(net, ds, horizon=int(g["data_horizon"]),
+                                       take_every_x=int(g["sp.take_every_x"]))
+        kw = dict(dt=float(g["dt"]), horizon=int(g["data_horizon"]),
+                  thresh_div=float(g[f"{name}.thresh_div"]),
+                  thresh_stable=float(g[f"{name}.thresh_stable"]),
+                  test_time=int(g[f"{name}.test_time"]))
+        ev = efw.FixedWingEvaluator(ctrl, FixedWingDynamics(), **kw)
+        np.random.seed(99)
+        dists = ev.run_eval(int(g["sp.nr_test"]), return_dists=True, printout=False)
+        assert np.abs(dists - g[f"{name}.dists"]).max() < 2e-4 * max(
+            1.0, np.abs(g[f"{name}.dists"]).max())
+        assert ds.eval_counter == int(g[f"{name}.eval_counter"])
+        assert ctrl.action_counter == int(g[f"{name}.action_counter"])
+        sl = slice(n_s, None)
+        for mine, key in ((ds.normed_states, "normed"), (ds.states, "states"),
+                          (ds.in_ref_states, "in_ref"), (ds.ref_states, "ref")):
+            want = g[f"{name}.{key}"]
+            assert np.abs(mine[sl].numpy() - want).max() < 2e-4 * max(
+                1.0, np.abs(want).max()), (name, key)
+        # (mean, std) form of the same evaluation
+        ds2 = SyntheticWingDataset(n_s, 10, 0.05, device="cpu", self_play=n_p / n_s,
+                                   mean=g["mean"].tolist(), std=g["std"].tolist())
+        ctrl2 = efw.FixedWingNetWrapper(net, ds2, horizon=10,
+                                        take_every_x=int(g["sp.take_every_x"]))
+        np.random.seed(99)
+        stats = efw.FixedWingEvaluator(ctrl2, FixedWingDynamics(), **kw).run_eval(
+            int(g["sp.nr_test"]), printout=False)
+        assert np.allclose(stats, g[f"{name}.stats"], rtol=2e-4, atol=2e-4)
+
+
+def test_wing_dataset_prepare_data_and_self_play_slots():
+    """SyntheticWingDataset.prepare_data = WingDataset.prepare_data
+    (dataset.py:322-350) on the synthetic samples' own definition, and the
+    cyclic slot bookkeeping of add_eval_data (wrap-around keeps the newest)."""
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dataset import SyntheticWingDataset
+    ds = SyntheticWingDataset(8, 20, 0.05, seed=3, device="cpu", self_play=1.5)
+    assert (ds.num_sampled_states, ds.num_self_play, len(ds)) == (8, 12, 20)
+    d = synthetic.wing_batch(30, 20, 0.05, seed=4)
+    normed, states, in_ref, ref = ds.prepare_data(d["state0"], d["target"])
+    assert torch.allclose(ref, d["ref"], atol=1e-5)
+    assert torch.allclose(in_ref, d["ref"][:, -1] - d["state0"][:, :3], atol=1e-5)
+    assert torch.allclose(normed, ((d["state0"] - ds.mean) / ds.std)[:, 3:])
+    sampled = ds.states[:8].clone()
+    ds.add_eval_data(d["state0"][:5], d["target"][:5])
+    assert ds.eval_counter == 5 and ds.get_eval_index() == 8 + 5
+    assert torch.equal(ds.states[8:13], d["state0"][:5])
+    ds.add_eval_data(d["state0"][5:30], d["target"][5:30])   # 25 more: wraps twice
+    assert ds.eval_counter == 30
+    # slot j of the 12 holds the newest sample with counter % 12 == j
+    for j in range(12):
+        newest = max(c for c in range(30) if c % 12 == j)
+        assert torch.equal(ds.states[8 + j], d["state0"][newest]), j
+    assert torch.equal(ds.states[:8], sampled)
+    ds.resample_data()
+    assert not torch.equal(ds.states[:8], sampled)
+    assert torch.equal(ds.states[8 + 5], d["state0"][29])    # self-play part kept

@@ -263,3 +263,39 @@ def test_wing_train_step_oracle_matches_reference_trainer():
         opt.step()
         for k, v in net.state_dict().items():
             assert rel_err(v.numpy(), g[f"w{step}.{k}"]) < 1e-6, (step, k)
+
+
+def test_wing_closed_loop_oracle_matches_reference_evaluator():
+    """G15: the batched restatement of FixedWingEvaluator.fly_to_point against
+    the recordings of the REAL evaluator with the shipped controller - flown
+    rows, div_to_linear and the div_target list of every flight, in all cases
+    (loose / tight thresholds, test_time, several targets, max_steps cut,
+    modified dynamics)."""
+    from conftest import wing_loop_case, wing_loop_policy
+    g = load_golden("wing_closed_loop.npz")
+    net = wing_loop_policy()
+    resets = 0
+    for case in map(str, g["cases"]):
+        targets, kw, mp = wing_loop_case(g, case)
+        out = tp.wing_closed_loop(
+            net, tp.WingOracle(modified_params=mp), torch.from_numpy(targets),
+            float(g["dt"]), g["mean"], g["std"], float(g["data_dt"]),
+            int(g["data_horizon"]), kw["max_steps"], kw["thresh_div"],
+            kw["thresh_stable"], kw["test_time"])
+        for i in range(targets.shape[0]):
+            want = g[f"{case}.{i}.traj"]
+            n = len(want)
+            assert int(out["steps"][i]) == n, (case, i)
+            assert np.abs(out["traj"][i, :n].numpy() - want).max() < 2e-4, (case, i)
+            assert np.abs(out["div_linear"][i, :n].numpy()
+                          - g[f"{case}.{i}.div_linear"]).max() < 2e-4, (case, i)
+            ev = torch.stack((out["div_pass"][i, :n], out["div_fail"][i, :n]), 1)
+            ev = ev.reshape(-1)
+            ev = ev[ev >= 0].tolist()
+            resets += int((out["div_fail"][i, :n] >= 0).sum())
+            if n == kw["max_steps"]:
+                ev.append(kw["thresh_div"])
+            want_t = g[f"{case}.{i}.div_target"]
+            assert len(ev) == len(want_t), (case, i)
+            assert np.abs(np.array(ev) - want_t).max() < 2e-4, (case, i)
+    assert resets > 40       # the divergence branches were flown
