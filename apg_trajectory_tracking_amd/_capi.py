@@ -170,6 +170,14 @@ SIGNATURES = {
                             _P, _P],
     "apg_wing_policy_bwd": [_P, _P, _P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P,
                             _P, _P, _P],
+    "apg_wing_learnt_param_count": [],
+    "apg_wing_learnt_workspace_floats": [_I],
+    "apg_wing_learnt_step_fwd": [
+        _P, _P, _F, ctypes.POINTER(ApgWingParams), ctypes.POINTER(ctypes.c_float),
+        _I, _P, _P],
+    "apg_wing_learnt_step_bwd": [
+        _P, _P, _F, ctypes.POINTER(ApgWingParams), ctypes.POINTER(ctypes.c_float),
+        _I, _P, _P, _P, _P, _P, _P],
     "apg_wing_mlp_closed_loop": [
         _P, _I, _P, _F, ctypes.POINTER(ApgWingParams),
         ctypes.POINTER(ApgWingPolicy), ctypes.POINTER(ctypes.c_float),

@@ -7,6 +7,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "apg_device.h"
 
 namespace apg {
@@ -119,6 +121,52 @@ inline bool is_default(const WingConst &k) {
   const WingConst d = default_table();
   return memcmp(&k, &d, sizeof(WingConst)) == 0;
 }
+
+// LearntFixedWingDynamics (fixed_wing_dynamics.py:270-326) keeps the WHOLE 3x3
+// inertia matrix as one trainable parameter: after an optimizer step it is
+// neither symmetric nor sparse.  The table of its step therefore carries the
+// matrix and its inverse in full (and b, which the parameter cotangents need).
+struct WingGeneralConst : WingConst {
+  float b;
+  float I[3][3], Iinv[3][3];
+};
+
+inline WingGeneralConst make_general_const(const ApgWingParams &p, float dt,
+                                           const float *I9) {
+  WingGeneralConst k;
+  static_cast<WingConst &>(k) = make_const(p, dt);
+  k.b = p.b;
+  double m[3][3], inv[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) m[i][j] = I9[i * 3 + j];
+  const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) -
+                     m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                     m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const int a = (j + 1) % 3, b2 = (j + 2) % 3, c = (i + 1) % 3, d = (i + 2) % 3;
+      inv[i][j] = (m[a][c] * m[b2][d] - m[a][d] * m[b2][c]) / det;  // adjugate
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) k.I[i][j] = (float)m[i][j], k.Iinv[i][j] = (float)inv[i][j];
+  return k;
+}
+
+template <typename K>
+struct wing_general_inertia
+    : std::is_same<typename std::remove_cv<K>::type, WingGeneralConst> {};
+
+// Cotangents of the physical parameters, in the order of ApgWingParams (41
+// floats; the I_* slots stay 0) followed by dL/dI row-major (9):
+// apg_wing_learnt_step_bwd's grad_params.
+constexpr int kWingParamGrads = 50;
+struct WingParamGrads {
+  static constexpr bool enabled = true;
+  float v[kWingParamGrads];
+};
+struct NoWingParamGrads {
+  static constexpr bool enabled = false;
+};
 
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kTanBound = 0.17632698070846498f;  // tan(10 deg)
@@ -282,13 +330,25 @@ __host__ __device__ __forceinline__ void wing_rates(const T (&s)[12], const T (&
   sd[7] = x.cph * q - x.sph * r;
   sd[8] = (x.sph * q + x.cph * r) * x.icth;
   // :250-255
-  x.h0 = k.Ixx * p + k.a13 * r, x.h1 = k.Iyy * q, x.h2 = k.a13 * p + k.Izz * r;
+  if constexpr (wing_general_inertia<KT>::value) {
+    x.h0 = k.I[0][0] * p + k.I[0][1] * q + k.I[0][2] * r;
+    x.h1 = k.I[1][0] * p + k.I[1][1] * q + k.I[1][2] * r;
+    x.h2 = k.I[2][0] * p + k.I[2][1] * q + k.I[2][2] * r;
+  } else {
+    x.h0 = k.Ixx * p + k.a13 * r, x.h1 = k.Iyy * q, x.h2 = k.a13 * p + k.Izz * r;
+  }
   const T r0 = l - (q * x.h2 - r * x.h1);
   const T r1 = m - (r * x.h0 - p * x.h2);
   const T r2 = n - (p * x.h1 - q * x.h0);
-  sd[9] = k.i00 * r0 + k.i02 * r2;
-  sd[10] = k.i11 * r1;
-  sd[11] = k.i02 * r0 + k.i22 * r2;
+  if constexpr (wing_general_inertia<KT>::value) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      sd[9 + i] = k.Iinv[i][0] * r0 + k.Iinv[i][1] * r1 + k.Iinv[i][2] * r2;
+  } else {
+    sd[9] = k.i00 * r0 + k.i02 * r2;
+    sd[10] = k.i11 * r1;
+    sd[11] = k.i02 * r0 + k.i22 * r2;
+  }
 }
 
 template <typename T, typename KT>
@@ -304,11 +364,14 @@ __host__ __device__ __forceinline__ void wing_step(T (&s)[12], const T (&a)[4], 
 // `s`, `a` are the PRE-step state and the action; x the matching aux.
 // `sd`: the state_dot wing_rates returned for (s, a) (its position part is
 // re-used by the yaw cotangent).
-template <typename T, typename KT>
+// `pg` (WingParamGrads, float only): += the cotangents of the physical
+// parameters for this trajectory; NoWingParamGrads compiles to nothing.
+template <typename T, typename KT, typename PG>
 __host__ __device__ __forceinline__ void wing_step_adjoint(T (&lam)[12], T (&ga)[4],
                                                   const T (&s)[12],
                                                   const WingAuxT<T> &x,
-                                                  const T (&sd)[12], KT &k) {
+                                                  const T (&sd)[12], KT &k,
+                                                  PG &pg) {
   const T u = s[3], v = s[4], w = s[5];
   const T p = s[9], q = s[10], r = s[11];
   const T zero = APG_T(0.f);
@@ -319,18 +382,31 @@ __host__ __device__ __forceinline__ void wing_step_adjoint(T (&lam)[12], T (&ga)
   T dp = zero, dq = zero, dr = zero;
 
   // omega_dot = I^-1 (M - omega x I omega)
-  const T gr0 = k.i00 * g[9] + k.i02 * g[11];
-  const T gr1 = k.i11 * g[10];
-  const T gr2 = k.i02 * g[9] + k.i22 * g[11];
+  T gr0, gr1, gr2;  // I^-T g_omega
+  if constexpr (wing_general_inertia<KT>::value) {
+    gr0 = k.Iinv[0][0] * g[9] + k.Iinv[1][0] * g[10] + k.Iinv[2][0] * g[11];
+    gr1 = k.Iinv[0][1] * g[9] + k.Iinv[1][1] * g[10] + k.Iinv[2][1] * g[11];
+    gr2 = k.Iinv[0][2] * g[9] + k.Iinv[1][2] * g[10] + k.Iinv[2][2] * g[11];
+  } else {
+    gr0 = k.i00 * g[9] + k.i02 * g[11];
+    gr1 = k.i11 * g[10];
+    gr2 = k.i02 * g[9] + k.i22 * g[11];
+  }
   {
     const T c0 = -gr0, c1 = -gr1, c2 = -gr2;  // cotangent of the cross
     dp += -c1 * x.h2 + c2 * x.h1;
     dq += c0 * x.h2 - c2 * x.h0;
     dr += -c0 * x.h1 + c1 * x.h0;
     const T gh0 = c1 * r - c2 * q, gh1 = -c0 * r + c2 * p, gh2 = c0 * q - c1 * p;
-    dp += k.Ixx * gh0 + k.a13 * gh2;
-    dq += k.Iyy * gh1;
-    dr += k.a13 * gh0 + k.Izz * gh2;
+    if constexpr (wing_general_inertia<KT>::value) {
+      dp += k.I[0][0] * gh0 + k.I[1][0] * gh1 + k.I[2][0] * gh2;
+      dq += k.I[0][1] * gh0 + k.I[1][1] * gh1 + k.I[2][1] * gh2;
+      dr += k.I[0][2] * gh0 + k.I[1][2] * gh1 + k.I[2][2] * gh2;
+    } else {
+      dp += k.Ixx * gh0 + k.a13 * gh2;
+      dq += k.Iyy * gh1;
+      dr += k.a13 * gh0 + k.Izz * gh2;
+    }
   }
   // euler rates
   {
@@ -429,6 +505,52 @@ __host__ __device__ __forceinline__ void wing_step_adjoint(T (&lam)[12], T (&ga)
   lam[3] += du, lam[4] += dv, lam[5] += dw;
   lam[6] += dph, lam[7] += dth, lam[8] += dps;
   lam[9] += dp, lam[10] += dq, lam[11] += dr;
+  if constexpr (PG::enabled) {
+    // the coefficient sums are linear in their coefficients; the rate terms
+    // carry c or b (k.CL_qc = CL_q c, ...), Q = rho/2 V^2 S, the moments Q c C
+    float *d = pg.v;
+    const T rq = x.r2V * q, rp = x.r2V * p, rr = x.r2V * r;
+    // mass enters through 1/mass only: g m of the weight is a detached copy
+    // in the reference (torch.tensor(g_m), :197) - so does g get no gradient
+    d[0] -= k.inv_mass * (g[3] * (sd[3] + (q * w - r * v)) +
+                          g[4] * (sd[4] + (r * u - p * w)) +
+                          g[5] * (sd[5] + (p * v - q * u)));
+    d[5] += gQ * 0.5f * x.V2 * k.S;                       // rho
+    d[6] += gQ * k.half_rho * x.V2;                       // S
+    d[7] += g_qt * rq / k.c + x.Q * (gr0 * x.Cl + gr1 * x.Cm + gr2 * x.Cn);  // c
+    d[10] += gCL, d[11] += gCL * x.alpha, d[12] += gCL * rq * k.c, d[13] += gCL * x.de;
+    d[14] += gCD, d[15] += gCD * x.alpha, d[16] += gCD * rq * k.c, d[17] += gCD * x.de;
+    d[30] += gCm, d[31] += gCm * x.alpha, d[32] += gCm * rq * k.c, d[33] += gCm * x.de;
+    d[40] += x.Tt * (gf2 * k.cos_eps - gf0 * k.sin_eps);  // epsilon
+    if constexpr (wing_general_inertia<KT>::value) {
+      d[8] += (g_pt * p + g_rt * r) * x.r2V / k.b;         // b
+      const T cg[3] = {gCY, gCl, gCn};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        float *e = d + (t == 0 ? 18 : t == 1 ? 24 : 34);
+        e[0] += cg[t], e[1] += cg[t] * x.beta, e[2] += cg[t] * rp * k.b;
+        e[3] += cg[t] * rr * k.b, e[4] += cg[t] * x.da, e[5] += cg[t] * x.dr;
+      }
+      // omega_dot = I^-1 (M - omega x I omega):
+      //   dL/dI_ij = -gr_i omega_dot_j - (gr x omega)_i omega_j
+      const T grv[3] = {gr0, gr1, gr2}, om[3] = {p, q, r};
+      const T gxo[3] = {gr1 * r - gr2 * q, gr2 * p - gr0 * r, gr0 * q - gr1 * p};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          d[41 + i * 3 + j] -= grv[i] * sd[9 + j] + gxo[i] * om[j];
+    }
+  }
+}
+
+template <typename T, typename KT>
+__host__ __device__ __forceinline__ void wing_step_adjoint(T (&lam)[12], T (&ga)[4],
+                                                  const T (&s)[12],
+                                                  const WingAuxT<T> &x,
+                                                  const T (&sd)[12], KT &k) {
+  NoWingParamGrads none;
+  wing_step_adjoint(lam, ga, s, x, sd, k, none);
 }
 
 }  // namespace

@@ -8,6 +8,7 @@ import torch
 
 from . import functional as F
 from .dataset import SyntheticWingDataset
+from .drone_loss import fixed_wing_mpc_loss
 from .models.hutter_model import Net
 from .train_base import TrainBase
 
@@ -112,7 +113,7 @@ class TrainFixedWing(TrainBase):
         with the policy inside HIP kernels (functional.wing_concurrent_policy_grads)."""
         n = self.net
         if not (self.fused_policy and isinstance(n, Net) and not n.conv
-                and self.horizon == 20 and hasattr(self.train_dynamics, "params")
+                and self.horizon == 20 and self.analytic_train_dynamics()
                 and n.states_in.weight.shape == (64, 9)
                 and n.ref_in.weight.shape == (64, 3)
                 and n.fc1.weight.shape == (64, 128)
@@ -129,6 +130,17 @@ class TrainFixedWing(TrainBase):
         self, current_state, action_seq, in_ref_state, ref_states
     ):
         self.optimizer_controller.zero_grad()
+        if not self.analytic_train_dynamics():
+            # learnt simulator (LearntFixedWingDynamics): unroll through its
+            # own forward, step by step, as the reference does (:94-106)
+            states = []
+            for k in range(action_seq.size()[1]):
+                current_state = self.train_dynamics(
+                    current_state, action_seq[:, k], dt=self.delta_t_train)
+                states.append(current_state)
+            loss = fixed_wing_mpc_loss(
+                torch.stack(states, dim=1), ref_states, action_seq)
+            return self._step(loss)
         loss = F.wing_rollout_loss(
             current_state, action_seq, ref_states, self.delta_t_train,
             self.train_dynamics.params)

@@ -540,6 +540,29 @@ int apg_wing_step_bwd(const float *state, const float *action, float dt,
                       const float *grad_next, float *grad_state,
                       float *grad_action, apg_stream_t stream);
 
+/* The physics step of LearntFixedWingDynamics (beyond SURVEY.md §8;
+ * neural_control/dynamics/fixed_wing_dynamics.py:270-326): simulate_fixed_wing
+ * (:98-267) with the CURRENT values of its trainable parameters - `params` (the
+ * I_* fields are ignored) and `inertia`, a HOST array of 9 = the 3x3 parameter
+ * `I` row-major, used in full (no symmetry or sparsity assumed).  AoS
+ * state [B,12] / action [B,4].  The reverse call returns dL/dstate, dL/daction
+ * (either may be NULL) and grad_params: apg_wing_learnt_param_count() = 50
+ * device floats, the batch-summed cotangents in the order of ApgWingParams'
+ * 41 fields (I_xx..I_xz and g: 0 - the reference's weight g*mass is a
+ * detached copy, :197, so mass gets its gradient through 1/mass only)
+ * followed by dL/dI row-major.  workspace:
+ * apg_wing_learnt_workspace_floats(B) device floats. */
+int apg_wing_learnt_param_count(void);
+int apg_wing_learnt_workspace_floats(int B);
+int apg_wing_learnt_step_fwd(const float *state, const float *action, float dt,
+                             const ApgWingParams *params, const float *inertia,
+                             int B, float *next_state, apg_stream_t stream);
+int apg_wing_learnt_step_bwd(const float *state, const float *action, float dt,
+                             const ApgWingParams *params, const float *inertia,
+                             int B, const float *grad_next, float *grad_state,
+                             float *grad_action, float *grad_params,
+                             float *workspace, apg_stream_t stream);
+
 /* Fused rollout of TrainFixedWing.train_controller_model
  * (scripts/train_fixed_wing.py:90-110) with fixed_wing_mpc_loss.
  *   ref [B,H,3] linear reference (WingDataset._compute_target_pos,

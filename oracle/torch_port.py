@@ -15,6 +15,7 @@ matters for fp32 rounding (e.g. 0.5*dt*dt*acc + 0.5*dt*vel, the add-then-
 subtract of the gyroscopic cross term); tensor assembly is this file's own.
 """
 import math
+import numpy as np
 import torch
 
 # ---- parameter tables (neural_control/dynamics/config_quad.json:1-29,
@@ -237,6 +238,7 @@ class WingOracle:
         prop = torch.stack((T * torch.cos(eps), torch.zeros_like(T),
                             T * torch.sin(eps)), 1)
         b2i = self.r_inertial_body(phi, theta, zero).transpose(1, 2)
+        g_m = g_m.item() if torch.is_tensor(g_m) else g_m      # a detached copy, :197
         grav = torch.tensor([[0.0], [0.0], [g_m]], dtype=self.dtype)
         f_xyz = self.r_body_wind(alpha, beta) @ aero + b2i @ grav \
             + prop.unsqueeze(2)
@@ -263,6 +265,37 @@ class WingOracle:
             (pos_dot[:, :, 0], uvw_dot, eul_dot[:, :, 0], omega_dot[:, :, 0]),
             dim=1)
         return state + dt * state_dot
+
+
+class LearntWingOracle:
+    """LearntFixedWingDynamics, fixed_wing_dynamics.py:270-326: the step above
+    with every config entry ([1] tensors, `cfg.<name>`) and the 3x3 inertia
+    matrix `I` as leaves that require grad, plus the residual MLP
+    (16 -> 64 relu -> 12) on [state, action] added to the simulated next
+    state.  `weights`: name -> array under the reference's state_dict names.
+    The weight g * mass enters WingOracle.__call__ through torch.tensor(...),
+    i.e. detached, as in the reference (:197): `cfg.g` gets no gradient."""
+
+    def __init__(self, weights, dtype=torch.float64):
+        self.dtype = dtype
+        self.p = {k: torch.tensor(np.asarray(v), dtype=dtype).requires_grad_(True)
+                  for k, v in weights.items()}
+        self.phys = WingOracle(dtype=dtype)
+        self.phys.I = self.p["I"]
+        self.phys.cfg = {k[len("cfg."):]: v for k, v in self.p.items()
+                         if k.startswith("cfg.")}
+
+    def parameters(self):
+        return self.p
+
+    def __call__(self, state, action, dt):
+        state, action = state.to(self.dtype), action.to(self.dtype)
+        sa = torch.cat((state, action), dim=1)
+        hidden = torch.relu(sa @ self.p["linear_state_1.weight"].t()
+                            + self.p["linear_state_1.bias"])
+        added = hidden @ self.p["linear_state_2.weight"].t() \
+            + self.p["linear_state_2.bias"]
+        return self.phys(state, action, dt) + added
 
 
 def fixed_wing_mpc_loss(states, linear_reference, action):

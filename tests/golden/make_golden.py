@@ -25,6 +25,8 @@ Fixtures:
                          with self play on (needs closed_loop.npz)
   schedules.npz      G14 TrainBase.run_control (speed curriculum) and
                          run_dynamics with scripted evaluation results
+  learnt_wing.npz    G16 LearntFixedWingDynamics forward + every parameter gradient
+                         + four optimizer steps
   wing_closed_loop.npz G15 FixedWingEvaluator.fly_to_point / run_eval with the
                          shipped wing controller (+ self play into WingDataset)
 
@@ -1085,12 +1087,77 @@ def g15_wing_closed_loop():
     save("wing_closed_loop.npz", **out)
 
 
+# -------------------------------------------------------------------- G16
+def g16_learnt_wing():
+    """Beyond §8: LearntFixedWingDynamics (fixed_wing_dynamics.py:270-326) -
+    all physical parameters trainable (ParameterDict `cfg`, 3x3 `I`) + residual
+    MLP - and the loss of TrainBase.train_dynamics_model
+    (scripts/train_base.py:160-186, l2 term off) against a FixedWingDynamics
+    with modified parameters.  Recorded: one forward value, the autograd
+    gradient of every parameter (`g` never gets one: the weight g * mass is a
+    detached copy, :197), then four momentum-SGD steps - after them `I` is a
+    general matrix - with losses, final parameters and the final prediction."""
+    from neural_control.dynamics.fixed_wing_dynamics import LearntFixedWingDynamics
+    import warnings
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(71)
+    dyn = LearntFixedWingDynamics()
+    with torch.no_grad():
+        dyn.linear_state_1.weight.normal_(0, 0.05)
+        dyn.linear_state_1.bias.normal_(0, 0.05)
+        dyn.linear_state_2.weight.normal_(0, 0.02)
+        dyn.linear_state_2.bias.normal_(0, 0.02)
+    target_mod = {"mass": 1.2, "CL0": 0.3, "rho": 1.1, "I_xx": 0.06, "Cm_q": -0.2}
+    target = FixedWingDynamics(modified_params=dict(target_mod))
+    B = 64
+    d = synthetic.wing_batch(B, 1, 0.05, seed=72)
+    g = torch.Generator().manual_seed(73)
+    state = d["state0"].clone()
+    state[:, :3] = torch.randn(B, 3, generator=g)
+    state[:, 9:12] += 0.3 * torch.randn(B, 3, generator=g)   # livelier rates
+    action = torch.rand(B, 4, generator=g)
+    dt = 0.05
+    out = {"state": npy(state), "action": npy(action), "dt": np.float32(dt),
+           "target_mod": np.array([f"{k}={v}" for k, v in sorted(target_mod.items())])}
+    for k, v in dyn.state_dict().items():
+        out["w." + k] = npy(v)
+    d1 = dyn(state, action, dt)
+    d2 = target(state, action, dt)
+    loss = torch.sum((d1 - d2)**2)
+    loss.backward()
+    out["next"], out["target_next"] = npy(d1), npy(d2)
+    out["loss"] = np.float64(loss.item())
+    for k, p in dyn.named_parameters():
+        out["g." + k] = npy(p.grad) if p.grad is not None else np.zeros(1, np.float32)
+        out["has_grad." + k] = np.bool_(p.grad is not None)
+    lr = 2e-5
+    opt = torch.optim.SGD(dyn.parameters(), lr=lr, momentum=0.9)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        l = torch.sum((dyn(state, action, dt) - d2.detach())**2)
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    out["steps.lr"] = np.float64(lr)
+    out["steps.loss"] = np.asarray(losses, np.float64)
+    for k, v in dyn.state_dict().items():
+        out["steps.w." + k] = npy(v)
+    with torch.no_grad():
+        out["steps.next"] = npy(dyn(state, action, dt))
+    print("loss", loss.item(), losses, "I after\n", dyn.I.detach().numpy())
+    print({k: float(np.abs(out["g." + k]).max()) for k in
+           ("I", "cfg.mass", "cfg.rho", "cfg.c", "cfg.b", "cfg.epsilon", "cfg.CL_q",
+            "cfg.Cn_r", "cfg.g")})
+    save("learnt_wing.npz", **out)
+
+
 FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
                 g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
                 g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
                 g11=g11_closed_loop, g12=g12_wing_train,
                 g13=g13_self_play, g14=g14_schedules,
-                g15=g15_wing_closed_loop)
+                g15=g15_wing_closed_loop, g16=g16_learnt_wing)
 
 if __name__ == "__main__":
     for key in (sys.argv[1:] or FIXTURES):

@@ -299,3 +299,37 @@ def test_wing_closed_loop_oracle_matches_reference_evaluator():
             assert len(ev) == len(want_t), (case, i)
             assert np.abs(np.array(ev) - want_t).max() < 2e-4, (case, i)
     assert resets > 40       # the divergence branches were flown
+
+
+def _learnt_wing_weights(g, prefix="w."):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+def test_learnt_wing_oracle_matches_reference_module():
+    """G16: LearntWingOracle against the REAL LearntFixedWingDynamics - forward
+    value, the loss of the simulator fit, the autograd gradient of every
+    parameter (float32 as recorded, and float64 within the recording's own
+    rounding), and the prediction after the reference's four optimizer steps
+    (whose `I` is a general matrix)."""
+    g = load_golden("learnt_wing.npz")
+    state, action = torch.from_numpy(g["state"]), torch.from_numpy(g["action"])
+    dt = float(g["dt"])
+    for dtype, tol in ((torch.float32, 2e-5), (torch.float64, 2e-4)):
+        dyn = tp.LearntWingOracle(_learnt_wing_weights(g), dtype=dtype)
+        nxt = dyn(state, action, dt)
+        assert rel_err(nxt.detach().numpy(), g["next"]) < 1e-5
+        loss = torch.sum((nxt - torch.from_numpy(g["target_next"]).to(dtype))**2)
+        assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 1e-4
+        loss.backward()
+        for k, p in dyn.parameters().items():
+            if not bool(g["has_grad." + k]):
+                assert p.grad is None or float(p.grad.abs().max()) == 0, k
+                continue
+            assert rel_err(p.grad.numpy(), g["g." + k]) < tol, (
+                k, rel_err(p.grad.numpy(), g["g." + k]))
+    after = tp.LearntWingOracle(_learnt_wing_weights(g, "steps.w."),
+                                dtype=torch.float64)
+    assert np.abs(after.p["I"].detach().numpy()
+                  - after.p["I"].detach().numpy().T).max() > 1e-3   # general I
+    with torch.no_grad():
+        assert rel_err(after(state, action, dt).numpy(), g["steps.next"]) < 1e-5
