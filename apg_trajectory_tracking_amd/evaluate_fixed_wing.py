@@ -93,7 +93,7 @@ class FixedWingEvaluator:
         steps = out["steps"].to(torch.int64)
         total = int(steps.sum())
         data = c.dataset
-        if getattr(data, "num_self_play", 0) > 0 and total > 0:
+        if getattr(data, "num_self_play", 0) > 0 and total > 0 and "seen" in out:
             dev = steps.device
             T = out["seen"].shape[0]
             first = c.action_counter + torch.cumsum(steps, 0) - steps
@@ -111,7 +111,10 @@ class FixedWingEvaluator:
         single = targets.ndim == 2
         if single:
             targets = targets[None]
-        out = self._closed_loop(targets, max_steps, True)
+        # the per-step rows (31 floats x max_steps per flight) only when they
+        # are returned or feed the self play
+        collecting = getattr(self.controller.dataset, "num_self_play", 0) > 0
+        out = self._closed_loop(targets, max_steps, return_traj or collecting)
         self._self_play(out)
         steps = out["steps"].cpu().numpy()
         if return_traj:

@@ -506,6 +506,47 @@ def wing_secondary(args, dev):
     return out
 
 
+def wing_eval_secondary(args, dev):
+    """Beyond SURVEY §8: the batched fixed-wing closed-loop evaluation
+    (FixedWingEvaluator.run_eval's flights in ONE launch of
+    apg_wing_mlp_closed_loop) with a random-init Net(9, 1, 3, 40) - an
+    untrained controller diverges and is put back on its line again and again
+    (the training-time branch), every flight runs until it passes x = 50 m or
+    uses up max_steps.  Informational: policy-in-the-loop steps per second."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dataset import SyntheticWingDataset
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    B, T = 16384, 200
+    torch.manual_seed(args.seed)
+    net = Net(9, 1, 3, 40, conv=False).to(dev)
+    g = torch.Generator().manual_seed(args.seed)
+    targets = torch.zeros(B, 1, 3)
+    targets[:, 0, 0] = 50.0
+    targets[:, 0, 1:] = torch.rand(B, 2, generator=g) * 10 - 5
+    targets = targets.to(dev)
+    kw = dict(data_dt=0.05, data_horizon=10, max_steps=T, thresh_div=4.0,
+              thresh_stable=0.4, test_time=0)
+    mean, std = SyntheticWingDataset.MEAN, SyntheticWingDataset.STD
+    p = FixedWingDynamics().params
+    out = F.wing_mlp_closed_loop(net, targets, 0.05, p, mean, std, **kw)
+    torch.cuda.synchronize()
+    steps = int(out["steps"].sum())
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n):
+        F.wing_mlp_closed_loop(net, targets, 0.05, p, mean, std, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    return {"workload": "fixed-wing closed-loop evaluation, random-init controller",
+            "flights": B, "max_steps": T, "closed_loop_steps": steps,
+            "ms_per_launch": ms, "closed_loop_steps_per_s": steps / ms * 1e3}
+
+
 # ----------------------------------------------------------------------------
 # Rank plumbing shared by the real run and --dry-run-cpu
 def agree_replays(replays, dist, dev):
@@ -836,6 +877,10 @@ def main():
             out["secondary"] = {"wing_rollout": wing_secondary(args, dev)}
         except Exception as e:      # informational only
             out["secondary"] = {"error": repr(e)}
+        try:
+            out["secondary"]["wing_closed_loop_eval"] = wing_eval_secondary(args, dev)
+        except Exception as e:
+            out["secondary"]["wing_closed_loop_eval"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.headline_only):
         out["cpu_baseline"] = cpu_baseline(args)
     elif rank == 0:
