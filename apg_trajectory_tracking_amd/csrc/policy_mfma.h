@@ -17,6 +17,14 @@ namespace apg {
 
 constexpr unsigned kDead = 0xFFFFFFFCu;  // buffer offset beyond any tensor
 
+// cache policy of the plane stores / loads (tuning knobs: experiment builds)
+#ifndef APG_PLANES_ST_AUX
+#define APG_PLANES_ST_AUX 2
+#endif
+#ifndef APG_PLANES_LD_AUX
+#define APG_PLANES_LD_AUX 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __host__ __device__ constexpr int rrow(int i) { return (i & 3) + 8 * (i >> 2); }
@@ -82,17 +90,19 @@ struct Planes {
   // voff: per-lane byte offset (VGPR), soff: plane * pitch (scalar)
   __device__ __forceinline__ float ld(unsigned voff, unsigned soff) const {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                         rsrc, (int)voff, (int)soff, 0));
+                                         rsrc, (int)voff, (int)soff, APG_PLANES_LD_AUX));
   }
   __device__ __forceinline__ unsigned ldu(unsigned voff, unsigned soff) const {
-    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0);
+    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff,
+                                                APG_PLANES_LD_AUX);
   }
   __device__ __forceinline__ void st(unsigned voff, unsigned soff, float v) const {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc,
-                                          (int)voff, (int)soff, 2);
+                                          (int)voff, (int)soff, APG_PLANES_ST_AUX);
   }
   __device__ __forceinline__ void stu(unsigned voff, unsigned soff, unsigned v) const {
-    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)voff, (int)soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)voff, (int)soff,
+                                          APG_PLANES_ST_AUX);
   }
 };
 
