@@ -4,6 +4,9 @@ dynamics at dt = delta_t_train + fixed_wing_mpc_loss + analytic adjoint) and
 `evaluate_model` (:142-197) on the batched closed-loop evaluator
 (evaluate_fixed_wing.FixedWingEvaluator: all test flights in one launch),
 with self play into the data set and the threshold curriculum."""
+import json
+import os
+
 import torch
 
 from . import functional as F
@@ -27,8 +30,28 @@ class TrainFixedWing(TrainBase):
             raise ValueError("sample in must be one of eval_env, train_env")
 
     def initialize_model(self, base_model=None, modified_params={},
-                         state_data=None, device=None, seed=0):
+                         state_data=None, device=None, seed=0,
+                         base_model_name="model_wing"):
+        """Policy + data set + optimizer (scripts/train_fixed_wing.py:46-88).
+        `base_model`: a module, or - as in the reference - the directory of a
+        trained model (`<dir>/model_wing`, here a state_dict checkpoint, see
+        checkpoint.py; its config.json supplies mean / std, :56-63).  The run's
+        parameters are written to `<save_path>/config.json` like the reference
+        does."""
         device = torch.device(device or "cuda")
+        if isinstance(base_model, (str, os.PathLike)):
+            from .checkpoint import load_policy
+            path = os.path.join(base_model, "config.json")
+            if not os.path.exists(path):
+                path = os.path.join(base_model, "param_dict.json")
+            with open(path) as f:
+                previous = json.load(f)
+            self.config["mean"] = previous["mean"]
+            self.config["std"] = previous["std"]
+            base_model = load_policy(os.path.join(base_model, base_model_name),
+                                     system="wing")
+        if isinstance(self.train_dynamics, torch.nn.Module):
+            self.train_dynamics.to(device)     # learnable simulator
         if base_model is not None:
             self.net = base_model
         else:
@@ -52,6 +75,11 @@ class TrainFixedWing(TrainBase):
         self.config["dt"] = self.delta_t
         self.config["take_every_x"] = self.self_play_every_x
         self.config["thresh_stable"] = self.thresh_stable_start
+        from . import parallel
+        if parallel.is_main():       # one writer under torch.distributed
+            os.makedirs(self.save_path, exist_ok=True)
+            with open(os.path.join(self.save_path, "config.json"), "w") as f:
+                json.dump(self.config, f, default=str)
         self.init_optimizer()
 
     # flights per launch while the self-play slots are first filled (the
@@ -145,3 +173,55 @@ class TrainFixedWing(TrainBase):
             current_state, action_seq, ref_states, self.delta_t_train,
             self.train_dynamics.params)
         return self._step(loss)
+
+
+def train_control(base_model, config, device=None):
+    """scripts/train_fixed_wing.py:200-215: train a controller from scratch or
+    from `base_model` (a policy module); self play samples come from the
+    training environment."""
+    from .dynamics.fixed_wing_dynamics import FixedWingDynamics
+    modified_params = config["modified_params"]
+    train_dynamics = FixedWingDynamics(modified_params)
+    eval_dynamics = FixedWingDynamics(modified_params)
+    config["sample_in"] = "train_env"
+    trainer = TrainFixedWing(train_dynamics, eval_dynamics, config)
+    trainer.initialize_model(base_model, modified_params=modified_params,
+                             device=device)
+    trainer.run_control(config, curriculum=0)
+    return trainer
+
+
+def train_dynamics(base_model, config, device=None):
+    """scripts/train_fixed_wing.py:218-241: fit LearntFixedWingDynamics to the
+    (modified) evaluation simulator, then train the controller through the
+    learnt one; thresholds high so that the tracking error is reliable."""
+    from .dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics, LearntFixedWingDynamics)
+    modified_params = config["modified_params"]
+    config["sample_in"] = "train_env"
+    config["thresh_div_start"] = 20
+    config["thresh_stable_start"] = 1.5
+    learnt = LearntFixedWingDynamics()
+    if device is not None or torch.cuda.is_available():
+        learnt = learnt.to(torch.device(device or "cuda"))
+    trainer = TrainFixedWing(
+        learnt, FixedWingDynamics(modified_params=modified_params), config)
+    trainer.initialize_model(base_model, modified_params=modified_params,
+                             device=device)
+    trainer.run_dynamics(config)
+    return trainer
+
+
+def train_sampling_finetune(base_model, config, device=None):
+    """scripts/train_fixed_wing.py:244-262: train in the nominal simulator on
+    states visited in the modified one (self play samples from `eval_env`)."""
+    from .dynamics.fixed_wing_dynamics import FixedWingDynamics
+    modified_params = config["modified_params"]
+    config["sample_in"] = "eval_env"
+    trainer = TrainFixedWing(
+        FixedWingDynamics(), FixedWingDynamics(modified_params=modified_params),
+        config)
+    trainer.initialize_model(base_model, modified_params=modified_params,
+                             device=device)
+    trainer.run_control(config, sampling_based_finetune=True)
+    return trainer

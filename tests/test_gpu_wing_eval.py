@@ -227,3 +227,53 @@ def test_trainer_evaluate_model_fills_the_self_play_slots(dev, tmp_path,
     assert t.results_dict["mean_success"][-1] == suc[0]
     loss = t.run_epoch(train="controller")
     assert np.isfinite(loss)
+
+
+def test_wing_entry_points_end_to_end(dev, tmp_path, monkeypatch):
+    """The reference's entry points (scripts/train_fixed_wing.py:200-262) run
+    through: evaluation flights (self play) -> resampling -> epoch; a model
+    directory written by one run (state_dict + config.json with mean / std)
+    is the `base_model` of the next; train_dynamics fits
+    LearntFixedWingDynamics first and then trains the controller through it."""
+    import json
+    import os
+    from apg_trajectory_tracking_amd import train_fixed_wing as tfw
+    monkeypatch.chdir(tmp_path)
+    cfg = dict(delta_t=0.05, delta_t_train=0.05, epoch_size=128, self_play=1,
+               self_play_every_x=2, batch_size=64, state_size=12, horizon=10,
+               ref_dim=3, action_dim=4, train_mode="concurrent", nr_epochs=3,
+               thresh_div_start=4, thresh_div_end=20, thresh_stable_start=.4,
+               thresh_stable_end=.8, learning_rate_controller=1e-7,
+               learning_rate_dynamics=1e-5, l2_lambda=0.01, resample_every=2,
+               system="wing", save_name="e2e", modified_params={})
+    torch.manual_seed(0)
+    np.random.seed(0)
+    t = tfw.train_control(wing_loop_policy(dev), dict(cfg), device=dev)
+    assert len(t.results_dict["loss"]) == 1 + 3
+    assert all(np.isfinite(t.results_dict["loss"]))
+    assert len(t.results_dict["mean_success"]) == 3
+    assert t.state_data.eval_counter > 0 and t.sampled_data_count == 128
+    out = tmp_path / "trained_models" / "wing" / "e2e"
+    assert {"config.json", "model_wing", "model_wing1", "model_wing2",
+            "results.json", "loss.csv"} <= set(os.listdir(out))
+    saved = json.load(open(out / "config.json"))
+    assert len(saved["mean"]) == 12 and saved["take_every_x"] == 2
+
+    # continue from the directory: weights and normalisation come from it
+    cfg2 = dict(cfg, nr_epochs=1, save_name="e2e_cont")
+    saved["mean"][3] = 11.0                       # recognisable
+    json.dump(saved, open(out / "config.json", "w"))
+    t2 = tfw.train_sampling_finetune(str(out), dict(cfg2, modified_params={"mass": 1.1}),
+                                     device=dev)
+    assert abs(float(t2.state_data.mean[3]) - 11.0) < 1e-6
+    assert t2.sample_in == "eval_env" and t2.results_dict["samples_in_d2"]
+
+    cfg3 = dict(cfg, nr_epochs=3, train_dyn_for_epochs=1, save_name="e2e_dyn",
+                modified_params={"mass": 1.2, "rho": 1.1})
+    t3 = tfw.train_dynamics(wing_loop_policy(dev), dict(cfg3), device=dev)
+    assert t3.results_dict["trained"] == ["dynamics", "dynamics", "controller"]
+    assert all(np.isfinite(t3.results_dict["loss"]))
+    assert t3.config["thresh_div_start"] == 20
+    dyn_sd = torch.load(tmp_path / "trained_models" / "wing" / "e2e_dyn" /
+                        "dynamics_model", map_location="cpu")
+    assert "I" in dyn_sd and "cfg.mass" in dyn_sd and "linear_state_1.weight" in dyn_sd
