@@ -27,8 +27,7 @@
      defined(APG_REG_REF_LOOK) || defined(APG_GEMM_ST_MAX) ||                  \
      defined(APG_GEMM_STREAM) || defined(APG_WING_WAVES) ||                    \
      defined(APG_WING_GROUP_PREFETCH) || defined(APG_WING_LITERALS) ||        \
-     defined(APG_WING_PK) || defined(APG_WING_PK_KMODE) ||                     \
-     defined(APG_PLANES_ST_AUX) || defined(APG_PLANES_LD_AUX))
+     defined(APG_WING_PK) || defined(APG_WING_PK_KMODE))
 #error "experiment macro in a product build (variants: -DAPG_EXPERIMENT_BUILD, tools/build_variant.py)"
 #endif
 

@@ -18,6 +18,10 @@ namespace apg {
 constexpr unsigned kDead = 0xFFFFFFFCu;  // buffer offset beyond any tensor
 
 // cache policy of the plane stores / loads (tuning knobs: experiment builds)
+#if !defined(APG_EXPERIMENT_BUILD) &&                                          \
+    (defined(APG_PLANES_ST_AUX) || defined(APG_PLANES_LD_AUX))
+#error "experiment macro in a product build (variants: -DAPG_EXPERIMENT_BUILD, tools/build_policy_variant.sh)"
+#endif
 #ifndef APG_PLANES_ST_AUX
 #define APG_PLANES_ST_AUX 2
 #endif

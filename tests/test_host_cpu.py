@@ -936,3 +936,18 @@ def test_wing_dataset_prepare_data_and_self_play_slots():
     ds.resample_data()
     assert not torch.equal(ds.states[:8], sampled)
     assert torch.equal(ds.states[8 + 5], d["state0"][29])    # self-play part kept
+
+
+def test_committed_pmc_counters_belong_to_the_committed_kernel_sources():
+    """bench.py reports `roofline.traffic` (and the fixed-wing VALU fraction)
+    only when profiles/pmc_traffic.json was taken on the kernel sources it
+    runs.  An edit to one of those files without a new PMC pass would drop the
+    fields from the driver's line silently - fail here instead."""
+    import json
+    import bench
+    with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+        pmc = json.load(f)
+    assert pmc["quad_B65536_H10_packed"]["kernel_build"] == bench.kernel_build_id()
+    assert pmc["quad_B65536_H10_packed"]["buffer_sets"] == 20
+    assert (pmc["wing_B131072_H20_soa"]["kernel_build"]
+            == bench.kernel_build_id(bench.WING_SOURCES))
