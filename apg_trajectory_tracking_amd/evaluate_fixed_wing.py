@@ -105,17 +105,22 @@ class FixedWingEvaluator:
                 data.add_eval_data(seen[:, :12], seen[:, 12:])
         c.action_counter += total
 
+    def _fly(self, targets, max_steps, return_traj=False):
+        """One launch for all flights + the self play that goes with it."""
+        # the per-step rows (31 floats x max_steps per flight) only when they
+        # are returned or feed the self play
+        collecting = getattr(self.controller.dataset, "num_self_play", 0) > 0
+        out = self._closed_loop(targets, max_steps, return_traj or collecting)
+        self._self_play(out)
+        return out
+
     def fly_to_point(self, target_points, max_steps=1000, do_avg_act=0,
                      return_traj=False):
         targets = np.asarray(target_points, dtype=np.float32)
         single = targets.ndim == 2
         if single:
             targets = targets[None]
-        # the per-step rows (31 floats x max_steps per flight) only when they
-        # are returned or feed the self play
-        collecting = getattr(self.controller.dataset, "num_self_play", 0) > 0
-        out = self._closed_loop(targets, max_steps, return_traj or collecting)
-        self._self_play(out)
+        out = self._fly(targets, max_steps, return_traj)
         steps = out["steps"].cpu().numpy()
         if return_traj:
             drone = out["drone"].permute(2, 0, 1).cpu().numpy()
@@ -134,9 +139,21 @@ class FixedWingEvaluator:
         yz = (np.random.rand(nr_test, 2) - .5) * 2 * x_std
         targets = np.concatenate(
             (np.full((nr_test, 1, 1), float(x_dist)), yz[:, None]), 2)
-        div_target, div_linear = self.fly_to_point(targets, max_steps=max_steps)
-        mean_div_target = np.array([np.mean(d) for d in div_target])
-        not_div_time = [len(d) for d in div_linear]
+        out = self._fly(targets.astype(np.float32), max_steps)
+        # per-flight mean of fly_to_point's div_target list, without building
+        # the lists: the entries of the steps flown, plus thresh_div for a
+        # flight that used up max_steps (:126-128)
+        steps = out["steps"].to(torch.int64)
+        ev = torch.stack((out["div_pass"], out["div_fail"]), 2).double()  # [T,B,2]
+        flown = torch.arange(ev.shape[0], device=ev.device)[:, None] < steps[None]
+        valid = (ev >= 0) & flown[:, :, None]
+        total = torch.where(valid, ev, torch.zeros_like(ev)).sum((0, 2))
+        count = valid.sum((0, 2))
+        cut = steps == max_steps
+        total = total + cut * float(self.thresh_div)
+        count = count + cut
+        mean_div_target = (total / count).cpu().numpy()
+        not_div_time = steps.cpu().numpy()
         mean_err, std_err = np.mean(mean_div_target), np.std(mean_div_target)
         if printout:
             print("Time not diverged: %3.2f (%3.2f)"

@@ -78,7 +78,8 @@ class _GraphedStep:
 
     def __call__(self):
         self.graph.replay()
-        return self.out
+        # a private copy: the next replay overwrites the captured output
+        return self.out.clone() if torch.is_tensor(self.out) else self.out
 
 
 class TrainBase:
@@ -169,6 +170,7 @@ class TrainBase:
         # all-reduce stays an eager call between the kernels and the update)
         self.graph_steps = False
         self._graphs = {}
+        self._index_bufs = {}
 
         # horizon / reference-window length (scripts/train_base.py:118-128)
         if self.train_mode in ["autoregressive", "LSTM"]:
@@ -237,20 +239,44 @@ class TrainBase:
         self.optimizer_controller.step()
         return loss
 
-    def _graphed(self, key, inputs, fn):
+    def _graphable(self):
+        return (self.graph_steps and parallel.world_size() == 1
+                and torch.cuda.is_available())
+
+    def _graphed(self, key, inputs, fn, volatile=()):
         """fn() - through a captured graph when `graph_steps` is on and the
-        inputs are the same tensor objects, unchanged, as at capture time."""
-        if not self.graph_steps or parallel.world_size() > 1 \
-                or not torch.cuda.is_available():
+        inputs are the same tensor objects, unchanged, as at capture time.
+        `volatile`: tensors the captured kernels read whose CONTENT may differ
+        from replay to replay (same object, same shape) - the index batch."""
+        if not self._graphable():
             return fn()
-        sig = tuple((id(t), t._version, tuple(t.shape)) for t in inputs)
+
+        def signature():
+            return (tuple((id(t), t._version, tuple(t.shape)) for t in inputs)
+                    + tuple((id(t), tuple(t.shape)) for t in volatile))
+        sig = signature()
         g = self._graphs.get(key)
         if g is None or g.signature != sig:
-            g = self._graphs[key] = _GraphedStep(fn, sig, list(inputs), self.net,
-                                                 self.optimizer_controller)
+            g = self._graphs[key] = _GraphedStep(
+                fn, sig, list(inputs) + list(volatile), self.net,
+                self.optimizer_controller)
             # the capture's own warm-up steps may have bumped nothing; re-read
-            g.signature = tuple((id(t), t._version, tuple(t.shape)) for t in inputs)
+            g.signature = signature()
         return g()
+
+    def _graph_index(self, index):
+        """The persistent device copy of an index batch that a captured step
+        reads (one buffer per batch size: the ragged last batch of an epoch
+        has its own graph): lets the shuffled minibatches of run_epoch replay
+        ONE captured step - only the buffer's content changes.  None when
+        steps are not graphed."""
+        if not self._graphable():
+            return None
+        buf = self._index_bufs.get(index.numel())
+        if buf is None:
+            buf = self._index_bufs[index.numel()] = torch.empty_like(index)
+        buf.copy_(index)
+        return buf
 
     def analytic_train_dynamics(self):
         """The fused rollouts integrate the ANALYTIC simulator described by

@@ -103,6 +103,14 @@ class TrainDrone(TrainBase):
         batch_size = current_state.size()[0] if index is None else index.numel()
         static = index is None and self.static_shard
         tensors = (current_state, in_ref_states, ref_states)
+        fused = self.fused_policy and (
+            self._fusable() if self.train_mode == "LSTM" else self._fusable_mlp())
+        held = (self._graph_index(index)
+                if index is not None and fused
+                and not (self.train_mode == "LSTM"
+                         and self.hidden_generator is not None) else None)
+        if held is not None:
+            index = held      # the captured gather reads this buffer
         if self.train_mode == "LSTM":
             if self.fused_policy and self._fusable():
                 def step():
@@ -116,6 +124,9 @@ class TrainDrone(TrainBase):
                     return self._step_direct(loss, grads, flat)
                 # (a private hidden-state generator is not registered with the
                 # graph: those runs step eagerly)
+                if held is not None:
+                    return self._graphed(("lstm", batch_size), tensors, step,
+                                         volatile=(held,))
                 if static and self.hidden_generator is None:
                     return self._graphed("lstm", tensors, step)
                 return step()
@@ -128,6 +139,9 @@ class TrainDrone(TrainBase):
                     self.delta_t, self.train_dynamics.params, index=index,
                     static_inputs=self.static_shard)
                 return self._step_direct(loss, grads, flat)
+            if held is not None:
+                return self._graphed(("autoregressive", batch_size), tensors, step,
+                                     volatile=(held,))
             if static:
                 return self._graphed("autoregressive", tensors, step)
             return step()
@@ -181,15 +195,22 @@ class TrainDrone(TrainBase):
             return ok
         if not ok:
             return None
+        tensors = (in_state, current_state, in_ref_states, ref_states)
+        held = None if index is None else self._graph_index(index)
+        if held is not None:
+            index = held      # the captured gather reads this buffer
+
         def step():
             loss, grads, flat = F.quad_concurrent_policy_grads(
                 n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
                 self.train_dynamics.params, index=index,
                 static_inputs=self.static_shard)
             return self._step_direct(loss, grads, flat)
+        if held is not None:
+            return self._graphed(("concurrent", held.numel()), tensors, step,
+                                 volatile=(held,))
         if index is None and self.static_shard:
-            return self._graphed("concurrent", (in_state, current_state,
-                                                in_ref_states, ref_states), step)
+            return self._graphed("concurrent", tensors, step)
         return step()
 
     # ------------------------------------------- packed (row-layout) path --

@@ -1381,3 +1381,45 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
         # captured generator state, so only the statistics agree
         assert all(np.isfinite(c)) and abs(c[0] - a[0]) / abs(a[0]) < 0.2
     F._STATIC_PLANES.entries.clear()
+
+
+@pytest.mark.parametrize("mode", ["concurrent", "autoregressive", "LSTM"])
+def test_run_epoch_replays_one_graph_over_shuffled_minibatches(dev, mode):
+    """TrainBase.graph_steps with the REAL epoch loop: shuffled index batches
+    (two full ones and a ragged tail per epoch) go through a persistent index
+    buffer, so every minibatch replays the step captured for its size.  Same
+    seed -> the epochs' losses and the final weights equal the eager loop's;
+    one graph per batch size, captured once."""
+    import copy
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    cfg = dict(QUAD_CFG, train_mode=mode, epoch_size=1000, self_play=0,
+               batch_size=384, learning_rate_controller=1e-6)
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(4)
+        t = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
+        t.initialize_model(device=dev, seed=6)
+        if graph:
+            t.net.load_state_dict(runs[0][2])      # same start
+        start = copy.deepcopy(t.net.state_dict())
+        t.graph_steps = graph
+        torch.manual_seed(11)                      # the permutations
+        torch.cuda.manual_seed(12)
+        losses = [t.run_epoch(train="controller", epoch=e) for e in range(3)]
+        runs.append((losses, {k: v.clone() for k, v in t.net.state_dict().items()},
+                     start))
+        if graph:
+            assert sorted(k[1] for k in t._graphs) == [232, 384]
+            assert sorted(t._index_bufs) == [232, 384]
+        else:
+            assert not t._graphs
+    (la, wa, _), (lb, wb, _) = runs
+    assert all(np.isfinite(la)) and all(np.isfinite(lb))
+    if mode != "LSTM":
+        assert np.allclose(la, lb, rtol=1e-5), (la, lb)
+        for k in wa:
+            assert rel_err(wb[k].cpu().numpy(), wa[k].cpu().numpy()) < 1e-5, k
+    else:      # fresh (h0, c0) per step from the captured generator state
+        assert abs(lb[0] - la[0]) / abs(la[0]) < 0.2

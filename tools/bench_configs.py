@@ -188,6 +188,33 @@ def main():
             te.run_epoch("controller", e + 1)
         torch.cuda.synchronize()
         emit("quad_run_epoch_per_batch", B, H, (_t.perf_counter() - t0) / (3 * nb) * 1e3)
+        # the same loop with the minibatch steps replayed from ONE captured
+        # graph (TrainBase.graph_steps: persistent index buffer)
+        te.graph_steps = True
+        te.run_epoch("controller", 4)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for e in range(3):
+            te.run_epoch("controller", e + 5)
+        torch.cuda.synchronize()
+        emit("quad_run_epoch_per_batch_graphed", B, H,
+             (_t.perf_counter() - t0) / (3 * nb) * 1e3)
+        for mode in ("autoregressive", "LSTM"):
+            cfg_r = dict(cfg, train_mode=mode, epoch_size=4 * B)
+            tr = TrainDrone(qdyn, qdyn, cfg_r)
+            tr.initialize_model(device=dev, seed=0)
+            for graphed in (False, True):
+                tr.graph_steps = graphed
+                tr.run_epoch("controller", 0)
+                torch.cuda.synchronize()
+                t0 = _t.perf_counter()
+                for e in range(2):
+                    tr.run_epoch("controller", e + 1)
+                torch.cuda.synchronize()
+                emit(f"quad_run_epoch_per_batch_{mode}" + ("_graphed" if graphed else ""),
+                     B, H, (_t.perf_counter() - t0) / (2 * 4) * 1e3)
+            del tr
+            torch.cuda.empty_cache()
 
     for mode, name, fused in (("autoregressive", "quad_ar_unfused", False),
                               ("autoregressive", "quad_ar_fused", True),
