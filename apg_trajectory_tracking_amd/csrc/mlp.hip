@@ -40,6 +40,7 @@
 // apg_planes_gemm.
 #include "apg_device.h"
 #include "policy_mfma.h"
+#include "policy_mfma16.h"
 #include "quad_math.h"
 
 namespace apg {
@@ -790,8 +791,15 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
 // kernel - the reverse pass of the network from dL/d(head pre-activations).
 // Planes are [feature][B]; the weight gradients come from apg_planes_gemm.
 constexpr int kNA = kH * 4;                       // head width (40)
-constexpr int cAo = kFwdLds;                      // [2][33][64] head A table
-constexpr int kCfLds = cAo + 2 * 33 * 64;         // 31 360 floats = 125 440 B
+// Forward tables of the concurrent kernel (fp16 split operands, policy_mfma16.h).
+// Bias tables ([rb][16][2] floats, indexed by the half-wave) first, then 60
+// A-operand blocks of 2 KB: states_in [rb], conv [kb], fc1 conv part
+// [rb][position pair][kb], fc1 state part / fc2 / fc3 / head [rb][kb].
+constexpr int hTbs = 0, hTb1 = 64, hTb2 = 128, hTb3 = 192, hTbo = 256, hTbc = 320;  // floats
+constexpr int hA = 2048;                          // bytes: first A block
+constexpr int nS = 0, nC = 2, n1c = 4, n1s = 28, n2 = 36, n3 = 44, nO = 52, nBlocks16 = 60;
+constexpr int kCfLds = (hA + nBlocks16 * kBlock16) / 4;  // 31 232 floats = 124 928 B
+static_assert(hTbc + 32 <= hA / 4, "LDS map");
 constexpr int cAoT = kBwdLds;                     // [2][20][64] head^T A table
 constexpr int kCbLds = cAoT + 2 * 20 * 64;        // 27 456 floats = 109 824 B
 
@@ -801,16 +809,57 @@ __host__ __device__ constexpr int khead(int c, int hi) {
   return (c < 16 ? rrow(c) : 32 + rrow(c - 16)) + 4 * hi;
 }
 
+// weight behind k-slot (kb, j, hi) of A block n, output row `row` (0..31 of
+// the block's row block) - the single definition of the forward k-orders
+__device__ __forceinline__ float cfwd_weight(const ApgMlpPolicy &p, int n, int row, int j,
+                                             int hi) {
+  if (n < nC) {                       // states_in: features 8 hi + j
+    const int k = 8 * hi + j;
+    return k < kNF ? p.w_s[((n - nS) * 32 + row) * kNF + k] : 0.f;
+  }
+  if (n < n1c) {                      // conv: slot s = (column j', tap), 15 of 16
+    const int s = (n - nC) * 8 + j, jc = s / 3, tap = s % 3, q = hi ? 4 + jc : jc;
+    return (s < 15 && row < kNC && (hi || jc < 4)) ? p.conv_w[row * 27 + q * 3 + tap] : 0.f;
+  }
+  if (n < n1s) {                      // fc1 on the conv outputs of a position pair
+    const int m = n - n1c, rb = m / 12, pp = (m / 3) % 4, kb = m % 3;
+    const int s = kb * 8 + j, pos = 2 * pp + s / 12, ch = rrow(s % 12) + 4 * hi;
+    return ch < kNC ? p.w_1[(rb * 32 + row) * kN1 + kW + ch * kNP + pos] : 0.f;
+  }
+  const int m = (n - n1s) % 8, rb = m / 4, kb = m % 4, k = kin(kb, j, hi);
+  const int out = rb * 32 + row;
+  if (n < n2) return p.w_1[out * kN1 + k];
+  if (n < n3) return p.w_2[out * kW + k];
+  if (n < nO) return p.w_3[out * kW + k];
+  return out < kNA ? p.w_out[out * kW + k] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void mlp_pack_cfwd_kernel(PackArgs A) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
-  pack_forward(A.dst, A.pol, tid, T, /*head4=*/false);
-  for (int idx = tid; idx < 2 * 33 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) % 33, rb = idx / (33 * 64);
-    const int m = rb * 32 + (l & 31);
-    float v = 0.f;
-    if (m < kNA) v = c < 32 ? A.pol.w_out[m * kW + kchain(c, l >> 5)]
-                            : (l < 32 ? A.pol.b_out[m] : 0.f);  // bias pair (1, 0)
-    A.dst[cAo + idx] = v;
+  const ApgMlpPolicy &p = A.pol;
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  // one thread per (block, lane, word): two weights -> fp16 high / low terms
+  for (int idx = tid; idx < nBlocks16 * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    const float w0 = cfwd_weight(p, n, l & 31, 2 * q, l >> 5);
+    const float w1 = cfwd_weight(p, n, l & 31, 2 * q + 1, l >> 5);
+    unsigned h, lo;
+    split_pair(w0, w1, h, lo);
+    dst[(hA + n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(hA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
+  }
+  for (int idx = tid; idx < 64; idx += T) {
+    const int hi = idx & 1, i = (idx >> 1) & 15, rb = idx >> 5;
+    const int row = rb * 32 + rrow(i) + 4 * hi;
+    A.dst[hTbs + idx] = p.b_s[row];
+    A.dst[hTb1 + idx] = p.b_1[row];
+    A.dst[hTb2 + idx] = p.b_2[row];
+    A.dst[hTb3 + idx] = p.b_3[row];
+    A.dst[hTbo + idx] = row < kNA ? p.b_out[row] : 0.f;
+  }
+  for (int idx = tid; idx < 32; idx += T) {
+    const int hi = idx & 1, i = idx >> 1, ch = rrow(i) + 4 * hi;
+    A.dst[hTbc + idx] = ch < kNC ? p.conv_b[ch] : 0.f;
   }
 }
 __global__ __launch_bounds__(256) void mlp_pack_cbwd_kernel(PackArgs A) {
@@ -868,62 +917,102 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
 #pragma unroll
     for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vr, (r * kRD + j) * pN);
 
-  // ---- policy forward (as mlp_rollout_fwd_kernel, window used as given)
+  // ---- policy forward on the 16-bit matrix pipe (policy_mfma16.h): every
+  // operand as two fp16 terms, three products per k-block
+  const LdsView16 L16(lds, lane);
+  const auto ident = [](int, int, float v) { return v; };
   f32x16 u[2], a[2];
-  init_bias(u, L, fTbs);
+  init_bias(u, L, hTbs);
+  {  // states_in: one k-block, features 8 hi .. 8 hi + 7
+    float v[8];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
-    const float bv = hi ? odd : feat[2 * p];
-    u[0] = mfma(L.A(fAs + (0 * 8 + p) * 64), bv, u[0]);
-    u[1] = mfma(L.A(fAs + (1 * 8 + p) * 64), bv, u[1]);
+    for (int j = 0; j < 8; ++j) v[j] = hi ? (8 + j < kNF ? feat[8 + j < kNF ? 8 + j : 0] : 0.f) : feat[j];
+    const Op16 x = split8(v);
+    u[0] = mma3(L16.A(hA, nS + 0), x, u[0]);
+    u[1] = mma3(L16.A(hA, nS + 1), x, u[1]);
   }
-  init_bias(a, L, fTb1);
+  // the window values, split once: high term in the low half-word, low term
+  // in the high half-word of one register per value
+  unsigned ws[kH][5];
+#pragma unroll
+  for (int r = 0; r < kH; ++r)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const _Float16 vh = (_Float16)w[r][j], vl = (_Float16)(w[r][j] - (float)vh);
+      const h16x2 pr = {vh, vl};
+      ws[r][j] = __builtin_bit_cast(unsigned, pr);
+    }
+  init_bias(a, L, hTb1);
   unsigned mbits[3] = {0u, 0u, 0u};
 #pragma unroll
-  for (int pos = 0; pos < kNP; ++pos) {
-    f32x16 cv;
+  for (int pp = 0; pp < kNP / 2; ++pp) {
+    float rv[24];  // relu(conv) of positions 2 pp, 2 pp + 1: registers 0..11 each
 #pragma unroll
-    for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2);
+    for (int e = 0; e < 2; ++e) {
+      const int pos = 2 * pp + e;
+      f32x16 cv;
 #pragma unroll
-    for (int p = 0; p < 15; ++p) {
-      cv = mfma(L.A(fAc + p * 64), w[pos + p % 3][p / 3], cv);
-      if (p % 4 == 3 || p == 14) {
-        const int cc = pos * 4 + (p == 14 ? 3 : p / 4);
-        const float tv = tanh_fast(u[cc >> 4][cc & 15]);
-        u[cc >> 4][cc & 15] = tv;
-        Px1.st(vr, ((cc >> 4) * 32 + rrow(cc & 15)) * pN, tv);
+      for (int i = 0; i < 16; ++i) cv[i] = L.T(hTbc + i * 2);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        Op16 x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // slots 2 q, 2 q + 1 of this k-block
+          const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
+          const unsigned r0 = ws[pos + s0 % 3][s0 / 3];
+          const unsigned r1 = s1 < 15 ? ws[pos + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
+          x.h[q] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);  // low half-words
+          x.l[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);  // high half-words
+        }
+        cv = mma3(L16.A(hA, nC + kb), x, cv);
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        float v = cv[i];
+        mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
+        v = fmaxf(v, 0.f);
+        Px1.st(i < 8 ? vc : vb_lo, (kW + rrow(i) * kNP + pos) * pN, v);
+        rv[e * 12 + i] = v;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      float v = cv[i];
-      mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
-      v = fmaxf(v, 0.f);
-      Px1.st(i < 8 ? vc : vb_lo, (kW + rrow(i) * kNP + pos) * pN, v);
-      a[0] = mfma(L.A(fA1c + ((0 * 8 + pos) * 12 + i) * 64), v, a[0]);
-      a[1] = mfma(L.A(fA1c + ((1 * 8 + pos) * 12 + i) * 64), v, a[1]);
+    for (int kb = 0; kb < 3; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rv[kb * 8 + j];
+      const Op16 x = split8(v);
+      a[0] = mma3(L16.A(hA, n1c + (0 * 4 + pp) * 3 + kb), x, a[0]);
+      a[1] = mma3(L16.A(hA, n1c + (1 * 4 + pp) * 3 + kb), x, a[1]);
     }
   }
 #pragma unroll
   for (int g = 0; g < 3; ++g) Pmk.stu(g < 2 ? vm : vb_lo, 2 * g * pN, mbits[g]);
-  dense64(a, u, L, fA1s);
-  init_bias(u, L, fTb2);
-  dense64_tanh(u, a, L, fA2, Ph, 0, vr, pN);
-  init_bias(a, L, fTb3);
-  dense64_tanh(a, u, L, fA3, Ph, kW, vr, pN);
-  // head: 40 outputs = row block 0 + rows 0..7 of row block 1, bias as an
-  // extra k-pair with the B operand (1, 0)
-  zero(u);
-#pragma unroll
-  for (int cc = 0; cc < 32; ++cc) {
-    const float bv = tanh_fast(a[cc >> 4][cc & 15]);
-    Ph.st(vr, (2 * kW + (cc >> 4) * 32 + rrow(cc & 15)) * pN, bv);
-    u[0] = mfma(L.A(cAo + (0 * 33 + cc) * 64), bv, u[0]);
-    u[1] = mfma(L.A(cAo + (1 * 33 + cc) * 64), bv, u[1]);
-  }
-  u[0] = mfma(L.A(cAo + (0 * 33 + 32) * 64), hi ? 0.f : 1.f, u[0]);
-  u[1] = mfma(L.A(cAo + (1 * 33 + 32) * 64), hi ? 0.f : 1.f, u[1]);
+  // fc1 state part on s1 = tanh(states_in), stored as the reverse pass needs it
+  dense64_16(a, u, L16, hA, n1s, [&](int rb, int i, float v) {
+    const float tv = tanh_fast(v);
+    Px1.st(vr, (rb * 32 + rrow(i)) * pN, tv);
+    return tv;
+  });
+  init_bias(u, L, hTb2);
+  dense64_16(u, a, L16, hA, n2, [&](int rb, int i, float v) {
+    const float tv = tanh_fast(v);
+    Ph.st(vr, (rb * 32 + rrow(i)) * pN, tv);
+    return tv;
+  });
+  init_bias(a, L, hTb3);
+  dense64_16(a, u, L16, hA, n3, [&](int rb, int i, float v) {
+    const float tv = tanh_fast(v);
+    Ph.st(vr, (kW + rb * 32 + rrow(i)) * pN, tv);
+    return tv;
+  });
+  // head: 40 outputs = row block 0 + rows 0..7 of row block 1
+  init_bias(u, L, hTbo);
+  dense64_16(u, a, L16, hA, nO, [&](int rb, int i, float v) {
+    const float tv = tanh_fast(v);
+    Ph.st(vr, (2 * kW + rb * 32 + rrow(i)) * pN, tv);
+    return tv;
+  });
+  (void)ident;
   // every lane needs all 40 actions (both halves run the same rollout)
   float act[kH][4];
 #pragma unroll
