@@ -594,6 +594,18 @@ __device__ __forceinline__ void tanh_adjoint(f32x16 (&v)[2], const float (&hv)[2
     }
 }
 
+// the same for a product that arrives scaled by 2^-ex (policy_mfma16.h)
+__device__ __forceinline__ void tanh_adjoint(f32x16 (&v)[2], const float (&hv)[2][16],
+                                             const Planes &out, int out_base,
+                                             unsigned vr, unsigned pN, int ex) {
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      v[rb][i] = __builtin_amdgcn_ldexpf(v[rb][i], ex);
+  tanh_adjoint(v, hv, out, out_base, vr, pN);
+}
+
 __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds(lds, A.tables, kBwdLds);
@@ -800,8 +812,11 @@ constexpr int hA = 2048;                          // bytes: first A block
 constexpr int nS = 0, nC = 2, n1c = 4, n1s = 28, n2 = 36, n3 = 44, nO = 52, nBlocks16 = 60;
 constexpr int kCfLds = (hA + nBlocks16 * kBlock16) / 4;  // 31 232 floats = 124 928 B
 static_assert(hTbc + 32 <= hA / 4, "LDS map");
-constexpr int cAoT = kBwdLds;                     // [2][20][64] head^T A table
-constexpr int kCbLds = cAoT + 2 * 20 * 64;        // 27 456 floats = 109 824 B
+// Reverse tables of the concurrent kernel: 50 transposed A-operand blocks
+// (policy_mfma16.h): head^T [rb][kb of 3], fc3^T, fc2^T, fc1^T state part
+// [rb][kb], fc1^T conv part [32-row block eb of 5][kb].
+constexpr int mOT = 0, m3T = 6, m2T = 14, m1sT = 22, m1cT = 30, mBlocks16 = 50;
+constexpr int kCbLds = mBlocks16 * kBlock16 / 4;  // 25 600 floats = 102 400 B
 
 // k index of head-output k-pair c (accumulator layout of the 40 outputs:
 // row block 0 registers 0..15, row block 1 registers 0..3)
@@ -862,12 +877,34 @@ __global__ __launch_bounds__(256) void mlp_pack_cfwd_kernel(PackArgs A) {
     A.dst[hTbc + idx] = ch < kNC ? p.conv_b[ch] : 0.f;
   }
 }
+// weight behind k-slot (kb, j, hi) of transposed A block n, output row `row`
+__device__ __forceinline__ float cbwd_weight(const ApgMlpPolicy &p, int n, int row, int j,
+                                             int hi) {
+  if (n < m3T) {                      // head^T: slots = this lane's 20 dL/dz rows
+    const int rb = n / 3, cc = (n % 3) * 8 + j;
+    return cc < 20 ? p.w_out[khead(cc, hi) * kW + rb * 32 + row] : 0.f;
+  }
+  if (n < m1cT) {
+    const int m = (n - m3T) % 8, rb = m / 4, k = kin(m % 4, j, hi), out = rb * 32 + row;
+    if (n < m2T) return p.w_3[k * kW + out];
+    if (n < m1sT) return p.w_2[k * kW + out];
+    return p.w_1[k * kN1 + out];
+  }
+  const int m = n - m1cT, eb = m / 4, k = kin(m % 4, j, hi);
+  return p.w_1[k * kN1 + kW + eb * 32 + row];
+}
+
 __global__ __launch_bounds__(256) void mlp_pack_cbwd_kernel(PackArgs A) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
-  pack_reverse(A.dst, A.pol, tid, T, /*head4=*/false);
-  for (int idx = tid; idx < 2 * 20 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) % 20, rb = idx / (20 * 64);
-    A.dst[cAoT + idx] = A.pol.w_out[khead(c, l >> 5) * kW + rb * 32 + (l & 31)];
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    const float w0 = cbwd_weight(A.pol, n, l & 31, 2 * q, l >> 5);
+    const float w1 = cbwd_weight(A.pol, n, l & 31, 2 * q + 1, l >> 5);
+    unsigned h, lo;
+    split_pair(w0, w1, h, lo);
+    dst[(n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
   }
 }
 
@@ -1122,33 +1159,53 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A
   float hv[2][16];
   load_acts(hv, Ph, 2 * kW, vr, pN);  // h3
   __builtin_amdgcn_sched_barrier(0);
+  // the reverse layers on the 16-bit matrix pipe: cotangents scaled per
+  // trajectory, split into two fp16 terms, three products per k-block
+  const LdsView16 L16(lds, lane);
   f32x16 d[2], e[2];
   zero(d);
+  int ex;
+  {  // dL/dh3 = W_out^T dL/dz: this lane's 20 rows fill 2.5 k-blocks
+    float amax = 0.f;
 #pragma unroll
-  for (int cc = 0; cc < 20; ++cc) {  // dL/dh3 = W_out^T dL/dz
-    d[0] = mfma(L.A(cAoT + (0 * 20 + cc) * 64), dzr[cc], d[0]);
-    d[1] = mfma(L.A(cAoT + (1 * 20 + cc) * 64), dzr[cc], d[1]);
+    for (int cc = 0; cc < 20; ++cc) amax = fmaxf(amax, fabsf(dzr[cc]));
+    ex = scale_exponent(amax);
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = kb * 8 + j < 20 ? __builtin_amdgcn_ldexpf(dzr[kb * 8 + j < 20 ? kb * 8 + j : 0], -ex)
+                               : 0.f;
+      const Op16 x = split8(v);
+      d[0] = mma3(L16.A(0, mOT + kb), x, d[0]);
+      d[1] = mma3(L16.A(0, mOT + 3 + kb), x, d[1]);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
-  tanh_adjoint(d, hv, Pdp, 2 * kW, vr, pN);  // d_pre3
-  load_acts(hv, Ph, kW, vr, pN);             // h2
+  tanh_adjoint(d, hv, Pdp, 2 * kW, vr, pN, ex);  // d_pre3
+  load_acts(hv, Ph, kW, vr, pN);                 // h2
   __builtin_amdgcn_sched_barrier(0);
+  Op16 x[4];
   zero(e);
-  dense64(e, d, L, rA3);
+  ex = scaled_split64(d, x);
+  dense64T_16(e, x, L16, 0, m3T);
   __builtin_amdgcn_sched_barrier(0);
-  tanh_adjoint(e, hv, Pdp, kW, vr, pN);      // d_pre2
-  load_acts(hv, Ph, 0, vr, pN);              // h1
+  tanh_adjoint(e, hv, Pdp, kW, vr, pN, ex);      // d_pre2
+  load_acts(hv, Ph, 0, vr, pN);                  // h1
   __builtin_amdgcn_sched_barrier(0);
   zero(d);
-  dense64(d, e, L, rA2);
+  ex = scaled_split64(e, x);
+  dense64T_16(d, x, L16, 0, m2T);
   __builtin_amdgcn_sched_barrier(0);
-  tanh_adjoint(d, hv, Pdp, 0, vr, pN);       // d_pre1
-  load_acts(hv, Px1, 0, vr, pN);             // s1
+  tanh_adjoint(d, hv, Pdp, 0, vr, pN, ex);       // d_pre1
+  load_acts(hv, Px1, 0, vr, pN);                 // s1
   __builtin_amdgcn_sched_barrier(0);
   zero(e);
-  dense64(e, d, L, rA1s);
+  ex = scaled_split64(d, x);                     // d_pre1 feeds both fc1^T parts
+  dense64T_16(e, x, L16, 0, m1sT);
   __builtin_amdgcn_sched_barrier(0);
-  tanh_adjoint(e, hv, Pdp, 3 * kW, vr, pN);  // d_pre_s
+  tanh_adjoint(e, hv, Pdp, 3 * kW, vr, pN, ex);  // d_pre_s
   // conv outputs (the network inputs carry no gradient in this mode)
 #pragma unroll
   for (int eb = 0; eb < 5; ++eb) {
@@ -1156,12 +1213,12 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A
 #pragma unroll
     for (int i = 0; i < 16; ++i) y[i] = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < 32; ++cc)
-      y = mfma(L.A(rA1c + (eb * 32 + cc) * 64), d[cc >> 4][cc & 15], y);
+    for (int kb = 0; kb < 4; ++kb) y = mma3(L16.A(0, m1cT + eb * 4 + kb), x[kb], y);
     const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      Pdc.st(vr, (eb * 32 + rrow(i)) * pN, ((mws >> rrow(i)) & 1u) ? y[i] : 0.f);
+      Pdc.st(vr, (eb * 32 + rrow(i)) * pN,
+             ((mws >> rrow(i)) & 1u) ? __builtin_amdgcn_ldexpf(y[i], ex) : 0.f);
   }
 }
 

@@ -99,6 +99,46 @@ struct LdsView16 {
   }
 };
 
+// Cotangents have no bounded range: each trajectory's vector is scaled by a
+// power of two (exact) that brings its largest entry into [0.5, 1) before the
+// split, and the product is scaled back by the consumer (ldexp with the
+// returned exponent).  `amax`: this lane's max |v| over ITS rows; both
+// half-waves of a trajectory agree on the exponent.
+__device__ __forceinline__ int scale_exponent(float amax) {
+  amax = fmaxf(amax, other_half(amax));
+  return amax > 0.f ? __builtin_amdgcn_frexp_expf(amax) : 0;
+}
+
+// the four k-blocks of a 64-wide cotangent in accumulator layout, scaled by
+// 2^-e (returned) and split; consumers multiply their result by 2^e
+__device__ __forceinline__ int scaled_split64(const f32x16 (&in)[2], Op16 (&x)[4]) {
+  float amax = 0.f;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(in[rb][i]));
+  const int e = scale_exponent(amax);
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = __builtin_amdgcn_ldexpf(in[kb >> 1][8 * (kb & 1) + j], -e);
+    x[kb] = split8(v);
+  }
+  return e;
+}
+
+// out[rb] = W^T-blocks [rb][kb] from `n0` times the split cotangent (scaled)
+__device__ __forceinline__ void dense64T_16(f32x16 (&out)[2], const Op16 (&x)[4],
+                                            const LdsView16 &L, int base, int n0) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    out[0] = mma3(L.A(base, n0 + kb), x[kb], out[0]);
+    out[1] = mma3(L.A(base, n0 + 4 + kb), x[kb], out[1]);
+  }
+}
+
 // 64-wide layer on accumulator-layout inputs: out[rb] += W[rb] . in, blocks
 // [rb][kb] from block index `n0`; `f` is applied to every input first (tanh of
 // the previous layer, or the identity) and may store it.
