@@ -156,6 +156,7 @@ __device__ __forceinline__ void dense64(f32x16 (&out)[2], const f32x16 (&in)[2],
 struct PackArgs {
   ApgMlpPolicy pol;
   float *dst;
+  int head_rows;   // rows of fc_out behind pol.w_out (4: autoregressive, 40: concurrent)
 };
 __global__ __launch_bounds__(256) void mlp_pack_fwd_kernel(PackArgs A) {
   pack_forward(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
@@ -179,6 +180,80 @@ __device__ __forceinline__ void dense64_tanh(f32x16 (&out)[2], f32x16 (&in)[2],
   }
 }
 
+// Forward tables of the training kernels (fp16 split operands,
+// policy_mfma16.h): the small fp32 tables indexed by the half-wave first -
+// biases [rb][16][2], the head's VALU weights of the autoregressive sweep
+// [4][2][16][2] + its bias - then 60 A-operand blocks of 2 KB: states_in [rb],
+// conv [kb], fc1 conv part [rb][position pair][kb], fc1 state part / fc2 /
+// fc3 / the concurrent mode's 40-row head [rb][kb].
+constexpr int hTbs = 0, hTb1 = 64, hTb2 = 128, hTb3 = 192, hTbo = 256, hTbc = 320;  // floats
+constexpr int hTo = 384, hBo = 640;               // floats: [4][2][16][2], [4]
+constexpr int hA = 4096;                          // bytes: first A block
+constexpr int nS = 0, nC = 2, n1c = 4, n1s = 28, n2 = 36, n3 = 44, nO = 52, nBlocks16 = 60;
+constexpr int kCfLds = (hA + nBlocks16 * kBlock16) / 4;  // 31 744 floats = 126 976 B
+static_assert(hBo + 4 <= hA / 4, "LDS map");
+constexpr int kNA = kH * 4;                       // head width of the concurrent mode (40)
+
+// weight behind k-slot (kb, j, hi) of A block n, output row `row` (0..31 of
+// the block's row block) - the single definition of the forward k-orders
+__device__ __forceinline__ float cfwd_weight(const ApgMlpPolicy &p, int n, int row, int j,
+                                             int hi, int head_rows) {
+  if (n < nC) {                       // states_in: features 8 hi + j
+    const int k = 8 * hi + j;
+    return k < kNF ? p.w_s[((n - nS) * 32 + row) * kNF + k] : 0.f;
+  }
+  if (n < n1c) {                      // conv: slot s = (column j', tap), 15 of 16
+    const int s = (n - nC) * 8 + j, jc = s / 3, tap = s % 3, q = hi ? 4 + jc : jc;
+    return (s < 15 && row < kNC && (hi || jc < 4)) ? p.conv_w[row * 27 + q * 3 + tap] : 0.f;
+  }
+  if (n < n1s) {                      // fc1 on the conv outputs of a position pair
+    const int m = n - n1c, rb = m / 12, pp = (m / 3) % 4, kb = m % 3;
+    const int s = kb * 8 + j, pos = 2 * pp + s / 12, ch = rrow(s % 12) + 4 * hi;
+    return ch < kNC ? p.w_1[(rb * 32 + row) * kN1 + kW + ch * kNP + pos] : 0.f;
+  }
+  const int m = (n - n1s) % 8, rb = m / 4, kb = m % 4, k = kin(kb, j, hi);
+  const int out = rb * 32 + row;
+  if (n < n2) return p.w_1[out * kN1 + k];
+  if (n < n3) return p.w_2[out * kW + k];
+  if (n < nO) return p.w_3[out * kW + k];
+  return out < head_rows ? p.w_out[out * kW + k] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_cfwd_kernel(PackArgs A) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+  const ApgMlpPolicy &p = A.pol;
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  // one thread per (block, lane, word): two weights -> fp16 high / low terms
+  for (int idx = tid; idx < nBlocks16 * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    const float w0 = cfwd_weight(p, n, l & 31, 2 * q, l >> 5, A.head_rows);
+    const float w1 = cfwd_weight(p, n, l & 31, 2 * q + 1, l >> 5, A.head_rows);
+    unsigned h, lo;
+    split_pair(w0, w1, h, lo);
+    dst[(hA + n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(hA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
+  }
+  for (int idx = tid; idx < 64; idx += T) {
+    const int hi = idx & 1, i = (idx >> 1) & 15, rb = idx >> 5;
+    const int row = rb * 32 + rrow(i) + 4 * hi;
+    A.dst[hTbs + idx] = p.b_s[row];
+    A.dst[hTb1 + idx] = p.b_1[row];
+    A.dst[hTb2 + idx] = p.b_2[row];
+    A.dst[hTb3 + idx] = p.b_3[row];
+    A.dst[hTbo + idx] = row < A.head_rows ? p.b_out[row] : 0.f;
+  }
+  for (int idx = tid; idx < 32; idx += T) {
+    const int hi = idx & 1, i = idx >> 1, ch = rrow(i) + 4 * hi;
+    A.dst[hTbc + idx] = ch < kNC ? p.conv_b[ch] : 0.f;
+  }
+  // the first four head rows as VALU weights (autoregressive sweep); a
+  // concurrent-mode head (40 rows) has them too
+  for (int idx = tid; idx < 256; idx += T) {
+    const int hi = idx & 1, i = (idx >> 1) & 15, rb = (idx >> 5) & 1, j = idx >> 6;
+    A.dst[hTo + idx] = p.w_out[j * kW + rb * 32 + rrow(i) + 4 * hi];
+  }
+  for (int idx = tid; idx < 4; idx += T) A.dst[hBo + idx] = p.b_out[idx];
+}
 struct FwdArgs {
   const float *state0, *in_ref;
   float *states, *actions;
@@ -191,7 +266,8 @@ struct FwdArgs {
 
 __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwdLds);
+  fill_lds(lds, A.tables, kCfLds);
+  const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,61 +314,99 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
 #pragma unroll
     for (int j = 0; j < kNF; ++j) Pfe.st(vn_lo, j * pN, feat[j]);
 
+    // the policy on the 16-bit matrix pipe (policy_mfma16.h): every operand as
+    // two fp16 terms, three products per k-block
     f32x16 u[2], a[2];
-    // state branch: 8 k-pairs of the 15 features
-    init_bias(u, L, fTbs);
+    init_bias(u, L, hTbs);
+    {  // state branch: one k-block, features 8 hi .. 8 hi + 7
+      float v[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
-      const float bv = hi ? odd : feat[2 * p];
-      u[0] = mfma(L.A(fAs + (0 * 8 + p) * 64), bv, u[0]);
-      u[1] = mfma(L.A(fAs + (1 * 8 + p) * 64), bv, u[1]);
+      for (int j = 0; j < 8; ++j)
+        v[j] = hi ? (8 + j < kNF ? feat[8 + j < kNF ? 8 + j : 0] : 0.f) : feat[j];
+      const Op16 x = split8(v);
+      u[0] = mma3(L16.A(hA, nS + 0), x, u[0]);
+      u[1] = mma3(L16.A(hA, nS + 1), x, u[1]);
     }
-    // conv (one 32-row block per window position) feeding fc1 directly; the
-    // tanh of the state branch (independent work) is spread over the
-    // positions so that it runs under the conv MFMAs
-    init_bias(a, L, fTb1);
-    unsigned mbits[3] = {0u, 0u, 0u};
+    // the window relative to the current position, split once per step: high
+    // term in the low half-word, low term in the high half-word
     const float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
+    unsigned ws[kH][5];
 #pragma unroll
-    for (int pos = 0; pos < kNP; ++pos) {
-      f32x16 cv;
+    for (int r = 0; r < kH; ++r)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2);
+      for (int j = 0; j < 5; ++j) {
+        const float x = j < 3 ? w[r][j] - sub[j] : w[r][j];
+        const _Float16 vh = (_Float16)x, vl = (_Float16)(x - (float)vh);
+        const h16x2 pr = {vh, vl};
+        ws[r][j] = __builtin_bit_cast(unsigned, pr);
+      }
+    init_bias(a, L, hTb1);
+    unsigned mbits[3] = {0u, 0u, 0u};
 #pragma unroll
-      for (int p = 0; p < 15; ++p) {
-        const int j = p / 3, tap = p % 3;
-        const float x = j < 3 ? w[pos + tap][j] - sub[j] : w[pos + tap][j];
-        cv = mfma(L.A(fAc + p * 64), x, cv);
-        if (p % 4 == 3 || p == 14) {  // 4 state-branch activations per position
-          const int c = pos * 4 + (p == 14 ? 3 : p / 4);
-          const float tv = tanh_fast(u[c >> 4][c & 15]);
-          u[c >> 4][c & 15] = tv;
-          Px1.st(vr, ((c >> 4) * 32 + rrow(c & 15)) * pN, tv);
+    for (int pp = 0; pp < kNP / 2; ++pp) {
+      float rv[24];  // relu(conv) of positions 2 pp, 2 pp + 1: registers 0..11 each
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int pos = 2 * pp + e;
+        f32x16 cv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cv[i] = L.T(hTbc + i * 2);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          Op16 x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {  // slots 2 q, 2 q + 1 of this k-block
+            const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
+            const unsigned r0 = ws[pos + s0 % 3][s0 / 3];
+            const unsigned r1 = s1 < 15 ? ws[pos + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
+            x.h[q] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);  // low half-words
+            x.l[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);  // high half-words
+          }
+          cv = mma3(L16.A(hA, nC + kb), x, cv);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {  // rows r(i) + 4 hi < 20 are real channels
+          float v = cv[i];
+          mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
+          v = fmaxf(v, 0.f);
+          // plane 64 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
+          Px1.st(i < 8 ? vc : vn_lo, (kW + rrow(i) * kNP + pos) * pN, v);
+          rv[e * 12 + i] = v;
         }
       }
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {  // rows r(i) + 4 hi < 20 are real channels
-        float v = cv[i];
-        mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
-        v = fmaxf(v, 0.f);
-        // plane 64 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
-        Px1.st(i < 8 ? vc : vn_lo, (kW + rrow(i) * kNP + pos) * pN, v);
-        a[0] = mfma(L.A(fA1c + ((0 * 8 + pos) * 12 + i) * 64), v, a[0]);
-        a[1] = mfma(L.A(fA1c + ((1 * 8 + pos) * 12 + i) * 64), v, a[1]);
+      for (int kb = 0; kb < 3; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = rv[kb * 8 + j];
+        const Op16 x = split8(v);
+        a[0] = mma3(L16.A(hA, n1c + (0 * 4 + pp) * 3 + kb), x, a[0]);
+        a[1] = mma3(L16.A(hA, n1c + (1 * 4 + pp) * 3 + kb), x, a[1]);
       }
     }
     // relu mask, trajectory-indexed: bit e = ch*8 + pos of word e >> 5
 #pragma unroll
     for (int g = 0; g < 3; ++g)
       Pmk.stu(g < 2 ? vm : vn_lo, 2 * g * pN, mbits[g]);
-    // fc1, state part
-    dense64(a, u, L, fA1s);
-    // h1 -> h2 -> h3 (tanh of a layer applied inside the next layer's loop)
-    init_bias(u, L, fTb2);
-    dense64_tanh(u, a, L, fA2, Ph, 0, vr, pN);
-    init_bias(a, L, fTb3);
-    dense64_tanh(a, u, L, fA3, Ph, kW, vr, pN);
+    // fc1 state part on s1 = tanh(states_in); h1 -> h2 -> h3 (the tanh of a
+    // layer is applied, and stored, where the next layer consumes it)
+    dense64_16(a, u, L16, hA, n1s, [&](int rb, int i, float v) {
+      const float tv = tanh_fast(v);
+      Px1.st(vr, (rb * 32 + rrow(i)) * pN, tv);
+      return tv;
+    });
+    init_bias(u, L, hTb2);
+    dense64_16(u, a, L16, hA, n2, [&](int rb, int i, float v) {
+      const float tv = tanh_fast(v);
+      Ph.st(vr, (rb * 32 + rrow(i)) * pN, tv);
+      return tv;
+    });
+    init_bias(a, L, hTb3);
+    dense64_16(a, u, L16, hA, n3, [&](int rb, int i, float v) {
+      const float tv = tanh_fast(v);
+      Ph.st(vr, (kW + rb * 32 + rrow(i)) * pN, tv);
+      return tv;
+    });
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -307,12 +421,12 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
       float z0 = 0.f, z1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        z0 = fmaf(L.T(fTo + ((j * 2 + 0) * 16 + i) * 2), a[0][i], z0);
-        z1 = fmaf(L.T(fTo + ((j * 2 + 1) * 16 + i) * 2), a[1][i], z1);
+        z0 = fmaf(L.T(hTo + ((j * 2 + 0) * 16 + i) * 2), a[0][i], z0);
+        z1 = fmaf(L.T(hTo + ((j * 2 + 1) * 16 + i) * 2), a[1][i], z1);
       }
       float z = z0 + z1;
       z += other_half(z);
-      act[j] = sigmoidf_(z + L.U(fBo + j));
+      act[j] = sigmoidf_(z + L.U(hBo + j));
       Pac.st(vb_lo, (k * 4 + j) * pB, act[j]);
     }
     quad_step(s, act, c, t);
@@ -802,16 +916,6 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
 // register-resident rollout and its adjoint (as quad.hip), then - second
 // kernel - the reverse pass of the network from dL/d(head pre-activations).
 // Planes are [feature][B]; the weight gradients come from apg_planes_gemm.
-constexpr int kNA = kH * 4;                       // head width (40)
-// Forward tables of the concurrent kernel (fp16 split operands, policy_mfma16.h).
-// Bias tables ([rb][16][2] floats, indexed by the half-wave) first, then 60
-// A-operand blocks of 2 KB: states_in [rb], conv [kb], fc1 conv part
-// [rb][position pair][kb], fc1 state part / fc2 / fc3 / head [rb][kb].
-constexpr int hTbs = 0, hTb1 = 64, hTb2 = 128, hTb3 = 192, hTbo = 256, hTbc = 320;  // floats
-constexpr int hA = 2048;                          // bytes: first A block
-constexpr int nS = 0, nC = 2, n1c = 4, n1s = 28, n2 = 36, n3 = 44, nO = 52, nBlocks16 = 60;
-constexpr int kCfLds = (hA + nBlocks16 * kBlock16) / 4;  // 31 232 floats = 124 928 B
-static_assert(hTbc + 32 <= hA / 4, "LDS map");
 // Reverse tables of the concurrent kernel: 50 transposed A-operand blocks
 // (policy_mfma16.h): head^T [rb][kb of 3], fc3^T, fc2^T, fc1^T state part
 // [rb][kb], fc1^T conv part [32-row block eb of 5][kb].
@@ -824,59 +928,6 @@ __host__ __device__ constexpr int khead(int c, int hi) {
   return (c < 16 ? rrow(c) : 32 + rrow(c - 16)) + 4 * hi;
 }
 
-// weight behind k-slot (kb, j, hi) of A block n, output row `row` (0..31 of
-// the block's row block) - the single definition of the forward k-orders
-__device__ __forceinline__ float cfwd_weight(const ApgMlpPolicy &p, int n, int row, int j,
-                                             int hi) {
-  if (n < nC) {                       // states_in: features 8 hi + j
-    const int k = 8 * hi + j;
-    return k < kNF ? p.w_s[((n - nS) * 32 + row) * kNF + k] : 0.f;
-  }
-  if (n < n1c) {                      // conv: slot s = (column j', tap), 15 of 16
-    const int s = (n - nC) * 8 + j, jc = s / 3, tap = s % 3, q = hi ? 4 + jc : jc;
-    return (s < 15 && row < kNC && (hi || jc < 4)) ? p.conv_w[row * 27 + q * 3 + tap] : 0.f;
-  }
-  if (n < n1s) {                      // fc1 on the conv outputs of a position pair
-    const int m = n - n1c, rb = m / 12, pp = (m / 3) % 4, kb = m % 3;
-    const int s = kb * 8 + j, pos = 2 * pp + s / 12, ch = rrow(s % 12) + 4 * hi;
-    return ch < kNC ? p.w_1[(rb * 32 + row) * kN1 + kW + ch * kNP + pos] : 0.f;
-  }
-  const int m = (n - n1s) % 8, rb = m / 4, kb = m % 4, k = kin(kb, j, hi);
-  const int out = rb * 32 + row;
-  if (n < n2) return p.w_1[out * kN1 + k];
-  if (n < n3) return p.w_2[out * kW + k];
-  if (n < nO) return p.w_3[out * kW + k];
-  return out < kNA ? p.w_out[out * kW + k] : 0.f;
-}
-
-__global__ __launch_bounds__(256) void mlp_pack_cfwd_kernel(PackArgs A) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
-  const ApgMlpPolicy &p = A.pol;
-  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
-  // one thread per (block, lane, word): two weights -> fp16 high / low terms
-  for (int idx = tid; idx < nBlocks16 * 64 * 4; idx += T) {
-    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
-    const float w0 = cfwd_weight(p, n, l & 31, 2 * q, l >> 5);
-    const float w1 = cfwd_weight(p, n, l & 31, 2 * q + 1, l >> 5);
-    unsigned h, lo;
-    split_pair(w0, w1, h, lo);
-    dst[(hA + n * kBlock16) / 4 + l * 4 + q] = h;
-    dst[(hA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
-  }
-  for (int idx = tid; idx < 64; idx += T) {
-    const int hi = idx & 1, i = (idx >> 1) & 15, rb = idx >> 5;
-    const int row = rb * 32 + rrow(i) + 4 * hi;
-    A.dst[hTbs + idx] = p.b_s[row];
-    A.dst[hTb1 + idx] = p.b_1[row];
-    A.dst[hTb2 + idx] = p.b_2[row];
-    A.dst[hTb3 + idx] = p.b_3[row];
-    A.dst[hTbo + idx] = row < kNA ? p.b_out[row] : 0.f;
-  }
-  for (int idx = tid; idx < 32; idx += T) {
-    const int hi = idx & 1, i = idx >> 1, ch = rrow(i) + 4 * hi;
-    A.dst[hTbc + idx] = ch < kNC ? p.conv_b[ch] : 0.f;
-  }
-}
 // weight behind k-slot (kb, j, hi) of transposed A block n, output row `row`
 __device__ __forceinline__ float cbwd_weight(const ApgMlpPolicy &p, int n, int row, int j,
                                              int hi) {
@@ -1260,7 +1311,11 @@ using namespace apg;
 
 extern "C" {
 
-int apg_quad_mlp_workspace_floats(void) { return kFwdLds > kBwdLds ? kFwdLds : kBwdLds; }
+int apg_quad_mlp_workspace_floats(void) {
+  int n = kFwdLds > kBwdLds ? kFwdLds : kBwdLds;
+  n = n > kCfLds ? n : kCfLds;
+  return n > kCbLds ? n : kCbLds;
+}
 
 int apg_quad_mlp_loss_partials_count(int B) {
   return B <= 0 ? 0 : ((B + kTrajPerBlock - 1) / kTrajPerBlock) * (kThreads / kWave);
@@ -1281,7 +1336,7 @@ int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
   }
   static bool attr = false;
   if (!attr) {
-    if (int e = raise_lds(mlp_rollout_fwd_kernel, kFwdLds)) return e;
+    if (int e = raise_lds(mlp_rollout_fwd_kernel, kCfLds)) return e;
     attr = true;
   }
   FwdArgs A;
@@ -1291,12 +1346,12 @@ int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
   A.c = make_const(*params, dt);
   A.B = B;
   PackArgs P;
-  P.pol = *policy, P.dst = workspace;
-  hipLaunchKernelGGL(mlp_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256),
+  P.pol = *policy, P.dst = workspace, P.head_rows = 4;
+  hipLaunchKernelGGL(mlp_pack_cfwd_kernel, dim3((kCfLds + 255) / 256), dim3(256),
                      0, (hipStream_t)stream, P);
   hipLaunchKernelGGL(mlp_rollout_fwd_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock),
-                     dim3(kThreads), kFwdLds * sizeof(float), (hipStream_t)stream,
+                     dim3(kThreads), kCfLds * sizeof(float), (hipStream_t)stream,
                      A);
   return check_launch("quad_mlp_rollout_fwd");
 }
@@ -1342,7 +1397,7 @@ int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
   A.c = make_const(*params, dt);
   A.w = *weights;
   PackArgs P;
-  P.pol = *policy, P.dst = workspace;
+  P.pol = *policy, P.dst = workspace, P.head_rows = 4;
   hipLaunchKernelGGL(mlp_pack_bwd_kernel, dim3((kBwdLds + 255) / 256), dim3(256),
                      0, st, P);
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
@@ -1393,7 +1448,7 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
   A.B = B, A.L = L, A.T = T, A.test_time = test_time;
   A.thresh_div = thresh_div, A.thresh_stable = thresh_stable;
   PackArgs P;
-  P.pol = *policy, P.dst = workspace;
+  P.pol = *policy, P.dst = workspace, P.head_rows = 4;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(mlp_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256),
                      0, st, P);
@@ -1446,7 +1501,7 @@ int apg_quad_mlp_concurrent_fwd_bwd(
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
   PackArgs P;
-  P.pol = *policy, P.dst = workspace;
+  P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   hipLaunchKernelGGL(mlp_pack_cfwd_kernel, dim3((kCfLds + 255) / 256), dim3(256),
                      0, st, P);
