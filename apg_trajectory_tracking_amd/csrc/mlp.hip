@@ -15,7 +15,12 @@
 //   h2 = tanh(W_2 h1 + b_2),  h3 = tanh(W_3 h2 + b_3)
 //   a  = sigmoid(W_o h3 + b_o)                     64 -> 4
 // ~28 k FMA per env-step: this IS GEMM-shaped, with the batch as the N
-// dimension, so the layers run on v_mfma_f32_32x32x2_f32 (exact fp32).
+// dimension, so the layers run on the matrix cores.  Since round 3 the
+// TRAINING kernels (both sweeps, both concurrent-mode kernels) use
+// v_mfma_f32_32x32x16_f16 on operands split into two fp16 terms - three
+// products per k-block, as exact as the fp32 instruction and 2.6 x faster
+// per layer (policy_mfma16.h); the closed-loop evaluation kernel keeps
+// v_mfma_f32_32x32x2_f32 and the fp32 tables (pack_forward).
 //
 // Mapping.  A wave owns 32 trajectories: lane l works for trajectory l & 31,
 // both half-waves carry the same state / window registers (the ~600-op
@@ -619,48 +624,66 @@ __global__ __launch_bounds__(kThreads) void mlp_closed_loop_kernel(LoopArgs A) {
 }
 
 // ------------------------------------------------------------ reverse sweep
-constexpr int rTo = 0;                    // [4][2][16][2]
-constexpr int rAq = rTo + 256;            // [20][3] sum over taps of conv_w
-constexpr int rA3 = 320;                  // [2][32][64]  fc3^T
-constexpr int rA2 = rA3 + 2 * 32 * 64;    // [2][32][64]  fc2^T
-constexpr int rA1s = rA2 + 2 * 32 * 64;   // [2][32][64]  fc1^T, state inputs
-constexpr int rA1c = rA1s + 2 * 32 * 64;  // [5][32][64]  fc1^T, conv inputs
-constexpr int rAs = rA1c + 5 * 32 * 64;   // [32][64]     states_in^T
-constexpr int kBwdLds = rAs + 32 * 64;    // 24 896 floats = 99 584 B
-static_assert(rAq + kNC * 3 <= rA3, "LDS map");
+// Reverse tables of the training kernels (fp16 split operands,
+// policy_mfma16.h): the autoregressive sweep's small fp32 tables first (head
+// weights for the VALU [4][2][16][2], tap sums of the conv weights [20][3]),
+// then 54 transposed A-operand blocks of 2 KB: the concurrent mode's head^T
+// [rb][kb of 3], fc3^T, fc2^T, fc1^T state part [rb][kb], fc1^T conv part
+// [32-row block eb of 5][kb], states_in^T [kb].
+constexpr int gTo = 0, gAq = 256;                 // floats
+constexpr int gA = 2048;                          // bytes: first A block
+constexpr int mOT = 0, m3T = 6, m2T = 14, m1sT = 22, m1cT = 30, mST = 50, mBlocks16 = 54;
+constexpr int kCbLds = (gA + mBlocks16 * kBlock16) / 4;  // 28 160 floats = 112 640 B
+static_assert(gAq + kNC * 3 <= gA / 4, "LDS map");
+// k index of head-output k-pair c of the concurrent mode (accumulator layout of
+// the 40 outputs: row block 0 registers 0..15, row block 1 registers 0..3)
+__host__ __device__ constexpr int khead(int c, int hi) {
+  return (c < 16 ? rrow(c) : 32 + rrow(c - 16)) + 4 * hi;
+}
 
-__device__ __forceinline__ void pack_reverse(float *lds, const ApgMlpPolicy &p,
-                                             int tid, int T, bool head4 = true) {
-  (void)head4;
-  for (int idx = tid; idx < 2 * 32 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) & 31, rb = idx >> 11;
-    const int m = rb * 32 + (l & 31), k = kchain(c, l >> 5);
-    lds[rA3 + idx] = p.w_3[k * kW + m];
-    lds[rA2 + idx] = p.w_2[k * kW + m];
-    lds[rA1s + idx] = p.w_1[k * kN1 + m];
+// weight behind k-slot (kb, j, hi) of transposed A block n, output row `row`
+__device__ __forceinline__ float cbwd_weight(const ApgMlpPolicy &p, int n, int row, int j,
+                                             int hi, int head_rows) {
+  if (n < m3T) {                      // head^T: slots = this lane's 20 dL/dz rows
+    const int rb = n / 3, cc = (n % 3) * 8 + j;
+    return (cc < 20 && khead(cc, hi) < head_rows) ? p.w_out[khead(cc, hi) * kW + rb * 32 + row]
+                                                  : 0.f;
   }
-  for (int idx = tid; idx < 5 * 32 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) & 31, eb = idx >> 11;
-    lds[rA1c + idx] = p.w_1[kchain(c, l >> 5) * kN1 + kW + eb * 32 + (l & 31)];
+  if (n < m1cT) {
+    const int m = (n - m3T) % 8, rb = m / 4, k = kin(m % 4, j, hi), out = rb * 32 + row;
+    if (n < m2T) return p.w_3[k * kW + out];
+    if (n < m1sT) return p.w_2[k * kW + out];
+    return p.w_1[k * kN1 + out];
   }
-  for (int idx = tid; idx < 32 * 64; idx += T) {
-    const int l = idx & 63, c = idx >> 6, m = l & 31;
-    lds[rAs + idx] = m < kNF ? p.w_s[kchain(c, l >> 5) * kNF + m] : 0.f;
+  if (n < mST) {
+    const int m = n - m1cT, eb = m / 4, k = kin(m % 4, j, hi);
+    return p.w_1[k * kN1 + kW + eb * 32 + row];
   }
-  for (int idx = tid; idx < 256; idx += T) {
+  return row < kNF ? p.w_s[kin(n - mST, j, hi) * kNF + row] : 0.f;  // states_in^T
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_cbwd_kernel(PackArgs A) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    const float w0 = cbwd_weight(A.pol, n, l & 31, 2 * q, l >> 5, A.head_rows);
+    const float w1 = cbwd_weight(A.pol, n, l & 31, 2 * q + 1, l >> 5, A.head_rows);
+    unsigned h, lo;
+    split_pair(w0, w1, h, lo);
+    dst[(gA + n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(gA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
+  }
+  const ApgMlpPolicy &p = A.pol;
+  for (int idx = tid; idx < 256; idx += T) {   // first four head rows, VALU order
     const int hi = idx & 1, i = (idx >> 1) & 15, rb = (idx >> 5) & 1, j = idx >> 6;
-    lds[rTo + idx] = p.w_out[j * kW + rb * 32 + rrow(i) + 4 * hi];
+    A.dst[gTo + idx] = p.w_out[j * kW + rb * 32 + rrow(i) + 4 * hi];
   }
   for (int idx = tid; idx < kNC * 3; idx += T) {
     const int ch = idx / 3, q = idx % 3;
-    lds[rAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
-                     p.conv_w[ch * 27 + q * 3 + 2];
+    A.dst[gAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
+                       p.conv_w[ch * 27 + q * 3 + 2];
   }
-}
-
-__global__ __launch_bounds__(256) void mlp_pack_bwd_kernel(PackArgs A) {
-  pack_reverse(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
-               gridDim.x * blockDim.x);
 }
 
 struct BwdArgs {
@@ -671,7 +694,7 @@ struct BwdArgs {
   float *d_zout;  // [4][N]
   float *d_conv;  // [720][B]: window-diagonal sums of the conv cotangents (kConvP)
   float *grad_state0;
-  const float *tables;  // packed operand tables (mlp_pack_bwd_kernel)
+  const float *tables;  // packed operand tables (mlp_pack_cbwd_kernel)
   QuadConst c;
   ApgQuadLossWeights w;
   int B, ref_cols, vel_col;
@@ -722,7 +745,8 @@ __device__ __forceinline__ void tanh_adjoint(f32x16 (&v)[2], const float (&hv)[2
 
 __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kBwdLds);
+  fill_lds(lds, A.tables, kCbLds);
+  const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -817,37 +841,48 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
         float v = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          v = fmaf(L.T(rTo + ((j * 2 + rb) * 16 + i) * 2), dz[j], v);
+          v = fmaf(L.T(gTo + ((j * 2 + rb) * 16 + i) * 2), dz[j], v);
         d[rb][i] = v;
       }
     __builtin_amdgcn_sched_barrier(0);
+    // the reverse layers on the 16-bit matrix pipe (policy_mfma16.h):
+    // cotangents scaled per trajectory, two fp16 terms, three products
     tanh_adjoint(d, hv, Pdp, 2 * kW, vr, pN);  // d_pre3
     load_acts(hv, Ph, kW, vr, pN);             // h2, lands under the product
     __builtin_amdgcn_sched_barrier(0);
+    Op16 x[4];
     zero(e);
-    dense64(e, d, L, rA3);
+    int ex = scaled_split64(d, x);
+    dense64T_16(e, x, L16, gA, m3T);
     __builtin_amdgcn_sched_barrier(0);
-    tanh_adjoint(e, hv, Pdp, kW, vr, pN);      // d_pre2
+    tanh_adjoint(e, hv, Pdp, kW, vr, pN, ex);  // d_pre2
     load_acts(hv, Ph, 0, vr, pN);              // h1
     __builtin_amdgcn_sched_barrier(0);
     zero(d);
-    dense64(d, e, L, rA2);
+    ex = scaled_split64(e, x);
+    dense64T_16(d, x, L16, gA, m2T);
     __builtin_amdgcn_sched_barrier(0);
-    tanh_adjoint(d, hv, Pdp, 0, vr, pN);       // d_pre1
+    tanh_adjoint(d, hv, Pdp, 0, vr, pN, ex);   // d_pre1
     load_acts(hv, Px1, 0, vr, pN);             // s1
     __builtin_amdgcn_sched_barrier(0);
-    // fc1 inputs, state branch
+    // fc1 inputs, state branch; d_pre1's split also feeds the conv part below
     zero(e);
-    dense64(e, d, L, rA1s);
+    const int ex1 = scaled_split64(d, x);
+    dense64T_16(e, x, L16, gA, m1sT);
     __builtin_amdgcn_sched_barrier(0);
-    tanh_adjoint(e, hv, Pdp, 3 * kW, vr, pN);  // d_pre_s
+    tanh_adjoint(e, hv, Pdp, 3 * kW, vr, pN, ex1);  // d_pre_s
     // features: one 32-row block (15 real rows), then both halves need all
     f32x16 f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) f[i] = 0.f;
+    {
+      Op16 xs[4];
+      const int exs = scaled_split64(e, xs);
 #pragma unroll
-    for (int cc = 0; cc < 32; ++cc)
-      f = mfma(L.A(rAs + cc * 64), e[cc >> 4][cc & 15], f);
+      for (int kb = 0; kb < 4; ++kb) f = mma3(L16.A(gA, mST + kb), xs[kb], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_ldexpf(f[i], exs);
+    }
     float dfeat[kNF], gs[12];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -866,8 +901,9 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) y[i] = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < 32; ++cc)
-        y = mfma(L.A(rA1c + (eb * 32 + cc) * 64), d[cc >> 4][cc & 15], y);
+      for (int kb = 0; kb < 4; ++kb) y = mma3(L16.A(gA, m1cT + eb * 4 + kb), x[kb], y);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y[i] = __builtin_amdgcn_ldexpf(y[i], ex1);
       const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];  // bit r(i) + 4 hi -> bit r(i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g,
@@ -887,7 +923,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
         Pdc.st(vb_lo, (unsigned)(kConvP + ch * kH + k) * pB, sum + other_half(sum));
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-          dpos[q] = fmaf(L.U(rAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
+          dpos[q] = fmaf(L.U(gAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
       }
     }
 #pragma unroll
@@ -916,48 +952,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_kernel(BwdArgs A) {
 // register-resident rollout and its adjoint (as quad.hip), then - second
 // kernel - the reverse pass of the network from dL/d(head pre-activations).
 // Planes are [feature][B]; the weight gradients come from apg_planes_gemm.
-// Reverse tables of the concurrent kernel: 50 transposed A-operand blocks
-// (policy_mfma16.h): head^T [rb][kb of 3], fc3^T, fc2^T, fc1^T state part
-// [rb][kb], fc1^T conv part [32-row block eb of 5][kb].
-constexpr int mOT = 0, m3T = 6, m2T = 14, m1sT = 22, m1cT = 30, mBlocks16 = 50;
-constexpr int kCbLds = mBlocks16 * kBlock16 / 4;  // 25 600 floats = 102 400 B
 
-// k index of head-output k-pair c (accumulator layout of the 40 outputs:
-// row block 0 registers 0..15, row block 1 registers 0..3)
-__host__ __device__ constexpr int khead(int c, int hi) {
-  return (c < 16 ? rrow(c) : 32 + rrow(c - 16)) + 4 * hi;
-}
-
-// weight behind k-slot (kb, j, hi) of transposed A block n, output row `row`
-__device__ __forceinline__ float cbwd_weight(const ApgMlpPolicy &p, int n, int row, int j,
-                                             int hi) {
-  if (n < m3T) {                      // head^T: slots = this lane's 20 dL/dz rows
-    const int rb = n / 3, cc = (n % 3) * 8 + j;
-    return cc < 20 ? p.w_out[khead(cc, hi) * kW + rb * 32 + row] : 0.f;
-  }
-  if (n < m1cT) {
-    const int m = (n - m3T) % 8, rb = m / 4, k = kin(m % 4, j, hi), out = rb * 32 + row;
-    if (n < m2T) return p.w_3[k * kW + out];
-    if (n < m1sT) return p.w_2[k * kW + out];
-    return p.w_1[k * kN1 + out];
-  }
-  const int m = n - m1cT, eb = m / 4, k = kin(m % 4, j, hi);
-  return p.w_1[k * kN1 + kW + eb * 32 + row];
-}
-
-__global__ __launch_bounds__(256) void mlp_pack_cbwd_kernel(PackArgs A) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
-  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
-  for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
-    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
-    const float w0 = cbwd_weight(A.pol, n, l & 31, 2 * q, l >> 5);
-    const float w1 = cbwd_weight(A.pol, n, l & 31, 2 * q + 1, l >> 5);
-    unsigned h, lo;
-    split_pair(w0, w1, h, lo);
-    dst[(n * kBlock16) / 4 + l * 4 + q] = h;
-    dst[(n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
-  }
-}
 
 struct ConcArgs {
   const float *feat, *in_ref, *state0, *ref;  // [15][B], [H][9][B], [12][B], [H][C][B]
@@ -1229,8 +1224,8 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A
         v[j] = kb * 8 + j < 20 ? __builtin_amdgcn_ldexpf(dzr[kb * 8 + j < 20 ? kb * 8 + j : 0], -ex)
                                : 0.f;
       const Op16 x = split8(v);
-      d[0] = mma3(L16.A(0, mOT + kb), x, d[0]);
-      d[1] = mma3(L16.A(0, mOT + 3 + kb), x, d[1]);
+      d[0] = mma3(L16.A(gA, mOT + kb), x, d[0]);
+      d[1] = mma3(L16.A(gA, mOT + 3 + kb), x, d[1]);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -1240,21 +1235,21 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A
   Op16 x[4];
   zero(e);
   ex = scaled_split64(d, x);
-  dense64T_16(e, x, L16, 0, m3T);
+  dense64T_16(e, x, L16, gA, m3T);
   __builtin_amdgcn_sched_barrier(0);
   tanh_adjoint(e, hv, Pdp, kW, vr, pN, ex);      // d_pre2
   load_acts(hv, Ph, 0, vr, pN);                  // h1
   __builtin_amdgcn_sched_barrier(0);
   zero(d);
   ex = scaled_split64(e, x);
-  dense64T_16(d, x, L16, 0, m2T);
+  dense64T_16(d, x, L16, gA, m2T);
   __builtin_amdgcn_sched_barrier(0);
   tanh_adjoint(d, hv, Pdp, 0, vr, pN, ex);       // d_pre1
   load_acts(hv, Px1, 0, vr, pN);                 // s1
   __builtin_amdgcn_sched_barrier(0);
   zero(e);
   ex = scaled_split64(d, x);                     // d_pre1 feeds both fc1^T parts
-  dense64T_16(e, x, L16, 0, m1sT);
+  dense64T_16(e, x, L16, gA, m1sT);
   __builtin_amdgcn_sched_barrier(0);
   tanh_adjoint(e, hv, Pdp, 3 * kW, vr, pN, ex);  // d_pre_s
   // conv outputs (the network inputs carry no gradient in this mode)
@@ -1264,7 +1259,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A
 #pragma unroll
     for (int i = 0; i < 16; ++i) y[i] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) y = mma3(L16.A(0, m1cT + eb * 4 + kb), x[kb], y);
+    for (int kb = 0; kb < 4; ++kb) y = mma3(L16.A(gA, m1cT + eb * 4 + kb), x[kb], y);
     const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -1312,8 +1307,7 @@ using namespace apg;
 extern "C" {
 
 int apg_quad_mlp_workspace_floats(void) {
-  int n = kFwdLds > kBwdLds ? kFwdLds : kBwdLds;
-  n = n > kCfLds ? n : kCfLds;
+  int n = kFwdLds > kCfLds ? kFwdLds : kCfLds;
   return n > kCbLds ? n : kCbLds;
 }
 
@@ -1385,7 +1379,7 @@ int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
   }
   static bool attr = false;
   if (!attr) {
-    if (int e = raise_lds(mlp_rollout_bwd_kernel, kBwdLds)) return e;
+    if (int e = raise_lds(mlp_rollout_bwd_kernel, kCbLds)) return e;
     attr = true;
   }
   BwdArgs A;
@@ -1398,12 +1392,12 @@ int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
   A.w = *weights;
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = 4;
-  hipLaunchKernelGGL(mlp_pack_bwd_kernel, dim3((kBwdLds + 255) / 256), dim3(256),
+  hipLaunchKernelGGL(mlp_pack_cbwd_kernel, dim3((kCbLds + 255) / 256), dim3(256),
                      0, st, P);
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   hipLaunchKernelGGL(mlp_rollout_bwd_kernel, dim3(blocks), dim3(kThreads),
-                     kBwdLds * sizeof(float), st, A);
+                     kCbLds * sizeof(float), st, A);
   if (int e = check_launch("quad_mlp_rollout_bwd")) return e;
   if (loss)
     return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave),
