@@ -30,6 +30,7 @@
 // saved inputs, all as [feature][H*B] planes; apg_planes_gemm reduces them.
 #include "apg_device.h"
 #include "policy_mfma.h"
+#include "policy_mfma16.h"
 #include "quad_math.h"
 
 namespace apg {
@@ -118,6 +119,56 @@ __global__ __launch_bounds__(256) void lstm_pack_fwd_kernel(PackArgs A) {
                gridDim.x * blockDim.x);
 }
 
+// Forward tables of the TRAINING sweep (fp16 split operands, policy_mfma16.h;
+// the closed-loop kernel keeps the fp32 tables above): the small fp32 tables
+// (same content as fTo / fTbg / fTbc / fBo), then 16 A-operand blocks of 2 KB:
+// W_ih on the features, W_hh, conv [kb], W_ih on the conv outputs of a
+// position pair [pp][kb].
+constexpr int hTo = 0, hTbg = 32, hTbc = 64, hBo = 96;   // floats
+constexpr int hA = 512;                                  // bytes: first A block
+constexpr int nF = 0, nH = 1, nC = 2, nG = 4, nBlocks16 = 16;
+constexpr int kFwd16Lds = (hA + nBlocks16 * kBlock16) / 4;  // 8 320 floats = 33 280 B
+
+// weight behind k-slot j (of 8) of A block n for half-wave hi, gate row `row`
+__device__ __forceinline__ float fwd16_weight(const ApgLstmPolicy &p, int n, int row, int j,
+                                              int hi) {
+  if (n == nF) {                       // features 8 hi + j
+    const int k = 8 * hi + j;
+    return k < kNF ? p.w_ih[row * kNX + k] : 0.f;
+  }
+  if (n == nH)                         // hidden units j + 4 hi, 4 of the 8 slots
+    return j < 4 ? p.w_hh[row * kNH + j + 4 * hi] : 0.f;
+  if (n < nG) {                        // conv: slot s = (column j', tap), 15 of 16
+    const int sl = (n - nC) * 8 + j, jc = sl / 3, tap = sl % 3, q = hi ? 4 + jc : jc;
+    return (sl < 15 && row < kNC && (hi || jc < 4)) ? p.conv_w[row * 27 + q * 3 + tap] : 0.f;
+  }
+  const int m = n - nG, pp = m / 3, sl = (m % 3) * 8 + j;
+  const int pos = 2 * pp + sl / 12, ch = rrow(sl % 12) + 4 * hi;
+  return ch < kNC ? p.w_ih[row * kNX + kNF + ch * kNP + pos] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void lstm_pack_fwd16_kernel(PackArgs A) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+  const ApgLstmPolicy &p = A.pol;
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  for (int idx = tid; idx < nBlocks16 * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    unsigned h, lo;
+    split_pair(fwd16_weight(p, n, l & 31, 2 * q, l >> 5),
+               fwd16_weight(p, n, l & 31, 2 * q + 1, l >> 5), h, lo);
+    dst[(hA + n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(hA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
+  }
+  for (int idx = tid; idx < 32; idx += T) {
+    const int hi = idx & 1, r = (idx >> 1) & 3, j = idx >> 3;
+    A.dst[hTo + idx] = p.w_out[j * kNH + r + 4 * hi];
+    const int i = idx >> 1, row = rrow(i) + 4 * hi;
+    A.dst[hTbg + idx] = p.b_ih[row] + p.b_hh[row];
+    A.dst[hTbc + idx] = row < kNC ? p.conv_b[row] : 0.f;
+  }
+  for (int idx = tid; idx < 4; idx += T) A.dst[hBo + idx] = p.b_out[idx];
+}
+
 struct FwdArgs {
   const float *state0, *in_ref, *h0, *c0;
   float *states, *actions, *x, *gates, *hc, *hnew;
@@ -129,7 +180,8 @@ struct FwdArgs {
 
 __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwdLds);
+  fill_lds(lds, A.tables, kFwd16Lds);
+  const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -183,46 +235,74 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
       Phc.st(vr, r * pN, h[r]);
       Phc.st(vr, (kNH + r) * pN, cell[r]);
     }
-    // gates: two accumulators (even / odd k-pairs) keep the MFMAs independent
+    // gates on the 16-bit matrix pipe (policy_mfma16.h): every operand as two
+    // fp16 terms, three products per k-block; two accumulators keep the
+    // matrix instructions of neighbouring blocks independent
     f32x16 g0, g1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) g0[i] = L.T(fTbg + i * 2), g1[i] = 0.f;
+    for (int i = 0; i < 16; ++i) g0[i] = L.T(hTbg + i * 2), g1[i] = 0.f;
+    {
+      float v[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
-      const float bv = hi ? odd : feat[2 * p];
-      if (p & 1) g1 = mfma(L.A(fAf + p * 64), bv, g1);
-      else g0 = mfma(L.A(fAf + p * 64), bv, g0);
+      for (int j = 0; j < 8; ++j)
+        v[j] = hi ? (8 + j < kNF ? feat[8 + j < kNF ? 8 + j : 0] : 0.f) : feat[j];
+      g0 = mma3(L16.A(hA, nF), split8(v), g0);
+      const float vh[8] = {h[0], h[1], h[2], h[3], 0.f, 0.f, 0.f, 0.f};
+      g1 = mma3(L16.A(hA, nH), split8(vh), g1);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (r & 1) g1 = mfma(L.A(fAh + r * 64), h[r], g1);
-      else g0 = mfma(L.A(fAh + r * 64), h[r], g0);
-    }
-    // conv (one 32-row block per window position) feeding the gates directly
+    // conv (one 32-row block per window position) feeding the gates; the
+    // window relative to the current position is split once per step
     unsigned mbits[3] = {0u, 0u, 0u};
     const float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
+    unsigned ws[kH][5];
 #pragma unroll
-    for (int pos = 0; pos < kNP; ++pos) {
-      f32x16 cv, cw;
+    for (int r = 0; r < kH; ++r)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2), cw[i] = 0.f;
-#pragma unroll
-      for (int p = 0; p < 15; ++p) {
-        const int j = p / 3, tap = p % 3;
-        const float xv = j < 3 ? w[pos + tap][j] - sub[j] : w[pos + tap][j];
-        if (p & 1) cw = mfma(L.A(fAc + p * 64), xv, cw);
-        else cv = mfma(L.A(fAc + p * 64), xv, cv);
+      for (int j = 0; j < 5; ++j) {
+        const float xv = j < 3 ? w[r][j] - sub[j] : w[r][j];
+        const _Float16 vh = (_Float16)xv, vl = (_Float16)(xv - (float)vh);
+        const h16x2 pr = {vh, vl};
+        ws[r][j] = __builtin_bit_cast(unsigned, pr);
       }
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {  // rows r(i) + 4 hi < 20 are real channels
-        float v = cv[i] + cw[i];
-        mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
-        v = fmaxf(v, 0.f);
-        // plane 15 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
-        Px.st(i < 8 ? vc : vn_lo, (kNF + rrow(i) * kNP + pos) * pN, v);
-        if (i & 1) g1 = mfma(L.A(fAg + (pos * 12 + i) * 64), v, g1);
-        else g0 = mfma(L.A(fAg + (pos * 12 + i) * 64), v, g0);
+    for (int pp = 0; pp < kNP / 2; ++pp) {
+      float rv[24];  // relu(conv) of positions 2 pp, 2 pp + 1: registers 0..11 each
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int pos = 2 * pp + e;
+        f32x16 cv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cv[i] = L.T(hTbc + i * 2);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          Op16 x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
+            const unsigned r0 = ws[pos + s0 % 3][s0 / 3];
+            const unsigned r1 = s1 < 15 ? ws[pos + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
+            x.h[q] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);  // low half-words
+            x.l[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);  // high half-words
+          }
+          cv = mma3(L16.A(hA, nC + kb), x, cv);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {  // rows r(i) + 4 hi < 20 are real channels
+          float v = cv[i];
+          mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
+          v = fmaxf(v, 0.f);
+          // plane 15 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
+          Px.st(i < 8 ? vc : vn_lo, (kNF + rrow(i) * kNP + pos) * pN, v);
+          rv[e * 12 + i] = v;
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 3; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = rv[kb * 8 + j];
+        if (kb & 1) g1 = mma3(L16.A(hA, nG + pp * 3 + kb), split8(v), g1);
+        else g0 = mma3(L16.A(hA, nG + pp * 3 + kb), split8(v), g0);
       }
     }
     // relu mask, trajectory-indexed: bit e = ch*8 + pos of word e >> 5
@@ -249,9 +329,9 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
     for (int j = 0; j < 4; ++j) {
       float z = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) z = fmaf(L.T(fTo + (j * 4 + r) * 2), h[r], z);
+      for (int r = 0; r < 4; ++r) z = fmaf(L.T(hTo + (j * 4 + r) * 2), h[r], z);
       z += other_half(z);
-      act[j] = sigmoidf_(z + L.U(fBo + j));
+      act[j] = sigmoidf_(z + L.U(hBo + j));
       Pac.st(vb_lo, (k * 4 + j) * pB, act[j]);
     }
     quad_step(s, act, c, t);
@@ -442,37 +522,46 @@ __global__ __launch_bounds__(kThreads) void lstm_closed_loop_kernel(LoopArgs A) 
 }
 
 // ------------------------------------------------------------ reverse sweep
-constexpr int rTo = 0;               // [4 j][4 r][2]
-constexpr int rAq = rTo + 32;        // [20][3] sum over taps of conv_w
-constexpr int rAf = 128;             // [16][64]     W_ih^T, feature rows
-constexpr int rAh = rAf + 16 * 64;   // [16][64]     W_hh^T
-constexpr int rAc = rAh + 16 * 64;   // [5][16][64]  W_ih^T, conv rows
-constexpr int kBwdLds = rAc + 5 * 16 * 64;  // 7 296 floats
+// Reverse tables of the training sweep (fp16 split operands): the small fp32
+// tables (rTo, rAq content), then 14 transposed A-operand blocks: W_hh^T [kb],
+// W_ih^T feature rows [kb], W_ih^T conv rows [32-row block eb of 5][kb]; the
+// k-slots are the 32 gate rows in accumulator order (k-block kb = registers
+// 8 kb .. 8 kb + 7: row rrow(8 kb + j) + 4 hi).
+constexpr int gTo = 0, gAq = 32;                         // floats
+constexpr int gA = 512;                                  // bytes
+constexpr int mH = 0, mF = 2, mC = 4, mBlocks16 = 14;
+constexpr int kBwd16Lds = (gA + mBlocks16 * kBlock16) / 4;  // 7 296 floats = 29 184 B
+static_assert(gAq + kNC * 3 <= gA / 4, "LDS map");
 
-__device__ __forceinline__ void pack_reverse(float *dst, const ApgLstmPolicy &p,
-                                             int tid, int T) {
-  for (int idx = tid; idx < 16 * 64; idx += T) {
-    const int l = idx & 63, cc = idx >> 6, m = l & 31, k = kchain(cc, l >> 5);
-    dst[rAf + idx] = m < kNF ? p.w_ih[k * kNX + m] : 0.f;
-    dst[rAh + idx] = m < kNH ? p.w_hh[k * kNH + m] : 0.f;
-  }
-  for (int idx = tid; idx < 5 * 16 * 64; idx += T) {
-    const int l = idx & 63, cc = (idx >> 6) & 15, eb = idx >> 10;
-    dst[rAc + idx] = p.w_ih[kchain(cc, l >> 5) * kNX + kNF + eb * 32 + (l & 31)];
+__device__ __forceinline__ float bwd16_weight(const ApgLstmPolicy &p, int n, int row, int j,
+                                              int hi) {
+  const int kb = n & 1, k = rrow(8 * kb + j) + 4 * hi;   // gate row of this slot
+  if (n < mF) return row < kNH ? p.w_hh[k * kNH + row] : 0.f;
+  if (n < mC) return row < kNF ? p.w_ih[k * kNX + row] : 0.f;
+  return p.w_ih[k * kNX + kNF + ((n - mC) >> 1) * 32 + row];
+}
+
+__global__ __launch_bounds__(256) void lstm_pack_bwd16_kernel(PackArgs A) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+  const ApgLstmPolicy &p = A.pol;
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    unsigned h, lo;
+    split_pair(bwd16_weight(p, n, l & 31, 2 * q, l >> 5),
+               bwd16_weight(p, n, l & 31, 2 * q + 1, l >> 5), h, lo);
+    dst[(gA + n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(gA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
   }
   for (int idx = tid; idx < 32; idx += T) {
     const int hi = idx & 1, r = (idx >> 1) & 3, j = idx >> 3;
-    dst[rTo + idx] = p.w_out[j * kNH + r + 4 * hi];
+    A.dst[gTo + idx] = p.w_out[j * kNH + r + 4 * hi];
   }
   for (int idx = tid; idx < kNC * 3; idx += T) {
     const int ch = idx / 3, q = idx % 3;
-    dst[rAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
-                     p.conv_w[ch * 27 + q * 3 + 2];
+    A.dst[gAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
+                       p.conv_w[ch * 27 + q * 3 + 2];
   }
-}
-__global__ __launch_bounds__(256) void lstm_pack_bwd_kernel(PackArgs A) {
-  pack_reverse(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
-               gridDim.x * blockDim.x);
 }
 
 struct BwdArgs {
@@ -493,7 +582,8 @@ struct BwdArgs {
 
 __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kBwdLds);
+  fill_lds(lds, A.tables, kBwd16Lds);
+  const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -594,7 +684,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
       const float tc = tanh_fast(fmaf(gf, cp[r], gi * gg));
       float dht = dh[r];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dht = fmaf(L.T(rTo + (j * 4 + r) * 2), dz[j], dht);
+      for (int j = 0; j < 4; ++j) dht = fmaf(L.T(gTo + (j * 4 + r) * 2), dz[j], dht);
       const float dct = dc[r] + dht * go * (1.f - tc * tc);
       dG[r] = dct * gg * gi * (1.f - gi);
       dG[4 + r] = dct * cp[r] * gf * (1.f - gf);
@@ -605,13 +695,35 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) Pdg.st(vr, ((i >> 2) * kNH + (i & 3)) * pN, dG[i]);
     // dL/dh_prev = W_hh^T dG and dL/dfeatures = W_ih[:, :15]^T dG
+    // (16-bit matrix pipe, policy_mfma16.h: the gate cotangents scaled per
+    // trajectory, two fp16 terms, three products per k-block)
+    Op16 xg[2];
+    int ex;
+    {
+      float amax = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(dG[i]));
+      ex = scale_exponent(amax);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_ldexpf(dG[8 * kb + j], -ex);
+        xg[kb] = split8(v);
+      }
+    }
     f32x16 yh, yf;
 #pragma unroll
     for (int i = 0; i < 16; ++i) yh[i] = 0.f, yf[i] = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      yh = mfma(L.A(rAh + cc * 64), dG[cc], yh);
-      yf = mfma(L.A(rAf + cc * 64), dG[cc], yf);
+    for (int kb = 0; kb < 2; ++kb) {
+      yh = mma3(L16.A(gA, mH + kb), xg[kb], yh);
+      yf = mma3(L16.A(gA, mF + kb), xg[kb], yf);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      yh[i] = __builtin_amdgcn_ldexpf(yh[i], ex);
+      yf[i] = __builtin_amdgcn_ldexpf(yf[i], ex);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) dh[r] = yh[r];  // rows r + 4 hi = the lane's units
@@ -630,14 +742,13 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
     float dpos[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int eb = 0; eb < 5; ++eb) {
-      f32x16 y0, y1;
+      f32x16 y0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) y0[i] = 0.f, y1[i] = 0.f;
+      for (int i = 0; i < 16; ++i) y0[i] = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < 16; cc += 2) {
-        y0 = mfma(L.A(rAc + (eb * 16 + cc) * 64), dG[cc], y0);
-        y1 = mfma(L.A(rAc + (eb * 16 + cc + 1) * 64), dG[cc + 1], y1);
-      }
+      for (int kb = 0; kb < 2; ++kb) y0 = mma3(L16.A(gA, mC + eb * 2 + kb), xg[kb], y0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y0[i] = __builtin_amdgcn_ldexpf(y0[i], ex);
       const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];  // bit r(i) + 4 hi -> bit r(i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g,
@@ -646,7 +757,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = 4 * g + ii;
-          const float dcp = ((mws >> rrow(i)) & 1u) ? y0[i] + y1[i] : 0.f;
+          const float dcp = ((mws >> rrow(i)) & 1u) ? y0[i] : 0.f;
           dgn[ch][ii] += dcp;
           sum += dcp;
         }
@@ -657,7 +768,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
         Pdc.st(vb_lo, (unsigned)(kConvP + ch * kH + k) * pB, sum + other_half(sum));
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-          dpos[q] = fmaf(L.U(rAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
+          dpos[q] = fmaf(L.U(gAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
       }
     }
 #pragma unroll
@@ -709,7 +820,8 @@ using namespace apg;
 extern "C" {
 
 int apg_quad_lstm_workspace_floats(void) {
-  return kFwdLds > kBwdLds ? kFwdLds : kBwdLds;
+  int n = kFwdLds > kFwd16Lds ? kFwdLds : kFwd16Lds;
+  return n > kBwd16Lds ? n : kBwd16Lds;
 }
 
 int apg_quad_lstm_loss_partials_count(int B) {
@@ -742,11 +854,11 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
   PackArgs P;
   P.pol = *policy, P.dst = workspace;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(lstm_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256),
+  hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256),
                      0, st, P);
   hipLaunchKernelGGL(lstm_rollout_fwd_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kFwdLds * sizeof(float), st, A);
+                     kFwd16Lds * sizeof(float), st, A);
   return check_launch("quad_lstm_rollout_fwd");
 }
 
@@ -790,11 +902,11 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
   PackArgs P;
   P.pol = *policy, P.dst = workspace;
-  hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3((kBwdLds + 255) / 256), dim3(256),
+  hipLaunchKernelGGL(lstm_pack_bwd16_kernel, dim3((kBwd16Lds + 255) / 256), dim3(256),
                      0, st, P);
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   hipLaunchKernelGGL(lstm_rollout_bwd_kernel, dim3(blocks), dim3(kThreads),
-                     kBwdLds * sizeof(float), st, A);
+                     kBwd16Lds * sizeof(float), st, A);
   if (int e = check_launch("quad_lstm_rollout_bwd")) return e;
   if (loss)
     return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave), loss, st);
