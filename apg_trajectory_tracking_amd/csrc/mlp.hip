@@ -335,21 +335,23 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
     // the window relative to the current position, split once per step: high
     // term in the low half-word, low term in the high half-word
     const float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
-    unsigned ws[kH][5];
-#pragma unroll
-    for (int r = 0; r < kH; ++r)
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const float x = j < 3 ? w[r][j] - sub[j] : w[r][j];
-        const _Float16 vh = (_Float16)x, vl = (_Float16)(x - (float)vh);
-        const h16x2 pr = {vh, vl};
-        ws[r][j] = __builtin_bit_cast(unsigned, pr);
-      }
     init_bias(a, L, hTb1);
     unsigned mbits[3] = {0u, 0u, 0u};
 #pragma unroll
     for (int pp = 0; pp < kNP / 2; ++pp) {
       float rv[24];  // relu(conv) of positions 2 pp, 2 pp + 1: registers 0..11 each
+      // window rows 2 pp .. 2 pp + 3 relative to the current position, split:
+      // high term in the low half-word, low term in the high half-word
+      unsigned ws[4][5];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const float xv = j < 3 ? w[2 * pp + r][j] - sub[j] : w[2 * pp + r][j];
+          const _Float16 vh = (_Float16)xv, vl = (_Float16)(xv - (float)vh);
+          const h16x2 pr = {vh, vl};
+          ws[r][j] = __builtin_bit_cast(unsigned, pr);
+        }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int pos = 2 * pp + e;
@@ -362,8 +364,8 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {  // slots 2 q, 2 q + 1 of this k-block
             const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
-            const unsigned r0 = ws[pos + s0 % 3][s0 / 3];
-            const unsigned r1 = s1 < 15 ? ws[pos + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
+            const unsigned r0 = ws[e + s0 % 3][s0 / 3];
+            const unsigned r1 = s1 < 15 ? ws[e + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
             x.h[q] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);  // low half-words
             x.l[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);  // high half-words
           }
@@ -1014,22 +1016,23 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
     u[0] = mma3(L16.A(hA, nS + 0), x, u[0]);
     u[1] = mma3(L16.A(hA, nS + 1), x, u[1]);
   }
-  // the window values, split once: high term in the low half-word, low term
-  // in the high half-word of one register per value
-  unsigned ws[kH][5];
-#pragma unroll
-  for (int r = 0; r < kH; ++r)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const _Float16 vh = (_Float16)w[r][j], vl = (_Float16)(w[r][j] - (float)vh);
-      const h16x2 pr = {vh, vl};
-      ws[r][j] = __builtin_bit_cast(unsigned, pr);
-    }
   init_bias(a, L, hTb1);
   unsigned mbits[3] = {0u, 0u, 0u};
 #pragma unroll
   for (int pp = 0; pp < kNP / 2; ++pp) {
     float rv[24];  // relu(conv) of positions 2 pp, 2 pp + 1: registers 0..11 each
+    // window rows 2 pp .. 2 pp + 3, split: high term in the low half-word, low
+    // term in the high half-word of one register per value
+    unsigned ws[4][5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const float xv = w[2 * pp + r][j];
+        const _Float16 vh = (_Float16)xv, vl = (_Float16)(xv - (float)vh);
+        const h16x2 pr = {vh, vl};
+        ws[r][j] = __builtin_bit_cast(unsigned, pr);
+      }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int pos = 2 * pp + e;
@@ -1042,8 +1045,8 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
 #pragma unroll
         for (int q = 0; q < 4; ++q) {  // slots 2 q, 2 q + 1 of this k-block
           const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
-          const unsigned r0 = ws[pos + s0 % 3][s0 / 3];
-          const unsigned r1 = s1 < 15 ? ws[pos + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
+          const unsigned r0 = ws[e + s0 % 3][s0 / 3];
+          const unsigned r1 = s1 < 15 ? ws[e + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
           x.h[q] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);  // low half-words
           x.l[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);  // high half-words
         }
