@@ -221,31 +221,36 @@ def cpu_baseline(args):
 # ----------------------------------------------------------------------------
 # Training steps (secondary blocks of the line).  Each is the REAL trainer
 # method on this rank's shard and carries its own roofline: the step's MFMA
-# work (policy sweeps in exact fp32 on v_mfma_f32_32x32x2_f32 + the
-# weight-gradient products) against the 157.3 TFLOP/s fp32 matrix peak, its
-# algorithmic plane traffic against 8 TB/s, and the achieved fraction of the
-# LARGER of the two floors.  Per-wave MFMA counts are the kernels' static
-# instruction counts (hipcc -S of csrc/mlp.hip, lstm.hip; one wave = 32
-# trajectories, one MFMA = 32 x 32 x 2 x 2 flop); plane bytes are the planes
+# work (policy sweeps as fp16-split products on v_mfma_f32_32x32x16_f16
+# against the 2.5 PFLOP/s dense fp16 peak + the weight-gradient products in
+# exact fp32 against the 157.3 TFLOP/s fp32 matrix peak), its algorithmic
+# plane traffic against 8 TB/s, and the achieved fraction of the LARGER of the
+# two floors.  Per-wave MFMA counts are the kernels' static instruction counts
+# (hipcc -S of csrc/mlp.hip, lstm.hip; one wave = 32 trajectories, one fp16
+# MFMA = 32 x 32 x 16 x 2 flop); plane bytes are the planes
 # the sweeps write / read once plus one more read by the products
 # (measured FETCH / WRITE equal these counts).
 FP32_MFMA_PEAK_TFLOPS = 157.3
+# the sweeps' layers run as v_mfma_f32_32x32x16_f16 on operands split into two
+# fp16 terms (three instructions per k-block of 16, 32 768 flop each, every one
+# of them counted): dense fp16 peak of MI355X_MICROARCH.md
+FP16_MFMA_PEAK_TFLOPS = 2500.0
 STEP_MODELS = {
-    # mode: MFMAs per wave (forward, reverse; per step for the unrolled modes),
-    # plane bytes per env-step and per trajectory
-    "concurrent": dict(mfma_once=586 + 392, mfma_per_step=0,
+    # mode: fp16 MFMAs per wave (forward + reverse; per step for the unrolled
+    # modes), plane bytes per env-step and per trajectory
+    "concurrent": dict(mfma_once=222 + 150, mfma_per_step=0,
                        # 431 + 456 planes of B floats written, read once more
                        # by the products; inputs: features 60 + in_ref 360 +
                        # state0 48 + ref 360
                        bytes_per_traj=(431 + 456) * 4 * 2 + 828, bytes_per_step=0),
-    "autoregressive": dict(mfma_once=0, mfma_per_step=520 + 384,
+    "autoregressive": dict(mfma_once=0, mfma_per_step=198 + 144,
                            # fwd 436 planes + states/actions written, reverse
                            # reads 1 153 B and writes 260 planes per env-step +
                            # 720 planes per trajectory, products read the 431
                            # activation + 260 cotangent planes once
                            bytes_per_step=1808 + 1153 + 1040 + (431 + 260) * 4,
                            bytes_per_traj=2880 * 2 + 48 + 20 * 72),
-    "LSTM": dict(mfma_once=0, mfma_per_step=228 + 112,
+    "LSTM": dict(mfma_once=0, mfma_per_step=90 + 42,
                  # x 700 + gates 128 + h/c 96 + states/actions 64 written and
                  # re-read by the reverse sweep, cotangents 144 written, the
                  # products read x, gates' cotangents and h once more
@@ -257,24 +262,28 @@ STEP_MODELS = {
 def step_roofline(mode, B, H, n_params, ms):
     m = STEP_MODELS[mode]
     waves = (B + 31) // 32
-    sweep_flops = (m["mfma_once"] + m["mfma_per_step"] * H) * 4096.0 * waves
+    sweep_flops = (m["mfma_once"] + m["mfma_per_step"] * H) * 32768.0 * waves
     cols = B * (H if m["mfma_per_step"] else 1)      # columns of the products
-    product_flops = 2.0 * n_params * cols
-    flops = sweep_flops + product_flops
+    product_flops = 2.0 * n_params * cols            # exact-fp32 matrix instructions
     nbytes = float(B) * (m["bytes_per_traj"] + m["bytes_per_step"] * H)
-    mfma_ms = flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+    mfma_ms = (sweep_flops / (FP16_MFMA_PEAK_TFLOPS * 1e12)
+               + product_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
     hbm_ms = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
     floor = max(mfma_ms, hbm_ms)
     return {
         "bound": "mfma" if mfma_ms >= hbm_ms else "hbm",
-        "mfma_fp32": {"flops_per_step": flops, "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS,
-                      "floor_ms": mfma_ms,
-                      "achieved_TFLOPs": flops / (ms * 1e-3) / 1e12},
+        "mfma": {"sweep_fp16_flops_per_step": sweep_flops,
+                 "product_fp32_flops_per_step": product_flops,
+                 "peak_TFLOPs": {"fp16": FP16_MFMA_PEAK_TFLOPS,
+                                 "fp32": FP32_MFMA_PEAK_TFLOPS},
+                 "floor_ms": mfma_ms},
         "hbm": {"plane_bytes_per_step": nbytes, "peak_GBps": HBM_PEAK_GBS,
                 "floor_ms": hbm_ms, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9},
         "frac": floor / ms,
-        "what": "larger of (MFMA flops / 157.3 TF, plane bytes / 8 TB/s) over the "
-                "measured step; exact fp32 throughout",
+        "what": "larger of (sweep fp16-MFMA flops / 2.5 PF + product fp32-MFMA flops "
+                "/ 157.3 TF, plane bytes / 8 TB/s) over the measured step; the "
+                "sweeps' layers are fp16-split products at fp32 accuracy "
+                "(csrc/policy_mfma16.h), the products exact fp32",
     }
 
 

@@ -615,9 +615,10 @@ def test_bench_line_contract():
         assert t["fused"] is True and t["ms_per_step"] > 0, key
         q = t["roofline"]
         assert q["bound"] in ("mfma", "hbm")
-        floor = max(q["mfma_fp32"]["floor_ms"], q["hbm"]["floor_ms"])
+        floor = max(q["mfma"]["floor_ms"], q["hbm"]["floor_ms"])
         assert abs(q["frac"] - floor / t["ms_per_step"]) < 1e-9 and 0 < q["frac"] < 1
-        assert q["mfma_fp32"]["peak_TFLOPs"] == 157.3 and q["hbm"]["peak_GBps"] == 8000.0
+        assert q["mfma"]["peak_TFLOPs"] == {"fp16": 2500.0, "fp32": 157.3}
+        assert q["hbm"]["peak_GBps"] == 8000.0
     assert d["train_step_packed"]["ms_per_step"] > 0
     assert "quad_rollout_rows_kernel" in d["train_step_packed"]["what"]
     c = d["cpu_baseline"]
