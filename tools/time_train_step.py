@@ -1,0 +1,33 @@
+"""One fused training step of TrainDrone at B = 65 536 on a resident shard,
+eager launches (no graph), for per-kernel profiling:
+    python tools/time_train_step.py concurrent|autoregressive|LSTM
+    rocprofv3 --kernel-trace --stats -- python tools/time_train_step.py <mode>
+Prints the eager wall time per step (host gaps included)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from apg_trajectory_tracking_amd.train_drone import TrainDrone
+from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import FlightmareDynamics
+dev = torch.device("cuda:0")
+B, H, dt = 65536, 10, 0.1
+mode = sys.argv[1] if len(sys.argv) > 1 else "concurrent"
+cfg = dict(delta_t=dt, delta_t_train=dt, epoch_size=B, self_play=0, batch_size=B, state_size=12,
+           horizon=H, train_mode=mode, ref_dim=9, action_dim=4, learning_rate_controller=1e-9,
+           system="quad", modified_params={})
+q = FlightmareDynamics()
+t = TrainDrone(q, q, cfg)
+torch.manual_seed(0)
+t.initialize_model(device=dev, seed=0)
+t.static_shard = True
+d = t.state_data
+def step():
+    if mode == "concurrent":
+        t.train_concurrent_fused(d.normed_states, d.states, d.in_ref_states, d.ref_states)
+    else:
+        t.train_recurrent_model(d.normed_states, d.states, d.in_ref_states, d.ref_states)
+for _ in range(5): step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): step()
+e1.record(); torch.cuda.synchronize()
+print(mode, "ms/step", e0.elapsed_time(e1) / 20)
