@@ -16,6 +16,7 @@
 // cotangent planes x activation planes by apg_planes_gemm_grouped.
 #include "apg_device.h"
 #include "policy_mfma.h"
+#include "policy_mfma16.h"
 #include "wing_math.h"
 
 namespace apg {
@@ -86,6 +87,65 @@ __global__ __launch_bounds__(256) void wing_pack_fwd_kernel(PackArgs A) {
   }
 }
 
+// Tables of the TRAINING kernels (fp16 split operands, policy_mfma16.h; the
+// closed-loop kernel keeps the fp32 tables above).  Forward: the bias tables
+// [rb][16][2] (first layer 4 row blocks, then fc1, fc2, fc3, head 3 row
+// blocks), then 48 A-operand blocks of 2 KB: first layer [rb of 4] (one
+// k-block: inputs 8 hi + j of the 12), fc1 [rb][kb of 8], fc2 / fc3 [rb][kb],
+// head [rb of 3][kb].
+constexpr int hT0 = 0, hT1 = 128, hT2 = 192, hT3 = 256, hTo = 320;   // floats
+constexpr int hA = 2048;                                            // bytes
+constexpr int n0 = 0, n1 = 4, n2 = 20, n3 = 28, nO = 36, nBlocks16 = 48;
+constexpr int kFwd16Lds = (hA + nBlocks16 * kBlock16) / 4;   // 25 088 floats = 100 352 B
+static_assert(hTo + 96 <= hA / 4, "LDS map");
+
+// input index of slot j of k-block kb for a layer fed by FOUR row blocks
+// (fc1: 128 inputs) or two (64): registers 8 (kb & 1) .. + 7 of block kb >> 1
+__device__ __forceinline__ float wing_fwd16_weight(const ApgWingPolicy &p, int n, int row,
+                                                   int j, int hi) {
+  if (n < n1) {                        // [states_in 0; 0 ref_in], inputs 8 hi + j
+    const int m = n * 32 + row, k = 8 * hi + j;
+    if (m < kW && k < kNS) return p.w_s[m * kNS + k];
+    if (m >= kW && k >= kNS && k < kNI) return p.w_r[(m - kW) * kNR + (k - kNS)];
+    return 0.f;
+  }
+  if (n < n2) {
+    const int m = n - n1, rb = m / 8, kb = m % 8;
+    return p.w_1[(rb * 32 + row) * kW0 + kin(kb, j, hi)];
+  }
+  if (n < nO) {
+    const int m = (n - n2) % 8, rb = m / 4, k = kin(m % 4, j, hi);
+    return n < n3 ? p.w_2[(rb * 32 + row) * kW + k] : p.w_3[(rb * 32 + row) * kW + k];
+  }
+  const int m = n - nO, rb = m / 4, out = rb * 32 + row;
+  return out < kNA ? p.w_out[out * kW + kin(m % 4, j, hi)] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void wing_pack_fwd16_kernel(PackArgs A) {
+  const ApgWingPolicy &p = A.pol;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  for (int idx = tid; idx < nBlocks16 * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    unsigned h, lo;
+    split_pair(wing_fwd16_weight(p, n, l & 31, 2 * q, l >> 5),
+               wing_fwd16_weight(p, n, l & 31, 2 * q + 1, l >> 5), h, lo);
+    dst[(hA + n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(hA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
+  }
+  for (int idx = tid; idx < 128; idx += T) {
+    const int hi = idx & 1, i = (idx >> 1) & 15, rb = idx >> 5;
+    const int row = rb * 32 + rrow(i) + 4 * hi;
+    A.dst[hT0 + idx] = row < kW ? p.b_s[row] : p.b_r[row - kW];
+    if (rb < 2) {
+      A.dst[hT1 + idx] = p.b_1[row];
+      A.dst[hT2 + idx] = p.b_2[row];
+      A.dst[hT3 + idx] = p.b_3[row];
+    }
+    if (rb < 3) A.dst[hTo + idx] = row < kNA ? p.b_out[row] : 0.f;
+  }
+}
+
 struct Args {
   const float *feat, *ref_in;   // [9][B], [3][B]
   float *actions;               // [80][B] = [H][4][B]
@@ -98,7 +158,7 @@ struct Args {
 
 __global__ __launch_bounds__(kThreads) void wing_policy_fwd_kernel(Args A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwdLds);
+  fill_lds(lds, A.tables, kFwd16Lds);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -117,30 +177,41 @@ __global__ __launch_bounds__(kThreads) void wing_policy_fwd_kernel(Args A) {
 #pragma unroll
   for (int j = 0; j < kNR; ++j) in[kNS + j] = Prf.ld(vb, j * pN);
 
-  // first layer: [states_in 0; 0 ref_in], 12 -> 128
+  // the layers on the 16-bit matrix pipe (policy_mfma16.h): every operand as
+  // two fp16 terms, three products per k-block
+  const LdsView16 L16(lds, lane);
+  // first layer: [states_in 0; 0 ref_in], 12 -> 128: one k-block
   f32x16 x[4];
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[rb][i] = L.T(fT0 + (rb * 16 + i) * 2);
+    for (int i = 0; i < 16; ++i) x[rb][i] = L.T(hT0 + (rb * 16 + i) * 2);
+  {
+    float v[8];
 #pragma unroll
-  for (int p = 0; p < 6; ++p) {
-    const float bv = hi ? in[2 * p + 1] : in[2 * p];
+    for (int j = 0; j < 8; ++j) v[j] = hi ? (8 + j < kNI ? in[8 + j < kNI ? 8 + j : 0] : 0.f) : in[j];
+    const Op16 xi = split8(v);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) x[rb] = mfma(L.A(fA0 + (rb * 6 + p) * 64), bv, x[rb]);
+    for (int rb = 0; rb < 4; ++rb) x[rb] = mma3(L16.A(hA, n0 + rb), xi, x[rb]);
   }
-  // fc1 (tanh of the first layer applied where it is consumed)
+  // fc1 (tanh of the first layer applied, and stored, where it is consumed)
   f32x16 u[2], a[2];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[rb][i] = L.T(fT1 + (rb * 16 + i) * 2);
+    for (int i = 0; i < 16; ++i) a[rb][i] = L.T(hT1 + (rb * 16 + i) * 2);
 #pragma unroll
-  for (int c = 0; c < 64; ++c) {
-    const float bv = tanh_fast(x[c >> 4][c & 15]);
-    Px1.st(vr, ((c >> 4) * 32 + rrow(c & 15)) * pN, bv);
-    a[0] = mfma(L.A(fA1 + (0 * 64 + c) * 64), bv, a[0]);
-    a[1] = mfma(L.A(fA1 + (1 * 64 + c) * 64), bv, a[1]);
+  for (int kb = 0; kb < 8; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = 8 * (kb & 1) + j;
+      v[j] = tanh_fast(x[kb >> 1][i]);
+      Px1.st(vr, ((kb >> 1) * 32 + rrow(i)) * pN, v[j]);
+    }
+    const Op16 xv = split8(v);
+    a[0] = mma3(L16.A(hA, n1 + kb), xv, a[0]);
+    a[1] = mma3(L16.A(hA, n1 + 8 + kb), xv, a[1]);
   }
   // fc2, fc3
 #pragma unroll
@@ -148,32 +219,33 @@ __global__ __launch_bounds__(kThreads) void wing_policy_fwd_kernel(Args A) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) u[rb][i] = L.T((layer ? fT3 : fT2) + (rb * 16 + i) * 2);
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const float bv = tanh_fast(a[c >> 4][c & 15]);
-      Ph.st(vr, (layer * kW + (c >> 4) * 32 + rrow(c & 15)) * pN, bv);
-      u[0] = mfma(L.A((layer ? fA3 : fA2) + (0 * 32 + c) * 64), bv, u[0]);
-      u[1] = mfma(L.A((layer ? fA3 : fA2) + (1 * 32 + c) * 64), bv, u[1]);
-    }
+      for (int i = 0; i < 16; ++i) u[rb][i] = L.T((layer ? hT3 : hT2) + (rb * 16 + i) * 2);
+    dense64_16(u, a, L16, hA, layer ? n3 : n2, [&](int rb, int i, float v) {
+      const float tv = tanh_fast(v);
+      Ph.st(vr, (layer * kW + rb * 32 + rrow(i)) * pN, tv);
+      return tv;
+    });
     a[0] = u[0], a[1] = u[1];
   }
-  // head: 80 outputs in three row blocks, bias as an extra k-pair (1, 0)
+  // head: 80 outputs in three row blocks
   f32x16 z[3];
 #pragma unroll
   for (int rb = 0; rb < 3; ++rb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) z[rb][i] = 0.f;
+    for (int i = 0; i < 16; ++i) z[rb][i] = L.T(hTo + (rb * 16 + i) * 2);
 #pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const float bv = tanh_fast(a[c >> 4][c & 15]);
-    Ph.st(vr, (2 * kW + (c >> 4) * 32 + rrow(c & 15)) * pN, bv);
+  for (int kb = 0; kb < 4; ++kb) {
+    float v[8];
 #pragma unroll
-    for (int rb = 0; rb < 3; ++rb) z[rb] = mfma(L.A(fAo + (rb * 33 + c) * 64), bv, z[rb]);
+    for (int j = 0; j < 8; ++j) {
+      const int i = 8 * (kb & 1) + j;
+      v[j] = tanh_fast(a[kb >> 1][i]);
+      Ph.st(vr, (2 * kW + (kb >> 1) * 32 + rrow(i)) * pN, v[j]);
+    }
+    const Op16 xv = split8(v);
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb) z[rb] = mma3(L16.A(hA, nO + rb * 4 + kb), xv, z[rb]);
   }
-#pragma unroll
-  for (int rb = 0; rb < 3; ++rb)
-    z[rb] = mfma(L.A(fAo + (rb * 33 + 32) * 64), hi ? 0.f : 1.f, z[rb]);
   // actions = sigmoid(z): accumulator rows ARE the action planes
 #pragma unroll
   for (int rb = 0; rb < 3; ++rb)
@@ -396,41 +468,48 @@ __global__ __launch_bounds__(kThreads) void wing_closed_loop_kernel(WingLoopArgs
 }
 
 // ------------------------------------------------------------------ reverse
-constexpr int rAo = 0;                    // [2][40][64] head^T
-constexpr int rA3 = rAo + 2 * 40 * 64;    // [2][32][64] fc3^T
-constexpr int rA2 = rA3 + 2 * 32 * 64;    // [2][32][64] fc2^T
-constexpr int rA1 = rA2 + 2 * 32 * 64;    // [4][32][64] fc1^T (128 outputs)
-constexpr int kBwdLds = rA1 + 4 * 32 * 64;  // 21 504 floats = 86 016 B
-
 // k index of head k-pair c (accumulator layout of the 80 outputs: row blocks
 // 0 and 1 registers 0..15, row block 2 registers 0..7)
 __host__ __device__ constexpr int khead(int c, int hi) {
   return (c >> 4) * 32 + rrow(c & 15) + 4 * hi;
 }
 
-__global__ __launch_bounds__(256) void wing_pack_bwd_kernel(PackArgs A) {
-  const ApgWingPolicy &p = A.pol;
-  float *dst = A.dst;
+// Reverse tables (fp16 split operands): 42 transposed blocks: head^T
+// [rb][kb of 5] (this lane's 40 dL/dz rows), fc3^T, fc2^T [rb][kb], fc1^T
+// [rb of 4][kb].
+constexpr int mOT = 0, m3T = 10, m2T = 18, m1T = 26, mBlocks16 = 42;
+constexpr int kBwd16Lds = mBlocks16 * kBlock16 / 4;   // 21 504 floats = 86 016 B
+
+__device__ __forceinline__ float wing_bwd16_weight(const ApgWingPolicy &p, int n, int row,
+                                                   int j, int hi) {
+  if (n < m3T) {
+    const int rb = n / 5, c = (n % 5) * 8 + j;       // dz register c: head row khead(c, hi)
+    return p.w_out[khead(c, hi) * kW + rb * 32 + row];
+  }
+  if (n < m1T) {
+    const int m = (n - m3T) % 8, rb = m / 4, k = kin(m % 4, j, hi);
+    return n < m2T ? p.w_3[k * kW + rb * 32 + row] : p.w_2[k * kW + rb * 32 + row];
+  }
+  const int m = n - m1T, rb = m / 4;
+  return p.w_1[kin(m % 4, j, hi) * kW0 + rb * 32 + row];
+}
+
+__global__ __launch_bounds__(256) void wing_pack_bwd16_kernel(PackArgs A) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
-  for (int idx = tid; idx < 2 * 40 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) % 40, rb = idx / (40 * 64);
-    dst[rAo + idx] = p.w_out[khead(c, l >> 5) * kW + rb * 32 + (l & 31)];
-  }
-  for (int idx = tid; idx < 2 * 32 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) & 31, rb = idx >> 11;
-    const int m = rb * 32 + (l & 31), k = kchain(c, l >> 5);
-    dst[rA3 + idx] = p.w_3[k * kW + m];
-    dst[rA2 + idx] = p.w_2[k * kW + m];
-  }
-  for (int idx = tid; idx < 4 * 32 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) & 31, rb = idx >> 11;
-    dst[rA1 + idx] = p.w_1[kchain(c, l >> 5) * kW0 + rb * 32 + (l & 31)];
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    unsigned h, lo;
+    split_pair(wing_bwd16_weight(A.pol, n, l & 31, 2 * q, l >> 5),
+               wing_bwd16_weight(A.pol, n, l & 31, 2 * q + 1, l >> 5), h, lo);
+    dst[(n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
   }
 }
 
 __global__ __launch_bounds__(kThreads) void wing_policy_bwd_kernel(Args A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kBwdLds);
+  fill_lds(lds, A.tables, kBwd16Lds);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -458,17 +537,32 @@ __global__ __launch_bounds__(kThreads) void wing_policy_bwd_kernel(Args A) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) hv[rb][i] = Ph.ld(vr, (2 * kW + rb * 32 + rrow(i)) * pN);
   __builtin_amdgcn_sched_barrier(0);
+  // the reverse layers on the 16-bit matrix pipe: cotangents scaled per
+  // trajectory, two fp16 terms, three products per k-block
+  const LdsView16 L16(lds, lane);
   f32x16 d[2], e[2];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[rb][i] = 0.f;
+  int ex;
+  {  // dL/dh3 = W_out^T dL/dz: this lane's 40 rows = 5 k-blocks
+    float amax = 0.f;
 #pragma unroll
-  for (int c = 0; c < 40; ++c) {
-    d[0] = mfma(L.A(rAo + (0 * 40 + c) * 64), dz[c], d[0]);
-    d[1] = mfma(L.A(rAo + (1 * 40 + c) * 64), dz[c], d[1]);
+    for (int c = 0; c < 40; ++c) amax = fmaxf(amax, fabsf(dz[c]));
+    ex = scale_exponent(amax);
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_ldexpf(dz[kb * 8 + j], -ex);
+      const Op16 xv = split8(v);
+      d[0] = mma3(L16.A(0, mOT + kb), xv, d[0]);
+      d[1] = mma3(L16.A(0, mOT + 5 + kb), xv, d[1]);
+    }
   }
-  // fc3, fc2: v *= 1 - act^2, store, multiply by the transposed weights
+  Op16 xs[4];
+  // fc3, fc2: v = 2^ex v (1 - act^2), store, multiply by the transposed weights
 #pragma unroll
   for (int layer = 2; layer >= 1; --layer) {
     __builtin_amdgcn_sched_barrier(0);
@@ -476,7 +570,7 @@ __global__ __launch_bounds__(kThreads) void wing_policy_bwd_kernel(Args A) {
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        d[rb][i] *= 1.f - hv[rb][i] * hv[rb][i];
+        d[rb][i] = __builtin_amdgcn_ldexpf(d[rb][i], ex) * (1.f - hv[rb][i] * hv[rb][i]);
         Pdp.st(vr, (layer * kW + rb * 32 + rrow(i)) * pN, d[rb][i]);  // d_pre fc3 / fc2
       }
 #pragma unroll
@@ -489,12 +583,8 @@ __global__ __launch_bounds__(kThreads) void wing_policy_bwd_kernel(Args A) {
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) e[rb][i] = 0.f;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const float bv = d[c >> 4][c & 15];
-      e[0] = mfma(L.A((layer == 2 ? rA3 : rA2) + (0 * 32 + c) * 64), bv, e[0]);
-      e[1] = mfma(L.A((layer == 2 ? rA3 : rA2) + (1 * 32 + c) * 64), bv, e[1]);
-    }
+    ex = scaled_split64(d, xs);
+    dense64T_16(e, xs, L16, 0, layer == 2 ? m3T : m2T);
     d[0] = e[0], d[1] = e[1];
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -502,7 +592,7 @@ __global__ __launch_bounds__(kThreads) void wing_policy_bwd_kernel(Args A) {
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      d[rb][i] *= 1.f - hv[rb][i] * hv[rb][i];
+      d[rb][i] = __builtin_amdgcn_ldexpf(d[rb][i], ex) * (1.f - hv[rb][i] * hv[rb][i]);
       Pdp.st(vr, (rb * 32 + rrow(i)) * pN, d[rb][i]);  // d_pre fc1
     }
   // first layer: 128 outputs, then tanh' from the saved x1
@@ -512,18 +602,18 @@ __global__ __launch_bounds__(kThreads) void wing_policy_bwd_kernel(Args A) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) xv[rb][i] = Px1.ld(vr, (rb * 32 + rrow(i)) * pN);
   __builtin_amdgcn_sched_barrier(0);
+  ex = scaled_split64(d, xs);
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb) {
     f32x16 y;
 #pragma unroll
     for (int i = 0; i < 16; ++i) y[i] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c)
-      y = mfma(L.A(rA1 + (rb * 32 + c) * 64), d[c >> 4][c & 15], y);
+    for (int kb = 0; kb < 4; ++kb) y = mma3(L16.A(0, m1T + rb * 4 + kb), xs[kb], y);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       Pdp.st(vr, (3 * kW + rb * 32 + rrow(i)) * pN,
-             y[i] * (1.f - xv[rb][i] * xv[rb][i]));  // d_pre first layer
+             __builtin_amdgcn_ldexpf(y[i], ex) * (1.f - xv[rb][i] * xv[rb][i]));  // d_pre first layer
   }
 }
 
@@ -559,7 +649,8 @@ using namespace apg;
 extern "C" {
 
 int apg_wing_policy_workspace_floats(void) {
-  return kFwdLds > kBwdLds ? kFwdLds : kBwdLds;
+  int n = kFwdLds > kFwd16Lds ? kFwdLds : kFwd16Lds;
+  return n > kBwd16Lds ? n : kBwd16Lds;
 }
 
 int apg_wing_policy_fwd(const float *feat, const float *ref_in,
@@ -574,7 +665,7 @@ int apg_wing_policy_fwd(const float *feat, const float *ref_in,
   }
   static bool attr = false;
   if (!attr) {
-    if (int e = raise_lds(wing_policy_fwd_kernel, kFwdLds)) return e;
+    if (int e = raise_lds(wing_policy_fwd_kernel, kFwd16Lds)) return e;
     attr = true;
   }
   Args A = {};
@@ -583,11 +674,11 @@ int apg_wing_policy_fwd(const float *feat, const float *ref_in,
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wing_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256), 0,
+  hipLaunchKernelGGL(wing_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256), 0,
                      st, P);
   hipLaunchKernelGGL(wing_policy_fwd_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kFwdLds * sizeof(float), st, A);
+                     kFwd16Lds * sizeof(float), st, A);
   return check_launch("wing_policy_fwd");
 }
 
@@ -603,7 +694,7 @@ int apg_wing_policy_bwd(const float *actions, const float *grad_actions,
   }
   static bool attr = false;
   if (!attr) {
-    if (int e = raise_lds(wing_policy_bwd_kernel, kBwdLds)) return e;
+    if (int e = raise_lds(wing_policy_bwd_kernel, kBwd16Lds)) return e;
     attr = true;
   }
   Args A = {};
@@ -613,11 +704,11 @@ int apg_wing_policy_bwd(const float *actions, const float *grad_actions,
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wing_pack_bwd_kernel, dim3((kBwdLds + 255) / 256), dim3(256), 0,
+  hipLaunchKernelGGL(wing_pack_bwd16_kernel, dim3((kBwd16Lds + 255) / 256), dim3(256), 0,
                      st, P);
   hipLaunchKernelGGL(wing_policy_bwd_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kBwdLds * sizeof(float), st, A);
+                     kBwd16Lds * sizeof(float), st, A);
   return check_launch("wing_policy_bwd");
 }
 
