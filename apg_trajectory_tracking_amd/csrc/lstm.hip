@@ -17,13 +17,15 @@
 // k = 3)) (160)], gates = W_ih x + W_hh h + b (32 = i, f, g, o x 8 units),
 // c' = sig(f) c + sig(i) tanh(g), h' = sig(o) tanh(c'), a = sig(W_out h' + b).
 // The 32 x 183 gate projection and the conv are GEMM-shaped with the batch as
-// N: they run on v_mfma_f32_32x32x2_f32 in the layout of policy_mfma.h (one
-// wave = 32 trajectories, lane l works for trajectory l & 31).  The gate
+// N: they run on the matrix cores in the layout of policy_mfma.h (one wave =
+// 32 trajectories, lane l works for trajectory l & 31) - rounds 1-2 as
+// v_mfma_f32_32x32x2_f32, since round 3 as v_mfma_f32_32x32x16_f16 products of
+// fp16-split operands (policy_mfma16.h: fp32 accuracy, 90 + 42 instructions
+// of 32 cycles per step and wave instead of 228 + 112 of 64).  The gate
 // accumulator puts (i, f, g, o) of hidden unit u = r + 4 (l >> 5) into
 // registers r, 4 + r, 8 + r, 12 + r of ONE lane, so the cell update is
 // lane-local, and h' (4 registers per lane) is directly the B operand of the
 // next step's W_hh product: the recurrence needs no data movement at all.
-// 228 MFMAs per step and wave forward, 112 in the reverse sweep.
 //
 // Weight gradients: the reverse sweep writes the per-(step, trajectory)
 // cotangent planes (gate / head / conv pre-activations) next to the forward's
@@ -67,61 +69,15 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
 }
 
 // ------------------------------------------------------------ forward sweep
-constexpr int fTo = 0;               // [4 j][4 r][2]   W_out[j][r + 4 hi]
-constexpr int fTbg = fTo + 32;       // [16][2]         b_ih + b_hh
-constexpr int fTbc = fTbg + 32;      // [16][2]         conv bias
-constexpr int fBo = fTbc + 32;       // [4]
-constexpr int fAf = 128;             // [8][64]         W_ih, feature k-pairs
-constexpr int fAh = fAf + 8 * 64;    // [4][64]         W_hh, k-pair (r, r + 4)
-constexpr int fAc = fAh + 4 * 64;    // [15][64]        conv
-constexpr int fAg = fAc + 15 * 64;   // [8 pos][12][64] W_ih, conv inputs
-constexpr int kFwdLds = fAg + 8 * 12 * 64;  // 8 000 floats
-
-__device__ __forceinline__ void pack_forward(float *dst, const ApgLstmPolicy &p,
-                                             int tid, int T) {
-  for (int idx = tid; idx < 8 * 64; idx += T) {
-    const int l = idx & 63, pp = idx >> 6, k = 2 * pp + (l >> 5);
-    dst[fAf + idx] = k < kNF ? p.w_ih[(l & 31) * kNX + k] : 0.f;
-  }
-  for (int idx = tid; idx < 4 * 64; idx += T) {
-    const int l = idx & 63, r = idx >> 6;
-    dst[fAh + idx] = p.w_hh[(l & 31) * kNH + r + 4 * (l >> 5)];
-  }
-  // conv k-pair (j, tap): the lower half multiplies reference column j (< 4),
-  // the upper half column 4 + j, so a lane only keeps 5 of the 9 columns
-  for (int idx = tid; idx < 15 * 64; idx += T) {
-    const int l = idx & 63, pp = idx >> 6, ch = l & 31;
-    const int j = pp / 3, tap = pp % 3, hi = l >> 5;
-    const int q = hi ? 4 + j : j;
-    dst[fAc + idx] = (ch < kNC && (hi || j < 4)) ? p.conv_w[ch * 27 + q * 3 + tap] : 0.f;
-  }
-  for (int idx = tid; idx < 8 * 12 * 64; idx += T) {
-    const int l = idx & 63, q = idx >> 6, i = q % 12, pos = q / 12;
-    const int ch = rrow(i) + 4 * (l >> 5);
-    dst[fAg + idx] = ch < kNC ? p.w_ih[(l & 31) * kNX + kNF + ch * kNP + pos] : 0.f;
-  }
-  for (int idx = tid; idx < 32; idx += T) {
-    const int hi = idx & 1, r = (idx >> 1) & 3, j = idx >> 3;
-    dst[fTo + idx] = p.w_out[j * kNH + r + 4 * hi];
-    const int i = idx >> 1, row = rrow(i) + 4 * hi;
-    dst[fTbg + idx] = p.b_ih[row] + p.b_hh[row];
-    dst[fTbc + idx] = row < kNC ? p.conv_b[row] : 0.f;
-  }
-  for (int idx = tid; idx < 4; idx += T) dst[fBo + idx] = p.b_out[idx];
-}
-
 struct PackArgs {
   ApgLstmPolicy pol;
   float *dst;
 };
-__global__ __launch_bounds__(256) void lstm_pack_fwd_kernel(PackArgs A) {
-  pack_forward(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
-               gridDim.x * blockDim.x);
-}
 
-// Forward tables of the TRAINING sweep (fp16 split operands, policy_mfma16.h;
-// the closed-loop kernel keeps the fp32 tables above): the small fp32 tables
-// (same content as fTo / fTbg / fTbc / fBo), then 16 A-operand blocks of 2 KB:
+// Forward tables (fp16 split operands, policy_mfma16.h): the small fp32 tables
+// indexed by the half-wave - head weights for the VALU [4 j][4 r][2], gate
+// bias b_ih + b_hh [16][2], conv bias [16][2], head bias [4] - then 16
+// A-operand blocks of 2 KB:
 // W_ih on the features, W_hh, conv [kb], W_ih on the conv outputs of a
 // position pair [pp][kb].
 constexpr int hTo = 0, hTbg = 32, hTbc = 64, hBo = 96;   // floats
@@ -173,7 +129,7 @@ struct FwdArgs {
   const float *state0, *in_ref, *h0, *c0;
   float *states, *actions, *x, *gates, *hc, *hnew;
   unsigned *mask;        // [5][N] relu bits of the conv outputs
-  const float *tables;   // packed operand tables (lstm_pack_fwd_kernel)
+  const float *tables;   // packed operand tables (lstm_pack_fwd16_kernel)
   QuadConst c;
   int B;
 };
@@ -210,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
     cell[r] = Pc0.ld(vb_u, r * pitchB);
   }
   // sliding reference window, raw values: columns 0..4 in the lower half,
-  // 4..8 in the upper half (see pack_forward)
+  // 4..8 in the upper half (see fwd16_weight)
   float w[kH][5];
 #pragma unroll
   for (int r = 0; r < kH; ++r)
@@ -372,7 +328,8 @@ struct LoopArgs {
 
 __global__ __launch_bounds__(kThreads) void lstm_closed_loop_kernel(LoopArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwdLds);
+  fill_lds(lds, A.tables, kFwd16Lds);
+  const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -425,42 +382,65 @@ __global__ __launch_bounds__(kThreads) void lstm_closed_loop_kernel(LoopArgs A) 
     const Trig t = make_trig(&s[3]);
     float feat[kNF];
     quad_features(s, t, feat);
+    // gates and conv on the 16-bit matrix pipe (policy_mfma16.h), as the
+    // forward training sweep, nothing saved
     f32x16 g0, g1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) g0[i] = L.T(fTbg + i * 2), g1[i] = 0.f;
+    for (int i = 0; i < 16; ++i) g0[i] = L.T(hTbg + i * 2), g1[i] = 0.f;
+    {
+      float v[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
-      const float bv = hi ? odd : feat[2 * p];
-      if (p & 1) g1 = mfma(L.A(fAf + p * 64), bv, g1);
-      else g0 = mfma(L.A(fAf + p * 64), bv, g0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (r & 1) g1 = mfma(L.A(fAh + r * 64), h[r], g1);
-      else g0 = mfma(L.A(fAh + r * 64), h[r], g0);
+      for (int j = 0; j < 8; ++j)
+        v[j] = hi ? (8 + j < kNF ? feat[8 + j < kNF ? 8 + j : 0] : 0.f) : feat[j];
+      g0 = mma3(L16.A(hA, nF), split8(v), g0);
+      const float vh[8] = {h[0], h[1], h[2], h[3], 0.f, 0.f, 0.f, 0.f};
+      g1 = mma3(L16.A(hA, nH), split8(vh), g1);
     }
     // lower: position columns relative to the drone; upper: the last three
     // columns are reference velocity minus drone velocity (prepare_data)
     const float sub[5] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? s[6] : s[2],
                           hi ? s[7] : 0.f, hi ? s[8] : 0.f};
 #pragma unroll
-    for (int pos = 0; pos < kNP; ++pos) {
-      f32x16 cv, cw;
+    for (int pp = 0; pp < kNP / 2; ++pp) {
+      float rv[24];
+      unsigned ws[4][5];  // window rows 2 pp .. 2 pp + 3, split (high | low << 16)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2), cw[i] = 0.f;
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int p = 0; p < 15; ++p) {
-        const int j = p / 3, tap = p % 3;
-        const float xv = w[pos + tap][j] - sub[j];
-        if (p & 1) cw = mfma(L.A(fAc + p * 64), xv, cw);
-        else cv = mfma(L.A(fAc + p * 64), xv, cv);
+        for (int j = 0; j < 5; ++j) {
+          const float xv = w[2 * pp + r][j] - sub[j];
+          const _Float16 vh = (_Float16)xv, vl = (_Float16)(xv - (float)vh);
+          const h16x2 pr = {vh, vl};
+          ws[r][j] = __builtin_bit_cast(unsigned, pr);
+        }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x16 cv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cv[i] = L.T(hTbc + i * 2);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          Op16 x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
+            const unsigned r0 = ws[e + s0 % 3][s0 / 3];
+            const unsigned r1 = s1 < 15 ? ws[e + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
+            x.h[q] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);
+            x.l[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
+          }
+          cv = mma3(L16.A(hA, nC + kb), x, cv);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rv[e * 12 + i] = fmaxf(cv[i], 0.f);
       }
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        const float v = fmaxf(cv[i] + cw[i], 0.f);
-        if (i & 1) g1 = mfma(L.A(fAg + (pos * 12 + i) * 64), v, g1);
-        else g0 = mfma(L.A(fAg + (pos * 12 + i) * 64), v, g0);
+      for (int kb = 0; kb < 3; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = rv[kb * 8 + j];
+        if (kb & 1) g1 = mma3(L16.A(hA, nG + pp * 3 + kb), split8(v), g1);
+        else g0 = mma3(L16.A(hA, nG + pp * 3 + kb), split8(v), g0);
       }
     }
 #pragma unroll
@@ -477,9 +457,9 @@ __global__ __launch_bounds__(kThreads) void lstm_closed_loop_kernel(LoopArgs A) 
     for (int j = 0; j < 4; ++j) {
       float z = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) z = fmaf(L.T(fTo + (j * 4 + r) * 2), h[r], z);
+      for (int r = 0; r < 4; ++r) z = fmaf(L.T(hTo + (j * 4 + r) * 2), h[r], z);
       z += other_half(z);
-      act[j] = fminf(fmaxf(sigmoidf_(z + L.U(fBo + j)), 0.f), 1.f);  // np.clip
+      act[j] = fminf(fmaxf(sigmoidf_(z + L.U(hBo + j)), 0.f), 1.f);  // np.clip
       Pac.st(vrec, (k * 4 + j) * pB, act[j]);
     }
     quad_step(s, act, c, t);
@@ -822,8 +802,7 @@ using namespace apg;
 extern "C" {
 
 int apg_quad_lstm_workspace_floats(void) {
-  int n = kFwdLds > kFwd16Lds ? kFwdLds : kFwd16Lds;
-  return n > kBwd16Lds ? n : kBwd16Lds;
+  return kFwd16Lds > kBwd16Lds ? kFwd16Lds : kBwd16Lds;
 }
 
 int apg_quad_lstm_loss_partials_count(int B) {
@@ -951,11 +930,11 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
   PackArgs P;
   P.pol = *policy, P.dst = workspace;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(lstm_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256),
+  hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256),
                      0, st, P);
   hipLaunchKernelGGL(lstm_closed_loop_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kFwdLds * sizeof(float), st, A);
+                     kFwd16Lds * sizeof(float), st, A);
   return check_launch("quad_lstm_closed_loop");
 }
 

@@ -15,12 +15,11 @@
 //   h2 = tanh(W_2 h1 + b_2),  h3 = tanh(W_3 h2 + b_3)
 //   a  = sigmoid(W_o h3 + b_o)                     64 -> 4
 // ~28 k FMA per env-step: this IS GEMM-shaped, with the batch as the N
-// dimension, so the layers run on the matrix cores.  Since round 3 the
-// TRAINING kernels (both sweeps, both concurrent-mode kernels) use
-// v_mfma_f32_32x32x16_f16 on operands split into two fp16 terms - three
-// products per k-block, as exact as the fp32 instruction and 2.6 x faster
-// per layer (policy_mfma16.h); the closed-loop evaluation kernel keeps
-// v_mfma_f32_32x32x2_f32 and the fp32 tables (pack_forward).
+// dimension, so the layers run on the matrix cores.  Since round 3 every
+// kernel here (both sweeps, both concurrent-mode kernels, the closed-loop
+// evaluation) uses v_mfma_f32_32x32x16_f16 on operands split into two fp16
+// terms - three products per k-block, as exact as v_mfma_f32_32x32x2_f32
+// (rounds 1-2) and 2.6 x faster per layer (policy_mfma16.h).
 //
 // Mapping.  A wave owns 32 trajectories: lane l works for trajectory l & 31,
 // both half-waves carry the same state / window registers (the ~600-op
@@ -71,71 +70,6 @@ constexpr int kConvPlanes = kConvP + kNC * kH;  // 720
 constexpr int kThreads = 512;
 constexpr int kTrajPerBlock = kThreads / 2;
 // ------------------------------------------------------------ forward sweep
-// LDS map (floats).  The small tables indexed by the half-wave come first,
-// the A-operand tables (indexed by the lane) after them; see LdsView.
-constexpr int fTo = 0;                      // [4][2][16][2]
-constexpr int fTbs = fTo + 256;             // [2][16][2] x 4 layers
-constexpr int fTb1 = fTbs + 64, fTb2 = fTb1 + 64, fTb3 = fTb2 + 64;
-constexpr int fTbc = fTb3 + 64;             // [16][2]
-constexpr int fBo = fTbc + 32;              // [4]
-constexpr int fAs = 576;                    // [2][8][64]
-constexpr int fAc = fAs + 2 * 8 * 64;       // [15][64]
-constexpr int fA1s = fAc + 15 * 64;         // [2][32][64]
-constexpr int fA1c = fA1s + 2 * 32 * 64;    // [2][8 pos][12 regs][64]
-constexpr int fA2 = fA1c + 2 * 8 * 12 * 64; // [2][32][64]
-constexpr int fA3 = fA2 + 2 * 32 * 64;      // [2][32][64]
-constexpr int kFwdLds = fA3 + 2 * 32 * 64;  // 27 136 floats = 108 544 B
-static_assert(fBo + 4 <= fAs, "LDS map");
-
-__device__ __forceinline__ void pack_forward(float *lds, const ApgMlpPolicy &p,
-                                             int tid, int T, bool head4 = true) {
-  (void)head4;  // w_out rows 0..3 / b_out 0..3 are read either way
-  for (int idx = tid; idx < 2 * 8 * 64; idx += T) {
-    const int l = idx & 63, pp = (idx >> 6) & 7, rb = idx >> 9;
-    const int k = 2 * pp + (l >> 5);
-    lds[fAs + idx] = k < kNF ? p.w_s[(rb * 32 + (l & 31)) * kNF + k] : 0.f;
-  }
-  // conv k-pair (j, tap): the lower half multiplies reference column j (< 4),
-  // the upper half column 4 + j, so a lane only keeps 5 of the 9 columns
-  for (int idx = tid; idx < 15 * 64; idx += T) {
-    const int l = idx & 63, pp = idx >> 6, ch = l & 31;
-    const int j = pp / 3, tap = pp % 3, hi = l >> 5;
-    const int q = hi ? 4 + j : j;
-    lds[fAc + idx] = (ch < kNC && (hi || j < 4)) ? p.conv_w[ch * 27 + q * 3 + tap] : 0.f;
-  }
-  for (int idx = tid; idx < 2 * 32 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) & 31, rb = idx >> 11;
-    const int m = rb * 32 + (l & 31), k = kchain(c, l >> 5);
-    lds[fA1s + idx] = p.w_1[m * kN1 + k];
-    lds[fA2 + idx] = p.w_2[m * kW + k];
-    lds[fA3 + idx] = p.w_3[m * kW + k];
-  }
-  for (int idx = tid; idx < 2 * 8 * 12 * 64; idx += T) {
-    const int l = idx & 63, q = idx >> 6;
-    const int i = q % 12, pos = (q / 12) & 7, rb = q / 96;
-    const int ch = rrow(i) + 4 * (l >> 5);
-    lds[fA1c + idx] =
-        ch < kNC ? p.w_1[(rb * 32 + (l & 31)) * kN1 + kW + ch * kNP + pos] : 0.f;
-  }
-  for (int idx = tid; idx < 256; idx += T) {
-    const int hi = idx & 1, i = (idx >> 1) & 15, rb = (idx >> 5) & 1, j = idx >> 6;
-    lds[fTo + idx] = p.w_out[j * kW + rb * 32 + rrow(i) + 4 * hi];
-  }
-  for (int idx = tid; idx < 64; idx += T) {
-    const int hi = idx & 1, i = (idx >> 1) & 15, rb = idx >> 5;
-    const int row = rb * 32 + rrow(i) + 4 * hi;
-    lds[fTbs + idx] = p.b_s[row];
-    lds[fTb1 + idx] = p.b_1[row];
-    lds[fTb2 + idx] = p.b_2[row];
-    lds[fTb3 + idx] = p.b_3[row];
-  }
-  for (int idx = tid; idx < 32; idx += T) {
-    const int hi = idx & 1, i = idx >> 1, ch = rrow(i) + 4 * hi;
-    lds[fTbc + idx] = ch < kNC ? p.conv_b[ch] : 0.f;
-  }
-  for (int idx = tid; idx < 4; idx += T) lds[fBo + idx] = p.b_out[idx];
-}
-
 // acc[rb] (row block rb of a 64-wide layer) = bias table at `tab`
 __device__ __forceinline__ void init_bias(f32x16 (&acc)[2], const LdsView &L, int tab) {
 #pragma unroll
@@ -144,48 +78,16 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[2], const LdsView &L, in
     for (int i = 0; i < 16; ++i) acc[rb][i] = L.T(tab + (rb * 16 + i) * 2);
 }
 
-// out[rb_out] += W[rb_out rows][64 inputs] . in    ([2][32][64] A table at `tab`)
-__device__ __forceinline__ void dense64(f32x16 (&out)[2], const f32x16 (&in)[2],
-                                        const LdsView &L, int tab) {
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const float b = in[c >> 4][c & 15];
-    out[0] = mfma(L.A(tab + (0 * 32 + c) * 64), b, out[0]);
-    out[1] = mfma(L.A(tab + (1 * 32 + c) * 64), b, out[1]);
-  }
-}
-
-// The operand tables are gathered ONCE per launch into a global workspace
-// (52 k elements, one small kernel); every workgroup then fills its LDS with a
-// linear, fully coalesced copy instead of 27 k scattered loads of its own.
+// The operand tables are gathered ONCE per launch into a global workspace (one
+// small kernel); every workgroup then fills its LDS with a linear, fully
+// coalesced copy instead of scattered loads of its own.
 struct PackArgs {
   ApgMlpPolicy pol;
   float *dst;
   int head_rows;   // rows of fc_out behind pol.w_out (4: autoregressive, 40: concurrent)
 };
-__global__ __launch_bounds__(256) void mlp_pack_fwd_kernel(PackArgs A) {
-  pack_forward(A.dst, A.pol, blockIdx.x * blockDim.x + threadIdx.x,
-               gridDim.x * blockDim.x);
-}
 
-// dense64 with the previous layer's tanh applied where the input is consumed
-// (and the activation written to its plane): the VALU work of element c sits
-// between the MFMAs of elements c - 1 and c, under the matrix pipe's shadow.
-__device__ __forceinline__ void dense64_tanh(f32x16 (&out)[2], f32x16 (&in)[2],
-                                             const LdsView &L, int tab,
-                                             const Planes &P, int plane0,
-                                             unsigned vr, unsigned pN) {
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const float b = tanh_fast(in[c >> 4][c & 15]);
-    in[c >> 4][c & 15] = b;
-    P.st(vr, (plane0 + (c >> 4) * 32 + rrow(c & 15)) * pN, b);
-    out[0] = mfma(L.A(tab + (0 * 32 + c) * 64), b, out[0]);
-    out[1] = mfma(L.A(tab + (1 * 32 + c) * 64), b, out[1]);
-  }
-}
-
-// Forward tables of the training kernels (fp16 split operands,
+// Forward tables of the kernels (fp16 split operands,
 // policy_mfma16.h): the small fp32 tables indexed by the half-wave first -
 // biases [rb][16][2], the head's VALU weights of the autoregressive sweep
 // [4][2][16][2] + its bias - then 60 A-operand blocks of 2 KB: states_in [rb],
@@ -264,7 +166,7 @@ struct FwdArgs {
   float *states, *actions;
   float *feat, *x1, *h;  // [15][N], [224][N], [192][N] (h1, h2, h3)
   unsigned *mask;        // [5][N]
-  const float *tables;  // packed operand tables (mlp_pack_fwd_kernel)
+  const float *tables;  // packed operand tables (mlp_pack_cfwd_kernel)
   QuadConst c;
   int B;
 };
@@ -296,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = Ps0.ld(vb, i * pitchB);
   // sliding reference window, raw values: columns 0..4 in the lower half,
-  // 4..8 in the upper half (see pack_forward)
+  // 4..8 in the upper half (see cfwd_weight)
   const unsigned vwin = live ? vb + (hi ? 4u * pitchB : 0u) : kDead;
   float w[kH][5];
 #pragma unroll
@@ -475,7 +377,8 @@ struct LoopArgs {
 
 __global__ __launch_bounds__(kThreads) void mlp_closed_loop_kernel(LoopArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwdLds);
+  fill_lds(lds, A.tables, kCfLds);
+  const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -492,7 +395,7 @@ __global__ __launch_bounds__(kThreads) void mlp_closed_loop_kernel(LoopArgs A) {
   const Planes Pss(A.start, A.start ? T * 12 : 0, pitchB);
   const unsigned vb = live ? (unsigned)b * 4u : kDead;
   // window columns of this half-wave: lower (x, y, z, vx, -), upper (vy, vz,
-  // vx, vy, vz) - policy channels 0-3 / 4-8 (see pack_forward); trajectory
+  // vx, vy, vz) - policy channels 0-3 / 4-8 (see cfwd_weight); trajectory
   // columns 6..8 are the velocity
   unsigned vcol[5];
 #pragma unroll
@@ -522,66 +425,86 @@ __global__ __launch_bounds__(kThreads) void mlp_closed_loop_kernel(LoopArgs A) {
     const Trig t = make_trig(&s[3]);
     float feat[kNF];
     quad_features(s, t, feat);
+    // the policy on the 16-bit matrix pipe (policy_mfma16.h), as the forward
+    // training sweep, nothing saved
     f32x16 u[2], a[2];
-    init_bias(u, L, fTbs);
+    init_bias(u, L, hTbs);
+    {
+      float v[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const float odd = 2 * p + 1 < kNF ? feat[2 * p + 1 < kNF ? 2 * p + 1 : 0] : 0.f;
-      const float bv = hi ? odd : feat[2 * p];
-      u[0] = mfma(L.A(fAs + (0 * 8 + p) * 64), bv, u[0]);
-      u[1] = mfma(L.A(fAs + (1 * 8 + p) * 64), bv, u[1]);
+      for (int j = 0; j < 8; ++j)
+        v[j] = hi ? (8 + j < kNF ? feat[8 + j < kNF ? 8 + j : 0] : 0.f) : feat[j];
+      const Op16 x = split8(v);
+      u[0] = mma3(L16.A(hA, nS + 0), x, u[0]);
+      u[1] = mma3(L16.A(hA, nS + 1), x, u[1]);
     }
-    init_bias(a, L, fTb1);
+    init_bias(a, L, hTb1);
     // lower: position columns relative to the drone; upper: the last three
     // columns are reference velocity minus drone velocity
     const float sub[5] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? s[6] : s[2],
                           hi ? s[7] : 0.f, hi ? s[8] : 0.f};
 #pragma unroll
-    for (int pos = 0; pos < kNP; ++pos) {
-      f32x16 cv;
+    for (int pp = 0; pp < kNP / 2; ++pp) {
+      float rv[24];
+      unsigned ws[4][5];  // window rows 2 pp .. 2 pp + 3, split (high | low << 16)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cv[i] = L.T(fTbc + i * 2);
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int p = 0; p < 15; ++p) {
-        const int j = p / 3, tap = p % 3;
-        cv = mfma(L.A(fAc + p * 64), w[pos + tap][j] - sub[j], cv);
-        if (p % 4 == 3 || p == 14) {
-          const int cc = pos * 4 + (p == 14 ? 3 : p / 4);
-          u[cc >> 4][cc & 15] = tanh_fast(u[cc >> 4][cc & 15]);
+        for (int j = 0; j < 5; ++j) {
+          const float xv = w[2 * pp + r][j] - sub[j];
+          const _Float16 vh = (_Float16)xv, vl = (_Float16)(xv - (float)vh);
+          const h16x2 pr = {vh, vl};
+          ws[r][j] = __builtin_bit_cast(unsigned, pr);
         }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x16 cv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cv[i] = L.T(hTbc + i * 2);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          Op16 x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
+            const unsigned r0 = ws[e + s0 % 3][s0 / 3];
+            const unsigned r1 = s1 < 15 ? ws[e + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
+            x.h[q] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);
+            x.l[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
+          }
+          cv = mma3(L16.A(hA, nC + kb), x, cv);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rv[e * 12 + i] = fmaxf(cv[i], 0.f);
       }
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        const float v = fmaxf(cv[i], 0.f);
-        a[0] = mfma(L.A(fA1c + ((0 * 8 + pos) * 12 + i) * 64), v, a[0]);
-        a[1] = mfma(L.A(fA1c + ((1 * 8 + pos) * 12 + i) * 64), v, a[1]);
+      for (int kb = 0; kb < 3; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = rv[kb * 8 + j];
+        const Op16 x = split8(v);
+        a[0] = mma3(L16.A(hA, n1c + (0 * 4 + pp) * 3 + kb), x, a[0]);
+        a[1] = mma3(L16.A(hA, n1c + (1 * 4 + pp) * 3 + kb), x, a[1]);
       }
     }
-    dense64(a, u, L, fA1s);
-#pragma unroll
-    for (int layer = 0; layer < 2; ++layer) {
-      init_bias(u, L, layer ? fTb3 : fTb2);
-#pragma unroll
-      for (int cc = 0; cc < 32; ++cc) {
-        const float bv = tanh_fast(a[cc >> 4][cc & 15]);
-        u[0] = mfma(L.A((layer ? fA3 : fA2) + (0 * 32 + cc) * 64), bv, u[0]);
-        u[1] = mfma(L.A((layer ? fA3 : fA2) + (1 * 32 + cc) * 64), bv, u[1]);
-      }
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) a[rb] = u[rb];
-    }
+    const auto th = [](int, int, float v) { return tanh_fast(v); };
+    dense64_16(a, u, L16, hA, n1s, th);
+    init_bias(u, L, hTb2);
+    dense64_16(u, a, L16, hA, n2, th);
+    init_bias(a, L, hTb3);
+    dense64_16(a, u, L16, hA, n3, th);
     float act[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float z0 = 0.f, z1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        z0 = fmaf(L.T(fTo + ((j * 2 + 0) * 16 + i) * 2), tanh_fast(a[0][i]), z0);
-        z1 = fmaf(L.T(fTo + ((j * 2 + 1) * 16 + i) * 2), tanh_fast(a[1][i]), z1);
+        z0 = fmaf(L.T(hTo + ((j * 2 + 0) * 16 + i) * 2), tanh_fast(a[0][i]), z0);
+        z1 = fmaf(L.T(hTo + ((j * 2 + 1) * 16 + i) * 2), tanh_fast(a[1][i]), z1);
       }
       float z = z0 + z1;
       z += other_half(z);
-      act[j] = fminf(fmaxf(sigmoidf_(z + L.U(fBo + j)), 0.f), 1.f);  // np.clip
+      act[j] = fminf(fmaxf(sigmoidf_(z + L.U(hBo + j)), 0.f), 1.f);  // np.clip
       Pac.st(vrec, (k * 4 + j) * pB, act[j]);
     }
     quad_step(s, act, c, t);
@@ -1310,8 +1233,7 @@ using namespace apg;
 extern "C" {
 
 int apg_quad_mlp_workspace_floats(void) {
-  int n = kFwdLds > kCfLds ? kFwdLds : kCfLds;
-  return n > kCbLds ? n : kCbLds;
+  return kCfLds > kCbLds ? kCfLds : kCbLds;
 }
 
 int apg_quad_mlp_loss_partials_count(int B) {
@@ -1435,7 +1357,7 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
   }
   static bool attr = false;
   if (!attr) {
-    if (int e = raise_lds(mlp_closed_loop_kernel, kFwdLds)) return e;
+    if (int e = raise_lds(mlp_closed_loop_kernel, kCfLds)) return e;
     attr = true;
   }
   LoopArgs A;
@@ -1447,11 +1369,11 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = 4;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mlp_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256),
+  hipLaunchKernelGGL(mlp_pack_cfwd_kernel, dim3((kCfLds + 255) / 256), dim3(256),
                      0, st, P);
   hipLaunchKernelGGL(mlp_closed_loop_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kFwdLds * sizeof(float), st, A);
+                     kCfLds * sizeof(float), st, A);
   return check_launch("quad_mlp_closed_loop");
 }
 

@@ -12,8 +12,10 @@
 // [H][4][B] planes - exactly what that kernel reads - and the reverse kernel
 // starts from its dL/dactions planes.  Same layout as policy_mfma.h: one wave =
 // 32 trajectories, layers chain through the accumulator registers; the two
-// input branches are ONE block-diagonal 12 -> 128 layer.  Weight gradients:
-// cotangent planes x activation planes by apg_planes_gemm_grouped.
+// input branches are ONE block-diagonal 12 -> 128 layer.  Since round 3 the
+// layers are v_mfma_f32_32x32x16_f16 products of fp16-split operands
+// (policy_mfma16.h: fp32 accuracy, cotangents scaled per trajectory).  Weight
+// gradients: cotangent planes x activation planes by apg_planes_gemm_grouped.
 #include "apg_device.h"
 #include "policy_mfma.h"
 #include "policy_mfma16.h"
@@ -29,66 +31,13 @@ constexpr int kThreads = 512;
 constexpr int kTrajPerBlock = kThreads / 2;
 
 // ------------------------------------------------------------------ forward
-constexpr int fT0 = 0;                    // [4][16][2] first-layer bias (b_s, b_r)
-constexpr int fT1 = fT0 + 128;            // [2][16][2] x 3
-constexpr int fT2 = fT1 + 64, fT3 = fT2 + 64;
-constexpr int fA0 = 320;                  // [4][6][64]  block-diagonal first layer
-constexpr int fA1 = fA0 + 4 * 6 * 64;     // [2][64][64] fc1 (128 inputs)
-constexpr int fA2 = fA1 + 2 * 64 * 64;    // [2][32][64]
-constexpr int fA3 = fA2 + 2 * 32 * 64;
-constexpr int fAo = fA3 + 2 * 32 * 64;    // [3][33][64] head + bias pair
-constexpr int kFwdLds = fAo + 3 * 33 * 64;  // 24 576 floats = 98 304 B
-
 struct PackArgs {
   ApgWingPolicy pol;
   float *dst;
   int head_rows;  // rows of fc_out behind pol.w_out / b_out that may be read
 };
 
-__global__ __launch_bounds__(256) void wing_pack_fwd_kernel(PackArgs A) {
-  const ApgWingPolicy &p = A.pol;
-  float *dst = A.dst;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
-  for (int idx = tid; idx < 4 * 6 * 64; idx += T) {
-    const int l = idx & 63, pp = (idx >> 6) % 6, rb = idx / (6 * 64);
-    const int m = rb * 32 + (l & 31), k = 2 * pp + (l >> 5);
-    float v = 0.f;
-    if (m < kW && k < kNS) v = p.w_s[m * kNS + k];
-    if (m >= kW && k >= kNS) v = p.w_r[(m - kW) * kNR + (k - kNS)];
-    dst[fA0 + idx] = v;
-  }
-  for (int idx = tid; idx < 2 * 64 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) & 63, rb = idx >> 12;
-    dst[fA1 + idx] = p.w_1[(rb * 32 + (l & 31)) * kW0 + kchain(c, l >> 5)];
-  }
-  for (int idx = tid; idx < 2 * 32 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) & 31, rb = idx >> 11;
-    const int m = rb * 32 + (l & 31), k = kchain(c, l >> 5);
-    dst[fA2 + idx] = p.w_2[m * kW + k];
-    dst[fA3 + idx] = p.w_3[m * kW + k];
-  }
-  for (int idx = tid; idx < 3 * 33 * 64; idx += T) {
-    const int l = idx & 63, c = (idx >> 6) % 33, rb = idx / (33 * 64);
-    const int m = rb * 32 + (l & 31);
-    float v = 0.f;
-    if (m < A.head_rows) v = c < 32 ? p.w_out[m * kW + kchain(c, l >> 5)]
-                            : (l < 32 ? p.b_out[m] : 0.f);  // bias pair (1, 0)
-    dst[fAo + idx] = v;
-  }
-  for (int idx = tid; idx < 128; idx += T) {
-    const int hi = idx & 1, i = (idx >> 1) & 15, rb = idx >> 5;
-    const int row = rb * 32 + rrow(i) + 4 * hi;
-    dst[fT0 + idx] = row < kW ? p.b_s[row] : p.b_r[row - kW];
-    if (rb < 2) {
-      dst[fT1 + idx] = p.b_1[row];
-      dst[fT2 + idx] = p.b_2[row];
-      dst[fT3 + idx] = p.b_3[row];
-    }
-  }
-}
-
-// Tables of the TRAINING kernels (fp16 split operands, policy_mfma16.h; the
-// closed-loop kernel keeps the fp32 tables above).  Forward: the bias tables
+// Tables (fp16 split operands, policy_mfma16.h).  Forward: the bias tables
 // [rb][16][2] (first layer 4 row blocks, then fc1, fc2, fc3, head 3 row
 // blocks), then 48 A-operand blocks of 2 KB: first layer [rb of 4] (one
 // k-block: inputs 8 hi + j of the 12), fc1 [rb][kb of 8], fc2 / fc3 [rb][kb],
@@ -102,7 +51,7 @@ static_assert(hTo + 96 <= hA / 4, "LDS map");
 // input index of slot j of k-block kb for a layer fed by FOUR row blocks
 // (fc1: 128 inputs) or two (64): registers 8 (kb & 1) .. + 7 of block kb >> 1
 __device__ __forceinline__ float wing_fwd16_weight(const ApgWingPolicy &p, int n, int row,
-                                                   int j, int hi) {
+                                                   int j, int hi, int head_rows) {
   if (n < n1) {                        // [states_in 0; 0 ref_in], inputs 8 hi + j
     const int m = n * 32 + row, k = 8 * hi + j;
     if (m < kW && k < kNS) return p.w_s[m * kNS + k];
@@ -118,7 +67,7 @@ __device__ __forceinline__ float wing_fwd16_weight(const ApgWingPolicy &p, int n
     return n < n3 ? p.w_2[(rb * 32 + row) * kW + k] : p.w_3[(rb * 32 + row) * kW + k];
   }
   const int m = n - nO, rb = m / 4, out = rb * 32 + row;
-  return out < kNA ? p.w_out[out * kW + kin(m % 4, j, hi)] : 0.f;
+  return out < head_rows ? p.w_out[out * kW + kin(m % 4, j, hi)] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void wing_pack_fwd16_kernel(PackArgs A) {
@@ -128,8 +77,8 @@ __global__ __launch_bounds__(256) void wing_pack_fwd16_kernel(PackArgs A) {
   for (int idx = tid; idx < nBlocks16 * 64 * 4; idx += T) {
     const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
     unsigned h, lo;
-    split_pair(wing_fwd16_weight(p, n, l & 31, 2 * q, l >> 5),
-               wing_fwd16_weight(p, n, l & 31, 2 * q + 1, l >> 5), h, lo);
+    split_pair(wing_fwd16_weight(p, n, l & 31, 2 * q, l >> 5, A.head_rows),
+               wing_fwd16_weight(p, n, l & 31, 2 * q + 1, l >> 5, A.head_rows), h, lo);
     dst[(hA + n * kBlock16) / 4 + l * 4 + q] = h;
     dst[(hA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
   }
@@ -142,7 +91,7 @@ __global__ __launch_bounds__(256) void wing_pack_fwd16_kernel(PackArgs A) {
       A.dst[hT2 + idx] = p.b_2[row];
       A.dst[hT3 + idx] = p.b_3[row];
     }
-    if (rb < 3) A.dst[hTo + idx] = row < kNA ? p.b_out[row] : 0.f;
+    if (rb < 3) A.dst[hTo + idx] = row < A.head_rows ? p.b_out[row] : 0.f;
   }
 }
 
@@ -304,7 +253,8 @@ __device__ __forceinline__ float dist3(const float (&a)[3], const float (&b)[3])
 
 __global__ __launch_bounds__(kThreads) void wing_closed_loop_kernel(WingLoopArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwdLds);
+  fill_lds(lds, A.tables, kFwd16Lds);
+  const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -355,51 +305,57 @@ __global__ __launch_bounds__(kThreads) void wing_closed_loop_kernel(WingLoopArgs
         in[kNS + j] = (obs[j] + (rel[j] / nrm) * A.vec_len * A.horizon) - obs[j];
     }
 
-    // the policy (as wing_policy_fwd_kernel, nothing saved, first head block)
+    // the policy (as wing_policy_fwd_kernel: fp16-split operands on the 16-bit
+    // matrix pipe; nothing saved, first head block only)
     f32x16 x[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) x[rb][i] = L.T(fT0 + (rb * 16 + i) * 2);
+      for (int i = 0; i < 16; ++i) x[rb][i] = L.T(hT0 + (rb * 16 + i) * 2);
+    {
+      float v[8];
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
-      const float bv = hi ? in[2 * p + 1] : in[2 * p];
+      for (int j = 0; j < 8; ++j)
+        v[j] = hi ? (8 + j < kNI ? in[8 + j < kNI ? 8 + j : 0] : 0.f) : in[j];
+      const Op16 xi = split8(v);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) x[rb] = mfma(L.A(fA0 + (rb * 6 + p) * 64), bv, x[rb]);
+      for (int rb = 0; rb < 4; ++rb) x[rb] = mma3(L16.A(hA, n0 + rb), xi, x[rb]);
     }
     f32x16 u[2], a[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) a[rb][i] = L.T(fT1 + (rb * 16 + i) * 2);
+      for (int i = 0; i < 16; ++i) a[rb][i] = L.T(hT1 + (rb * 16 + i) * 2);
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
-      const float bv = tanh_fast(x[c >> 4][c & 15]);
-      a[0] = mfma(L.A(fA1 + (0 * 64 + c) * 64), bv, a[0]);
-      a[1] = mfma(L.A(fA1 + (1 * 64 + c) * 64), bv, a[1]);
+    for (int kb = 0; kb < 8; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tanh_fast(x[kb >> 1][8 * (kb & 1) + j]);
+      const Op16 xv = split8(v);
+      a[0] = mma3(L16.A(hA, n1 + kb), xv, a[0]);
+      a[1] = mma3(L16.A(hA, n1 + 8 + kb), xv, a[1]);
     }
+    const auto th = [](int, int, float v) { return tanh_fast(v); };
 #pragma unroll
     for (int layer = 0; layer < 2; ++layer) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          u[rb][i] = L.T((layer ? fT3 : fT2) + (rb * 16 + i) * 2);
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const float bv = tanh_fast(a[c >> 4][c & 15]);
-        u[0] = mfma(L.A((layer ? fA3 : fA2) + (0 * 32 + c) * 64), bv, u[0]);
-        u[1] = mfma(L.A((layer ? fA3 : fA2) + (1 * 32 + c) * 64), bv, u[1]);
-      }
+          u[rb][i] = L.T((layer ? hT3 : hT2) + (rb * 16 + i) * 2);
+      dense64_16(u, a, L16, hA, layer ? n3 : n2, th);
       a[0] = u[0], a[1] = u[1];
     }
     f32x16 z;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    for (int i = 0; i < 16; ++i) z[i] = L.T(hTo + i * 2);
 #pragma unroll
-    for (int c = 0; c < 32; ++c)
-      z = mfma(L.A(fAo + c * 64), tanh_fast(a[c >> 4][c & 15]), z);
-    z = mfma(L.A(fAo + 32 * 64), hi ? 0.f : 1.f, z);
+    for (int kb = 0; kb < 4; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tanh_fast(a[kb >> 1][8 * (kb & 1) + j]);
+      z = mma3(L16.A(hA, nO + kb), split8(v), z);
+    }
     // head rows 0..3 (the first action of the plan) sit in registers 0..3 of
     // the lower half-wave
     float act[4];
@@ -649,8 +605,7 @@ using namespace apg;
 extern "C" {
 
 int apg_wing_policy_workspace_floats(void) {
-  int n = kFwdLds > kFwd16Lds ? kFwdLds : kFwd16Lds;
-  return n > kBwd16Lds ? n : kBwd16Lds;
+  return kFwd16Lds > kBwd16Lds ? kFwd16Lds : kBwd16Lds;
 }
 
 int apg_wing_policy_fwd(const float *feat, const float *ref_in,
@@ -745,7 +700,7 @@ int apg_wing_mlp_closed_loop(const float *targets, int n_targets,
   }
   static bool attr = false;
   if (!attr) {
-    if (int e = raise_lds(wing_closed_loop_kernel, kFwdLds)) return e;
+    if (int e = raise_lds(wing_closed_loop_kernel, kFwd16Lds)) return e;
     attr = true;
   }
   WingLoopArgs A = {};
@@ -761,11 +716,11 @@ int apg_wing_mlp_closed_loop(const float *targets, int n_targets,
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = 4;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wing_pack_fwd_kernel, dim3((kFwdLds + 255) / 256), dim3(256), 0,
+  hipLaunchKernelGGL(wing_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256), 0,
                      st, P);
   hipLaunchKernelGGL(wing_closed_loop_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kFwdLds * sizeof(float), st, A);
+                     kFwd16Lds * sizeof(float), st, A);
   return check_launch("wing_mlp_closed_loop");
 }
 
