@@ -952,3 +952,43 @@ def test_committed_pmc_counters_belong_to_the_committed_kernel_sources():
     assert pmc["quad_B65536_H10_packed"]["buffer_sets"] == 20
     assert (pmc["wing_B131072_H20_soa"]["kernel_build"]
             == bench.kernel_build_id(bench.WING_SOURCES))
+
+
+def test_two_term_fp16_split_reaches_fp32_rounding_level():
+    """The arithmetic behind csrc/policy_mfma16.h, emulated with numpy: operands
+    split into two fp16 terms (x_h = fp16(x), x_l = fp16(x - x_h)), a dot
+    product as W_l x_h + W_h x_l + W_h x_h accumulated in fp32.  For operands
+    in the policy's range (weights ~ U(-0.25, 0.25), tanh activations) the
+    result is as close to the exact product as a plain fp32 evaluation; plain
+    fp16 / bf16 operands are 3 orders of magnitude off; tiny cotangents need
+    the per-trajectory power-of-two scaling the reverse kernels apply."""
+    rng = np.random.default_rng(0)
+    W = ((rng.random((64, 64)) - 0.5) * 0.5).astype(np.float32)
+    x = np.tanh((rng.random((64, 4096)) - 0.5) * 3).astype(np.float32)
+    exact = W.astype(np.float64) @ x.astype(np.float64)
+    scale = np.abs(exact).max()
+
+    def split(a):
+        h = a.astype(np.float16)
+        lo = (a - h.astype(np.float32)).astype(np.float16)
+        return h.astype(np.float32), lo.astype(np.float32)
+
+    def three_products(Wm, xm):
+        Wh, Wl = split(Wm)
+        xh, xl = split(xm)
+        return (Wl @ xh + Wh @ xl + Wh @ xh).astype(np.float32)   # fp32 accumulate
+    err_split = np.abs(three_products(W, x) - exact).max() / scale
+    err_fp32 = np.abs((W @ x) - exact).max() / scale
+    err_fp16 = np.abs(W.astype(np.float16).astype(np.float32)
+                      @ x.astype(np.float16).astype(np.float32) - exact).max() / scale
+    assert err_split < 4 * max(err_fp32, 6e-8) and err_split < 5e-7
+    assert err_fp16 > 100 * err_split
+    # cotangents of magnitude 1e-6: unscaled, the low terms underflow fp16 ...
+    d = (x * 1e-6).astype(np.float32)
+    exact_d = W.astype(np.float64) @ d.astype(np.float64)
+    raw = np.abs(three_products(W, d) - exact_d).max() / np.abs(exact_d).max()
+    # ... scaled per column by the power of two of its largest entry, they do not
+    e = np.frexp(np.abs(d).max(0))[1]
+    scaled = np.ldexp(three_products(W, np.ldexp(d, -e).astype(np.float32)), e)
+    fixed = np.abs(scaled - exact_d).max() / np.abs(exact_d).max()
+    assert fixed < 5e-7 and raw > 20 * fixed
