@@ -1,15 +1,17 @@
 // policy_mfma.h - building blocks shared by the in-kernel policies (mlp.hip,
-// lstm.hip): the policy layers of a trajectory batch on
-// v_mfma_f32_32x32x2_f32 with one wave = 32 trajectories.
+// lstm.hip, mlp_wing.hip): one wave = 32 trajectories, the layers on 32 x 32
+// matrix-core tiles.
 //
-// For D = A B + C with A = weights [32 outputs x 2 k], B = activations
-// [2 k x 32 trajectories]:
-//   A operand: lane l supplies A[l & 31][l >> 5]
-//   B operand: lane l supplies B[l >> 5][l & 31]
-//   C / D    : register i of lane l is row r(i) + 4 (l >> 5), column l & 31,
-//              with r(i) = (i & 3) + 8 (i >> 2).
-// Hence accumulator register i of a layer's output IS the B operand of the
-// next layer for the k-pair (r(i), r(i) + 4) - layers chain with no shuffles.
+// For D = A B + C with A = weights [32 outputs x k], B = activations
+// [k x 32 trajectories], lane l works for trajectory l & 31 (half-wave
+// hi = l >> 5) and the accumulator C / D puts row r(i) + 4 hi, column l & 31
+// into register i, r(i) = (i & 3) + 8 (i >> 2).  An accumulator register of a
+// layer's output is therefore directly an input element of the next layer for
+// the same trajectory - layers chain with no shuffles.  Rounds 1-2 multiplied
+// with v_mfma_f32_32x32x2_f32; since round 3 the operands are split into fp16
+// terms for v_mfma_f32_32x32x16_f16 (policy_mfma16.h, which also defines the
+// operand order).  This header keeps what both share: the accumulator layout,
+// LDS / plane access, tanh.
 #pragma once
 #include "apg_device.h"
 
@@ -32,15 +34,6 @@ constexpr unsigned kDead = 0xFFFFFFFCu;  // buffer offset beyond any tensor
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __host__ __device__ constexpr int rrow(int i) { return (i & 3) + 8 * (i >> 2); }
-// input index fed by accumulator register c & 15 of row block c >> 4
-__host__ __device__ constexpr int kchain(int c, int hi) {
-  return (c >> 4) * 32 + rrow(c & 15) + 4 * hi;
-}
-
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
 // tanh(x) = 1 - 2 / (1 + e^(2x)): one v_exp and one v_rcp, no select.  Exact
 // limits (e -> inf: 1, e -> 0: -1); absolute error <= 2e-7 everywhere (near 0
 // the subtraction cancels, so the RELATIVE error of tiny outputs is larger -
