@@ -166,10 +166,10 @@ SIGNATURES = {
     "apg_to_soa": [_P, _P, _I, _I, _I, _P, _P],
     "apg_to_soa_multi": [ctypes.POINTER(ApgSoaItem), _I, _I, _P],
     "apg_wing_policy_workspace_floats": [],
-    "apg_wing_policy_fwd": [_P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P, _P, _P,
-                            _P, _P],
-    "apg_wing_policy_bwd": [_P, _P, _P, _P, ctypes.POINTER(ApgWingPolicy), _I, _P,
+    "apg_wing_policy_fwd": [_P, _P, ctypes.POINTER(ApgWingPolicy), _I, _I, _P, _P,
                             _P, _P, _P],
+    "apg_wing_policy_bwd": [_P, _P, _P, _P, ctypes.POINTER(ApgWingPolicy), _I, _I,
+                            _P, _P, _P, _P],
     "apg_wing_learnt_param_count": [],
     "apg_wing_learnt_workspace_floats": [_I],
     "apg_wing_learnt_step_fwd": [

@@ -102,7 +102,7 @@ struct Args {
   float *x1, *h;                // [128][B], [192][B]
   float *d_zout, *d_pre;        // [80][B], [320][B]: fc1, fc2, fc3 (64 each), first layer (128)
   const float *tables;
-  int B;
+  int B, NA;   // NA = 4 H head rows in use (40 or 80)
 };
 
 __global__ __launch_bounds__(kThreads) void wing_policy_fwd_kernel(Args A) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void wing_policy_fwd_kernel(Args A) {
   const bool live = b < B;
   const unsigned pN = (unsigned)B * 4u;
   const Planes Pfe(A.feat, kNS, pN), Prf(A.ref_in, kNR, pN);
-  const Planes Pac(A.actions, kNA, pN), Px1(A.x1, kW0, pN), Ph(A.h, 3 * kW, pN);
+  const Planes Pac(A.actions, A.NA, pN), Px1(A.x1, kW0, pN), Ph(A.h, 3 * kW, pN);
   const unsigned vb = live ? (unsigned)b * 4u : kDead;
   const unsigned vr = live ? vb + (hi ? 4u * pN : 0u) : kDead;  // + row 4 hi
 
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(kThreads) void wing_policy_fwd_kernel(Args A) {
   for (int rb = 0; rb < 3; ++rb)
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (rb * 32 + rrow(i) + 4 < kNA)  // rows r(i), r(i) + 4 both < 80
-        Pac.st(vr, (rb * 32 + rrow(i)) * pN, sigmoidf_(z[rb][i]));
+      if (rb * 32 + rrow(i) + 4 < kNA)  // rows r(i), r(i) + 4 both < 80; rows >= NA
+        Pac.st(vr, (rb * 32 + rrow(i)) * pN, sigmoidf_(z[rb][i]));  // are out of range
 }
 
 // ------------------------------------------------------ closed-loop evaluation
@@ -437,10 +437,10 @@ constexpr int mOT = 0, m3T = 10, m2T = 18, m1T = 26, mBlocks16 = 42;
 constexpr int kBwd16Lds = mBlocks16 * kBlock16 / 4;   // 21 504 floats = 86 016 B
 
 __device__ __forceinline__ float wing_bwd16_weight(const ApgWingPolicy &p, int n, int row,
-                                                   int j, int hi) {
+                                                   int j, int hi, int head_rows) {
   if (n < m3T) {
     const int rb = n / 5, c = (n % 5) * 8 + j;       // dz register c: head row khead(c, hi)
-    return p.w_out[khead(c, hi) * kW + rb * 32 + row];
+    return khead(c, hi) < head_rows ? p.w_out[khead(c, hi) * kW + rb * 32 + row] : 0.f;
   }
   if (n < m1T) {
     const int m = (n - m3T) % 8, rb = m / 4, k = kin(m % 4, j, hi);
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(256) void wing_pack_bwd16_kernel(PackArgs A) {
   for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
     const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
     unsigned h, lo;
-    split_pair(wing_bwd16_weight(A.pol, n, l & 31, 2 * q, l >> 5),
-               wing_bwd16_weight(A.pol, n, l & 31, 2 * q + 1, l >> 5), h, lo);
+    split_pair(wing_bwd16_weight(A.pol, n, l & 31, 2 * q, l >> 5, A.head_rows),
+               wing_bwd16_weight(A.pol, n, l & 31, 2 * q + 1, l >> 5, A.head_rows), h, lo);
     dst[(n * kBlock16) / 4 + l * 4 + q] = h;
     dst[(n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
   }
@@ -473,13 +473,14 @@ __global__ __launch_bounds__(kThreads) void wing_policy_bwd_kernel(Args A) {
   const int B = A.B;
   const bool live = b < B;
   const unsigned pN = (unsigned)B * 4u;
-  const Planes Pac(A.actions, kNA, pN), Pga(A.grad_actions, kNA, pN);
+  const Planes Pac(A.actions, A.NA, pN), Pga(A.grad_actions, A.NA, pN);
   const Planes Px1(A.x1, kW0, pN), Ph(A.h, 3 * kW, pN);
-  const Planes Pdz(A.d_zout, kNA, pN), Pdp(A.d_pre, 3 * kW + kW0, pN);
+  const Planes Pdz(A.d_zout, A.NA, pN), Pdp(A.d_pre, 3 * kW + kW0, pN);
   const unsigned vb = live ? (unsigned)b * 4u : kDead;
   const unsigned vr = live ? vb + (hi ? 4u * pN : 0u) : kDead;
 
-  // dL/dz = dL/da * a (1 - a), 40 k-pairs in accumulator layout
+  // dL/dz = dL/da * a (1 - a), 40 k-pairs in accumulator layout (rows beyond
+  // NA are outside the buffers: they load 0 and their stores are dropped)
   float dz[40];
 #pragma unroll
   for (int c = 0; c < 40; ++c) {
@@ -573,6 +574,14 @@ __global__ __launch_bounds__(kThreads) void wing_policy_bwd_kernel(Args A) {
   }
 }
 
+int check_wing_horizon(int H) {
+  if (H != 10 && H != 20) {
+    set_error("the fused fixed-wing policy is built for horizon 10 or 20 (got %d)", H);
+    return APG_ERR_ARG;
+  }
+  return APG_OK;
+}
+
 int check_wing_policy(const ApgWingPolicy *pol, int B) {
   if (!pol) { set_error("policy is NULL"); return APG_ERR_ARG; }
   if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
@@ -609,10 +618,11 @@ int apg_wing_policy_workspace_floats(void) {
 }
 
 int apg_wing_policy_fwd(const float *feat, const float *ref_in,
-                        const ApgWingPolicy *policy, int B, float *actions,
+                        const ApgWingPolicy *policy, int B, int H, float *actions,
                         float *x1, float *h, float *workspace,
                         apg_stream_t stream) {
   if (int e = check_wing_policy(policy, B)) return e;
+  if (int e = check_wing_horizon(H)) return e;
   if (B == 0) return APG_OK;
   if (!feat || !ref_in || !actions || !x1 || !h || !workspace) {
     set_error("NULL buffer");
@@ -625,9 +635,9 @@ int apg_wing_policy_fwd(const float *feat, const float *ref_in,
   }
   Args A = {};
   A.feat = feat, A.ref_in = ref_in, A.actions = actions, A.x1 = x1, A.h = h;
-  A.tables = workspace, A.B = B;
+  A.tables = workspace, A.B = B, A.NA = 4 * H;
   PackArgs P;
-  P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
+  P.pol = *policy, P.dst = workspace, P.head_rows = 4 * H;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wing_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256), 0,
                      st, P);
@@ -639,9 +649,10 @@ int apg_wing_policy_fwd(const float *feat, const float *ref_in,
 
 int apg_wing_policy_bwd(const float *actions, const float *grad_actions,
                         const float *x1, const float *h,
-                        const ApgWingPolicy *policy, int B, float *d_zout,
+                        const ApgWingPolicy *policy, int B, int H, float *d_zout,
                         float *d_pre, float *workspace, apg_stream_t stream) {
   if (int e = check_wing_policy(policy, B)) return e;
+  if (int e = check_wing_horizon(H)) return e;
   if (B == 0) return APG_OK;
   if (!actions || !grad_actions || !x1 || !h || !d_zout || !d_pre || !workspace) {
     set_error("NULL buffer");
@@ -655,9 +666,9 @@ int apg_wing_policy_bwd(const float *actions, const float *grad_actions,
   Args A = {};
   A.actions = const_cast<float *>(actions), A.grad_actions = grad_actions;
   A.x1 = const_cast<float *>(x1), A.h = const_cast<float *>(h);
-  A.d_zout = d_zout, A.d_pre = d_pre, A.tables = workspace, A.B = B;
+  A.d_zout = d_zout, A.d_pre = d_pre, A.tables = workspace, A.B = B, A.NA = 4 * H;
   PackArgs P;
-  P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
+  P.pol = *policy, P.dst = workspace, P.head_rows = 4 * H;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wing_pack_bwd16_kernel, dim3((kBwd16Lds + 255) / 256), dim3(256), 0,
                      st, P);

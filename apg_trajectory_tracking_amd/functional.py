@@ -1541,21 +1541,23 @@ def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
                                  weights=None, index=None):
     """The fixed-wing concurrent training step without the autograd tape:
     loss = fixed_wing_mpc_loss(unroll(dyn, state0, sigmoid(net(normed,
-    in_ref))), ref) for `Net(9, 1, 3, 80, conv=False)` with the policy on the
+    in_ref))), ref) for `Net(9, 1, 3, 4 H, conv=False)`, H = 10 or 20, with the policy on the
     matrix cores (apg_wing_policy_fwd / _bwd) around the fused rollout
     (apg_wing_rollout_fwd_bwd).  normed [B,9], in_ref [B,3], state0 [B,12],
-    ref [B,20,3].  Returns (loss, {parameter name: gradient}, flat) like
+    ref [B,H,3].  Returns (loss, {parameter name: gradient}, flat) like
     quad_concurrent_policy_grads; `index` selects the batch rows out of whole
     data-set tensors in the same way."""
-    B, H = (state0.shape[0] if index is None else index.numel()), 20
+    B, H = (state0.shape[0] if index is None else index.numel()), ref.shape[1]
+    NA = 4 * H
     pw = dict(zip(("w_s", "b_s", "w_r", "b_r", "w_1", "b_1", "w_2", "b_2", "w_3",
                    "b_3", "w_out", "b_out"),
                   (_f32c(v).contiguous() for v in _net_params(net, _WING_PARAMS))))
     if (pw["w_s"].shape != (64, 9) or pw["w_r"].shape != (64, 3)
-            or pw["w_1"].shape != (64, 128) or pw["w_out"].shape != (80, 64)
+            or pw["w_1"].shape != (64, 128) or pw["w_out"].shape != (NA, 64)
+            or H not in (10, 20)
             or normed.shape[1] != 9 or in_ref.reshape(in_ref.shape[0], -1).shape[1] != 3
             or ref.shape[1:] != (H, 3)):
-        raise ValueError("fused path needs Net(9, 1, 3, 80, conv=False), H = 20")
+        raise ValueError("fused path needs Net(9, 1, 3, 4 H, conv=False), H = 10 or 20")
     dev = state0.device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     with torch.no_grad():
@@ -1571,29 +1573,31 @@ def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
         actions = new(H, 4, B)
         ws = new(lib().apg_wing_policy_workspace_floats())
         st = stream_of(acts)
-        check(lib().apg_wing_policy_fwd(ptr(feat), ptr(rin), ctypes.byref(pol), B,
+        check(lib().apg_wing_policy_fwd(ptr(feat), ptr(rin), ctypes.byref(pol), B, H,
                                         ptr(actions), ptr(x1), ptr(h), ptr(ws), st),
               "apg_wing_policy_fwd")
         res = wing_rollout_fwd_bwd(s0_planes, actions, ref_planes, dt, params,
                                    weights, layout="soa", want_grad_state0=False)
-        cot = new(80 + 320, B)
-        d_zout, d_pre = cot[:80], cot[80:]
+        cot = new(NA + 320, B)
+        d_zout, d_pre = cot[:NA], cot[NA:]
         check(lib().apg_wing_policy_bwd(
             ptr(actions), ptr(res["grad_actions"]), ptr(x1), ptr(h),
-            ctypes.byref(pol), B, ptr(d_zout), ptr(d_pre), ptr(ws), st),
+            ctypes.byref(pol), B, H, ptr(d_zout), ptr(d_pre), ptr(ws), st),
             "apg_wing_policy_bwd")
         flat, gr = _flat_grads(dev, {
             "states_in.weight": (64, 9), "states_in.bias": (64,),
             "ref_in.weight": (64, 3), "ref_in.bias": (64,),
             "fc1.weight": (64, 128), "fc1.bias": (64,), "fc2.weight": (64, 64),
             "fc2.bias": (64,), "fc3.weight": (64, 64), "fc3.bias": (64,),
-            "fc_out.weight": (80, 64), "fc_out.bias": (80,)})
+            "fc_out.weight": (NA, 64), "fc_out.bias": (NA,)})
         R = lambda lo, hi_: make_bdesc(dev, range(lo, hi_), key=("wing", lo, hi_))
-        _run_products([
-            dict(A=d_zout[:64], M=64, S=1, Bp=acts, bdesc=R(268, 332),
-                 out=gr["fc_out.weight"][:64], bias_out=gr["fc_out.bias"][:64]),
-            dict(A=d_zout[64:], M=16, S=1, Bp=acts, bdesc=R(268, 332),
-                 out=gr["fc_out.weight"][64:], bias_out=gr["fc_out.bias"][64:]),
+        head = [dict(A=d_zout[:min(NA, 64)], M=min(NA, 64), S=1, Bp=acts,
+                     bdesc=R(268, 332), out=gr["fc_out.weight"][:64],
+                     bias_out=gr["fc_out.bias"][:64])]
+        if NA > 64:       # M <= 64 per product: the 80-row head in two parts
+            head.append(dict(A=d_zout[64:], M=NA - 64, S=1, Bp=acts, bdesc=R(268, 332),
+                             out=gr["fc_out.weight"][64:], bias_out=gr["fc_out.bias"][64:]))
+        _run_products(head + [
             dict(A=d_pre[128:192], M=64, S=1, Bp=acts, bdesc=R(204, 268),
                  out=gr["fc3.weight"], bias_out=gr["fc3.bias"]),
             dict(A=d_pre[64:128], M=64, S=1, Bp=acts, bdesc=R(140, 204),

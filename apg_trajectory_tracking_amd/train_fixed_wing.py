@@ -141,11 +141,11 @@ class TrainFixedWing(TrainBase):
         with the policy inside HIP kernels (functional.wing_concurrent_policy_grads)."""
         n = self.net
         if not (self.fused_policy and isinstance(n, Net) and not n.conv
-                and self.horizon == 20 and self.analytic_train_dynamics()
+                and self.horizon in (10, 20) and self.analytic_train_dynamics()
                 and n.states_in.weight.shape == (64, 9)
                 and n.ref_in.weight.shape == (64, 3)
                 and n.fc1.weight.shape == (64, 128)
-                and n.fc_out.weight.shape == (80, 64)):
+                and n.fc_out.weight.shape == (4 * self.horizon, 64)):
             return False if probe else None
         if probe:
             return True

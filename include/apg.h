@@ -468,27 +468,29 @@ typedef struct ApgWingPolicy {
   const float *b_2;    /* [64] */
   const float *w_3;    /* [64][64]  fc3.weight */
   const float *b_3;    /* [64] */
-  const float *w_out;  /* [80][64]  fc_out.weight */
-  const float *b_out;  /* [80] */
+  const float *w_out;  /* [4 H][64] fc_out.weight */
+  const float *b_out;  /* [4 H] */
 } ApgWingPolicy;
 
 /* Policy part of the fixed-wing concurrent step on the matrix cores
  * (scripts/train_base.py:198-204: actions = sigmoid(net(in_state,
- * in_ref_state))).  Forward: feat [9][B] (normed_states), ref_in [3][B] ->
- * actions [80][B] = [H = 20][4][B], the SoA action sequence of
+ * in_ref_state))) for Net(9, 1, 3, 4 H, conv=False), H = 20 (BASELINE config
+ * 4) or 10 (the horizon of the reference's shipped configs/wing_config.json;
+ * w_out / b_out then have 40 rows).  Forward: feat [9][B] (normed_states),
+ * ref_in [3][B] -> actions [4 H][B] = [H][4][B], the SoA action sequence of
  * apg_wing_rollout_fwd_bwd; saved x1 [128][B], h [192][B] (h1, h2, h3).
- * Reverse: from grad_actions [80][B] (that kernel's dL/dactions) -> d_zout
- * [80][B] and d_pre [320][B] (fc1, fc2, fc3 pre-activation cotangents, 64
+ * Reverse: from grad_actions [4 H][B] (that kernel's dL/dactions) -> d_zout
+ * [4 H][B] and d_pre [320][B] (fc1, fc2, fc3 pre-activation cotangents, 64
  * planes each, then the first layer's 128); weight gradients by
  * apg_planes_gemm(_grouped).  workspace: apg_wing_policy_workspace_floats(). */
 int apg_wing_policy_workspace_floats(void);
 int apg_wing_policy_fwd(const float *feat, const float *ref_in,
-                        const ApgWingPolicy *policy, int B, float *actions,
+                        const ApgWingPolicy *policy, int B, int H, float *actions,
                         float *x1, float *h, float *workspace,
                         apg_stream_t stream);
 int apg_wing_policy_bwd(const float *actions, const float *grad_actions,
                         const float *x1, const float *h,
-                        const ApgWingPolicy *policy, int B, float *d_zout,
+                        const ApgWingPolicy *policy, int B, int H, float *d_zout,
                         float *d_pre, float *workspace, apg_stream_t stream);
 
 /* Closed-loop evaluation of the fixed-wing controller - beyond SURVEY.md §8:

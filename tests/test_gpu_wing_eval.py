@@ -277,3 +277,46 @@ def test_wing_entry_points_end_to_end(dev, tmp_path, monkeypatch):
     dyn_sd = torch.load(tmp_path / "trained_models" / "wing" / "e2e_dyn" /
                         "dynamics_model", map_location="cpu")
     assert "I" in dyn_sd and "cfg.mass" in dyn_sd and "linear_state_1.weight" in dyn_sd
+
+
+@pytest.mark.parametrize("B", [48, 1000])
+def test_fused_wing_step_at_the_reference_horizon_of_ten(dev, B):
+    """The fused fixed-wing training step (policy on the matrix cores) also
+    takes horizon 10 - the horizon of the reference's own configs/
+    wing_config.json and of the controller it ships (head of 40 rows): two SGD
+    steps equal the torch-policy-around-the-fused-rollout path, and the
+    trainer picks the fused step for it."""
+    import copy
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dataset import SyntheticWingDataset
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    from apg_trajectory_tracking_amd.train_fixed_wing import TrainFixedWing
+    H, dt = 10, 0.05
+    cfg = dict(delta_t=dt, delta_t_train=dt, epoch_size=B, self_play=0, batch_size=B,
+               state_size=12, horizon=H, ref_dim=3, action_dim=4,
+               learning_rate_controller=1e-7, system="wing", modified_params={})
+    data = SyntheticWingDataset(B, H, dt, seed=5, device=dev)
+    proto = wing_loop_policy("cpu")              # the shipped Net(9, 1, 3, 40)
+    runs = []
+    for fused in (False, True):
+        t = TrainFixedWing(FixedWingDynamics(), FixedWingDynamics(), dict(cfg))
+        t.net = copy.deepcopy(proto).to(dev).train()
+        t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=1e-7, momentum=0.9)
+        assert t.train_concurrent_fused(None, None, None, None, probe=True)
+        losses = []
+        for _ in range(2):
+            if fused:
+                loss = t.train_concurrent_fused(data.normed_states, data.states,
+                                                data.in_ref_states, data.ref_states)
+            else:
+                acts = torch.sigmoid(t.net(data.normed_states, data.in_ref_states))
+                loss = t.train_controller_model(data.states, acts.reshape(-1, H, 4),
+                                                data.in_ref_states, data.ref_states)
+            losses.append(loss.item())
+        runs.append((losses, {k: v.clone() for k, v in t.net.state_dict().items()}))
+    (la, wa), (lb, wb) = runs
+    assert np.allclose(la, lb, rtol=1e-5), (la, lb)
+    assert la[1] != la[0]
+    for k in wa:
+        assert rel_err(wb[k].cpu().numpy(), wa[k].cpu().numpy()) < 1e-5, k
