@@ -170,6 +170,8 @@ SIGNATURES = {
                             _P, _P, _P],
     "apg_wing_policy_bwd": [_P, _P, _P, _P, ctypes.POINTER(ApgWingPolicy), _I, _I,
                             _P, _P, _P, _P],
+    "apg_linear_wgrad_workspace_floats": [_I, _I],
+    "apg_linear_wgrad": [_P, _P, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
     "apg_wing_learnt_param_count": [],
     "apg_wing_learnt_workspace_floats": [_I],
     "apg_wing_learnt_step_fwd": [
@@ -214,7 +216,8 @@ SIGNATURES = {
     "apg_last_error_string": [],
 }
 _RESTYPES = {"apg_last_error_string": ctypes.c_char_p,
-             "apg_planes_gemm_multi_workspace_floats": ctypes.c_longlong}
+             "apg_planes_gemm_multi_workspace_floats": ctypes.c_longlong,
+             "apg_linear_wgrad_workspace_floats": ctypes.c_longlong}
 
 _lib = None
 

@@ -12,7 +12,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libapg_hip.so")
 SOURCES = ["common.hip", "quad.hip", "wing.hip", "cartpole.hip", "lstm.hip",
-           "mlp.hip", "mlp_wing.hip", "wing_learnt.hip",
+           "mlp.hip", "mlp_wing.hip", "wing_learnt.hip", "linear_wgrad.hip",
            "planes_gemm.hip"]
 # -fno-slp-vectorize: hipcc's SLP pass packs neighbouring f32 ops into
 # v_pk_fma/mul/add_f32; on gfx950 a packed op issues no faster than two plain

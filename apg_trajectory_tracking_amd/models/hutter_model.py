@@ -4,6 +4,8 @@ Linear over the flattened window), three 64-wide tanh layers, linear head."""
 import torch
 import torch.nn as nn
 
+from ..nn import Linear
+
 from .common import (CONV_CHANNELS, CONV_KERNEL, DENSE_WIDTH, encode_window,
                      window_feature_count)
 
@@ -17,12 +19,12 @@ class Net(nn.Module):
         self.horizon, self.conv = horizon, conv
         self.reshape_len = window_feature_count(horizon, conv)
         # registration order = the reference's state_dict order
-        self.states_in = nn.Linear(state_dim, W)
+        self.states_in = Linear(state_dim, W)
         self.conv_ref = nn.Conv1d(ref_dim, CONV_CHANNELS, kernel_size=CONV_KERNEL)
-        self.ref_in = nn.Linear(horizon * ref_dim, W)     # conv=False branch
-        self.fc1 = nn.Linear(W + self.reshape_len, W)
-        self.fc2, self.fc3 = nn.Linear(W, W), nn.Linear(W, W)
-        self.fc_out = nn.Linear(W, nr_actions_predict)
+        self.ref_in = Linear(horizon * ref_dim, W)     # conv=False branch
+        self.fc1 = Linear(W + self.reshape_len, W)
+        self.fc2, self.fc3 = Linear(W, W), Linear(W, W)
+        self.fc_out = Linear(W, nr_actions_predict)
 
     def trunk(self, state, ref):
         """Everything up to (not including) the output layer: [B,64]."""

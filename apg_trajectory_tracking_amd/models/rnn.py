@@ -7,6 +7,8 @@ the steps of one unroll and re-drawn from N(0,1) by reset_hidden_state()
 import torch
 import torch.nn as nn
 
+from ..nn import Linear
+
 from .common import (CONV_CHANNELS, CONV_KERNEL, DENSE_WIDTH, encode_window,
                      window_feature_count)
 
@@ -23,8 +25,8 @@ class LSTM_NEW(nn.Module):
         self.reshape_len = window_feature_count(horizon, conv)
         # registration order = the reference's state_dict order
         self.conv_ref = nn.Conv1d(ref_dim, CONV_CHANNELS, kernel_size=CONV_KERNEL)
-        self.ref_in = nn.Linear(horizon * ref_dim, DENSE_WIDTH)
-        self.fc_out = nn.Linear(HIDDEN, nr_actions_predict)
+        self.ref_in = Linear(horizon * ref_dim, DENSE_WIDTH)
+        self.fc_out = Linear(HIDDEN, nr_actions_predict)
         self.lstm = nn.LSTMCell(state_dim + self.reshape_len, HIDDEN)
         self.hidden_state = self.cell_state = None
         self.reset_hidden_state(1)

@@ -5,16 +5,18 @@ the policy and the caller's tensor is modified."""
 import torch
 import torch.nn as nn
 
+from ..nn import Linear
+
 
 class Net(nn.Module):
 
     def __init__(self, in_size, out_size):
         super().__init__()
-        self.fc0 = nn.Linear(in_size, 32)
-        self.fc1 = nn.Linear(32, 64)
-        self.fc2 = nn.Linear(64, 64)
-        self.fc3 = nn.Linear(64, 32)
-        self.fc_out = nn.Linear(32, out_size)
+        self.fc0 = Linear(in_size, 32)
+        self.fc1 = Linear(32, 64)
+        self.fc2 = Linear(64, 64)
+        self.fc3 = Linear(64, 32)
+        self.fc_out = Linear(32, out_size)
 
     def forward(self, x):
         x[:, 0] *= 0

@@ -371,6 +371,20 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
         out["what"] = ("TrainDrone.train_controller_packed: PyTorch policy (not the "
                        "reference architecture) -> [H, B, 4] action rows -> "
                        "quad_rollout_rows_kernel -> policy backward (rocBLAS) + SGD")
+        # the same policy with the library's drop-in Linear (nn.py: weight
+        # gradients by apg_linear_wgrad instead of rocBLAS)
+        from apg_trajectory_tracking_amd import nn as apg_nn
+        for name in ("a", "b", "c"):
+            old = getattr(t.net, name)
+            new = apg_nn.Linear(old.in_features, old.out_features).to(dev)
+            new.load_state_dict(old.state_dict())
+            setattr(t.net, name, new)
+        t.init_optimizer()
+        ms2, _ = timed_steps(step, args.train_steps, dist)
+        out["with_apg_nn_linear"] = {
+            "ms_per_step": ms2,
+            "what": "the same step, the policy's three layers as "
+                    "apg_trajectory_tracking_amd.nn.Linear"}
     else:
         fused = {"concurrent": t.train_concurrent_fused(None, None, None, None, probe=True),
                  "autoregressive": t.fused_policy and t._fusable_mlp(),

@@ -441,6 +441,17 @@ int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspac
                           apg_stream_t stream);
 
 /* ---------------------------------------------------------- fixed wing --- */
+/* Weight gradient of a PyTorch-side policy layer y = x W^T + b (where the
+ * policy is not inside a kernel: scripts/train_base.py:198-209 ->
+ * loss.backward() on torch.nn.Linear): dW[m][n] = sum_b dY[b][m] X[b][n] and,
+ * if db is not NULL, db[m] = sum_b dY[b][m], for row-major dY [B, M], X [B, N]
+ * (each below 4 GiB).  Split-K over the whole chip on the fp32 matrix
+ * instruction, fixed summation order.  workspace:
+ * apg_linear_wgrad_workspace_floats(M, N) device floats. */
+long long apg_linear_wgrad_workspace_floats(int M, int N);
+int apg_linear_wgrad(const float *dY, const float *X, long long B, int M, int N,
+                     float *dW, float *db, float *workspace, apg_stream_t stream);
+
 /* Parameters of neural_control/dynamics/fixed_wing_dynamics.py:18-39 +
  * config_fixed_wing.json after `cfg.update(modified_params)`. */
 typedef struct ApgWingParams {

@@ -1,0 +1,111 @@
+"""apg_linear_wgrad / apg_trajectory_tracking_amd.nn.Linear on the GPU: the
+weight gradient of a PyTorch-side policy layer against torch's own (float64)
+and the drop-in module against torch.nn.Linear through a training step."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,M,N,bias", [
+    (1, 4, 8, True), (7, 64, 15, True), (300, 64, 224, True), (301, 40, 64, False),
+    (65536, 64, 64, True), (65537, 80, 64, True), (4099, 200, 300, True),
+    (131072, 64, 128, True)])
+def test_wgrad_vs_float64(dev, B, M, N, bias):
+    """dW = dY^T X and db = sum dY: one row, odd row counts (the pair of a last
+    single row lies beyond the tensors), widths that are no multiple of 32,
+    several 64 x 128 tiles, the benchmark batch."""
+    from apg_trajectory_tracking_amd import nn as apg_nn
+    g = torch.Generator().manual_seed(B + M)
+    x = torch.randn(B, N, generator=g)
+    w = torch.randn(M, N, generator=g) * 0.1
+    b = torch.randn(M, generator=g) if bias else None
+    dy = torch.randn(B, M, generator=g)
+    xd = x.to(dev)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    y = apg_nn.linear(xd, wd, bd)
+    assert isinstance(y.grad_fn, apg_nn._LinearWgrad._backward_cls)
+    y.backward(dy.to(dev))
+    want_w = dy.double().t() @ x.double()
+    assert rel_err(wd.grad.cpu().numpy(), want_w.numpy()) < 1e-5
+    if bias:
+        assert rel_err(bd.grad.cpu().numpy(), dy.double().sum(0).numpy()) < 1e-5
+    ref = torch.nn.functional.linear(x.double(), w.double(), None if b is None else b.double())
+    assert rel_err(y.detach().cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_input_gradient_and_leading_dimensions(dev):
+    """dL/dx is the plain product; inputs with more than two dimensions are
+    flattened over their leading ones like torch.nn.Linear does."""
+    from apg_trajectory_tracking_amd import nn as apg_nn
+    torch.manual_seed(3)
+    lin = apg_nn.Linear(9, 20).to(dev)
+    ref = torch.nn.Linear(9, 20).to(dev)
+    ref.load_state_dict(lin.state_dict())
+    x = torch.randn(6, 10, 9, device=dev, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    cot = torch.randn(6, 10, 20, device=dev)
+    (lin(x) * cot).sum().backward()
+    (ref(x2) * cot).sum().backward()
+    assert rel_err(x.grad.cpu().numpy(), x2.grad.cpu().numpy()) < 1e-6
+    assert rel_err(lin.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 1e-5
+    assert rel_err(lin.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 1e-5
+    with torch.no_grad():                      # no tape: plain F.linear
+        assert lin(x).grad_fn is None
+    cpu = apg_nn.Linear(9, 20)                 # CPU tensors: it IS torch.nn.Linear
+    xc = torch.randn(5, 9)
+    assert torch.equal(cpu(xc), torch.nn.functional.linear(xc, cpu.weight, cpu.bias))
+    cpu(xc).sum().backward()
+    assert cpu.weight.grad is not None
+
+
+def test_policy_step_equals_torch_linear_layers(dev):
+    """hutter_model.Net (the package's policy class, built on the drop-in
+    Linear) through two optimizer steps of the row-layout training path
+    against the same network with torch.nn.Linear layers."""
+    import copy
+    from apg_trajectory_tracking_amd.dataset import SyntheticQuadDataset
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    B, H = 1000, 10
+    cfg = dict(delta_t=0.1, delta_t_train=0.1, epoch_size=B, self_play=0, batch_size=B,
+               state_size=12, horizon=H, train_mode="concurrent", ref_dim=9,
+               action_dim=4, learning_rate_controller=1e-6, system="quad",
+               modified_params={})
+    data = SyntheticQuadDataset(B, H, 0.1, seed=3, device=dev)
+    torch.manual_seed(0)
+    proto = Net(15, H, 9, 4 * H, conv=1)
+    runs = []
+    for plain in (False, True):
+        net = copy.deepcopy(proto)
+        if plain:
+            for name, mod in list(net.named_children()):
+                if isinstance(mod, torch.nn.Linear):
+                    lin = torch.nn.Linear(mod.in_features, mod.out_features)
+                    lin.load_state_dict(mod.state_dict())
+                    setattr(net, name, lin)
+        dyn = FlightmareDynamics()
+        t = TrainDrone(dyn, dyn, dict(cfg))
+        t.net = net.to(dev)
+        t.state_data = data
+        t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=1e-6, momentum=0.9)
+        rows = data.packed()
+        losses = [t.train_controller_packed(data.normed_states, data.in_ref_states,
+                                            *rows).item() for _ in range(2)]
+        runs.append((losses, {k: v.clone() for k, v in t.net.state_dict().items()}))
+    (la, wa), (lb, wb) = runs
+    assert np.allclose(la, lb, rtol=1e-5), (la, lb)
+    for k in wa:
+        assert rel_err(wa[k].cpu().numpy(), wb[k].cpu().numpy()) < 1e-5, k
