@@ -252,8 +252,12 @@ class TrainBase:
             return fn()
 
         def signature():
+            # + the parameter tensors and the optimizer the capture is tied to
+            # (a replaced network or optimizer must not replay the old graph)
             return (tuple((id(t), t._version, tuple(t.shape)) for t in inputs)
-                    + tuple((id(t), tuple(t.shape)) for t in volatile))
+                    + tuple((id(t), tuple(t.shape)) for t in volatile)
+                    + tuple(id(p) for p in self.net.parameters())
+                    + (id(self.optimizer_controller),))
         sig = signature()
         g = self._graphs.get(key)
         if g is None or g.signature != sig:

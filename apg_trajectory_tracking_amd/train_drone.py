@@ -244,12 +244,20 @@ class TrainDrone(TrainBase):
         state0_rows [3, B, 4], ref_rows [H, B, 6] = [pos, vel]; policy inputs
         in the reference's layout.  Same arithmetic as run_epoch's concurrent
         body followed by train_controller_model."""
-        self.optimizer_controller.zero_grad()
-        action_rows = self.policy_action_rows(in_state, in_ref_states)
-        loss = F.quad_rollout_loss(
-            state0_rows, action_rows, ref_rows, self.delta_t,
-            self.train_dynamics.params, layout="packed")
-        return self._step(loss)
+        def step():
+            self.optimizer_controller.zero_grad()
+            action_rows = self.policy_action_rows(in_state, in_ref_states)
+            loss = F.quad_rollout_loss(
+                state0_rows, action_rows, ref_rows, self.delta_t,
+                self.train_dynamics.params, layout="packed")
+            return self._step(loss).detach()
+        if self.static_shard:
+            # resident tensors: forward, autograd's backward and the update are
+            # captured once and replayed (graph_steps; the policy is arbitrary
+            # PyTorch code, so ~40 small launches per step otherwise)
+            return self._graphed("packed", (in_state, in_ref_states, state0_rows,
+                                            ref_rows), step)
+        return step()
 
     def _fusable_learnt(self):
         from .dynamics.quad_dynamics_trained import LearntDynamics
