@@ -928,7 +928,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
   // ---- policy forward on the 16-bit matrix pipe (policy_mfma16.h): every
   // operand as two fp16 terms, three products per k-block
   const LdsView16 L16(lds, lane);
-  const auto ident = [](int, int, float v) { return v; };
   f32x16 u[2], a[2];
   init_bias(u, L, hTbs);
   {  // states_in: one k-block, features 8 hi .. 8 hi + 7
@@ -1021,7 +1020,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
     Ph.st(vr, (2 * kW + rb * 32 + rrow(i)) * pN, tv);
     return tv;
   });
-  (void)ident;
   // every lane needs all 40 actions (both halves run the same rollout)
   float act[kH][4];
 #pragma unroll
