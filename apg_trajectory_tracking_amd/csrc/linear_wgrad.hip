@@ -21,19 +21,20 @@ namespace apg {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kTM = 2;                 // tile: 64 x (TN * 32) outputs per workgroup column,
-                                      // TN = 4, or 2 for layers of at most 64 inputs
+// 64 x 64 outputs per workgroup column: 208 registers per wave leave room for
+// two workgroups per CU (a 64 x 128 tile - 352 registers, one wave per SIMD -
+// measured 2-4 x slower per byte, profiles/r03_linear_wgrad.jsonl)
+constexpr int kTM = 2, kTN = 2;
 constexpr int kThreads = 256;
 constexpr int kUnroll = 4;            // row pairs in flight per wave
 
 struct WgradArgs {
   const float *dY, *X;
-  float *part;          // [split][tiles][kTM*32][TN*32 + 1]
+  float *part;          // [split][tiles][kTM*32][kTN*32 + 1]
   long long B;
   int M, N, split;
 };
 
-template <int kTN>
 __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(WgradArgs A) {
   constexpr int kW = kTN * 32 + 1;    // partial row pitch; last column = row sums
   __shared__ float red[kTM * 32 * kW];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(WgradArgs A) {
 struct WreduceArgs {
   const float *part;
   float *dW, *db;
-  int M, N, split, tiles_n, tiles, TN;
+  int M, N, split, tiles_n, tiles;
 };
 
 // dW[m][n] (and db[m]) = sum over the split: 32 outputs per workgroup, 32
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(1024) void linear_wgrad_reduce_kernel(WreduceArgs R
   __shared__ double sh[32][33];
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
   const int idx = blockIdx.x * 32 + x;
-  const int cols = R.N + 1, kTN = R.TN, kW = kTN * 32 + 1;
+  const int cols = R.N + 1, kW = kTN * 32 + 1;
   const bool ok = idx < R.M * cols;
   const int m = ok ? idx / cols : 0, n = ok ? idx % cols : 0;
   // column N of the output = the row sums, kept by the FIRST tile of each tile row
@@ -209,13 +210,9 @@ int cu_count_() {
   return n;
 }
 
-void shape(int M, int N, int &tm, int &tn, int &TN, int &split) {
-  // 64 x 64 tiles: 208 registers per wave leave room for two workgroups per
-  // CU; the 64 x 128 instance (352 registers, one wave per SIMD) measured
-  // 2-4 x slower per byte and is only kept for experiments
-  TN = 2;
+void shape(int M, int N, int &tm, int &tn, int &split) {
   tm = (M + kTM * 32 - 1) / (kTM * 32);
-  tn = (N + TN * 32 - 1) / (TN * 32);
+  tn = (N + kTN * 32 - 1) / (kTN * 32);
   // two workgroups per CU over all tiles, at least one per tile
   split = (2 * cu_count_() + tm * tn - 1) / (tm * tn);
   if (split < 1) split = 1;
@@ -230,9 +227,9 @@ extern "C" {
 
 long long apg_linear_wgrad_workspace_floats(int M, int N) {
   if (M < 1 || N < 1) return 0;
-  int tm, tn, TN, split;
-  shape(M, N, tm, tn, TN, split);
-  return (long long)split * tm * tn * (kTM * 32 * (TN * 32 + 1));
+  int tm, tn, split;
+  shape(M, N, tm, tn, split);
+  return (long long)split * tm * tn * (kTM * 32 * (kTN * 32 + 1));
 }
 
 int apg_linear_wgrad(const float *dY, const float *X, long long B, int M, int N,
@@ -258,20 +255,17 @@ int apg_linear_wgrad(const float *dY, const float *X, long long B, int M, int N,
     }
     return APG_OK;
   }
-  int tm, tn, TN, split;
-  shape(M, N, tm, tn, TN, split);
+  int tm, tn, split;
+  shape(M, N, tm, tn, split);
   // no more workgroups along the rows than groups of row pairs
   const long long groups = ((B + 1) / 2 + kUnroll - 1) / kUnroll;
   if ((long long)split * 4 > groups) split = (int)((groups + 3) / 4);
   WgradArgs A;
   A.dY = dY, A.X = X, A.part = workspace, A.B = B, A.M = M, A.N = N, A.split = split;
-  if (TN == 2)
-    hipLaunchKernelGGL(linear_wgrad_kernel<2>, dim3(split, tn, tm), dim3(kThreads), 0, st, A);
-  else
-    hipLaunchKernelGGL(linear_wgrad_kernel<4>, dim3(split, tn, tm), dim3(kThreads), 0, st, A);
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(split, tn, tm), dim3(kThreads), 0, st, A);
   WreduceArgs R;
   R.part = workspace, R.dW = dW, R.db = db, R.M = M, R.N = N, R.split = split;
-  R.tiles_n = tn, R.tiles = tm * tn, R.TN = TN;
+  R.tiles_n = tn, R.tiles = tm * tn;
   hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((M * (N + 1) + 31) / 32), dim3(1024),
                      0, st, R);
   return check_launch("linear_wgrad");
