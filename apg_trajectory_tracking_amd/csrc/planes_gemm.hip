@@ -10,7 +10,8 @@
 // shape and takes 1.5 ms per call; this kernel streams both operands from HBM
 // once and is bound by that stream.  Two kernels:
 //  * plain products (S = 1; six of the seven of an autoregressive step):
-//    planes_gemm_stream_kernel - global -> registers -> v_mfma_f32_16x16x4_f32,
+//    planes_gemm_stream_kernel - global -> registers -> v_mfma_f32_16x16x32_bf16
+//    on exact three-term bf16 splits of the fp32 operands,
 //    split-K over all waves, no LDS tile (described at stream_body below);
 //  * segmented products (S > 1) and the grouped launch for short planes:
 //    planes_gemm_kernel, the LDS-tile kernel described next.  Its per-column
@@ -272,12 +273,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
 
 // ---------------------------------------------------------------------------
 // The long-plane kernel: operands go global -> registers -> matrix core, no
-// LDS tile and no barrier in the main loop.  With v_mfma_f32_16x16x4_f32 lane
-// l supplies A[l & 15][k = l >> 4] and B[k = l >> 4][l & 15]; the reduction
-// index may be permuted freely as long as A and B agree, so lane (i, g) loads
-// 8 CONSECUTIVE floats of its row's plane (two 16-byte loads at column
-// 32 c + 8 g) and the m-th of them is its operand of the m-th MFMA of the
-// chunk: 16 rows x 128 contiguous bytes per load pair, every operand element
+// LDS tile and no barrier in the main loop.  Lane (i, g) = (l & 15, l >> 4)
+// loads 8 CONSECUTIVE floats of row i's plane (two 16-byte loads at column
+// 32 c + 8 g): the lane's 8 k-slots of a 16 x 16 x 32 matrix instruction
+// (split3 / mfma_bf16 above); 16 rows x 128 contiguous bytes per load pair, every operand element
 // is fetched exactly once, and each wave streams its own chunks of 32 columns
 // (split-K over all waves of the grid) with the next chunk's loads in flight
 // while this one multiplies (S = 1 products only: the segmented conv product
@@ -289,6 +288,52 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
 constexpr unsigned kDeadOff2 = 0xffffff00u;  // + the 16-byte immediate: still out of range
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// The stream kernel's matrix instruction.  v_mfma_f32_16x16x4_f32 (rounds 1-2)
+// took 8 instructions of 32 cycles per chunk and tile: for the 4 x 7 shape
+// 7 168 cycles per chunk against ~11 500 of memory time at the HBM rate, and
+// the two only overlap in steady state - the short planes of the grouped
+// launch (6-9 chunks per wave) paid their sum.  With v_mfma_f32_16x16x32_bf16
+// lane l supplies A[l & 15][k-slots 8 (l >> 4) + j] - exactly the 8 consecutive
+// floats the lane has loaded - so a chunk is ONE instruction (~17 cycles) per
+// product of terms.  Every fp32 operand is cut into THREE bf16 terms by
+// truncation, x = h + m + l exactly (8 + 8 + 8 significant bits; bf16 has
+// fp32's exponent, so cotangents need no scaling), and a tile takes the six
+// products of weight >= 2^-16 (h h, h m, m h, m m, h l, l h): what is dropped
+// is <= 2^-23 of |a||b| per product, the rounding of an fp32 multiply.
+// Measured (profiles/r03_gemm_stream_bf16x3.txt): grouped launch of the
+// concurrent step 60 -> 42 us, 4 x 7 product of the autoregressive step
+// 113 -> 87 us (5.3 TB/s), full-size parity unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Terms {
+  u32x4 t[3];  // high, middle, low terms of 8 values, packed in pairs
+};
+__device__ __forceinline__ float trunc_bf16(float x) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
+}
+// high half-words of (x0, x1) as one packed pair
+__device__ __forceinline__ unsigned pack_hi(float x0, float x1) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1),
+                               __builtin_bit_cast(unsigned, x0), 0x07060302u);
+}
+__device__ __forceinline__ Terms split3(u32x4 lo4, u32x4 hi4) {
+  Terms o;
+  const f32x4 v[2] = {__builtin_bit_cast(f32x4, lo4), __builtin_bit_cast(f32x4, hi4)};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = v[q >> 1][2 * (q & 1)], x1 = v[q >> 1][2 * (q & 1) + 1];
+    const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);   // exact
+    const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);   // exact, <= 8 bits left
+    o.t[0][q] = pack_hi(x0, x1);
+    o.t[1][q] = pack_hi(r0, r1);
+    o.t[2][q] = pack_hi(s0, s1);
+  }
+  return o;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 template <int MB, int NB>
 __device__ __forceinline__ void stream_body(const GemmArgs &G, int bid, int nb,
@@ -351,26 +396,27 @@ __device__ __forceinline__ void stream_body(const GemmArgs &G, int bid, int nb,
         for (int m = 0; m < 8; ++m)
           if (n0 + m >= G.N) fa[rb][m >> 2][m & 3] = 0u;
     }
-    // (whole-vector bit casts: __builtin_bit_cast of a single vector ELEMENT
-    // reads element 0 whatever the index - clang 19 / ROCm 7.2)
+    // row sums from the exact fp32 values, then the chunk's 8 k-slots per lane
+    // as three bf16 terms each and six products per tile
+    Terms ta[MB];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f32x4 va[MB], vb[NB];
+    for (int rb = 0; rb < MB; ++rb) {
+      const f32x4 v0 = __builtin_bit_cast(f32x4, fa[rb][0]);
+      const f32x4 v1 = __builtin_bit_cast(f32x4, fa[rb][1]);
+      rsum[rb] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+      ta[rb] = split3(fa[rb][0], fa[rb][1]);
+    }
 #pragma unroll
-      for (int rb = 0; rb < MB; ++rb) va[rb] = __builtin_bit_cast(f32x4, fa[rb][h]);
+    for (int cb = 0; cb < NB; ++cb) {
+      const Terms tb = split3(fb[cb][0], fb[cb][1]);
+      // smallest products first; the row blocks take turns, so that an
+      // instruction does not wait for the one before it
+      constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int cb = 0; cb < NB; ++cb) vb[cb] = __builtin_bit_cast(f32x4, fb[cb][h]);
+      for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int rb = 0; rb < MB; ++rb) {
-          const float a = va[rb][e];
-          rsum[rb] += a;
-#pragma unroll
-          for (int cb = 0; cb < NB; ++cb)
-            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vb[cb][e],
-                                                               acc[rb][cb], 0, 0, 0);
-        }
+        for (int rb = 0; rb < MB; ++rb)
+          acc[rb][cb] = mfma_bf16(ta[rb].t[kTa[t]], tb.t[kTb[t]], acc[rb][cb]);
     }
   };
   // two register sets: the loads of chunk c+1 are in flight while chunk c
@@ -388,36 +434,37 @@ __device__ __forceinline__ void stream_body(const GemmArgs &G, int bid, int nb,
     load(fa0, fb0);
     multiply(fa1, fb1, c1);
   }
-  // sum the 4 waves through LDS: red [MB*16][W]
+  // sum the 4 waves through LDS: every wave writes its accumulators to its own
+  // [MB*16][W] region at the same time, then all threads add the four regions
+  // in wave order (fixed order: deterministic).  (Four read-modify-write passes
+  // over one region, wave after wave, cost ~5 us per launch for 28 tiles.)
   // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+  constexpr int kRegion = MB * 16 * W;
+  float *mine = red + wave * kRegion;
 #pragma unroll
   for (int rb = 0; rb < MB; ++rb) {
     rsum[rb] += __shfl_xor(rsum[rb], 16, 64);
     rsum[rb] += __shfl_xor(rsum[rb], 32, 64);
   }
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
 #pragma unroll
-      for (int rb = 0; rb < MB; ++rb) {
+  for (int rb = 0; rb < MB; ++rb) {
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb)
+    for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int idx = (rb * 16 + 4 * g + r) * W + cb * 16 + i16;
-            if (w == 0) red[idx] = acc[rb][cb][r];
-            else red[idx] += acc[rb][cb][r];
-          }
-        if (w == 0 && lane < 16) red[(rb * 16 + lane) * W + NB * 16] = 0.f;
-      }
-    }
-    __syncthreads();
-    if (wave == w && G.with_ones && lane < 16) {  // row sums -> column J
-#pragma unroll
-      for (int rb = 0; rb < MB; ++rb) red[(rb * 16 + lane) * W + G.J] += rsum[rb];
-    }
-    __syncthreads();
+      for (int r = 0; r < 4; ++r)
+        mine[(rb * 16 + 4 * g + r) * W + cb * 16 + i16] = acc[rb][cb][r];
+    if (lane < 16) mine[(rb * 16 + lane) * W + NB * 16] = 0.f;
   }
-  for (int i = tid; i < MB * 16 * W; i += kThreads) out[i] = red[i];
+  // row sums -> column J (a dead column of the accumulators, or the extra one):
+  // same wave, LDS operations complete in order
+  __builtin_amdgcn_wave_barrier();
+  if (G.with_ones && lane < 16) {
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) mine[(rb * 16 + lane) * W + G.J] = rsum[rb];
+  }
+  __syncthreads();
+  for (int i = tid; i < kRegion; i += kThreads)
+    out[i] = ((red[i] + red[kRegion + i]) + red[2 * kRegion + i]) + red[3 * kRegion + i];
 }
 
 template <int MB, int NB>
@@ -504,17 +551,19 @@ struct ReduceArgs {
   ReduceItem it[kMaxGroup];
 };
 
+// (16 / 64 / 128 outputs per block measured 0.8-1.3 x / 1.3-1.8 x / 1.7-2.1 x the time)
+constexpr int kRedX = 32, kRedY = 1024 / kRedX;  // outputs x slices per block
 __global__ __launch_bounds__(1024) void planes_gemm_reduce_kernel(ReduceArgs R) {
-  __shared__ double sh[32][33];
+  __shared__ double sh[kRedY][kRedX + 1];
   const ReduceItem &q = R.it[blockIdx.y];
-  if ((int)blockIdx.x * 32 >= q.M * q.Jt) return;
-  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
-  const int idx = blockIdx.x * 32 + x;
+  if ((int)blockIdx.x * kRedX >= q.M * q.Jt) return;
+  const int x = threadIdx.x % kRedX, y = threadIdx.x / kRedX;
+  const int idx = blockIdx.x * kRedX + x;
   const bool ok = idx < q.M * q.Jt;
   const int m = ok ? idx / q.Jt : 0, j = ok ? idx % q.Jt : 0;
   const float *p = q.part + (size_t)m * q.W + j;
   const size_t stride = (size_t)q.rows * q.W;
-  const int per = (q.num_wg + 31) / 32;
+  const int per = (q.num_wg + kRedY - 1) / kRedY;
   const int w0 = y * per, w1 = w0 + per < q.num_wg ? w0 + per : q.num_wg;
   double acc[4] = {0, 0, 0, 0};
   int w = w0;
@@ -527,7 +576,7 @@ __global__ __launch_bounds__(1024) void planes_gemm_reduce_kernel(ReduceArgs R) 
   __syncthreads();
   if (y == 0 && ok) {
     double t = 0;
-    for (int k = 0; k < 32; ++k) t += sh[k][x];
+    for (int k = 0; k < kRedY; ++k) t += sh[k][x];
     const float v = (float)t;
     if (j == q.J && q.bias) q.bias[m] = v;  // row sums to their own vector
     else q.C[(size_t)m * q.ldc + j] = v;
@@ -587,7 +636,7 @@ long long stream_partial_floats(int M, int J) {
 
 template <int MB, int NB>
 int launch_stream(const GemmArgs &G, int num_wg, hipStream_t st) {
-  const size_t lds = (size_t)MB * 16 * (NB * 16 + 1) * sizeof(float);
+  const size_t lds = (size_t)4 * MB * 16 * (NB * 16 + 1) * sizeof(float);  // a region per wave
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     if (hipFuncSetAttribute((const void *)planes_gemm_stream_kernel<MB, NB>,
@@ -765,7 +814,7 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
     R.it[0] = ReduceItem{workspace, C, with_ones ? bias_out : nullptr, num_wg, NB * 32,
                          MB * 32, M, Jt, J, ldc};
   }
-  hipLaunchKernelGGL(planes_gemm_reduce_kernel, dim3((M * Jt + 31) / 32, 1),
+  hipLaunchKernelGGL(planes_gemm_reduce_kernel, dim3((M * Jt + kRedX - 1) / kRedX, 1),
                      dim3(1024), 0, st, R);
   return check_launch("planes_gemm_reduce");
 }
@@ -788,20 +837,27 @@ static bool multi_grouped(const ApgGemmProblem *problems, int n) {
   return plain > 1;
 }
 
+// a grouped product's share of the workgroups: the rows it streams.  (Adding
+// a term per accumulator tile for the matrix instructions it issues moved the
+// launch by < 1 us once those were on the 16-bit pipe: profiles/r03_gemm_stream_bf16x3.txt)
+static double group_cost(const ApgGemmProblem &q) {
+  return (double)(q.M + q.J) * (double)q.N;
+}
+
 static void multi_wgs(const ApgGemmProblem *problems, int n, int *wgs) {
   const bool grouped = multi_grouped(problems, n);
   double total = 0;
   int plain = 0;
   for (int p = 0; p < n; ++p)
     if (use_stream(problems[p].S)) {
-      total += (double)(problems[p].M + problems[p].J) * (double)problems[p].N;
+      total += group_cost(problems[p]);
       ++plain;
     }
   const int pool = cu_count() > plain ? cu_count() - plain : 0;
   for (int p = 0; p < n; ++p) {
     const ApgGemmProblem &q = problems[p];
     if (grouped && use_stream(q.S))
-      wgs[p] = 1 + (int)(pool * ((double)(q.M + q.J) * (double)q.N / total));
+      wgs[p] = 1 + (int)(pool * (group_cost(q) / total));
     else
       wgs[p] = apg_planes_gemm_default_wgs(q.M, q.S, q.J, q.with_ones);
   }
@@ -864,7 +920,7 @@ int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspac
       SG.shape[SG.n] = mb * 16 + nb;
       SG.wg0[SG.n + 1] = SG.wg0[SG.n] + wgs[p];
       ++SG.n;
-      const size_t lds = (size_t)rows * W * sizeof(float);
+      const size_t lds = (size_t)4 * rows * W * sizeof(float);   // a region per wave
       group_lds = lds > group_lds ? lds : group_lds;
     } else {
       const int MB = (q.M + 31) / 32, NB = (Jt + 31) / 32;
@@ -874,7 +930,7 @@ int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspac
     R.it[p] = ReduceItem{part, q.C, q.with_ones ? q.bias_out : nullptr, wgs[p], W,
                          rows, q.M, Jt, q.J, q.ldc};
     part += (size_t)wgs[p] * rows * W;
-    const int blocks = (q.M * Jt + 31) / 32;
+    const int blocks = (q.M * Jt + kRedX - 1) / kRedX;
     max_blocks = blocks > max_blocks ? blocks : max_blocks;
   }
   if (SG.n > 0) {
@@ -882,7 +938,7 @@ int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspac
     if (!attr_set) {  // room for the largest partial any shape can have
       if (hipFuncSetAttribute((const void *)planes_gemm_stream_grouped_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              64 * 1024) != hipSuccess)
+                              kLdsBytes) != hipSuccess)
         return check_launch("hipFuncSetAttribute(planes_gemm_stream_grouped)");
       attr_set = true;
     }

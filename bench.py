@@ -221,9 +221,11 @@ def cpu_baseline(args):
 # ----------------------------------------------------------------------------
 # Training steps (secondary blocks of the line).  Each is the REAL trainer
 # method on this rank's shard and carries its own roofline: the step's MFMA
-# work (policy sweeps as fp16-split products on v_mfma_f32_32x32x16_f16
-# against the 2.5 PFLOP/s dense fp16 peak + the weight-gradient products in
-# exact fp32 against the 157.3 TFLOP/s fp32 matrix peak), its algorithmic
+# work (policy sweeps as fp16-split products on v_mfma_f32_32x32x16_f16 and
+# the weight-gradient products as six bf16 products per multiply-add on
+# v_mfma_f32_16x16x32_bf16, both against the 2.5 PFLOP/s dense 16-bit peak;
+# the small conv product still issues fp32 matrix instructions and is counted
+# with the others), its algorithmic
 # plane traffic against 8 TB/s, and the achieved fraction of the LARGER of the
 # two floors.  Per-wave MFMA counts are the kernels' static instruction counts
 # (hipcc -S of csrc/mlp.hip, lstm.hip; one wave = 32 trajectories, one fp16
@@ -264,26 +266,27 @@ def step_roofline(mode, B, H, n_params, ms):
     waves = (B + 31) // 32
     sweep_flops = (m["mfma_once"] + m["mfma_per_step"] * H) * 32768.0 * waves
     cols = B * (H if m["mfma_per_step"] else 1)      # columns of the products
-    product_flops = 2.0 * n_params * cols            # exact-fp32 matrix instructions
+    # three-term bf16 operands, six products per multiply-add (planes_gemm.hip)
+    product_flops = 6 * 2.0 * n_params * cols
     nbytes = float(B) * (m["bytes_per_traj"] + m["bytes_per_step"] * H)
-    mfma_ms = (sweep_flops / (FP16_MFMA_PEAK_TFLOPS * 1e12)
-               + product_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
+    mfma_ms = (sweep_flops + product_flops) / (FP16_MFMA_PEAK_TFLOPS * 1e12) * 1e3
     hbm_ms = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
     floor = max(mfma_ms, hbm_ms)
     return {
         "bound": "mfma" if mfma_ms >= hbm_ms else "hbm",
         "mfma": {"sweep_fp16_flops_per_step": sweep_flops,
-                 "product_fp32_flops_per_step": product_flops,
+                 "product_bf16x3_flops_per_step": product_flops,
                  "peak_TFLOPs": {"fp16": FP16_MFMA_PEAK_TFLOPS,
                                  "fp32": FP32_MFMA_PEAK_TFLOPS},
                  "floor_ms": mfma_ms},
         "hbm": {"plane_bytes_per_step": nbytes, "peak_GBps": HBM_PEAK_GBS,
                 "floor_ms": hbm_ms, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9},
         "frac": floor / ms,
-        "what": "larger of (sweep fp16-MFMA flops / 2.5 PF + product fp32-MFMA flops "
-                "/ 157.3 TF, plane bytes / 8 TB/s) over the measured step; the "
-                "sweeps' layers are fp16-split products at fp32 accuracy "
-                "(csrc/policy_mfma16.h), the products exact fp32",
+        "what": "larger of ((sweep fp16-MFMA flops + product bf16-MFMA flops) / 2.5 PF, "
+                "plane bytes / 8 TB/s) over the measured step; the sweeps' layers "
+                "are fp16-split products (csrc/policy_mfma16.h), the weight-gradient "
+                "products exact three-term bf16 splits, six products per multiply-add "
+                "(csrc/planes_gemm.hip) - both at fp32 accuracy",
     }
 
 

@@ -384,8 +384,7 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
                               float *start_states, float *workspace,
                               apg_stream_t stream);
 
-/* "Planes x planes" reduction GEMM on the matrix cores
- * (v_mfma_f32_32x32x2_f32, exact fp32):
+/* "Planes x planes" reduction GEMM on the matrix cores (fp32 accuracy):
  *   C[m*ldc + j] = sum_{s<S} sum_{n<N} A[(m*S + s)*N + n] * B[bplane(j,s)*N + n]
  *   bplane(j, s) = bdesc[j] + (s / sdiv) * bdesc[J + j] + (s % sdiv) * bdesc[2J + j]
  * for m < M <= 64, j < J (J + with_ones <= 192, <= 128 when M > 32);
@@ -403,9 +402,10 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
  * 32-bit buffer offsets): hand B over from the first plane the product uses
  * (bdesc relative to it) when the tensor behind it is larger.
  * Two kernels behind it: plain products (S = 1) stream their operands global ->
- * registers -> v_mfma_f32_16x16x4_f32 (split-K over all waves, no LDS tile);
+ * registers -> v_mfma_f32_16x16x32_bf16 on exact three-term bf16 splits of the
+ * fp32 operands, six products per tile (split-K over all waves, no LDS tile);
  * segmented products (S > 1, the conv windows) go through LDS tiles filled by
- * direct-to-LDS DMA.  apg_planes_gemm_default_wgs: the num_wg measured best for
+ * direct-to-LDS DMA and v_mfma_f32_32x32x2_f32.  apg_planes_gemm_default_wgs: the num_wg measured best for
  * the shape (what apg_planes_gemm_multi uses). */
 int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg);
 int apg_planes_gemm_default_wgs(int M, int S, int J, int with_ones);
