@@ -11,7 +11,7 @@
 // once and is bound by that stream.  Two kernels:
 //  * plain products (S = 1; six of the seven of an autoregressive step):
 //    planes_gemm_stream_kernel - global -> registers -> v_mfma_f32_16x16x32_bf16
-//    on exact three-term bf16 splits of the fp32 operands,
+//    on three-term bf16 splits of the fp32 operands,
 //    split-K over all waves, no LDS tile (described at stream_body below);
 //  * segmented products (S > 1) and the grouped launch for short planes:
 //    planes_gemm_kernel, the LDS-tile kernel described next.  Its per-column
@@ -297,10 +297,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // lane l supplies A[l & 15][k-slots 8 (l >> 4) + j] - exactly the 8 consecutive
 // floats the lane has loaded - so a chunk is ONE instruction (~17 cycles) per
 // product of terms.  Every fp32 operand is cut into THREE bf16 terms by
-// truncation, x = h + m + l exactly (8 + 8 + 8 significant bits; bf16 has
-// fp32's exponent, so cotangents need no scaling), and a tile takes the six
-// products of weight >= 2^-16 (h h, h m, m h, m m, h l, l h): what is dropped
-// is <= 2^-23 of |a||b| per product, the rounding of an fp32 multiply.
+// rounding to nearest, x = h + m + l + (<= 2^-24 |x|) with |m| <= 2^-8 |x|,
+// |l| <= 2^-16 |x| (bf16 has fp32's exponent, so cotangents need no scaling),
+// and a tile takes the six products of weight >= 2^-16 (h h, h m, m h, m m,
+// h l, l h): what is dropped (m l, l m, l l, the terms' own remainders) is
+// <= 2^-22 of |a||b| per product in the worst case and 2^-24 - the rounding of
+// an fp32 multiply - typically (tests/test_host_cpu.py emulates it).
 // Measured (profiles/r03_gemm_stream_bf16x3.txt): grouped launch of the
 // concurrent step 60 -> 42 us, 4 x 7 product of the autoregressive step
 // 113 -> 87 us (5.3 TB/s), full-size parity unchanged.
@@ -308,13 +310,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Terms {
   u32x4 t[3];  // high, middle, low terms of 8 values, packed in pairs
 };
-__device__ __forceinline__ float trunc_bf16(float x) {
-  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
-}
-// high half-words of (x0, x1) as one packed pair
-__device__ __forceinline__ unsigned pack_hi(float x0, float x1) {
-  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1),
-                               __builtin_bit_cast(unsigned, x0), 0x07060302u);
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// (x0, x1) rounded to bf16 (v_cvt_pk_bf16_f32, to nearest even), packed; `f0`,
+// `f1`: the rounded values back in fp32
+__device__ __forceinline__ unsigned round_pair(float x0, float x1, float &f0, float &f1) {
+  const bf16x2 v = {(__bf16)x0, (__bf16)x1};
+  const unsigned p = __builtin_bit_cast(unsigned, v);
+  f0 = __builtin_bit_cast(float, p << 16);
+  f1 = __builtin_bit_cast(float, p & 0xffff0000u);
+  return p;
 }
 __device__ __forceinline__ Terms split3(u32x4 lo4, u32x4 hi4) {
   Terms o;
@@ -322,11 +326,11 @@ __device__ __forceinline__ Terms split3(u32x4 lo4, u32x4 hi4) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float x0 = v[q >> 1][2 * (q & 1)], x1 = v[q >> 1][2 * (q & 1) + 1];
-    const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);   // exact
-    const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1);   // exact, <= 8 bits left
-    o.t[0][q] = pack_hi(x0, x1);
-    o.t[1][q] = pack_hi(r0, r1);
-    o.t[2][q] = pack_hi(s0, s1);
+    float h0, h1, m0, m1, l0, l1;
+    o.t[0][q] = round_pair(x0, x1, h0, h1);
+    const float r0 = x0 - h0, r1 = x1 - h1;           // exact, |r| <= 2^-8 |x|
+    o.t[1][q] = round_pair(r0, r1, m0, m1);
+    o.t[2][q] = round_pair(r0 - m0, r1 - m1, l0, l1); // exact difference, rounded once more
   }
   return o;
 }

@@ -285,7 +285,7 @@ def step_roofline(mode, B, H, n_params, ms):
         "what": "larger of ((sweep fp16-MFMA flops + product bf16-MFMA flops) / 2.5 PF, "
                 "plane bytes / 8 TB/s) over the measured step; the sweeps' layers "
                 "are fp16-split products (csrc/policy_mfma16.h), the weight-gradient "
-                "products exact three-term bf16 splits, six products per multiply-add "
+                "products three-term bf16 splits, six products per multiply-add "
                 "(csrc/planes_gemm.hip) - both at fp32 accuracy",
     }
 

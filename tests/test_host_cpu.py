@@ -992,3 +992,46 @@ def test_two_term_fp16_split_reaches_fp32_rounding_level():
     scaled = np.ldexp(three_products(W, np.ldexp(d, -e).astype(np.float32)), e)
     fixed = np.abs(scaled - exact_d).max() / np.abs(exact_d).max()
     assert fixed < 5e-7 and raw > 20 * fixed
+
+
+def test_three_term_bf16_split_and_six_products_reach_fp32_rounding():
+    """The numerics behind the weight-gradient stream products
+    (csrc/planes_gemm.hip, split3 / mfma_bf16): an fp32 value cut into three
+    bf16 terms by rounding to nearest is reproduced to 2^-24 (fp32's exponent
+    range: no scaling for cotangents of any magnitude), and the six products of
+    weight >= 2^-16 differ from the exact product by <= 2^-22 of |a||b| in the
+    worst case, ~2^-24 - an fp32 multiply's rounding - in the mean."""
+    rng = np.random.default_rng(11)
+    mag = 10.0 ** rng.uniform(-30, 30, 8192)          # sixty decades
+    a = (rng.standard_normal(8192) * mag).astype(np.float32)
+    b = (rng.standard_normal(8192) * 10.0 ** rng.uniform(-3, 3, 8192)).astype(np.float32)
+
+    def bf16(x):          # round to nearest even, as v_cvt_pk_bf16_f32
+        u = x.view(np.uint32).astype(np.uint64)
+        u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+        return u.astype(np.uint32).view(np.float32)
+
+    def split3(x):
+        h = bf16(x)
+        r = x - h                                      # exact in fp32
+        assert np.array_equal(r.astype(np.float64), x.astype(np.float64) - h)
+        m = bf16(r)
+        s = r - m                                      # exact
+        assert np.array_equal(s.astype(np.float64), r.astype(np.float64) - m)
+        return h, m, bf16(s)
+
+    ta, tb = split3(a), split3(b)
+    for t, x in ((ta, a), (tb, b)):
+        total = t[0].astype(np.float64) + t[1].astype(np.float64) + t[2].astype(np.float64)
+        assert (np.abs(total - x) <= 2.0 ** -24 * np.abs(x)).all()
+        assert (np.abs(t[1]) <= 2.0 ** -8 * np.abs(x)).all()
+        assert (np.abs(t[2]) <= 2.0 ** -16 * np.abs(x)).all()
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    six = sum(ta[i].astype(np.float64) * tb[j].astype(np.float64)
+              for i, j in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)))
+    rel = np.abs(six - exact) / np.abs(exact)
+    assert rel.max() < 2.0 ** -22 and rel.mean() < 2.0 ** -24, (rel.max(), rel.mean())
+    # the three products of a two-term split stop at 2^-16: not enough
+    two = sum(ta[i].astype(np.float64) * tb[j].astype(np.float64)
+              for i, j in ((1, 0), (0, 1), (0, 0)))
+    assert (np.abs(two - exact) / np.abs(exact)).max() > 2.0 ** -18
