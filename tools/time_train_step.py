@@ -1,8 +1,9 @@
 """One fused training step of TrainDrone at B = 65 536 on a resident shard,
 eager launches (no graph), for per-kernel profiling:
-    python tools/time_train_step.py concurrent|autoregressive|LSTM
+    python tools/time_train_step.py concurrent|autoregressive|LSTM [graph]
     rocprofv3 --kernel-trace --stats -- python tools/time_train_step.py <mode>
-Prints the eager wall time per step (host gaps included)."""
+Prints the eager wall time per step (host gaps included); with `graph` the
+step is replayed from the trainer's captured graph (what bench.py times)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from apg_trajectory_tracking_amd.train_drone import TrainDrone
@@ -18,6 +19,8 @@ t = TrainDrone(q, q, cfg)
 torch.manual_seed(0)
 t.initialize_model(device=dev, seed=0)
 t.static_shard = True
+t.graph_steps = len(sys.argv) > 2 and sys.argv[2] == "graph"
+reps = 200 if t.graph_steps else 20
 d = t.state_data
 def step():
     if mode == "concurrent":
@@ -28,6 +31,6 @@ for _ in range(5): step()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(20): step()
+for _ in range(reps): step()
 e1.record(); torch.cuda.synchronize()
-print(mode, "ms/step", e0.elapsed_time(e1) / 20)
+print(mode, "graph" if t.graph_steps else "eager", "ms/step", e0.elapsed_time(e1) / reps)
