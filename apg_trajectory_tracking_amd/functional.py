@@ -819,6 +819,13 @@ def _soa_source(t, out, index):
     return t, R, ld, B, out
 
 
+def _is_plane_view(t):
+    """[B, R] fp32 device tensor that is the transposed view of contiguous
+    [R][B] planes (LSTM_NEW.reset_hidden_state draws them that way)."""
+    return (t.dim() == 2 and t.is_cuda and t.dtype == torch.float32
+            and t.shape[0] > 1 and t.stride() == (1, t.shape[0]))
+
+
 def to_soa(t, out=None, index=None):
     """[B, ...] fp32 -> [..., B] planes (apg_to_soa: both sides coalesced).  A
     leading slice of longer rows (e.g. ref[:, :H]) is read in place through its
@@ -961,7 +968,10 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
         if src and hit is None:
             _STATIC_PLANES.store("recurrent", src, (refbuf, inr, s0, states, rf))
-        h0s, c0s = to_soa_multi([(h0, None), (c0, None)])
+        if all(_is_plane_view(t) for t in (h0, c0)):
+            h0s, c0s = h0.detach().t(), c0.detach().t()   # already [8][B] planes
+        else:
+            h0s, c0s = to_soa_multi([(h0, None), (c0, None)])
         pw = dict(
             conv_w=_f32c(conv_w), conv_b=_f32c(conv_b), w_ih=_f32c(w_ih),
             w_hh=_f32c(w_hh), b_ih=_f32c(b_ih), b_hh=_f32c(b_hh),

@@ -36,13 +36,24 @@ class LSTM_NEW(nn.Module):
         dev = self.fc_out.weight.device
         # with a generator: draw on ITS device, then move
         where = dev if generator is None else generator.device
-        draw = lambda: torch.randn(batch_size, HIDDEN, generator=generator,
-                                   device=where).to(dev)
-        self.hidden_state = draw()
-        self.cell_state = draw()
+        if torch.device(where).type == "cpu":
+            # the reference's two draws from a CPU stream, value for value
+            draw = lambda: torch.randn(batch_size, HIDDEN, generator=generator,
+                                       device=where).to(dev)
+            self.hidden_state = draw()
+            self.cell_state = draw()
+        else:
+            # device stream (no draw-for-draw counterpart): one launch for both,
+            # drawn in the plane layout the fused kernels read ([8][B]; the
+            # [B, 8] tensors are transposed views, iid entries either way) -
+            # no layout change per step
+            both = torch.randn(2, HIDDEN, batch_size, generator=generator,
+                               device=where).to(dev)
+            self.hidden_state, self.cell_state = both[0].t(), both[1].t()
 
     def forward(self, state, ref):
         x = torch.cat((state, encode_window(self, ref)), dim=1)
-        carry = self.lstm(x, (self.hidden_state, self.cell_state))
+        carry = self.lstm(x, (self.hidden_state.contiguous(),
+                              self.cell_state.contiguous()))
         self.hidden_state, self.cell_state = carry
         return self.fc_out(self.hidden_state)
