@@ -112,11 +112,24 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
   return v;
 }
 
-// workgroup copy of the packed operand tables into LDS (linear, coalesced)
+// Workgroup copy of the packed operand tables into LDS: direct-to-LDS DMA, one
+// wave instruction per KiB (64 lanes x 16 B), every wave issues its share
+// back to back and waits once.  (Rounds 1-3 copied through registers in a loop
+// the compiler does not unroll - 16 dependent load -> ds_write round trips per
+// thread before the first instruction of the sweep: 2.5-3 us per launch,
+// profiles/r03_gemm_stream_bf16x3.txt.)
 __device__ __forceinline__ void fill_lds(float *lds, const float *src, int floats) {
-  const float4 *s4 = reinterpret_cast<const float4 *>(src);
-  float4 *d4 = reinterpret_cast<float4 *>(lds);
-  for (int i = threadIdx.x; i < floats / 4; i += blockDim.x) d4[i] = s4[i];
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  const auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0,
+                                                   (unsigned)floats * 4u, 0x00020000);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves = blockDim.x >> 6;
+  for (int c = wave * 256; c < floats; c += waves * 256)
+    if (c + lane * 4 < floats)   // (a last, partial KiB: the other lanes stay out)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(lds + c), 16,
+                                               (c + lane * 4) * 4, 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
 
