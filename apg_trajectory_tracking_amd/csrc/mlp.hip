@@ -126,8 +126,8 @@ __device__ __forceinline__ float cfwd_weight(const ApgMlpPolicy &p, int n, int r
   return out < head_rows ? p.w_out[out * kW + k] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void mlp_pack_cfwd_kernel(PackArgs A) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+// (tid of T threads: the kernels below share the two bodies)
+__device__ __forceinline__ void pack_cfwd(const PackArgs &A, int tid, int T) {
   const ApgMlpPolicy &p = A.pol;
   unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
   // one thread per (block, lane, word): two weights -> fp16 high / low terms
@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256) void mlp_pack_cfwd_kernel(PackArgs A) {
     A.dst[hTo + idx] = p.w_out[j * kW + rb * 32 + rrow(i) + 4 * hi];
   }
   for (int idx = tid; idx < 4; idx += T) A.dst[hBo + idx] = p.b_out[idx];
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_cfwd_kernel(PackArgs A) {
+  pack_cfwd(A, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 struct FwdArgs {
   const float *state0, *in_ref;
@@ -587,8 +591,7 @@ __device__ __forceinline__ float cbwd_weight(const ApgMlpPolicy &p, int n, int r
   return row < kNF ? p.w_s[kin(n - mST, j, hi) * kNF + row] : 0.f;  // states_in^T
 }
 
-__global__ __launch_bounds__(256) void mlp_pack_cbwd_kernel(PackArgs A) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+__device__ __forceinline__ void pack_cbwd(const PackArgs &A, int tid, int T) {
   unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
   for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
     const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
@@ -608,6 +611,23 @@ __global__ __launch_bounds__(256) void mlp_pack_cbwd_kernel(PackArgs A) {
     const int ch = idx / 3, q = idx % 3;
     A.dst[gAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
                        p.conv_w[ch * 27 + q * 3 + 2];
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_cbwd_kernel(PackArgs A) {
+  pack_cbwd(A, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// both tables in one launch (the concurrent step runs its sweeps back to
+// back): blocks [0, fwd_blocks) write the forward tables at dst, the others the
+// reverse tables at dst + kCfLds
+__global__ __launch_bounds__(256) void mlp_pack_pair_kernel(PackArgs A, int fwd_blocks) {
+  if ((int)blockIdx.x < fwd_blocks) {
+    pack_cfwd(A, blockIdx.x * blockDim.x + threadIdx.x, fwd_blocks * blockDim.x);
+  } else {
+    A.dst += kCfLds;
+    pack_cbwd(A, (blockIdx.x - fwd_blocks) * blockDim.x + threadIdx.x,
+              (gridDim.x - fwd_blocks) * blockDim.x);
   }
 }
 
@@ -1376,7 +1396,7 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
 }
 
 int apg_quad_mlp_concurrent_workspace_floats(void) {
-  return kCfLds > kCbLds ? kCfLds : kCbLds;
+  return kCfLds + kCbLds;   // forward and reverse tables, packed by one launch
 }
 
 int apg_quad_mlp_concurrent_fwd_bwd(
@@ -1420,12 +1440,12 @@ int apg_quad_mlp_concurrent_fwd_bwd(
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
-  hipLaunchKernelGGL(mlp_pack_cfwd_kernel, dim3((kCfLds + 255) / 256), dim3(256),
-                     0, st, P);
+  const int fwd_blocks = (kCfLds + 255) / 256, bwd_blocks = (kCbLds + 255) / 256;
+  hipLaunchKernelGGL(mlp_pack_pair_kernel, dim3(fwd_blocks + bwd_blocks), dim3(256), 0, st,
+                     P, fwd_blocks);
   hipLaunchKernelGGL(mlp_concurrent_fwd_kernel, dim3(blocks), dim3(kThreads),
                      kCfLds * sizeof(float), st, A);
-  hipLaunchKernelGGL(mlp_pack_cbwd_kernel, dim3((kCbLds + 255) / 256), dim3(256),
-                     0, st, P);
+  A.tables = workspace + kCfLds;
   hipLaunchKernelGGL(mlp_concurrent_bwd_kernel, dim3(blocks), dim3(kThreads),
                      kCbLds * sizeof(float), st, A);
   if (int e = check_launch("quad_mlp_concurrent_fwd_bwd")) return e;
