@@ -291,19 +291,27 @@ def step_roofline(mode, B, H, n_params, ms):
 
 
 def timed_steps(step, n, dist):
-    """ms per step of `n` calls, bracketed by barrier + synchronize."""
+    """(ms per step, last output, per-chunk ms) of `n` calls, each chunk
+    bracketed by barrier + synchronize (so every rank sees the slowest rank).  The calls are timed in four chunks and the MEDIAN
+    chunk is reported: one host or driver stall inside a 20-step region (seen
+    once: 60 ms in an LSTM block, 3.5 ms "per step") would otherwise be the
+    number; every chunk's mean is in the line next to it."""
     for _ in range(3):
         out = step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        out = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    return (time.perf_counter() - t0) / n * 1e3, out
+    chunks = []
+    sizes = [n // 4 + (1 if i < n % 4 else 0) for i in range(4)]
+    for m in [c for c in sizes if c > 0]:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(m):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        chunks.append((time.perf_counter() - t0) / m * 1e3)
+    return sorted(chunks)[(len(chunks) - 1) // 2], out, chunks
 
 
 def trainer_step_probe(args, dev, dyn, dist, mode):
@@ -361,10 +369,11 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
     else:
         step = lambda: t.train_recurrent_model(
             None, Shard.states, Shard.in_ref_states, Shard.ref_states)
-    ms, total = timed_steps(step, args.train_steps, dist)
+    ms, total, chunks = timed_steps(step, args.train_steps, dist)
     n_params = sum(p.numel() for p in t.net.parameters() if p.requires_grad)
     out = {
         "ms_per_step": ms,
+        "ms_per_step_chunks": chunks,   # four timed chunks; ms_per_step = their median
         "env_steps_per_s": world * B * H / (ms * 1e-3),
         "batch_per_gpu": B, "global_batch": world * B,
         "allreduce_floats": n_params + 1,
@@ -383,9 +392,9 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
             new.load_state_dict(old.state_dict())
             setattr(t.net, name, new)
         t.init_optimizer()
-        ms2, _ = timed_steps(step, args.train_steps, dist)
+        ms2, _, chunks2 = timed_steps(step, args.train_steps, dist)
         out["with_apg_nn_linear"] = {
-            "ms_per_step": ms2,
+            "ms_per_step": ms2, "ms_per_step_chunks": chunks2,
             "what": "the same step, the policy's three layers as "
                     "apg_trajectory_tracking_amd.nn.Linear"}
     else:
