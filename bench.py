@@ -80,7 +80,7 @@ def parse():
                     help="rank logic only, gloo on the CPU, stub kernels")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the fixed-wing dual-roofline block")
-    ap.add_argument("--train-steps", type=int, default=20,
+    ap.add_argument("--train-steps", type=int, default=40,
                     help="steps of the secondary full-training-step "
                          "measurement (0 disables it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
