@@ -276,8 +276,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
 // LDS tile and no barrier in the main loop.  Lane (i, g) = (l & 15, l >> 4)
 // loads 8 CONSECUTIVE floats of row i's plane (two 16-byte loads at column
 // 32 c + 8 g): the lane's 8 k-slots of a 16 x 16 x 32 matrix instruction
-// (split3 / mfma_bf16 above); 16 rows x 128 contiguous bytes per load pair, every operand element
-// is fetched exactly once, and each wave streams its own chunks of 32 columns
+// (split3 / mfma_bf16 below); 16 rows x 128 contiguous bytes per load pair,
+// every operand element is fetched exactly once, and each wave streams its own
+// chunks of 32 columns
 // (split-K over all waves of the grid) with the next chunk's loads in flight
 // while this one multiplies (S = 1 products only: the segmented conv product
 // re-reads its windows per segment and is faster through the LDS tiles).
