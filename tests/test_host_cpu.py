@@ -139,6 +139,16 @@ def test_models_match_reference_outputs():
     h = lstm.hidden_state.clone()
     lstm.reset_hidden_state(5, generator=torch.Generator().manual_seed(1))
     assert torch.equal(h, lstm.hidden_state) and h.shape == (5, 8)
+    # CPU streams: the reference's two draws, h first, value for value
+    # (models/rnn.py draws ONE [2][8][B] tensor only on a device stream)
+    g2 = torch.Generator().manual_seed(1)
+    assert torch.equal(h, torch.randn(5, 8, generator=g2))
+    assert torch.equal(lstm.cell_state, torch.randn(5, 8, generator=g2))
+    torch.manual_seed(3)
+    lstm.reset_hidden_state(3)
+    torch.manual_seed(3)
+    assert torch.equal(lstm.hidden_state, torch.randn(3, 8))
+    assert torch.equal(lstm.cell_state, torch.randn(3, 8))
     out = lstm(torch.zeros(5, 15), torch.zeros(5, 10, 9))
     assert out.shape == (5, 4)
     gc = load_golden("cartpole.npz")
