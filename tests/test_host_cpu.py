@@ -145,10 +145,10 @@ def test_models_match_reference_outputs():
     assert torch.equal(h, torch.randn(5, 8, generator=g2))
     assert torch.equal(lstm.cell_state, torch.randn(5, 8, generator=g2))
     torch.manual_seed(3)
-    lstm.reset_hidden_state(3)
+    lstm.reset_hidden_state(5)
     torch.manual_seed(3)
-    assert torch.equal(lstm.hidden_state, torch.randn(3, 8))
-    assert torch.equal(lstm.cell_state, torch.randn(3, 8))
+    assert torch.equal(lstm.hidden_state, torch.randn(5, 8))
+    assert torch.equal(lstm.cell_state, torch.randn(5, 8))
     out = lstm(torch.zeros(5, 15), torch.zeros(5, 10, 9))
     assert out.shape == (5, 4)
     gc = load_golden("cartpole.npz")
