@@ -731,7 +731,12 @@ int default_wgs(int MB, int NB) {
 
 // one workgroup (4 waves, one per SIMD) per CU: a wave holds all accumulator
 // tiles and two sets of operand registers
-int stream_default_wgs(int, int) { return cu_count(); }
+int stream_default_wgs(int M, int J) {
+  // ... except the smallest shape (the LSTM's 4 x 8 output layer: 12 live rows,
+  // 1.5 KB per wave and chunk): too few bytes in flight with one workgroup per
+  // CU, and its 76 registers leave room for four (18.2 -> 11.4 us; eight: 14.4)
+  return cu_count() * (stream_mb(M) + stream_nb(J) <= 2 ? 4 : 1);
+}
 
 const char *check_problem(const float *A, const float *Bp, const int *bdesc,
                           const float *C, int M, int S, int J, int Jt, int sdiv,
