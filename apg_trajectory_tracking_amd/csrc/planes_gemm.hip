@@ -13,8 +13,10 @@
 //    planes_gemm_stream_kernel - global -> registers -> v_mfma_f32_16x16x32_bf16
 //    on three-term bf16 splits of the fp32 operands,
 //    split-K over all waves, no LDS tile (described at stream_body below);
-//  * segmented products (S > 1) and the grouped launch for short planes:
-//    planes_gemm_kernel, the LDS-tile kernel described next.  Its per-column
+//  * segmented products (S > 1) with 16 or more B rows, and the grouped launch
+//    for short planes: planes_gemm_kernel, the LDS-tile kernel described next
+//    (a segmented product with fewer B rows - the 3 position planes of the
+//    conv gradient - streams too: use_stream).  Its per-column
 //    two-level segment stride lets the conv-weight gradient read the sliding
 //    reference windows straight from the [2H][9][B] reference tensor (segment
 //    = (window position, step)) and the positions before each step from the
@@ -280,8 +282,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
 // every operand element is fetched exactly once, and each wave streams its own
 // chunks of 32 columns
 // (split-K over all waves of the grid) with the next chunk's loads in flight
-// while this one multiplies (S = 1 products only: the segmented conv product
-// re-reads its windows per segment and is faster through the LDS tiles).
+// while this one multiplies (plain products, and segmented ones with a few B
+// rows; the segmented window product re-reads its windows per segment and is
+// faster through the LDS tiles).
 // One wave holds ALL MB x NB accumulator tiles of
 // 16 x 16 (4 registers each); the 4 waves of a workgroup are summed through
 // LDS at the end and the partial C goes to the same second stage as above.
@@ -360,39 +363,52 @@ __device__ __forceinline__ void stream_body(const GemmArgs &G, int bid, int nb,
       const_cast<float *>(G.A), 0, (unsigned)G.a_bytes, 0x00020000);
   const auto rB = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(G.Bp), 0, (unsigned)G.b_bytes, 0x00020000);
-  unsigned offA[MB], offB[NB];
+  // Segments (S > 1, small products only: see use_stream): row m of A is the S
+  // planes (m S + s), B row j of segment s the plane bplane(j, s); a chunk of 32
+  // columns never crosses a segment (chunk index = segment * chunks per
+  // segment + chunk of the segment).
+  unsigned offA[MB], offB[NB], bs1[NB], bs2[NB];
 #pragma unroll
   for (int rb = 0; rb < MB; ++rb) {
     const int row = rb * 16 + i16;
-    offA[rb] = row < G.M ? (unsigned)row * plane_bytes + g * 32 : kDeadOff2;
+    offA[rb] = row < G.M ? (unsigned)(row * G.S) * plane_bytes + g * 32 : kDeadOff2;
   }
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) {
     const int j = cb * 16 + i16, jc = j < G.J ? j : 0;
     offB[cb] = j < G.J ? (unsigned)G.bdesc[jc] * plane_bytes + g * 32 : kDeadOff2;
+    bs1[cb] = G.S > 1 ? (unsigned)G.bdesc[G.J + jc] * plane_bytes : 0u;
+    bs2[cb] = G.S > 1 ? (unsigned)G.bdesc[2 * G.J + jc] * plane_bytes : 0u;
   }
   // the waves of the grid take chunks of 32 columns wave-strided: at any time
   // the grid reads one contiguous stretch of every plane
-  const int cps = (int)((G.N + 31) / 32);
+  const int cps1 = (int)((G.N + 31) / 32);   // chunks of one segment
+  const int cps = cps1 * G.S;
   const int nw = nb * 4;
   int cc = bid * 4 + wave;
   auto load = [&](u32x4 (&fa)[MB][2], u32x4 (&fb)[NB][2]) {
     const bool live = cc < cps;
-    const unsigned colb = (unsigned)cc * 128u;
+    const int s = G.S > 1 ? cc / cps1 : 0, c = cc - s * cps1;
+    const unsigned colb = (unsigned)c * 128u, sa = (unsigned)s * plane_bytes;
+    const unsigned s1 = (unsigned)(s / G.sdiv), s2 = (unsigned)(s % G.sdiv);
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) {
-      const unsigned off = (live && offA[rb] != kDeadOff2) ? offA[rb] + colb : kDeadOff2;
+      const unsigned off =
+          (live && offA[rb] != kDeadOff2) ? offA[rb] + sa + colb : kDeadOff2;
       fa[rb][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)off, 0, 0);
       fa[rb][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)off + 16, 0, 0);
     }
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
-      const unsigned off = (live && offB[cb] != kDeadOff2) ? offB[cb] + colb : kDeadOff2;
+      const unsigned off = (live && offB[cb] != kDeadOff2)
+                               ? offB[cb] + s1 * bs1[cb] + s2 * bs2[cb] + colb
+                               : kDeadOff2;
       fb[cb][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)off, 0, 0);
       fb[cb][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)off + 16, 0, 0);
     }
   };
   auto multiply = [&](u32x4 (&fa)[MB][2], u32x4 (&fb)[NB][2], int cc_) {
+    cc_ = G.S > 1 ? cc_ % cps1 : cc_;   // the chunk of its segment
     const int n0 = cc_ * 32 + g * 8;  // this lane's first column of the chunk
     if ((long long)cc_ * 32 + 32 > G.N) {  // ragged last chunk: zero A beyond N
 #pragma unroll
@@ -775,11 +791,14 @@ using namespace apg;
 extern "C" {
 
 // which kernel runs a product: the register-streaming one for plain (S = 1)
-// products, the LDS-tile one for segmented products
-static bool use_stream(int S) { return APG_GEMM_STREAM && S == 1; }
+// products and for segmented ones with fewer than 16 B rows (the position
+// product of the conv gradient: 3 rows - the LDS-tile kernel moves 32-row tiles
+// for them and takes 21-24 us for 60 MB), the LDS-tile one for the others (the
+// sliding windows: their segments share B rows through the L2)
+static bool use_stream(int S, int J) { return APG_GEMM_STREAM && (S == 1 || J < 16); }
 
 static long long partial_floats(int M, int S, int J, int with_ones) {
-  if (use_stream(S)) return stream_partial_floats(M, J);
+  if (use_stream(S, J)) return stream_partial_floats(M, J);
   const int MB = (M + 31) / 32, NB = (J + (with_ones ? 1 : 0) + 31) / 32;
   return (long long)MB * 32 * NB * 32;
 }
@@ -792,7 +811,7 @@ int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg) {
 }
 
 int apg_planes_gemm_default_wgs(int M, int S, int J, int with_ones) {
-  if (use_stream(S)) return stream_default_wgs(M, J);
+  if (use_stream(S, J)) return stream_default_wgs(M, J);
   return default_wgs((M + 31) / 32, (J + (with_ones ? 1 : 0) + 31) / 32);
 }
 
@@ -814,7 +833,7 @@ int apg_planes_gemm(const float *A, int M, int S, const float *Bp,
   fill_args(G, A, Bp, bdesc, workspace, M, S, J, sdiv, with_ones, b_planes, N);
   hipStream_t st = (hipStream_t)stream;
   ReduceArgs R;
-  if (use_stream(S)) {
+  if (use_stream(S, J)) {
     if (int e = launch_stream_shape(G, num_wg, st)) return e;
     R.it[0] = ReduceItem{workspace, C, with_ones ? bias_out : nullptr, num_wg,
                          stream_nb(J) * 16 + 1, stream_mb(M) * 16, M, Jt, J, ldc};
@@ -840,7 +859,7 @@ constexpr long long kGroupMaxN = 262144;
 static bool multi_grouped(const ApgGemmProblem *problems, int n) {
   int plain = 0;
   for (int p = 0; p < n; ++p)
-    if (use_stream(problems[p].S)) {
+    if (use_stream(problems[p].S, problems[p].J)) {
       if (problems[p].N > kGroupMaxN) return false;
       ++plain;
     }
@@ -851,7 +870,7 @@ static bool multi_grouped(const ApgGemmProblem *problems, int n) {
 // a term per accumulator tile for the matrix instructions it issues moved the
 // launch by < 1 us once those were on the 16-bit pipe: profiles/r03_gemm_stream_bf16x3.txt)
 static double group_cost(const ApgGemmProblem &q) {
-  return (double)(q.M + q.J) * (double)q.N;
+  return (double)(q.M + q.J) * (double)q.S * (double)q.N;
 }
 
 static void multi_wgs(const ApgGemmProblem *problems, int n, int *wgs) {
@@ -859,14 +878,14 @@ static void multi_wgs(const ApgGemmProblem *problems, int n, int *wgs) {
   double total = 0;
   int plain = 0;
   for (int p = 0; p < n; ++p)
-    if (use_stream(problems[p].S)) {
+    if (use_stream(problems[p].S, problems[p].J)) {
       total += group_cost(problems[p]);
       ++plain;
     }
   const int pool = cu_count() > plain ? cu_count() - plain : 0;
   for (int p = 0; p < n; ++p) {
     const ApgGemmProblem &q = problems[p];
-    if (grouped && use_stream(q.S))
+    if (grouped && use_stream(q.S, q.J))
       wgs[p] = 1 + (int)(pool * (group_cost(q) / total));
     else
       wgs[p] = apg_planes_gemm_default_wgs(q.M, q.S, q.J, q.with_ones);
@@ -920,10 +939,10 @@ int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspac
     fill_args(G, q.A, q.B, q.bdesc, part, q.M, q.S, q.J, q.sdiv, q.with_ones,
               q.b_planes, q.N);
     int rows, W;
-    if (use_stream(q.S) && !grouped) {
+    if (use_stream(q.S, q.J) && !grouped) {
       if (int e = launch_stream_shape(G, wgs[p], st)) return e;
       rows = stream_mb(q.M) * 16, W = stream_nb(q.J) * 16 + 1;
-    } else if (use_stream(q.S)) {
+    } else if (use_stream(q.S, q.J)) {
       const int mb = stream_mb(q.M), nb = stream_nb(q.J);
       rows = mb * 16, W = nb * 16 + 1;
       SG.g[SG.n] = G;

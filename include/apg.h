@@ -401,10 +401,11 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
  * `b_planes` planes; A (M*S planes) and B must each stay below 4 GiB (unsigned
  * 32-bit buffer offsets): hand B over from the first plane the product uses
  * (bdesc relative to it) when the tensor behind it is larger.
- * Two kernels behind it: plain products (S = 1) stream their operands global ->
+ * Two kernels behind it: plain products (S = 1; and segmented ones with J < 16)
+ * stream their operands global ->
  * registers -> v_mfma_f32_16x16x32_bf16 on three-term bf16 splits of the
  * fp32 operands, six products per tile (split-K over all waves, no LDS tile);
- * segmented products (S > 1, the conv windows) go through LDS tiles filled by
+ * the other segmented products (S > 1, the conv windows) go through LDS tiles filled by
  * direct-to-LDS DMA and v_mfma_f32_32x32x2_f32.  apg_planes_gemm_default_wgs: the num_wg measured best for
  * the shape (what apg_planes_gemm_multi uses). */
 int apg_planes_gemm_workspace_floats(int M, int J, int with_ones, int num_wg);
