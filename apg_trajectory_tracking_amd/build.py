@@ -23,19 +23,20 @@ COMMON_FLAGS = ["-fno-slp-vectorize"]
 # with the wave (gfx950 firmware feature) - the packed-rows rollout issues its
 # first loads without waiting for an s_load round trip
 EXTRA_FLAGS = {"quad.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
-HEADERS = [os.path.join(CSRC, "apg_device.h"),
-           os.path.join(CSRC, "quad_math.h"),
-           os.path.join(CSRC, "policy_mfma.h"),
-           os.path.join(CSRC, "wing_math.h"),
-           os.path.join(CSRC, "cartpole_math.h"),
-           os.path.join(REPO, "include", "apg.h")]
+def _headers():
+    """Every header a source may include: all of csrc/*.h plus the C ABI (a
+    hand-kept list once missed policy_mfma16.h, so `python -m ...build` did
+    not see edits to it)."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
+        os.path.join(REPO, "include", "apg.h")]
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
