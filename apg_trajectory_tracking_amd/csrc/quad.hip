@@ -384,17 +384,71 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
 
-#ifndef APG_ROWS_BLOCK
-#define APG_ROWS_BLOCK 64   // threads per workgroup (64 / 128 / 256)
+// The request / store schedule of quad_rollout_rows_kernel, FROZEN: every
+// value below won its sweep on the 20-buffer-set protocol (DESIGN.md §3.1,
+// profiles/r02_ab_jit.json, r02_ab_actpre.json, r03_ab_quad.json).  The product
+// build has no knobs; a variant build (tools/build_variant.py,
+// -DAPG_EXPERIMENT_BUILD) may override single values through APG_ROWS_*.
+namespace rows_tune {
+#ifdef APG_EXPERIMENT_BUILD
+#define APG_ROWS_TUNE(frozen, knob) (knob)
+#else
+#define APG_ROWS_TUNE(frozen, knob) (frozen)
 #endif
+#ifndef APG_ROWS_BLOCK
+#define APG_ROWS_BLOCK 64
+#endif
+#ifndef APG_ROWS_ACT_PRE
+#define APG_ROWS_ACT_PRE 3
+#endif
+#ifndef APG_ROWS_REF_PER_STEP
+#define APG_ROWS_REF_PER_STEP 1
+#endif
+#ifndef APG_ROWS_REF_LOOK
+#define APG_ROWS_REF_LOOK 3
+#endif
+#ifndef APG_ROWS_ST_AUX
+#define APG_ROWS_ST_AUX 2
+#endif
+#ifndef APG_ROWS_LD_AUX
+#define APG_ROWS_LD_AUX 0
+#endif
+#ifndef APG_ROWS_STORE_AT_END
+#define APG_ROWS_STORE_AT_END 1
+#endif
+#ifndef APG_ROWS_STORE_FLUSH_AT
+#define APG_ROWS_STORE_FLUSH_AT (-1)
+#endif
+#ifndef APG_ROWS_REF_TOP
+#define APG_ROWS_REF_TOP 0
+#endif
+constexpr int kBlock = APG_ROWS_TUNE(64, APG_ROWS_BLOCK);  // threads per workgroup: one wave
+constexpr int kActPreMax = APG_ROWS_TUNE(3, APG_ROWS_ACT_PRE);  // action rows requested up front
+constexpr int kRefPerStep = APG_ROWS_TUNE(1, APG_ROWS_REF_PER_STEP);  // (kRefLookMax == 0 only)
+// just-in-time reference rows: the last kRefLook forward steps request rows
+// H-1 .. H-kRefLook, reverse step k requests row k - kRefLook
+constexpr int kRefLookMax = APG_ROWS_TUNE(3, APG_ROWS_REF_LOOK);
+constexpr int kStAux = APG_ROWS_TUNE(2, APG_ROWS_ST_AUX);  // dL/dactions stores: nt
+constexpr int kLdAux = APG_ROWS_TUNE(0, APG_ROWS_LD_AUX);  // input rows: default cache policy
+// dL/dactions rows wait in registers (the action rows' own) and are written
+// AFTER the reverse sweep: once the inputs come from HBM, writes in flight
+// slow the reads (8.63 -> 8.39 us at 20 buffer sets); kStoreFlushAt >= 0: rows
+// above it are written when that step is done, later rows at once
+constexpr bool kStoreAtEnd = APG_ROWS_TUNE(1, APG_ROWS_STORE_AT_END) != 0;
+constexpr int kStoreFlushAt = APG_ROWS_TUNE(-1, APG_ROWS_STORE_FLUSH_AT);
+// true: rows below H - kRefLook all requested at the top of the reverse sweep
+constexpr bool kRefTop = APG_ROWS_TUNE(0, APG_ROWS_REF_TOP) != 0;
+#undef APG_ROWS_TUNE
+}  // namespace rows_tune
+
 template <int HT, bool STATES_OUT>
-__global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
+__global__ __launch_bounds__(rows_tune::kBlock) void quad_rollout_rows_kernel(
     const float *state0, const float *actions, const float *ref, int B, float dt,
     float half_dt, float half_dt2, float g0, float g1, float g2, float k0,
     float k1, float k2, RowArgs R) {
   APG_STAMP_DECL;
   APG_STAMP_AT(0);
-  const int b = blockIdx.x * APG_ROWS_BLOCK + threadIdx.x;
+  const int b = blockIdx.x * rows_tune::kBlock + threadIdx.x;
   const bool live = b < B;
   const int bb = live ? b : B - 1;  // keep the wave convergent for the reduce
   // Request schedule.  Loads return in order, so the order of the requests IS
@@ -404,36 +458,9 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
   // they are requested first, all of them; the reference rows follow in
   // REVERSE step order, kRefPerStep per forward step, so that the reverse
   // sweep consumes them while they are still streaming in.
-#ifndef APG_ROWS_ACT_PRE
-#define APG_ROWS_ACT_PRE 3
-#endif
-#ifndef APG_ROWS_REF_PER_STEP
-#define APG_ROWS_REF_PER_STEP 1
-#endif
-  constexpr int kActPre = HT < (APG_ROWS_ACT_PRE) ? HT : (APG_ROWS_ACT_PRE);
-  constexpr int kRefPerStep = APG_ROWS_REF_PER_STEP;
-#ifndef APG_ROWS_REF_LOOK
-#define APG_ROWS_REF_LOOK 3
-#endif
-#ifndef APG_ROWS_ST_AUX
-#define APG_ROWS_ST_AUX 2  // nt
-#endif
-#ifndef APG_ROWS_LD_AUX
-#define APG_ROWS_LD_AUX 0  // default cache policy for the input rows
-#endif
-#ifndef APG_ROWS_STORE_AT_END
-#define APG_ROWS_STORE_AT_END 1  // dL/dactions rows wait in registers (the
-#endif                            // action rows' own) and are written AFTER the
-#ifndef APG_ROWS_STORE_FLUSH_AT   // reverse sweep: once the inputs come from
-#define APG_ROWS_STORE_FLUSH_AT (-1)  // HBM, writes in flight slow the reads
-#endif                            // (8.63 -> 8.39 us at 20 buffer sets)
-#ifndef APG_ROWS_REF_TOP
-#define APG_ROWS_REF_TOP 0  // 1: rows below H - kRefLook all requested before
-#endif                      //    the first store (top of the reverse sweep)
-  // kRefLook > 0: just-in-time reference rows - the last kRefLook forward
-  // steps request rows H-1 .. H-kRefLook, reverse step k requests row
-  // k - kRefLook, so that the reverse sweep reads while it computes
-  constexpr int kRefLook = APG_ROWS_REF_LOOK > HT ? HT : APG_ROWS_REF_LOOK;
+  using namespace rows_tune;
+  constexpr int kActPre = HT < kActPreMax ? HT : kActPreMax;
+  constexpr int kRefLook = kRefLookMax > HT ? HT : kRefLookMax;
   const auto r_s0 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(state0), 0, 3 * B * 16, 0x00020000);
   const auto r_act = __builtin_amdgcn_make_buffer_rsrc(
@@ -446,16 +473,16 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
   u4v s4[3], a4[HT], rA[HT];
   u2v rB[HT];
   auto ld_ref = [&](int kr) {
-    rA[kr] = __builtin_amdgcn_raw_buffer_load_b128(r_ref, v24, kr * p24, APG_ROWS_LD_AUX);
-    rB[kr] = __builtin_amdgcn_raw_buffer_load_b64(r_ref, v24 + 16, kr * p24, APG_ROWS_LD_AUX);
+    rA[kr] = __builtin_amdgcn_raw_buffer_load_b128(r_ref, v24, kr * p24, kLdAux);
+    rB[kr] = __builtin_amdgcn_raw_buffer_load_b64(r_ref, v24 + 16, kr * p24, kLdAux);
   };
 #pragma unroll
   for (int g = 0; g < 3; ++g)
-    s4[g] = __builtin_amdgcn_raw_buffer_load_b128(r_s0, v16, g * p16, APG_ROWS_LD_AUX);
+    s4[g] = __builtin_amdgcn_raw_buffer_load_b128(r_s0, v16, g * p16, kLdAux);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < kActPre; ++k)
-    a4[k] = __builtin_amdgcn_raw_buffer_load_b128(r_act, v16, k * p16, APG_ROWS_LD_AUX);
+    a4[k] = __builtin_amdgcn_raw_buffer_load_b128(r_act, v16, k * p16, kLdAux);
   __builtin_amdgcn_sched_barrier(0);
 
   // everything below the first requests can wait for the rest of the arguments
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
     {  // requests of this step
       if (k + kActPre < HT)
         a4[k + kActPre] = __builtin_amdgcn_raw_buffer_load_b128(
-            r_act, v16, (k + kActPre) * p16, APG_ROWS_LD_AUX);
+            r_act, v16, (k + kActPre) * p16, kLdAux);
       if constexpr (kRefLook == 0) {
 #pragma unroll
         for (int j = 0; j < kRefPerStep; ++j) {
@@ -535,7 +562,7 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
 #pragma unroll
   for (int k = HT - 1; k >= 0; --k) {
-    if constexpr (kRefLook > 0 && APG_ROWS_REF_TOP) {
+    if constexpr (kRefLook > 0 && kRefTop) {
       if (k == HT - 1) {
 #pragma unroll
         for (int kr = HT - 1 - kRefLook; kr >= 0; --kr) ld_ref(kr);
@@ -570,37 +597,32 @@ __global__ __launch_bounds__(APG_ROWS_BLOCK) void quad_rollout_rows_kernel(
       ga[i] = wr2 * d;
     }
     quad_step_adjoint(lam, ga, a0, st_w[k], c, st_trig[k]);
-#if APG_ROWS_STORE_AT_END
-    // rows k > kFlush are kept in registers and written when step kFlush is
-    // done (kFlush = -1, shipped: all of them after the sweep), later rows at
-    // once (profiles/r03_ab_quad.json `store_timing`)
-    constexpr int kFlush = APG_ROWS_STORE_FLUSH_AT;
-    a4[k] = (u4v){f2u(ga[0]), f2u(ga[1]), f2u(ga[2]), f2u(ga[3])};
-    if (k <= kFlush) {
-      if (k == kFlush) {
+    if constexpr (kStoreAtEnd) {
+      // rows k > kFlush are kept in registers and written when step kFlush is
+      // done (kFlush = -1, shipped: all of them after the sweep), later rows at
+      // once (profiles/r03_ab_quad.json `store_timing`)
+      constexpr int kFlush = kStoreFlushAt;
+      a4[k] = (u4v){f2u(ga[0]), f2u(ga[1]), f2u(ga[2]), f2u(ga[3])};
+      if (k <= kFlush) {
+        if (k == kFlush) {
 #pragma unroll
-        for (int j = HT - 1; j > kFlush; --j)
-          __builtin_amdgcn_raw_buffer_store_b128(a4[j], r_ga, st16, j * p16,
-                                                 APG_ROWS_ST_AUX);
+          for (int j = HT - 1; j > kFlush; --j)
+            __builtin_amdgcn_raw_buffer_store_b128(a4[j], r_ga, st16, j * p16, kStAux);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(a4[k], r_ga, st16, k * p16, kStAux);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(a4[k], r_ga, st16, k * p16,
-                                             APG_ROWS_ST_AUX);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(
+          (u4v){f2u(ga[0]), f2u(ga[1]), f2u(ga[2]), f2u(ga[3])}, r_ga, st16, k * p16,
+          kStAux);
     }
-#else
-    __builtin_amdgcn_raw_buffer_store_b128(
-        (u4v){f2u(ga[0]), f2u(ga[1]), f2u(ga[2]), f2u(ga[3])}, r_ga, st16, k * p16,
-        APG_ROWS_ST_AUX);
-#endif
     if (k == HT / 2) APG_STAMP_AT(6);
   }
-#if APG_ROWS_STORE_AT_END
-  if constexpr (APG_ROWS_STORE_FLUSH_AT < 0) {
+  if constexpr (kStoreAtEnd && kStoreFlushAt < 0) {
 #pragma unroll
     for (int k = HT - 1; k >= 0; --k)
-      __builtin_amdgcn_raw_buffer_store_b128(a4[k], r_ga, st16, k * p16,
-                                             APG_ROWS_ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(a4[k], r_ga, st16, k * p16, kStAux);
   }
-#endif
   if (R.grad_state0) {
     const auto r_gs = __builtin_amdgcn_make_buffer_rsrc(R.grad_state0, 0,
                                                         3 * B * 16, 0x00020000);
@@ -1229,7 +1251,7 @@ int launch_rollout_rows(const RolloutArgs &A, hipStream_t st) {
   R.grad_state0 = A.grad_state0, R.states_out = A.states_out;
   R.prev = A.prev;
   const QuadConst &c = A.c;
-  const dim3 grid(grid_for(A.B, APG_ROWS_BLOCK)), block(APG_ROWS_BLOCK);
+  const dim3 grid(grid_for(A.B, rows_tune::kBlock)), block(rows_tune::kBlock);
 #define APG_ROWS(HT)                                                        \
   hipLaunchKernelGGL((quad_rollout_rows_kernel<HT, SO>), grid, block, 0, st,  \
                      A.state0, A.actions, A.ref, A.B, c.dt, c.half_dt,        \
