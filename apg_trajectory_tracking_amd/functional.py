@@ -892,6 +892,12 @@ class _StaticPlanes:
 _STATIC_PLANES = _StaticPlanes()
 
 
+def static_plane_refs():
+    """Strong references to every kept plane copy (a captured step graph reads
+    them by address: its owner keeps them alive past an eviction here)."""
+    return [e[3] for e in _STATIC_PLANES.entries]
+
+
 def _ref_and_states(in_ref, state0, B, H, index=None, also=()):
     """One buffer for everything the conv-weight product reads as B operand:
     planes [0, 2H*9) = the reference tensor [2H][9][B], planes [2H*9, +(H+1)*12)

@@ -12,7 +12,11 @@ pass over dY and X on the fp32 matrix instruction (exact fp32).
 
 `Linear` is a drop-in subclass: same parameters, same state_dict keys, same
 results; on CPU tensors (oracle-side tests, checkpoint conversion) it IS
-torch.nn.Linear.  The package's own model classes use it."""
+torch.nn.Linear.  The package's own model classes use it, and the trainers
+give an arbitrary user policy the same treatment: `use_apg_linear(net)`
+(TrainBase.init_optimizer, opt out with `trainer.swap_linear = False`) turns
+every plain `torch.nn.Linear` leaf into this class in place - same Parameter
+objects, same state_dict keys."""
 import torch
 import torch.nn as nn
 
@@ -28,7 +32,11 @@ class _LinearWgrad(torch.autograd.Function):
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
+        # once_differentiable: the raw-pointer kernel below is invisible to
+        # autograd, so double backward / create_graph=True raises instead of
+        # silently returning wrong higher-order gradients
         x, weight = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad
         need_b = need_b and ctx.has_bias
@@ -38,8 +46,14 @@ class _LinearWgrad(torch.autograd.Function):
             M, N = weight.shape
             dy = grad_out.reshape(-1, M)
             xx = x.reshape(-1, N)
-            if dy.dtype != torch.float32 or not dy.is_cuda:
-                raise RuntimeError("apg nn.Linear backward: fp32 HIP tensors expected")
+            if (dy.dtype != torch.float32 or xx.dtype != torch.float32
+                    or not dy.is_cuda or dy.numel() * 4 >= _MAX_OPERAND_BYTES
+                    or xx.numel() * 4 >= _MAX_OPERAND_BYTES):
+                # what the kernel is not built for (another dtype, an operand of
+                # 4 GiB or more: 32-bit byte offsets): autograd's own formulas
+                gw = dy.t().matmul(xx).to(weight.dtype) if need_w else None
+                gb = dy.sum(0).to(weight.dtype) if need_b else None
+                return gx, gw, gb
             dy, xx = dy.contiguous(), xx.contiguous()
             lib = _capi.lib()
             gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
@@ -52,6 +66,9 @@ class _LinearWgrad(torch.autograd.Function):
             if not need_w:
                 gw = None
         return gx, gw, gb
+
+
+_MAX_OPERAND_BYTES = 1 << 32
 
 
 def linear(x, weight, bias=None):
@@ -68,3 +85,17 @@ class Linear(nn.Linear):
 
     def forward(self, x):
         return linear(x, self.weight, self.bias)
+
+
+def use_apg_linear(module):
+    """Turn every plain `torch.nn.Linear` in `module` (exact type: subclasses
+    keep their own forward) into `Linear`, IN PLACE: the class of the layer
+    object is switched, so parameters, buffers, hooks, state_dict keys and
+    every reference an optimizer holds stay what they were.  Returns the
+    number of layers switched."""
+    n = 0
+    for m in module.modules():
+        if type(m) is nn.Linear:
+            m.__class__ = Linear
+            n += 1
+    return n

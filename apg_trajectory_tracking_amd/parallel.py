@@ -76,9 +76,8 @@ class GradAllReducer:
         return self._bucket
 
     @torch.no_grad()
-    def sync(self, loss):
-        if world_size() == 1:
-            return loss
+    def pack(self, loss):
+        """Gradients + loss into the bucket (the all-reduce message)."""
         b = self._ensure_bucket(loss)
         off = 0
         for p in self.params:
@@ -89,11 +88,23 @@ class GradAllReducer:
                 b[off:off + n].copy_(p.grad.reshape(-1))
             off += n
         b[off] = loss.detach().reshape(())
-        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
+        return b
+
+    @torch.no_grad()
+    def unpack(self):
+        """The (reduced) bucket back into the gradients; returns the loss."""
+        b, off = self._bucket, 0
         for p in self.params:
             n = p.numel()
             if p.grad is not None:
                 p.grad.copy_(b[off:off + n].view_as(p.grad))
             off += n
         return b[off].clone()
+
+    @torch.no_grad()
+    def sync(self, loss):
+        if world_size() == 1:
+            return loss
+        b = self.pack(loss)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+        return self.unpack()

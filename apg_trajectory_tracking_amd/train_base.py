@@ -41,17 +41,44 @@ def momentum_sgd(params, lr):
 
 
 class _GraphedStep:
-    """One optimizer step captured into a HIP graph (kernels of the fused
-    paths, the weight-gradient products, the fused SGD update) and replayed:
-    the ~12 launches of a step cost the host ~0.25 ms of Python and launch
-    overhead, more than the GPU needs for the concurrent step.  Valid while
-    the step's input tensors are the same objects with the same in-place
-    version (TrainBase._graphed re-captures otherwise); allocations made
-    during capture live in the graph's private pool, so the gradient views the
-    optimizer reads keep their addresses across replays."""
+    """One optimizer step captured into HIP graphs and replayed: the ~12
+    launches of a step cost the host ~0.25 ms of Python and launch overhead,
+    more than the GPU needs for the concurrent step.
 
-    def __init__(self, fn, signature, keep, net, optimizer):
+    The step is cut at the slot of the data-parallel all-reduce:
+        part A  everything up to the gradient message (sweeps, weight-gradient
+                products, loss into the message's last slot; or forward +
+                autograd's backward + the bucket pack)
+        slot    all-reduce(sum) of the message - ALWAYS an eager call (a
+                captured RCCL collective that misbehaves hangs instead of
+                failing); nothing at all with one rank
+        part B  (bucket unpack,) the fused SGD update, the step's loss
+    One rank: A and B are captured into ONE graph (`split` False).  More than
+    one rank - or `TrainBase.split_graph` forced, which is how a single GPU
+    tests this scheduling - : two graphs that share a memory pool, the
+    collective between their replays.  So the N > 1 step replays the same
+    kernels from graphs as the N = 1 step does; only the collective is added.
+
+    Valid while the step's input tensors are the same objects (for resident
+    shards: with the same in-place version), the parameters / optimizer are
+    the same objects and the values the captured kernels got BY VALUE are
+    unchanged - the simulator's parameter struct, dt, the optimizer's
+    hyper-parameters (TrainBase._graph_signature re-captures otherwise).
+    Allocations made during capture live in the graph's private pool, so the
+    gradient views the optimizer reads keep their addresses across replays;
+    the plane-layout copies of a resident shard that the captured kernels read
+    are referenced from here (functional._StaticPlanes may evict them).
+
+    `capture` False (no GPU; tests/test_distributed_cpu.py): the same
+    A -> slot -> B scheduling, run eagerly."""
+
+    def __init__(self, part_a, part_b, reduce, signature, keep, net, optimizer,
+                 capture=True, split=False):
         self.signature, self.keep = signature, keep
+        self.part_a, self.part_b, self.reduce = part_a, part_b, reduce
+        self.capture, self.split = capture, split
+        if not capture:
+            return
         # the warm-up steps (allocator, momentum buffers, lazy inits, plane
         # caches - all outside the capture) must not train: parameters and
         # momentum are put back afterwards (a missing momentum buffer is a
@@ -64,7 +91,7 @@ class _GraphedStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                fn()
+                self._eager()
         torch.cuda.current_stream().wait_stream(side)
         with torch.no_grad():
             for p, v, b in zip(params, saved, bufs):
@@ -72,78 +99,78 @@ class _GraphedStep:
                 now = optimizer.state.get(p, {}).get("momentum_buffer")
                 if now is not None:
                     now.zero_() if b is None else now.copy_(b)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fn()
+        # with a process group alive its watchdog thread polls events; only
+        # THIS thread's calls may invalidate the capture
+        mode = ({"capture_error_mode": "thread_local"}
+                if parallel.world_size() > 1 else {})
+        if split:
+            self.graph_a = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a, **mode):
+                self.msg = part_a()
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), **mode):
+                self.out = part_b(self.msg)
+        else:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, **mode):
+                self.out = part_b(part_a())
+        from . import functional
+        self.planes = functional.static_plane_refs()
+
+    def _eager(self):
+        msg = self.part_a()
+        self.reduce(msg)
+        return self.part_b(msg)
 
     def __call__(self):
-        self.graph.replay()
+        if not self.capture:
+            return self._eager()
+        if self.split:
+            self.graph_a.replay()
+            self.reduce(self.msg)
+            self.graph_b.replay()
+        else:
+            self.graph.replay()
         # a private copy: the next replay overwrites the captured output
         return self.out.clone() if torch.is_tensor(self.out) else self.out
 
 
+class _NullWriter:
+    """Stand-in for the reference's `self.writer` (scripts/train_base.py:8-22,
+    116: a tensorboard SummaryWriter, or a shim whose `add_scalar` does nothing
+    when tensorboard is missing).  Scripts written against the reference call
+    `trainer.writer.add_scalar(...)` (scripts/train_drone.py:198); nothing is
+    logged here - the per-step losses are in `results_dict`."""
+
+    def add_scalar(self, *args, **kwargs):
+        return None
+
+    add_scalars = add_histogram = add_text = flush = close = add_scalar
+
+
+# The config schema of scripts/train_base.py:32-64 - keyword -> default.  Every
+# key becomes an attribute of the trainer (except `system` / `save_name`, which
+# only name the output directory); unknown keys are accepted and ignored, as
+# the reference's **kwargs does (its JSON configs carry extra entries).
+_CONFIG_DEFAULTS = dict(
+    sample_in="train_env", delta_t=0.05, delta_t_train=0.05, epoch_size=500,
+    vec_std=0.15, self_play=1.5, self_play_every_x=2, batch_size=8,
+    reset_strength=1.2, max_drone_dist=0.25, max_steps=1000,
+    thresh_div_start=4, thresh_div_end=20, thresh_stable_start=.4,
+    thresh_stable_end=.8, state_size=12, horizon=10, ref_dim=3, action_dim=4,
+    l2_lambda=0.1, learning_rate_controller=0.0001, learning_rate_dynamics=0.001,
+    speed_factor=.6, resample_every=3, suc_up_down=1, train_mode="concurrent",
+    system="quad", save_name="test_model")
+
+
 class TrainBase:
 
-    def __init__(
-        self,
-        train_dynamics,
-        eval_dynamics,
-        sample_in="train_env",
-        delta_t=0.05,
-        delta_t_train=0.05,
-        epoch_size=500,
-        vec_std=0.15,
-        self_play=1.5,
-        self_play_every_x=2,
-        batch_size=8,
-        reset_strength=1.2,
-        max_drone_dist=0.25,
-        max_steps=1000,
-        thresh_div_start=4,
-        thresh_div_end=20,
-        thresh_stable_start=.4,
-        thresh_stable_end=.8,
-        state_size=12,
-        horizon=10,
-        ref_dim=3,
-        action_dim=4,
-        l2_lambda=0.1,
-        learning_rate_controller=0.0001,
-        learning_rate_dynamics=0.001,
-        speed_factor=.6,
-        resample_every=3,
-        suc_up_down=1,
-        train_mode="concurrent",
-        system="quad",
-        save_name="test_model",
-        **kwargs
-    ):
-        self.sample_in = sample_in
-        self.delta_t = delta_t
-        self.delta_t_train = delta_t_train
-        self.epoch_size = epoch_size
-        self.vec_std = vec_std
-        self.self_play = self_play
-        self.self_play_every_x = self_play_every_x
-        self.batch_size = batch_size
-        self.reset_strength = reset_strength
-        self.max_drone_dist = max_drone_dist
-        self.thresh_div_start = thresh_div_start
-        self.thresh_div_end = thresh_div_end
-        self.thresh_stable_start = thresh_stable_start
-        self.thresh_stable_end = thresh_stable_end
-        self.state_size = state_size
-        self.horizon = horizon
-        self.ref_dim = ref_dim
-        self.action_dim = action_dim
-        self.l2_lambda = l2_lambda
-        self.speed_factor = speed_factor
-        self.max_steps = max_steps
-        self.resample_every = resample_every
-        self.suc_up_down = suc_up_down
-        self.learning_rate_controller = learning_rate_controller
-        self.learning_rate_dynamics = learning_rate_dynamics
-        self.train_mode = train_mode
+    def __init__(self, train_dynamics, eval_dynamics, **config):
+        cfg = {k: config.get(k, d) for k, d in _CONFIG_DEFAULTS.items()}
+        system, save_name = cfg.pop("system"), cfg.pop("save_name")
+        for key, value in cfg.items():
+            setattr(self, key, value)
+        suc_up_down = self.suc_up_down
 
         self.results_dict = defaultdict(list)
         self.results_dict["loss"].append(0)
@@ -159,16 +186,26 @@ class TrainBase:
         self.sampled_data_count = 0
         self.current_score = 0 if suc_up_down == 1 else np.inf
 
+        self.writer = _NullWriter()
         self.state_data = None
         self.net = None
         self.trainloader = None
         self.optimizer_controller = None
         self.grad_sync = None
         self.shuffle = True
-        # True: steps on unchanged resident tensors are replayed from a
-        # captured HIP graph (single process only: the data-parallel
-        # all-reduce stays an eager call between the kernels and the update)
-        self.graph_steps = False
+        # True (default since round 4): the fused steps of run_epoch (index
+        # batches) and steps on unchanged resident tensors (static_shard) are
+        # replayed from captured HIP graphs (_GraphedStep: with more than one
+        # rank as two graphs around the eager all-reduce).  The simulator's
+        # parameters, dt and the optimizer's hyper-parameters are part of the
+        # capture's signature: changing them re-captures, nothing goes stale.
+        self.graph_steps = True
+        # None: two graphs around the all-reduce slot iff world > 1; True
+        # forces that form on one rank (tests, bench.py's like-for-like number)
+        self.split_graph = None
+        # True: run the graphed scheduling without a GPU (parts executed
+        # eagerly; the gloo tests of the N > 1 step)
+        self.graph_emulation = False
         self._graphs = {}
         self._index_bufs = {}
 
@@ -198,6 +235,13 @@ class TrainBase:
             self.dataset_tensors(), self.batch_size, shuffle=self.shuffle,
             shard=(parallel.rank(), parallel.world_size()),
             shard_seed=getattr(self, "shard_seed", 0))
+        # an arbitrary user policy gets the library's weight gradient: plain
+        # torch.nn.Linear layers become nn.Linear in place (dW = dY^T X over
+        # 65 536 rows: 15-70 us instead of rocBLAS' 155-225 us per layer);
+        # state_dict keys and parameter objects are unchanged
+        if getattr(self, "swap_linear", True) and isinstance(self.net, torch.nn.Module):
+            from .nn import use_apg_linear
+            use_apg_linear(self.net)
         # replicas must start equal: the sum all-reduce keeps them equal
         parallel.broadcast_module(self.net)
         if isinstance(self.train_dynamics, torch.nn.Module):
@@ -240,33 +284,125 @@ class TrainBase:
         return loss
 
     def _graphable(self):
-        return (self.graph_steps and parallel.world_size() == 1
-                and torch.cuda.is_available())
+        return bool(self.graph_steps) and (torch.cuda.is_available()
+                                           or self.graph_emulation)
 
-    def _graphed(self, key, inputs, fn, volatile=()):
-        """fn() - through a captured graph when `graph_steps` is on and the
-        inputs are the same tensor objects, unchanged, as at capture time.
-        `volatile`: tensors the captured kernels read whose CONTENT may differ
-        from replay to replay (same object, same shape) - the index batch."""
+    def _reducing(self):
+        """The step has an all-reduce slot (real or, when forced, empty)."""
+        return parallel.world_size() > 1 or bool(self.split_graph)
+
+    @staticmethod
+    def _reduce(msg):
+        if msg is not None and parallel.world_size() > 1:
+            parallel.dist.all_reduce(msg, op=parallel.dist.ReduceOp.SUM)
+
+    def _graph_signature(self, inputs, volatile):
+        """What a captured step is tied to.  Resident-shard captures (no
+        `volatile` index buffer) also depend on the CONTENT of their inputs
+        (kept plane copies): the in-place version counters are part of it."""
+        import ctypes
+        dyn = self.train_dynamics
+        phys = getattr(dyn, "params", None)
+        phys = bytes(phys) if isinstance(phys, ctypes.Structure) else id(dyn)
+        opt = self.optimizer_controller
+        hyper = tuple(tuple(sorted((k, v) for k, v in g.items()
+                                   if isinstance(v, (int, float, bool))))
+                      for g in opt.param_groups)
+        versions = not volatile
+        return (tuple((id(t), t._version if versions else 0, tuple(t.shape))
+                      for t in inputs)
+                + tuple((id(t), tuple(t.shape)) for t in volatile)
+                # a replaced network or optimizer must not replay the old graph
+                + tuple(id(p) for p in self.net.parameters())
+                + (id(opt), hyper, phys, float(self.delta_t),
+                   float(self.delta_t_train), self._reducing()))
+
+    def _graphed(self, key, inputs, parts, volatile=()):
+        """Run the step `parts` = (part_a, part_b) (see _GraphedStep) - through
+        captured graphs when `graph_steps` is on and the capture's signature
+        still holds.  `volatile`: tensors the captured kernels read whose
+        CONTENT may differ from replay to replay (same object, same shape) -
+        the index batch."""
+        part_a, part_b = parts
         if not self._graphable():
-            return fn()
-
-        def signature():
-            # + the parameter tensors and the optimizer the capture is tied to
-            # (a replaced network or optimizer must not replay the old graph)
-            return (tuple((id(t), t._version, tuple(t.shape)) for t in inputs)
-                    + tuple((id(t), tuple(t.shape)) for t in volatile)
-                    + tuple(id(p) for p in self.net.parameters())
-                    + (id(self.optimizer_controller),))
-        sig = signature()
+            msg = part_a()
+            self._reduce(msg)
+            return part_b(msg)
+        sig = self._graph_signature(inputs, volatile)
         g = self._graphs.get(key)
         if g is None or g.signature != sig:
-            g = self._graphs[key] = _GraphedStep(
-                fn, sig, list(inputs) + list(volatile), self.net,
-                self.optimizer_controller)
-            # the capture's own warm-up steps may have bumped nothing; re-read
-            g.signature = signature()
+            try:
+                g = _GraphedStep(
+                    part_a, part_b, self._reduce, sig,
+                    list(inputs) + list(volatile), self.net,
+                    self.optimizer_controller,
+                    capture=torch.cuda.is_available(), split=self._reducing())
+            except RuntimeError as e:
+                # a capture that the runtime refuses must not end the run: this
+                # trainer steps eagerly from here on (the warm-up steps have
+                # been undone, the failed capture trained nothing)
+                import warnings
+                warnings.warn(f"graph capture of the {key} step failed ({e}); "
+                              "graph_steps switched off for this trainer")
+                self.graph_steps = False
+                self._graphs.clear()
+                torch.cuda.synchronize()
+                msg = part_a()
+                self._reduce(msg)
+                return part_b(msg)
+            self._graphs[key] = g
+            # the capture's own warm-up steps may have bumped versions; re-read
+            g.signature = self._graph_signature(inputs, volatile)
         return g()
+
+    def _direct_parts(self, compute):
+        """(part_a, part_b) of a fused-policy step: compute() -> (loss,
+        {name: gradient}, flat) as the functional `*_grads` entry points
+        return them; the gradients are attached as `.grad` directly."""
+        state = {}
+
+        def part_a():
+            loss, grads, flat = compute()
+            for name, p in self.net.named_parameters():
+                p.grad = grads.get(name)
+            state["loss"], state["flat"] = loss, flat
+            if not self._reducing():
+                return None
+            if flat is not None:
+                flat[-1] = loss.detach().reshape(())
+                return flat
+            return self.grad_sync.pack(loss.detach())
+
+        def part_b(msg):
+            if msg is None:
+                loss = state["loss"]
+            elif msg is state["flat"]:
+                loss = msg[-1]
+            else:
+                loss = self.grad_sync.unpack()
+            self.optimizer_controller.step()
+            return loss
+        return part_a, part_b
+
+    def _autograd_parts(self, forward_loss):
+        """(part_a, part_b) of a step whose policy is plain PyTorch:
+        forward_loss() builds the loss, autograd's backward fills `.grad`."""
+        state = {}
+
+        def part_a():
+            self.optimizer_controller.zero_grad()
+            loss = forward_loss()
+            loss.backward()
+            state["loss"] = loss.detach()
+            if not self._reducing() or self.grad_sync is None:
+                return None
+            return self.grad_sync.pack(state["loss"])
+
+        def part_b(msg):
+            loss = state["loss"] if msg is None else self.grad_sync.unpack()
+            self.optimizer_controller.step()
+            return loss
+        return part_a, part_b
 
     def _graph_index(self, index):
         """The persistent device copy of an index batch that a captured step

@@ -113,38 +113,37 @@ class TrainDrone(TrainBase):
             index = held      # the captured gather reads this buffer
         if self.train_mode == "LSTM":
             if self.fused_policy and self._fusable():
-                def step():
+                def compute():
                     self.net.reset_hidden_state(
                         batch_size, generator=self.hidden_generator)
-                    loss, grads, flat = F.quad_lstm_rollout_grads(
+                    return F.quad_lstm_rollout_grads(
                         self.net, current_state, in_ref_states, ref_states,
                         self.delta_t, self.train_dynamics.params,
                         self.net.hidden_state, self.net.cell_state, index=index,
                         static_inputs=self.static_shard)
-                    return self._step_direct(loss, grads, flat)
                 # (a private hidden-state generator is not registered with the
                 # graph: those runs step eagerly)
                 if held is not None:
-                    return self._graphed(("lstm", batch_size), tensors, step,
-                                         volatile=(held,))
+                    return self._graphed(("lstm", batch_size), tensors,
+                                         self._direct_parts(compute), volatile=(held,))
                 if static and self.hidden_generator is None:
-                    return self._graphed("lstm", tensors, step)
-                return step()
+                    return self._graphed("lstm", tensors, self._direct_parts(compute))
+                return self._step_direct(*compute())
             self.net.reset_hidden_state(
                 batch_size, generator=self.hidden_generator)
         elif self.fused_policy and self._fusable_mlp():
-            def step():
-                loss, grads, flat = F.quad_mlp_rollout_grads(
+            def compute():
+                return F.quad_mlp_rollout_grads(
                     self.net, current_state, in_ref_states, ref_states,
                     self.delta_t, self.train_dynamics.params, index=index,
                     static_inputs=self.static_shard)
-                return self._step_direct(loss, grads, flat)
             if held is not None:
-                return self._graphed(("autoregressive", batch_size), tensors, step,
-                                     volatile=(held,))
+                return self._graphed(("autoregressive", batch_size), tensors,
+                                     self._direct_parts(compute), volatile=(held,))
             if static:
-                return self._graphed("autoregressive", tensors, step)
-            return step()
+                return self._graphed("autoregressive", tensors,
+                                     self._direct_parts(compute))
+            return self._step_direct(*compute())
         if index is not None:     # per-step path: materialise the batch
             current_state, in_ref_states, ref_states = (
                 t.index_select(0, index) for t in
@@ -200,18 +199,17 @@ class TrainDrone(TrainBase):
         if held is not None:
             index = held      # the captured gather reads this buffer
 
-        def step():
-            loss, grads, flat = F.quad_concurrent_policy_grads(
+        def compute():
+            return F.quad_concurrent_policy_grads(
                 n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
                 self.train_dynamics.params, index=index,
                 static_inputs=self.static_shard)
-            return self._step_direct(loss, grads, flat)
         if held is not None:
-            return self._graphed(("concurrent", held.numel()), tensors, step,
-                                 volatile=(held,))
+            return self._graphed(("concurrent", held.numel()), tensors,
+                                 self._direct_parts(compute), volatile=(held,))
         if index is None and self.static_shard:
-            return self._graphed("concurrent", tensors, step)
-        return step()
+            return self._graphed("concurrent", tensors, self._direct_parts(compute))
+        return self._step_direct(*compute())
 
     # ------------------------------------------- packed (row-layout) path --
     # scripts/train_base.py:198-209 + scripts/train_drone.py:175-203 for ANY
@@ -244,20 +242,20 @@ class TrainDrone(TrainBase):
         state0_rows [3, B, 4], ref_rows [H, B, 6] = [pos, vel]; policy inputs
         in the reference's layout.  Same arithmetic as run_epoch's concurrent
         body followed by train_controller_model."""
-        def step():
-            self.optimizer_controller.zero_grad()
+        def forward_loss():
             action_rows = self.policy_action_rows(in_state, in_ref_states)
-            loss = F.quad_rollout_loss(
+            return F.quad_rollout_loss(
                 state0_rows, action_rows, ref_rows, self.delta_t,
                 self.train_dynamics.params, layout="packed")
-            return self._step(loss).detach()
         if self.static_shard:
             # resident tensors: forward, autograd's backward and the update are
             # captured once and replayed (graph_steps; the policy is arbitrary
             # PyTorch code, so ~40 small launches per step otherwise)
             return self._graphed("packed", (in_state, in_ref_states, state0_rows,
-                                            ref_rows), step)
-        return step()
+                                            ref_rows),
+                                 self._autograd_parts(forward_loss)).detach()
+        self.optimizer_controller.zero_grad()
+        return self._step(forward_loss()).detach()
 
     def _fusable_learnt(self):
         from .dynamics.quad_dynamics_trained import LearntDynamics

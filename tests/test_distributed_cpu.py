@@ -145,12 +145,15 @@ def _epoch_run(world_sharded):
     return losses, {k: v.numpy() for k, v in trainer.net.state_dict().items()}
 
 
-def _ar_steps(lo, hi):
+def _ar_steps(lo, hi, graphed=False, split=None):
     """The code path of `bench.py --mode ar` / BASELINE configs[2]: the REAL
     TrainDrone.train_recurrent_model (autoregressive, fused branch) ->
     TrainBase._step_direct -> one flat all-reduce + SGD.  Only the kernel
     call (functional.quad_mlp_rollout_grads) is replaced by the CPU oracle's
-    autoregressive unroll, handing back the same (loss, views, flat) triple."""
+    autoregressive unroll, handing back the same (loss, views, flat) triple.
+    `graphed`: through TrainBase._graphed / _GraphedStep's scheduling (part A
+    -> all-reduce slot -> part B), emulated eagerly as there is no GPU here -
+    with two ranks that is the split form the GPUs run."""
     from apg_trajectory_tracking_amd import functional as F, synthetic
     from apg_trajectory_tracking_amd.models.hutter_model import Net
     from apg_trajectory_tracking_amd.train_drone import TrainDrone
@@ -189,9 +192,16 @@ def _ar_steps(lo, hi):
         t.state_data = Data
         t.init_optimizer()
         assert t._fusable_mlp()
-        losses = [float(t.train_recurrent_model(
-            None, Data.states[lo:hi], Data.in_ref_states[lo:hi],
-            Data.ref_states[lo:hi])) for _ in range(2)]
+        shard = (Data.states[lo:hi], Data.in_ref_states[lo:hi], Data.ref_states[lo:hi])
+        if graphed:
+            t.static_shard, t.graph_steps, t.graph_emulation = True, True, True
+            t.split_graph = split
+        else:
+            t.graph_steps = False
+        losses = [float(t.train_recurrent_model(None, *shard)) for _ in range(2)]
+        if graphed:      # one _GraphedStep, replayed; split iff it has the slot
+            g, = t._graphs.values()
+            assert g.split == (dist.is_initialized() or bool(split)) and not g.capture
         return losses, {k: v.numpy() for k, v in t.net.state_dict().items()}
     finally:
         F.quad_mlp_rollout_grads = orig
@@ -226,6 +236,11 @@ def _worker(rank, world, port, out_dir):
         # bench.py --mode ar: autoregressive trainer step, flat all-reduce
         losses, sd = _ar_steps(lo, hi)
         np.savez(os.path.join(out_dir, f"ar_rank{rank}.npz"),
+                 losses=np.array(losses), **sd)
+        # the same through the graphed step's scheduling (two parts around the
+        # eager all-reduce: what `graph_steps` runs with more than one rank)
+        losses, sd = _ar_steps(lo, hi, graphed=True)
+        np.savez(os.path.join(out_dir, f"arg_rank{rank}.npz"),
                  losses=np.array(losses), **sd)
         # the epoch loop itself: parameter broadcast, shared permutation,
         # per-rank slices of every global minibatch
@@ -264,6 +279,12 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
         for k, v in ref_sd.items():
             assert rel_err(g[k], v) < 1e-5, (r, k)
 
+    for r in range(world):          # split-graph scheduling == the eager step
+        g, e = np.load(tmp_path / f"arg_rank{r}.npz"), np.load(tmp_path / f"ar_rank{r}.npz")
+        assert np.array_equal(g["losses"], e["losses"])
+        for k in ref_sd:
+            assert np.array_equal(g[k], e[k]), (r, k)
+
     ref_losses, ref_sd = _epoch_run(False)          # run_epoch, sharded loader
     for r in range(world):
         g = np.load(tmp_path / f"epoch_rank{r}.npz")
@@ -280,6 +301,58 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
         np.testing.assert_allclose(g["losses"], ref_losses, rtol=1e-5)
         for k, v in ref_sd.items():
             assert rel_err(g[k], v) < 1e-5, (r, k)
+
+
+def test_graphed_step_scheduling_single_process():
+    """One rank: the graphed step is ONE part-A + part-B sequence without a
+    message; with `split_graph` forced it has the (empty) all-reduce slot and
+    the loss travels in the flat buffer's last element - both equal the eager
+    step bit for bit."""
+    eager = _ar_steps(0, B)
+    for split in (None, True):
+        losses, sd = _ar_steps(0, B, graphed=True, split=split)
+        assert losses == eager[0]
+        for k, v in eager[1].items():
+            assert np.array_equal(sd[k], v), k
+
+
+def test_graph_signature_covers_values_captured_by_value():
+    """a captured step bakes in the simulator's parameter struct,
+    dt and the optimizer's learning rate - each of them must change the
+    signature (so the step is re-captured, not replayed stale)."""
+    import ctypes
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+
+    class P(ctypes.Structure):
+        _fields_ = [("mass", ctypes.c_float), ("g", ctypes.c_float)]
+
+    class Dyn:
+        params = P(1.0, 9.81)
+    cfg = dict(delta_t=DT, horizon=H, batch_size=B, ref_dim=9, action_dim=4,
+               train_mode="autoregressive", system="quad")
+    t = TrainDrone(Dyn(), Dyn(), cfg)
+    t.net = Net(15, H, 9, 4, conv=1)
+    from apg_trajectory_tracking_amd.train_base import momentum_sgd
+    t.optimizer_controller = momentum_sgd(t.net.parameters(), 1e-4)
+    x = torch.zeros(4, 12)
+    base = t._graph_signature((x,), ())
+    assert t._graph_signature((x,), ()) == base
+    t.train_dynamics.params.mass = 1.5
+    s1 = t._graph_signature((x,), ())
+    assert s1 != base
+    t.delta_t = 0.05
+    s2 = t._graph_signature((x,), ())
+    assert s2 != s1
+    t.optimizer_controller.param_groups[0]["lr"] = 3e-4
+    s3 = t._graph_signature((x,), ())
+    assert s3 != s2
+    x.add_(1)                    # resident-shard captures follow the content
+    assert t._graph_signature((x,), ()) != s3
+    idx = torch.zeros(4, dtype=torch.int64)
+    v0 = t._graph_signature((x,), (idx,))
+    x.add_(1)                    # index-batch captures read the data set live
+    assert t._graph_signature((x,), (idx,)) == v0
 
 
 def test_grad_allreducer_is_noop_single_process():

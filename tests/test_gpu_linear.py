@@ -141,27 +141,129 @@ def test_packed_step_replayed_from_a_graph_equals_eager(dev):
     torch.manual_seed(1)
     proto = Policy()
     runs = []
-    for graph in (False, True):
+    from apg_trajectory_tracking_amd.parallel import GradAllReducer
+    for graph, split in ((False, None), (True, None), (True, True)):
         dyn = FlightmareDynamics()
         t = TrainDrone(dyn, dyn, dict(cfg))
         t.net = copy.deepcopy(proto).to(dev)
         t.state_data = data
         t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=1e-6, momentum=0.9)
-        t.static_shard, t.graph_steps = True, graph
+        t.grad_sync = GradAllReducer(t.net.parameters())
+        t.static_shard, t.graph_steps, t.split_graph = True, graph, split
         losses = [t.train_controller_packed(data.normed_states, data.in_ref_states,
                                             *rows).item() for _ in range(3)]
         runs.append((losses, {k: v.clone() for k, v in t.net.state_dict().items()}))
         assert (len(t._graphs) == 1) == graph
         if graph:       # a new network: the old capture must not be replayed
             first = t._graphs["packed"]
+            assert first.split == bool(split)
             t.net = copy.deepcopy(proto).to(dev)
             t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=1e-6,
                                                      momentum=0.9)
+            t.grad_sync = GradAllReducer(t.net.parameters())
             again = t.train_controller_packed(data.normed_states, data.in_ref_states,
                                               *rows).item()
             assert t._graphs["packed"] is not first
             assert abs(again - losses[0]) / losses[0] < 1e-6
-    (la, wa), (lb, wb) = runs
+    (la, wa), (lb, wb), (lc, wc) = runs
     assert np.allclose(la, lb, rtol=1e-6) and la[0] != la[2]
     for k in wa:
         assert rel_err(wb[k].cpu().numpy(), wa[k].cpu().numpy()) < 1e-6, k
+    # the N > 1 form (graph A: forward + backward + bucket pack; empty
+    # all-reduce slot; graph B: unpack + update) on one GPU: same numbers
+    assert np.allclose(la, lc, rtol=1e-6)
+    for k in wa:
+        assert rel_err(wc[k].cpu().numpy(), wa[k].cpu().numpy()) < 1e-6, k
+
+
+def test_unmodified_user_policy_gets_the_library_weight_gradient(dev):
+    """a user's policy written with stock torch.nn.Linear layers
+    takes the fast weight-gradient path without the caller doing anything -
+    init_optimizer switches the layers in place (same Parameter objects, same
+    state_dict keys), run_epoch's row-layout path then calls apg_linear_wgrad
+    once per layer and step; `swap_linear = False` opts out.  Both give the
+    same epoch."""
+    import copy
+    from apg_trajectory_tracking_amd import nn as apg_nn
+    from apg_trajectory_tracking_amd.dataset import SyntheticQuadDataset
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+
+    class UserPolicy(torch.nn.Module):      # nothing of this package in here
+        def __init__(self):
+            super().__init__()
+            self.inp = torch.nn.Linear(15 + 90, 64)
+            self.mid = torch.nn.Linear(64, 32)
+            self.out = torch.nn.Linear(32, 40)
+
+        def forward(self, state, ref):
+            x = torch.cat((state, ref.flatten(1)), 1)
+            return self.out(torch.tanh(self.mid(torch.tanh(self.inp(x)))))
+    B, H = 900, 10
+    cfg = dict(delta_t=0.1, delta_t_train=0.1, epoch_size=B, self_play=0, batch_size=300,
+               state_size=12, horizon=H, train_mode="concurrent", ref_dim=9,
+               action_dim=4, learning_rate_controller=1e-6, system="quad",
+               modified_params={})
+    torch.manual_seed(5)
+    proto = UserPolicy()
+    calls = []
+    real_check = apg_nn._capi.check
+    runs = []
+    try:
+        apg_nn._capi.check = lambda st, name: (calls.append(name), real_check(st, name))[1]
+        for swap in (True, False):
+            dyn = FlightmareDynamics()
+            t = TrainDrone(dyn, dyn, dict(cfg))
+            t.net = copy.deepcopy(proto).to(dev)
+            t.state_data = SyntheticQuadDataset(B, H, 0.1, seed=4, device=dev)
+            t.swap_linear = swap
+            t.graph_steps = False        # count the calls of every step
+            keys, ids = list(t.net.state_dict()), [id(p) for p in t.net.parameters()]
+            t.init_optimizer()
+            assert list(t.net.state_dict()) == keys
+            assert [id(p) for p in t.net.parameters()] == ids
+            assert all((type(m) is apg_nn.Linear) == swap
+                       for m in (t.net.inp, t.net.mid, t.net.out))
+            del calls[:]
+            torch.manual_seed(9)         # the permutation
+            loss = t.run_epoch(train="controller", epoch=0)
+            assert calls.count("apg_linear_wgrad") == (3 * 3 if swap else 0), calls
+            runs.append((loss, {k: v.clone() for k, v in t.net.state_dict().items()}))
+    finally:
+        apg_nn._capi.check = real_check
+    (la, wa), (lb, wb) = runs
+    assert abs(la - lb) / abs(lb) < 1e-5
+    for k in wa:
+        assert rel_err(wa[k].cpu().numpy(), wb[k].cpu().numpy()) < 1e-5, k
+
+
+def test_drop_in_linear_refuses_double_backward_and_falls_back_when_unsupported(dev):
+    """the backward is once-differentiable (create_graph raises
+    instead of returning silent garbage); operands the kernel is not built for
+    take autograd's own formulas instead of raising."""
+    from apg_trajectory_tracking_amd import nn as apg_nn
+    torch.manual_seed(3)
+    lin = apg_nn.Linear(7, 5).to(dev)
+    x = torch.randn(33, 7, device=dev, requires_grad=True)
+    g2 = torch.autograd.grad(lin(x).pow(2).sum(), lin.weight, create_graph=True)[0]
+    with pytest.raises(RuntimeError):
+        g2.sum().backward()
+    # an operand the kernel is not built for (>= 4 GiB; here the limit is
+    # lowered instead): autograd's own formulas, same numbers
+    calls = []
+    real_check = apg_nn._capi.check
+    apg_nn._capi.check = lambda st, name: (calls.append(name), real_check(st, name))[1]
+    limit = apg_nn._MAX_OPERAND_BYTES
+    try:
+        grads = []
+        for lim in (limit, 64):
+            apg_nn._MAX_OPERAND_BYTES = lim
+            lin.zero_grad()
+            lin(x.detach()).pow(2).sum().backward()
+            grads.append((lin.weight.grad.clone(), lin.bias.grad.clone()))
+        assert calls == ["apg_linear_wgrad"]          # the second pass fell back
+    finally:
+        apg_nn._MAX_OPERAND_BYTES, apg_nn._capi.check = limit, real_check
+    assert rel_err(grads[1][0].cpu().numpy(), grads[0][0].cpu().numpy()) < 1e-6
+    assert rel_err(grads[1][1].cpu().numpy(), grads[0][1].cpu().numpy()) < 1e-6

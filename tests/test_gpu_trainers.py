@@ -1340,7 +1340,9 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
     proto = (LSTM_NEW(15, H, 9, 4, conv=1) if mode == "LSTM" else
              Net(15, H, 9, 40 if mode == "concurrent" else 4, conv=1))
     losses = []
-    for static, graph in ((False, False), (True, False), (True, True)):
+    finals = []
+    for static, graph, split in ((False, False, None), (True, False, None),
+                                 (True, True, None), (True, True, True)):
         F._STATIC_PLANES.entries.clear()
         t = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
         t.net = type(proto)(15, H, 9, proto.fc_out.out_features, conv=1).to(dev)
@@ -1349,6 +1351,7 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
                                                  momentum=0.9)
         t.static_shard = static
         t.graph_steps = graph        # + the step replayed from a HIP graph
+        t.split_graph = split        # ... as two graphs around the all-reduce slot
         if mode == "LSTM":           # (h0, c0): the default generator, re-seeded
             torch.cuda.manual_seed(77)
         s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
@@ -1364,9 +1367,12 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
                 loss = t.train_recurrent_model(None, s0, in_ref, ref)
             out.append(loss.item())
         losses.append(out)
+        finals.append({k: v.clone() for k, v in t.net.state_dict().items()})
         assert (len(F._STATIC_PLANES.entries) > 0) == static
         assert (len(t._graphs) > 0) == graph
-    a, b, c = losses
+        for g in t._graphs.values():
+            assert g.capture and g.split == bool(split)
+    a, b, c, d_ = losses
     assert abs(a[1] - a[2]) / abs(a[1]) > 1e-4       # the change matters
     for x, y in zip(a, b):
         assert abs(x - y) / abs(x) < 1e-6, (a, b)
@@ -1376,10 +1382,74 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
         # after the data changed
         for x, y in zip(a, c):
             assert abs(x - y) / abs(x) < 1e-6, (a, c)
+        # the N > 1 form on one GPU - graph A, (empty) all-reduce slot, graph B,
+        # the loss through the flat buffer's last element - is the eager step
+        # BIT FOR BIT: losses and the weights after four updates
+        assert d_ == b and d_ == c, (b, c, d_)
+        for k in finals[1]:
+            assert torch.equal(finals[3][k], finals[1][k]), k
+            assert torch.equal(finals[3][k], finals[2][k]), k
     else:
         # fresh (h0, c0) ~ N(0, 1) every step: graphed steps draw through the
         # captured generator state, so only the statistics agree
         assert all(np.isfinite(c)) and abs(c[0] - a[0]) / abs(a[0]) < 0.2
+    F._STATIC_PLANES.entries.clear()
+
+
+def test_graphed_step_follows_lr_and_physics_changes(dev):
+    """the captured kernels get the simulator's parameters, dt and
+    the learning rate BY VALUE.  Changing any of them after the capture must
+    re-capture (they are part of the signature): lr = 0 stops the weights, a
+    new parameter struct gives the loss of an eager trainer built with it."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    B, H = 300, 10
+    cfg = dict(QUAD_CFG, train_mode="concurrent", batch_size=B,
+               learning_rate_controller=1e-7)
+    d = synthetic.quad_polynomial_batch(B, H, 0.1, seed=19, ref_length=H)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    normed = state_preprocessing(s0)
+    torch.manual_seed(2)
+    proto = Net(15, H, 9, 40, conv=1)
+    windy = {"translational_drag": [0.3, -0.2, 0.1]}
+
+    def trainer(params, graph):
+        F._STATIC_PLANES.entries.clear()
+        t = make_trainer(TrainDrone, FlightmareDynamics(modified_params=params), cfg)
+        t.net = Net(15, H, 9, 40, conv=1).to(dev)
+        t.net.load_state_dict(proto.state_dict())
+        t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=1e-7,
+                                                 momentum=0.9)
+        t.static_shard, t.graph_steps = True, graph
+        return t
+    step = lambda t: t.train_concurrent_fused(normed, s0, in_ref, ref).item()
+    t = trainer({}, True)
+    l0 = step(t)
+    first = t._graphs["concurrent"]
+    step(t)
+    assert t._graphs["concurrent"] is first          # replayed
+    # lr -> 0 (momentum 0 too: the buffers must not move the weights either)
+    t.optimizer_controller.param_groups[0].update(lr=0.0, momentum=0.0)
+    before = {k: v.clone() for k, v in t.net.state_dict().items()}
+    step(t)
+    assert t._graphs["concurrent"] is not first      # re-captured
+    for k, v in t.net.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    # new physics on the SAME weights: the loss of an eager trainer with it
+    second = t._graphs["concurrent"]
+    t.train_dynamics = FlightmareDynamics(modified_params=windy)
+    l_new = step(t)
+    assert t._graphs["concurrent"] is not second
+    e = trainer(windy, False)
+    e.net.load_state_dict(before)
+    l_eager = step(e)
+    assert l_new == l_eager and abs(l_new - l0) / abs(l0) > 1e-4, (l0, l_new, l_eager)
+    # a captured graph keeps the plane copies it reads alive past an eviction
+    assert t._graphs["concurrent"].planes
     F._STATIC_PLANES.entries.clear()
 
 
