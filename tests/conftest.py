@@ -43,6 +43,40 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / denom)
 
 
+def per_trajectory_err(got, want):
+    """e_b = max|got_b - want_b| / max|want_b| for every trajectory b (leading
+    axis); float64."""
+    want = np.asarray(want, dtype=np.float64)
+    B = want.shape[0]
+    g, w = np.asarray(got, dtype=np.float64).reshape(B, -1), want.reshape(B, -1)
+    return np.abs(g - w).max(1) / np.maximum(np.abs(w).max(1), 1e-30)
+
+
+def assert_no_worse_than_fp32(dev, f32, f64, what, factor=2.0, floor=1e-6,
+                              bar=1e-4, frac=1e-3):
+    """VERDICT r3 #4a: the float64 oracle arbitrates.  Per-trajectory errors
+    of the DEVICE result and of the float32 ORACLE (the reference's own
+    arithmetic) are both taken against the float64 oracle; on the worst
+    `frac` of the trajectories (each side's own worst set: the errors are
+    rounding noise, the same trajectory is not the worst for both) the device
+    must not be more than `factor` x as far from the exact result as the
+    reference's float32 path is - in the maximum and in the mean of that set -
+    and every single trajectory must meet north_star's 1e-4 by itself.
+    Returns the statistics (printed by the callers: -s shows them)."""
+    e_dev = np.sort(per_trajectory_err(dev, f64))
+    e_f32 = np.sort(per_trajectory_err(f32, f64))
+    n = max(1, int(len(e_dev) * frac))
+    stats = dict(what=what, worst_dev=e_dev[-1], worst_f32=e_f32[-1],
+                 tail_mean_dev=e_dev[-n:].mean(), tail_mean_f32=e_f32[-n:].mean(),
+                 median_dev=np.median(e_dev), median_f32=np.median(e_f32), tail=n)
+    print("fp64 arbiter:", {k: (float("%.3g" % v) if isinstance(v, float) else v)
+                            for k, v in stats.items()})
+    assert e_dev[-1] < bar, stats
+    assert e_dev[-1] <= factor * e_f32[-1] + floor, stats
+    assert e_dev[-n:].mean() <= factor * e_f32[-n:].mean() + floor, stats
+    return stats
+
+
 # ---- fixed-wing closed loop (G15): shared by the CPU and the GPU tests ------
 def wing_loop_policy(device="cpu"):
     """The controller the reference ships (trained_models/wing), rebuilt from

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_no_worse_than_fp32, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -88,8 +88,20 @@ def test_recurrent_fused_full_size_vs_fp64_oracle(dev, mode):
     assert abs(loss.item() - loss64.item()) / loss64.item() < 1e-5
     assert rel_err(st, inter.detach().numpy()) < TOL
     assert rel_err(ac, acts.detach().numpy()) < TOL
-    worst, med = per_traj(st, inter.detach().numpy())
-    assert worst < 1e-3 and med < 1e-5, (worst, med)
+    _, med = per_traj(st, inter.detach().numpy())
+    assert med < 1e-5, med
+    # per trajectory the float64 oracle arbitrates: the same unroll in float32
+    # (the reference's arithmetic) is the yardstick for the kernels' error
+    with torch.no_grad():
+        net32 = copy.deepcopy(net)
+        if mode == "lstm":
+            net32.hidden_state, net32.cell_state = h0.clone(), c0.clone()
+        inter32, acts32, _ = tp.quad_recurrent_unroll(
+            net32, tp.QuadOracle(), d["state0"], d["in_ref"], d["ref"], H, dt)
+    assert_no_worse_than_fp32(st, inter32.numpy(), inter.detach().numpy(),
+                              f"{mode} states")
+    assert_no_worse_than_fp32(ac, acts32.numpy(), acts.detach().numpy(),
+                              f"{mode} actions")
     got = {k: N(p.grad) for k, p in gnet.named_parameters() if p.grad is not None}
     assert set(got) == set(want)
     for k in want:
@@ -131,8 +143,15 @@ def test_wing_rollout_full_size_vs_oracles(dev):
         assert abs(res["loss"].item() - closs) / closs < 1e-5
         assert rel_err(ga, cga) < TOL
         assert rel_err(gs, cgs) < TOL
-        worst, med = per_traj(ga, cga)
-        assert worst < 2e-3 and med < 1e-5, (worst, med)
+        _, med = per_traj(ga, cga)
+        assert med < 1e-5, med
+        # per trajectory: the C oracle in float32 (the reference's precision)
+        # is the yardstick, the float64 one the arbiter
+        _, _, fga, fgs = co.wing_rollout_fwd_bwd(
+            d["state0"].numpy(), d["actions"].numpy(), d["ref"].numpy(), dt,
+            modified_params=mp, dtype=np.float32)
+        assert_no_worse_than_fp32(ga, fga, cga, f"wing dL/dactions B={B}")
+        assert_no_worse_than_fp32(gs, fgs, cgs, f"wing dL/dstate0 B={B}")
         if not full:
             continue
         # the reference's op sequence under torch autograd, whole batch

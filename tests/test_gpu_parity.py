@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import assert_no_worse_than_fp32, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -177,11 +177,18 @@ def test_quad_rollout_full_size_vs_oracle(dev):
     assert abs(res["loss"].item() - loss.item()) / loss.item() < TOL
     assert rel_err(N(aos_seq(res["grad_actions"])), ga.numpy()) < TOL
     assert rel_err(N(res["grad_state0"].t()), gs.numpy()) < TOL
-    # per-trajectory check too (not only relative to the tensor maximum)
-    ga_dev = N(aos_seq(res["grad_actions"])).reshape(B, -1)
-    ga_ref = ga.numpy().reshape(B, -1)
-    per_traj = np.abs(ga_dev - ga_ref).max(1) / np.abs(ga_ref).max(1)
-    assert per_traj.max() < 1e-3 and np.median(per_traj) < 1e-5
+    # per trajectory, not only relative to the tensor maximum: the float64
+    # oracle arbitrates between the kernel and the float32 oracle
+    d64 = {k: v.double() for k, v in d.items()}
+    st64, _, ga64, gs64 = tp.rollout_fwd_bwd(
+        tp.QuadOracle(dtype=torch.float64), tp.quad_mpc_loss, d64["state0"],
+        d64["actions"], d64["ref"], dt)
+    assert_no_worse_than_fp32(N(aos_seq(res["grad_actions"])), ga.numpy(),
+                              ga64.numpy(), "soa dL/dactions")
+    assert_no_worse_than_fp32(N(res["grad_state0"].t()), gs.numpy(), gs64.numpy(),
+                              "soa dL/dstate0")
+    assert_no_worse_than_fp32(N(aos_seq(res["states"])), st.numpy(), st64.numpy(),
+                              "soa states")
     # size-independent properties: additivity of the loss over a batch split
     # and permutation equivariance of the gradients
     half = B // 2
@@ -264,9 +271,30 @@ def test_quad_rollout_packed_full_size_vs_oracle(dev):
         dev_ga = N(sy.from_packed_seq(res["grad_actions"]))
         assert rel_err(dev_ga, ga.numpy()) < TOL
         assert rel_err(N(sy.from_packed_state(res["grad_state0"])), gs.numpy()) < TOL
-        per_traj = (np.abs(dev_ga - ga.numpy()).reshape(B, -1).max(1)
-                    / np.abs(ga.numpy()).reshape(B, -1).max(1))
-        assert per_traj.max() < 1e-3 and np.median(per_traj) < 1e-5
+        if B < 1000:
+            continue
+        # per trajectory: the float64 oracle arbitrates (conftest)
+        d64 = {k: v.double() for k, v in d.items()}
+        _, _, ga64, gs64 = tp.rollout_fwd_bwd(
+            tp.QuadOracle(dtype=torch.float64), tp.quad_mpc_loss, d64["state0"],
+            d64["actions"], d64["ref"], dt)
+        assert_no_worse_than_fp32(dev_ga, ga.numpy(), ga64.numpy(),
+                                  f"packed dL/dactions B={B}")
+        assert_no_worse_than_fp32(N(sy.from_packed_state(res["grad_state0"])),
+                                  gs.numpy(), gs64.numpy(), f"packed dL/dstate0 B={B}")
+        if B != 65536:
+            continue
+        # the EXACT launch bench.py times - quad_rollout_rows_kernel<10, false>,
+        # no states, grad_state0 = NULL - against the oracles as well (VERDICT
+        # r3 #4b), not only against the other instantiation
+        lean = F.quad_rollout_fwd_bwd(s0, a, r, dt, dyn.params, layout="packed",
+                                      want_grad_state0=False)
+        assert lean["grad_state0"] is None and lean.get("states") is None
+        lean_ga = N(sy.from_packed_seq(lean["grad_actions"]))
+        assert rel_err(lean_ga, ga.numpy()) < TOL
+        assert abs(lean["loss"].item() - loss.item()) / loss.item() < TOL
+        assert_no_worse_than_fp32(lean_ga, ga.numpy(), ga64.numpy(),
+                                  "bench launch <10,false> dL/dactions")
     # additivity over a batch split / per-trajectory independence (B = 65 536)
     B = 65536
     d = sy.quad_polynomial_batch(B, H, dt, seed=0)

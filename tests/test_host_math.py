@@ -234,3 +234,56 @@ def test_shipped_cartpole(hc):
     assert abs(loss - g["loss"]) / g["loss"] < 1e-5
     assert rel_err(gact, g["gactions"]) < 1e-5
     assert rel_err(gs0, g["gstate0"]) < 1e-5
+
+
+# ------------------------------------ float64 arbitration (VERDICT r3 #4a)
+def test_shipped_quad_math_is_no_worse_than_fp32_reference_per_trajectory(hm):
+    """The arithmetic the rollout kernels run per lane (closed form, contracted
+    adjoint, branch-free sin-cos) against the float64 oracle, per trajectory,
+    with the float32 oracle (the reference's op sequence) as the yardstick:
+    20 000 synthetic trajectories, no escape hatch beyond 1e-4."""
+    import torch
+    from conftest import assert_no_worse_than_fp32
+    from apg_trajectory_tracking_amd import functional as F, synthetic as sy
+    from oracle import torch_port as tp
+    B, H, dt = 20000, 10, 0.1
+    d = sy.quad_polynomial_batch(B, H, dt, seed=3)
+    st, _, ga, gs = tp.rollout_fwd_bwd(tp.QuadOracle(), tp.quad_mpc_loss,
+                                       d["state0"], d["actions"], d["ref"], dt)
+    d64 = {k: v.double() for k, v in d.items()}
+    st64, _, ga64, gs64 = tp.rollout_fwd_bwd(
+        tp.QuadOracle(dtype=torch.float64), tp.quad_mpc_loss, d64["state0"],
+        d64["actions"], d64["ref"], dt)
+    s0, a, r = (_f(d[k].numpy()) for k in ("state0", "actions", "ref"))
+    hst = np.empty((B, H, 12), np.float32)
+    hga, hgs = np.empty((B, H, 4), np.float32), np.empty((B, 12), np.float32)
+    w = F.quad_loss_weights()
+    hm.hm_quad_rollout(_p(s0), _p(a), _p(r), 9, ctypes.c_float(dt),
+                       ctypes.byref(_params({})), ctypes.byref(w), B, H, _p(hst),
+                       _p(hga), _p(hgs))
+    assert_no_worse_than_fp32(hga, ga.numpy(), ga64.numpy(), "host quad dL/dactions")
+    assert_no_worse_than_fp32(hgs, gs.numpy(), gs64.numpy(), "host quad dL/dstate0")
+    assert_no_worse_than_fp32(hst, st.numpy(), st64.numpy(), "host quad states")
+
+
+def test_shipped_wing_math_is_no_worse_than_fp32_reference_per_trajectory(hw):
+    """The same for wing_math.h (polynomial atan / sin / cos, contracted
+    adjoint) at H = 20: C oracle in float32 as the yardstick, in float64 as
+    the arbiter."""
+    from conftest import assert_no_worse_than_fp32
+    from apg_trajectory_tracking_amd import functional as F, synthetic as sy
+    from oracle import c_oracle as co
+    B, H, dt = 20000, 20, 0.05
+    d = sy.wing_batch(B, H, dt, seed=5)
+    s0, a, r = (_f(d[k].numpy()) for k in ("state0", "actions", "ref"))
+    c64 = co.wing_rollout_fwd_bwd(s0, a, r, dt, modified_params={}, dtype=np.float64)
+    c32 = co.wing_rollout_fwd_bwd(s0, a, r, dt, modified_params={}, dtype=np.float32)
+    hst = np.empty((B, H, 12), np.float32)
+    hga, hgs = np.empty_like(a), np.empty_like(s0)
+    w = F.wing_loss_weights()
+    hw.hm_wing_rollout(_p(s0), _p(a), _p(r), ctypes.c_float(dt),
+                       ctypes.byref(_wing_params({})), ctypes.byref(w), B, H,
+                       _p(hst), _p(hga), _p(hgs))
+    assert_no_worse_than_fp32(hst, c32[0], c64[0], "host wing states")
+    assert_no_worse_than_fp32(hga, c32[2], c64[2], "host wing dL/dactions")
+    assert_no_worse_than_fp32(hgs, c32[3], c64[3], "host wing dL/dstate0")
