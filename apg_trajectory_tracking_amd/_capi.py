@@ -201,6 +201,7 @@ SIGNATURES = {
         ctypes.POINTER(ApgDeferredLoss), _P],
     "apg_wing_rollout_fwd": [_P, _P, _F, ctypes.POINTER(ApgWingParams), _I,
                              _I, _I, _P, _P],
+    "apg_wing_set_two_per_lane": [_I],
     "apg_cartpole_step_fwd": [_P, _P, _F, ctypes.POINTER(ApgCartpoleParams),
                               _I, _I, _P, _P],
     "apg_cartpole_step_bwd": [_P, _P, _F, ctypes.POINTER(ApgCartpoleParams),

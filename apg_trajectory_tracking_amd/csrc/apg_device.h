@@ -39,6 +39,25 @@ constexpr int kWave = 64;  // CDNA wavefront
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
 
+// ---- state that is cached per DEVICE (host) --------------------------------
+// hipFuncSetAttribute and the CU count belong to the current device; a process
+// may drive more than one GPU, so "done once" / "looked up once" is kept per
+// device id (an unknown device is never cached).
+constexpr int kMaxDevices = 64;
+int device_slot();            // current device id in [0, kMaxDevices), or -1
+int device_cu_count();        // CUs of the current device (256 if unknown)
+struct PerDeviceOnce {
+  bool done[kMaxDevices] = {};
+  bool test() const {
+    const int d = device_slot();
+    return d >= 0 && done[d];
+  }
+  void set() {
+    const int d = device_slot();
+    if (d >= 0) done[d] = true;
+  }
+};
+
 // ---- per-lane loads / stores ----------------------------------------------
 // "state-like" tensors: [B][S] (AoS) or [S][B] (SoA)
 template <int LAYOUT, int S>

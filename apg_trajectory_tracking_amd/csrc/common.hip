@@ -16,6 +16,24 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+int device_slot() {
+  int d = -1;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices) ? d : -1;
+}
+
+int device_cu_count() {
+  static int cus[kMaxDevices] = {};
+  const int d = device_slot();
+  if (d >= 0 && cus[d] > 0) return cus[d];
+  int v = 0;
+  if (d < 0 || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) !=
+                   hipSuccess || v <= 0) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  return cus[d] = v;
+}
+
 int check_launch(const char *what) {
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) return APG_OK;

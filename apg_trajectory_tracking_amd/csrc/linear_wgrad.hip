@@ -195,20 +195,7 @@ __global__ __launch_bounds__(1024) void linear_wgrad_reduce_kernel(WreduceArgs R
   }
 }
 
-int cu_count_() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) ==
-            hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
-    (void)hipGetLastError();
-  }
-  return n;
-}
+int cu_count_() { return device_cu_count(); }
 
 void shape(int M, int N, int &tm, int &tn, int &split) {
   tm = (M + kTM * 32 - 1) / (kTM * 32);

@@ -1271,10 +1271,10 @@ int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
     if (int e = raise_lds(mlp_rollout_fwd_kernel, kCfLds)) return e;
-    attr = true;
+    attr.set();
   }
   FwdArgs A;
   A.state0 = state0, A.in_ref = in_ref, A.states = states, A.actions = actions;
@@ -1320,10 +1320,10 @@ int apg_quad_mlp_rollout_bwd(const float *state0, const float *states,
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
     if (int e = raise_lds(mlp_rollout_bwd_kernel, kCbLds)) return e;
-    attr = true;
+    attr.set();
   }
   BwdArgs A;
   A.state0 = state0, A.states = states, A.actions = actions, A.ref = ref;
@@ -1373,10 +1373,10 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
     if (int e = raise_lds(mlp_closed_loop_kernel, kCfLds)) return e;
-    attr = true;
+    attr.set();
   }
   LoopArgs A;
   A.traj = traj, A.div = div, A.steps = steps, A.drone = drone;
@@ -1423,11 +1423,11 @@ int apg_quad_mlp_concurrent_fwd_bwd(
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
     if (int e = raise_lds(mlp_concurrent_fwd_kernel, kCfLds)) return e;
     if (int e = raise_lds(mlp_concurrent_bwd_kernel, kCbLds)) return e;
-    attr = true;
+    attr.set();
   }
   ConcArgs A;
   A.feat = feat, A.in_ref = in_ref, A.state0 = state0, A.ref = ref;

@@ -628,10 +628,10 @@ int apg_wing_policy_fwd(const float *feat, const float *ref_in,
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
     if (int e = raise_lds(wing_policy_fwd_kernel, kFwd16Lds)) return e;
-    attr = true;
+    attr.set();
   }
   Args A = {};
   A.feat = feat, A.ref_in = ref_in, A.actions = actions, A.x1 = x1, A.h = h;
@@ -658,10 +658,10 @@ int apg_wing_policy_bwd(const float *actions, const float *grad_actions,
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
     if (int e = raise_lds(wing_policy_bwd_kernel, kBwd16Lds)) return e;
-    attr = true;
+    attr.set();
   }
   Args A = {};
   A.actions = const_cast<float *>(actions), A.grad_actions = grad_actions;
@@ -709,10 +709,10 @@ int apg_wing_mlp_closed_loop(const float *targets, int n_targets,
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
     if (int e = raise_lds(wing_closed_loop_kernel, kFwd16Lds)) return e;
-    attr = true;
+    attr.set();
   }
   WingLoopArgs A = {};
   A.targets = targets, A.state0 = state0, A.div_linear = div_linear;

@@ -212,9 +212,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &G, int bid, int nb,
     // of the last multiply have been consumed by its MFMAs.
     __builtin_amdgcn_s_barrier();
     const long long n0 = (long long)col_tile(ct_m) * kKT;
-    if (G.N - n0 < kKT) {  // ragged last tile of a segment: zero A beyond N
+    if (G.N - n0 < kKT) {  // ragged last tile of a segment: zero A AND B beyond
+      // N (what lies there is the next plane, or another tensor: 0 x Inf = NaN)
       const int rem = (int)(G.N - n0);
-      for (int e = tid; e < MB * 32 * kKT; e += kThreads)
+      for (int e = tid; e < (MB + NB) * 32 * kKT; e += kThreads)
         if ((e & 63) >= rem) lds[p * BUF + tile_index(e >> 6, e & 63)] = 0.f;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -410,12 +411,17 @@ __device__ __forceinline__ void stream_body(const GemmArgs &G, int bid, int nb,
   auto multiply = [&](u32x4 (&fa)[MB][2], u32x4 (&fb)[NB][2], int cc_) {
     cc_ = G.S > 1 ? cc_ % cps1 : cc_;   // the chunk of its segment
     const int n0 = cc_ * 32 + g * 8;  // this lane's first column of the chunk
-    if ((long long)cc_ * 32 + 32 > G.N) {  // ragged last chunk: zero A beyond N
+    if ((long long)cc_ * 32 + 32 > G.N) {  // ragged last chunk: zero A AND B
+      // beyond N (the columns there belong to the next plane or to another
+      // tensor; a non-finite value against a zeroed A would still be NaN)
 #pragma unroll
-      for (int rb = 0; rb < MB; ++rb)
+      for (int m = 0; m < 8; ++m)
+        if (n0 + m >= G.N) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-          if (n0 + m >= G.N) fa[rb][m >> 2][m & 3] = 0u;
+          for (int rb = 0; rb < MB; ++rb) fa[rb][m >> 2][m & 3] = 0u;
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb) fb[cb][m >> 2][m & 3] = 0u;
+        }
     }
     // row sums from the exact fp32 values, then the chunk's 8 k-slots per lane
     // as three bf16 terms each and six products per tile
@@ -631,13 +637,13 @@ __global__ __launch_bounds__(256) void planes_gemm_grouped_reduce_kernel(GroupAr
 template <int MB, int NB>
 int launch(const GemmArgs &G, int num_wg, hipStream_t st) {
   const size_t lds = Shape<MB, NB>::lds_bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (!attr_set.test()) {
     if (hipFuncSetAttribute((const void *)planes_gemm_kernel<MB, NB>,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return check_launch("hipFuncSetAttribute(planes_gemm)");
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((planes_gemm_kernel<MB, NB>), dim3(num_wg), dim3(kThreads),
                      lds, st, G);
@@ -658,13 +664,13 @@ long long stream_partial_floats(int M, int J) {
 template <int MB, int NB>
 int launch_stream(const GemmArgs &G, int num_wg, hipStream_t st) {
   const size_t lds = (size_t)4 * MB * 16 * (NB * 16 + 1) * sizeof(float);  // a region per wave
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
+  static PerDeviceOnce attr_set;
+  if (!attr_set.test() && lds > 48 * 1024) {
     if (hipFuncSetAttribute((const void *)planes_gemm_stream_kernel<MB, NB>,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return check_launch("hipFuncSetAttribute(planes_gemm_stream)");
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((planes_gemm_stream_kernel<MB, NB>), dim3(num_wg),
                      dim3(kThreads), lds, st, G);
@@ -720,20 +726,7 @@ int shape_lds_bytes(int MB, int NB) {
   return ((APG_GEMM_ST_MAX >= 3 && 3 * buf <= kLdsBytes) ? 3 : 2) * buf;
 }
 
-int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) ==
-            hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
-    (void)hipGetLastError();
-  }
-  return n;
-}
+int cu_count() { return device_cu_count(); }
 
 // workgroups per CU as measured best (tools/bench_gemm.py, WGS sweep): what the
 // LDS holds, but at most 2 - except the 32 x 32 shape, whose tiles are so
@@ -963,13 +956,13 @@ int apg_planes_gemm_multi(const ApgGemmProblem *problems, int n, float *workspac
     max_blocks = blocks > max_blocks ? blocks : max_blocks;
   }
   if (SG.n > 0) {
-    static bool attr_set = false;
-    if (!attr_set) {  // room for the largest partial any shape can have
+    static PerDeviceOnce attr_set;
+    if (!attr_set.test()) {  // room for the largest partial any shape can have
       if (hipFuncSetAttribute((const void *)planes_gemm_stream_grouped_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsBytes) != hipSuccess)
         return check_launch("hipFuncSetAttribute(planes_gemm_stream_grouped)");
-      attr_set = true;
+      attr_set.set();
     }
     hipLaunchKernelGGL(planes_gemm_stream_grouped_kernel, dim3(SG.wg0[SG.n]),
                        dim3(kThreads), group_lds, st, SG);
@@ -1028,13 +1021,13 @@ int apg_planes_gemm_grouped(const ApgGemmProblem *problems, int n,
   GA.wg0[n] = given;
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = Shape<2, 4>::lds_bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (!attr_set.test()) {
     if (hipFuncSetAttribute((const void *)planes_gemm_grouped_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return check_launch("hipFuncSetAttribute(planes_gemm_grouped)");
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL(planes_gemm_grouped_kernel, dim3(given), dim3(kThreads), lds, st,
                      GA);

@@ -539,7 +539,23 @@ int check_args(const void *p0, const void *p1, const void *params, int B,
 
 using namespace apg;
 
+// two trajectories per lane: 0 never, 1 whenever possible, 2 by batch size
+// (shipped; experiment builds may start from another value)
+#ifndef APG_WING_PK
+#define APG_WING_PK 2
+#endif
+static int g_wing_pk_mode = APG_WING_PK;
+
 extern "C" {
+
+int apg_wing_set_two_per_lane(int mode) {
+  if (mode < 0 || mode > 2) {
+    set_error("apg_wing_set_two_per_lane: mode must be 0, 1 or 2 (got %d)", mode);
+    return APG_ERR_ARG;
+  }
+  g_wing_pk_mode = mode;
+  return APG_OK;
+}
 
 int apg_wing_step_fwd(const float *state, const float *action, float dt,
                       const ApgWingParams *params, int B, int layout,
@@ -645,25 +661,14 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
   // Two trajectories per lane (packed fp32, one wave per SIMD) as soon as the
   // one-per-lane kernel would put more than one wave on a SIMD; needs the
   // plane layout, an even batch and 8-byte aligned tensors.
-#ifndef APG_WING_PK
-#define APG_WING_PK 2   // 0 never, 1 whenever possible, 2 by batch size
-#endif
-  static int simds = 0;
-  if (!simds) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) !=
-            hipSuccess || cus <= 0)
-      cus = 256;
-    simds = 4 * cus;
-  }
+  const int simds = 4 * device_cu_count();
   const auto al8 = [](const void *q) { return ((size_t)q & 7) == 0; };
   const bool pk_ok = layout == APG_LAYOUT_SOA && buf_ok && (B & 1) == 0 &&
                      al8(state0) && al8(actions) && al8(ref) && al8(grad_actions) &&
                      al8(grad_state0) && al8(states_out);
-  // APG_WING_PK in the environment (tests): 1 = whenever possible, 0 = never
-  int pk_mode = APG_WING_PK;
-  if (const char *e = getenv("APG_WING_PK")) pk_mode = atoi(e);
+  // nothing in the environment changes the shipped choice; tests pick a
+  // kernel through apg_wing_set_two_per_lane (1 = whenever possible, 0 = never)
+  const int pk_mode = g_wing_pk_mode;
   if (pk_ok && (pk_mode == 1 || (pk_mode == 2 && grid_for(B, 64) > simds))) {
     const size_t lds2 = 2 * lds;
     const dim3 grid2(grid_for(B / 2, 64)), block2(64);

@@ -593,6 +593,12 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
 int apg_wing_rollout_fwd(const float *state0, const float *actions, float dt,
                          const ApgWingParams *params, int B, int H, int layout,
                          float *states_out, apg_stream_t stream);
+/* Test / measurement hook, process-wide: which of the two fused fixed-wing
+ * kernels apg_wing_rollout_fwd_bwd launches for plane-layout batches.
+ *   2 (default) two trajectories per lane once the batch exceeds one wave per
+ *     SIMD, 1 whenever the batch is even and 8-byte aligned, 0 never.
+ * Nothing in the environment influences the choice. */
+int apg_wing_set_two_per_lane(int mode);
 
 /* ------------------------------------------------------------ cartpole --- */
 /* neural_control/dynamics/cartpole_dynamics.py:23-43 + config_cartpole.json

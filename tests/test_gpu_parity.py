@@ -23,6 +23,21 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def wing_pk():
+    """Selects the fixed-wing rollout kernel for plane-layout batches through
+    the C ABI's hook (apg_wing_set_two_per_lane: 1 = two trajectories per lane
+    whenever possible, 0 = never); the shipped choice (2: by batch size) is
+    restored afterwards."""
+    from apg_trajectory_tracking_amd import _capi
+
+    def choose(mode):
+        _capi.check(_capi.lib().apg_wing_set_two_per_lane(int(mode)),
+                    "apg_wing_set_two_per_lane")
+    yield choose
+    choose(2)
+
+
 def D(x, dev):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
@@ -446,7 +461,7 @@ def test_wing_step_and_vjp(dev, tag, mp):
 
 @pytest.mark.parametrize("layout", ["aos", "soa", "soa_two_per_lane"])
 @pytest.mark.parametrize("H", [20, 10])
-def test_wing_rollout_golden(dev, layout, H, monkeypatch):
+def test_wing_rollout_golden(dev, layout, H, wing_pk):
     """G5 rollouts (incl. samples beyond the alpha / beta clamp).
     soa_two_per_lane: the packed-fp32 kernel (two trajectories per lane) that
     large batches use, forced here on the 64-trajectory golden batch."""
@@ -458,10 +473,10 @@ def test_wing_rollout_golden(dev, layout, H, monkeypatch):
     dyn = FixedWingDynamics()
     s0, a, r = D(g[p + "state0"], dev), D(g[p + "actions"], dev), D(g[p + "ref"], dev)
     if layout == "soa_two_per_lane":
-        monkeypatch.setenv("APG_WING_PK", "1")
+        wing_pk(1)
         layout = "soa"
     else:
-        monkeypatch.setenv("APG_WING_PK", "0")
+        wing_pk(0)
     if layout == "soa":
         s0, a, r = soa_state(s0), soa_seq(a), soa_seq(r)
     res = F.wing_rollout_fwd_bwd(s0, a, r, 0.05, dyn.params, layout=layout,
@@ -651,7 +666,7 @@ def test_quad_rollout_max_batch_chunk_additivity(dev):
 
 
 @pytest.mark.parametrize("B,H", [(100, 7), (1, 20), (333, 13), (258, 13)])
-def test_wing_ragged_any_horizon_vs_oracle(dev, B, H, monkeypatch):
+def test_wing_ragged_any_horizon_vs_oracle(dev, B, H, wing_pk):
     from apg_trajectory_tracking_amd import functional as F, synthetic
     from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
         FixedWingDynamics)
@@ -665,7 +680,7 @@ def test_wing_ragged_any_horizon_vs_oracle(dev, B, H, monkeypatch):
     # (even batches also through the two-trajectories-per-lane kernel, with the
     # modified coefficient table read from the kernel arguments)
     for layout in ("aos", "soa") + (("two_per_lane",) if B % 2 == 0 else ()):
-        monkeypatch.setenv("APG_WING_PK", "1" if layout == "two_per_lane" else "0")
+        wing_pk(1 if layout == "two_per_lane" else 0)
         if layout == "two_per_lane":
             layout = "soa"
         a = (d["state0"].to(dev), d["actions"].to(dev), d["ref"].to(dev))
@@ -766,6 +781,26 @@ def test_planes_gemm_mfma_vs_torch(dev):
                 rows = torch.stack([B64[o + s * bstride] for o in offs])
                 ref[m, :J] += rows @ a
                 ref[m, J] += a.sum()
+        assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
+    # ragged N next to a plane that holds non-finite values and is
+    # NOT part of the product - the chunk's columns beyond N are that plane's
+    # first ones; both operands' tails are zeroed (0 x Inf would be NaN).
+    # Register-streaming kernel (S = 1) and LDS-tile kernel (segments).
+    for (M, S, P, J, bstride, N) in ((16, 1, 12, 4, 0, 777), (20, 8, 91, 27, 9, 1300)):
+        A = torch.randn(M * S, N, generator=g).to(dev)
+        Bp = torch.randn(P, N, generator=g).to(dev)
+        Bp[P - 1] = float("inf")
+        offs = ([t * 9 + c for c in range(9) for t in range(3)] if bstride
+                else list(range(P - 1 - J, P - 1)))
+        C = F.planes_gemm(A, M, S, Bp, F.make_bdesc(dev, offs, bstride))
+        assert torch.isfinite(C).all()
+        A64, B64 = A.double().cpu(), Bp.double().cpu()
+        ref = torch.zeros(M, J + 1, dtype=torch.float64)
+        for m in range(M):
+            for s_ in range(S):
+                rows = torch.stack([B64[o + s_ * bstride] for o in offs])
+                ref[m, :J] += rows @ A64[m * S + s_]
+                ref[m, J] += A64[m * S + s_].sum()
         assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
     # per-column two-level segment strides (segment = (pos, step)), strided output
     H, Bn = 5, 203

@@ -14,6 +14,12 @@ from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (  # noqa: 
 
 
 def main():
+    # WING_PK=0|1|2: which rollout kernel (apg_wing_set_two_per_lane; the
+    # library itself reads nothing from the environment)
+    if "WING_PK" in os.environ:
+        from apg_trajectory_tracking_amd import _capi
+        _capi.check(_capi.lib().apg_wing_set_two_per_lane(int(os.environ["WING_PK"])),
+                    "apg_wing_set_two_per_lane")
     dev = torch.device("cuda:0")
     dyn = FixedWingDynamics()
     H, dt = 20, 0.05
