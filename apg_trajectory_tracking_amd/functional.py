@@ -620,6 +620,59 @@ class RolloutPlan:
         return self.out["loss"]
 
 
+# ------------------------------------- operand range of the in-kernel policies
+# The policy layers inside the kernels multiply fp32 operands as two fp16 terms
+# (csrc/policy_mfma16.h): a first-layer input of magnitude >= 65 504 would
+# become inf in its high term.  Cotangents are rescaled per trajectory inside
+# the kernels, activations are bounded by tanh / relu of bounded values; what
+# the CALLER controls are the tensors the first layers read - the normalised
+# state features, the initial state (velocities, body rates; in the recurrent
+# modes the features are rebuilt from the evolving state, which a rollout of
+# H = 10 steps moves by < 30 m/s and < 30 m) and the reference windows (metres,
+# m/s).  Contract (include/apg.h): every such value is finite with magnitude
+# < 2^14 = 16 384.  It is enforced here, on the host: the first time a tensor
+# object (in this in-place version) is seen, its largest magnitude is read
+# back ONCE - a data set that is stepped on for epochs costs one check, a
+# captured step graph none (its warm-up steps have checked) - and a violation
+# raises ValueError instead of training on inf.  Tiny values lose nothing that
+# matters: the low term keeps an ABSOLUTE accuracy of 2^-25.
+POLICY_INPUT_LIMIT = 16384.0
+CHECK_POLICY_INPUT_RANGE = True
+
+
+class _RangeGuard:
+    def __init__(self, slots=32):
+        self.slots, self.seen = slots, []
+
+    def __call__(self, what, **tensors):
+        if not CHECK_POLICY_INPUT_RANGE:
+            return
+        import weakref
+        fresh = []
+        for name, t in tensors.items():
+            if t is None or not torch.is_tensor(t) or t.numel() == 0:
+                continue
+            if any(r() is t and v == t._version for r, v in self.seen):
+                continue
+            fresh.append((name, t))
+        if not fresh or (fresh[0][1].is_cuda and torch.cuda.is_current_stream_capturing()):
+            return
+        amax = torch.stack([t.detach().abs().amax().float() for _, t in fresh]).tolist()
+        for (name, t), m in zip(fresh, amax):
+            if not m < POLICY_INPUT_LIMIT:          # also catches NaN / inf
+                raise ValueError(
+                    f"{what}: `{name}` holds a value of magnitude {m:g}; the "
+                    f"in-kernel policy takes finite inputs below "
+                    f"{POLICY_INPUT_LIMIT:g} (fp16-split operands, include/apg.h "
+                    "\"operand range\") - normalise the data or use the "
+                    "PyTorch policy path (fused_policy = False)")
+            self.seen.append((weakref.ref(t), t._version))
+        self.seen = [e for e in self.seen if e[0]() is not None][-self.slots:]
+
+
+_guard_policy_inputs = _RangeGuard()
+
+
 # ----------------------------------------- fused LSTM-policy unroll (K7)
 _GEMM_WGS = None   # None: sized from the LDS footprint (workgroups per CU x 256)
 _bdesc_cache = {}
@@ -967,6 +1020,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
         if w_ih.shape != (32, 175) or conv_w.shape != (20, 9, 3):
             raise ValueError("fused path needs LSTM_NEW(15, 10, 9, 4, conv=1)")
+        _guard_policy_inputs("fused LSTM unroll", state0=state0, in_ref=in_ref)
         dev = state0.device
         src = getattr(ctx, "static_src", None) if index is None else None
         hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
@@ -1094,6 +1148,8 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
         if 256 * N * 4 >= 2 ** 32:
             raise ValueError("batch too large for one fused launch "
                              "(B <= 400 000); split it")
+        _guard_policy_inputs("fused autoregressive unroll", state0=state0,
+                             in_ref=in_ref)
         dev = state0.device
         src = getattr(ctx, "static_src", None) if index is None else None
         hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
@@ -1216,6 +1272,7 @@ def quad_mlp_closed_loop(net, traj, dt, params, max_steps=251, thresh_div=1.0,
     (the reference's Random adds 3 to z: do that before the call).
     Returns dict(div [T,B], steps [B] int32, and with want_trajectory: drone
     [T+1,12,B], actions [T,4,B], start_states [T,12,B])."""
+    _guard_policy_inputs("closed-loop evaluation", traj=traj)
     B, L, _ = traj.shape
     H = 10
     dev = traj.device
@@ -1258,6 +1315,7 @@ def quad_lstm_closed_loop(net, traj, dt, params, h0, c0, max_steps=251,
     """quad_mlp_closed_loop for an `LSTM_NEW(15, 10, 9, 4, conv=1)` controller;
     h0 / c0 [B, 8]: the hidden / cell state at the start of every run (the
     reference resets it once per evaluator and carries it through the run)."""
+    _guard_policy_inputs("closed-loop evaluation", traj=traj)
     B, L, _ = traj.shape
     H = 10
     dev = traj.device
@@ -1308,6 +1366,7 @@ def wing_mlp_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
     fly_to_point appends nothing to div_target), steps [B] int32, and with
     want_trajectory: drone [T,16,B] (state after the step + action), seen
     [T,15,B] (state the policy saw + its target))."""
+    _guard_policy_inputs("closed-loop evaluation", targets=targets)
     B, n_targets, _ = targets.shape
     dev = targets.device
     tg = _f32c(targets).permute(1, 2, 0).contiguous()
@@ -1369,6 +1428,7 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         if (w_s.shape != (64, 15) or conv_w.shape != (20, 9, 3)
                 or w_1.shape != (64, 224) or w_out.shape != (40, 64)):
             raise ValueError("fused path needs Net(15, 10, 9, 40, conv=1)")
+        _guard_policy_inputs("fused concurrent step", normed=normed, in_ref=in_ref)
         dev = state0.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         # one buffer for the B operands of the weight products:
@@ -1574,6 +1634,7 @@ def wing_concurrent_policy_grads(net, normed, in_ref, state0, ref, dt, params,
             or normed.shape[1] != 9 or in_ref.reshape(in_ref.shape[0], -1).shape[1] != 3
             or ref.shape[1:] != (H, 3)):
         raise ValueError("fused path needs Net(9, 1, 3, 4 H, conv=False), H = 10 or 20")
+    _guard_policy_inputs("fused fixed-wing step", normed=normed, in_ref=in_ref)
     dev = state0.device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     with torch.no_grad():

@@ -32,6 +32,23 @@
  *    PACKED a lane moves a whole row with one 16-byte access (1 KiB per wave
  *    instruction) - a quarter of the memory instructions, which is what the
  *    one-wave-per-SIMD rollout kernel is paced by.
+ *  - Operand range.  The dynamics, losses and adjoints are plain fp32 and take
+ *    any finite input.  The entry points that run a POLICY NETWORK inside the
+ *    kernel (apg_quad_mlp_*, apg_quad_lstm_*, apg_wing_policy_*,
+ *    apg_wing_mlp_closed_loop) evaluate its layers on the 16-bit matrix pipe
+ *    with every fp32 operand split into two fp16 terms (fp32 accuracy,
+ *    csrc/policy_mfma16.h).  Cotangents are rescaled per trajectory inside the
+ *    kernels; the first-layer inputs are not: normalised features, initial
+ *    state, reference windows / trajectories and network weights must be
+ *    FINITE with |x| < 16 384 (2^14; fp16 overflows at 65 504, the margin
+ *    covers what a rollout adds to a state).  Smaller is always fine: the low
+ *    term keeps an absolute accuracy of 2^-25.  The library cannot see device
+ *    data at enqueue time - the caller checks (the Python host does, once per
+ *    tensor version: functional._guard_policy_inputs raises ValueError); a
+ *    violation yields inf / NaN losses, never a wrong finite number.
+ *    apg_planes_gemm / apg_linear_wgrad split into bf16 terms (fp32's exponent
+ *    range): finite operands of any magnitude; a non-finite operand gives a
+ *    non-finite (NaN) result where fp32 arithmetic would give inf.
  */
 #ifndef APG_H_
 #define APG_H_

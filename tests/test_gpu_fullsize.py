@@ -228,3 +228,120 @@ def test_fused_ar_sweeps_beyond_two_gib_of_planes(dev, monkeypatch):
     assert abs(l0 - l1.item()) / abs(l0) < 1e-5
     for k in g0:
         assert rel_err(g1[k].double().cpu().numpy(), g0[k].numpy()) < 1e-4, k
+
+
+@pytest.mark.parametrize("mode", ["concurrent", "ar", "lstm"])
+@pytest.mark.parametrize("scale", [1e-6, 1.0e4])
+def test_in_kernel_policy_operand_range_vs_fp64_oracle(dev, mode, scale):
+    """the fp16-split layers' range contract (include/apg.h
+    "operand range": first-layer inputs finite and below 2^14).  Inside the
+    contract - state / reference magnitudes of 1e-6 and of 1e4 (velocities,
+    reference windows and features of that size) - loss, states and every
+    parameter gradient meet 1e-4 against the float64 oracle; the tiny inputs
+    ride on the low term's ABSOLUTE accuracy."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    from oracle import torch_port as tp
+    B, H, dt = 2048, 10, 0.1
+    R = H if mode == "concurrent" else 2 * H
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=31, ref_length=R)
+    # positions / velocities of the state, every reference column: x scale
+    # (attitude and body rates stay physical: they enter through sin / cos)
+    s0 = d["state0"].clone()
+    s0[:, 0:3] *= scale
+    s0[:, 6:9] *= scale
+    in_ref, ref = d["in_ref"] * scale, d["ref"] * scale
+    torch.manual_seed(12)
+    net = (LSTM_NEW(15, H, 9, 4, conv=1) if mode == "lstm"
+           else Net(15, H, 9, 40 if mode == "concurrent" else 4, conv=1))
+    gen = torch.Generator().manual_seed(6)
+    h0, c0 = torch.randn(B, 8, generator=gen), torch.randn(B, 8, generator=gen)
+    net64 = copy.deepcopy(net).double()
+    orc = tp.QuadOracle(dtype=torch.float64)
+    if mode == "concurrent":
+        acts = torch.sigmoid(net64(tp.quad_state_features(s0.double()),
+                                   in_ref.double())).reshape(-1, H, 4)
+        loss64 = tp.quad_mpc_loss(tp.unroll(orc, s0.double(), acts, dt),
+                                  ref.double(), acts)
+    else:
+        if mode == "lstm":
+            net64.hidden_state, net64.cell_state = h0.double(), c0.double()
+        inter, _, loss64 = tp.quad_recurrent_unroll(
+            net64, orc, s0.double(), in_ref.double(), ref.double(), H, dt)
+    loss64.backward()
+    gnet = copy.deepcopy(net).to(dev)
+    dyn = FlightmareDynamics()
+    g0, gi, gr = s0.to(dev), in_ref.to(dev), ref.to(dev)
+    if mode == "concurrent":
+        with torch.no_grad():
+            normed = state_preprocessing(g0)
+        loss, grads, _ = F.quad_concurrent_policy_grads(
+            gnet, normed, g0, gi, gr, dt, dyn.params)
+    elif mode == "ar":
+        loss, grads, _ = F.quad_mlp_rollout_grads(gnet, g0, gi, gr, dt, dyn.params)
+    else:
+        loss, grads, _ = F.quad_lstm_rollout_grads(
+            gnet, g0, gi, gr, dt, dyn.params, h0.to(dev), c0.to(dev))
+    assert np.isfinite(loss.item())
+    assert abs(loss.item() - loss64.item()) / abs(loss64.item()) < 1e-5
+    for k, p in net64.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(grads[k]).all(), k
+            e = rel_err(N(grads[k]), p.grad.numpy())
+            assert e < TOL, (k, e)
+
+
+def test_in_kernel_policy_refuses_inputs_beyond_the_split_range(dev):
+    """... and OUTSIDE the contract nothing trains on a silent inf: the host
+    reads each input tensor's largest magnitude once (per in-place version)
+    and raises; non-finite inputs likewise; a checked tensor is not read
+    again; a changed one is."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    B, H, dt = 256, 10, 0.1
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=3, ref_length=2 * H)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    dyn = FlightmareDynamics()
+    torch.manual_seed(1)
+    ar, conc = Net(15, H, 9, 4, conv=1).to(dev), Net(15, H, 9, 40, conv=1).to(dev)
+    lstm = LSTM_NEW(15, H, 9, 4, conv=1).to(dev)
+    h0 = torch.zeros(B, 8, device=dev)
+    ok = lambda: F.quad_mlp_rollout_grads(ar, s0, in_ref, ref, dt, dyn.params)
+    assert np.isfinite(ok()[0].item())
+    guard = F._guard_policy_inputs
+    n_seen = len(guard.seen)
+    ok()                                    # same tensors: not read again
+    assert len(guard.seen) == n_seen
+    big = in_ref.clone()
+    big[7, 3, 1] = 1.0e5                    # one reference value of 100 km
+    with pytest.raises(ValueError, match="magnitude 100000"):
+        F.quad_mlp_rollout_grads(ar, s0, big, ref, dt, dyn.params)
+    with pytest.raises(ValueError, match="in_ref"):
+        F.quad_lstm_rollout_grads(lstm, s0, big, ref, dt, dyn.params, h0, h0)
+    fast = s0.clone()
+    fast[3, 6] = -7.0e4                     # a velocity beyond the range
+    with pytest.raises(ValueError, match="state0"):
+        F.quad_mlp_rollout_grads(ar, fast, in_ref, ref, dt, dyn.params)
+    with torch.no_grad():
+        normed = state_preprocessing(fast)
+    with pytest.raises(ValueError, match="normed"):
+        F.quad_concurrent_policy_grads(conc, normed, fast, in_ref[:, :H], ref[:, :H],
+                                       dt, dyn.params)
+    bad = in_ref.clone()
+    bad[0, 0, 0] = float("nan")
+    with pytest.raises(ValueError):
+        F.quad_mlp_rollout_grads(ar, s0, bad, ref, dt, dyn.params)
+    with pytest.raises(ValueError, match="traj"):
+        F.quad_mlp_closed_loop(ar, big, dt, dyn.params, max_steps=5)
+    # a tensor that passed is read again after an in-place change
+    in_ref[1, 1, 1] = 3.0e4
+    with pytest.raises(ValueError):
+        ok()
