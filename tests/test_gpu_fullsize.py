@@ -231,14 +231,17 @@ def test_fused_ar_sweeps_beyond_two_gib_of_planes(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["concurrent", "ar", "lstm"])
-@pytest.mark.parametrize("scale", [1e-6, 1.0e4])
+@pytest.mark.parametrize("scale", [1e-6, 1.0e3])
 def test_in_kernel_policy_operand_range_vs_fp64_oracle(dev, mode, scale):
     """the fp16-split layers' range contract (include/apg.h
     "operand range": first-layer inputs finite and below 2^14).  Inside the
-    contract - state / reference magnitudes of 1e-6 and of 1e4 (velocities,
-    reference windows and features of that size) - loss, states and every
-    parameter gradient meet 1e-4 against the float64 oracle; the tiny inputs
-    ride on the low term's ABSOLUTE accuracy."""
+    contract - state / reference magnitudes of 1e-6 and of 1.5e4 (the synthetic
+    set's largest value is 15.2: velocities, reference windows and features x
+    1 000) - the loss and every parameter gradient meet 1e-4 against the
+    float64 oracle; the tiny inputs ride on the low term's ABSOLUTE accuracy.
+    Gradients are compared on the scale of the network's largest gradient
+    entry: at 1.5e4 the first layers' tanh units are saturated and their
+    gradients are exactly zero on both sides."""
     from apg_trajectory_tracking_amd import functional as F, synthetic
     from apg_trajectory_tracking_amd.dataset import state_preprocessing
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
@@ -286,13 +289,18 @@ def test_in_kernel_policy_operand_range_vs_fp64_oracle(dev, mode, scale):
     else:
         loss, grads, _ = F.quad_lstm_rollout_grads(
             gnet, g0, gi, gr, dt, dyn.params, h0.to(dev), c0.to(dev))
+    assert float(max(g0.abs().max(), gi.abs().max())) < F.POLICY_INPUT_LIMIT
     assert np.isfinite(loss.item())
     assert abs(loss.item() - loss64.item()) / abs(loss64.item()) < 1e-5
-    for k, p in net64.named_parameters():
-        if p.grad is not None:
-            assert torch.isfinite(grads[k]).all(), k
-            e = rel_err(N(grads[k]), p.grad.numpy())
-            assert e < TOL, (k, e)
+    want = {k: p.grad.numpy() for k, p in net64.named_parameters()
+            if p.grad is not None}
+    gmax = max(np.abs(v).max() for v in want.values())
+    assert gmax > 0
+    for k, w in want.items():
+        assert torch.isfinite(grads[k]).all(), k
+        e = np.abs(N(grads[k]).astype(np.float64) - w).max() / max(
+            np.abs(w).max(), 1e-3 * gmax)
+        assert e < TOL, (k, e)
 
 
 def test_in_kernel_policy_refuses_inputs_beyond_the_split_range(dev):
