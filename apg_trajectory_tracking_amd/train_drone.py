@@ -290,6 +290,23 @@ class TrainDrone(TrainBase):
         env = (self.eval_dynamics if self.sample_in == "eval_env"
                else self.train_dynamics)
         if isinstance(env, torch.nn.Module):
+            # DEVIATION from the reference: its train_dynamics()
+            # flow flies the LEARNT simulator here (residual network
+            # included), so self-play states, the score and the threshold
+            # ladder come from that model; the batched closed-loop kernel
+            # integrates analytic simulators only, so the evaluation dynamics
+            # - the system the learnt model is being fitted to - is flown
+            # instead.  Said once per trainer, recorded in the results.
+            if not getattr(self, "_warned_env_substitution", False):
+                import warnings
+                warnings.warn(
+                    f"evaluate_model: sample_in={self.sample_in!r} selects the "
+                    f"learnt simulator {type(env).__name__}; the batched "
+                    "closed-loop evaluation flies the analytic eval_dynamics "
+                    "instead (self-play states and scores come from it)")
+                self._warned_env_substitution = True
+                self.results_dict["evaluation_env"].append(
+                    "eval_dynamics (substituted for the learnt train_dynamics)")
             env = self.eval_dynamics
         if not (isinstance(n, (Net, LSTM_NEW)) and n.conv and self.horizon == 10
                 and hasattr(env, "params")
