@@ -146,6 +146,39 @@ int apg_to_soa(const float *src, const long long *index, int B, int R, int ld,
   return apg_to_soa_multi(&item, 1, B, stream);
 }
 
+// Measurement aid ("the measured achievable copy bandwidth next
+// to the datasheet peak"): a plain device-to-device stream, 16 bytes per lane
+// and iteration, grid-strided so that the grid reads / writes one contiguous
+// stretch at a time, non-temporal stores - the access pattern of the fused
+// rollouts without their arithmetic.
+static __global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__restrict__ src,
+                                                          uint4 *__restrict__ dst,
+                                                          long long n16) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    const uint4 v = src[i];
+    __builtin_nontemporal_store(v.x, &dst[i].x);
+    __builtin_nontemporal_store(v.y, &dst[i].y);
+    __builtin_nontemporal_store(v.z, &dst[i].z);
+    __builtin_nontemporal_store(v.w, &dst[i].w);
+  }
+}
+
+int apg_stream_copy(const void *src, void *dst, long long bytes, apg_stream_t stream) {
+  if (!src || !dst || bytes < 0 || (bytes & 15) || ((size_t)src & 15) || ((size_t)dst & 15)) {
+    apg::set_error("apg_stream_copy: 16-byte aligned pointers and size expected");
+    return APG_ERR_ARG;
+  }
+  if (bytes == 0) return APG_OK;
+  const long long n16 = bytes / 16;
+  long long blocks = (n16 + 255) / 256;
+  const long long cap = (long long)apg::device_cu_count() * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16);
+  return apg::check_launch("stream_copy");
+}
+
 int apg_reduce_loss_partials(const float *partials, int n, float *loss,
                              apg_stream_t stream) {
   if (!partials || !loss || n < 0) {

@@ -111,7 +111,7 @@ def make_sets(args, rank, dev, nsets=None, first=0):
     return sets
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, gpu_set0=None):
     """The reference's CPU PyTorch autograd path (restated in
     oracle/torch_port.py, pinned to the reference by tests/golden) timed on
     this box's host cores on the same workload shape.  The intra-op thread
@@ -125,6 +125,27 @@ def cpu_baseline(args):
     dyn = tp.QuadOracle()
     run = lambda: tp.rollout_fwd_bwd(dyn, tp.quad_mpc_loss, d["state0"],
                                      d["actions"], d["ref"], args.dt)
+    # parity of the very launches that were timed: buffer set 0 of rank 0 is
+    # this seed's batch - the GPU's loss and dL/dactions of it against the CPU
+    # port's, on the same tensors (north_star: 1e-4 relative)
+    parity = None
+    if gpu_set0 is not None:
+        _, c_loss, c_ga, _ = run()
+        g_ga = gpu_set0["grad_actions"].double()
+        c_ga = c_ga.double()
+        per = ((g_ga - c_ga).abs().flatten(1).amax(1)
+               / c_ga.abs().flatten(1).amax(1).clamp_min(1e-30))
+        parity = {
+            "what": "GPU (the timed launch of buffer set 0: quad_rollout_rows_kernel"
+                    "<10,false> when packed) vs the CPU port on the same tensors",
+            "loss_gpu": gpu_set0["loss"], "loss_cpu": float(c_loss),
+            "loss_rel_err": abs(gpu_set0["loss"] - float(c_loss)) / abs(float(c_loss)),
+            "grad_actions_rel_err": float((g_ga - c_ga).abs().max() / c_ga.abs().max()),
+            "grad_actions_worst_trajectory_rel_err": float(per.max()),
+            "tolerance": 1e-4,
+        }
+        parity["ok"] = bool(parity["loss_rel_err"] < 1e-4
+                            and parity["grad_actions_rel_err"] < 1e-4)
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
     sweep = {}
@@ -195,6 +216,7 @@ def cpu_baseline(args):
     except Exception as e:
         c_wing = {"error": repr(e)}
     return {
+        "parity_check": parity,
         "c_oracle": c_port,
         "c_oracle_wing": c_wing,
         # the same two numbers as flat, named fields (all host CPUs, OpenMP)
@@ -244,20 +266,26 @@ STEP_MODELS = {
                        # 431 + 456 planes of B floats written, read once more
                        # by the products; inputs: features 60 + in_ref 360 +
                        # state0 48 + ref 360
-                       bytes_per_traj=(431 + 456) * 4 * 2 + 828, bytes_per_step=0),
+                       bytes_per_traj=(431 + 456) * 4 * 2 + 828, bytes_per_step=0,
+                       # features 60 + state0 48 + in_ref H*36 + ref H*36
+                       algo_bytes_per_traj=60 + 48 + 360 + 360),
     "autoregressive": dict(mfma_once=0, mfma_per_step=198 + 144,
                            # fwd 436 planes + states/actions written, reverse
                            # reads 1 153 B and writes 260 planes per env-step +
                            # 720 planes per trajectory, products read the 431
                            # activation + 260 cotangent planes once
                            bytes_per_step=1808 + 1153 + 1040 + (431 + 260) * 4,
-                           bytes_per_traj=2880 * 2 + 48 + 20 * 72),
+                           bytes_per_traj=2880 * 2 + 48 + 20 * 72,
+                           # state0 48 + in_ref 2H*36 + ref H*36
+                           algo_bytes_per_traj=48 + 720 + 360),
     "LSTM": dict(mfma_once=0, mfma_per_step=90 + 42,
                  # x 700 + gates 128 + h/c 96 + states/actions 64 written and
                  # re-read by the reverse sweep, cotangents 144 written, the
                  # products read x, gates' cotangents and h once more
                  bytes_per_step=(988 + 924 + 144) + (700 + 128 + 32),
-                 bytes_per_traj=288 * 2 + 48 + 20 * 72),
+                 bytes_per_traj=288 * 2 + 48 + 20 * 72,
+                 # state0 48 + in_ref 720 + ref 360 + h0 / c0 64
+                 algo_bytes_per_traj=48 + 720 + 360 + 64),
 }
 
 
@@ -272,7 +300,17 @@ def step_roofline(mode, B, H, n_params, ms):
     mfma_ms = (sweep_flops + product_flops) / (FP16_MFMA_PEAK_TFLOPS * 1e12) * 1e3
     hbm_ms = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
     floor = max(mfma_ms, hbm_ms)
+    # the step's ALGORITHMIC inputs: what a step must read whatever its design
+    # (per trajectory: features 60 + state0 48 + the reference rows the policy
+    # and the loss read) + the parameters in and their gradients out
+    algo = float(B) * m["algo_bytes_per_traj"] + 2.0 * 4 * n_params
     return {
+        # the plane bytes are this design's own traffic - the
+        # fractions that do not grade the step against itself
+        "frac_vs_mfma_floor": mfma_ms / ms,
+        "plane_bytes_over_algorithmic": nbytes / algo,
+        "algorithmic_bytes_per_step": algo,
+        "frac_vs_algorithmic_bytes": algo / (HBM_PEAK_GBS * 1e9) * 1e3 / ms,
         "bound": "mfma" if mfma_ms >= hbm_ms else "hbm",
         "mfma": {"sweep_fp16_flops_per_step": sweep_flops,
                  "product_bf16x3_flops_per_step": product_flops,
@@ -355,8 +393,11 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
         Shard.normed_states = state_preprocessing(Shard.states)
     t.state_data = Shard
     t.static_shard = True        # every step is on this resident shard:
-    t.graph_steps = world == 1   # plane copies kept, the step replayed as a graph
-    t.init_optimizer()
+    # plane copies kept, the step replayed from captured graphs - with more
+    # than one rank as two graphs around the eager all-reduce (_GraphedStep),
+    # i.e. the N > 1 step replays the same kernels as the N = 1 step
+    t.graph_steps = True
+    t.init_optimizer()           # (swaps torch.nn.Linear leaves: swap_linear)
     if mode == "packed":
         ref6 = torch.cat((d["ref"][:, :, :3], d["ref"][:, :, 6:9]), 2)
         rows = (synthetic.to_packed_state(d["state0"]).to(dev),
@@ -378,25 +419,44 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
         "batch_per_gpu": B, "global_batch": world * B,
         "allreduce_floats": n_params + 1,
         "global_loss": float(total.item()),
+        "launch": ("one captured HIP graph per step" if world == 1 else
+                   "two captured HIP graphs per step around the eager all-reduce"),
     }
+    # like-for-like companions: the same step launched eagerly
+    # (no graphs: what a multi-rank step was before round 4) and, on one rank,
+    # in the split form the N > 1 step uses (graph A, empty all-reduce slot,
+    # graph B) - a scaling curve compares `ms_per_step` at N with
+    # `ms_per_step_split_graph` at 1
+    t.graph_steps = False
+    out["ms_per_step_eager"], _, _ = timed_steps(step, max(8, args.train_steps // 2), dist)
+    if world == 1:
+        t.graph_steps, t.split_graph = True, True
+        t._graphs.clear()
+        out["ms_per_step_split_graph"], _, _ = timed_steps(
+            step, max(8, args.train_steps // 2), dist)
+        t.split_graph = None
+        t._graphs.clear()
+    t.graph_steps = True
     if mode == "packed":
-        out["what"] = ("TrainDrone.train_controller_packed: PyTorch policy (not the "
-                       "reference architecture) -> [H, B, 4] action rows -> "
-                       "quad_rollout_rows_kernel -> policy backward (rocBLAS) + SGD")
-        # the same policy with the library's drop-in Linear (nn.py: weight
-        # gradients by apg_linear_wgrad instead of rocBLAS)
-        from apg_trajectory_tracking_amd import nn as apg_nn
-        for name in ("a", "b", "c"):
-            old = getattr(t.net, name)
-            new = apg_nn.Linear(old.in_features, old.out_features).to(dev)
-            new.load_state_dict(old.state_dict())
-            setattr(t.net, name, new)
-        t.init_optimizer()
-        ms2, _, chunks2 = timed_steps(step, args.train_steps, dist)
-        out["with_apg_nn_linear"] = {
+        out["what"] = ("TrainDrone.train_controller_packed: an arbitrary PyTorch policy "
+                       "(stock torch.nn.Linear layers, switched in place to the library's "
+                       "weight gradient by init_optimizer) -> [H, B, 4] action rows -> "
+                       "quad_rollout_rows_kernel -> autograd backward + SGD")
+        out["linear_layers"] = sorted({type(m).__module__ + "." + type(m).__name__
+                                       for m in t.net.modules()
+                                       if isinstance(m, torch.nn.Linear)})
+        # opt-out comparison: the same policy with rocBLAS weight gradients
+        t2 = TrainDrone(dyn, dyn, cfg)
+        t2.swap_linear = False
+        t2.net = PlainPolicy(H).to(dev)
+        t2.state_data, t2.static_shard, t2.graph_steps = Shard, True, True
+        t2.init_optimizer()
+        step2 = lambda: t2.train_controller_packed(
+            Shard.normed_states, Shard.in_ref_states, *rows)
+        ms2, _, chunks2 = timed_steps(step2, args.train_steps, dist)
+        out["with_stock_torch_linear"] = {
             "ms_per_step": ms2, "ms_per_step_chunks": chunks2,
-            "what": "the same step, the policy's three layers as "
-                    "apg_trajectory_tracking_amd.nn.Linear"}
+            "what": "swap_linear = False: dW = dY^T X through rocBLAS"}
     else:
         fused = {"concurrent": t.train_concurrent_fused(None, None, None, None, probe=True),
                  "autoregressive": t.fused_policy and t._fusable_mlp(),
@@ -424,6 +484,55 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
     return out
 
 
+def run_epoch_probe(args, dev, dyn):
+    """what TrainBase.run_epoch runs (scripts/train_base.py:
+    188-218), timed as it is: a resident data set of 4 x B trajectories,
+    shuffled index batches of B = 65 536 (device-side permutation, the gather
+    folded into the fused step's layout change), every step through the real
+    trainer method, the loss accumulated on the device and read back once per
+    epoch.  Eager launches and graph replays (the default since round 4: one
+    captured step per batch size, the index batch copied into a persistent
+    buffer).  ms per BATCH, host clock around whole epochs."""
+    import contextlib
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    H, B, nb = args.horizon, args.batch, 4
+    out = {"batches_per_epoch": nb, "batch": B,
+           "what": "TrainDrone.run_epoch('controller'): shuffled index batches, "
+                   "fused step per batch, one loss read-back per epoch"}
+    for key, mode in (("concurrent", "concurrent"), ("ar", "autoregressive"),
+                      ("lstm", "LSTM")):
+        cfg = dict(delta_t=args.dt, delta_t_train=args.dt, epoch_size=nb * B,
+                   self_play=0, batch_size=B, state_size=12, horizon=H,
+                   train_mode=mode, ref_dim=9, action_dim=4,
+                   learning_rate_controller=1e-9, system="quad", modified_params={},
+                   save_name="bench_run_epoch")
+        res = {}
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                t = TrainDrone(dyn, dyn, cfg)
+                t.initialize_model(device=dev, seed=args.seed)
+                for graphed in (False, True):
+                    t.graph_steps = graphed
+                    t._graphs.clear()
+                    t.run_epoch("controller", 0)          # warm-up / capture
+                    torch.cuda.synchronize()
+                    epochs = 3
+                    t0 = time.perf_counter()
+                    for e in range(epochs):
+                        t.run_epoch("controller", e + 1)
+                    torch.cuda.synchronize()
+                    ms = (time.perf_counter() - t0) / (epochs * nb) * 1e3
+                    res["ms_per_batch" if graphed else "ms_per_batch_eager"] = ms
+                res["env_steps_per_s"] = B * H / (res["ms_per_batch"] * 1e-3)
+                res["graphs"] = sorted(str(k) for k in t._graphs)
+            del t
+        except Exception as e:      # secondary block
+            res = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        out[key] = res
+    return out
+
+
 class PlainPolicy(torch.nn.Module):
     """A policy that is not the reference architecture (for `train_step_packed`)."""
 
@@ -436,6 +545,39 @@ class PlainPolicy(torch.nn.Module):
     def forward(self, state, ref):
         x = torch.cat((state, ref.flatten(1)), 1)
         return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+
+
+def measured_copy_bandwidth(dev):
+    """the copy bandwidth this box delivers, next to the 8 TB/s
+    datasheet peak.  apg_stream_copy (16-byte accesses, non-temporal stores -
+    the rollouts' access pattern without arithmetic) over 1 GiB -> 1 GiB (far
+    beyond the 256 MiB Infinity Cache), HIP events on the launch stream;
+    GB/s counts bytes read + bytes written."""
+    from apg_trajectory_tracking_amd import _capi
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.fill_(1)
+    st = _capi.stream_of(src)
+    run = lambda: _capi.check(_capi.lib().apg_stream_copy(
+        src.data_ptr(), dst.data_ptr(), n, st), "apg_stream_copy")
+    for _ in range(3):
+        run()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ok = bool((dst[:: 1 << 20] == 1).all())
+    del src, dst
+    torch.cuda.empty_cache()
+    return {"GBps": 2 * n / (ms * 1e-3) / 1e9, "bytes_each_way": n, "ms": ms,
+            "verified": ok,
+            "what": "apg_stream_copy 1 GiB -> 1 GiB, read + write bytes per second"}
 
 
 KERNEL_SOURCES = ("quad.hip", "quad_math.h", "apg_device.h")
@@ -895,6 +1037,22 @@ def main():
             "what": "informational: the K kernel-only launches as two independent "
                     "chains of one graph (even / odd buffer sets); `value` and "
                     "`roofline` are the serial launches"}
+    # results of buffer set 0 (the cpu_baseline leg compares them with the CPU
+    # port on the same tensors: `cpu_baseline.parity_check`)
+    gpu_set0 = None
+    if rank == 0:
+        from apg_trajectory_tracking_amd import synthetic as _sy
+        ga0 = plans[0].out["grad_actions"]
+        ga0 = {"packed": _sy.from_packed_seq, "soa": _sy.from_soa_seq,
+               "aos": lambda t: t}[args.layout](ga0)
+        gpu_set0 = {"loss": loss_check, "grad_actions": ga0.detach().cpu()}
+    copy_gbps = None
+    if not args.headline_only:
+        try:
+            copy_gbps = measured_copy_bandwidth(dev)
+        except Exception as e:          # informational only
+            copy_gbps = {"error": repr(e)}
+    out["roofline"]["copy_GBps_measured"] = copy_gbps
     del plans, kplans, sets, g_steps, g_kernel
     gc.collect()
     torch.cuda.empty_cache()
@@ -907,6 +1065,16 @@ def main():
                 out[key] = trainer_step_probe(args, dev, dyn, dist, mode)
             except Exception as e:      # secondary blocks must not kill the line
                 out[key] = {"error": repr(e)}
+    if (rank == 0 and world == 1 and args.train_steps > 0
+            and not (args.no_secondary or args.headline_only)):
+        try:
+            out["run_epoch"] = run_epoch_probe(args, dev, dyn)
+            ts, re_ = out.get("train_step", {}), out["run_epoch"].get("concurrent", {})
+            if "ms_per_step" in ts and "ms_per_batch" in re_:
+                out["run_epoch"]["concurrent"]["over_train_step"] = (
+                    re_["ms_per_batch"] / ts["ms_per_step"])
+        except Exception as e:
+            out["run_epoch"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not (args.no_secondary or args.headline_only):
         try:
             out["secondary"] = {"wing_rollout": wing_secondary(args, dev)}
@@ -917,7 +1085,8 @@ def main():
         except Exception as e:
             out["secondary"]["wing_closed_loop_eval"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.headline_only):
-        out["cpu_baseline"] = cpu_baseline(args)
+        out["cpu_baseline"] = cpu_baseline(args, gpu_set0)
+        out["parity_check"] = out["cpu_baseline"].pop("parity_check")
     elif rank == 0:
         out["cpu_baseline"] = None
     if dist is not None:
