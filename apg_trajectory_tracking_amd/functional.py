@@ -951,20 +951,59 @@ def static_plane_refs():
     return [e[3] for e in _STATIC_PLANES.entries]
 
 
-def _ref_and_states(in_ref, state0, B, H, index=None, also=()):
+def _ref_and_states(in_ref, state0, B, H, index=None, also=(), out=None):
     """One buffer for everything the conv-weight product reads as B operand:
     planes [0, 2H*9) = the reference tensor [2H][9][B], planes [2H*9, +(H+1)*12)
     = [state0; states of the rollout] ([H+1][12][B], the kernels write the H
     new states in place).  `also`: further [B, ...] tensors of the same
-    (indexed) batch converted by the same launch.  Returns (buffer, in_ref
-    view, state0 view, states view, *planes of `also`)."""
-    buf = torch.empty(2 * H * 9 + (H + 1) * 12, B, dtype=torch.float32,
-                      device=state0.device)
+    (indexed) batch converted by the same launch.  `out`: the tuple a previous
+    call returned, refilled in place (same batch size).  Returns (buffer,
+    in_ref view, state0 view, states view, *planes of `also`)."""
+    if out is None:
+        buf = torch.empty(2 * H * 9 + (H + 1) * 12, B, dtype=torch.float32,
+                          device=state0.device)
+        extra = [None] * len(also)
+    else:
+        buf, extra = out[0], list(out[4:])
     inr = buf[:2 * H * 9].view(2 * H, 9, B)
     st_all = buf[2 * H * 9:].view(H + 1, 12, B)
     outs = to_soa_multi([(in_ref[:, :2 * H], inr), (state0, st_all[0])] +
-                        [(t, None) for t in also], index=index)
+                        list(zip(also, extra)), index=index)
     return (buf, inr, st_all[0], st_all[1:], *outs[2:])
+
+
+def quad_recurrent_prepare(state0, in_ref, ref, index=None, out=None, H=10):
+    """The layout change (and, with `index`, the minibatch gather) of an
+    autoregressive / LSTM step's inputs, as its own call: run_epoch issues it
+    one batch ahead on a side stream (TrainBase._pipelined_epoch) and hands the
+    result to quad_mlp_rollout_grads / quad_lstm_rollout_grads as `prepared`.
+    `out`: a previous result to refill (same batch size)."""
+    B = state0.shape[0] if index is None else index.numel()
+    if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
+        raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
+    _guard_policy_inputs("fused recurrent unroll", state0=state0, in_ref=in_ref)
+    return _ref_and_states(_f32c(in_ref), _f32c(state0), B, H, index,
+                           also=(ref[:, :H],), out=out)
+
+
+def quad_concurrent_prepare(normed, state0, in_ref, ref, index=None, out=None, H=10):
+    """The same for the concurrent step: (acts [431 + 9 H][B] with the feature
+    planes 0..14 and the in_ref planes 431.. filled, state0 planes, ref
+    planes)."""
+    B = state0.shape[0] if index is None else index.numel()
+    if in_ref.shape[1] < H or in_ref.shape[2] != 9 or ref.shape[1] < H \
+            or normed.shape[1] != 15:
+        raise ValueError("normed [B,15], in_ref [B,>=H,9], ref [B,>=H,9|6], H = 10")
+    _guard_policy_inputs("fused concurrent step", normed=normed, in_ref=in_ref)
+    if out is None:
+        acts = torch.empty(431 + H * 9, B, dtype=torch.float32, device=state0.device)
+        s0 = rf = None
+    else:
+        acts, s0, rf = out
+    _, _, s0, rf = to_soa_multi(
+        [(normed, acts[:15]), (in_ref[:, :H], acts[431:].view(H, 9, B)), (state0, s0),
+         (ref[:, :H], rf)], index=index)
+    return acts, s0, rf
 
 
 _CONV_DIAG_PLANES = 720      # 20 ch x 2 half-waves x 13 diagonals + 20 ch x H
@@ -1014,20 +1053,25 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, state0, in_ref, ref, h0, c0, conv_w, conv_b, w_ih, w_hh,
                 b_ih, b_hh, w_out, b_out, dt, params, weights, index=None):
-        B = state0.shape[0] if index is None else index.numel()
         H = 10
-        if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
-            raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
         if w_ih.shape != (32, 175) or conv_w.shape != (20, 9, 3):
             raise ValueError("fused path needs LSTM_NEW(15, 10, 9, 4, conv=1)")
-        _guard_policy_inputs("fused LSTM unroll", state0=state0, in_ref=in_ref)
-        dev = state0.device
-        src = getattr(ctx, "static_src", None) if index is None else None
-        hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
-        refbuf, inr, s0, states, rf = hit or _ref_and_states(
-            _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
-        if src and hit is None:
-            _STATIC_PLANES.store("recurrent", src, (refbuf, inr, s0, states, rf))
+        prepared = getattr(ctx, "prepared", None)
+        if prepared is not None:     # quad_recurrent_prepare ran ahead
+            refbuf, inr, s0, states, rf = prepared
+            B = s0.shape[-1]
+        else:
+            B = state0.shape[0] if index is None else index.numel()
+            if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
+                raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
+            _guard_policy_inputs("fused LSTM unroll", state0=state0, in_ref=in_ref)
+            src = getattr(ctx, "static_src", None) if index is None else None
+            hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
+            refbuf, inr, s0, states, rf = hit or _ref_and_states(
+                _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
+            if src and hit is None:
+                _STATIC_PLANES.store("recurrent", src, (refbuf, inr, s0, states, rf))
+        dev = s0.device
         if all(_is_plane_view(t) for t in (h0, c0)):
             h0s, c0s = h0.detach().t(), c0.detach().t()   # already [8][B] planes
         else:
@@ -1137,26 +1181,33 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, state0, in_ref, ref, w_s, b_s, conv_w, conv_b, w_1, b_1,
                 w_2, b_2, w_3, b_3, w_out, b_out, dt, params, weights, index=None):
-        B = state0.shape[0] if index is None else index.numel()
         H = 10
-        if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
-            raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
         if (w_s.shape != (64, 15) or conv_w.shape != (20, 9, 3)
                 or w_1.shape != (64, 224) or w_out.shape != (4, 64)):
             raise ValueError("fused path needs Net(15, 10, 9, 4, conv=1)")
+        prepared = getattr(ctx, "prepared", None)
+        if prepared is not None:     # quad_recurrent_prepare ran ahead
+            B = prepared[2].shape[-1]
+        else:
+            B = state0.shape[0] if index is None else index.numel()
+            if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9 or ref.shape[1] < H:
+                raise ValueError("in_ref [B,2H,9] and ref [B,>=H,9|6] with H = 10")
         N = H * B
         if 256 * N * 4 >= 2 ** 32:
             raise ValueError("batch too large for one fused launch "
                              "(B <= 400 000); split it")
-        _guard_policy_inputs("fused autoregressive unroll", state0=state0,
-                             in_ref=in_ref)
-        dev = state0.device
-        src = getattr(ctx, "static_src", None) if index is None else None
-        hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
-        refbuf, inr, s0, states, rf = hit or _ref_and_states(
-            _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
-        if src and hit is None:
-            _STATIC_PLANES.store("recurrent", src, (refbuf, inr, s0, states, rf))
+        if prepared is not None:
+            refbuf, inr, s0, states, rf = prepared
+        else:
+            _guard_policy_inputs("fused autoregressive unroll", state0=state0,
+                                 in_ref=in_ref)
+            src = getattr(ctx, "static_src", None) if index is None else None
+            hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
+            refbuf, inr, s0, states, rf = hit or _ref_and_states(
+                _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
+            if src and hit is None:
+                _STATIC_PLANES.store("recurrent", src, (refbuf, inr, s0, states, rf))
+        dev = s0.device
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -1421,31 +1472,29 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
     def forward(ctx, normed, state0, in_ref, ref, w_s, b_s, conv_w, conv_b, w_1,
                 b_1, w_2, b_2, w_3, b_3, w_out, b_out, dt, params, weights,
                 index=None):
-        B, H = (state0.shape[0] if index is None else index.numel()), 10
-        if in_ref.shape[1] < H or in_ref.shape[2] != 9 or ref.shape[1] < H \
-                or normed.shape[1] != 15:
-            raise ValueError("normed [B,15], in_ref [B,>=H,9], ref [B,>=H,9|6], H = 10")
+        H = 10
         if (w_s.shape != (64, 15) or conv_w.shape != (20, 9, 3)
                 or w_1.shape != (64, 224) or w_out.shape != (40, 64)):
             raise ValueError("fused path needs Net(15, 10, 9, 40, conv=1)")
-        _guard_policy_inputs("fused concurrent step", normed=normed, in_ref=in_ref)
-        dev = state0.device
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        prepared = getattr(ctx, "prepared", None)
         # one buffer for the B operands of the weight products:
         # feat (15) | x1 (224) | h1, h2, h3 (192) | in_ref rows (H*9)
-        src = getattr(ctx, "static_src", None) if index is None else None
-        hit = _STATIC_PLANES.lookup("concurrent", src) if src else None
-        if hit is not None:
-            acts, s0, rf = hit       # feat / in_ref planes still valid, the
-        else:                        # kernels rewrite x1 and h every step
-            acts = new(431 + H * 9, B)
-        feat, x1, h, inr = acts[:15], acts[15:239], acts[239:431], acts[431:]
-        if hit is None:
-            _, _, s0, rf = to_soa_multi(
-                [(normed, feat), (in_ref[:, :H], inr.view(H, 9, B)), (state0, None),
-                 (ref[:, :H], None)], index=index)
-            if src:
+        if prepared is not None:     # quad_concurrent_prepare ran ahead
+            acts, s0, rf = prepared
+            B = s0.shape[-1]
+        else:
+            B = state0.shape[0] if index is None else index.numel()
+            src = getattr(ctx, "static_src", None) if index is None else None
+            hit = _STATIC_PLANES.lookup("concurrent", src) if src else None
+            # (a hit: feat / in_ref planes still valid, the kernels rewrite x1
+            # and h every step)
+            acts, s0, rf = hit or quad_concurrent_prepare(
+                normed, state0, in_ref, ref, index)
+            if src and hit is None:
                 _STATIC_PLANES.store("concurrent", src, (acts, s0, rf))
+        dev = s0.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        feat, x1, h, inr = acts[:15], acts[15:239], acts[239:431], acts[431:]
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
         pw = dict(zip(names, (_f32c(v).contiguous() for v in (
@@ -1528,7 +1577,8 @@ def _net_params(net, names):
 
 
 def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
-                                 weights=None, index=None, static_inputs=False):
+                                 weights=None, index=None, static_inputs=False,
+                                 prepared=None):
     """quad_concurrent_policy_loss + its parameter gradients, without autograd:
     returns (loss, {parameter name: gradient}, flat); the gradients are
     contiguous views of the flat buffer (no per-parameter clone as
@@ -1556,13 +1606,16 @@ _MAX_FUSED_AR_BATCH = 393216
 
 
 def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
-                           index=None, static_inputs=False):
+                           index=None, static_inputs=False, prepared=None):
     """quad_mlp_rollout_loss (autoregressive unroll) + parameter gradients,
     without autograd; see quad_concurrent_policy_grads.  Batches beyond
     393 216 trajectories are processed in chunks (losses and gradients are sums
     over trajectories, so the chunks simply add up)."""
-    B = state0.shape[0] if index is None else index.numel()
+    B = (prepared[2].shape[-1] if prepared is not None
+         else state0.shape[0] if index is None else index.numel())
     if B > _MAX_FUSED_AR_BATCH:
+        if prepared is not None:
+            raise ValueError("prepared batches must fit one fused launch")
         n = -(-B // _MAX_FUSED_AR_BATCH)
         step = -(-B // n)
         if index is None:
@@ -1578,7 +1631,9 @@ def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
                 loss = loss + l
         return loss, gr, flat
     ctx = _DirectCtx()
-    if static_inputs and index is None:
+    if prepared is not None:     # quad_recurrent_prepare's result
+        ctx.prepared = prepared
+    elif static_inputs and index is None:
         ctx.static_src = (state0, in_ref, ref)
     with torch.no_grad():
         loss, _, _ = _QuadMlpRolloutLoss.forward(
@@ -1594,10 +1649,13 @@ _LSTM_PARAMS = ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
 
 
 def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
-                            weights=None, index=None, static_inputs=False):
+                            weights=None, index=None, static_inputs=False,
+                            prepared=None):
     """quad_lstm_rollout_loss + parameter gradients, without autograd."""
     ctx = _DirectCtx()
-    if static_inputs and index is None:
+    if prepared is not None:     # quad_recurrent_prepare's result
+        ctx.prepared = prepared
+    elif static_inputs and index is None:
         ctx.static_src = (state0, in_ref, ref)
     with torch.no_grad():
         loss, _, _ = _QuadLstmRolloutLoss.forward(

@@ -95,16 +95,45 @@ class TrainDrone(TrainBase):
         self.init_optimizer()
 
     def train_recurrent_model(
-        self, in_state, current_state, in_ref_states, ref_states, index=None
+        self, in_state, current_state, in_ref_states, ref_states, index=None,
+        prepared=None, slot=0
     ):
         """`index` (fused paths only): the tensors are the whole data set, the
-        batch is rows `index` (gathered inside the kernels' layout change)."""
+        batch is rows `index` (gathered inside the kernels' layout change).
+        `prepared` (fused paths only): functional.quad_recurrent_prepare's
+        result for this batch - the layout change already ran (one batch ahead,
+        TrainBase._pipelined_epoch; `slot` = which of its two buffer sets) and
+        the four tensors are unused."""
         self.optimizer_controller.zero_grad()
+        fused = self.fused_policy and (
+            self._fusable() if self.train_mode == "LSTM" else self._fusable_mlp())
+        if prepared is not None:
+            if not fused:
+                raise ValueError("prepared batches need the fused policy path")
+            batch_size = prepared[2].shape[-1]
+            kw = dict(prepared=prepared)
+            lstm_eager = self.train_mode == "LSTM" and self.hidden_generator is not None
+            key = (self.train_mode.lower(), batch_size, "slot", slot)
+            if self.train_mode == "LSTM":
+                def compute():
+                    self.net.reset_hidden_state(
+                        batch_size, generator=self.hidden_generator)
+                    return F.quad_lstm_rollout_grads(
+                        self.net, None, None, None, self.delta_t,
+                        self.train_dynamics.params, self.net.hidden_state,
+                        self.net.cell_state, **kw)
+            else:
+                def compute():
+                    return F.quad_mlp_rollout_grads(
+                        self.net, None, None, None, self.delta_t,
+                        self.train_dynamics.params, **kw)
+            if lstm_eager:
+                return self._step_direct(*compute())
+            return self._graphed(key, (), self._direct_parts(compute),
+                                 volatile=tuple(prepared))
         batch_size = current_state.size()[0] if index is None else index.numel()
         static = index is None and self.static_shard
         tensors = (current_state, in_ref_states, ref_states)
-        fused = self.fused_policy and (
-            self._fusable() if self.train_mode == "LSTM" else self._fusable_mlp())
         held = (self._graph_index(index)
                 if index is not None and fused
                 and not (self.train_mode == "LSTM"
@@ -164,6 +193,30 @@ class TrainDrone(TrainBase):
             intermediate_states, ref_states[:, :self.horizon], action_seq)
         return self._step(loss)
 
+    def prefetch_plan(self):
+        """run_epoch's hook for the fused modes: (prepare, step) - `prepare(
+        index, out)` is the batch's layout change + row gather (issued one
+        batch ahead on a side stream, TrainBase._pipelined_epoch), `step(
+        prepared, slot)` the optimizer step on its result.  None: no fused
+        path for this trainer / network."""
+        if not (torch.cuda.is_available() and self.trainloader is not None
+                and self.trainloader.tensors[0].is_cuda):
+            return None
+        normed, states, in_ref, ref = self.trainloader.tensors
+        if self.train_mode == "concurrent":
+            if not self.train_concurrent_fused(None, None, None, None, probe=True):
+                return None
+            return (lambda index, out: F.quad_concurrent_prepare(
+                        normed, states, in_ref, ref, index=index, out=out),
+                    lambda prepared, slot: self.train_concurrent_fused(
+                        None, None, None, None, prepared=prepared, slot=slot))
+        if not self.recurrent_indexed_ok():
+            return None
+        return (lambda index, out: F.quad_recurrent_prepare(
+                    states, in_ref, ref, index=index, out=out),
+                lambda prepared, slot: self.train_recurrent_model(
+                    None, None, None, None, prepared=prepared, slot=slot))
+
     def recurrent_indexed_ok(self):
         """run_epoch may hand index batches to train_recurrent_model."""
         return self.fused_policy and (
@@ -179,10 +232,12 @@ class TrainDrone(TrainBase):
 
     def train_concurrent_fused(
         self, in_state, current_state, in_ref_states, ref_states, index=None,
-        probe=False
+        probe=False, prepared=None, slot=0
     ):
         """scripts/train_base.py:198-204 + scripts/train_drone.py:175-203 with
-        the policy inside the kernels (apg_quad_mlp_concurrent_fwd_bwd)."""
+        the policy inside the kernels (apg_quad_mlp_concurrent_fwd_bwd).
+        `prepared`: functional.quad_concurrent_prepare's result for this batch
+        (see train_recurrent_model)."""
         n = self.net
         ok = (self.fused_policy and isinstance(n, Net) and n.conv
                 and self.horizon == 10 and self.analytic_train_dynamics()
@@ -194,6 +249,14 @@ class TrainDrone(TrainBase):
             return ok
         if not ok:
             return None
+        if prepared is not None:
+            def compute():
+                return F.quad_concurrent_policy_grads(
+                    n, None, None, None, None, self.delta_t,
+                    self.train_dynamics.params, prepared=prepared)
+            return self._graphed(("concurrent", prepared[1].shape[-1], "slot", slot),
+                                 (), self._direct_parts(compute),
+                                 volatile=tuple(prepared))
         tensors = (in_state, current_state, in_ref_states, ref_states)
         held = None if index is None else self._graph_index(index)
         if held is not None:

@@ -486,16 +486,17 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
 
 def run_epoch_probe(args, dev, dyn):
     """what TrainBase.run_epoch runs (scripts/train_base.py:
-    188-218), timed as it is: a resident data set of 4 x B trajectories,
+    188-218), timed as it is: a resident data set of 16 x B trajectories,
     shuffled index batches of B = 65 536 (device-side permutation, the gather
     folded into the fused step's layout change), every step through the real
     trainer method, the loss accumulated on the device and read back once per
-    epoch.  Eager launches and graph replays (the default since round 4: one
-    captured step per batch size, the index batch copied into a persistent
-    buffer).  ms per BATCH, host clock around whole epochs."""
+    epoch; the next batch's layout change + gather runs on a side stream while
+    the current batch steps (TrainBase._pipelined_epoch).  Eager launches and
+    graph replays (the default since round 4: one captured step per batch size
+    and buffer set).  ms per BATCH, host clock around whole epochs."""
     import contextlib
     from apg_trajectory_tracking_amd.train_drone import TrainDrone
-    H, B, nb = args.horizon, args.batch, 4
+    H, B, nb = args.horizon, args.batch, 16
     out = {"batches_per_epoch": nb, "batch": B,
            "what": "TrainDrone.run_epoch('controller'): shuffled index batches, "
                    "fused step per batch, one loss read-back per epoch"}

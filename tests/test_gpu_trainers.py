@@ -1453,13 +1453,17 @@ def test_graphed_step_follows_lr_and_physics_changes(dev):
     F._STATIC_PLANES.entries.clear()
 
 
+@pytest.mark.parametrize("prefetch", [True, False])
 @pytest.mark.parametrize("mode", ["concurrent", "autoregressive", "LSTM"])
-def test_run_epoch_replays_one_graph_over_shuffled_minibatches(dev, mode):
+def test_run_epoch_replays_one_graph_over_shuffled_minibatches(dev, mode, prefetch):
     """TrainBase.graph_steps with the REAL epoch loop: shuffled index batches
-    (two full ones and a ragged tail per epoch) go through a persistent index
-    buffer, so every minibatch replays the step captured for its size.  Same
-    seed -> the epochs' losses and the final weights equal the eager loop's;
-    one graph per batch size, captured once."""
+    (two full ones and a ragged tail per epoch).  `prefetch_batches` (default):
+    the batch's layout change + row gather runs one batch ahead on a side
+    stream into one of two buffer sets, every minibatch replays the step
+    captured for (its size, its buffer set); without it the index batch is
+    copied into a persistent buffer the captured gather reads.  Same seed ->
+    the epochs' losses and the final weights equal the eager loop's (which
+    runs the same pipeline, or none), graphs are captured once."""
     import copy
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
@@ -1467,29 +1471,38 @@ def test_run_epoch_replays_one_graph_over_shuffled_minibatches(dev, mode):
     cfg = dict(QUAD_CFG, train_mode=mode, epoch_size=1000, self_play=0,
                batch_size=384, learning_rate_controller=1e-6)
     runs = []
-    for graph in (False, True):
+    for graph, pre in ((False, False), (False, prefetch), (True, prefetch)):
         torch.manual_seed(4)
         t = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
         t.initialize_model(device=dev, seed=6)
-        if graph:
+        if runs:
             t.net.load_state_dict(runs[0][2])      # same start
         start = copy.deepcopy(t.net.state_dict())
-        t.graph_steps = graph
+        t.graph_steps, t.prefetch_batches = graph, pre
         torch.manual_seed(11)                      # the permutations
         torch.cuda.manual_seed(12)
         losses = [t.run_epoch(train="controller", epoch=e) for e in range(3)]
         runs.append((losses, {k: v.clone() for k, v in t.net.state_dict().items()},
                      start))
-        if graph:
+        if graph and pre:
+            # batch i of an epoch uses buffer set i & 1: 384, 384, 232
+            assert sorted((k[1], k[3]) for k in t._graphs) == [(232, 0), (384, 0), (384, 1)]
+            assert not t._index_bufs
+            first = dict(t._graphs)
+            t.run_epoch(train="controller", epoch=3)
+            assert all(t._graphs[k] is g for k, g in first.items())   # no re-capture
+        elif graph:
             assert sorted(k[1] for k in t._graphs) == [232, 384]
             assert sorted(t._index_bufs) == [232, 384]
         else:
             assert not t._graphs
-    (la, wa, _), (lb, wb, _) = runs
-    assert all(np.isfinite(la)) and all(np.isfinite(lb))
+    (la, wa, _), (lb, wb, _), (lc, wc, _) = runs
+    assert all(np.isfinite(la)) and all(np.isfinite(lc))
     if mode != "LSTM":
-        assert np.allclose(la, lb, rtol=1e-5), (la, lb)
-        for k in wa:
-            assert rel_err(wb[k].cpu().numpy(), wa[k].cpu().numpy()) < 1e-5, k
+        for l_, w_ in ((lb, wb), (lc, wc)):
+            assert np.allclose(la, l_, rtol=1e-5), (la, l_)
+            for k in wa:
+                assert rel_err(w_[k].cpu().numpy(), wa[k].cpu().numpy()) < 1e-5, k
     else:      # fresh (h0, c0) per step from the captured generator state
-        assert abs(lb[0] - la[0]) / abs(la[0]) < 0.2
+        assert abs(lb[0] - la[0]) / abs(la[0]) < 1e-5     # eager: same draws
+        assert abs(lc[0] - la[0]) / abs(la[0]) < 0.2
