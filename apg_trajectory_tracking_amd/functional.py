@@ -969,6 +969,8 @@ def _ref_and_states(in_ref, state0, B, H, index=None, also=(), out=None):
     st_all = buf[2 * H * 9:].view(H + 1, 12, B)
     outs = to_soa_multi([(in_ref[:, :2 * H], inr), (state0, st_all[0])] +
                         list(zip(also, extra)), index=index)
+    if out is not None:
+        return out        # the same tensor objects, refilled
     return (buf, inr, st_all[0], st_all[1:], *outs[2:])
 
 
@@ -1003,7 +1005,7 @@ def quad_concurrent_prepare(normed, state0, in_ref, ref, index=None, out=None, H
     _, _, s0, rf = to_soa_multi(
         [(normed, acts[:15]), (in_ref[:, :H], acts[431:].view(H, 9, B)), (state0, s0),
          (ref[:, :H], rf)], index=index)
-    return acts, s0, rf
+    return out if out is not None else (acts, s0, rf)
 
 
 _CONV_DIAG_PLANES = 720      # 20 ch x 2 half-waves x 13 diagonals + 20 ch x H

@@ -75,10 +75,20 @@ class _GraphedStep:
     def __init__(self, part_a, part_b, reduce, signature, keep, net, optimizer,
                  capture=True, split=False):
         self.signature, self.keep = signature, keep
-        self.part_a, self.part_b, self.reduce = part_a, part_b, reduce
-        self.capture, self.split = capture, split
+        self.reduce, self.capture, self.split = reduce, capture, split
         if not capture:
+            self.part_a, self.part_b = part_a, part_b
             return
+        # (a captured step does NOT keep the closures: they reference the
+        # trainer, and trainer -> graphs -> closures -> trainer would leave the
+        # graphs to the cyclic collector, which may then destroy a HIP graph
+        # in the middle of somebody else's capture)
+        import gc
+
+        def eager():
+            msg = part_a()
+            reduce(msg)
+            return part_b(msg)
         # the warm-up steps (allocator, momentum buffers, lazy inits, plane
         # caches - all outside the capture) must not train: parameters and
         # momentum are put back afterwards (a missing momentum buffer is a
@@ -91,7 +101,7 @@ class _GraphedStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                self._eager()
+                eager()
         torch.cuda.current_stream().wait_stream(side)
         with torch.no_grad():
             for p, v, b in zip(params, saved, bufs):
@@ -103,21 +113,30 @@ class _GraphedStep:
         # THIS thread's calls may invalidate the capture
         mode = ({"capture_error_mode": "thread_local"}
                 if parallel.world_size() > 1 else {})
-        if split:
-            self.graph_a = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_a, **mode):
-                self.msg = part_a()
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), **mode):
-                self.out = part_b(self.msg)
-        else:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, **mode):
-                self.out = part_b(part_a())
+        # no garbage collection inside a capture: a collected tensor or graph
+        # of somebody else would issue HIP calls the capture forbids
+        was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            if split:
+                self.graph_a = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_a, **mode):
+                    self.msg = part_a()
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), **mode):
+                    self.out = part_b(self.msg)
+            else:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, **mode):
+                    self.out = part_b(part_a())
+        finally:
+            if was_enabled:
+                gc.enable()
         from . import functional
         self.planes = functional.static_plane_refs()
 
-    def _eager(self):
+    def _eager(self):         # emulation (capture False) only
         msg = self.part_a()
         self.reduce(msg)
         return self.part_b(msg)
@@ -320,7 +339,9 @@ class TrainBase:
         versions = not volatile
         return (tuple((id(t), t._version if versions else 0, tuple(t.shape))
                       for t in inputs)
-                + tuple((id(t), tuple(t.shape)) for t in volatile)
+                # (volatile buffers by ADDRESS: views of one persistent buffer
+                # are new tensor objects every time they are taken)
+                + tuple((t.data_ptr(), tuple(t.shape)) for t in volatile)
                 # a replaced network or optimizer must not replay the old graph
                 + tuple(id(p) for p in self.net.parameters())
                 + (id(opt), hyper, phys, float(self.delta_t),
