@@ -1590,9 +1590,13 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
     rows are gathered while they are brought into the plane layout.
     `static_inputs` (index None): the caller steps repeatedly on these very
     tensor objects (its resident shard) - their plane-layout copies are kept
-    while the tensors stay unchanged (_StaticPlanes)."""
+    while the tensors stay unchanged (_StaticPlanes).  `prepared`: the result
+    of quad_concurrent_prepare for this batch (the four tensors are then
+    unused and may be None)."""
     ctx = _DirectCtx()
-    if static_inputs and index is None:
+    if prepared is not None:
+        ctx.prepared = prepared
+    elif static_inputs and index is None:
         ctx.static_src = (normed, state0, in_ref, ref)
     with torch.no_grad():
         loss = _QuadConcurrentPolicyLoss.forward(

@@ -677,13 +677,13 @@ typedef struct ApgSoaItem {
 int apg_to_soa_multi(const ApgSoaItem *items, int n, int B, apg_stream_t stream);
 /* Number of floats `loss_partials` must hold for a batch of B. */
 int apg_loss_partials_count(int B);
-/* APG_VERSION_MAJOR * 1000 + APG_VERSION_MINOR. */
 /* Measurement aid: device-to-device stream copy (16-byte accesses, grid-
  * strided, non-temporal stores) - the copy bandwidth this GPU delivers, quoted
  * next to the 8 TB/s datasheet peak in bench.py's roofline.
  * 16-byte aligned pointers, bytes a multiple of 16. */
 int apg_stream_copy(const void *src, void *dst, long long bytes, apg_stream_t stream);
 
+/* APG_VERSION_MAJOR * 1000 + APG_VERSION_MINOR. */
 int apg_version(void);
 /* Description of the last error on the calling thread ("" if none). */
 const char *apg_last_error_string(void);
