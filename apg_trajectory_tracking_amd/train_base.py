@@ -233,8 +233,12 @@ class TrainBase:
         self._graphs = {}
         self._index_bufs = {}
         # True: run_epoch issues the layout change + row gather of batch i + 1
-        # on a side stream while batch i steps (_pipelined_epoch)
-        self.prefetch_batches = True
+        # on a side stream while batch i steps (_pipelined_epoch).  Off by
+        # default: measured on the MI355X at B = 65 536 it does not pay - the
+        # overlapped gather slows the step's memory-bound kernels by as much as
+        # it costs alone (concurrent 0.240 vs 0.238 ms per batch, LSTM 0.565 vs
+        # 0.525, autoregressive 1.164 vs 1.143; profiles/r04_run_epoch.jsonl)
+        self.prefetch_batches = False
         self._prefetch = {}
 
         # horizon / reference-window length (scripts/train_base.py:118-128)
@@ -570,6 +574,23 @@ class TrainBase:
             self._borrow_loss, self._epoch_sigs = False, None
         return running, i
 
+    def _indexed_epoch(self, step):
+        """One epoch of `step(index)` over the loader's index batches (the
+        gather is folded into the fused step's layout change, inside its
+        captured graph).  Inside the loop nothing a capture depends on changes:
+        graph signatures are computed once per key, the step's loss is taken
+        without a private copy and added to the running loss in place.
+        Returns (running_loss, last batch index)."""
+        running, i = None, -1
+        self._borrow_loss, self._epoch_sigs = True, {}
+        try:
+            for i, index in enumerate(self.trainloader.iter_indices(), 0):
+                loss = step(index).detach()
+                running = loss.clone() if running is None else running.add_(loss)
+        finally:
+            self._borrow_loss, self._epoch_sigs = False, None
+        return running, i
+
     def run_epoch(self, train="controller", epoch=0):
         if train not in ("controller", "dynamics"):
             raise ValueError("train must be 'controller' or 'dynamics'")
@@ -586,10 +607,8 @@ class TrainBase:
                                                 probe=True)):
             # fused step with the minibatch gather folded into its first pass
             tensors = self.trainloader.tensors
-            for i, index in enumerate(self.trainloader.iter_indices(), 0):
-                loss = self.train_concurrent_fused(*tensors, index=index).detach()
-                running_loss = loss if running_loss is None else running_loss + loss
-            return self._finish_epoch(running_loss, i, train)
+            return self._finish_epoch(*self._indexed_epoch(
+                lambda index: self.train_concurrent_fused(*tensors, index=index)), train)
         if (train == "controller" and self.train_mode == "concurrent"
                 and hasattr(self.trainloader, "iter_indices")
                 and getattr(self, "use_packed_path", True)
@@ -617,10 +636,8 @@ class TrainBase:
                 and hasattr(self.trainloader, "iter_indices")
                 and getattr(self, "recurrent_indexed_ok", lambda: False)()):
             tensors = self.trainloader.tensors
-            for i, index in enumerate(self.trainloader.iter_indices(), 0):
-                loss = self.train_recurrent_model(*tensors, index=index).detach()
-                running_loss = loss if running_loss is None else running_loss + loss
-            return self._finish_epoch(running_loss, i, train)
+            return self._finish_epoch(*self._indexed_epoch(
+                lambda index: self.train_recurrent_model(*tensors, index=index)), train)
         for i, data in enumerate(self.trainloader, 0):
             in_state, current_state, in_ref_state, ref_states = data
             if train == "dynamics":

@@ -490,10 +490,10 @@ def run_epoch_probe(args, dev, dyn):
     shuffled index batches of B = 65 536 (device-side permutation, the gather
     folded into the fused step's layout change), every step through the real
     trainer method, the loss accumulated on the device and read back once per
-    epoch; the next batch's layout change + gather runs on a side stream while
-    the current batch steps (TrainBase._pipelined_epoch).  Eager launches and
-    graph replays (the default since round 4: one captured step per batch size
-    and buffer set).  ms per BATCH, host clock around whole epochs."""
+    epoch.  Eager launches and graph replays (the default since round 4: one
+    captured step per batch size, the index batch copied into a persistent
+    buffer the captured gather reads).  ms per BATCH, host clock around whole
+    epochs."""
     import contextlib
     from apg_trajectory_tracking_amd.train_drone import TrainDrone
     H, B, nb = args.horizon, args.batch, 16

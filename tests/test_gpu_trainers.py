@@ -1457,7 +1457,7 @@ def test_graphed_step_follows_lr_and_physics_changes(dev):
 @pytest.mark.parametrize("mode", ["concurrent", "autoregressive", "LSTM"])
 def test_run_epoch_replays_one_graph_over_shuffled_minibatches(dev, mode, prefetch):
     """TrainBase.graph_steps with the REAL epoch loop: shuffled index batches
-    (two full ones and a ragged tail per epoch).  `prefetch_batches` (default):
+    (two full ones and a ragged tail per epoch).  `prefetch_batches` (opt-in):
     the batch's layout change + row gather runs one batch ahead on a side
     stream into one of two buffer sets, every minibatch replays the step
     captured for (its size, its buffer set); without it the index batch is
