@@ -80,6 +80,11 @@ class ApgMlpPolicy(ctypes.Structure):
         "w_3", "b_3", "w_out", "b_out")]
 
 
+class ApgMlpPolicyGrads(ctypes.Structure):
+    """Where apg_quad_mlp_concurrent_step puts each parameter's gradient."""
+    _fields_ = ApgMlpPolicy._fields_
+
+
 class ApgWingPolicy(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "w_s", "b_s", "w_r", "b_r", "w_1", "b_1", "w_2", "b_2", "w_3", "b_3",
@@ -155,6 +160,12 @@ SIGNATURES = {
         _P, _P, _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_mlp_step_workspace_floats": [],
+    "apg_quad_mlp_step_partials_floats": [_I],
+    "apg_quad_mlp_concurrent_step": [
+        _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
+        _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P, _P],
     "apg_quad_mlp_closed_loop": [
         _P, _I, _F, ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgMlpPolicy),
         _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -219,6 +230,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"apg_last_error_string": ctypes.c_char_p,
              "apg_planes_gemm_multi_workspace_floats": ctypes.c_longlong,
+             "apg_quad_mlp_step_partials_floats": ctypes.c_longlong,
              "apg_linear_wgrad_workspace_floats": ctypes.c_longlong}
 
 _lib = None

@@ -1212,6 +1212,558 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A
   }
 }
 
+// ------------------------------------------ concurrent mode, round 4: the
+// reverse pass of the network WITH its weight gradients.
+// Until round 3 the reverse kernel wrote 456 cotangent planes (119 MB at
+// B = 65 536) for a second pass - seven planes_gemm products that read them and
+// the 431 activation planes again (60-74 us of the 177 us step).  Here the
+// products happen inside the reverse kernel:
+//
+//   dW[m][k] = sum_n delta[m][n] x[k][n]       (n = trajectory)
+//
+// is a matrix product whose REDUCTION index is the trajectory, so it wants both
+// operands as [row][8 consecutive trajectories] per lane.  x already is that in
+// global memory (the forward kernel's planes are [row][B]: a lane reads 64
+// contiguous bytes of its row, no transposition - what planes_gemm's stream
+// kernel does).  delta lives in accumulator layout (trajectory = lane): it is
+// transposed through LDS - every wave writes its 32 trajectories' values as
+// fp16 high / low terms to [term][row][256 trajectories] (2-byte stores), a
+// workgroup barrier, then OWNER waves read 16-byte k-slots of a row and
+// multiply against x on v_mfma_f32_32x32x16_f16 (three products per k-block,
+// policy_mfma16.h).  One workgroup = 8 waves = 256 trajectories; a layer's
+// 32 x 32 blocks of dW are dealt to the waves (one block = 16 k-blocks x 3
+// instructions), their results go to a per-workgroup partial buffer and ONE
+// second-stage launch sums the workgroups in a fixed order (deterministic) -
+// it also reduces the loss partials, so the step has no other small launch.
+// delta is scaled by a power of two per workgroup and layer (largest entry into
+// [0.5, 1); exact) - a trajectory with small cotangents keeps an ABSOLUTE
+// accuracy of 2^-25 of the workgroup's largest, which is what a sum over
+// trajectories needs.
+// LDS: the transposed operand tables (100 KB, ordered so that the tables of the
+// layers already passed lie next to the staging area) + the staging area
+// (<= 67.6 KB for a 64-row layer; the conv cotangents - 160 rows - in two
+// halves of four window positions).  HBM per 65 536 trajectories: reads 67 MB
+// (tanh') + 136 MB (x for the products) + masks, writes 38 MB of partials
+// instead of 119 MB of cotangent planes + 232 MB of product reads.
+constexpr int wC = 0, wS = 20, w2 = 28, w3 = 36, wO = 44, wBlocks = 50;
+constexpr int kWgTabBytes = wBlocks * kBlock16;   // 102 400
+constexpr int kWgTabFloats = kWgTabBytes / 4;
+constexpr int kLdsAll = 160 * 1024;
+constexpr int kRS = 528;              // staged row: 256 fp16 + 16 B (b128 reads conflict-free)
+constexpr int kMetaBytes = 256;       // tail of the LDS: per-wave |delta| maxima
+constexpr int kStageEnd = kLdsAll - kMetaBytes;
+__host__ __device__ constexpr int stage_base(int rows) { return kStageEnd - 2 * rows * kRS; }
+static_assert(stage_base(40) >= kWgTabBytes, "head staging next to live tables");
+static_assert(stage_base(64) >= wO * kBlock16, "64-row staging may only cover the head tables");
+static_assert(stage_base(80) >= wS * kBlock16, "conv staging must not touch the fc1 conv tables");
+// partial slots of a workgroup (1024 floats each, accumulator order [reg][lane])
+constexpr int sOut = 0, sFc3 = 4, sFc2 = 8, sFc1 = 12, sSin = 26, sConv = 28, sBias = 36,
+              kSlots = 37;
+// first planes of the x blocks in the activation buffer (feat | x1 | h1 h2 h3 | in_ref)
+constexpr int pFeat = 0, pX1 = 15, pH1 = 239, pH2 = 303, pH3 = 367, pInr = 431,
+              kActPlanes = 431 + kH * kRD;
+
+__device__ __forceinline__ float cwg_weight(const ApgMlpPolicy &p, int n, int row, int j,
+                                            int hi, int head_rows) {
+  const int old = n < wS ? m1cT + n : n < w2 ? m1sT + (n - wS) : n < w3 ? m2T + (n - w2)
+                  : n < wO ? m3T + (n - w3) : mOT + (n - wO);
+  return cbwd_weight(p, old, row, j, hi, head_rows);
+}
+
+__device__ __forceinline__ void pack_cwg(const PackArgs &A, int tid, int T) {
+  unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
+  for (int idx = tid; idx < wBlocks * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    const float w0 = cwg_weight(A.pol, n, l & 31, 2 * q, l >> 5, A.head_rows);
+    const float w1 = cwg_weight(A.pol, n, l & 31, 2 * q + 1, l >> 5, A.head_rows);
+    unsigned h, lo;
+    split_pair(w0, w1, h, lo);
+    dst[(n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
+  }
+}
+
+// forward tables at dst, the in-sweep reverse tables at dst + kCfLds
+__global__ __launch_bounds__(256) void mlp_pack_step_kernel(PackArgs A, int fwd_blocks) {
+  if ((int)blockIdx.x < fwd_blocks) {
+    pack_cfwd(A, blockIdx.x * blockDim.x + threadIdx.x, fwd_blocks * blockDim.x);
+  } else {
+    A.dst += kCfLds;
+    pack_cwg(A, (blockIdx.x - fwd_blocks) * blockDim.x + threadIdx.x,
+             (gridDim.x - fwd_blocks) * blockDim.x);
+  }
+}
+
+struct WgArgs {
+  const float *acts;     // [521][B]: feat 0..14 | x1 15..238 | h1 h2 h3 239..430 | in_ref 431..520
+  const unsigned *mask;  // [5][B]
+  const float *d_zout;   // [40][B] (the forward kernel's dL/d(head pre-activations))
+  float *part;           // [workgroups][kSlots][1024]
+  const float *tables;
+  int B;
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
+  return v;
+}
+
+// two cotangents of neighbouring rows -> their fp16 terms into the staging area
+// (`p` = this lane's slot of row_a; row_b = row_a + rstep rows further)
+__device__ __forceinline__ void stage_pair(char *p, int term_bytes, int rstep, float a, float b) {
+  unsigned h, l;
+  split_pair(a, b, h, l);
+  *reinterpret_cast<unsigned short *>(p) = (unsigned short)h;
+  *reinterpret_cast<unsigned short *>(p + rstep * kRS) = (unsigned short)(h >> 16);
+  *reinterpret_cast<unsigned short *>(p + term_bytes) = (unsigned short)l;
+  *reinterpret_cast<unsigned short *>(p + term_bytes + rstep * kRS) = (unsigned short)(l >> 16);
+}
+
+// a 64-row cotangent in accumulator layout (rows 32 rb + r(i) + 4 hi) x 2^-e
+__device__ __forceinline__ void stage64(char *lds, const f32x16 (&v)[2], int e, int wave,
+                                        int lane) {
+  char *p = lds + stage_base(64) + ((lane >> 5) * 4) * kRS + (wave * 32 + (lane & 31)) * 2;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2)
+      stage_pair(p + (32 * rb + rrow(i)) * kRS, 64 * kRS, 1,
+                 __builtin_amdgcn_ldexpf(v[rb][i], -e), __builtin_amdgcn_ldexpf(v[rb][i + 1], -e));
+}
+
+// workgroup exponent: every wave has left its |delta| maximum in the LDS tail
+__device__ __forceinline__ int wg_exponent(const char *lds) {
+  const float *m = reinterpret_cast<const float *>(lds + kStageEnd);
+  float a = m[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / 64; ++w) a = fmaxf(a, m[w]);
+  return a > 0.f ? __builtin_amdgcn_frexp_expf(a) : 0;
+}
+
+__device__ __forceinline__ void post_max(char *lds, float lane_max, int wave, int lane) {
+  const float a = wave_max(lane_max);
+  if (lane == 0) reinterpret_cast<float *>(lds + kStageEnd)[wave] = a;
+}
+
+// One 32 x 32 block of a layer's weight gradient over the workgroup's 256
+// trajectories: rows 32 mb .. of the staged cotangent (LDS) against the 32
+// planes from `plane0` of the activation buffer (x_rows of them are real; row
+// `ones_row` is a row of ones: the bias gradient rides along as a column).
+// ONES: no x at all, B operand = ones (bias of a layer whose x block is full).
+// The k-slot order is free as long as both operands agree: instruction kb of
+// trajectory group g (32 trajectories = one source wave) takes trajectories
+// 32 g + 16 hi + 8 kb + j, so a lane's x is 64 contiguous bytes of its plane.
+template <bool ONES>
+__device__ __forceinline__ f32x16 wgrad_block(const char *lds, int sbase, int rows_total,
+                                              int mb, int a_rows, const Planes &X, int plane0,
+                                              int x_rows, int ones_row, unsigned pN,
+                                              unsigned col0_bytes, int ncols, int lane) {
+  const int row = lane & 31, hi = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // (rows beyond the block's `a_rows` staged ones re-read row 0: their output
+  // rows are never used, but the reads must stay inside the staging area)
+  const char *pd = lds + sbase + (32 * mb + (row < a_rows ? row : 0)) * kRS + hi * 32;
+  const int term = rows_total * kRS;
+  const unsigned voff = row < x_rows ? (unsigned)row * pN + (unsigned)hi * 64u : kDead;
+  const unsigned soff = (unsigned)plane0 * pN + col0_bytes;
+  // x of trajectory group g: 64 contiguous bytes of this lane's plane; the
+  // loads of group g + 1 are in flight while group g multiplies (two register
+  // sets; sched_barriers keep the compiler from hoisting all eight groups)
+  auto load_x = [&](u32x4 (&q)[4], int g) {
+    if constexpr (!ONES) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        q[j] = __builtin_amdgcn_raw_buffer_load_b128(
+            X.rsrc, (int)voff, (int)(soff + g * 128 + j * 16), APG_PLANES_LD_AUX);
+    }
+  };
+  auto multiply = [&](const u32x4 (&q)[4], int g) {
+    Op16 xk[2];
+    if constexpr (ONES) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xk[kb].h[c] = 0x3c003c00u, xk[kb].l[c] = 0u;
+    } else {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * j + c] = __builtin_bit_cast(float, q[j][c]);
+      if (ncols < kTrajPerBlock) {   // ragged last workgroup: columns beyond B are
+#pragma unroll                      // somebody else's plane
+        for (int j = 0; j < 16; ++j)
+          if (32 * g + 16 * hi + j >= ncols) v[j] = 0.f;
+      }
+      if (row == ones_row) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = 32 * g + 16 * hi + j < ncols ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float w8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w8[j] = v[8 * kb + j];
+        xk[kb] = split8(w8);
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      Op16 dk;
+      dk.h = *reinterpret_cast<const u32x4 *>(pd + g * 64 + kb * 16);
+      dk.l = *reinterpret_cast<const u32x4 *>(pd + term + g * 64 + kb * 16);
+      acc = mma3(dk, xk[kb], acc);
+    }
+  };
+  u32x4 qa[4], qb[4];
+  load_x(qa, 0);
+#pragma unroll
+  for (int g = 0; g < kThreads / 64; g += 2) {
+    load_x(qb, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(qa, g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 2 < kThreads / 64) load_x(qa, g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(qb, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void store_block(float *slot, const f32x16 &acc, float back,
+                                            int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(acc[i] * back, slot + i * 64 + lane);
+}
+
+// bias gradient of a layer with a full x block: row sums of both row blocks
+__device__ __forceinline__ void bias_item(const char *lds, int sbase, int rows_total,
+                                          int n_mb, const Planes &X, float back,
+                                          float *bias_slot, int lane) {
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    if (mb >= n_mb) break;
+    const f32x16 acc = wgrad_block<true>(lds, sbase, rows_total, mb,
+                                         rows_total - 32 * mb < 32 ? rows_total - 32 * mb : 32,
+                                         X, 0, 0, -1, 0u, 0u, kTrajPerBlock, lane);
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        bias_slot[32 * mb + rrow(i) + 4 * (lane >> 5)] = acc[i] * back;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  char *lds = reinterpret_cast<char *>(lds_f);
+  fill_lds(lds_f, A.tables, kWgTabFloats);
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b0 = blockIdx.x * kTrajPerBlock;
+  const int b = b0 + wave * 32 + (lane & 31);
+  const int B = A.B;
+  const bool live = b < B;
+  const int ncols = B - b0 < kTrajPerBlock ? B - b0 : kTrajPerBlock;
+  const unsigned pN = (unsigned)B * 4u;
+  const Planes Pact(A.acts, kActPlanes, pN), Pmk(A.mask, 5, pN), Pdz(A.d_zout, kNA, pN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  const unsigned vr = live ? vb + (hi ? 4u * pN : 0u) : kDead;
+  const unsigned col0 = (unsigned)b0 * 4u;
+  float *part = A.part + (size_t)blockIdx.x * kSlots * 1024;
+  const LdsView16 L16(lds, lane);
+
+  float dzr[20];
+#pragma unroll
+  for (int cc = 0; cc < 20; ++cc) dzr[cc] = Pdz.ld(vr, khead(cc, 0) * pN);
+  unsigned mw[5];
+#pragma unroll
+  for (int eb = 0; eb < 5; ++eb) mw[eb] = Pmk.ldu(vb, eb * pN);
+  // ------------------------------------------------ head: delta = dL/dz (40 rows)
+  float amax = 0.f;
+#pragma unroll
+  for (int cc = 0; cc < 20; ++cc) amax = fmaxf(amax, fabsf(dzr[cc]));
+  post_max(lds, amax, wave, lane);
+  __syncthreads();
+  int ew = wg_exponent(lds);
+  {
+    char *p = lds + stage_base(40) + (hi * 4) * kRS + (wave * 32 + (lane & 31)) * 2;
+#pragma unroll
+    for (int cc = 0; cc < 20; cc += 2)
+      stage_pair(p + khead(cc, 0) * kRS, 40 * kRS, 1, __builtin_amdgcn_ldexpf(dzr[cc], -ew),
+                 __builtin_amdgcn_ldexpf(dzr[cc + 1], -ew));
+  }
+  __syncthreads();
+  f32x16 d[2], e[2];
+  int ex;
+  {  // weight gradient of the head: 2 x 2 blocks against h3, bias
+    const float back = __builtin_amdgcn_ldexpf(1.f, ew);
+    if (wave < 4) {
+      const int cb = wave >> 1, mb = wave & 1;
+      store_block(part + (sOut + cb * 2 + mb) * 1024,
+                  wgrad_block<false>(lds, stage_base(40), 40, mb, mb ? 8 : 32, Pact,
+                                     pH3 + 32 * cb, 32, -1, pN, col0, ncols, lane),
+                  back, lane);
+    } else if (wave == 4) {
+      bias_item(lds, stage_base(40), 40, 2, Pact, back, part + sBias * 1024 + 0, lane);
+    }
+  }
+  float hv[2][16];
+  auto load_hv = [&](int plane) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hv[rb][i] = Pact.ld(vr, (plane + rb * 32 + rrow(i)) * pN);
+  };
+  load_hv(pH3);
+  zero(d);
+  {  // dL/dh3 = W_out^T dL/dz (per-trajectory scale, as in the plane version)
+    ex = scale_exponent(amax);
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = kb * 8 + j < 20 ? __builtin_amdgcn_ldexpf(dzr[kb * 8 + j < 20 ? kb * 8 + j : 0], -ex)
+                               : 0.f;
+      const Op16 x = split8(v);
+      d[0] = mma3(L16.A(0, wO + kb), x, d[0]);
+      d[1] = mma3(L16.A(0, wO + 3 + kb), x, d[1]);
+    }
+  }
+  // (tanh' of h3; the planes of the cotangents are not written any more)
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      d[rb][i] = __builtin_amdgcn_ldexpf(d[rb][i], ex) * (1.f - hv[rb][i] * hv[rb][i]);
+
+  // one 64-row layer: stage `dl`, (barrier), multiply through W^T (blocks from
+  // `tab`) into `nx`, weight gradient against the planes from `xplane`
+  auto layer64 = [&](f32x16 (&dl)[2], f32x16 (&nx)[2], int tab, int xplane, int slot,
+                     int bias_id, int &exn) {
+    float am = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) am = fmaxf(am, fabsf(dl[rb][i]));
+    post_max(lds, am, wave, lane);
+    __syncthreads();   // maxima in; the previous layer's staged rows are done with
+    const int e_ = wg_exponent(lds);
+    stage64(lds, dl, e_, wave, lane);
+    __syncthreads();
+    const float back = __builtin_amdgcn_ldexpf(1.f, e_);
+    if (wave < 4) {
+      const int cb = wave >> 1, mb = wave & 1;
+      store_block(part + (slot + cb * 2 + mb) * 1024,
+                  wgrad_block<false>(lds, stage_base(64), 64, mb, 32, Pact, xplane + 32 * cb,
+                                     32, -1, pN, col0, ncols, lane),
+                  back, lane);
+    } else if (wave == 4) {
+      bias_item(lds, stage_base(64), 64, 2, Pact, back, part + sBias * 1024 + bias_id * 64,
+                lane);
+    }
+    load_hv(xplane);     // the activations of the layer below (tanh' after the product)
+    Op16 x[4];
+    zero(nx);
+    exn = scaled_split64(dl, x);
+    dense64T_16(nx, x, L16, 0, tab);
+  };
+  auto tanh_back = [&](f32x16 (&v)[2], int exv) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        v[rb][i] = __builtin_amdgcn_ldexpf(v[rb][i], exv) * (1.f - hv[rb][i] * hv[rb][i]);
+  };
+  // ---- fc3: delta = d_pre3 (d), x = h2
+  layer64(d, e, w3, pH2, sFc3, 1, ex);
+  tanh_back(e, ex);
+  // ---- fc2: delta = d_pre2 (e), x = h1
+  layer64(e, d, w2, pH1, sFc2, 2, ex);
+  tanh_back(d, ex);
+  // ---- fc1: delta = d_pre1 (d), x = [s1, relu(conv)] = the 224 x1 planes
+  Op16 x1s[4];   // d_pre1, scaled per trajectory and split: also the conv part below
+  int ex1;
+  {
+    float am = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) am = fmaxf(am, fabsf(d[rb][i]));
+    post_max(lds, am, wave, lane);
+    __syncthreads();
+    const int e_ = wg_exponent(lds);
+    stage64(lds, d, e_, wave, lane);
+    __syncthreads();
+    const float back = __builtin_amdgcn_ldexpf(1.f, e_);
+    // 7 x 2 blocks + the bias: 15 items over the 8 waves
+#pragma unroll 1
+    for (int it = wave; it < 15; it += kThreads / 64) {
+      if (it < 14) {
+        const int cb = it >> 1, mb = it & 1;
+        store_block(part + (sFc1 + it) * 1024,
+                    wgrad_block<false>(lds, stage_base(64), 64, mb, 32, Pact, pX1 + 32 * cb,
+                                       32, -1, pN, col0, ncols, lane),
+                    back, lane);
+      } else {
+        bias_item(lds, stage_base(64), 64, 2, Pact, back, part + sBias * 1024 + 3 * 64, lane);
+      }
+    }
+    load_hv(pX1);        // s1 = planes 15..78
+    zero(e);
+    ex1 = scaled_split64(d, x1s);
+    dense64T_16(e, x1s, L16, 0, wS);
+  }
+  tanh_back(e, ex1);   // d_pre_s
+  // ---- states_in: delta = d_pre_s (e), x = the 15 feature planes + ones (bias)
+  {
+    float am = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) am = fmaxf(am, fabsf(e[rb][i]));
+    post_max(lds, am, wave, lane);
+    __syncthreads();
+    const int e_ = wg_exponent(lds);
+    stage64(lds, e, e_, wave, lane);
+    __syncthreads();
+    if (wave < 2)
+      store_block(part + (sSin + wave) * 1024,
+                  wgrad_block<false>(lds, stage_base(64), 64, wave, 32, Pact, pFeat, kNF, kNF,
+                                     pN, col0, ncols, lane),
+                  __builtin_amdgcn_ldexpf(1.f, e_), lane);
+  }
+  // ---- conv: delta = relu'(.) W_1c^T d_pre1, 20 channels x 8 window positions;
+  // a lane holds positions ii + 4 hi of its channels, so the lower half-waves
+  // stage positions 0..3 and then the upper ones 4..7 (80 rows each); the
+  // window of position pos is the 27 in_ref planes from 9 pos, + ones (bias)
+  float dc[5][16];
+  {
+    float am = 0.f;
+#pragma unroll
+    for (int eb = 0; eb < 5; ++eb) {
+      f32x16 y;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y[i] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) y = mma3(L16.A(0, wC + eb * 4 + kb), x1s[kb], y);
+      const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        dc[eb][i] = ((mws >> rrow(i)) & 1u) ? __builtin_amdgcn_ldexpf(y[i], ex1) : 0.f;
+        am = fmaxf(am, fabsf(dc[eb][i]));
+      }
+    }
+    post_max(lds, am, wave, lane);
+  }
+  __syncthreads();
+  const int ec = wg_exponent(lds);
+  const float backc = __builtin_amdgcn_ldexpf(1.f, ec);
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (hi == half) {
+      char *p = lds + stage_base(80) + (wave * 32 + (lane & 31)) * 2;
+#pragma unroll
+      for (int eb = 0; eb < 5; ++eb)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2)   // row = 20 (position & 3) + channel
+          stage_pair(p + (20 * (i & 3) + eb * 4 + (i >> 2)) * kRS, 80 * kRS, 20,
+                     __builtin_amdgcn_ldexpf(dc[eb][i], -ec),
+                     __builtin_amdgcn_ldexpf(dc[eb][i + 1], -ec));
+    }
+    __syncthreads();
+    if (wave < 4) {
+      // rows 20 wave .. 20 wave + 19 of the staged half: not a multiple of 32,
+      // so the block is addressed from row 20 wave with mb = 0
+      const int pos = 4 * half + wave;
+      const f32x16 acc = wgrad_block<false>(lds, stage_base(80) + 20 * wave * kRS, 80, 0, kNC,
+                                            Pact, pInr + kRD * pos, 27, 27, pN, col0, ncols,
+                                            lane);
+      store_block(part + (sConv + pos) * 1024, acc, backc, lane);
+    }
+    __syncthreads();
+  }
+}
+
+// Second stage: the workgroups' partial blocks summed in a fixed order
+// (deterministic), scattered into the parameter gradients; block 0 also sums
+// the loss partials of the forward kernel.
+struct WgReduceArgs {
+  const float *part;
+  ApgMlpPolicyGrads g;
+  const float *loss_partials;
+  float *loss;
+  int wgs, n_partials;
+};
+
+// destination of element (slot, reg i, lane) - or NULL (padding)
+__device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, int i, int lane) {
+  const int rowb = rrow(i) + 4 * (lane >> 5), col = lane & 31;
+  if (slot < sFc1) {                       // head, fc3, fc2: [cb][mb]
+    const int q = slot & 3, cb = q >> 1, m = 32 * (q & 1) + rowb, k = 32 * cb + col;
+    if (slot < sFc3) return m < kNA ? g.w_out + m * kW + k : nullptr;
+    return (slot < sFc2 ? g.w_3 : g.w_2) + m * kW + k;
+  }
+  if (slot < sSin) {                       // fc1: 7 column blocks x 2 row blocks
+    const int it = slot - sFc1, cb = it >> 1, m = 32 * (it & 1) + rowb;
+    return g.w_1 + m * kN1 + 32 * cb + col;
+  }
+  if (slot < sConv) {                      // states_in: 15 columns + the bias column
+    const int m = 32 * (slot - sSin) + rowb;
+    return col < kNF ? g.w_s + m * kNF + col : col == kNF ? g.b_s + m : nullptr;
+  }
+  if (slot < sBias) {                      // conv, position slot - sConv: only slot
+    if (slot != sConv || rowb >= kNC) return nullptr;   // sConv collects all eight
+    if (col < 27) return g.conv_w + rowb * 27 + (col % kRD) * 3 + col / kRD;
+    return col == 27 ? g.conv_b + rowb : nullptr;
+  }
+  const int e = i * 64 + lane;             // bias slot: [layer][64]
+  if (e >= 4 * 64) return nullptr;
+  const int layer = e >> 6, m = e & 63;
+  return layer == 0 ? (m < kNA ? g.b_out + m : nullptr)
+         : layer == 1 ? g.b_3 + m : layer == 2 ? g.b_2 + m : g.b_1 + m;
+}
+
+__global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
+  const int t = blockIdx.x * 256 + threadIdx.x;   // (slot, reg, lane)
+  if (t < kSlots * 1024) {
+    const int slot = t >> 10, i = (t >> 6) & 15, lane = t & 63;
+    float *dst = wg_dest(A.g, slot, i, lane);
+    if (dst) {
+      const int n_src = slot == sConv ? kNP : 1;   // the eight position blocks
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int q = 0; q < n_src; ++q) {
+        const float *p = A.part + (size_t)(slot + q) * 1024 + (t & 1023);
+        const size_t stride = (size_t)kSlots * 1024;
+        int w = 0;
+        for (; w + 4 <= A.wgs; w += 4) {
+          s0 += p[(size_t)w * stride];
+          s1 += p[(size_t)(w + 1) * stride];
+          s2 += p[(size_t)(w + 2) * stride];
+          s3 += p[(size_t)(w + 3) * stride];
+        }
+        for (; w < A.wgs; ++w) s0 += p[(size_t)w * stride];
+      }
+      *dst = (s0 + s1) + (s2 + s3);
+    }
+  }
+  if (blockIdx.x == 0 && A.loss) {   // fixed-shape sum of the loss partials
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < A.n_partials; k += 256) acc += (double)A.loss_partials[k];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *A.loss = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+  }
+}
+
 int check_mlp(const ApgQuadParams *params, const ApgMlpPolicy *pol, int B, int H) {
   if (!params || !pol) { set_error("params / policy is NULL"); return APG_ERR_ARG; }
   if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
@@ -1452,6 +2004,93 @@ int apg_quad_mlp_concurrent_fwd_bwd(
   if (loss)
     return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave), loss, st);
   return APG_OK;
+}
+
+
+int apg_quad_mlp_step_workspace_floats(void) { return kCfLds + kWgTabFloats; }
+
+long long apg_quad_mlp_step_partials_floats(int B) {
+  return B <= 0 ? 0 : (long long)((B + kTrajPerBlock - 1) / kTrajPerBlock) * kSlots * 1024;
+}
+
+int apg_quad_mlp_concurrent_step(
+    const float *state0, const float *ref, int ref_cols, float dt,
+    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+    const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
+    float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
+    float *states, float *workspace, float *partials, apg_stream_t stream) {
+  if (int e = check_mlp(params, policy, B, H)) return e;
+  if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
+  if (ref_cols != 9 && ref_cols != 6) {
+    set_error("ref_cols must be 9 or 6");
+    return APG_ERR_ARG;
+  }
+  if (!grads || !grads->w_s || !grads->b_s || !grads->conv_w || !grads->conv_b ||
+      !grads->w_1 || !grads->b_1 || !grads->w_2 || !grads->b_2 || !grads->w_3 ||
+      !grads->b_3 || !grads->w_out || !grads->b_out) {
+    set_error("gradient pointer is NULL");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    // no trajectory: zero gradients, zero loss
+    const ApgMlpPolicyGrads &g = *grads;
+    float *ptrs[12] = {g.w_s, g.b_s, g.conv_w, g.conv_b, g.w_1, g.b_1,
+                       g.w_2, g.b_2, g.w_3, g.b_3, g.w_out, g.b_out};
+    const size_t n[12] = {kW * kNF, kW, kNC * 27, kNC, kW * kN1, kW,
+                          kW * kW, kW, kW * kW, kW, kNA * kW, kNA};
+    for (int i = 0; i < 12; ++i)
+      if (hipMemsetAsync(ptrs[i], 0, n[i] * sizeof(float), st) != hipSuccess)
+        return check_launch("memset(grads)");
+    if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
+      return check_launch("memset(loss)");
+    return APG_OK;
+  }
+  if (!state0 || !ref || !acts || !relu_mask || !d_zout || !loss_partials || !workspace ||
+      !partials) {
+    set_error("NULL buffer");
+    return APG_ERR_ARG;
+  }
+  if ((long long)B * 4 * kActPlanes >= (1ll << 32) - 64) {
+    set_error("B too large for 32-bit plane offsets; split the batch");
+    return APG_ERR_ARG;
+  }
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
+    if (int e = raise_lds(mlp_concurrent_fwd_kernel, kCfLds)) return e;
+    if (int e = raise_lds(mlp_concurrent_bwd_wg_kernel, kLdsAll / 4)) return e;
+    attr.set();
+  }
+  const size_t plane = (size_t)B;
+  ConcArgs A;
+  A.feat = acts + pFeat * plane, A.in_ref = acts + pInr * plane;
+  A.state0 = state0, A.ref = ref;
+  A.x1 = acts + pX1 * plane, A.h = acts + pH1 * plane, A.mask = relu_mask;
+  A.d_zout = d_zout, A.d_pre = nullptr, A.d_conv = nullptr;
+  A.states = states, A.loss_partials = loss_partials;
+  A.tables = workspace;
+  A.c = make_const(*params, dt);
+  A.w = *weights;
+  A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
+  PackArgs P;
+  P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
+  const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
+  const int fwd_blocks = (kCfLds + 255) / 256, bwd_blocks = (kWgTabFloats + 255) / 256;
+  hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks), dim3(256), 0, st,
+                     P, fwd_blocks);
+  hipLaunchKernelGGL(mlp_concurrent_fwd_kernel, dim3(blocks), dim3(kThreads),
+                     kCfLds * sizeof(float), st, A);
+  WgArgs W;
+  W.acts = acts, W.mask = relu_mask, W.d_zout = d_zout, W.part = partials;
+  W.tables = workspace + kCfLds, W.B = B;
+  hipLaunchKernelGGL(mlp_concurrent_bwd_wg_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st,
+                     W);
+  WgReduceArgs R;
+  R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
+  R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((kSlots * 1024 + 255) / 256), dim3(256), 0,
+                     st, R);
+  return check_launch("quad_mlp_concurrent_step");
 }
 
 }  // extern "C"

@@ -1573,10 +1573,35 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         require_device(acts, s0, rf, *pw.values())
         pol = _capi.ApgMlpPolicy(**{k: ptr(v) for k, v in pw.items()})
         relu_mask = torch.empty(5, B, dtype=torch.int32, device=dev)
-        cot = new(40 + 256 + 160, B)      # d_zout | d_pre | d_conv
-        d_zout, d_pre, d_conv = cot[:40], cot[40:296], cot[296:]
         partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
         loss = new(1)
+        ctx.dims = (B, H)
+        if CONCURRENT_IN_SWEEP:
+            # round 4: the weight gradients are accumulated inside the reverse
+            # pass (apg_quad_mlp_concurrent_step) - no cotangent planes, no
+            # second pass of products; every gradient is a view of `flat`
+            flat, gr = _flat_grads(dev, {
+                "states_in.weight": (64, 15), "states_in.bias": (64,),
+                "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,),
+                "fc1.weight": (64, 224), "fc1.bias": (64,), "fc2.weight": (64, 64),
+                "fc2.bias": (64,), "fc3.weight": (64, 64), "fc3.bias": (64,),
+                "fc_out.weight": (40, 64), "fc_out.bias": (40,)})
+            gs = _capi.ApgMlpPolicyGrads(**{
+                k: ptr(gr[n]) for k, n in zip(names, _MLP_PARAMS)})
+            d_zout = new(40, B)
+            ws = new(lib().apg_quad_mlp_step_workspace_floats())
+            part = new(max(1, lib().apg_quad_mlp_step_partials_floats(B)))
+            check(lib().apg_quad_mlp_concurrent_step(
+                ptr(s0), ptr(rf), rf.shape[1], float(dt), ctypes.byref(params),
+                ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(acts),
+                relu_mask.data_ptr(), ptr(d_zout), ptr(partials), ptr(loss),
+                ctypes.byref(gs), None, ptr(ws), ptr(part), stream_of(s0)),
+                "apg_quad_mlp_concurrent_step")
+            ctx.flat_grads = (flat, gr)
+            ctx.save_for_backward(acts)
+            return loss.reshape(())
+        cot = new(40 + 256 + 160, B)      # d_zout | d_pre | d_conv
+        d_zout, d_pre, d_conv = cot[:40], cot[40:296], cot[296:]
         ws = new(lib().apg_quad_mlp_concurrent_workspace_floats())
         check(lib().apg_quad_mlp_concurrent_fwd_bwd(
             ptr(feat), ptr(inr), ptr(s0), ptr(rf), rf.shape[1], float(dt),
@@ -1584,15 +1609,25 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
             ptr(x1), ptr(h), relu_mask.data_ptr(), ptr(d_zout), ptr(d_pre),
             ptr(d_conv), ptr(partials), ptr(loss), None, ptr(ws),
             stream_of(s0)), "apg_quad_mlp_concurrent_fwd_bwd")
+        ctx.flat_grads = None
         ctx.save_for_backward(acts, cot)
-        ctx.dims = (B, H)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        flat, gr = _conc_param_grads(ctx.saved_tensors, ctx.dims)
-        flat *= g
+        flat, gr = ctx.flat_grads or _conc_param_grads(ctx.saved_tensors, ctx.dims)
+        if ctx.flat_grads is not None:
+            gr = {k: v * g for k, v in gr.items()}
+        else:
+            flat *= g
         return (None, None, None, None, *[gr[k] for k in _MLP_PARAMS], None, None, None)
+
+
+# True: the concurrent step accumulates its weight gradients inside the reverse
+# kernel (csrc/mlp.hip, mlp_concurrent_bwd_wg_kernel); False: cotangent planes +
+# planes_gemm products (rounds 1-3; kept for comparison and as the planes API's
+# user)
+CONCURRENT_IN_SWEEP = True
 
 
 def _conc_param_grads(saved, dims):
@@ -1670,7 +1705,7 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
         loss = _QuadConcurrentPolicyLoss.forward(
             ctx, normed, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt,
             params, weights or quad_loss_weights(), index)
-        flat, gr = _conc_param_grads(ctx.saved_tensors, ctx.dims)
+        flat, gr = ctx.flat_grads or _conc_param_grads(ctx.saved_tensors, ctx.dims)
     return loss, gr, flat
 
 

@@ -364,6 +364,38 @@ int apg_quad_mlp_concurrent_fwd_bwd(
     float *d_conv, float *loss_partials, float *loss, float *states,
     float *workspace, apg_stream_t stream);
 
+/* Round 4: the same step with the weight gradients accumulated INSIDE the
+ * reverse pass (no cotangent planes, no second pass of products): pack, forward
+ * + rollout + adjoint, reverse pass with the products of every layer on the
+ * matrix cores (cotangents transposed through LDS, activations read from the
+ * forward kernel's planes), one fixed-order second stage that also sums the
+ * loss.  One loss.backward() of the reference produces every parameter
+ * gradient (scripts/train_drone.py:175-203); so does this call.
+ *   acts [521][B]: planes 0..14 = feat (in), 431..520 = in_ref [H][9] (in), the
+ *     224 + 192 planes between them are written (x1, h1, h2, h3);
+ *   state0 [12][B], ref [H][ref_cols][B] (in); relu_mask [5][B], d_zout [40][B]
+ *     (scratch); loss_partials (apg_quad_mlp_loss_partials_count(B)), loss [1]
+ *     or NULL, states [H][12][B] or NULL;
+ *   grads: where each parameter's gradient goes (12 device pointers, shapes of
+ *     the policy's tensors; typically views of one flat buffer);
+ *   workspace: apg_quad_mlp_step_workspace_floats() floats,
+ *   partials:  apg_quad_mlp_step_partials_floats(B) floats. */
+typedef struct ApgMlpPolicyGrads {
+  float *w_s, *b_s;        /* [64][15], [64]  */
+  float *conv_w, *conv_b;  /* [20][9][3], [20] */
+  float *w_1, *b_1;        /* [64][224], [64] */
+  float *w_2, *b_2, *w_3, *b_3; /* [64][64], [64] */
+  float *w_out, *b_out;    /* [40][64], [40]  */
+} ApgMlpPolicyGrads;
+int apg_quad_mlp_step_workspace_floats(void);
+long long apg_quad_mlp_step_partials_floats(int B);
+int apg_quad_mlp_concurrent_step(
+    const float *state0, const float *ref, int ref_cols, float dt,
+    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+    const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
+    float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
+    float *states, float *workspace, float *partials, apg_stream_t stream);
+
 /* Batched closed-loop evaluation: the loop of
  * QuadEvaluator.follow_trajectory("rand") (scripts/evaluate_drone.py:81-194)
  * for B reference trajectories in one launch - per step the H-row reference
