@@ -1245,6 +1245,13 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A
 // halves of four window positions).  HBM per 65 536 trajectories: reads 67 MB
 // (tanh') + 136 MB (x for the products) + masks, writes 38 MB of partials
 // instead of 119 MB of cotangent planes + 232 MB of product reads.
+#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_WG_KNOCKOUT)
+#error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
+#endif
+#ifndef APG_WG_KNOCKOUT
+#define APG_WG_KNOCKOUT 0   // timing experiments: 1 no products, 2 no staging, 4 no partial
+                            // stores, 8 no x loads, 16 no matrix instructions, 32 no x split
+#endif
 constexpr int wC = 0, wS = 20, w2 = 28, w3 = 36, wO = 44, wBlocks = 50;
 constexpr int kWgTabBytes = wBlocks * kBlock16;   // 102 400
 constexpr int kWgTabFloats = kWgTabBytes / 4;
@@ -1259,6 +1266,10 @@ static_assert(stage_base(80) >= wS * kBlock16, "conv staging must not touch the 
 // partial slots of a workgroup (1024 floats each, accumulator order [reg][lane])
 constexpr int sOut = 0, sFc3 = 4, sFc2 = 8, sFc1 = 12, sSin = 26, sConv = 28, sBias = 36,
               kSlots = 37;
+// second stage: workgroups per first-level chunk, element columns of 256
+constexpr int kRedChunk = 32;
+constexpr int kRedColumns = (kSlots * 1024 + 255) / 256;
+
 // first planes of the x blocks in the activation buffer (feat | x1 | h1 h2 h3 | in_ref)
 constexpr int pFeat = 0, pX1 = 15, pH1 = 239, pH2 = 303, pH3 = 367, pInr = 431,
               kActPlanes = 431 + kH * kRD;
@@ -1312,6 +1323,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // two cotangents of neighbouring rows -> their fp16 terms into the staging area
 // (`p` = this lane's slot of row_a; row_b = row_a + rstep rows further)
 __device__ __forceinline__ void stage_pair(char *p, int term_bytes, int rstep, float a, float b) {
+  if (APG_WG_KNOCKOUT & 2) return;
   unsigned h, l;
   split_pair(a, b, h, l);
   *reinterpret_cast<unsigned short *>(p) = (unsigned short)h;
@@ -1354,88 +1366,159 @@ __device__ __forceinline__ void post_max(char *lds, float lane_max, int wave, in
 // The k-slot order is free as long as both operands agree: instruction kb of
 // trajectory group g (32 trajectories = one source wave) takes trajectories
 // 32 g + 16 hi + 8 kb + j, so a lane's x is 64 contiguous bytes of its plane.
-template <bool ONES>
-__device__ __forceinline__ f32x16 wgrad_block(const char *lds, int sbase, int rows_total,
-                                              int mb, int a_rows, const Planes &X, int plane0,
-                                              int x_rows, int ones_row, unsigned pN,
-                                              unsigned col0_bytes, int ncols, int lane) {
-  const int row = lane & 31, hi = lane >> 5;
-  f32x16 acc;
+// The x operand of a block product, four trajectory groups deep: `begin` issues
+// the loads of groups 0..3 - BEFORE the layer's cotangents are staged and the
+// barrier is passed (x does not depend on them), so their latency (~2 us under
+// load; two groups in flight left every product latency-bound: 5.5 us per
+// block) is hidden behind the staging - and every `take` re-issues four groups
+// ahead.
+constexpr int kXDepth = 4;
+struct XPipe {
+  u32x4 q[kXDepth][4];
+  unsigned voff, soff;
+  __device__ __forceinline__ void load(const Planes &X, int set, int g) {
+    if (APG_WG_KNOCKOUT & 8) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  // (rows beyond the block's `a_rows` staged ones re-read row 0: their output
-  // rows are never used, but the reads must stay inside the staging area)
-  const char *pd = lds + sbase + (32 * mb + (row < a_rows ? row : 0)) * kRS + hi * 32;
-  const int term = rows_total * kRS;
-  const unsigned voff = row < x_rows ? (unsigned)row * pN + (unsigned)hi * 64u : kDead;
-  const unsigned soff = (unsigned)plane0 * pN + col0_bytes;
-  // x of trajectory group g: 64 contiguous bytes of this lane's plane; the
-  // loads of group g + 1 are in flight while group g multiplies (two register
-  // sets; sched_barriers keep the compiler from hoisting all eight groups)
-  auto load_x = [&](u32x4 (&q)[4], int g) {
-    if constexpr (!ONES) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        q[j] = __builtin_amdgcn_raw_buffer_load_b128(
-            X.rsrc, (int)voff, (int)(soff + g * 128 + j * 16), APG_PLANES_LD_AUX);
+      for (int j = 0; j < 4; ++j) q[set][j] = u32x4{voff, soff, (unsigned)g, 1u};
+      return;
     }
-  };
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      q[set][j] = __builtin_amdgcn_raw_buffer_load_b128(
+          X.rsrc, (int)voff, (int)(soff + g * 128 + j * 16), APG_PLANES_LD_AUX);
+  }
+  __device__ __forceinline__ void begin(const Planes &X, int plane0, int x_rows, unsigned pN,
+                                        unsigned col0_bytes, int lane) {
+    const int row = lane & 31, hi = lane >> 5;
+    voff = row < x_rows ? (unsigned)row * pN + (unsigned)hi * 64u : kDead;
+    soff = (unsigned)plane0 * pN + col0_bytes;
+    if (APG_WG_KNOCKOUT & 1) return;
+#pragma unroll
+    for (int g = 0; g < kXDepth; ++g) load(X, g, g);
+  }
+};
+
+// One 32 x 32 block of a layer's weight gradient over the workgroup's 256
+// trajectories: rows 32 mb .. of the staged cotangent (LDS) against the 32
+// planes `xp` was begun on (x_rows of them real; row `ones_row` is a row of
+// ones: the bias gradient rides along as a column).  The k-slot order is free
+// as long as both operands agree: instruction kb of trajectory group g (32
+// trajectories = one source wave) takes trajectories 32 g + 16 hi + 8 kb + j,
+// so a lane's x is 64 contiguous bytes of its plane.
+template <int NMB>
+__device__ __forceinline__ void wgrad_block(f32x16 (&acc)[NMB], const char *lds, int sbase,
+                                            int rows_total, int mb0, int a_rows1,
+                                            const Planes &X, XPipe &xp, int ones_row, int ncols,
+                                            int lane) {
+  const int row = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < NMB; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+  if (APG_WG_KNOCKOUT & 1) return;
+  // NMB row blocks mb0, mb0 + 1 share the x operand: x is loaded and split once
+  // (the loads are what this product is paced by: a lane's 64 bytes are one of
+  // 32 different planes per instruction).  Rows beyond the LAST block's
+  // `a_rows1` staged ones re-read row 0: their output rows are never used, but
+  // the reads must stay inside the staging area.
+  const char *pd[NMB];
+#pragma unroll
+  for (int m = 0; m < NMB; ++m) {
+    const int r = (m == NMB - 1 && row >= a_rows1) ? 0 : row;
+    pd[m] = lds + sbase + (32 * (mb0 + m) + r) * kRS + hi * 32;
+  }
+  const int term = rows_total * kRS;
   auto multiply = [&](const u32x4 (&q)[4], int g) {
     Op16 xk[2];
-    if constexpr (ONES) {
+    float v[16];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+    for (int j = 0; j < 4; ++j) {
+      // (the whole vector is cast: bit_cast of an ext-vector ELEMENT reads
+      // element 0 whatever the index, clang 19 / ROCm 7.2)
+      typedef float f32x4_ __attribute__((ext_vector_type(4)));
+      const f32x4_ f = __builtin_bit_cast(f32x4_, q[j]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xk[kb].h[c] = 0x3c003c00u, xk[kb].l[c] = 0u;
-    } else {
-      float v[16];
+      for (int c = 0; c < 4; ++c) v[4 * j + c] = f[c];
+    }
+    if (ncols < kTrajPerBlock) {   // ragged last workgroup: columns beyond B are
+#pragma unroll                    // somebody else's plane
+      for (int j = 0; j < 16; ++j)
+        if (32 * g + 16 * hi + j >= ncols) v[j] = 0.f;
+    }
+    if (ones_row >= 0) {   // (wave-uniform: only the feature / window blocks)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 16; ++j)
+        v[j] = row == ones_row ? (32 * g + 16 * hi + j < ncols ? 1.f : 0.f) : v[j];
+    }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[4 * j + c] = __builtin_bit_cast(float, q[j][c]);
-      if (ncols < kTrajPerBlock) {   // ragged last workgroup: columns beyond B are
-#pragma unroll                      // somebody else's plane
-        for (int j = 0; j < 16; ++j)
-          if (32 * g + 16 * hi + j >= ncols) v[j] = 0.f;
-      }
-      if (row == ones_row) {
+    for (int kb = 0; kb < 2; ++kb) {
+      float w8[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = 32 * g + 16 * hi + j < ncols ? 1.f : 0.f;
-      }
+      for (int j = 0; j < 8; ++j) w8[j] = v[8 * kb + j];
+      if (APG_WG_KNOCKOUT & 32) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        float w8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w8[j] = v[8 * kb + j];
+        for (int c = 0; c < 4; ++c)
+          xk[kb].h[c] = __builtin_bit_cast(unsigned, w8[2 * c]),
+          xk[kb].l[c] = __builtin_bit_cast(unsigned, w8[2 * c + 1]);
+      } else {
         xk[kb] = split8(w8);
       }
     }
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      Op16 dk;
-      dk.h = *reinterpret_cast<const u32x4 *>(pd + g * 64 + kb * 16);
-      dk.l = *reinterpret_cast<const u32x4 *>(pd + term + g * 64 + kb * 16);
-      acc = mma3(dk, xk[kb], acc);
-    }
-  };
-  u32x4 qa[4], qb[4];
-  load_x(qa, 0);
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-  for (int g = 0; g < kThreads / 64; g += 2) {
-    load_x(qb, g + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(qa, g);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 2 < kThreads / 64) load_x(qa, g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(qb, g + 1);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < NMB; ++m) {
+        Op16 dk;
+        dk.h = *reinterpret_cast<const u32x4 *>(pd[m] + g * 64 + kb * 16);
+        dk.l = *reinterpret_cast<const u32x4 *>(pd[m] + term + g * 64 + kb * 16);
+        if (APG_WG_KNOCKOUT & 16) {   // keep every operand alive, no matrix work
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[m][c] += __builtin_bit_cast(float, dk.h[c] ^ xk[kb].h[c]) +
+                         __builtin_bit_cast(float, dk.l[c] ^ xk[kb].l[c]);
+        } else {
+          acc[m] = mma3(dk, xk[kb], acc[m]);
+        }
+      }
+  };
+  // (rolled over the two halves: the product is instantiated a dozen times)
+#pragma unroll 1
+  for (int g0 = 0; g0 < kThreads / 64; g0 += kXDepth) {
+#pragma unroll
+    for (int k = 0; k < kXDepth; ++k) {
+      multiply(xp.q[k], g0 + k);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g0 == 0) xp.load(X, k, kXDepth + k);   // groups 4..7, four ahead
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+}
+
+// the same against a B operand of ones: the row sums (bias of a layer whose x
+// block is full), no loads
+__device__ __forceinline__ f32x16 wgrad_ones(const char *lds, int sbase, int rows_total,
+                                             int mb, int a_rows, int lane) {
+  const int row = lane & 31, hi = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (APG_WG_KNOCKOUT & 1) return acc;
+  const char *pd = lds + sbase + (32 * mb + (row < a_rows ? row : 0)) * kRS + hi * 32;
+  const int term = rows_total * kRS;
+  const u32x4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#pragma unroll 1
+  for (int g = 0; g < kThreads / 64; ++g)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      acc = mfma16(*reinterpret_cast<const u32x4 *>(pd + term + g * 64 + kb * 16), ones, acc);
+      acc = mfma16(*reinterpret_cast<const u32x4 *>(pd + g * 64 + kb * 16), ones, acc);
+    }
   return acc;
 }
 
 __device__ __forceinline__ void store_block(float *slot, const f32x16 &acc, float back,
                                             int lane) {
+  if (APG_WG_KNOCKOUT & 4) return;
 #pragma unroll
   for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(acc[i] * back, slot + i * 64 + lane);
 }
@@ -1447,9 +1530,8 @@ __device__ __forceinline__ void bias_item(const char *lds, int sbase, int rows_t
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     if (mb >= n_mb) break;
-    const f32x16 acc = wgrad_block<true>(lds, sbase, rows_total, mb,
-                                         rows_total - 32 * mb < 32 ? rows_total - 32 * mb : 32,
-                                         X, 0, 0, -1, 0u, 0u, kTrajPerBlock, lane);
+    const f32x16 acc = wgrad_ones(
+        lds, sbase, rows_total, mb, rows_total - 32 * mb < 32 ? rows_total - 32 * mb : 32, lane);
     if ((lane & 31) == 0) {
 #pragma unroll
       for (int i = 0; i < 16; ++i)
@@ -1461,7 +1543,6 @@ __device__ __forceinline__ void bias_item(const char *lds, int sbase, int rows_t
 __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   char *lds = reinterpret_cast<char *>(lds_f);
-  fill_lds(lds_f, A.tables, kWgTabFloats);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b0 = blockIdx.x * kTrajPerBlock;
@@ -1475,21 +1556,31 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
   const unsigned vr = live ? vb + (hi ? 4u * pN : 0u) : kDead;
   const unsigned col0 = (unsigned)b0 * 4u;
   float *part = A.part + (size_t)blockIdx.x * kSlots * 1024;
-  const LdsView16 L16(lds, lane);
 
+  // this wave's own inputs first (they return while the tables stream in)
   float dzr[20];
 #pragma unroll
   for (int cc = 0; cc < 20; ++cc) dzr[cc] = Pdz.ld(vr, khead(cc, 0) * pN);
   unsigned mw[5];
 #pragma unroll
   for (int eb = 0; eb < 5; ++eb) mw[eb] = Pmk.ldu(vb, eb * pN);
+  // Work items of a layer = its 32-plane COLUMN blocks, both row blocks at once
+  // (they share x: it is loaded and split once): waves 0 and 1 own the two
+  // column blocks of the 64 x 64 layers (and of the head), wave 2 their bias;
+  // fc1 has seven column blocks (waves 0..6) + its bias (wave 7).  The x of an
+  // item is requested before the layer's cotangents are staged (XPipe).
+  XPipe xp;
+  if (wave < 2) xp.begin(Pact, pH3 + 32 * wave, 32, pN, col0, lane);
+  fill_lds(lds_f, A.tables, kWgTabFloats);
+  const LdsView16 L16(lds, lane);
+
   // ------------------------------------------------ head: delta = dL/dz (40 rows)
   float amax = 0.f;
 #pragma unroll
   for (int cc = 0; cc < 20; ++cc) amax = fmaxf(amax, fabsf(dzr[cc]));
   post_max(lds, amax, wave, lane);
   __syncthreads();
-  int ew = wg_exponent(lds);
+  const int ew = wg_exponent(lds);
   {
     char *p = lds + stage_base(40) + (hi * 4) * kRS + (wave * 32 + (lane & 31)) * 2;
 #pragma unroll
@@ -1500,18 +1591,8 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
   __syncthreads();
   f32x16 d[2], e[2];
   int ex;
-  {  // weight gradient of the head: 2 x 2 blocks against h3, bias
-    const float back = __builtin_amdgcn_ldexpf(1.f, ew);
-    if (wave < 4) {
-      const int cb = wave >> 1, mb = wave & 1;
-      store_block(part + (sOut + cb * 2 + mb) * 1024,
-                  wgrad_block<false>(lds, stage_base(40), 40, mb, mb ? 8 : 32, Pact,
-                                     pH3 + 32 * cb, 32, -1, pN, col0, ncols, lane),
-                  back, lane);
-    } else if (wave == 4) {
-      bias_item(lds, stage_base(40), 40, 2, Pact, back, part + sBias * 1024 + 0, lane);
-    }
-  }
+  // the saved activations a layer's tanh' needs are requested BEFORE the
+  // layer's weight-gradient items: they land while the items multiply
   float hv[2][16];
   auto load_hv = [&](int plane) {
 #pragma unroll
@@ -1520,6 +1601,18 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
       for (int i = 0; i < 16; ++i) hv[rb][i] = Pact.ld(vr, (plane + rb * 32 + rrow(i)) * pN);
   };
   load_hv(pH3);
+  {  // weight gradient of the head: 2 x 2 blocks against h3, bias
+    const float back = __builtin_amdgcn_ldexpf(1.f, ew);
+    if (wave < 2) {
+      f32x16 acc[2];
+      wgrad_block<2>(acc, lds, stage_base(40), 40, 0, 8, Pact, xp, -1, ncols, lane);
+      xp.begin(Pact, pH2 + 32 * wave, 32, pN, col0, lane);   // fc3's x, a layer ahead
+      store_block(part + (sOut + wave * 2 + 0) * 1024, acc[0], back, lane);
+      store_block(part + (sOut + wave * 2 + 1) * 1024, acc[1], back, lane);
+    } else if (wave == 2) {
+      bias_item(lds, stage_base(40), 40, 2, Pact, back, part + sBias * 1024 + 0, lane);
+    }
+  }
   zero(d);
   {  // dL/dh3 = W_out^T dL/dz (per-trajectory scale, as in the plane version)
     ex = scale_exponent(amax);
@@ -1535,44 +1628,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
       d[1] = mma3(L16.A(0, wO + 3 + kb), x, d[1]);
     }
   }
-  // (tanh' of h3; the planes of the cotangents are not written any more)
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      d[rb][i] = __builtin_amdgcn_ldexpf(d[rb][i], ex) * (1.f - hv[rb][i] * hv[rb][i]);
-
-  // one 64-row layer: stage `dl`, (barrier), multiply through W^T (blocks from
-  // `tab`) into `nx`, weight gradient against the planes from `xplane`
-  auto layer64 = [&](f32x16 (&dl)[2], f32x16 (&nx)[2], int tab, int xplane, int slot,
-                     int bias_id, int &exn) {
-    float am = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) am = fmaxf(am, fabsf(dl[rb][i]));
-    post_max(lds, am, wave, lane);
-    __syncthreads();   // maxima in; the previous layer's staged rows are done with
-    const int e_ = wg_exponent(lds);
-    stage64(lds, dl, e_, wave, lane);
-    __syncthreads();
-    const float back = __builtin_amdgcn_ldexpf(1.f, e_);
-    if (wave < 4) {
-      const int cb = wave >> 1, mb = wave & 1;
-      store_block(part + (slot + cb * 2 + mb) * 1024,
-                  wgrad_block<false>(lds, stage_base(64), 64, mb, 32, Pact, xplane + 32 * cb,
-                                     32, -1, pN, col0, ncols, lane),
-                  back, lane);
-    } else if (wave == 4) {
-      bias_item(lds, stage_base(64), 64, 2, Pact, back, part + sBias * 1024 + bias_id * 64,
-                lane);
-    }
-    load_hv(xplane);     // the activations of the layer below (tanh' after the product)
-    Op16 x[4];
-    zero(nx);
-    exn = scaled_split64(dl, x);
-    dense64T_16(nx, x, L16, 0, tab);
-  };
   auto tanh_back = [&](f32x16 (&v)[2], int exv) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -1580,41 +1635,69 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
       for (int i = 0; i < 16; ++i)
         v[rb][i] = __builtin_amdgcn_ldexpf(v[rb][i], exv) * (1.f - hv[rb][i] * hv[rb][i]);
   };
-  // ---- fc3: delta = d_pre3 (d), x = h2
-  layer64(d, e, w3, pH2, sFc3, 1, ex);
-  tanh_back(e, ex);
-  // ---- fc2: delta = d_pre2 (e), x = h1
-  layer64(e, d, w2, pH1, sFc2, 2, ex);
-  tanh_back(d, ex);
-  // ---- fc1: delta = d_pre1 (d), x = [s1, relu(conv)] = the 224 x1 planes
-  Op16 x1s[4];   // d_pre1, scaled per trajectory and split: also the conv part below
-  int ex1;
-  {
+  tanh_back(d, ex);   // d_pre3 (the cotangent planes are not written any more)
+
+  // stage a 64-row cotangent with the workgroup's exponent (two barriers: the
+  // maxima are in and the previous layer's staged rows are done with; then the
+  // staged rows are visible); returns 2^e
+  auto stage_layer = [&](const f32x16 (&dl)[2]) {
     float am = 0.f;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) am = fmaxf(am, fabsf(d[rb][i]));
+      for (int i = 0; i < 16; ++i) am = fmaxf(am, fabsf(dl[rb][i]));
     post_max(lds, am, wave, lane);
     __syncthreads();
     const int e_ = wg_exponent(lds);
-    stage64(lds, d, e_, wave, lane);
+    stage64(lds, dl, e_, wave, lane);
     __syncthreads();
-    const float back = __builtin_amdgcn_ldexpf(1.f, e_);
-    // 7 x 2 blocks + the bias: 15 items over the 8 waves
-#pragma unroll 1
-    for (int it = wave; it < 15; it += kThreads / 64) {
-      if (it < 14) {
-        const int cb = it >> 1, mb = it & 1;
-        store_block(part + (sFc1 + it) * 1024,
-                    wgrad_block<false>(lds, stage_base(64), 64, mb, 32, Pact, pX1 + 32 * cb,
-                                       32, -1, pN, col0, ncols, lane),
-                    back, lane);
-      } else {
-        bias_item(lds, stage_base(64), 64, 2, Pact, back, part + sBias * 1024 + 3 * 64, lane);
-      }
+    return __builtin_amdgcn_ldexpf(1.f, e_);
+  };
+  // one 64 x 64 layer: weight gradient of `dl` against the planes `xp` was
+  // begun on, x of the NEXT layer requested, then dl through W^T (blocks `tab`)
+  auto layer64 = [&](f32x16 (&dl)[2], f32x16 (&nx)[2], int tab, int hv_plane, int slot,
+                     int bias_id, int next_plane, int &exn) {
+    const float back = stage_layer(dl);
+    load_hv(hv_plane);
+    if (wave < 2) {
+      f32x16 acc[2];
+      wgrad_block<2>(acc, lds, stage_base(64), 64, 0, 32, Pact, xp, -1, ncols, lane);
+      xp.begin(Pact, next_plane + 32 * wave, 32, pN, col0, lane);
+      store_block(part + (slot + wave * 2 + 0) * 1024, acc[0], back, lane);
+      store_block(part + (slot + wave * 2 + 1) * 1024, acc[1], back, lane);
+    } else if (wave == 2) {
+      bias_item(lds, stage_base(64), 64, 2, Pact, back, part + sBias * 1024 + bias_id * 64,
+                lane);
     }
+    Op16 x[4];
+    zero(nx);
+    exn = scaled_split64(dl, x);
+    dense64T_16(nx, x, L16, 0, tab);
+  };
+  // ---- fc3: delta = d_pre3 (d), x = h2; then fc2's x = h1
+  layer64(d, e, w3, pH2, sFc3, 1, pH1, ex);
+  tanh_back(e, ex);
+  // ---- fc2: delta = d_pre2 (e), x = h1; then fc1's x: wave w takes column
+  // block w of its seven (waves 0, 1 were begun by the layer above)
+  layer64(e, d, w2, pH1, sFc2, 2, pX1, ex);
+  tanh_back(d, ex);
+  // ---- fc1: delta = d_pre1 (d), x = [s1, relu(conv)] = the 224 x1 planes
+  if (wave >= 2 && wave < 7) xp.begin(Pact, pX1 + 32 * wave, 32, pN, col0, lane);
+  Op16 x1s[4];   // d_pre1, scaled per trajectory and split: also the conv part below
+  int ex1;
+  {
+    const float back = stage_layer(d);
     load_hv(pX1);        // s1 = planes 15..78
+    if (wave < 7) {
+      f32x16 acc[2];
+      wgrad_block<2>(acc, lds, stage_base(64), 64, 0, 32, Pact, xp, -1, ncols, lane);
+      // states_in's x (the 15 feature planes + ones)
+      if (wave == 0) xp.begin(Pact, pFeat, kNF, pN, col0, lane);
+      store_block(part + (sFc1 + wave * 2 + 0) * 1024, acc[0], back, lane);
+      store_block(part + (sFc1 + wave * 2 + 1) * 1024, acc[1], back, lane);
+    } else {
+      bias_item(lds, stage_base(64), 64, 2, Pact, back, part + sBias * 1024 + 3 * 64, lane);
+    }
     zero(e);
     ex1 = scaled_split64(d, x1s);
     dense64T_16(e, x1s, L16, 0, wS);
@@ -1622,26 +1705,18 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
   tanh_back(e, ex1);   // d_pre_s
   // ---- states_in: delta = d_pre_s (e), x = the 15 feature planes + ones (bias)
   {
-    float am = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) am = fmaxf(am, fabsf(e[rb][i]));
-    post_max(lds, am, wave, lane);
-    __syncthreads();
-    const int e_ = wg_exponent(lds);
-    stage64(lds, e, e_, wave, lane);
-    __syncthreads();
-    if (wave < 2)
-      store_block(part + (sSin + wave) * 1024,
-                  wgrad_block<false>(lds, stage_base(64), 64, wave, 32, Pact, pFeat, kNF, kNF,
-                                     pN, col0, ncols, lane),
-                  __builtin_amdgcn_ldexpf(1.f, e_), lane);
+    const float back = stage_layer(e);
+    if (wave == 0) {
+      f32x16 acc[2];
+      wgrad_block<2>(acc, lds, stage_base(64), 64, 0, 32, Pact, xp, kNF, ncols, lane);
+      store_block(part + (sSin + 0) * 1024, acc[0], back, lane);
+      store_block(part + (sSin + 1) * 1024, acc[1], back, lane);
+    }
   }
   // ---- conv: delta = relu'(.) W_1c^T d_pre1, 20 channels x 8 window positions;
   // a lane holds positions ii + 4 hi of its channels, so the lower half-waves
   // stage positions 0..3 and then the upper ones 4..7 (80 rows each); the
-  // window of position pos is the 27 in_ref planes from 9 pos, + ones (bias)
+  // window of position pos is the 27 in_ref planes from 9 pos, + ones (bias).
   float dc[5][16];
   {
     float am = 0.f;
@@ -1661,12 +1736,21 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
     }
     post_max(lds, am, wave, lane);
   }
+  // the first windows' x (waves 4..7 multiply): on its way through the barrier
+  // and the staging of the first half
+  __builtin_amdgcn_sched_barrier(0);   // (not above the products: registers)
+  if (wave >= 4) xp.begin(Pact, pInr + kRD * (wave - 4), 27, pN, col0, lane);
   __syncthreads();
   const int ec = wg_exponent(lds);
   const float backc = __builtin_amdgcn_ldexpf(1.f, ec);
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     if (hi == half) {
+      // (opaque per iteration: otherwise the compiler converts all 80 values
+      // of both halves ahead of the loop and spills them)
+      int ecl = ec;
+      asm volatile("" : "+v"(ecl));
+      const int ec = ecl;
       char *p = lds + stage_base(80) + (wave * 32 + (lane & 31)) * 2;
 #pragma unroll
       for (int eb = 0; eb < 5; ++eb)
@@ -1677,14 +1761,15 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
                      __builtin_amdgcn_ldexpf(dc[eb][i + 1], -ec));
     }
     __syncthreads();
-    if (wave < 4) {
-      // rows 20 wave .. 20 wave + 19 of the staged half: not a multiple of 32,
-      // so the block is addressed from row 20 wave with mb = 0
-      const int pos = 4 * half + wave;
-      const f32x16 acc = wgrad_block<false>(lds, stage_base(80) + 20 * wave * kRS, 80, 0, kNC,
-                                            Pact, pInr + kRD * pos, 27, 27, pN, col0, ncols,
-                                            lane);
-      store_block(part + (sConv + pos) * 1024, acc, backc, lane);
+    if (wave >= 4) {
+      // rows 20 q .. 20 q + 19 of the staged half (q = wave - 4): not a multiple
+      // of 32, so the block is addressed from row 20 q with mb = 0
+      const int q = wave - 4, pos = 4 * half + q;
+      f32x16 acc[1];
+      wgrad_block<1>(acc, lds, stage_base(80) + 20 * q * kRS, 80, 0, kNC, Pact, xp, 27, ncols,
+                     lane);
+      if (half == 0) xp.begin(Pact, pInr + kRD * (4 + q), 27, pN, col0, lane);
+      store_block(part + (sConv + pos) * 1024, acc[0], backc, lane);
     }
     __syncthreads();
   }
@@ -1693,14 +1778,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
 // Second stage: the workgroups' partial blocks summed in a fixed order
 // (deterministic), scattered into the parameter gradients; block 0 also sums
 // the loss partials of the forward kernel.
-struct WgReduceArgs {
-  const float *part;
-  ApgMlpPolicyGrads g;
-  const float *loss_partials;
-  float *loss;
-  int wgs, n_partials;
-};
-
 // destination of element (slot, reg i, lane) - or NULL (padding)
 __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, int i, int lane) {
   const int rowb = rrow(i) + 4 * (lane >> 5), col = lane & 31;
@@ -1729,27 +1806,58 @@ __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, 
          : layer == 1 ? g.b_3 + m : layer == 2 ? g.b_2 + m : g.b_1 + m;
 }
 
+// Second stage, two launches.  Level 1: blockIdx.y = a chunk of kRedChunk
+// workgroups, summed per element in workgroup order into chunk_sums[chunk][kSlots
+// * 1024] - thousands of blocks, the 38 MB of partials stream at the HBM rate
+// (one block per element column over all 256 workgroups, the first version,
+// took 248 us).  Level 2 sums the chunks in order, scatters into the parameter
+// gradients and sums the forward kernel's loss partials.  (Both levels in ONE
+// launch - the last block of a column, found by a ticket between device-scope
+// fences, doing level 2 - was built and measured: 135 us.  A device-scope
+// release on this part writes the XCD's L2 back; a thousand blocks doing it
+// cost more than the launch boundary they save.)
+struct WgReduceArgs {
+  const float *part;   // level 2's source: chunk sums, or the partials themselves
+  ApgMlpPolicyGrads g;
+  const float *loss_partials;
+  float *loss;
+  int wgs, n_partials;   // wgs: how many [kSlots * 1024] rows `part` has
+};
+
+__global__ __launch_bounds__(256) void mlp_wgrad_reduce1_kernel(const float *part,
+                                                                float *chunk_sums, int wgs) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= kSlots * 1024) return;
+  const size_t stride = (size_t)kSlots * 1024;
+  const int w0 = blockIdx.y * kRedChunk;
+  const float *p = part + (size_t)w0 * stride + t;
+  float v[kRedChunk];
+#pragma unroll
+  for (int k = 0; k < kRedChunk; ++k) v[k] = w0 + k < wgs ? p[(size_t)k * stride] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kRedChunk; ++k) s += v[k];   // fixed order
+  chunk_sums[(size_t)blockIdx.y * stride + t] = s;
+}
+
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
   const int t = blockIdx.x * 256 + threadIdx.x;   // (slot, reg, lane)
+  const size_t stride = (size_t)kSlots * 1024;
   if (t < kSlots * 1024) {
     const int slot = t >> 10, i = (t >> 6) & 15, lane = t & 63;
     float *dst = wg_dest(A.g, slot, i, lane);
     if (dst) {
       const int n_src = slot == sConv ? kNP : 1;   // the eight position blocks
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      float s = 0.f;
       for (int q = 0; q < n_src; ++q) {
         const float *p = A.part + (size_t)(slot + q) * 1024 + (t & 1023);
-        const size_t stride = (size_t)kSlots * 1024;
-        int w = 0;
-        for (; w + 4 <= A.wgs; w += 4) {
-          s0 += p[(size_t)w * stride];
-          s1 += p[(size_t)(w + 1) * stride];
-          s2 += p[(size_t)(w + 2) * stride];
-          s3 += p[(size_t)(w + 3) * stride];
-        }
-        for (; w < A.wgs; ++w) s0 += p[(size_t)w * stride];
+        float v[kRedChunk];   // all loads in flight, then a fixed-order sum
+#pragma unroll
+        for (int w = 0; w < kRedChunk; ++w) v[w] = w < A.wgs ? p[(size_t)w * stride] : 0.f;
+#pragma unroll
+        for (int w = 0; w < kRedChunk; ++w) s += v[w];
       }
-      *dst = (s0 + s1) + (s2 + s3);
+      *dst = s;
     }
   }
   if (blockIdx.x == 0 && A.loss) {   // fixed-shape sum of the loss partials
@@ -2010,7 +2118,10 @@ int apg_quad_mlp_concurrent_fwd_bwd(
 int apg_quad_mlp_step_workspace_floats(void) { return kCfLds + kWgTabFloats; }
 
 long long apg_quad_mlp_step_partials_floats(int B) {
-  return B <= 0 ? 0 : (long long)((B + kTrajPerBlock - 1) / kTrajPerBlock) * kSlots * 1024;
+  if (B <= 0) return 0;
+  const long long wgs = (B + kTrajPerBlock - 1) / kTrajPerBlock;
+  // the workgroups' partials + the chunk sums of the first reduction level
+  return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlots * 1024;
 }
 
 int apg_quad_mlp_concurrent_step(
@@ -2088,8 +2199,14 @@ int apg_quad_mlp_concurrent_step(
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
-  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((kSlots * 1024 + 255) / 256), dim3(256), 0,
-                     st, R);
+  if (blocks > kRedChunk) {
+    const int chunks = (blocks + kRedChunk - 1) / kRedChunk;
+    float *chunk_sums = partials + (size_t)blocks * kSlots * 1024;
+    hipLaunchKernelGGL(mlp_wgrad_reduce1_kernel, dim3(kRedColumns, chunks), dim3(256), 0, st,
+                       partials, chunk_sums, blocks);
+    R.part = chunk_sums, R.wgs = chunks;
+  }
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(kRedColumns), dim3(256), 0, st, R);
   return check_launch("quad_mlp_concurrent_step");
 }
 
