@@ -262,11 +262,16 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0
 STEP_MODELS = {
     # mode: fp16 MFMAs per wave (forward + reverse; per step for the unrolled
     # modes), plane bytes per env-step and per trajectory
-    "concurrent": dict(mfma_once=222 + 150, mfma_per_step=0,
-                       # 431 + 456 planes of B floats written, read once more
-                       # by the products; inputs: features 60 + in_ref 360 +
-                       # state0 48 + ref 360
-                       bytes_per_traj=(431 + 456) * 4 * 2 + 828, bytes_per_step=0,
+    # round 4: weight gradients inside the reverse kernel - forward 222,
+    # reverse 150, and per workgroup of 256 trajectories 36 block products of 48
+    # + 8 bias blocks of 32 instructions (= 248 per wave-equivalent of 32)
+    "concurrent": dict(mfma_once=222 + 150 + 248, mfma_per_step=0, products_in_sweep=True,
+                       # forward writes 431 planes; reverse reads 256 (tanh') +
+                       # 521 (x of the products) + 45 (d_zout, masks) planes and
+                       # writes 37 x 4 KB of partials per 256 trajectories, read
+                       # once more by the second stage; inputs 828
+                       bytes_per_traj=(431 + 256 + 521 + 45) * 4 + 2 * 37 * 4096 // 256 + 828,
+                       bytes_per_step=0,
                        # features 60 + state0 48 + in_ref H*36 + ref H*36
                        algo_bytes_per_traj=60 + 48 + 360 + 360),
     "autoregressive": dict(mfma_once=0, mfma_per_step=198 + 144,
@@ -294,8 +299,9 @@ def step_roofline(mode, B, H, n_params, ms):
     waves = (B + 31) // 32
     sweep_flops = (m["mfma_once"] + m["mfma_per_step"] * H) * 32768.0 * waves
     cols = B * (H if m["mfma_per_step"] else 1)      # columns of the products
-    # three-term bf16 operands, six products per multiply-add (planes_gemm.hip)
-    product_flops = 6 * 2.0 * n_params * cols
+    # three-term bf16 operands, six products per multiply-add (planes_gemm.hip);
+    # none when the products are part of the sweep's own instruction count
+    product_flops = 0.0 if m.get("products_in_sweep") else 6 * 2.0 * n_params * cols
     nbytes = float(B) * (m["bytes_per_traj"] + m["bytes_per_step"] * H)
     mfma_ms = (sweep_flops + product_flops) / (FP16_MFMA_PEAK_TFLOPS * 1e12) * 1e3
     hbm_ms = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3

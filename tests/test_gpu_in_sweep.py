@@ -1,0 +1,169 @@
+"""Round 4: the concurrent training step with its weight gradients accumulated
+INSIDE the reverse kernel (apg_quad_mlp_concurrent_step; csrc/mlp.hip,
+mlp_concurrent_bwd_wg_kernel) - no cotangent planes, no second pass of
+products.  One loss.backward() of the reference yields every parameter
+gradient (scripts/train_drone.py:175-203); this path must too, to the same
+1e-4 as the plane + product path it replaces (which stays available behind
+functional.CONCURRENT_IN_SWEEP = False and is the comparison here)."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+H, DT = 10, 0.1
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def in_sweep_switch():
+    from apg_trajectory_tracking_amd import functional as F
+    before = F.CONCURRENT_IN_SWEEP
+    yield lambda on: setattr(F, "CONCURRENT_IN_SWEEP", bool(on))
+    F.CONCURRENT_IN_SWEEP = before
+
+
+def N(t):
+    return t.detach().double().cpu().numpy()
+
+
+def _case(B, seed, dev):
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    d = synthetic.quad_polynomial_batch(B, H, DT, seed=seed)
+    s0 = d["state0"].to(dev)
+    with torch.no_grad():
+        normed = state_preprocessing(s0)
+    return d, (normed, s0, d["in_ref"].to(dev), d["ref"].to(dev))
+
+
+def _fp64_grads(net, d):
+    from oracle import torch_port as tp
+    net64 = copy.deepcopy(net).double().cpu()
+    s64 = d["state0"].double()
+    acts = torch.sigmoid(net64(tp.quad_state_features(s64),
+                               d["in_ref"].double())).reshape(-1, H, 4)
+    loss = tp.quad_mpc_loss(tp.unroll(tp.QuadOracle(dtype=torch.float64), s64, acts, DT),
+                            d["ref"].double(), acts)
+    loss.backward()
+    return loss.item(), {k: p.grad.numpy() for k, p in net64.named_parameters()
+                         if p.grad is not None}
+
+
+# 1: one lane; 31 / 77: part of a wave; 256: exactly one workgroup; 257: a
+# second workgroup with one trajectory; 300, 4113: ragged last workgroups;
+# 8192 + 3: more than one chunk of the second stage (32 workgroups)
+@pytest.mark.parametrize("B", [1, 31, 77, 256, 257, 300, 4113, 8195])
+def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_switch):
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    torch.manual_seed(8)
+    net = Net(15, H, 9, 4 * H, conv=1)
+    gnet = copy.deepcopy(net).to(dev)
+    d, inputs = _case(B, 100 + B, dev)
+    dyn = FlightmareDynamics()
+    res = []
+    for on in (True, False):
+        in_sweep_switch(on)
+        loss, grads, flat = F.quad_concurrent_policy_grads(gnet, *inputs, DT, dyn.params)
+        assert flat.numel() == sum(p.numel() for p in gnet.parameters()) + 1
+        res.append((loss.item(), {k: N(v) for k, v in grads.items()}))
+    loss64, want = _fp64_grads(net, d)
+    (l1, g1), (l0, g0) = res
+    assert l1 == l0                               # the same forward kernel
+    assert abs(l1 - loss64) / abs(loss64) < 1e-5
+    assert set(g1) == set(want)
+    for k, w in want.items():
+        assert rel_err(g1[k], w) < 1e-4, (k, rel_err(g1[k], w))
+        assert rel_err(g1[k], g0[k]) < 2e-5, (k, rel_err(g1[k], g0[k]))
+
+
+def test_in_sweep_is_deterministic_and_feeds_autograd(dev, in_sweep_switch):
+    """Fixed-order second stage: equal inputs give equal bits; loss.backward()
+    of the autograd entry point delivers the same gradients (scaled by the
+    upstream cotangent)."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    in_sweep_switch(True)
+    torch.manual_seed(3)
+    net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+    _, inputs = _case(9000, 5, dev)
+    dyn = FlightmareDynamics()
+    l0, g0, f0 = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
+    f0 = f0.clone()
+    for _ in range(3):
+        l1, g1, f1 = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
+        assert torch.equal(f1[:-1], f0[:-1]) and torch.equal(l1, l0)
+    loss = F.quad_concurrent_policy_loss(net, *inputs, DT, dyn.params)
+    (2.5 * loss).backward()
+    for k, p in net.named_parameters():
+        assert torch.allclose(p.grad, 2.5 * g0[k], rtol=1e-6, atol=0), k
+
+
+def test_concurrent_step_through_the_c_abi(dev):
+    """apg_quad_mlp_concurrent_step called directly (plain pointers): the
+    result of the Python entry point; B = 0 zeroes the gradients and the loss;
+    argument errors come back as APG_ERR_ARG."""
+    from apg_trajectory_tracking_amd import _capi, functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    lib = _capi.lib()
+    B = 700
+    torch.manual_seed(11)
+    net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+    _, inputs = _case(B, 17, dev)
+    dyn = FlightmareDynamics()
+    F.CONCURRENT_IN_SWEEP = True
+    want_loss, want, _ = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
+    acts, s0, rf = F.quad_concurrent_prepare(*inputs)
+    new = lambda *s: torch.full(s, 7.0, device=dev)
+    names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2", "w_3", "b_3",
+             "w_out", "b_out")
+    params = [p.detach().contiguous() for p in F._net_params(net, F._MLP_PARAMS)]
+    pol = _capi.ApgMlpPolicy(**{k: v.data_ptr() for k, v in zip(names, params)})
+    grads = [new(*p.shape) for p in params]
+    gs = _capi.ApgMlpPolicyGrads(**{k: v.data_ptr() for k, v in zip(names, grads)})
+    mask = torch.empty(5, B, dtype=torch.int32, device=dev)
+    dz, lp = new(40, B), new(lib.apg_quad_mlp_loss_partials_count(B))
+    loss = new(1)
+    ws = new(lib.apg_quad_mlp_step_workspace_floats())
+    part = new(lib.apg_quad_mlp_step_partials_floats(B))
+    w = F.quad_loss_weights()
+
+    def call(batch, grads_struct=gs):
+        return lib.apg_quad_mlp_concurrent_step(
+            s0.data_ptr(), rf.data_ptr(), rf.shape[1], DT, ctypes.byref(dyn.params),
+            ctypes.byref(w), ctypes.byref(pol), batch, H, acts.data_ptr(),
+            mask.data_ptr(), dz.data_ptr(), lp.data_ptr(), loss.data_ptr(),
+            ctypes.byref(grads_struct), None, ws.data_ptr(), part.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert call(B) == 0
+    torch.cuda.synchronize()
+    assert loss.item() == want_loss.item()
+    for g, k in zip(grads, F._MLP_PARAMS):
+        assert torch.equal(g, want[k].view_as(g)), k
+    assert call(0) == 0
+    torch.cuda.synchronize()
+    assert loss.item() == 0.0 and all(float(g.abs().max()) == 0.0 for g in grads)
+    bad = _capi.ApgMlpPolicyGrads(**{k: v.data_ptr() for k, v in zip(names, grads)})
+    bad.w_2 = None
+    assert call(B, bad) == -1 and b"gradient pointer" in lib.apg_last_error_string()
+    assert lib.apg_quad_mlp_concurrent_step(
+        s0.data_ptr(), rf.data_ptr(), 7, DT, ctypes.byref(dyn.params), ctypes.byref(w),
+        ctypes.byref(pol), B, H, acts.data_ptr(), mask.data_ptr(), dz.data_ptr(),
+        lp.data_ptr(), loss.data_ptr(), ctypes.byref(gs), None, ws.data_ptr(),
+        part.data_ptr(), None) == -1
