@@ -315,10 +315,23 @@ __global__ __launch_bounds__(APG_ROLLOUT_BLOCK) APG_WING_OCCUPANCY void wing_rol
 // 2: VGPR-resident for the whole kernel (no scalar traffic, but with two
 // trajectories per lane the 256 architectural VGPRs are full: the table ends
 // up in AGPRs and every use costs a v_accvgpr_read - measured, not shipped).
+#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_WING_CLOCK)
+#error "experiment macro in a product build (variants: tools/build_wing_variant.sh)"
+#endif
+#ifdef APG_WING_CLOCK
+// Shader clock under the kernel: every wave stamps s_memtime
+// (shader cycles) and s_memrealtime (the constant 100 MHz reference clock) at
+// its first and last instruction; tools/wing_clock.py reads them back.
+__device__ unsigned long long apg_wing_clock[4 * 4096];
+#endif
 template <int KMODE>
 __global__ __launch_bounds__(64) void wing_rollout_pk_kernel(WingRolloutArgs A) {
   extern __shared__ fx2 stash2[];
   typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+#ifdef APG_WING_CLOCK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(),
+                           clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lane = threadIdx.x;
   const int pr = blockIdx.x * 64 + lane;     // pair of trajectories
   const int npairs = A.B >> 1;
@@ -501,6 +514,13 @@ __global__ __launch_bounds__(64) void wing_rollout_pk_kernel(WingRolloutArgs A) 
 #pragma unroll
     for (int i = 0; i < 12; ++i) st2(r_gs, i, lam[i]);
   }
+#ifdef APG_WING_CLOCK
+  if (lane == 0 && blockIdx.x < 4096) {
+    unsigned long long *c = apg_wing_clock + 4 * blockIdx.x;
+    c[0] = clk_t0, c[1] = __builtin_amdgcn_s_memtime();
+    c[2] = clk_r0, c[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 #undef APG_LAUNDER
 }
 
@@ -547,6 +567,14 @@ using namespace apg;
 static int g_wing_pk_mode = APG_WING_PK;
 
 extern "C" {
+
+#ifdef APG_WING_CLOCK
+int apg_wing_clock_read(unsigned long long *host, int n) {   // experiment builds only
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(apg_wing_clock),
+                             (size_t)n * sizeof(unsigned long long)) == hipSuccess
+             ? APG_OK : APG_ERR_HIP;
+}
+#endif
 
 int apg_wing_set_two_per_lane(int mode) {
   if (mode < 0 || mode > 2) {
