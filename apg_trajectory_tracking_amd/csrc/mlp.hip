@@ -1815,7 +1815,9 @@ __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, 
 // launch - the last block of a column, found by a ticket between device-scope
 // fences, doing level 2 - was built and measured: 135 us.  A device-scope
 // release on this part writes the XCD's L2 back; a thousand blocks doing it
-// cost more than the launch boundary they save.)
+// cost more than the launch boundary they save.  One launch of 148 blocks of
+// 1 024 threads, four sub-groups per column each summing a quarter of the
+// workgroups: 40 us - too few blocks to stream 38 MB.)
 struct WgReduceArgs {
   const float *part;   // level 2's source: chunk sums, or the partials themselves
   ApgMlpPolicyGrads g;
