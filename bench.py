@@ -676,6 +676,23 @@ def wing_secondary(args, dev):
     except (OSError, ValueError):
         entry = None
     build = kernel_build_id(WING_SOURCES)
+    # flop-based roofline next to the instruction-count one:
+    # USEFUL fp32 flops = what one evaluation of the step, its adjoint (which
+    # contains a second evaluation) and the loss need, the checkpoint scheme's
+    # re-integration excluded.  Counted on the scalar arithmetic of
+    # csrc/wing_math.h (one evaluation of state_dot ~190 VALU
+    # ops, the adjoint ~300, 815 per env-step with 0.75 re-integrations): 680
+    # ops per env-step at 1.4 flop per op (40 % of them fused multiply-adds)
+    useful = 680 * 1.4 * B * H
+    out["fp32_flops"] = {
+        "useful_flops_per_launch": useful,
+        "achieved_TFLOPs": useful / sec / 1e12,
+        "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS,
+        "frac": useful / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+        "what": "680 useful scalar ops per env-step (evaluation + adjoint incl. its own "
+                "evaluation, no re-integration) x 1.4 flop per op over the 157.3 TFLOP/s "
+                "fp32 vector peak; the shader clock under this kernel is 2.25 GHz "
+                "(profiles/r04_wing_clock.jsonl)"}
     if entry and entry.get("kernel_build") == build:
         n_valu = entry["valu_wave_instructions_per_launch"]
         out["fp32_valu"] = {
