@@ -65,13 +65,22 @@ class TensorBatches:
         full, tail = divmod(n, self.batch_size)
         return full + (1 if tail and not self._too_small(tail) else 0)
 
-    def iter_indices(self):
-        """The same batches as __iter__, as index tensors (int64, on the data's
-        device) into `self.tensors`: lets a consumer fold the row gather into
-        its own first pass over the data (functional.to_soa(index=...))."""
+    def epoch_order(self):
+        """This epoch's sample order (one draw of the permutation, exactly what
+        iter_indices() would draw)."""
         n = self.tensors[0].shape[0]
         dev = self.tensors[0].device
-        order = self._permutation(n, dev) if self.shuffle else torch.arange(n, device=dev)
+        return self._permutation(n, dev) if self.shuffle else torch.arange(n, device=dev)
+
+    def iter_indices(self, order=None):
+        """The same batches as __iter__, as index tensors (int64, on the data's
+        device) into `self.tensors`: lets a consumer fold the row gather into
+        its own first pass over the data (functional.to_soa(index=...)).
+        `order`: an epoch_order() drawn (or kept in a persistent buffer) by the
+        caller; the batches are then views of it."""
+        n = self.tensors[0].shape[0]
+        if order is None:
+            order = self.epoch_order()
         for lo in range(0, n, self.batch_size):
             if self._too_small(min(self.batch_size, n - lo)):
                 continue

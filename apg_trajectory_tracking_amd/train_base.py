@@ -240,6 +240,15 @@ class TrainBase:
         # 0.525, autoregressive 1.164 vs 1.143; profiles/r04_run_epoch.jsonl)
         self.prefetch_batches = False
         self._prefetch = {}
+        # True (with graph_steps, one process): a whole EPOCH of the fused index
+        # loops is captured into one HIP graph - per batch: gather, step,
+        # update, running loss - and replayed per epoch with a fresh
+        # permutation copied into the buffer its gathers read.  The host then
+        # issues one launch per epoch instead of ~10 calls per batch (which,
+        # at ~0.21 ms per batch, had become the bound of run_epoch).
+        self.graph_epochs = True
+        self._epoch_graphs = {}
+        self._in_epoch_capture = False
 
         # horizon / reference-window length (scripts/train_base.py:118-128)
         if self.train_mode in ["autoregressive", "LSTM"]:
@@ -316,8 +325,10 @@ class TrainBase:
         return loss
 
     def _graphable(self):
-        return bool(self.graph_steps) and (torch.cuda.is_available()
-                                           or self.graph_emulation)
+        # (inside the capture of a whole epoch the steps run "eagerly": their
+        # launches are what is being captured)
+        return (bool(self.graph_steps) and not self._in_epoch_capture
+                and (torch.cuda.is_available() or self.graph_emulation))
 
     def _reducing(self):
         """The step has an all-reduce slot (real or, when forced, empty)."""
@@ -527,7 +538,7 @@ class TrainBase:
         self.results_dict["loss_dyn_per_step"].append(loss.detach())
         return loss
 
-    def _pipelined_epoch(self, prepare, step):
+    def _pipelined_epoch(self, prepare, step, indices=None):
         """One epoch over the loader's index batches with the input pipeline
         one batch ahead: `prepare(index, out)` - the layout change with the row
         gather folded in, 69-90 us per 65 536-trajectory batch, a quarter of a
@@ -554,7 +565,7 @@ class TrainBase:
                 slot["bufs"] = prepare(index, slot.get("bufs"))
                 slot["ready"] = side.record_event()
             return slot
-        batches = enumerate(self.trainloader.iter_indices())
+        batches = enumerate(self.trainloader.iter_indices() if indices is None else indices)
         cur = next(batches, None)
         slot = issue(*cur) if cur is not None else None
         running, i = None, -1
@@ -574,7 +585,7 @@ class TrainBase:
             self._borrow_loss, self._epoch_sigs = False, None
         return running, i
 
-    def _indexed_epoch(self, step):
+    def _indexed_epoch(self, step, indices=None):
         """One epoch of `step(index)` over the loader's index batches (the
         gather is folded into the fused step's layout change, inside its
         captured graph).  Inside the loop nothing a capture depends on changes:
@@ -584,12 +595,71 @@ class TrainBase:
         running, i = None, -1
         self._borrow_loss, self._epoch_sigs = True, {}
         try:
-            for i, index in enumerate(self.trainloader.iter_indices(), 0):
+            for i, index in enumerate(
+                    self.trainloader.iter_indices() if indices is None else indices, 0):
                 loss = step(index).detach()
                 running = loss.clone() if running is None else running.add_(loss)
         finally:
             self._borrow_loss, self._epoch_sigs = False, None
         return running, i
+
+    def _epoch_graph_ok(self):
+        ld = self.trainloader
+        return (self.graph_epochs and self._graphable() and torch.cuda.is_available()
+                and not self._reducing() and hasattr(ld, "epoch_order")
+                and getattr(ld, "shard", None) is None and ld.tensors[0].is_cuda)
+
+    def _graphed_epoch(self, key, loop):
+        """One epoch of `loop(indices) -> (running_loss, last index)` - through
+        ONE captured graph of the whole epoch when `graph_epochs` applies.  The
+        first epoch on a given configuration runs eagerly (it trains, and warms
+        everything a capture may not do: lazy allocations, descriptors, the
+        range check of the inputs); the second one is captured with its
+        batches as views of a persistent order buffer and replayed; from then
+        on an epoch is: draw the permutation, copy it into that buffer, one
+        graph launch.  Re-captured (after another eager epoch) when anything
+        the capture is tied to changes: data-set tensors, batch size,
+        parameters, optimizer settings, simulator parameters, dt."""
+        ld = self.trainloader
+        if not self._epoch_graph_ok():
+            return loop(None)
+        order = ld.epoch_order()          # the one draw an eager epoch makes
+        sig = (self._graph_signature(ld.tensors, (ld.tensors[0],))
+               + (ld.batch_size, ld.shuffle, bool(self.prefetch_batches)))
+        eg = self._epoch_graphs.get(key)
+        if eg is None or eg["sig"] != sig:
+            self._epoch_graphs[key] = {"sig": sig, "graph": None}
+            return loop(ld.iter_indices(order=order))
+        if eg["graph"] is None:
+            import gc
+            perm = torch.empty_like(order)
+            graph = torch.cuda.CUDAGraph()
+            stale = self._prefetch.pop("slots", None)     # no events from outside
+            self._prefetch["slots"] = {}
+            was_enabled = gc.isenabled()
+            gc.collect()
+            gc.disable()
+            self._in_epoch_capture = True
+            try:
+                with torch.cuda.graph(graph):
+                    running, last = loop(ld.iter_indices(order=perm))
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f"capture of the {key} epoch failed ({e}); graph_epochs "
+                              "switched off for this trainer")
+                self.graph_epochs = False
+                self._epoch_graphs.clear()
+                torch.cuda.synchronize()
+                return loop(ld.iter_indices(order=order))
+            finally:
+                self._in_epoch_capture = False
+                self._prefetch["slots"] = stale if stale is not None else {}
+                if was_enabled:
+                    gc.enable()
+            eg.update(graph=graph, perm=perm, running=running, last=last)
+        eg["perm"].copy_(order)
+        eg["graph"].replay()
+        return eg["running"], eg["last"]
 
     def run_epoch(self, train="controller", epoch=0):
         if train not in ("controller", "dynamics"):
@@ -600,15 +670,19 @@ class TrainBase:
                 if train == "controller" and self.prefetch_batches
                 and hasattr(self.trainloader, "iter_indices") else None)
         if plan is not None:
-            return self._finish_epoch(*self._pipelined_epoch(*plan), train)
+            return self._finish_epoch(*self._graphed_epoch(
+                (self.train_mode, "prefetch"),
+                lambda indices: self._pipelined_epoch(*plan, indices=indices)), train)
         if (train == "controller" and self.train_mode == "concurrent"
                 and hasattr(self.trainloader, "iter_indices")
                 and self.train_concurrent_fused(None, None, None, None,
                                                 probe=True)):
             # fused step with the minibatch gather folded into its first pass
             tensors = self.trainloader.tensors
-            return self._finish_epoch(*self._indexed_epoch(
-                lambda index: self.train_concurrent_fused(*tensors, index=index)), train)
+            return self._finish_epoch(*self._graphed_epoch(
+                ("concurrent", "indexed"), lambda indices: self._indexed_epoch(
+                    lambda index: self.train_concurrent_fused(*tensors, index=index),
+                    indices)), train)
         if (train == "controller" and self.train_mode == "concurrent"
                 and hasattr(self.trainloader, "iter_indices")
                 and getattr(self, "use_packed_path", True)
@@ -636,8 +710,16 @@ class TrainBase:
                 and hasattr(self.trainloader, "iter_indices")
                 and getattr(self, "recurrent_indexed_ok", lambda: False)()):
             tensors = self.trainloader.tensors
-            return self._finish_epoch(*self._indexed_epoch(
-                lambda index: self.train_recurrent_model(*tensors, index=index)), train)
+            if (self.train_mode == "LSTM"
+                    and getattr(self, "hidden_generator", None) is not None):
+                # a private generator is not registered with graphs: eager steps
+                return self._finish_epoch(*self._indexed_epoch(
+                    lambda index: self.train_recurrent_model(*tensors, index=index)),
+                    train)
+            return self._finish_epoch(*self._graphed_epoch(
+                (self.train_mode, "indexed"), lambda indices: self._indexed_epoch(
+                    lambda index: self.train_recurrent_model(*tensors, index=index),
+                    indices)), train)
         for i, data in enumerate(self.trainloader, 0):
             in_state, current_state, in_ref_state, ref_states = data
             if train == "dynamics":

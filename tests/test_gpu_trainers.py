@@ -1463,7 +1463,9 @@ def test_run_epoch_replays_one_graph_over_shuffled_minibatches(dev, mode, prefet
     captured for (its size, its buffer set); without it the index batch is
     copied into a persistent buffer the captured gather reads.  Same seed ->
     the epochs' losses and the final weights equal the eager loop's (which
-    runs the same pipeline, or none), graphs are captured once."""
+    runs the same pipeline, or none), graphs are captured once.  From the
+    second epoch on the whole epoch is ONE graph (`graph_epochs`): a fresh
+    permutation is copied into the buffer its gathers read."""
     import copy
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
@@ -1484,6 +1486,11 @@ def test_run_epoch_replays_one_graph_over_shuffled_minibatches(dev, mode, prefet
         losses = [t.run_epoch(train="controller", epoch=e) for e in range(3)]
         runs.append((losses, {k: v.clone() for k, v in t.net.state_dict().items()},
                      start))
+        if graph:
+            # the first epoch stepped through per-batch graphs, the second was
+            # captured WHOLE (graph_epochs) and replayed, the third replayed
+            (eg,) = t._epoch_graphs.values()
+            assert eg["graph"] is not None and eg["last"] == 2
         if graph and pre:
             # batch i of an epoch uses buffer set i & 1: 384, 384, 232
             assert sorted((k[1], k[3]) for k in t._graphs) == [(232, 0), (384, 0), (384, 1)]
