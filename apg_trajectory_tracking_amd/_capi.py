@@ -165,7 +165,7 @@ SIGNATURES = {
     "apg_quad_mlp_concurrent_step": [
         _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
-        _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P, _P],
+        _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P, _P, _P],
     "apg_quad_mlp_closed_loop": [
         _P, _I, _F, ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgMlpPolicy),
         _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],

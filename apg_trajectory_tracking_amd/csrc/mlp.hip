@@ -2131,7 +2131,8 @@ int apg_quad_mlp_concurrent_step(
     const ApgQuadParams *params, const ApgQuadLossWeights *weights,
     const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
     float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
-    float *states, float *workspace, float *partials, apg_stream_t stream) {
+    float *states, float *workspace, float *partials, apg_event_t after_reverse,
+    apg_stream_t stream) {
   if (int e = check_mlp(params, policy, B, H)) return e;
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
   if (ref_cols != 9 && ref_cols != 6) {
@@ -2198,6 +2199,11 @@ int apg_quad_mlp_concurrent_step(
   W.tables = workspace + kCfLds, W.B = B;
   hipLaunchKernelGGL(mlp_concurrent_bwd_wg_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st,
                      W);
+  // the inputs (activation planes, state0, ref) are not read past this point:
+  // a caller that pipelines batches may start refilling the NEXT batch's
+  // buffers behind this event while the second stage and the update run
+  if (after_reverse && hipEventRecord((hipEvent_t)after_reverse, st) != hipSuccess)
+    return check_launch("hipEventRecord(after_reverse)");
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);

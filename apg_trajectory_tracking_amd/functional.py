@@ -1595,8 +1595,9 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
                 ptr(s0), ptr(rf), rf.shape[1], float(dt), ctypes.byref(params),
                 ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(acts),
                 relu_mask.data_ptr(), ptr(d_zout), ptr(partials), ptr(loss),
-                ctypes.byref(gs), None, ptr(ws), ptr(part), stream_of(s0)),
-                "apg_quad_mlp_concurrent_step")
+                ctypes.byref(gs), None, ptr(ws), ptr(part),
+                getattr(getattr(ctx, "after_reverse", None), "cuda_event", None),
+                stream_of(s0)), "apg_quad_mlp_concurrent_step")
             ctx.flat_grads = (flat, gr)
             ctx.save_for_backward(acts)
             return loss.reshape(())
@@ -1683,7 +1684,7 @@ def _net_params(net, names):
 
 def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
                                  weights=None, index=None, static_inputs=False,
-                                 prepared=None):
+                                 prepared=None, after_reverse=None):
     """quad_concurrent_policy_loss + its parameter gradients, without autograd:
     returns (loss, {parameter name: gradient}, flat); the gradients are
     contiguous views of the flat buffer (no per-parameter clone as
@@ -1695,8 +1696,11 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
     tensor objects (its resident shard) - their plane-layout copies are kept
     while the tensors stay unchanged (_StaticPlanes).  `prepared`: the result
     of quad_concurrent_prepare for this batch (the four tensors are then
-    unused and may be None)."""
+    unused and may be None).  `after_reverse`: a torch.cuda.Event recorded once
+    the reverse kernel - the last reader of the inputs - is enqueued (in-sweep
+    path only; run_epoch refills the next batch's buffers behind it)."""
     ctx = _DirectCtx()
+    ctx.after_reverse = after_reverse
     if prepared is not None:
         ctx.prepared = prepared
     elif static_inputs and index is None:

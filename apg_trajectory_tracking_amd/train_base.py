@@ -541,25 +541,35 @@ class TrainBase:
     def _pipelined_epoch(self, prepare, step, indices=None):
         """One epoch over the loader's index batches with the input pipeline
         one batch ahead: `prepare(index, out)` - the layout change with the row
-        gather folded in, 69-90 us per 65 536-trajectory batch, a quarter of a
-        concurrent step - runs on a side stream into one of two buffer sets
-        while the previous batch's step runs on the current stream; `step(
-        prepared, slot)` then starts from planes that are already there (and is
-        replayed from the graph captured for that slot).  Two events per slot
-        order the streams: `ready` (gather done -> step may read) and `freed`
-        (step done -> the next gather into this slot may write).  The running
-        loss is accumulated on the device.  Returns (running_loss, last batch
-        index)."""
+        gather folded in, ~31 us per 65 536-trajectory batch - runs on a side
+        stream into one of two buffer sets; `step(prepared, slot, after)` then
+        starts from planes that are already there.  Events order the streams:
+        `ready` (gather done -> step may read), `freed` (step done -> the next
+        gather into this slot may write).
+        WHEN the gather of batch i + 1 starts decides whether it pays: next to
+        the sweeps of step i it slows them by as much as it costs alone
+        (measured: no gain).  So where the launches are under this loop's
+        control - inside the capture of a whole epoch, or without step graphs
+        - it is forked LATE: behind the event the step records once its reverse
+        kernel, the last reader of the inputs, is enqueued (`after`; the
+        second stage, the update and the running-loss add then run next to
+        the gather: ~30 us of small, latency-bound kernels).  With per-step
+        graphs the event would be inside a replayed graph; the gather is then
+        issued up front, before step i.  Returns (running_loss, last index)."""
         main = torch.cuda.current_stream()
         st = self._prefetch
         if "stream" not in st:
-            st["stream"], st["slots"] = torch.cuda.Stream(), {}
+            st["stream"] = torch.cuda.Stream()
+        st.setdefault("slots", {})
         side = st["stream"]
+        late = self._in_epoch_capture or not self._graphable()
         side.wait_stream(main)       # the permutation, the data set's last update
 
-        def issue(i, index):
+        def issue(i, index, behind=None):
             slot = st["slots"].setdefault((index.numel(), i & 1), {})
             with torch.cuda.stream(side):
+                if behind is not None:
+                    side.wait_event(behind)
                 if "freed" in slot:
                     side.wait_event(slot["freed"])
                 slot["bufs"] = prepare(index, slot.get("bufs"))
@@ -575,10 +585,18 @@ class TrainBase:
             while cur is not None:
                 i = cur[0]
                 nxt = next(batches, None)
-                nxt_slot = issue(*nxt) if nxt is not None else None
+                nxt_slot = None
+                if nxt is not None and not late:
+                    nxt_slot = issue(*nxt)
                 main.wait_event(slot["ready"])
-                loss = step(slot["bufs"], i & 1).detach()
+                after = None
+                if late:
+                    after = torch.cuda.Event()
+                    after.record(main)       # (creates the handle the step re-records)
+                loss = step(slot["bufs"], i & 1, after).detach()
                 slot["freed"] = main.record_event()
+                if nxt is not None and late:
+                    nxt_slot = issue(*nxt, behind=after)
                 running = loss.clone() if running is None else running.add_(loss)
                 cur, slot = nxt, nxt_slot
         finally:
@@ -625,7 +643,7 @@ class TrainBase:
             return loop(None)
         order = ld.epoch_order()          # the one draw an eager epoch makes
         sig = (self._graph_signature(ld.tensors, (ld.tensors[0],))
-               + (ld.batch_size, ld.shuffle, bool(self.prefetch_batches)))
+               + (ld.batch_size, ld.shuffle))
         eg = self._epoch_graphs.get(key)
         if eg is None or eg["sig"] != sig:
             self._epoch_graphs[key] = {"sig": sig, "graph": None}
@@ -666,8 +684,13 @@ class TrainBase:
             raise ValueError("train must be 'controller' or 'dynamics'")
         running_loss = None
         i = -1
+        # (the concurrent epoch graph forks the next batch's gather behind the
+        # reverse kernel: that is where it is free)
+        want_plan = self.prefetch_batches or (
+            self.train_mode == "concurrent" and self.trainloader is not None
+            and hasattr(self.trainloader, "epoch_order") and self._epoch_graph_ok())
         plan = (getattr(self, "prefetch_plan", lambda: None)()
-                if train == "controller" and self.prefetch_batches
+                if train == "controller" and want_plan
                 and hasattr(self.trainloader, "iter_indices") else None)
         if plan is not None:
             return self._finish_epoch(*self._graphed_epoch(

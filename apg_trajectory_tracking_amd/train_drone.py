@@ -208,13 +208,16 @@ class TrainDrone(TrainBase):
                 return None
             return (lambda index, out: F.quad_concurrent_prepare(
                         normed, states, in_ref, ref, index=index, out=out),
-                    lambda prepared, slot: self.train_concurrent_fused(
-                        None, None, None, None, prepared=prepared, slot=slot))
+                    lambda prepared, slot, after=None: self.train_concurrent_fused(
+                        None, None, None, None, prepared=prepared, slot=slot,
+                        after_reverse=after))
         if not self.recurrent_indexed_ok():
             return None
         return (lambda index, out: F.quad_recurrent_prepare(
                     states, in_ref, ref, index=index, out=out),
-                lambda prepared, slot: self.train_recurrent_model(
+                # (recurrent steps: the inputs are read by the products as well;
+                # the event stays where the loop recorded it - before the step)
+                lambda prepared, slot, after=None: self.train_recurrent_model(
                     None, None, None, None, prepared=prepared, slot=slot))
 
     def recurrent_indexed_ok(self):
@@ -232,7 +235,7 @@ class TrainDrone(TrainBase):
 
     def train_concurrent_fused(
         self, in_state, current_state, in_ref_states, ref_states, index=None,
-        probe=False, prepared=None, slot=0
+        probe=False, prepared=None, slot=0, after_reverse=None
     ):
         """scripts/train_base.py:198-204 + scripts/train_drone.py:175-203 with
         the policy inside the kernels (apg_quad_mlp_concurrent_fwd_bwd).
@@ -253,7 +256,8 @@ class TrainDrone(TrainBase):
             def compute():
                 return F.quad_concurrent_policy_grads(
                     n, None, None, None, None, self.delta_t,
-                    self.train_dynamics.params, prepared=prepared)
+                    self.train_dynamics.params, prepared=prepared,
+                    after_reverse=after_reverse)
             return self._graphed(("concurrent", prepared[1].shape[-1], "slot", slot),
                                  (), self._direct_parts(compute),
                                  volatile=tuple(prepared))

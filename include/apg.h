@@ -61,6 +61,7 @@ extern "C" {
 #define APG_VERSION_MINOR 1
 
 typedef void *apg_stream_t; /* hipStream_t */
+typedef void *apg_event_t;  /* hipEvent_t */
 
 enum { APG_LAYOUT_SOA = 0, APG_LAYOUT_AOS = 1, APG_LAYOUT_PACKED = 2 };
 
@@ -379,7 +380,11 @@ int apg_quad_mlp_concurrent_fwd_bwd(
  *   grads: where each parameter's gradient goes (12 device pointers, shapes of
  *     the policy's tensors; typically views of one flat buffer);
  *   workspace: apg_quad_mlp_step_workspace_floats() floats,
- *   partials:  apg_quad_mlp_step_partials_floats(B) floats. */
+ *   partials:  apg_quad_mlp_step_partials_floats(B) floats;
+ *   after_reverse: optional hipEvent_t recorded on `stream` once the reverse
+ *     kernel is enqueued - the last reader of acts / state0 / ref; a caller
+ *     that pipelines batches refills the next batch's buffers behind it while
+ *     the second stage and the optimizer run (NULL: none). */
 typedef struct ApgMlpPolicyGrads {
   float *w_s, *b_s;        /* [64][15], [64]  */
   float *conv_w, *conv_b;  /* [20][9][3], [20] */
@@ -394,7 +399,8 @@ int apg_quad_mlp_concurrent_step(
     const ApgQuadParams *params, const ApgQuadLossWeights *weights,
     const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
     float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
-    float *states, float *workspace, float *partials, apg_stream_t stream);
+    float *states, float *workspace, float *partials, apg_event_t after_reverse,
+    apg_stream_t stream);
 
 /* Batched closed-loop evaluation: the loop of
  * QuadEvaluator.follow_trajectory("rand") (scripts/evaluate_drone.py:81-194)

@@ -152,7 +152,7 @@ def test_concurrent_step_through_the_c_abi(dev):
             s0.data_ptr(), rf.data_ptr(), rf.shape[1], DT, ctypes.byref(dyn.params),
             ctypes.byref(w), ctypes.byref(pol), batch, H, acts.data_ptr(),
             mask.data_ptr(), dz.data_ptr(), lp.data_ptr(), loss.data_ptr(),
-            ctypes.byref(grads_struct), None, ws.data_ptr(), part.data_ptr(), None)
+            ctypes.byref(grads_struct), None, ws.data_ptr(), part.data_ptr(), None, None)
     torch.cuda.synchronize()
     assert call(B) == 0
     torch.cuda.synchronize()
@@ -169,4 +169,4 @@ def test_concurrent_step_through_the_c_abi(dev):
         s0.data_ptr(), rf.data_ptr(), 7, DT, ctypes.byref(dyn.params), ctypes.byref(w),
         ctypes.byref(pol), B, H, acts.data_ptr(), mask.data_ptr(), dz.data_ptr(),
         lp.data_ptr(), loss.data_ptr(), ctypes.byref(gs), None, ws.data_ptr(),
-        part.data_ptr(), None) == -1
+        part.data_ptr(), None, None) == -1
