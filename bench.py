@@ -492,17 +492,22 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
 
 def run_epoch_probe(args, dev, dyn):
     """what TrainBase.run_epoch runs (scripts/train_base.py:
-    188-218), timed as it is: a resident data set of 16 x B trajectories,
+    188-218), timed as it is: a resident data set of 32 x B trajectories,
     shuffled index batches of B = 65 536 (device-side permutation, the gather
     folded into the fused step's layout change), every step through the real
     trainer method, the loss accumulated on the device and read back once per
-    epoch.  Eager launches and graph replays (the default since round 4: one
-    captured step per batch size, the index batch copied into a persistent
-    buffer the captured gather reads).  ms per BATCH, host clock around whole
+    epoch (the reference's `loss.item()` per batch became one `.item()` per
+    epoch; it is still a synchronisation per epoch, amortised over the epoch's
+    32 batches here - the reference's own configuration has 62 per epoch).
+    Eager launches, and the default since round 4: graphs - the first epoch
+    per-step graphs, from the second on ONE graph per epoch (`graph_epochs`:
+    a fresh permutation is copied into the buffer the captured gathers read;
+    in the concurrent mode the next batch's gather runs behind the reverse
+    kernel of the current one).  ms per BATCH, host clock around whole
     epochs."""
     import contextlib
     from apg_trajectory_tracking_amd.train_drone import TrainDrone
-    H, B, nb = args.horizon, args.batch, 16
+    H, B, nb = args.horizon, args.batch, 32
     out = {"batches_per_epoch": nb, "batch": B,
            "what": "TrainDrone.run_epoch('controller'): shuffled index batches, "
                    "fused step per batch, one loss read-back per epoch"}
@@ -521,7 +526,8 @@ def run_epoch_probe(args, dev, dyn):
                 for graphed in (False, True):
                     t.graph_steps = graphed
                     t._graphs.clear()
-                    t.run_epoch("controller", 0)          # warm-up / capture
+                    t.run_epoch("controller", 0)          # warm-up (eager epoch)
+                    t.run_epoch("controller", 0)          # capture of the epoch graph
                     torch.cuda.synchronize()
                     epochs = 3
                     t0 = time.perf_counter()
@@ -532,6 +538,8 @@ def run_epoch_probe(args, dev, dyn):
                     res["ms_per_batch" if graphed else "ms_per_batch_eager"] = ms
                 res["env_steps_per_s"] = B * H / (res["ms_per_batch"] * 1e-3)
                 res["graphs"] = sorted(str(k) for k in t._graphs)
+                res["epoch_graphs"] = sorted(
+                    str(k) for k, v in t._epoch_graphs.items() if v.get("graph") is not None)
             del t
         except Exception as e:      # secondary block
             res = {"error": repr(e)}
