@@ -85,6 +85,19 @@ class ApgMlpPolicyGrads(ctypes.Structure):
     _fields_ = ApgMlpPolicy._fields_
 
 
+class ApgStepEvents(ctypes.Structure):
+    """hipEvent_t handles a pipelined caller hands to the training step."""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "inputs_ready", "after_forward", "after_reverse")]
+
+
+class ApgMlpSgdUpdate(ctypes.Structure):
+    """apg_quad_mlp_concurrent_train_step's optimizer part: momentum SGD on
+    the policy's tensors and the optimizer's momentum buffers."""
+    _fields_ = [("lr", ctypes.c_double), ("momentum", ctypes.c_double),
+                ("param", ApgMlpPolicyGrads), ("momentum_buf", ApgMlpPolicyGrads)]
+
+
 class ApgWingPolicy(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "w_s", "b_s", "w_r", "b_r", "w_1", "b_1", "w_2", "b_2", "w_3", "b_3",
@@ -166,6 +179,11 @@ SIGNATURES = {
         _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
         _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P, _P, _P],
+    "apg_quad_mlp_concurrent_train_step": [
+        _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
+        _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P,
+        ctypes.POINTER(ApgMlpSgdUpdate), ctypes.POINTER(ApgStepEvents), _P],
     "apg_quad_mlp_closed_loop": [
         _P, _I, _F, ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgMlpPolicy),
         _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],

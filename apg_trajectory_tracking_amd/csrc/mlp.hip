@@ -1821,6 +1821,12 @@ __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, 
 struct WgReduceArgs {
   const float *part;   // level 2's source: chunk sums, or the partials themselves
   ApgMlpPolicyGrads g;
+  // optimizer step inside the second stage (apg_quad_mlp_concurrent_train_step):
+  // the thread that has summed a gradient element also owns the parameter and
+  // its momentum entry
+  ApgMlpPolicyGrads param, mom;
+  double lr, momentum;
+  bool update;
   const float *loss_partials;
   float *loss;
   int wgs, n_partials;   // wgs: how many [kSlots * 1024] rows `part` has
@@ -1860,6 +1866,15 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
         for (int w = 0; w < kRedChunk; ++w) s += v[w];
       }
       *dst = s;
+      if (A.update) {   // torch.optim.SGD: buf = momentum buf + grad, p -= lr buf
+        float *pp = wg_dest(A.param, slot, i, lane), *pm = wg_dest(A.mom, slot, i, lane);
+        // (in double with one rounding each, as torch's fused SGD kernel does
+        // it: a trainer that steps through optimizer.step() - the multi-rank
+        // form - gets the same bits)
+        const float buf = (float)(A.momentum * (double)*pm + (double)s);
+        *pm = buf;
+        *pp = (float)((double)*pp - A.lr * (double)buf);
+      }
     }
   }
   if (blockIdx.x == 0 && A.loss) {   // fixed-shape sum of the loss partials
@@ -2126,6 +2141,13 @@ long long apg_quad_mlp_step_partials_floats(int B) {
   return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlots * 1024;
 }
 
+namespace {
+bool all_set(const ApgMlpPolicyGrads &g) {
+  return g.w_s && g.b_s && g.conv_w && g.conv_b && g.w_1 && g.b_1 && g.w_2 && g.b_2 &&
+         g.w_3 && g.b_3 && g.w_out && g.b_out;
+}
+}  // namespace
+
 int apg_quad_mlp_concurrent_step(
     const float *state0, const float *ref, int ref_cols, float dt,
     const ApgQuadParams *params, const ApgQuadLossWeights *weights,
@@ -2133,20 +2155,45 @@ int apg_quad_mlp_concurrent_step(
     float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
     float *states, float *workspace, float *partials, apg_event_t after_reverse,
     apg_stream_t stream) {
+  ApgStepEvents ev = {nullptr, nullptr, after_reverse};
+  return apg_quad_mlp_concurrent_train_step(
+      state0, ref, ref_cols, dt, params, weights, policy, B, H, acts, relu_mask, d_zout,
+      loss_partials, loss, grads, states, workspace, partials, nullptr, &ev, stream);
+}
+
+int apg_quad_mlp_concurrent_train_step(
+    const float *state0, const float *ref, int ref_cols, float dt,
+    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+    const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
+    float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
+    float *states, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
+    const ApgStepEvents *events, apg_stream_t stream) {
   if (int e = check_mlp(params, policy, B, H)) return e;
+  if (update && (!all_set(update->param) || !all_set(update->momentum_buf))) {
+    set_error("update: parameter / momentum pointer is NULL");
+    return APG_ERR_ARG;
+  }
+  if (update && !(update->lr == update->lr && update->momentum == update->momentum)) {
+    set_error("update: lr / momentum is NaN");
+    return APG_ERR_ARG;
+  }
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
   if (ref_cols != 9 && ref_cols != 6) {
     set_error("ref_cols must be 9 or 6");
     return APG_ERR_ARG;
   }
-  if (!grads || !grads->w_s || !grads->b_s || !grads->conv_w || !grads->conv_b ||
-      !grads->w_1 || !grads->b_1 || !grads->w_2 || !grads->b_2 || !grads->w_3 ||
-      !grads->b_3 || !grads->w_out || !grads->b_out) {
+  if (!grads || !all_set(*grads)) {
     set_error("gradient pointer is NULL");
     return APG_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
+    // (an update with zero gradients would still move the parameters by the
+    // decaying momentum: not implemented)
+    if (update) {
+      set_error("update with B = 0 is not supported");
+      return APG_ERR_ARG;
+    }
     // no trajectory: zero gradients, zero loss
     const ApgMlpPolicyGrads &g = *grads;
     float *ptrs[12] = {g.w_s, g.b_s, g.conv_w, g.conv_b, g.w_1, g.b_1,
@@ -2192,8 +2239,16 @@ int apg_quad_mlp_concurrent_step(
   const int fwd_blocks = (kCfLds + 255) / 256, bwd_blocks = (kWgTabFloats + 255) / 256;
   hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks), dim3(256), 0, st,
                      P, fwd_blocks);
+  // (the tables are packed while the caller's producer of acts / state0 / ref -
+  // a gather on another stream - may still be running)
+  if (events && events->inputs_ready &&
+      hipStreamWaitEvent(st, (hipEvent_t)events->inputs_ready, 0) != hipSuccess)
+    return check_launch("hipStreamWaitEvent(inputs_ready)");
   hipLaunchKernelGGL(mlp_concurrent_fwd_kernel, dim3(blocks), dim3(kThreads),
                      kCfLds * sizeof(float), st, A);
+  if (events && events->after_forward &&
+      hipEventRecord((hipEvent_t)events->after_forward, st) != hipSuccess)
+    return check_launch("hipEventRecord(after_forward)");
   WgArgs W;
   W.acts = acts, W.mask = relu_mask, W.d_zout = d_zout, W.part = partials;
   W.tables = workspace + kCfLds, W.B = B;
@@ -2202,11 +2257,15 @@ int apg_quad_mlp_concurrent_step(
   // the inputs (activation planes, state0, ref) are not read past this point:
   // a caller that pipelines batches may start refilling the NEXT batch's
   // buffers behind this event while the second stage and the update run
-  if (after_reverse && hipEventRecord((hipEvent_t)after_reverse, st) != hipSuccess)
+  if (events && events->after_reverse &&
+      hipEventRecord((hipEvent_t)events->after_reverse, st) != hipSuccess)
     return check_launch("hipEventRecord(after_reverse)");
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
+  R.update = update != nullptr;
+  R.param = update ? update->param : *grads, R.mom = update ? update->momentum_buf : *grads;
+  R.lr = update ? update->lr : 0.0, R.momentum = update ? update->momentum : 0.0;
   if (blocks > kRedChunk) {
     const int chunks = (blocks + kRedChunk - 1) / kRedChunk;
     float *chunk_sums = partials + (size_t)blocks * kSlots * 1024;

@@ -1532,6 +1532,15 @@ def wing_mlp_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
 
 
 # --------------------------- concurrent mode with the policy inside (config 2)
+def _step_events(events):
+    """{"inputs_ready" | "after_forward" | "after_reverse": torch.cuda.Event}
+    -> ApgStepEvents* (or None)."""
+    if not events:
+        return None
+    return ctypes.byref(_capi.ApgStepEvents(**{
+        k: getattr(e, "cuda_event", None) for k, e in events.items() if e is not None}))
+
+
 class _QuadConcurrentPolicyLoss(torch.autograd.Function):
     """loss of the concurrent training step with `Net(15, 10, 9, 40, conv=1)`
     inside the kernels (apg_quad_mlp_concurrent_fwd_bwd): policy once per
@@ -1591,13 +1600,30 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
             d_zout = new(40, B)
             ws = new(lib().apg_quad_mlp_step_workspace_floats())
             part = new(max(1, lib().apg_quad_mlp_step_partials_floats(B)))
-            check(lib().apg_quad_mlp_concurrent_step(
+            upd = None
+            update = getattr(ctx, "update", None)
+            if update is not None:
+                # the optimizer inside the second stage: momentum SGD on the
+                # very tensors the policy struct points at
+                lr, momentum, bufs = update
+                if B == 0 or any(pw[k].data_ptr() != v.data_ptr() for k, v in zip(names, (
+                        w_s, b_s, conv_w, conv_b, w_1, b_1, w_2, b_2, w_3, b_3,
+                        w_out, b_out))):
+                    raise ValueError("in-kernel update needs a non-empty batch and "
+                                     "contiguous float32 parameters")
+                require_device(*bufs.values())
+                upd = ctypes.byref(_capi.ApgMlpSgdUpdate(
+                    lr=float(lr), momentum=float(momentum),
+                    param=_capi.ApgMlpPolicyGrads(**{k: ptr(v) for k, v in pw.items()}),
+                    momentum_buf=_capi.ApgMlpPolicyGrads(**{
+                        k: ptr(bufs[n]) for k, n in zip(names, _MLP_PARAMS)})))
+            check(lib().apg_quad_mlp_concurrent_train_step(
                 ptr(s0), ptr(rf), rf.shape[1], float(dt), ctypes.byref(params),
                 ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(acts),
                 relu_mask.data_ptr(), ptr(d_zout), ptr(partials), ptr(loss),
-                ctypes.byref(gs), None, ptr(ws), ptr(part),
-                getattr(getattr(ctx, "after_reverse", None), "cuda_event", None),
-                stream_of(s0)), "apg_quad_mlp_concurrent_step")
+                ctypes.byref(gs), None, ptr(ws), ptr(part), upd,
+                _step_events(getattr(ctx, "events", None)),
+                stream_of(s0)), "apg_quad_mlp_concurrent_train_step")
             ctx.flat_grads = (flat, gr)
             ctx.save_for_backward(acts)
             return loss.reshape(())
@@ -1684,7 +1710,7 @@ def _net_params(net, names):
 
 def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
                                  weights=None, index=None, static_inputs=False,
-                                 prepared=None, after_reverse=None):
+                                 prepared=None, events=None, update=None):
     """quad_concurrent_policy_loss + its parameter gradients, without autograd:
     returns (loss, {parameter name: gradient}, flat); the gradients are
     contiguous views of the flat buffer (no per-parameter clone as
@@ -1696,11 +1722,21 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
     tensor objects (its resident shard) - their plane-layout copies are kept
     while the tensors stay unchanged (_StaticPlanes).  `prepared`: the result
     of quad_concurrent_prepare for this batch (the four tensors are then
-    unused and may be None).  `after_reverse`: a torch.cuda.Event recorded once
-    the reverse kernel - the last reader of the inputs - is enqueued (in-sweep
-    path only; run_epoch refills the next batch's buffers behind it)."""
+    unused and may be None).  `events`: torch.cuda.Events of a pipelined caller,
+    {"inputs_ready": waited on before the forward kernel, "after_forward" /
+    "after_reverse": recorded once that kernel is enqueued} (include/apg.h,
+    ApgStepEvents; in-sweep path only; run_epoch issues the next batch's gather
+    behind one of them).
+    `update` = (lr, momentum, {parameter name: momentum buffer}): the step also
+    APPLIES torch.optim.SGD's update (buf = momentum buf + grad, p -= lr buf)
+    to the network's parameters and these buffers, inside the second stage
+    (apg_quad_mlp_concurrent_train_step; in-sweep path, one process)."""
     ctx = _DirectCtx()
-    ctx.after_reverse = after_reverse
+    ctx.events = events
+    if update is not None:
+        if not CONCURRENT_IN_SWEEP:
+            raise ValueError("update needs the in-sweep path")
+        ctx.update = update
     if prepared is not None:
         ctx.prepared = prepared
     elif static_inputs and index is None:

@@ -159,6 +159,31 @@ class _GraphedStep:
         return self.out.clone()
 
 
+class _EpochLoss:
+    """The running loss of an epoch, kept on the device.  `fresh`: every step
+    hands out a loss tensor of its own (eager launches - also the ones being
+    captured into an epoch graph): the tensors are collected and summed by ONE
+    launch at the end of the epoch.  Otherwise the loss is the replayed step
+    graph's output buffer, overwritten by the next replay: it is added to the
+    running sum at once."""
+
+    def __init__(self, fresh):
+        self.fresh, self.items, self.running = fresh, [], None
+
+    def add(self, loss):
+        if self.fresh:
+            self.items.append(loss.reshape(()))
+        elif self.running is None:
+            self.running = loss.clone()
+        else:
+            self.running.add_(loss)
+
+    def total(self):
+        if self.fresh and self.items:
+            return torch.stack(self.items).sum(dtype=torch.float64)
+        return self.running
+
+
 class _NullWriter:
     """Stand-in for the reference's `self.writer` (scripts/train_base.py:8-22,
     116: a tensorboard SummaryWriter, or a shim whose `add_scalar` does nothing
@@ -248,6 +273,22 @@ class TrainBase:
         # at ~0.21 ms per batch, had become the bound of run_epoch).
         self.graph_epochs = True
         self._epoch_graphs = {}
+        # True: a graphed step returns the captured loss buffer itself - valid
+        # until the NEXT step overwrites it (run_epoch's loops take it that
+        # way) - instead of a private copy, which is one more launch behind
+        # every replay (~14 us per step at the concurrent step's size)
+        self.borrow_loss = False
+        # which of the step's events the next batch's gather is issued behind
+        # (_pipelined_epoch, late fork): "after_forward" | "after_reverse" |
+        # "before" (the step's first launch).  Measured inside the epoch graph
+        # at 32 batches of 65 536 (tools/time_run_epoch.py, three runs each):
+        # 0.174-0.176 | 0.179-0.181 | 0.192-0.194 ms per batch - behind the
+        # forward kernel the gather trickles through the reverse kernel's 69 us
+        # without slowing it and is nearly done when the second stage starts
+        self.gather_fork = "after_forward"
+        # one process, plain momentum SGD: the concurrent step applies the
+        # optimizer's update inside its second-stage kernel (_in_kernel_update)
+        self.in_kernel_update = True
         self._in_epoch_capture = False
 
         # horizon / reference-window length (scripts/train_base.py:118-128)
@@ -305,7 +346,38 @@ class TrainBase:
         self.optimizer_controller.step()
         return loss
 
-    def _step_direct(self, loss, named_grads, flat=None):
+    def _in_kernel_update(self, available=True):
+        """(lr, momentum, {name: momentum buffer}) when the fused step may apply
+        the optimizer's update itself (`in_kernel_update`, one process, the
+        optimizer is plain momentum SGD as init_optimizer builds it, float32
+        contiguous parameters) - else None: the step is followed by
+        optimizer.step().  Missing momentum buffers are created as zeros, which
+        is what SGD's first step assumes (buf = grad = momentum * 0 + grad)."""
+        from . import functional as F
+        opt = self.optimizer_controller
+        if (not available or not getattr(self, "in_kernel_update", True)
+                or self._reducing() or type(opt) is not optim.SGD
+                or len(opt.param_groups) != 1):
+            return None
+        g = opt.param_groups[0]
+        if (not g["momentum"] or g["dampening"] or g["nesterov"] or g["weight_decay"]
+                or g.get("maximize")):
+            return None
+        named = dict(self.net.named_parameters())
+        listed = {id(p) for p in g["params"]}
+        bufs = {}
+        for name in F._MLP_PARAMS:
+            p = named.get(name)
+            if (p is None or id(p) not in listed or not p.is_cuda or not p.requires_grad
+                    or p.dtype != torch.float32 or not p.is_contiguous()):
+                return None
+            st = opt.state[p]
+            if st.get("momentum_buffer") is None:
+                st["momentum_buffer"] = torch.zeros_like(p)
+            bufs[name] = st["momentum_buffer"]
+        return float(g["lr"]), float(g["momentum"]), bufs
+
+    def _step_direct(self, loss, named_grads, flat=None, stepped=False):
         """_step for the fused-policy paths: the kernels already produced the
         parameter gradients (contiguous views of one flat buffer), so they are
         attached as `.grad` directly - no autograd tape, no per-parameter
@@ -321,7 +393,8 @@ class TrainBase:
                 loss = flat[-1].clone()
             elif self.grad_sync is not None:
                 loss = self.grad_sync.sync(loss.detach())
-        self.optimizer_controller.step()
+        if not stepped:      # (stepped: the kernels have applied the update)
+            self.optimizer_controller.step()
         return loss
 
     def _graphable(self):
@@ -359,6 +432,9 @@ class TrainBase:
                 + tuple((t.data_ptr(), tuple(t.shape)) for t in volatile)
                 # a replaced network or optimizer must not replay the old graph
                 + tuple(id(p) for p in self.net.parameters())
+                # (load_state_dict replaces the momentum buffers)
+                + tuple(getattr(st.get("momentum_buffer"), "data_ptr", int)()
+                        for st in opt.state.values())
                 + (id(opt), hyper, phys, float(self.delta_t),
                    float(self.delta_t_train), self._reducing()))
 
@@ -407,9 +483,9 @@ class TrainBase:
             g.signature = self._graph_signature(inputs, volatile)
             if cache is not None:
                 cache[key] = g.signature
-        return g(borrow=getattr(self, "_borrow_loss", False))
+        return g(borrow=getattr(self, "_borrow_loss", False) or self.borrow_loss)
 
-    def _direct_parts(self, compute):
+    def _direct_parts(self, compute, stepped=False):
         """(part_a, part_b) of a fused-policy step: compute() -> (loss,
         {name: gradient}, flat) as the functional `*_grads` entry points
         return them; the gradients are attached as `.grad` directly."""
@@ -434,7 +510,8 @@ class TrainBase:
                 loss = msg[-1]
             else:
                 loss = self.grad_sync.unpack()
-            self.optimizer_controller.step()
+            if not stepped:
+                self.optimizer_controller.step()
             return loss
         return part_a, part_b
 
@@ -563,6 +640,8 @@ class TrainBase:
         st.setdefault("slots", {})
         side = st["stream"]
         late = self._in_epoch_capture or not self._graphable()
+        import inspect
+        takes_events = "events" in inspect.signature(step).parameters
         side.wait_stream(main)       # the permutation, the data set's last update
 
         def issue(i, index, behind=None):
@@ -578,7 +657,7 @@ class TrainBase:
         batches = enumerate(self.trainloader.iter_indices() if indices is None else indices)
         cur = next(batches, None)
         slot = issue(*cur) if cur is not None else None
-        running, i = None, -1
+        running, i = _EpochLoss(fresh=not self._graphable()), -1
         self._borrow_loss = True     # the loss is consumed right here
         self._epoch_sigs = {}        # nothing a capture depends on changes in here
         try:
@@ -588,20 +667,31 @@ class TrainBase:
                 nxt_slot = None
                 if nxt is not None and not late:
                     nxt_slot = issue(*nxt)
-                main.wait_event(slot["ready"])
-                after = None
-                if late:
+                if late and takes_events:
+                    # the step waits for its planes itself - after its pack
+                    # launch - and records where the next gather may start
                     after = torch.cuda.Event()
                     after.record(main)       # (creates the handle the step re-records)
-                loss = step(slot["bufs"], i & 1, after).detach()
+                    events = {"inputs_ready": slot["ready"]}
+                    if self.gather_fork != "before":
+                        events[self.gather_fork] = after
+                    loss = step(slot["bufs"], i & 1, events)
+                else:
+                    main.wait_event(slot["ready"])
+                    after = None
+                    if late:
+                        after = torch.cuda.Event()
+                        after.record(main)
+                    loss = step(slot["bufs"], i & 1)
+                loss = loss.detach()
                 slot["freed"] = main.record_event()
                 if nxt is not None and late:
                     nxt_slot = issue(*nxt, behind=after)
-                running = loss.clone() if running is None else running.add_(loss)
+                running.add(loss)
                 cur, slot = nxt, nxt_slot
         finally:
             self._borrow_loss, self._epoch_sigs = False, None
-        return running, i
+        return running.total(), i
 
     def _indexed_epoch(self, step, indices=None):
         """One epoch of `step(index)` over the loader's index batches (the
@@ -610,16 +700,15 @@ class TrainBase:
         graph signatures are computed once per key, the step's loss is taken
         without a private copy and added to the running loss in place.
         Returns (running_loss, last batch index)."""
-        running, i = None, -1
+        running, i = _EpochLoss(fresh=not self._graphable()), -1
         self._borrow_loss, self._epoch_sigs = True, {}
         try:
             for i, index in enumerate(
                     self.trainloader.iter_indices() if indices is None else indices, 0):
-                loss = step(index).detach()
-                running = loss.clone() if running is None else running.add_(loss)
+                running.add(step(index).detach())
         finally:
             self._borrow_loss, self._epoch_sigs = False, None
-        return running, i
+        return running.total(), i
 
     def _epoch_graph_ok(self):
         ld = self.trainloader
@@ -646,8 +735,13 @@ class TrainBase:
                + (ld.batch_size, ld.shuffle))
         eg = self._epoch_graphs.get(key)
         if eg is None or eg["sig"] != sig:
-            self._epoch_graphs[key] = {"sig": sig, "graph": None}
-            return loop(ld.iter_indices(order=order))
+            self._epoch_graphs[key] = eg = {"sig": sig, "graph": None}
+            out = loop(ld.iter_indices(order=order))
+            # (the first steps create what the signature also covers: the
+            # optimizer's momentum buffers)
+            eg["sig"] = (self._graph_signature(ld.tensors, (ld.tensors[0],))
+                         + (ld.batch_size, ld.shuffle))
+            return out
         if eg["graph"] is None:
             import gc
             perm = torch.empty_like(order)

@@ -208,16 +208,17 @@ class TrainDrone(TrainBase):
                 return None
             return (lambda index, out: F.quad_concurrent_prepare(
                         normed, states, in_ref, ref, index=index, out=out),
-                    lambda prepared, slot, after=None: self.train_concurrent_fused(
+                    # (takes the loop's events: ApgStepEvents)
+                    lambda prepared, slot, events=None: self.train_concurrent_fused(
                         None, None, None, None, prepared=prepared, slot=slot,
-                        after_reverse=after))
+                        events=events))
         if not self.recurrent_indexed_ok():
             return None
         return (lambda index, out: F.quad_recurrent_prepare(
                     states, in_ref, ref, index=index, out=out),
                 # (recurrent steps: the inputs are read by the products as well;
                 # the event stays where the loop recorded it - before the step)
-                lambda prepared, slot, after=None: self.train_recurrent_model(
+                lambda prepared, slot: self.train_recurrent_model(
                     None, None, None, None, prepared=prepared, slot=slot))
 
     def recurrent_indexed_ok(self):
@@ -235,7 +236,7 @@ class TrainDrone(TrainBase):
 
     def train_concurrent_fused(
         self, in_state, current_state, in_ref_states, ref_states, index=None,
-        probe=False, prepared=None, slot=0, after_reverse=None
+        probe=False, prepared=None, slot=0, events=None
     ):
         """scripts/train_base.py:198-204 + scripts/train_drone.py:175-203 with
         the policy inside the kernels (apg_quad_mlp_concurrent_fwd_bwd).
@@ -252,14 +253,18 @@ class TrainDrone(TrainBase):
             return ok
         if not ok:
             return None
+        # one process: the optimizer's update happens inside the step's second
+        # stage (no separate SGD launch); more ranks: after the all-reduce
+        update = self._in_kernel_update(F.CONCURRENT_IN_SWEEP)
+        stepped = update is not None
         if prepared is not None:
             def compute():
                 return F.quad_concurrent_policy_grads(
                     n, None, None, None, None, self.delta_t,
                     self.train_dynamics.params, prepared=prepared,
-                    after_reverse=after_reverse)
+                    events=events, update=update)
             return self._graphed(("concurrent", prepared[1].shape[-1], "slot", slot),
-                                 (), self._direct_parts(compute),
+                                 (), self._direct_parts(compute, stepped),
                                  volatile=tuple(prepared))
         tensors = (in_state, current_state, in_ref_states, ref_states)
         held = None if index is None else self._graph_index(index)
@@ -270,13 +275,14 @@ class TrainDrone(TrainBase):
             return F.quad_concurrent_policy_grads(
                 n, in_state, current_state, in_ref_states, ref_states, self.delta_t,
                 self.train_dynamics.params, index=index,
-                static_inputs=self.static_shard)
+                static_inputs=self.static_shard, update=update)
         if held is not None:
             return self._graphed(("concurrent", held.numel()), tensors,
-                                 self._direct_parts(compute), volatile=(held,))
+                                 self._direct_parts(compute, stepped), volatile=(held,))
         if index is None and self.static_shard:
-            return self._graphed("concurrent", tensors, self._direct_parts(compute))
-        return self._step_direct(*compute())
+            return self._graphed("concurrent", tensors,
+                                 self._direct_parts(compute, stepped))
+        return self._step_direct(*compute(), stepped=stepped)
 
     # ------------------------------------------- packed (row-layout) path --
     # scripts/train_base.py:198-209 + scripts/train_drone.py:175-203 for ANY

@@ -416,7 +416,13 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
     else:
         step = lambda: t.train_recurrent_model(
             None, Shard.states, Shard.in_ref_states, Shard.ref_states)
+    # the loss of a graphed step is taken as run_epoch's loops take it: the
+    # captured output buffer, valid until the next step (`borrow_loss`); a
+    # private copy per step is one more launch behind every replay
+    # (`ms_per_step_private_loss`)
+    t.borrow_loss = True
     ms, total, chunks = timed_steps(step, args.train_steps, dist)
+    total = total.clone()
     n_params = sum(p.numel() for p in t.net.parameters() if p.requires_grad)
     out = {
         "ms_per_step": ms,
@@ -428,11 +434,22 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
         "launch": ("one captured HIP graph per step" if world == 1 else
                    "two captured HIP graphs per step around the eager all-reduce"),
     }
+    if mode == "concurrent":
+        # one process: the optimizer's update is applied by the second stage of
+        # the step itself (apg_quad_mlp_concurrent_train_step); the split form
+        # below - what N > 1 runs - keeps optimizer.step() behind the all-reduce
+        out["optimizer_update"] = ("inside the step's second-stage kernel"
+                                   if t._in_kernel_update() is not None
+                                   else "optimizer.step() (fused torch SGD)")
     # like-for-like companions: the same step launched eagerly
     # (no graphs: what a multi-rank step was before round 4) and, on one rank,
     # in the split form the N > 1 step uses (graph A, empty all-reduce slot,
     # graph B) - a scaling curve compares `ms_per_step` at N with
     # `ms_per_step_split_graph` at 1
+    t.borrow_loss = False
+    out["ms_per_step_private_loss"], _, _ = timed_steps(
+        step, max(8, args.train_steps // 2), dist)
+    t.borrow_loss = True
     t.graph_steps = False
     out["ms_per_step_eager"], _, _ = timed_steps(step, max(8, args.train_steps // 2), dist)
     if world == 1:

@@ -402,6 +402,43 @@ int apg_quad_mlp_concurrent_step(
     float *states, float *workspace, float *partials, apg_event_t after_reverse,
     apg_stream_t stream);
 
+/* The same call with the optimizer inside: torch.optim.SGD(lr, momentum = 0.9)
+ * as the reference builds it (scripts/train_base.py:140-143) and applies it
+ * after loss.backward() (scripts/train_drone.py:200-203),
+ *     buf = momentum * buf + grad;   param -= lr * buf
+ * done by the second stage's threads right where they have summed a gradient
+ * element (one launch and one pass over the parameters less per step).
+ * `update->param` are the tensors `policy` points at (the pack launch at the
+ * head of the call has read them before they change), `update->momentum_buf`
+ * the optimizer's momentum buffers (all zero before the first step).  The
+ * gradients are still written to `grads`.  update NULL: no update, exactly
+ * apg_quad_mlp_concurrent_step.  Single-process training only: with more than
+ * one rank the gradients must be all-reduced BEFORE the update - call the
+ * plain step, reduce, then step the optimizer. */
+/* Stream events of a pipelined caller (each may be NULL; hipEvent_t):
+ *   inputs_ready   waited on (hipStreamWaitEvent) after the pack launch, before
+ *                  the forward kernel - the first reader of acts / state0 / ref:
+ *                  the producer of these buffers (a gather on another stream)
+ *                  may still be running while the tables are packed;
+ *   after_forward  recorded once the forward kernel is enqueued;
+ *   after_reverse  recorded once the reverse kernel - the last reader of the
+ *                  inputs - is enqueued (as apg_quad_mlp_concurrent_step's). */
+typedef struct ApgStepEvents {
+  apg_event_t inputs_ready, after_forward, after_reverse;
+} ApgStepEvents;
+typedef struct ApgMlpSgdUpdate {
+  double lr, momentum;     /* (torch's fused SGD computes in double, rounds once) */
+  ApgMlpPolicyGrads param;
+  ApgMlpPolicyGrads momentum_buf;
+} ApgMlpSgdUpdate;
+int apg_quad_mlp_concurrent_train_step(
+    const float *state0, const float *ref, int ref_cols, float dt,
+    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+    const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
+    float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
+    float *states, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
+    const ApgStepEvents *events, apg_stream_t stream);
+
 /* Batched closed-loop evaluation: the loop of
  * QuadEvaluator.follow_trajectory("rand") (scripts/evaluate_drone.py:81-194)
  * for B reference trajectories in one launch - per step the H-row reference

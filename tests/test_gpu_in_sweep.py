@@ -170,3 +170,72 @@ def test_concurrent_step_through_the_c_abi(dev):
         ctypes.byref(pol), B, H, acts.data_ptr(), mask.data_ptr(), dz.data_ptr(),
         lp.data_ptr(), loss.data_ptr(), ctypes.byref(gs), None, ws.data_ptr(),
         part.data_ptr(), None, None) == -1
+
+
+def test_train_step_through_the_c_abi(dev):
+    """apg_quad_mlp_concurrent_train_step: the gradients of the plain step,
+    then buf = momentum buf + grad, p -= lr buf on the parameter and momentum
+    tensors handed in - twice, against the same arithmetic in torch; NULL
+    pointers inside the update and B = 0 are argument errors."""
+    from apg_trajectory_tracking_amd import _capi, functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    lib = _capi.lib()
+    B, lr, mom = 900, 2e-6, 0.9
+    torch.manual_seed(12)
+    net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+    _, inputs = _case(B, 19, dev)
+    dyn = FlightmareDynamics()
+    F.CONCURRENT_IN_SWEEP = True
+    acts, s0, rf = F.quad_concurrent_prepare(*inputs)
+    new = lambda *s: torch.zeros(s, device=dev)
+    names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2", "w_3", "b_3",
+             "w_out", "b_out")
+    params = [p.detach() for p in F._net_params(net, F._MLP_PARAMS)]
+    struct = lambda ts: _capi.ApgMlpPolicyGrads(**{k: v.data_ptr() for k, v in zip(names, ts)})
+    pol = _capi.ApgMlpPolicy(**{k: v.data_ptr() for k, v in zip(names, params)})
+    grads, bufs = [new(*p.shape) for p in params], [new(*p.shape) for p in params]
+    gs = struct(grads)
+    upd = _capi.ApgMlpSgdUpdate(lr=lr, momentum=mom, param=struct(params),
+                                momentum_buf=struct(bufs))
+    mask = torch.empty(5, B, dtype=torch.int32, device=dev)
+    dz, lp = new(40, B), new(lib.apg_quad_mlp_loss_partials_count(B))
+    loss = new(1)
+    ws = new(lib.apg_quad_mlp_step_workspace_floats())
+    part = new(lib.apg_quad_mlp_step_partials_floats(B))
+    w = F.quad_loss_weights()
+
+    def call(batch, update):
+        return lib.apg_quad_mlp_concurrent_train_step(
+            s0.data_ptr(), rf.data_ptr(), rf.shape[1], DT, ctypes.byref(dyn.params),
+            ctypes.byref(w), ctypes.byref(pol), batch, H, acts.data_ptr(),
+            mask.data_ptr(), dz.data_ptr(), lp.data_ptr(), loss.data_ptr(),
+            ctypes.byref(gs), None, ws.data_ptr(), part.data_ptr(),
+            ctypes.byref(update) if update is not None else None, None, None)
+    want_p = [p.clone() for p in params]
+    want_m = [torch.zeros_like(p) for p in params]
+    for step in range(2):
+        # the gradients the step will see: the plain call on the current weights
+        torch.cuda.synchronize()
+        assert call(B, None) == 0
+        torch.cuda.synchronize()
+        g_now = [g.clone() for g in grads]
+        l_now = loss.item()
+        for p_, m_, g_ in zip(want_p, want_m, g_now):
+            m_.mul_(mom).add_(g_)
+            p_.sub_(lr * m_)
+        assert call(B, upd) == 0
+        torch.cuda.synchronize()
+        assert loss.item() == l_now
+        for k, g, g0, p, m, wp, wm in zip(F._MLP_PARAMS, grads, g_now, params, bufs, want_p,
+                                          want_m):
+            assert torch.equal(g, g0), k
+            assert torch.allclose(m, wm, rtol=1e-6, atol=1e-6 * float(wm.abs().max())), k
+            assert torch.allclose(p, wp, rtol=1e-6, atol=1e-9), k
+            assert not torch.equal(p, wp + lr * wm), k    # it moved
+    broken = _capi.ApgMlpSgdUpdate(lr=lr, momentum=mom, param=struct(params),
+                                   momentum_buf=struct(bufs))
+    broken.momentum_buf.b_3 = None
+    assert call(B, broken) == -1 and b"update" in lib.apg_last_error_string()
+    assert call(0, upd) == -1 and b"B = 0" in lib.apg_last_error_string()

@@ -1332,6 +1332,7 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
     from apg_trajectory_tracking_amd.models.hutter_model import Net
     from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
     from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    from apg_trajectory_tracking_amd.train_base import momentum_sgd
     B, H = 300, 10
     cfg = dict(QUAD_CFG, train_mode=mode, batch_size=B, learning_rate_controller=1e-7)
     R = H if mode == "concurrent" else 2 * H
@@ -1347,8 +1348,7 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
         t = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
         t.net = type(proto)(15, H, 9, proto.fc_out.out_features, conv=1).to(dev)
         t.net.load_state_dict(proto.state_dict())
-        t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=1e-7,
-                                                 momentum=0.9)
+        t.optimizer_controller = momentum_sgd(t.net.parameters(), 1e-7)
         t.static_shard = static
         t.graph_steps = graph        # + the step replayed from a HIP graph
         t.split_graph = split        # ... as two graphs around the all-reduce slot
@@ -1450,6 +1450,75 @@ def test_graphed_step_follows_lr_and_physics_changes(dev):
     assert l_new == l_eager and abs(l_new - l0) / abs(l0) > 1e-4, (l0, l_new, l_eager)
     # a captured graph keeps the plane copies it reads alive past an eviction
     assert t._graphs["concurrent"].planes
+    F._STATIC_PLANES.entries.clear()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_in_kernel_update_is_the_optimizers_step(dev, graph):
+    """The concurrent step's second stage applies torch.optim.SGD's update
+    itself (apg_quad_mlp_concurrent_train_step) when one process trains:
+    parameters, momentum buffers and losses of four steps equal a trainer that
+    calls optimizer.step() after the same kernels; the optimizer's state_dict
+    is the one torch would hold; optimizers the kernel does not implement
+    (nesterov, weight decay, Adam) keep optimizer.step()."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    from apg_trajectory_tracking_amd.train_base import momentum_sgd
+    B, H = 1500, 10
+    cfg = dict(QUAD_CFG, train_mode="concurrent", batch_size=B)
+    d = synthetic.quad_polynomial_batch(B, H, 0.1, seed=23, ref_length=H)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    normed = state_preprocessing(s0)
+    torch.manual_seed(4)
+    proto = Net(15, H, 9, 40, conv=1)
+
+    def run(in_kernel, make_opt=None):
+        F._STATIC_PLANES.entries.clear()
+        t = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
+        t.net = Net(15, H, 9, 40, conv=1).to(dev)
+        t.net.load_state_dict(proto.state_dict())
+        t.optimizer_controller = (make_opt or (lambda ps: momentum_sgd(ps, 3e-6)))(
+            t.net.parameters())
+        t.static_shard, t.graph_steps, t.in_kernel_update = True, graph, in_kernel
+        losses = [t.train_concurrent_fused(normed, s0, in_ref, ref).item()
+                  for _ in range(4)]
+        return t, losses
+    a, la = run(True)
+    b, lb = run(False)
+    assert a._in_kernel_update() is not None and b._in_kernel_update() is None
+    assert la == lb, (la, lb)
+    assert la[3] < la[0]
+    moved = 0
+    # (the trainer's optimizer is torch's FUSED momentum SGD, whose arithmetic
+    # - double, one rounding - the kernel repeats: the same bits)
+    for (k, pa), (_, pb) in zip(a.net.named_parameters(), b.net.named_parameters()):
+        assert torch.equal(pa, pb), (k, float((pa - pb).abs().max()), float(pb.abs().max()))
+        if pa.grad is not None:
+            assert torch.equal(pa.grad, pb.grad), k
+            ma = a.optimizer_controller.state[pa]["momentum_buffer"]
+            mb = b.optimizer_controller.state[pb]["momentum_buffer"]
+            assert torch.equal(ma, mb), (k, float((ma - mb).abs().max()))
+            moved += int(not torch.equal(pa.detach().cpu(), proto.state_dict()[k]))
+    assert moved == 12
+    # the state survives a round trip through the optimizer's own format
+    sd = a.optimizer_controller.state_dict()
+    fresh = momentum_sgd(a.net.parameters(), 3e-6)
+    fresh.load_state_dict(sd)
+    a.optimizer_controller = fresh
+    l5 = a.train_concurrent_fused(normed, s0, in_ref, ref).item()
+    l5b = b.train_concurrent_fused(normed, s0, in_ref, ref).item()
+    assert l5 == l5b
+    # anything but plain momentum SGD: the optimizer object steps
+    for make in (lambda ps: torch.optim.SGD(ps, lr=3e-6, momentum=0.9, nesterov=True),
+                 lambda ps: torch.optim.SGD(ps, lr=3e-6, momentum=0.9, weight_decay=1e-3),
+                 lambda ps: torch.optim.SGD(ps, lr=3e-6),
+                 lambda ps: torch.optim.Adam(ps, lr=1e-5)):
+        c, lc = run(True, make)
+        assert c._in_kernel_update() is None and lc[1] != lc[0]
     F._STATIC_PLANES.entries.clear()
 
 

@@ -1,7 +1,7 @@
 """The real epoch loop (TrainDrone.run_epoch: shuffled index batches of
 B = 65 536 out of a resident data set, fused step per batch) for per-kernel
 profiling of what a BATCH costs beyond the step:
-    python tools/time_run_epoch.py concurrent|autoregressive|LSTM [graph|eager] [batches] [prefetch|noprefetch] [noepoch]
+    python tools/time_run_epoch.py concurrent|autoregressive|LSTM [graph|eager] [batches] [prefetch|noprefetch] [noepoch|epoch] [after_reverse|after_forward]
     rocprofv3 --kernel-trace --output-format csv -d out -- python tools/time_run_epoch.py ...
     python tools/trace_step.py out/*/*_kernel_trace.csv <first kernel of a batch>"""
 import contextlib
@@ -23,6 +23,7 @@ graph = not (len(sys.argv) > 2 and sys.argv[2] == "eager")
 nb = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 prefetch = not (len(sys.argv) > 4 and sys.argv[4] == "noprefetch")
 epoch_graph = not (len(sys.argv) > 5 and sys.argv[5] == "noepoch")
+fork = sys.argv[6] if len(sys.argv) > 6 else None
 cfg = dict(delta_t=dt, delta_t_train=dt, epoch_size=nb * B, self_play=0, batch_size=B,
            state_size=12, horizon=H, train_mode=mode, ref_dim=9, action_dim=4,
            learning_rate_controller=1e-9, system="quad", modified_params={},
@@ -35,6 +36,8 @@ with contextlib.redirect_stdout(sys.stderr):
     t.graph_steps = graph
     t.prefetch_batches = prefetch
     t.graph_epochs = epoch_graph
+    if fork:
+        t.gather_fork = fork
     t.run_epoch("controller", 0)     # (graph_epochs: eager epoch, then the capture)
     t.run_epoch("controller", 0)
     torch.cuda.synchronize()
@@ -45,4 +48,4 @@ with contextlib.redirect_stdout(sys.stderr):
     torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / (epochs * nb) * 1e3
 print(f'{{"mode": "{mode}", "graphed": {str(graph).lower()}, "prefetch": {str(prefetch).lower()}, "epoch_graph": {str(epoch_graph and graph).lower()}, "batches_per_epoch": {nb}, '
-      f'"ms_per_batch": {ms:.4f}}}')
+      f'"gather_fork": "{t.gather_fork}", "ms_per_batch": {ms:.4f}}}')
