@@ -90,5 +90,32 @@ def build(force=False, verbose=False):
     return LIB
 
 
+LIB_CPU = os.path.join(CSRC, "libapg_cpu.so")
+
+
+def build_cpu(force=False, verbose=False):
+    """libapg_cpu.so (include/apg_cpu.h): the per-trajectory headers of the
+    kernels compiled for the HOST behind the `..._cpu` twins of the dynamics
+    entry points.  A separate library that the package never loads."""
+    src = os.path.join(CSRC, "cpu_twins.hip")
+    deps = [src, os.path.join(REPO, "include", "apg_cpu.h"), __file__] + _headers()
+    if (not force and os.path.exists(LIB_CPU)
+            and os.path.getmtime(LIB_CPU) >= max(os.path.getmtime(d) for d in deps)):
+        return LIB_CPU
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # (-no-hip-rt: the library depends on libstdc++ / libm only - it loads on
+    # a machine without ROCm)
+    cmd = [hipcc, "--cuda-host-only", "-no-hip-rt", "-O2", "-std=c++17", "-fPIC",
+           "-shared",
+           "-I", os.path.join(REPO, "include"), "-I", CSRC, "-o", LIB_CPU, src]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc (host) failed on cpu_twins.hip:\n{r.stdout}")
+    return LIB_CPU
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_cpu(force="--force" in sys.argv, verbose=True))
