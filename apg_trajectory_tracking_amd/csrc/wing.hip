@@ -666,9 +666,12 @@ int apg_wing_rollout_fwd_bwd(const float *state0, const float *actions,
   A.prev = has_prev ? *deferred : ApgDeferredLoss{nullptr, 0, nullptr};
   A.B = B, A.H = H;
   // checkpoint stride: keep the stash of a wave <= 6 slots (18 KB) so that
-  // >= 8 waves fit a CU's 160 KB of LDS (APG_WING_STRIDE overrides, 1..4)
+  // >= 8 waves fit a CU's 160 KB of LDS.  (Stride sweeps: variant builds
+  // only, tools/build_wing_variant.sh - the product reads no environment.)
   int stride = (H + 5) / 6;
+#ifdef APG_EXPERIMENT_BUILD
   if (const char *e = getenv("APG_WING_STRIDE")) stride = atoi(e);
+#endif
   if (stride < 1) stride = 1;
   if (stride > kWingMaxStride) stride = kWingMaxStride;
   A.stride = stride;

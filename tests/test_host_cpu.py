@@ -780,6 +780,18 @@ def test_conv_gradient_from_window_diagonals():
     assert torch.allclose(P.sum((1, 2)), bias.grad, rtol=1e-10, atol=1e-10)
 
 
+def test_product_library_reads_no_environment():
+    """nothing in the environment may change what the shipped
+    kernels do - the library does not even import getenv (tuning knobs are
+    read by experiment builds only)."""
+    import subprocess
+    from apg_trajectory_tracking_amd import build
+    lib = build.build()
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True,
+                         text=True, check=True).stdout
+    assert "getenv" not in und
+
+
 def test_product_build_refuses_experiment_macros(monkeypatch):
     """Kernel-variant macros cannot reach the shipped library: build.py
     refuses them in APG_HIPCC_FLAGS, the sources #error on them unless the
