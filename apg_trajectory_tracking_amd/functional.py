@@ -1650,6 +1650,90 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         return (None, None, None, None, *[gr[k] for k in _MLP_PARAMS], None, None, None)
 
 
+class QuadConcurrentStepPlan:
+    """The concurrent training step of `Net(15, 10, 9, 40, conv=1)` with
+    everything around the launch made ONCE: scratch planes, the flat gradient
+    buffer, partials, the argument structs.  `launch()` is then one call into
+    apg_quad_mlp_concurrent_train_step (five kernel launches) and nothing else:
+    ~20 us of host time per step, so a Python loop keeps the GPU busy without
+    a captured graph - and without the ~6-14 us a graph replay costs between
+    two steps on this platform (tools/ab_graph_alternation.py).
+      prepared  (acts [521][B], state0 planes, ref planes): what
+                quad_concurrent_prepare returned - refilled in place by the
+                caller between launches when the batch changes;
+      update    (lr, momentum, {name: momentum buffer}) or None, as for
+                quad_concurrent_policy_grads.
+    Valid while the network's parameter tensors, `prepared`'s buffers, the
+    physics struct, dt and the optimizer settings are the ones given here
+    (TrainBase rebuilds it when its step signature changes).  The gradients are
+    views of `flat` (+ one slot for the loss), `named` by parameter name."""
+
+    def __init__(self, net, prepared, dt, params, weights=None, update=None):
+        if not CONCURRENT_IN_SWEEP:
+            raise ValueError("the step plan needs the in-sweep path")
+        acts, s0, rf = prepared
+        B, H = s0.shape[-1], 10
+        tensors = _net_params(net, _MLP_PARAMS)
+        shapes = {"states_in.weight": (64, 15), "conv_ref.weight": (20, 9, 3),
+                  "fc1.weight": (64, 224), "fc_out.weight": (40, 64)}
+        for n, t in zip(_MLP_PARAMS, tensors):
+            if n in shapes and tuple(t.shape) != shapes[n]:
+                raise ValueError("fused path needs Net(15, 10, 9, 40, conv=1)")
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("the step plan needs contiguous float32 parameters")
+        if B == 0:
+            raise ValueError("the step plan needs a non-empty batch")
+        require_device(acts, s0, rf, *tensors)
+        dev = s0.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
+                 "w_3", "b_3", "w_out", "b_out")
+        self.flat, self.named = _flat_grads(dev, {
+            n: tuple(t.shape) for n, t in zip(_MLP_PARAMS, tensors)})
+        self.loss = new(1)
+        self.loss0 = self.loss.reshape(())
+        # everything the launch reads or writes stays referenced from here
+        self._keep = dict(
+            prepared=prepared, tensors=[t.detach() for t in tensors],
+            relu_mask=torch.empty(5, B, dtype=torch.int32, device=dev),
+            partials=new(max(1, lib().apg_quad_mlp_loss_partials_count(B))),
+            d_zout=new(40, B), ws=new(lib().apg_quad_mlp_step_workspace_floats()),
+            part=new(max(1, lib().apg_quad_mlp_step_partials_floats(B))),
+            params=params, weights=weights or quad_loss_weights())
+        k = self._keep
+        k["pol"] = _capi.ApgMlpPolicy(**{a: ptr(t) for a, t in zip(names, k["tensors"])})
+        k["gs"] = _capi.ApgMlpPolicyGrads(**{
+            a: ptr(self.named[n]) for a, n in zip(names, _MLP_PARAMS)})
+        upd = None
+        if update is not None:
+            lr, momentum, bufs = update
+            require_device(*bufs.values())
+            k["bufs"] = bufs
+            k["upd"] = _capi.ApgMlpSgdUpdate(
+                lr=float(lr), momentum=float(momentum),
+                param=_capi.ApgMlpPolicyGrads(**{a: ptr(t) for a, t in
+                                                 zip(names, k["tensors"])}),
+                momentum_buf=_capi.ApgMlpPolicyGrads(**{
+                    a: ptr(bufs[n]) for a, n in zip(names, _MLP_PARAMS)}))
+            upd = ctypes.byref(k["upd"])
+        self.updates = update is not None
+        self._dev = dev
+        self._fn = lib().apg_quad_mlp_concurrent_train_step
+        self._args = (ptr(s0), ptr(rf), rf.shape[1], float(dt), ctypes.byref(params),
+                      ctypes.byref(k["weights"]), ctypes.byref(k["pol"]), B, H, ptr(acts),
+                      k["relu_mask"].data_ptr(), ptr(k["d_zout"]), ptr(k["partials"]),
+                      ptr(self.loss), ctypes.byref(k["gs"]), None, ptr(k["ws"]),
+                      ptr(k["part"]), upd)
+
+    def launch(self, events=None):
+        """Enqueue the step on the current stream; returns the loss (0-dim view
+        of the plan's loss buffer: overwritten by the next launch)."""
+        check(self._fn(*self._args, _step_events(events),
+                       torch.cuda.current_stream(self._dev).cuda_stream),
+              "apg_quad_mlp_concurrent_train_step")
+        return self.loss0
+
+
 # True: the concurrent step accumulates its weight gradients inside the reverse
 # kernel (csrc/mlp.hip, mlp_concurrent_bwd_wg_kernel); False: cotangent planes +
 # planes_gemm products (rounds 1-3; kept for comparison and as the planes API's

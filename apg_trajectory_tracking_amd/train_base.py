@@ -159,6 +159,32 @@ class _GraphedStep:
         return self.out.clone()
 
 
+class _PlannedStep:
+    """A fused step whose buffers, structs and arguments were made once
+    (functional.QuadConcurrentStepPlan): calling it is `before()` - the batch's
+    gather, if any - and ONE call into the library.  Lives in the trainer's
+    `_graphs` table under the key a captured graph of the same step would
+    have, with the same life cycle (rebuilt when the signature changes); it is
+    what a single-process concurrent step uses instead of a graph - nothing
+    is captured, the ~20 us the call costs the host keep the GPU busy, and the
+    idle gap between two graph replays is gone."""
+    capture, split, planned = False, False, True
+
+    def __init__(self, plan, net, before=None):
+        self.plan, self.before, self.signature = plan, before, None
+        self.grads = [(p, plan.named.get(name)) for name, p in net.named_parameters()]
+        from . import functional
+        self.planes = functional.static_plane_refs()
+
+    def __call__(self, borrow=False, events=None):
+        if self.before is not None:
+            self.before()
+        loss = self.plan.launch(events)
+        for p, g in self.grads:
+            p.grad = g
+        return loss if borrow else loss.clone()
+
+
 class _EpochLoss:
     """The running loss of an epoch, kept on the device.  `fresh`: every step
     hands out a loss tensor of its own (eager launches - also the ones being
@@ -273,6 +299,15 @@ class TrainBase:
         # at ~0.21 ms per batch, had become the bound of run_epoch).
         self.graph_epochs = True
         self._epoch_graphs = {}
+        # graphs only where the host is the bound: {train_mode: trajectories
+        # per rank and batch from which steps are launched eagerly}.  The
+        # autoregressive step at B = 65 536 is 1.1 ms of kernels against ~0.3 ms
+        # of host work per step; replayed from a graph (per step or per epoch)
+        # it is 2-4 % SLOWER than the same 19 kernels launched in stream order
+        # (1.125 against 1.086 ms, every box so far; per batch in run_epoch
+        # 1.134 against 1.098): the small-kernel tail of the step pays a graph
+        # node's heavier fences.  Break-even ~ 0.3 ms of kernels.
+        self.graph_batch_limit = {"autoregressive": 16384}
         # True: a graphed step returns the captured loss buffer itself - valid
         # until the NEXT step overwrites it (run_epoch's loops take it that
         # way) - instead of a private copy, which is one more launch behind
@@ -289,6 +324,10 @@ class TrainBase:
         # one process, plain momentum SGD: the concurrent step applies the
         # optimizer's update inside its second-stage kernel (_in_kernel_update)
         self.in_kernel_update = True
+        # ... and runs from a step plan instead of a captured graph: buffers
+        # and argument structs made once, one library call per step
+        # (_PlannedStep; needs graph_steps and the in-kernel update)
+        self.plan_steps = True
         self._in_epoch_capture = False
 
         # horizon / reference-window length (scripts/train_base.py:118-128)
@@ -400,8 +439,14 @@ class TrainBase:
     def _graphable(self):
         # (inside the capture of a whole epoch the steps run "eagerly": their
         # launches are what is being captured)
-        return (bool(self.graph_steps) and not self._in_epoch_capture
-                and (torch.cuda.is_available() or self.graph_emulation))
+        if not (bool(self.graph_steps) and not self._in_epoch_capture
+                and (torch.cuda.is_available() or self.graph_emulation)):
+            return False
+        # a step whose kernels outlast the host's launch work gains nothing
+        # from a graph - and loses 2-4 % on this platform (see graph_batch_limit)
+        limit = self.graph_batch_limit.get(self.train_mode)
+        per_rank = int(self.batch_size) // max(1, parallel.world_size())
+        return not (limit and per_rank >= limit)
 
     def _reducing(self):
         """The step has an all-reduce slot (real or, when forced, empty)."""
@@ -458,7 +503,7 @@ class TrainBase:
             if cache is not None:
                 cache[key] = sig
         g = self._graphs.get(key)
-        if g is None or g.signature != sig:
+        if g is None or getattr(g, "planned", False) or g.signature != sig:
             try:
                 g = _GraphedStep(
                     part_a, part_b, self._reduce, sig,
@@ -484,6 +529,30 @@ class TrainBase:
             if cache is not None:
                 cache[key] = g.signature
         return g(borrow=getattr(self, "_borrow_loss", False) or self.borrow_loss)
+
+    def _plannable(self):
+        """A single-process fused step may run from a step plan (_PlannedStep)
+        instead of a captured graph."""
+        return (bool(self.plan_steps) and self._graphable() and not self._reducing()
+                and torch.cuda.is_available())
+
+    def _planned(self, key, inputs, build, volatile=(), events=None):
+        """Run the step from its plan, (re)built by `build()` when the signature
+        of `_graphed` no longer holds (same meaning of `inputs` / `volatile`)."""
+        cache = getattr(self, "_epoch_sigs", None)
+        sig = cache.get(key) if cache is not None else None
+        if sig is None:
+            sig = self._graph_signature(inputs, volatile)
+            if cache is not None:
+                cache[key] = sig
+        g = self._graphs.get(key)
+        if not isinstance(g, _PlannedStep) or g.signature != sig:
+            g = self._graphs[key] = build()
+            g.signature = self._graph_signature(inputs, volatile)
+            if cache is not None:
+                cache[key] = g.signature
+        return g(borrow=getattr(self, "_borrow_loss", False) or self.borrow_loss,
+                 events=events)
 
     def _direct_parts(self, compute, stepped=False):
         """(part_a, part_b) of a fused-policy step: compute() -> (loss,

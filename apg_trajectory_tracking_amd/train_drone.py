@@ -23,7 +23,7 @@ from .dataset import SyntheticQuadDataset, state_preprocessing
 from .drone_loss import quad_mpc_loss
 from .models.hutter_model import Net
 from .models.rnn import LSTM_NEW
-from .train_base import TrainBase
+from .train_base import TrainBase, _PlannedStep
 
 
 class TrainDrone(TrainBase):
@@ -257,6 +257,42 @@ class TrainDrone(TrainBase):
         # stage (no separate SGD launch); more ranks: after the all-reduce
         update = self._in_kernel_update(F.CONCURRENT_IN_SWEEP)
         stepped = update is not None
+        planned = stepped and self._plannable()
+        dyn = self.train_dynamics
+        if planned and prepared is not None:
+            # (a slot of the pipelined epoch: its buffers are refilled by the
+            # loop's gather, the plan reads them by address)
+            return self._planned(
+                ("concurrent", prepared[1].shape[-1], "slot", slot), (),
+                lambda: _PlannedStep(F.QuadConcurrentStepPlan(
+                    n, prepared, self.delta_t, dyn.params, update=update), n),
+                volatile=tuple(prepared), events=events)
+        if planned and index is not None:
+            held = self._graph_index(index)       # persistent copy of the batch rows
+            B = held.numel()
+
+            def build():
+                out = F.quad_concurrent_prepare(in_state, current_state, in_ref_states,
+                                                ref_states, index=held)
+                gather = lambda: F.quad_concurrent_prepare(
+                    in_state, current_state, in_ref_states, ref_states, index=held,
+                    out=out)
+                return _PlannedStep(F.QuadConcurrentStepPlan(
+                    n, out, self.delta_t, dyn.params, update=update), n, before=gather)
+            return self._planned(("concurrent", B),
+                                 (in_state, current_state, in_ref_states, ref_states),
+                                 build, volatile=(held,))
+        if planned and self.static_shard and in_state is not None:
+            src = (in_state, current_state, in_ref_states, ref_states)
+
+            def build():
+                hit = F._STATIC_PLANES.lookup("concurrent", src)
+                if hit is None:
+                    hit = F._STATIC_PLANES.store(
+                        "concurrent", src, F.quad_concurrent_prepare(*src))
+                return _PlannedStep(F.QuadConcurrentStepPlan(
+                    n, hit, self.delta_t, dyn.params, update=update), n)
+            return self._planned("concurrent", src, build)
         if prepared is not None:
             def compute():
                 return F.quad_concurrent_policy_grads(

@@ -434,6 +434,15 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
         "launch": ("one captured HIP graph per step" if world == 1 else
                    "two captured HIP graphs per step around the eager all-reduce"),
     }
+    default_graph = bool(t._graphs) and not any(
+        getattr(g, "planned", False) for g in t._graphs.values())
+    if any(getattr(g, "planned", False) for g in t._graphs.values()):
+        # (single-process concurrent step: buffers and argument structs made
+        # once, one library call = five launches per step, no capture)
+        out["launch"] = "step plan: one library call per step, no graph"
+    elif not t._graphs:
+        # (TrainBase.graph_batch_limit: kernels outlast the host's launch work)
+        out["launch"] = "kernels launched in stream order (no graph at this batch size)"
     if mode == "concurrent":
         # one process: the optimizer's update is applied by the second stage of
         # the step itself (apg_quad_mlp_concurrent_train_step); the split form
@@ -450,14 +459,23 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
     out["ms_per_step_private_loss"], _, _ = timed_steps(
         step, max(8, args.train_steps // 2), dist)
     t.borrow_loss = True
+    if world == 1 and not default_graph:
+        # the same step replayed from ONE captured graph (rounds 3-4's form)
+        limits, t.graph_batch_limit, t.plan_steps = t.graph_batch_limit, {}, False
+        t._graphs.clear()
+        out["ms_per_step_single_graph"], _, _ = timed_steps(
+            step, max(8, args.train_steps // 2), dist)
+        t.graph_batch_limit, t.plan_steps = limits, True
+        t._graphs.clear()
     t.graph_steps = False
     out["ms_per_step_eager"], _, _ = timed_steps(step, max(8, args.train_steps // 2), dist)
     if world == 1:
+        limits, t.graph_batch_limit = t.graph_batch_limit, {}
         t.graph_steps, t.split_graph = True, True
         t._graphs.clear()
         out["ms_per_step_split_graph"], _, _ = timed_steps(
             step, max(8, args.train_steps // 2), dist)
-        t.split_graph = None
+        t.split_graph, t.graph_batch_limit = None, limits
         t._graphs.clear()
     t.graph_steps = True
     if mode == "packed":

@@ -1342,8 +1342,12 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
              Net(15, H, 9, 40 if mode == "concurrent" else 4, conv=1))
     losses = []
     finals = []
-    for static, graph, split in ((False, False, None), (True, False, None),
-                                 (True, True, None), (True, True, True)):
+    # (the single-process concurrent step runs from a step plan by default -
+    # _PlannedStep, no capture; plan False: its captured-graph form)
+    for static, graph, split, plan in (
+            (False, False, None, True), (True, False, None, True),
+            (True, True, None, True), (True, True, True, True),
+            (True, True, None, False)):
         F._STATIC_PLANES.entries.clear()
         t = make_trainer(TrainDrone, FlightmareDynamics(), cfg)
         t.net = type(proto)(15, H, 9, proto.fc_out.out_features, conv=1).to(dev)
@@ -1352,6 +1356,7 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
         t.static_shard = static
         t.graph_steps = graph        # + the step replayed from a HIP graph
         t.split_graph = split        # ... as two graphs around the all-reduce slot
+        t.plan_steps = plan
         if mode == "LSTM":           # (h0, c0): the default generator, re-seeded
             torch.cuda.manual_seed(77)
         s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
@@ -1371,8 +1376,10 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
         assert (len(F._STATIC_PLANES.entries) > 0) == static
         assert (len(t._graphs) > 0) == graph
         for g in t._graphs.values():
-            assert g.capture and g.split == bool(split)
-    a, b, c, d_ = losses
+            planned = getattr(g, "planned", False)
+            assert planned == (mode == "concurrent" and plan and not split)
+            assert (g.capture or planned) and g.split == bool(split)
+    a, b, c, d_, e_ = losses
     assert abs(a[1] - a[2]) / abs(a[1]) > 1e-4       # the change matters
     for x, y in zip(a, b):
         assert abs(x - y) / abs(x) < 1e-6, (a, b)
@@ -1385,10 +1392,11 @@ def test_static_shard_keeps_plane_copies_only_while_unchanged(dev, mode):
         # the N > 1 form on one GPU - graph A, (empty) all-reduce slot, graph B,
         # the loss through the flat buffer's last element - is the eager step
         # BIT FOR BIT: losses and the weights after four updates
-        assert d_ == b and d_ == c, (b, c, d_)
+        assert d_ == b and d_ == c and d_ == e_, (b, c, d_, e_)
         for k in finals[1]:
             assert torch.equal(finals[3][k], finals[1][k]), k
             assert torch.equal(finals[3][k], finals[2][k]), k
+            assert torch.equal(finals[3][k], finals[4][k]), k
     else:
         # fresh (h0, c0) ~ N(0, 1) every step: graphed steps draw through the
         # captured generator state, so only the statistics agree
