@@ -708,9 +708,11 @@ class TrainBase:
             st["stream"] = torch.cuda.Stream()
         st.setdefault("slots", {})
         side = st["stream"]
-        late = self._in_epoch_capture or not self._graphable()
         import inspect
         takes_events = "events" in inspect.signature(step).parameters
+        # (a planned step is a plain launch as well: it takes the events)
+        late = (self._in_epoch_capture or not self._graphable()
+                or (takes_events and self._plannable()))
         side.wait_stream(main)       # the permutation, the data set's last update
 
         def issue(i, index, behind=None):
