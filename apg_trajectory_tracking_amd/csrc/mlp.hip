@@ -908,6 +908,9 @@ struct ConcArgs {
   float *states;        // [H][12][B] or NULL
   float *loss_partials;
   const float *tables;
+  // [waves][4] or NULL: max |conv output|, |feature|, |in_ref| of each wave's 32
+  // trajectories (the trajectory-major reverse kernel scales by them)
+  float *xmax;
   QuadConst c;
   ApgQuadLossWeights w;
   int B, ref_cols, vel_col;
@@ -944,6 +947,33 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
   for (int r = 0; r < kH; ++r)
 #pragma unroll
     for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vr, (r * kRD + j) * pN);
+  // (maxima of the |v| BIT PATTERNS, unsigned: inf / NaN lie above every finite
+  // value - see TmMeta)
+  unsigned xm_conv = 0u;
+  const auto umax = [](unsigned m, float v) {
+    const unsigned b_ = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+    return b_ > m ? b_ : m;
+  };
+  if (A.xmax) {   // (wave-uniform)
+    unsigned mf = 0u, mi = 0u;
+#pragma unroll
+    for (int j = 0; j < kNF; ++j) mf = umax(mf, feat[j]);
+#pragma unroll
+    for (int r = 0; r < kH; ++r)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) mi = umax(mi, w[r][j]);
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      const unsigned of = (unsigned)__shfl_xor((int)mf, sft, 64),
+                     oi = (unsigned)__shfl_xor((int)mi, sft, 64);
+      mf = of > mf ? of : mf, mi = oi > mi ? oi : mi;
+    }
+    if (lane == 0) {
+      unsigned *q = reinterpret_cast<unsigned *>(A.xmax) +
+                    (size_t)(blockIdx.x * (kThreads / 64) + wave) * 4;
+      q[1] = mf, q[2] = mi;
+    }
+  }
 
   // ---- policy forward on the 16-bit matrix pipe (policy_mfma16.h): every
   // operand as two fp16 terms, three products per k-block
@@ -998,6 +1028,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
       for (int i = 0; i < 12; ++i) {
         float v = cv[i];
         mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
+        xm_conv = umax(xm_conv, v);   // (before the relu: it would drop a NaN)
         v = fmaxf(v, 0.f);
         Px1.st(i < 8 ? vc : vb_lo, (kW + rrow(i) * kNP + pos) * pN, v);
         rv[e * 12 + i] = v;
@@ -1015,6 +1046,16 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
   }
 #pragma unroll
   for (int g = 0; g < 3; ++g) Pmk.stu(g < 2 ? vm : vb_lo, 2 * g * pN, mbits[g]);
+  if (A.xmax) {
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)xm_conv, sft, 64);
+      xm_conv = o > xm_conv ? o : xm_conv;
+    }
+    if (lane == 0)
+      reinterpret_cast<unsigned *>(A.xmax)[(size_t)(blockIdx.x * (kThreads / 64) + wave) * 4] =
+          xm_conv;
+  }
   // fc1 state part on s1 = tanh(states_in), stored as the reverse pass needs it
   dense64_16(a, u, L16, hA, n1s, [&](int rb, int i, float v) {
     const float tv = tanh_fast(v);
@@ -1295,13 +1336,33 @@ __device__ __forceinline__ void pack_cwg(const PackArgs &A, int tid, int T) {
 }
 
 // forward tables at dst, the in-sweep reverse tables at dst + kCfLds
+// after them, two floats for the trajectory-major reverse kernel: ns, nc with
+// 2^ns / 2^nc above the largest column 1-norm of W_1's state / conv part - a
+// bound on |W_1^T delta| per unit of max |delta| (the LAST block computes them)
 __global__ __launch_bounds__(256) void mlp_pack_step_kernel(PackArgs A, int fwd_blocks) {
+  if (blockIdx.x + 1 == gridDim.x) {
+    __shared__ float col[256];
+    const int t = threadIdx.x;
+    float sum = 0.f;
+    if (t < kN1)
+      for (int k = 0; k < kW; ++k) sum += fabsf(A.pol.w_1[k * kN1 + t]);
+    col[t] = sum;
+    __syncthreads();
+    if (t < 2) {
+      float m = 0.f;
+      for (int i = t ? kW : 0; i < (t ? kN1 : kW); ++i) m = fmaxf(m, col[i]);
+      // (a non-finite norm: 0 - the gradients are non-finite anyway)
+      A.dst[kCfLds + kWgTabFloats + t] =
+          m > 0.f && m < 3.0e38f ? (float)__builtin_amdgcn_frexp_expf(m) : 0.f;
+    }
+    return;
+  }
   if ((int)blockIdx.x < fwd_blocks) {
     pack_cfwd(A, blockIdx.x * blockDim.x + threadIdx.x, fwd_blocks * blockDim.x);
   } else {
     A.dst += kCfLds;
     pack_cwg(A, (blockIdx.x - fwd_blocks) * blockDim.x + threadIdx.x,
-             (gridDim.x - fwd_blocks) * blockDim.x);
+             (gridDim.x - 1 - fwd_blocks) * blockDim.x);
   }
 }
 
@@ -1311,6 +1372,7 @@ struct WgArgs {
   const float *d_zout;   // [40][B] (the forward kernel's dL/d(head pre-activations))
   float *part;           // [workgroups][kSlots][1024]
   const float *tables;
+  const float *xmax;     // [waves][4] (the forward kernel's; trajectory-major kernel only)
   int B;
 };
 
@@ -1775,11 +1837,617 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same reverse pass with TRAJECTORY-MAJOR weight products (round 4, last
+// third): no cotangent staging, no owner waves, one barrier per layer.
+//
+// The matrix instruction computes D[m][n] = sum_k A[m][k] B[k][n] with lane l
+// supplying row m = l & 31 of A and column n = l & 31 of B, eight k-slots each.
+// The two operand register layouts are the same, so issuing the instruction
+// with its operands SWAPPED yields the transposed product: where the chain
+// computes e = W^T delta (feature-major: row = feature in the registers,
+// column = trajectory in the lane) from the table block (A) and the split
+// cotangent (B), the same two register sets the other way round give
+// e^T[trajectory][feature] - 16 trajectories per lane, the feature in the
+// lane.  That is exactly the A operand of the weight product
+//   dW[m][k] = sum_n delta[m][n] x[k][n]
+// (row = feature, k-slots = trajectories), and the matching B operand - x with
+// the feature in the lane and the same 16 trajectories in the registers - is
+// four 16-byte loads per lane from the forward kernel's planes.  So every wave
+// multiplies ITS 32 trajectories' cotangents against its own x (K = 32 per
+// block product: two instructions x three split terms) and adds the 32 x 32
+// blocks into the workgroup's fp32 accumulators in LDS (ds_add_f32); a layer's
+// accumulators are flushed to the partial buffer behind ONE barrier while the
+// next layer adds into another region.  Costs: every layer product twice (the
+// matrix pipe was ~15 % busy).  The accumulators are FIXED POINT (below):
+// integer sums do not depend on the order in which the eight waves add, so the
+// kernel is bit-reproducible like the staged one
+// (apg_quad_mlp_set_weight_products switches between them).
+// LDS: tables [0, 100 K) as above; accumulator regions in the 60 KB behind them
+// and, for fc1's 14 blocks, also in the tables of the layers already passed:
+//   R_A [100 K, 116 K)  head, then fc2          R_B [116 K, 132 K)  fc3
+//   fc1: blocks 0..6 in [72 K, 100 K) (w3 / head tables, dead and zeroed after
+//        fc3's barrier), blocks 7..13 in [116 K, 144 K)
+//   states_in [144 K, 152 K), conv [152 K, 156 K), biases [156 K, 157 K)
+constexpr int tRA = 100 * 1024, tRB = 116 * 1024, tF1a = 72 * 1024, tF1b = 116 * 1024,
+              tSin = 144 * 1024, tConv = 152 * 1024, tBias = 156 * 1024, tMeta = 157 * 1024,
+              tConvLo = tMeta + 256;   // [20][32] low limbs of the conv block (2.5 KB)
+static_assert(tConvLo + kNC * 32 * 4 <= kLdsAll, "LDS map");
+// partial slots of this kernel: as above up to sConv, which holds ALL positions
+constexpr int uConv = sConv, uBias = sConv + 1, kSlotsTm = sConv + 2;
+// The accumulators are 32-bit FIXED POINT: ds_add_f32 costs ~0.4 us per wave
+// instruction on this part (the first build: 350 us per launch), ds_add_u32 runs
+// at LDS speed - and integer sums do not depend on the order of the eight
+// waves, so the kernel is bit-reproducible.  Both operands of a block product
+// are scaled into [-1, 1] by powers of two (exact): the cotangent by the
+// WORKGROUP's exponent of the layer (the waves' maxima are exchanged through
+// LDS one layer ahead, behind the barrier that is there anyway), x by 1 (tanh
+// planes) or by the workgroup's exponent of its plane group (conv outputs,
+// features, in_ref: measured from the planes before the first barrier).  A
+// wave's block element is then |sum of 32 products| <= 32, eight waves <= 2^8:
+// unit 2^-22, sums below 2^30.  Quantisation 2^-23 of the layer's largest
+// cotangent x largest x per addition - the absolute accuracy the staged
+// kernel's per-workgroup fp16 split has (2^-25), three bits coarser.  The
+// cotangents of states_in and conv are produced inside the fc1 phase, so their
+// exponents are BOUNDS: fc1's exponent + that of the largest column 1-norm of
+// W_1's state / conv part (two floats behind the tables, mlp_pack_step_kernel).
+// The conv block collects 8 positions as well - 2^11 terms, unit 2^-19 - and its
+// cotangent's exponent is a loose bound (above), so it keeps a second limb: the
+// rounding remainder of every addition in units of 2^-38 (compact [channel][32]).
+constexpr int kFix = 22, kFixConv = 19;
+// Maxima are taken on the BIT PATTERNS of |v| (unsigned): finite values order as
+// they do as floats, inf and every NaN lie above them - a non-finite cotangent or
+// x is seen (a float max would drop a NaN, the integer conversion turn it into
+// 0) and the workgroup's gradient blocks are written as NaN from there on.
+constexpr unsigned kInfBits = 0x7f800000u;
+struct TmMeta {           // at tMeta; written by plain stores, one slot per wave
+  unsigned dmax[4][8];    // max |cotangent| bits of head, fc3, fc2, fc1
+};
+__device__ __forceinline__ unsigned umax_abs(unsigned m, float v) {
+  const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+  return b > m ? b : m;
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)v, s, 64);
+    v = o > v ? o : v;
+  }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// exponent e with 2^e above the value whose bits are `a` (0 for zero; a
+// non-finite value sets `bad`)
+__device__ __forceinline__ int bits_exp(unsigned a, bool &bad, bool nonneg_floor) {
+  if (a >= kInfBits) {
+    bad = true;
+    return 0;
+  }
+  const int e = a ? __builtin_amdgcn_frexp_expf(__builtin_bit_cast(float, a)) : 0;
+  return nonneg_floor && e < 0 ? 0 : e;
+}
+
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+typedef int i32x4_ __attribute__((ext_vector_type(4)));
+
+// 32 planes from `soff` (scalar: first plane x pitch + the wave's first
+// trajectory), one per lane & 31, trajectory-major: v[4 g + c] = trajectory
+// c + 8 g + 4 hi of the wave - the trajectory set of accumulator register 4 g + c
+struct TBlock {
+  u32x4 q[4];
+  __device__ __forceinline__ void load(const Planes &X, unsigned voff, unsigned soff) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      q[g] = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, (int)voff, (int)(soff + 32 * g),
+                                                   APG_PLANES_LD_AUX);
+  }
+  __device__ __forceinline__ void get(float (&v)[16]) const {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4_ f = __builtin_bit_cast(f32x4_, q[g]);   // (whole vector: see wgrad_block)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[4 * g + c] = f[c];
+    }
+  }
+  __device__ __forceinline__ float absmax() const {
+    float v[16], m = 0.f;
+    get(v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, fabsf(v[i]));
+    return m;
+  }
+};
+
+// the two k-blocks (8 trajectories per half-wave each) of 16 trajectory-major
+// values x 2^-e
+__device__ __forceinline__ void split16(const float (&v)[16], int e, Op16 (&o)[2]) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    float w8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w8[j] = __builtin_amdgcn_ldexpf(v[8 * kk + j], -e);
+    o[kk] = split8(w8);
+  }
+}
+
+#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_TM_KNOCKOUT)
+#error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
+#endif
+#ifndef APG_TM_KNOCKOUT
+#define APG_TM_KNOCKOUT 0   // timing experiments: 1 float atomics (ds_add_f32) on the same data
+#endif
+// v (in units of the accumulator's scale) into the fixed-point accumulator at p
+__device__ __forceinline__ void lds_add(char *p, float v, int fix = kFix) {
+  if (APG_TM_KNOCKOUT & 1) {
+    __hip_atomic_fetch_add(reinterpret_cast<float *>(p), v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+  const int q = (int)__builtin_rintf(__builtin_amdgcn_ldexpf(v, fix));
+  __hip_atomic_fetch_add(reinterpret_cast<int *>(p), q, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// two-limb addition (conv block; states_in's blocks, whose exponent is a bound as
+// well): v = hi 2^-fix + lo 2^-2 fix + O(2^-2 fix - 1)
+__device__ __forceinline__ void lds_add2(char *hi, char *lo, float v, int fix = kFixConv) {
+  const float s_ = __builtin_amdgcn_ldexpf(v, fix), qh = __builtin_rintf(s_);
+  __hip_atomic_fetch_add(reinterpret_cast<int *>(hi), (int)qh, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(reinterpret_cast<int *>(lo),
+                         (int)__builtin_rintf(__builtin_amdgcn_ldexpf(s_ - qh, fix)),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// acc (a 32 x 32 block in accumulator layout, scaled operands) into the LDS block
+__device__ __forceinline__ void add_block(char *blk_lane, const f32x16 &acc) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lds_add(blk_lane + i * 256, acc[i]);
+}
+
+// workgroup: `floats` fixed-point accumulators at `off` -> dst as floats x 2^e
+// (e = the product of the operand scales), optionally zeroed for the next user
+__device__ __forceinline__ void flush_region(char *lds, int off, int floats, float *dst, int e,
+                                             bool rezero, bool bad, int fix = kFix) {
+  const i32x4_ z = {0, 0, 0, 0};
+  for (int idx = threadIdx.x; idx < floats / 4; idx += kThreads) {
+    i32x4_ *p = reinterpret_cast<i32x4_ *>(lds + off) + idx;
+    const i32x4_ q = *p;
+    f32x4_ v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      v[c] = bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)q[c], e - fix);
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_ *>(dst) + idx);
+    if (rezero) *p = z;
+  }
+}
+
+__device__ __forceinline__ void zero_region(char *lds, int off, int bytes) {
+  const f32x4_ z = {0.f, 0.f, 0.f, 0.f};
+  for (int idx = threadIdx.x; idx < bytes / 16; idx += kThreads)
+    reinterpret_cast<f32x4_ *>(lds + off)[idx] = z;
+}
+
+// the workgroup's exponent from the eight waves' slots
+__device__ __forceinline__ int wg_exp(const unsigned (&slots)[8], bool &bad) {
+  unsigned a = slots[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) a = slots[w] > a ? slots[w] : a;
+  return bits_exp(a, bad, false);
+}
+
+__global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  char *lds = reinterpret_cast<char *>(lds_f);
+  const int lane = threadIdx.x & 63, hi = lane >> 5, row = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b0 = blockIdx.x * kTrajPerBlock;
+  const int b = b0 + wave * 32 + row;
+  const int B = A.B;
+  const bool live = b < B;
+  const unsigned pN = (unsigned)B * 4u;
+  const Planes Pact(A.acts, kActPlanes, pN), Pdz(A.d_zout, kNA, pN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  const unsigned vr = live ? vb + (hi ? 4u * pN : 0u) : kDead;
+  // trajectory-major addressing: lane = plane `row` of a 32-plane block, its
+  // 16 trajectories start 4 hi into the wave's 32
+  const unsigned wcol = (unsigned)(b0 + wave * 32) * 4u;
+  const unsigned vt = (unsigned)row * pN + (unsigned)hi * 16u;
+  const int nw = B - (b0 + wave * 32);      // live trajectories of this wave (may be <= 0)
+  float *part = A.part + (size_t)blockIdx.x * kSlotsTm * 1024;
+  char *lane_blk = lds + lane * 4;           // + region + block * 4096 + i * 256
+  TmMeta &meta = *reinterpret_cast<TmMeta *>(lds + tMeta);
+  // 2^ns, 2^nc: above the largest column 1-norm of W_1's state / conv part
+  const int ns = (int)A.tables[kWgTabFloats], nc = (int)A.tables[kWgTabFloats + 1];
+  bool bad = false;         // (workgroup-uniform) a non-finite operand was seen
+
+  // ---- this wave's inputs: dL/dz feature-major (20 rows per half-wave) and
+  // trajectory-major (rows 0..31 and 32..39), h3's first block; the maxima of
+  // the unbounded x plane groups (this wave's 32 trajectories)
+  float dzr[20];
+#pragma unroll
+  for (int cc = 0; cc < 20; ++cc) dzr[cc] = Pdz.ld(vr, khead(cc, 0) * pN);
+  TBlock tz[2], tx;
+  tz[0].load(Pdz, vt, wcol);
+  tz[1].load(Pdz, row < kNA - 32 ? vt : kDead, 32u * pN + wcol);
+  tx.load(Pact, vt, (unsigned)pH3 * pN + wcol);
+  {
+    zero_region(lds, tRA, tMeta - tRA);
+    zero_region(lds, tConvLo, kNC * 32 * 4);
+    fill_lds_issue(lds_f, A.tables, kWgTabFloats);
+    unsigned amax = 0u;
+#pragma unroll
+    for (int cc = 0; cc < 20; ++cc) amax = umax_abs(amax, dzr[cc]);
+    amax = wave_umax(amax);
+    if (lane == 0) meta.dmax[0][wave] = amax;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the table DMA
+    __syncthreads();
+  }
+  // The scales of the unbounded x plane groups (conv outputs, features + the
+  // ones row, in_ref): the workgroup's maxima, which the forward kernel left per
+  // wave (reading the planes for them here cost 9-16 us, wherever it was put)
+  unsigned mc = 0u, mf = 0x3f800000u /* the ones row */, mi = 0u;
+  {
+    const unsigned *q = reinterpret_cast<const unsigned *>(A.xmax) +
+                        (size_t)blockIdx.x * (kThreads / 64) * 4;
+#pragma unroll
+    for (int w8 = 0; w8 < kThreads / 64; ++w8) {
+      mc = q[4 * w8] > mc ? q[4 * w8] : mc;
+      mf = q[4 * w8 + 1] > mf ? q[4 * w8 + 1] : mf;
+      mi = q[4 * w8 + 2] > mi ? q[4 * w8 + 2] : mi;
+    }
+  }
+  const int fc = bits_exp(mc, bad, true), ff = bits_exp(mf, bad, true),
+            fi = bits_exp(mi, bad, true);
+  const LdsView16 L16(lds, lane);
+
+  float hv[2][16];
+  auto load_hv = [&](int plane) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hv[rb][i] = Pact.ld(vr, (plane + rb * 32 + rrow(i)) * pN);
+  };
+  // this wave's largest next-layer cotangent -> its slot (read behind the barrier)
+  auto post = [&](const f32x16 (&v)[2], int phase) {
+    unsigned am = 0u;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) am = umax_abs(am, v[rb][i]);
+    am = wave_umax(am);
+    if (lane == 0) meta.dmax[phase][wave] = am;
+  };
+  // bias gradient of 32 rows: sums over the lane's 16 trajectories, both halves
+  auto add_bias = [&](const float (&v)[16], int e, int layer, int mb, int rows) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += __builtin_amdgcn_ldexpf(v[i], -e);
+    s += other_half(s);
+    if (hi == 0 && row < rows) lds_add(lds + tBias + (layer * 64 + 32 * mb + row) * 4, s);
+  };
+
+  // ------------------------------------------------------------- head
+  f32x16 d[2], e[2];
+  float dT[2][16];        // the current layer's cotangent, trajectory-major
+  const int e0 = wg_exp(meta.dmax[0], bad);
+  {
+    Op16 x0[3];
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = kb * 8 + j < 20 ? __builtin_amdgcn_ldexpf(dzr[kb * 8 + j < 20 ? kb * 8 + j : 0], -e0)
+                               : 0.f;
+      x0[kb] = split8(v);
+    }
+    Op16 az[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      float v[16];
+      tz[mb].get(v);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)   // columns beyond B are somebody else's plane
+        v[i] = rrow(i) + 4 * hi < nw ? v[i] : 0.f;
+      add_bias(v, e0, 0, mb, mb ? kNA - 32 : 32);
+      split16(v, e0, az[mb]);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float xv[16];
+      tx.get(xv);
+      if (nb == 0) tx.load(Pact, vt, (unsigned)(pH3 + 32) * pN + wcol);
+      else tx.load(Pact, vt, (unsigned)pH2 * pN + wcol);     // fc3's first x block
+
+      Op16 bx[2];
+      split16(xv, 0, bx);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(az[mb][kk], bx[kk], acc);
+        add_block(lane_blk + tRA + (2 * nb + mb) * 4096, acc);
+      }
+      // d(h3)^T, block nb: the head tables as B operand
+      f32x16 t;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 3; ++kb) t = mma3(x0[kb], L16.A(0, wO + 3 * nb + kb), t);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        dT[nb][i] = __builtin_amdgcn_ldexpf(t[i], e0) * (1.f - xv[i] * xv[i]);
+    }
+    load_hv(pH3);
+    zero(d);
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+      d[0] = mma3(L16.A(0, wO + kb), x0[kb], d[0]);
+      d[1] = mma3(L16.A(0, wO + 3 + kb), x0[kb], d[1]);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        d[rb][i] = __builtin_amdgcn_ldexpf(d[rb][i], e0) * (1.f - hv[rb][i] * hv[rb][i]);
+    post(d, 1);
+  }
+  __syncthreads();
+  flush_region(lds, tRA, 4 * 1024, part + sOut * 1024, e0, true, bad);
+  flush_region(lds, tBias, 64, part + uBias * 1024, e0, false, bad);
+
+  // One 64 x 64 layer: dl / dT = its cotangent in both layouts, e_ = the
+  // workgroup's exponent for it.  Weight blocks against the two x blocks (the
+  // second one and `next_plane`'s first are requested on the way), the
+  // cotangent of the layer below in both layouts (tables `tab`), tanh' with
+  // the x blocks / the planes `x_plane`; its maxima go to slot `phase + 1`.
+  auto layer64 = [&](f32x16 (&dl)[2], f32x16 (&nx)[2], int e_, int tab, int x_plane,
+                     int region, int bias_id, int next_plane, int phase) {
+    Op16 x[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = __builtin_amdgcn_ldexpf(dl[kb >> 1][8 * (kb & 1) + j], -e_);
+      x[kb] = split8(v);
+    }
+    Op16 ad[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      add_bias(dT[mb], e_, bias_id, mb, 32);
+      split16(dT[mb], e_, ad[mb]);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float xv[16];
+      tx.get(xv);
+      tx.load(Pact, vt, (unsigned)(nb == 0 ? x_plane + 32 : next_plane) * pN + wcol);
+      Op16 bx[2];
+      split16(xv, 0, bx);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(ad[mb][kk], bx[kk], acc);
+        add_block(lane_blk + region + (2 * nb + mb) * 4096, acc);
+      }
+      f32x16 t;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) t = mma3(x[kb], L16.A(0, tab + 4 * nb + kb), t);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        dT[nb][i] = __builtin_amdgcn_ldexpf(t[i], e_) * (1.f - xv[i] * xv[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_hv(x_plane);
+    zero(nx);
+    dense64T_16(nx, x, L16, 0, tab);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        nx[rb][i] = __builtin_amdgcn_ldexpf(nx[rb][i], e_) * (1.f - hv[rb][i] * hv[rb][i]);
+    post(nx, phase + 1);
+  };
+  // ---- fc3: x = h2 -> cotangent of h2's pre-activations
+  const int e3 = wg_exp(meta.dmax[1], bad);
+  layer64(d, e, e3, w3, pH2, tRB, 1, pH1, 1);
+  __syncthreads();
+  flush_region(lds, tRB, 4 * 1024, part + sFc3 * 1024, e3, true, bad);
+  flush_region(lds, tBias + 256, 64, part + uBias * 1024 + 64, e3, false, bad);
+  zero_region(lds, tF1a, tRA - tF1a);        // w3 and head tables: fc1's first blocks
+  // ---- fc2: x = h1
+  const int e2 = wg_exp(meta.dmax[2], bad);
+  layer64(e, d, e2, w2, pH1, tRA, 2, pX1, 2);
+  __syncthreads();
+  flush_region(lds, tRA, 4 * 1024, part + sFc2 * 1024, e2, false, bad);
+  flush_region(lds, tBias + 512, 64, part + uBias * 1024 + 128, e2, false, bad);
+
+  // ---- fc1 (x = the 224 x1 planes: s1 | relu(conv)), states_in and conv
+  const int e1 = wg_exp(meta.dmax[3], bad);
+  const int es = e1 + ns, ec = e1 + nc;      // bounds of |d_pre_s|, |d conv|
+  {
+    Op16 x1s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = __builtin_amdgcn_ldexpf(d[kb >> 1][8 * (kb & 1) + j], -e1);
+      x1s[kb] = split8(v);
+    }
+    Op16 ad[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      add_bias(dT[mb], e1, 3, mb, 32);
+      split16(dT[mb], e1, ad[mb]);
+    }
+    // B operands that stay: the 15 feature planes + a row of ones (states_in's
+    // bias column), the 90 in_ref planes in three blocks (conv windows)
+    Op16 bfeat[2], binr[3][2];
+    {
+      TBlock tf;
+      tf.load(Pact, row < kNF ? vt : kDead, (unsigned)pFeat * pN + wcol);
+      float v[16];
+      tf.get(v);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = row == kNF ? 1.f : v[i];
+      split16(v, ff, bfeat);
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb) {
+        tf.load(Pact, 32 * jb + row < kH * kRD ? vt : kDead,
+                (unsigned)(pInr + 32 * jb) * pN + wcol);
+        tf.get(v);
+        split16(v, fi, binr[jb]);
+      }
+    }
+    // fc1's weight blocks 2 nb, 2 nb + 1 against x block nb (scaled by 2^-fx)
+    auto fc1_blocks = [&](const float (&xv)[16], int fx, int nb) {
+      Op16 bx[2];
+      split16(xv, fx, bx);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(ad[mb][kk], bx[kk], acc);
+        const int blk = 2 * nb + mb;     // blocks 0..6 in the first piece
+        add_block(lane_blk + (blk < 7 ? tF1a + blk * 4096 : tF1b + (blk - 7) * 4096), acc);
+      }
+    };
+    // the transposed product of d_pre1 against four table blocks from `blk0`
+    auto transposed = [&](int blk0) {
+      const char *tb = L16.b0 + blk0 * kBlock16;   // (all below 60 KB)
+      f32x16 t;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        Op16 w;
+        w.h = *reinterpret_cast<const u32x4 *>(tb + kb * kBlock16);
+        w.l = *reinterpret_cast<const u32x4 *>(tb + kb * kBlock16 + 1024);
+        t = mma3(x1s[kb], w, t);
+      }
+      return t;
+    };
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      // s1's blocks: also states_in - cotangent of its pre-activations, block
+      // nb, and the weight block against the features
+      float xv[16];
+      tx.get(xv);
+      tx.load(Pact, vt, (unsigned)(pX1 + 32 * (nb + 1)) * pN + wcol);
+      fc1_blocks(xv, 0, nb);
+      const f32x16 t = transposed(wS + 4 * nb);
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        v[i] = __builtin_amdgcn_ldexpf(t[i], e1) * (1.f - xv[i] * xv[i]);
+      Op16 as[2];
+      split16(v, es, as);
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc = mma3(as[kk], bfeat[kk], acc);
+      // 16 columns are real (15 features + the ones row): compact [reg][half][16],
+      // 2 KB of high limbs per block, the low limbs 4 KB further
+      if (row < 16) {
+        char *q = lds + tSin + nb * 2048 + (hi * 16 + row) * 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lds_add2(q + i * 128, q + 4096 + i * 128, acc[i], kFix);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (int eb = 0; eb < 5; ++eb) {
+      // conv blocks: x block 2 + eb = the saved conv outputs e = 32 eb + row
+      // (channel 4 eb + row / 8, position row % 8); their cotangent with relu'
+      // from the saved outputs, then its products against the in_ref planes
+      float xv[16];
+      tx.get(xv);
+      if (eb < 4) tx.load(Pact, vt, (unsigned)(pX1 + 32 * (eb + 3)) * pN + wcol);
+      fc1_blocks(xv, fc, eb + 2);
+      const f32x16 t = transposed(wC + 4 * eb);
+      float v[16], sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[i] = xv[i] > 0.f ? __builtin_amdgcn_ldexpf(t[i], e1 - ec) : 0.f;   // / 2^ec
+        sum += v[i];
+      }
+      // the conv block's rows of channels 4 eb .. 4 eb + 3 (accumulator layout:
+      // channel ch = register (ch & 3) + 4 (ch >> 3) of half-wave (ch >> 2) & 1)
+      char *cblk = lds + tConv + ((4 * (eb >> 1)) * 64 + 32 * (eb & 1)) * 4;
+      char *clo = lds + tConvLo + 4 * eb * 32 * 4;        // low limbs: [channel][32]
+      sum += other_half(sum);
+      // bias: column 27; the block's unit carries in_ref's scale 2^fi as well
+      if (hi == 0)
+        lds_add2(cblk + ((row >> 3) * 64 + 27) * 4, clo + ((row >> 3) * 32 + 27) * 4,
+                 __builtin_amdgcn_ldexpf(sum, -fi));
+      Op16 ac[2];
+      split16(v, 0, ac);
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(ac[kk], binr[jb][kk], acc);
+        // register 4 g + c of lane (hi, col): conv output row c + 8 g + 4 hi of the
+        // block = channel 4 eb + g at position c + 4 hi, against in_ref plane
+        // j = 32 jb + col: tap q = j - 9 position of that channel's 27
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int q = 32 * jb + row - kRD * (c + 4 * hi);
+          if (q >= 0 && q < 27) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              lds_add2(cblk + (g * 64 + q) * 4, clo + (g * 32 + q) * 4, acc[4 * g + c]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  // fc1: blocks 0..3 against s1 (unit 2^e1), 4..13 against the conv outputs (2^(e1 + fc))
+  flush_region(lds, tF1a, 4 * 1024, part + sFc1 * 1024, e1, false, bad);
+  flush_region(lds, tF1a + 4 * 4096, 3 * 1024, part + (sFc1 + 4) * 1024, e1 + fc, false, bad);
+  flush_region(lds, tF1b, 7 * 1024, part + (sFc1 + 7) * 1024, e1 + fc, false, bad);
+  flush_region(lds, tBias + 768, 64, part + uBias * 1024 + 192, e1, false, bad);
+  for (int idx = threadIdx.x; idx < 2 * 512; idx += kThreads) {   // states_in: both limbs
+    const int nb = idx >> 9, r_ = idx & 511, at = (r_ >> 5) * 64 + 32 * ((r_ >> 4) & 1) + (r_ & 15);
+    const int *q = reinterpret_cast<const int *>(lds + tSin) + nb * 512 + r_;
+    const double v = (double)q[0] + (double)q[1024] * (1.0 / (double)(1 << kFix));
+    part[(sSin + nb) * 1024 + at] =
+        bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)v, es + ff - kFix);
+  }
+  // conv: both limbs of the 20 x 28 used elements (accumulator layout in the slot)
+  for (int idx = threadIdx.x; idx < kNC * 32; idx += kThreads) {
+    const int ch = idx >> 5, q = idx & 31;
+    const int at = ((ch & 3) + 4 * (ch >> 3)) * 64 + 32 * ((ch >> 2) & 1) + q;
+    const double v = (double)reinterpret_cast<const int *>(lds + tConv)[at] +
+                     (double)reinterpret_cast<const int *>(lds + tConvLo)[idx] *
+                         (1.0 / (double)(1 << kFixConv));
+    part[uConv * 1024 + at] =
+        bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)v, ec + fi - kFixConv);
+  }
+}
+
 // Second stage: the workgroups' partial blocks summed in a fixed order
 // (deterministic), scattered into the parameter gradients; block 0 also sums
 // the loss partials of the forward kernel.
 // destination of element (slot, reg i, lane) - or NULL (padding)
-__device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, int i, int lane) {
+__device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, int i, int lane,
+                                          int bias_slot) {
   const int rowb = rrow(i) + 4 * (lane >> 5), col = lane & 31;
   if (slot < sFc1) {                       // head, fc3, fc2: [cb][mb]
     const int q = slot & 3, cb = q >> 1, m = 32 * (q & 1) + rowb, k = 32 * cb + col;
@@ -1794,8 +2462,8 @@ __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, 
     const int m = 32 * (slot - sSin) + rowb;
     return col < kNF ? g.w_s + m * kNF + col : col == kNF ? g.b_s + m : nullptr;
   }
-  if (slot < sBias) {                      // conv, position slot - sConv: only slot
-    if (slot != sConv || rowb >= kNC) return nullptr;   // sConv collects all eight
+  if (slot < bias_slot) {                  // conv, position slot - sConv: only slot
+    if (slot != sConv || rowb >= kNC) return nullptr;   // sConv collects all of them
     if (col < 27) return g.conv_w + rowb * 27 + (col % kRD) * 3 + col / kRD;
     return col == 27 ? g.conv_b + rowb : nullptr;
   }
@@ -1827,16 +2495,20 @@ struct WgReduceArgs {
   ApgMlpPolicyGrads param, mom;
   double lr, momentum;
   bool update;
+  // slot layout of the reverse kernel that wrote `part`: slots per workgroup,
+  // where the bias slot is, how many conv position blocks follow sConv
+  int n_slots, bias_slot, conv_src;
   const float *loss_partials;
   float *loss;
   int wgs, n_partials;   // wgs: how many [kSlots * 1024] rows `part` has
 };
 
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce1_kernel(const float *part,
-                                                                float *chunk_sums, int wgs) {
+                                                                float *chunk_sums, int wgs,
+                                                                int n_slots) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= kSlots * 1024) return;
-  const size_t stride = (size_t)kSlots * 1024;
+  if (t >= n_slots * 1024) return;
+  const size_t stride = (size_t)n_slots * 1024;
   const int w0 = blockIdx.y * kRedChunk;
   const float *p = part + (size_t)w0 * stride + t;
   float v[kRedChunk];
@@ -1850,12 +2522,12 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce1_kernel(const float *par
 
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
   const int t = blockIdx.x * 256 + threadIdx.x;   // (slot, reg, lane)
-  const size_t stride = (size_t)kSlots * 1024;
-  if (t < kSlots * 1024) {
+  const size_t stride = (size_t)A.n_slots * 1024;
+  if (t < A.n_slots * 1024) {
     const int slot = t >> 10, i = (t >> 6) & 15, lane = t & 63;
-    float *dst = wg_dest(A.g, slot, i, lane);
+    float *dst = wg_dest(A.g, slot, i, lane, A.bias_slot);
     if (dst) {
-      const int n_src = slot == sConv ? kNP : 1;   // the eight position blocks
+      const int n_src = slot == sConv ? A.conv_src : 1;   // the position blocks
       float s = 0.f;
       for (int q = 0; q < n_src; ++q) {
         const float *p = A.part + (size_t)(slot + q) * 1024 + (t & 1023);
@@ -1867,7 +2539,8 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
       }
       *dst = s;
       if (A.update) {   // torch.optim.SGD: buf = momentum buf + grad, p -= lr buf
-        float *pp = wg_dest(A.param, slot, i, lane), *pm = wg_dest(A.mom, slot, i, lane);
+        float *pp = wg_dest(A.param, slot, i, lane, A.bias_slot),
+              *pm = wg_dest(A.mom, slot, i, lane, A.bias_slot);
         // (in double with one rounding each, as torch's fused SGD kernel does
         // it: a trainer that steps through optimizer.step() - the multi-rank
         // form - gets the same bits)
@@ -2111,6 +2784,7 @@ int apg_quad_mlp_concurrent_fwd_bwd(
   A.x1 = x1, A.h = h, A.mask = relu_mask, A.d_zout = d_zout, A.d_pre = d_pre;
   A.d_conv = d_conv, A.states = states, A.loss_partials = loss_partials;
   A.tables = workspace;
+  A.xmax = nullptr;
   A.c = make_const(*params, dt);
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
@@ -2132,13 +2806,31 @@ int apg_quad_mlp_concurrent_fwd_bwd(
 }
 
 
-int apg_quad_mlp_step_workspace_floats(void) { return kCfLds + kWgTabFloats; }
+int apg_quad_mlp_step_workspace_floats(void) { return kCfLds + kWgTabFloats + 4; }
 
 long long apg_quad_mlp_step_partials_floats(int B) {
   if (B <= 0) return 0;
   const long long wgs = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   // the workgroups' partials + the chunk sums of the first reduction level
-  return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlots * 1024;
+  // + the forward kernel's per-wave x maxima
+  return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlots * 1024 + wgs * 32;
+}
+
+namespace {
+// which reverse kernel the concurrent step launches: 1 trajectory-major
+// products with fixed-point LDS accumulators (the default), 0 the staged
+// products of the first half of round 4 (kept: an independent implementation
+// of the same sums, tests/test_gpu_in_sweep.py compares the two)
+int g_weight_products = 1;
+}  // namespace
+
+int apg_quad_mlp_set_weight_products(int mode) {
+  if (mode != 0 && mode != 1) {
+    set_error("weight products: 0 (staged) or 1 (trajectory-major)");
+    return APG_ERR_ARG;
+  }
+  g_weight_products = mode;
+  return APG_OK;
 }
 
 namespace {
@@ -2220,6 +2912,7 @@ int apg_quad_mlp_concurrent_train_step(
   if (!attr.test()) {
     if (int e = raise_lds(mlp_concurrent_fwd_kernel, kCfLds)) return e;
     if (int e = raise_lds(mlp_concurrent_bwd_wg_kernel, kLdsAll / 4)) return e;
+    if (int e = raise_lds(mlp_concurrent_bwd_tm_kernel, kLdsAll / 4)) return e;
     attr.set();
   }
   const size_t plane = (size_t)B;
@@ -2230,6 +2923,9 @@ int apg_quad_mlp_concurrent_train_step(
   A.d_zout = d_zout, A.d_pre = nullptr, A.d_conv = nullptr;
   A.states = states, A.loss_partials = loss_partials;
   A.tables = workspace;
+  // (behind the workgroups' partials and the chunk sums)
+  A.xmax = partials + (size_t)(apg_quad_mlp_step_partials_floats(B) -
+                                (long long)((B + kTrajPerBlock - 1) / kTrajPerBlock) * 32);
   A.c = make_const(*params, dt);
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
@@ -2237,7 +2933,7 @@ int apg_quad_mlp_concurrent_train_step(
   P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   const int fwd_blocks = (kCfLds + 255) / 256, bwd_blocks = (kWgTabFloats + 255) / 256;
-  hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks), dim3(256), 0, st,
+  hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks + 1), dim3(256), 0, st,
                      P, fwd_blocks);
   // (the tables are packed while the caller's producer of acts / state0 / ref -
   // a gather on another stream - may still be running)
@@ -2251,9 +2947,14 @@ int apg_quad_mlp_concurrent_train_step(
     return check_launch("hipEventRecord(after_forward)");
   WgArgs W;
   W.acts = acts, W.mask = relu_mask, W.d_zout = d_zout, W.part = partials;
-  W.tables = workspace + kCfLds, W.B = B;
-  hipLaunchKernelGGL(mlp_concurrent_bwd_wg_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st,
-                     W);
+  W.tables = workspace + kCfLds, W.B = B, W.xmax = A.xmax;
+  const bool tm = g_weight_products == 1;
+  if (tm)
+    hipLaunchKernelGGL(mlp_concurrent_bwd_tm_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st,
+                       W);
+  else
+    hipLaunchKernelGGL(mlp_concurrent_bwd_wg_kernel, dim3(blocks), dim3(kThreads), kLdsAll,
+                       st, W);
   // the inputs (activation planes, state0, ref) are not read past this point:
   // a caller that pipelines batches may start refilling the NEXT batch's
   // buffers behind this event while the second stage and the update run
@@ -2263,17 +2964,20 @@ int apg_quad_mlp_concurrent_train_step(
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
+  R.n_slots = tm ? kSlotsTm : kSlots, R.bias_slot = tm ? uBias : sBias;
+  R.conv_src = tm ? 1 : kNP;
+  const int columns = (R.n_slots * 1024 + 255) / 256;
   R.update = update != nullptr;
   R.param = update ? update->param : *grads, R.mom = update ? update->momentum_buf : *grads;
   R.lr = update ? update->lr : 0.0, R.momentum = update ? update->momentum : 0.0;
   if (blocks > kRedChunk) {
     const int chunks = (blocks + kRedChunk - 1) / kRedChunk;
-    float *chunk_sums = partials + (size_t)blocks * kSlots * 1024;
-    hipLaunchKernelGGL(mlp_wgrad_reduce1_kernel, dim3(kRedColumns, chunks), dim3(256), 0, st,
-                       partials, chunk_sums, blocks);
+    float *chunk_sums = partials + (size_t)blocks * R.n_slots * 1024;
+    hipLaunchKernelGGL(mlp_wgrad_reduce1_kernel, dim3(columns, chunks), dim3(256), 0, st,
+                       partials, chunk_sums, blocks, R.n_slots);
     R.part = chunk_sums, R.wgs = chunks;
   }
-  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(kRedColumns), dim3(256), 0, st, R);
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(columns), dim3(256), 0, st, R);
   return check_launch("quad_mlp_concurrent_step");
 }
 

@@ -118,6 +118,20 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 // the compiler does not unroll - 16 dependent load -> ds_write round trips per
 // thread before the first instruction of the sweep: 2.5-3 us per launch,
 // profiles/r03_gemm_stream_bf16x3.txt.)
+// the same without the wait and the barrier: the caller has more to do first
+__device__ __forceinline__ void fill_lds_issue(float *lds, const float *src, int floats) {
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  const auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0,
+                                                   (unsigned)floats * 4u, 0x00020000);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves = blockDim.x >> 6;
+  for (int c = wave * 256; c < floats; c += waves * 256)
+    if (c + lane * 4 < floats)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(lds + c), 16,
+                                               (c + lane * 4) * 4, 0, 0, 0);
+}
+
 __device__ __forceinline__ void fill_lds(float *lds, const float *src, int floats) {
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
   const auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0,

@@ -32,6 +32,16 @@ def in_sweep_switch():
     F.CONCURRENT_IN_SWEEP = before
 
 
+@pytest.fixture(params=[1, 0], ids=["trajectory_major", "staged"])
+def products(request):
+    """Both reverse kernels of the step (include/apg.h,
+    apg_quad_mlp_set_weight_products): 1 = the default."""
+    from apg_trajectory_tracking_amd import functional as F
+    F.set_concurrent_weight_products(request.param)
+    yield request.param
+    F.set_concurrent_weight_products(1)
+
+
 def N(t):
     return t.detach().double().cpu().numpy()
 
@@ -63,7 +73,8 @@ def _fp64_grads(net, d):
 # second workgroup with one trajectory; 300, 4113: ragged last workgroups;
 # 8192 + 3: more than one chunk of the second stage (32 workgroups)
 @pytest.mark.parametrize("B", [1, 31, 77, 256, 257, 300, 4113, 8195])
-def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_switch):
+def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_switch,
+                                                             products):
     from apg_trajectory_tracking_amd import functional as F
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
@@ -89,8 +100,10 @@ def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_s
         assert rel_err(g1[k], g0[k]) < 2e-5, (k, rel_err(g1[k], g0[k]))
 
 
-def test_in_sweep_is_deterministic_and_feeds_autograd(dev, in_sweep_switch):
-    """Fixed-order second stage: equal inputs give equal bits; loss.backward()
+def test_in_sweep_is_deterministic_and_feeds_autograd(dev, in_sweep_switch, products):
+    """Fixed-order sums (staged kernel) / fixed-point accumulators (trajectory-
+    major kernel) and a fixed-order second stage: equal inputs give equal bits,
+    at a batch of several workgroups and chunks as well; loss.backward()
     of the autograd entry point delivers the same gradients (scaled by the
     upstream cotangent)."""
     from apg_trajectory_tracking_amd import functional as F
@@ -239,3 +252,48 @@ def test_train_step_through_the_c_abi(dev):
     broken.momentum_buf.b_3 = None
     assert call(B, broken) == -1 and b"update" in lib.apg_last_error_string()
     assert call(0, upd) == -1 and b"B = 0" in lib.apg_last_error_string()
+
+
+def test_both_product_kernels_agree_at_full_size_and_flag_non_finite_operands(dev):
+    """B = 65 536: the trajectory-major kernel against the staged one on every
+    parameter gradient (two independent implementations of the same sums), both
+    bit-reproducible; a NaN planted in one trajectory's features (behind the
+    host's range check) gives a non-finite loss with both and NaN in EVERY
+    gradient with the trajectory-major kernel - never a finite number (its
+    fixed-point conversion would turn a NaN into 0 if nothing looked)."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    B = 65536
+    torch.manual_seed(21)
+    net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+    _, inputs = _case(B, 5, dev)
+    dyn = FlightmareDynamics()
+    got = {}
+    try:
+        for mode in (1, 0):
+            F.set_concurrent_weight_products(mode)
+            prepared = F.quad_concurrent_prepare(*inputs)
+            plan = F.QuadConcurrentStepPlan(net, prepared, DT, dyn.params)
+            plan.launch()
+            first = plan.flat.clone()
+            plan.launch()
+            assert torch.equal(plan.flat[:-1], first[:-1]), mode      # reproducible
+            got[mode] = {k: N(v) for k, v in plan.named.items()}
+            # one trajectory's feature becomes NaN / inf
+            for poison in (float("nan"), float("inf")):
+                prepared[0][3, 40000] = poison
+                loss = plan.launch()
+                torch.cuda.synchronize()
+                assert not torch.isfinite(loss).item(), (mode, poison)
+                if mode == 1:     # (the staged kernel masks part of the conv block)
+                    for k, v in plan.named.items():
+                        assert not torch.isfinite(v).any(), (mode, poison, k)
+                else:
+                    assert not torch.isfinite(plan.flat[:-1]).all(), (mode, poison)
+                prepared[0][3, 40000] = 0.25
+    finally:
+        F.set_concurrent_weight_products(1)
+    for k in got[1]:
+        assert rel_err(got[1][k], got[0][k]) < 5e-6, (k, rel_err(got[1][k], got[0][k]))
