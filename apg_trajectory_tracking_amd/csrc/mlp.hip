@@ -1341,16 +1341,22 @@ __device__ __forceinline__ void pack_cwg(const PackArgs &A, int tid, int T) {
 // bound on |W_1^T delta| per unit of max |delta| (the LAST block computes them)
 __global__ __launch_bounds__(256) void mlp_pack_step_kernel(PackArgs A, int fwd_blocks) {
   if (blockIdx.x + 1 == gridDim.x) {
-    __shared__ float col[256];
+    // thread t: column t of W_1 (wave 0 = the 64 state columns, waves 1..3 the
+    // 160 conv columns); wave maxima by shuffles - nothing serial in here, this
+    // block must not outlast the table blocks it is launched with
+    __shared__ float wmax[4];
     const int t = threadIdx.x;
     float sum = 0.f;
-    if (t < kN1)
+    if (t < kN1) {
+#pragma unroll
       for (int k = 0; k < kW; ++k) sum += fabsf(A.pol.w_1[k * kN1 + t]);
-    col[t] = sum;
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) sum = fmaxf(sum, __shfl_xor(sum, sft, 64));
+    if ((t & 63) == 0) wmax[t >> 6] = sum;
     __syncthreads();
     if (t < 2) {
-      float m = 0.f;
-      for (int i = t ? kW : 0; i < (t ? kN1 : kW); ++i) m = fmaxf(m, col[i]);
+      const float m = t ? fmaxf(fmaxf(wmax[1], wmax[2]), wmax[3]) : wmax[0];
       // (a non-finite norm: 0 - the gradients are non-finite anyway)
       A.dst[kCfLds + kWgTabFloats + t] =
           m > 0.f && m < 3.0e38f ? (float)__builtin_amdgcn_frexp_expf(m) : 0.f;
@@ -2179,8 +2185,8 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
 #pragma unroll
       for (int i = 0; i < 16; ++i)
         dT[nb][i] = __builtin_amdgcn_ldexpf(t[i], e0) * (1.f - xv[i] * xv[i]);
+      if (nb == 0) load_hv(pH3);
     }
-    load_hv(pH3);
     zero(d);
 #pragma unroll
     for (int kb = 0; kb < 3; ++kb) {
@@ -2244,9 +2250,11 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
 #pragma unroll
       for (int i = 0; i < 16; ++i)
         dT[nb][i] = __builtin_amdgcn_ldexpf(t[i], e_) * (1.f - xv[i] * xv[i]);
+      // (the tanh' operands of the feature-major chain below: requested here so
+      // that they land under the second block's products)
+      if (nb == 0) load_hv(x_plane);
       __builtin_amdgcn_sched_barrier(0);
     }
-    load_hv(x_plane);
     zero(nx);
     dense64T_16(nx, x, L16, 0, tab);
 #pragma unroll
