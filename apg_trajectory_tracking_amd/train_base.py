@@ -402,6 +402,18 @@ class TrainBase:
         if (not g["momentum"] or g["dampening"] or g["nesterov"] or g["weight_decay"]
                 or g.get("maximize")):
             return None
+        # (called once per step: the walk over the network and the optimizer's
+        # state is repeated only when one of them is a different object -
+        # load_state_dict installs a new state mapping - or the policy tensors,
+        # the buffers or the settings the answer depends on have changed)
+        tensors = F.mlp_param_objects(self.net)
+        fast = (id(opt), id(opt.state), g["lr"], g["momentum"]) + tuple(map(id, tensors))
+        hit = getattr(self, "_iku", None)
+        if hit is not None and hit[0] == fast and all(
+                opt.state[p].get("momentum_buffer") is b
+                for p, b in zip(tensors, hit[1][2].values())):
+            return hit[1]
+        self._iku = None
         named = dict(self.net.named_parameters())
         listed = {id(p) for p in g["params"]}
         bufs = {}
@@ -414,7 +426,10 @@ class TrainBase:
             if st.get("momentum_buffer") is None:
                 st["momentum_buffer"] = torch.zeros_like(p)
             bufs[name] = st["momentum_buffer"]
-        return float(g["lr"]), float(g["momentum"]), bufs
+        out = float(g["lr"]), float(g["momentum"]), bufs
+        if len(tensors) == len(bufs):
+            self._iku = (fast, out)
+        return out
 
     def _step_direct(self, loss, named_grads, flat=None, stepped=False):
         """_step for the fused-policy paths: the kernels already produced the
@@ -457,10 +472,13 @@ class TrainBase:
         if msg is not None and parallel.world_size() > 1:
             parallel.dist.all_reduce(msg, op=parallel.dist.ReduceOp.SUM)
 
-    def _graph_signature(self, inputs, volatile):
+    def _graph_signature(self, inputs, volatile, params=None):
         """What a captured step is tied to.  Resident-shard captures (no
         `volatile` index buffer) also depend on the CONTENT of their inputs
-        (kept plane copies): the in-place version counters are part of it."""
+        (kept plane copies): the in-place version counters are part of it.
+        `params`: the parameter tensors the step reads, when the caller knows
+        them (the fused paths: 12 attribute reads instead of a walk over the
+        module tree, which costs more than the rest of the signature)."""
         import ctypes
         dyn = self.train_dynamics
         phys = getattr(dyn, "params", None)
@@ -476,10 +494,9 @@ class TrainBase:
                 # are new tensor objects every time they are taken)
                 + tuple((t.data_ptr(), tuple(t.shape)) for t in volatile)
                 # a replaced network or optimizer must not replay the old graph
-                + tuple(id(p) for p in self.net.parameters())
+                + tuple(map(id, self.net.parameters() if params is None else params))
                 # (load_state_dict replaces the momentum buffers)
-                + tuple(getattr(st.get("momentum_buffer"), "data_ptr", int)()
-                        for st in opt.state.values())
+                + tuple(id(st.get("momentum_buffer")) for st in opt.state.values())
                 + (id(opt), hyper, phys, float(self.delta_t),
                    float(self.delta_t_train), self._reducing()))
 
@@ -536,19 +553,19 @@ class TrainBase:
         return (bool(self.plan_steps) and self._graphable() and not self._reducing()
                 and torch.cuda.is_available())
 
-    def _planned(self, key, inputs, build, volatile=(), events=None):
+    def _planned(self, key, inputs, build, volatile=(), events=None, params=None):
         """Run the step from its plan, (re)built by `build()` when the signature
         of `_graphed` no longer holds (same meaning of `inputs` / `volatile`)."""
         cache = getattr(self, "_epoch_sigs", None)
         sig = cache.get(key) if cache is not None else None
         if sig is None:
-            sig = self._graph_signature(inputs, volatile)
+            sig = self._graph_signature(inputs, volatile, params)
             if cache is not None:
                 cache[key] = sig
         g = self._graphs.get(key)
         if not isinstance(g, _PlannedStep) or g.signature != sig:
             g = self._graphs[key] = build()
-            g.signature = self._graph_signature(inputs, volatile)
+            g.signature = self._graph_signature(inputs, volatile, params)
             if cache is not None:
                 cache[key] = g.signature
         return g(borrow=getattr(self, "_borrow_loss", False) or self.borrow_loss,

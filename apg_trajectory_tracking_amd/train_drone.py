@@ -259,6 +259,7 @@ class TrainDrone(TrainBase):
         stepped = update is not None
         planned = stepped and self._plannable()
         dyn = self.train_dynamics
+        tensors12 = (F.mlp_param_objects(n) or None) if planned else None
         if planned and prepared is not None:
             # (a slot of the pipelined epoch: its buffers are refilled by the
             # loop's gather, the plan reads them by address)
@@ -266,7 +267,7 @@ class TrainDrone(TrainBase):
                 ("concurrent", prepared[1].shape[-1], "slot", slot), (),
                 lambda: _PlannedStep(F.QuadConcurrentStepPlan(
                     n, prepared, self.delta_t, dyn.params, update=update), n),
-                volatile=tuple(prepared), events=events)
+                volatile=tuple(prepared), events=events, params=tensors12)
         if planned and index is not None:
             held = self._graph_index(index)       # persistent copy of the batch rows
             B = held.numel()
@@ -281,7 +282,7 @@ class TrainDrone(TrainBase):
                     n, out, self.delta_t, dyn.params, update=update), n, before=gather)
             return self._planned(("concurrent", B),
                                  (in_state, current_state, in_ref_states, ref_states),
-                                 build, volatile=(held,))
+                                 build, volatile=(held,), params=tensors12)
         if planned and self.static_shard and in_state is not None:
             src = (in_state, current_state, in_ref_states, ref_states)
 
@@ -292,7 +293,7 @@ class TrainDrone(TrainBase):
                         "concurrent", src, F.quad_concurrent_prepare(*src))
                 return _PlannedStep(F.QuadConcurrentStepPlan(
                     n, hit, self.delta_t, dyn.params, update=update), n)
-            return self._planned("concurrent", src, build)
+            return self._planned("concurrent", src, build, params=tensors12)
         if prepared is not None:
             def compute():
                 return F.quad_concurrent_policy_grads(
