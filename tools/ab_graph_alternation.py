@@ -19,6 +19,7 @@ t = TrainDrone(q, q, cfg)
 torch.manual_seed(0)
 t.initialize_model(device=dev, seed=0)
 t.static_shard, t.graph_steps, t.borrow_loss = True, True, True
+t.plan_steps = False           # (this part is about captured graphs)
 d = t.state_data
 step = lambda: t.train_concurrent_fused(d.normed_states, d.states, d.in_ref_states, d.ref_states)
 step(); step()
@@ -43,7 +44,9 @@ def timed(fn, n=400):
 for rep in range(3):
     same = timed(lambda i: ga.graph.replay())
     alt = timed(lambda i: (ga if i & 1 else gb).graph.replay())
+    t.plan_steps = True        # ... and the trainer's default: the step plan
     via = timed(lambda i: step())
+    t.plan_steps = False
     print(f'{{"same_graph_ms": {same:.4f}, "alternating_ms": {alt:.4f}, '
           f'"through_trainer_ms": {via:.4f}}}')
 

@@ -22,6 +22,9 @@ for m in concurrent autoregressive LSTM; do
 done
 for m in concurrent LSTM autoregressive; do k=to_soa_kernel; [ $m = concurrent ] && k=mlp_concurrent_fwd_kernel; rocprofv3 --kernel-trace --output-format csv -d $O/re -- python tools/time_run_epoch.py $m graph 8 > /dev/null 2>&1; python tools/trace_step.py $(ls $O/re/*/*kernel_trace.csv | head -1) $k > $O/run_epoch_${m}_timeline.txt; rm -rf $O/re; done
 python tools/ab_graph_alternation.py > $O/ab_graph_alternation.jsonl 2>/dev/null
+python tools/ab_weight_products.py time > $O/ab_weight_products.txt 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/wp -- python tools/ab_weight_products.py time > /dev/null 2>&1
+grep -i "concurrent\|wgrad\|pack_step" $(ls $O/wp/*/*kernel_stats.csv | head -1) | cut -d, -f1-4 >> $O/ab_weight_products.txt; rm -rf $O/wp
 # 6. packed step timeline
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pk -- python bench.py --steps 5 --warmup 2 --min-ms 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 cp $(ls $O/pk/*/*kernel_stats.csv | head -1) $O/bench_full_kernel_stats.csv; rm -rf $O/pk
