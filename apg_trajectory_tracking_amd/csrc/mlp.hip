@@ -2253,7 +2253,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
       // (the tanh' operands of the feature-major chain below: requested here so
       // that they land under the second block's products)
       if (nb == 0) load_hv(x_plane);
-      __builtin_amdgcn_sched_barrier(0);
     }
     zero(nx);
     dense64T_16(nx, x, L16, 0, tab);
@@ -2373,7 +2372,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
 #pragma unroll
         for (int i = 0; i < 16; ++i) lds_add2(q + i * 128, q + 4096 + i * 128, acc[i], kFix);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll 1
     for (int eb = 0; eb < 5; ++eb) {
@@ -2422,7 +2420,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();

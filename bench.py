@@ -262,15 +262,17 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0
 STEP_MODELS = {
     # mode: fp16 MFMAs per wave (forward + reverse; per step for the unrolled
     # modes), plane bytes per env-step and per trajectory
-    # round 4: weight gradients inside the reverse kernel - forward 222,
-    # reverse 150, and per workgroup of 256 trajectories 36 block products of 48
-    # + 8 bias blocks of 32 instructions (= 248 per wave-equivalent of 32)
-    "concurrent": dict(mfma_once=222 + 150 + 248, mfma_per_step=0, products_in_sweep=True,
+    # round 4: weight gradients inside the reverse kernel.  Forward 222; the
+    # trajectory-major reverse kernel 474 per wave: head 24 + 18 + 18 (weight
+    # blocks, transposed product, chain), fc3 / fc2 24 + 24 + 24 each, fc1 84 +
+    # 24 + 12 (its 14 blocks, states_in's cotangent and blocks) + conv 5 x (12 +
+    # 18).  (The staged kernel: 150 + 248.)
+    "concurrent": dict(mfma_once=222 + 474, mfma_per_step=0, products_in_sweep=True,
                        # forward writes 431 planes; reverse reads 256 (tanh') +
-                       # 521 (x of the products) + 45 (d_zout, masks) planes and
-                       # writes 37 x 4 KB of partials per 256 trajectories, read
+                       # 521 (x of the products) + 80 (d_zout twice) planes and
+                       # writes 30 x 4 KB of partials per 256 trajectories, read
                        # once more by the second stage; inputs 828
-                       bytes_per_traj=(431 + 256 + 521 + 45) * 4 + 2 * 37 * 4096 // 256 + 828,
+                       bytes_per_traj=(431 + 256 + 521 + 80) * 4 + 2 * 30 * 4096 // 256 + 828,
                        bytes_per_step=0,
                        # features 60 + state0 48 + in_ref H*36 + ref H*36
                        algo_bytes_per_traj=60 + 48 + 360 + 360),
