@@ -1954,13 +1954,6 @@ struct TBlock {
       for (int c = 0; c < 4; ++c) v[4 * g + c] = f[c];
     }
   }
-  __device__ __forceinline__ float absmax() const {
-    float v[16], m = 0.f;
-    get(v);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) m = fmaxf(m, fabsf(v[i]));
-    return m;
-  }
 };
 
 // the two k-blocks (8 trajectories per half-wave each) of 16 trajectory-major

@@ -40,8 +40,16 @@ __host__ __device__ constexpr int kin(int kb, int j, int hi) {
 // two fp32 values -> their packed fp16 high terms and packed fp16 low terms
 __device__ __forceinline__ void split_pair(float a, float b, unsigned &h, unsigned &l) {
   const h16x2 vh = {(_Float16)a, (_Float16)b};  // v_cvt_pk_f16_f32, round to nearest
-  const h16x2 vl = {(_Float16)(a - (float)vh[0]), (_Float16)(b - (float)vh[1])};
   h = __builtin_bit_cast(unsigned, vh);
+  // the remainders a - a_h, b - b_h (exact) as ONE mixed-precision fma each:
+  // v_fma_mix_f32 reads the fp16 term out of the packed register (the compiler
+  // does not form it: it converts back and subtracts, two instructions)
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]"
+      : "=v"(ra) : "v"(h), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=v"(rb) : "v"(h), "v"(b));
+  const h16x2 vl = {(_Float16)ra, (_Float16)rb};
   l = __builtin_bit_cast(unsigned, vl);
 }
 
