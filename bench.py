@@ -80,7 +80,7 @@ def parse():
                     help="rank logic only, gloo on the CPU, stub kernels")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the fixed-wing dual-roofline block")
-    ap.add_argument("--train-steps", type=int, default=40,
+    ap.add_argument("--train-steps", type=int, default=400,
                     help="steps of the secondary full-training-step "
                          "measurement (0 disables it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -338,10 +338,13 @@ def step_roofline(mode, B, H, n_params, ms):
 
 def timed_steps(step, n, dist):
     """(ms per step, last output, per-chunk ms) of `n` calls, each chunk
-    bracketed by barrier + synchronize (so every rank sees the slowest rank).  The calls are timed in four chunks and the MEDIAN
-    chunk is reported: one host or driver stall inside a 20-step region (seen
-    once: 60 ms in an LSTM block, 3.5 ms "per step") would otherwise be the
-    number; every chunk's mean is in the line next to it."""
+    bracketed by barrier + synchronize (so every rank sees the slowest rank).
+    The calls are timed in four chunks and the MEDIAN chunk is reported: one
+    host or driver stall inside a region (seen once: 60 ms in an LSTM block,
+    3.5 ms "per step") would otherwise be the number; every chunk's mean is in
+    the line next to it.  Chunks of 100 steps by default (--train-steps 400): a
+    chunk pays one pipeline fill and one synchronize, ~50 us - at 10 steps per
+    chunk that was 4 % of the concurrent step."""
     for _ in range(3):
         out = step()
     chunks = []
