@@ -494,7 +494,10 @@ class TrainBase:
                 # are new tensor objects every time they are taken)
                 + tuple((t.data_ptr(), tuple(t.shape)) for t in volatile)
                 # a replaced network or optimizer must not replay the old graph
-                + tuple(map(id, self.net.parameters() if params is None else params))
+                # (`p.data = other` keeps the Parameter object and moves its
+                # storage: the address is part of it)
+                + tuple((id(p), p.data_ptr())
+                        for p in (self.net.parameters() if params is None else params))
                 # (load_state_dict replaces the momentum buffers)
                 + tuple(id(st.get("momentum_buffer")) for st in opt.state.values())
                 + (id(opt), hyper, phys, float(self.delta_t),

@@ -353,6 +353,20 @@ def test_graph_signature_covers_values_captured_by_value():
     v0 = t._graph_signature((x,), (idx,))
     x.add_(1)                    # index-batch captures read the data set live
     assert t._graph_signature((x,), (idx,)) == v0
+    # a parameter whose STORAGE moves (`p.data = ...` keeps the object): the
+    # captured kernels hold the old address
+    t.net.fc2.weight.data = t.net.fc2.weight.data.clone()
+    v1 = t._graph_signature((x,), (idx,))
+    assert v1 != v0
+    # the fused paths pass the 12 parameter objects they read themselves
+    from apg_trajectory_tracking_amd import functional as F
+    objs = F.mlp_param_objects(t.net)
+    assert len(objs) == 12 and all(isinstance(p, torch.nn.Parameter) for p in objs)
+    assert objs[6] is t.net.fc2.weight
+    w0 = t._graph_signature((x,), (idx,), objs)
+    t.net.fc3.bias = torch.nn.Parameter(t.net.fc3.bias.detach().clone())
+    assert t._graph_signature((x,), (idx,), F.mlp_param_objects(t.net)) != w0
+    assert F.mlp_param_objects(torch.nn.Linear(3, 3)) == ()
 
 
 def test_grad_allreducer_is_noop_single_process():
