@@ -2529,11 +2529,17 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
       float s = 0.f;
       for (int q = 0; q < n_src; ++q) {
         const float *p = A.part + (size_t)(slot + q) * 1024 + (t & 1023);
-        float v[kRedChunk];   // all loads in flight, then a fixed-order sum
+        // kRedChunk rows at a time (all loads in flight, then a fixed-order
+        // sum); more than kRedChunk chunk rows - batches beyond 262 144
+        // trajectories - take further rounds
+        for (int w0 = 0; w0 < A.wgs; w0 += kRedChunk) {
+          float v[kRedChunk];
 #pragma unroll
-        for (int w = 0; w < kRedChunk; ++w) v[w] = w < A.wgs ? p[(size_t)w * stride] : 0.f;
+          for (int w = 0; w < kRedChunk; ++w)
+            v[w] = w0 + w < A.wgs ? p[(size_t)(w0 + w) * stride] : 0.f;
 #pragma unroll
-        for (int w = 0; w < kRedChunk; ++w) s += v[w];
+          for (int w = 0; w < kRedChunk; ++w) s += v[w];
+        }
       }
       *dst = s;
       if (A.update) {   // torch.optim.SGD: buf = momentum buf + grad, p -= lr buf

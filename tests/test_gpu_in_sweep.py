@@ -297,3 +297,34 @@ def test_both_product_kernels_agree_at_full_size_and_flag_non_finite_operands(de
         F.set_concurrent_weight_products(1)
     for k in got[1]:
         assert rel_err(got[1][k], got[0][k]) < 5e-6, (k, rel_err(got[1][k], got[0][k]))
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["trajectory_major", "staged"])
+def test_step_gradients_add_up_over_batch_halves_beyond_32_chunks(dev, mode):
+    """B = 300 011 is 1 172 workgroups = 37 chunk rows of the second stage (its
+    last level sums 32 rows per round): loss and every gradient must equal
+    the sum over two halves of the batch (each below 32 chunks) - sums over
+    trajectories are linear.  (Until late in round 4 the last level read 32
+    chunk rows and no more: batches beyond 262 144 lost the rest silently.)"""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    B, cut = 300011, 150016
+    torch.manual_seed(31)
+    net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+    _, inputs = _case(B, 9, dev)
+    dyn = FlightmareDynamics()
+    F.set_concurrent_weight_products(mode)
+    try:
+        whole = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
+        parts = [F.quad_concurrent_policy_grads(
+            net, *(t[sl].contiguous() for t in inputs), DT, dyn.params)
+            for sl in (slice(0, cut), slice(cut, B))]
+    finally:
+        F.set_concurrent_weight_products(1)
+    loss = parts[0][0].double() + parts[1][0].double()
+    assert abs(whole[0].double() - loss).item() <= 2e-6 * abs(loss.item())
+    for k, g in whole[1].items():
+        want = N(parts[0][1][k]) + N(parts[1][1][k])
+        assert rel_err(N(g), want) < 1e-5, (k, rel_err(N(g), want))
