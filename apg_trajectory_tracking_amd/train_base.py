@@ -410,7 +410,7 @@ class TrainBase:
         fast = (id(opt), id(opt.state), g["lr"], g["momentum"]) + tuple(map(id, tensors))
         hit = getattr(self, "_iku", None)
         if hit is not None and hit[0] == fast and all(
-                opt.state[p].get("momentum_buffer") is b
+                p.requires_grad and opt.state[p].get("momentum_buffer") is b
                 for p, b in zip(tensors, hit[1][2].values())):
             return hit[1]
         self._iku = None
