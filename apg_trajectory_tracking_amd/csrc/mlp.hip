@@ -1309,7 +1309,6 @@ constexpr int sOut = 0, sFc3 = 4, sFc2 = 8, sFc1 = 12, sSin = 26, sConv = 28, sB
               kSlots = 37;
 // second stage: workgroups per first-level chunk, element columns of 256
 constexpr int kRedChunk = 32;
-constexpr int kRedColumns = (kSlots * 1024 + 255) / 256;
 
 // first planes of the x blocks in the activation buffer (feat | x1 | h1 h2 h3 | in_ref)
 constexpr int pFeat = 0, pX1 = 15, pH1 = 239, pH2 = 303, pH3 = 367, pInr = 431,
