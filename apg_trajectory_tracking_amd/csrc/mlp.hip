@@ -1900,6 +1900,10 @@ constexpr int uConv = sConv, uBias = sConv + 1, kSlotsTm = sConv + 2;
 // cotangent's exponent is a loose bound (above), so it keeps a second limb: the
 // rounding remainder of every addition in units of 2^-38 (compact [channel][32]).
 constexpr int kFix = 22, kFixConv = 19;
+// The unit is folded into the operand scales (2^11 x 2^11, conv 2^10 x 2^9:
+// |operand| <= 2 048, far inside fp16), so a block element leaves the matrix
+// pipe already in accumulator units: the conversion is a rounding, no scaling.
+constexpr int kPreD = 11, kPreX = kFix - kPreD, kPreDc = 10, kPreXc = kFixConv - kPreDc;
 // Maxima are taken on the BIT PATTERNS of |v| (unsigned): finite values order as
 // they do as floats, inf and every NaN lie above them - a non-finite cotangent or
 // x is seen (a float max would drop a NaN, the integer conversion turn it into
@@ -1980,7 +1984,8 @@ __device__ __forceinline__ void lds_add(char *p, float v, int fix = kFix) {
                            __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
   }
-  const int q = (int)__builtin_rintf(__builtin_amdgcn_ldexpf(v, fix));
+  (void)fix;   // (v arrives in units of 2^-fix: see kPreD)
+  const int q = (int)__builtin_rintf(v);
   __hip_atomic_fetch_add(reinterpret_cast<int *>(p), q, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -1988,7 +1993,7 @@ __device__ __forceinline__ void lds_add(char *p, float v, int fix = kFix) {
 // two-limb addition (conv block; states_in's blocks, whose exponent is a bound as
 // well): v = hi 2^-fix + lo 2^-2 fix + O(2^-2 fix - 1)
 __device__ __forceinline__ void lds_add2(char *hi, char *lo, float v, int fix = kFixConv) {
-  const float s_ = __builtin_amdgcn_ldexpf(v, fix), qh = __builtin_rintf(s_);
+  const float s_ = v, qh = __builtin_rintf(s_);   // (v in units of 2^-fix already)
   __hip_atomic_fetch_add(reinterpret_cast<int *>(hi), (int)qh, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
   __hip_atomic_fetch_add(reinterpret_cast<int *>(lo),
@@ -2119,7 +2124,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
   auto add_bias = [&](const float (&v)[16], int e, int layer, int mb, int rows) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += __builtin_amdgcn_ldexpf(v[i], -e);
+    for (int i = 0; i < 16; ++i) s += __builtin_amdgcn_ldexpf(v[i], kFix - e);
     s += other_half(s);
     if (hi == 0 && row < rows) lds_add(lds + tBias + (layer * 64 + 32 * mb + row) * 4, s);
   };
@@ -2148,7 +2153,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
       for (int i = 0; i < 16; ++i)   // columns beyond B are somebody else's plane
         v[i] = rrow(i) + 4 * hi < nw ? v[i] : 0.f;
       add_bias(v, e0, 0, mb, mb ? kNA - 32 : 32);
-      split16(v, e0, az[mb]);
+      split16(v, e0 - kPreD, az[mb]);
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -2158,7 +2163,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
       else tx.load(Pact, vt, (unsigned)pH2 * pN + wcol);     // fc3's first x block
 
       Op16 bx[2];
-      split16(xv, 0, bx);
+      split16(xv, -kPreX, bx);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         f32x16 acc;
@@ -2216,7 +2221,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       add_bias(dT[mb], e_, bias_id, mb, 32);
-      split16(dT[mb], e_, ad[mb]);
+      split16(dT[mb], e_ - kPreD, ad[mb]);
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -2224,7 +2229,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
       tx.get(xv);
       tx.load(Pact, vt, (unsigned)(nb == 0 ? x_plane + 32 : next_plane) * pN + wcol);
       Op16 bx[2];
-      split16(xv, 0, bx);
+      split16(xv, -kPreX, bx);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         f32x16 acc;
@@ -2286,7 +2291,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       add_bias(dT[mb], e1, 3, mb, 32);
-      split16(dT[mb], e1, ad[mb]);
+      split16(dT[mb], e1 - kPreD, ad[mb]);
     }
     // B operands that stay: the 15 feature planes + a row of ones (states_in's
     // bias column), the 90 in_ref planes in three blocks (conv windows)
@@ -2298,19 +2303,19 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
       tf.get(v);
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = row == kNF ? 1.f : v[i];
-      split16(v, ff, bfeat);
+      split16(v, ff - kPreX, bfeat);
 #pragma unroll
       for (int jb = 0; jb < 3; ++jb) {
         tf.load(Pact, 32 * jb + row < kH * kRD ? vt : kDead,
                 (unsigned)(pInr + 32 * jb) * pN + wcol);
         tf.get(v);
-        split16(v, fi, binr[jb]);
+        split16(v, fi - kPreXc, binr[jb]);
       }
     }
     // fc1's weight blocks 2 nb, 2 nb + 1 against x block nb (scaled by 2^-fx)
     auto fc1_blocks = [&](const float (&xv)[16], int fx, int nb) {
       Op16 bx[2];
-      split16(xv, fx, bx);
+      split16(xv, fx - kPreX, bx);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         f32x16 acc;
@@ -2351,7 +2356,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
       for (int i = 0; i < 16; ++i)
         v[i] = __builtin_amdgcn_ldexpf(t[i], e1) * (1.f - xv[i] * xv[i]);
       Op16 as[2];
-      split16(v, es, as);
+      split16(v, es - kPreD, as);
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -2389,9 +2394,9 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
       // bias: column 27; the block's unit carries in_ref's scale 2^fi as well
       if (hi == 0)
         lds_add2(cblk + ((row >> 3) * 64 + 27) * 4, clo + ((row >> 3) * 32 + 27) * 4,
-                 __builtin_amdgcn_ldexpf(sum, -fi));
+                 __builtin_amdgcn_ldexpf(sum, kFixConv - fi));
       Op16 ac[2];
-      split16(v, 0, ac);
+      split16(v, -kPreDc, ac);
 #pragma unroll
       for (int jb = 0; jb < 3; ++jb) {
         f32x16 acc;

@@ -2,7 +2,8 @@
 (csrc/mlp.hip, mlp_concurrent_bwd_tm_kernel), modelled on the host: operands
 scaled into [-1, 1] by the workgroup's exponents, split into two fp16 terms,
 three products per term pair accumulated in fp32 per wave (32 trajectories),
-rounded to 32-bit fixed point (unit 2^-22) and added over the eight waves.
+rounded to 32-bit fixed point (unit 2^-22, folded into the operand scales as
+2^11 x 2^11) and added over the eight waves.
 What the model pins: the integer sum does not depend on the order of the waves
 (bit-reproducibility), it cannot overflow for operands at their bounds, and
 the result is as close to float64 as an fp32 sum.  (The kernel itself is
@@ -10,7 +11,7 @@ compared with float64 autograd on the GPU: tests/test_gpu_in_sweep.py.)"""
 import numpy as np
 import pytest
 
-FIX = 22
+FIX, PRE = 22, 11
 
 
 def _exp(a):
@@ -47,9 +48,11 @@ def _workgroup_block(delta, x, order):
     total = np.zeros((32, 32), np.int64)
     for w in order:
         sl = slice(32 * w, 32 * w + 32)
-        acc = _wave_block(np.ldexp(delta[:, sl], -e).astype(np.float32),
-                          np.ldexp(x[:, sl], -f).astype(np.float32))
-        q = np.rint(np.ldexp(acc.astype(np.float64), FIX)).astype(np.int64)
+        # (the unit is folded into the operand scales, 2^11 each: the block
+        # element leaves the matrix pipe in accumulator units)
+        acc = _wave_block(np.ldexp(delta[:, sl], PRE - e).astype(np.float32),
+                          np.ldexp(x[:, sl], FIX - PRE - f).astype(np.float32))
+        q = np.rint(acc.astype(np.float64)).astype(np.int64)
         assert np.abs(q).max() < 2 ** 28
         total += q
     assert np.abs(total).max() < 2 ** 31          # fits the 32-bit accumulator
