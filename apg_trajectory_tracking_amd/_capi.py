@@ -185,6 +185,13 @@ SIGNATURES = {
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
         _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P,
         ctypes.POINTER(ApgMlpSgdUpdate), ctypes.POINTER(ApgStepEvents), _P],
+    "apg_quad_mlp_rollout_step_workspace_floats": [],
+    "apg_quad_mlp_rollout_step_partials_floats": [_I],
+    "apg_quad_mlp_rollout_train_step": [
+        _P, _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
+        _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P,
+        ctypes.POINTER(ApgMlpSgdUpdate), _P],
     "apg_quad_mlp_closed_loop": [
         _P, _I, _F, ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgMlpPolicy),
         _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -250,6 +257,7 @@ SIGNATURES = {
 _RESTYPES = {"apg_last_error_string": ctypes.c_char_p,
              "apg_planes_gemm_multi_workspace_floats": ctypes.c_longlong,
              "apg_quad_mlp_step_partials_floats": ctypes.c_longlong,
+             "apg_quad_mlp_rollout_step_partials_floats": ctypes.c_longlong,
              "apg_linear_wgrad_workspace_floats": ctypes.c_longlong}
 
 _lib = None

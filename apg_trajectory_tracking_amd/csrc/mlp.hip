@@ -171,10 +171,22 @@ struct FwdArgs {
   float *feat, *x1, *h;  // [15][N], [224][N], [192][N] (h1, h2, h3)
   unsigned *mask;        // [5][N]
   const float *tables;  // packed operand tables (mlp_pack_cfwd_kernel)
+  // [waves][H][4] or NULL: per step max relu(conv), |feature|, a bound of the
+  // |window value|s of each wave's 32 trajectories (the in-sweep reverse kernel's
+  // fixed-point scales, see mlp_rollout_bwd_tm_kernel)
+  float *xmax;
   QuadConst c;
   int B;
 };
 
+__device__ __forceinline__ float wave_fmax(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
+  return v;
+}
+
+// XMAX: also leave the step maxima at A.xmax (compile time: the step loop has no branch)
+template <bool XMAX>
 __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds(lds, A.tables, kCfLds);
@@ -209,6 +221,13 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
   for (int r = 0; r < kH; ++r)
 #pragma unroll
     for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vwin, (r * kRD + j) * pitchB);
+  float wmax_raw = 0.f;   // largest |window value| of the rows seen so far (A.xmax)
+  if (XMAX) {
+#pragma unroll
+    for (int r = 0; r < kH; ++r)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) wmax_raw = fmaxf(wmax_raw, fabsf(w[r][j]));
+  }
 
 #pragma unroll 1
   for (int k = 0; k < kH; ++k) {
@@ -224,6 +243,19 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
     quad_features(s, t, feat);
 #pragma unroll
     for (int j = 0; j < kNF; ++j) Pfe.st(vn_lo, j * pN, feat[j]);
+    float xm_c = 0.f;   // largest relu(conv) of this step (see A.xmax)
+    if (XMAX) {         // feature and window maxima: transient
+      float xm_f = 0.f;
+#pragma unroll
+      for (int j = 0; j < kNF; ++j) xm_f = fmaxf(xm_f, fabsf(feat[j]));
+      // window values are raw - position (columns 0..2, lower half): a bound
+      const float xm_i = wmax_raw + (hi ? 0.f : fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fabsf(s[2])));
+      const float rf = wave_fmax(xm_f), ri = wave_fmax(xm_i);
+      if (lane == 0) {
+        float *q = A.xmax + ((size_t)(blockIdx.x * (kThreads / 64) + wave) * kH + k) * 4;
+        q[1] = rf, q[2] = ri;
+      }
+    }
 
     // the policy on the 16-bit matrix pipe (policy_mfma16.h): every operand as
     // two fp16 terms, three products per k-block
@@ -282,6 +314,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
           float v = cv[i];
           mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
           v = fmaxf(v, 0.f);
+          if (XMAX) xm_c = fmaxf(xm_c, v);
           // plane 64 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
           Px1.st(i < 8 ? vc : vn_lo, (kW + rrow(i) * kNP + pos) * pN, v);
           rv[e * 12 + i] = v;
@@ -301,6 +334,11 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
       Pmk.stu(g < 2 ? vm : vn_lo, 2 * g * pN, mbits[g]);
+    if (XMAX) {
+      const float rc = wave_fmax(xm_c);
+      if (lane == 0)
+        A.xmax[((size_t)(blockIdx.x * (kThreads / 64) + wave) * kH + k) * 4] = rc;
+    }
     // fc1 state part on s1 = tanh(states_in); h1 -> h2 -> h3 (the tanh of a
     // layer is applied, and stored, where the next layer consumes it)
     dense64_16(a, u, L16, hA, n1s, [&](int rb, int i, float v) {
@@ -352,6 +390,10 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
         for (int j = 0; j < 5; ++j) w[r][j] = w[r + 1][j];
 #pragma unroll
       for (int j = 0; j < 5; ++j) w[kH - 1][j] = Pin.ld(vwin, ((k + kH) * kRD + j) * pB);
+      if (XMAX) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) wmax_raw = fmaxf(wmax_raw, fabsf(w[kH - 1][j]));
+      }
     }
   }
 }
@@ -2449,11 +2491,11 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
 // the loss partials of the forward kernel.
 // destination of element (slot, reg i, lane) - or NULL (padding)
 __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, int i, int lane,
-                                          int bias_slot) {
+                                          int bias_slot, int head_rows = kNA) {
   const int rowb = rrow(i) + 4 * (lane >> 5), col = lane & 31;
   if (slot < sFc1) {                       // head, fc3, fc2: [cb][mb]
     const int q = slot & 3, cb = q >> 1, m = 32 * (q & 1) + rowb, k = 32 * cb + col;
-    if (slot < sFc3) return m < kNA ? g.w_out + m * kW + k : nullptr;
+    if (slot < sFc3) return m < head_rows ? g.w_out + m * kW + k : nullptr;
     return (slot < sFc2 ? g.w_3 : g.w_2) + m * kW + k;
   }
   if (slot < sSin) {                       // fc1: 7 column blocks x 2 row blocks
@@ -2472,7 +2514,7 @@ __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, 
   const int e = i * 64 + lane;             // bias slot: [layer][64]
   if (e >= 4 * 64) return nullptr;
   const int layer = e >> 6, m = e & 63;
-  return layer == 0 ? (m < kNA ? g.b_out + m : nullptr)
+  return layer == 0 ? (m < head_rows ? g.b_out + m : nullptr)
          : layer == 1 ? g.b_3 + m : layer == 2 ? g.b_2 + m : g.b_1 + m;
 }
 
@@ -2500,6 +2542,7 @@ struct WgReduceArgs {
   // slot layout of the reverse kernel that wrote `part`: slots per workgroup,
   // where the bias slot is, how many conv position blocks follow sConv
   int n_slots, bias_slot, conv_src;
+  int head_rows;       // rows of fc_out (40: concurrent mode, 4: autoregressive)
   const float *loss_partials;
   float *loss;
   int wgs, n_partials;   // wgs: how many [kSlots * 1024] rows `part` has
@@ -2527,7 +2570,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
   const size_t stride = (size_t)A.n_slots * 1024;
   if (t < A.n_slots * 1024) {
     const int slot = t >> 10, i = (t >> 6) & 15, lane = t & 63;
-    float *dst = wg_dest(A.g, slot, i, lane, A.bias_slot);
+    float *dst = wg_dest(A.g, slot, i, lane, A.bias_slot, A.head_rows);
     if (dst) {
       const int n_src = slot == sConv ? A.conv_src : 1;   // the position blocks
       float s = 0.f;
@@ -2547,8 +2590,8 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
       }
       *dst = s;
       if (A.update) {   // torch.optim.SGD: buf = momentum buf + grad, p -= lr buf
-        float *pp = wg_dest(A.param, slot, i, lane, A.bias_slot),
-              *pm = wg_dest(A.mom, slot, i, lane, A.bias_slot);
+        float *pp = wg_dest(A.param, slot, i, lane, A.bias_slot, A.head_rows),
+              *pm = wg_dest(A.mom, slot, i, lane, A.bias_slot, A.head_rows);
         // (in double with one rounding each, as torch's fused SGD kernel does
         // it: a trainer that steps through optimizer.step() - the multi-rank
         // form - gets the same bits)
@@ -2568,6 +2611,846 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
     __syncthreads();
     if (threadIdx.x == 0) *A.loss = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
   }
+}
+
+// ---------------------------------------------------------------------------
+// Round 5: the AUTOREGRESSIVE reverse sweep with every weight gradient inside
+// (TrainDrone.train_recurrent_model's loss.backward(), scripts/train_drone.py:
+// 113-173, in ONE launch: no cotangent planes, no product launches).
+//
+// Until round 4 the reverse sweep wrote 256 cotangent planes of H B floats and
+// 720 conv diagonals for nine planes_gemm launches that read them and the 431
+// activation planes again (474 us of the 1 111 us step at B = 65 536).  Here
+// the products happen where the cotangents are, in the trajectory-major form
+// of mlp_concurrent_bwd_tm_kernel: per step and layer every wave multiplies
+// ITS 32 trajectories' cotangent (swapped-operand product: trajectory in the
+// registers, feature in the lane) against its own x (four 16-byte loads per
+// lane from the forward sweep's planes) and adds the 32 x 32 blocks into the
+// workgroup's 32-bit fixed-point accumulators in LDS (ds_add_u32: order-free,
+// bit-reproducible).  What the recurrence adds to the concurrent form:
+//  * the operand tables (50 blocks, 102 KB) stay live for all H steps, so only
+//    56 KB of LDS are left for accumulators: a step is FIVE phases - head +
+//    fc3 | fc2 | fc1 (s1 columns) + states_in | fc1 (conv columns 0..95) |
+//    fc1 (conv columns 96..159), the conv block collecting over the last two -
+//    whose blocks alternate between two 24 KB regions; behind each phase's
+//    barrier the region is FLUSHED into the workgroup's own partial buffer in
+//    global memory (fixed point -> float x the step's scale, one
+//    global_atomic_add_f32 per element, no return value; the first step
+//    stores) while the next phase adds into the other region.  The partial
+//    buffer is 120 KB per workgroup, L2 / Infinity-Cache resident: 10 x 31 MB
+//    of read-modify-write at the caches against 2.9 GB of HBM planes gone.
+//    One thread owns an element for the whole sweep and the steps add in
+//    order: the sums are deterministic.
+//  * the cotangent scale changes from step to step, so every phase has its own
+//    workgroup exponent (the waves' maxima are exchanged through LDS behind
+//    the barrier that is there anyway; a step's first barrier sits behind the
+//    NEXT step's dynamics adjoint and head, which produce the first maxima)
+//    and the flush applies it: the global accumulators are plain floats.
+//  * the feature-major chain feeds the dynamics adjoint, so - unlike in the
+//    concurrent kernel - it keeps the PER-TRAJECTORY power-of-two scaling of
+//    scaled_split64; the swapped products take the same operands, their rows
+//    (trajectories) therefore arrive with different scales, and the exponents
+//    are brought into the accumulator layout by one more matrix instruction
+//    (texp: D[trajectory][feature] = ex[trajectory]).
+//  * the windows of the conv product are relative to the drone's position of
+//    the step: the in_ref blocks are loaded trajectory-major per step and the
+//    position planes subtracted from their columns 0..2 before the split.
+// Tables (bytes from gA; blocks of 2 KB in cbwd_weight's order): fc1^T conv
+// part [eb][kb] first (addressed with a run-time block index: below 60 KB),
+// states_in^T, the two head^T blocks (4 real k-slots), fc3^T, fc2^T, fc1^T
+// state part.
+#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_AR_KNOCKOUT)
+#error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
+#endif
+#ifndef APG_AR_KNOCKOUT
+#define APG_AR_KNOCKOUT 0   // timing experiments: 1 no global atomics, 2 no weight-block
+                            // products, 4 no LDS adds, 8 no conv-weight products,
+                            // 16 no workgroup barriers
+#endif
+constexpr int a1c = 0, aS = 20, aH = 24, a3 = 26, a2 = 34, a1s = 42, aBlocks = 50;
+constexpr int kArTabBytes = gA + aBlocks * kBlock16;   // 104 448
+constexpr int kArTabFloats = kArTabBytes / 4;
+// LDS behind the tables: two alternating accumulator regions of six blocks, the
+// conv block, bias sums [4][64], the head block [4][64], meta
+constexpr int kArRegion = 6 * 4096;
+constexpr int rX = kArTabBytes, rY = rX + kArRegion, rConv = rY + kArRegion,
+              rBias = rConv + 4096, rHead = rBias + 1024, rMeta = rHead + 1024;
+static_assert((rMeta - rX) % 16 == 0, "zeroed in 16-byte pieces");
+
+__device__ __forceinline__ float car_weight(const ApgMlpPolicy &p, int n, int row, int j,
+                                            int hi) {
+  const int old = n < aS ? m1cT + (n - a1c) : n < aH ? mST + (n - aS)
+                  : n < a3 ? mOT + 3 * (n - aH) : n < a2 ? m3T + (n - a3)
+                  : n < a1s ? m2T + (n - a2) : m1sT + (n - a1s);
+  return cbwd_weight(p, old, row, j, hi, 4);
+}
+
+// forward tables at dst, the reverse tables of mlp_rollout_bwd_tm_kernel at
+// dst + kCfLds, behind them ns, nc (see mlp_pack_step_kernel; the LAST block)
+__global__ __launch_bounds__(256) void mlp_pack_ar_kernel(PackArgs A, int fwd_blocks) {
+  if (blockIdx.x + 1 == gridDim.x) {
+    __shared__ float wmax[4];
+    const int t = threadIdx.x;
+    float sum = 0.f;
+    if (t < kN1) {
+#pragma unroll
+      for (int k = 0; k < kW; ++k) sum += fabsf(A.pol.w_1[k * kN1 + t]);
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) sum = fmaxf(sum, __shfl_xor(sum, sft, 64));
+    if ((t & 63) == 0) wmax[t >> 6] = sum;
+    __syncthreads();
+    if (t < 2) {
+      const float m = t ? fmaxf(fmaxf(wmax[1], wmax[2]), wmax[3]) : wmax[0];
+      A.dst[kCfLds + kArTabFloats + t] =
+          m > 0.f && m < 3.0e38f ? (float)__builtin_amdgcn_frexp_expf(m) : 0.f;
+    }
+    return;
+  }
+  if ((int)blockIdx.x < fwd_blocks) {
+    pack_cfwd(A, blockIdx.x * blockDim.x + threadIdx.x, fwd_blocks * blockDim.x);
+    return;
+  }
+  const int tid = (blockIdx.x - fwd_blocks) * blockDim.x + threadIdx.x;
+  const int T = (gridDim.x - 1 - fwd_blocks) * blockDim.x;
+  float *dstf = A.dst + kCfLds;
+  unsigned *dst = reinterpret_cast<unsigned *>(dstf);
+  for (int idx = tid; idx < aBlocks * 64 * 4; idx += T) {
+    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+    const float w0 = car_weight(A.pol, n, l & 31, 2 * q, l >> 5);
+    const float w1 = car_weight(A.pol, n, l & 31, 2 * q + 1, l >> 5);
+    unsigned h, lo;
+    split_pair(w0, w1, h, lo);
+    dst[(gA + n * kBlock16) / 4 + l * 4 + q] = h;
+    dst[(gA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
+  }
+  const ApgMlpPolicy &p = A.pol;
+  for (int idx = tid; idx < 256; idx += T) {   // the four head rows, VALU order
+    const int hi = idx & 1, i = (idx >> 1) & 15, rb = (idx >> 5) & 1, j = idx >> 6;
+    dstf[gTo + idx] = p.w_out[j * kW + rb * 32 + rrow(i) + 4 * hi];
+  }
+  for (int idx = tid; idx < kNC * 3; idx += T) {
+    const int ch = idx / 3, q = idx % 3;
+    dstf[gAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
+                      p.conv_w[ch * 27 + q * 3 + 2];
+  }
+}
+
+struct ArTmArgs {
+  const float *state0, *states, *actions, *ref, *in_ref;
+  const float *feat, *x1, *h;    // [15][N], [224][N], [192][N] (the forward sweep's)
+  const unsigned *mask;          // [5][N]
+  float *loss_partials;
+  float *part;                   // [workgroups][kSlotsTm][1024]
+  float *grad_state0;
+  const float *tables;
+  const float *xmax;             // [waves][H][4] (the forward sweep's)
+  QuadConst c;
+  ApgQuadLossWeights w;
+  int B, ref_cols, vel_col;
+};
+
+// A trajectory-major block of an UNBOUNDED plane group with every value clamped
+// to the group's scale 2^f (live columns are inside it by construction: no-op).
+// The columns beyond the batch are somebody else's - another step's or another
+// trajectory's - values: finite, but not bound by THIS workgroup's maxima; they
+// meet a zero cotangent and must not become an overflowed fp16 operand on the
+// way.  (tanh planes need nothing: every column is in [-1, 1].)
+__device__ __forceinline__ void get_clamped(const TBlock &t, float (&v)[16], int f) {
+  t.get(v);
+  const float lim = __builtin_amdgcn_ldexpf(1.f, f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], -lim, lim);
+}
+
+// the per-trajectory exponents `ex` (lane = trajectory) in accumulator layout of
+// a swapped product: E[i] = ex of trajectory r(i) + 4 hi - one matrix
+// instruction, D[trajectory][feature] = ex[trajectory] x 1 (k-slot 0 only;
+// exponents are small integers: exact in fp16)
+__device__ __forceinline__ void texp(int ex, int hi, int (&E)[16]) {
+  const _Float16 hx = (_Float16)(float)ex;
+  u32x4 a = {0u, 0u, 0u, 0u}, o = {0u, 0u, 0u, 0u};
+  a[0] = hi ? 0u : (unsigned)__builtin_bit_cast(unsigned short, hx);
+  o[0] = hi ? 0u : 0x3c00u;
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  z = mfma16(a, o, z);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) E[i] = (int)z[i];
+}
+
+// The workgroup's accumulators in global memory through a buffer resource: the
+// per-thread part of an address is ONE VGPR (4 threadIdx.x), the block offset a
+// scalar - no 64-bit address pairs per flush site.  One element += v, no return
+// value (buffer_atomic_add_f32: executed at the L2); this thread owns the element
+// for the whole sweep, the steps add in order.
+__device__ __forceinline__ void gadd(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff,
+                                     float v) {
+  if (APG_AR_KNOCKOUT & 1) return;
+  __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r, (int)voff, (int)soff, 0);
+}
+
+// workgroup: N fixed-point accumulators at `off` -> += the floats from byte `dst`
+// of the partial buffer (x 2^(e - fix)), re-zeroed for their next user
+template <int N>
+__device__ __forceinline__ void flush_add(char *lds, int off, __amdgpu_buffer_rsrc_t r,
+                                          unsigned dst, int e, bool bad, int fix = kFix) {
+  static_assert(N % kThreads == 0 || N < kThreads, "whole rounds of the workgroup");
+  if (N < kThreads && (int)threadIdx.x >= N) return;   // (whole waves: N = 64, 256)
+  int *p = reinterpret_cast<int *>(lds + off) + threadIdx.x;
+#pragma unroll
+  for (int m = 0; m < (N < kThreads ? 1 : N / kThreads); ++m) {
+    const int q = p[m * kThreads];
+    p[m * kThreads] = 0;
+    gadd(r, threadIdx.x * 4u, dst + (unsigned)m * kThreads * 4u,
+         bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)q, e - fix));
+  }
+}
+
+// (knock-out builds: keep a block product alive without the LDS additions)
+__device__ __forceinline__ void ar_sink(const f32x16 &acc) {
+  float s_ = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s_ += acc[i];
+  asm volatile("" ::"v"(s_));
+}
+__device__ __forceinline__ void ar_barrier() {
+  if (APG_AR_KNOCKOUT & 16) return;
+  __syncthreads();
+}
+
+struct ArMeta {           // at rMeta; written by plain stores, one slot per wave
+  unsigned dmax[5][8];    // max |cotangent| bits of head, fc3, fc2, fc1, conv
+};
+static_assert(rMeta + (int)sizeof(ArMeta) <= kLdsAll, "LDS map");
+
+// B operand of the identity product that brings a trajectory-major block (an A
+// operand as split16 made it: k-slot j of k-block kk, half hi = trajectory
+// (j & 3) + 8 (j >> 2) + 16 kk + 4 hi) into accumulator layout, trajectory in
+// the lane: slot (kk, hi, j) of column n is 1 where that trajectory IS n.  From
+// the lane index: one half-word of the lane's eight is set.
+__device__ __forceinline__ void ident_operands(int lane_o, u32x4 (&I)[2]) {
+  const int n = lane_o & 31, hi = lane_o >> 5, m = n - 4 * hi;
+  const bool valid = m >= 0 && (m & 4) == 0;
+  const int kk = (m >> 4) & 1, q = ((m >> 3) & 1) * 2 + ((m >> 1) & 1);
+  const unsigned one = (m & 1) ? 0x3c000000u : 0x3c00u;
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) I[k2][q2] = (valid && kk == k2 && q == q2) ? one : 0u;
+}
+
+// 32 planes x the wave's 32 trajectories from their trajectory-major split (two
+// k-blocks, scaled by 2^s) to accumulator layout (feature r(i) + 4 hi of the
+// lane's trajectory, x 2^s): four matrix instructions instead of 32 loads per
+// lane of bytes the wave has just read in the other orientation
+__device__ __forceinline__ f32x16 to_feature_major(const Op16 (&bx)[2], const u32x4 (&I)[2]) {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    z = mfma16(bx[kk].l, I[kk], z);
+    z = mfma16(bx[kk].h, I[kk], z);
+  }
+  return z;
+}
+
+__global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  char *lds = reinterpret_cast<char *>(lds_f);
+  const int lane = threadIdx.x & 63, hi = lane >> 5, row = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b0 = blockIdx.x * kTrajPerBlock;
+  const int b = b0 + wave * 32 + row;
+  const int B = A.B;
+  const bool live = b < B, st_lo = live && hi == 0;
+  const unsigned pitchB = (unsigned)B * 4u, pitchN = pitchB * kH;
+  const QuadConst c = A.c;
+  const Planes Ps0(A.state0, 12, pitchB), Pst(A.states, kH * 12, pitchB);
+  const Planes Pac(A.actions, kH * 4, pitchB), Prf(A.ref, kH * A.ref_cols, pitchB);
+  const Planes Pin(A.in_ref, 2 * kH * kRD, pitchB);
+  const Planes Pfe(A.feat, kNF, pitchN), Px1(A.x1, kN1, pitchN), Ph(A.h, 3 * kW, pitchN);
+  const Planes Pmk(A.mask, 5, pitchN);
+  const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  // trajectory-major addressing: lane = plane `row` of a 32-plane block, its 16
+  // trajectories start 4 hi into the wave's 32
+  const unsigned wcolB = (unsigned)(b0 + wave * 32) * 4u;
+  const unsigned vtN = (unsigned)row * pitchN + (unsigned)hi * 16u;
+  const unsigned vtB = (unsigned)row * pitchB + (unsigned)hi * 16u;
+  // this workgroup's accumulators in global memory ([kSlotsTm][1024] floats)
+  const __amdgpu_buffer_rsrc_t part = __builtin_amdgcn_make_buffer_rsrc(
+      A.part + (size_t)blockIdx.x * kSlotsTm * 1024, 0, kSlotsTm * 4096, 0x00020000);
+  char *lane_blk = lds + lane * 4;
+  ArMeta &meta = *reinterpret_cast<ArMeta *>(lds + rMeta);
+  const int ns = (int)A.tables[kArTabFloats];
+  bool bad = false;         // (workgroup-uniform) a non-finite operand was seen
+
+  zero_region(lds, rX, rMeta - rX);
+  {  // the global accumulators start at zero: every flush is an atomic add
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int m = 0; m < kSlotsTm * 256; m += kThreads)
+      __builtin_amdgcn_raw_buffer_store_b128(z, part, (int)(threadIdx.x * 16u), m * 16, 0);
+  }
+  fill_lds_issue(lds_f, A.tables, kArTabFloats);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const LdsView16 L16(lds, lane);
+  const LdsView L(lds_f, lane);
+  float lam[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lam[i] = 0.f;
+  float loss = 0.f;
+  int rg = rX, ro = rY;     // the region the current phase adds into / the other one
+  int e5 = 0, ecv = 0;      // scales of the blocks whose flush is deferred to the next step
+  TBlock tx, tx2;
+  const auto post = [&](const f32x16 (&v)[2], int phase) {
+    unsigned am = 0u;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) am = umax_abs(am, v[rb][i]);
+    am = wave_umax(am);
+    if (lane == 0) meta.dmax[phase][wave] = am;
+  };
+  // bias gradient of 32 rows: sums over the lane's 16 trajectories, both halves
+  const auto add_bias = [&](const float (&v)[16], int e, int layer, int mb) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += __builtin_amdgcn_ldexpf(v[i], kFix - e);
+    s += other_half(s);
+    if (hi == 0) lds_add(lds + rBias + (layer * 64 + 32 * mb + row) * 4, s);
+  };
+  // the deferred blocks of a step: fc1's last four (conv columns 96..159) and
+  // the conv block
+  const auto flush_tail = [&]() {
+    flush_add<4 * 1024>(lds, rg, part, (sFc1 + 10) * 4096, e5, bad);
+    flush_add<1024>(lds, rConv, part, uConv * 4096, ecv, bad, kFixConv);
+  };
+
+#pragma unroll 1
+  for (int k = kH - 1; k >= 0; --k) {
+    const unsigned pB = opaque(pitchB), pN = opaque(pitchN);
+    const unsigned col = (unsigned)b * 4u + (unsigned)k * pitchB;
+    const unsigned vn = live ? col : kDead;
+    const unsigned wcolN = wcolB + (unsigned)k * pB;   // (scalar) column k B + the wave's first
+    // the identity operands of the transpositions: made per step from an opaque
+    // lane index (eight registers that would otherwise live through the sweep)
+    u32x4 ident[2];
+    {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      ident_operands(lane_o, ident);
+    }
+    // ------------------------------------------------ dynamics adjoint, head
+    float dz[4];
+    unsigned m0 = 0u;
+    f32x16 d[2], e[2];
+    float x3[2][16];      // h3, trajectory-major (both blocks: the head's x, tanh' of fc3)
+    {
+      float sn[12], sc[12], a[4], rp[3], rv[3];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        sn[i] = Pst.ld(vb, (k * 12 + i) * pB);
+        sc[i] = k > 0 ? Pst.ld(vb, ((k - 1) * 12 + i) * pB) : Ps0.ld(vb, i * pB);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = Pac.ld(vb, (k * 4 + j) * pB);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        rp[i] = Prf.ld(vb, (k * A.ref_cols + i) * pB);
+        rv[i] = Prf.ld(vb, (k * A.ref_cols + A.vel_col + i) * pB);
+      }
+      tx.load(Ph, vtN, (unsigned)(2 * kW) * pN + wcolN);        // h3, block 0
+      tx2.load(Ph, vtN, (unsigned)(2 * kW + 32) * pN + wcolN);  // h3, block 1
+      __builtin_amdgcn_sched_barrier(0);
+      float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float dp = sn[i] - rp[i], dv = sn[6 + i] - rv[i], wn = sn[9 + i];
+        lp += dp * dp, lv += dv * dv, lw += wn * wn;
+        lam[i] += 2.f * A.w.pos * dp;
+        lam[6 + i] += 2.f * A.w.vel * dv;
+        lam[9 + i] += 2.f * A.w.av * wn;
+      }
+      const float da0 = a[0] - 0.5f;
+      float ga[4];
+      ga[0] = 2.f * A.w.thrust * da0;
+#pragma unroll
+      for (int j = 1; j < 4; ++j) {
+        const float dd = a[j] - 0.5f;
+        lr += dd * dd;
+        ga[j] = 2.f * A.w.rates * dd;
+      }
+      loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
+              A.w.thrust * da0 * da0;
+      const Trig t = make_trig(&sc[3]);
+      quad_step_adjoint(lam, ga, a[0], &sc[9], c, t);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dz[j] = ga[j] * a[j] * (1.f - a[j]);
+        m0 = umax_abs(m0, dz[j]);
+      }
+    }
+    tx.get(x3[0]);
+    tx2.get(x3[1]);
+    tx.load(Ph, vtN, (unsigned)kW * pN + wcolN);   // fc3's first x block (h2)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      // d_pre3 = (W_out^T dL/dz) tanh'(h3): the head on the VALU, h3 in
+      // accumulator layout from its trajectory-major block
+      Op16 bx[2];
+      split16(x3[rb], -kPreX, bx);
+      const f32x16 hf = to_feature_major(bx, ident);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v = fmaf(L.T(gTo + ((j * 2 + rb) * 16 + i) * 2), dz[j], v);
+        const float h3 = __builtin_amdgcn_ldexpf(hf[i], -kPreX);
+        d[rb][i] = v * (1.f - h3 * h3);
+      }
+    }
+    m0 = wave_umax(m0);
+    if (lane == 0) meta.dmax[0][wave] = m0;
+    post(d, 1);
+    // the scales of the unbounded x plane groups of this step (conv outputs,
+    // features + the ones row, window values): the workgroup's maxima, left per
+    // wave and step by the forward sweep
+    unsigned mc = 0u, mf = 0x3f800000u /* the ones row */, mi = 0u;
+    {
+      const unsigned *q = reinterpret_cast<const unsigned *>(A.xmax) +
+                          ((size_t)blockIdx.x * (kThreads / 64) * kH + k) * 4;
+#pragma unroll
+      for (int w8 = 0; w8 < kThreads / 64; ++w8) {
+        mc = q[w8 * kH * 4] > mc ? q[w8 * kH * 4] : mc;
+        mf = q[w8 * kH * 4 + 1] > mf ? q[w8 * kH * 4 + 1] : mf;
+        mi = q[w8 * kH * 4 + 2] > mi ? q[w8 * kH * 4 + 2] : mi;
+      }
+    }
+    const int fc = bits_exp(mc, bad, true), ff = bits_exp(mf, bad, true),
+              fi = bits_exp(mi, bad, true);
+    ar_barrier();
+    // the previous step's last phase and its conv block (the first step: zeros)
+    flush_tail();
+    { const int r_ = rg; rg = ro, ro = r_; }
+
+    // ------------------------------------------------ phase 1: head, fc3
+    const int e0 = wg_exp(meta.dmax[0], bad), e3 = wg_exp(meta.dmax[1], bad);
+    float dT[2][16];        // the current layer's cotangent, trajectory-major
+    {
+      // dL/dz^T by an identity product (scaled into accumulator units), W_out's
+      // and b_out's gradient, d_pre3^T from the two head^T blocks
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v8[j] = (hi == 0 && j < 4) ? __builtin_amdgcn_ldexpf(dz[j < 4 ? j : 0], kPreD - e0) : 0.f;
+      const Op16 x0 = split8(v8);
+      // k-slot 8 hi + j of column c is 1 where it IS c
+      u32x4 idz;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        idz[q] = (8 * hi + 2 * q == row ? 0x3c00u : 0u) |
+                 (8 * hi + 2 * q + 1 == row ? 0x3c000000u : 0u);
+      f32x16 tzv;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tzv[i] = 0.f;
+      tzv = mfma16(x0.l, idz, tzv);
+      tzv = mfma16(x0.h, idz, tzv);
+      float tz[16], sb = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        tz[i] = tzv[i];
+        sb += __builtin_amdgcn_ldexpf(tz[i], kFix - kPreD);
+      }
+      sb += other_half(sb);
+      if (hi == 0 && row < 4) lds_add(lds + rBias + row * 4, sb);
+      Op16 az[2];
+      split16(tz, 0, az);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        Op16 bx[2];
+        split16(x3[nb], -kPreX, bx);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(az[kk], bx[kk], acc);
+        if (hi == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lds_add(lds + rHead + (i * 64 + 32 * nb + row) * 4, acc[i]);
+        }
+        f32x16 tt;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tt[i] = 0.f;
+        tt = mma3(x0, L16.A(gA, aH + nb), tt);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          dT[nb][i] = __builtin_amdgcn_ldexpf(tt[i], e0 - kPreD) * (1.f - x3[nb][i] * x3[nb][i]);
+      }
+    }
+    // One 64 x 64 layer: dl / dT = its cotangent in both layouts, e_ = the
+    // workgroup's exponent for it, x = planes [x_plane, +64) of X (the second
+    // block and `next_plane`'s first of Xn are requested on the way).  Weight
+    // blocks into the region at `rb`, the cotangent of the layer below in both
+    // layouts (tables `tab`; tanh' from the x blocks, brought into accumulator
+    // layout by to_feature_major), its maxima into slot `phase + 1`.
+    const auto layer64 = [&](f32x16 (&dl)[2], f32x16 (&nx)[2], int e_, int tab, const Planes &X,
+                             int x_plane, const Planes &Xn, int next_plane, int bias_id,
+                             int phase, char *rb) {
+      Op16 x[4];
+      const int ex = scaled_split64(dl, x);
+      Op16 ad[2][2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        add_bias(dT[mb], e_, bias_id, mb);
+        split16(dT[mb], e_ - kPreD, ad[mb]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        float xv[16];
+        tx.get(xv);
+        if (nb == 0) tx.load(X, vtN, (unsigned)(x_plane + 32) * pN + wcolN);
+        else tx.load(Xn, vtN, (unsigned)next_plane * pN + wcolN);
+        Op16 bx[2];
+        split16(xv, -kPreX, bx);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          if (APG_AR_KNOCKOUT & 2) break;
+          f32x16 acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) acc = mma3(ad[mb][kk], bx[kk], acc);
+          if (APG_AR_KNOCKOUT & 4) ar_sink(acc); else
+          add_block(rb + (2 * nb + mb) * 4096, acc);
+        }
+        f32x16 tt;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tt[i] = 0.f, nx[nb][i] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const Op16 w = L16.A(gA, tab + 4 * nb + kb);
+          tt = mma3(x[kb], w, tt);           // trajectory-major
+          nx[nb] = mma3(w, x[kb], nx[nb]);   // feature-major: the same block, operands swapped
+        }
+        int E[16];
+        texp(ex, hi, E);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          dT[nb][i] = __builtin_amdgcn_ldexpf(tt[i], E[i]) * (1.f - xv[i] * xv[i]);
+        const f32x16 hf = to_feature_major(bx, ident);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float hx = __builtin_amdgcn_ldexpf(hf[i], -kPreX);
+          nx[nb][i] = __builtin_amdgcn_ldexpf(nx[nb][i], ex) * (1.f - hx * hx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      post(nx, phase + 1);
+    };
+    layer64(d, e, e3, a3, Ph, kW, Ph, 0, 1, 1, lane_blk + rg);   // x = h2 -> d_pre2
+    ar_barrier();
+    if (threadIdx.x < 4 * 64) {   // W_out: [4][64] (waves 0..3)
+      const int idx = threadIdx.x;
+      int *p = reinterpret_cast<int *>(lds + rHead) + idx;
+      const int q = *p;
+      *p = 0;
+      gadd(part, (unsigned)((idx >> 6) * 64 + (idx & 31)) * 4u,
+           (sOut + 2 * ((idx >> 5) & 1)) * 4096,
+           bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)q, e0 - kFix));
+    }
+    flush_add<64>(lds, rBias, part, uBias * 4096, e0, bad);
+    flush_add<4 * 1024>(lds, rg, part, sFc3 * 4096, e3, bad);
+    flush_add<64>(lds, rBias + 256, part, uBias * 4096 + 256, e3, bad);
+    { const int r_ = rg; rg = ro, ro = r_; }
+
+    // ------------------------------------------------ phase 2: fc2 (x = h1)
+    const int e2 = wg_exp(meta.dmax[2], bad);
+    layer64(e, d, e2, a2, Ph, 0, Px1, 0, 2, 2, lane_blk + rg);   // -> d_pre1
+    ar_barrier();
+    flush_add<4 * 1024>(lds, rg, part, sFc2 * 4096, e2, bad);
+    flush_add<64>(lds, rBias + 512, part, uBias * 4096 + 512, e2, bad);
+    { const int r_ = rg; rg = ro, ro = r_; }
+
+    // ------------- phase 3: fc1 against s1 (x1 planes 0..63), states_in; the
+    // conv cotangent feature-major (position cotangent, its exact maximum)
+    const int e1 = wg_exp(meta.dmax[3], bad);
+    const int es = e1 + ns;                    // a bound of |d_pre_s|
+    Op16 x1s[4];    // d_pre1, scaled per trajectory and split: all of fc1^T's parts
+    const int ex1 = scaled_split64(d, x1s);
+    Op16 ad[2][2];  // d_pre1^T with the workgroup's scale: all of fc1's weight blocks
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      add_bias(dT[mb], e1, 3, mb);
+      split16(dT[mb], e1 - kPreD, ad[mb]);
+    }
+    // fc1's weight blocks of x block `xv` (scaled by 2^-fx), both row blocks
+    const auto fc1_blocks = [&](const Op16 (&bx)[2], char *blk) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        if (APG_AR_KNOCKOUT & 2) break;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(ad[mb][kk], bx[kk], acc);
+        if (APG_AR_KNOCKOUT & 4) ar_sink(acc); else
+        add_block(blk + mb * 4096, acc);
+      }
+    };
+    {
+      Op16 bfeat[2];   // the 15 feature planes + a row of ones (states_in's bias column)
+      {
+        TBlock tf;
+        tf.load(Pfe, row < kNF ? vtN : kDead, wcolN);
+        float v[16];
+        get_clamped(tf, v, ff);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = row == kNF ? 1.f : v[i];
+        split16(v, ff - kPreX, bfeat);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        float xv[16];
+        tx.get(xv);
+        tx.load(Px1, vtN, (unsigned)(32 * (nb + 1)) * pN + wcolN);
+        Op16 bx[2];
+        split16(xv, -kPreX, bx);
+        fc1_blocks(bx, lane_blk + rg + 2 * nb * 4096);
+        f32x16 tt;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tt[i] = 0.f, e[nb][i] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const Op16 w = L16.A(gA, a1s + 4 * nb + kb);
+          tt = mma3(x1s[kb], w, tt);
+          e[nb] = mma3(w, x1s[kb], e[nb]);
+        }
+        int E1[16];
+        texp(ex1, hi, E1);
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          v[i] = __builtin_amdgcn_ldexpf(tt[i], E1[i]) * (1.f - xv[i] * xv[i]);   // d_pre_s^T
+        Op16 as[2];
+        split16(v, es - kPreD, as);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(as[kk], bfeat[kk], acc);
+        // 16 columns are real (15 features + the ones row): compact [reg][half][16],
+        // 2 KB of high limbs per block, the low limbs 4 KB further
+        if (row < 16) {
+          char *q = lds + rg + 4 * 4096 + nb * 2048 + (hi * 16 + row) * 4;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) lds_add2(q + i * 128, q + 4096 + i * 128, acc[i], kFix);
+        }
+        // feature-major d_pre_s (block nb of its rows)
+        const f32x16 hf = to_feature_major(bx, ident);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float hx = __builtin_amdgcn_ldexpf(hf[i], -kPreX);
+          e[nb][i] = __builtin_amdgcn_ldexpf(e[nb][i], ex1) * (1.f - hx * hx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {  // feature-major: the feature cotangent, the state cotangent
+      // (the pre-step state and its trigonometry again: 18 registers that would
+      // otherwise live from the dynamics adjoint to here)
+      float sc[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i)
+        sc[i] = k > 0 ? Pst.ld(vb, ((k - 1) * 12 + i) * pB) : Ps0.ld(vb, i * pB);
+      f32x16 f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) f[i] = 0.f;
+      Op16 xs[4];
+      const int exs = scaled_split64(e, xs);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) f = mma3(L16.A(gA, aS + kb), xs[kb], f);
+      const Trig t = make_trig(&sc[3]);
+      float dfeat[kNF], gs[12];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float own = __builtin_amdgcn_ldexpf(f[i], exs), oth = other_half(own);
+        dfeat[rrow(i)] = hi ? oth : own;
+        if (rrow(i) + 4 < kNF) dfeat[rrow(i) + 4 < kNF ? rrow(i) + 4 : 0] = hi ? own : oth;
+      }
+      quad_features_adjoint(sc, t, dfeat, gs);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) lam[i] += gs[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {  // feature-major conv cotangent: relu', the sum over the positions of a
+       // channel -> the cotangent of the drone's position (window columns 0..2
+       // are relative), and its largest entry -> the conv block's exact scale
+      unsigned mw[5];
+#pragma unroll
+      for (int eb = 0; eb < 5; ++eb) mw[eb] = Pmk.ldu(vn, eb * pN);
+      float dpos[3] = {0.f, 0.f, 0.f};
+      unsigned cm = 0u;
+#pragma unroll 1
+      for (int eb = 0; eb < 5; ++eb) {
+        const char *tb = L16.b0 + gA + (a1c + 4 * eb) * kBlock16;   // (below 60 KB)
+        f32x16 y;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[i] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          Op16 w;
+          w.h = *reinterpret_cast<const u32x4 *>(tb + kb * kBlock16);
+          w.l = *reinterpret_cast<const u32x4 *>(tb + kb * kBlock16 + 1024);
+          y = mma3(w, x1s[kb], y);
+        }
+        const unsigned mwe = eb == 0 ? mw[0] : eb == 1 ? mw[1] : eb == 2 ? mw[2]
+                             : eb == 3 ? mw[3] : mw[4];
+        const unsigned mws = hi ? mwe >> 4 : mwe;  // bit r(i) + 4 hi -> bit r(i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g, positions ii + 4 hi
+          float sg = 0.f;
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * g + ii;
+            const float yv = ((mws >> rrow(i)) & 1u) ? __builtin_amdgcn_ldexpf(y[i], ex1) : 0.f;
+            cm = umax_abs(cm, yv);
+            sg += yv;
+          }
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            dpos[q] = fmaf(lds_f[L.o_0 + gAq + (eb * 4 + g) * 3 + q], sg, dpos[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) lam[q] -= dpos[q] + other_half(dpos[q]);
+      cm = wave_umax(cm);
+      if (lane == 0) meta.dmax[4][wave] = cm;
+    }
+    ar_barrier();
+    flush_add<4 * 1024>(lds, rg, part, sFc1 * 4096, e1, bad);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {   // states_in: both limbs, block nb
+      const int r_ = threadIdx.x, at = (r_ >> 5) * 64 + 32 * ((r_ >> 4) & 1) + (r_ & 15);
+      int *q = reinterpret_cast<int *>(lds + rg + 4 * 4096) + nb * 512 + r_;
+      const double v = (double)q[0] + (double)q[1024] * (1.0 / (double)(1 << kFix));
+      q[0] = 0, q[1024] = 0;
+      gadd(part, (unsigned)at * 4u, (sSin + nb) * 4096,
+           bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)v, es + ff - kFix));
+    }
+    flush_add<64>(lds, rBias + 768, part, uBias * 4096 + 768, e1, bad);
+    { const int r_ = rg; rg = ro, ro = r_; }
+
+    // ------- phases 4, 5: fc1 against the conv outputs (five blocks of 32 x1
+    // planes), the conv weights
+    const int ec = wg_exp(meta.dmax[4], bad);   // 2^ec above the largest |d conv|
+    Op16 binr[3][2];   // the 90 window planes of this step, relative, in three blocks
+    {
+      const Planes Pp = k > 0 ? Pst : Ps0;
+      const unsigned pbase = k > 0 ? (unsigned)((k - 1) * 12) * pB : 0u;
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb) {
+        const int j = 32 * jb + row;
+        TBlock tf, tp;
+        tf.load(Pin, j < kH * kRD ? vtB : kDead, (unsigned)(k * kRD + 32 * jb) * pB + wcolB);
+        tp.load(Pp, (j < kH * kRD && j % kRD < 3) ? (unsigned)(j % kRD) * pitchB + (unsigned)hi * 16u
+                                                 : kDead, pbase + wcolB);
+        float v[16], pv[16];
+        tf.get(v);
+        tp.get(pv);
+        const float lim = __builtin_amdgcn_ldexpf(1.f, fi);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)   // (clamped: see get_clamped)
+          v[i] = __builtin_amdgcn_fmed3f(v[i] - pv[i], -lim, lim);
+        split16(v, fi - kPreXc, binr[jb]);
+      }
+    }
+#pragma unroll 1
+    for (int eb = 0; eb < 5; ++eb) {
+      if (eb == 3) {
+        ar_barrier();
+        flush_add<6 * 1024>(lds, rg, part, (sFc1 + 4) * 4096, e1 + fc, bad);
+        const int r_ = rg; rg = ro, ro = r_;
+      }
+      // x block 2 + eb = the saved conv outputs e = 32 eb + row (channel
+      // 4 eb + row / 8, position row % 8)
+      float xv[16];
+      get_clamped(tx, xv, fc);
+      if (eb < 4) tx.load(Px1, vtN, (unsigned)(kW + 32 * (eb + 1)) * pN + wcolN);
+      // (lane indices opaque per block: the scatter addresses below are made
+      // here, not kept in registers through the whole sweep)
+      int row_e = row, hi_e = hi;
+      asm volatile("" : "+v"(row_e), "+v"(hi_e));
+      {
+        Op16 bx[2];
+        split16(xv, fc - kPreX, bx);
+        fc1_blocks(bx, lane_blk + rg + 2 * (eb < 3 ? eb : eb - 3) * 4096);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the cotangent of this block's conv outputs, trajectory-major, relu' from
+      // the saved outputs, then its products against the window planes
+      const char *tb = L16.b0 + gA + (a1c + 4 * eb) * kBlock16;   // (below 60 KB)
+      f32x16 tt;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tt[i] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        Op16 w;
+        w.h = *reinterpret_cast<const u32x4 *>(tb + kb * kBlock16);
+        w.l = *reinterpret_cast<const u32x4 *>(tb + kb * kBlock16 + 1024);
+        tt = mma3(x1s[kb], w, tt);
+      }
+      int E1[16];
+      texp(ex1, hi, E1);
+      float v[16], sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[i] = xv[i] > 0.f ? __builtin_amdgcn_ldexpf(tt[i], E1[i] - ec) : 0.f;   // / 2^ec
+        sum += v[i];
+      }
+      // the conv block's rows of channels 4 eb .. 4 eb + 3 (accumulator layout:
+      // channel ch = register (ch & 3) + 4 (ch >> 3) of half-wave (ch >> 2) & 1)
+      char *cblk = lds + rConv + ((4 * (eb >> 1)) * 64 + 32 * (eb & 1)) * 4;
+      sum += other_half(sum);
+      // bias: column 27; the block's unit carries the windows' scale 2^fi as well
+      if (hi_e == 0)
+        lds_add(cblk + ((row_e >> 3) * 64 + 27) * 4, __builtin_amdgcn_ldexpf(sum, kFixConv - fi));
+      Op16 ac[2];
+      split16(v, -kPreDc, ac);
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb) {
+        if (APG_AR_KNOCKOUT & 8) break;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(ac[kk], binr[jb][kk], acc);
+        // register 4 g + c of lane (hi, col): conv output row c + 8 g + 4 hi of the
+        // block = channel 4 eb + g at position c + 4 hi, against window plane
+        // j = 32 jb + col: tap q = j - 9 position of that channel's 27
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int q = 32 * jb + row_e - kRD * (cc + 4 * hi_e);
+          if (q >= 0 && q < 27) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lds_add(cblk + (g * 64 + q) * 4, acc[4 * g + cc]);
+          }
+        }
+      }
+    }
+    e5 = e1 + fc, ecv = ec + fi;
+  }
+  ar_barrier();
+  flush_tail();
+  if (st_lo && A.grad_state0)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) A.grad_state0[(size_t)i * B + b] = lam[i];
+  write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
 }
 
 int check_mlp(const ApgQuadParams *params, const ApgMlpPolicy *pol, int B, int H) {
@@ -2631,20 +3514,21 @@ int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
   }
   static PerDeviceOnce attr;
   if (!attr.test()) {
-    if (int e = raise_lds(mlp_rollout_fwd_kernel, kCfLds)) return e;
+    if (int e = raise_lds(mlp_rollout_fwd_kernel<false>, kCfLds)) return e;
     attr.set();
   }
   FwdArgs A;
   A.state0 = state0, A.in_ref = in_ref, A.states = states, A.actions = actions;
   A.feat = feat, A.x1 = x1, A.h = h, A.mask = relu_mask;
   A.tables = workspace;
+  A.xmax = nullptr;
   A.c = make_const(*params, dt);
   A.B = B;
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = 4;
   hipLaunchKernelGGL(mlp_pack_cfwd_kernel, dim3((kCfLds + 255) / 256), dim3(256),
                      0, (hipStream_t)stream, P);
-  hipLaunchKernelGGL(mlp_rollout_fwd_kernel,
+  hipLaunchKernelGGL(mlp_rollout_fwd_kernel<false>,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock),
                      dim3(kThreads), kCfLds * sizeof(float), (hipStream_t)stream,
                      A);
@@ -2974,6 +3858,7 @@ int apg_quad_mlp_concurrent_train_step(
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
   R.n_slots = tm ? kSlotsTm : kSlots, R.bias_slot = tm ? uBias : sBias;
   R.conv_src = tm ? 1 : kNP;
+  R.head_rows = kNA;
   const int columns = (R.n_slots * 1024 + 255) / 256;
   R.update = update != nullptr;
   R.param = update ? update->param : *grads, R.mom = update ? update->momentum_buf : *grads;
@@ -2987,6 +3872,117 @@ int apg_quad_mlp_concurrent_train_step(
   }
   hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(columns), dim3(256), 0, st, R);
   return check_launch("quad_mlp_concurrent_step");
+}
+
+int apg_quad_mlp_rollout_step_workspace_floats(void) { return kCfLds + kArTabFloats + 4; }
+
+long long apg_quad_mlp_rollout_step_partials_floats(int B) {
+  if (B <= 0) return 0;
+  const long long wgs = (B + kTrajPerBlock - 1) / kTrajPerBlock;
+  // the workgroups' accumulators + the chunk sums of the first reduction level
+  // + the forward sweep's per-wave, per-step x maxima
+  return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlotsTm * 1024 +
+         wgs * (kThreads / kWave) * kH * 4;
+}
+
+int apg_quad_mlp_rollout_train_step(
+    const float *state0, const float *in_ref, const float *ref, int ref_cols, float dt,
+    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+    const ApgMlpPolicy *policy, int B, int H, float *states, float *actions, float *acts,
+    unsigned *relu_mask, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
+    float *grad_state0, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
+    apg_stream_t stream) {
+  if (int e = check_mlp(params, policy, B, H)) return e;
+  if (update && (!all_set(update->param) || !all_set(update->momentum_buf))) {
+    set_error("update: parameter / momentum pointer is NULL");
+    return APG_ERR_ARG;
+  }
+  if (update && !(update->lr == update->lr && update->momentum == update->momentum)) {
+    set_error("update: lr / momentum is NaN");
+    return APG_ERR_ARG;
+  }
+  if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
+  if (ref_cols != 9 && ref_cols != 6) {
+    set_error("ref_cols must be 9 or 6");
+    return APG_ERR_ARG;
+  }
+  if (!grads || !all_set(*grads)) {
+    set_error("gradient pointer is NULL");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (update) {
+      set_error("update with B = 0 is not supported");
+      return APG_ERR_ARG;
+    }
+    const ApgMlpPolicyGrads &g = *grads;
+    float *ptrs[12] = {g.w_s, g.b_s, g.conv_w, g.conv_b, g.w_1, g.b_1,
+                       g.w_2, g.b_2, g.w_3, g.b_3, g.w_out, g.b_out};
+    const size_t n[12] = {kW * kNF, kW, kNC * 27, kNC, kW * kN1, kW,
+                          kW * kW, kW, kW * kW, kW, 4 * kW, 4};
+    for (int i = 0; i < 12; ++i)
+      if (hipMemsetAsync(ptrs[i], 0, n[i] * sizeof(float), st) != hipSuccess)
+        return check_launch("memset(grads)");
+    if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
+      return check_launch("memset(loss)");
+    return APG_OK;
+  }
+  if (!state0 || !in_ref || !ref || !states || !actions || !acts || !relu_mask ||
+      !loss_partials || !workspace || !partials) {
+    set_error("NULL buffer");
+    return APG_ERR_ARG;
+  }
+  static PerDeviceOnce attr;
+  if (!attr.test()) {
+    if (int e = raise_lds(mlp_rollout_fwd_kernel<true>, kCfLds)) return e;
+    if (int e = raise_lds(mlp_rollout_bwd_tm_kernel, kLdsAll / 4)) return e;
+    attr.set();
+  }
+  const size_t N = (size_t)B * kH;
+  const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
+  float *xmax = partials + (size_t)(apg_quad_mlp_rollout_step_partials_floats(B) -
+                                    (long long)blocks * (kThreads / kWave) * kH * 4);
+  PackArgs P;
+  P.pol = *policy, P.dst = workspace, P.head_rows = 4;
+  const int fwd_blocks = (kCfLds + 255) / 256, bwd_blocks = (kArTabFloats + 255) / 256;
+  hipLaunchKernelGGL(mlp_pack_ar_kernel, dim3(fwd_blocks + bwd_blocks + 1), dim3(256), 0, st,
+                     P, fwd_blocks);
+  FwdArgs F;
+  F.state0 = state0, F.in_ref = in_ref, F.states = states, F.actions = actions;
+  F.feat = acts, F.x1 = acts + kNF * N, F.h = acts + (kNF + kN1) * N, F.mask = relu_mask;
+  F.tables = workspace;
+  F.xmax = xmax;
+  F.c = make_const(*params, dt);
+  F.B = B;
+  hipLaunchKernelGGL(mlp_rollout_fwd_kernel<true>, dim3(blocks), dim3(kThreads),
+                     kCfLds * sizeof(float), st, F);
+  ArTmArgs A;
+  A.state0 = state0, A.states = states, A.actions = actions, A.ref = ref, A.in_ref = in_ref;
+  A.feat = F.feat, A.x1 = F.x1, A.h = F.h, A.mask = relu_mask;
+  A.loss_partials = loss_partials, A.part = partials, A.grad_state0 = grad_state0;
+  A.tables = workspace + kCfLds, A.xmax = xmax;
+  A.c = F.c;
+  A.w = *weights;
+  A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
+  hipLaunchKernelGGL(mlp_rollout_bwd_tm_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st, A);
+  WgReduceArgs R;
+  R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
+  R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
+  R.n_slots = kSlotsTm, R.bias_slot = uBias, R.conv_src = 1, R.head_rows = 4;
+  const int columns = (R.n_slots * 1024 + 255) / 256;
+  R.update = update != nullptr;
+  R.param = update ? update->param : *grads, R.mom = update ? update->momentum_buf : *grads;
+  R.lr = update ? update->lr : 0.0, R.momentum = update ? update->momentum : 0.0;
+  if (blocks > kRedChunk) {
+    const int chunks = (blocks + kRedChunk - 1) / kRedChunk;
+    float *chunk_sums = partials + (size_t)blocks * R.n_slots * 1024;
+    hipLaunchKernelGGL(mlp_wgrad_reduce1_kernel, dim3(columns, chunks), dim3(256), 0, st,
+                       partials, chunk_sums, blocks, R.n_slots);
+    R.part = chunk_sums, R.wgs = chunks;
+  }
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(columns), dim3(256), 0, st, R);
+  return check_launch("quad_mlp_rollout_train_step");
 }
 
 }  // extern "C"

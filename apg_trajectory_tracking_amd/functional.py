@@ -1293,6 +1293,53 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
         feat, x1, h = acts[:15], acts[15:239], acts[239:431]
         relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
         st = stream_of(s0)
+        if AR_IN_SWEEP:
+            # round 5: every weight gradient is accumulated inside the reverse
+            # sweep (apg_quad_mlp_rollout_train_step) - no cotangent planes, no
+            # second pass of products; every gradient is a view of `flat`
+            flat, gr = _flat_grads(dev, {
+                "states_in.weight": (64, 15), "states_in.bias": (64,),
+                "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,),
+                "fc1.weight": (64, 224), "fc1.bias": (64,), "fc2.weight": (64, 64),
+                "fc2.bias": (64,), "fc3.weight": (64, 64), "fc3.bias": (64,),
+                "fc_out.weight": (4, 64), "fc_out.bias": (4,)})
+            gs = _capi.ApgMlpPolicyGrads(**{
+                k: ptr(gr[n]) for k, n in zip(names, _MLP_PARAMS)})
+            ws = new(lib().apg_quad_mlp_rollout_step_workspace_floats())
+            part = new(max(1, lib().apg_quad_mlp_rollout_step_partials_floats(B)))
+            partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
+            loss = new(1)
+            g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
+            upd = None
+            update = getattr(ctx, "update", None)
+            if update is not None:
+                lr, momentum, bufs = update
+                if B == 0 or any(pw[k].data_ptr() != v.data_ptr() for k, v in zip(names, (
+                        w_s, b_s, conv_w, conv_b, w_1, b_1, w_2, b_2, w_3, b_3,
+                        w_out, b_out))):
+                    raise ValueError("in-kernel update needs a non-empty batch and "
+                                     "contiguous float32 parameters")
+                require_device(*bufs.values())
+                upd = ctypes.byref(_capi.ApgMlpSgdUpdate(
+                    lr=float(lr), momentum=float(momentum),
+                    param=_capi.ApgMlpPolicyGrads(**{k: ptr(v) for k, v in pw.items()}),
+                    momentum_buf=_capi.ApgMlpPolicyGrads(**{
+                        k: ptr(bufs[n]) for k, n in zip(names, _MLP_PARAMS)})))
+            check(lib().apg_quad_mlp_rollout_train_step(
+                ptr(s0), ptr(inr), ptr(rf), rf.shape[1], float(dt),
+                ctypes.byref(params), ctypes.byref(weights), ctypes.byref(pol), B, H,
+                ptr(states), ptr(actions), ptr(acts), relu_mask.data_ptr(),
+                ptr(partials), ptr(loss), ctypes.byref(gs), ptr(g_s0), ptr(ws),
+                ptr(part), upd, st), "apg_quad_mlp_rollout_train_step")
+            ctx.flat_grads = (flat, gr)
+            ctx.save_for_backward(acts)
+            ctx.input_grads = (g_s0,)
+            ctx.mark_non_differentiable(states, actions)
+            ctx.dims = (B, H)
+            return loss.reshape(()), states, actions
+        ctx.flat_grads = None
+        if getattr(ctx, "update", None) is not None:
+            raise ValueError("update needs the in-sweep path")
         ws = new(lib().apg_quad_mlp_workspace_floats())
         check(lib().apg_quad_mlp_rollout_fwd(
             ptr(s0), ptr(inr), float(dt), ctypes.byref(params),
@@ -1317,8 +1364,11 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gs, _ga):
-        flat, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
-        flat *= g
+        if ctx.flat_grads is not None:
+            gr = {k: v * g for k, v in ctx.flat_grads[1].items()}
+        else:
+            flat, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
+            flat *= g
         g_s0 = None if ctx.input_grads[0] is None else ctx.input_grads[0].t() * g
         return (g_s0, None, None, *[gr[k] for k in _MLP_PARAMS], None, None, None)
 
@@ -1742,6 +1792,11 @@ class QuadConcurrentStepPlan:
         return self.loss0
 
 
+# True: the autoregressive step accumulates its weight gradients inside the
+# reverse sweep (csrc/mlp.hip, mlp_rollout_bwd_tm_kernel, round 5); False:
+# cotangent planes + planes_gemm products (rounds 1-4)
+AR_IN_SWEEP = True
+
 # True: the concurrent step accumulates its weight gradients inside the reverse
 # kernel (csrc/mlp.hip, mlp_concurrent_bwd_wg_kernel); False: cotangent planes +
 # planes_gemm products (rounds 1-3; kept for comparison and as the planes API's
@@ -1865,16 +1920,19 @@ _MAX_FUSED_AR_BATCH = 393216
 
 
 def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
-                           index=None, static_inputs=False, prepared=None):
+                           index=None, static_inputs=False, prepared=None,
+                           update=None):
     """quad_mlp_rollout_loss (autoregressive unroll) + parameter gradients,
-    without autograd; see quad_concurrent_policy_grads.  Batches beyond
-    393 216 trajectories are processed in chunks (losses and gradients are sums
-    over trajectories, so the chunks simply add up)."""
+    without autograd; see quad_concurrent_policy_grads (`update` as there:
+    momentum SGD inside the second stage, one process, one launch chunk).
+    Batches beyond 393 216 trajectories are processed in chunks (losses and
+    gradients are sums over trajectories, so the chunks simply add up)."""
     B = (prepared[2].shape[-1] if prepared is not None
          else state0.shape[0] if index is None else index.numel())
     if B > _MAX_FUSED_AR_BATCH:
-        if prepared is not None:
-            raise ValueError("prepared batches must fit one fused launch")
+        if prepared is not None or update is not None:
+            raise ValueError("prepared batches / in-kernel updates must fit one "
+                             "fused launch")
         n = -(-B // _MAX_FUSED_AR_BATCH)
         step = -(-B // n)
         if index is None:
@@ -1890,6 +1948,8 @@ def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
                 loss = loss + l
         return loss, gr, flat
     ctx = _DirectCtx()
+    if update is not None:
+        ctx.update = update
     if prepared is not None:     # quad_recurrent_prepare's result
         ctx.prepared = prepared
     elif static_inputs and index is None:
@@ -1898,7 +1958,7 @@ def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
         loss, _, _ = _QuadMlpRolloutLoss.forward(
             ctx, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt, params,
             weights or quad_loss_weights(), index)
-        flat, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
+        flat, gr = ctx.flat_grads or _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
     return loss, gr, flat
 
 

@@ -452,6 +452,35 @@ int apg_quad_mlp_concurrent_train_step(
     float *states, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
     const ApgStepEvents *events, apg_stream_t stream);
 
+/* The AUTOREGRESSIVE training step in one call (round 5; configs[2] per rank):
+ * TrainDrone.train_recurrent_model's unroll, loss and loss.backward()
+ * (scripts/train_drone.py:113-173) for Net(15, 10, 9, 4, conv=1) - the forward
+ * sweep (as apg_quad_mlp_rollout_fwd), then a reverse sweep that accumulates
+ * EVERY parameter gradient inside (trajectory-major block products per step
+ * and layer into 32-bit fixed-point LDS accumulators, flushed per phase into a
+ * workgroup-owned float accumulator in `partials`; csrc/mlp.hip,
+ * mlp_rollout_bwd_tm_kernel), then the fixed-order second stage of
+ * apg_quad_mlp_concurrent_step.  No cotangent planes, no apg_planes_gemm.
+ * Bit-reproducible run to run.
+ *   state0 [12][B], in_ref [2H][9][B], ref [H][ref_cols][B] (planes);
+ *   out: states [H][12][B], actions [H][4][B], acts [431][H*B] (feat | x1 |
+ *     h1 h2 h3: scratch the reverse sweep reads), relu_mask [5][H*B] (scratch),
+ *     loss_partials (apg_quad_mlp_loss_partials_count(B)), loss [1],
+ *     grads (every pointer set; fc_out is [4][64]), grad_state0 [12][B] or NULL;
+ *   workspace: apg_quad_mlp_rollout_step_workspace_floats() floats,
+ *   partials:  apg_quad_mlp_rollout_step_partials_floats(B) floats;
+ *   update: as apg_quad_mlp_concurrent_train_step (NULL: gradients only).
+ * Operand range: as the other in-kernel policies (finite, |x| < 2^14). */
+int apg_quad_mlp_rollout_step_workspace_floats(void);
+long long apg_quad_mlp_rollout_step_partials_floats(int B);
+int apg_quad_mlp_rollout_train_step(
+    const float *state0, const float *in_ref, const float *ref, int ref_cols, float dt,
+    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+    const ApgMlpPolicy *policy, int B, int H, float *states, float *actions, float *acts,
+    unsigned *relu_mask, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
+    float *grad_state0, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
+    apg_stream_t stream);
+
 /* Batched closed-loop evaluation: the loop of
  * QuadEvaluator.follow_trajectory("rand") (scripts/evaluate_drone.py:81-194)
  * for B reference trajectories in one launch - per step the H-row reference

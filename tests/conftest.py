@@ -84,6 +84,58 @@ def assert_no_worse_than_fp32(dev, f32, f64, what, factor=3.0, worst_factor=4.0,
     return stats
 
 
+def per_row_err(got, want):
+    """e_r = max|got_r - want_r| / max|want_r| for every OUTPUT ROW r of a
+    parameter (leading axis; a bias is one row per element); float64."""
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    if want.ndim == 1:
+        want, got = want[:, None], got[:, None]
+    R = want.shape[0]
+    g, w = got.reshape(R, -1), want.reshape(R, -1)
+    return np.abs(g - w).max(1), np.abs(w).max(1)
+
+
+def assert_param_rows_no_worse_than_fp32(dev, f32, f64, what, factor=4.0, eps=3e-5,
+                                         tensor_eps=2e-7, bar=1e-4):
+    """VERDICT r4 next #2a: the float64 oracle arbitrates PARAMETER gradients
+    per output row.  `dev`, `f32`, `f64`: {parameter name: gradient} of the
+    kernels, of float32 autograd (the reference's arithmetic) and of float64
+    autograd.  For every row r of every parameter
+        err_dev(r) <= factor * err_f32(r) + eps * |row| + tensor_eps * |tensor|
+    with err = max abs deviation over the row, |row| / |tensor| the largest
+    float64 magnitude of the row / of the whole parameter.  The last term is
+    what a SUM over the batch can promise a row whose own gradient is tiny:
+    float32 autograd itself rounds every partial sum at 2^-24 of the running
+    total.  `eps`: the kernels evaluate the policy with fp16-split products and
+    a fast tanh - per TRAJECTORY 3-4 x float32's noise on states and cotangents
+    (assert_no_worse_than_fp32, factor 4) - and a row whose trajectories' terms
+    cancel keeps that relative noise (it does not average against the row's own
+    scale), where float32 autograd, summing exactly rounded terms, reaches 2e-7;
+    measured 1.3e-5 on the worst row at 65 536.  On top, every
+    row meets north_star's `bar` against its OWN scale.  A per-tensor max norm
+    alone (conftest.rel_err) cannot see a row quantised at a unit set by another
+    row's (or another trajectory's) magnitude; this can.
+    Returns {name: worst ratio err_dev / bound}."""
+    out = {}
+    for k, w in f64.items():
+        ed, scale = per_row_err(dev[k], w)
+        ef, _ = per_row_err(f32[k], w)
+        tmax = np.abs(np.asarray(w)).max()
+        assert (ed <= bar * scale + tensor_eps * tmax).all(), (
+            what, k, "row", int((ed / np.maximum(scale, 1e-300)).argmax()),
+            float((ed / np.maximum(scale, 1e-300)).max()))
+        bound = factor * ef + eps * scale + tensor_eps * tmax
+        ratio = ed / np.maximum(bound, 1e-300)
+        out[k] = float(ratio.max())
+        r = int(ratio.argmax())
+        assert ratio.max() <= 1.0, (
+            what, k, "row", r, dict(err_dev=ed[r], err_f32=ef[r], row_scale=scale[r],
+                                    tensor_scale=float(np.abs(np.asarray(w)).max())))
+    print("fp64 row arbiter:", what, {k: float("%.3g" % v) for k, v in out.items()})
+    return out
+
+
 # ---- fixed-wing closed loop (G15): shared by the CPU and the GPU tests ------
 def wing_loop_policy(device="cpu"):
     """The controller the reference ships (trained_models/wing), rebuilt from
