@@ -452,6 +452,42 @@ int apg_quad_mlp_concurrent_train_step(
     float *states, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
     const ApgStepEvents *events, apg_stream_t stream);
 
+/* The LSTM-mode training step in one call (round 5; configs[4]): forward sweep
+ * (as apg_quad_lstm_rollout_fwd), then a reverse sweep that accumulates EVERY
+ * parameter gradient inside (csrc/lstm.hip, lstm_rollout_bwd_tm_kernel:
+ * trajectory-major block products per step into fixed-point LDS accumulators,
+ * one barrier per step, flushed into a workgroup-owned float accumulator in
+ * `partials`), then a fixed-order second stage.  No cotangent planes, no
+ * apg_planes_gemm.  Bit-reproducible run to run.
+ *   state0 [12][B], in_ref [2H][9][B], ref [H][ref_cols][B], h0 / c0 [8][B];
+ *   out: states [H][12][B], actions [H][4][B]; scratch the reverse sweep reads:
+ *     acts [199][H*B] (x 175 | h_prev, c_prev 16 | h_new 8), gates [32][H*B],
+ *     relu_mask [5][H*B]; loss [1];
+ *     grads (every pointer set; bias_ih and bias_hh receive the same values),
+ *     grad_state0 [12][B], grad_h0 / grad_c0 [8][B] or NULL;
+ *   workspace: apg_quad_lstm_step_workspace_floats() floats,
+ *   partials:  apg_quad_lstm_step_partials_floats(B) floats;
+ *   update: momentum SGD inside the second stage as
+ *     apg_quad_mlp_concurrent_train_step's (NULL: gradients only). */
+typedef struct ApgLstmPolicyGrads {
+  float *conv_w, *conv_b, *w_ih, *w_hh, *b_ih, *b_hh, *w_out, *b_out;
+} ApgLstmPolicyGrads;
+typedef struct ApgLstmSgdUpdate {
+  double lr, momentum;
+  ApgLstmPolicyGrads param;
+  ApgLstmPolicyGrads momentum_buf;
+} ApgLstmSgdUpdate;
+int apg_quad_lstm_step_workspace_floats(void);
+long long apg_quad_lstm_step_partials_floats(int B);
+int apg_quad_lstm_rollout_train_step(
+    const float *state0, const float *in_ref, const float *ref, int ref_cols,
+    const float *h0, const float *c0, float dt, const ApgQuadParams *params,
+    const ApgQuadLossWeights *weights, const ApgLstmPolicy *policy, int B, int H,
+    float *states, float *actions, float *acts, float *gates, unsigned *relu_mask,
+    float *loss, const ApgLstmPolicyGrads *grads, float *grad_state0, float *grad_h0,
+    float *grad_c0, float *workspace, float *partials, const ApgLstmSgdUpdate *update,
+    apg_stream_t stream);
+
 /* The AUTOREGRESSIVE training step in one call (round 5; configs[2] per rank):
  * TrainDrone.train_recurrent_model's unroll, loss and loss.backward()
  * (scripts/train_drone.py:113-173) for Net(15, 10, 9, 4, conv=1) - the forward
