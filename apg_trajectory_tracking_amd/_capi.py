@@ -100,13 +100,7 @@ class ApgMlpSgdUpdate(ctypes.Structure):
 
 class ApgLstmPolicyGrads(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")]
-
-
-class ApgLstmSgdUpdate(ctypes.Structure):
-    """apg_quad_lstm_rollout_train_step's optimizer part (see ApgMlpSgdUpdate)."""
-    _fields_ = [("lr", ctypes.c_double), ("momentum", ctypes.c_double),
-                ("param", ApgLstmPolicyGrads), ("momentum_buf", ApgLstmPolicyGrads)]
+        "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")]
 
 
 class ApgWingPolicy(ctypes.Structure):
@@ -201,8 +195,8 @@ SIGNATURES = {
     "apg_quad_lstm_rollout_train_step": [
         _P, _P, _P, _I, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgLstmPolicy), _I, _I,
-        _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicyGrads), _P, _P, _P, _P, _P,
-        ctypes.POINTER(ApgLstmSgdUpdate), _P],
+        _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicyGrads), _P, _P, _P, _P, _P,
+        _P],
     "apg_quad_mlp_rollout_step_workspace_floats": [],
     "apg_quad_mlp_rollout_step_partials_floats": [_I],
     "apg_quad_mlp_rollout_train_step": [

@@ -832,18 +832,25 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
 // whose region is flushed into the workgroup's global accumulator (float x the
 // step's scales, buffer_atomic_add_f32) while this step adds into the other.
 // One workgroup = 8 waves = 256 trajectories (the forward sweep keeps 4).
+// The conv weights are the exception: their cotangent still leaves as the 17
+// window-diagonal sums per channel (kConvP above, 720 planes of B floats) for
+// the two small segmented products of apg_planes_gemm.  The in-sweep form of
+// that block was built and measured (tools/patches/lstm_conv_in_sweep.patch):
+// 15 block products per step against the window planes + a scattered
+// accumulation cost 15 us per step where the diagonals cost 2 - the diagonal
+// sums ARE the reduction that makes this gradient cheap, and they are per
+// trajectory (they live in the lane).
 // Blocks of a region (4 KB each, accumulator order [register][lane]):
 //   0      W_ih on the features (columns 0..14) + b_ih = b_hh (column 15: ones)
 //   1..5   W_ih on the conv outputs, 32 columns each
 //   6      W_hh (columns 0..7)
 //   7      fc_out (rows 0..3: columns 0..7, column 8 = b_out)
-//   8      conv_ref (rows = 20 channels, columns = 27 taps + bias)
-constexpr int uFeat = 0, uCv = 1, uHh = 6, uHead = 7, uConv = 8, kTmSlots = 9;
+constexpr int uFeat = 0, uCv = 1, uHh = 6, uHead = 7, kTmSlots = 8;
 constexpr int kLdsAll = 160 * 1024;
 constexpr int kTmRegion = kTmSlots * 4096;
 constexpr int rTab = kBwd16Lds * 4, rR0 = rTab, rR1 = rR0 + kTmRegion, rMeta = rR1 + kTmRegion;
 struct LstmMeta {
-  unsigned dmax[3][8];   // max |dL/dz|, |dG|, |d conv| bits per wave
+  unsigned dmax[2][8];   // max |dL/dz|, |dG| bits per wave
 };
 constexpr int kTmLds = rMeta + (int)sizeof(LstmMeta);
 static_assert(kTmLds <= kLdsAll && rTab % 16 == 0, "LDS map");
@@ -854,6 +861,7 @@ struct TmArgs {
   const unsigned *mask;
   const float *gates, *hc, *hnew, *x;   // the forward sweep's planes
   float *loss_partials;
+  float *d_conv;                        // [720][B]: conv cotangents along the diagonals
   float *part;                          // [workgroups][kTmSlots][1024]
   float *grad_state0, *grad_h0, *grad_c0;
   const float *tables;
@@ -876,13 +884,12 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
   const QuadConst c = A.c;
   const Planes Ps0(A.state0, 12, pitchB), Pst(A.states, kH * 12, pitchB);
   const Planes Pac(A.actions, kH * 4, pitchB), Prf(A.ref, kH * A.ref_cols, pitchB);
-  const Planes Pin(A.in_ref, 2 * kH * kRD, pitchB);
   const Planes Pg(A.gates, kNG, pitchN), Phc(A.hc, 2 * kNH, pitchN), Phn(A.hnew, kNH, pitchN);
   const Planes Px(A.x, kNX, pitchN), Pmk(A.mask, 5, pitchN);
+  const Planes Pdc(A.d_conv, kConvPlanes, pitchB);
   const unsigned vb = live ? (unsigned)b * 4u : kDead;
   const unsigned wcolB = (unsigned)(b0 + wave * 32) * 4u;
   const unsigned vtN = (unsigned)row * pitchN + (unsigned)hi * 16u;
-  const unsigned vtB = (unsigned)row * pitchB + (unsigned)hi * 16u;
   const __amdgpu_buffer_rsrc_t part = __builtin_amdgcn_make_buffer_rsrc(
       A.part + (size_t)blockIdx.x * kTmSlots * 1024, 0, kTmSlots * 4096, 0x00020000);
   char *lane_blk = lds + lane * 4;
@@ -911,7 +918,16 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
   float loss = 0.f;
   int rg = rR0, ro = rR1;   // this step's accumulator region / the other one
   // scales of the region that is flushed behind the next barrier
-  int p_feat = 0, p_cv = 0, p_g = 0, p_z = 0, p_conv = 0;
+  int p_feat = 0, p_cv = 0, p_g = 0, p_z = 0;
+  // sliding diagonal sums of the conv cotangents: dgn[ch][ii] = diagonal
+  // tau = k + ii of this half-wave's positions (see kConvP)
+  float dgn[kNC][4];
+#pragma unroll
+  for (int ch = 0; ch < kNC; ++ch)
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) dgn[ch][ii] = 0.f;
+  const unsigned vg = live ? (unsigned)b * 4u + (hi ? kTau * pitchB : 0u) : kDead;
+  const unsigned vb_lo = st_lo ? (unsigned)b * 4u : kDead;
 
 #pragma unroll 1
   for (int k = kH - 1; k >= 0; --k) {
@@ -925,7 +941,7 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
     float dz[4];
     Op16 xg[2];
     int ex;
-    unsigned m_z = 0u, m_g = 0u, m_c = 0u;
+    unsigned m_z = 0u, m_g = 0u;
     TBlock tx;
     tx.load(Px, row < kNF ? vtN : kDead, wcolN);   // the features, trajectory-major
     {
@@ -1034,8 +1050,8 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
       quad_features_adjoint(sc, t, dfeat, gs);
 #pragma unroll
       for (int i = 0; i < 12; ++i) lam[i] += gs[i];
-      // conv cotangent feature-major: the position cotangent and its largest
-      // entry (the conv block's exact scale)
+      // conv cotangent (feature-major): the position cotangent; for the conv
+      // weights it leaves summed along the window diagonals (kConvP)
       float dpos[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int eb = 0; eb < 5; ++eb) {
@@ -1046,15 +1062,21 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
         for (int kb = 0; kb < 2; ++kb) y0 = mma3(L16.A(gA, mC + eb * 2 + kb), xg[kb], y0);
         const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];  // bit r(i) + 4 hi -> bit r(i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g,
+          const int ch = eb * 4 + g;     // positions ii + 4 hi
           float sum = 0.f;
 #pragma unroll
           for (int ii = 0; ii < 4; ++ii) {
             const int i = 4 * g + ii;
             const float dcp = ((mws >> rrow(i)) & 1u) ? __builtin_amdgcn_ldexpf(y0[i], ex) : 0.f;
-            m_c = umax_abs(m_c, dcp);
+            dgn[ch][ii] += dcp;
             sum += dcp;
           }
+          // diagonal tau = k + 3 is complete; the others move up one position
+          Pdc.st(vg, (unsigned)(ch * 2 * kTau + k + 3) * pB, dgn[ch][3]);
+          dgn[ch][3] = dgn[ch][2], dgn[ch][2] = dgn[ch][1], dgn[ch][1] = dgn[ch][0];
+          dgn[ch][0] = 0.f;
+          Pdc.st(vb_lo, (unsigned)(kConvP + ch * kH + k) * pB, sum + other_half(sum));
 #pragma unroll
           for (int q = 0; q < 3; ++q)
             dpos[q] = fmaf(L.U(gAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
@@ -1063,9 +1085,9 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
 #pragma unroll
       for (int q = 0; q < 3; ++q) lam[q] -= dpos[q] + other_half(dpos[q]);
     }
-    m_z = wave_umax(m_z), m_g = wave_umax(m_g), m_c = wave_umax(m_c);
-    if (lane == 0) meta.dmax[0][wave] = m_z, meta.dmax[1][wave] = m_g, meta.dmax[2][wave] = m_c;
-    unsigned mc = 0u, mf = 0x3f800000u /* the ones row */, mi = 0u;
+    m_z = wave_umax(m_z), m_g = wave_umax(m_g);
+    if (lane == 0) meta.dmax[0][wave] = m_z, meta.dmax[1][wave] = m_g;
+    unsigned mc = 0u, mf = 0x3f800000u /* the ones row */;
     {
       const unsigned *q = reinterpret_cast<const unsigned *>(A.xmax) +
                           ((size_t)blockIdx.x * (kTmThreads / 64) * kH + k) * 4;
@@ -1073,21 +1095,17 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
       for (int w8 = 0; w8 < kTmThreads / 64; ++w8) {
         mc = q[w8 * kH * 4] > mc ? q[w8 * kH * 4] : mc;
         mf = q[w8 * kH * 4 + 1] > mf ? q[w8 * kH * 4 + 1] : mf;
-        mi = q[w8 * kH * 4 + 2] > mi ? q[w8 * kH * 4 + 2] : mi;
       }
     }
-    const int fc = bits_exp(mc, bad, true), ff = bits_exp(mf, bad, true),
-              fi = bits_exp(mi, bad, true);
+    const int fc = bits_exp(mc, bad, true), ff = bits_exp(mf, bad, true);
     if (!(APG_AR_KNOCKOUT & 16)) __syncthreads();
     // ---- the previous step's blocks -> the global accumulator (first step: zeros)
     flush_add<1024>(lds, ro + uFeat * 4096, part, uFeat * 4096, p_g + p_feat, bad);
     flush_add<5 * 1024>(lds, ro + uCv * 4096, part, uCv * 4096, p_g + p_cv, bad);
     flush_add<1024>(lds, ro + uHh * 4096, part, uHh * 4096, p_g, bad);
     flush_add<1024>(lds, ro + uHead * 4096, part, uHead * 4096, p_z, bad);
-    flush_add<1024>(lds, ro + uConv * 4096, part, uConv * 4096, p_conv, bad, kFixConv);
     // --------------------------------------------------------- trajectory-major
-    const int e0 = wg_exp(meta.dmax[0], bad), eg = wg_exp(meta.dmax[1], bad),
-              ec = wg_exp(meta.dmax[2], bad);
+    const int e0 = wg_exp(meta.dmax[0], bad), eg = wg_exp(meta.dmax[1], bad);
     char *rb = lane_blk + rg;
     Op16 ag[2];    // dG^T with the workgroup's scale: A operand of the W_ih / W_hh blocks
     {
@@ -1176,28 +1194,6 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
         for (int i = 0; i < 4; ++i) lds_add(rb + uHead * 4096 + i * 256, acc[i]);
       }
     }
-    // the 90 window planes of this step, relative to the drone's position
-    Op16 binr[3][2];
-    {
-      const Planes Pp = k > 0 ? Pst : Ps0;
-      const unsigned pbase = k > 0 ? (unsigned)((k - 1) * 12) * pB : 0u;
-#pragma unroll
-      for (int jb = 0; jb < 3; ++jb) {
-        const int j = 32 * jb + row;
-        TBlock tf, tp;
-        tf.load(Pin, j < kH * kRD ? vtB : kDead, (unsigned)(k * kRD + 32 * jb) * pB + wcolB);
-        tp.load(Pp, (j < kH * kRD && j % kRD < 3) ? (unsigned)(j % kRD) * pitchB + (unsigned)hi * 16u
-                                                 : kDead, pbase + wcolB);
-        float v[16], pv[16];
-        tf.get(v);
-        tp.get(pv);
-        const float lim = __builtin_amdgcn_ldexpf(1.f, fi);
-#pragma unroll
-        for (int i = 0; i < 16; ++i)   // (clamped: see get_clamped)
-          v[i] = __builtin_amdgcn_fmed3f(v[i] - pv[i], -lim, lim);
-        split16(v, fi - kPreXc, binr[jb]);
-      }
-    }
 #pragma unroll 1
     for (int eb = 0; eb < 5; ++eb) {
       // x block 1 + eb = the saved conv outputs e = 32 eb + row (channel
@@ -1205,64 +1201,16 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
       float xv[16];
       get_clamped(tx, xv, fc);
       if (eb < 4) tx.load(Px, vtN, (unsigned)(kNF + 32 * (eb + 1)) * pN + wcolN);
-      int row_e = row, hi_e = hi;
-      asm volatile("" : "+v"(row_e), "+v"(hi_e));
-      {
-        Op16 bx[2];
-        split16(xv, fc - kPreX, bx);
-        f32x16 acc;
+      Op16 bx[2];
+      split16(xv, fc - kPreX, bx);
+      f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) acc = mma3(ag[kk], bx[kk], acc);
-        add_block(rb + (uCv + eb) * 4096, acc);
-      }
-      // the cotangent of this block's conv outputs, trajectory-major, relu' from
-      // the saved outputs, then its products against the window planes
-      const char *tb = L16.b0 + gA + (mC + 2 * eb) * kBlock16;
-      f32x16 tt;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) tt[i] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        Op16 w;
-        w.h = *reinterpret_cast<const u32x4 *>(tb + kb * kBlock16);
-        w.l = *reinterpret_cast<const u32x4 *>(tb + kb * kBlock16 + 1024);
-        tt = mma3(xg[kb], w, tt);
-      }
-      int E1[16];
-      texp(ex, hi, E1);
-      float v[16], sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        v[i] = xv[i] > 0.f ? __builtin_amdgcn_ldexpf(tt[i], E1[i] - ec) : 0.f;   // / 2^ec
-        sum += v[i];
-      }
-      char *cblk = lds + rg + uConv * 4096 + ((4 * (eb >> 1)) * 64 + 32 * (eb & 1)) * 4;
-      sum += other_half(sum);
-      if (hi_e == 0)
-        lds_add(cblk + ((row_e >> 3) * 64 + 27) * 4, __builtin_amdgcn_ldexpf(sum, kFixConv - fi));
-      Op16 ac[2];
-      split16(v, -kPreDc, ac);
-#pragma unroll
-      for (int jb = 0; jb < 3; ++jb) {
-        if (APG_AR_KNOCKOUT & 8) break;
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) acc = mma3(ac[kk], binr[jb][kk], acc);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int q = 32 * jb + row_e - kRD * (cc + 4 * hi_e);
-          if (q >= 0 && q < 27) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) lds_add(cblk + (g * 64 + q) * 4, acc[4 * g + cc]);
-          }
-        }
-      }
+      for (int kk = 0; kk < 2; ++kk) acc = mma3(ag[kk], bx[kk], acc);
+      add_block(rb + (uCv + eb) * 4096, acc);
     }
-    p_feat = ff, p_cv = fc, p_g = eg, p_z = e0, p_conv = ec + fi;
+    p_feat = ff, p_cv = fc, p_g = eg, p_z = e0;
     { const int r_ = rg; rg = ro, ro = r_; }
   }
   __syncthreads();
@@ -1270,7 +1218,12 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
   flush_add<5 * 1024>(lds, ro + uCv * 4096, part, uCv * 4096, p_g + p_cv, bad);
   flush_add<1024>(lds, ro + uHh * 4096, part, uHh * 4096, p_g, bad);
   flush_add<1024>(lds, ro + uHead * 4096, part, uHead * 4096, p_z, bad);
-  flush_add<1024>(lds, ro + uConv * 4096, part, uConv * 4096, p_conv, bad, kFixConv);
+  // the diagonals tau = 0..2 (after the last shift they sit in slots 1..3)
+#pragma unroll
+  for (int ch = 0; ch < kNC; ++ch)
+#pragma unroll
+    for (int tau = 0; tau < 3; ++tau)
+      Pdc.st(vg, (unsigned)(ch * 2 * kTau + tau) * pitchB, dgn[ch][tau + 1]);
   if (st_lo && A.grad_state0)
 #pragma unroll
     for (int i = 0; i < 12; ++i) A.grad_state0[(size_t)i * B + b] = lam[i];
@@ -1288,7 +1241,7 @@ __global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs 
 // last level also sums the loss partials.  As mlp.hip's: a first level over
 // chunks of kRedChunk workgroups when there are more than that.
 struct LstmGrads {   // = ApgLstmPolicyGrads
-  float *conv_w, *conv_b, *w_ih, *w_hh, *b_ih, *b_hh, *w_out, *b_out;
+  float *w_ih, *w_hh, *b_ih, *b_hh, *w_out, *b_out;
 };
 // destinations of element (slot, register i, lane): at most two (b_ih and b_hh
 // are two parameters with one gradient)
@@ -1306,12 +1259,9 @@ __device__ __forceinline__ int tm_dest(const LstmGrads &g, int slot, int i, int 
     dst[0] = g.w_ih + m * kNX + kNF + 32 * (slot - uCv) + col;
   } else if (slot == uHh) {
     if (col < kNH) dst[0] = g.w_hh + m * kNH + col;
-  } else if (slot == uHead) {
-    if (m < 4 && col < kNH) dst[0] = g.w_out + m * kNH + col;
-    else if (m < 4 && col == kNH) dst[0] = g.b_out + m;
-  } else if (m < kNC) {
-    if (col < 27) dst[0] = g.conv_w + m * 27 + (col % kRD) * 3 + col / kRD;
-    else if (col == 27) dst[0] = g.conv_b + m;
+  } else if (m < 4) {   // uHead
+    if (col < kNH) dst[0] = g.w_out + m * kNH + col;
+    else if (col == kNH) dst[0] = g.b_out + m;
   }
   return (dst[0] != nullptr) + (dst[1] != nullptr);
 }
@@ -1334,9 +1284,7 @@ __global__ __launch_bounds__(256) void lstm_wgrad_reduce1_kernel(const float *pa
 
 struct TmReduceArgs {
   const float *part;
-  LstmGrads g, param, mom;
-  double lr, momentum;
-  bool update;
+  LstmGrads g;
   const float *loss_partials;
   float *loss;
   int wgs, n_partials;
@@ -1361,18 +1309,6 @@ __global__ __launch_bounds__(256) void lstm_wgrad_reduce_kernel(TmReduceArgs A) 
         for (int w = 0; w < kRedChunk; ++w) s += v[w];
       }
       for (int q = 0; q < nd; ++q) *dst[q] = s;
-      if (A.update) {   // torch.optim.SGD: buf = momentum buf + grad, p -= lr buf
-        // (bias_ih and bias_hh: two parameters even where one gradient tensor
-        // serves both)
-        float *pp[2], *pm[2];
-        const int np = tm_dest(A.param, slot, i, lane, pp);
-        tm_dest(A.mom, slot, i, lane, pm);
-        for (int q = 0; q < np; ++q) {
-          const float buf = (float)(A.momentum * (double)*pm[q] + (double)s);
-          *pm[q] = buf;
-          *pp[q] = (float)((double)*pp[q] - A.lr * (double)buf);
-        }
-      }
     }
   }
   if (blockIdx.x == 0 && A.loss) {   // fixed-shape sum of the loss partials
@@ -1569,21 +1505,13 @@ int apg_quad_lstm_rollout_train_step(
     const float *h0, const float *c0, float dt, const ApgQuadParams *params,
     const ApgQuadLossWeights *weights, const ApgLstmPolicy *policy, int B, int H,
     float *states, float *actions, float *acts, float *gates, unsigned *relu_mask,
-    float *loss, const ApgLstmPolicyGrads *grads, float *grad_state0, float *grad_h0,
-    float *grad_c0, float *workspace, float *partials, const ApgLstmSgdUpdate *update,
+    float *d_conv, float *loss, const ApgLstmPolicyGrads *grads, float *grad_state0,
+    float *grad_h0, float *grad_c0, float *workspace, float *partials,
     apg_stream_t stream) {
   if (int e = check_lstm(params, policy, B, H)) return e;
   const auto all_set = [](const ApgLstmPolicyGrads &g) {
-    return g.conv_w && g.conv_b && g.w_ih && g.w_hh && g.b_ih && g.b_hh && g.w_out && g.b_out;
+    return g.w_ih && g.w_hh && g.b_ih && g.b_hh && g.w_out && g.b_out;
   };
-  if (update && (!all_set(update->param) || !all_set(update->momentum_buf))) {
-    set_error("update: parameter / momentum pointer is NULL");
-    return APG_ERR_ARG;
-  }
-  if (update && !(update->lr == update->lr && update->momentum == update->momentum)) {
-    set_error("update: lr / momentum is NaN");
-    return APG_ERR_ARG;
-  }
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
   if (ref_cols != 9 && ref_cols != 6) {
     set_error("ref_cols must be 9 or 6");
@@ -1593,21 +1521,12 @@ int apg_quad_lstm_rollout_train_step(
     set_error("gradient pointer is NULL");
     return APG_ERR_ARG;
   }
-  if (update && (update->param.b_hh == update->param.b_ih ||
-                 update->momentum_buf.b_hh == update->momentum_buf.b_ih)) {
-    set_error("update: bias_ih and bias_hh are two parameters (two momentum buffers)");
-    return APG_ERR_ARG;
-  }
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
-    if (update) {
-      set_error("update with B = 0 is not supported");
-      return APG_ERR_ARG;
-    }
     const ApgLstmPolicyGrads &g = *grads;
-    float *ptrs[8] = {g.conv_w, g.conv_b, g.w_ih, g.w_hh, g.b_ih, g.b_hh, g.w_out, g.b_out};
-    const size_t n[8] = {kNC * 27, kNC, kNG * kNX, kNG * kNH, kNG, kNG, 4 * kNH, 4};
-    for (int i = 0; i < 8; ++i)
+    float *ptrs[6] = {g.w_ih, g.w_hh, g.b_ih, g.b_hh, g.w_out, g.b_out};
+    const size_t n[6] = {kNG * kNX, kNG * kNH, kNG, kNG, 4 * kNH, 4};
+    for (int i = 0; i < 6; ++i)
       if (hipMemsetAsync(ptrs[i], 0, n[i] * sizeof(float), st) != hipSuccess)
         return check_launch("memset(grads)");
     if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
@@ -1615,7 +1534,7 @@ int apg_quad_lstm_rollout_train_step(
     return APG_OK;
   }
   if (!state0 || !in_ref || !ref || !h0 || !c0 || !states || !actions || !acts || !gates ||
-      !relu_mask || !workspace || !partials) {
+      !relu_mask || !d_conv || !workspace || !partials) {
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
@@ -1654,7 +1573,7 @@ int apg_quad_lstm_rollout_train_step(
   TmArgs A;
   A.state0 = state0, A.states = states, A.actions = actions, A.ref = ref, A.in_ref = in_ref;
   A.mask = relu_mask, A.gates = gates, A.hc = F.hc, A.hnew = F.hnew, A.x = F.x;
-  A.loss_partials = loss_partials, A.part = partials;
+  A.loss_partials = loss_partials, A.part = partials, A.d_conv = d_conv;
   A.grad_state0 = grad_state0, A.grad_h0 = grad_h0, A.grad_c0 = grad_c0;
   A.tables = workspace + kFwd16Lds, A.xmax = xmax;
   A.c = F.c;
@@ -1663,14 +1582,10 @@ int apg_quad_lstm_rollout_train_step(
   hipLaunchKernelGGL(lstm_rollout_bwd_tm_kernel, dim3(blocks), dim3(kTmThreads), kTmLds, st, A);
   TmReduceArgs R;
   const auto as_g = [](const ApgLstmPolicyGrads &g) {
-    return LstmGrads{g.conv_w, g.conv_b, g.w_ih, g.w_hh, g.b_ih, g.b_hh, g.w_out, g.b_out};
+    return LstmGrads{g.w_ih, g.w_hh, g.b_ih, g.b_hh, g.w_out, g.b_out};
   };
   R.part = partials, R.g = as_g(*grads), R.loss_partials = loss_partials, R.loss = loss;
   R.wgs = blocks, R.n_partials = blocks * (kTmThreads / kWave);
-  R.update = update != nullptr;
-  R.param = as_g(update ? update->param : *grads);
-  R.mom = as_g(update ? update->momentum_buf : *grads);
-  R.lr = update ? update->lr : 0.0, R.momentum = update ? update->momentum : 0.0;
   const int columns = (kTmSlots * 1024 + 255) / 256;
   if (blocks > kRedChunk) {
     const int chunks = (blocks + kRedChunk - 1) / kRedChunk;

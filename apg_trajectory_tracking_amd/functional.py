@@ -1164,46 +1164,41 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
         st = stream_of(s0)
         if LSTM_IN_SWEEP:
-            # round 5: every weight gradient is accumulated inside the reverse
-            # sweep (apg_quad_lstm_rollout_train_step) - no cotangent planes, no
-            # second pass of products; every gradient is a view of `flat`
+            # round 5: the gate / recurrent / head weight gradients are
+            # accumulated inside the reverse sweep
+            # (apg_quad_lstm_rollout_train_step) - no cotangent planes of H*B
+            # columns, no products over them; the conv weights keep their
+            # diagonal sums + two small segmented products.  Every gradient is a
+            # view of `flat`.
             flat, gr = _flat_grads(dev, {
                 "lstm.weight_ih": (32, 175), "lstm.weight_hh": (32, 8),
                 "lstm.bias_ih": (32,), "fc_out.weight": (4, 8), "fc_out.bias": (4,),
                 "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,)})
             gr["lstm.bias_hh"] = gr["lstm.bias_ih"]     # one gradient, two parameters
-            gnames = {"conv_w": "conv_ref.weight", "conv_b": "conv_ref.bias",
-                      "w_ih": "lstm.weight_ih", "w_hh": "lstm.weight_hh",
+            gnames = {"w_ih": "lstm.weight_ih", "w_hh": "lstm.weight_hh",
                       "b_ih": "lstm.bias_ih", "b_hh": "lstm.bias_hh",
                       "w_out": "fc_out.weight", "b_out": "fc_out.bias"}
             gs = _capi.ApgLstmPolicyGrads(**{k: ptr(gr[n]) for k, n in gnames.items()})
             ws = new(lib().apg_quad_lstm_step_workspace_floats())
             part = new(max(1, lib().apg_quad_lstm_step_partials_floats(B)))
             loss = new(1)
+            d_conv = new(_CONV_DIAG_PLANES, B)
             g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
             g_h0 = new(8, B) if ctx.needs_input_grad[3] else None
             g_c0 = new(8, B) if ctx.needs_input_grad[4] else None
-            upd = None
-            update = getattr(ctx, "update", None)
-            if update is not None:
-                lr, momentum, bufs = update
-                given = dict(conv_w=conv_w, conv_b=conv_b, w_ih=w_ih, w_hh=w_hh, b_ih=b_ih,
-                             b_hh=b_hh, w_out=w_out, b_out=b_out)
-                if B == 0 or any(pw[k].data_ptr() != v.data_ptr() for k, v in given.items()):
-                    raise ValueError("in-kernel update needs a non-empty batch and "
-                                     "contiguous float32 parameters")
-                require_device(*bufs.values())
-                upd = ctypes.byref(_capi.ApgLstmSgdUpdate(
-                    lr=float(lr), momentum=float(momentum),
-                    param=_capi.ApgLstmPolicyGrads(**{k: ptr(v) for k, v in pw.items()}),
-                    momentum_buf=_capi.ApgLstmPolicyGrads(**{
-                        k: ptr(bufs[n]) for k, n in gnames.items()})))
             check(lib().apg_quad_lstm_rollout_train_step(
                 ptr(s0), ptr(inr), ptr(rf), rf.shape[1], ptr(h0s), ptr(c0s), float(dt),
                 ctypes.byref(params), ctypes.byref(weights), ctypes.byref(pol), B, H,
                 ptr(states), ptr(actions), ptr(acts), ptr(gates), relu_mask.data_ptr(),
-                ptr(loss), ctypes.byref(gs), ptr(g_s0), ptr(g_h0), ptr(g_c0), ptr(ws),
-                ptr(part), upd, st), "apg_quad_lstm_rollout_train_step")
+                ptr(d_conv), ptr(loss), ctypes.byref(gs), ptr(g_s0), ptr(g_h0), ptr(g_c0),
+                ptr(ws), ptr(part), st), "apg_quad_lstm_rollout_train_step")
+            if B > 0:
+                conv, finish = _conv_diag_problems(d_conv, refbuf, B, H,
+                                                   gr["conv_ref.weight"], gr["conv_ref.bias"])
+                _run_products(conv)
+                finish()
+            else:
+                gr["conv_ref.weight"].zero_(), gr["conv_ref.bias"].zero_()
             ctx.flat_grads = (flat, gr)
             ctx.save_for_backward(acts)
             ctx.input_grads = (g_s0, g_h0, g_c0)
@@ -1211,8 +1206,6 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             ctx.dims = (B, H)
             return loss.reshape(()), states, actions
         ctx.flat_grads = None
-        if getattr(ctx, "update", None) is not None:
-            raise ValueError("update needs the in-sweep path")
         ws = new(lib().apg_quad_lstm_workspace_floats())
         check(lib().apg_quad_lstm_rollout_fwd(
             ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
@@ -1845,9 +1838,10 @@ class QuadConcurrentStepPlan:
         return self.loss0
 
 
-# True: the LSTM step accumulates its weight gradients inside the reverse sweep
-# (csrc/lstm.hip, lstm_rollout_bwd_tm_kernel, round 5); False: cotangent planes +
-# planes_gemm products (rounds 1-4)
+# True: the LSTM step accumulates its gate / recurrent / head weight gradients
+# inside the reverse sweep (csrc/lstm.hip, lstm_rollout_bwd_tm_kernel, round 5; the
+# conv weights keep their diagonal sums + two small products); False: cotangent
+# planes + planes_gemm products (rounds 1-4)
 LSTM_IN_SWEEP = True
 
 # True: the autoregressive step accumulates its weight gradients inside the
@@ -2027,12 +2021,9 @@ _LSTM_PARAMS = ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
 
 def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
                             weights=None, index=None, static_inputs=False,
-                            prepared=None, update=None):
-    """quad_lstm_rollout_loss + parameter gradients, without autograd (`update`:
-    as quad_concurrent_policy_grads - momentum SGD inside the second stage)."""
+                            prepared=None):
+    """quad_lstm_rollout_loss + parameter gradients, without autograd."""
     ctx = _DirectCtx()
-    if update is not None:
-        ctx.update = update
     if prepared is not None:     # quad_recurrent_prepare's result
         ctx.prepared = prepared
     elif static_inputs and index is None:

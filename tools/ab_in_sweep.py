@@ -1,7 +1,7 @@
 """In-sweep weight gradients (round 5) against the plane + product path of
 rounds 1-4, autoregressive and LSTM steps at B = 65 536 (gradients only, eager
 launches, resident inputs prepared once):
-    python tools/ab_in_sweep.py [ar|lstm ...]"""
+    python tools/ab_in_sweep.py [ar|lstm ...] [in|planes]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from apg_trajectory_tracking_amd import functional as F, synthetic
@@ -27,9 +27,10 @@ def step(mode):
                                      prepared=prepared)
 
 
-for mode in (sys.argv[1:] or ["ar", "lstm"]):
+only = [a for a in sys.argv[1:] if a in ("in", "planes")]
+for mode in ([a for a in sys.argv[1:] if a in ("ar", "lstm")] or ["ar", "lstm"]):
     for rep in range(2):
-        for on in (True, False):
+        for on in ((True, False) if not only else (only[0] == "in",)):
             F.AR_IN_SWEEP = F.LSTM_IN_SWEEP = on
             for _ in range(5):
                 step(mode)
