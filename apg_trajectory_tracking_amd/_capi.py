@@ -98,11 +98,6 @@ class ApgMlpSgdUpdate(ctypes.Structure):
                 ("param", ApgMlpPolicyGrads), ("momentum_buf", ApgMlpPolicyGrads)]
 
 
-class ApgLstmPolicyGrads(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in (
-        "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")]
-
-
 class ApgWingPolicy(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "w_s", "b_s", "w_r", "b_r", "w_1", "b_1", "w_2", "b_2", "w_3", "b_3",
@@ -190,13 +185,6 @@ SIGNATURES = {
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
         _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P,
         ctypes.POINTER(ApgMlpSgdUpdate), ctypes.POINTER(ApgStepEvents), _P],
-    "apg_quad_lstm_step_workspace_floats": [],
-    "apg_quad_lstm_step_partials_floats": [_I],
-    "apg_quad_lstm_rollout_train_step": [
-        _P, _P, _P, _I, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
-        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgLstmPolicy), _I, _I,
-        _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicyGrads), _P, _P, _P, _P, _P,
-        _P],
     "apg_quad_mlp_rollout_step_workspace_floats": [],
     "apg_quad_mlp_rollout_step_partials_floats": [_I],
     "apg_quad_mlp_rollout_train_step": [
@@ -270,7 +258,6 @@ _RESTYPES = {"apg_last_error_string": ctypes.c_char_p,
              "apg_planes_gemm_multi_workspace_floats": ctypes.c_longlong,
              "apg_quad_mlp_step_partials_floats": ctypes.c_longlong,
              "apg_quad_mlp_rollout_step_partials_floats": ctypes.c_longlong,
-             "apg_quad_lstm_step_partials_floats": ctypes.c_longlong,
              "apg_linear_wgrad_workspace_floats": ctypes.c_longlong}
 
 _lib = None

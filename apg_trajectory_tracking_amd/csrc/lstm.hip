@@ -33,7 +33,6 @@
 #include "apg_device.h"
 #include "policy_mfma.h"
 #include "policy_mfma16.h"
-#include "policy_tm.h"
 #include "quad_math.h"
 
 namespace apg {
@@ -131,16 +130,10 @@ struct FwdArgs {
   float *states, *actions, *x, *gates, *hc, *hnew;
   unsigned *mask;        // [5][N] relu bits of the conv outputs
   const float *tables;   // packed operand tables (lstm_pack_fwd16_kernel)
-  // [waves][H][4] (XMAX): per step max relu(conv), |feature|, a bound of the
-  // |window value|s of each wave's 32 trajectories - the in-sweep reverse
-  // kernel's fixed-point scales (lstm_rollout_bwd_tm_kernel)
-  float *xmax;
   QuadConst c;
   int B;
 };
 
-// XMAX: also leave the step maxima at A.xmax (compile time: the step loop has no branch)
-template <bool XMAX>
 __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds(lds, A.tables, kFwd16Lds);
@@ -179,13 +172,6 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   for (int r = 0; r < kH; ++r)
 #pragma unroll
     for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vb_u, (r * kRD + j) * pitchB);
-  float wmax_raw = 0.f;   // largest |window value| of the rows seen so far (XMAX)
-  if (XMAX) {
-#pragma unroll
-    for (int r = 0; r < kH; ++r)
-#pragma unroll
-      for (int j = 0; j < 5; ++j) wmax_raw = fmaxf(wmax_raw, fabsf(w[r][j]));
-  }
 
 #pragma unroll 1
   for (int k = 0; k < kH; ++k) {
@@ -200,19 +186,6 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
     quad_features(s, t, feat);
 #pragma unroll
     for (int j = 0; j < kNF; ++j) Px.st(vn_lo, j * pN, feat[j]);
-    float xm_c = 0.f;   // largest relu(conv) of this step (XMAX)
-    if (XMAX) {         // feature and window maxima: transient
-      float xm_f = 0.f;
-#pragma unroll
-      for (int j = 0; j < kNF; ++j) xm_f = fmaxf(xm_f, fabsf(feat[j]));
-      // window values are raw - position (columns 0..2, lower half): a bound
-      const float xm_i = wmax_raw + (hi ? 0.f : fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fabsf(s[2])));
-      const float rf = wave_fmax(xm_f), ri = wave_fmax(xm_i);
-      if (lane == 0) {
-        float *q = A.xmax + ((size_t)(blockIdx.x * (kThreads / 64) + wave) * kH + k) * 4;
-        q[1] = rf, q[2] = ri;
-      }
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       Phc.st(vr, r * pN, h[r]);
@@ -276,7 +249,6 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
           float v = cv[i];
           mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
           v = fmaxf(v, 0.f);
-          if (XMAX) xm_c = fmaxf(xm_c, v);
           // plane 15 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
           Px.st(i < 8 ? vc : vn_lo, (kNF + rrow(i) * kNP + pos) * pN, v);
           rv[e * 12 + i] = v;
@@ -294,11 +266,6 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
     // relu mask, trajectory-indexed: bit e = ch*8 + pos of word e >> 5
 #pragma unroll
     for (int g = 0; g < 3; ++g) Pmk.stu(g < 2 ? vm : vn_lo, 2 * g * pN, mbits[g]);
-    if (XMAX) {
-      const float rc = wave_fmax(xm_c);
-      if (lane == 0)
-        A.xmax[((size_t)(blockIdx.x * (kThreads / 64) + wave) * kH + k) * 4] = rc;
-    }
     // cell update: (i, f, g, o) of unit r + 4 hi are registers r, 4+r, 8+r, 12+r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -335,10 +302,6 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
         for (int j = 0; j < 5; ++j) w[r][j] = w[r + 1][j];
 #pragma unroll
       for (int j = 0; j < 5; ++j) w[kH - 1][j] = Pin.ld(vb_u, ((k + kH) * kRD + j) * pB);
-      if (XMAX) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) wmax_raw = fmaxf(wmax_raw, fabsf(w[kH - 1][j]));
-      }
     }
   }
 }
@@ -811,518 +774,6 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
   write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
 }
 
-// ---------------------------------------------------------------------------
-// Round 5: the LSTM reverse sweep with every weight gradient inside (the
-// loss.backward() of TrainDrone.train_recurrent_model, scripts/train_drone.py:
-// 113-173, LSTM mode, in ONE launch: no cotangent planes, no product launches).
-//
-// Until round 4 the reverse sweep wrote the gate / head cotangent planes and
-// the conv diagonals for three planes_gemm launches (195 us of the 534 us step
-// at B = 65 536).  Here the products happen where the cotangents are, in the
-// trajectory-major form of policy_tm.h: the gate cotangent dG is brought into
-// [trajectory][gate row] form by an identity product of its own split, x (15
-// features + 160 conv outputs), h_prev and h_new come from the forward sweep's
-// planes as 16-byte loads, every wave multiplies its own 32 trajectories and
-// adds the 32 x 32 blocks into fixed-point accumulators in LDS.  The LSTM's
-// tables are small (29 KB), so ALL nine blocks of a step fit twice: the steps
-// alternate between two accumulator regions and ONE barrier per step does
-// everything - it publishes the waves' maxima of the step (dz, dG, the conv
-// cotangent: all of them exist before the first product, the recurrence itself
-// is feature-major and lane-local) and it fences the previous step's additions,
-// whose region is flushed into the workgroup's global accumulator (float x the
-// step's scales, buffer_atomic_add_f32) while this step adds into the other.
-// One workgroup = 8 waves = 256 trajectories (the forward sweep keeps 4).
-// The conv weights are the exception: their cotangent still leaves as the 17
-// window-diagonal sums per channel (kConvP above, 720 planes of B floats) for
-// the two small segmented products of apg_planes_gemm.  The in-sweep form of
-// that block was built and measured (tools/patches/lstm_conv_in_sweep.patch):
-// 15 block products per step against the window planes + a scattered
-// accumulation cost 15 us per step where the diagonals cost 2 - the diagonal
-// sums ARE the reduction that makes this gradient cheap, and they are per
-// trajectory (they live in the lane).
-// Blocks of a region (4 KB each, accumulator order [register][lane]):
-//   0      W_ih on the features (columns 0..14) + b_ih = b_hh (column 15: ones)
-//   1..5   W_ih on the conv outputs, 32 columns each
-//   6      W_hh (columns 0..7)
-//   7      fc_out (rows 0..3: columns 0..7, column 8 = b_out)
-constexpr int uFeat = 0, uCv = 1, uHh = 6, uHead = 7, kTmSlots = 8;
-constexpr int kLdsAll = 160 * 1024;
-constexpr int kTmRegion = kTmSlots * 4096;
-constexpr int rTab = kBwd16Lds * 4, rR0 = rTab, rR1 = rR0 + kTmRegion, rMeta = rR1 + kTmRegion;
-struct LstmMeta {
-  unsigned dmax[2][8];   // max |dL/dz|, |dG| bits per wave
-};
-constexpr int kTmLds = rMeta + (int)sizeof(LstmMeta);
-static_assert(kTmLds <= kLdsAll && rTab % 16 == 0, "LDS map");
-constexpr int kRedChunk = 32;
-
-struct TmArgs {
-  const float *state0, *states, *actions, *ref, *in_ref;
-  const unsigned *mask;
-  const float *gates, *hc, *hnew, *x;   // the forward sweep's planes
-  float *loss_partials;
-  float *d_conv;                        // [720][B]: conv cotangents along the diagonals
-  float *part;                          // [workgroups][kTmSlots][1024]
-  float *grad_state0, *grad_h0, *grad_c0;
-  const float *tables;
-  const float *xmax;                    // [waves][H][4]
-  QuadConst c;
-  ApgQuadLossWeights w;
-  int B, ref_cols, vel_col;
-};
-
-__global__ __launch_bounds__(kTmThreads) void lstm_rollout_bwd_tm_kernel(TmArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds_f[];
-  char *lds = reinterpret_cast<char *>(lds_f);
-  const int lane = threadIdx.x & 63, hi = lane >> 5, row = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b0 = blockIdx.x * (kTmThreads / 2);
-  const int b = b0 + wave * 32 + row;
-  const int B = A.B;
-  const bool live = b < B, st_lo = live && hi == 0;
-  const unsigned pitchB = (unsigned)B * 4u, pitchN = pitchB * kH;
-  const QuadConst c = A.c;
-  const Planes Ps0(A.state0, 12, pitchB), Pst(A.states, kH * 12, pitchB);
-  const Planes Pac(A.actions, kH * 4, pitchB), Prf(A.ref, kH * A.ref_cols, pitchB);
-  const Planes Pg(A.gates, kNG, pitchN), Phc(A.hc, 2 * kNH, pitchN), Phn(A.hnew, kNH, pitchN);
-  const Planes Px(A.x, kNX, pitchN), Pmk(A.mask, 5, pitchN);
-  const Planes Pdc(A.d_conv, kConvPlanes, pitchB);
-  const unsigned vb = live ? (unsigned)b * 4u : kDead;
-  const unsigned wcolB = (unsigned)(b0 + wave * 32) * 4u;
-  const unsigned vtN = (unsigned)row * pitchN + (unsigned)hi * 16u;
-  const __amdgpu_buffer_rsrc_t part = __builtin_amdgcn_make_buffer_rsrc(
-      A.part + (size_t)blockIdx.x * kTmSlots * 1024, 0, kTmSlots * 4096, 0x00020000);
-  char *lane_blk = lds + lane * 4;
-  LstmMeta &meta = *reinterpret_cast<LstmMeta *>(lds + rMeta);
-  bool bad = false;
-
-  zero_region(lds, rR0, rMeta - rR0);
-  {  // the global accumulators start at zero: every flush is an atomic add
-    const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int m = 0; m < kTmSlots * 256; m += kTmThreads)
-      if (m + (int)threadIdx.x < kTmSlots * 256)
-        __builtin_amdgcn_raw_buffer_store_b128(z, part, (int)(threadIdx.x * 16u), m * 16, 0);
-  }
-  fill_lds_issue(lds_f, A.tables, kBwd16Lds);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const LdsView16 L16(lds, lane);
-  const LdsView L(lds_f, lane);
-
-  float lam[12], dh[4], dc[4];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) lam[i] = 0.f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) dh[r] = 0.f, dc[r] = 0.f;
-  float loss = 0.f;
-  int rg = rR0, ro = rR1;   // this step's accumulator region / the other one
-  // scales of the region that is flushed behind the next barrier
-  int p_feat = 0, p_cv = 0, p_g = 0, p_z = 0;
-  // sliding diagonal sums of the conv cotangents: dgn[ch][ii] = diagonal
-  // tau = k + ii of this half-wave's positions (see kConvP)
-  float dgn[kNC][4];
-#pragma unroll
-  for (int ch = 0; ch < kNC; ++ch)
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii) dgn[ch][ii] = 0.f;
-  const unsigned vg = live ? (unsigned)b * 4u + (hi ? kTau * pitchB : 0u) : kDead;
-  const unsigned vb_lo = st_lo ? (unsigned)b * 4u : kDead;
-
-#pragma unroll 1
-  for (int k = kH - 1; k >= 0; --k) {
-    const unsigned pB = opaque(pitchB), pN = opaque(pitchN);
-    const unsigned col = (unsigned)b * 4u + (unsigned)k * pitchB;
-    const unsigned vn = live ? col : kDead;
-    const unsigned vr = live ? col + (hi ? 4u * pitchN : 0u) : kDead;
-    const unsigned wcolN = wcolB + (unsigned)k * pB;
-    // ----------------------------------------------------------- feature-major
-    // (the reverse step of lstm_rollout_bwd_kernel without its plane stores)
-    float dz[4];
-    Op16 xg[2];
-    int ex;
-    unsigned m_z = 0u, m_g = 0u;
-    TBlock tx;
-    tx.load(Px, row < kNF ? vtN : kDead, wcolN);   // the features, trajectory-major
-    {
-      float sn[12], sc[12], a[4], rp[3], rv[3];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        sn[i] = Pst.ld(vb, (k * 12 + i) * pB);
-        sc[i] = k > 0 ? Pst.ld(vb, ((k - 1) * 12 + i) * pB) : Ps0.ld(vb, i * pB);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = Pac.ld(vb, (k * 4 + j) * pB);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        rp[i] = Prf.ld(vb, (k * A.ref_cols + i) * pB);
-        rv[i] = Prf.ld(vb, (k * A.ref_cols + A.vel_col + i) * pB);
-      }
-      unsigned mw[5];
-#pragma unroll
-      for (int eb = 0; eb < 5; ++eb) mw[eb] = Pmk.ldu(vn, eb * pN);
-      float gt[16], cp[4];  // activated gates and c_prev of units r + 4 hi
-#pragma unroll
-      for (int i = 0; i < 16; ++i) gt[i] = Pg.ld(vr, ((i >> 2) * kNH + (i & 3)) * pN);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cp[r] = Phc.ld(vr, (kNH + r) * pN);
-      __builtin_amdgcn_sched_barrier(0);
-      float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float dp = sn[i] - rp[i], dv = sn[6 + i] - rv[i], wn = sn[9 + i];
-        lp += dp * dp, lv += dv * dv, lw += wn * wn;
-        lam[i] += 2.f * A.w.pos * dp;
-        lam[6 + i] += 2.f * A.w.vel * dv;
-        lam[9 + i] += 2.f * A.w.av * wn;
-      }
-      const float da0 = a[0] - 0.5f;
-      float ga[4];
-      ga[0] = 2.f * A.w.thrust * da0;
-#pragma unroll
-      for (int j = 1; j < 4; ++j) {
-        const float d = a[j] - 0.5f;
-        lr += d * d;
-        ga[j] = 2.f * A.w.rates * d;
-      }
-      loss += A.w.pos * lp + A.w.vel * lv + A.w.av * lw + A.w.rates * lr +
-              A.w.thrust * da0 * da0;
-      const Trig t = make_trig(&sc[3]);
-      quad_step_adjoint(lam, ga, a[0], &sc[9], c, t);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dz[j] = ga[j] * a[j] * (1.f - a[j]);
-        m_z = umax_abs(m_z, dz[j]);
-      }
-      f32x16 dG;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float gi = gt[r], gf = gt[4 + r], gg = gt[8 + r], go = gt[12 + r];
-        const float tc = tanh_fast(fmaf(gf, cp[r], gi * gg));
-        float dht = dh[r];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dht = fmaf(L.T(gTo + (j * 4 + r) * 2), dz[j], dht);
-        const float dct = dc[r] + dht * go * (1.f - tc * tc);
-        dG[r] = dct * gg * gi * (1.f - gi);
-        dG[4 + r] = dct * cp[r] * gf * (1.f - gf);
-        dG[8 + r] = dct * gi * (1.f - gg * gg);
-        dG[12 + r] = dht * tc * go * (1.f - go);
-        dc[r] = dct * gf;
-      }
-      {
-        float amax = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          amax = fmaxf(amax, fabsf(dG[i]));
-          m_g = umax_abs(m_g, dG[i]);
-        }
-        ex = scale_exponent(amax);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_ldexpf(dG[8 * kb + j], -ex);
-          xg[kb] = split8(v);
-        }
-      }
-      f32x16 yh, yf;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) yh[i] = 0.f, yf[i] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        yh = mma3(L16.A(gA, mH + kb), xg[kb], yh);
-        yf = mma3(L16.A(gA, mF + kb), xg[kb], yf);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        yh[i] = __builtin_amdgcn_ldexpf(yh[i], ex);
-        yf[i] = __builtin_amdgcn_ldexpf(yf[i], ex);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dh[r] = yh[r];  // rows r + 4 hi = the lane's units
-      float dfeat[kNF], gs[12];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float own = yf[i], oth = other_half(own);
-        dfeat[rrow(i)] = hi ? oth : own;
-        if (rrow(i) + 4 < kNF) dfeat[rrow(i) + 4 < kNF ? rrow(i) + 4 : 0] = hi ? own : oth;
-      }
-      quad_features_adjoint(sc, t, dfeat, gs);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) lam[i] += gs[i];
-      // conv cotangent (feature-major): the position cotangent; for the conv
-      // weights it leaves summed along the window diagonals (kConvP)
-      float dpos[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int eb = 0; eb < 5; ++eb) {
-        f32x16 y0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) y0[i] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) y0 = mma3(L16.A(gA, mC + eb * 2 + kb), xg[kb], y0);
-        const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];  // bit r(i) + 4 hi -> bit r(i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3: channel eb*4 + g,
-          const int ch = eb * 4 + g;     // positions ii + 4 hi
-          float sum = 0.f;
-#pragma unroll
-          for (int ii = 0; ii < 4; ++ii) {
-            const int i = 4 * g + ii;
-            const float dcp = ((mws >> rrow(i)) & 1u) ? __builtin_amdgcn_ldexpf(y0[i], ex) : 0.f;
-            dgn[ch][ii] += dcp;
-            sum += dcp;
-          }
-          // diagonal tau = k + 3 is complete; the others move up one position
-          Pdc.st(vg, (unsigned)(ch * 2 * kTau + k + 3) * pB, dgn[ch][3]);
-          dgn[ch][3] = dgn[ch][2], dgn[ch][2] = dgn[ch][1], dgn[ch][1] = dgn[ch][0];
-          dgn[ch][0] = 0.f;
-          Pdc.st(vb_lo, (unsigned)(kConvP + ch * kH + k) * pB, sum + other_half(sum));
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            dpos[q] = fmaf(L.U(gAq + (eb * 4 + g) * 3 + q), sum, dpos[q]);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) lam[q] -= dpos[q] + other_half(dpos[q]);
-    }
-    m_z = wave_umax(m_z), m_g = wave_umax(m_g);
-    if (lane == 0) meta.dmax[0][wave] = m_z, meta.dmax[1][wave] = m_g;
-    unsigned mc = 0u, mf = 0x3f800000u /* the ones row */;
-    {
-      const unsigned *q = reinterpret_cast<const unsigned *>(A.xmax) +
-                          ((size_t)blockIdx.x * (kTmThreads / 64) * kH + k) * 4;
-#pragma unroll
-      for (int w8 = 0; w8 < kTmThreads / 64; ++w8) {
-        mc = q[w8 * kH * 4] > mc ? q[w8 * kH * 4] : mc;
-        mf = q[w8 * kH * 4 + 1] > mf ? q[w8 * kH * 4 + 1] : mf;
-      }
-    }
-    const int fc = bits_exp(mc, bad, true), ff = bits_exp(mf, bad, true);
-    if (!(APG_AR_KNOCKOUT & 16)) __syncthreads();
-    // ---- the previous step's blocks -> the global accumulator (first step: zeros)
-    flush_add<1024>(lds, ro + uFeat * 4096, part, uFeat * 4096, p_g + p_feat, bad);
-    flush_add<5 * 1024>(lds, ro + uCv * 4096, part, uCv * 4096, p_g + p_cv, bad);
-    flush_add<1024>(lds, ro + uHh * 4096, part, uHh * 4096, p_g, bad);
-    flush_add<1024>(lds, ro + uHead * 4096, part, uHead * 4096, p_z, bad);
-    // --------------------------------------------------------- trajectory-major
-    const int e0 = wg_exp(meta.dmax[0], bad), eg = wg_exp(meta.dmax[1], bad);
-    char *rb = lane_blk + rg;
-    Op16 ag[2];    // dG^T with the workgroup's scale: A operand of the W_ih / W_hh blocks
-    {
-      // dG^T by the identity product of its own split (k-slot j of k-block kb,
-      // half hi = gate row r(8 kb + j) + 4 hi), rows rescaled per trajectory
-      f32x16 gz;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) gz[i] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        u32x4 idg;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          idg[q] = (rrow(8 * kb + 2 * q) + 4 * hi == row ? 0x3c00u : 0u) |
-                   (rrow(8 * kb + 2 * q + 1) + 4 * hi == row ? 0x3c000000u : 0u);
-        gz = mfma16(xg[kb].l, idg, gz);
-        gz = mfma16(xg[kb].h, idg, gz);
-      }
-      int E[16];
-      texp(ex, hi, E);
-      float gT[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) gT[i] = __builtin_amdgcn_ldexpf(gz[i], E[i]);
-      split16(gT, eg - kPreD, ag);
-    }
-    {  // W_ih on the features + the bias column
-      float v[16];
-      get_clamped(tx, v, ff);
-      tx.load(Px, vtN, (unsigned)kNF * pN + wcolN);   // conv outputs, block 0
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = row == kNF ? 1.f : v[i];
-      Op16 bx[2];
-      split16(v, ff - kPreX, bx);
-      f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) acc = mma3(ag[kk], bx[kk], acc);
-      add_block(rb + uFeat * 4096, acc);
-    }
-    {  // W_hh: x = h_prev (8 planes); fc_out: dL/dz^T against h_new + ones
-      TBlock th, tn;
-      th.load(Phc, row < kNH ? vtN : kDead, wcolN);
-      tn.load(Phn, row < kNH ? vtN : kDead, wcolN);
-      float v[16];
-      th.get(v);
-      Op16 bx[2];
-      split16(v, -kPreX, bx);
-      f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) acc = mma3(ag[kk], bx[kk], acc);
-      if (row < kNH) add_block(rb + uHh * 4096, acc);
-      // dL/dz^T by an identity product, scaled into accumulator units
-      float v8[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v8[j] = (hi == 0 && j < 4) ? __builtin_amdgcn_ldexpf(dz[j < 4 ? j : 0], kPreD - e0) : 0.f;
-      const Op16 x0 = split8(v8);
-      u32x4 idz;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        idz[q] = (8 * hi + 2 * q == row ? 0x3c00u : 0u) |
-                 (8 * hi + 2 * q + 1 == row ? 0x3c000000u : 0u);
-      f32x16 tzv;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) tzv[i] = 0.f;
-      tzv = mfma16(x0.l, idz, tzv);
-      tzv = mfma16(x0.h, idz, tzv);
-      float tz[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) tz[i] = tzv[i];
-      Op16 az[2];
-      split16(tz, 0, az);
-      tn.get(v);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = row == kNH ? 1.f : v[i];
-      split16(v, -kPreX, bx);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) acc = mma3(az[kk], bx[kk], acc);
-      if (hi == 0 && row <= kNH) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lds_add(rb + uHead * 4096 + i * 256, acc[i]);
-      }
-    }
-#pragma unroll 1
-    for (int eb = 0; eb < 5; ++eb) {
-      // x block 1 + eb = the saved conv outputs e = 32 eb + row (channel
-      // 4 eb + row / 8, position row % 8)
-      float xv[16];
-      get_clamped(tx, xv, fc);
-      if (eb < 4) tx.load(Px, vtN, (unsigned)(kNF + 32 * (eb + 1)) * pN + wcolN);
-      Op16 bx[2];
-      split16(xv, fc - kPreX, bx);
-      f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) acc = mma3(ag[kk], bx[kk], acc);
-      add_block(rb + (uCv + eb) * 4096, acc);
-    }
-    p_feat = ff, p_cv = fc, p_g = eg, p_z = e0;
-    { const int r_ = rg; rg = ro, ro = r_; }
-  }
-  __syncthreads();
-  flush_add<1024>(lds, ro + uFeat * 4096, part, uFeat * 4096, p_g + p_feat, bad);
-  flush_add<5 * 1024>(lds, ro + uCv * 4096, part, uCv * 4096, p_g + p_cv, bad);
-  flush_add<1024>(lds, ro + uHh * 4096, part, uHh * 4096, p_g, bad);
-  flush_add<1024>(lds, ro + uHead * 4096, part, uHead * 4096, p_z, bad);
-  // the diagonals tau = 0..2 (after the last shift they sit in slots 1..3)
-#pragma unroll
-  for (int ch = 0; ch < kNC; ++ch)
-#pragma unroll
-    for (int tau = 0; tau < 3; ++tau)
-      Pdc.st(vg, (unsigned)(ch * 2 * kTau + tau) * pitchB, dgn[ch][tau + 1]);
-  if (st_lo && A.grad_state0)
-#pragma unroll
-    for (int i = 0; i < 12; ++i) A.grad_state0[(size_t)i * B + b] = lam[i];
-  if (live && A.grad_h0)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) A.grad_h0[(size_t)(r + 4 * hi) * B + b] = dh[r];
-  if (live && A.grad_c0)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) A.grad_c0[(size_t)(r + 4 * hi) * B + b] = dc[r];
-  write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
-}
-
-// Second stage: the workgroups' accumulators summed in a fixed order
-// (deterministic) and scattered into the parameter gradients; block 0 of the
-// last level also sums the loss partials.  As mlp.hip's: a first level over
-// chunks of kRedChunk workgroups when there are more than that.
-struct LstmGrads {   // = ApgLstmPolicyGrads
-  float *w_ih, *w_hh, *b_ih, *b_hh, *w_out, *b_out;
-};
-// destinations of element (slot, register i, lane): at most two (b_ih and b_hh
-// are two parameters with one gradient)
-__device__ __forceinline__ int tm_dest(const LstmGrads &g, int slot, int i, int lane,
-                                       float *(&dst)[2]) {
-  const int m = rrow(i) + 4 * (lane >> 5), col = lane & 31;
-  dst[0] = dst[1] = nullptr;
-  if (slot == uFeat) {
-    if (col < kNF) dst[0] = g.w_ih + m * kNX + col;
-    else if (col == kNF) {
-      dst[0] = g.b_ih + m;
-      if (g.b_hh != g.b_ih) dst[1] = g.b_hh + m;
-    }
-  } else if (slot < uHh) {
-    dst[0] = g.w_ih + m * kNX + kNF + 32 * (slot - uCv) + col;
-  } else if (slot == uHh) {
-    if (col < kNH) dst[0] = g.w_hh + m * kNH + col;
-  } else if (m < 4) {   // uHead
-    if (col < kNH) dst[0] = g.w_out + m * kNH + col;
-    else if (col == kNH) dst[0] = g.b_out + m;
-  }
-  return (dst[0] != nullptr) + (dst[1] != nullptr);
-}
-
-__global__ __launch_bounds__(256) void lstm_wgrad_reduce1_kernel(const float *part,
-                                                                 float *chunk_sums, int wgs) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= kTmSlots * 1024) return;
-  const size_t stride = (size_t)kTmSlots * 1024;
-  const int w0 = blockIdx.y * kRedChunk;
-  const float *p = part + (size_t)w0 * stride + t;
-  float v[kRedChunk];
-#pragma unroll
-  for (int k = 0; k < kRedChunk; ++k) v[k] = w0 + k < wgs ? p[(size_t)k * stride] : 0.f;
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < kRedChunk; ++k) s += v[k];   // fixed order
-  chunk_sums[(size_t)blockIdx.y * stride + t] = s;
-}
-
-struct TmReduceArgs {
-  const float *part;
-  LstmGrads g;
-  const float *loss_partials;
-  float *loss;
-  int wgs, n_partials;
-};
-
-__global__ __launch_bounds__(256) void lstm_wgrad_reduce_kernel(TmReduceArgs A) {
-  const int t = blockIdx.x * 256 + threadIdx.x;   // (slot, reg, lane)
-  const size_t stride = (size_t)kTmSlots * 1024;
-  if (t < kTmSlots * 1024) {
-    const int slot = t >> 10, i = (t >> 6) & 15, lane = t & 63;
-    float *dst[2];
-    const int nd = tm_dest(A.g, slot, i, lane, dst);
-    if (nd) {
-      const float *p = A.part + t;
-      float s = 0.f;
-      for (int w0 = 0; w0 < A.wgs; w0 += kRedChunk) {
-        float v[kRedChunk];
-#pragma unroll
-        for (int w = 0; w < kRedChunk; ++w)
-          v[w] = w0 + w < A.wgs ? p[(size_t)(w0 + w) * stride] : 0.f;
-#pragma unroll
-        for (int w = 0; w < kRedChunk; ++w) s += v[w];
-      }
-      for (int q = 0; q < nd; ++q) *dst[q] = s;
-    }
-  }
-  if (blockIdx.x == 0 && A.loss) {   // fixed-shape sum of the loss partials
-    __shared__ double sm[4];
-    double acc = 0.0;
-    for (int k = threadIdx.x; k < A.n_partials; k += 256) acc += (double)A.loss_partials[k];
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) *A.loss = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
-  }
-}
-
 int check_lstm(const ApgQuadParams *params, const ApgLstmPolicy *pol, int B, int H) {
   if (!params || !pol) { set_error("params / policy is NULL"); return APG_ERR_ARG; }
   if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
@@ -1379,7 +830,6 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
   A.hnew = hnew;
   A.mask = relu_mask;
   A.tables = workspace;
-  A.xmax = nullptr;
   A.c = make_const(*params, dt);
   A.B = B;
   PackArgs P;
@@ -1387,7 +837,7 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256),
                      0, st, P);
-  hipLaunchKernelGGL(lstm_rollout_fwd_kernel<false>,
+  hipLaunchKernelGGL(lstm_rollout_fwd_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
                      kFwd16Lds * sizeof(float), st, A);
   return check_launch("quad_lstm_rollout_fwd");
@@ -1486,116 +936,6 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
                      kFwd16Lds * sizeof(float), st, A);
   return check_launch("quad_lstm_closed_loop");
-}
-
-int apg_quad_lstm_step_workspace_floats(void) { return kFwd16Lds + kBwd16Lds; }
-
-long long apg_quad_lstm_step_partials_floats(int B) {
-  if (B <= 0) return 0;
-  const long long wgs = (B + kTmThreads / 2 - 1) / (kTmThreads / 2);
-  // the workgroups' accumulators + the chunk sums of the first reduction level
-  // + the per-wave loss partials + the forward sweep's per-wave, per-step maxima
-  const long long waves = wgs * (kTmThreads / kWave);
-  return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kTmSlots * 1024 + waves +
-         waves * kH * 4;
-}
-
-int apg_quad_lstm_rollout_train_step(
-    const float *state0, const float *in_ref, const float *ref, int ref_cols,
-    const float *h0, const float *c0, float dt, const ApgQuadParams *params,
-    const ApgQuadLossWeights *weights, const ApgLstmPolicy *policy, int B, int H,
-    float *states, float *actions, float *acts, float *gates, unsigned *relu_mask,
-    float *d_conv, float *loss, const ApgLstmPolicyGrads *grads, float *grad_state0,
-    float *grad_h0, float *grad_c0, float *workspace, float *partials,
-    apg_stream_t stream) {
-  if (int e = check_lstm(params, policy, B, H)) return e;
-  const auto all_set = [](const ApgLstmPolicyGrads &g) {
-    return g.w_ih && g.w_hh && g.b_ih && g.b_hh && g.w_out && g.b_out;
-  };
-  if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
-  if (ref_cols != 9 && ref_cols != 6) {
-    set_error("ref_cols must be 9 or 6");
-    return APG_ERR_ARG;
-  }
-  if (!grads || !all_set(*grads)) {
-    set_error("gradient pointer is NULL");
-    return APG_ERR_ARG;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  if (B == 0) {
-    const ApgLstmPolicyGrads &g = *grads;
-    float *ptrs[6] = {g.w_ih, g.w_hh, g.b_ih, g.b_hh, g.w_out, g.b_out};
-    const size_t n[6] = {kNG * kNX, kNG * kNH, kNG, kNG, 4 * kNH, 4};
-    for (int i = 0; i < 6; ++i)
-      if (hipMemsetAsync(ptrs[i], 0, n[i] * sizeof(float), st) != hipSuccess)
-        return check_launch("memset(grads)");
-    if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
-      return check_launch("memset(loss)");
-    return APG_OK;
-  }
-  if (!state0 || !in_ref || !ref || !h0 || !c0 || !states || !actions || !acts || !gates ||
-      !relu_mask || !d_conv || !workspace || !partials) {
-    set_error("NULL buffer");
-    return APG_ERR_ARG;
-  }
-  static PerDeviceOnce attr;
-  if (!attr.test()) {
-    if (hipFuncSetAttribute((const void *)lstm_rollout_bwd_tm_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kTmLds) != hipSuccess)
-      return check_launch("hipFuncSetAttribute(lstm_rollout_bwd_tm)");
-    attr.set();
-  }
-  const size_t N = (size_t)B * kH;
-  const int blocks = (B + kTmThreads / 2 - 1) / (kTmThreads / 2);
-  // (the forward sweep covers every wave of the reverse grid - the tail waves
-  // beyond the batch leave their, finite, maxima too)
-  const int fblocks = blocks * (kTmThreads / kThreads);
-  const long long waves = (long long)blocks * (kTmThreads / kWave);
-  float *loss_partials = partials + (size_t)(blocks + (blocks + kRedChunk - 1) / kRedChunk) *
-                                        kTmSlots * 1024;
-  float *xmax = loss_partials + waves;
-  PackArgs P;
-  P.pol = *policy, P.dst = workspace;
-  hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256), 0, st, P);
-  P.dst = workspace + kFwd16Lds;
-  hipLaunchKernelGGL(lstm_pack_bwd16_kernel, dim3((kBwd16Lds + 255) / 256), dim3(256), 0, st, P);
-  FwdArgs F;
-  F.state0 = state0, F.in_ref = in_ref, F.h0 = h0, F.c0 = c0;
-  F.states = states, F.actions = actions;
-  F.x = acts, F.hc = acts + (size_t)kNX * N, F.hnew = acts + (size_t)(kNX + 2 * kNH) * N;
-  F.gates = gates, F.mask = relu_mask;
-  F.tables = workspace;
-  F.xmax = xmax;
-  F.c = make_const(*params, dt);
-  F.B = B;
-  hipLaunchKernelGGL(lstm_rollout_fwd_kernel<true>, dim3(fblocks), dim3(kThreads),
-                     kFwd16Lds * sizeof(float), st, F);
-  TmArgs A;
-  A.state0 = state0, A.states = states, A.actions = actions, A.ref = ref, A.in_ref = in_ref;
-  A.mask = relu_mask, A.gates = gates, A.hc = F.hc, A.hnew = F.hnew, A.x = F.x;
-  A.loss_partials = loss_partials, A.part = partials, A.d_conv = d_conv;
-  A.grad_state0 = grad_state0, A.grad_h0 = grad_h0, A.grad_c0 = grad_c0;
-  A.tables = workspace + kFwd16Lds, A.xmax = xmax;
-  A.c = F.c;
-  A.w = *weights;
-  A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
-  hipLaunchKernelGGL(lstm_rollout_bwd_tm_kernel, dim3(blocks), dim3(kTmThreads), kTmLds, st, A);
-  TmReduceArgs R;
-  const auto as_g = [](const ApgLstmPolicyGrads &g) {
-    return LstmGrads{g.w_ih, g.w_hh, g.b_ih, g.b_hh, g.w_out, g.b_out};
-  };
-  R.part = partials, R.g = as_g(*grads), R.loss_partials = loss_partials, R.loss = loss;
-  R.wgs = blocks, R.n_partials = blocks * (kTmThreads / kWave);
-  const int columns = (kTmSlots * 1024 + 255) / 256;
-  if (blocks > kRedChunk) {
-    const int chunks = (blocks + kRedChunk - 1) / kRedChunk;
-    float *chunk_sums = partials + (size_t)blocks * kTmSlots * 1024;
-    hipLaunchKernelGGL(lstm_wgrad_reduce1_kernel, dim3(columns, chunks), dim3(256), 0, st,
-                       partials, chunk_sums, blocks);
-    R.part = chunk_sums, R.wgs = chunks;
-  }
-  hipLaunchKernelGGL(lstm_wgrad_reduce_kernel, dim3(columns), dim3(256), 0, st, R);
-  return check_launch("quad_lstm_rollout_train_step");
 }
 
 }  // extern "C"

@@ -1163,49 +1163,6 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         gates = new(32, N)
         relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
         st = stream_of(s0)
-        if LSTM_IN_SWEEP:
-            # round 5: the gate / recurrent / head weight gradients are
-            # accumulated inside the reverse sweep
-            # (apg_quad_lstm_rollout_train_step) - no cotangent planes of H*B
-            # columns, no products over them; the conv weights keep their
-            # diagonal sums + two small segmented products.  Every gradient is a
-            # view of `flat`.
-            flat, gr = _flat_grads(dev, {
-                "lstm.weight_ih": (32, 175), "lstm.weight_hh": (32, 8),
-                "lstm.bias_ih": (32,), "fc_out.weight": (4, 8), "fc_out.bias": (4,),
-                "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,)})
-            gr["lstm.bias_hh"] = gr["lstm.bias_ih"]     # one gradient, two parameters
-            gnames = {"w_ih": "lstm.weight_ih", "w_hh": "lstm.weight_hh",
-                      "b_ih": "lstm.bias_ih", "b_hh": "lstm.bias_hh",
-                      "w_out": "fc_out.weight", "b_out": "fc_out.bias"}
-            gs = _capi.ApgLstmPolicyGrads(**{k: ptr(gr[n]) for k, n in gnames.items()})
-            ws = new(lib().apg_quad_lstm_step_workspace_floats())
-            part = new(max(1, lib().apg_quad_lstm_step_partials_floats(B)))
-            loss = new(1)
-            d_conv = new(_CONV_DIAG_PLANES, B)
-            g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
-            g_h0 = new(8, B) if ctx.needs_input_grad[3] else None
-            g_c0 = new(8, B) if ctx.needs_input_grad[4] else None
-            check(lib().apg_quad_lstm_rollout_train_step(
-                ptr(s0), ptr(inr), ptr(rf), rf.shape[1], ptr(h0s), ptr(c0s), float(dt),
-                ctypes.byref(params), ctypes.byref(weights), ctypes.byref(pol), B, H,
-                ptr(states), ptr(actions), ptr(acts), ptr(gates), relu_mask.data_ptr(),
-                ptr(d_conv), ptr(loss), ctypes.byref(gs), ptr(g_s0), ptr(g_h0), ptr(g_c0),
-                ptr(ws), ptr(part), st), "apg_quad_lstm_rollout_train_step")
-            if B > 0:
-                conv, finish = _conv_diag_problems(d_conv, refbuf, B, H,
-                                                   gr["conv_ref.weight"], gr["conv_ref.bias"])
-                _run_products(conv)
-                finish()
-            else:
-                gr["conv_ref.weight"].zero_(), gr["conv_ref.bias"].zero_()
-            ctx.flat_grads = (flat, gr)
-            ctx.save_for_backward(acts)
-            ctx.input_grads = (g_s0, g_h0, g_c0)
-            ctx.mark_non_differentiable(states, actions)
-            ctx.dims = (B, H)
-            return loss.reshape(()), states, actions
-        ctx.flat_grads = None
         ws = new(lib().apg_quad_lstm_workspace_floats())
         check(lib().apg_quad_lstm_rollout_fwd(
             ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
@@ -1234,11 +1191,8 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gs, _ga):
-        if ctx.flat_grads is not None:
-            gr = {k: v * g for k, v in ctx.flat_grads[1].items()}
-        else:
-            flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
-            flat *= g
+        flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
+        flat *= g
         grads = [gr[k] for k in ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
                                  "lstm.weight_hh", "lstm.bias_ih", "lstm.bias_hh",
                                  "fc_out.weight", "fc_out.bias")]
@@ -1838,12 +1792,6 @@ class QuadConcurrentStepPlan:
         return self.loss0
 
 
-# True: the LSTM step accumulates its gate / recurrent / head weight gradients
-# inside the reverse sweep (csrc/lstm.hip, lstm_rollout_bwd_tm_kernel, round 5; the
-# conv weights keep their diagonal sums + two small products); False: cotangent
-# planes + planes_gemm products (rounds 1-4)
-LSTM_IN_SWEEP = True
-
 # True: the autoregressive step accumulates its weight gradients inside the
 # reverse sweep (csrc/mlp.hip, mlp_rollout_bwd_tm_kernel, round 5); False:
 # cotangent planes + planes_gemm products (rounds 1-4)
@@ -2032,7 +1980,7 @@ def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
         loss, _, _ = _QuadLstmRolloutLoss.forward(
             ctx, state0, in_ref, ref, h0, c0, *_net_params(net, _LSTM_PARAMS), dt,
             params, weights or quad_loss_weights(), index)
-        flat, gr = ctx.flat_grads or _lstm_param_grads(ctx.saved_tensors, ctx.dims)
+        flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
     return loss, gr, flat
 
 

@@ -452,41 +452,6 @@ int apg_quad_mlp_concurrent_train_step(
     float *states, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
     const ApgStepEvents *events, apg_stream_t stream);
 
-/* The LSTM-mode training step (round 5; configs[4]): forward sweep (as
- * apg_quad_lstm_rollout_fwd), then a reverse sweep that accumulates the gate,
- * recurrent and head weight gradients inside (csrc/lstm.hip,
- * lstm_rollout_bwd_tm_kernel: trajectory-major block products per step into
- * fixed-point LDS accumulators, one barrier per step, flushed into a
- * workgroup-owned float accumulator in `partials`), then a fixed-order second
- * stage.  No gate / head cotangent planes, no apg_planes_gemm over H*B rows.
- * The conv weights are the exception: their cotangent leaves as the window-
- * diagonal sums d_conv [720][B] of apg_quad_lstm_rollout_bwd - feed them to
- * the two small segmented apg_planes_gemm products as before (the diagonal
- * sums are what makes that gradient cheap).
- * Bit-reproducible run to run.
- *   state0 [12][B], in_ref [2H][9][B], ref [H][ref_cols][B], h0 / c0 [8][B];
- *   out: states [H][12][B], actions [H][4][B]; scratch the reverse sweep reads:
- *     acts [199][H*B] (x 175 | h_prev, c_prev 16 | h_new 8), gates [32][H*B],
- *     relu_mask [5][H*B]; d_conv [720][B]; loss [1];
- *     grads: w_ih [32][175], w_hh [32][8], b_ih / b_hh [32] (the same values;
- *     the two pointers may be equal), w_out [4][8], b_out [4];
- *     grad_state0 [12][B], grad_h0 / grad_c0 [8][B] or NULL;
- *   workspace: apg_quad_lstm_step_workspace_floats() floats,
- *   partials:  apg_quad_lstm_step_partials_floats(B) floats. */
-typedef struct ApgLstmPolicyGrads {
-  float *w_ih, *w_hh, *b_ih, *b_hh, *w_out, *b_out;
-} ApgLstmPolicyGrads;
-int apg_quad_lstm_step_workspace_floats(void);
-long long apg_quad_lstm_step_partials_floats(int B);
-int apg_quad_lstm_rollout_train_step(
-    const float *state0, const float *in_ref, const float *ref, int ref_cols,
-    const float *h0, const float *c0, float dt, const ApgQuadParams *params,
-    const ApgQuadLossWeights *weights, const ApgLstmPolicy *policy, int B, int H,
-    float *states, float *actions, float *acts, float *gates, unsigned *relu_mask,
-    float *d_conv, float *loss, const ApgLstmPolicyGrads *grads, float *grad_state0,
-    float *grad_h0, float *grad_c0, float *workspace, float *partials,
-    apg_stream_t stream);
-
 /* The AUTOREGRESSIVE training step in one call (round 5; configs[2] per rank):
  * TrainDrone.train_recurrent_model's unroll, loss and loss.backward()
  * (scripts/train_drone.py:113-173) for Net(15, 10, 9, 4, conv=1) - the forward

@@ -226,129 +226,3 @@ def test_ar_step_through_the_c_abi(dev, ar_switch):
     assert loss.item() == 0.0 and all(float(g.abs().max()) == 0.0 for g in grads)
     assert call(B, grads_=None) != 0 and b"gradient" in lib.apg_last_error_string()
     assert call(-1) != 0
-
-
-# ----------------------------------------------------------------- LSTM mode
-@pytest.fixture
-def lstm_switch():
-    from apg_trajectory_tracking_amd import functional as F
-    before = F.LSTM_IN_SWEEP
-    yield lambda on: setattr(F, "LSTM_IN_SWEEP", bool(on))
-    F.LSTM_IN_SWEEP = before
-
-
-def _lstm_case(B, seed, dev):
-    d, inputs = _case(B, seed, dev)
-    gen = torch.Generator().manual_seed(seed + 1)
-    h0 = torch.randn(B, 8, generator=gen)
-    c0 = torch.randn(B, 8, generator=gen)
-    return d, inputs, h0, c0
-
-
-def _lstm_oracle_grads(net, d, h0, c0, dtype):
-    from oracle import torch_port as tp
-    n = copy.deepcopy(net).to(dtype).cpu()
-    n.hidden_state, n.cell_state = h0.to(dtype), c0.to(dtype)
-    _, _, loss = tp.quad_recurrent_unroll(
-        n, tp.QuadOracle(dtype=dtype), d["state0"].to(dtype), d["in_ref"].to(dtype),
-        d["ref"].to(dtype), H, DT)
-    loss.backward()
-    return loss.item(), {k: p.grad.double().numpy() for k, p in n.named_parameters()
-                         if p.grad is not None}
-
-
-@pytest.mark.parametrize("B", [1, 31, 77, 128, 129, 256, 257, 300, 4113, 8195])
-def test_lstm_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, lstm_switch):
-    """apg_quad_lstm_rollout_train_step (csrc/lstm.hip, lstm_rollout_bwd_tm_kernel)
-    against float64 autograd of the reference's LSTM unroll and against the
-    plane + product path; ragged workgroups of both sweeps' block sizes (128 /
-    256 trajectories), more than one chunk of the second stage."""
-    from apg_trajectory_tracking_amd import functional as F
-    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
-        FlightmareDynamics)
-    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
-    torch.manual_seed(8)
-    net = LSTM_NEW(15, H, 9, 4, conv=1)
-    gnet = copy.deepcopy(net).to(dev)
-    d, inputs, h0, c0 = _lstm_case(B, 300 + B, dev)
-    dyn = FlightmareDynamics()
-    res = []
-    for on in (True, False):
-        lstm_switch(on)
-        loss, grads, flat = F.quad_lstm_rollout_grads(
-            gnet, *inputs, DT, dyn.params, h0.to(dev), c0.to(dev))
-        res.append((loss.item(), {k: N(v) for k, v in grads.items()}))
-    loss64, want = _lstm_oracle_grads(net, d, h0, c0, torch.float64)
-    (l1, g1), (l0, g0) = res
-    assert l1 == l0
-    assert abs(l1 - loss64) / abs(loss64) < 1e-5
-    assert set(want) <= set(g1)
-    for k, w in want.items():
-        assert rel_err(g1[k], w) < 1e-4, (k, rel_err(g1[k], w))
-        assert rel_err(g1[k], g0[k]) < 2e-5, (k, rel_err(g1[k], g0[k]))
-
-
-def test_lstm_in_sweep_is_deterministic_and_feeds_autograd(dev, lstm_switch):
-    from apg_trajectory_tracking_amd import functional as F
-    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
-        FlightmareDynamics)
-    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
-    lstm_switch(True)
-    torch.manual_seed(3)
-    net = LSTM_NEW(15, H, 9, 4, conv=1).to(dev)
-    _, inputs, h0, c0 = _lstm_case(9000, 5, dev)
-    h0, c0 = h0.to(dev), c0.to(dev)
-    dyn = FlightmareDynamics()
-    l0, g0, f0 = F.quad_lstm_rollout_grads(net, *inputs, DT, dyn.params, h0, c0)
-    f0 = f0.clone()
-    for _ in range(3):
-        l1, g1, f1 = F.quad_lstm_rollout_grads(net, *inputs, DT, dyn.params, h0, c0)
-        assert torch.equal(f1[:-1], f0[:-1]) and torch.equal(l1, l0)
-    outs = []
-    for on in (True, False):
-        lstm_switch(on)
-        net.zero_grad()
-        s0 = inputs[0].clone().requires_grad_(True)
-        hh, cc = h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
-        loss, states, actions = F.quad_lstm_rollout_loss(
-            net, s0, *inputs[1:], DT, dyn.params, hh, cc)
-        (2.5 * loss).backward()
-        outs.append((s0.grad.clone(), hh.grad.clone(), cc.grad.clone(), states.clone(),
-                     actions.clone(), {k: p.grad.clone() for k, p in net.named_parameters()
-                                       if p.grad is not None}))
-    a, b_ = outs
-    assert torch.equal(a[3], b_[3]) and torch.equal(a[4], b_[4])
-    for i in range(3):
-        assert rel_err(N(a[i]), N(b_[i])) < 1e-6, i
-    assert set(a[5]) == set(b_[5])
-    for k in a[5]:
-        assert torch.allclose(a[5][k], 2.5 * g0[k], rtol=1e-6, atol=0), k
-
-
-def test_lstm_in_sweep_full_size_bits_and_rows(dev, lstm_switch):
-    """BASELINE configs[4], 65 536 trajectories: bit-reproducible, every output
-    row of every parameter gradient as good as float32 autograd's (float64
-    arbitrates)."""
-    from conftest import assert_param_rows_no_worse_than_fp32
-    from apg_trajectory_tracking_amd import functional as F
-    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
-        FlightmareDynamics)
-    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
-    lstm_switch(True)
-    B = 65536
-    torch.manual_seed(5)
-    net = LSTM_NEW(15, H, 9, 4, conv=1)
-    gnet = copy.deepcopy(net).to(dev)
-    d, inputs, h0, c0 = _lstm_case(B, 23, dev)
-    dyn = FlightmareDynamics()
-    hd, cd = h0.to(dev), c0.to(dev)
-    l0, g0, f0 = F.quad_lstm_rollout_grads(gnet, *inputs, DT, dyn.params, hd, cd)
-    f0 = f0.clone()
-    l1, g1, f1 = F.quad_lstm_rollout_grads(gnet, *inputs, DT, dyn.params, hd, cd)
-    assert torch.equal(f1[:-1], f0[:-1]) and torch.equal(l1, l0)
-    _, want = _lstm_oracle_grads(net, d, h0, c0, torch.float64)
-    _, f32 = _lstm_oracle_grads(net, d, h0, c0, torch.float32)
-    got = {k: N(v) for k, v in g1.items()}
-    for k, w in want.items():
-        assert rel_err(got[k], w) < 1e-4, (k, rel_err(got[k], w))
-    assert_param_rows_no_worse_than_fp32(got, f32, want, "LSTM, 65 536")
