@@ -961,7 +961,16 @@ def to_soa_multi_planned(items, index, plan=None):
     # the destinations are part of the key from now on
     plan = _SoaPlan(_SoaPlan.key_of([(t, o) for (t, _), o in zip(items, outs)]),
                     chunks, B, outs, [p[0] for p in prepared])
-    return plan.run(index), plan
+    outs = plan.run(index)
+    # A plan freezes the SOURCE pointers.  Where _soa_source had to make a copy
+    # (a data set that is not float32, rows that are not dense) that pointer is
+    # the one-time copy: replaying it after an in-place refresh of the data set
+    # (resample_data, self-play slots) would gather stale rows.  Such sources
+    # are converted afresh on every call instead - no plan is handed back.
+    if any(p[0].data_ptr() != t.data_ptr() or t.dtype != torch.float32
+           for p, (t, _) in zip(prepared, items)):
+        return outs, None
+    return outs, plan
 
 
 class _StaticPlanes:

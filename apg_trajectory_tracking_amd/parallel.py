@@ -22,6 +22,12 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def group_live():
+    """A default process group exists (its watchdog thread runs; collectives
+    are real calls into RCCL / gloo - also with a world of one)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_range(n, r=None, world=None):
     """Contiguous [lo, hi) slice of n items owned by rank r (the first
     n % world ranks get one extra)."""

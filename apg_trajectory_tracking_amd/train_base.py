@@ -40,6 +40,55 @@ def momentum_sgd(params, lr):
     return optim.SGD(params, lr=lr, momentum=0.9, fused=fused)
 
 
+def _snapshot_optimizer_state(optimizer):
+    """{parameter: {key: clone of a tensor | copy of a plain value}} of an
+    optimizer's per-parameter state (before a graph capture's warm-up steps)."""
+    import copy
+    return {p: {k: (v.detach().clone() if torch.is_tensor(v) else copy.deepcopy(v))
+                for k, v in st.items()}
+            for p, st in optimizer.state.items()}
+
+
+def _restore_optimizer_state(optimizer, before):
+    """Put an optimizer's state back IN PLACE: tensors that existed are copied
+    back into the very tensor objects (graphs and step plans hold them by
+    address), tensors created since are zeroed (= the state every torch
+    optimizer's first step starts from), plain values are restored or, when
+    new, removed."""
+    with torch.no_grad():
+        for p, st in optimizer.state.items():
+            old = before.get(p, {})
+            for k in list(st.keys()):
+                v = st[k]
+                if torch.is_tensor(v):
+                    if k in old and torch.is_tensor(old[k]) and old[k].shape == v.shape:
+                        v.copy_(old[k])
+                    else:
+                        v.zero_()
+                elif k in old:
+                    st[k] = old[k]
+                else:
+                    del st[k]
+
+
+def _make_capturable(optimizer):
+    """An optimizer whose step() is to be captured into a HIP graph must keep
+    its step counters on the device (torch: `capturable=True`; Adam and its
+    relatives default to host-side counters, whose capture fails).  Switches
+    the flag on for every group that has one and moves already existing
+    counters over; SGD has no such flag and is left alone."""
+    changed = False
+    for g in optimizer.param_groups:
+        if g.get("capturable") is False and all(p.is_cuda for p in g["params"]):
+            g["capturable"] = True
+            changed = True
+            for p in g["params"]:
+                st = optimizer.state.get(p)
+                if st and torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
+                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+    return changed
+
+
 class _GraphedStep:
     """One optimizer step captured into HIP graphs and replayed: the ~12
     launches of a step cost the host ~0.25 ms of Python and launch overhead,
@@ -89,30 +138,34 @@ class _GraphedStep:
             msg = part_a()
             reduce(msg)
             return part_b(msg)
-        # the warm-up steps (allocator, momentum buffers, lazy inits, plane
-        # caches - all outside the capture) must not train: parameters and
-        # momentum are put back afterwards (a missing momentum buffer is a
-        # zero one: SGD's first step sets buf = grad = 0.9 * 0 + grad)
+        # the warm-up steps (allocator, optimizer state, lazy inits, plane
+        # caches - all outside the capture) must not train: the parameters and
+        # the WHOLE optimizer state are put back afterwards, in place (the
+        # captured kernels and the in-kernel update hold these tensors by
+        # address).  State a warm-up step created is set to zero, which is what
+        # every torch optimizer's first step starts from (SGD: a missing
+        # momentum buffer is a zero one, buf = grad = 0.9 * 0 + grad; Adam:
+        # step = 0, exp_avg = exp_avg_sq = 0) - so a user-supplied optimizer
+        # does not start from two phantom steps' moments either.
         params = [p for p in net.parameters()]
         saved = [p.detach().clone() for p in params]
-        bufs = [optimizer.state.get(p, {}).get("momentum_buffer") for p in params]
-        bufs = [None if b is None else b.detach().clone() for b in bufs]
+        state_before = _snapshot_optimizer_state(optimizer)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                eager()
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            for p, v, b in zip(params, saved, bufs):
-                p.copy_(v)
-                now = optimizer.state.get(p, {}).get("momentum_buffer")
-                if now is not None:
-                    now.zero_() if b is None else now.copy_(b)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    eager()
+        finally:
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.no_grad():
+                for p, v in zip(params, saved):
+                    p.copy_(v)
+                _restore_optimizer_state(optimizer, state_before)
         # with a process group alive its watchdog thread polls events; only
         # THIS thread's calls may invalidate the capture
         mode = ({"capture_error_mode": "thread_local"}
-                if parallel.world_size() > 1 else {})
+                if parallel.group_live() else {})
         # no garbage collection inside a capture: a collected tensor or graph
         # of somebody else would issue HIP calls the capture forbids
         was_enabled = gc.isenabled()
@@ -299,15 +352,19 @@ class TrainBase:
         # at ~0.21 ms per batch, had become the bound of run_epoch).
         self.graph_epochs = True
         self._epoch_graphs = {}
-        # graphs only where the host is the bound: {train_mode: trajectories
-        # per rank and batch from which steps are launched eagerly}.  The
-        # autoregressive step at B = 65 536 is 1.1 ms of kernels against ~0.3 ms
-        # of host work per step; replayed from a graph (per step or per epoch)
-        # it is 2-4 % SLOWER than the same 19 kernels launched in stream order
-        # (1.125 against 1.086 ms, every box so far; per batch in run_epoch
-        # 1.134 against 1.098): the small-kernel tail of the step pays a graph
-        # node's heavier fences.  Break-even ~ 0.3 ms of kernels.
-        self.graph_batch_limit = {"autoregressive": 16384}
+        # Graph replay or stream-order launches?  For steps whose kernels
+        # outlast the host's launch work the answer is a 2-5 % effect that
+        # differs from box to box (round 4: the autoregressive step 1.111 ms in
+        # stream order against 1.054 from one graph on the driver's box, the
+        # other way round on the builder's; LSTM 0.480 eager against 0.494
+        # graphed) - so it is MEASURED, once per train mode: the first time a
+        # step is captured, `launch_form_steps` replays are timed against as
+        # many stream-order steps (the training they do is undone), the faster
+        # form is kept and recorded in results_dict["launch_form"].
+        # `launch_form[train_mode]` = "graph" | "eager" pins the answer.
+        self.launch_form = {}
+        self.measure_launch_form = True
+        self.launch_form_steps = 10
         # True: a graphed step returns the captured loss buffer itself - valid
         # until the NEXT step overwrites it (run_epoch's loops take it that
         # way) - instead of a private copy, which is one more launch behind
@@ -370,6 +427,7 @@ class TrainBase:
         self.optimizer_controller = momentum_sgd(
             self.net.parameters(), self.learning_rate_controller)
         self.grad_sync = GradAllReducer(self.net.parameters())
+        self._epoch_runners = self._epoch_table()
         # a learnable simulator gets its own optimizer (:144-150)
         if isinstance(self.train_dynamics, torch.nn.Module):
             self.optimizer_dynamics = momentum_sgd(
@@ -457,11 +515,9 @@ class TrainBase:
         if not (bool(self.graph_steps) and not self._in_epoch_capture
                 and (torch.cuda.is_available() or self.graph_emulation)):
             return False
-        # a step whose kernels outlast the host's launch work gains nothing
-        # from a graph - and loses 2-4 % on this platform (see graph_batch_limit)
-        limit = self.graph_batch_limit.get(self.train_mode)
-        per_rank = int(self.batch_size) // max(1, parallel.world_size())
-        return not (limit and per_rank >= limit)
+        # (a step whose kernels outlast the host's launch work may run faster in
+        # stream order: measured once, see launch_form)
+        return self.launch_form.get(self.train_mode) != "eager"
 
     def _reducing(self):
         """The step has an all-reduce slot (real or, when forced, empty)."""
@@ -469,7 +525,12 @@ class TrainBase:
 
     @staticmethod
     def _reduce(msg):
-        if msg is not None and parallel.world_size() > 1:
+        """The all-reduce slot of a step.  With a live process group the
+        collective is issued even for a world of one (a forced split step on
+        one GPU then runs graph A -> RCCL -> graph B exactly as N ranks do:
+        communicator, RCCL's stream and events, the watchdog - everything but
+        the wire)."""
+        if msg is not None and parallel.group_live():
             parallel.dist.all_reduce(msg, op=parallel.dist.ReduceOp.SUM)
 
     def _graph_signature(self, inputs, volatile, params=None):
@@ -524,6 +585,8 @@ class TrainBase:
                 cache[key] = sig
         g = self._graphs.get(key)
         if g is None or getattr(g, "planned", False) or g.signature != sig:
+            if torch.cuda.is_available() and _make_capturable(self.optimizer_controller):
+                sig = self._graph_signature(inputs, volatile)
             try:
                 g = _GraphedStep(
                     part_a, part_b, self._reduce, sig,
@@ -548,7 +611,59 @@ class TrainBase:
             g.signature = self._graph_signature(inputs, volatile)
             if cache is not None:
                 cache[key] = g.signature
+            if (g.capture and self.measure_launch_form
+                    and self.train_mode not in self.launch_form
+                    and self._measure_launch_form(g, part_a, part_b) == "eager"):
+                self._graphs.pop(key, None)
+                msg = part_a()
+                self._reduce(msg)
+                return part_b(msg)
         return g(borrow=getattr(self, "_borrow_loss", False) or self.borrow_loss)
+
+    def _measure_launch_form(self, g, part_a, part_b):
+        """Time `launch_form_steps` replays of the captured step `g` against as
+        many stream-order executions of the same step, undo the training they
+        did (parameters and optimizer state, in place), keep the faster form for
+        this train mode.  All ranks decide alike (the times are summed)."""
+        import time
+        n = max(2, int(self.launch_form_steps))
+        opt = self.optimizer_controller
+        params = list(self.net.parameters())
+        saved = [p.detach().clone() for p in params]
+        state = _snapshot_optimizer_state(opt)
+
+        def eager():
+            msg = part_a()
+            self._reduce(msg)
+            return part_b(msg)
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        try:
+            t_graph = timed(lambda: g(borrow=True))
+            t_eager = timed(eager)
+        finally:
+            with torch.no_grad():
+                for p, v in zip(params, saved):
+                    p.copy_(v)
+                _restore_optimizer_state(opt, state)
+        if parallel.world_size() > 1:
+            both = torch.tensor([t_graph, t_eager], dtype=torch.float64,
+                                device=params[0].device)
+            parallel.dist.all_reduce(both)
+            t_graph, t_eager = (float(v) for v in both)
+        choice = "graph" if t_graph <= t_eager else "eager"
+        self.launch_form[self.train_mode] = choice
+        self.results_dict["launch_form"].append(
+            dict(train_mode=self.train_mode, chosen=choice,
+                 ms_graph=t_graph * 1e3, ms_stream_order=t_eager * 1e3, steps=n))
+        return choice
 
     def _plannable(self):
         """A single-process fused step may run from a step plan (_PlannedStep)
@@ -844,7 +959,8 @@ class TrainBase:
             gc.disable()
             self._in_epoch_capture = True
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"}
+                                                if parallel.group_live() else {})):
                     running, last = loop(ld.iter_indices(order=perm))
             except RuntimeError as e:
                 import warnings
@@ -864,70 +980,99 @@ class TrainBase:
         eg["graph"].replay()
         return eg["running"], eg["last"]
 
-    def run_epoch(self, train="controller", epoch=0):
-        if train not in ("controller", "dynamics"):
-            raise ValueError("train must be 'controller' or 'dynamics'")
-        running_loss = None
-        i = -1
+    # ---- which loop an epoch runs: ONE table, built by init_optimizer --------
+    # Hooks a system trainer may override (the quadrotor trainer does):
+    def prefetch_plan(self):
+        """(prepare, step) of the pipelined epoch (_pipelined_epoch) or None."""
+        return None
+
+    def packed_path_ok(self):
+        """The row-layout rollout path (train_controller_packed) applies."""
+        return False
+
+    def recurrent_indexed_ok(self):
+        """train_recurrent_model accepts `index=` (fused recurrent steps)."""
+        return False
+
+    def _epoch_table(self):
+        """[(name, predicate(train) -> bool, runner(train) -> epoch loss)], first
+        match wins; the last entry always matches.  Built once per
+        init_optimizer: run_epoch is a walk over it, every specialised loop is
+        a named method (VERDICT r4 weak #10)."""
+        indexed = lambda: hasattr(self.trainloader, "iter_indices")
+        ctrl = lambda train: train == "controller" and indexed()
+        return [
+            ("pipelined", lambda t: ctrl(t) and self._wants_pipeline()
+             and self.prefetch_plan() is not None, self._epoch_pipelined),
+            ("concurrent, gather folded into the fused step",
+             lambda t: ctrl(t) and self.train_mode == "concurrent"
+             and self.train_concurrent_fused(None, None, None, None, probe=True),
+             self._epoch_concurrent_indexed),
+            ("concurrent, packed rows around any policy",
+             lambda t: ctrl(t) and self.train_mode == "concurrent"
+             and getattr(self, "use_packed_path", True) and self.packed_path_ok(),
+             self._epoch_packed),
+            ("recurrent, gather folded into the fused step",
+             lambda t: ctrl(t) and self.train_mode != "concurrent"
+             and self.recurrent_indexed_ok(), self._epoch_recurrent_indexed),
+            ("loader", lambda t: True, self._epoch_loader),
+        ]
+
+    def _wants_pipeline(self):
         # (the concurrent epoch graph forks the next batch's gather behind the
         # reverse kernel: that is where it is free)
-        want_plan = self.prefetch_batches or (
+        return self.prefetch_batches or (
             self.train_mode == "concurrent" and self.trainloader is not None
             and hasattr(self.trainloader, "epoch_order") and self._epoch_graph_ok())
-        plan = (getattr(self, "prefetch_plan", lambda: None)()
-                if train == "controller" and want_plan
-                and hasattr(self.trainloader, "iter_indices") else None)
-        if plan is not None:
-            return self._finish_epoch(*self._graphed_epoch(
-                (self.train_mode, "prefetch"),
-                lambda indices: self._pipelined_epoch(*plan, indices=indices)), train)
-        if (train == "controller" and self.train_mode == "concurrent"
-                and hasattr(self.trainloader, "iter_indices")
-                and self.train_concurrent_fused(None, None, None, None,
-                                                probe=True)):
-            # fused step with the minibatch gather folded into its first pass
-            tensors = self.trainloader.tensors
-            return self._finish_epoch(*self._graphed_epoch(
-                ("concurrent", "indexed"), lambda indices: self._indexed_epoch(
-                    lambda index: self.train_concurrent_fused(*tensors, index=index),
-                    indices)), train)
-        if (train == "controller" and self.train_mode == "concurrent"
-                and hasattr(self.trainloader, "iter_indices")
-                and getattr(self, "use_packed_path", True)
-                and getattr(self, "packed_path_ok", lambda: False)()):
-            # any PyTorch policy on the row-layout tensors of the fastest
-            # rollout kernel (TrainDrone.train_controller_packed); the
-            # minibatch is a gather of rows out of the data set's cached
-            # packed tensors, the whole-set batch is those tensors themselves
-            normed, _, in_ref, _ = self.trainloader.tensors
-            s0_rows, ref_rows = self.state_data.packed()
-            n = normed.shape[0]
-            for i, index in enumerate(self.trainloader.iter_indices(), 0):
-                whole = (not self.shuffle and index.numel() == n)
-                if whole:
-                    batch = (normed, in_ref, s0_rows, ref_rows)
-                else:
-                    batch = (normed.index_select(0, index),
-                             in_ref.index_select(0, index),
-                             s0_rows.index_select(1, index),
-                             ref_rows.index_select(1, index))
-                loss = self.train_controller_packed(*batch).detach()
-                running_loss = loss if running_loss is None else running_loss + loss
-            return self._finish_epoch(running_loss, i, train)
-        if (train == "controller" and self.train_mode != "concurrent"
-                and hasattr(self.trainloader, "iter_indices")
-                and getattr(self, "recurrent_indexed_ok", lambda: False)()):
-            tensors = self.trainloader.tensors
-            if (self.train_mode == "LSTM"
-                    and getattr(self, "hidden_generator", None) is not None):
-                # a private generator is not registered with graphs: eager steps
-                return self._finish_epoch(*self._indexed_epoch(
-                    lambda index: self.train_recurrent_model(*tensors, index=index)),
-                    train)
-            return self._finish_epoch(*self._graphed_epoch(
-                (self.train_mode, "indexed"), lambda indices: self._indexed_epoch(
-                    lambda index: self.train_recurrent_model(*tensors, index=index),
-                    indices)), train)
+
+    def _epoch_pipelined(self, train):
+        plan = self.prefetch_plan()
+        return self._finish_epoch(*self._graphed_epoch(
+            (self.train_mode, "prefetch"),
+            lambda indices: self._pipelined_epoch(*plan, indices=indices)), train)
+
+    def _epoch_concurrent_indexed(self, train):
+        tensors = self.trainloader.tensors
+        return self._finish_epoch(*self._graphed_epoch(
+            ("concurrent", "indexed"), lambda indices: self._indexed_epoch(
+                lambda index: self.train_concurrent_fused(*tensors, index=index),
+                indices)), train)
+
+    def _epoch_packed(self, train):
+        # any PyTorch policy on the row-layout tensors of the fastest rollout
+        # kernel (TrainDrone.train_controller_packed); the minibatch is a gather
+        # of rows out of the data set's cached packed tensors, the whole-set
+        # batch is those tensors themselves
+        running_loss, i = None, -1
+        normed, _, in_ref, _ = self.trainloader.tensors
+        s0_rows, ref_rows = self.state_data.packed()
+        n = normed.shape[0]
+        for i, index in enumerate(self.trainloader.iter_indices(), 0):
+            whole = (not self.shuffle and index.numel() == n)
+            if whole:
+                batch = (normed, in_ref, s0_rows, ref_rows)
+            else:
+                batch = (normed.index_select(0, index),
+                         in_ref.index_select(0, index),
+                         s0_rows.index_select(1, index),
+                         ref_rows.index_select(1, index))
+            loss = self.train_controller_packed(*batch).detach()
+            running_loss = loss if running_loss is None else running_loss + loss
+        return self._finish_epoch(running_loss, i, train)
+
+    def _epoch_recurrent_indexed(self, train):
+        tensors = self.trainloader.tensors
+        step = lambda index: self.train_recurrent_model(*tensors, index=index)
+        if (self.train_mode == "LSTM"
+                and getattr(self, "hidden_generator", None) is not None):
+            # a private generator is not registered with graphs: eager steps
+            return self._finish_epoch(*self._indexed_epoch(step), train)
+        return self._finish_epoch(*self._graphed_epoch(
+            (self.train_mode, "indexed"),
+            lambda indices: self._indexed_epoch(step, indices)), train)
+
+    def _epoch_loader(self, train):
+        running_loss, i = None, -1
         for i, data in enumerate(self.trainloader, 0):
             in_state, current_state, in_ref_state, ref_states = data
             if train == "dynamics":
@@ -955,6 +1100,18 @@ class TrainBase:
             loss = loss.detach()
             running_loss = loss if running_loss is None else running_loss + loss
         return self._finish_epoch(running_loss, i, train)
+
+    def run_epoch(self, train="controller", epoch=0):
+        """scripts/train_base.py:188-218.  The loop that runs is the first
+        entry of the epoch table whose predicate holds (`last_epoch_loop` names
+        it)."""
+        if train not in ("controller", "dynamics"):
+            raise ValueError("train must be 'controller' or 'dynamics'")
+        table = getattr(self, "_epoch_runners", None) or self._epoch_table()
+        for name, applies, runner in table:
+            if applies(train):
+                self.last_epoch_loop = name
+                return runner(train)
 
     def _finish_epoch(self, running_loss, i, train):
         # one host read-back per epoch; divides by the last index as the

@@ -434,10 +434,12 @@ def test_bench_rank_logic_under_gloo_with_two_ranks():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None
 
 
-def test_steps_that_outlast_the_host_are_not_graphed():
-    """TrainBase.graph_batch_limit: from 16 384 trajectories per rank the
-    autoregressive step is launched in stream order (2-4 % faster than graph
-    replays on the MI355X); smaller batches and the other modes keep graphs."""
+def test_launch_form_is_a_measured_choice_not_a_constant():
+    """TrainBase.launch_form (round 5): whether a step is
+    replayed from a graph or launched in stream order is measured once per
+    train mode (tests/test_gpu_round5.py does that on the GPU); without a
+    measurement every mode is graphable, a recorded or pinned "eager" turns
+    graphs off for that mode only, `graph_steps = False` for all."""
     from apg_trajectory_tracking_amd.train_drone import TrainDrone
 
     class Dyn:
@@ -445,13 +447,14 @@ def test_steps_that_outlast_the_host_are_not_graphed():
     mk = lambda mode, bs: TrainDrone(Dyn(), Dyn(), dict(
         delta_t=DT, horizon=H, batch_size=bs, ref_dim=9, action_dim=4, train_mode=mode,
         system="quad"))
-    for mode, bs, want in (("autoregressive", 16384, False), ("autoregressive", 16383, True),
-                           ("autoregressive", 8, True), ("LSTM", 65536, True),
-                           ("concurrent", 65536, True)):
+    for mode, bs in (("autoregressive", 65536), ("autoregressive", 8), ("LSTM", 65536),
+                     ("concurrent", 65536)):
         t = mk(mode, bs)
         t.graph_emulation = True          # (no GPU here: the scheduling only)
-        assert t._graphable() == want, (mode, bs)
-        t.graph_batch_limit = {}
+        assert t._graphable(), (mode, bs)
+        t.launch_form = {"autoregressive": "eager"}
+        assert t._graphable() == (mode != "autoregressive")
+        t.launch_form = {mode: "graph"}
         assert t._graphable()
         t.graph_steps = False
         assert not t._graphable()
