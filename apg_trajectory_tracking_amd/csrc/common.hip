@@ -129,6 +129,40 @@ __global__ __launch_bounds__(256) void to_soa_kernel(SoaArgs A) {
 
 }  // namespace apg
 
+// The same bytes through other launch shapes (bench.py reports all of them next
+// to apg_stream_copy: VERDICT r4 weak #9 - is the probe or the box what stands
+// between 4.9 and the guide's 6.29 TB/s?).
+//   1  one 16-byte element per thread, the whole array as the grid, plain stores
+//   2  grid capped at 8 blocks per CU, four elements in flight per thread
+//   3  as 2 with non-temporal 16-byte stores
+//   4  as 1 with 1 024-thread blocks
+typedef float f32x4_copy __attribute__((ext_vector_type(4)));
+static __global__ __launch_bounds__(1024) void copy_flat_kernel(
+    const f32x4_copy *__restrict__ src, f32x4_copy *__restrict__ dst, long long n16) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+template <bool NT>
+static __global__ __launch_bounds__(256) void copy_unroll4_kernel(
+    const f32x4_copy *__restrict__ src, f32x4_copy *__restrict__ dst, long long n16) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const f32x4_copy a = src[i], b = src[i + stride], c = src[i + 2 * stride],
+                     d = src[i + 3 * stride];
+    if (NT) {
+      __builtin_nontemporal_store(a, dst + i);
+      __builtin_nontemporal_store(b, dst + i + stride);
+      __builtin_nontemporal_store(c, dst + i + 2 * stride);
+      __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    } else {
+      dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+    }
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+
 extern "C" {
 
 int apg_to_soa_multi(const ApgSoaItem *items, int n, int B, apg_stream_t stream) {
@@ -186,6 +220,41 @@ static __global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__
     __builtin_nontemporal_store(v.z, &dst[i].z);
     __builtin_nontemporal_store(v.w, &dst[i].w);
   }
+}
+
+int apg_stream_copy_shape(const void *src, void *dst, long long bytes, int shape,
+                          apg_stream_t stream) {
+  if (shape == 0) return apg_stream_copy(src, dst, bytes, stream);
+  if (!src || !dst || bytes < 0 || (bytes & 15) || ((size_t)src & 15) || ((size_t)dst & 15)) {
+    apg::set_error("apg_stream_copy_shape: 16-byte aligned pointers and size expected");
+    return APG_ERR_ARG;
+  }
+  if (shape < 1 || shape > 4) {
+    apg::set_error("apg_stream_copy_shape: shape 0..4");
+    return APG_ERR_ARG;
+  }
+  if (bytes == 0) return APG_OK;
+  const long long n16 = bytes / 16;
+  hipStream_t st = (hipStream_t)stream;
+  const f32x4_copy *s_ = (const f32x4_copy *)src;
+  f32x4_copy *d_ = (f32x4_copy *)dst;
+  if (shape == 1 || shape == 4) {
+    const int block = shape == 1 ? 256 : 1024;
+    const long long blocks = (n16 + block - 1) / block;
+    if (blocks > 0x7fffffffll) { apg::set_error("too large"); return APG_ERR_ARG; }
+    hipLaunchKernelGGL(copy_flat_kernel, dim3((unsigned)blocks), dim3(block), 0, st, s_, d_, n16);
+  } else {
+    long long blocks = (n16 + 255) / 256;
+    const long long cap = (long long)apg::device_cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    if (shape == 2)
+      hipLaunchKernelGGL(copy_unroll4_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st,
+                         s_, d_, n16);
+    else
+      hipLaunchKernelGGL(copy_unroll4_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st,
+                         s_, d_, n16);
+  }
+  return apg::check_launch("stream_copy_shape");
 }
 
 int apg_stream_copy(const void *src, void *dst, long long bytes, apg_stream_t stream) {

@@ -2418,7 +2418,8 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
 // the loss partials of the forward kernel.
 // destination of element (slot, reg i, lane) - or NULL (padding)
 __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, int i, int lane,
-                                          int bias_slot, int head_rows = kNA) {
+                                          int bias_slot, int head_rows = kNA,
+                                          bool conv_bias_here = false) {
   const int rowb = rrow(i) + 4 * (lane >> 5), col = lane & 31;
   if (slot < sFc1) {                       // head, fc3, fc2: [cb][mb]
     const int q = slot & 3, cb = q >> 1, m = 32 * (q & 1) + rowb, k = 32 * cb + col;
@@ -2436,13 +2437,14 @@ __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, 
   if (slot < bias_slot) {                  // conv, position slot - sConv: only slot
     if (slot != sConv || rowb >= kNC) return nullptr;   // sConv collects all of them
     if (col < 27) return g.conv_w + rowb * 27 + (col % kRD) * 3 + col / kRD;
-    return col == 27 ? g.conv_b + rowb : nullptr;
+    return col == 27 && !conv_bias_here ? g.conv_b + rowb : nullptr;
   }
   // bias slot(s): [layer][64]; the trajectory-major kernels' per-wave sums are
   // further sources of the same elements (bias_src in the reduce kernel)
   const int e = i * 64 + lane;
   if (slot != bias_slot || e >= 4 * 64) return nullptr;
   const int layer = e >> 6, m = e & 63;
+  if (layer == 0 && conv_bias_here && m >= 32 && m < 32 + kNC) return g.conv_b + (m - 32);
   return layer == 0 ? (m < head_rows ? g.b_out + m : nullptr)
          : layer == 1 ? g.b_3 + m : layer == 2 ? g.b_2 + m : g.b_1 + m;
 }
@@ -2474,6 +2476,7 @@ struct WgReduceArgs {
   int bias_src;        // per-wave bias sums behind the bias slot's first 256 floats
                        // (every 256 floats, across slot boundaries): 8, or 1
   int head_rows;       // rows of fc_out (40: concurrent mode, 4: autoregressive)
+  bool conv_bias_here; // the conv bias sits in the bias slot (layer 0, entries 32..51)
   const float *loss_partials;
   float *loss;
   int wgs, n_partials;   // wgs: how many [kSlots * 1024] rows `part` has
@@ -2501,7 +2504,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
   const size_t stride = (size_t)A.n_slots * 1024;
   if (t < A.n_slots * 1024) {
     const int slot = t >> 10, i = (t >> 6) & 15, lane = t & 63;
-    float *dst = wg_dest(A.g, slot, i, lane, A.bias_slot, A.head_rows);
+    float *dst = wg_dest(A.g, slot, i, lane, A.bias_slot, A.head_rows, A.conv_bias_here);
     if (dst) {
       const bool is_bias = slot == A.bias_slot;
       // the conv position blocks (1024 floats apart) / the waves' bias sums (256)
@@ -2524,8 +2527,8 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
       }
       *dst = s;
       if (A.update) {   // torch.optim.SGD: buf = momentum buf + grad, p -= lr buf
-        float *pp = wg_dest(A.param, slot, i, lane, A.bias_slot, A.head_rows),
-              *pm = wg_dest(A.mom, slot, i, lane, A.bias_slot, A.head_rows);
+        float *pp = wg_dest(A.param, slot, i, lane, A.bias_slot, A.head_rows, A.conv_bias_here),
+              *pm = wg_dest(A.mom, slot, i, lane, A.bias_slot, A.head_rows, A.conv_bias_here);
         // (in double with one rounding each, as torch's fused SGD kernel does
         // it: a trainer that steps through optimizer.step() - the multi-rank
         // form - gets the same bits)
@@ -2597,10 +2600,10 @@ constexpr int a1c = 0, aS = 20, aH = 24, a3 = 26, a2 = 34, a1s = 42, aBlocks = 5
 constexpr int kArTabBytes = gA + aBlocks * kBlock16;   // 104 448
 constexpr int kArTabFloats = kArTabBytes / 4;
 // LDS behind the tables: two alternating accumulator regions of six blocks, the
-// conv block, bias sums [4][64], the head block [4][64], meta
+// conv block, the head block [4][64], meta
 constexpr int kArRegion = 6 * 4096;
 constexpr int rX = kArTabBytes, rY = rX + kArRegion, rConv = rY + kArRegion,
-              rBias = rConv + 4096, rHead = rBias + 1024, rMeta = rHead + 1024;
+              rHead = rConv + 4096, rMeta = rHead + 1024;
 static_assert((rMeta - rX) % 16 == 0, "zeroed in 16-byte pieces");
 
 __device__ __forceinline__ float car_weight(const ApgMlpPolicy &p, int n, int row, int j,
@@ -2751,13 +2754,20 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
     am = wave_umax(am);
     if (lane == 0) meta.dmax[phase][wave] = am;
   };
-  // bias gradient of 32 rows: sums over the lane's 16 trajectories, both halves
-  const auto add_bias = [&](const float (&v)[16], int e, int layer, int mb) {
+  // Bias gradients: a float per WAVE and row (sum over the wave's 32
+  // trajectories), added straight into this wave's own entries of the two bias
+  // slots ([4 waves][4 layers][64] each; layer 0 = fc_out's 4 rows, its entries
+  // 32..51 the conv bias) - one writer per address, the steps in order; the
+  // second stage sums the eight waves in order.  No fixed-point unit involved.
+  const unsigned bias_soff = (unsigned)(uBias + (wave >> 2)) * 4096u + (unsigned)(wave & 3) * 1024u;
+  const auto add_bias = [&](const float (&v)[16], int layer, int mb) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += __builtin_amdgcn_ldexpf(v[i], kFix - e);
+    for (int i = 0; i < 16; ++i) s += v[i];
     s += other_half(s);
-    if (hi == 0) lds_add(lds + rBias + (layer * 64 + 32 * mb + row) * 4, s);
+    if (hi == 0)
+      gadd(part, (unsigned)(layer * 64 + 32 * mb + row) * 4u, bias_soff,
+           bad ? __builtin_nanf("") : s);
   };
   // the deferred blocks of a step: fc1's last four (conv columns 96..159) and
   // the conv block
@@ -2900,10 +2910,12 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         tz[i] = tzv[i];
-        sb += __builtin_amdgcn_ldexpf(tz[i], kFix - kPreD);
+        sb += tz[i];
       }
       sb += other_half(sb);
-      if (hi == 0 && row < 4) lds_add(lds + rBias + row * 4, sb);
+      if (hi == 0 && row < 4)
+        gadd(part, (unsigned)row * 4u, bias_soff,
+             bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf(sb, e0 - kPreD));
       Op16 az[2];
       split16(tz, 0, az);
 #pragma unroll
@@ -2942,7 +2954,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
       Op16 ad[2][2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        add_bias(dT[mb], e_, bias_id, mb);
+        add_bias(dT[mb], bias_id, mb);
         split16(dT[mb], e_ - kPreD, ad[mb]);
       }
 #pragma unroll
@@ -2999,9 +3011,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
            (sOut + 2 * ((idx >> 5) & 1)) * 4096,
            bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)q, e0 - kFix));
     }
-    flush_add<64>(lds, rBias, part, uBias * 4096, e0, bad);
     flush_add<4 * 1024>(lds, rg, part, sFc3 * 4096, e3, bad);
-    flush_add<64>(lds, rBias + 256, part, uBias * 4096 + 256, e3, bad);
     { const int r_ = rg; rg = ro, ro = r_; }
 
     // ------------------------------------------------ phase 2: fc2 (x = h1)
@@ -3009,7 +3019,6 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
     layer64(e, d, e2, a2, Ph, 0, Px1, 0, 2, 2, lane_blk + rg);   // -> d_pre1
     ar_barrier();
     flush_add<4 * 1024>(lds, rg, part, sFc2 * 4096, e2, bad);
-    flush_add<64>(lds, rBias + 512, part, uBias * 4096 + 512, e2, bad);
     { const int r_ = rg; rg = ro, ro = r_; }
 
     // ------------- phase 3: fc1 against s1 (x1 planes 0..63), states_in; the
@@ -3021,7 +3030,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
     Op16 ad[2][2];  // d_pre1^T with the workgroup's scale: all of fc1's weight blocks
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      add_bias(dT[mb], e1, 3, mb);
+      add_bias(dT[mb], 3, mb);
       split16(dT[mb], e1 - kPreD, ad[mb]);
     }
     // fc1's weight blocks of x block `xv` (scaled by 2^-fx), both row blocks
@@ -3179,7 +3188,6 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
       gadd(part, (unsigned)at * 4u, (sSin + nb) * 4096,
            bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)v, es + ff - kFix));
     }
-    flush_add<64>(lds, rBias + 768, part, uBias * 4096 + 768, e1, bad);
     { const int r_ = rg; rg = ro, ro = r_; }
 
     // ------- phases 4, 5: fc1 against the conv outputs (five blocks of 32 x1
@@ -3253,9 +3261,22 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
       // channel ch = register (ch & 3) + 4 (ch >> 3) of half-wave (ch >> 2) & 1)
       char *cblk = lds + rConv + ((4 * (eb >> 1)) * 64 + 32 * (eb & 1)) * 4;
       sum += other_half(sum);
-      // bias: column 27; the block's unit carries the windows' scale 2^fi as well
-      if (hi_e == 0)
-        lds_add(cblk + ((row_e >> 3) * 64 + 27) * 4, __builtin_amdgcn_ldexpf(sum, kFixConv - fi));
+      // conv bias: the eight positions of a channel are eight neighbouring lanes
+      // (DPP row shifts inside the group), then as the other biases - not a
+      // column of the conv block, whose unit carries the windows' scale 2^fi
+      // (single limb: with windows of 3e4 m the bias kept 4 bits there)
+      sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+          0, __builtin_bit_cast(int, sum), 0x111 /* row_shr:1 */, 0xf, 0xf, true)) *
+             ((row_e & 7) >= 1 ? 1.f : 0.f);
+      sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+          0, __builtin_bit_cast(int, sum), 0x112 /* row_shr:2 */, 0xf, 0xf, true)) *
+             ((row_e & 7) >= 2 ? 1.f : 0.f);
+      sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+          0, __builtin_bit_cast(int, sum), 0x114 /* row_shr:4 */, 0xf, 0xf, true)) *
+             ((row_e & 7) >= 4 ? 1.f : 0.f);
+      if (hi_e == 0 && (row_e & 7) == 7)   // the group's last lane holds the channel's sum
+        gadd(part, (unsigned)(32 + 4 * eb + (row_e >> 3)) * 4u, bias_soff,
+             bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf(sum, ec));
       Op16 ac[2];
       split16(v, -kPreDc, ac);
 #pragma unroll
@@ -3695,7 +3716,7 @@ int apg_quad_mlp_concurrent_train_step(
   R.n_slots = tm ? kSlotsTm : kSlots, R.bias_slot = tm ? uBias : sBias;
   R.conv_src = tm ? 1 : kNP;
   R.bias_src = tm ? 8 : 1;
-  R.head_rows = kNA;
+  R.head_rows = kNA, R.conv_bias_here = false;
   const int columns = (R.n_slots * 1024 + 255) / 256;
   R.update = update != nullptr;
   R.param = update ? update->param : *grads, R.mom = update ? update->momentum_buf : *grads;
@@ -3806,7 +3827,8 @@ int apg_quad_mlp_rollout_train_step(
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
-  R.n_slots = kSlotsTm, R.bias_slot = uBias, R.conv_src = 1, R.bias_src = 1, R.head_rows = 4;
+  R.n_slots = kSlotsTm, R.bias_slot = uBias, R.conv_src = 1, R.bias_src = 8, R.head_rows = 4;
+  R.conv_bias_here = true;
   const int columns = (R.n_slots * 1024 + 255) / 256;
   R.update = update != nullptr;
   R.param = update ? update->param : *grads, R.mom = update ? update->momentum_buf : *grads;

@@ -276,13 +276,23 @@ STEP_MODELS = {
                        bytes_per_step=0,
                        # features 60 + state0 48 + in_ref H*36 + ref H*36
                        algo_bytes_per_traj=60 + 48 + 360 + 360),
-    "autoregressive": dict(mfma_once=0, mfma_per_step=198 + 144,
-                           # fwd 436 planes + states/actions written, reverse
-                           # reads 1 153 B and writes 260 planes per env-step +
-                           # 720 planes per trajectory, products read the 431
-                           # activation + 260 cotangent planes once
-                           bytes_per_step=1808 + 1153 + 1040 + (431 + 260) * 4,
-                           bytes_per_traj=2880 * 2 + 48 + 20 * 72,
+    # round 5: weight gradients inside the reverse sweep
+    # (mlp_rollout_bwd_tm_kernel).  Forward 198; reverse 571 per wave and step:
+    # h3 transposes 8, head 2 + 6 + 6, fc3 / fc2 24 + 24 + 24 + 8 + 2 each (weight
+    # blocks, transposed product, chain, tanh' transposes, exponents), fc1 on
+    # s1 24 + 24 + 24 + 8 + 2 + states_in 12 + 12, the feature-major conv
+    # cotangent 60, five conv blocks of 12 + 12 + 1 + 18.  (Rounds 3-4: 198 +
+    # 144 + the nine plane products.)
+    "autoregressive": dict(mfma_once=0, mfma_per_step=198 + 571, products_in_sweep=True,
+                           # fwd writes 436 planes + states / actions (1 808 B per
+                           # env-step); the reverse sweep reads the 431
+                           # activation planes trajectory-major + masks, states,
+                           # actions, reference (1 844); the per-workgroup
+                           # accumulators (120 KB x 10 read-modify-writes) stay
+                           # in the caches; once per trajectory: state0, in_ref
+                           # by both sweeps, windows for the conv block
+                           bytes_per_step=1808 + 1844,
+                           bytes_per_traj=48 + 2 * 20 * 36 + 10 * 36 * 2,
                            # state0 48 + in_ref 2H*36 + ref H*36
                            algo_bytes_per_traj=48 + 720 + 360),
     "LSTM": dict(mfma_once=0, mfma_per_step=90 + 42,
@@ -363,6 +373,12 @@ def timed_steps(step, n, dist):
     return sorted(chunks)[(len(chunks) - 1) // 2], out, chunks
 
 
+def chunk_stats(chunks):
+    """mean and max next to the median chunk (an outlier
+    chunk - a host or driver stall - is visible, not dropped)."""
+    return {"ms_per_step_mean": sum(chunks) / len(chunks), "ms_per_step_max": max(chunks)}
+
+
 def trainer_step_probe(args, dev, dyn, dist, mode):
     """One training step per rank through the REAL trainer method
     (TrainDrone): policy inside the fused kernels (matrix cores), weight-
@@ -431,6 +447,7 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
     n_params = sum(p.numel() for p in t.net.parameters() if p.requires_grad)
     out = {
         "ms_per_step": ms,
+        **chunk_stats(chunks),
         "ms_per_step_chunks": chunks,   # four timed chunks; ms_per_step = their median
         "env_steps_per_s": world * B * H / (ms * 1e-3),
         "batch_per_gpu": B, "global_batch": world * B,
@@ -446,8 +463,11 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
         # once, one library call = five launches per step, no capture)
         out["launch"] = "step plan: one library call per step, no graph"
     elif not t._graphs:
-        # (TrainBase.graph_batch_limit: kernels outlast the host's launch work)
-        out["launch"] = "kernels launched in stream order (no graph at this batch size)"
+        # (TrainBase.launch_form: measured at the first capture of the mode)
+        out["launch"] = "kernels launched in stream order (measured faster than graph replays)"
+    # graph replay or stream order: measured by the trainer at its first capture
+    # of this mode (TrainBase._measure_launch_form), not a constant
+    out["launch_form"] = [dict(r) for r in t.results_dict.get("launch_form", [])]
     if mode == "concurrent":
         # one process: the optimizer's update is applied by the second stage of
         # the step itself (apg_quad_mlp_concurrent_train_step); the split form
@@ -464,25 +484,31 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
     out["ms_per_step_private_loss"], _, _ = timed_steps(
         step, max(8, args.train_steps // 2), dist)
     t.borrow_loss = True
+    chosen = dict(t.launch_form)
+    t.measure_launch_form = False
     if world == 1 and not default_graph:
         # the same step replayed from ONE captured graph (rounds 3-4's form)
-        limits, t.graph_batch_limit, t.plan_steps = t.graph_batch_limit, {}, False
+        t.launch_form, t.plan_steps = {tmode: "graph"}, False
         t._graphs.clear()
         out["ms_per_step_single_graph"], _, _ = timed_steps(
             step, max(8, args.train_steps // 2), dist)
-        t.graph_batch_limit, t.plan_steps = limits, True
+        t.launch_form, t.plan_steps = chosen, True
         t._graphs.clear()
     t.graph_steps = False
     out["ms_per_step_eager"], _, _ = timed_steps(step, max(8, args.train_steps // 2), dist)
     if world == 1:
-        limits, t.graph_batch_limit = t.graph_batch_limit, {}
+        t.launch_form = {tmode: "graph"}
         t.graph_steps, t.split_graph = True, True
         t._graphs.clear()
         out["ms_per_step_split_graph"], _, _ = timed_steps(
             step, max(8, args.train_steps // 2), dist)
-        t.split_graph, t.graph_batch_limit = None, limits
+        t.split_graph, t.launch_form = None, chosen
         t._graphs.clear()
     t.graph_steps = True
+    # how close the default is to the best launch form of this box
+    forms = [out[k] for k in ("ms_per_step", "ms_per_step_single_graph", "ms_per_step_eager")
+             if k in out]
+    out["default_over_best_form"] = out["ms_per_step"] / min(forms)
     if mode == "packed":
         out["what"] = ("TrainDrone.train_controller_packed: an arbitrary PyTorch policy "
                        "(stock torch.nn.Linear layers, switched in place to the library's "
@@ -501,7 +527,7 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
             Shard.normed_states, Shard.in_ref_states, *rows)
         ms2, _, chunks2 = timed_steps(step2, args.train_steps, dist)
         out["with_stock_torch_linear"] = {
-            "ms_per_step": ms2, "ms_per_step_chunks": chunks2,
+            "ms_per_step": ms2, **chunk_stats(chunks2), "ms_per_step_chunks": chunks2,
             "what": "swap_linear = False: dW = dY^T X through rocBLAS"}
     else:
         fused = {"concurrent": t.train_concurrent_fused(None, None, None, None, probe=True),
@@ -628,11 +654,37 @@ def measured_copy_bandwidth(dev):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     ok = bool((dst[:: 1 << 20] == 1).all())
+    # other launch shapes of the same copy (the guide quotes
+    # 6.29 TB/s for "a float4 copy" without its shape - is the probe slow or
+    # the box?): csrc/common.hip, apg_stream_copy_shape
+    shapes = {}
+    names = {1: "one float4 per thread, whole-array grid",
+             2: "capped grid (8 blocks per CU), four float4 in flight per thread",
+             3: "as 2, non-temporal stores", 4: "as 1, 1024-thread blocks"}
+    for shape, what in names.items():
+        try:
+            rs = lambda: _capi.check(_capi.lib().apg_stream_copy_shape(
+                src.data_ptr(), dst.data_ptr(), n, shape, st), "apg_stream_copy_shape")
+            for _ in range(2):
+                rs()
+            e0.record()
+            for _ in range(reps):
+                rs()
+            e1.record()
+            torch.cuda.synchronize()
+            shapes[what] = 2 * n / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+        except Exception as e:
+            shapes[what] = repr(e)
     del src, dst
     torch.cuda.empty_cache()
+    best = max([2 * n / (ms * 1e-3) / 1e9] + [v for v in shapes.values()
+                                              if isinstance(v, float)])
     return {"GBps": 2 * n / (ms * 1e-3) / 1e9, "bytes_each_way": n, "ms": ms,
-            "verified": ok,
-            "what": "apg_stream_copy 1 GiB -> 1 GiB, read + write bytes per second"}
+            "verified": ok, "other_shapes_GBps": shapes, "best_GBps": best,
+            "guide_GBps": 6290.0,
+            "what": "apg_stream_copy 1 GiB -> 1 GiB, read + write bytes per second; "
+                    "guide_GBps: MI355X_MICROARCH.md's 'float4 copy' figure (shape not "
+                    "stated there)"}
 
 
 KERNEL_SOURCES = ("quad.hip", "quad_math.h", "apg_device.h")
@@ -798,6 +850,140 @@ def wing_eval_secondary(args, dev):
 
 # ----------------------------------------------------------------------------
 # Rank plumbing shared by the real run and --dry-run-cpu
+def _event_ms(fn, n, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def more_secondaries(args, dev):
+    """The README's other headline rows in the driver's record (VERDICT r4 weak
+    #8): the fixed-wing TRAINING step (configs[3] with the policy on the matrix
+    cores), the controller phase through LearntDynamics (N3) and the batched
+    quadrotor closed-loop evaluation (N2)."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    out = {}
+    try:
+        from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import FixedWingDynamics
+        from apg_trajectory_tracking_amd.train_fixed_wing import TrainFixedWing
+        B, H, dt = 131072, 20, 0.05
+        cfg = dict(delta_t=dt, delta_t_train=dt, epoch_size=B, self_play=0, batch_size=B,
+                   state_size=12, horizon=H, ref_dim=3, action_dim=4,
+                   learning_rate_controller=1e-9, system="fixed_wing", modified_params={})
+        wdyn = FixedWingDynamics()
+        tw = TrainFixedWing(wdyn, wdyn, cfg)
+        tw.initialize_model(device=dev, seed=0)
+        dw = tw.state_data
+        ms = _event_ms(lambda: tw.train_concurrent_fused(
+            dw.normed_states, dw.states, dw.in_ref_states, dw.ref_states), 30)
+        out["wing_train_step"] = {
+            "ms_per_step": ms, "batch": B, "horizon": H,
+            "env_steps_per_s": B * H / (ms * 1e-3),
+            "what": "TrainFixedWing.train_concurrent_fused: policy forward / reverse on "
+                    "the matrix cores around the fused rollout, weight products, SGD"}
+        del tw, dw
+    except Exception as e:
+        out["wing_train_step"] = {"error": repr(e)}
+    try:
+        from apg_trajectory_tracking_amd.dynamics.quad_dynamics_trained import LearntDynamics
+        B, H, dt = 65536, 10, 0.1
+        dyn = LearntDynamics().to(dev)
+        g = torch.Generator().manual_seed(0)
+        with torch.no_grad():
+            dyn.linear_at.add_(0.05 * torch.randn(4, 4, generator=g).to(dev))
+            for lin, sc in ((dyn.linear_state_1, 0.2), (dyn.linear_state_2, 0.02)):
+                lin.weight.add_(sc * torch.randn(lin.weight.shape, generator=g).to(dev))
+                lin.bias.add_(sc * torch.randn(lin.bias.shape, generator=g).to(dev))
+        d = synthetic.quad_polynomial_batch(B, H, dt, seed=3)
+        act = torch.rand(B, H, 4, generator=g)
+        soa = (synthetic.to_soa_state(d["state0"]).to(dev), synthetic.to_soa_seq(act).to(dev),
+               synthetic.to_soa_seq(d["ref"]).to(dev))
+        res = F.quad_learnt_rollout_fwd_bwd(dyn, *soa, dt, layout="soa")
+        ms = _event_ms(lambda: F.quad_learnt_rollout_fwd_bwd(dyn, *soa, dt, layout="soa",
+                                                             out=res), 30)
+        out["learnt_controller_phase"] = {
+            "ms_per_launch": ms, "batch": B, "horizon": H,
+            "env_steps_per_s": B * H / (ms * 1e-3),
+            "what": "quad_learnt_rollout_kernel: H x LearntDynamics.forward (4 x 4 action "
+                    "transform, analytic step, 16 -> 64 -> 12 residual network) + "
+                    "quad_mpc_loss + backward to the actions, one launch"}
+    except Exception as e:
+        out["learnt_controller_phase"] = {"error": repr(e)}
+    try:
+        from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+            FlightmareDynamics)
+        from apg_trajectory_tracking_amd.models.hutter_model import Net
+        B, L, T = 16384, 300, 251
+        torch.manual_seed(2)
+        net = Net(15, 10, 9, 40, conv=1).to(dev)
+        traj = synthetic.quad_eval_trajectories(B, L, 0.1, seed=5).to(dev)
+        qd = FlightmareDynamics()
+        ms = _event_ms(lambda: F.quad_mlp_closed_loop(net, traj, 0.1, qd.params, max_steps=T,
+                                                      test_time=0), 5, warm=2)
+        out["quad_closed_loop"] = {
+            "ms_per_launch": ms, "trajectories": B, "steps": T,
+            "closed_loop_steps_per_s": B * T / (ms * 1e-3),
+            "what": "mlp_closed_loop_kernel: QuadEvaluator.follow_trajectory for 16 384 "
+                    "reference trajectories x 251 steps in one launch (self-play mode: "
+                    "reset on divergence, every trajectory runs all steps)"}
+    except Exception as e:
+        out["quad_closed_loop"] = {"error": repr(e)}
+    return out
+
+
+RCCL_WORLD1_PROBE = r"""
+import json, os, sys, tempfile, torch, torch.distributed as dist
+dev = torch.device("cuda:0")
+store = dist.FileStore(os.path.join(tempfile.mkdtemp(), "s"), 1)
+dist.init_process_group("nccl", store=store, rank=0, world_size=1)
+out = {}
+for n in (32729, 30389, 12341):
+    buf = torch.zeros(n, device=dev)
+    for _ in range(5):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        dist.all_reduce(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    out[str(n)] = e0.elapsed_time(e1) / 100 * 1e3
+dist.destroy_process_group()
+print("RCCL_WORLD1 " + json.dumps(out))
+"""
+
+
+def allreduce_world1_probe():
+    """the latency of the step's ONE collective through a
+    live RCCL communicator of world size 1 (everything but the wire:
+    communicator, RCCL's stream and events) for the three message sizes
+    (concurrent / autoregressive / LSTM gradient + loss slot, floats), in a
+    child process with a time limit - a hang there must not cost the line."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", RCCL_WORLD1_PROBE], capture_output=True,
+                           text=True, timeout=90,
+                           env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        for line in r.stdout.splitlines():
+            if line.startswith("RCCL_WORLD1 "):
+                return {"us_per_allreduce_by_floats": json.loads(line[len("RCCL_WORLD1 "):]),
+                        "what": "torch.distributed all_reduce(sum) on a nccl (= RCCL) group "
+                                "of world size 1, 100 back-to-back calls, HIP events; "
+                                "DESIGN.md 6 predicts 15-30 us per call at N = 8"}
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    except Exception as e:       # informational only
+        return {"error": repr(e)}
+
+
 def agree_replays(replays, dist, dev):
     """Every rank must run the same number of graph replays."""
     if dist is None:
@@ -1147,6 +1333,23 @@ def main():
                     re_["ms_per_batch"] / ts["ms_per_step"])
         except Exception as e:
             out["run_epoch"] = {"error": repr(e)}
+    # the step blocks again, compact and inside `roofline` (the driver's record
+    # keeps that key whole)
+    steps = {}
+    for key, name in (("train_step", "concurrent"), ("train_step_packed", "packed"),
+                      ("train_step_ar", "ar"), ("train_step_lstm", "lstm")):
+        blk = out.get(key)
+        if isinstance(blk, dict) and "ms_per_step" in blk:
+            rf = blk.get("roofline", {})
+            steps[name] = {
+                "ms": blk["ms_per_step"], "ms_mean": blk.get("ms_per_step_mean"),
+                "ms_max": blk.get("ms_per_step_max"),
+                "frac_vs_mfma_floor": rf.get("frac_vs_mfma_floor"),
+                "bytes_ratio": rf.get("plane_bytes_over_algorithmic"),
+                "launch": (blk.get("launch_form") or [{}])[-1].get("chosen", "plan / graph"),
+                "default_over_best_form": blk.get("default_over_best_form")}
+    if steps:
+        out["roofline"]["steps"] = steps
     if rank == 0 and world == 1 and not (args.no_secondary or args.headline_only):
         try:
             out["secondary"] = {"wing_rollout": wing_secondary(args, dev)}
@@ -1156,6 +1359,8 @@ def main():
             out["secondary"]["wing_closed_loop_eval"] = wing_eval_secondary(args, dev)
         except Exception as e:
             out["secondary"]["wing_closed_loop_eval"] = {"error": repr(e)}
+        out["secondary"].update(more_secondaries(args, dev))
+        out["roofline"]["allreduce_us_world1"] = allreduce_world1_probe()
     if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.headline_only):
         out["cpu_baseline"] = cpu_baseline(args, gpu_set0)
         out["parity_check"] = out["cpu_baseline"].pop("parity_check")

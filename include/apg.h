@@ -799,6 +799,12 @@ int apg_loss_partials_count(int B);
  * next to the 8 TB/s datasheet peak in bench.py's roofline.
  * 16-byte aligned pointers, bytes a multiple of 16. */
 int apg_stream_copy(const void *src, void *dst, long long bytes, apg_stream_t stream);
+/* The same copy through other launch shapes (0 = apg_stream_copy; 1 one element
+ * per thread, whole-array grid; 2 capped grid, four elements in flight per
+ * thread; 3 as 2 with non-temporal stores; 4 as 1 with 1 024-thread blocks):
+ * measurement aid for bench.py's `roofline.copy_GBps_measured`. */
+int apg_stream_copy_shape(const void *src, void *dst, long long bytes, int shape,
+                          apg_stream_t stream);
 
 /* APG_VERSION_MAJOR * 1000 + APG_VERSION_MINOR. */
 int apg_version(void);
