@@ -173,7 +173,6 @@ SIGNATURES = {
         _P, _P, _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "apg_quad_mlp_set_weight_products": [_I],
     "apg_quad_mlp_step_workspace_floats": [],
     "apg_quad_mlp_step_partials_floats": [_I],
     "apg_quad_mlp_concurrent_step": [

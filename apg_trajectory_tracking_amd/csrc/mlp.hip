@@ -1291,60 +1291,21 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_kernel(ConcArgs A
   }
 }
 
-// ------------------------------------------ concurrent mode, round 4: the
-// reverse pass of the network WITH its weight gradients.
-// Until round 3 the reverse kernel wrote 456 cotangent planes (119 MB at
-// B = 65 536) for a second pass - seven planes_gemm products that read them and
-// the 431 activation planes again (60-74 us of the 177 us step).  Here the
-// products happen inside the reverse kernel:
-//
-//   dW[m][k] = sum_n delta[m][n] x[k][n]       (n = trajectory)
-//
-// is a matrix product whose REDUCTION index is the trajectory, so it wants both
-// operands as [row][8 consecutive trajectories] per lane.  x already is that in
-// global memory (the forward kernel's planes are [row][B]: a lane reads 64
-// contiguous bytes of its row, no transposition - what planes_gemm's stream
-// kernel does).  delta lives in accumulator layout (trajectory = lane): it is
-// transposed through LDS - every wave writes its 32 trajectories' values as
-// fp16 high / low terms to [term][row][256 trajectories] (2-byte stores), a
-// workgroup barrier, then OWNER waves read 16-byte k-slots of a row and
-// multiply against x on v_mfma_f32_32x32x16_f16 (three products per k-block,
-// policy_mfma16.h).  One workgroup = 8 waves = 256 trajectories; a layer's
-// 32 x 32 blocks of dW are dealt to the waves (one block = 16 k-blocks x 3
-// instructions), their results go to a per-workgroup partial buffer and ONE
-// second-stage launch sums the workgroups in a fixed order (deterministic) -
-// it also reduces the loss partials, so the step has no other small launch.
-// delta is scaled by a power of two per workgroup and layer (largest entry into
-// [0.5, 1); exact) - a trajectory with small cotangents keeps an ABSOLUTE
-// accuracy of 2^-25 of the workgroup's largest, which is what a sum over
-// trajectories needs.
-// LDS: the transposed operand tables (100 KB, ordered so that the tables of the
-// layers already passed lie next to the staging area) + the staging area
-// (<= 67.6 KB for a 64-row layer; the conv cotangents - 160 rows - in two
-// halves of four window positions).  HBM per 65 536 trajectories: reads 67 MB
-// (tanh') + 136 MB (x for the products) + masks, writes 38 MB of partials
-// instead of 119 MB of cotangent planes + 232 MB of product reads.
-#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_WG_KNOCKOUT)
-#error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
-#endif
-#ifndef APG_WG_KNOCKOUT
-#define APG_WG_KNOCKOUT 0   // timing experiments: 1 no products, 2 no staging, 4 no partial
-                            // stores, 8 no x loads, 16 no matrix instructions, 32 no x split
-#endif
+// ------------------------------------------ concurrent mode, rounds 4-5: the
+// reverse pass of the network WITH its weight gradients, the step's second
+// stage (mlp_concurrent_bwd_tm_kernel below; the round-4 "staged" kernel -
+// cotangents transposed through LDS, owner waves - lives in
+// tools/patches/mlp_concurrent_bwd_wg.patch).
+// Reverse tables of the in-sweep kernels: [eb][kb] fc1^T conv part first, fc1^T
+// state part, fc2^T, fc3^T, the concurrent head^T (cbwd_weight's blocks in the
+// order the layers are passed, so that the tables of finished layers can be
+// re-used as accumulator space).
 constexpr int wC = 0, wS = 20, w2 = 28, w3 = 36, wO = 44, wBlocks = 50;
 constexpr int kWgTabBytes = wBlocks * kBlock16;   // 102 400
 constexpr int kWgTabFloats = kWgTabBytes / 4;
 constexpr int kLdsAll = 160 * 1024;
-constexpr int kRS = 528;              // staged row: 256 fp16 + 16 B (b128 reads conflict-free)
-constexpr int kMetaBytes = 256;       // tail of the LDS: per-wave |delta| maxima
-constexpr int kStageEnd = kLdsAll - kMetaBytes;
-__host__ __device__ constexpr int stage_base(int rows) { return kStageEnd - 2 * rows * kRS; }
-static_assert(stage_base(40) >= kWgTabBytes, "head staging next to live tables");
-static_assert(stage_base(64) >= wO * kBlock16, "64-row staging may only cover the head tables");
-static_assert(stage_base(80) >= wS * kBlock16, "conv staging must not touch the fc1 conv tables");
 // partial slots of a workgroup (1024 floats each, accumulator order [reg][lane])
-constexpr int sOut = 0, sFc3 = 4, sFc2 = 8, sFc1 = 12, sSin = 26, sConv = 28, sBias = 36,
-              kSlots = 37;
+constexpr int sOut = 0, sFc3 = 4, sFc2 = 8, sFc1 = 12, sSin = 26, sConv = 28;
 // second stage: workgroups per first-level chunk, element columns of 256
 constexpr int kRedChunk = 32;
 
@@ -1413,472 +1374,11 @@ struct WgArgs {
   const float *acts;     // [521][B]: feat 0..14 | x1 15..238 | h1 h2 h3 239..430 | in_ref 431..520
   const unsigned *mask;  // [5][B]
   const float *d_zout;   // [40][B] (the forward kernel's dL/d(head pre-activations))
-  float *part;           // [workgroups][kSlots][1024]
+  float *part;           // [workgroups][kSlotsTm][1024]
   const float *tables;
   const float *xmax;     // [waves][4] (the forward kernel's; trajectory-major kernel only)
   int B;
 };
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
-  return v;
-}
-
-// two cotangents of neighbouring rows -> their fp16 terms into the staging area
-// (`p` = this lane's slot of row_a; row_b = row_a + rstep rows further)
-__device__ __forceinline__ void stage_pair(char *p, int term_bytes, int rstep, float a, float b) {
-  if (APG_WG_KNOCKOUT & 2) return;
-  unsigned h, l;
-  split_pair(a, b, h, l);
-  *reinterpret_cast<unsigned short *>(p) = (unsigned short)h;
-  *reinterpret_cast<unsigned short *>(p + rstep * kRS) = (unsigned short)(h >> 16);
-  *reinterpret_cast<unsigned short *>(p + term_bytes) = (unsigned short)l;
-  *reinterpret_cast<unsigned short *>(p + term_bytes + rstep * kRS) = (unsigned short)(l >> 16);
-}
-
-// a 64-row cotangent in accumulator layout (rows 32 rb + r(i) + 4 hi) x 2^-e
-__device__ __forceinline__ void stage64(char *lds, const f32x16 (&v)[2], int e, int wave,
-                                        int lane) {
-  char *p = lds + stage_base(64) + ((lane >> 5) * 4) * kRS + (wave * 32 + (lane & 31)) * 2;
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-    for (int i = 0; i < 16; i += 2)
-      stage_pair(p + (32 * rb + rrow(i)) * kRS, 64 * kRS, 1,
-                 __builtin_amdgcn_ldexpf(v[rb][i], -e), __builtin_amdgcn_ldexpf(v[rb][i + 1], -e));
-}
-
-// workgroup exponent: every wave has left its |delta| maximum in the LDS tail
-__device__ __forceinline__ int wg_exponent(const char *lds) {
-  const float *m = reinterpret_cast<const float *>(lds + kStageEnd);
-  float a = m[0];
-#pragma unroll
-  for (int w = 1; w < kThreads / 64; ++w) a = fmaxf(a, m[w]);
-  return a > 0.f ? __builtin_amdgcn_frexp_expf(a) : 0;
-}
-
-__device__ __forceinline__ void post_max(char *lds, float lane_max, int wave, int lane) {
-  const float a = wave_max(lane_max);
-  if (lane == 0) reinterpret_cast<float *>(lds + kStageEnd)[wave] = a;
-}
-
-// One 32 x 32 block of a layer's weight gradient over the workgroup's 256
-// trajectories: rows 32 mb .. of the staged cotangent (LDS) against the 32
-// planes from `plane0` of the activation buffer (x_rows of them are real; row
-// `ones_row` is a row of ones: the bias gradient rides along as a column).
-// ONES: no x at all, B operand = ones (bias of a layer whose x block is full).
-// The k-slot order is free as long as both operands agree: instruction kb of
-// trajectory group g (32 trajectories = one source wave) takes trajectories
-// 32 g + 16 hi + 8 kb + j, so a lane's x is 64 contiguous bytes of its plane.
-// The x operand of a block product, four trajectory groups deep: `begin` issues
-// the loads of groups 0..3 - BEFORE the layer's cotangents are staged and the
-// barrier is passed (x does not depend on them), so their latency (~2 us under
-// load; two groups in flight left every product latency-bound: 5.5 us per
-// block) is hidden behind the staging - and every `take` re-issues four groups
-// ahead.
-constexpr int kXDepth = 4;
-struct XPipe {
-  u32x4 q[kXDepth][4];
-  unsigned voff, soff;
-  __device__ __forceinline__ void load(const Planes &X, int set, int g) {
-    if (APG_WG_KNOCKOUT & 8) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q[set][j] = u32x4{voff, soff, (unsigned)g, 1u};
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      q[set][j] = __builtin_amdgcn_raw_buffer_load_b128(
-          X.rsrc, (int)voff, (int)(soff + g * 128 + j * 16), APG_PLANES_LD_AUX);
-  }
-  __device__ __forceinline__ void begin(const Planes &X, int plane0, int x_rows, unsigned pN,
-                                        unsigned col0_bytes, int lane) {
-    const int row = lane & 31, hi = lane >> 5;
-    voff = row < x_rows ? (unsigned)row * pN + (unsigned)hi * 64u : kDead;
-    soff = (unsigned)plane0 * pN + col0_bytes;
-    if (APG_WG_KNOCKOUT & 1) return;
-#pragma unroll
-    for (int g = 0; g < kXDepth; ++g) load(X, g, g);
-  }
-};
-
-// One 32 x 32 block of a layer's weight gradient over the workgroup's 256
-// trajectories: rows 32 mb .. of the staged cotangent (LDS) against the 32
-// planes `xp` was begun on (x_rows of them real; row `ones_row` is a row of
-// ones: the bias gradient rides along as a column).  The k-slot order is free
-// as long as both operands agree: instruction kb of trajectory group g (32
-// trajectories = one source wave) takes trajectories 32 g + 16 hi + 8 kb + j,
-// so a lane's x is 64 contiguous bytes of its plane.
-template <int NMB>
-__device__ __forceinline__ void wgrad_block(f32x16 (&acc)[NMB], const char *lds, int sbase,
-                                            int rows_total, int mb0, int a_rows1,
-                                            const Planes &X, XPipe &xp, int ones_row, int ncols,
-                                            int lane) {
-  const int row = lane & 31, hi = lane >> 5;
-#pragma unroll
-  for (int m = 0; m < NMB; ++m)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-  if (APG_WG_KNOCKOUT & 1) return;
-  // NMB row blocks mb0, mb0 + 1 share the x operand: x is loaded and split once
-  // (the loads are what this product is paced by: a lane's 64 bytes are one of
-  // 32 different planes per instruction).  Rows beyond the LAST block's
-  // `a_rows1` staged ones re-read row 0: their output rows are never used, but
-  // the reads must stay inside the staging area.
-  const char *pd[NMB];
-#pragma unroll
-  for (int m = 0; m < NMB; ++m) {
-    const int r = (m == NMB - 1 && row >= a_rows1) ? 0 : row;
-    pd[m] = lds + sbase + (32 * (mb0 + m) + r) * kRS + hi * 32;
-  }
-  const int term = rows_total * kRS;
-  auto multiply = [&](const u32x4 (&q)[4], int g) {
-    Op16 xk[2];
-    float v[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // (the whole vector is cast: bit_cast of an ext-vector ELEMENT reads
-      // element 0 whatever the index, clang 19 / ROCm 7.2)
-      typedef float f32x4_ __attribute__((ext_vector_type(4)));
-      const f32x4_ f = __builtin_bit_cast(f32x4_, q[j]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) v[4 * j + c] = f[c];
-    }
-    if (ncols < kTrajPerBlock) {   // ragged last workgroup: columns beyond B are
-#pragma unroll                    // somebody else's plane
-      for (int j = 0; j < 16; ++j)
-        if (32 * g + 16 * hi + j >= ncols) v[j] = 0.f;
-    }
-    if (ones_row >= 0) {   // (wave-uniform: only the feature / window blocks)
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        v[j] = row == ones_row ? (32 * g + 16 * hi + j < ncols ? 1.f : 0.f) : v[j];
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float w8[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) w8[j] = v[8 * kb + j];
-      if (APG_WG_KNOCKOUT & 32) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          xk[kb].h[c] = __builtin_bit_cast(unsigned, w8[2 * c]),
-          xk[kb].l[c] = __builtin_bit_cast(unsigned, w8[2 * c + 1]);
-      } else {
-        xk[kb] = split8(w8);
-      }
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int m = 0; m < NMB; ++m) {
-        Op16 dk;
-        dk.h = *reinterpret_cast<const u32x4 *>(pd[m] + g * 64 + kb * 16);
-        dk.l = *reinterpret_cast<const u32x4 *>(pd[m] + term + g * 64 + kb * 16);
-        if (APG_WG_KNOCKOUT & 16) {   // keep every operand alive, no matrix work
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            acc[m][c] += __builtin_bit_cast(float, dk.h[c] ^ xk[kb].h[c]) +
-                         __builtin_bit_cast(float, dk.l[c] ^ xk[kb].l[c]);
-        } else {
-          acc[m] = mma3(dk, xk[kb], acc[m]);
-        }
-      }
-  };
-  // (rolled over the two halves: the product is instantiated a dozen times)
-#pragma unroll 1
-  for (int g0 = 0; g0 < kThreads / 64; g0 += kXDepth) {
-#pragma unroll
-    for (int k = 0; k < kXDepth; ++k) {
-      multiply(xp.q[k], g0 + k);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g0 == 0) xp.load(X, k, kXDepth + k);   // groups 4..7, four ahead
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-// the same against a B operand of ones: the row sums (bias of a layer whose x
-// block is full), no loads
-__device__ __forceinline__ f32x16 wgrad_ones(const char *lds, int sbase, int rows_total,
-                                             int mb, int a_rows, int lane) {
-  const int row = lane & 31, hi = lane >> 5;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  if (APG_WG_KNOCKOUT & 1) return acc;
-  const char *pd = lds + sbase + (32 * mb + (row < a_rows ? row : 0)) * kRS + hi * 32;
-  const int term = rows_total * kRS;
-  const u32x4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-#pragma unroll 1
-  for (int g = 0; g < kThreads / 64; ++g)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      acc = mfma16(*reinterpret_cast<const u32x4 *>(pd + term + g * 64 + kb * 16), ones, acc);
-      acc = mfma16(*reinterpret_cast<const u32x4 *>(pd + g * 64 + kb * 16), ones, acc);
-    }
-  return acc;
-}
-
-__device__ __forceinline__ void store_block(float *slot, const f32x16 &acc, float back,
-                                            int lane) {
-  if (APG_WG_KNOCKOUT & 4) return;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(acc[i] * back, slot + i * 64 + lane);
-}
-
-// bias gradient of a layer with a full x block: row sums of both row blocks
-__device__ __forceinline__ void bias_item(const char *lds, int sbase, int rows_total,
-                                          int n_mb, const Planes &X, float back,
-                                          float *bias_slot, int lane) {
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    if (mb >= n_mb) break;
-    const f32x16 acc = wgrad_ones(
-        lds, sbase, rows_total, mb, rows_total - 32 * mb < 32 ? rows_total - 32 * mb : 32, lane);
-    if ((lane & 31) == 0) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        bias_slot[32 * mb + rrow(i) + 4 * (lane >> 5)] = acc[i] * back;
-    }
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds_f[];
-  char *lds = reinterpret_cast<char *>(lds_f);
-  const int lane = threadIdx.x & 63, hi = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b0 = blockIdx.x * kTrajPerBlock;
-  const int b = b0 + wave * 32 + (lane & 31);
-  const int B = A.B;
-  const bool live = b < B;
-  const int ncols = B - b0 < kTrajPerBlock ? B - b0 : kTrajPerBlock;
-  const unsigned pN = (unsigned)B * 4u;
-  const Planes Pact(A.acts, kActPlanes, pN), Pmk(A.mask, 5, pN), Pdz(A.d_zout, kNA, pN);
-  const unsigned vb = live ? (unsigned)b * 4u : kDead;
-  const unsigned vr = live ? vb + (hi ? 4u * pN : 0u) : kDead;
-  const unsigned col0 = (unsigned)b0 * 4u;
-  float *part = A.part + (size_t)blockIdx.x * kSlots * 1024;
-
-  // this wave's own inputs first (they return while the tables stream in)
-  float dzr[20];
-#pragma unroll
-  for (int cc = 0; cc < 20; ++cc) dzr[cc] = Pdz.ld(vr, khead(cc, 0) * pN);
-  unsigned mw[5];
-#pragma unroll
-  for (int eb = 0; eb < 5; ++eb) mw[eb] = Pmk.ldu(vb, eb * pN);
-  // Work items of a layer = its 32-plane COLUMN blocks, both row blocks at once
-  // (they share x: it is loaded and split once): waves 0 and 1 own the two
-  // column blocks of the 64 x 64 layers (and of the head), wave 2 their bias;
-  // fc1 has seven column blocks (waves 0..6) + its bias (wave 7).  The x of an
-  // item is requested before the layer's cotangents are staged (XPipe).
-  XPipe xp;
-  if (wave < 2) xp.begin(Pact, pH3 + 32 * wave, 32, pN, col0, lane);
-  fill_lds(lds_f, A.tables, kWgTabFloats);
-  const LdsView16 L16(lds, lane);
-
-  // ------------------------------------------------ head: delta = dL/dz (40 rows)
-  float amax = 0.f;
-#pragma unroll
-  for (int cc = 0; cc < 20; ++cc) amax = fmaxf(amax, fabsf(dzr[cc]));
-  post_max(lds, amax, wave, lane);
-  __syncthreads();
-  const int ew = wg_exponent(lds);
-  {
-    char *p = lds + stage_base(40) + (hi * 4) * kRS + (wave * 32 + (lane & 31)) * 2;
-#pragma unroll
-    for (int cc = 0; cc < 20; cc += 2)
-      stage_pair(p + khead(cc, 0) * kRS, 40 * kRS, 1, __builtin_amdgcn_ldexpf(dzr[cc], -ew),
-                 __builtin_amdgcn_ldexpf(dzr[cc + 1], -ew));
-  }
-  __syncthreads();
-  f32x16 d[2], e[2];
-  int ex;
-  // the saved activations a layer's tanh' needs are requested BEFORE the
-  // layer's weight-gradient items: they land while the items multiply
-  float hv[2][16];
-  auto load_hv = [&](int plane) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) hv[rb][i] = Pact.ld(vr, (plane + rb * 32 + rrow(i)) * pN);
-  };
-  load_hv(pH3);
-  {  // weight gradient of the head: 2 x 2 blocks against h3, bias
-    const float back = __builtin_amdgcn_ldexpf(1.f, ew);
-    if (wave < 2) {
-      f32x16 acc[2];
-      wgrad_block<2>(acc, lds, stage_base(40), 40, 0, 8, Pact, xp, -1, ncols, lane);
-      xp.begin(Pact, pH2 + 32 * wave, 32, pN, col0, lane);   // fc3's x, a layer ahead
-      store_block(part + (sOut + wave * 2 + 0) * 1024, acc[0], back, lane);
-      store_block(part + (sOut + wave * 2 + 1) * 1024, acc[1], back, lane);
-    } else if (wave == 2) {
-      bias_item(lds, stage_base(40), 40, 2, Pact, back, part + sBias * 1024 + 0, lane);
-    }
-  }
-  zero(d);
-  {  // dL/dh3 = W_out^T dL/dz (per-trajectory scale, as in the plane version)
-    ex = scale_exponent(amax);
-#pragma unroll
-    for (int kb = 0; kb < 3; ++kb) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = kb * 8 + j < 20 ? __builtin_amdgcn_ldexpf(dzr[kb * 8 + j < 20 ? kb * 8 + j : 0], -ex)
-                               : 0.f;
-      const Op16 x = split8(v);
-      d[0] = mma3(L16.A(0, wO + kb), x, d[0]);
-      d[1] = mma3(L16.A(0, wO + 3 + kb), x, d[1]);
-    }
-  }
-  auto tanh_back = [&](f32x16 (&v)[2], int exv) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        v[rb][i] = __builtin_amdgcn_ldexpf(v[rb][i], exv) * (1.f - hv[rb][i] * hv[rb][i]);
-  };
-  tanh_back(d, ex);   // d_pre3 (the cotangent planes are not written any more)
-
-  // stage a 64-row cotangent with the workgroup's exponent (two barriers: the
-  // maxima are in and the previous layer's staged rows are done with; then the
-  // staged rows are visible); returns 2^e
-  auto stage_layer = [&](const f32x16 (&dl)[2]) {
-    float am = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) am = fmaxf(am, fabsf(dl[rb][i]));
-    post_max(lds, am, wave, lane);
-    __syncthreads();
-    const int e_ = wg_exponent(lds);
-    stage64(lds, dl, e_, wave, lane);
-    __syncthreads();
-    return __builtin_amdgcn_ldexpf(1.f, e_);
-  };
-  // one 64 x 64 layer: weight gradient of `dl` against the planes `xp` was
-  // begun on, x of the NEXT layer requested, then dl through W^T (blocks `tab`)
-  auto layer64 = [&](f32x16 (&dl)[2], f32x16 (&nx)[2], int tab, int hv_plane, int slot,
-                     int bias_id, int next_plane, int &exn) {
-    const float back = stage_layer(dl);
-    load_hv(hv_plane);
-    if (wave < 2) {
-      f32x16 acc[2];
-      wgrad_block<2>(acc, lds, stage_base(64), 64, 0, 32, Pact, xp, -1, ncols, lane);
-      xp.begin(Pact, next_plane + 32 * wave, 32, pN, col0, lane);
-      store_block(part + (slot + wave * 2 + 0) * 1024, acc[0], back, lane);
-      store_block(part + (slot + wave * 2 + 1) * 1024, acc[1], back, lane);
-    } else if (wave == 2) {
-      bias_item(lds, stage_base(64), 64, 2, Pact, back, part + sBias * 1024 + bias_id * 64,
-                lane);
-    }
-    Op16 x[4];
-    zero(nx);
-    exn = scaled_split64(dl, x);
-    dense64T_16(nx, x, L16, 0, tab);
-  };
-  // ---- fc3: delta = d_pre3 (d), x = h2; then fc2's x = h1
-  layer64(d, e, w3, pH2, sFc3, 1, pH1, ex);
-  tanh_back(e, ex);
-  // ---- fc2: delta = d_pre2 (e), x = h1; then fc1's x: wave w takes column
-  // block w of its seven (waves 0, 1 were begun by the layer above)
-  layer64(e, d, w2, pH1, sFc2, 2, pX1, ex);
-  tanh_back(d, ex);
-  // ---- fc1: delta = d_pre1 (d), x = [s1, relu(conv)] = the 224 x1 planes
-  if (wave >= 2 && wave < 7) xp.begin(Pact, pX1 + 32 * wave, 32, pN, col0, lane);
-  Op16 x1s[4];   // d_pre1, scaled per trajectory and split: also the conv part below
-  int ex1;
-  {
-    const float back = stage_layer(d);
-    load_hv(pX1);        // s1 = planes 15..78
-    if (wave < 7) {
-      f32x16 acc[2];
-      wgrad_block<2>(acc, lds, stage_base(64), 64, 0, 32, Pact, xp, -1, ncols, lane);
-      // states_in's x (the 15 feature planes + ones)
-      if (wave == 0) xp.begin(Pact, pFeat, kNF, pN, col0, lane);
-      store_block(part + (sFc1 + wave * 2 + 0) * 1024, acc[0], back, lane);
-      store_block(part + (sFc1 + wave * 2 + 1) * 1024, acc[1], back, lane);
-    } else {
-      bias_item(lds, stage_base(64), 64, 2, Pact, back, part + sBias * 1024 + 3 * 64, lane);
-    }
-    zero(e);
-    ex1 = scaled_split64(d, x1s);
-    dense64T_16(e, x1s, L16, 0, wS);
-  }
-  tanh_back(e, ex1);   // d_pre_s
-  // ---- states_in: delta = d_pre_s (e), x = the 15 feature planes + ones (bias)
-  {
-    const float back = stage_layer(e);
-    if (wave == 0) {
-      f32x16 acc[2];
-      wgrad_block<2>(acc, lds, stage_base(64), 64, 0, 32, Pact, xp, kNF, ncols, lane);
-      store_block(part + (sSin + 0) * 1024, acc[0], back, lane);
-      store_block(part + (sSin + 1) * 1024, acc[1], back, lane);
-    }
-  }
-  // ---- conv: delta = relu'(.) W_1c^T d_pre1, 20 channels x 8 window positions;
-  // a lane holds positions ii + 4 hi of its channels, so the lower half-waves
-  // stage positions 0..3 and then the upper ones 4..7 (80 rows each); the
-  // window of position pos is the 27 in_ref planes from 9 pos, + ones (bias).
-  float dc[5][16];
-  {
-    float am = 0.f;
-#pragma unroll
-    for (int eb = 0; eb < 5; ++eb) {
-      f32x16 y;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) y[i] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) y = mma3(L16.A(0, wC + eb * 4 + kb), x1s[kb], y);
-      const unsigned mws = hi ? mw[eb] >> 4 : mw[eb];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        dc[eb][i] = ((mws >> rrow(i)) & 1u) ? __builtin_amdgcn_ldexpf(y[i], ex1) : 0.f;
-        am = fmaxf(am, fabsf(dc[eb][i]));
-      }
-    }
-    post_max(lds, am, wave, lane);
-  }
-  // the first windows' x (waves 4..7 multiply): on its way through the barrier
-  // and the staging of the first half
-  __builtin_amdgcn_sched_barrier(0);   // (not above the products: registers)
-  if (wave >= 4) xp.begin(Pact, pInr + kRD * (wave - 4), 27, pN, col0, lane);
-  __syncthreads();
-  const int ec = wg_exponent(lds);
-  const float backc = __builtin_amdgcn_ldexpf(1.f, ec);
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    if (hi == half) {
-      // (opaque per iteration: otherwise the compiler converts all 80 values
-      // of both halves ahead of the loop and spills them)
-      int ecl = ec;
-      asm volatile("" : "+v"(ecl));
-      const int ec = ecl;
-      char *p = lds + stage_base(80) + (wave * 32 + (lane & 31)) * 2;
-#pragma unroll
-      for (int eb = 0; eb < 5; ++eb)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2)   // row = 20 (position & 3) + channel
-          stage_pair(p + (20 * (i & 3) + eb * 4 + (i >> 2)) * kRS, 80 * kRS, 20,
-                     __builtin_amdgcn_ldexpf(dc[eb][i], -ec),
-                     __builtin_amdgcn_ldexpf(dc[eb][i + 1], -ec));
-    }
-    __syncthreads();
-    if (wave >= 4) {
-      // rows 20 q .. 20 q + 19 of the staged half (q = wave - 4): not a multiple
-      // of 32, so the block is addressed from row 20 q with mb = 0
-      const int q = wave - 4, pos = 4 * half + q;
-      f32x16 acc[1];
-      wgrad_block<1>(acc, lds, stage_base(80) + 20 * q * kRS, 80, 0, kNC, Pact, xp, 27, ncols,
-                     lane);
-      if (half == 0) xp.begin(Pact, pInr + kRD * (4 + q), 27, pN, col0, lane);
-      store_block(part + (sConv + pos) * 1024, acc[0], backc, lane);
-    }
-    __syncthreads();
-  }
-}
 
 // ---------------------------------------------------------------------------
 // The same reverse pass with TRAJECTORY-MAJOR weight products (round 4, last
@@ -1905,7 +1405,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_wg_kernel(WgArgs 
 // matrix pipe was ~15 % busy).  The accumulators are FIXED POINT (below):
 // integer sums do not depend on the order in which the eight waves add, so the
 // kernel is bit-reproducible like the staged one
-// (apg_quad_mlp_set_weight_products switches between them).
 // LDS: tables [0, 100 K) as above; accumulator regions in the 60 KB behind them
 // and, for fc1's 14 blocks, also in the tables of the layers already passed:
 //   R_A [100 K, 116 K)  head, then fc2          R_B [116 K, 132 K)  fc3
@@ -2450,7 +1949,7 @@ __device__ __forceinline__ float *wg_dest(const ApgMlpPolicyGrads &g, int slot, 
 }
 
 // Second stage, two launches.  Level 1: blockIdx.y = a chunk of kRedChunk
-// workgroups, summed per element in workgroup order into chunk_sums[chunk][kSlots
+// workgroups, summed per element in workgroup order into chunk_sums[chunk][slots
 // * 1024] - thousands of blocks, the 38 MB of partials stream at the HBM rate
 // (one block per element column over all 256 workgroups, the first version,
 // took 248 us).  Level 2 sums the chunks in order, scatters into the parameter
@@ -2479,7 +1978,7 @@ struct WgReduceArgs {
   bool conv_bias_here; // the conv bias sits in the bias slot (layer 0, entries 32..51)
   const float *loss_partials;
   float *loss;
-  int wgs, n_partials;   // wgs: how many [kSlots * 1024] rows `part` has
+  int wgs, n_partials;   // wgs: how many [n_slots * 1024] rows `part` has
 };
 
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce1_kernel(const float *part,
@@ -3562,24 +3061,7 @@ long long apg_quad_mlp_step_partials_floats(int B) {
   const long long wgs = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   // the workgroups' partials + the chunk sums of the first reduction level
   // + the forward kernel's per-wave x maxima
-  return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlots * 1024 + wgs * 32;
-}
-
-namespace {
-// which reverse kernel the concurrent step launches: 1 trajectory-major
-// products with fixed-point LDS accumulators (the default), 0 the staged
-// products of the first half of round 4 (kept: an independent implementation
-// of the same sums, tests/test_gpu_in_sweep.py compares the two)
-int g_weight_products = 1;
-}  // namespace
-
-int apg_quad_mlp_set_weight_products(int mode) {
-  if (mode != 0 && mode != 1) {
-    set_error("weight products: 0 (staged) or 1 (trajectory-major)");
-    return APG_ERR_ARG;
-  }
-  g_weight_products = mode;
-  return APG_OK;
+  return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlotsTm * 1024 + wgs * 32;
 }
 
 namespace {
@@ -3660,7 +3142,6 @@ int apg_quad_mlp_concurrent_train_step(
   static PerDeviceOnce attr;
   if (!attr.test()) {
     if (int e = raise_lds(mlp_concurrent_fwd_kernel, kCfLds)) return e;
-    if (int e = raise_lds(mlp_concurrent_bwd_wg_kernel, kLdsAll / 4)) return e;
     if (int e = raise_lds(mlp_concurrent_bwd_tm_kernel, kLdsAll / 4)) return e;
     attr.set();
   }
@@ -3697,13 +3178,7 @@ int apg_quad_mlp_concurrent_train_step(
   WgArgs W;
   W.acts = acts, W.mask = relu_mask, W.d_zout = d_zout, W.part = partials;
   W.tables = workspace + kCfLds, W.B = B, W.xmax = A.xmax;
-  const bool tm = g_weight_products == 1;
-  if (tm)
-    hipLaunchKernelGGL(mlp_concurrent_bwd_tm_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st,
-                       W);
-  else
-    hipLaunchKernelGGL(mlp_concurrent_bwd_wg_kernel, dim3(blocks), dim3(kThreads), kLdsAll,
-                       st, W);
+  hipLaunchKernelGGL(mlp_concurrent_bwd_tm_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st, W);
   // the inputs (activation planes, state0, ref) are not read past this point:
   // a caller that pipelines batches may start refilling the NEXT batch's
   // buffers behind this event while the second stage and the update run
@@ -3713,9 +3188,7 @@ int apg_quad_mlp_concurrent_train_step(
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
-  R.n_slots = tm ? kSlotsTm : kSlots, R.bias_slot = tm ? uBias : sBias;
-  R.conv_src = tm ? 1 : kNP;
-  R.bias_src = tm ? 8 : 1;
+  R.n_slots = kSlotsTm, R.bias_slot = uBias, R.conv_src = 1, R.bias_src = 8;
   R.head_rows = kNA, R.conv_bias_here = false;
   const int columns = (R.n_slots * 1024 + 255) / 256;
   R.update = update != nullptr;

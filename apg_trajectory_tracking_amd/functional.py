@@ -1709,14 +1709,6 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         return (None, None, None, None, *[gr[k] for k in _MLP_PARAMS], None, None, None)
 
 
-def set_concurrent_weight_products(mode):
-    """Which reverse kernel the concurrent step launches (process-wide;
-    include/apg.h, apg_quad_mlp_set_weight_products): 1 trajectory-major
-    products with fixed-point LDS accumulators (default), 0 staged products."""
-    check(lib().apg_quad_mlp_set_weight_products(int(mode)),
-          "apg_quad_mlp_set_weight_products")
-
-
 class QuadConcurrentStepPlan:
     """The concurrent training step of `Net(15, 10, 9, 40, conv=1)` with
     everything around the launch made ONCE: scratch planes, the flat gradient

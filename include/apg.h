@@ -394,19 +394,16 @@ typedef struct ApgMlpPolicyGrads {
 } ApgMlpPolicyGrads;
 int apg_quad_mlp_step_workspace_floats(void);
 long long apg_quad_mlp_step_partials_floats(int B);
-/* Process-wide choice of the reverse kernel of the two step calls below:
- *   1  (default) trajectory-major products: every wave multiplies its own 32
- *      trajectories' cotangents - obtained in [trajectory][feature] form by
- *      issuing the layer's matrix instructions with the operands swapped -
- *      against its own x and adds the 32 x 32 blocks into 32-bit FIXED-POINT
- *      accumulators in LDS (ds_add_u32: order-independent, so results are
- *      bit-reproducible); one barrier per layer;
- *   0  staged products (first half of round 4): cotangents transposed through
- *      LDS, owner waves, fp32 sums in a fixed order.
- * Both give every gradient to fp32 accuracy (tests/test_gpu_in_sweep.py); a
- * non-finite cotangent or activation yields NaN gradients in both.  Nothing in
- * the environment influences the choice. */
-int apg_quad_mlp_set_weight_products(int mode);
+/* The reverse kernel of the two step calls below (csrc/mlp.hip,
+ * mlp_concurrent_bwd_tm_kernel): every wave multiplies its own 32 trajectories'
+ * cotangents - obtained in [trajectory][feature] form by issuing the layer's
+ * matrix instructions with the operands swapped - against its own x and adds
+ * the 32 x 32 blocks into 32-bit FIXED-POINT accumulators in LDS (ds_add_u32:
+ * order-independent, so results are bit-reproducible); one barrier per layer.
+ * Round 5: the chain's operands are scaled per trajectory, the head's rows
+ * have their own exponents, the biases are per-wave float sums.  A non-finite
+ * cotangent or activation yields NaN gradients.  Nothing in the environment
+ * influences the kernel.  (Round 4's staged kernel: tools/patches/.) */
 int apg_quad_mlp_concurrent_step(
     const float *state0, const float *ref, int ref_cols, float dt,
     const ApgQuadParams *params, const ApgQuadLossWeights *weights,

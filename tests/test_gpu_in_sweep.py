@@ -1,6 +1,6 @@
 """Round 4: the concurrent training step with its weight gradients accumulated
 INSIDE the reverse kernel (apg_quad_mlp_concurrent_step; csrc/mlp.hip,
-mlp_concurrent_bwd_wg_kernel) - no cotangent planes, no second pass of
+mlp_concurrent_bwd_tm_kernel) - no cotangent planes, no second pass of
 products.  One loss.backward() of the reference yields every parameter
 gradient (scripts/train_drone.py:175-203); this path must too, to the same
 1e-4 as the plane + product path it replaces (which stays available behind
@@ -30,16 +30,6 @@ def in_sweep_switch():
     before = F.CONCURRENT_IN_SWEEP
     yield lambda on: setattr(F, "CONCURRENT_IN_SWEEP", bool(on))
     F.CONCURRENT_IN_SWEEP = before
-
-
-@pytest.fixture(params=[1, 0], ids=["trajectory_major", "staged"])
-def products(request):
-    """Both reverse kernels of the step (include/apg.h,
-    apg_quad_mlp_set_weight_products): 1 = the default."""
-    from apg_trajectory_tracking_amd import functional as F
-    F.set_concurrent_weight_products(request.param)
-    yield request.param
-    F.set_concurrent_weight_products(1)
 
 
 def N(t):
@@ -73,8 +63,7 @@ def _fp64_grads(net, d):
 # second workgroup with one trajectory; 300, 4113: ragged last workgroups;
 # 8192 + 3: more than one chunk of the second stage (32 workgroups)
 @pytest.mark.parametrize("B", [1, 31, 77, 256, 257, 300, 4113, 8195])
-def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_switch,
-                                                             products):
+def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_switch):
     from apg_trajectory_tracking_amd import functional as F
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
@@ -100,7 +89,7 @@ def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_s
         assert rel_err(g1[k], g0[k]) < 2e-5, (k, rel_err(g1[k], g0[k]))
 
 
-def test_in_sweep_is_deterministic_and_feeds_autograd(dev, in_sweep_switch, products):
+def test_in_sweep_is_deterministic_and_feeds_autograd(dev, in_sweep_switch):
     """Fixed-order sums (staged kernel) / fixed-point accumulators (trajectory-
     major kernel) and a fixed-order second stage: equal inputs give equal bits,
     at a batch of several workgroups and chunks as well; loss.backward()
@@ -254,13 +243,13 @@ def test_train_step_through_the_c_abi(dev):
     assert call(0, upd) == -1 and b"B = 0" in lib.apg_last_error_string()
 
 
-def test_both_product_kernels_agree_at_full_size_and_flag_non_finite_operands(dev):
-    """B = 65 536: the trajectory-major kernel against the staged one on every
-    parameter gradient (two independent implementations of the same sums), both
-    bit-reproducible; a NaN planted in one trajectory's features (behind the
-    host's range check) gives a non-finite loss with both and NaN in EVERY
-    gradient with the trajectory-major kernel - never a finite number (its
-    fixed-point conversion would turn a NaN into 0 if nothing looked)."""
+def test_in_sweep_kernel_agrees_with_plane_path_at_full_size_and_flags_non_finite(dev, in_sweep_switch):
+    """B = 65 536: the trajectory-major kernel against the plane + product path
+    on every parameter gradient (two independent implementations of the same
+    sums), bit-reproducible; a NaN / inf planted in one trajectory's features
+    (behind the host's range check) gives a non-finite loss and NaN in EVERY
+    gradient - never a finite number (the fixed-point conversion would turn a
+    NaN into 0 if nothing looked)."""
     from apg_trajectory_tracking_amd import functional as F
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
@@ -270,37 +259,29 @@ def test_both_product_kernels_agree_at_full_size_and_flag_non_finite_operands(de
     net = Net(15, H, 9, 4 * H, conv=1).to(dev)
     _, inputs = _case(B, 5, dev)
     dyn = FlightmareDynamics()
-    got = {}
-    try:
-        for mode in (1, 0):
-            F.set_concurrent_weight_products(mode)
-            prepared = F.quad_concurrent_prepare(*inputs)
-            plan = F.QuadConcurrentStepPlan(net, prepared, DT, dyn.params)
-            plan.launch()
-            first = plan.flat.clone()
-            plan.launch()
-            assert torch.equal(plan.flat[:-1], first[:-1]), mode      # reproducible
-            got[mode] = {k: N(v) for k, v in plan.named.items()}
-            # one trajectory's feature becomes NaN / inf
-            for poison in (float("nan"), float("inf")):
-                prepared[0][3, 40000] = poison
-                loss = plan.launch()
-                torch.cuda.synchronize()
-                assert not torch.isfinite(loss).item(), (mode, poison)
-                if mode == 1:     # (the staged kernel masks part of the conv block)
-                    for k, v in plan.named.items():
-                        assert not torch.isfinite(v).any(), (mode, poison, k)
-                else:
-                    assert not torch.isfinite(plan.flat[:-1]).all(), (mode, poison)
-                prepared[0][3, 40000] = 0.25
-    finally:
-        F.set_concurrent_weight_products(1)
-    for k in got[1]:
-        assert rel_err(got[1][k], got[0][k]) < 5e-6, (k, rel_err(got[1][k], got[0][k]))
+    in_sweep_switch(True)
+    prepared = F.quad_concurrent_prepare(*inputs)
+    plan = F.QuadConcurrentStepPlan(net, prepared, DT, dyn.params)
+    plan.launch()
+    first = plan.flat.clone()
+    plan.launch()
+    assert torch.equal(plan.flat[:-1], first[:-1])                    # reproducible
+    got = {k: N(v) for k, v in plan.named.items()}
+    for poison in (float("nan"), float("inf")):      # one trajectory's feature
+        prepared[0][3, 40000] = poison
+        loss = plan.launch()
+        torch.cuda.synchronize()
+        assert not torch.isfinite(loss).item(), poison
+        for k, v in plan.named.items():
+            assert not torch.isfinite(v).any(), (poison, k)
+        prepared[0][3, 40000] = 0.25
+    in_sweep_switch(False)
+    _, planes, _ = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
+    for k in got:
+        assert rel_err(got[k], N(planes[k])) < 5e-6, (k, rel_err(got[k], N(planes[k])))
 
 
-@pytest.mark.parametrize("mode", [1, 0], ids=["trajectory_major", "staged"])
-def test_step_gradients_add_up_over_batch_halves_beyond_32_chunks(dev, mode):
+def test_step_gradients_add_up_over_batch_halves_beyond_32_chunks(dev):
     """B = 300 011 is 1 172 workgroups = 37 chunk rows of the second stage (its
     last level sums 32 rows per round): loss and every gradient must equal
     the sum over two halves of the batch (each below 32 chunks) - sums over
@@ -315,14 +296,10 @@ def test_step_gradients_add_up_over_batch_halves_beyond_32_chunks(dev, mode):
     net = Net(15, H, 9, 4 * H, conv=1).to(dev)
     _, inputs = _case(B, 9, dev)
     dyn = FlightmareDynamics()
-    F.set_concurrent_weight_products(mode)
-    try:
-        whole = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
-        parts = [F.quad_concurrent_policy_grads(
-            net, *(t[sl].contiguous() for t in inputs), DT, dyn.params)
-            for sl in (slice(0, cut), slice(cut, B))]
-    finally:
-        F.set_concurrent_weight_products(1)
+    whole = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
+    parts = [F.quad_concurrent_policy_grads(
+        net, *(t[sl].contiguous() for t in inputs), DT, dyn.params)
+        for sl in (slice(0, cut), slice(cut, B))]
     loss = parts[0][0].double() + parts[1][0].double()
     assert abs(whole[0].double() - loss).item() <= 2e-6 * abs(loss.item())
     for k, g in whole[1].items():

@@ -780,17 +780,6 @@ def test_conv_gradient_from_window_diagonals():
     assert torch.allclose(P.sum((1, 2)), bias.grad, rtol=1e-10, atol=1e-10)
 
 
-def test_weight_product_selector_is_a_host_call_with_argument_check():
-    """apg_quad_mlp_set_weight_products: no device work, callable without a GPU;
-    anything but 0 / 1 is refused."""
-    from apg_trajectory_tracking_amd import _capi
-    lib = _capi.lib()
-    assert lib.apg_quad_mlp_set_weight_products(0) == 0
-    assert lib.apg_quad_mlp_set_weight_products(2) == -1
-    assert b"weight products" in lib.apg_last_error_string()
-    assert lib.apg_quad_mlp_set_weight_products(1) == 0          # the default
-
-
 def test_product_library_reads_no_environment():
     """nothing in the environment may change what the shipped
     kernels do - the library does not even import getenv (tuning knobs are
