@@ -198,6 +198,13 @@ SIGNATURES = {
         _P, _I, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgLstmPolicy), _I, _I, _I, _F, _F, _I, _P, _P, _P, _P,
         _P, _P, _P],
+    "apg_quad_mlp_closed_loop_env": [
+        _P, _I, _F, ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgLearntResidual),
+        ctypes.POINTER(ApgMlpPolicy), _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_closed_loop_env": [
+        _P, _I, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgLearntResidual), ctypes.POINTER(ApgLstmPolicy), _I, _I, _I,
+        _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "apg_planes_gemm_grouped": [ctypes.POINTER(ApgGemmProblem), _I, _P, _I, _P],
     "apg_to_soa": [_P, _P, _I, _I, _I, _P, _P],
     "apg_to_soa_multi": [ctypes.POINTER(ApgSoaItem), _I, _I, _P],

@@ -34,6 +34,7 @@
 #include "policy_mfma.h"
 #include "policy_mfma16.h"
 #include "quad_math.h"
+#include "learnt_residual.h"
 
 namespace apg {
 namespace {
@@ -324,11 +325,15 @@ struct LoopArgs {
   QuadConst c;
   int B, L, T, test_time;
   float thresh_div, thresh_stable;
+  int learnt;         // LearntDynamics environment (learnt_residual.h)
 };
 
+// LEARNT: the environment is a LearntDynamics (a second instantiation, so that the
+// analytic loop keeps its registers)
+template <bool LEARNT>
 __global__ __launch_bounds__(kThreads) void lstm_closed_loop_kernel(LoopArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwd16Lds);
+  fill_lds(lds, A.tables, kFwd16Lds + (LEARNT ? kLearntFloats : 0));
   const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
@@ -462,7 +467,8 @@ __global__ __launch_bounds__(kThreads) void lstm_closed_loop_kernel(LoopArgs A) 
       act[j] = fminf(fmaxf(sigmoidf_(z + L.U(hBo + j)), 0.f), 1.f);  // np.clip
       Pac.st(vrec, (k * 4 + j) * pB, act[j]);
     }
-    quad_step(s, act, c, t);
+    if (LEARNT) learnt_quad_step(s, act, c, t, lds + kFwd16Lds, hi);
+    else quad_step(s, act, c, t);
     // window row 0 is reference[cur] after get_ref_traj: project_on_ref
     float d2 = 0.f;
 #pragma unroll
@@ -802,7 +808,8 @@ using namespace apg;
 extern "C" {
 
 int apg_quad_lstm_workspace_floats(void) {
-  return kFwd16Lds > kBwd16Lds ? kFwd16Lds : kBwd16Lds;
+  // (+ the packed LearntDynamics weights of the closed-loop evaluation)
+  return (kFwd16Lds > kBwd16Lds ? kFwd16Lds : kBwd16Lds) + kLearntFloats;
 }
 
 int apg_quad_lstm_loss_partials_count(int B) {
@@ -903,7 +910,24 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
                               int *steps, float *drone, float *actions,
                               float *start_states, float *workspace,
                               apg_stream_t stream) {
+  return apg_quad_lstm_closed_loop_env(traj, L, h0, c0, dt, params, nullptr, policy, B, H,
+                                       max_steps, thresh_div, thresh_stable, test_time, div,
+                                       steps, drone, actions, start_states, workspace, stream);
+}
+
+int apg_quad_lstm_closed_loop_env(const float *traj, int L, const float *h0, const float *c0,
+                                  float dt, const ApgQuadParams *params,
+                                  const ApgLearntResidual *learnt, const ApgLstmPolicy *policy,
+                                  int B, int H, int max_steps, float thresh_div,
+                                  float thresh_stable, int test_time, float *div, int *steps,
+                                  float *drone, float *actions, float *start_states,
+                                  float *workspace, apg_stream_t stream) {
   if (int e = check_lstm(params, policy, B, H)) return e;
+  if (learnt && (!learnt->linear_at || !learnt->w1 || !learnt->b1 || !learnt->w2 ||
+                 !learnt->b2)) {
+    set_error("learnt simulator: weight pointer is NULL");
+    return APG_ERR_ARG;
+  }
   if (L <= kH || max_steps < 1) {
     set_error("closed loop needs L > %d reference rows and max_steps >= 1", kH);
     return APG_ERR_ARG;
@@ -927,14 +951,21 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
   A.c = make_const(*params, dt);
   A.B = B, A.L = L, A.T = T, A.test_time = test_time;
   A.thresh_div = thresh_div, A.thresh_stable = thresh_stable;
+  A.learnt = learnt != nullptr;
   PackArgs P;
   P.pol = *policy, P.dst = workspace;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256),
                      0, st, P);
-  hipLaunchKernelGGL(lstm_closed_loop_kernel,
-                     dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kFwd16Lds * sizeof(float), st, A);
+  if (learnt)
+    hipLaunchKernelGGL(learnt_pack_kernel, dim3((kLearntFloats + 255) / 256), dim3(256), 0, st,
+                       *learnt, workspace + kFwd16Lds);
+  const dim3 grid((B + kTrajPerBlock - 1) / kTrajPerBlock);
+  if (learnt)
+    hipLaunchKernelGGL(lstm_closed_loop_kernel<true>, grid, dim3(kThreads),
+                       (kFwd16Lds + kLearntFloats) * sizeof(float), st, A);
+  else
+    hipLaunchKernelGGL(lstm_closed_loop_kernel<false>, grid, dim3(kThreads), kFwd16Lds * sizeof(float), st, A);
   return check_launch("quad_lstm_closed_loop");
 }
 

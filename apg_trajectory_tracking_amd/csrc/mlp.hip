@@ -47,6 +47,7 @@
 #include "policy_mfma16.h"
 #include "policy_tm.h"
 #include "quad_math.h"
+#include "learnt_residual.h"
 
 namespace apg {
 namespace {
@@ -415,11 +416,16 @@ struct LoopArgs {
   QuadConst c;
   int B, L, T, test_time;
   float thresh_div, thresh_stable;
+  int learnt;         // the environment is a LearntDynamics: its packed weights
+                      // follow the policy tables (learnt_residual.h)
 };
 
+// LEARNT: the environment is a LearntDynamics (a second instantiation, so that the
+// analytic loop keeps its registers)
+template <bool LEARNT>
 __global__ __launch_bounds__(kThreads) void mlp_closed_loop_kernel(LoopArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kCfLds);
+  fill_lds(lds, A.tables, kCfLds + (LEARNT ? kLearntFloats : 0));
   const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
@@ -549,7 +555,8 @@ __global__ __launch_bounds__(kThreads) void mlp_closed_loop_kernel(LoopArgs A) {
       act[j] = fminf(fmaxf(sigmoidf_(z + L.U(hBo + j)), 0.f), 1.f);  // np.clip
       Pac.st(vrec, (k * 4 + j) * pB, act[j]);
     }
-    quad_step(s, act, c, t);
+    if (LEARNT) learnt_quad_step(s, act, c, t, lds + kCfLds, hi);
+    else quad_step(s, act, c, t);
     // window row 0 is reference[cur] after get_ref_traj: project_on_ref
     float d2 = 0.f;
 #pragma unroll
@@ -2848,7 +2855,8 @@ using namespace apg;
 extern "C" {
 
 int apg_quad_mlp_workspace_floats(void) {
-  return kCfLds > kCbLds ? kCfLds : kCbLds;
+  // (+ the packed LearntDynamics weights of the closed-loop evaluation)
+  return (kCfLds > kCbLds ? kCfLds : kCbLds) + kLearntFloats;
 }
 
 int apg_quad_mlp_loss_partials_count(int B) {
@@ -2954,7 +2962,23 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
                              int *steps, float *drone, float *actions,
                              float *start_states, float *workspace,
                              apg_stream_t stream) {
+  return apg_quad_mlp_closed_loop_env(traj, L, dt, params, nullptr, policy, B, H, max_steps,
+                                      thresh_div, thresh_stable, test_time, div, steps, drone,
+                                      actions, start_states, workspace, stream);
+}
+
+int apg_quad_mlp_closed_loop_env(const float *traj, int L, float dt,
+                                 const ApgQuadParams *params, const ApgLearntResidual *learnt,
+                                 const ApgMlpPolicy *policy, int B, int H, int max_steps,
+                                 float thresh_div, float thresh_stable, int test_time,
+                                 float *div, int *steps, float *drone, float *actions,
+                                 float *start_states, float *workspace, apg_stream_t stream) {
   if (int e = check_mlp(params, policy, B, H)) return e;
+  if (learnt && (!learnt->linear_at || !learnt->w1 || !learnt->b1 || !learnt->w2 ||
+                 !learnt->b2)) {
+    set_error("learnt simulator: weight pointer is NULL");
+    return APG_ERR_ARG;
+  }
   if (L <= kH || max_steps < 1) {
     set_error("closed loop needs L > %d reference rows and max_steps >= 1", kH);
     return APG_ERR_ARG;
@@ -2973,7 +2997,8 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
   }
   static PerDeviceOnce attr;
   if (!attr.test()) {
-    if (int e = raise_lds(mlp_closed_loop_kernel, kCfLds)) return e;
+    if (int e = raise_lds(mlp_closed_loop_kernel<true>, kCfLds + kLearntFloats)) return e;
+    if (int e = raise_lds(mlp_closed_loop_kernel<false>, kCfLds)) return e;
     attr.set();
   }
   LoopArgs A;
@@ -2982,14 +3007,21 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
   A.c = make_const(*params, dt);
   A.B = B, A.L = L, A.T = T, A.test_time = test_time;
   A.thresh_div = thresh_div, A.thresh_stable = thresh_stable;
+  A.learnt = learnt != nullptr;
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = 4;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(mlp_pack_cfwd_kernel, dim3((kCfLds + 255) / 256), dim3(256),
                      0, st, P);
-  hipLaunchKernelGGL(mlp_closed_loop_kernel,
-                     dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kCfLds * sizeof(float), st, A);
+  if (learnt)
+    hipLaunchKernelGGL(learnt_pack_kernel, dim3((kLearntFloats + 255) / 256), dim3(256), 0, st,
+                       *learnt, workspace + kCfLds);
+  const dim3 grid((B + kTrajPerBlock - 1) / kTrajPerBlock);
+  if (learnt)
+    hipLaunchKernelGGL(mlp_closed_loop_kernel<true>, grid, dim3(kThreads),
+                       (kCfLds + kLearntFloats) * sizeof(float), st, A);
+  else
+    hipLaunchKernelGGL(mlp_closed_loop_kernel<false>, grid, dim3(kThreads), kCfLds * sizeof(float), st, A);
   return check_launch("quad_mlp_closed_loop");
 }
 

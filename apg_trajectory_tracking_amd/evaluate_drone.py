@@ -27,10 +27,19 @@ class QuadEvaluator:
                  test_time=0, speed_factor=.6, train_mode="concurrent",
                  trajectory_length=501, **kwargs):
         """controller: the policy (hutter_model.Net or rnn.LSTM_NEW, conv
-        branch) or an object with a `.net`; environment: the FlightmareDynamics the
-        reference's eval_env steps with (its `.params` are used)."""
+        branch) or an object with a `.net`; environment: the dynamics the
+        reference's eval_env steps with - FlightmareDynamics (its `.params` are
+        used) or, after train_dynamics() swapped it in (scripts/train_drone.py:
+        44-45), a LearntDynamics module: the kernel then steps through the
+        action transform, the analytic step and the residual network."""
+        from .dynamics.quad_dynamics_trained import LearntDynamics
         self.net = getattr(controller, "net", controller)
         self.dynamics = getattr(environment, "dynamics", environment)
+        self.learnt = (self.dynamics if isinstance(self.dynamics, LearntDynamics)
+                       else None)
+        if self.learnt is None and isinstance(self.dynamics, torch.nn.Module):
+            raise TypeError(
+                f"no closed-loop kernel steps through {type(self.dynamics).__name__}")
         if ref_length != 10:
             raise ValueError("the fused evaluator is built for horizon 10")
         self.horizon = ref_length
@@ -51,9 +60,9 @@ class QuadEvaluator:
                                torch.randn(B, 8, device=dev))
             return F.quad_lstm_closed_loop(
                 self.net, traj, self.dt, self.dynamics.params, self.hidden[0],
-                self.hidden[1], **kw)
+                self.hidden[1], learnt=self.learnt, **kw)
         return F.quad_mlp_closed_loop(self.net, traj, self.dt,
-                                      self.dynamics.params, **kw)
+                                      self.dynamics.params, learnt=self.learnt, **kw)
 
     def reference_batch(self, nr_test, seed=None):
         """Counterpart of `Random.__init__` (random_traj.py:28-35): nr_test

@@ -1442,8 +1442,19 @@ def quad_mlp_rollout_loss(net, state0, in_ref, ref, dt, params, weights=None):
 
 
 # ------------------------------------------ batched closed-loop evaluation (N2)
+def _closed_loop_env(learnt):
+    """(struct or None, params override) for the closed-loop kernels: `learnt`
+    is a LearntDynamics module (the simulator train_dynamics() fits and
+    evaluate_model then flies, scripts/train_drone.py:44-45) or None."""
+    if learnt is None:
+        return None, None
+    model = _learnt_model(learnt)
+    return ctypes.byref(model), model
+
+
 def quad_mlp_closed_loop(net, traj, dt, params, max_steps=251, thresh_div=1.0,
-                         thresh_stable=1.0, test_time=0, want_trajectory=False):
+                         thresh_stable=1.0, test_time=0, want_trajectory=False,
+                         learnt=None):
     """`QuadEvaluator.follow_trajectory("rand")` (scripts/evaluate_drone.py:
     81-194) for a batch of reference trajectories in one launch
     (apg_quad_mlp_closed_loop).  net: hutter_model.Net(15, 10, 9, 4 or 40,
@@ -1451,7 +1462,10 @@ def quad_mlp_closed_loop(net, traj, dt, params, max_steps=251, thresh_div=1.0,
     does.  traj [B, L, 9] = (position, euler, velocity) rows, used as given
     (the reference's Random adds 3 to z: do that before the call).
     Returns dict(div [T,B], steps [B] int32, and with want_trajectory: drone
-    [T+1,12,B], actions [T,4,B], start_states [T,12,B])."""
+    [T+1,12,B], actions [T,4,B], start_states [T,12,B]).
+    learnt: a LearntDynamics module - the environment steps through it (action
+    transform, analytic step on `params`, residual network) instead of
+    FlightmareDynamics."""
     _guard_policy_inputs("closed-loop evaluation", traj=traj)
     B, L, _ = traj.shape
     H = 10
@@ -1478,11 +1492,12 @@ def quad_mlp_closed_loop(net, traj, dt, params, max_steps=251, thresh_div=1.0,
     actions = new(T, 4, B) if want_trajectory else None
     start = new(T, 12, B) if want_trajectory else None
     ws = new(lib().apg_quad_mlp_workspace_floats())
-    check(lib().apg_quad_mlp_closed_loop(
-        ptr(tr), L, float(dt), ctypes.byref(params), ctypes.byref(pol), B, H,
+    env, _keep = _closed_loop_env(learnt)
+    check(lib().apg_quad_mlp_closed_loop_env(
+        ptr(tr), L, float(dt), ctypes.byref(params), env, ctypes.byref(pol), B, H,
         int(max_steps), float(thresh_div), float(thresh_stable), int(test_time),
         ptr(div), steps.data_ptr(), ptr(drone), ptr(actions), ptr(start),
-        ptr(ws), stream_of(tr)), "apg_quad_mlp_closed_loop")
+        ptr(ws), stream_of(tr)), "apg_quad_mlp_closed_loop_env")
     out = dict(div=div, steps=steps)
     if want_trajectory:
         out.update(drone=drone, actions=actions, start_states=start)
@@ -1491,7 +1506,7 @@ def quad_mlp_closed_loop(net, traj, dt, params, max_steps=251, thresh_div=1.0,
 
 def quad_lstm_closed_loop(net, traj, dt, params, h0, c0, max_steps=251,
                           thresh_div=1.0, thresh_stable=1.0, test_time=0,
-                          want_trajectory=False):
+                          want_trajectory=False, learnt=None):
     """quad_mlp_closed_loop for an `LSTM_NEW(15, 10, 9, 4, conv=1)` controller;
     h0 / c0 [B, 8]: the hidden / cell state at the start of every run (the
     reference resets it once per evaluator and carries it through the run)."""
@@ -1519,12 +1534,13 @@ def quad_lstm_closed_loop(net, traj, dt, params, h0, c0, max_steps=251,
     actions = new(T, 4, B) if want_trajectory else None
     start = new(T, 12, B) if want_trajectory else None
     ws = new(lib().apg_quad_lstm_workspace_floats())
-    check(lib().apg_quad_lstm_closed_loop(
-        ptr(tr), L, ptr(h0s), ptr(c0s), float(dt), ctypes.byref(params),
+    env, _keep = _closed_loop_env(learnt)
+    check(lib().apg_quad_lstm_closed_loop_env(
+        ptr(tr), L, ptr(h0s), ptr(c0s), float(dt), ctypes.byref(params), env,
         ctypes.byref(pol), B, H, int(max_steps), float(thresh_div),
         float(thresh_stable), int(test_time), ptr(div), steps.data_ptr(),
         ptr(drone), ptr(actions), ptr(start), ptr(ws), stream_of(tr)),
-        "apg_quad_lstm_closed_loop")
+        "apg_quad_lstm_closed_loop_env")
     out = dict(div=div, steps=steps)
     if want_trajectory:
         out.update(drone=drone, actions=actions, start_states=start)

@@ -392,35 +392,18 @@ class TrainDrone(TrainBase):
         resampling, divergence-threshold curriculum, checkpoint, statistics."""
         from .evaluate_drone import QuadEvaluator
         n = self.net
-        # the environment flown in: `sample_in` (scripts/train_drone.py:39-49).
-        # The batched loop integrates an analytic simulator; when the chosen
-        # one is a learnt nn.Module, the analytic evaluation dynamics is flown
-        # instead (statistics and self-play states then come from the system
-        # the learnt model is fitted to).
+        # the environment flown in: `sample_in` (scripts/train_drone.py:39-49);
+        # after train_dynamics() that is the LEARNT simulator, residual
+        # network included (:44-45) - the closed-loop kernels step through it
+        # (csrc/learnt_residual.h), so self-play states, the score and the
+        # threshold ladder come from the same model as in the reference
+        from .dynamics.quad_dynamics_trained import LearntDynamics
         env = (self.eval_dynamics if self.sample_in == "eval_env"
                else self.train_dynamics)
-        if isinstance(env, torch.nn.Module):
-            # DEVIATION from the reference (ADVICE r3): its train_dynamics()
-            # flow flies the LEARNT simulator here (residual network
-            # included), so self-play states, the score and the threshold
-            # ladder come from that model; the batched closed-loop kernel
-            # integrates analytic simulators only, so the evaluation dynamics
-            # - the system the learnt model is being fitted to - is flown
-            # instead.  Said once per trainer, recorded in the results.
-            if not getattr(self, "_warned_env_substitution", False):
-                import warnings
-                warnings.warn(
-                    f"evaluate_model: sample_in={self.sample_in!r} selects the "
-                    f"learnt simulator {type(env).__name__}; the batched "
-                    "closed-loop evaluation flies the analytic eval_dynamics "
-                    "instead (self-play states and scores come from it)")
-                self._warned_env_substitution = True
-                self.results_dict["evaluation_env"].append(
-                    "eval_dynamics (substituted for the learnt train_dynamics)")
-            env = self.eval_dynamics
         if not (isinstance(n, (Net, LSTM_NEW)) and n.conv and self.horizon == 10
                 and hasattr(env, "params")
-                and not isinstance(env, torch.nn.Module)):
+                and (isinstance(env, LearntDynamics)
+                     or not isinstance(env, torch.nn.Module))):
             return None          # no fused evaluator for this architecture
         self.config.setdefault("thresh_div", self.thresh_div_start)
         self.config.setdefault("thresh_stable", self.thresh_stable_start)

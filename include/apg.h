@@ -500,6 +500,21 @@ int apg_quad_mlp_closed_loop(const float *traj, int L, float dt,
                              int *steps, float *drone, float *actions,
                              float *start_states, float *workspace,
                              apg_stream_t stream);
+/* ... with the environment a caller chooses: `learnt` NULL = FlightmareDynamics
+ * (the function above), else the LEARNT simulator of train_dynamics()
+ * (LearntDynamics, neural_control/dynamics/quad_dynamics_trained.py:10-69:
+ * action transform, the analytic step on `params`, the relu residual) - what
+ * QuadEvaluator flies after scripts/train_drone.py:44-45 swapped
+ * eval_env.dynamics for the train dynamics. */
+int apg_quad_mlp_closed_loop_env(const float *traj, int L, float dt,
+                                 const ApgQuadParams *params,
+                                 const ApgLearntResidual *learnt,
+                                 const ApgMlpPolicy *policy, int B, int H,
+                                 int max_steps, float thresh_div,
+                                 float thresh_stable, int test_time, float *div,
+                                 int *steps, float *drone, float *actions,
+                                 float *start_states, float *workspace,
+                                 apg_stream_t stream);
 
 /* The same closed loop for the LSTM controller (LSTM_NEW): hidden / cell
  * state h0 / c0 [8][B] carried through all steps (QuadEvaluator resets it once,
@@ -514,6 +529,16 @@ int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,
                               int *steps, float *drone, float *actions,
                               float *start_states, float *workspace,
                               apg_stream_t stream);
+int apg_quad_lstm_closed_loop_env(const float *traj, int L, const float *h0,
+                                  const float *c0, float dt,
+                                  const ApgQuadParams *params,
+                                  const ApgLearntResidual *learnt,
+                                  const ApgLstmPolicy *policy, int B, int H,
+                                  int max_steps, float thresh_div,
+                                  float thresh_stable, int test_time, float *div,
+                                  int *steps, float *drone, float *actions,
+                                  float *start_states, float *workspace,
+                                  apg_stream_t stream);
 
 /* "Planes x planes" reduction GEMM on the matrix cores (fp32 accuracy):
  *   C[m*ldc + j] = sum_{s<S} sum_{n<N} A[(m*S + s)*N + n] * B[bplane(j,s)*N + n]

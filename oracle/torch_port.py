@@ -131,6 +131,31 @@ class QuadOracle:
         return torch.cat((new_pos, new_att, new_vel, new_omega), dim=1)
 
 
+class LearntQuadOracle:
+    """LearntDynamics.forward, quad_dynamics_trained.py:10-69: the 4 x 4 action
+    transform (:62-64), the Flightmare step with the kinv / inertia of
+    CONSTRUCTION time (:48-50: torch.diag copies the step keeps using), the
+    residual network 16 -> 64 -> 12 on [state, transformed action] (:52-58)
+    added to the new state (:66-69).  `weights`: the module's state_dict
+    (linear_at, linear_state_1/2.weight/.bias; the physical parameters in it do
+    not enter the step)."""
+
+    def __init__(self, weights, initial_params=None, dtype=torch.float32):
+        self.base = QuadOracle(modified_params=initial_params, dtype=dtype)
+        t = lambda k: torch.as_tensor(weights[k]).to(dtype)
+        self.A = t("linear_at")
+        self.w1, self.b1 = t("linear_state_1.weight"), t("linear_state_1.bias")
+        self.w2, self.b2 = t("linear_state_2.weight"), t("linear_state_2.bias")
+        self.dtype = dtype
+
+    def __call__(self, state, action, dt):
+        state, action = state.to(self.dtype), action.to(self.dtype)
+        at = (self.A @ action.unsqueeze(2))[:, :, 0]
+        new_state = self.base(state, at, dt)
+        hidden = torch.relu(torch.cat((state, at), dim=1) @ self.w1.t() + self.b1)
+        return new_state + hidden @ self.w2.t() + self.b2
+
+
 def quad_mpc_loss(states, ref_states, action_seq):
     """neural_control/drone_loss.py:12-39."""
     prior = torch.tensor([.5, .5, .5], dtype=states.dtype)

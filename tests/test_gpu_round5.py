@@ -305,3 +305,143 @@ def test_split_graph_step_through_a_live_rccl_group_of_one(dev):
     finally:
         dist.destroy_process_group()
         F._STATIC_PLANES.entries.clear()
+
+
+# ---------------------------------------------------------------- item 5
+def _g17(dev):
+    """(golden G17, shipped controller, LSTM controller + its start state, the
+    package's LearntDynamics carrying the fixture's fitted simulator)."""
+    import ast
+    from apg_trajectory_tracking_amd.checkpoint import build_policy
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_trained import LearntDynamics
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    g, g11, ck = (load_golden("closed_loop_learnt.npz"), load_golden("closed_loop.npz"),
+                  load_golden("checkpoints.npz"))
+    net = build_policy("quad", {k[len("quad.w."):]: torch.from_numpy(ck[k])
+                                for k in ck.files if k.startswith("quad.w.")}).to(dev)
+    lstm = LSTM_NEW(15, 10, 9, 4, conv=1)
+    lstm.load_state_dict({k[len("lstm.w."):]: torch.from_numpy(g11[k])
+                          for k in g11.files if k.startswith("lstm.w.")})
+    init = {kv.split("=")[0]: ast.literal_eval(kv.split("=")[1]) for kv in g["init"]}
+    dyn = LearntDynamics(initial_params=init)
+    dyn.load_state_dict({k[len("dyn."):]: torch.from_numpy(g[k]) for k in g.files
+                         if k.startswith("dyn.")})
+    hidden = (torch.from_numpy(g11["lstm.h0"]).to(dev), torch.from_numpy(g11["lstm.c0"]).to(dev))
+    return g, net, lstm.to(dev), hidden, dyn.to(dev)
+
+
+@pytest.mark.parametrize("case", ["train", "test", "tight", "lstm_train", "lstm_test"])
+def test_closed_loop_through_the_learnt_simulator_matches_reference_evaluator(dev, case):
+    """G17 / N2 x N3 (VERDICT r4 missing #2): the closed-loop kernels stepping
+    through LearntDynamics - action transform, Flightmare step with the
+    construction-time kinv / inertia, residual network - against the REAL
+    QuadEvaluator.follow_trajectory over QuadRotorEnvBase(LearntDynamics)
+    (scripts/train_drone.py:44-45, 205-238), shipped controller and LSTM;
+    through QuadEvaluator, as TrainDrone.evaluate_model calls it."""
+    from apg_trajectory_tracking_amd import functional as F
+    from apg_trajectory_tracking_amd.evaluate_drone import QuadEvaluator
+    g, net, lstm, hidden, dyn = _g17(dev)
+    traj = torch.from_numpy(g["trajs"]).to(dev).clone()
+    traj[:, :, 2] += 3          # Random.__init__, random_traj.py:34
+    kw = dict(max_steps=int(g["max_steps"]), thresh_div=float(g[f"{case}.thresh_div"]),
+              thresh_stable=float(g[f"{case}.thresh_stable"]),
+              test_time=int(g[f"{case}.test_time"]), want_trajectory=True)
+    if case.startswith("lstm"):
+        out = F.quad_lstm_closed_loop(lstm, traj, float(g["dt"]), dyn.params, *hidden,
+                                      learnt=dyn, **kw)
+    else:
+        out = F.quad_mlp_closed_loop(net, traj, float(g["dt"]), dyn.params, learnt=dyn, **kw)
+    for i in range(traj.shape[0]):
+        n = len(g[f"{case}.{i}.div"])
+        assert int(out["steps"][i]) == n, (case, i)
+        assert rel_err(N(out["drone"][:n + 1, :, i]), g[f"{case}.{i}.drone"]) < 1e-4
+        assert np.abs(N(out["div"][:n, i]) - g[f"{case}.{i}.div"]).max() < 2e-4
+        want = g[f"{case}.{i}.actions"]
+        want = want[:, 0] if want.ndim == 3 else want
+        assert rel_err(N(out["actions"][:n, :, i]), want) < 1e-4
+    # the evaluator object hands the learnt simulator on by itself
+    ctrl = lstm if case.startswith("lstm") else net
+    ev = QuadEvaluator(ctrl, dyn, ref_length=10, dt=float(g["dt"]),
+                       test_time=kw["test_time"])
+    assert ev.learnt is dyn
+    if case.startswith("lstm"):
+        ev.hidden = hidden
+    _, drone, divs, _ = ev.follow_trajectory(
+        "rand", max_nr_steps=kw["max_steps"], thresh_stable=kw["thresh_stable"],
+        thresh_div=kw["thresh_div"], trajectories=traj)
+    for i in range(traj.shape[0]):
+        assert len(divs[i]) == len(g[f"{case}.{i}.div"])
+        assert np.abs(N(divs[i]) - g[f"{case}.{i}.div"]).max() < 2e-4
+    # the residual and the action transform matter in this fixture
+    if case == "train":
+        plain = F.quad_mlp_closed_loop(net, traj, float(g["dt"]), dyn.params, **kw)
+        n = len(g["train.0.div"])
+        assert rel_err(N(plain["drone"][:n + 1, :, 0]), g["train.0.drone"]) > 1e-2
+
+
+def test_closed_loop_learnt_simulator_large_batch_vs_oracle(dev):
+    """The learnt-simulator closed loop over several workgroups with a ragged
+    tail, MLP and LSTM controller, against the batched oracle loop."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from oracle import torch_port as tp
+    g, net, lstm, _, dyn = _g17(dev)
+    weights = {k[len("dyn."):]: g[k] for k in g.files if k.startswith("dyn.")}
+    import ast
+    init = {kv.split("=")[0]: ast.literal_eval(kv.split("=")[1]) for kv in g["init"]}
+    B, L, steps = 300, 40, 30
+    traj = synthetic.quad_eval_trajectories(B, L, 0.1, seed=9)
+    lifted = traj.clone()
+    lifted[:, :, 2] += 3
+    gen = torch.Generator().manual_seed(4)
+    h0, c0 = torch.randn(B, 8, generator=gen), torch.randn(B, 8, generator=gen)
+    for ctrl, name in ((net, "mlp"), (lstm, "lstm")):
+        cpu = __import__("copy").deepcopy(ctrl).cpu()
+        if name == "lstm":
+            cpu.hidden_state, cpu.cell_state = h0.clone(), c0.clone()
+            out = F.quad_lstm_closed_loop(ctrl, lifted.to(dev), 0.1, dyn.params, h0.to(dev),
+                                          c0.to(dev), max_steps=steps, thresh_div=0.4,
+                                          learnt=dyn)
+        else:
+            out = F.quad_mlp_closed_loop(ctrl, lifted.to(dev), 0.1, dyn.params,
+                                         max_steps=steps, thresh_div=0.4, learnt=dyn)
+        ref = tp.quad_closed_loop(cpu, tp.LearntQuadOracle(weights, init), traj, 0.1, 10,
+                                  steps, 0.4, 1.0, 0)
+        same = [i for i in range(B) if int(out["steps"][i]) == int(ref["steps"][i])]
+        assert len(same) > 0.97 * B, name
+        bad = [i for i in same
+               if np.abs(N(out["div"][:int(ref["steps"][i]), i])
+                         - ref["div"][i, :int(ref["steps"][i])].numpy()).max() > 2e-3]
+        assert len(bad) <= 0.03 * B, (name, len(bad))
+
+
+def test_evaluate_model_flies_the_learnt_simulator_without_a_substitution(dev):
+    """TrainDrone.evaluate_model with sample_in = "train_env" and a learnt
+    training simulator (the reference's train_dynamics() flow): no warning, and
+    the statistics are those of the learnt simulator's closed loop - not those
+    of the analytic evaluation dynamics rounds 3 / 4 substituted."""
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.evaluate_drone import QuadEvaluator
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    g, net, _, _, dyn = _g17(dev)
+    cfg = dict(QUAD_CFG, batch_size=32, epoch_size=64, self_play=0, nr_test=64,
+               sample_in="train_env", max_steps=40, thresh_div_start=0.3,
+               thresh_div_end=2.0, thresh_stable_start=1.0)
+    t = TrainDrone(dyn, FlightmareDynamics(), cfg)
+    t.initialize_model(device=dev, seed=2)
+    t.net = net
+    t.save_path = "/tmp/apg_eval_test_learnt"
+    torch.manual_seed(12)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", UserWarning)    # (the substitution's category)
+        res = t.evaluate_model(0)
+    assert res is not None
+    stats = {}
+    for name, env in (("learnt", dyn), ("analytic", FlightmareDynamics())):
+        torch.manual_seed(12)
+        stats[name] = QuadEvaluator(net, env, ref_length=10, dt=0.1).run_eval(
+            "rand", nr_test=64, max_steps=40, thresh_div=0.3, thresh_stable=1.0)
+    assert t.results_dict["mean_divergence"][-1] == pytest.approx(stats["learnt"][4])
+    assert t.results_dict["mean_success"][-1] == pytest.approx(stats["learnt"][0])
+    assert abs(stats["analytic"][4] - stats["learnt"][4]) > 1e-3 * abs(stats["learnt"][4])
+    assert "evaluation_env" not in t.results_dict or not t.results_dict["evaluation_env"]

@@ -286,12 +286,14 @@ def test_flat_gradient_layout_and_new_argument_errors():
 
 
 def _oracle_closed_loop(net_, traj, dt, params, max_steps=251, thresh_div=1.0,
-                        thresh_stable=1.0, test_time=0, want_trajectory=False):
+                        thresh_stable=1.0, test_time=0, want_trajectory=False,
+                        learnt=None):
     """Stand-in for functional.quad_mlp_closed_loop on CPU: the batched oracle
     loop (test infrastructure) in the kernel's output format."""
     from oracle import torch_port as tp
     flat = traj.clone()       # the kernel takes the lifted reference, the oracle
     flat[:, :, 2] -= 3        # lifts it itself (random_traj.py:34)
+    assert learnt is None
     o = tp.quad_closed_loop(net_, tp.QuadOracle(), flat, dt, 10, max_steps,
                             thresh_div, thresh_stable, test_time)
     T_ = min(max_steps, traj.shape[1] + 1)
