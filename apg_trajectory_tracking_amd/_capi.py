@@ -228,6 +228,12 @@ SIGNATURES = {
         ctypes.POINTER(ApgWingPolicy), ctypes.POINTER(ctypes.c_float),
         ctypes.POINTER(ctypes.c_float), _F, _I, _I, _I, _F, _F, _I, _P, _P, _P,
         _P, _P, _P, _P, _P],
+    "apg_wing_mlp_closed_loop_env": [
+        _P, _I, _P, _F, ctypes.POINTER(ApgWingParams), ctypes.POINTER(ctypes.c_float),
+        ctypes.POINTER(ApgLearntResidual),
+        ctypes.POINTER(ApgWingPolicy), ctypes.POINTER(ctypes.c_float),
+        ctypes.POINTER(ctypes.c_float), _F, _I, _I, _I, _F, _F, _I, _P, _P, _P,
+        _P, _P, _P, _P, _P],
     "apg_planes_gemm_workspace_floats": [_I, _I, _I, _I],
     "apg_planes_gemm_default_wgs": [_I, _I, _I, _I],
     "apg_planes_gemm_multi_workspace_floats": [ctypes.POINTER(ApgGemmProblem), _I],

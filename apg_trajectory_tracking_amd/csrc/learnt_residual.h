@@ -26,28 +26,15 @@ static __global__ __launch_bounds__(256) void learnt_pack_kernel(ApgLearntResidu
   if (t < 64) dst[kLrB1 + t] = m.b1[t];
   if (t < 768) dst[kLrW2 + t] = m.w2[(t % 12) * 64 + t / 12];
   if (t < 12) dst[kLrB2 + t] = m.b2[t];
-  if (t < 16) dst[kLrA + t] = m.linear_at[t];
+  if (t < 16) dst[kLrA + t] = m.linear_at ? m.linear_at[t] : (t % 5 == 0 ? 1.f : 0.f);
   if (t >= kLrA + 16 && t < kLearntFloats) dst[t] = 0.f;
 }
 
-// one environment step through the learnt simulator; `lr`: the packed weights
-// in LDS; every lane of a trajectory's two half-waves ends with the same state
-__device__ __forceinline__ void learnt_quad_step(float (&s)[12], const float (&act)[4],
-                                                 const QuadConst &c, const Trig &t,
-                                                 const float *lr, int hi) {
+// s += W2 relu(W1 x + b1) + b2 for x = [state before the step, action]: the 64
+// hidden units split between the two half-waves of a trajectory
+__device__ __forceinline__ void learnt_residual_add(float (&s)[12], const float (&x)[16],
+                                                    const float *lr, int hi) {
   typedef float f32x4_lr __attribute__((ext_vector_type(4)));
-  float at[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x4_lr a = *reinterpret_cast<const f32x4_lr *>(lr + kLrA + 4 * i);
-    at[i] = fmaf(a[3], act[3], fmaf(a[2], act[2], fmaf(a[1], act[1], a[0] * act[0])));
-  }
-  float x[16];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) x[i] = s[i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[12 + i] = at[i];
-  quad_step(s, at, c, t);
   float add[12];
 #pragma unroll
   for (int o = 0; o < 12; ++o) add[o] = 0.f;
@@ -74,6 +61,26 @@ __device__ __forceinline__ void learnt_quad_step(float (&s)[12], const float (&a
   }
 #pragma unroll
   for (int o = 0; o < 12; ++o) s[o] += add[o] + other_half(add[o]) + lr[kLrB2 + o];
+}
+
+// one environment step through the learnt quadrotor simulator; `lr`: the packed
+// weights in LDS; both half-waves of a trajectory end with the same state
+__device__ __forceinline__ void learnt_quad_step(float (&s)[12], const float (&act)[4],
+                                                 const QuadConst &c, const Trig &t,
+                                                 const float *lr, int hi) {
+  typedef float f32x4_lr __attribute__((ext_vector_type(4)));
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x[i] = s[i];
+  float at[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4_lr a = *reinterpret_cast<const f32x4_lr *>(lr + kLrA + 4 * i);
+    x[12 + i] = at[i] =
+        fmaf(a[3], act[3], fmaf(a[2], act[2], fmaf(a[1], act[1], a[0] * act[0])));
+  }
+  quad_step(s, at, c, t);
+  learnt_residual_add(s, x, lr, hi);
 }
 
 }  // namespace apg

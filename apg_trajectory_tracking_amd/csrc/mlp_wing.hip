@@ -20,6 +20,7 @@
 #include "policy_mfma.h"
 #include "policy_mfma16.h"
 #include "wing_math.h"
+#include "learnt_residual.h"
 
 namespace apg {
 namespace {
@@ -227,7 +228,7 @@ struct WingLoopArgs {
   float *drone;          // [T][16][B] or NULL: state after the step + action
   float *seen;           // [T][15][B] or NULL: state the policy saw + its target
   const float *tables;
-  WingConst k;
+  WingGeneralConst k;         // (the full inertia matrix: LearntFixedWingDynamics only)
   float mean[kNS], std[kNS];  // entries 3..11 of the data set's mean / std
   float vec_len, horizon;     // 12 * dt of the data set, its horizon
   float thresh_div, thresh_stable, des_speed;
@@ -251,9 +252,17 @@ __device__ __forceinline__ float dist3(const float (&a)[3], const float (&b)[3])
   return sqrtf(x * x + y * y + z * z);
 }
 
+// LEARNT: the environment steps through LearntFixedWingDynamics.forward
+// (neural_control/dynamics/fixed_wing_dynamics.py:270-326): simulate_fixed_wing on
+// its CURRENT parameters - the 3 x 3 inertia in full - plus the residual network
+// on [state, action] (learnt_residual.h, weights behind the policy tables); what
+// SimpleWingEnv(train_dynamics) is after train_dynamics() (scripts/
+// train_fixed_wing.py:42-43).  A second instantiation: the analytic loop keeps
+// its registers.
+template <bool LEARNT>
 __global__ __launch_bounds__(kThreads) void wing_closed_loop_kernel(WingLoopArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwd16Lds);
+  fill_lds(lds, A.tables, kFwd16Lds + (LEARNT ? kLearntFloats : 0));
   const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
@@ -366,7 +375,17 @@ __global__ __launch_bounds__(kThreads) void wing_closed_loop_kernel(WingLoopArgs
     }
 
     // SimpleWingEnv.step
-    wing_step(s, act, A.k);
+    if (LEARNT) {
+      float x[16];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) x[i] = s[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[12 + j] = act[j];
+      wing_step(s, act, A.k);
+      learnt_residual_add(s, x, lds + kFwd16Lds, hi);
+    } else {
+      wing_step(s, act, static_cast<const WingConst &>(A.k));
+    }
 #pragma unroll
     for (int i = 0; i < 12; ++i) obs[i] = s[i];
     const bool stable =
@@ -614,7 +633,8 @@ using namespace apg;
 extern "C" {
 
 int apg_wing_policy_workspace_floats(void) {
-  return kFwd16Lds > kBwd16Lds ? kFwd16Lds : kBwd16Lds;
+  // (+ the packed residual network of a learnt environment's closed loop)
+  return (kFwd16Lds > kBwd16Lds ? kFwd16Lds : kBwd16Lds) + kLearntFloats;
 }
 
 int apg_wing_policy_fwd(const float *feat, const float *ref_in,
@@ -688,7 +708,29 @@ int apg_wing_mlp_closed_loop(const float *targets, int n_targets,
                              float *div_linear, float *div_pass, float *div_fail,
                              int *steps, float *drone, float *seen,
                              float *workspace, apg_stream_t stream) {
+  return apg_wing_mlp_closed_loop_env(targets, n_targets, state0, dt, params, nullptr, nullptr,
+                                      policy, mean, std, data_dt, data_horizon, B, max_steps,
+                                      thresh_div, thresh_stable, test_time, div_linear,
+                                      div_pass, div_fail, steps, drone, seen, workspace, stream);
+}
+
+int apg_wing_mlp_closed_loop_env(const float *targets, int n_targets, const float *state0,
+                                 float dt, const ApgWingParams *params, const float *inertia,
+                                 const ApgLearntResidual *learnt, const ApgWingPolicy *policy,
+                                 const float *mean, const float *std, float data_dt,
+                                 int data_horizon, int B, int max_steps, float thresh_div,
+                                 float thresh_stable, int test_time, float *div_linear,
+                                 float *div_pass, float *div_fail, int *steps, float *drone,
+                                 float *seen, float *workspace, apg_stream_t stream) {
   if (int e = check_wing_policy(policy, B)) return e;
+  if ((inertia != nullptr) != (learnt != nullptr)) {
+    set_error("learnt environment: `inertia` and `learnt` come together");
+    return APG_ERR_ARG;
+  }
+  if (learnt && (!learnt->w1 || !learnt->b1 || !learnt->w2 || !learnt->b2)) {
+    set_error("learnt simulator: weight pointer is NULL");
+    return APG_ERR_ARG;
+  }
   if (!params || !mean || !std) {
     set_error("params / mean / std is NULL");
     return APG_ERR_ARG;
@@ -711,13 +753,16 @@ int apg_wing_mlp_closed_loop(const float *targets, int n_targets,
   }
   static PerDeviceOnce attr;
   if (!attr.test()) {
-    if (int e = raise_lds(wing_closed_loop_kernel, kFwd16Lds)) return e;
+    if (int e = raise_lds(wing_closed_loop_kernel<false>, kFwd16Lds)) return e;
+    if (int e = raise_lds(wing_closed_loop_kernel<true>, kFwd16Lds + kLearntFloats)) return e;
     attr.set();
   }
   WingLoopArgs A = {};
   A.targets = targets, A.state0 = state0, A.div_linear = div_linear;
   A.div_pass = div_pass, A.div_fail = div_fail, A.steps = steps, A.drone = drone;
-  A.seen = seen, A.tables = workspace, A.k = make_const(*params, dt);
+  A.seen = seen, A.tables = workspace;
+  if (learnt) A.k = make_general_const(*params, dt, inertia);
+  else static_cast<WingConst &>(A.k) = make_const(*params, dt);
   for (int j = 0; j < kNS; ++j) A.mean[j] = mean[3 + j], A.std[j] = std[3 + j];
   // `ref_vector * vec_len_per_step * (i + 1)`: the Python double 12 * dt enters
   // the float32 tensor product rounded to float32 (dataset.py:312-319)
@@ -729,9 +774,16 @@ int apg_wing_mlp_closed_loop(const float *targets, int n_targets,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wing_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256), 0,
                      st, P);
-  hipLaunchKernelGGL(wing_closed_loop_kernel,
-                     dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kFwd16Lds * sizeof(float), st, A);
+  const dim3 grid((B + kTrajPerBlock - 1) / kTrajPerBlock);
+  if (learnt) {
+    hipLaunchKernelGGL(learnt_pack_kernel, dim3((kLearntFloats + 255) / 256), dim3(256), 0, st,
+                       *learnt, workspace + kFwd16Lds);
+    hipLaunchKernelGGL(wing_closed_loop_kernel<true>, grid, dim3(kThreads),
+                       (kFwd16Lds + kLearntFloats) * sizeof(float), st, A);
+  } else {
+    hipLaunchKernelGGL(wing_closed_loop_kernel<false>, grid, dim3(kThreads),
+                       kFwd16Lds * sizeof(float), st, A);
+  }
   return check_launch("wing_mlp_closed_loop");
 }
 

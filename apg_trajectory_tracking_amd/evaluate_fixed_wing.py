@@ -43,11 +43,20 @@ class FixedWingEvaluator:
                  thresh_div=10, thresh_stable=0.8, test_time=0, **kwargs):
         """controller: a FixedWingNetWrapper; env: the FixedWingDynamics the
         reference's SimpleWingEnv steps with (or an object with `.dynamics`);
-        its `.params` are used."""
+        its `.params` are used - or, after train_dynamics() (scripts/
+        train_fixed_wing.py:42-43), a LearntFixedWingDynamics module: the kernel
+        then steps through its physics on the module's current parameters plus
+        its residual network."""
+        from .dynamics.fixed_wing_dynamics import LearntFixedWingDynamics
         if render:
             raise ValueError("there is no renderer on the GPU path")
         self.controller = controller
         self.dynamics = getattr(env, "dynamics", env)
+        self.learnt = (self.dynamics
+                       if isinstance(self.dynamics, LearntFixedWingDynamics) else None)
+        if self.learnt is None and isinstance(self.dynamics, torch.nn.Module):
+            raise TypeError(
+                f"no closed-loop kernel steps through {type(self.dynamics).__name__}")
         self.dt = dt
         self.horizon = horizon
         self.thresh_div = thresh_div
@@ -67,7 +76,7 @@ class FixedWingEvaluator:
             data_horizon=d.horizon, max_steps=max_steps,
             thresh_div=self.thresh_div, thresh_stable=self.thresh_stable,
             test_time=int(bool(self.test_time)),
-            want_trajectory=want_trajectory)
+            want_trajectory=want_trajectory, learnt=self.learnt)
 
     def _div_target(self, out, max_steps):
         """fly_to_point's div_target list per flight: what each step appended

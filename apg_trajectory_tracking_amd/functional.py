@@ -1550,7 +1550,7 @@ def quad_lstm_closed_loop(net, traj, dt, params, h0, c0, max_steps=251,
 def wing_mlp_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
                          data_horizon=10, state0=None, max_steps=1000,
                          thresh_div=10.0, thresh_stable=0.8, test_time=0,
-                         want_trajectory=False):
+                         want_trajectory=False, learnt=None):
     """`FixedWingEvaluator.fly_to_point` (scripts/evaluate_fixed_wing.py:45-131)
     for a batch of target lists in one launch (apg_wing_mlp_closed_loop).
     net: hutter_model.Net(9, 1, 3, 4*k, conv=False) - the first action of the
@@ -1561,7 +1561,11 @@ def wing_mlp_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
     Returns dict(div_linear [T,B], div_pass [T,B], div_fail [T,B] (-1 where
     fly_to_point appends nothing to div_target), steps [B] int32, and with
     want_trajectory: drone [T,16,B] (state after the step + action), seen
-    [T,15,B] (state the policy saw + its target))."""
+    [T,15,B] (state the policy saw + its target)).
+    learnt: a LearntFixedWingDynamics module - the environment steps through its
+    forward (the physics on the CURRENT values of its parameters, `params` is
+    not read, plus the residual network), one device-to-host read of its 50
+    physical numbers per call."""
     _guard_policy_inputs("closed-loop evaluation", targets=targets)
     B, n_targets, _ = targets.shape
     dev = targets.device
@@ -1592,13 +1596,29 @@ def wing_mlp_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
     drone = new(T, 16, B) if want_trajectory else None
     seen = new(T, 15, B) if want_trajectory else None
     ws = new(lib().apg_wing_policy_workspace_floats())
-    check(lib().apg_wing_mlp_closed_loop(
-        ptr(tg), n_targets, ptr(s0), float(dt), ctypes.byref(params),
+    I9 = model = None
+    if learnt is not None:
+        host = torch.cat((learnt._theta().detach().reshape(-1).float(),
+                          learnt.I.detach().reshape(-1).float())).cpu().tolist()
+        params = _capi.ApgWingParams(*host[:41])
+        I9 = (ctypes.c_float * 9)(*host[41:])
+        res = [learnt.linear_state_1.weight, learnt.linear_state_1.bias,
+               learnt.linear_state_2.weight, learnt.linear_state_2.bias]
+        for t in res:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise RuntimeError("LearntFixedWingDynamics tensors must be contiguous "
+                                   "fp32 device tensors (module.to('cuda'))")
+        if tuple(res[0].shape) != (64, 16) or tuple(res[2].shape) != (12, 64):
+            raise ValueError("closed loop expects the 16 -> 64 -> 12 residual network")
+        model = _capi.ApgLearntResidual(None, *[t.data_ptr() for t in res])
+    check(lib().apg_wing_mlp_closed_loop_env(
+        ptr(tg), n_targets, ptr(s0), float(dt), ctypes.byref(params), I9,
+        None if model is None else ctypes.byref(model),
         ctypes.byref(pol), mean, std, float(data_dt), int(data_horizon), B, T,
         float(thresh_div), float(thresh_stable), int(test_time),
         ptr(div_linear), ptr(div_pass), ptr(div_fail), steps.data_ptr(),
         ptr(drone), ptr(seen), ptr(ws), stream_of(tg)),
-        "apg_wing_mlp_closed_loop")
+        "apg_wing_mlp_closed_loop_env")
     out = dict(div_linear=div_linear, div_pass=div_pass, div_fail=div_fail,
                steps=steps)
     if want_trajectory:

@@ -92,29 +92,16 @@ class TrainFixedWing(TrainBase):
         flights for the score, resampling, the divergence / stability
         threshold ladders, checkpoint, statistics."""
         from .evaluate_fixed_wing import FixedWingEvaluator, FixedWingNetWrapper
+        from .dynamics.fixed_wing_dynamics import LearntFixedWingDynamics
         n = self.net
         env = (self.eval_dynamics if self.sample_in == "eval_env"
                else self.train_dynamics)
-        if isinstance(env, torch.nn.Module):
-            # DEVIATION from the reference (ADVICE r3): its train_dynamics()
-            # flow flies the LEARNT simulator here (residual network
-            # included), so self-play states, the score and the threshold
-            # ladder come from that model; the batched closed-loop kernel
-            # integrates analytic simulators only, so the evaluation dynamics
-            # - the system the learnt model is being fitted to - is flown
-            # instead.  Said once per trainer, recorded in the results.
-            if not getattr(self, "_warned_env_substitution", False):
-                import warnings
-                warnings.warn(
-                    f"evaluate_model: sample_in={self.sample_in!r} selects the "
-                    f"learnt simulator {type(env).__name__}; the batched "
-                    "closed-loop evaluation flies the analytic eval_dynamics "
-                    "instead (self-play states and scores come from it)")
-                self._warned_env_substitution = True
-                self.results_dict["evaluation_env"].append(
-                    "eval_dynamics (substituted for the learnt train_dynamics)")
-            env = self.eval_dynamics
+        # (after train_dynamics() `env` is the LEARNT simulator, residual network
+        # included, scripts/train_fixed_wing.py:42-43: the closed-loop kernel
+        # steps through it, csrc/learnt_residual.h)
         if not (isinstance(n, Net) and not n.conv and hasattr(env, "params")
+                and (isinstance(env, LearntFixedWingDynamics)
+                     or not isinstance(env, torch.nn.Module))
                 and hasattr(self.state_data, "add_eval_data")
                 and n.fc1.weight.shape == (64, 128)):
             return None          # no fused evaluator for this architecture

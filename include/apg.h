@@ -692,6 +692,25 @@ int apg_wing_mlp_closed_loop(const float *targets, int n_targets,
                              float *div_linear, float *div_pass, float *div_fail,
                              int *steps, float *drone, float *seen,
                              float *workspace, apg_stream_t stream);
+/* ... with a LEARNT environment (LearntFixedWingDynamics.forward,
+ * neural_control/dynamics/fixed_wing_dynamics.py:270-326 - what
+ * SimpleWingEnv(train_dynamics) steps with after train_dynamics(),
+ * scripts/train_fixed_wing.py:42-43): `params` = the CURRENT values of the
+ * module's parameters, `inertia` = its 3x3 parameter `I` (HOST array of 9,
+ * row-major, used in full, as apg_wing_learnt_step_fwd), `learnt` = the residual
+ * network on [state, action] (linear_at is not read).  inertia and learnt both
+ * NULL: the function above. */
+int apg_wing_mlp_closed_loop_env(const float *targets, int n_targets,
+                                 const float *state0, float dt,
+                                 const ApgWingParams *params, const float *inertia,
+                                 const ApgLearntResidual *learnt,
+                                 const ApgWingPolicy *policy, const float *mean,
+                                 const float *std, float data_dt, int data_horizon,
+                                 int B, int max_steps, float thresh_div,
+                                 float thresh_stable, int test_time,
+                                 float *div_linear, float *div_pass, float *div_fail,
+                                 int *steps, float *drone, float *seen,
+                                 float *workspace, apg_stream_t stream);
 
 /* Weights of fixed_wing_mpc_loss, neural_control/drone_loss.py:72-82
  * (reference values: pos 10, action 0.1). */

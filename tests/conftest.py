@@ -191,7 +191,7 @@ def wing_loop_case(g, case):
 def oracle_wing_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
                             data_horizon=10, state0=None, max_steps=1000,
                             thresh_div=10.0, thresh_stable=0.8, test_time=0,
-                            want_trajectory=False, modified_params=None):
+                            want_trajectory=False, modified_params=None, learnt=None):
     """The oracle's closed loop behind the signature and the output layout of
     functional.wing_mlp_closed_loop: lets the CPU suite run the evaluator's
     host logic without the kernel (tests only)."""
@@ -199,7 +199,8 @@ def oracle_wing_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
     import torch
     from oracle import torch_port as tp
     out = tp.wing_closed_loop(
-        copy.deepcopy(net).cpu(), tp.WingOracle(modified_params=modified_params),
+        copy.deepcopy(net).cpu(),
+        learnt if learnt is not None else tp.WingOracle(modified_params=modified_params),
         targets.cpu(), dt, mean, std, data_dt, data_horizon, max_steps, thresh_div,
         thresh_stable, test_time, state0=None if state0 is None else state0.cpu())
     res = dict(div_linear=out["div_linear"].t().float(),

@@ -1250,13 +1250,97 @@ def g17_closed_loop_learnt():
     save("closed_loop_learnt.npz", **out)
 
 
+def g18_wing_closed_loop_learnt():
+    """G15's flights through the LEARNT fixed-wing simulator - the reference's
+    train_dynamics() flow with `sample_in = "train_env"`: SimpleWingEnv(
+    train_dynamics) with a LearntFixedWingDynamics (scripts/train_fixed_wing.py:
+    42-43, 142-197): the REAL FixedWingEvaluator.fly_to_point over
+    SimpleWingEnv.step -> LearntFixedWingDynamics.forward (physics on the live
+    parameters, 3x3 inertia in full, + residual network 16 -> 64 -> 12), with the
+    controller the reference ships.  The module is a "fitted" one: every
+    physical parameter moved by a few per cent, `I` neither symmetric nor
+    sparse, a non-zero residual network."""
+    import evaluate_fixed_wing as efw
+    from neural_control.controllers.network_wrapper import FixedWingNetWrapper
+    from neural_control.dynamics.fixed_wing_dynamics import LearntFixedWingDynamics
+
+    net, cfg, Env, dataset = _wing_eval_parts()
+    g15 = np.load(os.path.join(HERE, "wing_closed_loop.npz"))
+    dt = 0.05
+    torch.manual_seed(181)
+    dyn = LearntFixedWingDynamics()
+    with torch.no_grad():
+        for k, v in dyn.cfg.items():
+            if k != "g":
+                v.mul_(1 + 0.03 * torch.randn(1))
+        dyn.I.add_(dyn.I.abs().max() * 0.02 * torch.randn(3, 3))
+        dyn.linear_state_1.weight.normal_(0, 0.05)
+        dyn.linear_state_1.bias.normal_(0, 0.05)
+        dyn.linear_state_2.weight.normal_(0, 0.004)
+        dyn.linear_state_2.bias.normal_(0, 0.002)
+    dyn.eval()
+    cases = {
+        "eval": dict(src="eval", test_time=1, thresh_div=10, thresh_stable=3, max_steps=1000),
+        "train": dict(src="train", test_time=0, thresh_div=4, thresh_stable=.4,
+                      max_steps=1000),
+        "tight": dict(src="tight", test_time=0, thresh_div=.3, thresh_stable=.4,
+                      max_steps=300),
+        "tight_test": dict(src="tight", test_time=1, thresh_div=.3, thresh_stable=.4,
+                           max_steps=300),
+        "multi": dict(src="multi", test_time=0, thresh_div=4, thresh_stable=.8,
+                      max_steps=1000),
+    }
+    out = {"dt": np.float32(dt), "data_dt": np.float32(cfg["delta_t"]),
+           "data_horizon": np.int64(cfg["horizon"]),
+           "mean": np.asarray(cfg["mean"], np.float32),
+           "std": np.asarray(cfg["std"], np.float32),
+           "cases": np.array(sorted(cases))}
+    for k, v in dyn.state_dict().items():
+        out["dyn." + k] = npy(v)
+    for name, c in cases.items():
+        targets = g15[f"{c['src']}.targets"].astype(np.float64)
+        out[f"{name}.targets"] = targets.astype(np.float32)
+        for key in ("test_time", "max_steps"):
+            out[f"{name}.{key}"] = np.int64(c[key])
+        for key in ("thresh_div", "thresh_stable"):
+            out[f"{name}.{key}"] = np.float32(c[key])
+        lens = []
+        for i in range(len(targets)):
+            def make():
+                ctrl = FixedWingNetWrapper(net, dataset(), horizon=cfg["horizon"])
+                return efw.FixedWingEvaluator(
+                    ctrl, Env(dyn, dt), dt=dt, horizon=cfg["horizon"], render=0,
+                    thresh_div=c["thresh_div"], thresh_stable=c["thresh_stable"],
+                    test_time=c["test_time"])
+            with torch.no_grad():
+                traj = make().fly_to_point(targets[i], max_steps=c["max_steps"],
+                                           return_traj=True)
+                dtg, dlin = make().fly_to_point(targets[i], max_steps=c["max_steps"])
+            out[f"{name}.{i}.traj"] = np.asarray(traj, np.float32)
+            out[f"{name}.{i}.div_target"] = np.asarray(dtg, np.float64)
+            out[f"{name}.{i}.div_linear"] = np.asarray(dlin, np.float64)
+            lens.append((len(dlin), len(dtg), round(float(np.max(dlin)), 3)))
+        print(name, lens)
+    # the learnt parts matter: the same flight in the analytic simulator
+    with torch.no_grad():
+        ctrl = FixedWingNetWrapper(net, dataset(), horizon=cfg["horizon"])
+        plain = efw.FixedWingEvaluator(
+            ctrl, Env(FixedWingDynamics(), dt), dt=dt, horizon=cfg["horizon"], render=0,
+            thresh_div=10, thresh_stable=3, test_time=1).fly_to_point(
+                g15["eval.targets"][0].astype(np.float64), max_steps=1000, return_traj=True)
+    n = min(len(plain), len(out["eval.0.traj"]))
+    print("analytic vs learnt, first flight:",
+          np.abs(np.asarray(plain)[:n] - out["eval.0.traj"][:n]).max())
+    save("wing_closed_loop_learnt.npz", **out)
+
+
 FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
                 g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
                 g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
                 g11=g11_closed_loop, g12=g12_wing_train,
                 g13=g13_self_play, g14=g14_schedules,
                 g15=g15_wing_closed_loop, g16=g16_learnt_wing,
-                g17=g17_closed_loop_learnt)
+                g17=g17_closed_loop_learnt, g18=g18_wing_closed_loop_learnt)
 
 if __name__ == "__main__":
     for key in (sys.argv[1:] or FIXTURES):

@@ -320,3 +320,132 @@ def test_fused_wing_step_at_the_reference_horizon_of_ten(dev, B):
     assert la[1] != la[0]
     for k in wa:
         assert rel_err(wb[k].cpu().numpy(), wa[k].cpu().numpy()) < 1e-5, k
+
+
+# -------------------------------------------- the LEARNT simulator in the loop
+def learnt_wing_module(g, dev):
+    """The package's LearntFixedWingDynamics carrying G18's fitted simulator."""
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        LearntFixedWingDynamics)
+    dyn = LearntFixedWingDynamics()
+    dyn.load_state_dict({k[len("dyn."):]: torch.from_numpy(g[k]) for k in g.files
+                         if k.startswith("dyn.")})
+    return dyn.to(dev)
+
+
+@pytest.mark.parametrize("case", ["eval", "train", "tight", "tight_test", "multi"])
+def test_fly_to_point_through_the_learnt_simulator(dev, case):
+    """G18 (VERDICT r4 missing #2, the wing twin): every flight of a case in one
+    launch with the environment stepping through LearntFixedWingDynamics.forward
+    - physics on the module's current parameters, its 3 x 3 inertia in full,
+    the residual network - against the REAL FixedWingEvaluator over
+    SimpleWingEnv(LearntFixedWingDynamics)."""
+    from apg_trajectory_tracking_amd import evaluate_fixed_wing as efw
+    g = load_golden("wing_closed_loop_learnt.npz")
+    net = wing_loop_policy(dev)
+    dyn = learnt_wing_module(g, dev)
+    kw = dict(max_steps=int(g[f"{case}.max_steps"]),
+              thresh_div=float(g[f"{case}.thresh_div"]),
+              thresh_stable=float(g[f"{case}.thresh_stable"]),
+              test_time=int(g[f"{case}.test_time"]))
+    targets = g[f"{case}.targets"]
+
+    def make():
+        ctrl = efw.FixedWingNetWrapper(net, plain_dataset(g, dev),
+                                       horizon=int(g["data_horizon"]))
+        ev = efw.FixedWingEvaluator(
+            ctrl, dyn, dt=float(g["dt"]), horizon=int(g["data_horizon"]),
+            thresh_div=kw["thresh_div"], thresh_stable=kw["thresh_stable"],
+            test_time=kw["test_time"])
+        assert ev.learnt is dyn
+        return ev
+    trajs = make().fly_to_point(targets, max_steps=kw["max_steps"], return_traj=True)
+    div_target, div_linear = make().fly_to_point(targets, max_steps=kw["max_steps"])
+    for i in range(targets.shape[0]):
+        want = g[f"{case}.{i}.traj"]
+        assert trajs[i].shape == want.shape, (case, i, trajs[i].shape, want.shape)
+        assert rel_err(trajs[i], want) < ROW_TOL, (case, i)
+        assert np.abs(div_linear[i] - g[f"{case}.{i}.div_linear"]).max() < DIST_TOL
+        want_t = g[f"{case}.{i}.div_target"]
+        assert div_target[i].shape == want_t.shape, (case, i)
+        assert np.abs(div_target[i] - want_t).max() < DIST_TOL, (case, i)
+
+
+def test_learnt_closed_loop_batch_vs_oracle(dev):
+    """The learnt-simulator loop at B = 300 (two workgroups, ragged) with given
+    start states against the oracle's loop over LearntWingOracle."""
+    from apg_trajectory_tracking_amd import functional as F
+    from oracle import torch_port as tp
+    g = load_golden("wing_closed_loop_learnt.npz")
+    net = wing_loop_policy(dev)
+    dyn = learnt_wing_module(g, dev)
+    oracle = tp.LearntWingOracle({k[len("dyn."):]: g[k] for k in g.files
+                                  if k.startswith("dyn.")}, dtype=torch.float32)
+    B, T = 300, 120
+    gen = torch.Generator().manual_seed(21)
+    targets = torch.zeros(B, 2, 3)
+    targets[:, :, 0] = torch.tensor([30., 60.]) + 6 * torch.rand(B, 2, generator=gen) - 3
+    targets[:, :, 1:] = 8 * torch.rand(B, 2, 2, generator=gen) - 4
+    state0 = torch.zeros(B, 12)
+    state0[:, 3] = 11.5 + 0.3 * torch.randn(B, generator=gen)
+    state0[:, 1:3] = 0.5 * torch.randn(B, 2, generator=gen)
+    kw = dict(data_dt=float(g["data_dt"]), data_horizon=int(g["data_horizon"]),
+              max_steps=T, thresh_div=0.9, thresh_stable=0.35, test_time=0,
+              want_trajectory=True)
+    out = F.wing_mlp_closed_loop(net, targets.to(dev), float(g["dt"]), dyn.params,
+                                 g["mean"].tolist(), g["std"].tolist(),
+                                 state0=state0.to(dev), learnt=dyn, **kw)
+    with torch.no_grad():
+        ref = oracle_wing_closed_loop(net, targets, float(g["dt"]), None, g["mean"], g["std"],
+                                      state0=state0, learnt=oracle, **kw)
+    steps, rsteps = out["steps"].cpu().numpy(), ref["steps"].numpy()
+    skipped = 0
+    for i in range(B):
+        n = int(rsteps[i])
+        mine = {k: out[k][:n, ..., i].cpu().numpy() for k in
+                ("div_linear", "div_pass", "div_fail", "drone")}
+        want = {k: ref[k][:n, ..., i].numpy() for k in mine}
+        same = (steps[i] == n
+                and np.array_equal(mine["div_pass"] >= 0, want["div_pass"] >= 0)
+                and np.array_equal(mine["div_fail"] >= 0, want["div_fail"] >= 0))
+        if not same:
+            near = (np.abs(want["div_linear"] - kw["thresh_div"]).min() < 1e-3
+                    or np.abs(np.abs(want["drone"][:, 6:8]) - kw["thresh_stable"]).min() < 1e-4)
+            assert near, i
+            skipped += 1
+            continue
+        assert rel_err(mine["drone"], want["drone"]) < ROW_TOL, i
+        assert np.abs(mine["div_linear"] - want["div_linear"]).max() < DIST_TOL, i
+    assert skipped <= 3, skipped
+
+
+def test_trainer_flies_the_learnt_simulator_without_a_substitution(dev, tmp_path,
+                                                                   monkeypatch):
+    """TrainFixedWing.evaluate_model with `sample_in = "train_env"` and a learnt
+    training simulator: no substitution warning; the visited states in the
+    self-play slots are those of flights through the learnt simulator."""
+    import warnings
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import (
+        FixedWingDynamics)
+    from apg_trajectory_tracking_amd.train_fixed_wing import TrainFixedWing
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("wing_closed_loop_learnt.npz")
+    cfg = dict(delta_t=0.05, delta_t_train=0.05, epoch_size=64, self_play=4,
+               self_play_every_x=2, batch_size=64, state_size=12, horizon=10,
+               ref_dim=3, action_dim=4, train_mode="concurrent",
+               thresh_div_start=4, thresh_div_end=20, thresh_stable_start=.4,
+               thresh_stable_end=.8, learning_rate_controller=1e-7,
+               system="wing", save_name="t", sample_in="train_env",
+               resample_every=3)
+    slots = {}
+    for name, env in (("learnt", learnt_wing_module(g, dev)), ("analytic", FixedWingDynamics())):
+        t = TrainFixedWing(env, FixedWingDynamics(), dict(cfg))
+        t.initialize_model(base_model=wing_loop_policy(dev), device=dev, seed=5)
+        np.random.seed(4)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", UserWarning)
+            res = t.evaluate_model(0)
+        assert res is not None
+        d = t.state_data
+        slots[name] = d.states[d.num_sampled_states:].clone()
+    assert (slots["learnt"] - slots["analytic"]).abs().max() > 1e-2

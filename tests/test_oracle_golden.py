@@ -354,6 +354,44 @@ def test_wing_closed_loop_oracle_matches_reference_evaluator():
     assert resets > 40       # the divergence branches were flown
 
 
+def test_wing_closed_loop_oracle_through_the_learnt_simulator():
+    """G18: the fly_to_point restatement over LearntWingOracle (physics on the
+    module's current parameters, general 3x3 inertia, residual network) against
+    the REAL FixedWingEvaluator over SimpleWingEnv(LearntFixedWingDynamics)."""
+    from conftest import wing_loop_case, wing_loop_policy
+    g = load_golden("wing_closed_loop_learnt.npz")
+    net = wing_loop_policy()
+    dyn = tp.LearntWingOracle(_learnt_wing_weights(g, "dyn."), dtype=torch.float32)
+    resets = 0
+    for case in map(str, g["cases"]):
+        kw = dict(max_steps=int(g[f"{case}.max_steps"]),
+                  thresh_div=float(g[f"{case}.thresh_div"]),
+                  thresh_stable=float(g[f"{case}.thresh_stable"]),
+                  test_time=int(g[f"{case}.test_time"]))
+        targets = g[f"{case}.targets"]
+        with torch.no_grad():
+            out = tp.wing_closed_loop(
+                net, dyn, torch.from_numpy(targets), float(g["dt"]), g["mean"], g["std"],
+                float(g["data_dt"]), int(g["data_horizon"]), kw["max_steps"],
+                kw["thresh_div"], kw["thresh_stable"], kw["test_time"])
+        for i in range(targets.shape[0]):
+            want = g[f"{case}.{i}.traj"]
+            n = len(want)
+            assert int(out["steps"][i]) == n, (case, i)
+            assert np.abs(out["traj"][i, :n].numpy() - want).max() < 2e-4, (case, i)
+            assert np.abs(out["div_linear"][i, :n].numpy()
+                          - g[f"{case}.{i}.div_linear"]).max() < 2e-4, (case, i)
+            ev = torch.stack((out["div_pass"][i, :n], out["div_fail"][i, :n]), 1).reshape(-1)
+            ev = ev[ev >= 0].tolist()
+            resets += int((out["div_fail"][i, :n] >= 0).sum())
+            if n == kw["max_steps"]:
+                ev.append(kw["thresh_div"])
+            want_t = g[f"{case}.{i}.div_target"]
+            assert len(ev) == len(want_t), (case, i)
+            assert np.abs(np.array(ev) - want_t).max() < 2e-4, (case, i)
+    assert resets > 40
+
+
 def _learnt_wing_weights(g, prefix="w."):
     return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
 
