@@ -40,7 +40,8 @@ class _LinearWgrad(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad
         need_b = need_b and ctx.has_bias
-        gx = grad_out.matmul(weight) if need_x else None
+        gx = (grad_out.matmul(weight.to(grad_out.dtype)).to(x.dtype)
+              if need_x else None)
         gw = gb = None
         if need_w or need_b:
             M, N = weight.shape
@@ -51,7 +52,11 @@ class _LinearWgrad(torch.autograd.Function):
                     or xx.numel() * 4 >= _MAX_OPERAND_BYTES):
                 # what the kernel is not built for (another dtype, an operand of
                 # 4 GiB or more: 32-bit byte offsets): autograd's own formulas
-                gw = dy.t().matmul(xx).to(weight.dtype) if need_w else None
+                # (mixed dtypes - autocast hands a half grad_out to a float x:
+                # the product in the wider of the two, as autograd's linear does)
+                wide = torch.promote_types(dy.dtype, xx.dtype)
+                gw = (dy.to(wide).t().matmul(xx.to(wide)).to(weight.dtype)
+                      if need_w else None)
                 gb = dy.sum(0).to(weight.dtype) if need_b else None
                 return gx, gw, gb
             dy, xx = dy.contiguous(), xx.contiguous()

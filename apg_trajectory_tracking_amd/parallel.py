@@ -28,6 +28,19 @@ def group_live():
     return dist.is_available() and dist.is_initialized()
 
 
+def any_rank(flag):
+    """`flag` OR-ed over the ranks (one process: `flag`).  A host decision all
+    ranks must take alike - re-capturing a step graph, whose warm-up steps issue
+    collectives - costs one small all-reduce and a read-back where it is asked."""
+    if world_size() <= 1:
+        return bool(flag)
+    import torch
+    dev = ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item())
+
+
 def shard_range(n, r=None, world=None):
     """Contiguous [lo, hi) slice of n items owned by rank r (the first
     n % world ranks get one extra)."""

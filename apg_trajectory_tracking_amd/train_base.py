@@ -456,6 +456,13 @@ class TrainBase:
                 or self._reducing() or type(opt) is not optim.SGD
                 or len(opt.param_groups) != 1):
             return None
+        # a user's step hooks run around optimizer.step(): with hooks registered
+        # (on this optimizer or globally) the step is left to the optimizer
+        from torch.optim import optimizer as _opt_mod
+        if (opt._optimizer_step_pre_hooks or opt._optimizer_step_post_hooks
+                or getattr(_opt_mod, "_global_optimizer_pre_hooks", None)
+                or getattr(_opt_mod, "_global_optimizer_post_hooks", None)):
+            return None
         g = opt.param_groups[0]
         if (not g["momentum"] or g["dampening"] or g["nesterov"] or g["weight_decay"]
                 or g.get("maximize")):
@@ -466,6 +473,9 @@ class TrainBase:
         # the buffers or the settings the answer depends on have changed)
         tensors = F.mlp_param_objects(self.net)
         fast = (id(opt), id(opt.state), g["lr"], g["momentum"]) + tuple(map(id, tensors))
+        # (an LR scheduler asks whether the optimizer has stepped: it has,
+        # inside the kernel)
+        opt._opt_called = True
         hit = getattr(self, "_iku", None)
         if hit is not None and hit[0] == fast and all(
                 p.requires_grad and opt.state[p].get("momentum_buffer") is b
@@ -508,6 +518,11 @@ class TrainBase:
         if not stepped:      # (stepped: the kernels have applied the update)
             self.optimizer_controller.step()
         return loss
+
+    def _held_state(self):
+        """The optimizer-state tensors a captured step or a plan addresses."""
+        return [v for st in self.optimizer_controller.state.values()
+                for v in st.values() if torch.is_tensor(v)]
 
     def _graphable(self):
         # (inside the capture of a whole epoch the steps run "eagerly": their
@@ -559,8 +574,11 @@ class TrainBase:
                 # storage: the address is part of it)
                 + tuple((id(p), p.data_ptr())
                         for p in (self.net.parameters() if params is None else params))
-                # (load_state_dict replaces the momentum buffers)
-                + tuple(id(st.get("momentum_buffer")) for st in opt.state.values())
+                # (load_state_dict replaces the momentum buffers; graphs and plans
+                # hold them by ADDRESS and keep a reference - `_held_state` - so
+                # a freed buffer's id cannot come back under a new one: ADVICE r4)
+                + tuple((id(b), b.data_ptr() if torch.is_tensor(b) else 0)
+                        for b in (st.get("momentum_buffer") for st in opt.state.values()))
                 + (id(opt), hyper, phys, float(self.delta_t),
                    float(self.delta_t_train), self._reducing()))
 
@@ -579,18 +597,25 @@ class TrainBase:
         # of host time per step otherwise: parameter ids, optimizer settings)
         cache = getattr(self, "_epoch_sigs", None)
         sig = cache.get(key) if cache is not None else None
-        if sig is None:
+        fresh_sig = sig is None
+        if fresh_sig:
             sig = self._graph_signature(inputs, volatile)
             if cache is not None:
                 cache[key] = sig
         g = self._graphs.get(key)
-        if g is None or getattr(g, "planned", False) or g.signature != sig:
+        stale = g is None or getattr(g, "planned", False) or g.signature != sig
+        if fresh_sig:
+            # a re-capture runs warm-up steps with their own all-reduces: every
+            # rank re-captures when one has to (agreed where the signature is
+            # taken afresh - once per key and epoch inside run_epoch)
+            stale = parallel.any_rank(stale)
+        if stale:
             if torch.cuda.is_available() and _make_capturable(self.optimizer_controller):
                 sig = self._graph_signature(inputs, volatile)
             try:
                 g = _GraphedStep(
                     part_a, part_b, self._reduce, sig,
-                    list(inputs) + list(volatile), self.net,
+                    list(inputs) + list(volatile) + self._held_state(), self.net,
                     self.optimizer_controller,
                     capture=torch.cuda.is_available(), split=self._reducing())
             except RuntimeError as e:
@@ -683,6 +708,7 @@ class TrainBase:
         g = self._graphs.get(key)
         if not isinstance(g, _PlannedStep) or g.signature != sig:
             g = self._graphs[key] = build()
+            g.held_state = self._held_state()    # (addressed by the plan)
             g.signature = self._graph_signature(inputs, volatile, params)
             if cache is not None:
                 cache[key] = g.signature
@@ -1108,10 +1134,29 @@ class TrainBase:
         if train not in ("controller", "dynamics"):
             raise ValueError("train must be 'controller' or 'dynamics'")
         table = getattr(self, "_epoch_runners", None) or self._epoch_table()
+        self._guard_data_set(train)
         for name, applies, runner in table:
             if applies(train):
                 self.last_epoch_loop = name
                 return runner(train)
+
+    def _guard_data_set(self, train):
+        """The in-kernel policies take finite inputs below 2^14 (fp16-split
+        operands, include/apg.h).  Steps that replay a graph, a plan or an epoch
+        graph never pass the per-call host check, and the data set is rewritten
+        in place between epochs (resample_data, self-play add_eval_data): its
+        tensors are checked here, before the epoch's first replay - one
+        read-back per tensor and in-place version, nothing when unchanged."""
+        d = self.state_data
+        if (train != "controller" or d is None
+                or not getattr(self, "fused_policy", False)):
+            return
+        from . import functional as F
+        tensors = {k: getattr(d, k, None)
+                   for k in ("normed_states", "states", "in_ref_states", "ref_states")}
+        F._guard_policy_inputs(
+            "run_epoch (data set)",
+            **{k: t for k, t in tensors.items() if torch.is_tensor(t) and t.is_cuda})
 
     def _finish_epoch(self, running_loss, i, train):
         # one host read-back per epoch; divides by the last index as the

@@ -145,7 +145,7 @@ def _epoch_run(world_sharded):
     return losses, {k: v.numpy() for k, v in trainer.net.state_dict().items()}
 
 
-def _ar_steps(lo, hi, graphed=False, split=None):
+def _ar_steps(lo, hi, graphed=False, split=None, new_buffers_on_rank=None):
     """The code path of `bench.py --mode ar` / BASELINE configs[2]: the REAL
     TrainDrone.train_recurrent_model (autoregressive, fused branch) ->
     TrainBase._step_direct -> one flat all-reduce + SGD.  Only the kernel
@@ -202,6 +202,18 @@ def _ar_steps(lo, hi, graphed=False, split=None):
         if graphed:      # one _GraphedStep, replayed; split iff it has the slot
             g, = t._graphs.values()
             assert g.split == (dist.is_initialized() or bool(split)) and not g.capture
+        if new_buffers_on_rank is not None:
+            # ONE rank's optimizer state is re-installed (new momentum
+            # buffer objects) - every rank re-captures, so the warm-up collectives
+            # of a real capture would pair up; the held buffers stay referenced
+            opt = t.optimizer_controller
+            assert all(any(b is h for h in g.keep)
+                       for b in (st["momentum_buffer"] for st in opt.state.values()))
+            if dist.get_rank() == new_buffers_on_rank:
+                opt.load_state_dict(__import__("copy").deepcopy(opt.state_dict()))
+            losses.append(float(t.train_recurrent_model(None, *shard)))
+            g2, = t._graphs.values()
+            assert g2 is not g, "this rank replayed while another re-captured"
         return losses, {k: v.numpy() for k, v in t.net.state_dict().items()}
     finally:
         F.quad_mlp_rollout_grads = orig
@@ -247,6 +259,12 @@ def _worker(rank, world, port, out_dir):
         losses, sd = _epoch_run(True)
         np.savez(os.path.join(out_dir, f"epoch_rank{rank}.npz"),
                  losses=np.array(losses), **sd)
+        # host decisions every rank takes alike
+        from apg_trajectory_tracking_amd import parallel
+        assert parallel.any_rank(rank == 1) and not parallel.any_rank(False)
+        losses, sd = _ar_steps(lo, hi, graphed=True, new_buffers_on_rank=1)
+        np.savez(os.path.join(out_dir, f"recap_rank{rank}.npz"),
+                 losses=np.array(losses), **sd)
     finally:
         dist.destroy_process_group()
 
@@ -284,6 +302,11 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
         assert np.array_equal(g["losses"], e["losses"])
         for k in ref_sd:
             assert np.array_equal(g[k], e[k]), (r, k)
+
+    a, b = (np.load(tmp_path / f"recap_rank{r}.npz") for r in range(2))
+    assert np.array_equal(a["losses"], b["losses"]) and len(a["losses"]) == 3
+    for k in ref_sd:                # ... and the re-captured step trained alike
+        assert np.array_equal(a[k], b[k]), k
 
     ref_losses, ref_sd = _epoch_run(False)          # run_epoch, sharded loader
     for r in range(world):

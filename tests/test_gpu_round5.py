@@ -445,3 +445,71 @@ def test_evaluate_model_flies_the_learnt_simulator_without_a_substitution(dev):
     assert t.results_dict["mean_success"][-1] == pytest.approx(stats["learnt"][0])
     assert abs(stats["analytic"][4] - stats["learnt"][4]) > 1e-3 * abs(stats["learnt"][4])
     assert "evaluation_env" not in t.results_dict or not t.results_dict["evaluation_env"]
+
+
+# ------------------------------------------------------------- ADVICE r4, lows
+def test_step_hooks_keep_the_optimizer_in_charge_and_schedulers_see_steps(dev):
+    """With the in-kernel update optimizer.step() is never called: a user's
+    step hooks would be skipped.  With hooks registered the update is left to
+    the optimizer (the hook runs once per step, the result is the same); without
+    hooks an LR scheduler does not warn about a step it did not see."""
+    t, step = _trainer("concurrent", 1024, dev)
+    assert t._in_kernel_update(True) is not None
+    sched = torch.optim.lr_scheduler.StepLR(t.optimizer_controller, step_size=100)
+    step()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        sched.step()                   # "scheduler.step() before optimizer.step()"
+    plain = [float(step()) for _ in range(2)]
+    h, hstep = _trainer("concurrent", 1024, dev)
+    calls = []
+    h.optimizer_controller.register_step_post_hook(lambda opt, a, k: calls.append(1))
+    assert h._in_kernel_update(True) is None
+    hooked = [float(hstep()) for _ in range(3)]
+    assert len(calls) == 3
+    assert hooked[1:] == pytest.approx(plain, rel=1e-6)
+
+
+def test_data_set_written_in_place_is_checked_again_before_replays(dev):
+    """The operand-range contract of the in-kernel policies (finite, below 2^14)
+    on paths that replay: an epoch trains from plans / graphs, then the data
+    set is written in place (as resample_data / add_eval_data do) - the next
+    run_epoch raises instead of training on inf."""
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    for mode in ("concurrent", "autoregressive"):
+        cfg = dict(QUAD_CFG, train_mode=mode, batch_size=96, epoch_size=300, self_play=0)
+        t = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), cfg)
+        t.initialize_model(device=dev, seed=3)
+        assert np.isfinite(t.run_epoch("controller", 0))
+        assert np.isfinite(t.run_epoch("controller", 1))
+        with torch.no_grad():
+            t.state_data.in_ref_states[7, 3, 2] = float("inf")
+        with pytest.raises(ValueError, match="in_ref_states"):
+            t.run_epoch("controller", 2)
+        with torch.no_grad():
+            t.state_data.in_ref_states[7, 3, 2] = 0.5
+            t.state_data.states[11, 0] = 3e4
+        with pytest.raises(ValueError, match="states"):
+            t.run_epoch("controller", 3)
+
+
+def test_linear_weight_gradient_with_mixed_dtypes_under_autocast(dev):
+    """init_optimizer switches a user policy's torch.nn.Linear layers to the
+    library's weight gradient; under autocast grad_out is half and x float:
+    the fallback multiplies in the wider type, as stock nn.Linear does."""
+    from apg_trajectory_tracking_amd import nn as apg_nn
+    torch.manual_seed(0)
+    lin, ref = apg_nn.Linear(24, 16).to(dev), torch.nn.Linear(24, 16).to(dev)
+    ref.load_state_dict(lin.state_dict())
+    x = torch.randn(64, 24, device=dev)
+    outs = []
+    for m in (lin, ref):
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        y.float().pow(2).sum().backward()
+        outs.append((m.weight.grad, m.bias.grad, xi.grad))
+    for a, b in zip(*outs):
+        assert a.dtype == b.dtype and rel_err(N(a), N(b)) < 1e-2
