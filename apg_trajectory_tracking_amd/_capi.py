@@ -91,6 +91,16 @@ class ApgStepEvents(ctypes.Structure):
         "inputs_ready", "after_forward", "after_reverse")]
 
 
+class ApgBatchRows(ctypes.Structure):
+    """A minibatch named by row numbers into the data set's tensors
+    (apg_quad_mlp_concurrent_train_step_rows)."""
+    _fields_ = ([("index", ctypes.c_void_p)]
+                + [(n, ctypes.c_void_p) for n in ("normed", "state0", "in_ref", "ref")]
+                + [(n, ctypes.c_int) for n in (
+                    "ld_normed", "ld_state0", "ld_in_ref", "ld_ref")]
+                + [("n_rows", ctypes.c_longlong), ("running_loss", ctypes.c_void_p)])
+
+
 class ApgMlpSgdUpdate(ctypes.Structure):
     """apg_quad_mlp_concurrent_train_step's optimizer part: momentum SGD on
     the policy's tensors and the optimizer's momentum buffers."""
@@ -181,6 +191,11 @@ SIGNATURES = {
         _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P, _P, _P],
     "apg_quad_mlp_concurrent_train_step": [
         _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
+        _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P,
+        ctypes.POINTER(ApgMlpSgdUpdate), ctypes.POINTER(ApgStepEvents), _P],
+    "apg_quad_mlp_concurrent_train_step_rows": [
+        ctypes.POINTER(ApgBatchRows), _I, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
         _P, _P, _P, _P, _P, ctypes.POINTER(ApgMlpPolicyGrads), _P, _P, _P,
         ctypes.POINTER(ApgMlpSgdUpdate), ctypes.POINTER(ApgStepEvents), _P],

@@ -959,11 +959,48 @@ struct ConcArgs {
   QuadConst c;
   ApgQuadLossWeights w;
   int B, ref_cols, vel_col;
+  // ROWS (below): feat / in_ref / state0 / ref are the DATA SET's tensors [N][ld_*]
+  // and `index` [B] names this batch's rows; the feature and window planes the
+  // reverse kernel reads are written to o_feat [15][B] / o_in_ref [90][B]
+  const long long *index;
+  float *o_feat, *o_in_ref;
+  int ld_feat, ld_in_ref, ld_state0, ld_ref;
+  unsigned bytes_feat, bytes_in_ref, bytes_state0, bytes_ref;
 };
 
+// ROWS: the minibatch gather folded into this kernel (VERDICT r4 next #4;
+// TrainBase.run_epoch's batch selection, scripts/train_base.py:191-194).  The
+// workgroup's rows are brought into LDS through the index (gather_rows_issue,
+// policy_mfma.h) before the operand tables - features + windows [256][15] /
+// [256][91] where the tables go afterwards, the start states [256][13] behind the
+// tables - and the reference rows [256][91] over the tables once the policy is
+// done with them, while the rollout runs.
+constexpr int kRowPadW = kH * kRD + 1, kRowPadF = kNF, kRowPadS = 13;   // odd strides
+constexpr int zWin = 0, zFeat = kTrajPerBlock * kRowPadW,               // floats
+              zS0 = kCfLds, zRows = zS0 + kTrajPerBlock * kRowPadS,
+              kCfRowsLds = zRows + kTrajPerBlock;
+static_assert(zFeat + kTrajPerBlock * kRowPadF <= kCfLds, "staging under the tables");
+static_assert(kCfRowsLds * 4 <= 160 * 1024, "LDS");
+
+template <bool ROWS>
 __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kCfLds);
+  if (ROWS) {
+    const int t = threadIdx.x, b_ = blockIdx.x * kTrajPerBlock + t;
+    // (a dead trajectory reads the batch's last row: finite data, never stored)
+    if (t < kTrajPerBlock)
+      reinterpret_cast<int *>(lds + zRows)[t] = (int)A.index[b_ < A.B ? b_ : A.B - 1];
+    __syncthreads();
+    const int *rows = reinterpret_cast<const int *>(lds + zRows);
+    gather_rows_issue<kRowPadW>(lds + zWin, rows, A.in_ref, A.bytes_in_ref, A.ld_in_ref,
+                                kH * kRD);
+    gather_rows_issue<kRowPadF>(lds + zFeat, rows, A.feat, A.bytes_feat, A.ld_feat, kNF);
+    gather_rows_issue<kRowPadS>(lds + zS0, rows, A.state0, A.bytes_state0, A.ld_state0, 12);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+    fill_lds(lds, A.tables, kCfLds);
+  }
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -985,13 +1022,26 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
   const unsigned vm = live ? vb + (hi ? pN : 0u) : kDead;        // + mask word hi
 
   float feat[kNF];
-#pragma unroll
-  for (int j = 0; j < kNF; ++j) feat[j] = Pfe.ld(vb, j * pN);
   float w[kH][5];  // policy reference input, columns 0..4 / 4..8 per half
+  const int tl = wave * 32 + (lane & 31);   // this lane's trajectory of the workgroup
+  if (ROWS) {
+    const float *pf = lds + zFeat + tl * kRowPadF, *pw = lds + zWin + tl * kRowPadW + 4 * hi;
 #pragma unroll
-  for (int r = 0; r < kH; ++r)
+    for (int j = 0; j < kNF; ++j) feat[j] = pf[j];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vr, (r * kRD + j) * pN);
+    for (int r = 0; r < kH; ++r)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) w[r][j] = pw[r * kRD + j];
+    __syncthreads();                      // every wave has its rows: the tables may land
+    fill_lds_issue(lds, A.tables, kCfLds);
+  } else {
+#pragma unroll
+    for (int j = 0; j < kNF; ++j) feat[j] = Pfe.ld(vb, j * pN);
+#pragma unroll
+    for (int r = 0; r < kH; ++r)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vr, (r * kRD + j) * pN);
+  }
   // (maxima of the |v| BIT PATTERNS, unsigned: inf / NaN lie above every finite
   // value - see TmMeta)
   unsigned xm_conv = 0u;
@@ -1020,6 +1070,19 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
     }
   }
 
+  if (ROWS) {   // the table DMA issued above
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the planes the reverse kernel multiplies with (its x^T blocks)
+    const Planes Pof(A.o_feat, kNF, pN), Poi(A.o_in_ref, kH * kRD, pN);
+#pragma unroll
+    for (int j = 0; j < kNF; ++j) Pof.st(vb_lo, j * pN, feat[j]);
+#pragma unroll
+    for (int r = 0; r < kH; ++r)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)   // (column 4 is in both halves: the lower one stores it)
+        Poi.st(hi && j == 0 ? kDead : vr, (r * kRD + j) * pN, w[r][j]);
+  }
   // ---- policy forward on the 16-bit matrix pipe (policy_mfma16.h): every
   // operand as two fp16 terms, three products per k-block
   const LdsView16 L16(lds, lane);
@@ -1138,8 +1201,17 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
 
   // ---- rollout + adjoint in registers (quad_rollout_reg_kernel's structure)
   float s[12];
+  if (ROWS) {
+    // the tables are dead: the reference rows land over them while the rollout runs
+    __syncthreads();
+    gather_rows_issue<kRowPadW>(lds + zWin, reinterpret_cast<const int *>(lds + zRows), A.ref,
+                                A.bytes_ref, A.ld_ref, kH * A.ref_cols);
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = Ps0.ld(vb, i * pN);
+    for (int i = 0; i < 12; ++i) s[i] = lds[zS0 + tl * kRowPadS + i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = Ps0.ld(vb, i * pN);
+  }
   Trig st_trig[kH];
   float st_w[kH + 1][3], st_pv[kH][6];
 #pragma unroll
@@ -1159,18 +1231,29 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
 #pragma unroll
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
   float rp[3], rv[3];
+  const float *pr = lds + zWin + tl * kRowPadW;
+  if (ROWS) {   // the reference rows (and every store so far) have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    rp[i] = Prf.ld(vb, ((kH - 1) * A.ref_cols + i) * pN);
-    rv[i] = Prf.ld(vb, ((kH - 1) * A.ref_cols + A.vel_col + i) * pN);
+    rp[i] = ROWS ? pr[(kH - 1) * A.ref_cols + i]
+                 : Prf.ld(vb, ((kH - 1) * A.ref_cols + i) * pN);
+    rv[i] = ROWS ? pr[(kH - 1) * A.ref_cols + A.vel_col + i]
+                 : Prf.ld(vb, ((kH - 1) * A.ref_cols + A.vel_col + i) * pN);
   }
 #pragma unroll
   for (int k = kH - 1; k >= 0; --k) {
     float np_[3], nv_[3];  // next iteration's reference row, one step ahead
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      np_[i] = k > 0 ? Prf.ld(vb, ((k - 1) * A.ref_cols + i) * pN) : 0.f;
-      nv_[i] = k > 0 ? Prf.ld(vb, ((k - 1) * A.ref_cols + A.vel_col + i) * pN) : 0.f;
+      np_[i] = k == 0 ? 0.f
+               : ROWS ? pr[(k - 1) * A.ref_cols + i]
+                      : Prf.ld(vb, ((k - 1) * A.ref_cols + i) * pN);
+      nv_[i] = k == 0 ? 0.f
+               : ROWS ? pr[(k - 1) * A.ref_cols + A.vel_col + i]
+                      : Prf.ld(vb, ((k - 1) * A.ref_cols + A.vel_col + i) * pN);
     }
     float lp = 0.f, lv = 0.f, lw = 0.f, lr = 0.f;
 #pragma unroll
@@ -1985,6 +2068,7 @@ struct WgReduceArgs {
   bool conv_bias_here; // the conv bias sits in the bias slot (layer 0, entries 32..51)
   const float *loss_partials;
   float *loss;
+  float *loss_sum;       // or NULL: += the loss (an epoch loop's running sum)
   int wgs, n_partials;   // wgs: how many [n_slots * 1024] rows `part` has
 };
 
@@ -2052,7 +2136,11 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
     for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) *A.loss = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+    if (threadIdx.x == 0) {
+      const float l = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+      *A.loss = l;
+      if (A.loss_sum) *A.loss_sum += l;   // (one thread, stream order: deterministic)
+    }
   }
 }
 
@@ -3055,7 +3143,7 @@ int apg_quad_mlp_concurrent_fwd_bwd(
   }
   static PerDeviceOnce attr;
   if (!attr.test()) {
-    if (int e = raise_lds(mlp_concurrent_fwd_kernel, kCfLds)) return e;
+    if (int e = raise_lds(mlp_concurrent_fwd_kernel<false>, kCfLds)) return e;
     if (int e = raise_lds(mlp_concurrent_bwd_kernel, kCbLds)) return e;
     attr.set();
   }
@@ -3074,7 +3162,7 @@ int apg_quad_mlp_concurrent_fwd_bwd(
   const int fwd_blocks = (kCfLds + 255) / 256, bwd_blocks = (kCbLds + 255) / 256;
   hipLaunchKernelGGL(mlp_pack_pair_kernel, dim3(fwd_blocks + bwd_blocks), dim3(256), 0, st,
                      P, fwd_blocks);
-  hipLaunchKernelGGL(mlp_concurrent_fwd_kernel, dim3(blocks), dim3(kThreads),
+  hipLaunchKernelGGL(mlp_concurrent_fwd_kernel<false>, dim3(blocks), dim3(kThreads),
                      kCfLds * sizeof(float), st, A);
   A.tables = workspace + kCfLds;
   hipLaunchKernelGGL(mlp_concurrent_bwd_kernel, dim3(blocks), dim3(kThreads),
@@ -3097,6 +3185,13 @@ long long apg_quad_mlp_step_partials_floats(int B) {
 }
 
 namespace {
+int concurrent_train_step(
+    const ApgBatchRows *rows, const float *state0, const float *ref, int ref_cols, float dt,
+    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+    const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
+    float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
+    float *states, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
+    const ApgStepEvents *events, apg_stream_t stream);
 bool all_set(const ApgMlpPolicyGrads &g) {
   return g.w_s && g.b_s && g.conv_w && g.conv_b && g.w_1 && g.b_1 && g.w_2 && g.b_2 &&
          g.w_3 && g.b_3 && g.w_out && g.b_out;
@@ -3118,6 +3213,50 @@ int apg_quad_mlp_concurrent_step(
 
 int apg_quad_mlp_concurrent_train_step(
     const float *state0, const float *ref, int ref_cols, float dt,
+    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+    const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
+    float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
+    float *states, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
+    const ApgStepEvents *events, apg_stream_t stream) {
+  return concurrent_train_step(nullptr, state0, ref, ref_cols, dt, params, weights, policy, B, H,
+                               acts, relu_mask, d_zout, loss_partials, loss, grads, states,
+                               workspace, partials, update, events, stream);
+}
+
+int apg_quad_mlp_concurrent_train_step_rows(
+    const ApgBatchRows *rows, int ref_cols, float dt, const ApgQuadParams *params,
+    const ApgQuadLossWeights *weights, const ApgMlpPolicy *policy, int B, int H, float *acts,
+    unsigned *relu_mask, float *d_zout, float *loss_partials, float *loss,
+    const ApgMlpPolicyGrads *grads, float *states, float *workspace, float *partials,
+    const ApgMlpSgdUpdate *update, const ApgStepEvents *events, apg_stream_t stream) {
+  if (!rows) { set_error("rows is NULL"); return APG_ERR_ARG; }
+  if (B > 0 && (!rows->index || !rows->normed || !rows->state0 || !rows->in_ref || !rows->ref)) {
+    set_error("rows: NULL pointer");
+    return APG_ERR_ARG;
+  }
+  if (rows->n_rows < 1 || rows->ld_normed < kNF || rows->ld_state0 < 12 ||
+      rows->ld_in_ref < kH * kRD || rows->ld_ref < kH * ref_cols) {
+    set_error("rows: need n_rows >= 1 and row strides of at least 15 / 12 / 90 / H x ref_cols");
+    return APG_ERR_ARG;
+  }
+  const long long widest = rows->ld_in_ref > rows->ld_ref ? rows->ld_in_ref : rows->ld_ref;
+  if (rows->n_rows * widest * 4 >= (1ll << 32) - 64 ||
+      rows->n_rows * (long long)rows->ld_normed * 4 >= (1ll << 32) - 64 ||
+      rows->n_rows * (long long)rows->ld_state0 * 4 >= (1ll << 32) - 64) {
+    set_error("rows: a data-set tensor of 4 GiB or more (32-bit row offsets); gather the "
+              "batch with apg_to_soa_multi instead");
+    return APG_ERR_ARG;
+  }
+  return concurrent_train_step(rows, nullptr, nullptr, ref_cols, dt, params, weights, policy, B,
+                               H, acts, relu_mask, d_zout, loss_partials, loss, grads, states,
+                               workspace, partials, update, events, stream);
+}
+
+}  // extern "C"
+
+namespace {
+int concurrent_train_step(
+    const ApgBatchRows *rows, const float *state0, const float *ref, int ref_cols, float dt,
     const ApgQuadParams *params, const ApgQuadLossWeights *weights,
     const ApgMlpPolicy *policy, int B, int H, float *acts, unsigned *relu_mask,
     float *d_zout, float *loss_partials, float *loss, const ApgMlpPolicyGrads *grads,
@@ -3162,8 +3301,8 @@ int apg_quad_mlp_concurrent_train_step(
       return check_launch("memset(loss)");
     return APG_OK;
   }
-  if (!state0 || !ref || !acts || !relu_mask || !d_zout || !loss_partials || !workspace ||
-      !partials) {
+  if ((!rows && (!state0 || !ref)) || !acts || !relu_mask || !d_zout || !loss_partials ||
+      !workspace || !partials) {
     set_error("NULL buffer");
     return APG_ERR_ARG;
   }
@@ -3173,7 +3312,8 @@ int apg_quad_mlp_concurrent_train_step(
   }
   static PerDeviceOnce attr;
   if (!attr.test()) {
-    if (int e = raise_lds(mlp_concurrent_fwd_kernel, kCfLds)) return e;
+    if (int e = raise_lds(mlp_concurrent_fwd_kernel<false>, kCfLds)) return e;
+    if (int e = raise_lds(mlp_concurrent_fwd_kernel<true>, kCfRowsLds)) return e;
     if (int e = raise_lds(mlp_concurrent_bwd_tm_kernel, kLdsAll / 4)) return e;
     attr.set();
   }
@@ -3191,6 +3331,17 @@ int apg_quad_mlp_concurrent_train_step(
   A.c = make_const(*params, dt);
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
+  A.index = nullptr, A.o_feat = A.o_in_ref = nullptr;
+  if (rows) {
+    A.index = rows->index;
+    A.o_feat = acts + pFeat * plane, A.o_in_ref = acts + pInr * plane;
+    A.feat = rows->normed, A.in_ref = rows->in_ref, A.state0 = rows->state0, A.ref = rows->ref;
+    A.ld_feat = rows->ld_normed, A.ld_in_ref = rows->ld_in_ref;
+    A.ld_state0 = rows->ld_state0, A.ld_ref = rows->ld_ref;
+    const auto bytes = [&](int ld) { return (unsigned)(rows->n_rows * (long long)ld * 4); };
+    A.bytes_feat = bytes(A.ld_feat), A.bytes_in_ref = bytes(A.ld_in_ref);
+    A.bytes_state0 = bytes(A.ld_state0), A.bytes_ref = bytes(A.ld_ref);
+  }
   PackArgs P;
   P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
@@ -3202,8 +3353,12 @@ int apg_quad_mlp_concurrent_train_step(
   if (events && events->inputs_ready &&
       hipStreamWaitEvent(st, (hipEvent_t)events->inputs_ready, 0) != hipSuccess)
     return check_launch("hipStreamWaitEvent(inputs_ready)");
-  hipLaunchKernelGGL(mlp_concurrent_fwd_kernel, dim3(blocks), dim3(kThreads),
-                     kCfLds * sizeof(float), st, A);
+  if (rows)
+    hipLaunchKernelGGL(mlp_concurrent_fwd_kernel<true>, dim3(blocks), dim3(kThreads),
+                       kCfRowsLds * sizeof(float), st, A);
+  else
+    hipLaunchKernelGGL(mlp_concurrent_fwd_kernel<false>, dim3(blocks), dim3(kThreads),
+                       kCfLds * sizeof(float), st, A);
   if (events && events->after_forward &&
       hipEventRecord((hipEvent_t)events->after_forward, st) != hipSuccess)
     return check_launch("hipEventRecord(after_forward)");
@@ -3219,6 +3374,7 @@ int apg_quad_mlp_concurrent_train_step(
     return check_launch("hipEventRecord(after_reverse)");
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
+  R.loss_sum = rows && loss ? rows->running_loss : nullptr;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
   R.n_slots = kSlotsTm, R.bias_slot = uBias, R.conv_src = 1, R.bias_src = 8;
   R.head_rows = kNA, R.conv_bias_here = false;
@@ -3236,6 +3392,9 @@ int apg_quad_mlp_concurrent_train_step(
   hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(columns), dim3(256), 0, st, R);
   return check_launch("quad_mlp_concurrent_step");
 }
+}  // namespace
+
+extern "C" {
 
 int apg_quad_mlp_rollout_step_workspace_floats(void) { return kCfLds + kArTabFloats + 4; }
 
@@ -3330,7 +3489,7 @@ int apg_quad_mlp_rollout_train_step(
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
   hipLaunchKernelGGL(mlp_rollout_bwd_tm_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st, A);
   WgReduceArgs R;
-  R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
+  R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss, R.loss_sum = nullptr;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
   R.n_slots = kSlotsTm, R.bias_slot = uBias, R.conv_src = 1, R.bias_src = 8, R.head_rows = 4;
   R.conv_bias_here = true;

@@ -147,4 +147,32 @@ __device__ __forceinline__ void fill_lds(float *lds, const float *src, int float
   __syncthreads();
 }
 
+// Minibatch rows read THROUGH THE INDEX by the kernel that consumes them (round 5;
+// TrainBase.run_epoch's batch selection, scripts/train_base.py:191-194, without a
+// gather pass): the workgroup's 256 trajectories' rows of one [N][ld] data-set
+// tensor land in LDS as [256][P] (P odd: a lane per trajectory then reads without
+// bank conflicts) by direct-to-LDS loads - one wave instruction moves 64
+// consecutive floats of that image, i.e. pieces of at most two source rows: a few
+// cache lines per instruction, where a lane-per-trajectory load touches 64.
+// rows: the workgroup's 256 source row numbers (LDS); R <= P columns are read,
+// the pad columns get zeros (offset kDead).
+template <int P>
+__device__ __forceinline__ void gather_rows_issue(float *dst, const int *rows,
+                                                  const float *base, unsigned bytes, int ld,
+                                                  int R) {
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  const auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes,
+                                                   0x00020000);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves = blockDim.x >> 6;
+  for (int n = wave; n < 4 * P; n += waves) {      // 256 P / 64 instructions
+    const int e = n * 64 + lane, t = e / P, j = e - t * P;
+    const unsigned voff =
+        j < R ? ((unsigned)rows[t] * (unsigned)ld + (unsigned)j) * 4u : kDead;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + n * 64), 4, (int)voff, 0, 0,
+                                             0);
+  }
+}
+
 }  // namespace apg

@@ -1763,11 +1763,32 @@ class QuadConcurrentStepPlan:
     (TrainBase rebuilds it when its step signature changes).  The gradients are
     views of `flat` (+ one slot for the loss), `named` by parameter name."""
 
-    def __init__(self, net, prepared, dt, params, weights=None, update=None):
+    def __init__(self, net, prepared, dt, params, weights=None, update=None, rows=None):
+        """rows = (normed [N,15], state0 [N,12], in_ref [N,>=10,9], ref [N,>=10,9|6],
+        B): the DATA SET's tensors - `launch(index=...)` then names the batch by
+        row numbers and the forward kernel reads the rows itself
+        (apg_quad_mlp_concurrent_train_step_rows: no gather pass, `prepared` is
+        None)."""
         if not CONCURRENT_IN_SWEEP:
             raise ValueError("the step plan needs the in-sweep path")
-        acts, s0, rf = prepared
-        B, H = s0.shape[-1], 10
+        if rows is not None:
+            normed, st0, inr, rfs, B = rows
+            for t in (normed, st0, inr, rfs):
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise ValueError("rows: contiguous float32 device tensors")
+            N = st0.shape[0]
+            if (normed.shape != (N, 15) or st0.shape != (N, 12) or inr.shape[0] != N
+                    or inr.shape[1] < 10 or inr.shape[2] != 9 or rfs.shape[0] != N
+                    or rfs.shape[1] < 10 or rfs.shape[2] not in (9, 6)):
+                raise ValueError("rows: normed [N,15], state0 [N,12], in_ref [N,>=10,9], "
+                                 "ref [N,>=10,9|6]")
+            acts = torch.empty(431 + 90, B, dtype=torch.float32, device=st0.device)
+            s0 = rf = None
+            prepared = (acts, None, None)
+            H = 10
+        else:
+            acts, s0, rf = prepared
+            B, H = s0.shape[-1], 10
         tensors = _net_params(net, _MLP_PARAMS)
         shapes = {"states_in.weight": (64, 15), "conv_ref.weight": (20, 9, 3),
                   "fc1.weight": (64, 224), "fc_out.weight": (40, 64)}
@@ -1778,8 +1799,9 @@ class QuadConcurrentStepPlan:
                 raise ValueError("the step plan needs contiguous float32 parameters")
         if B == 0:
             raise ValueError("the step plan needs a non-empty batch")
-        require_device(acts, s0, rf, *tensors)
-        dev = s0.device
+        require_device(acts, *tensors) if rows is not None else \
+            require_device(acts, s0, rf, *tensors)
+        dev = acts.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
                  "w_3", "b_3", "w_out", "b_out")
@@ -1813,16 +1835,40 @@ class QuadConcurrentStepPlan:
             upd = ctypes.byref(k["upd"])
         self.updates = update is not None
         self._dev = dev
-        self._fn = lib().apg_quad_mlp_concurrent_train_step
-        self._args = (ptr(s0), ptr(rf), rf.shape[1], float(dt), ctypes.byref(params),
-                      ctypes.byref(k["weights"]), ctypes.byref(k["pol"]), B, H, ptr(acts),
-                      k["relu_mask"].data_ptr(), ptr(k["d_zout"]), ptr(k["partials"]),
-                      ptr(self.loss), ctypes.byref(k["gs"]), None, ptr(k["ws"]),
-                      ptr(k["part"]), upd)
+        self.B = B
+        tail = (float(dt), ctypes.byref(params),
+                ctypes.byref(k["weights"]), ctypes.byref(k["pol"]), B, H, ptr(acts),
+                k["relu_mask"].data_ptr(), ptr(k["d_zout"]), ptr(k["partials"]),
+                ptr(self.loss), ctypes.byref(k["gs"]), None, ptr(k["ws"]),
+                ptr(k["part"]), upd)
+        # rows plans: every launch adds its loss to `running` (an epoch loop
+        # zeroes it, reads it once at the end)
+        self.running = torch.zeros(1, dtype=torch.float32, device=dev)
+        if rows is not None:
+            k["rows_src"] = (normed, st0, inr, rfs)
+            self._rows = k["rows"] = _capi.ApgBatchRows(
+                index=None, normed=ptr(normed), state0=ptr(st0), in_ref=ptr(inr),
+                ref=ptr(rfs), ld_normed=15, ld_state0=12,
+                ld_in_ref=inr.shape[1] * 9, ld_ref=rfs.shape[1] * rfs.shape[2], n_rows=N,
+                running_loss=ptr(self.running))
+            self._fn = lib().apg_quad_mlp_concurrent_train_step_rows
+            self._args = (ctypes.byref(self._rows), rfs.shape[2]) + tail
+        else:
+            self._rows = None
+            self._fn = lib().apg_quad_mlp_concurrent_train_step
+            self._args = (ptr(s0), ptr(rf), rf.shape[1]) + tail
 
-    def launch(self, events=None):
+    def launch(self, events=None, index=None):
         """Enqueue the step on the current stream; returns the loss (0-dim view
-        of the plan's loss buffer: overwritten by the next launch)."""
+        of the plan's loss buffer: overwritten by the next launch).  index (rows
+        plans): int64 [B] device tensor, contiguous - this batch's rows; the
+        caller keeps it alive until the step has run."""
+        if self._rows is not None:
+            if (index is None or index.dtype != torch.int64 or not index.is_cuda
+                    or index.numel() != self.B or not index.is_contiguous()):
+                raise ValueError("rows plan: index must be a contiguous int64 device "
+                                 f"tensor of {self.B} row numbers")
+            self._rows.index = index.data_ptr()
         check(self._fn(*self._args, _step_events(events),
                        torch.cuda.current_stream(self._dev).cuda_stream),
               "apg_quad_mlp_concurrent_train_step")

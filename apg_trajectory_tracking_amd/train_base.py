@@ -229,10 +229,11 @@ class _PlannedStep:
         from . import functional
         self.planes = functional.static_plane_refs()
 
-    def __call__(self, borrow=False, events=None):
+    def __call__(self, borrow=False, events=None, index=None):
         if self.before is not None:
             self.before()
-        loss = self.plan.launch(events)
+        loss = (self.plan.launch(events) if index is None
+                else self.plan.launch(events, index=index))
         for p, g in self.grads:
             p.grad = g
         return loss if borrow else loss.clone()
@@ -696,7 +697,8 @@ class TrainBase:
         return (bool(self.plan_steps) and self._graphable() and not self._reducing()
                 and torch.cuda.is_available())
 
-    def _planned(self, key, inputs, build, volatile=(), events=None, params=None):
+    def _planned(self, key, inputs, build, volatile=(), events=None, params=None,
+                 index=None):
         """Run the step from its plan, (re)built by `build()` when the signature
         of `_graphed` no longer holds (same meaning of `inputs` / `volatile`)."""
         cache = getattr(self, "_epoch_sigs", None)
@@ -712,6 +714,9 @@ class TrainBase:
             g.signature = self._graph_signature(inputs, volatile, params)
             if cache is not None:
                 cache[key] = g.signature
+        if index is not None:     # (a rows plan: the batch is named per launch)
+            return g(borrow=getattr(self, "_borrow_loss", False) or self.borrow_loss,
+                     events=events, index=index)
         return g(borrow=getattr(self, "_borrow_loss", False) or self.borrow_loss,
                  events=events)
 
@@ -1028,6 +1033,9 @@ class TrainBase:
         indexed = lambda: hasattr(self.trainloader, "iter_indices")
         ctrl = lambda train: train == "controller" and indexed()
         return [
+            ("concurrent, rows read through the index by the forward kernel",
+             lambda t: ctrl(t) and self.train_mode == "concurrent"
+             and self.concurrent_rows_ok(), self._epoch_concurrent_rows),
             ("pipelined", lambda t: ctrl(t) and self._wants_pipeline()
              and self.prefetch_plan() is not None, self._epoch_pipelined),
             ("concurrent, gather folded into the fused step",
@@ -1043,6 +1051,10 @@ class TrainBase:
              and self.recurrent_indexed_ok(), self._epoch_recurrent_indexed),
             ("loader", lambda t: True, self._epoch_loader),
         ]
+
+    def concurrent_rows_ok(self):
+        """Hook: the fused concurrent step reads index batches itself."""
+        return False
 
     def _wants_pipeline(self):
         # (the concurrent epoch graph forks the next batch's gather behind the
@@ -1063,6 +1075,45 @@ class TrainBase:
             ("concurrent", "indexed"), lambda indices: self._indexed_epoch(
                 lambda index: self.train_concurrent_fused(*tensors, index=index),
                 indices)), train)
+
+    def _epoch_concurrent_rows(self, train):
+        """The concurrent epoch with every batch named by its rows: per batch
+        ONE library call (apg_quad_mlp_concurrent_train_step_rows - the forward
+        kernel reads the data set through the index, the second stage applies
+        the update and adds the loss to the plan's running sum).  The first
+        batch of each size goes through the step's own entry point (which builds
+        or re-validates the plan, once per epoch); the others call the plan
+        directly - ~25 us of host time against ~140 us of kernels, so the launches
+        run back to back in stream order: no graph, no gather, no loss kernel."""
+        ld = self.trainloader
+        tensors = ld.tensors
+        for g in self._graphs.values():
+            if getattr(g, "planned", False) and hasattr(g.plan, "running"):
+                g.plan.running.zero_()
+        fast, i = {}, -1
+        self._borrow_loss, self._epoch_sigs = True, {}
+        order = ld.epoch_order() if hasattr(ld, "prefetch_order") else None
+        if order is not None:          # the next epoch's permutation, drawn beside this one
+            if "order_stream" not in self._prefetch:
+                self._prefetch["order_stream"] = torch.cuda.Stream()
+            ld.prefetch_order(self._prefetch["order_stream"])
+        try:
+            for i, index in enumerate(ld.iter_indices(order)):
+                plan = fast.get(index.numel())
+                if plan is not None:
+                    plan.launch(index=index)
+                    continue
+                self.train_concurrent_fused(*tensors, index=index)
+                g = self._graphs.get(("concurrent", index.numel(), "rows"))
+                if getattr(g, "planned", False):
+                    fast[index.numel()] = g.plan
+        finally:
+            self._borrow_loss, self._epoch_sigs = False, None
+        total = None
+        for plan in fast.values():
+            total = plan.running.clone() if total is None else total + plan.running
+        return self._finish_epoch(total if total is not None
+                                  else torch.zeros(1, device=tensors[0].device), i, train)
 
     def _epoch_packed(self, train):
         # any PyTorch policy on the row-layout tensors of the fastest rollout

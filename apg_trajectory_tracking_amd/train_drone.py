@@ -221,6 +221,30 @@ class TrainDrone(TrainBase):
                 lambda prepared, slot: self.train_recurrent_model(
                     None, None, None, None, prepared=prepared, slot=slot))
 
+    # the concurrent step names its batch by row numbers and the forward kernel
+    # reads the data set's rows itself (no gather pass)
+    rows_in_kernel = True
+
+    @staticmethod
+    def _rows_ok(normed, states, in_ref, ref, index):
+        ok = lambda t: (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                        and t.numel() * 4 < (1 << 32) - 64)
+        return (all(ok(t) for t in (normed, states, in_ref, ref))
+                and index.is_cuda and index.dtype == torch.int64 and index.is_contiguous()
+                and normed.dim() == 2 and normed.shape[1] == 15 and in_ref.dim() == 3
+                and in_ref.shape[1] >= 10 and in_ref.shape[2] == 9 and ref.dim() == 3
+                and ref.shape[1] >= 10 and ref.shape[2] in (9, 6))
+
+    def concurrent_rows_ok(self):
+        ld = self.trainloader
+        if not (self.rows_in_kernel and torch.cuda.is_available() and ld is not None
+                and self.train_concurrent_fused(None, None, None, None, probe=True)
+                and self._in_kernel_update(F.CONCURRENT_IN_SWEEP) is not None
+                and self._plannable()):
+            return False
+        probe = torch.empty(0, dtype=torch.int64, device=ld.tensors[0].device)
+        return self._rows_ok(*ld.tensors, probe)
+
     def recurrent_indexed_ok(self):
         """run_epoch may hand index batches to train_recurrent_model."""
         return self.fused_policy and (
@@ -268,6 +292,19 @@ class TrainDrone(TrainBase):
                 lambda: _PlannedStep(F.QuadConcurrentStepPlan(
                     n, prepared, self.delta_t, dyn.params, update=update), n),
                 volatile=tuple(prepared), events=events, params=tensors12)
+        if planned and index is not None and self.rows_in_kernel and self._rows_ok(
+                in_state, current_state, in_ref_states, ref_states, index):
+            # the forward kernel reads the batch's rows through the index itself
+            # (apg_quad_mlp_concurrent_train_step_rows): no gather, no copy of
+            # the index - the plan takes its address per launch
+            B = index.numel()
+            src = (in_state, current_state, in_ref_states, ref_states)
+            return self._planned(
+                ("concurrent", B, "rows"), src,
+                lambda: _PlannedStep(F.QuadConcurrentStepPlan(
+                    n, None, self.delta_t, dyn.params, update=update,
+                    rows=src + (B,)), n),
+                params=tensors12, index=index)
         if planned and index is not None:
             held = self._graph_index(index)       # persistent copy of the batch rows
             B = held.numel()

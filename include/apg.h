@@ -449,6 +449,31 @@ int apg_quad_mlp_concurrent_train_step(
     float *states, float *workspace, float *partials, const ApgMlpSgdUpdate *update,
     const ApgStepEvents *events, apg_stream_t stream);
 
+/* The same step with the minibatch selection inside (round 5; the batch
+ * selection of TrainBase.run_epoch, scripts/train_base.py:191-194, without a
+ * gather pass): the forward kernel reads its trajectories' rows of the DATA SET's
+ * tensors through `index` - normed [N][ld_normed] (15 columns read), state0
+ * [N][ld_state0] (12), in_ref [N][ld_in_ref] (90), ref [N][ld_ref] (H x
+ * ref_cols), float32 device memory, row strides in floats, every tensor below
+ * 4 GiB - and writes the feature / window planes of `acts` itself (the caller
+ * fills nothing).  index [B]: int64 row numbers in [0, n_rows), device memory.
+ * running_loss (or NULL): one device float the step's loss is ADDED to - the
+ * epoch loop's `running_loss += loss` (scripts/train_base.py:212) without a
+ * launch of its own; needs `loss`. */
+typedef struct ApgBatchRows {
+  const long long *index;
+  const float *normed, *state0, *in_ref, *ref;
+  int ld_normed, ld_state0, ld_in_ref, ld_ref;
+  long long n_rows;
+  float *running_loss;
+} ApgBatchRows;
+int apg_quad_mlp_concurrent_train_step_rows(
+    const ApgBatchRows *rows, int ref_cols, float dt, const ApgQuadParams *params,
+    const ApgQuadLossWeights *weights, const ApgMlpPolicy *policy, int B, int H,
+    float *acts, unsigned *relu_mask, float *d_zout, float *loss_partials, float *loss,
+    const ApgMlpPolicyGrads *grads, float *states, float *workspace, float *partials,
+    const ApgMlpSgdUpdate *update, const ApgStepEvents *events, apg_stream_t stream);
+
 /* The AUTOREGRESSIVE training step in one call (round 5; configs[2] per rank):
  * TrainDrone.train_recurrent_model's unroll, loss and loss.backward()
  * (scripts/train_drone.py:113-173) for Net(15, 10, 9, 4, conv=1) - the forward

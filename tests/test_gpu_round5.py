@@ -513,3 +513,99 @@ def test_linear_weight_gradient_with_mixed_dtypes_under_autocast(dev):
         outs.append((m.weight.grad, m.bias.grad, xi.grad))
     for a, b in zip(*outs):
         assert a.dtype == b.dtype and rel_err(N(a), N(b)) < 1e-2
+
+
+# ------------------------------------------------- item 4: the gather, folded
+@pytest.mark.parametrize("B,rows_per_ref", [(65536, 10), (1000, 20), (31, 10)])
+def test_rows_read_through_the_index_equal_the_gathered_step(dev, B, rows_per_ref):
+    """apg_quad_mlp_concurrent_train_step_rows - the forward
+    kernel reads its trajectories' rows of the data set's tensors through the
+    index (direct-to-LDS loads) - against the same step on planes gathered by
+    apg_to_soa_multi: loss, every gradient and the parameters after three
+    in-kernel SGD steps, bit for bit (the arithmetic is the same; only where the
+    inputs come from differs).  Ragged batch, repeated rows, 20-row windows."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    N_ = 3 * B + 17
+    d = synthetic.quad_polynomial_batch(N_, H, DT, seed=5, ref_length=rows_per_ref)
+    st, inr, rf = (d[k].to(dev).contiguous() for k in ("state0", "in_ref", "ref"))
+    with torch.no_grad():
+        normed = state_preprocessing(st).contiguous()
+    gen = torch.Generator().manual_seed(B)
+    index = torch.randint(0, N_, (B,), generator=gen).to(dev)
+    index[B // 2] = index[0]                                  # a row used twice
+    params = FlightmareDynamics().params
+    results = []
+    for rows in (False, True):
+        torch.manual_seed(1)
+        net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+        names = F._MLP_PARAMS
+        bufs = {n: torch.zeros_like(p) for n, p in net.named_parameters() if n in names}
+        update = (1e-6, 0.9, bufs)
+        if rows:
+            plan = F.QuadConcurrentStepPlan(net, None, DT, params, update=update,
+                                            rows=(normed, st, inr, rf, B))
+            step = lambda: plan.launch(index=index)
+        else:
+            prepared = F.quad_concurrent_prepare(normed, st, inr, rf, index=index)
+            plan = F.QuadConcurrentStepPlan(net, prepared, DT, params, update=update)
+            step = lambda: plan.launch()
+        losses = [float(step()) for _ in range(3)]
+        results.append((losses, plan.flat.clone(), [p.detach().clone() for p in net.parameters()]))
+    (l0, g0, p0), (l1, g1, p1) = results
+    assert l0 == l1 and np.isfinite(l0).all()
+    assert torch.equal(g0[:-1], g1[:-1])     # (the last slot is the all-reduce's loss)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
+def test_rows_step_argument_checks(dev):
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    d = synthetic.quad_polynomial_batch(64, H, DT, seed=5, ref_length=10)
+    st, inr, rf = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    normed = state_preprocessing(st)
+    net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+    params = FlightmareDynamics().params
+    plan = F.QuadConcurrentStepPlan(net, None, DT, params, rows=(normed, st, inr, rf, 32))
+    with pytest.raises(ValueError):
+        plan.launch()                                             # no index
+    with pytest.raises(ValueError):
+        plan.launch(index=torch.arange(32, device=dev, dtype=torch.int32))
+    with pytest.raises(ValueError):
+        plan.launch(index=torch.arange(31, device=dev))
+    with pytest.raises(ValueError):
+        F.QuadConcurrentStepPlan(net, None, DT, params,
+                                 rows=(normed.double(), st, inr, rf, 32))
+    assert np.isfinite(float(plan.launch(index=torch.arange(32, device=dev))))
+
+
+def test_run_epoch_concurrent_names_its_batches_by_rows(dev):
+    """run_epoch's concurrent loop takes the rows path (no to_soa gather) and
+    trains exactly as the loop over gathered batches does."""
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    outs = []
+    for rows in (True, False):
+        cfg = dict(QUAD_CFG, batch_size=96, epoch_size=300, self_play=0)
+        t = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), cfg)
+        t.rows_in_kernel = rows
+        t.shuffle = False
+        t.initialize_model(device=dev, seed=3)
+        if outs:
+            t.net.load_state_dict(first)
+        else:
+            first = copy.deepcopy(t.net.state_dict())
+        losses = [t.run_epoch("controller", e) for e in range(3)]
+        assert ("rows" in t.last_epoch_loop) == rows
+        outs.append((losses, _params(t)))
+    assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-6)   # (sums in another order)
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)

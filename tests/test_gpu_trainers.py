@@ -1558,6 +1558,10 @@ def test_run_epoch_replays_one_graph_over_shuffled_minibatches(dev, mode, prefet
             t.net.load_state_dict(runs[0][2])      # same start
         start = copy.deepcopy(t.net.state_dict())
         t.graph_steps, t.prefetch_batches = graph, pre
+        # (one process, fp32 data set: the concurrent epoch names its batches by
+        # rows - tests/test_gpu_round5.py; this is the gather pipeline that
+        # N > 1 ranks, other optimizers and other data sets run)
+        t.rows_in_kernel = False
         torch.manual_seed(11)                      # the permutations
         torch.cuda.manual_seed(12)
         losses = [t.run_epoch(train="controller", epoch=e) for e in range(3)]
