@@ -459,10 +459,7 @@ class TrainBase:
             return None
         # a user's step hooks run around optimizer.step(): with hooks registered
         # (on this optimizer or globally) the step is left to the optimizer
-        from torch.optim import optimizer as _opt_mod
-        if (opt._optimizer_step_pre_hooks or opt._optimizer_step_post_hooks
-                or getattr(_opt_mod, "_global_optimizer_pre_hooks", None)
-                or getattr(_opt_mod, "_global_optimizer_post_hooks", None)):
+        if self._step_hooks():
             return None
         g = opt.param_groups[0]
         if (not g["momentum"] or g["dampening"] or g["nesterov"] or g["weight_decay"]
@@ -525,11 +522,24 @@ class TrainBase:
         return [v for st in self.optimizer_controller.state.values()
                 for v in st.values() if torch.is_tensor(v)]
 
+    def _step_hooks(self):
+        """The optimizer has step hooks (its own or global ones)."""
+        from torch.optim import optimizer as _opt_mod
+        opt = self.optimizer_controller
+        return bool(getattr(opt, "_optimizer_step_pre_hooks", None)
+                    or getattr(opt, "_optimizer_step_post_hooks", None)
+                    or getattr(_opt_mod, "_global_optimizer_pre_hooks", None)
+                    or getattr(_opt_mod, "_global_optimizer_post_hooks", None))
+
     def _graphable(self):
         # (inside the capture of a whole epoch the steps run "eagerly": their
         # launches are what is being captured)
         if not (bool(self.graph_steps) and not self._in_epoch_capture
                 and (torch.cuda.is_available() or self.graph_emulation)):
+            return False
+        # (a replayed graph runs no Python: step hooks would be skipped, and a
+        # capture's warm-up steps would call them for steps that are undone)
+        if self._step_hooks():
             return False
         # (a step whose kernels outlast the host's launch work may run faster in
         # stream order: measured once, see launch_form)
