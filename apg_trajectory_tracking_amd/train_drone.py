@@ -107,6 +107,14 @@ class TrainDrone(TrainBase):
         self.optimizer_controller.zero_grad()
         fused = self.fused_policy and (
             self._fusable() if self.train_mode == "LSTM" else self._fusable_mlp())
+        # autoregressive, one process: the reverse sweep's second stage applies
+        # the optimizer's update (as the concurrent step's does)
+        update = None
+        if fused and self.train_mode != "LSTM":
+            nb = (prepared[2].shape[-1] if prepared is not None
+                  else current_state.size()[0] if index is None else index.numel())
+            update = self._in_kernel_update(F.AR_IN_SWEEP and 0 < nb <= F._MAX_FUSED_AR_BATCH)
+        stepped = update is not None
         if prepared is not None:
             if not fused:
                 raise ValueError("prepared batches need the fused policy path")
@@ -126,10 +134,10 @@ class TrainDrone(TrainBase):
                 def compute():
                     return F.quad_mlp_rollout_grads(
                         self.net, None, None, None, self.delta_t,
-                        self.train_dynamics.params, **kw)
+                        self.train_dynamics.params, update=update, **kw)
             if lstm_eager:
                 return self._step_direct(*compute())
-            return self._graphed(key, (), self._direct_parts(compute),
+            return self._graphed(key, (), self._direct_parts(compute, stepped),
                                  volatile=tuple(prepared))
         batch_size = current_state.size()[0] if index is None else index.numel()
         static = index is None and self.static_shard
@@ -165,14 +173,14 @@ class TrainDrone(TrainBase):
                 return F.quad_mlp_rollout_grads(
                     self.net, current_state, in_ref_states, ref_states,
                     self.delta_t, self.train_dynamics.params, index=index,
-                    static_inputs=self.static_shard)
+                    static_inputs=self.static_shard, update=update)
             if held is not None:
                 return self._graphed(("autoregressive", batch_size), tensors,
-                                     self._direct_parts(compute), volatile=(held,))
+                                     self._direct_parts(compute, stepped), volatile=(held,))
             if static:
                 return self._graphed("autoregressive", tensors,
-                                     self._direct_parts(compute))
-            return self._step_direct(*compute())
+                                     self._direct_parts(compute, stepped))
+            return self._step_direct(*compute(), stepped=stepped)
         if index is not None:     # per-step path: materialise the batch
             current_state, in_ref_states, ref_states = (
                 t.index_select(0, index) for t in

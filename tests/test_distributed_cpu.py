@@ -160,7 +160,8 @@ def _ar_steps(lo, hi, graphed=False, split=None, new_buffers_on_rank=None):
     from oracle import torch_port as tp
 
     def oracle_grads(net, state0, in_ref, ref, dt, params, weights=None,
-                     index=None, static_inputs=False):
+                     index=None, static_inputs=False, update=None):
+        assert update is None      # (CPU tensors: the optimizer object steps)
         _, _, loss = tp.quad_recurrent_unroll(net, tp.QuadOracle(), state0,
                                               in_ref, ref, H, dt)
         named = list(net.named_parameters())

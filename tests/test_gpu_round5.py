@@ -609,3 +609,29 @@ def test_run_epoch_concurrent_names_its_batches_by_rows(dev):
     assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-6)   # (sums in another order)
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_autoregressive_step_applies_the_update_inside_its_second_stage(dev, graph):
+    """The autoregressive trainer step with momentum SGD applied by the reverse
+    sweep's second stage (one process) == the same step followed by
+    optimizer.step() (torch's fused SGD: the same arithmetic): losses, gradients,
+    parameters and momentum buffers of four steps, bit for bit."""
+    from apg_trajectory_tracking_amd import functional as F
+    outs = []
+    for in_kernel in (True, False):
+        F._STATIC_PLANES.entries.clear()
+        t, step = _trainer("autoregressive", 1500, dev)
+        t.graph_steps, t.in_kernel_update = graph, in_kernel
+        t.measure_launch_form = False
+        losses = [float(step()) for _ in range(4)]
+        assert (t._in_kernel_update(True) is not None) == in_kernel
+        bufs = [t.optimizer_controller.state[p]["momentum_buffer"].clone()
+                for p in t.net.parameters() if p.grad is not None]
+        outs.append((losses, _params(t), bufs,
+                     [p.grad.clone() for p in t.net.parameters() if p.grad is not None]))
+    (la, pa, ba, ga), (lb, pb, bb, gb) = outs
+    assert la == lb and la[3] < la[0]
+    for xs, ys in ((pa, pb), (ba, bb), (ga, gb)):
+        assert len(xs) == len(ys) and all(torch.equal(x, y) for x, y in zip(xs, ys))
+    F._STATIC_PLANES.entries.clear()

@@ -93,13 +93,16 @@ def blocks_of(body):
     """[(label, loop header or None, [mnemonics])] in program order."""
     out, cur = [], ["entry", None, []]
     for l in body:
-        m = re.match(r"^\.?(LBB\d+_\d+):\s*(;.*)?$", l)
+        m = re.match(r"^\.?(LBB\d+_\d+):\s*(;.*)?$", l) or \
+            re.match(r"^; %(bb\.\d+):\s*(;.*)?$", l)
         if m:
             out.append(tuple(cur))
             note = m.group(2) or ""
             hdr = None
             if "Loop Header" in note:
                 hdr = m.group(1)[1:]
+            elif m.group(1).startswith("bb.") and "in Loop" not in note:
+                hdr = cur[1] if False else None
             mm = re.search(r"in Loop: Header=(BB\d+_\d+)", note)
             if mm:
                 hdr = mm.group(1)
@@ -118,6 +121,10 @@ def main():
     ap.add_argument("--asm")
     ap.add_argument("--kernel", default="wing_rollout_pk_kernelILi1E")
     ap.add_argument("--trips", nargs="*", default=["BB4_73=20", "BB4_93=5", "BB4_4=0"])
+    # blocks behind a condition of the launch: factor on their loop's trip count
+    # (defaults: the states_out stores of the forward step - no states are asked
+    # for in the bench launch; the checkpoint stash - every 4th forward step)
+    ap.add_argument("--scale", nargs="*", default=["bb.77=0", "LBB4_75=0.25"])
     ap.add_argument("--ghz", type=float, default=2.25)
     ap.add_argument("--measured-cycles", type=float, default=123616.0)
     ap.add_argument("--json")
@@ -131,6 +138,7 @@ def main():
              os.path.join(SRC, "wing.hip"), "-o", asm], stderr=subprocess.DEVNULL)
     trips = dict(t.split("=") for t in a.trips)
     trips = {k: float(v) for k, v in trips.items()}
+    scale = {k: float(v) for k, v in (t.split("=") for t in a.scale)}
     blocks = blocks_of(kernel_body(asm, a.kernel))
     per_class = collections.Counter()
     per_loop = collections.Counter()
@@ -143,6 +151,7 @@ def main():
             seen_loops.add(hdr)
         if mult is None:
             sys.exit(f"loop {hdr} has no trip count (--trips {hdr}=N)")
+        mult *= scale.get(label, 1.0)
         for op in ops:
             c = classify(op)
             static[c] += 1
@@ -151,7 +160,8 @@ def main():
             per_loop[hdr or "straight-line"] += mult * COST[c][0]
     total = sum(per_class.values())
     res = {
-        "kernel": a.kernel, "trips": trips, "loops_found": sorted(seen_loops),
+        "kernel": a.kernel, "trips": trips, "block_scale": scale,
+        "loops_found": sorted(seen_loops),
         "static_instructions": dict(static), "dynamic_instructions": dict(counts),
         "cycles_per_class": {k: round(v, 1) for k, v in per_class.items()},
         "cycles_per_loop": {k: round(v, 1) for k, v in per_loop.items()},
