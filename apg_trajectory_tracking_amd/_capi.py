@@ -105,7 +105,8 @@ class ApgMlpSgdUpdate(ctypes.Structure):
     """apg_quad_mlp_concurrent_train_step's optimizer part: momentum SGD on
     the policy's tensors and the optimizer's momentum buffers."""
     _fields_ = [("lr", ctypes.c_double), ("momentum", ctypes.c_double),
-                ("param", ApgMlpPolicyGrads), ("momentum_buf", ApgMlpPolicyGrads)]
+                ("param", ApgMlpPolicyGrads), ("momentum_buf", ApgMlpPolicyGrads),
+                ("resident", ctypes.c_int)]
 
 
 class ApgWingPolicy(ctypes.Structure):

@@ -1534,6 +1534,7 @@ constexpr int uConv = sConv, uBias = sConv + 1, kSlotsTm = sConv + 3;
 static_assert(kThreads == kTmThreads, "policy_tm.h");
 struct TmMeta {           // at tMeta; written by plain stores, one slot per wave
   unsigned dmax[4][8];    // max |cotangent| bits of head, fc3, fc2, fc1
+  float wnorm[8];         // largest column 1-norm of W_1 in row block `wave` of W_1^T
 };
 
 __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs A) {
@@ -1557,9 +1558,32 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
   float *part = A.part + (size_t)blockIdx.x * kSlotsTm * 1024;
   char *lane_blk = lds + lane * 4;           // + region + block * 4096 + i * 256
   TmMeta &meta = *reinterpret_cast<TmMeta *>(lds + tMeta);
-  // 2^ns, 2^nc: above the largest column 1-norm of W_1's state / conv part
-  const int ns = (int)A.tables[kWgTabFloats], nc = (int)A.tables[kWgTabFloats + 1];
   bool bad = false;         // (workgroup-uniform) a non-finite operand was seen
+  // The column 1-norms of W_1 (a bound on |W_1^T delta| per unit of max |delta|:
+  // the scales of the states_in / conv cotangents, which are produced inside
+  // the fc1 phase) - from the packed tables, first thing (nothing else is live
+  // yet): wave w takes row block w of W_1^T (five blocks of the conv part, two
+  // of the state part), a lane its row's 2 x 32 entries; the maxima are read
+  // behind the layer barriers.  (Round 4: a block of the pack launch computed
+  // them from the weights.  The tables' fp16 pairs carry the weights to 2^-22:
+  // the same exponents.)
+  if (wave < 7) {
+    const int n0 = wave < 5 ? wC + 4 * wave : wS + 4 * (wave - 5);
+    const u32x4 *tb = reinterpret_cast<const u32x4 *>(A.tables) + n0 * (kBlock16 / 16) + lane;
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const u32x4 th = tb[kb * (kBlock16 / 16)], tl = tb[kb * (kBlock16 / 16) + 64];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const h16x2 h_ = __builtin_bit_cast(h16x2, th[q]), l_ = __builtin_bit_cast(h16x2, tl[q]);
+        sum += fabsf((float)h_[0] + (float)l_[0]) + fabsf((float)h_[1] + (float)l_[1]);
+      }
+    }
+    sum += other_half(sum);
+    sum = wave_fmax(sum);
+    if (lane == 0) meta.wnorm[wave] = sum;
+  }
 
   // ---- this wave's inputs: dL/dz feature-major (20 rows per half-wave) and
   // trajectory-major (rows 0..31 and 32..39), h3's first block; the maxima of
@@ -1603,6 +1627,16 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
     }
     __syncthreads();
   }
+  // 2^ns, 2^nc: above the largest column 1-norm of W_1's state / conv part
+  // (a non-finite norm: 0 - the gradients are non-finite anyway); scalars
+  const auto norm_exp = [](float m) {
+    return __builtin_amdgcn_readfirstlane(
+        m > 0.f && m < 3.0e38f ? __builtin_amdgcn_frexp_expf(m) : 0);
+  };
+  int nc = norm_exp(fmaxf(fmaxf(fmaxf(meta.wnorm[0], meta.wnorm[1]),
+                                fmaxf(meta.wnorm[2], meta.wnorm[3])), meta.wnorm[4]));
+  int ns = norm_exp(fmaxf(meta.wnorm[5], meta.wnorm[6]));
+  asm volatile("" : "+s"(nc), "+s"(ns));    // (computed HERE, kept in scalar registers)
   // exponent of this lane's head rows (32 mb + row): 2^e above the row's largest
   // cotangent of the workgroup (biased exponent field E: value < 2^(E - 126))
   int erow[2];
@@ -1636,7 +1670,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
   const int fc = bits_exp(mc, bad, true), ff = bits_exp(mf, bad, true),
             fi = bits_exp(mi, bad, true);
   const LdsView16 L16(lds, lane);
-
   float hv[2][16];
   auto load_hv = [&](int plane) {
 #pragma unroll
@@ -2070,7 +2103,87 @@ struct WgReduceArgs {
   float *loss;
   float *loss_sum;       // or NULL: += the loss (an epoch loop's running sum)
   int wgs, n_partials;   // wgs: how many [n_slots * 1024] rows `part` has
+  // resident operand tables (see kMapFlag32): the thread that has updated a
+  // parameter also rewrites its entries of the packed tables in `ws`
+  char *ws;
+  const int *map;        // [n_slots * 1024][4] byte offsets into ws, -1: none
 };
+
+// Resident operand tables (round 5).  The step's kernels read the policy from
+// PACKED tables (fp16 pairs in matrix-operand order + a few float tables,
+// mlp_pack_step_kernel: a launch of its own at the head of every step, 5-6 us).
+// When the update happens inside the second stage the new value of a parameter
+// is in the register of exactly one thread - which then writes the parameter's
+// table entries for the NEXT step itself, and the pack launch goes away.  Where
+// a parameter sits in the tables is not re-derived by hand: once per workspace
+// the pack kernel runs on parameter arrays that hold their own indices, and the
+// result is inverted into map[reduce thread][4] (tabmap_* below; the fp16 pair
+// of an index < 32 768 adds up to it exactly).
+constexpr int kMapFlag32 = 1 << 30;   // the entry is one float (bias / VALU-head tables)
+constexpr int kParamFloats = kW * kNF + kW + kNC * 27 + kNC + kW * kN1 + kW +
+                             2 * (kW * kW + kW) + kNA * kW + kNA;   // 26 904
+constexpr int kMapInts = (sConv + 3) * 1024 * 4;
+
+__host__ __device__ inline ApgMlpPolicyGrads params_in(float *base) {
+  ApgMlpPolicyGrads g;
+  float *q = base;
+  g.w_s = q, q += kW * kNF;
+  g.b_s = q, q += kW;
+  g.conv_w = q, q += kNC * 27;
+  g.conv_b = q, q += kNC;
+  g.w_1 = q, q += kW * kN1;
+  g.b_1 = q, q += kW;
+  g.w_2 = q, q += kW * kW;
+  g.b_2 = q, q += kW;
+  g.w_3 = q, q += kW * kW;
+  g.b_3 = q, q += kW;
+  g.w_out = q, q += kNA * kW;
+  g.b_out = q;
+  return g;
+}
+
+__global__ __launch_bounds__(256) void tabmap_iota_kernel(float *par) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < kParamFloats) par[i] = (float)(i + 1);
+}
+
+// owner[id] = the second-stage thread that sums (and updates) parameter `id`
+__global__ __launch_bounds__(256) void tabmap_owner_kernel(float *par, int *owner, int *map,
+                                                           int n_slots, int bias_slot) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_slots * 1024) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) map[t * 4 + k] = -1;
+  const float *dst = wg_dest(params_in(par), t >> 10, (t >> 6) & 15, t & 63, bias_slot, kNA,
+                             false);
+  if (dst) owner[dst - par] = t;
+}
+
+// tab: the tables packed from index-valued parameters; every entry is appended
+// to the list of its parameter's owner thread
+__global__ __launch_bounds__(256) void tabmap_invert_kernel(const float *tab, const int *owner,
+                                                            int *map) {
+  const int p = blockIdx.x * 256 + threadIdx.x;   // float index into the workspace
+  if (p >= kCfLds + kWgTabFloats) return;
+  const auto record = [&](float x, int off) {
+    const int id = (int)x - 1;
+    if (id < 0 || id >= kParamFloats) return;
+    int *m = map + owner[id] * 4;
+    for (int k = 0; k < 4; ++k)
+      if (atomicCAS(m + k, -1, off) == -1) return;
+  };
+  if (p < hA / 4) {                   // the forward kernels' float tables
+    record(tab[p], p * 4 | kMapFlag32);
+    return;
+  }
+  const int region = p < kCfLds ? hA : kCfLds * 4;   // first block of this table (bytes)
+  if ((p * 4 - region) % kBlock16 >= 1024) return;   // a word of low terms
+  const h16x2 h = __builtin_bit_cast(h16x2, tab[p]), l = __builtin_bit_cast(h16x2, tab[p + 256]);
+  record((float)h[0] + (float)l[0], p * 4);
+  record((float)h[1] + (float)l[1], p * 4 + 2);
+}
+
+
 
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce1_kernel(const float *part,
                                                                 float *chunk_sums, int wgs,
@@ -2124,7 +2237,23 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
         // form - gets the same bits)
         const float buf = (float)(A.momentum * (double)*pm + (double)s);
         *pm = buf;
-        *pp = (float)((double)*pp - A.lr * (double)buf);
+        const float np_ = (float)((double)*pp - A.lr * (double)buf);
+        *pp = np_;
+        if (A.map) {      // this parameter's entries of the packed tables
+#pragma unroll 1
+          for (int k = 0; k < 4; ++k) {
+            const int e = A.map[t * 4 + k];
+            if (e < 0) break;
+            char *q = A.ws + (e & (kMapFlag32 - 1));
+            if (e & kMapFlag32) {
+              *reinterpret_cast<float *>(q) = np_;
+            } else {      // split_pair's two terms (policy_mfma16.h)
+              const _Float16 h_ = (_Float16)np_;
+              *reinterpret_cast<_Float16 *>(q) = h_;
+              *reinterpret_cast<_Float16 *>(q + 1024) = (_Float16)(np_ - (float)h_);
+            }
+          }
+        }
       }
     }
   }
@@ -3174,14 +3303,19 @@ int apg_quad_mlp_concurrent_fwd_bwd(
 }
 
 
-int apg_quad_mlp_step_workspace_floats(void) { return kCfLds + kWgTabFloats + 4; }
+// [forward tables | in-sweep reverse tables | 4 | map of the resident tables]
+int apg_quad_mlp_step_workspace_floats(void) { return kCfLds + kWgTabFloats + 4 + kMapInts; }
 
 long long apg_quad_mlp_step_partials_floats(int B) {
   if (B <= 0) return 0;
   const long long wgs = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   // the workgroups' partials + the chunk sums of the first reduction level
   // + the forward kernel's per-wave x maxima
-  return (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlotsTm * 1024 + wgs * 32;
+  const long long need = (wgs + (wgs + kRedChunk - 1) / kRedChunk) * kSlotsTm * 1024 + wgs * 32;
+  // (also the scratch of the one-time table map: index parameters, their
+  // tables, owners)
+  const long long scratch = 2ll * kParamFloats + kCfLds + kWgTabFloats + 8;
+  return need > scratch ? need : scratch;
 }
 
 namespace {
@@ -3326,8 +3460,10 @@ int concurrent_train_step(
   A.states = states, A.loss_partials = loss_partials;
   A.tables = workspace;
   // (behind the workgroups' partials and the chunk sums)
-  A.xmax = partials + (size_t)(apg_quad_mlp_step_partials_floats(B) -
-                                (long long)((B + kTrajPerBlock - 1) / kTrajPerBlock) * 32);
+  {
+    const long long wgs_ = (B + kTrajPerBlock - 1) / kTrajPerBlock;
+    A.xmax = partials + (size_t)((wgs_ + (wgs_ + kRedChunk - 1) / kRedChunk) * kSlotsTm * 1024);
+  }
   A.c = make_const(*params, dt);
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
@@ -3346,8 +3482,42 @@ int concurrent_train_step(
   P.pol = *policy, P.dst = workspace, P.head_rows = kNA;
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   const int fwd_blocks = (kCfLds + 255) / 256, bwd_blocks = (kWgTabFloats + 255) / 256;
-  hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks + 1), dim3(256), 0, st,
-                     P, fwd_blocks);
+  // resident tables (ApgMlpSgdUpdate.resident): 2 - the workspace holds the tables
+  // of exactly these parameters, left by the previous call's second stage: no
+  // pack launch; 1 - pack, and (re)build the map the second stage scatters by
+  const int resident = update ? update->resident : 0;
+  if (resident < 0 || resident > 2) {
+    set_error("update: resident must be 0, 1 or 2");
+    return APG_ERR_ARG;
+  }
+  int *map = reinterpret_cast<int *>(workspace + kCfLds + kWgTabFloats + 4);
+  if (resident == 1) {
+    // index-valued parameters -> their tables -> owners -> map (scratch: partials,
+    // overwritten by the step afterwards)
+    float *par = partials, *tab = partials + kParamFloats;
+    int *owner = reinterpret_cast<int *>(tab + kCfLds + kWgTabFloats + 4);
+    // (the pack kernel leaves the gaps of the float tables alone: whatever the
+    // scratch held there would be read as parameter indices)
+    if (hipMemsetAsync(tab, 0, (size_t)(kCfLds + kWgTabFloats + 4) * sizeof(float), st) !=
+        hipSuccess)
+      return check_launch("memset(table map scratch)");
+    hipLaunchKernelGGL(tabmap_iota_kernel, dim3((kParamFloats + 255) / 256), dim3(256), 0, st,
+                       par);
+    PackArgs Q;
+    const ApgMlpPolicyGrads f = params_in(par);
+    Q.pol = ApgMlpPolicy{f.w_s, f.b_s, f.conv_w, f.conv_b, f.w_1, f.b_1,
+                         f.w_2, f.b_2, f.w_3, f.b_3, f.w_out, f.b_out};
+    Q.dst = tab, Q.head_rows = kNA;
+    hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks + 1), dim3(256), 0,
+                       st, Q, fwd_blocks);
+    hipLaunchKernelGGL(tabmap_owner_kernel, dim3(kSlotsTm * 4), dim3(256), 0, st, par, owner,
+                       map, kSlotsTm, uBias);
+    hipLaunchKernelGGL(tabmap_invert_kernel, dim3((kCfLds + kWgTabFloats + 255) / 256),
+                       dim3(256), 0, st, tab, owner, map);
+  }
+  if (resident != 2)
+    hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks + 1), dim3(256), 0,
+                       st, P, fwd_blocks);
   // (the tables are packed while the caller's producer of acts / state0 / ref -
   // a gather on another stream - may still be running)
   if (events && events->inputs_ready &&
@@ -3375,6 +3545,7 @@ int concurrent_train_step(
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss;
   R.loss_sum = rows && loss ? rows->running_loss : nullptr;
+  R.ws = reinterpret_cast<char *>(workspace), R.map = resident ? map : nullptr;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
   R.n_slots = kSlotsTm, R.bias_slot = uBias, R.conv_src = 1, R.bias_src = 8;
   R.head_rows = kNA, R.conv_bias_here = false;
@@ -3490,6 +3661,7 @@ int apg_quad_mlp_rollout_train_step(
   hipLaunchKernelGGL(mlp_rollout_bwd_tm_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st, A);
   WgReduceArgs R;
   R.part = partials, R.g = *grads, R.loss_partials = loss_partials, R.loss = loss, R.loss_sum = nullptr;
+  R.ws = nullptr, R.map = nullptr;
   R.wgs = blocks, R.n_partials = blocks * (kThreads / kWave);
   R.n_slots = kSlotsTm, R.bias_slot = uBias, R.conv_src = 1, R.bias_src = 8, R.head_rows = 4;
   R.conv_bias_here = true;

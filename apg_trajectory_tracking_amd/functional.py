@@ -1340,6 +1340,9 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
                 ptr(states), ptr(actions), ptr(acts), relu_mask.data_ptr(),
                 ptr(partials), ptr(loss), ctypes.byref(gs), ptr(g_s0), ptr(ws),
                 ptr(part), upd, st), "apg_quad_mlp_rollout_train_step")
+            if update is not None:
+                note_in_kernel_update([w_s, b_s, conv_w, conv_b, w_1, b_1, w_2, b_2, w_3,
+                                       b_3, w_out, b_out] + list(update[2].values()))
             ctx.flat_grads = (flat, gr)
             ctx.save_for_backward(acts)
             ctx.input_grads = (g_s0,)
@@ -1627,6 +1630,17 @@ def wing_mlp_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
 
 
 # --------------------------- concurrent mode with the policy inside (config 2)
+def note_in_kernel_update(tensors):
+    """The kernels have written these tensors (parameters, momentum buffers)
+    through raw pointers: bump their in-place version counters, as any in-place
+    op would - autograd's saved-tensor checks and everything that caches what it
+    derived from the parameters (the step plans' resident operand tables)
+    compare them.  Not under stream capture (the bump would happen once, at
+    capture; who replays a graph that updates parameters bumps after the
+    replay: train_base)."""
+    torch.autograd.graph.increment_version(list(tensors))
+
+
 def _step_events(events):
     """{"inputs_ready" | "after_forward" | "after_reverse": torch.cuda.Event}
     -> ApgStepEvents* (or None)."""
@@ -1719,6 +1733,9 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
                 ctypes.byref(gs), None, ptr(ws), ptr(part), upd,
                 _step_events(getattr(ctx, "events", None)),
                 stream_of(s0)), "apg_quad_mlp_concurrent_train_step")
+            if update is not None:
+                note_in_kernel_update([w_s, b_s, conv_w, conv_b, w_1, b_1, w_2, b_2, w_3,
+                                       b_3, w_out, b_out] + list(update[2].values()))
             ctx.flat_grads = (flat, gr)
             ctx.save_for_backward(acts)
             return loss.reshape(())
@@ -1826,6 +1843,7 @@ class QuadConcurrentStepPlan:
             lr, momentum, bufs = update
             require_device(*bufs.values())
             k["bufs"] = bufs
+            self._written = list(k["tensors"]) + list(bufs.values())
             k["upd"] = _capi.ApgMlpSgdUpdate(
                 lr=float(lr), momentum=float(momentum),
                 param=_capi.ApgMlpPolicyGrads(**{a: ptr(t) for a, t in
@@ -1834,6 +1852,13 @@ class QuadConcurrentStepPlan:
                     a: ptr(bufs[n]) for a, n in zip(names, _MLP_PARAMS)}))
             upd = ctypes.byref(k["upd"])
         self.updates = update is not None
+        # resident operand tables (ApgMlpSgdUpdate.resident): the plan owns the
+        # workspace, so the second stage can keep the packed tables current and
+        # the pack launch at the head of the step goes away - as long as nobody
+        # else writes the parameters (their in-place version counters, which the
+        # kernel's update does not touch, are compared before every launch)
+        self.resident_tables = RESIDENT_TABLES and update is not None
+        self._versions = None
         self._dev = dev
         self.B = B
         tail = (float(dt), ctypes.byref(params),
@@ -1869,11 +1894,29 @@ class QuadConcurrentStepPlan:
                 raise ValueError("rows plan: index must be a contiguous int64 device "
                                  f"tensor of {self.B} row numbers")
             self._rows.index = index.data_ptr()
+        if self.resident_tables:
+            k = self._keep
+            if torch.cuda.is_current_stream_capturing():
+                # (a replayed graph runs no Python: it could not notice a parameter
+                # written from outside - captured steps pack their tables)
+                k["upd"].resident, self._versions = 0, None
+            else:
+                now = [t._version for t in k["tensors"]]
+                k["upd"].resident = 2 if now == self._versions else 1
+                self._versions = now
         check(self._fn(*self._args, _step_events(events),
                        torch.cuda.current_stream(self._dev).cuda_stream),
               "apg_quad_mlp_concurrent_train_step")
+        if self.updates:
+            note_in_kernel_update(self._written)
+            if self._versions is not None:      # (ours: the tables follow them)
+                self._versions = [t._version for t in self._keep["tensors"]]
         return self.loss0
 
+
+# True: a step plan with the in-kernel update keeps its packed operand tables
+# current from step to step (no pack launch)
+RESIDENT_TABLES = True
 
 # True: the autoregressive step accumulates its weight gradients inside the
 # reverse sweep (csrc/mlp.hip, mlp_rollout_bwd_tm_kernel, round 5); False:

@@ -148,6 +148,7 @@ class _GraphedStep:
         # step = 0, exp_avg = exp_avg_sq = 0) - so a user-supplied optimizer
         # does not start from two phantom steps' moments either.
         params = [p for p in net.parameters()]
+        self.params = [p.detach() for p in params]
         saved = [p.detach().clone() for p in params]
         state_before = _snapshot_optimizer_state(optimizer)
         side = torch.cuda.Stream()
@@ -186,6 +187,10 @@ class _GraphedStep:
         finally:
             if was_enabled:
                 gc.enable()
+        # the gradient tensors the captured step writes (its `.grad`s): attached
+        # again after every replay - zero_grad(), or an eager step in between,
+        # would otherwise leave `.grad` pointing somewhere else (or nowhere)
+        self.grads = [(p, p.grad) for p in params]
         from . import functional
         self.planes = functional.static_plane_refs()
 
@@ -206,6 +211,11 @@ class _GraphedStep:
             self.graph_b.replay()
         else:
             self.graph.replay()
+        # (the replay has written the parameters - optimizer or in-kernel update -
+        # without running Python: bump their version counters here)
+        torch.autograd.graph.increment_version(self.params)
+        for p, g in self.grads:
+            p.grad = g
         # a private copy: the next replay overwrites the captured output
         if borrow or not torch.is_tensor(self.out):
             return self.out
@@ -1019,6 +1029,7 @@ class TrainBase:
             eg.update(graph=graph, perm=perm, running=running, last=last)
         eg["perm"].copy_(order)
         eg["graph"].replay()
+        torch.autograd.graph.increment_version([p.detach() for p in self.net.parameters()])
         return eg["running"], eg["last"]
 
     # ---- which loop an epoch runs: ONE table, built by init_optimizer --------

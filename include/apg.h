@@ -436,10 +436,20 @@ int apg_quad_mlp_concurrent_step(
 typedef struct ApgStepEvents {
   apg_event_t inputs_ready, after_forward, after_reverse;
 } ApgStepEvents;
+/* resident (apg_quad_mlp_concurrent_train_step[_rows] only; 0 elsewhere): the
+ * kernels read the policy from packed operand tables in `workspace`, normally
+ * re-packed from the parameters by a launch at the head of every call.  A
+ * caller that keeps the SAME workspace from call to call and changes the
+ * parameters through this update only may let the second stage keep the tables
+ * current instead: 1 - pack now, build the table map, scatter the updated
+ * parameters into the tables; 2 - the tables of the previous call are current
+ * (no parameter was written by anyone else since): no pack launch.  0: pack
+ * every call, leave nothing behind. */
 typedef struct ApgMlpSgdUpdate {
   double lr, momentum;     /* (torch's fused SGD computes in double, rounds once) */
   ApgMlpPolicyGrads param;
   ApgMlpPolicyGrads momentum_buf;
+  int resident;
 } ApgMlpSgdUpdate;
 int apg_quad_mlp_concurrent_train_step(
     const float *state0, const float *ref, int ref_cols, float dt,

@@ -259,7 +259,7 @@ def test_flat_gradient_layout_and_new_argument_errors():
     assert ctypes.sizeof(_capi.ApgLstmPolicy) == 8 * 8
     assert ctypes.sizeof(_capi.ApgWingPolicy) == 12 * 8
     assert ctypes.sizeof(_capi.ApgMlpPolicyGrads) == 12 * 8
-    assert ctypes.sizeof(_capi.ApgMlpSgdUpdate) == 2 * 8 + 24 * 8
+    assert ctypes.sizeof(_capi.ApgMlpSgdUpdate) == 2 * 8 + 24 * 8 + 8   # (+ resident, padded)
     assert ctypes.sizeof(_capi.ApgGemmProblem) == 5 * 8 + 8 + 7 * 4 + 4
     lib = _capi.lib()
     assert lib.apg_to_soa(None, None, 4, 0, 0, None, None) == -1
