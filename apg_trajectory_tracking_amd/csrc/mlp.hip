@@ -1423,40 +1423,16 @@ __device__ __forceinline__ void pack_cwg(const PackArgs &A, int tid, int T) {
   }
 }
 
-// forward tables at dst, the in-sweep reverse tables at dst + kCfLds
-// after them, two floats for the trajectory-major reverse kernel: ns, nc with
-// 2^ns / 2^nc above the largest column 1-norm of W_1's state / conv part - a
-// bound on |W_1^T delta| per unit of max |delta| (the LAST block computes them)
+// forward tables at dst, the in-sweep reverse tables at dst + kCfLds.  (Round 4
+// had a last block here that left the exponents of W_1's largest column 1-norms
+// behind the tables; the reverse kernel takes them from the tables itself now.)
 __global__ __launch_bounds__(256) void mlp_pack_step_kernel(PackArgs A, int fwd_blocks) {
-  if (blockIdx.x + 1 == gridDim.x) {
-    // thread t: column t of W_1 (wave 0 = the 64 state columns, waves 1..3 the
-    // 160 conv columns); wave maxima by shuffles - nothing serial in here, this
-    // block must not outlast the table blocks it is launched with
-    __shared__ float wmax[4];
-    const int t = threadIdx.x;
-    float sum = 0.f;
-    if (t < kN1) {
-#pragma unroll
-      for (int k = 0; k < kW; ++k) sum += fabsf(A.pol.w_1[k * kN1 + t]);
-    }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) sum = fmaxf(sum, __shfl_xor(sum, sft, 64));
-    if ((t & 63) == 0) wmax[t >> 6] = sum;
-    __syncthreads();
-    if (t < 2) {
-      const float m = t ? fmaxf(fmaxf(wmax[1], wmax[2]), wmax[3]) : wmax[0];
-      // (a non-finite norm: 0 - the gradients are non-finite anyway)
-      A.dst[kCfLds + kWgTabFloats + t] =
-          m > 0.f && m < 3.0e38f ? (float)__builtin_amdgcn_frexp_expf(m) : 0.f;
-    }
-    return;
-  }
   if ((int)blockIdx.x < fwd_blocks) {
     pack_cfwd(A, blockIdx.x * blockDim.x + threadIdx.x, fwd_blocks * blockDim.x);
   } else {
     A.dst += kCfLds;
     pack_cwg(A, (blockIdx.x - fwd_blocks) * blockDim.x + threadIdx.x,
-             (gridDim.x - 1 - fwd_blocks) * blockDim.x);
+             (gridDim.x - fwd_blocks) * blockDim.x);
   }
 }
 
@@ -3508,7 +3484,7 @@ int concurrent_train_step(
     Q.pol = ApgMlpPolicy{f.w_s, f.b_s, f.conv_w, f.conv_b, f.w_1, f.b_1,
                          f.w_2, f.b_2, f.w_3, f.b_3, f.w_out, f.b_out};
     Q.dst = tab, Q.head_rows = kNA;
-    hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks + 1), dim3(256), 0,
+    hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks), dim3(256), 0,
                        st, Q, fwd_blocks);
     hipLaunchKernelGGL(tabmap_owner_kernel, dim3(kSlotsTm * 4), dim3(256), 0, st, par, owner,
                        map, kSlotsTm, uBias);
@@ -3516,7 +3492,7 @@ int concurrent_train_step(
                        dim3(256), 0, st, tab, owner, map);
   }
   if (resident != 2)
-    hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks + 1), dim3(256), 0,
+    hipLaunchKernelGGL(mlp_pack_step_kernel, dim3(fwd_blocks + bwd_blocks), dim3(256), 0,
                        st, P, fwd_blocks);
   // (the tables are packed while the caller's producer of acts / state0 / ref -
   // a gather on another stream - may still be running)

@@ -48,4 +48,5 @@ with contextlib.redirect_stdout(sys.stderr):
     torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / (epochs * nb) * 1e3
 print(f'{{"mode": "{mode}", "graphed": {str(graph).lower()}, "prefetch": {str(prefetch).lower()}, "epoch_graph": {str(epoch_graph and graph).lower()}, "batches_per_epoch": {nb}, '
-      f'"gather_fork": "{t.gather_fork}", "ms_per_batch": {ms:.4f}}}')
+      f'"gather_fork": "{t.gather_fork}", "ms_per_batch": {ms:.4f}, '
+      f'"epoch_loop": "{t.last_epoch_loop}", "launch_form": "{t.launch_form.get(mode)}"}}')
