@@ -1073,15 +1073,8 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
   if (ROWS) {   // the table DMA issued above
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // the planes the reverse kernel multiplies with (its x^T blocks)
-    const Planes Pof(A.o_feat, kNF, pN), Poi(A.o_in_ref, kH * kRD, pN);
-#pragma unroll
-    for (int j = 0; j < kNF; ++j) Pof.st(vb_lo, j * pN, feat[j]);
-#pragma unroll
-    for (int r = 0; r < kH; ++r)
-#pragma unroll
-      for (int j = 0; j < 5; ++j)   // (column 4 is in both halves: the lower one stores it)
-        Poi.st(hi && j == 0 ? kDead : vr, (r * kRD + j) * pN, w[r][j]);
+    // (the reverse kernel reads the feature / window blocks of x^T from the data
+    // set's rows itself: no planes of them are written)
   }
   // ---- policy forward on the 16-bit matrix pipe (policy_mfma16.h): every
   // operand as two fp16 terms, three products per k-block
@@ -1444,6 +1437,12 @@ struct WgArgs {
   const float *tables;
   const float *xmax;     // [waves][4] (the forward kernel's; trajectory-major kernel only)
   int B;
+  // ROWS: the feature / window blocks of x^T are read from the DATA SET's rows
+  // through the batch's index (the forward kernel then writes no planes of them)
+  const long long *index;
+  const float *r_feat, *r_in_ref;
+  int ld_feat, ld_in_ref;
+  unsigned bytes_feat, bytes_in_ref;
 };
 
 // ---------------------------------------------------------------------------
@@ -1513,6 +1512,7 @@ struct TmMeta {           // at tMeta; written by plain stores, one slot per wav
   float wnorm[8];         // largest column 1-norm of W_1 in row block `wave` of W_1^T
 };
 
+template <bool ROWS>
 __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   char *lds = reinterpret_cast<char *>(lds_f);
@@ -1860,7 +1860,41 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
     // B operands that stay: the 15 feature planes + a row of ones (states_in's
     // bias column), the 90 in_ref planes in three blocks (conv windows)
     Op16 bfeat[2], binr[3][2];
-    {
+    if (ROWS) {
+      // x^T straight from the data set: lane = column `row` of the block, its 16
+      // trajectories c + 8 g + 4 hi are 16 rows named by the index - one dword
+      // load each, a half-wave on 32 consecutive floats of ONE row.  The wave's
+      // 32 row numbers: one per lane, handed around by v_readlane.
+      const int bw = b0 + wave * 32 + row;
+      const unsigned r_ = (unsigned)A.index[bw < B ? bw : B - 1];
+      const unsigned rf = r_ * (unsigned)A.ld_feat, ri = r_ * (unsigned)A.ld_in_ref;
+      const auto sf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.r_feat), 0,
+                                                        (int)A.bytes_feat, 0x00020000);
+      const auto si = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.r_in_ref), 0,
+                                                        (int)A.bytes_in_ref, 0x00020000);
+      float v[16];
+      const auto rows_block = [&](__amdgpu_buffer_rsrc_t rs, unsigned rbase, int col, bool on) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)rbase, c + 8 * g),
+                           a1 = (unsigned)__builtin_amdgcn_readlane((int)rbase, c + 8 * g + 4);
+            const unsigned off = on ? ((hi ? a1 : a0) + (unsigned)col) * 4u : kDead;
+            v[4 * g + c] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, APG_PLANES_LD_AUX));
+          }
+      };
+      rows_block(sf, rf, row, row < kNF);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = row == kNF ? 1.f : v[i];
+      split16(v, ff - kPreX, bfeat);
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb) {
+        rows_block(si, ri, 32 * jb + row, 32 * jb + row < kH * kRD);
+        split16(v, fi - kPreXc, binr[jb]);
+      }
+    } else {
       TBlock tf;
       tf.load(Pact, row < kNF ? vt : kDead, (unsigned)pFeat * pN + wcol);
       float v[16];
@@ -3424,7 +3458,8 @@ int concurrent_train_step(
   if (!attr.test()) {
     if (int e = raise_lds(mlp_concurrent_fwd_kernel<false>, kCfLds)) return e;
     if (int e = raise_lds(mlp_concurrent_fwd_kernel<true>, kCfRowsLds)) return e;
-    if (int e = raise_lds(mlp_concurrent_bwd_tm_kernel, kLdsAll / 4)) return e;
+    if (int e = raise_lds(mlp_concurrent_bwd_tm_kernel<false>, kLdsAll / 4)) return e;
+    if (int e = raise_lds(mlp_concurrent_bwd_tm_kernel<true>, kLdsAll / 4)) return e;
     attr.set();
   }
   const size_t plane = (size_t)B;
@@ -3511,7 +3546,27 @@ int concurrent_train_step(
   WgArgs W;
   W.acts = acts, W.mask = relu_mask, W.d_zout = d_zout, W.part = partials;
   W.tables = workspace + kCfLds, W.B = B, W.xmax = A.xmax;
-  hipLaunchKernelGGL(mlp_concurrent_bwd_tm_kernel, dim3(blocks), dim3(kThreads), kLdsAll, st, W);
+  W.index = nullptr, W.r_feat = W.r_in_ref = nullptr;
+  if (rows && B % kTrajPerBlock) {
+    // A ragged last workgroup reads its dead trajectories' x^T entries past the
+    // end of a plane - the head of the next plane: finite numbers, times a zero
+    // cotangent.  Behind the LAST activation plane that is the window region,
+    // which nobody writes in this mode: keep its head finite.
+    const size_t head = (size_t)kTrajPerBlock * 4;
+    const size_t region = (size_t)kH * kRD * plane * 4;
+    if (hipMemsetAsync(acts + pInr * plane, 0, head < region ? head : region, st) != hipSuccess)
+      return check_launch("memset(window planes' head)");
+  }
+  if (rows) {
+    W.index = rows->index, W.r_feat = rows->normed, W.r_in_ref = rows->in_ref;
+    W.ld_feat = A.ld_feat, W.ld_in_ref = A.ld_in_ref;
+    W.bytes_feat = A.bytes_feat, W.bytes_in_ref = A.bytes_in_ref;
+    hipLaunchKernelGGL(mlp_concurrent_bwd_tm_kernel<true>, dim3(blocks), dim3(kThreads), kLdsAll,
+                       st, W);
+  } else {
+    hipLaunchKernelGGL(mlp_concurrent_bwd_tm_kernel<false>, dim3(blocks), dim3(kThreads), kLdsAll,
+                       st, W);
+  }
   // the inputs (activation planes, state0, ref) are not read past this point:
   // a caller that pipelines batches may start refilling the NEXT batch's
   // buffers behind this event while the second stage and the update run
