@@ -3625,6 +3625,10 @@ int apg_quad_mlp_rollout_train_step(
     set_error("update: lr / momentum is NaN");
     return APG_ERR_ARG;
   }
+  if (update && update->resident != 0) {
+    set_error("update: resident operand tables are the concurrent step's (resident must be 0)");
+    return APG_ERR_ARG;
+  }
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
   if (ref_cols != 9 && ref_cols != 6) {
     set_error("ref_cols must be 9 or 6");
