@@ -101,8 +101,6 @@ def blocks_of(body):
             hdr = None
             if "Loop Header" in note:
                 hdr = m.group(1)[1:]
-            elif m.group(1).startswith("bb.") and "in Loop" not in note:
-                hdr = cur[1] if False else None
             mm = re.search(r"in Loop: Header=(BB\d+_\d+)", note)
             if mm:
                 hdr = mm.group(1)
