@@ -694,3 +694,41 @@ def test_resident_tables_equal_repacked_tables(dev, B):
     for lo, hi in ((352, 384), (644, 1024)):    # gaps of the float tables: never written
         ta[lo:hi] = tb[lo:hi] = 0
     assert torch.equal(ta, tb)
+
+
+def test_rows_epochs_with_shuffle_are_reproducible_and_draw_ahead(dev):
+    """The rows epoch loop draws the NEXT epoch's permutation on a side stream
+    while the current one runs: same seeds -> the same epochs, bit for bit; the
+    order drawn ahead is the one the next epoch uses; a changed data-set size
+    drops it."""
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    runs = []
+    for _ in range(2):
+        cfg = dict(QUAD_CFG, batch_size=128, epoch_size=1000, self_play=0)
+        t = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), cfg)
+        t.initialize_model(device=dev, seed=3)
+        if runs:
+            t.net.load_state_dict(first)
+        else:
+            first = copy.deepcopy(t.net.state_dict())
+        torch.manual_seed(21)
+        torch.cuda.manual_seed(22)
+        losses = []
+        for e in range(3):
+            ahead = getattr(t.trainloader, "_order_ahead", None)
+            losses.append(t.run_epoch("controller", e))
+            assert "rows" in t.last_epoch_loop
+            if e:
+                assert ahead is not None and sorted(ahead[0].tolist()) == list(range(1000))
+        runs.append((losses, _params(t)))
+        assert t.trainloader._order_ahead[0].numel() == 1000
+    assert runs[0][0] == runs[1][0] and len(set(runs[0][0])) == 3
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+    # an order drawn for another data-set size is not used
+    ld = t.trainloader
+    ld._order_ahead = (torch.arange(7, device=dev), torch.cuda.Event())
+    ld._order_ahead[1].record()
+    assert ld.epoch_order().numel() == 1000 and not hasattr(ld, "_order_ahead")
