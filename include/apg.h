@@ -465,8 +465,10 @@ int apg_quad_mlp_concurrent_train_step(
  * tensors through `index` - normed [N][ld_normed] (15 columns read), state0
  * [N][ld_state0] (12), in_ref [N][ld_in_ref] (90), ref [N][ld_ref] (H x
  * ref_cols), float32 device memory, row strides in floats, every tensor below
- * 4 GiB - and writes the feature / window planes of `acts` itself (the caller
- * fills nothing).  index [B]: int64 row numbers in [0, n_rows), device memory.
+ * 4 GiB; the reverse kernel reads the features and windows it multiplies with
+ * from the same rows.  The feature / window planes of `acts` (0..14, 431..520)
+ * are not used in this form: the caller fills nothing.  index [B]: int64 row
+ * numbers in [0, n_rows), device memory.
  * running_loss (or NULL): one device float the step's loss is ADDED to - the
  * epoch loop's `running_loss += loss` (scripts/train_base.py:212) without a
  * launch of its own; needs `loss`. */
