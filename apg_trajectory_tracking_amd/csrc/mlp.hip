@@ -2219,6 +2219,21 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
     const int slot = t >> 10, i = (t >> 6) & 15, lane = t & 63;
     float *dst = wg_dest(A.g, slot, i, lane, A.bias_slot, A.head_rows, A.conv_bias_here);
     if (dst) {
+      // what the update will need, requested BEFORE the partial sums (the loads
+      // return in order: the parameter, its momentum entry and the table map
+      // arrive under the sums' latency instead of behind it)
+      float *pp = nullptr, *pm = nullptr;
+      float p_old = 0.f, m_old = 0.f;
+      int ent[4] = {-1, -1, -1, -1};
+      if (A.update) {
+        pp = wg_dest(A.param, slot, i, lane, A.bias_slot, A.head_rows, A.conv_bias_here);
+        pm = wg_dest(A.mom, slot, i, lane, A.bias_slot, A.head_rows, A.conv_bias_here);
+        p_old = *pp, m_old = *pm;
+        if (A.map) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ent[k] = A.map[t * 4 + k];
+        }
+      }
       const bool is_bias = slot == A.bias_slot;
       // the conv position blocks (1024 floats apart) / the waves' bias sums (256)
       const int n_src = slot == sConv ? A.conv_src : is_bias ? A.bias_src : 1;
@@ -2240,19 +2255,17 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
       }
       *dst = s;
       if (A.update) {   // torch.optim.SGD: buf = momentum buf + grad, p -= lr buf
-        float *pp = wg_dest(A.param, slot, i, lane, A.bias_slot, A.head_rows, A.conv_bias_here),
-              *pm = wg_dest(A.mom, slot, i, lane, A.bias_slot, A.head_rows, A.conv_bias_here);
         // (in double with one rounding each, as torch's fused SGD kernel does
         // it: a trainer that steps through optimizer.step() - the multi-rank
         // form - gets the same bits)
-        const float buf = (float)(A.momentum * (double)*pm + (double)s);
+        const float buf = (float)(A.momentum * (double)m_old + (double)s);
         *pm = buf;
-        const float np_ = (float)((double)*pp - A.lr * (double)buf);
+        const float np_ = (float)((double)p_old - A.lr * (double)buf);
         *pp = np_;
         if (A.map) {      // this parameter's entries of the packed tables
-#pragma unroll 1
+#pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int e = A.map[t * 4 + k];
+            const int e = ent[k];
             if (e < 0) break;
             char *q = A.ws + (e & (kMapFlag32 - 1));
             if (e & kMapFlag32) {
