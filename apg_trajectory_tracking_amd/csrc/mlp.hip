@@ -2244,13 +2244,21 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(WgReduceArgs A) {
         // kRedChunk rows at a time (all loads in flight, then a fixed-order
         // sum); more than kRedChunk chunk rows - batches beyond 262 144
         // trajectories - take further rounds
-        for (int w0 = 0; w0 < A.wgs; w0 += kRedChunk) {
-          float v[kRedChunk];
+        if (A.wgs <= 8) {   // (the eight chunk rows of a 65 536 batch: no idle slots)
+          float v[8];
 #pragma unroll
-          for (int w = 0; w < kRedChunk; ++w)
-            v[w] = w0 + w < A.wgs ? p[(size_t)(w0 + w) * stride] : 0.f;
+          for (int w = 0; w < 8; ++w) v[w] = w < A.wgs ? p[(size_t)w * stride] : 0.f;
 #pragma unroll
-          for (int w = 0; w < kRedChunk; ++w) s += v[w];
+          for (int w = 0; w < 8; ++w) s += v[w];
+        } else {
+          for (int w0 = 0; w0 < A.wgs; w0 += kRedChunk) {
+            float v[kRedChunk];
+#pragma unroll
+            for (int w = 0; w < kRedChunk; ++w)
+              v[w] = w0 + w < A.wgs ? p[(size_t)(w0 + w) * stride] : 0.f;
+#pragma unroll
+            for (int w = 0; w < kRedChunk; ++w) s += v[w];
+          }
         }
       }
       *dst = s;
