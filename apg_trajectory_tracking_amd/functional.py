@@ -1869,6 +1869,7 @@ class QuadConcurrentStepPlan:
         # rows plans: every launch adds its loss to `running` (an epoch loop
         # zeroes it, reads it once at the end)
         self.running = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.launches = 0
         if rows is not None:
             k["rows_src"] = (normed, st0, inr, rfs)
             self._rows = k["rows"] = _capi.ApgBatchRows(
@@ -1907,6 +1908,7 @@ class QuadConcurrentStepPlan:
         check(self._fn(*self._args, _step_events(events),
                        torch.cuda.current_stream(self._dev).cuda_stream),
               "apg_quad_mlp_concurrent_train_step")
+        self.launches += 1
         if self.updates:
             note_in_kernel_update(self._written)
             if self._versions is not None:      # (ours: the tables follow them)

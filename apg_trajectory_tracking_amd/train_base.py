@@ -1111,7 +1111,7 @@ class TrainBase:
         for g in self._graphs.values():
             if getattr(g, "planned", False) and hasattr(g.plan, "running"):
                 g.plan.running.zero_()
-        fast, i = {}, -1
+        fast, i, extra = {}, -1, None
         self._borrow_loss, self._epoch_sigs = True, {}
         order = ld.epoch_order() if hasattr(ld, "prefetch_order") else None
         if order is not None:          # the next epoch's permutation, drawn beside this one
@@ -1124,13 +1124,19 @@ class TrainBase:
                 if plan is not None:
                     plan.launch(index=index)
                     continue
-                self.train_concurrent_fused(*tensors, index=index)
-                g = self._graphs.get(("concurrent", index.numel(), "rows"))
-                if getattr(g, "planned", False):
-                    fast[index.numel()] = g.plan
+                key = ("concurrent", index.numel(), "rows")
+                g0 = self._graphs.get(key)
+                n0 = getattr(getattr(g0, "plan", None), "launches", None)
+                loss = self.train_concurrent_fused(*tensors, index=index)
+                g = self._graphs.get(key)
+                if (getattr(g, "planned", False) and hasattr(g.plan, "running")
+                        and (g is not g0 or g.plan.launches != n0)):
+                    fast[index.numel()] = g.plan     # (its running sum has this step)
+                else:      # the step took another route: its loss is added here
+                    extra = loss.detach().clone() if extra is None else extra + loss.detach()
         finally:
             self._borrow_loss, self._epoch_sigs = False, None
-        total = None
+        total = None if extra is None else extra.reshape(1)
         for plan in fast.values():
             total = plan.running.clone() if total is None else total + plan.running
         return self._finish_epoch(total if total is not None
