@@ -3530,8 +3530,10 @@ int concurrent_train_step(
     int *owner = reinterpret_cast<int *>(tab + kCfLds + kWgTabFloats + 4);
     // (the pack kernel leaves the gaps of the float tables alone: whatever the
     // scratch held there would be read as parameter indices)
-    if (hipMemsetAsync(tab, 0, (size_t)(kCfLds + kWgTabFloats + 4) * sizeof(float), st) !=
-        hipSuccess)
+    // (... and the owner table, so that nothing in this path indexes by garbage)
+    if (hipMemsetAsync(tab, 0,
+                       (size_t)(kCfLds + kWgTabFloats + 4 + kParamFloats) * sizeof(float),
+                       st) != hipSuccess)
       return check_launch("memset(table map scratch)");
     hipLaunchKernelGGL(tabmap_iota_kernel, dim3((kParamFloats + 255) / 256), dim3(256), 0, st,
                        par);
