@@ -3516,10 +3516,11 @@ int concurrent_train_step(
   const int fwd_blocks = (kCfLds + 255) / 256, bwd_blocks = (kWgTabFloats + 255) / 256;
   // resident tables (ApgMlpSgdUpdate.resident): 2 - the workspace holds the tables
   // of exactly these parameters, left by the previous call's second stage: no
-  // pack launch; 1 - pack, and (re)build the map the second stage scatters by
+  // pack launch; 1 - pack, and build the map the second stage scatters by; 3 -
+  // pack (somebody else wrote the parameters), the workspace's map is still good
   const int resident = update ? update->resident : 0;
-  if (resident < 0 || resident > 2) {
-    set_error("update: resident must be 0, 1 or 2");
+  if (resident < 0 || resident > 3) {
+    set_error("update: resident must be 0, 1, 2 or 3");
     return APG_ERR_ARG;
   }
   int *map = reinterpret_cast<int *>(workspace + kCfLds + kWgTabFloats + 4);

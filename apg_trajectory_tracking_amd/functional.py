@@ -1858,7 +1858,7 @@ class QuadConcurrentStepPlan:
         # else writes the parameters (their in-place version counters, which the
         # kernel's update does not touch, are compared before every launch)
         self.resident_tables = RESIDENT_TABLES and update is not None
-        self._versions = None
+        self._versions, self._map_built = None, False
         self._dev = dev
         self.B = B
         tail = (float(dt), ctypes.byref(params),
@@ -1903,8 +1903,11 @@ class QuadConcurrentStepPlan:
                 k["upd"].resident, self._versions = 0, None
             else:
                 now = [t._version for t in k["tensors"]]
-                k["upd"].resident = 2 if now == self._versions else 1
-                self._versions = now
+                # 1: first launch on this workspace (builds the table map); then
+                # 2 while nobody else has written the parameters, else 3 (pack)
+                k["upd"].resident = (2 if now == self._versions
+                                     else 3 if self._map_built else 1)
+                self._versions, self._map_built = now, True
         check(self._fn(*self._args, _step_events(events),
                        torch.cuda.current_stream(self._dev).cuda_stream),
               "apg_quad_mlp_concurrent_train_step")

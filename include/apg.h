@@ -441,10 +441,12 @@ typedef struct ApgStepEvents {
  * re-packed from the parameters by a launch at the head of every call.  A
  * caller that keeps the SAME workspace from call to call and changes the
  * parameters through this update only may let the second stage keep the tables
- * current instead: 1 - pack now, build the table map, scatter the updated
- * parameters into the tables; 2 - the tables of the previous call are current
- * (no parameter was written by anyone else since): no pack launch.  0: pack
- * every call, leave nothing behind. */
+ * current instead: 1 - pack now, build the table map (first call on a
+ * workspace), scatter the updated parameters into the tables; 2 - the tables of
+ * the previous call are current (no parameter was written by anyone else
+ * since): no pack launch; 3 - pack now (somebody else wrote the parameters), the
+ * workspace's map is still the one of an earlier call with 1.  0: pack every
+ * call, leave nothing behind. */
 typedef struct ApgMlpSgdUpdate {
   double lr, momentum;     /* (torch's fused SGD computes in double, rounds once) */
   ApgMlpPolicyGrads param;

@@ -676,7 +676,7 @@ def test_resident_tables_equal_repacked_tables(dev, B):
                     net.fc2.bias.mul_(1.5)
             losses.append(float(plan.launch()))
             flags.append(plan._keep["upd"].resident)
-        assert flags == ([1, 2, 2, 2, 1, 2] if resident else [0] * 6)
+        assert flags == ([1, 2, 2, 2, 3, 2] if resident else [0] * 6)
         outs.append((losses, plan.flat[:-1].clone(), [p.detach().clone() for p in net.parameters()],
                      [b.clone() for b in bufs.values()], plan, net))
     (la, ga, pa, ba, plan_a, net_a), (lb, gb, pb, bb, _, _) = outs
