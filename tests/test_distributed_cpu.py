@@ -482,3 +482,27 @@ def test_launch_form_is_a_measured_choice_not_a_constant():
         assert t._graphable()
         t.graph_steps = False
         assert not t._graphable()
+
+
+def test_epoch_table_falls_through_to_what_applies_without_a_gpu():
+    """run_epoch is a walk over ONE table.  Its first
+    entry - the concurrent epoch that names its batches by rows - needs the
+    kernels; on a CPU data set it does not apply and the walk goes on; the
+    loader's order prefetch is a no-op off the GPU."""
+    from apg_trajectory_tracking_amd.dataset import TensorBatches
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+
+    class Dyn:
+        params = None
+    t = TrainDrone(Dyn(), Dyn(), dict(delta_t=DT, horizon=H, batch_size=8, ref_dim=9,
+                                      action_dim=4, train_mode="concurrent", system="quad"))
+    names = [name for name, _, _ in t._epoch_table()]
+    assert "rows" in names[0] and names[-1] == "loader" and len(names) == 6
+    ld = TensorBatches((torch.arange(20.).reshape(10, 2),), 4, shuffle=True)
+    t.trainloader = ld
+    assert not t.concurrent_rows_ok()
+    assert not t._rows_ok(torch.zeros(4, 15), torch.zeros(4, 12), torch.zeros(4, 10, 9),
+                          torch.zeros(4, 10, 9), torch.zeros(4, dtype=torch.int64))
+    ld.prefetch_order(None)                      # CPU: nothing is drawn ahead
+    assert not hasattr(ld, "_order_ahead")
+    assert sorted(ld.epoch_order().tolist()) == list(range(10))

@@ -261,6 +261,8 @@ def test_flat_gradient_layout_and_new_argument_errors():
     assert ctypes.sizeof(_capi.ApgMlpPolicyGrads) == 12 * 8
     assert ctypes.sizeof(_capi.ApgMlpSgdUpdate) == 2 * 8 + 24 * 8 + 8   # (+ resident, padded)
     assert ctypes.sizeof(_capi.ApgGemmProblem) == 5 * 8 + 8 + 7 * 4 + 4
+    assert ctypes.sizeof(_capi.ApgBatchRows) == 5 * 8 + 4 * 4 + 8 + 8    # (round 5)
+    assert ctypes.sizeof(_capi.ApgLearntResidual) == 5 * 8
     lib = _capi.lib()
     assert lib.apg_to_soa(None, None, 4, 0, 0, None, None) == -1
     assert b"apg_to_soa" in lib.apg_last_error_string()
