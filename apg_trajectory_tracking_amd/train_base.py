@@ -625,10 +625,14 @@ class TrainBase:
                 cache[key] = sig
         g = self._graphs.get(key)
         stale = g is None or getattr(g, "planned", False) or g.signature != sig
-        if fresh_sig:
+        if fresh_sig and cache is not None:
             # a re-capture runs warm-up steps with their own all-reduces: every
-            # rank re-captures when one has to (agreed where the signature is
-            # taken afresh - once per key and epoch inside run_epoch)
+            # rank re-captures when one has to.  Agreed where the signature is
+            # taken afresh inside run_epoch - once per key and epoch; a direct
+            # step call takes its signature every time, and a collective with a
+            # read-back per step would cost more than the step's own all-reduce:
+            # there the ranks are expected to change what a capture depends on
+            # together (as SPMD code does)
             stale = parallel.any_rank(stale)
         if stale:
             if torch.cuda.is_available() and _make_capturable(self.optimizer_controller):

@@ -212,7 +212,9 @@ def _ar_steps(lo, hi, graphed=False, split=None, new_buffers_on_rank=None):
                        for b in (st["momentum_buffer"] for st in opt.state.values()))
             if dist.get_rank() == new_buffers_on_rank:
                 opt.load_state_dict(__import__("copy").deepcopy(opt.state_dict()))
+            t._epoch_sigs = {}      # (a new epoch: where run_epoch takes signatures afresh)
             losses.append(float(t.train_recurrent_model(None, *shard)))
+            t._epoch_sigs = None
             g2, = t._graphs.values()
             assert g2 is not g, "this rank replayed while another re-captured"
         return losses, {k: v.numpy() for k, v in t.net.state_dict().items()}
