@@ -1332,10 +1332,12 @@ def main():
             and not (args.no_secondary or args.headline_only)):
         try:
             out["run_epoch"] = run_epoch_probe(args, dev, dyn)
-            ts, re_ = out.get("train_step", {}), out["run_epoch"].get("concurrent", {})
-            if "ms_per_step" in ts and "ms_per_batch" in re_:
-                out["run_epoch"]["concurrent"]["over_train_step"] = (
-                    re_["ms_per_batch"] / ts["ms_per_step"])
+            for mode_key, step_key in (("concurrent", "train_step"), ("ar", "train_step_ar"),
+                                       ("lstm", "train_step_lstm")):
+                ts, re_ = out.get(step_key, {}), out["run_epoch"].get(mode_key, {})
+                if "ms_per_step" in ts and "ms_per_batch" in re_:
+                    out["run_epoch"][mode_key]["over_train_step"] = (
+                        re_["ms_per_batch"] / ts["ms_per_step"])
         except Exception as e:
             out["run_epoch"] = {"error": repr(e)}
     # the step blocks again, compact and inside `roofline` (the driver's record
