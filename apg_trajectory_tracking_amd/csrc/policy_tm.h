@@ -93,7 +93,7 @@ __device__ __forceinline__ void split16(const float (&v)[16], int e, Op16 (&o)[2
   }
 }
 
-#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_TM_KNOCKOUT)
+#if !defined(APG_EXPERIMENT_BUILD) && (defined(APG_TM_KNOCKOUT) || defined(APG_TM_PLAIN_PARTIALS))
 #error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
 #endif
 #ifndef APG_TM_KNOCKOUT
@@ -141,7 +141,12 @@ __device__ __forceinline__ void flush_region(char *lds, int off, int floats, flo
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       v[c] = bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf((float)q[c], e - fix);
+#ifdef APG_TM_PLAIN_PARTIALS     /* experiment builds: cached stores of the partials -
+                                    second stage -1.1 us, this kernel +2.3: not shipped */
+    reinterpret_cast<f32x4_ *>(dst)[idx] = v;
+#else
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4_ *>(dst) + idx);
+#endif
     if (rezero) *p = z;
   }
 }
