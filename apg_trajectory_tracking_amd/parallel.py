@@ -28,6 +28,36 @@ def group_live():
     return dist.is_available() and dist.is_initialized()
 
 
+_suspended = False
+
+
+class collectives_suspended:
+    """Context: the steps' gradient all-reduce (`reduce_sum`) is skipped while
+    everything else about an N-rank step stays as it is (split graphs, the
+    flat message, the optimizer behind the slot).  Measurement only - `bench.py`
+    times the N-rank step with and without its collective on the same ranks
+    (`parallel_efficiency`); the ranks' weights drift apart inside it, so the
+    caller re-broadcasts (or discards the trainer) afterwards."""
+
+    def __enter__(self):
+        global _suspended
+        self._was, _suspended = _suspended, True
+        return self
+
+    def __exit__(self, *exc):
+        global _suspended
+        _suspended = self._was
+        return False
+
+
+def reduce_sum(msg, group=None):
+    """THE collective of a training step: in-place all-reduce(sum) of the flat
+    gradient (+ loss slot) message over RCCL (`nccl`) or gloo.  Issued whenever
+    a process group is live - also for a world of one."""
+    if msg is not None and group_live() and not _suspended:
+        dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+
+
 def any_rank(flag):
     """`flag` OR-ed over the ranks (one process: `flag`).  A host decision all
     ranks must take alike - re-capturing a step graph, whose warm-up steps issue
@@ -125,5 +155,5 @@ class GradAllReducer:
         if world_size() == 1:
             return loss
         b = self.pack(loss)
-        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+        reduce_sum(b, group=self.group)
         return self.unpack()

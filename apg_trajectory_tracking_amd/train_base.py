@@ -519,7 +519,7 @@ class TrainBase:
         if parallel.world_size() > 1:
             if flat is not None:
                 flat[-1] = loss.detach().reshape(())
-                parallel.dist.all_reduce(flat, op=parallel.dist.ReduceOp.SUM)
+                parallel.reduce_sum(flat)
                 loss = flat[-1].clone()
             elif self.grad_sync is not None:
                 loss = self.grad_sync.sync(loss.detach())
@@ -566,8 +566,7 @@ class TrainBase:
         one GPU then runs graph A -> RCCL -> graph B exactly as N ranks do:
         communicator, RCCL's stream and events, the watchdog - everything but
         the wire)."""
-        if msg is not None and parallel.group_live():
-            parallel.dist.all_reduce(msg, op=parallel.dist.ReduceOp.SUM)
+        parallel.reduce_sum(msg)
 
     def _graph_signature(self, inputs, volatile, params=None):
         """What a captured step is tied to.  Resident-shard captures (no

@@ -2,8 +2,11 @@
 """bench.py - env-steps/s of the fused APG rollout (forward + backward through
 the quadrotor dynamics + quad_mpc_loss) on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (one process per
-GPU under torch.distributed.run for N > 1) prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line
+on rank 0.  N > 1 runs one process per GPU under torch.distributed.run: either
+the caller launches it that way (the driver's form) or - when RANK is not in
+the environment - this file launches itself (`self_launch`), so the plain
+command works for every N the node has GPUs for.
 
 A "step" is one pass of the hot path over one batch: the fused kernel
 apg_quad_rollout_fwd_bwd (H x dynamics, loss, analytic adjoint down to
@@ -485,6 +488,20 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
     # in the split form the N > 1 step uses (graph A, empty all-reduce slot,
     # graph B) - a scaling curve compares `ms_per_step` at N with
     # `ms_per_step_split_graph` at 1
+    if world > 1:
+        # the same N-rank step with its collective switched off (split graphs,
+        # message and optimizer slot unchanged; all GPUs busy at once): what the
+        # all-reduce costs THIS step on THIS node
+        from apg_trajectory_tracking_amd import parallel
+        with parallel.collectives_suspended():
+            out["ms_per_step_no_collective"], _, _ = timed_steps(
+                step, max(8, args.train_steps // 2), dist)
+        parallel.broadcast_module(t.net)      # (the replicas drifted: lr 1e-9, but still)
+        out["parallel_efficiency"] = out["ms_per_step_no_collective"] / ms
+        out["parallel_efficiency_what"] = (
+            "N-rank step without its all-reduce / N-rank step, same ranks, same "
+            "process; <= 1.  The driver computes the curve's own efficiency from "
+            "`value` at N = 1, 2, 4, 8")
     t.borrow_loss = False
     out["ms_per_step_private_loss"], _, _ = timed_steps(
         step, max(8, args.train_steps // 2), dist)
@@ -1070,23 +1087,156 @@ def dry_run_cpu(args, dist, rank, world):
         flat = torch.full((30389 + 1,), float(rank + 1))
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         out["allreduce_check"] = float(flat[-1]) == world * (world + 1) / 2
+        out["rccl"] = collective_probe(dist, dev, world)   # (gloo here)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out["steps_summary"] = steps_summary(out)
         print(json.dumps(out))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) as a plain command: this process
+    becomes the launcher - the same `torch.distributed.run` line the driver
+    uses, one rank per GPU, rendezvous on 127.0.0.1 and a free port - and
+    returns the launcher's exit code; rank 0 of the children prints the line.
+    N is checked against the node first: an explicit error, not a hang in the
+    rendezvous or in RCCL's init."""
+    import socket
+    import subprocess
+    if not args.dry_run_cpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+        have = torch.cuda.device_count()
+        if args.gpus > have:
+            raise SystemExit(f"--gpus {args.gpus}: this node shows {have} GPU(s) "
+                             "(torch.cuda.device_count()); one rank per GPU is the "
+                             "only form this bench runs")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                        "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL needs it here)
+    env.setdefault("OMP_NUM_THREADS", "8")              # (the launcher would say 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def collective_probe(dist, dev, world):
+    """What the process group saw: world, backend, library version and the
+    latency of the training steps' ONE collective - all_reduce(sum) of the flat
+    gradient + loss-slot message - for the three message sizes (concurrent /
+    autoregressive / LSTM, floats), 100 back-to-back calls on the live group.
+    Every rank calls this; the times are rank 0's (HIP events on the GPU, the
+    host clock under gloo)."""
+    backend = dist.get_backend()
+    out = {"world": world, "backend": backend, "allreduce_us": {}}
+    if backend == "nccl":
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    for n in (32729, 30389, 12341):
+        buf = torch.ones(n + 1, device=dev)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        buf.fill_(1.0)
+        sync()
+        dist.barrier()
+        reps = 100
+        if dev.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                dist.all_reduce(buf)
+            e1.record()
+            sync()
+            us = e0.elapsed_time(e1) / reps * 1e3
+        else:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dist.all_reduce(buf)
+            us = (time.perf_counter() - t0) / reps * 1e6
+        out["allreduce_us"][str(n + 1)] = us
+        # the sum really crossed the ranks: rank + 1 in every slot -> N (N + 1) / 2
+        buf.fill_(float(dist.get_rank() + 1))
+        dist.all_reduce(buf)
+        out["sums_ok"] = bool(out.get("sums_ok", True)
+                              and float(buf[0]) == float(buf[-1]) == world * (world + 1) / 2)
+    out["what"] = ("torch.distributed all_reduce(sum) of the step's flat gradient + loss "
+                   "message (floats) on the live group, 100 back-to-back calls; nccl = "
+                   "RCCL over xGMI")
+    return out
+
+
+def steps_summary(out):
+    """The numbers README's table quotes, compact (<= 1 200 characters) and LAST
+    in the line: the driver's record keeps the final ~2 000 characters of
+    stdout whatever else it drops (VERDICT r5 weak #7)."""
+    r4 = lambda v: None if v is None else float(f"{v:.4g}")
+    s = {}
+    for key, name in (("train_step", "concurrent"), ("train_step_packed", "packed"),
+                      ("train_step_ar", "ar"), ("train_step_lstm", "lstm")):
+        blk = out.get(key)
+        if isinstance(blk, dict) and "ms_per_step" in blk:
+            rf = blk.get("roofline") or {}
+            s[name] = {"ms": r4(blk["ms_per_step"]),
+                       "frac_vs_mfma_floor": r4(rf.get("frac_vs_mfma_floor")),
+                       "bytes_ratio": r4(rf.get("plane_bytes_over_algorithmic"))}
+            if "parallel_efficiency" in blk:
+                s[name]["parallel_efficiency"] = r4(blk["parallel_efficiency"])
+                s[name]["global_batch"] = blk.get("global_batch")
+    sec = out.get("secondary") if isinstance(out.get("secondary"), dict) else {}
+    ws = sec.get("wing_train_step") or {}
+    if "ms_per_step" in ws:
+        s["wing_step"] = {"ms": r4(ws["ms_per_step"]),
+                          "frac_vs_mfma_floor": r4(ws.get("frac_vs_mfma_floor")),
+                          "bytes_ratio": r4(ws.get("plane_bytes_over_algorithmic"))}
+    re_ = out.get("run_epoch") if isinstance(out.get("run_epoch"), dict) else {}
+    ep = {k: {"ms_per_batch": r4(v.get("ms_per_batch")),
+              "over_train_step": r4(v.get("over_train_step"))}
+          for k, v in re_.items() if isinstance(v, dict) and "ms_per_batch" in v}
+    if ep:
+        s["run_epoch"] = ep
+    wr = sec.get("wing_rollout") or {}
+    if "us_per_launch" in wr:
+        s["wing_rollout_us"] = r4(wr["us_per_launch"])
+        s["wing_rollout_frac_hbm"] = r4((wr.get("hbm") or {}).get("frac"))
+    for key, name in (("quad_closed_loop", "quad_closed_loop_ms"),
+                      ("wing_closed_loop_eval", "wing_closed_loop_ms"),
+                      ("learnt_controller_phase", "learnt_phase_ms")):
+        if "ms_per_launch" in (sec.get(key) or {}):
+            s[name] = r4(sec[key]["ms_per_launch"])
+    rf = out.get("roofline") or {}
+    s["headline"] = {"kernel_us": r4(rf.get("kernel_us_avg")), "frac": r4(rf.get("frac")),
+                     "stream_floor_us": r4(rf.get("stream_floor_us")),
+                     "n_gpus": out.get("n_gpus")}
+    rc = out.get("rccl") if isinstance(out.get("rccl"), dict) else None
+    if rc and "allreduce_us" in rc:
+        s["rccl"] = {"world": rc["world"], "backend": rc["backend"],
+                     "allreduce_us": {k: r4(v) for k, v in rc["allreduce_us"].items()}}
+    cb = out.get("cpu_baseline") if isinstance(out.get("cpu_baseline"), dict) else {}
+    if "value" in cb:
+        s["cpu_port_env_steps_per_s"] = r4(cb["value"])
+    return s
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                "--gpus N > 1 must be launched with torch.distributed.run "
-                "(one process per GPU)")
-    launched = world > 1 or "RANK" in os.environ   # by torch.distributed.run
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} "
+                         "ranks (one process per GPU: the two must agree)")
+    launched = "RANK" in os.environ   # by torch.distributed.run
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -1098,6 +1248,9 @@ def main():
         return dry_run_cpu(args, dist, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but this node shows "
+                         f"{torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -1373,6 +1526,13 @@ def main():
         out["parity_check"] = out["cpu_baseline"].pop("parity_check")
     elif rank == 0:
         out["cpu_baseline"] = None
+    if dist is not None and world > 1:
+        try:
+            out["rccl"] = collective_probe(dist, dev, world)
+        except Exception as e:          # informational only
+            out["rccl"] = {"error": repr(e)}
+    if rank == 0:
+        out["steps_summary"] = steps_summary(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

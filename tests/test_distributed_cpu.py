@@ -265,6 +265,15 @@ def _worker(rank, world, port, out_dir):
         # host decisions every rank takes alike
         from apg_trajectory_tracking_amd import parallel
         assert parallel.any_rank(rank == 1) and not parallel.any_rank(False)
+        # bench.py's `parallel_efficiency` leg: the step's collective switched off
+        # and on again on a live group (any_rank is not part of it)
+        msg = torch.full((3,), float(rank + 1))
+        with parallel.collectives_suspended():
+            parallel.reduce_sum(msg)
+            assert msg.tolist() == [float(rank + 1)] * 3
+            assert parallel.any_rank(rank == 0)
+        parallel.reduce_sum(msg)
+        assert msg.tolist() == [3.0] * 3
         losses, sd = _ar_steps(lo, hi, graphed=True, new_buffers_on_rank=1)
         np.savez(os.path.join(out_dir, f"recap_rank{rank}.npz"),
                  losses=np.array(losses), **sd)
@@ -458,6 +467,76 @@ def test_bench_rank_logic_under_gloo_with_two_ranks():
     assert abs(d["value"] - 2 * 65536 * 10 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["allreduce_check"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None
+
+
+def test_bench_gpus_2_as_a_plain_command_launches_itself():
+    """`python3 bench.py --gpus 2 ... --dry-run-cpu` with NO
+    launcher around it (the form the driver uses for N = 1) re-executes itself
+    under torch.distributed.run, exits 0 and prints ONE line with n_gpus 2 that
+    says what the process group saw (`rccl`: world, backend, the three
+    all-reduce latencies, the sum checked) and ends in `steps_summary`."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run(
+        [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "20",
+         "--warmup", "5", "--dry-run-cpu"],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["config"]["global_batch"] == 2 * 65536
+    assert d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo"
+    assert sorted(d["rccl"]["allreduce_us"]) == ["12342", "30390", "32730"]
+    assert d["rccl"]["sums_ok"] is True
+    assert list(d)[-1] == "steps_summary"
+    assert d["steps_summary"]["rccl"]["world"] == 2
+    assert len(json.dumps(d["steps_summary"])) <= 1200
+    # N = 1 stays a single process with no group and no `rccl` key
+    r1 = subprocess.run(
+        [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "5",
+         "--warmup", "2", "--dry-run-cpu"],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and "rccl" not in d1
+    # without a GPU the real bench says so (and never hangs in a rendezvous)
+    r2 = subprocess.run(
+        [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "5",
+         "--warmup", "2"], capture_output=True, text=True, timeout=300, env=env)
+    if not torch.cuda.is_available():
+        assert r2.returncode != 0 and "MI355X" in r2.stderr
+
+
+def test_launcher_world_and_gpus_flag_must_agree():
+    """A launcher that started W ranks for `--gpus N != W` is an error on every
+    rank (before any process group exists), not a silently different job."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2",
+                        "--dry-run-cpu"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_suspended_collectives_skip_only_the_gradient_all_reduce():
+    """parallel.collectives_suspended (bench.py's `parallel_efficiency` leg):
+    inside it `reduce_sum` is a no-op, outside it is the all-reduce; with no
+    process group both are no-ops."""
+    from apg_trajectory_tracking_amd import parallel
+    t = torch.ones(4)
+    parallel.reduce_sum(t)
+    parallel.reduce_sum(None)
+    with parallel.collectives_suspended():
+        assert parallel._suspended
+        parallel.reduce_sum(t)
+    assert not parallel._suspended and t.tolist() == [1.0] * 4
 
 
 def test_launch_form_is_a_measured_choice_not_a_constant():
