@@ -280,6 +280,7 @@ SIGNATURES = {
     "apg_loss_partials_count": [_I],
     "apg_stream_copy": [_P, _P, ctypes.c_longlong, _P],
     "apg_stream_copy_shape": [_P, _P, ctypes.c_longlong, _I, _P],
+    "apg_stream_rows_probe": [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _I, _P],
     "apg_version": [],
     "apg_last_error_string": [],
 }

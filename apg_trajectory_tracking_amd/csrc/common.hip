@@ -162,8 +162,79 @@ static __global__ __launch_bounds__(256) void copy_unroll4_kernel(
   for (; i < n16; i += stride) dst[i] = src[i];
 }
 
+// The headline launch's BYTES in the fast copy shape: one
+// 16-byte element per thread over the whole input as the grid; `out16` of the
+// threads also store one element.  No arithmetic, no per-trajectory dependence
+// of a store on all of a trajectory's loads - a floor, not a model.
+//   1  the first out16 threads store (plain)        2  the same, non-temporal
+//   3  stores interleaved with the loads (thread i of every group of `grp` stores
+//      when i < out_per_grp: 28 loads : 10 stores = groups of 14 with 5 stores)
+//   4  as 3, non-temporal
+//   5 / 6  as 1 / 2 with 64-thread blocks (one wave per workgroup: the rollout's)
+template <int SHAPE>
+static __global__ __launch_bounds__(256) void stream_rows_probe_kernel(
+    const f32x4_copy *__restrict__ in, f32x4_copy *__restrict__ out, long long in16,
+    long long out16, int grp, int out_per_grp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in16) return;
+  const f32x4_copy v = in[i];
+  constexpr bool NT = SHAPE == 2 || SHAPE == 4;
+  long long o;
+  if (SHAPE <= 2) {
+    o = i < out16 ? i : -1;
+  } else {
+    const long long g = i / grp;
+    const int r = (int)(i - g * grp);
+    o = r < out_per_grp ? g * out_per_grp + r : -1;
+    if (o >= out16) o = -1;
+  }
+  if (o >= 0) {
+    if (NT) __builtin_nontemporal_store(v, out + o);
+    else out[o] = v;
+  } else if (v.x + v.y == -1.2345e30f && v.z == 7.0f) {
+    out[0] = v;      // (never: keeps the load of a thread that stores nothing)
+  }
+}
+
 
 extern "C" {
+
+int apg_stream_rows_probe(const void *in, long long in_bytes, void *out, long long out_bytes,
+                          int shape, apg_stream_t stream) {
+  if (!in || !out || in_bytes <= 0 || out_bytes < 0 || (in_bytes & 15) || (out_bytes & 15) ||
+      ((size_t)in & 15) || ((size_t)out & 15) || out_bytes > in_bytes) {
+    apg::set_error("apg_stream_rows_probe: 16-byte aligned pointers and sizes, "
+                   "0 <= out_bytes <= in_bytes expected");
+    return APG_ERR_ARG;
+  }
+  if (shape < 1 || shape > 6) {
+    apg::set_error("apg_stream_rows_probe: shape 1..6");
+    return APG_ERR_ARG;
+  }
+  const long long in16 = in_bytes / 16, out16 = out_bytes / 16;
+  // smallest group with a whole number of loads and stores (28 : 10 -> 14 : 5)
+  long long a = in16, b = out16 > 0 ? out16 : in16;
+  while (b) { const long long t = a % b; a = b; b = t; }
+  const long long grp = in16 / a, opg = out16 / a;
+  if (grp > 0x7fffffffll) { apg::set_error("apg_stream_rows_probe: sizes"); return APG_ERR_ARG; }
+  const int block = shape >= 5 ? 64 : 256;
+  const long long blocks = (in16 + block - 1) / block;
+  if (blocks > 0x7fffffffll) { apg::set_error("too large"); return APG_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const f32x4_copy *s_ = (const f32x4_copy *)in;
+  f32x4_copy *d_ = (f32x4_copy *)out;
+#define APG_PROBE(S)                                                                        \
+  hipLaunchKernelGGL(stream_rows_probe_kernel<S>, dim3((unsigned)blocks), dim3(block), 0, st, \
+                     s_, d_, in16, out16, (int)grp, (int)opg)
+  switch (shape) {
+    case 1: case 5: APG_PROBE(1); break;
+    case 2: case 6: APG_PROBE(2); break;
+    case 3: APG_PROBE(3); break;
+    default: APG_PROBE(4); break;
+  }
+#undef APG_PROBE
+  return apg::check_launch("stream_rows_probe");
+}
 
 int apg_to_soa_multi(const ApgSoaItem *items, int n, int B, apg_stream_t stream) {
   if (!items || n < 1 || n > APG_SOA_MAX_ITEMS || B < 0) {

@@ -2532,9 +2532,10 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
 
 #pragma unroll 1
   for (int k = kH - 1; k >= 0; --k) {
-    const unsigned pB = opaque(pitchB), pN = opaque(pitchN);
+    // (knock-out 64: every per-lane plane sits 256 bytes from the next - cache resident)
+    const unsigned pB = (APG_AR_KNOCKOUT & 64) ? 256u : opaque(pitchB), pN = opaque(pitchN);
     const unsigned col = (unsigned)b * 4u + (unsigned)k * pitchB;
-    const unsigned vn = live ? col : kDead;
+    const unsigned vn = live ? ((APG_AR_KNOCKOUT & 64) ? (unsigned)lane * 4u : col) : kDead;
     const unsigned wcolN = wcolB + (unsigned)k * pB;   // (scalar) column k B + the wave's first
     // the identity operands of the transpositions: made per step from an opaque
     // lane index (eight registers that would otherwise live through the sweep)

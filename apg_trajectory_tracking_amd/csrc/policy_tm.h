@@ -60,12 +60,27 @@ __device__ __forceinline__ int bits_exp(unsigned a, bool &bad, bool nonneg_floor
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
 typedef int i32x4_ __attribute__((ext_vector_type(4)));
 
+#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_AR_KNOCKOUT)
+#error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
+#endif
+#ifndef APG_AR_KNOCKOUT
+#define APG_AR_KNOCKOUT 0   // timing experiments (recurrent sweeps): 1 no global atomics,
+                            // 2 no weight-block products, 4 no LDS adds, 8 no conv-weight
+                            // products, 16 no workgroup barriers, 32 the trajectory-major
+                            // block loads read one cache-resident 2 KB window, 64 the
+                            // per-lane state / action / reference loads read cached planes
+#endif
+
 // 32 planes from `soff` (scalar: first plane x pitch + the wave's first
 // trajectory), one per lane & 31, trajectory-major: v[4 g + c] = trajectory
 // c + 8 g + 4 hi of the wave - the trajectory set of accumulator register 4 g + c
 struct TBlock {
   u32x4 q[4];
   __device__ __forceinline__ void load(const Planes &X, unsigned voff, unsigned soff) {
+    if (APG_AR_KNOCKOUT & 32) {
+      voff = (threadIdx.x & 31u) * 64u + ((threadIdx.x & 32u) ? 16u : 0u);
+      soff = 0u;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       q[g] = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, (int)voff, (int)(soff + 32 * g),
@@ -200,14 +215,6 @@ __device__ __forceinline__ void texp(int ex, int hi, int (&E)[16]) {
 // scalar - no 64-bit address pairs per flush site.  One element += v, no return
 // value (buffer_atomic_add_f32: executed at the L2); this thread owns the element
 // for the whole sweep, the steps add in order.
-#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_AR_KNOCKOUT)
-#error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
-#endif
-#ifndef APG_AR_KNOCKOUT
-#define APG_AR_KNOCKOUT 0   // timing experiments (recurrent sweeps): 1 no global atomics,
-                            // 2 no weight-block products, 4 no LDS adds, 8 no conv-weight
-                            // products, 16 no workgroup barriers
-#endif
 __device__ __forceinline__ void gadd(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff,
                                      float v) {
   if (APG_AR_KNOCKOUT & 1) return;

@@ -709,6 +709,53 @@ def measured_copy_bandwidth(dev):
                     "stated there)"}
 
 
+def stream_floor_probe(args, dev, nsets):
+    """the headline launch's bytes - 28 input rows + 10 output
+    rows of B x 16 B - moved by the fastest copy shape of this GPU (one float4 per
+    thread, whole-array grid; csrc/common.hip `stream_rows_probe_kernel`) under
+    the headline's own protocol: `nsets` rotating buffer sets, 2 000 launches,
+    one HIP-event pair on the launch stream.  No arithmetic and no trajectory
+    structure: a floor for the rollout kernel's launch, not a model of it."""
+    from apg_trajectory_tracking_amd import _capi
+    H, B = args.horizon, args.batch
+    in_bytes = B * (48 + 16 * H + 24 * H)          # state0 + actions + ref(pos, vel)
+    out_bytes = B * 16 * H                         # dL/dactions
+    ins = [torch.randn(in_bytes // 4, device=dev) for _ in range(nsets)]
+    outs = [torch.empty(out_bytes // 4, device=dev) for _ in range(nsets)]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    lib = _capi.lib()
+    names = {1: "first 10/28 of the threads store, plain", 2: "first 10/28 store, nt",
+             3: "stores spread between the loads, plain", 4: "stores spread, nt",
+             5: "as 1, one wave per workgroup", 6: "as 2, one wave per workgroup"}
+    res = {}
+    n = 2000
+    for shape, what in names.items():
+        def run(i):
+            _capi.check(lib.apg_stream_rows_probe(
+                ins[i % nsets].data_ptr(), in_bytes, outs[i % nsets].data_ptr(), out_bytes,
+                shape, st), "apg_stream_rows_probe")
+        for i in range(40):
+            run(i)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            run(i)
+        e1.record()
+        torch.cuda.synchronize()
+        res[what] = e0.elapsed_time(e1) / n * 1e3
+    # the stores landed where they should (shape 1: out == the head of in)
+    _capi.check(lib.apg_stream_rows_probe(ins[0].data_ptr(), in_bytes, outs[0].data_ptr(),
+                                          out_bytes, 1, st), "apg_stream_rows_probe")
+    ok = bool(torch.equal(outs[0], ins[0][:out_bytes // 4]))
+    best = min(res.values())
+    return {"us_by_shape": res, "best_us": best, "verified": ok,
+            "in_bytes": in_bytes, "out_bytes": out_bytes, "buffer_sets": nsets,
+            "launches": n, "GBps_best": (in_bytes + out_bytes) / best / 1e3,
+            "what": "apg_stream_rows_probe: the headline launch's algorithmic bytes, one "
+                    "float4 per thread over a whole-array grid, python launches, HIP events"}
+
+
 KERNEL_SOURCES = ("quad.hip", "quad_math.h", "apg_device.h")
 WING_SOURCES = ("wing.hip", "wing_math.h", "apg_device.h")
 FP32_VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2   # 157.3 TFLOP/s spec = one
@@ -1469,6 +1516,14 @@ def main():
         except Exception as e:          # informational only
             copy_gbps = {"error": repr(e)}
     out["roofline"]["copy_GBps_measured"] = copy_gbps
+    if not args.headline_only:
+        try:
+            fl = stream_floor_probe(args, dev, nset)
+            out["roofline"]["stream_floor_us"] = fl["best_us"]
+            out["roofline"]["stream_floor"] = fl
+            out["roofline"]["kernel_over_stream_floor"] = kernel_ms * 1e3 / fl["best_us"]
+        except Exception as e:          # informational only
+            out["roofline"]["stream_floor"] = {"error": repr(e)}
     del plans, kplans, sets, g_steps, g_kernel
     gc.collect()
     torch.cuda.empty_cache()

@@ -885,6 +885,15 @@ int apg_stream_copy(const void *src, void *dst, long long bytes, apg_stream_t st
  * measurement aid for bench.py's `roofline.copy_GBps_measured`. */
 int apg_stream_copy_shape(const void *src, void *dst, long long bytes, int shape,
                           apg_stream_t stream);
+/* Measurement aid for `roofline.stream_floor_us`: the bytes of ONE headline
+ * launch (in_bytes read - state0 + actions + reference rows - and
+ * out_bytes written - dL/dactions rows) moved in the fastest copy shape this GPU
+ * has (one 16-byte element per thread, the whole input as the grid), with no
+ * arithmetic.  shape 1 / 2: the first out_bytes/16 threads store (plain /
+ * non-temporal); 3 / 4: the stores spread evenly between the loads; 5 / 6: as
+ * 1 / 2 with one wave per workgroup. */
+int apg_stream_rows_probe(const void *in, long long in_bytes, void *out, long long out_bytes,
+                          int shape, apg_stream_t stream);
 
 /* APG_VERSION_MAJOR * 1000 + APG_VERSION_MINOR. */
 int apg_version(void);

@@ -1,0 +1,136 @@
+"""Round 6, VERDICT r5 "next" #4 (the three parity holes) and #1 on the GPU:
+  * the per-row float64 arbiter on the LSTM step's parameter gradients
+    (configs[4]) and on the fixed-wing policy's (configs[3]);
+  * the fused fixed-wing TRAINING step at B = 131 072, H = 20 - the launch
+    `secondary.wing_train_step` times - against float64 autograd over
+    oracle.torch_port (scripts/train_fixed_wing.py:90-116,
+    neural_control/drone_loss.py:72-82);
+  * `python bench.py --gpus N` as a plain command on a box with fewer GPUs:
+    an explicit error, not a hang."""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, assert_param_rows_no_worse_than_fp32, rel_err
+
+pytestmark = pytest.mark.gpu
+H, DT = 10, 0.1
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda:0")
+
+
+def N(t):
+    return t.detach().double().cpu().numpy()
+
+
+@pytest.mark.parametrize("case", ["random_init", "outlier_per_workgroup"])
+def test_lstm_parameter_gradient_rows_vs_fp64_at_full_size(dev, case):
+    """configs[4] (LSTM, B = 65 536, H = 10): every ROW of every parameter
+    gradient of the fused step (sweeps + planes_gemm products) against float64
+    autograd, float32 autograd as the yardstick - the arbiter that judges the
+    concurrent and autoregressive steps (tests/test_gpu_round5.py).  The hidden
+    state of rnn.py:30-33 is drawn once and fed to kernels and oracles alike."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    from oracle import torch_port as tp
+    B = 65536
+    torch.manual_seed(31)
+    net = LSTM_NEW(15, H, 9, 4, conv=1)
+    d = synthetic.quad_polynomial_batch(B, H, DT, seed=77, ref_length=2 * H)
+    if case == "outlier_per_workgroup":
+        d["ref"] = d["ref"].clone()
+        d["ref"][7::256] *= 1.0e3
+    gen = torch.Generator().manual_seed(6)
+    h0 = torch.randn(B, 8, generator=gen)
+    c0 = torch.randn(B, 8, generator=gen)
+
+    def oracle(dtype):
+        n = copy.deepcopy(net).to(dtype)
+        n.hidden_state, n.cell_state = h0.to(dtype), c0.to(dtype)
+        _, _, loss = tp.quad_recurrent_unroll(
+            n, tp.QuadOracle(dtype=dtype), d["state0"].to(dtype), d["in_ref"].to(dtype),
+            d["ref"].to(dtype), H, DT)
+        loss.backward()
+        return {k: p.grad.double().numpy() for k, p in n.named_parameters()
+                if p.grad is not None}
+    want, f32 = oracle(torch.float64), oracle(torch.float32)
+    gnet = copy.deepcopy(net).to(dev)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    loss, _, _ = F.quad_lstm_rollout_loss(gnet, s0, in_ref, ref, DT,
+                                          FlightmareDynamics().params, h0.to(dev), c0.to(dev))
+    loss.backward()
+    got = {k: N(p.grad) for k, p in gnet.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    for k, w in want.items():
+        assert rel_err(got[k], w) < 1e-4, (k, rel_err(got[k], w))
+    assert_param_rows_no_worse_than_fp32(got, f32, want, f"LSTM, {case}")
+
+
+def test_wing_fused_step_full_size_vs_fp64_oracle(dev):
+    """configs[3] as a TRAINING step: TrainFixedWing.train_concurrent_fused at
+    B = 131 072, H = 20 (mlp_wing.hip policy forward / reverse on the matrix
+    cores around wing_rollout_pk_kernel, weight products, SGD) - loss and every
+    parameter gradient against float64 autograd over the oracle's op sequence,
+    per-tensor at north_star's 1e-4 and per row by the arbiter."""
+    from apg_trajectory_tracking_amd.dataset import SyntheticWingDataset
+    from apg_trajectory_tracking_amd.dynamics.fixed_wing_dynamics import FixedWingDynamics
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.train_fixed_wing import TrainFixedWing
+    from oracle import torch_port as tp
+    B, Hw, dt = 131072, 20, 0.05
+    cfg = dict(delta_t=dt, delta_t_train=dt, epoch_size=B, self_play=0, batch_size=B,
+               state_size=12, horizon=Hw, ref_dim=3, action_dim=4,
+               learning_rate_controller=1e-12, system="fixed_wing", modified_params={})
+    data = SyntheticWingDataset(B, Hw, dt, seed=17, device=dev)
+    torch.manual_seed(6)
+    net = Net(9, 1, 3, 4 * Hw, conv=False)
+    t = TrainFixedWing(FixedWingDynamics(), FixedWingDynamics(), dict(cfg))
+    t.net = copy.deepcopy(net).to(dev)
+    t.optimizer_controller = torch.optim.SGD(t.net.parameters(), lr=1e-12, momentum=0.9)
+    loss = t.train_concurrent_fused(data.normed_states, data.states, data.in_ref_states,
+                                    data.ref_states)
+    assert loss is not None, "the fused fixed-wing step did not apply"
+    got = {k: N(p.grad) for k, p in t.net.named_parameters() if p.grad is not None}
+
+    def oracle(dtype):
+        n = copy.deepcopy(net).to(dtype)
+        acts = torch.sigmoid(n(data.normed_states.cpu().to(dtype),
+                               data.in_ref_states.cpu().to(dtype))).reshape(-1, Hw, 4)
+        states = tp.unroll(tp.WingOracle(dtype=dtype), data.states.cpu().to(dtype), acts, dt)
+        l = tp.fixed_wing_mpc_loss(states, data.ref_states.cpu().to(dtype), acts)
+        l.backward()
+        return float(l), {k: p.grad.double().numpy() for k, p in n.named_parameters()
+                          if p.grad is not None}
+    l64, want = oracle(torch.float64)
+    _, f32 = oracle(torch.float32)
+    assert abs(loss.item() - l64) / l64 < 1e-5, (loss.item(), l64)
+    assert set(got) == set(want)
+    for k, w in want.items():
+        assert rel_err(got[k], w) < 1e-4, (k, rel_err(got[k], w))
+    assert_param_rows_no_worse_than_fp32(got, f32, want, "fixed wing fused step, B = 131 072")
+
+
+def test_bench_gpus_beyond_the_node_is_an_explicit_error(dev):
+    """`python bench.py --gpus N` with N above
+    torch.cuda.device_count() says so and exits at once (no rendezvous, no RCCL
+    init that would wait for ranks that cannot exist)."""
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n),
+                        "--steps", "20", "--warmup", "5"], capture_output=True, text=True,
+                       timeout=240, env=env)
+    assert r.returncode != 0
+    assert f"--gpus {n}" in r.stderr and "GPU(s)" in r.stderr, r.stderr[-500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -578,7 +578,8 @@ def test_initialize_model_from_checkpoint_directory(tmp_path, monkeypatch):
 def test_bench_line_contract():
     """The committed bench lines (profiles/) carry every field the driver's
     contract names, with consistent arithmetic; bench.py refuses to run
-    without a GPU or with --gpus N outside torch.distributed.run."""
+    without a GPU - also as `--gpus N` (which launches itself under
+    torch.distributed.run since round 6: tests/test_distributed_cpu.py)."""
     import json
     import subprocess
     import sys
@@ -646,9 +647,10 @@ def test_bench_line_contract():
         assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"],
-                       capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
 
 
 @pytest.mark.filterwarnings("ignore::RuntimeWarning")   # mean of no complete run
