@@ -1902,7 +1902,9 @@ class QuadConcurrentStepPlan:
                 # written from outside - captured steps pack their tables)
                 k["upd"].resident, self._versions = 0, None
             else:
-                now = [t._version for t in k["tensors"]]
+                # (version counter AND storage address: `p.data = other` moves the
+                # storage without touching the counter of the Parameter)
+                now = [(t._version, t.data_ptr()) for t in k["tensors"]]
                 # 1: first launch on this workspace (builds the table map); then
                 # 2 while nobody else has written the parameters, else 3 (pack)
                 k["upd"].resident = (2 if now == self._versions
@@ -1915,8 +1917,18 @@ class QuadConcurrentStepPlan:
         if self.updates:
             note_in_kernel_update(self._written)
             if self._versions is not None:      # (ours: the tables follow them)
-                self._versions = [t._version for t in self._keep["tensors"]]
+                self._versions = [(t._version, t.data_ptr()) for t in self._keep["tensors"]]
         return self.loss0
+
+    def invalidate(self):
+        """The parameters were written behind autograd's back - through `p.data`
+        (`p.data.clamp_()`, `p.data.copy_()`: weight clipping, soft updates), which
+        bumps a version counter this plan cannot see.  The next launch
+        packs the operand tables from the parameters again (one pack launch, ~6 us).
+        TrainBase calls this at the start of every epoch; a caller that writes
+        `.data` between steps calls it after each write, or builds its trainer with
+        `resident_tables = False` (pack at every step)."""
+        self._versions = None
 
 
 # True: a step plan with the in-kernel update keeps its packed operand tables

@@ -342,6 +342,11 @@ class TrainBase:
         # None: two graphs around the all-reduce slot iff world > 1; True
         # forces that form on one rank (tests, bench.py's like-for-like number)
         self.split_graph = None
+        # True: a step plan's operand tables stay resident between steps (no pack
+        # launch); False: packed at every step - for callers that write the
+        # parameters through `.data` between steps without calling
+        # `plan.invalidate()` ("resident operand tables")
+        self.resident_tables = True
         # True: run the graphed scheduling without a GPU (parts executed
         # eagerly; the gloo tests of the N > 1 step)
         self.graph_emulation = False
@@ -733,6 +738,8 @@ class TrainBase:
         g = self._graphs.get(key)
         if not isinstance(g, _PlannedStep) or g.signature != sig:
             g = self._graphs[key] = build()
+            if not self.resident_tables:
+                g.plan.resident_tables = False
             g.held_state = self._held_state()    # (addressed by the plan)
             g.signature = self._graph_signature(inputs, volatile, params)
             if cache is not None:
@@ -1216,6 +1223,15 @@ class TrainBase:
             raise ValueError("train must be 'controller' or 'dynamics'")
         table = getattr(self, "_epoch_runners", None) or self._epoch_table()
         self._guard_data_set(train)
+        # step plans keep their packed operand tables from step to step and notice
+        # foreign parameter writes by version counter + address; a write through
+        # `p.data` moves neither: the tables are packed afresh at the
+        # first batch of every epoch - one ~6 us launch per epoch and plan
+        for g in self._graphs.values():
+            if getattr(g, "planned", False):
+                if not self.resident_tables:
+                    g.plan.resident_tables = False
+                g.plan.invalidate()
         for name, applies, runner in table:
             if applies(train):
                 self.last_epoch_loop = name

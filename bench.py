@@ -713,8 +713,8 @@ def stream_floor_probe(args, dev, nsets):
     """the headline launch's bytes - 28 input rows + 10 output
     rows of B x 16 B - moved by the fastest copy shape of this GPU (one float4 per
     thread, whole-array grid; csrc/common.hip `stream_rows_probe_kernel`) under
-    the headline's own protocol: `nsets` rotating buffer sets, 2 000 launches,
-    one HIP-event pair on the launch stream.  No arithmetic and no trajectory
+    the headline's own protocol: `nsets` rotating buffer sets, 2 000 launches
+    replayed from a captured graph, one HIP-event pair on the launch stream.  No arithmetic and no trajectory
     structure: a floor for the rollout kernel's launch, not a model of it."""
     from apg_trajectory_tracking_amd import _capi
     H, B = args.horizon, args.batch
@@ -722,28 +722,41 @@ def stream_floor_probe(args, dev, nsets):
     out_bytes = B * 16 * H                         # dL/dactions
     ins = [torch.randn(in_bytes // 4, device=dev) for _ in range(nsets)]
     outs = [torch.empty(out_bytes // 4, device=dev) for _ in range(nsets)]
-    st = torch.cuda.current_stream(dev).cuda_stream
     lib = _capi.lib()
     names = {1: "first 10/28 of the threads store, plain", 2: "first 10/28 store, nt",
              3: "stores spread between the loads, plain", 4: "stores spread, nt",
              5: "as 1, one wave per workgroup", 6: "as 2, one wave per workgroup"}
     res = {}
-    n = 2000
+    per_graph, replays = 400, 5
+    n = per_graph * replays
+    side = torch.cuda.Stream(device=dev)
     for shape, what in names.items():
         def run(i):
             _capi.check(lib.apg_stream_rows_probe(
                 ins[i % nsets].data_ptr(), in_bytes, outs[i % nsets].data_ptr(), out_bytes,
-                shape, st), "apg_stream_rows_probe")
-        for i in range(40):
-            run(i)
+                shape, torch.cuda.current_stream(dev).cuda_stream), "apg_stream_rows_probe")
+        with torch.cuda.stream(side):
+            for i in range(40):
+                run(i)
+        torch.cuda.synchronize()
+        # as the headline: the launches replayed from ONE captured graph (a Python /
+        # ctypes launch costs about what this kernel takes - the host must not pace it)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(per_graph):
+                run(i)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(n):
-            run(i)
-        e1.record()
+        with torch.cuda.stream(side):
+            g.replay()
+            e0.record()
+            for _ in range(replays):
+                g.replay()
+            e1.record()
         torch.cuda.synchronize()
         res[what] = e0.elapsed_time(e1) / n * 1e3
+        del g
+    st = torch.cuda.current_stream(dev).cuda_stream
     # the stores landed where they should (shape 1: out == the head of in)
     _capi.check(lib.apg_stream_rows_probe(ins[0].data_ptr(), in_bytes, outs[0].data_ptr(),
                                           out_bytes, 1, st), "apg_stream_rows_probe")
@@ -753,7 +766,8 @@ def stream_floor_probe(args, dev, nsets):
             "in_bytes": in_bytes, "out_bytes": out_bytes, "buffer_sets": nsets,
             "launches": n, "GBps_best": (in_bytes + out_bytes) / best / 1e3,
             "what": "apg_stream_rows_probe: the headline launch's algorithmic bytes, one "
-                    "float4 per thread over a whole-array grid, python launches, HIP events"}
+                    "float4 per thread over a whole-array grid, 400 launches per captured graph x 5 "
+                    "replays, HIP events on the launch stream"}
 
 
 KERNEL_SOURCES = ("quad.hip", "quad_math.h", "apg_device.h")

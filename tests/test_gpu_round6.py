@@ -134,3 +134,46 @@ def test_bench_gpus_beyond_the_node_is_an_explicit_error(dev):
     assert r.returncode != 0
     assert f"--gpus {n}" in r.stderr and "GPU(s)" in r.stderr, r.stderr[-500:]
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_resident_tables_after_a_write_through_data_need_invalidate(dev):
+    """a parameter written through `p.data` bumps a version counter
+    the step plan cannot see - its resident operand tables would stay stale.
+    `plan.invalidate()` (TrainBase.run_epoch calls it for every plan at the start
+    of an epoch) makes the next launch pack again; a moved storage
+    (`p.data = other`) is seen by itself (the address is part of the key).  Both
+    against a plan that packs at every step: bit for bit."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    B = 1024
+    d = synthetic.quad_polynomial_batch(B, H, DT, seed=6, ref_length=H)
+    st, inr, rf = (d[k].to(dev).contiguous() for k in ("state0", "in_ref", "ref"))
+    normed = state_preprocessing(st).contiguous()
+    params = FlightmareDynamics().params
+    prepared = F.quad_concurrent_prepare(normed, st, inr, rf)
+    outs = []
+    for resident in (True, False):
+        torch.manual_seed(1)
+        net = Net(15, H, 9, 4 * H, conv=1).to(dev)
+        bufs = {n: torch.zeros_like(p) for n, p in net.named_parameters() if n in F._MLP_PARAMS}
+        plan = F.QuadConcurrentStepPlan(net, prepared, DT, params,
+                                        update=(2e-4 / B, 0.9, bufs))
+        plan.resident_tables = resident
+        flags, losses = [], []
+        for i in range(7):
+            if i == 2:          # weight clipping behind autograd's back
+                net.fc2.weight.data.clamp_(-0.05, 0.05)
+                plan.invalidate()
+            if i == 4:          # the storage is replaced
+                net.fc3.bias.data = net.fc3.bias.data.clone() * 0.5
+            losses.append(float(plan.launch()))
+            flags.append(plan._keep["upd"].resident)
+        if resident:
+            assert flags == [1, 2, 3, 2, 3, 2, 2], flags
+        outs.append((losses, [p.detach().clone() for p in net.parameters()]))
+    (la, pa), (lb, pb) = outs
+    assert la == lb and np.isfinite(la).all()
+    assert all(torch.equal(x, y) for x, y in zip(pa, pb))

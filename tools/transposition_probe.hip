@@ -14,7 +14,10 @@
 //   * the feature-major chain  d' = (W^T d) (1 - x^2)  (24 matrix instructions,
 //     x brought into accumulator layout by an identity product as the kernels do),
 //   * the four 32 x 32 weight blocks  dW += d x^T  (24 matrix instructions) added
-//     into a [64][64] accumulator in LDS (ds_add_f32 here),
+//     into the workgroup's fixed-point accumulators in LDS exactly as the kernels
+//     do (policy_tm.h add_block: rint + ds_add_u32; workgroup exponent exchanged
+//     through LDS behind ONE barrier per layer, two alternating regions, the other
+//     region flushed into the workgroup's global partials by atomic adds),
 // and differs ONLY in how the A operands of the weight blocks are made:
 //   0 swapped    what is shipped: the chain a second time with the operands
 //                swapped (trajectory-major result), tanh' and split again
@@ -22,7 +25,8 @@
 //                instructions per 32 features), rescale, split
 //   2 lds_tr     the split cotangent written to LDS as packed fp16 (ds_write_b64,
 //                8-byte units swizzled) and read back with ds_read_b64_tr_b16:
-//                the result IS the A operand (per-trajectory scales folded into x)
+//                the result IS the A operand up to the per-trajectory scales, which
+//                a packed fp16 multiply per dword applies (exact: powers of two)
 //   3 permlane   the same exchange in registers: six lane-bit <-> register-bit
 //                stages (v_perm_b32 + DPP, DPP with bank masks, v_permlane16_swap,
 //                v_permlane32_swap)
@@ -62,8 +66,9 @@ int device_cu_count() { return 256; }
 
 constexpr int kThr = 512, kWavesWG = kThr / 64;
 constexpr int kTab = 8 * kBlock16;                 // W^T as 8 A-operand blocks
-constexpr int kAcc = kTab;                         // [64][64] floats
-constexpr int kStage = kAcc + 64 * 64 * 4;         // per-wave staging (variant 2)
+constexpr int kAcc = kTab;                         // two regions of four 4 KB blocks
+constexpr int kMeta = kAcc + 2 * 16384;            // the waves' maxima [2][8]
+constexpr int kStage = kMeta + 256;                // per-wave staging (variant 2)
 constexpr int kSub = 1152, kTerm = 4 * kSub, kStageWave = 2 * kTerm;   // 9 216 B per wave
 constexpr int kLdsB = 147456;                      // 144 KB: one workgroup per CU
 
@@ -71,7 +76,7 @@ struct Args {
   const float *d0;     // [64][B]   incoming cotangent
   const float *x;      // [64][B]   the layer's input activations (tanh values)
   const float *W;      // [64][64]  W[m][k]
-  float *partial;      // [workgroups][64 * 64]
+  float *partial;      // [workgroups][4 blocks][16 registers][64 lanes]
   int B, iters;
 };
 
@@ -194,7 +199,10 @@ __global__ __launch_bounds__(kThr) void probe_kernel(Args A) {
     *reinterpret_cast<u32x4 *>(lds + blk * kBlock16 + lane * 16) = o.h;
     *reinterpret_cast<u32x4 *>(lds + blk * kBlock16 + 1024 + lane * 16) = o.l;
   }
-  for (int i = threadIdx.x; i < 64 * 64; i += kThr) reinterpret_cast<float *>(lds + kAcc)[i] = 0.f;
+  zero_region(lds, kAcc, 2 * 16384 + 256);
+  const __amdgpu_buffer_rsrc_t part = __builtin_amdgcn_make_buffer_rsrc(
+      A.partial + (size_t)blockIdx.x * 4096, 0, 16384, 0x00020000);
+  for (int i = threadIdx.x; i < 4096; i += kThr) A.partial[(size_t)blockIdx.x * 4096 + i] = 0.f;
   __syncthreads();
   const LdsView16 L16(lds, lane);
   // incoming cotangent, accumulator layout
@@ -226,22 +234,28 @@ __global__ __launch_bounds__(kThr) void probe_kernel(Args A) {
   u32x4 ident[2];
   ident_operands(lane, ident);
   char *stage = lds + kStage + wave * kStageWave;
-  float *accl = reinterpret_cast<float *>(lds + kAcc);
+  unsigned (*slots)[8] = reinterpret_cast<unsigned (*)[8]>(lds + kMeta);
+  int rg = kAcc, ro = kAcc + 16384, e_prev = 0;
 
 #pragma unroll 1
   for (int it = 0; it < A.iters; ++it) {
     // ---- common: split of the incoming cotangent (per-trajectory scale 2^ex)
     Op16 x[4];
     const int ex = scaled_split64(d, x);
-    // the wave's exponent (the kernels exchange a workgroup exponent through LDS
-    // behind a barrier that is there anyway)
+    // the workgroup's exponent: the waves' maxima through LDS, one barrier per
+    // layer; behind it the OTHER region (the previous layer's blocks) is flushed
     unsigned am = 0u;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) am = umax_abs(am, d[rb][i]);
+    am = wave_umax(am);
+    if (lane == 0) slots[it & 1][wave] = am;
+    __syncthreads();
     bool bad = false;
-    const int ew = bits_exp(wave_umax(am), bad, false);
+    const int ew = wg_exp(slots[it & 1], bad);
+    if (it > 0) flush_add<4096>(lds, ro, part, 0, e_prev, bad);
+    e_prev = ew;
     // ---- the A operands of the weight blocks
     Op16 ad[2][2];
     int E[16];
@@ -283,35 +297,45 @@ __global__ __launch_bounds__(kThr) void probe_kernel(Args A) {
           for (int q = 0; q < 4; ++q)
             ad[mb][kk].h[q] = uh[8 * mb + 4 * kk + q], ad[mb][kk].l[q] = ul[8 * mb + 4 * kk + q];
     }
+    if constexpr (V >= 2) {
+      // per-trajectory scales 2^(E - ew + kPreD) of the k-slots, packed fp16 pairs
+      typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
+      hv2 sc[2][4];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const hv2 t = {(_Float16)__builtin_amdgcn_ldexpf(1.f, E[8 * kk + 2 * q] - ew + kPreD),
+                         (_Float16)__builtin_amdgcn_ldexpf(1.f, E[8 * kk + 2 * q + 1] - ew + kPreD)};
+          sc[kk][q] = t;
+        }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // (element copies first: __builtin_bit_cast of a vector ELEMENT
+            // expression reads element 0 of the vector)
+            const unsigned wh = ad[mb][kk].h[q], wl = ad[mb][kk].l[q];
+            ad[mb][kk].h[q] = __builtin_bit_cast(unsigned, __builtin_bit_cast(hv2, wh) * sc[kk][q]);
+            ad[mb][kk].l[q] = __builtin_bit_cast(unsigned, __builtin_bit_cast(hv2, wl) * sc[kk][q]);
+          }
+    }
     // ---- per x block: weight blocks, chain
     f32x16 nx[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       Op16 bx[2];      // x as the chain needs it (tanh'), scaled 2^kPreX
       split16(xT[nb], -kPreX, bx);
-      Op16 bp[2];      // x as the weight blocks need it
-      if constexpr (V <= 1) {
-        bp[0] = bx[0], bp[1] = bx[1];
-      } else {         // per-trajectory scales of the A operand folded in
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-          v[i] = __builtin_amdgcn_ldexpf(xT[nb][i], E[i] - ew + kPreX);
-        split16(v, 0, bp);
-      }
-      const int back = V <= 1 ? ew - kPreD - kPreX : ew - kPreX;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) acc = mma3(ad[mb][kk], bp[kk], acc);
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-          __hip_atomic_fetch_add(accl + (32 * mb + rrow(i) + 4 * hi) * 64 + 32 * nb + row,
-                                 __builtin_amdgcn_ldexpf(acc[i], back), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int kk = 0; kk < 2; ++kk) acc = mma3(ad[mb][kk], bx[kk], acc);
+        add_block(lds + rg + (2 * mb + nb) * 4096 + lane * 4, acc);
       }
       f32x16 tt;
 #pragma unroll
@@ -338,10 +362,11 @@ __global__ __launch_bounds__(kThr) void probe_kernel(Args A) {
       __builtin_amdgcn_sched_barrier(0);
     }
     d[0] = nx[0], d[1] = nx[1];
+    { const int r_ = rg; rg = ro, ro = r_; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 64 * 64; i += kThr)
-    A.partial[(size_t)blockIdx.x * 4096 + i] = accl[i];
+  bool bad = false;
+  flush_add<4096>(lds, ro, part, 0, e_prev, bad);
 }
 
 template <int V>
@@ -429,9 +454,12 @@ int main() {
     for (int e = 0; e < 4096; ++e) {
       double s = 0;
       for (int p = 0; p < blocks; ++p) s += P[(size_t)p * 4096 + e];
-      int m = e >> 6;
-      if (v == 3) m = v3_feature(m >> 5, m & 31);   // variant 3's own row order
-      worst = fmax(worst, fabs(s - ref[m * 64 + (e & 63)]));
+      // accumulator layout: block 2 mb + nb, register i, lane (hi, col)
+      const int blk = e >> 10, i = (e >> 6) & 15, ln = e & 63;
+      const int a = rrow(i) + 4 * (ln >> 5), k = 32 * (blk & 1) + (ln & 31);
+      int m = 32 * (blk >> 1) + a;
+      if (v == 3) m = v3_feature(blk >> 1, a);   // variant 3's own row order
+      worst = fmax(worst, fabs(s - ref[m * 64 + k]));
     }
     A.iters = 200;
     const float ms = dispatch(v, A, blocks, 5);

@@ -62,7 +62,7 @@ for name, lines in bodies.items():
         ins.append(s.split(";")[0].strip())
     best = None
     for i, s in enumerate(ins):
-        m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", s)
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", s)
         if m and m.group(1) in labels and labels[m.group(1)] <= i:
             span = (labels[m.group(1)], i + 1)
             if best is None or span[1] - span[0] > best[1] - best[0]:
