@@ -2514,15 +2514,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
   // 32..51 the conv bias) - one writer per address, the steps in order; the
   // second stage sums the eight waves in order.  No fixed-point unit involved.
   const unsigned bias_soff = (unsigned)(uBias + (wave >> 2)) * 4096u + (unsigned)(wave & 3) * 1024u;
-  const auto add_bias = [&](const float (&v)[16], int layer, int mb) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += v[i];
-    s += other_half(s);
-    if (hi == 0)
-      gadd(part, (unsigned)(layer * 64 + 32 * mb + row) * 4u, bias_soff,
-           bad ? __builtin_nanf("") : s);
-  };
+  // (transposed_operands below adds them)
   // the deferred blocks of a step: fc1's last four (conv columns 96..159) and
   // the conv block
   const auto flush_tail = [&]() {
@@ -2641,10 +2633,9 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
 
     // ------------------------------------------------ phase 1: head, fc3
     const int e0 = wg_exp(meta.dmax[0], bad), e3 = wg_exp(meta.dmax[1], bad);
-    float dT[2][16];        // the current layer's cotangent, trajectory-major
     {
       // dL/dz^T by an identity product (scaled into accumulator units), W_out's
-      // and b_out's gradient, d_pre3^T from the two head^T blocks
+      // and b_out's gradient
       float v8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
@@ -2686,32 +2677,53 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
 #pragma unroll
           for (int i = 0; i < 4; ++i) lds_add(lds + rHead + (i * 64 + 32 * nb + row) * 4, acc[i]);
         }
-        f32x16 tt;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tt[i] = 0.f;
-        tt = mma3(x0, L16.A(gA, aH + nb), tt);
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-          dT[nb][i] = __builtin_amdgcn_ldexpf(tt[i], e0 - kPreD) * (1.f - x3[nb][i] * x3[nb][i]);
       }
     }
-    // One 64 x 64 layer: dl / dT = its cotangent in both layouts, e_ = the
+    // The A operands of a layer's weight blocks from its cotangent in the chain's
+    // orientation (round 6; until round 5 the chain ran a second time with its
+    // operands swapped to get them: tools/transposition_probe.hip prices both,
+    // profiles/r06_transposition_probe.jsonl - 7.5 against 5.6 us per layer): the
+    // split the chain needs anyway, x[kb] = d 2^-ex[trajectory] as fp16 pairs with
+    // the trajectory in the lane, times an identity B operand puts trajectory
+    // r(i) + 4 hi of feature `lane & 31` into register i (4 matrix instructions per
+    // 32 features, exact: every product is a value times one); the trajectories'
+    // exponents arrive in the same layout (texp) and the rescale to the
+    // workgroup's unit 2^(e_ - kPreD) is one ldexp per value.  Bias gradient: the
+    // float sum of the wave's 32 trajectories per row, as before.
+    const auto transposed_operands = [&](const Op16 (&x)[4], int ex, int e_, int bias_id,
+                                         Op16 (&ad)[2][2]) {
+      int E[16];
+      texp(ex, hi, E);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const Op16 pr[2] = {x[2 * mb], x[2 * mb + 1]};
+        const f32x16 tz = to_feature_major(pr, ident);
+        float v[16], sb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          v[i] = __builtin_amdgcn_ldexpf(tz[i], E[i] - e_ + kPreD);
+          sb += v[i];
+        }
+        sb += other_half(sb);
+        if (bias_id >= 0 && hi == 0)
+          gadd(part, (unsigned)(bias_id * 64 + 32 * mb + row) * 4u, bias_soff,
+               bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf(sb, e_ - kPreD));
+        split16(v, 0, ad[mb]);
+      }
+    };
+    // One 64 x 64 layer: dl = its cotangent (accumulator layout), e_ = the
     // workgroup's exponent for it, x = planes [x_plane, +64) of X (the second
     // block and `next_plane`'s first of Xn are requested on the way).  Weight
-    // blocks into the region at `rb`, the cotangent of the layer below in both
-    // layouts (tables `tab`; tanh' from the x blocks, brought into accumulator
-    // layout by to_feature_major), its maxima into slot `phase + 1`.
+    // blocks into the region at `rb`, the cotangent of the layer below (tables
+    // `tab`; tanh' from the x blocks, brought into accumulator layout by
+    // to_feature_major), its maxima into slot `phase + 1`.
     const auto layer64 = [&](f32x16 (&dl)[2], f32x16 (&nx)[2], int e_, int tab, const Planes &X,
                              int x_plane, const Planes &Xn, int next_plane, int bias_id,
                              int phase, char *rb) {
       Op16 x[4];
       const int ex = scaled_split64(dl, x);
       Op16 ad[2][2];
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        add_bias(dT[mb], bias_id, mb);
-        split16(dT[mb], e_ - kPreD, ad[mb]);
-      }
+      transposed_operands(x, ex, e_, bias_id, ad);
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         float xv[16];
@@ -2731,20 +2743,10 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
           if (APG_AR_KNOCKOUT & 4) ar_sink(acc); else
           add_block(rb + (2 * nb + mb) * 4096, acc);
         }
-        f32x16 tt;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tt[i] = 0.f, nx[nb][i] = 0.f;
+        for (int i = 0; i < 16; ++i) nx[nb][i] = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          const Op16 w = L16.A(gA, tab + 4 * nb + kb);
-          tt = mma3(x[kb], w, tt);           // trajectory-major
-          nx[nb] = mma3(w, x[kb], nx[nb]);   // feature-major: the same block, operands swapped
-        }
-        int E[16];
-        texp(ex, hi, E);
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-          dT[nb][i] = __builtin_amdgcn_ldexpf(tt[i], E[i]) * (1.f - xv[i] * xv[i]);
+        for (int kb = 0; kb < 4; ++kb) nx[nb] = mma3(L16.A(gA, tab + 4 * nb + kb), x[kb], nx[nb]);
         const f32x16 hf = to_feature_major(bx, ident);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -2783,11 +2785,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
     Op16 x1s[4];    // d_pre1, scaled per trajectory and split: all of fc1^T's parts
     const int ex1 = scaled_split64(d, x1s);
     Op16 ad[2][2];  // d_pre1^T with the workgroup's scale: all of fc1's weight blocks
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      add_bias(dT[mb], 3, mb);
-      split16(dT[mb], e1 - kPreD, ad[mb]);
-    }
+    transposed_operands(x1s, ex1, e1, 3, ad);
     // fc1's weight blocks of x block `xv` (scaled by 2^-fx), both row blocks
     const auto fc1_blocks = [&](const Op16 (&bx)[2], char *blk) {
 #pragma unroll
@@ -2802,8 +2800,8 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
         add_block(blk + mb * 4096, acc);
       }
     };
+    Op16 bfeat[2];   // the 15 feature planes + a row of ones (states_in's bias column)
     {
-      Op16 bfeat[2];   // the 15 feature planes + a row of ones (states_in's bias column)
       {
         TBlock tf;
         tf.load(Pfe, row < kNF ? vtN : kDead, wcolN);
@@ -2821,36 +2819,11 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
         Op16 bx[2];
         split16(xv, -kPreX, bx);
         fc1_blocks(bx, lane_blk + rg + 2 * nb * 4096);
-        f32x16 tt;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tt[i] = 0.f, e[nb][i] = 0.f;
+        for (int i = 0; i < 16; ++i) e[nb][i] = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          const Op16 w = L16.A(gA, a1s + 4 * nb + kb);
-          tt = mma3(x1s[kb], w, tt);
-          e[nb] = mma3(w, x1s[kb], e[nb]);
-        }
-        int E1[16];
-        texp(ex1, hi, E1);
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-          v[i] = __builtin_amdgcn_ldexpf(tt[i], E1[i]) * (1.f - xv[i] * xv[i]);   // d_pre_s^T
-        Op16 as[2];
-        split16(v, es - kPreD, as);
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) acc = mma3(as[kk], bfeat[kk], acc);
-        // 16 columns are real (15 features + the ones row): compact [reg][half][16],
-        // 2 KB of high limbs per block, the low limbs 4 KB further
-        if (row < 16) {
-          char *q = lds + rg + 4 * 4096 + nb * 2048 + (hi * 16 + row) * 4;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) lds_add2(q + i * 128, q + 4096 + i * 128, acc[i], kFix);
-        }
-        // feature-major d_pre_s (block nb of its rows)
+        for (int kb = 0; kb < 4; ++kb) e[nb] = mma3(L16.A(gA, a1s + 4 * nb + kb), x1s[kb], e[nb]);
+        // d_pre_s (block nb of its rows)
         const f32x16 hf = to_feature_major(bx, ident);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -2873,6 +2846,26 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_bwd_tm_kernel(ArTmArgs A
       for (int i = 0; i < 16; ++i) f[i] = 0.f;
       Op16 xs[4];
       const int exs = scaled_split64(e, xs);
+      {  // states_in's weight blocks: d_pre_s^T from the same split (no bias slot:
+         // its bias is the ones row of the feature block), unit 2^(es - kPreD)
+        Op16 as[2][2];
+        transposed_operands(xs, exs, es, -1, as);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          f32x16 acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) acc = mma3(as[nb][kk], bfeat[kk], acc);
+          // 16 columns are real (15 features + the ones row): compact [reg][half][16],
+          // 2 KB of high limbs per block, the low limbs 4 KB further
+          if (row < 16) {
+            char *q = lds + rg + 4 * 4096 + nb * 2048 + (hi * 16 + row) * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds_add2(q + i * 128, q + 4096 + i * 128, acc[i], kFix);
+          }
+        }
+      }
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) f = mma3(L16.A(gA, aS + kb), xs[kb], f);
       const Trig t = make_trig(&sc[3]);

@@ -71,6 +71,23 @@ def _restore_optimizer_state(optimizer, before):
                     del st[k]
 
 
+def _zero_state_is_fresh_state(optimizer):
+    """A capture's warm-up steps are undone by copying old state tensors back and
+    ZEROING the ones the warm-up created (`_restore_optimizer_state`): that equals
+    "never stepped" only where an optimizer's first step starts from zeros.  True
+    for the optimizers where it does - SGD without dampening (buf = grad either
+    way), Adam / AdamW / Adamax / RMSprop (zero moments, step 0); anything else
+    (SGD with dampening: its first step sets buf = grad, a zero buffer gives
+    (1 - dampening) grad; Adagrad's initial accumulator; NAdam's mu_product = 1;
+    unknown classes) steps eagerly - no warm-up, nothing to undo.  """
+    if optimizer is None:          # (no optimizer yet: nothing a warm-up could leave)
+        return True
+    if type(optimizer) is optim.SGD:
+        return all(not g.get("dampening") or not g.get("momentum")
+                   for g in optimizer.param_groups)
+    return type(optimizer) in (optim.Adam, optim.AdamW, optim.Adamax, optim.RMSprop)
+
+
 def _make_capturable(optimizer):
     """An optimizer whose step() is to be captured into a HIP graph must keep
     its step counters on the device (torch: `capturable=True`; Adam and its
@@ -486,13 +503,13 @@ class TrainBase:
         # the buffers or the settings the answer depends on have changed)
         tensors = F.mlp_param_objects(self.net)
         fast = (id(opt), id(opt.state), g["lr"], g["momentum"]) + tuple(map(id, tensors))
-        # (an LR scheduler asks whether the optimizer has stepped: it has,
-        # inside the kernel)
-        opt._opt_called = True
         hit = getattr(self, "_iku", None)
         if hit is not None and hit[0] == fast and all(
                 p.requires_grad and opt.state[p].get("momentum_buffer") is b
                 for p, b in zip(tensors, hit[1][2].values())):
+            # (an LR scheduler asks whether the optimizer has stepped: it has,
+            # inside the kernel - said only where the kernel really steps)
+            opt._opt_called = True
             return hit[1]
         self._iku = None
         named = dict(self.net.named_parameters())
@@ -510,6 +527,7 @@ class TrainBase:
         out = float(g["lr"]), float(g["momentum"]), bufs
         if len(tensors) == len(bufs):
             self._iku = (fast, out)
+        opt._opt_called = True
         return out
 
     def _step_direct(self, loss, named_grads, flat=None, stepped=False):
@@ -555,6 +573,10 @@ class TrainBase:
         # (a replayed graph runs no Python: step hooks would be skipped, and a
         # capture's warm-up steps would call them for steps that are undone)
         if self._step_hooks():
+            return False
+        # (the warm-up steps of a capture are undone by zeroing the state they
+        # created: only where zero state IS fresh state)
+        if not _zero_state_is_fresh_state(self.optimizer_controller):
             return False
         # (a step whose kernels outlast the host's launch work may run faster in
         # stream order: measured once, see launch_form)
@@ -641,6 +663,7 @@ class TrainBase:
         if stale:
             if torch.cuda.is_available() and _make_capturable(self.optimizer_controller):
                 sig = self._graph_signature(inputs, volatile)
+            failed = None
             try:
                 g = _GraphedStep(
                     part_a, part_b, self._reduce, sig,
@@ -648,15 +671,21 @@ class TrainBase:
                     self.optimizer_controller,
                     capture=torch.cuda.is_available(), split=self._reducing())
             except RuntimeError as e:
-                # a capture that the runtime refuses must not end the run: this
-                # trainer steps eagerly from here on (the warm-up steps have
-                # been undone, the failed capture trained nothing)
+                failed = e
+            # a capture that the runtime refuses must not end the run: the trainer
+            # steps eagerly from here on (the warm-up steps have been undone, the
+            # failed capture trained nothing) - on EVERY rank when it failed on
+            # one: the others would otherwise enter the launch-form measurement's
+            # collectives alone
+            if parallel.any_rank(failed is not None):
                 import warnings
-                warnings.warn(f"graph capture of the {key} step failed ({e}); "
+                warnings.warn(f"graph capture of the {key} step failed "
+                              f"({failed if failed is not None else 'on another rank'}); "
                               "graph_steps switched off for this trainer")
                 self.graph_steps = False
                 self._graphs.clear()
-                torch.cuda.synchronize()
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 msg = part_a()
                 self._reduce(msg)
                 return part_b(msg)
@@ -685,6 +714,15 @@ class TrainBase:
         params = list(self.net.parameters())
         saved = [p.detach().clone() for p in params]
         state = _snapshot_optimizer_state(opt)
+        # the timing steps' other side effects: the device generator
+        # the LSTM's hidden-state draws consume, a dedicated hidden-state generator,
+        # the running loss sums of step plans
+        dev = params[0].device
+        rng = torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None
+        hgen = getattr(self, "hidden_generator", None)
+        hstate = hgen.get_state() if isinstance(hgen, torch.Generator) else None
+        sums = [(pl.plan.running, pl.plan.running.clone(), pl.plan, pl.plan.launches)
+                for pl in self._graphs.values() if getattr(pl, "planned", False)]
 
         def eager():
             msg = part_a()
@@ -707,6 +745,13 @@ class TrainBase:
                 for p, v in zip(params, saved):
                     p.copy_(v)
                 _restore_optimizer_state(opt, state)
+                for running, was, plan, launches in sums:
+                    running.copy_(was)
+                    plan.launches = launches
+            if rng is not None:
+                torch.cuda.set_rng_state(rng, dev)
+            if hstate is not None:
+                hgen.set_state(hstate)
         if parallel.world_size() > 1:
             both = torch.tensor([t_graph, t_eager], dtype=torch.float64,
                                 device=params[0].device)

@@ -237,8 +237,13 @@ class TrainDrone(TrainBase):
     def _rows_ok(normed, states, in_ref, ref, index):
         ok = lambda t: (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
                         and t.numel() * 4 < (1 << 32) - 64)
+        # (every shape the rows plan insists on: a mismatch falls back to the
+        # gather path instead of raising from the plan - ADVICE r5)
+        N = states.shape[0] if states.dim() == 2 else -1
         return (all(ok(t) for t in (normed, states, in_ref, ref))
                 and index.is_cuda and index.dtype == torch.int64 and index.is_contiguous()
+                and states.dim() == 2 and states.shape[1] == 12
+                and normed.shape[0] == N and in_ref.shape[0] == N and ref.shape[0] == N
                 and normed.dim() == 2 and normed.shape[1] == 15 and in_ref.dim() == 3
                 and in_ref.shape[1] >= 10 and in_ref.shape[2] == 9 and ref.dim() == 3
                 and ref.shape[1] >= 10 and ref.shape[2] in (9, 6))
@@ -307,6 +312,12 @@ class TrainDrone(TrainBase):
             # the index - the plan takes its address per launch
             B = index.numel()
             src = (in_state, current_state, in_ref_states, ref_states)
+            # the kernel reads THESE tensors' rows: the operand range of the
+            # in-kernel policy is checked on them (cached by in-place version:
+            # nothing per step) - a direct call with an index gets the check the
+            # gather path's entry points make
+            F._guard_policy_inputs("fused concurrent step (rows)", normed=in_state,
+                                   in_ref=in_ref_states)
             return self._planned(
                 ("concurrent", B, "rows"), src,
                 lambda: _PlannedStep(F.QuadConcurrentStepPlan(

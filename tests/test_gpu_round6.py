@@ -140,9 +140,10 @@ def test_resident_tables_after_a_write_through_data_need_invalidate(dev):
     """a parameter written through `p.data` bumps a version counter
     the step plan cannot see - its resident operand tables would stay stale.
     `plan.invalidate()` (TrainBase.run_epoch calls it for every plan at the start
-    of an epoch) makes the next launch pack again; a moved storage
-    (`p.data = other`) is seen by itself (the address is part of the key).  Both
-    against a plan that packs at every step: bit for bit."""
+    of an epoch) makes the next launch pack again.  Against a plan that packs at
+    every step: bit for bit.  (A REPLACED storage, `p.data = other`, is outside a
+    plan's contract - its argument structs hold the parameters' addresses;
+    TrainBase's step signature carries them and rebuilds the plan.)"""
     from apg_trajectory_tracking_amd import functional as F, synthetic
     from apg_trajectory_tracking_amd.dataset import state_preprocessing
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
@@ -167,8 +168,9 @@ def test_resident_tables_after_a_write_through_data_need_invalidate(dev):
             if i == 2:          # weight clipping behind autograd's back
                 net.fc2.weight.data.clamp_(-0.05, 0.05)
                 plan.invalidate()
-            if i == 4:          # the storage is replaced
-                net.fc3.bias.data = net.fc3.bias.data.clone() * 0.5
+            if i == 4:          # ... and a soft update, again through .data
+                net.fc3.bias.data.mul_(0.5)
+                plan.invalidate()
             losses.append(float(plan.launch()))
             flags.append(plan._keep["upd"].resident)
         if resident:

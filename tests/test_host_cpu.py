@@ -1065,3 +1065,31 @@ def test_three_term_bf16_split_and_six_products_reach_fp32_rounding():
     two = sum(ta[i].astype(np.float64) * tb[j].astype(np.float64)
               for i, j in ((1, 0), (0, 1), (0, 0)))
     assert (np.abs(two - exact) / np.abs(exact)).max() > 2.0 ** -18
+
+
+def test_graph_capture_only_where_zero_state_is_fresh_state():
+    """a capture's warm-up steps are undone by ZEROING the optimizer
+    state they created - equal to "never stepped" for SGD without dampening and
+    the Adam family, not for SGD with dampening (first step: buf = grad) or for
+    optimizers this code does not know: those step eagerly."""
+    from apg_trajectory_tracking_amd.train_base import _zero_state_is_fresh_state as ok
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    assert ok(None)
+    assert ok(torch.optim.SGD(p, lr=0.1, momentum=0.9))
+    assert ok(torch.optim.SGD(p, lr=0.1, momentum=0.0, dampening=0.5))
+    assert not ok(torch.optim.SGD(p, lr=0.1, momentum=0.9, dampening=0.5))
+    assert ok(torch.optim.Adam(p)) and ok(torch.optim.AdamW(p)) and ok(torch.optim.RMSprop(p))
+    assert not ok(torch.optim.Adagrad(p, initial_accumulator_value=0.1))
+    assert not ok(torch.optim.NAdam(p))
+    # the claim itself, for the allow-listed SGD: zeroed buffer == no buffer
+    for damp, same in ((0.0, True), (0.5, False)):
+        outs = []
+        for zeroed in (False, True):
+            q = torch.nn.Parameter(torch.ones(3))
+            o = torch.optim.SGD([q], lr=0.1, momentum=0.9, dampening=damp)
+            if zeroed:
+                o.state[q]["momentum_buffer"] = torch.zeros(3)
+            q.grad = torch.full((3,), 2.0)
+            o.step()
+            outs.append(q.detach().clone())
+        assert torch.equal(*outs) == same
