@@ -74,6 +74,21 @@ class ApgLstmPolicy(ctypes.Structure):
         "conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")]
 
 
+class ApgLstmPolicyGrads(ctypes.Structure):
+    _fields_ = ApgLstmPolicy._fields_
+
+
+class ApgLstmStepTail(ctypes.Structure):
+    """include/apg.h: what apg_quad_lstm_step_tail does after the products."""
+    _fields_ = [("grad", ApgLstmPolicyGrads), ("ih_hh", ctypes.c_void_p),
+                ("conv_pos", ctypes.c_void_p), ("update", ctypes.c_int),
+                ("lr", ctypes.c_double), ("momentum", ctypes.c_double),
+                ("param", ApgLstmPolicyGrads), ("mom", ApgLstmPolicyGrads),
+                ("tables_fwd", ctypes.c_void_p), ("tables_bwd", ctypes.c_void_p),
+                ("loss_partials", ctypes.c_void_p), ("n_partials", ctypes.c_int),
+                ("loss", ctypes.c_void_p), ("loss_sum", ctypes.c_void_p)]
+
+
 class ApgMlpPolicy(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2",
@@ -170,6 +185,16 @@ SIGNATURES = {
         _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgLstmPolicy),
         _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_tables_floats": [_I],
+    "apg_quad_lstm_pack_tables": [ctypes.POINTER(ApgLstmPolicy), _P, _P, _P],
+    "apg_quad_lstm_rollout_fwd_packed": [
+        _P, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams), _P, _I, _I,
+        _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_rollout_bwd_packed": [
+        _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgQuadLossWeights), _P,
+        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_step_tail": [ctypes.POINTER(ApgLstmStepTail), _P],
     "apg_quad_mlp_rollout_fwd": [
         _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgMlpPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],

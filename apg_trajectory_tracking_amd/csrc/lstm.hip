@@ -104,8 +104,7 @@ __device__ __forceinline__ float fwd16_weight(const ApgLstmPolicy &p, int n, int
   return ch < kNC ? p.w_ih[row * kNX + kNF + ch * kNP + pos] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void lstm_pack_fwd16_kernel(PackArgs A) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+__device__ __forceinline__ void pack_fwd16(const PackArgs &A, int tid, int T) {
   const ApgLstmPolicy &p = A.pol;
   unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
   for (int idx = tid; idx < nBlocks16 * 64 * 4; idx += T) {
@@ -124,6 +123,9 @@ __global__ __launch_bounds__(256) void lstm_pack_fwd16_kernel(PackArgs A) {
     A.dst[hTbc + idx] = row < kNC ? p.conv_b[row] : 0.f;
   }
   for (int idx = tid; idx < 4; idx += T) A.dst[hBo + idx] = p.b_out[idx];
+}
+__global__ __launch_bounds__(256) void lstm_pack_fwd16_kernel(PackArgs A) {
+  pack_fwd16(A, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 struct FwdArgs {
@@ -529,8 +531,7 @@ __device__ __forceinline__ float bwd16_weight(const ApgLstmPolicy &p, int n, int
   return p.w_ih[k * kNX + kNF + ((n - mC) >> 1) * 32 + row];
 }
 
-__global__ __launch_bounds__(256) void lstm_pack_bwd16_kernel(PackArgs A) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+__device__ __forceinline__ void pack_bwd16(const PackArgs &A, int tid, int T) {
   const ApgLstmPolicy &p = A.pol;
   unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
   for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
@@ -549,6 +550,92 @@ __global__ __launch_bounds__(256) void lstm_pack_bwd16_kernel(PackArgs A) {
     const int ch = idx / 3, q = idx % 3;
     A.dst[gAq + idx] = p.conv_w[ch * 27 + q * 3] + p.conv_w[ch * 27 + q * 3 + 1] +
                        p.conv_w[ch * 27 + q * 3 + 2];
+  }
+}
+__global__ __launch_bounds__(256) void lstm_pack_bwd16_kernel(PackArgs A) {
+  pack_bwd16(A, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+// both table sets in one launch (the first blocks the forward tables)
+__global__ __launch_bounds__(256) void lstm_pack_both_kernel(PackArgs F, PackArgs R, int fwd_blocks) {
+  if ((int)blockIdx.x < fwd_blocks)
+    pack_fwd16(F, blockIdx.x * blockDim.x + threadIdx.x, fwd_blocks * blockDim.x);
+  else
+    pack_bwd16(R, (blockIdx.x - fwd_blocks) * blockDim.x + threadIdx.x,
+               (gridDim.x - fwd_blocks) * blockDim.x);
+}
+
+// ------------------------------------------------------------ the step's tail
+// Round 6: what followed the weight-gradient products of an
+// LSTM training step as SIX launches - conv_ref.weight -= the position part, the
+// two copies out of [dW_ih | dW_hh], torch's fused SGD, the loss reduction, and at
+// the head of the next step the two table packs - is ONE workgroup here (6 516
+// parameters): gradients into their tensors, momentum SGD with torch's rounding
+// (scripts/train_base.py:130-150: optim.SGD(lr, momentum = 0.9)), the operand
+// tables of the NEXT step's sweeps from the updated parameters, the loss.
+struct TailArgs {
+  ApgLstmStepTail t;
+};
+constexpr int kTailThreads = 1024;
+__global__ __launch_bounds__(kTailThreads) void lstm_step_tail_kernel(TailArgs A) {
+  const ApgLstmStepTail &t = A.t;
+  const int tid = threadIdx.x;
+  // parameter e of tensor q: gradient source, destination, parameter, momentum
+  const int sizes[8] = {kNC * 27, kNC, kNG * kNX, kNG * kNH, kNG, kNG, 4 * kNH, 4};
+  float *const par[8] = {t.param.conv_w, t.param.conv_b, t.param.w_ih, t.param.w_hh,
+                         t.param.b_ih,   t.param.b_hh,   t.param.w_out, t.param.b_out};
+  float *const mom[8] = {t.mom.conv_w, t.mom.conv_b, t.mom.w_ih, t.mom.w_hh,
+                         t.mom.b_ih,   t.mom.b_hh,   t.mom.w_out, t.mom.b_out};
+  float *const grd[8] = {t.grad.conv_w, t.grad.conv_b, t.grad.w_ih, t.grad.w_hh,
+                         t.grad.b_ih,   t.grad.b_hh,   t.grad.w_out, t.grad.b_out};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    for (int e = tid; e < sizes[q]; e += kTailThreads) {
+      float g;
+      if (q == 0) {          // conv_ref.weight [20][9][3]: windows - (c < 3) positions
+        const int ch = e / 27, c = (e % 27) / 3;
+        g = grd[0][e] - (c < 3 ? t.conv_pos[ch * 3 + c] : 0.f);
+      } else if (q == 2) {   // lstm.weight_ih out of [dW_ih | dW_hh] [32][183]
+        g = t.ih_hh[(e / kNX) * (kNX + kNH) + e % kNX];
+      } else if (q == 3) {
+        g = t.ih_hh[(e / kNH) * (kNX + kNH) + kNX + e % kNH];
+      } else if (q == 5) {   // lstm.bias_hh: the same sums as bias_ih
+        g = grd[4][e];
+      } else {
+        g = grd[q][e];
+      }
+      if (q == 0 || q == 2 || q == 3 || (q == 5 && grd[5] != grd[4])) grd[q][e] = g;
+      if (t.update) {        // torch.optim.SGD in double, one rounding each (mlp.hip)
+        const float buf = (float)(t.momentum * (double)mom[q][e] + (double)g);
+        mom[q][e] = buf;
+        par[q][e] = (float)((double)par[q][e] - t.lr * (double)buf);
+      }
+    }
+  }
+  if (t.loss) {              // fixed-shape sum of the loss partials
+    __shared__ double sm[kTailThreads / 64];
+    double acc = 0.0;
+    for (int k = tid; k < t.n_partials; k += kTailThreads) acc += (double)t.loss_partials[k];
+#pragma unroll
+    for (int s_ = 32; s_ >= 1; s_ >>= 1) acc += __shfl_xor(acc, s_, 64);
+    if ((tid & 63) == 0) sm[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < kTailThreads / 64; ++w) tot += sm[w];
+      *t.loss = (float)tot;
+      if (t.loss_sum) *t.loss_sum += (float)tot;
+    }
+  }
+  if (t.tables_fwd && t.tables_bwd) {
+    __threadfence_block();
+    __syncthreads();         // every parameter of this step is written
+    PackArgs P;
+    P.pol.conv_w = par[0], P.pol.conv_b = par[1], P.pol.w_ih = par[2], P.pol.w_hh = par[3];
+    P.pol.b_ih = par[4], P.pol.b_hh = par[5], P.pol.w_out = par[6], P.pol.b_out = par[7];
+    P.dst = t.tables_fwd;
+    pack_fwd16(P, tid, kTailThreads);
+    P.dst = t.tables_bwd;
+    pack_bwd16(P, tid, kTailThreads);
   }
 }
 
@@ -780,8 +867,10 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
   write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
 }
 
-int check_lstm(const ApgQuadParams *params, const ApgLstmPolicy *pol, int B, int H) {
-  if (!params || !pol) { set_error("params / policy is NULL"); return APG_ERR_ARG; }
+// pol NULL: the caller holds packed tables instead of the parameters
+int check_lstm(const ApgQuadParams *params, const ApgLstmPolicy *pol, int B, int H,
+               bool packed = false) {
+  if (!params || (!pol && !packed)) { set_error("params / policy is NULL"); return APG_ERR_ARG; }
   if (B < 0) { set_error("B must be >= 0 (got %d)", B); return APG_ERR_ARG; }
   if ((long long)B * kH * 4 * kNX >= (1ll << 32) - 64) {
     set_error("B too large for 32-bit plane offsets (max %d); split the batch",
@@ -792,8 +881,8 @@ int check_lstm(const ApgQuadParams *params, const ApgLstmPolicy *pol, int B, int
     set_error("the fused LSTM rollout is built for horizon %d (got %d)", kH, H);
     return APG_ERR_ARG;
   }
-  if (!pol->conv_w || !pol->conv_b || !pol->w_ih || !pol->w_hh || !pol->b_ih ||
-      !pol->b_hh || !pol->w_out || !pol->b_out) {
+  if (pol && (!pol->conv_w || !pol->conv_b || !pol->w_ih || !pol->w_hh || !pol->b_ih ||
+              !pol->b_hh || !pol->w_out || !pol->b_out)) {
     set_error("policy weight pointer is NULL");
     return APG_ERR_ARG;
   }
@@ -816,15 +905,14 @@ int apg_quad_lstm_loss_partials_count(int B) {
   return B <= 0 ? 0 : ((B + kTrajPerBlock - 1) / kTrajPerBlock) * (kThreads / kWave);
 }
 
-int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
-                              const float *h0, const float *c0, float dt,
-                              const ApgQuadParams *params,
-                              const ApgLstmPolicy *policy, int B, int H,
-                              float *states, float *actions, float *x,
-                              float *gates, float *hc, float *hnew,
-                              unsigned *relu_mask, float *workspace,
-                              apg_stream_t stream) {
-  if (int e = check_lstm(params, policy, B, H)) return e;
+// `policy` given: its tables are packed into `workspace` first; NULL: `workspace`
+// holds them already (apg_quad_lstm_pack_tables / apg_quad_lstm_step_tail)
+static int lstm_fwd(const float *state0, const float *in_ref, const float *h0,
+                    const float *c0, float dt, const ApgQuadParams *params,
+                    const ApgLstmPolicy *policy, int B, int H, float *states,
+                    float *actions, float *x, float *gates, float *hc, float *hnew,
+                    unsigned *relu_mask, float *workspace, apg_stream_t stream) {
+  if (int e = check_lstm(params, policy, B, H, true)) return e;
   if (B == 0) return APG_OK;
   if (!state0 || !in_ref || !h0 || !c0 || !states || !actions || !x || !gates ||
       !hc || !hnew || !relu_mask || !workspace) {
@@ -839,29 +927,51 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
   A.tables = workspace;
   A.c = make_const(*params, dt);
   A.B = B;
-  PackArgs P;
-  P.pol = *policy, P.dst = workspace;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256),
-                     0, st, P);
+  if (policy) {
+    PackArgs P;
+    P.pol = *policy, P.dst = workspace;
+    hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256),
+                       0, st, P);
+  }
   hipLaunchKernelGGL(lstm_rollout_fwd_kernel,
                      dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
                      kFwd16Lds * sizeof(float), st, A);
   return check_launch("quad_lstm_rollout_fwd");
 }
 
-int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
-                              const float *actions, const float *ref,
-                              int ref_cols, const unsigned *relu_mask,
-                              const float *gates, const float *hc, float dt,
+int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
+                              const float *h0, const float *c0, float dt,
                               const ApgQuadParams *params,
-                              const ApgQuadLossWeights *weights,
                               const ApgLstmPolicy *policy, int B, int H,
-                              float *loss_partials, float *loss, float *d_gates,
-                              float *d_zout, float *d_conv, float *grad_state0,
-                              float *grad_h0, float *grad_c0, float *workspace,
+                              float *states, float *actions, float *x,
+                              float *gates, float *hc, float *hnew,
+                              unsigned *relu_mask, float *workspace,
                               apg_stream_t stream) {
-  if (int e = check_lstm(params, policy, B, H)) return e;
+  if (!policy) { set_error("policy is NULL"); return APG_ERR_ARG; }
+  return lstm_fwd(state0, in_ref, h0, c0, dt, params, policy, B, H, states, actions, x, gates,
+                  hc, hnew, relu_mask, workspace, stream);
+}
+
+int apg_quad_lstm_rollout_fwd_packed(const float *state0, const float *in_ref,
+                                     const float *h0, const float *c0, float dt,
+                                     const ApgQuadParams *params, const float *tables_fwd,
+                                     int B, int H, float *states, float *actions, float *x,
+                                     float *gates, float *hc, float *hnew,
+                                     unsigned *relu_mask, apg_stream_t stream) {
+  return lstm_fwd(state0, in_ref, h0, c0, dt, params, nullptr, B, H, states, actions, x, gates,
+                  hc, hnew, relu_mask, const_cast<float *>(tables_fwd), stream);
+}
+
+static int lstm_bwd(const float *state0, const float *states, const float *actions,
+                    const float *ref, int ref_cols, const unsigned *relu_mask,
+                    const float *gates, const float *hc, float dt,
+                    const ApgQuadParams *params, const ApgQuadLossWeights *weights,
+                    const ApgLstmPolicy *policy, int B, int H, float *loss_partials,
+                    float *loss, float *d_gates, float *d_zout, float *d_conv,
+                    float *grad_state0, float *grad_h0, float *grad_c0, float *workspace,
+                    apg_stream_t stream) {
+  if (int e = check_lstm(params, policy, B, H, true)) return e;
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
   if (ref_cols != 9 && ref_cols != 6) {
     set_error("ref_cols must be 9 or 6");
@@ -888,10 +998,12 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
   A.c = make_const(*params, dt);
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
-  PackArgs P;
-  P.pol = *policy, P.dst = workspace;
-  hipLaunchKernelGGL(lstm_pack_bwd16_kernel, dim3((kBwd16Lds + 255) / 256), dim3(256),
-                     0, st, P);
+  if (policy) {
+    PackArgs P;
+    P.pol = *policy, P.dst = workspace;
+    hipLaunchKernelGGL(lstm_pack_bwd16_kernel, dim3((kBwd16Lds + 255) / 256), dim3(256),
+                       0, st, P);
+  }
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
   hipLaunchKernelGGL(lstm_rollout_bwd_kernel, dim3(blocks), dim3(kThreads),
                      kBwd16Lds * sizeof(float), st, A);
@@ -899,6 +1011,94 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
   if (loss)
     return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave), loss, st);
   return APG_OK;
+}
+
+int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
+                              const float *actions, const float *ref,
+                              int ref_cols, const unsigned *relu_mask,
+                              const float *gates, const float *hc, float dt,
+                              const ApgQuadParams *params,
+                              const ApgQuadLossWeights *weights,
+                              const ApgLstmPolicy *policy, int B, int H,
+                              float *loss_partials, float *loss, float *d_gates,
+                              float *d_zout, float *d_conv, float *grad_state0,
+                              float *grad_h0, float *grad_c0, float *workspace,
+                              apg_stream_t stream) {
+  if (!policy) { set_error("policy is NULL"); return APG_ERR_ARG; }
+  return lstm_bwd(state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt, params,
+                  weights, policy, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
+                  grad_state0, grad_h0, grad_c0, workspace, stream);
+}
+
+int apg_quad_lstm_rollout_bwd_packed(const float *state0, const float *states,
+                                     const float *actions, const float *ref, int ref_cols,
+                                     const unsigned *relu_mask, const float *gates,
+                                     const float *hc, float dt, const ApgQuadParams *params,
+                                     const ApgQuadLossWeights *weights,
+                                     const float *tables_bwd, int B, int H,
+                                     float *loss_partials, float *loss, float *d_gates,
+                                     float *d_zout, float *d_conv, float *grad_state0,
+                                     float *grad_h0, float *grad_c0, apg_stream_t stream) {
+  return lstm_bwd(state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt, params,
+                  weights, nullptr, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
+                  grad_state0, grad_h0, grad_c0, const_cast<float *>(tables_bwd), stream);
+}
+
+int apg_quad_lstm_tables_floats(int reverse) { return reverse ? kBwd16Lds : kFwd16Lds; }
+
+int apg_quad_lstm_pack_tables(const ApgLstmPolicy *policy, float *tables_fwd,
+                              float *tables_bwd, apg_stream_t stream) {
+  if (!policy || !tables_fwd || !tables_bwd) {
+    set_error("apg_quad_lstm_pack_tables: NULL argument");
+    return APG_ERR_ARG;
+  }
+  if (!policy->conv_w || !policy->conv_b || !policy->w_ih || !policy->w_hh || !policy->b_ih ||
+      !policy->b_hh || !policy->w_out || !policy->b_out) {
+    set_error("policy weight pointer is NULL");
+    return APG_ERR_ARG;
+  }
+  PackArgs F, R;
+  F.pol = *policy, F.dst = tables_fwd;
+  R.pol = *policy, R.dst = tables_bwd;
+  const int fb = (kFwd16Lds + 255) / 256, rb = (kBwd16Lds + 255) / 256;
+  hipLaunchKernelGGL(lstm_pack_both_kernel, dim3(fb + rb), dim3(256), 0, (hipStream_t)stream, F,
+                     R, fb);
+  return check_launch("quad_lstm_pack_tables");
+}
+
+int apg_quad_lstm_step_tail(const ApgLstmStepTail *tail, apg_stream_t stream) {
+  if (!tail) { set_error("apg_quad_lstm_step_tail: tail is NULL"); return APG_ERR_ARG; }
+  const ApgLstmStepTail &t = *tail;
+  const float *const need[] = {t.grad.conv_w, t.grad.conv_b, t.grad.w_ih, t.grad.w_hh,
+                               t.grad.b_ih, t.grad.b_hh, t.grad.w_out, t.grad.b_out,
+                               t.ih_hh, t.conv_pos};
+  for (const float *q : need)
+    if (!q) { set_error("apg_quad_lstm_step_tail: NULL gradient buffer"); return APG_ERR_ARG; }
+  if (t.update || t.tables_fwd || t.tables_bwd) {
+    const float *const pm[] = {t.param.conv_w, t.param.conv_b, t.param.w_ih, t.param.w_hh,
+                               t.param.b_ih, t.param.b_hh, t.param.w_out, t.param.b_out};
+    for (const float *q : pm)
+      if (!q) { set_error("apg_quad_lstm_step_tail: NULL parameter"); return APG_ERR_ARG; }
+  }
+  if (t.update) {
+    const float *const pm[] = {t.mom.conv_w, t.mom.conv_b, t.mom.w_ih, t.mom.w_hh,
+                               t.mom.b_ih, t.mom.b_hh, t.mom.w_out, t.mom.b_out};
+    for (const float *q : pm)
+      if (!q) { set_error("apg_quad_lstm_step_tail: NULL momentum buffer"); return APG_ERR_ARG; }
+  }
+  if ((t.tables_fwd == nullptr) != (t.tables_bwd == nullptr)) {
+    set_error("apg_quad_lstm_step_tail: both table sets or none");
+    return APG_ERR_ARG;
+  }
+  if (t.loss && (!t.loss_partials || t.n_partials < 0)) {
+    set_error("apg_quad_lstm_step_tail: loss without partials");
+    return APG_ERR_ARG;
+  }
+  TailArgs A;
+  A.t = t;
+  hipLaunchKernelGGL(lstm_step_tail_kernel, dim3(1), dim3(kTailThreads), 0, (hipStream_t)stream,
+                     A);
+  return check_launch("quad_lstm_step_tail");
 }
 
 int apg_quad_lstm_closed_loop(const float *traj, int L, const float *h0,

@@ -1172,12 +1172,23 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         gates = new(32, N)
         relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
         st = stream_of(s0)
-        ws = new(lib().apg_quad_lstm_workspace_floats())
-        check(lib().apg_quad_lstm_rollout_fwd(
-            ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
-            ctypes.byref(params), ctypes.byref(pol), B, H, ptr(states),
-            ptr(actions), ptr(x), ptr(gates), ptr(hc), ptr(hnew),
-            relu_mask.data_ptr(), ptr(ws), st), "apg_quad_lstm_rollout_fwd")
+        # resident operand tables (round 6, the trainers' step): packed once, kept
+        # current by the step's tail - the sweeps launch nothing but themselves
+        tables = getattr(ctx, "lstm_tables", None)
+        if tables is not None:
+            tables.ensure(list(pw.values()), pol, st)
+            check(lib().apg_quad_lstm_rollout_fwd_packed(
+                ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
+                ctypes.byref(params), ptr(tables.fwd), B, H, ptr(states),
+                ptr(actions), ptr(x), ptr(gates), ptr(hc), ptr(hnew),
+                relu_mask.data_ptr(), st), "apg_quad_lstm_rollout_fwd_packed")
+        else:
+            ws = new(lib().apg_quad_lstm_workspace_floats())
+            check(lib().apg_quad_lstm_rollout_fwd(
+                ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
+                ctypes.byref(params), ctypes.byref(pol), B, H, ptr(states),
+                ptr(actions), ptr(x), ptr(gates), ptr(hc), ptr(hnew),
+                relu_mask.data_ptr(), ptr(ws), st), "apg_quad_lstm_rollout_fwd")
         partials = new(max(1, lib().apg_quad_lstm_loss_partials_count(B)))
         loss = new(1)
         d_gates, d_zout, d_conv = new(32, N), new(4, N), new(_CONV_DIAG_PLANES, B)
@@ -1185,13 +1196,23 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
         g_h0 = new(8, B) if ctx.needs_input_grad[3] else None
         g_c0 = new(8, B) if ctx.needs_input_grad[4] else None
-        check(lib().apg_quad_lstm_rollout_bwd(
-            ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1],
-            relu_mask.data_ptr(), ptr(gates), ptr(hc), float(dt),
-            ctypes.byref(params),
-            ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
-            ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), ptr(g_s0),
-            ptr(g_h0), ptr(g_c0), ptr(ws), st), "apg_quad_lstm_rollout_bwd")
+        if tables is not None:
+            # (loss = NULL: the step's tail sums the partials)
+            check(lib().apg_quad_lstm_rollout_bwd_packed(
+                ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1],
+                relu_mask.data_ptr(), ptr(gates), ptr(hc), float(dt),
+                ctypes.byref(params), ctypes.byref(weights), ptr(tables.bwd), B, H,
+                ptr(partials), None, ptr(d_gates), ptr(d_zout), ptr(d_conv), ptr(g_s0),
+                ptr(g_h0), ptr(g_c0), st), "apg_quad_lstm_rollout_bwd_packed")
+            ctx.lstm_tail = (partials, loss, pw)
+        else:
+            check(lib().apg_quad_lstm_rollout_bwd(
+                ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1],
+                relu_mask.data_ptr(), ptr(gates), ptr(hc), float(dt),
+                ctypes.byref(params),
+                ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
+                ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), ptr(g_s0),
+                ptr(g_h0), ptr(g_c0), ptr(ws), st), "apg_quad_lstm_rollout_bwd")
         ctx.save_for_backward(refbuf, acts, d_gates, d_zout, d_conv)
         ctx.input_grads = (g_s0, g_h0, g_c0)
         ctx.mark_non_differentiable(states, actions)
@@ -1209,10 +1230,68 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         return (g_s0, None, None, g_h0, g_c0, *grads, None, None, None)
 
 
-def _lstm_param_grads(saved, dims):
+class LstmResidentTables:
+    """The operand tables of the two LSTM sweeps (csrc/lstm.hip: fp16-split
+    A-operand blocks + small fp32 tables, 33 + 29 KB) in buffers that outlive the
+    step: packed by ONE launch when the parameters are not the ones the tables
+    were made from (in-place version counter and storage address of the eight
+    tensors), refreshed by apg_quad_lstm_step_tail after its update.  A write
+    through `p.data` is not seen: `invalidate()` (TrainBase.run_epoch calls it at
+    the start of every epoch), as for the concurrent step's plan."""
+
+    def __init__(self, dev):
+        n = lib().apg_quad_lstm_tables_floats
+        self.fwd = torch.empty(n(0), dtype=torch.float32, device=dev)
+        self.bwd = torch.empty(n(1), dtype=torch.float32, device=dev)
+        self.key = None
+        self.packs = 0
+
+    @staticmethod
+    def _key(tensors):
+        return [(t._version, t.data_ptr()) for t in tensors]
+
+    def ensure(self, tensors, pol, st):
+        key = self._key(tensors)
+        # (a replayed graph runs no Python: a captured step always packs)
+        if key != self.key or torch.cuda.is_current_stream_capturing():
+            check(lib().apg_quad_lstm_pack_tables(ctypes.byref(pol), ptr(self.fwd),
+                                                  ptr(self.bwd), st),
+                  "apg_quad_lstm_pack_tables")
+            self.packs += 1
+            self.key = key
+
+    def refreshed(self, tensors):
+        """The tail has packed the tables from `tensors` as they are now."""
+        self.key = self._key(tensors)
+
+    def invalidate(self):
+        self.key = None
+
+
+_LSTM_TABLES = None
+
+
+def lstm_resident_tables(net, dev):
+    """The LstmResidentTables of `net` (made on first use)."""
+    global _LSTM_TABLES
+    if _LSTM_TABLES is None:
+        import weakref
+        _LSTM_TABLES = weakref.WeakKeyDictionary()
+    ent = _LSTM_TABLES.get(net)
+    if ent is None or ent.fwd.device != dev:
+        ent = _LSTM_TABLES[net] = LstmResidentTables(dev)
+    return ent
+
+
+def _lstm_param_grads(saved, dims, tail=None):
     """Weight gradients of the fused LSTM unroll from the saved planes: three
     matrix-core products; every gradient is a contiguous view of one flat
-    buffer (returned first), keyed by LSTM_NEW parameter name."""
+    buffer (returned first), keyed by LSTM_NEW parameter name.
+    tail = (partials, loss, {C name: parameter}, tables, update): what follows
+    the products is ONE launch (apg_quad_lstm_step_tail: gradients into place,
+    momentum SGD if `update` = (lr, momentum, {parameter name: buffer}), the next
+    step's tables, the loss) instead of three elementwise launches, the
+    optimizer's, the loss reduction and two table packs."""
     refbuf, acts, d_gates, d_zout, d_conv = saved
     B, H = dims
     dev = acts.device
@@ -1230,11 +1309,33 @@ def _lstm_param_grads(saved, dims):
              out=ih_hh, bias_out=gr["lstm.bias_ih"]),
         dict(A=d_zout, M=4, S=1, Bp=acts, bdesc=make_bdesc(dev, range(191, 199), key="out"),
              out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])] + conv)
-    finish()
-    # contiguous per-parameter gradients (the fused optimizer path wants them)
-    gr["lstm.weight_ih"].copy_(ih_hh[:, :175])
-    gr["lstm.weight_hh"].copy_(ih_hh[:, 175:])
     gr["lstm.bias_hh"] = gr["lstm.bias_ih"]
+    if tail is None:
+        finish()
+        # contiguous per-parameter gradients (the fused optimizer path wants them)
+        gr["lstm.weight_ih"].copy_(ih_hh[:, :175])
+        gr["lstm.weight_hh"].copy_(ih_hh[:, 175:])
+        return flat, gr
+    partials, loss, pw, tables, update = tail
+    G = _capi.ApgLstmPolicyGrads
+    names = dict(zip(("conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out"),
+                     _LSTM_PARAMS))
+    t = _capi.ApgLstmStepTail(
+        grad=G(**{c: ptr(gr[n]) for c, n in names.items()}),
+        ih_hh=ptr(ih_hh), conv_pos=ptr(conv[1]["out"]), update=int(update is not None),
+        param=G(**{c: ptr(pw[c]) for c in names}),
+        tables_fwd=ptr(tables.fwd), tables_bwd=ptr(tables.bwd),
+        loss_partials=ptr(partials), n_partials=partials.numel(), loss=ptr(loss))
+    if update is not None:
+        lr, momentum, bufs = update
+        t.lr, t.momentum = float(lr), float(momentum)
+        t.mom = G(**{c: ptr(bufs[n]) for c, n in names.items()})
+    check(lib().apg_quad_lstm_step_tail(ctypes.byref(t), stream_of(acts)),
+          "apg_quad_lstm_step_tail")
+    params8 = [pw[c] for c in names]
+    if update is not None and not torch.cuda.is_current_stream_capturing():
+        note_in_kernel_update(params8 + [bufs[n] for n in names.values()])
+    tables.refreshed(params8)
     return flat, gr
 
 
@@ -2112,18 +2213,32 @@ _LSTM_PARAMS = ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
 
 def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
                             weights=None, index=None, static_inputs=False,
-                            prepared=None):
-    """quad_lstm_rollout_loss + parameter gradients, without autograd."""
+                            prepared=None, update=None, resident_tables=True):
+    """quad_lstm_rollout_loss + parameter gradients, without autograd.
+    resident_tables (round 6): the sweeps read operand tables that stay packed
+    between steps (LstmResidentTables) and ONE launch behind the products puts
+    the gradients into place, reduces the loss and packs the next step's tables;
+    `update` = (lr, momentum, {parameter name: momentum buffer}): that launch
+    also applies torch.optim.SGD's momentum update (one process: the trainer
+    then skips optimizer.step())."""
     ctx = _DirectCtx()
     if prepared is not None:     # quad_recurrent_prepare's result
         ctx.prepared = prepared
     elif static_inputs and index is None:
         ctx.static_src = (state0, in_ref, ref)
+    if update is not None and not resident_tables:
+        raise ValueError("the in-kernel update needs the resident tables")
     with torch.no_grad():
+        if resident_tables:
+            ctx.lstm_tables = lstm_resident_tables(net, net.fc_out.weight.device)
         loss, _, _ = _QuadLstmRolloutLoss.forward(
             ctx, state0, in_ref, ref, h0, c0, *_net_params(net, _LSTM_PARAMS), dt,
             params, weights or quad_loss_weights(), index)
-        flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims)
+        tail = None
+        if resident_tables:
+            partials, loss1, pw = ctx.lstm_tail
+            tail = (partials, loss1, pw, ctx.lstm_tables, update)
+        flat, gr = _lstm_param_grads(ctx.saved_tensors, ctx.dims, tail)
     return loss, gr, flat
 
 

@@ -29,6 +29,7 @@ class LSTM_NEW(nn.Module):
         self.fc_out = Linear(HIDDEN, nr_actions_predict)
         self.lstm = nn.LSTMCell(state_dim + self.reshape_len, HIDDEN)
         self.hidden_state = self.cell_state = None
+        self.hidden_pool, self._pool = 16, None    # (device draws: see reset_hidden_state)
         self.reset_hidden_state(1)
 
     def reset_hidden_state(self, batch_size=1, generator=None):
@@ -46,9 +47,23 @@ class LSTM_NEW(nn.Module):
             # device stream (no draw-for-draw counterpart): one launch for both,
             # drawn in the plane layout the fused kernels read ([8][B]; the
             # [B, 8] tensors are transposed views, iid entries either way) -
-            # no layout change per step
-            both = torch.randn(2, HIDDEN, batch_size, generator=generator,
-                               device=where).to(dev)
+            # no layout change per step.  Round 6: `hidden_pool` batches' worth
+            # are drawn by ONE launch and handed out step by step (the draw was
+            # 7 us of a 450 us step, every step); not under stream capture,
+            # where a replay must draw for itself.
+            K = int(self.hidden_pool)
+            if K > 1 and not (torch.device(where).type == "cuda"
+                              and torch.cuda.is_current_stream_capturing()):
+                key = (batch_size, torch.device(where), torch.device(dev), id(generator))
+                pool = self._pool
+                if pool is None or pool[0] != key or pool[2] >= K:
+                    pool = self._pool = [key, torch.randn(
+                        K, 2, HIDDEN, batch_size, generator=generator, device=where).to(dev), 0]
+                both = pool[1][pool[2]]
+                pool[2] += 1
+            else:
+                both = torch.randn(2, HIDDEN, batch_size, generator=generator,
+                                   device=where).to(dev)
             self.hidden_state, self.cell_state = both[0].t(), both[1].t()
 
     def forward(self, state, ref):

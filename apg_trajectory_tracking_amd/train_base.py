@@ -40,6 +40,13 @@ def momentum_sgd(params, lr):
     return optim.SGD(params, lr=lr, momentum=0.9, fused=fused)
 
 
+def F_lstm_tables(net):
+    """The resident LSTM operand tables of `net`, if a step has made them."""
+    from . import functional as F
+    reg = F._LSTM_TABLES
+    return reg.get(net) if reg is not None else None
+
+
 def _snapshot_optimizer_state(optimizer):
     """{parameter: {key: clone of a tensor | copy of a plain value}} of an
     optimizer's per-parameter state (before a graph capture's warm-up steps)."""
@@ -476,7 +483,7 @@ class TrainBase:
         self.optimizer_controller.step()
         return loss
 
-    def _in_kernel_update(self, available=True):
+    def _in_kernel_update(self, available=True, names=None, tensors=None):
         """(lr, momentum, {name: momentum buffer}) when the fused step may apply
         the optimizer's update itself (`in_kernel_update`, one process, the
         optimizer is plain momentum SGD as init_optimizer builds it, float32
@@ -501,7 +508,9 @@ class TrainBase:
         # state is repeated only when one of them is a different object -
         # load_state_dict installs a new state mapping - or the policy tensors,
         # the buffers or the settings the answer depends on have changed)
-        tensors = F.mlp_param_objects(self.net)
+        # (names / tensors: another policy's parameter list - the LSTM's)
+        names = F._MLP_PARAMS if names is None else names
+        tensors = F.mlp_param_objects(self.net) if tensors is None else tensors
         fast = (id(opt), id(opt.state), g["lr"], g["momentum"]) + tuple(map(id, tensors))
         hit = getattr(self, "_iku", None)
         if hit is not None and hit[0] == fast and all(
@@ -515,7 +524,7 @@ class TrainBase:
         named = dict(self.net.named_parameters())
         listed = {id(p) for p in g["params"]}
         bufs = {}
-        for name in F._MLP_PARAMS:
+        for name in names:
             p = named.get(name)
             if (p is None or id(p) not in listed or not p.is_cuda or not p.requires_grad
                     or p.dtype != torch.float32 or not p.is_contiguous()):
@@ -723,6 +732,11 @@ class TrainBase:
         hstate = hgen.get_state() if isinstance(hgen, torch.Generator) else None
         sums = [(pl.plan.running, pl.plan.running.clone(), pl.plan, pl.plan.launches)
                 for pl in self._graphs.values() if getattr(pl, "planned", False)]
+        # (an LSTM hands out hidden states from a pool drawn ahead: the timing steps
+        # draw for themselves, from the generator state that is restored below)
+        pool = getattr(self.net, "hidden_pool", None)
+        if pool is not None:
+            self.net.hidden_pool = 0
 
         def eager():
             msg = part_a()
@@ -748,6 +762,8 @@ class TrainBase:
                 for running, was, plan, launches in sums:
                     running.copy_(was)
                     plan.launches = launches
+            if pool is not None:
+                self.net.hidden_pool = pool
             if rng is not None:
                 torch.cuda.set_rng_state(rng, dev)
             if hstate is not None:
@@ -1277,6 +1293,8 @@ class TrainBase:
                 if not self.resident_tables:
                     g.plan.resident_tables = False
                 g.plan.invalidate()
+        if self.net is not None and F_lstm_tables(self.net) is not None:
+            F_lstm_tables(self.net).invalidate()
         for name, applies, runner in table:
             if applies(train):
                 self.last_epoch_loop = name

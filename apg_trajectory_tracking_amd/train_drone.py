@@ -114,7 +114,17 @@ class TrainDrone(TrainBase):
             nb = (prepared[2].shape[-1] if prepared is not None
                   else current_state.size()[0] if index is None else index.numel())
             update = self._in_kernel_update(F.AR_IN_SWEEP and 0 < nb <= F._MAX_FUSED_AR_BATCH)
+        elif fused:
+            # LSTM (round 6): the launch behind the weight products applies the
+            # update, packs the next step's tables, reduces the loss
+            n = self.net
+            update = self._in_kernel_update(
+                self.resident_tables, names=F._LSTM_PARAMS,
+                tensors=(n.conv_ref.weight, n.conv_ref.bias, n.lstm.weight_ih,
+                         n.lstm.weight_hh, n.lstm.bias_ih, n.lstm.bias_hh,
+                         n.fc_out.weight, n.fc_out.bias))
         stepped = update is not None
+        lstm_kw = dict(update=update, resident_tables=bool(self.resident_tables))
         if prepared is not None:
             if not fused:
                 raise ValueError("prepared batches need the fused policy path")
@@ -129,14 +139,14 @@ class TrainDrone(TrainBase):
                     return F.quad_lstm_rollout_grads(
                         self.net, None, None, None, self.delta_t,
                         self.train_dynamics.params, self.net.hidden_state,
-                        self.net.cell_state, **kw)
+                        self.net.cell_state, **kw, **lstm_kw)
             else:
                 def compute():
                     return F.quad_mlp_rollout_grads(
                         self.net, None, None, None, self.delta_t,
                         self.train_dynamics.params, update=update, **kw)
             if lstm_eager:
-                return self._step_direct(*compute())
+                return self._step_direct(*compute(), stepped=stepped)
             return self._graphed(key, (), self._direct_parts(compute, stepped),
                                  volatile=tuple(prepared))
         batch_size = current_state.size()[0] if index is None else index.numel()
@@ -157,15 +167,17 @@ class TrainDrone(TrainBase):
                         self.net, current_state, in_ref_states, ref_states,
                         self.delta_t, self.train_dynamics.params,
                         self.net.hidden_state, self.net.cell_state, index=index,
-                        static_inputs=self.static_shard)
+                        static_inputs=self.static_shard, **lstm_kw)
                 # (a private hidden-state generator is not registered with the
                 # graph: those runs step eagerly)
                 if held is not None:
                     return self._graphed(("lstm", batch_size), tensors,
-                                         self._direct_parts(compute), volatile=(held,))
+                                         self._direct_parts(compute, stepped),
+                                         volatile=(held,))
                 if static and self.hidden_generator is None:
-                    return self._graphed("lstm", tensors, self._direct_parts(compute))
-                return self._step_direct(*compute())
+                    return self._graphed("lstm", tensors,
+                                         self._direct_parts(compute, stepped))
+                return self._step_direct(*compute(), stepped=stepped)
             self.net.reset_hidden_state(
                 batch_size, generator=self.hidden_generator)
         elif self.fused_policy and self._fusable_mlp():

@@ -277,6 +277,58 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               float *grad_h0, float *grad_c0, float *workspace,
                               apg_stream_t stream);
 
+/* The LSTM training step without its small launches (round 6; the loop body of
+ * scripts/train_base.py:198-214 for train_mode "LSTM": loss.backward() +
+ * optimizer.step()).  The operand tables of the two sweeps live in caller-owned
+ * buffers (apg_quad_lstm_tables_floats(0 | 1) floats) that apg_quad_lstm_pack_tables
+ * fills from the parameters in ONE launch and apg_quad_lstm_step_tail refreshes
+ * after its update: the `_packed` sweeps take the tables instead of the
+ * parameters and launch nothing but themselves (loss may be NULL: the tail
+ * reduces the partials). */
+int apg_quad_lstm_tables_floats(int reverse);
+int apg_quad_lstm_pack_tables(const ApgLstmPolicy *policy, float *tables_fwd,
+                              float *tables_bwd, apg_stream_t stream);
+int apg_quad_lstm_rollout_fwd_packed(const float *state0, const float *in_ref,
+                                     const float *h0, const float *c0, float dt,
+                                     const ApgQuadParams *params, const float *tables_fwd,
+                                     int B, int H, float *states, float *actions, float *x,
+                                     float *gates, float *hc, float *hnew,
+                                     unsigned *relu_mask, apg_stream_t stream);
+int apg_quad_lstm_rollout_bwd_packed(const float *state0, const float *states,
+                                     const float *actions, const float *ref, int ref_cols,
+                                     const unsigned *relu_mask, const float *gates,
+                                     const float *hc, float dt, const ApgQuadParams *params,
+                                     const ApgQuadLossWeights *weights,
+                                     const float *tables_bwd, int B, int H,
+                                     float *loss_partials, float *loss, float *d_gates,
+                                     float *d_zout, float *d_conv, float *grad_state0,
+                                     float *grad_h0, float *grad_c0, apg_stream_t stream);
+/* What follows the weight-gradient products of the step, in one launch of one
+ * workgroup: the gradients into their tensors (conv_ref.weight = grad.conv_w as
+ * the window product left it minus the position part conv_pos [20][3];
+ * lstm.weight_ih / weight_hh out of ih_hh [32][183]; lstm.bias_hh = bias_ih's;
+ * the others are where the products wrote them), then - if `update` - momentum
+ * SGD on the eight tensors with torch's arithmetic (buf = momentum buf + grad,
+ * p -= lr buf, each in double with one rounding), the tables of the next step's
+ * sweeps from the updated parameters (tables_fwd / tables_bwd, both or none),
+ * and the loss (loss = sum of n_partials floats; loss_sum += loss if given). */
+typedef struct ApgLstmPolicyGrads {
+  float *conv_w, *conv_b, *w_ih, *w_hh, *b_ih, *b_hh, *w_out, *b_out;
+} ApgLstmPolicyGrads;
+typedef struct ApgLstmStepTail {
+  ApgLstmPolicyGrads grad;      /* b_hh may alias b_ih */
+  const float *ih_hh;           /* [32][183] = [dW_ih | dW_hh] */
+  const float *conv_pos;        /* [20][3] */
+  int update;
+  double lr, momentum;
+  ApgLstmPolicyGrads param, mom;
+  float *tables_fwd, *tables_bwd;
+  const float *loss_partials;
+  int n_partials;
+  float *loss, *loss_sum;
+} ApgLstmStepTail;
+int apg_quad_lstm_step_tail(const ApgLstmStepTail *tail, apg_stream_t stream);
+
 /* ------------------------------------------- quad, MLP policy in-kernel ---- */
 /* hutter_model.Net with the conv branch (neural_control/models/
  * hutter_model.py:6-49) for state_dim 15, horizon 10, ref_dim 9, 4 actions:

@@ -179,3 +179,93 @@ def test_resident_tables_after_a_write_through_data_need_invalidate(dev):
     (la, pa), (lb, pb) = outs
     assert la == lb and np.isfinite(la).all()
     assert all(torch.equal(x, y) for x, y in zip(pa, pb))
+
+
+def _lstm_trainer(dev, B, in_kernel, seed=4):
+    from apg_trajectory_tracking_amd import synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    cfg = dict(delta_t=0.1, delta_t_train=0.1, epoch_size=1000, self_play=1, batch_size=B,
+               state_size=12, horizon=10, train_mode="LSTM", ref_dim=9, action_dim=4,
+               learning_rate_controller=1e-7, system="quad", modified_params={})
+    t = TrainDrone(FlightmareDynamics(), FlightmareDynamics(), cfg)
+    torch.manual_seed(seed)
+    t.net = LSTM_NEW(15, H, 9, 4, conv=1).to(dev)
+    d = synthetic.quad_polynomial_batch(B, H, DT, seed=9, ref_length=t.ref_length)
+
+    class Shard:
+        states, in_ref_states, ref_states = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    t.state_data, t.static_shard = Shard, True
+    gen = torch.Generator().manual_seed(3)
+    hc = torch.randn(2, 8, B, generator=gen).to(dev)
+
+    def fixed_reset(batch_size=1, generator=None, net=t.net):
+        net.hidden_state, net.cell_state = hc[0].t(), hc[1].t()
+    t.net.reset_hidden_state = fixed_reset
+    t.graph_steps = False
+    t.in_kernel_update = in_kernel
+    t.resident_tables = in_kernel
+    t.init_optimizer()
+    step = lambda: t.train_recurrent_model(None, Shard.states, Shard.in_ref_states,
+                                           Shard.ref_states)
+    return t, step
+
+
+@pytest.mark.parametrize("B", [1000, 65536])
+def test_lstm_step_tail_equals_the_separate_launches(dev, B):
+    """the LSTM step's tail - gradients into place, momentum
+    SGD, the next step's operand tables, the loss - as ONE launch
+    (apg_quad_lstm_step_tail) against what it replaces: three elementwise
+    launches, torch's fused SGD, the loss reduction and the two table packs of
+    the next step's sweeps.  Five steps: losses, gradients, parameters and
+    momentum buffers bit for bit; the resident tables are packed once."""
+    from apg_trajectory_tracking_amd import functional as F
+    outs = []
+    for in_kernel in (True, False):
+        t, step = _lstm_trainer(dev, B, in_kernel)
+        losses = [float(step()) for _ in range(5)]
+        grads = {k: p.grad.detach().clone() for k, p in t.net.named_parameters()
+                 if p.grad is not None}
+        bufs = [st["momentum_buffer"].clone() for st in t.optimizer_controller.state.values()
+                if st.get("momentum_buffer") is not None]
+        outs.append((losses, grads, [p.detach().clone() for p in t.net.parameters()], bufs))
+        tab = F._LSTM_TABLES.get(t.net) if F._LSTM_TABLES is not None else None
+        if in_kernel:
+            assert tab is not None and tab.packs == 1, tab and tab.packs
+            assert t._in_kernel_update(True, names=F._LSTM_PARAMS, tensors=tuple(
+                dict(t.net.named_parameters())[n] for n in F._LSTM_PARAMS)) is not None
+        else:
+            assert tab is None
+    (la, ga, pa, ba), (lb, gb, pb, bb) = outs
+    assert la == lb and np.isfinite(la).all() and la[-1] != la[0]
+    assert set(ga) == set(gb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    assert len(ba) == len(bb) == 8
+    for xs, ys in ((pa, pb), (ba, bb)):
+        assert all(torch.equal(x, y) for x, y in zip(xs, ys))
+
+
+def test_lstm_resident_tables_notice_foreign_writes(dev):
+    """A parameter written from outside (in-place version counter) makes the next
+    step pack again; a write through `.data` needs `invalidate()` - run_epoch's
+    epoch start does it."""
+    from apg_trajectory_tracking_amd import functional as F
+    t, step = _lstm_trainer(dev, 512, True)
+    ref, rstep = _lstm_trainer(dev, 512, False)
+    tab = lambda: F._LSTM_TABLES.get(t.net)
+    for i in range(5):
+        if i == 2:
+            for n in (t.net, ref.net):
+                with torch.no_grad():
+                    n.lstm.bias_ih.mul_(1.5)
+        if i == 4:
+            for n in (t.net, ref.net):
+                n.fc_out.weight.data.mul_(0.5)
+            tab().invalidate()
+        assert float(step()) == float(rstep()), i
+    assert tab().packs == 3
+    for a, b in zip(t.net.parameters(), ref.net.parameters()):
+        assert torch.equal(a, b)
