@@ -197,6 +197,9 @@ def _lstm_trainer(dev, B, in_kernel, seed=4):
 
     class Shard:
         states, in_ref_states, ref_states = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    from apg_trajectory_tracking_amd.dataset import state_preprocessing
+    with torch.no_grad():
+        Shard.normed_states = state_preprocessing(Shard.states)
     t.state_data, t.static_shard = Shard, True
     gen = torch.Generator().manual_seed(3)
     hc = torch.randn(2, 8, B, generator=gen).to(dev)

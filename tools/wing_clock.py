@@ -27,21 +27,26 @@ def main():
     lib.apg_wing_clock_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
     dyn = FixedWingDynamics()
     H, dt = 20, 0.05
-    for B, force in ((131072, None), (65536, 1), (32768, 1)):
+    # (sets: 1 = one buffer set, inputs cache resident; 4 = bench.py's
+    # secondary.wing_rollout protocol, four rotating sets)
+    for B, force, sets in ((131072, None, 1), (131072, None, 4), (65536, 1, 1), (32768, 1, 1)):
         if force is not None:
             _capi.check(lib.apg_wing_set_two_per_lane(force), "set")
-        d = synthetic.wing_batch(B, H, dt, seed=0)
-        plan = F.RolloutPlan("wing", synthetic.to_soa_state(d["state0"]).to(dev),
-                             synthetic.to_soa_seq(d["actions"]).to(dev),
-                             synthetic.to_soa_seq(d["ref"]).to(dev), dt, dyn.params,
-                             layout="soa", loss_mode="none")
-        for _ in range(200):          # the chip in its sustained state
-            plan.launch()
+        plans = []
+        for i in range(sets):
+            d = synthetic.wing_batch(B, H, dt, seed=i)
+            plans.append(F.RolloutPlan(
+                "wing", synthetic.to_soa_state(d["state0"]).to(dev),
+                synthetic.to_soa_seq(d["actions"]).to(dev),
+                synthetic.to_soa_seq(d["ref"]).to(dev), dt, dyn.params,
+                layout="soa", loss_mode="none"))
+        for i in range(200):          # the chip in its sustained state
+            plans[i % sets].launch()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(100):
-            plan.launch()
+        for i in range(100):
+            plans[i % sets].launch()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 100 * 1e3
@@ -52,14 +57,27 @@ def main():
         cycles, ref = c[:, 1] - c[:, 0], c[:, 3] - c[:, 2]
         ghz = cycles / (ref / REF_HZ) / 1e9
         span_us = (c[:, 3].max() - c[:, 2].min()) / REF_HZ * 1e6
+        # where the microseconds between a wave's own
+        # duration and the launch are - the ramp (first wave's start to the
+        # last wave's start), the waves themselves, the tail (median end to
+        # last end), and what the HIP events add around the span
+        t0 = c[:, 2].min()
+        us_of = lambda v: float((v - t0) / REF_HZ * 1e6)
+        attribution = {
+            "last_wave_start_us": us_of(c[:, 2].max()),
+            "median_wave_end_us": us_of(np.median(c[:, 3])),
+            "last_wave_end_us": us_of(c[:, 3].max()),
+            "events_minus_span_us": float(us - span_us),
+            "wave_us_at_2p25GHz": float(np.median(cycles) / 2.25e3),
+            "clock_loss_us": float(np.median(ref) / REF_HZ * 1e6 - np.median(cycles) / 2.25e3)}
         print(json.dumps({
-            "batch": B, "waves": waves, "us_per_launch_events": us,
+            "batch": B, "waves": waves, "buffer_sets": sets, "us_per_launch_events": us,
             "wave_cycles_median": float(np.median(cycles)),
             "wave_us_median": float(np.median(ref) / REF_HZ * 1e6),
             "launch_span_us_first_start_to_last_end": float(span_us),
             "shader_GHz_median": float(np.median(ghz)),
             "shader_GHz_p05_p95": [float(np.percentile(ghz, 5)), float(np.percentile(ghz, 95))],
-            "ref_clock_Hz": REF_HZ}))
+            "attribution": attribution, "ref_clock_Hz": REF_HZ}))
     _capi.check(lib.apg_wing_set_two_per_lane(2), "set")
 
 
