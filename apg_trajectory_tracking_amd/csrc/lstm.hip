@@ -104,17 +104,40 @@ __device__ __forceinline__ float fwd16_weight(const ApgLstmPolicy &p, int n, int
   return ch < kNC ? p.w_ih[row * kNX + kNF + ch * kNP + pos] : 0.f;
 }
 
+// the A-operand blocks of a table: four entries per round, every weight of a round
+// read before the first is split and stored (a pack by ONE workgroup - the step's
+// tail - is a chain of dependent loads otherwise)
+template <typename W>
+__device__ __forceinline__ void pack_blocks16(unsigned *dst, int base, int blocks, int tid, int T,
+                                              W weight) {
+  const int n_idx = blocks * 64 * 4;
+  for (int idx0 = tid; idx0 < n_idx; idx0 += 4 * T) {
+    float w[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = idx0 + r * T;
+      const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+      w[r][0] = idx < n_idx ? weight(n, l & 31, 2 * q, l >> 5) : 0.f;
+      w[r][1] = idx < n_idx ? weight(n, l & 31, 2 * q + 1, l >> 5) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = idx0 + r * T;
+      if (idx >= n_idx) break;
+      const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
+      unsigned h, lo;
+      split_pair(w[r][0], w[r][1], h, lo);
+      dst[(base + n * kBlock16) / 4 + l * 4 + q] = h;
+      dst[(base + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
+    }
+  }
+}
+
 __device__ __forceinline__ void pack_fwd16(const PackArgs &A, int tid, int T) {
   const ApgLstmPolicy &p = A.pol;
   unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
-  for (int idx = tid; idx < nBlocks16 * 64 * 4; idx += T) {
-    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
-    unsigned h, lo;
-    split_pair(fwd16_weight(p, n, l & 31, 2 * q, l >> 5),
-               fwd16_weight(p, n, l & 31, 2 * q + 1, l >> 5), h, lo);
-    dst[(hA + n * kBlock16) / 4 + l * 4 + q] = h;
-    dst[(hA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
-  }
+  pack_blocks16(dst, hA, nBlocks16, tid, T,
+                [&](int n, int row, int j, int hi) { return fwd16_weight(p, n, row, j, hi); });
   for (int idx = tid; idx < 32; idx += T) {
     const int hi = idx & 1, r = (idx >> 1) & 3, j = idx >> 3;
     A.dst[hTo + idx] = p.w_out[j * kNH + r + 4 * hi];
@@ -534,14 +557,8 @@ __device__ __forceinline__ float bwd16_weight(const ApgLstmPolicy &p, int n, int
 __device__ __forceinline__ void pack_bwd16(const PackArgs &A, int tid, int T) {
   const ApgLstmPolicy &p = A.pol;
   unsigned *dst = reinterpret_cast<unsigned *>(A.dst);
-  for (int idx = tid; idx < mBlocks16 * 64 * 4; idx += T) {
-    const int q = idx & 3, l = (idx >> 2) & 63, n = idx >> 8;
-    unsigned h, lo;
-    split_pair(bwd16_weight(p, n, l & 31, 2 * q, l >> 5),
-               bwd16_weight(p, n, l & 31, 2 * q + 1, l >> 5), h, lo);
-    dst[(gA + n * kBlock16) / 4 + l * 4 + q] = h;
-    dst[(gA + n * kBlock16 + 1024) / 4 + l * 4 + q] = lo;
-  }
+  pack_blocks16(dst, gA, mBlocks16, tid, T,
+                [&](int n, int row, int j, int hi) { return bwd16_weight(p, n, row, j, hi); });
   for (int idx = tid; idx < 32; idx += T) {
     const int hi = idx & 1, r = (idx >> 1) & 3, j = idx >> 3;
     A.dst[gTo + idx] = p.w_out[j * kNH + r + 4 * hi];

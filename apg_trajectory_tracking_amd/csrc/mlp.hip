@@ -1682,7 +1682,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
 
   // ------------------------------------------------------------- head
   f32x16 d[2], e[2];
-  float dT[2][16];        // the current layer's cotangent, trajectory-major
   const int e0 = wg_exp(meta.dmax[0], bad);
   (void)e0;   // (only its `bad` flag: the head's rows have their own exponents)
   {
@@ -1690,14 +1689,12 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
     // the workgroup's exponent: a trajectory whose cotangents are 1e-4 of the
     // workgroup's largest then kept 2^-22 x 1e4 of relative accuracy - its
     // weight terms and bias sums were as noisy as that, tests/test_gpu_round5.py);
-    // the swapped products' rows - trajectories - come back with their own
+    // the transposed operands' rows - trajectories - come back with their own
     // scales, the exponents are brought into accumulator layout by texp.
     float amx = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 20; ++cc) amx = fmaxf(amx, fabsf(dzr[cc]));
     const int ex0 = scale_exponent(amx);
-    int E0[16];
-    texp(ex0, hi, E0);
     Op16 x0[3];
 #pragma unroll
     for (int kb = 0; kb < 3; ++kb) {
@@ -1737,15 +1734,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
         for (int kk = 0; kk < 2; ++kk) acc = mma3(az[mb][kk], bx[kk], acc);
         add_block(lane_blk + tRA + (2 * nb + mb) * 4096, acc);
       }
-      // d(h3)^T, block nb: the head tables as B operand
-      f32x16 t;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t[i] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 3; ++kb) t = mma3(x0[kb], L16.A(0, wO + 3 * nb + kb), t);
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        dT[nb][i] = __builtin_amdgcn_ldexpf(t[i], E0[i]) * (1.f - xv[i] * xv[i]);
       if (nb == 0) load_hv(pH3);
     }
     zero(d);
@@ -1779,21 +1767,49 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
     }
   }
 
-  // One 64 x 64 layer: dl / dT = its cotangent in both layouts, e_ = the
+  // The A operands of a layer's weight blocks from its cotangent in the chain's
+  // orientation (round 6, as in mlp_rollout_bwd_tm_kernel; until round 5 the chain
+  // ran a second time with swapped operands for them:
+  // profiles/r06_transposition_probe.jsonl): the chain's own split x[kb] times an
+  // identity B operand = trajectory r(i) + 4 hi of feature `lane & 31` in register
+  // i (4 matrix instructions per 32 features, exact), the trajectories' exponents
+  // in the same layout (texp), one ldexp per value to the workgroup's unit.  The
+  // bias gradient: the wave's float sum per row, stored as before.
+  u32x4 ident[2];
+  ident_operands(lane, ident);
+  auto transposed_operands = [&](const Op16 (&x)[4], int ex, int e_, int bias_id,
+                                 Op16 (&ad)[2][2]) {
+    int E[16];
+    texp(ex, hi, E);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const Op16 pr[2] = {x[2 * mb], x[2 * mb + 1]};
+      const f32x16 tz = to_feature_major(pr, ident);
+      float v[16], sb = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[i] = __builtin_amdgcn_ldexpf(tz[i], E[i] - e_ + kPreD);
+        sb += v[i];
+      }
+      sb += other_half(sb);
+      if (hi == 0)
+        __builtin_nontemporal_store(
+            bad ? __builtin_nanf("") : __builtin_amdgcn_ldexpf(sb, e_ - kPreD),
+            bias_part + bias_id * 64 + 32 * mb + row);
+      split16(v, 0, ad[mb]);
+    }
+  };
+  // One 64 x 64 layer: dl = its cotangent (accumulator layout), e_ = the
   // workgroup's exponent for it.  Weight blocks against the two x blocks (the
   // second one and `next_plane`'s first are requested on the way), the
-  // cotangent of the layer below in both layouts (tables `tab`), tanh' with
-  // the x blocks / the planes `x_plane`; its maxima go to slot `phase + 1`.
+  // cotangent of the layer below (tables `tab`), tanh' with the planes
+  // `x_plane`; its maxima go to slot `phase + 1`.
   auto layer64 = [&](f32x16 (&dl)[2], f32x16 (&nx)[2], int e_, int tab, int x_plane,
                      int region, int bias_id, int next_plane, int phase) {
     Op16 x[4];
     const int ex = scaled_split64(dl, x);     // per trajectory
     Op16 ad[2][2];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      add_bias(dT[mb], bias_id, mb, 32);
-      split16(dT[mb], e_ - kPreD, ad[mb]);
-    }
+    transposed_operands(x, ex, e_, bias_id, ad);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       float xv[16];
@@ -1810,16 +1826,6 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
         for (int kk = 0; kk < 2; ++kk) acc = mma3(ad[mb][kk], bx[kk], acc);
         add_block(lane_blk + region + (2 * nb + mb) * 4096, acc);
       }
-      f32x16 t;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t[i] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) t = mma3(x[kb], L16.A(0, tab + 4 * nb + kb), t);
-      int E[16];
-      texp(ex, hi, E);
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        dT[nb][i] = __builtin_amdgcn_ldexpf(t[i], E[i]) * (1.f - xv[i] * xv[i]);
       // (the tanh' operands of the feature-major chain below: requested here so
       // that they land under the second block's products)
       if (nb == 0) load_hv(x_plane);
@@ -1852,11 +1858,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_bwd_tm_kernel(WgArgs 
     Op16 x1s[4];
     const int ex1 = scaled_split64(d, x1s);   // per trajectory
     Op16 ad[2][2];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      add_bias(dT[mb], 3, mb, 32);
-      split16(dT[mb], e1 - kPreD, ad[mb]);
-    }
+    transposed_operands(x1s, ex1, e1, 3, ad);
     // B operands that stay: the 15 feature planes + a row of ones (states_in's
     // bias column), the 90 in_ref planes in three blocks (conv windows)
     Op16 bfeat[2], binr[3][2];

@@ -1,6 +1,7 @@
 """One fused training step of TrainDrone at B = 65 536 on a resident shard,
 eager launches (no graph), for per-kernel profiling:
     python tools/time_train_step.py concurrent|autoregressive|LSTM [graph]
+    APG_STEP_LEGACY=1 ...   the LSTM step without round 6's resident tables / tail launch
     rocprofv3 --kernel-trace --stats -- python tools/time_train_step.py <mode>
 Prints the eager wall time per step (host gaps included); with `graph` the
 step is replayed from the trainer's captured graph (what bench.py times)."""
@@ -19,6 +20,9 @@ t = TrainDrone(q, q, cfg)
 torch.manual_seed(0)
 t.initialize_model(device=dev, seed=0)
 t.static_shard = True
+if os.environ.get("APG_STEP_LEGACY"):     # A/B: the step as it was before round 6's
+    t.resident_tables = False             # LSTM tail (tables packed per step,
+    t.in_kernel_update = False            # optimizer.step() as a launch of its own)
 t.graph_steps = len(sys.argv) > 2 and sys.argv[2] == "graph"
 reps = 200 if t.graph_steps else 20
 d = t.state_data
