@@ -1403,7 +1403,11 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
         feat, x1, h = acts[:15], acts[15:239], acts[239:431]
         relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
         st = stream_of(s0)
-        if AR_IN_SWEEP:
+        # (tests only: tests/plane_path.py hangs the rounds 1-4 sequence - cotangent
+        # planes + planes_gemm products - in here as an independent implementation
+        # of the same gradients; nothing in the package sets it)
+        plane_tail = getattr(ctx, "plane_tail", None)
+        if plane_tail is None:
             # round 5: every weight gradient is accumulated inside the reverse
             # sweep (apg_quad_mlp_rollout_train_step) - no cotangent planes, no
             # second pass of products; every gradient is a view of `flat`
@@ -1450,38 +1454,14 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
             ctx.mark_non_differentiable(states, actions)
             ctx.dims = (B, H)
             return loss.reshape(()), states, actions
-        ctx.flat_grads = None
-        if getattr(ctx, "update", None) is not None:
-            raise ValueError("update needs the in-sweep path")
-        ws = new(lib().apg_quad_mlp_workspace_floats())
-        check(lib().apg_quad_mlp_rollout_fwd(
-            ptr(s0), ptr(inr), float(dt), ctypes.byref(params),
-            ctypes.byref(pol), B, H, ptr(states), ptr(actions), ptr(feat),
-            ptr(x1), ptr(h), relu_mask.data_ptr(), ptr(ws), st),
-            "apg_quad_mlp_rollout_fwd")
-        partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
-        loss = new(1)
-        d_pre, d_zout, d_conv = new(256, N), new(4, N), new(_CONV_DIAG_PLANES, B)
-        g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
-        check(lib().apg_quad_mlp_rollout_bwd(
-            ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1], ptr(x1),
-            ptr(h), relu_mask.data_ptr(), float(dt), ctypes.byref(params),
-            ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
-            ptr(loss), ptr(d_pre), ptr(d_zout), ptr(d_conv), ptr(g_s0), ptr(ws),
-            st), "apg_quad_mlp_rollout_bwd")
-        ctx.save_for_backward(refbuf, acts, d_pre, d_zout, d_conv)
-        ctx.input_grads = (g_s0,)
-        ctx.mark_non_differentiable(states, actions)
-        ctx.dims = (B, H)
-        return loss.reshape(()), states, actions
+        return plane_tail(ctx, dict(
+            s0=s0, inr=inr, rf=rf, refbuf=refbuf, states=states, actions=actions,
+            acts=acts, feat=feat, x1=x1, h=h, relu_mask=relu_mask, pol=pol, params=params,
+            weights=weights, dt=dt, B=B, H=H, N=N, st=st, new=new))
 
     @staticmethod
     def backward(ctx, g, _gs, _ga):
-        if ctx.flat_grads is not None:
-            gr = {k: v * g for k, v in ctx.flat_grads[1].items()}
-        else:
-            flat, gr = _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
-            flat *= g
+        gr = {k: v * g for k, v in ctx.flat_grads[1].items()}
         g_s0 = None if ctx.input_grads[0] is None else ctx.input_grads[0].t() * g
         return (g_s0, None, None, *[gr[k] for k in _MLP_PARAMS], None, None, None)
 
@@ -1489,47 +1469,6 @@ class _QuadMlpRolloutLoss(torch.autograd.Function):
 _MLP_PARAMS = ("states_in.weight", "states_in.bias", "conv_ref.weight",
                "conv_ref.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
                "fc3.weight", "fc3.bias", "fc_out.weight", "fc_out.bias")
-
-
-def _mlp_param_grads(saved, dims, n_out, conv=None):
-    """Weight gradients of the fused MLP-policy kernels from the saved planes
-    (acts = feat 0..14 | x1 15..238 | h1 239.. | h2 303.. | h3 367..; d_pre =
-    fc1, fc2, fc3, states_in cotangents): matrix-core products over the plane
-    length; every gradient is a contiguous view of one flat buffer (returned
-    first), keyed by hutter_model.Net parameter name.  `conv`: how the conv
-    weight gradient reads its windows (default: the autoregressive unroll)."""
-    refbuf, acts, d_pre, d_zout, d_conv = saved
-    B, H = dims
-    dev = acts.device
-    flat, gr = _flat_grads(dev, {
-        "states_in.weight": (64, 15), "states_in.bias": (64,),
-        "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,),
-        "fc1.weight": (64, 224), "fc1.bias": (64,), "fc2.weight": (64, 64),
-        "fc2.bias": (64,), "fc3.weight": (64, 64), "fc3.bias": (64,),
-        "fc_out.weight": (n_out, 64), "fc_out.bias": (n_out,)})
-    R = lambda lo, hi_: make_bdesc(dev, range(lo, hi_), key=("mlp", lo, hi_))
-    probs = [
-        dict(A=d_pre[0:64], M=64, S=1, Bp=acts, bdesc=R(15, 127), with_ones=False,
-             out=gr["fc1.weight"]),
-        dict(A=d_pre[0:64], M=64, S=1, Bp=acts, bdesc=R(127, 239),
-             out=gr["fc1.weight"][:, 112:], bias_out=gr["fc1.bias"]),
-        dict(A=d_pre[64:128], M=64, S=1, Bp=acts, bdesc=R(239, 303),
-             out=gr["fc2.weight"], bias_out=gr["fc2.bias"]),
-        dict(A=d_pre[128:192], M=64, S=1, Bp=acts, bdesc=R(303, 367),
-             out=gr["fc3.weight"], bias_out=gr["fc3.bias"]),
-        dict(A=d_pre[192:256], M=64, S=1, Bp=acts, bdesc=R(0, 15),
-             out=gr["states_in.weight"], bias_out=gr["states_in.bias"]),
-        dict(A=d_zout, M=n_out, S=1, Bp=acts, bdesc=R(367, 431),
-             out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])]
-    if conv is None:
-        cp, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.weight"],
-                                         gr["conv_ref.bias"])
-    else:
-        cp, finish = [conv(d_conv, gr["conv_ref.weight"], gr["conv_ref.bias"])], None
-    _run_products(probs + cp)
-    if finish is not None:
-        finish()
-    return flat, gr
 
 
 def quad_mlp_rollout_loss(net, state0, in_ref, ref, dt, params, weights=None):
@@ -1795,7 +1734,8 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
         partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
         loss = new(1)
         ctx.dims = (B, H)
-        if CONCURRENT_IN_SWEEP:
+        plane_tail = getattr(ctx, "plane_tail", None)    # (tests only, as above)
+        if plane_tail is None:
             # round 4: the weight gradients are accumulated inside the reverse
             # pass (apg_quad_mlp_concurrent_step) - no cotangent planes, no
             # second pass of products; every gradient is a view of `flat`
@@ -1840,26 +1780,14 @@ class _QuadConcurrentPolicyLoss(torch.autograd.Function):
             ctx.flat_grads = (flat, gr)
             ctx.save_for_backward(acts)
             return loss.reshape(())
-        cot = new(40 + 256 + 160, B)      # d_zout | d_pre | d_conv
-        d_zout, d_pre, d_conv = cot[:40], cot[40:296], cot[296:]
-        ws = new(lib().apg_quad_mlp_concurrent_workspace_floats())
-        check(lib().apg_quad_mlp_concurrent_fwd_bwd(
-            ptr(feat), ptr(inr), ptr(s0), ptr(rf), rf.shape[1], float(dt),
-            ctypes.byref(params), ctypes.byref(weights), ctypes.byref(pol), B, H,
-            ptr(x1), ptr(h), relu_mask.data_ptr(), ptr(d_zout), ptr(d_pre),
-            ptr(d_conv), ptr(partials), ptr(loss), None, ptr(ws),
-            stream_of(s0)), "apg_quad_mlp_concurrent_fwd_bwd")
-        ctx.flat_grads = None
-        ctx.save_for_backward(acts, cot)
-        return loss.reshape(())
+        return plane_tail(ctx, dict(
+            acts=acts, feat=feat, x1=x1, h=h, inr=inr, s0=s0, rf=rf, relu_mask=relu_mask,
+            pol=pol, params=params, weights=weights, dt=dt, B=B, H=H, partials=partials,
+            loss=loss, new=new))
 
     @staticmethod
     def backward(ctx, g):
-        flat, gr = ctx.flat_grads or _conc_param_grads(ctx.saved_tensors, ctx.dims)
-        if ctx.flat_grads is not None:
-            gr = {k: v * g for k, v in gr.items()}
-        else:
-            flat *= g
+        gr = {k: v * g for k, v in ctx.flat_grads[1].items()}
         return (None, None, None, None, *[gr[k] for k in _MLP_PARAMS], None, None, None)
 
 
@@ -1887,8 +1815,6 @@ class QuadConcurrentStepPlan:
         row numbers and the forward kernel reads the rows itself
         (apg_quad_mlp_concurrent_train_step_rows: no gather pass, `prepared` is
         None)."""
-        if not CONCURRENT_IN_SWEEP:
-            raise ValueError("the step plan needs the in-sweep path")
         if rows is not None:
             normed, st0, inr, rfs, B = rows
             for t in (normed, st0, inr, rfs):
@@ -2036,34 +1962,6 @@ class QuadConcurrentStepPlan:
 # current from step to step (no pack launch)
 RESIDENT_TABLES = True
 
-# True: the autoregressive step accumulates its weight gradients inside the
-# reverse sweep (csrc/mlp.hip, mlp_rollout_bwd_tm_kernel, round 5); False:
-# cotangent planes + planes_gemm products (rounds 1-4)
-AR_IN_SWEEP = True
-
-# True: the concurrent step accumulates its weight gradients inside the reverse
-# kernel (csrc/mlp.hip, mlp_concurrent_bwd_wg_kernel); False: cotangent planes +
-# planes_gemm products (rounds 1-3; kept for comparison and as the planes API's
-# user)
-CONCURRENT_IN_SWEEP = True
-
-
-def _conc_param_grads(saved, dims):
-    acts, cot = saved
-    B, H = dims
-    dev = acts.device
-
-    def conv(d_conv, w_out, b_out):
-        # window rows are the in_ref planes behind the activations, segment = position
-        desc = make_bdesc(dev, [431 + t * 9 + c for c in range(9) for t in range(3)],
-                          9, 0, key=("conc_conv", H))
-        return dict(A=d_conv, M=20, S=8, Bp=acts, bdesc=desc, out=w_out.view(20, 27),
-                    bias_out=b_out)
-
-    return _mlp_param_grads((None, acts, cot[40:296], cot[:40], cot[296:]), dims, 40,
-                            conv=conv)
-
-
 def quad_concurrent_policy_loss(net, normed, state0, in_ref, ref, dt, params,
                                 weights=None):
     """The concurrent training step's loss for a `Net(15, 10, 9, 40, conv=1)`:
@@ -2143,8 +2041,6 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
     ctx = _DirectCtx()
     ctx.events = events
     if update is not None:
-        if not CONCURRENT_IN_SWEEP:
-            raise ValueError("update needs the in-sweep path")
         ctx.update = update
     if prepared is not None:
         ctx.prepared = prepared
@@ -2154,7 +2050,7 @@ def quad_concurrent_policy_grads(net, normed, state0, in_ref, ref, dt, params,
         loss = _QuadConcurrentPolicyLoss.forward(
             ctx, normed, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt,
             params, weights or quad_loss_weights(), index)
-        flat, gr = ctx.flat_grads or _conc_param_grads(ctx.saved_tensors, ctx.dims)
+        flat, gr = ctx.flat_grads
     return loss, gr, flat
 
 
@@ -2202,7 +2098,7 @@ def quad_mlp_rollout_grads(net, state0, in_ref, ref, dt, params, weights=None,
         loss, _, _ = _QuadMlpRolloutLoss.forward(
             ctx, state0, in_ref, ref, *_net_params(net, _MLP_PARAMS), dt, params,
             weights or quad_loss_weights(), index)
-        flat, gr = ctx.flat_grads or _mlp_param_grads(ctx.saved_tensors, ctx.dims, 4)
+        flat, gr = ctx.flat_grads
     return loss, gr, flat
 
 

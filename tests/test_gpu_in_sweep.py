@@ -4,7 +4,8 @@ mlp_concurrent_bwd_tm_kernel) - no cotangent planes, no second pass of
 products.  One loss.backward() of the reference yields every parameter
 gradient (scripts/train_drone.py:175-203); this path must too, to the same
 1e-4 as the plane + product path it replaces (which stays available behind
-functional.CONCURRENT_IN_SWEEP = False and is the comparison here)."""
+tests/plane_path.py since round 6 - the package has one path - and is the
+comparison here)."""
 import copy
 import ctypes
 
@@ -24,12 +25,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture
-def in_sweep_switch():
-    from apg_trajectory_tracking_amd import functional as F
-    before = F.CONCURRENT_IN_SWEEP
-    yield lambda on: setattr(F, "CONCURRENT_IN_SWEEP", bool(on))
-    F.CONCURRENT_IN_SWEEP = before
+import plane_path as PP
 
 
 def N(t):
@@ -63,7 +59,7 @@ def _fp64_grads(net, d):
 # second workgroup with one trajectory; 300, 4113: ragged last workgroups;
 # 8192 + 3: more than one chunk of the second stage (32 workgroups)
 @pytest.mark.parametrize("B", [1, 31, 77, 256, 257, 300, 4113, 8195])
-def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_switch):
+def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B):
     from apg_trajectory_tracking_amd import functional as F
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
@@ -74,9 +70,8 @@ def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_s
     d, inputs = _case(B, 100 + B, dev)
     dyn = FlightmareDynamics()
     res = []
-    for on in (True, False):
-        in_sweep_switch(on)
-        loss, grads, flat = F.quad_concurrent_policy_grads(gnet, *inputs, DT, dyn.params)
+    for fn in (F.quad_concurrent_policy_grads, PP.quad_concurrent_policy_grads_planes):
+        loss, grads, flat = fn(gnet, *inputs, DT, dyn.params)
         assert flat.numel() == sum(g.numel() for g in grads.values()) + 1   # + loss slot
         res.append((loss.item(), {k: N(v) for k, v in grads.items()}))
     loss64, want = _fp64_grads(net, d)
@@ -89,7 +84,7 @@ def test_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, in_sweep_s
         assert rel_err(g1[k], g0[k]) < 2e-5, (k, rel_err(g1[k], g0[k]))
 
 
-def test_in_sweep_is_deterministic_and_feeds_autograd(dev, in_sweep_switch):
+def test_in_sweep_is_deterministic_and_feeds_autograd(dev):
     """Fixed-order sums (staged kernel) / fixed-point accumulators (trajectory-
     major kernel) and a fixed-order second stage: equal inputs give equal bits,
     at a batch of several workgroups and chunks as well; loss.backward()
@@ -99,7 +94,6 @@ def test_in_sweep_is_deterministic_and_feeds_autograd(dev, in_sweep_switch):
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
     from apg_trajectory_tracking_amd.models.hutter_model import Net
-    in_sweep_switch(True)
     torch.manual_seed(3)
     net = Net(15, H, 9, 4 * H, conv=1).to(dev)
     _, inputs = _case(9000, 5, dev)
@@ -132,7 +126,6 @@ def test_concurrent_step_through_the_c_abi(dev):
     net = Net(15, H, 9, 4 * H, conv=1).to(dev)
     _, inputs = _case(B, 17, dev)
     dyn = FlightmareDynamics()
-    F.CONCURRENT_IN_SWEEP = True
     want_loss, want, _ = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
     acts, s0, rf = F.quad_concurrent_prepare(*inputs)
     new = lambda *s: torch.full(s, 7.0, device=dev)
@@ -189,7 +182,6 @@ def test_train_step_through_the_c_abi(dev):
     net = Net(15, H, 9, 4 * H, conv=1).to(dev)
     _, inputs = _case(B, 19, dev)
     dyn = FlightmareDynamics()
-    F.CONCURRENT_IN_SWEEP = True
     acts, s0, rf = F.quad_concurrent_prepare(*inputs)
     new = lambda *s: torch.zeros(s, device=dev)
     names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2", "w_3", "b_3",
@@ -243,7 +235,7 @@ def test_train_step_through_the_c_abi(dev):
     assert call(0, upd) == -1 and b"B = 0" in lib.apg_last_error_string()
 
 
-def test_in_sweep_kernel_agrees_with_plane_path_at_full_size_and_flags_non_finite(dev, in_sweep_switch):
+def test_in_sweep_kernel_agrees_with_plane_path_at_full_size_and_flags_non_finite(dev):
     """B = 65 536: the trajectory-major kernel against the plane + product path
     on every parameter gradient (two independent implementations of the same
     sums), bit-reproducible; a NaN / inf planted in one trajectory's features
@@ -259,7 +251,6 @@ def test_in_sweep_kernel_agrees_with_plane_path_at_full_size_and_flags_non_finit
     net = Net(15, H, 9, 4 * H, conv=1).to(dev)
     _, inputs = _case(B, 5, dev)
     dyn = FlightmareDynamics()
-    in_sweep_switch(True)
     prepared = F.quad_concurrent_prepare(*inputs)
     plan = F.QuadConcurrentStepPlan(net, prepared, DT, dyn.params)
     plan.launch()
@@ -275,8 +266,7 @@ def test_in_sweep_kernel_agrees_with_plane_path_at_full_size_and_flags_non_finit
         for k, v in plan.named.items():
             assert not torch.isfinite(v).any(), (poison, k)
         prepared[0][3, 40000] = 0.25
-    in_sweep_switch(False)
-    _, planes, _ = F.quad_concurrent_policy_grads(net, *inputs, DT, dyn.params)
+    _, planes, _ = PP.quad_concurrent_policy_grads_planes(net, *inputs, DT, dyn.params)
     for k in got:
         assert rel_err(got[k], N(planes[k])) < 5e-6, (k, rel_err(got[k], N(planes[k])))
 

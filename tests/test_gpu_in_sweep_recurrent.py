@@ -3,8 +3,9 @@ accumulated INSIDE the reverse sweep (apg_quad_mlp_rollout_train_step;
 csrc/mlp.hip, mlp_rollout_bwd_tm_kernel) - no cotangent planes, no
 planes_gemm launches.  One loss.backward() of the reference yields every
 parameter gradient (scripts/train_drone.py:113-173); this path must too, to the
-same 1e-4 as the plane + product path it replaces (which stays available behind
-functional.AR_IN_SWEEP = False and is the comparison here)."""
+same 1e-4 as the plane + product path it replaced (rounds 1-4; an independent
+implementation of the same sums that lives in tests/plane_path.py since round 6 -
+the package has one path - and is the comparison here)."""
 import copy
 import ctypes
 
@@ -24,12 +25,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture
-def ar_switch():
-    from apg_trajectory_tracking_amd import functional as F
-    before = F.AR_IN_SWEEP
-    yield lambda on: setattr(F, "AR_IN_SWEEP", bool(on))
-    F.AR_IN_SWEEP = before
+import plane_path as PP
 
 
 def N(t):
@@ -57,7 +53,7 @@ def _oracle_grads(net, d, dtype):
 # second workgroup with one trajectory; 300, 4113: ragged last workgroups;
 # 8192 + 3: more than one chunk of the second stage (32 workgroups)
 @pytest.mark.parametrize("B", [1, 31, 77, 256, 257, 300, 4113, 8195])
-def test_ar_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, ar_switch):
+def test_ar_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B):
     from apg_trajectory_tracking_amd import functional as F
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
@@ -68,9 +64,8 @@ def test_ar_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, ar_swit
     d, inputs = _case(B, 200 + B, dev)
     dyn = FlightmareDynamics()
     res = []
-    for on in (True, False):
-        ar_switch(on)
-        loss, grads, flat = F.quad_mlp_rollout_grads(gnet, *inputs, DT, dyn.params)
+    for fn in (F.quad_mlp_rollout_grads, PP.quad_mlp_rollout_grads_planes):
+        loss, grads, flat = fn(gnet, *inputs, DT, dyn.params)
         assert flat.numel() == sum(g.numel() for g in grads.values()) + 1   # + loss slot
         res.append((loss.item(), {k: N(v) for k, v in grads.items()}))
     loss64, want = _oracle_grads(net, d, torch.float64)
@@ -83,7 +78,7 @@ def test_ar_in_sweep_gradients_vs_fp64_oracle_and_plane_products(dev, B, ar_swit
         assert rel_err(g1[k], g0[k]) < 2e-5, (k, rel_err(g1[k], g0[k]))
 
 
-def test_ar_in_sweep_is_deterministic_and_feeds_autograd(dev, ar_switch):
+def test_ar_in_sweep_is_deterministic_and_feeds_autograd(dev):
     """Fixed-point LDS accumulators, a global accumulator element owned by ONE
     thread that adds the steps in order, a fixed-order second stage: equal
     inputs give equal bits, at a batch of several workgroups and chunks as
@@ -94,7 +89,6 @@ def test_ar_in_sweep_is_deterministic_and_feeds_autograd(dev, ar_switch):
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
     from apg_trajectory_tracking_amd.models.hutter_model import Net
-    ar_switch(True)
     torch.manual_seed(3)
     net = Net(15, H, 9, 4, conv=1).to(dev)
     _, inputs = _case(9000, 5, dev)
@@ -104,25 +98,20 @@ def test_ar_in_sweep_is_deterministic_and_feeds_autograd(dev, ar_switch):
     for _ in range(3):
         l1, g1, f1 = F.quad_mlp_rollout_grads(net, *inputs, DT, dyn.params)
         assert torch.equal(f1[:-1], f0[:-1]) and torch.equal(l1, l0)
-    outs = []
-    for on in (True, False):
-        ar_switch(on)
-        net.zero_grad()
-        s0 = inputs[0].clone().requires_grad_(True)
-        loss, states, actions = F.quad_mlp_rollout_loss(net, s0, *inputs[1:], DT, dyn.params)
-        (2.5 * loss).backward()
-        outs.append((s0.grad.clone(), states.clone(), actions.clone(),
-                     {k: p.grad.clone() for k, p in net.named_parameters()
-                      if p.grad is not None}))
-    (gs1, st1, ac1, p1), (gs0, st0, ac0, p0) = outs
-    assert torch.equal(st1, st0) and torch.equal(ac1, ac0)
-    assert rel_err(N(gs1), N(gs0)) < 1e-6
-    assert set(p1) == set(p0) == set(g0)
+    net.zero_grad()
+    s0 = inputs[0].clone().requires_grad_(True)
+    loss, states, actions = F.quad_mlp_rollout_loss(net, s0, *inputs[1:], DT, dyn.params)
+    (2.5 * loss).backward()
+    p1 = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    _, gp, _, gs0 = PP.quad_mlp_rollout_grads_planes(net, *inputs, DT, dyn.params,
+                                                     want_state_grad=True)
+    assert rel_err(N(s0.grad), 2.5 * N(gs0)) < 1e-6
+    assert set(p1) == set(gp) == set(g0)
     for k in p1:
         assert torch.allclose(p1[k], 2.5 * g0[k], rtol=1e-6, atol=0), k
 
 
-def test_ar_in_sweep_full_size_bits_and_rows(dev, ar_switch):
+def test_ar_in_sweep_full_size_bits_and_rows(dev):
     """BASELINE configs[2] per rank, 65 536 trajectories: bit-reproducible run
     to run, and every OUTPUT ROW of every parameter gradient as good as float32
     autograd's, the float64 oracle arbitrating (VERDICT r4 next #2a)."""
@@ -131,7 +120,6 @@ def test_ar_in_sweep_full_size_bits_and_rows(dev, ar_switch):
     from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
         FlightmareDynamics)
     from apg_trajectory_tracking_amd.models.hutter_model import Net
-    ar_switch(True)
     B = 65536
     torch.manual_seed(5)
     net = Net(15, H, 9, 4, conv=1)
@@ -150,7 +138,7 @@ def test_ar_in_sweep_full_size_bits_and_rows(dev, ar_switch):
     assert_param_rows_no_worse_than_fp32(got, f32, want, "autoregressive, 65 536")
 
 
-def test_ar_step_through_the_c_abi(dev, ar_switch):
+def test_ar_step_through_the_c_abi(dev):
     """apg_quad_mlp_rollout_train_step called directly (plain pointers): the
     result of the Python entry point; B = 0 zeroes the gradients and the loss;
     argument errors come back as APG_ERR_ARG; the in-kernel SGD update is
@@ -160,7 +148,6 @@ def test_ar_step_through_the_c_abi(dev, ar_switch):
         FlightmareDynamics)
     from apg_trajectory_tracking_amd.models.hutter_model import Net
     lib = _capi.lib()
-    ar_switch(True)
     B = 700
     torch.manual_seed(11)
     net = Net(15, H, 9, 4, conv=1).to(dev)

@@ -95,29 +95,22 @@ def test_parameter_gradient_rows_vs_fp64_at_full_size(dev, mode, case):
     gnet = copy.deepcopy(net).to(dev)
     dyn = FlightmareDynamics()
     s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    import plane_path as PP
     if mode == "concurrent":
         with torch.no_grad():
             normed = state_preprocessing(s0)
-        _, grads, _ = F.quad_concurrent_policy_grads(
-            gnet, normed, s0, in_ref[:, :H].contiguous(), ref[:, :H].contiguous(), DT,
-            dyn.params)
-    else:
-        assert F.AR_IN_SWEEP
-        _, grads, _ = F.quad_mlp_rollout_grads(gnet, s0, in_ref, ref, DT, dyn.params)
-    got = {k: N(v) for k, v in grads.items()}
-    # the same step with the plane + product path: the same cotangents, exact
-    # float accumulation instead of the fixed-point blocks
-    flag = "CONCURRENT_IN_SWEEP" if mode == "concurrent" else "AR_IN_SWEEP"
-    setattr(F, flag, False)
-    try:
-        if mode == "concurrent":
-            _, gp, _ = F.quad_concurrent_policy_grads(
-                gnet, normed, s0, in_ref[:, :H].contiguous(), ref[:, :H].contiguous(), DT,
+        args = (gnet, normed, s0, in_ref[:, :H].contiguous(), ref[:, :H].contiguous(), DT,
                 dyn.params)
-        else:
-            _, gp, _ = F.quad_mlp_rollout_grads(gnet, s0, in_ref, ref, DT, dyn.params)
-    finally:
-        setattr(F, flag, True)
+        _, grads, _ = F.quad_concurrent_policy_grads(*args)
+    else:
+        args = (gnet, s0, in_ref, ref, DT, dyn.params)
+        _, grads, _ = F.quad_mlp_rollout_grads(*args)
+    got = {k: N(v) for k, v in grads.items()}
+    # the same step through the plane + product sequence of rounds 1-4
+    # (tests/plane_path.py): the same cotangents, exact float accumulation instead
+    # of the fixed-point blocks
+    _, gp, _ = (PP.quad_concurrent_policy_grads_planes if mode == "concurrent"
+                else PP.quad_mlp_rollout_grads_planes)(*args)
     planes = {k: N(v) for k, v in gp.items()}
     want = _oracle(net, d, mode, torch.float64)
     f32 = _oracle(net, d, mode, torch.float32)
