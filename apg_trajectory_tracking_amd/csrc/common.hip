@@ -196,6 +196,33 @@ static __global__ __launch_bounds__(256) void stream_rows_probe_kernel(
   }
 }
 
+// shape 7: the rollout's own access pattern without its arithmetic (tools/
+// hbm_probe.hip `stream_rows<28, 10>`, rounds 2-3's yardstick): one trajectory per
+// lane, one wave per workgroup, every lane requests its 28 input rows of 16 bytes
+// ([row][B][4] floats), then stores 10 rows (non-temporal)
+static __global__ __launch_bounds__(64) void stream_rows_lane_kernel(const float *__restrict__ in,
+                                                                    float *__restrict__ out,
+                                                                    int B) {
+  typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  __amdgpu_buffer_rsrc_t ri =
+      __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, 28 * B * 16, 0x00020000);
+  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, 10 * B * 16,
+                                                                0x00020000);
+  u4_ v[28];
+#pragma unroll
+  for (int i = 0; i < 28; ++i)
+    v[i] = __builtin_amdgcn_raw_buffer_load_b128(ri, b * 16, i * B * 16, 0);
+  u4_ acc = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < 28; ++i) acc += v[i];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    acc.x += i;
+    __builtin_amdgcn_raw_buffer_store_b128(acc, ro, b * 16, i * B * 16, 2);
+  }
+}
+
 
 extern "C" {
 
@@ -207,11 +234,22 @@ int apg_stream_rows_probe(const void *in, long long in_bytes, void *out, long lo
                    "0 <= out_bytes <= in_bytes expected");
     return APG_ERR_ARG;
   }
-  if (shape < 1 || shape > 6) {
-    apg::set_error("apg_stream_rows_probe: shape 1..6");
+  if (shape < 1 || shape > 7) {
+    apg::set_error("apg_stream_rows_probe: shape 1..7");
     return APG_ERR_ARG;
   }
   const long long in16 = in_bytes / 16, out16 = out_bytes / 16;
+  if (shape == 7) {
+    const long long B = in16 / 28;
+    if (in16 % 28 || out16 != B * 10 || B % 64 || B > 0x3fffffll) {
+      apg::set_error("apg_stream_rows_probe: shape 7 moves 28 input and 10 output rows of "
+                     "B x 16 bytes, B a multiple of 64");
+      return APG_ERR_ARG;
+    }
+    hipLaunchKernelGGL(stream_rows_lane_kernel, dim3((unsigned)(B / 64)), dim3(64), 0,
+                       (hipStream_t)stream, (const float *)in, (float *)out, (int)B);
+    return apg::check_launch("stream_rows_probe");
+  }
   // smallest group with a whole number of loads and stores (28 : 10 -> 14 : 5)
   long long a = in16, b = out16 > 0 ? out16 : in16;
   while (b) { const long long t = a % b; a = b; b = t; }

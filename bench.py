@@ -711,8 +711,10 @@ def measured_copy_bandwidth(dev):
 
 def stream_floor_probe(args, dev, nsets):
     """the headline launch's bytes - 28 input rows + 10 output
-    rows of B x 16 B - moved by the fastest copy shape of this GPU (one float4 per
-    thread, whole-array grid; csrc/common.hip `stream_rows_probe_kernel`) under
+    rows of B x 16 B - moved without arithmetic, in the fastest copy shape of this
+    GPU (one float4 per thread, whole-array grid; csrc/common.hip
+    `stream_rows_probe_kernel`, six store placements) AND in the rollout's own
+    access pattern (`stream_rows_lane_kernel`: a trajectory per lane), under
     the headline's own protocol: `nsets` rotating buffer sets, 2 000 launches
     replayed from a captured graph, one HIP-event pair on the launch stream.  No arithmetic and no trajectory
     structure: a floor for the rollout kernel's launch, not a model of it."""
@@ -725,7 +727,9 @@ def stream_floor_probe(args, dev, nsets):
     lib = _capi.lib()
     names = {1: "first 10/28 of the threads store, plain", 2: "first 10/28 store, nt",
              3: "stores spread between the loads, plain", 4: "stores spread, nt",
-             5: "as 1, one wave per workgroup", 6: "as 2, one wave per workgroup"}
+             5: "as 1, one wave per workgroup", 6: "as 2, one wave per workgroup",
+             7: "the rollout's own pattern: a trajectory per lane, 28 row loads + "
+                "10 nt row stores per lane, one wave per workgroup"}
     res = {}
     per_graph, replays = 400, 5
     n = per_graph * replays
@@ -735,9 +739,12 @@ def stream_floor_probe(args, dev, nsets):
             _capi.check(lib.apg_stream_rows_probe(
                 ins[i % nsets].data_ptr(), in_bytes, outs[i % nsets].data_ptr(), out_bytes,
                 shape, torch.cuda.current_stream(dev).cuda_stream), "apg_stream_rows_probe")
-        with torch.cuda.stream(side):
-            for i in range(40):
-                run(i)
+        try:
+            with torch.cuda.stream(side):
+                for i in range(40):
+                    run(i)
+        except ValueError:       # (shape 7 is the H = 10 row counts only)
+            continue
         torch.cuda.synchronize()
         # as the headline: the launches replayed from ONE captured graph (a Python /
         # ctypes launch costs about what this kernel takes - the host must not pace it)

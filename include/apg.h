@@ -943,7 +943,11 @@ int apg_stream_copy_shape(const void *src, void *dst, long long bytes, int shape
  * has (one 16-byte element per thread, the whole input as the grid), with no
  * arithmetic.  shape 1 / 2: the first out_bytes/16 threads store (plain /
  * non-temporal); 3 / 4: the stores spread evenly between the loads; 5 / 6: as
- * 1 / 2 with one wave per workgroup. */
+ * 1 / 2 with one wave per workgroup; 7: the rollout's own pattern - one
+ * trajectory per lane, one wave per workgroup, 28 row loads then 10 non-temporal
+ * row stores of 16 bytes per lane (in_bytes = 28 x B x 16, out_bytes = 10 x B x
+ * 16, B a multiple of 64; the shape check of shape 7 is not verified by stores
+ * equal to loads: it writes sums). */
 int apg_stream_rows_probe(const void *in, long long in_bytes, void *out, long long out_bytes,
                           int shape, apg_stream_t stream);
 
