@@ -200,15 +200,6 @@ SIGNATURES = {
         ctypes.POINTER(ApgMlpPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_quad_mlp_workspace_floats": [],
     "apg_quad_mlp_loss_partials_count": [_I],
-    "apg_quad_mlp_rollout_bwd": [
-        _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
-        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy),
-        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
-    "apg_quad_mlp_concurrent_workspace_floats": [],
-    "apg_quad_mlp_concurrent_fwd_bwd": [
-        _P, _P, _P, _P, _I, _F, ctypes.POINTER(ApgQuadParams),
-        ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgMlpPolicy), _I, _I,
-        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_quad_mlp_step_workspace_floats": [],
     "apg_quad_mlp_step_partials_floats": [_I],
     "apg_quad_mlp_concurrent_step": [

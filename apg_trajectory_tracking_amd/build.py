@@ -12,8 +12,8 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libapg_hip.so")
 SOURCES = ["common.hip", "quad.hip", "wing.hip", "cartpole.hip", "lstm.hip",
-           "mlp.hip", "mlp_wing.hip", "wing_learnt.hip", "linear_wgrad.hip",
-           "planes_gemm.hip"]
+           "mlp_rollout.hip", "mlp_concurrent.hip", "mlp_wing.hip", "wing_learnt.hip",
+           "linear_wgrad.hip", "planes_gemm.hip"]
 # -fno-slp-vectorize: hipcc's SLP pass packs neighbouring f32 ops into
 # v_pk_fma/mul/add_f32; on gfx950 a packed op issues no faster than two plain
 # ones here and needs v_mov shuffles to form register pairs - measured on
@@ -116,6 +116,34 @@ def build_cpu(force=False, verbose=False):
     return LIB_CPU
 
 
+LIB_PLANES = os.path.join(CSRC, "libapg_planes.so")
+
+
+def build_planes(force=False, verbose=False):
+    """libapg_planes.so (include/apg_planes.h): the plane-writing reverse kernels
+    of rounds 1-4 behind their C entry points - a TEST library (tests/
+    plane_path.py loads it; the package never does): the product has one reverse
+    kernel per training mode.  mlp_planes.hip + common.hip (error plumbing, the
+    loss reduction), self-contained (-Bsymbolic: its own copies of the shared
+    helpers whatever else the process has loaded)."""
+    srcs = [os.path.join(CSRC, s) for s in ("mlp_planes.hip", "common.hip")]
+    deps = srcs + [os.path.join(REPO, "include", "apg_planes.h"), __file__] + _headers()
+    if (not force and os.path.exists(LIB_PLANES)
+            and os.path.getmtime(LIB_PLANES) >= max(os.path.getmtime(d) for d in deps)):
+        return LIB_PLANES
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *COMMON_FLAGS,
+           "-shared", "-Wl,-Bsymbolic", "-I", os.path.join(REPO, "include"), "-I", CSRC,
+           "-o", LIB_PLANES, *srcs]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on mlp_planes.hip:\n{r.stdout}")
+    return LIB_PLANES
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_cpu(force="--force" in sys.argv, verbose=True))
+    print(build_planes(force="--force" in sys.argv, verbose=True))

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
 // ------------------------------------------------------ closed-loop evaluation
 // N2 for the LSTM controller: QuadEvaluator.follow_trajectory
 // ("rand", scripts/evaluate_drone.py:81-194) for a batch of reference
-// trajectories - see mlp_closed_loop_kernel (mlp.hip) for the loop; here the
+// trajectories - see mlp_closed_loop_kernel (mlp_rollout.hip) for the loop; here the
 // hidden / cell state is carried through all steps (it is reset once per
 // evaluator, evaluate_drone.py:56-58, never on a divergence).
 struct LoopArgs {
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kTailThreads) void lstm_step_tail_kernel(TailArgs A
     const int q = qs[k], e = es[k];
     if (q < 0) continue;
     if (q == 0 || q == 2 || q == 3 || (q == 5 && grd[5] != grd[4])) grd[q][e] = g[k];
-    if (t.update) {        // torch.optim.SGD in double, one rounding each (mlp.hip)
+    if (t.update) {        // torch.optim.SGD in double, one rounding each (mlp_common.h)
       const float buf = (float)(t.momentum * (double)m_old[k] + (double)g[k]);
       mom[q][e] = buf;
       par[q][e] = (float)((double)p_old[k] - t.lr * (double)buf);

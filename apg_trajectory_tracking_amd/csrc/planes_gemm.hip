@@ -1,6 +1,6 @@
 // planes_gemm.hip - "planes x planes" reduction GEMM on the matrix cores.
 //
-// The weight gradients of the in-kernel policies (lstm.hip, mlp.hip) are
+// The weight gradients of the in-kernel policies (lstm.hip, mlp_wing.hip; mlp_planes.hip of the test library) are
 //   C[m][j] = sum_{s < S} sum_{n < N} A[(m*S + s)][n] * B[bplane(j, s)][n]
 //   bplane(j, s) = bdesc[0][j] + (s / sdiv) * bdesc[1][j] + (s % sdiv) * bdesc[2][j]
 // with small M (<= 64), small J (<= 192) and an enormous reduction length

@@ -1,4 +1,4 @@
-// policy_mfma.h - building blocks shared by the in-kernel policies (mlp.hip,
+// policy_mfma.h - building blocks shared by the in-kernel policies (mlp_rollout.hip, mlp_concurrent.hip,
 // lstm.hip, mlp_wing.hip): one wave = 32 trajectories, the layers on 32 x 32
 // matrix-core tiles.
 //

@@ -1,5 +1,5 @@
 // policy_tm.h - trajectory-major weight products inside the reverse sweeps
-// (mlp.hip: the concurrent and the autoregressive step; lstm.hip: the LSTM step).
+// (mlp_concurrent.hip / mlp_rollout.hip: the concurrent and the autoregressive step).
 //
 // dW[m][k] = sum_n delta[m][n] x[k][n] is a matrix product whose reduction index
 // is the trajectory.  The sweeps hold trajectories in the lane; the matrix

@@ -1354,7 +1354,7 @@ def quad_lstm_rollout_loss(net, state0, in_ref, ref, dt, params, h0, c0,
 # ------------------------------- fused autoregressive MLP-policy unroll (K8)
 class _QuadMlpRolloutLoss(torch.autograd.Function):
     """loss of the autoregressive unroll with the MLP policy inside the
-    kernel (apg_quad_mlp_rollout_fwd / _bwd, matrix cores).  Same contract as
+    kernel (apg_quad_mlp_rollout_train_step, matrix cores).  Same contract as
     _QuadLstmRolloutLoss; the network is hutter_model.Net(15, 10, 9, 4,
     conv=1)."""
 
@@ -1692,9 +1692,9 @@ def _step_events(events):
 
 class _QuadConcurrentPolicyLoss(torch.autograd.Function):
     """loss of the concurrent training step with `Net(15, 10, 9, 40, conv=1)`
-    inside the kernels (apg_quad_mlp_concurrent_fwd_bwd): policy once per
-    trajectory, rollout + quad_mpc_loss + adjoint, policy reverse pass;
-    backward() = the weight-gradient products over the batch."""
+    inside the kernels (apg_quad_mlp_concurrent_train_step): policy once per
+    trajectory, rollout + quad_mpc_loss + adjoint, policy reverse pass with every
+    weight gradient inside; backward() scales them by the upstream cotangent."""
 
     @staticmethod
     def forward(ctx, normed, state0, in_ref, ref, w_s, b_s, conv_w, conv_b, w_1,

@@ -288,7 +288,7 @@ class TrainDrone(TrainBase):
         probe=False, prepared=None, slot=0, events=None
     ):
         """scripts/train_base.py:198-204 + scripts/train_drone.py:175-203 with
-        the policy inside the kernels (apg_quad_mlp_concurrent_fwd_bwd).
+        the policy inside the kernels (apg_quad_mlp_concurrent_train_step).
         `prepared`: functional.quad_concurrent_prepare's result for this batch
         (see train_recurrent_model)."""
         n = self.net

@@ -253,7 +253,7 @@ def cpu_baseline(args, gpu_set0=None):
 # with the others), its algorithmic
 # plane traffic against 8 TB/s, and the achieved fraction of the LARGER of the
 # two floors.  Per-wave MFMA counts are the kernels' static instruction counts
-# (hipcc -S of csrc/mlp.hip, lstm.hip; one wave = 32 trajectories, one fp16
+# (hipcc -S of csrc/mlp_rollout.hip / mlp_concurrent.hip, lstm.hip; one wave = 32 trajectories, one fp16
 # MFMA = 32 x 32 x 16 x 2 flop); plane bytes are the planes
 # the sweeps write / read once plus one more read by the products
 # (measured FETCH / WRITE equal these counts).

@@ -12,11 +12,49 @@ mode (weight gradients inside the reverse sweeps); this module hangs the plane
 sequence into the autograd Functions' forward through a context hook
 (`ctx.plane_tail`) that nothing in the package sets."""
 import ctypes
+import os
 
 import torch
 
-from apg_trajectory_tracking_amd import functional as F
-from apg_trajectory_tracking_amd._capi import check, lib, ptr, stream_of
+from apg_trajectory_tracking_amd import _capi, functional as F
+from apg_trajectory_tracking_amd._capi import lib, ptr, stream_of
+
+# libapg_planes.so (include/apg_planes.h, csrc/mlp_planes.hip): the plane-writing
+# reverse kernels - a test library built next to the product's, loaded HERE only
+_P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+PLANES_LIB = os.path.join(os.path.dirname(_capi.LIB_PATH), "libapg_planes.so")
+PLANES_SIGNATURES = {
+    "apg_quad_mlp_rollout_bwd": [
+        _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(_capi.ApgQuadParams),
+        ctypes.POINTER(_capi.ApgQuadLossWeights), ctypes.POINTER(_capi.ApgMlpPolicy),
+        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_mlp_concurrent_workspace_floats": [],
+    "apg_quad_mlp_concurrent_fwd_bwd": [
+        _P, _P, _P, _P, _I, _F, ctypes.POINTER(_capi.ApgQuadParams),
+        ctypes.POINTER(_capi.ApgQuadLossWeights), ctypes.POINTER(_capi.ApgMlpPolicy), _I, _I,
+        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+}
+_planes = None
+
+
+def planes_lib():
+    global _planes
+    if _planes is None:
+        if not os.path.exists(PLANES_LIB):
+            raise RuntimeError(f"{PLANES_LIB} not found: python -m apg_trajectory_tracking_amd.build")
+        h = ctypes.CDLL(PLANES_LIB)
+        for name, argtypes in PLANES_SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes, fn.restype = argtypes, ctypes.c_int
+        h.apg_last_error_string.restype = ctypes.c_char_p
+        _planes = h
+    return _planes
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed ({code}): "
+                           f"{planes_lib().apg_last_error_string().decode()}")
 
 
 def _mlp_param_grads(saved, dims, n_out, conv=None):
@@ -80,7 +118,7 @@ def _ar_plane_tail(ctx, v):
     """apg_quad_mlp_rollout_fwd + _bwd: cotangent planes for the products."""
     new, B, H, N, st = v["new"], v["B"], v["H"], v["N"], v["st"]
     ws = new(lib().apg_quad_mlp_workspace_floats())
-    check(lib().apg_quad_mlp_rollout_fwd(
+    _capi.check(lib().apg_quad_mlp_rollout_fwd(
         ptr(v["s0"]), ptr(v["inr"]), float(v["dt"]), ctypes.byref(v["params"]),
         ctypes.byref(v["pol"]), B, H, ptr(v["states"]), ptr(v["actions"]), ptr(v["feat"]),
         ptr(v["x1"]), ptr(v["h"]), v["relu_mask"].data_ptr(), ptr(ws), st),
@@ -90,7 +128,7 @@ def _ar_plane_tail(ctx, v):
     d_pre, d_zout, d_conv = new(256, N), new(4, N), new(F._CONV_DIAG_PLANES, B)
     rf = v["rf"]
     ctx.g_s0 = new(12, B)         # dL/dstate0 planes
-    check(lib().apg_quad_mlp_rollout_bwd(
+    check(planes_lib().apg_quad_mlp_rollout_bwd(
         ptr(v["s0"]), ptr(v["states"]), ptr(v["actions"]), ptr(rf), rf.shape[1], ptr(v["x1"]),
         ptr(v["h"]), v["relu_mask"].data_ptr(), float(v["dt"]), ctypes.byref(v["params"]),
         ctypes.byref(v["weights"]), ctypes.byref(v["pol"]), B, H, ptr(partials),
@@ -107,9 +145,9 @@ def _conc_plane_tail(ctx, v):
     new, B, H = v["new"], v["B"], v["H"]
     cot = new(40 + 256 + 160, B)      # d_zout | d_pre | d_conv
     d_zout, d_pre, d_conv = cot[:40], cot[40:296], cot[296:]
-    ws = new(lib().apg_quad_mlp_concurrent_workspace_floats())
+    ws = new(planes_lib().apg_quad_mlp_concurrent_workspace_floats())
     rf = v["rf"]
-    check(lib().apg_quad_mlp_concurrent_fwd_bwd(
+    check(planes_lib().apg_quad_mlp_concurrent_fwd_bwd(
         ptr(v["feat"]), ptr(v["inr"]), ptr(v["s0"]), ptr(rf), rf.shape[1], float(v["dt"]),
         ctypes.byref(v["params"]), ctypes.byref(v["weights"]), ctypes.byref(v["pol"]), B, H,
         ptr(v["x1"]), ptr(v["h"]), v["relu_mask"].data_ptr(), ptr(d_zout), ptr(d_pre),

@@ -1,5 +1,5 @@
 """Round 4: the concurrent training step with its weight gradients accumulated
-INSIDE the reverse kernel (apg_quad_mlp_concurrent_step; csrc/mlp.hip,
+INSIDE the reverse kernel (apg_quad_mlp_concurrent_step; csrc/mlp_concurrent.hip,
 mlp_concurrent_bwd_tm_kernel) - no cotangent planes, no second pass of
 products.  One loss.backward() of the reference yields every parameter
 gradient (scripts/train_drone.py:175-203); this path must too, to the same

@@ -1,6 +1,6 @@
 """Round 5: the autoregressive training step with its weight gradients
 accumulated INSIDE the reverse sweep (apg_quad_mlp_rollout_train_step;
-csrc/mlp.hip, mlp_rollout_bwd_tm_kernel) - no cotangent planes, no
+csrc/mlp_rollout.hip, mlp_rollout_bwd_tm_kernel) - no cotangent planes, no
 planes_gemm launches.  One loss.backward() of the reference yields every
 parameter gradient (scripts/train_drone.py:113-173); this path must too, to the
 same 1e-4 as the plane + product path it replaced (rounds 1-4; an independent

@@ -1093,3 +1093,31 @@ def test_graph_capture_only_where_zero_state_is_fresh_state():
             o.step()
             outs.append(q.detach().clone())
         assert torch.equal(*outs) == same
+
+
+def test_planes_test_library_exports_its_header_and_the_product_does_not():
+    """Round 6: the plane-writing reverse kernels of rounds
+    1-4 are a TEST library - libapg_planes.so exports every function
+    include/apg_planes.h declares, libapg_hip.so none of them, and the package's
+    ctypes table does not know them (tests/plane_path.py binds them itself)."""
+    from apg_trajectory_tracking_amd import _capi, build
+    text = open(os.path.join(REPO, "include", "apg_planes.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(apg_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["apg_quad_mlp_concurrent_fwd_bwd", "apg_quad_mlp_concurrent_workspace_floats",
+                     "apg_quad_mlp_rollout_bwd"]
+    planes = ctypes.CDLL(build.build_planes())
+    product = _capi.lib()
+    for n in names:
+        assert hasattr(planes, n), n
+        assert not hasattr(product, n), f"{n} is still in libapg_hip.so"
+        assert n not in _capi.SIGNATURES
+    sys_path = os.path.join(REPO, "tests")
+    import sys
+    sys.path.insert(0, sys_path)
+    try:
+        import plane_path
+        assert set(plane_path.PLANES_SIGNATURES) == set(names)
+        assert plane_path.planes_lib() is not None
+    finally:
+        sys.path.remove(sys_path)

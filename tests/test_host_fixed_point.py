@@ -1,5 +1,5 @@
 """The numerics contract of the trajectory-major reverse kernel's accumulators
-(csrc/mlp.hip, mlp_concurrent_bwd_tm_kernel), modelled on the host: operands
+(csrc/mlp_concurrent.hip, mlp_concurrent_bwd_tm_kernel), modelled on the host: operands
 scaled into [-1, 1] by the workgroup's exponents, split into two fp16 terms,
 three products per term pair accumulated in fp32 per wave (32 trajectories),
 rounded to 32-bit fixed point (unit 2^-22, folded into the operand scales as

@@ -3,7 +3,7 @@
 // trajectory in the lane, feature in the registers) into the orientation the
 // WEIGHT PRODUCT needs (feature in the lane, trajectories in the k-slots of the
 // A operand), inside a reverse sweep like mlp_rollout_bwd_tm_kernel /
-// mlp_concurrent_bwd_tm_kernel (csrc/mlp.hip)?
+// mlp_concurrent_bwd_tm_kernel (csrc/mlp_rollout.hip, mlp_concurrent.hip)?
 //
 // One 64 x 64 tanh layer over B = 65 536 trajectories, workgroups of 8 waves
 // (32 trajectories per wave), one workgroup per CU, the kernels' own building
