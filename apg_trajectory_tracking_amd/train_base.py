@@ -328,6 +328,11 @@ _CONFIG_DEFAULTS = dict(
 
 class TrainBase:
 
+    # default of `measure_launch_form` for new trainers (the test suite pins it to
+    # False: whether a step replays a graph must not depend on the box's timing
+    # where the graph form itself is under test - tests/conftest.py)
+    MEASURE_LAUNCH_FORM = True
+
     def __init__(self, train_dynamics, eval_dynamics, **config):
         cfg = {k: config.get(k, d) for k, d in _CONFIG_DEFAULTS.items()}
         system, save_name = cfg.pop("system"), cfg.pop("save_name")
@@ -403,7 +408,7 @@ class TrainBase:
         # form is kept and recorded in results_dict["launch_form"].
         # `launch_form[train_mode]` = "graph" | "eager" pins the answer.
         self.launch_form = {}
-        self.measure_launch_form = True
+        self.measure_launch_form = type(self).MEASURE_LAUNCH_FORM
         self.launch_form_steps = 10
         # True: a graphed step returns the captured loss buffer itself - valid
         # until the NEXT step overwrites it (run_epoch's loops take it that

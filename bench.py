@@ -270,7 +270,10 @@ STEP_MODELS = {
     # blocks, transposed product, chain), fc3 / fc2 24 + 24 + 24 each, fc1 84 +
     # 24 + 12 (its 14 blocks, states_in's cotangent and blocks) + conv 5 x (12 +
     # 18).  (The staged kernel: 150 + 248.)
-    "concurrent": dict(mfma_once=222 + 474, mfma_per_step=0, products_in_sweep=True,
+    # Round 6: the weight blocks' A operands by identity transposition instead of
+    # a second, swapped chain: 442 (PMC, SQ_INSTS_MFMA per wave:
+    # profiles/r06_pmc_concurrent_step.txt).
+    "concurrent": dict(mfma_once=222 + 442, mfma_per_step=0, products_in_sweep=True,
                        # forward writes 431 planes; reverse reads 256 (tanh') +
                        # 521 (x of the products) + 80 (d_zout twice) planes and
                        # writes 30 x 4 KB of partials per 256 trajectories, read
@@ -286,7 +289,10 @@ STEP_MODELS = {
     # s1 24 + 24 + 24 + 8 + 2 + states_in 12 + 12, the feature-major conv
     # cotangent 60, five conv blocks of 12 + 12 + 1 + 18.  (Rounds 3-4: 198 +
     # 144 + the nine plane products.)
-    "autoregressive": dict(mfma_once=0, mfma_per_step=198 + 571, products_in_sweep=True,
+    # Round 6: ONE chain orientation (identity transposition for head, fc3, fc2,
+    # fc1 and states_in; the conv blocks keep the swapped product): 525 per wave
+    # and step (PMC: 5 250 per wave over the ten steps, profiles/r06_pmc_ar_step.txt).
+    "autoregressive": dict(mfma_once=0, mfma_per_step=198 + 525, products_in_sweep=True,
                            # fwd writes 436 planes + states / actions (1 808 B per
                            # env-step); the reverse sweep reads the 431
                            # activation planes trajectory-major + masks, states,

@@ -219,3 +219,19 @@ def oracle_wing_closed_loop(net, targets, dt, params, mean, std, data_dt=0.05,
         res.update(drone=out["traj"].permute(1, 2, 0).contiguous(),
                    seen=out["seen"].permute(1, 2, 0).contiguous())
     return res
+
+
+@pytest.fixture(autouse=True)
+def _launch_form_is_not_left_to_timing():
+    """TrainBase measures at a mode's first capture whether graph replays or
+    stream-order launches are faster ON THIS BOX and keeps the faster form
+    (tests/test_gpu_round5.py tests that, setting `measure_launch_form` itself).
+    Everywhere else a test that asks for `graph_steps` means the graph form: the
+    default is pinned off, so that `trainer._graphs` does not depend on timing
+    (seen once in round 6: the autoregressive step of a small batch chose stream
+    order on one box and `test_static_shard_keeps_plane_copies...` failed)."""
+    from apg_trajectory_tracking_amd.train_base import TrainBase
+    before = TrainBase.MEASURE_LAUNCH_FORM
+    TrainBase.MEASURE_LAUNCH_FORM = False
+    yield
+    TrainBase.MEASURE_LAUNCH_FORM = before
