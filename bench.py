@@ -499,15 +499,18 @@ def trainer_step_probe(args, dev, dyn, dist, mode):
         # message and optimizer slot unchanged; all GPUs busy at once): what the
         # all-reduce costs THIS step on THIS node
         from apg_trajectory_tracking_amd import parallel
-        with parallel.collectives_suspended():
-            out["ms_per_step_no_collective"], _, _ = timed_steps(
-                step, max(8, args.train_steps // 2), dist)
-        parallel.broadcast_module(t.net)      # (the replicas drifted: lr 1e-9, but still)
-        out["parallel_efficiency"] = out["ms_per_step_no_collective"] / ms
-        out["parallel_efficiency_what"] = (
-            "N-rank step without its all-reduce / N-rank step, same ranks, same "
-            "process; <= 1.  The driver computes the curve's own efficiency from "
-            "`value` at N = 1, 2, 4, 8")
+        try:
+            with parallel.collectives_suspended():
+                out["ms_per_step_no_collective"], _, _ = timed_steps(
+                    step, max(8, args.train_steps // 2), dist)
+            parallel.broadcast_module(t.net)  # (the replicas drifted: lr 1e-9, but still)
+            out["parallel_efficiency"] = out["ms_per_step_no_collective"] / ms
+            out["parallel_efficiency_what"] = (
+                "N-rank step without its all-reduce / N-rank step, same ranks, same "
+                "process; <= 1.  The driver computes the curve's own efficiency from "
+                "`value` at N = 1, 2, 4, 8")
+        except Exception as e:        # (this leg must not cost the block its numbers)
+            out["parallel_efficiency"] = {"error": repr(e)}
     t.borrow_loss = False
     out["ms_per_step_private_loss"], _, _ = timed_steps(
         step, max(8, args.train_steps // 2), dist)
@@ -1262,7 +1265,7 @@ def steps_summary(out):
             s[name] = {"ms": r4(blk["ms_per_step"]),
                        "frac_vs_mfma_floor": r4(rf.get("frac_vs_mfma_floor")),
                        "bytes_ratio": r4(rf.get("plane_bytes_over_algorithmic"))}
-            if "parallel_efficiency" in blk:
+            if isinstance(blk.get("parallel_efficiency"), float):
                 s[name]["parallel_efficiency"] = r4(blk["parallel_efficiency"])
                 s[name]["global_batch"] = blk.get("global_batch")
     sec = out.get("secondary") if isinstance(out.get("secondary"), dict) else {}
