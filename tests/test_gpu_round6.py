@@ -275,3 +275,44 @@ def test_lstm_resident_tables_notice_foreign_writes(dev):
     assert tab().packs == 3
     for a, b in zip(t.net.parameters(), ref.net.parameters()):
         assert torch.equal(a, b)
+
+
+def test_config2_eight_shards_summed_equal_the_whole_batch(dev):
+    """BASELINE configs[2] / SURVEY §8(e) "verification", on ONE GPU: the
+    autoregressive step's loss and every parameter gradient of a 524 288-trajectory
+    batch (a) as eight contiguous shards of 65 536 - what the eight ranks compute -
+    summed in rank order (what the all-reduce(sum) of the flat message does: the
+    reference's losses are sums over the batch, so no rescaling) and (b) as ONE call
+    on the whole batch (beyond the per-launch limit: processed in chunks).  Same
+    policy, same data: rel. error <= 1e-5 (float32 summation order only)."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.parallel import shard_range
+    B, world = 524288, 8
+    torch.manual_seed(12)
+    net = Net(15, H, 9, 4, conv=1).to(dev)
+    d = synthetic.quad_polynomial_batch(B, H, DT, seed=40, ref_length=2 * H)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    dyn = FlightmareDynamics()
+    flat_sum = None
+    for r in range(world):
+        lo, hi = shard_range(B, r, world)
+        assert hi - lo == 65536
+        loss, gr, flat = F.quad_mlp_rollout_grads(
+            net, s0[lo:hi].contiguous(), in_ref[lo:hi].contiguous(), ref[lo:hi].contiguous(),
+            DT, dyn.params)
+        flat = flat.clone()
+        flat[-1] = loss.reshape(())          # the message: gradients + loss slot
+        flat_sum = flat.double() if flat_sum is None else flat_sum + flat.double()
+    names = [(k, v.numel()) for k, v in gr.items()]
+    loss_w, gr_w, flat_w = F.quad_mlp_rollout_grads(net, s0, in_ref, ref, DT, dyn.params)
+    assert abs(flat_sum[-1].item() - loss_w.item()) <= 1e-5 * abs(loss_w.item())
+    off = 0
+    for k, n in names:
+        got = flat_sum[off:off + n].cpu().numpy()
+        want = gr_w[k].double().reshape(-1).cpu().numpy()
+        assert rel_err(got, want) < 1e-5, (k, rel_err(got, want))
+        off += n
+    assert off + 1 == flat_sum.numel()
