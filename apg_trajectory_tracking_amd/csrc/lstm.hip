@@ -33,6 +33,7 @@
 #include "apg_device.h"
 #include "policy_mfma.h"
 #include "policy_mfma16.h"
+#include "policy_tm.h"
 #include "quad_math.h"
 #include "learnt_residual.h"
 
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   const Planes Ps0(A.state0, 12, pitchB), Pin(A.in_ref, 2 * kH * kRD, pitchB);
   const Planes Ph0(A.h0, kNH, pitchB), Pc0(A.c0, kNH, pitchB);
   const Planes Pst(A.states, kH * 12, pitchB), Pac(A.actions, kH * 4, pitchB);
-  const Planes Px(A.x, kNX, pitchN), Pg(A.gates, kNG, pitchN);
+  const Planes Px(A.x, kNF, pitchN), Pg(A.gates, kNG, pitchN);
   const Planes Phc(A.hc, 2 * kNH, pitchN), Phn(A.hnew, kNH, pitchN);
   const Planes Pmk(A.mask, 5, pitchN);
   const unsigned vb = live ? (unsigned)b * 4u : kDead;
@@ -205,7 +206,6 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
     const unsigned col = (unsigned)b * 4u + (unsigned)k * pitchB;  // column k*B + b
     const unsigned vn_lo = st_lo ? col : kDead;
     const unsigned vr = live ? col + (hi ? 4u * pitchN : 0u) : kDead;   // + row 4 hi
-    const unsigned vc = live ? col + (hi ? 32u * pitchN : 0u) : kDead;  // + channel 4 hi
     const unsigned vm = live ? col + (hi ? pitchN : 0u) : kDead;        // + mask word hi
     const Trig t = make_trig(&s[3]);
     float feat[kNF];
@@ -274,10 +274,9 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
         for (int i = 0; i < 12; ++i) {  // rows r(i) + 4 hi < 20 are real channels
           float v = cv[i];
           mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
-          v = fmaxf(v, 0.f);
-          // plane 15 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
-          Px.st(i < 8 ? vc : vn_lo, (kNF + rrow(i) * kNP + pos) * pN, v);
-          rv[e * 12 + i] = v;
+          // (round 6: relu(conv) is NOT stored - 160 of the 236 planes this
+          // sweep wrote; lstm_gate_wgrad_kernel recomputes it from the window)
+          rv[e * 12 + i] = fmaxf(v, 0.f);
         }
       }
 #pragma unroll
@@ -903,6 +902,316 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
   write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
 }
 
+// --------------------------------------------------- gate weight gradients
+// Round 6.  [dW_ih | dW_hh] = d_gates [x ; h_prev]^T was a
+// stream product over 183 planes of H*B columns (480 MB at B = 65 536, 112 us)
+// of which the 160 relu(conv) columns are a function of the reference window -
+// 90 numbers per column that the forward sweep read from planes a tenth that
+// size.  This kernel forms the same sums WITHOUT those columns in memory, and
+// the forward sweep no longer writes them (it was bound by exactly these
+// stores).  The reduction index of a weight gradient is the trajectory, so the
+// products run trajectory-major (policy_tm.h):
+//   * conv with the operands of the forward sweep SWAPPED: the window slots of
+//     the lane's trajectory as A operand, the conv weight blocks of the forward
+//     tables as B - the accumulator then holds channel (lane & 31) of the 16
+//     trajectories r(i) + 4 hi in its registers: after bias + relu it IS the
+//     B operand (k-slot = trajectory) of the product, no transposition;
+//   * d_gates as A operand: gate row (lane & 31), the trajectories as four
+//     16-byte loads of that plane (TBlock), scaled by the wave's running
+//     power of two (block floating point: the accumulators are rescaled when a
+//     step's largest |d_gates| exceeds it) and split into two fp16 terms.
+// A workgroup is 8 waves x 2 groups of 32 trajectories, all ten steps of each;
+// the window positions are shared between two workgroups (PH = blockIdx & 1:
+// positions 4 PH .. 4 PH + 3: four 32 x 32 accumulators per lane) so that two
+// waves per SIMD fit the register file.  The fifth accumulator takes the columns
+// that ARE in memory: PH 0 [15 features | h_prev | 1] against d_gates (dW_ih's
+// first 15 columns, dW_hh, db), PH 1 [h_new | 1] against d_zout (the head's
+// dW_out, db_out - the product that was a launch of its own).  The waves of a
+// workgroup add up in wave order in LDS, lstm_gate_wgrad_reduce_kernel sums the
+// workgroups in index order: bit-reproducible.
+constexpr int kGwThreads = 512, kGwWaves = kGwThreads / 64, kGwGroups = 2;
+constexpr int kGwBlocks = 5;                      // accumulators per lane: 4 positions + 1
+constexpr int kGwPart = kGwBlocks * 16 * 64;      // one workgroup's partial: 5 120 floats
+constexpr int kGwTab = (hA + (nC + 2) * kBlock16) / 4;  // forward tables through the conv blocks
+constexpr int kGwActs = kNF + 3 * kNH;            // acts planes: 15 | 8 + 8 | 8
+constexpr int kGwNoExp = -100000;
+
+struct GwArgs {
+  const float *state0, *states, *in_ref;
+  const float *acts;      // [39][N]: features | h_prev, c_prev | h_new
+  const float *d_gates, *d_zout;
+  const float *tables;    // forward tables (lstm_pack_fwd16_kernel)
+  float *partials;        // [workgroups][kGwPart]
+  int B;
+};
+
+// the values of trajectories >= nvalid of a trajectory-major block: somebody
+// else's columns (TBlock) - they must meet zeros
+__device__ __forceinline__ void mask_tail(float (&v)[16], int hi, int nvalid) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (rrow(i) + 4 * hi >= nvalid) v[i] = 0.f;
+}
+
+// running block exponent: e = exponent above this step's largest |v| in the wave;
+// the accumulators `acc[0..n)` follow when it grows.  Returns the exponent in use.
+template <int N>
+__device__ __forceinline__ int block_exponent(const float (&v)[16], int &E, f32x16 *acc) {
+  unsigned m = 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m = umax_abs(m, v[i]);
+  m = wave_umax(m);
+  bool bad = false;   // (a non-finite cotangent goes through the products as it is)
+  const int e = bits_exp(m, bad, false);
+  if (e > E) {
+    if (E != kGwNoExp) {
+      const int d = E - e;
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = __builtin_amdgcn_ldexpf(acc[n][i], d);
+    }
+    E = e;
+  }
+  return E;
+}
+
+// relu of a matrix-pipe result in ONE instruction: the signed-integer maximum of
+// the bit pattern and 0 (negative floats are negative integers).  fmaxf and
+// fmed3 canonicalise their input first (a second v_max per value); inline
+// assembly is no option: the compiler's hazard recognizer does not see a
+// matrix-pipe result read by an asm statement and leaves out the wait states
+// (measured: stale accumulators).
+__device__ __forceinline__ float relu1(float v) {
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// what a step reads: issued one step ahead, right after the previous step's
+// blocks have been split
+struct GwLoads {
+  TBlock tg, ta, tz;
+  float pos[3];
+};
+// The sliding reference window of a lane (6 rows x 5 columns, raw) lives in LDS,
+// [slot of 7][column][wave][lane], written by direct-to-LDS loads: the row that
+// slides in for step k + 1 is fetched during step k into the seventh slot and
+// costs no registers on the way.  Row k + r (relative to 4 PH) is in slot
+// (k + r) % 7.
+constexpr int kGwSlots = 7;
+constexpr int kGwWin = kGwSlots * 5 * kGwThreads;   // floats
+
+template <int PH>
+__device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // tables | window | sum
+  float *const win = lds + kGwTab, *const red = lds + kGwTab + kGwWin;
+  const int lane = threadIdx.x & 63, hi = lane >> 5, row = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const LdsView16 L16(lds, lane);
+  const int B = A.B;
+  const unsigned pitchB = (unsigned)B * 4u, pitchN = pitchB * kH;
+  const Planes Ps0(A.state0, 12, pitchB), Pst(A.states, kH * 12, pitchB);
+  const Planes Pin(A.in_ref, 2 * kH * kRD, pitchB);
+  const Planes Pac(A.acts, kGwActs, pitchN), Pdg(A.d_gates, kNG, pitchN);
+  const Planes Pdz(A.d_zout, 4, pitchN);
+  // conv bias of THIS lane's channel (the table is in accumulator order)
+  const float cb = lds[hTbc + 2 * ((row & 3) + 4 * (row >> 3)) + ((row >> 2) & 1)];
+  // the fifth block's B operand: plane of column `row`, or the ones column
+  constexpr int kAuxCols = PH == 0 ? kNF + kNH : kNH, kAuxPlane0 = PH == 0 ? 0 : kNF + 2 * kNH;
+  const bool aux_row = row < kAuxCols, ones_row = row == kAuxCols;
+
+  f32x16 acc[kGwBlocks];
+#pragma unroll
+  for (int n = 0; n < kGwBlocks; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  int E = kGwNoExp, E2 = kGwNoExp;   // block exponents of d_gates / d_zout
+
+#pragma unroll 1
+  for (int gi = 0; gi < kGwGroups; ++gi) {
+    const int b0 = (((blockIdx.x >> 1) * kGwWaves + wave) * kGwGroups + gi) * 32;
+    if (b0 >= B) break;   // (wave-uniform; the wave still takes part in the sum below)
+    const int nvalid = B - b0;
+    const int b = b0 + row;
+    const bool live = b < B;
+    const unsigned vb = live ? (unsigned)b * 4u : kDead;
+    const unsigned vb_u = live ? vb + (hi ? 4u * pitchB : 0u) : kDead;  // window column + 4 hi
+    // trajectory-major blocks: the lane's plane, trajectories b0 + 4 hi ..; the WHOLE
+    // offset sits in the VGPR, so the buffer's range check covers the ragged tail
+    const unsigned tcol = (unsigned)b0 * 4u + (unsigned)hi * 16u;
+    const unsigned vg = (unsigned)row * pitchN + tcol;
+    const unsigned va = (unsigned)(kAuxPlane0 + (aux_row ? row : 0)) * pitchN + tcol;
+
+    // window row r (relative to 4 PH) -> its slot, straight into LDS
+    auto row_in = [&](int r, unsigned pB) {
+      const int slot = r % kGwSlots;
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            Pin.rsrc, (lds_ptr_t)(win + ((slot * 5 + j) * kGwWaves + wave) * 64), 4, (int)vb_u,
+            (int)(((r + 4 * PH) * kRD + j) * pB), 0, 0);
+    };
+    GwLoads ld;
+    auto issue = [&](int k) {   // the loads of step k (window: the row that slides in)
+      const unsigned pB = opaque(pitchB);
+      const unsigned kcol = (unsigned)k * pB;
+      ld.tg.load(Pdg, vg + kcol, 0u);
+      ld.ta.load(Pac, aux_row ? va + kcol : kDead, 0u);
+      if (PH == 1) ld.tz.load(Pdz, row < 4 ? vg + kcol : kDead, 0u);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)   // the current position: the state BEFORE step k
+        ld.pos[j] = k > 0 ? Pst.ld(vb, ((k - 1) * 12 + j) * pB) : Ps0.ld(vb, j * pB);
+      if (k > 0) row_in(k + 5, pB);
+    };
+    for (int r = 0; r < 6; ++r) row_in(r, pitchB);
+    issue(0);
+
+    int s0 = 0;   // k % 7
+#pragma unroll 1
+    for (int k = 0; k < kH; ++k) {
+      // everything issued for this step has landed (registers and LDS)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      typedef const volatile __attribute__((address_space(3))) float *win_ptr_t;
+      win_ptr_t wr[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int slot = s0 + r >= kGwSlots ? s0 + r - kGwSlots : s0 + r;
+        wr[r] = (win_ptr_t)(lds_ptr_t)lds + (kGwTab + (slot * 5 * kGwWaves + wave) * 64 + lane);
+      }
+      s0 = s0 + 1 == kGwSlots ? 0 : s0 + 1;
+      const float sub[3] = {hi ? 0.f : ld.pos[0], hi ? 0.f : ld.pos[1], hi ? 0.f : ld.pos[2]};
+      // d_gates of the step: scaled, split; the fifth block's operands
+      Op16 ad[2], bx[2], az[2];
+      {
+        float dv[16];
+        ld.tg.get(dv);
+        if (nvalid < 32) mask_tail(dv, hi, nvalid);
+        const int e = PH == 0 ? block_exponent<kGwBlocks>(dv, E, acc)
+                              : block_exponent<kGwBlocks - 1>(dv, E, acc);
+        split16(dv, e, ad);
+        float av[16];
+        ld.ta.get(av);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) av[i] = ones_row ? 1.f : av[i];
+        split16(av, 0, bx);
+        if (PH == 1) {
+          float zv[16];
+          ld.tz.get(zv);
+          if (nvalid < 32) mask_tail(zv, hi, nvalid);
+          split16(zv, block_exponent<1>(zv, E2, acc + 4), az);
+        }
+      }
+      if (k + 1 < kH) issue(k + 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc[4] = mma3(PH == 0 ? ad[kk] : az[kk], bx[kk], acc[4]);
+
+      // conv of position 4 PH + e4 with the operands swapped: window slot s =
+      // (column s / 3, tap s % 3) of the lane's trajectory, relative to the
+      // current position, split in pairs straight into the operand registers
+      auto conv = [&](int e4) {
+        f32x16 cv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cv[i] = cb;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          Op16 x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
+            const int c0 = s0 / 3, c1 = s1 < 15 ? s1 / 3 : 0;
+            const float r0 = wr[e4 + s0 % 3][c0 * kGwThreads];
+            const float v0 = c0 < 3 ? r0 - sub[c0] : r0;
+            float v1 = 0.f;
+            if (s1 < 15) {
+              const float r1 = wr[e4 + s1 % 3][c1 * kGwThreads];
+              v1 = c1 < 3 ? r1 - sub[c1] : r1;
+            }
+            unsigned h, l;
+            split_pair(v0, v1, h, l);
+            x.h[q] = h, x.l[q] = l;
+          }
+          cv = mma3(x, L16.A(hA, nC + kb), cv);   // [trajectory][channel]
+        }
+        return cv;
+      };
+      f32x16 cv = conv(0);
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        f32x16 nx;
+        if (e4 < 3) nx = conv(e4 + 1);   // on the matrix pipe while this one is split
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = relu1(cv[8 * kk + j]);
+          acc[e4] = mma3(ad[kk], split8(v), acc[e4]);
+        }
+        if (e4 < 3) cv = nx;
+      }
+    }
+  }
+  // the workgroup's sum, waves in order, at true scale
+#pragma unroll 1
+  for (int wv = 0; wv < kGwWaves; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int n = 0; n < kGwBlocks; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float *p = red + (n * 16 + i) * 64 + lane;
+          const float v = __builtin_amdgcn_ldexpf(acc[n][i], (n == 4 && PH == 1) ? E2 : E);
+          *p = wv ? *p + v : v;
+        }
+    }
+    __syncthreads();
+  }
+  float *dst = A.partials + (size_t)blockIdx.x * kGwPart;
+  for (int idx = threadIdx.x; idx < kGwPart; idx += kGwThreads) dst[idx] = red[idx];
+}
+
+__global__ __launch_bounds__(kGwThreads) void lstm_gate_wgrad_kernel(GwArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  fill_lds(lds, A.tables, kGwTab);
+  if (blockIdx.x & 1) gate_wgrad_body<1>(A);
+  else gate_wgrad_body<0>(A);
+}
+
+// sum of the workgroups' partials (index order) into the gradients: thread
+// (part, o) adds every 8th workgroup of output o's parity, part 0 adds the eight
+struct GwReduceArgs {
+  const float *partials;
+  int chunks;          // workgroup pairs
+  float *ih_hh;        // [32][183]
+  float *b_ih;         // [32]
+  float *w_out, *b_out;  // [4][8], [4]
+};
+__global__ __launch_bounds__(256) void lstm_gate_wgrad_reduce_kernel(GwReduceArgs A) {
+  __shared__ float part[8][32];
+  const int ol = threadIdx.x & 31, pt = threadIdx.x >> 5;
+  const int o = blockIdx.x * 32 + ol;          // < 2 kGwPart
+  const int ph = o / kGwPart, r = o - ph * kGwPart;
+  float s = 0.f;
+  for (int c = pt; c < A.chunks; c += 8) s += A.partials[(size_t)(2 * c + ph) * kGwPart + r];
+  part[pt][ol] = s;
+  __syncthreads();
+  if (pt) return;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += part[q][ol];
+  const int n = r >> 10, i = (r >> 6) & 15, lane = r & 63;
+  const int g = rrow(i) + 4 * (lane >> 5), col = lane & 31;
+  if (n < 4) {
+    if (col < kNC) A.ih_hh[g * (kNX + kNH) + kNF + col * kNP + 4 * ph + n] = s;
+  } else if (ph == 0) {
+    if (col < kNF) A.ih_hh[g * (kNX + kNH) + col] = s;
+    else if (col < kNF + kNH) A.ih_hh[g * (kNX + kNH) + kNX + col - kNF] = s;
+    else if (col == kNF + kNH) A.b_ih[g] = s;
+  } else if (g < 4) {
+    if (col < kNH) A.w_out[g * kNH + col] = s;
+    else if (col == kNH) A.b_out[g] = s;
+  }
+}
+
 // pol NULL: the caller holds packed tables instead of the parameters
 int check_lstm(const ApgQuadParams *params, const ApgLstmPolicy *pol, int B, int H,
                bool packed = false) {
@@ -1078,6 +1387,72 @@ int apg_quad_lstm_rollout_bwd_packed(const float *state0, const float *states,
   return lstm_bwd(state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt, params,
                   weights, nullptr, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
                   grad_state0, grad_h0, grad_c0, const_cast<float *>(tables_bwd), stream);
+}
+
+static int gw_blocks(int B) {
+  const int groups = (B + 31) / 32, per = kGwWaves * kGwGroups;
+  return 2 * ((groups + per - 1) / per);
+}
+
+int apg_quad_lstm_gate_wgrad_partials_floats(int B) {
+  return B <= 0 ? 0 : gw_blocks(B) * kGwPart;
+}
+
+int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const float *in_ref,
+                             const float *acts, const float *d_gates, const float *d_zout,
+                             const ApgLstmPolicy *policy, float *tables_fwd, int B, int H,
+                             float *partials, float *ih_hh, float *b_ih, float *w_out,
+                             float *b_out, apg_stream_t stream) {
+  if (H != kH) {
+    set_error("the fused LSTM rollout is built for horizon %d (got %d)", kH, H);
+    return APG_ERR_ARG;
+  }
+  if (B < 0 || (long long)B * kH * 4 * kNX >= (1ll << 32) - 64) {
+    set_error("apg_quad_lstm_gate_wgrad: B out of range (%d)", B);
+    return APG_ERR_ARG;
+  }
+  if (!ih_hh || !b_ih || !w_out || !b_out) {
+    set_error("apg_quad_lstm_gate_wgrad: NULL gradient buffer");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (hipMemsetAsync(ih_hh, 0, sizeof(float) * kNG * (kNX + kNH), st) != hipSuccess ||
+        hipMemsetAsync(b_ih, 0, sizeof(float) * kNG, st) != hipSuccess ||
+        hipMemsetAsync(w_out, 0, sizeof(float) * 4 * kNH, st) != hipSuccess ||
+        hipMemsetAsync(b_out, 0, sizeof(float) * 4, st) != hipSuccess)
+      return check_launch("memset(gate gradients)");
+    return APG_OK;
+  }
+  if (!state0 || !states || !in_ref || !acts || !d_gates || !d_zout || !tables_fwd ||
+      !partials) {
+    set_error("apg_quad_lstm_gate_wgrad: NULL buffer");
+    return APG_ERR_ARG;
+  }
+  if (policy) {
+    if (!policy->conv_w || !policy->conv_b || !policy->w_ih || !policy->w_hh ||
+        !policy->b_ih || !policy->b_hh || !policy->w_out || !policy->b_out) {
+      set_error("policy weight pointer is NULL");
+      return APG_ERR_ARG;
+    }
+    PackArgs P;
+    P.pol = *policy, P.dst = tables_fwd;
+    hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256), 0, st,
+                       P);
+  }
+  GwArgs A;
+  A.state0 = state0, A.states = states, A.in_ref = in_ref, A.acts = acts;
+  A.d_gates = d_gates, A.d_zout = d_zout, A.tables = tables_fwd, A.partials = partials;
+  A.B = B;
+  const int blocks = gw_blocks(B);
+  hipLaunchKernelGGL(lstm_gate_wgrad_kernel, dim3(blocks), dim3(kGwThreads),
+                     (kGwTab + kGwWin + kGwPart) * sizeof(float), st, A);
+  if (int e = check_launch("quad_lstm_gate_wgrad")) return e;
+  GwReduceArgs R;
+  R.partials = partials, R.chunks = blocks / 2;
+  R.ih_hh = ih_hh, R.b_ih = b_ih, R.w_out = w_out, R.b_out = b_out;
+  hipLaunchKernelGGL(lstm_gate_wgrad_reduce_kernel, dim3(2 * kGwPart / 32), dim3(256), 0, st, R);
+  return check_launch("quad_lstm_gate_wgrad_reduce");
 }
 
 int apg_quad_lstm_tables_floats(int reverse) { return reverse ? kBwd16Lds : kFwd16Lds; }

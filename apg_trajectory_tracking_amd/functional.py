@@ -1165,10 +1165,11 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         N = H * B
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         actions = new(H, 4, B)
-        # one buffer for everything the weight-gradient GEMMs read as B
-        # operand: x (175 planes), h_prev / c_prev (16), h_new (8)
-        acts = new(199, N)
-        x, hc, hnew = acts[:175], acts[175:191], acts[191:199]
+        # one buffer for what the weight-gradient kernel reads as B operand
+        # (apg_quad_lstm_gate_wgrad): state features (15 planes), h_prev / c_prev
+        # (16), h_new (8); round 6: the 160 relu(conv) inputs are recomputed there
+        acts = new(39, N)
+        x, hc, hnew = acts[:15], acts[15:31], acts[31:39]
         gates = new(32, N)
         relu_mask = torch.empty(5, N, dtype=torch.int32, device=dev)
         st = stream_of(s0)
@@ -1213,7 +1214,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
                 ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
                 ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), ptr(g_s0),
                 ptr(g_h0), ptr(g_c0), ptr(ws), st), "apg_quad_lstm_rollout_bwd")
-        ctx.save_for_backward(refbuf, acts, d_gates, d_zout, d_conv)
+        ctx.save_for_backward(refbuf, acts, d_gates, d_zout, d_conv, *pw.values())
         ctx.input_grads = (g_s0, g_h0, g_c0)
         ctx.mark_non_differentiable(states, actions)
         ctx.dims = (B, H)
@@ -1292,7 +1293,7 @@ def _lstm_param_grads(saved, dims, tail=None):
     momentum SGD if `update` = (lr, momentum, {parameter name: buffer}), the next
     step's tables, the loss) instead of three elementwise launches, the
     optimizer's, the loss reduction and two table packs."""
-    refbuf, acts, d_gates, d_zout, d_conv = saved
+    refbuf, acts, d_gates, d_zout, d_conv = saved[:5]
     B, H = dims
     dev = acts.device
     flat, gr = _flat_grads(dev, {
@@ -1300,15 +1301,28 @@ def _lstm_param_grads(saved, dims, tail=None):
         "lstm.bias_ih": (32,), "fc_out.weight": (4, 8), "fc_out.bias": (4,),
         "conv_ref.weight": (20, 9, 3), "conv_ref.bias": (20,)})
     ih_hh = torch.empty(32, 183, dtype=torch.float32, device=dev)
-    # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T, db = row sums;
-    # dW_out = d_zout . h_new^T; conv
+    # [dW_ih | dW_hh] = d_gates . [x ; h_prev]^T, db = row sums, dW_out = d_zout .
+    # h_new^T: ONE kernel that recomputes the conv part of x (round 6); the conv
+    # weights' own gradient: two segmented products over the window planes
+    st_all = refbuf[2 * H * 9:]
+    if tail is not None and tail[3] is not None:
+        pol, tab = None, tail[3].fwd          # resident tables (current: ensure())
+    else:
+        pw8 = dict(zip(("conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out",
+                        "b_out"), saved[5:13]))
+        pol = ctypes.byref(_capi.ApgLstmPolicy(**{k: ptr(v) for k, v in pw8.items()}))
+        tab = torch.empty(lib().apg_quad_lstm_workspace_floats(), dtype=torch.float32,
+                          device=dev)
+    scratch = torch.empty(max(1, lib().apg_quad_lstm_gate_wgrad_partials_floats(B)),
+                          dtype=torch.float32, device=dev)
+    check(lib().apg_quad_lstm_gate_wgrad(
+        ptr(st_all[:12]), ptr(st_all[12:]), ptr(refbuf[:2 * H * 9]), ptr(acts),
+        ptr(d_gates), ptr(d_zout), pol, ptr(tab), B, H, ptr(scratch), ptr(ih_hh),
+        ptr(gr["lstm.bias_ih"]), ptr(gr["fc_out.weight"]), ptr(gr["fc_out.bias"]),
+        stream_of(acts)), "apg_quad_lstm_gate_wgrad")
     conv, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.weight"],
                                        gr["conv_ref.bias"])
-    _run_products([
-        dict(A=d_gates, M=32, S=1, Bp=acts, bdesc=make_bdesc(dev, range(183), key="ih_hh"),
-             out=ih_hh, bias_out=gr["lstm.bias_ih"]),
-        dict(A=d_zout, M=4, S=1, Bp=acts, bdesc=make_bdesc(dev, range(191, 199), key="out"),
-             out=gr["fc_out.weight"], bias_out=gr["fc_out.bias"])] + conv)
+    _run_products(conv)
     gr["lstm.bias_hh"] = gr["lstm.bias_ih"]
     if tail is None:
         finish()

@@ -230,7 +230,9 @@ typedef struct ApgLstmPolicy {
  * SoA only:  state0 [12][B], in_ref [2H][9][B], h0 / c0 [8][B].
  * Outputs (caller-allocated, N = H*B, plane index = step*B + trajectory):
  *   states [H][12][B], actions [H][4][B],
- *   x [175][N]   LSTM inputs (features, relu(conv)),
+ *   x [15][N]    the state features (LSTM inputs 0..14; round 6: the 160
+ *                relu(conv) inputs are NOT stored - apg_quad_lstm_gate_wgrad
+ *                recomputes them from the window for the weight gradient),
  *   gates [32][N] activated gates (i, f, g, o), hc [16][N] = h_prev, c_prev,
  *   hnew [8][N], relu_mask [5][N] (bit ch*8+pos = conv output > 0).
  * `workspace`: apg_quad_lstm_workspace_floats() floats of scratch (weights in
@@ -260,7 +262,7 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
  *     planes [520, 720): P[ch][k] = sum_pos d[ch][pos][k], plane = 520 + ch*10 + k
  * optional grad_state0 [12][B], grad_h0 / grad_c0 [8][B].
  *   dW_ih = d_gates x^T, dW_hh = d_gates h_prev^T, db_ih = db_hh = sum d_gates,
- *   dW_out = d_zout hnew^T, db_out = sum d_zout,
+ *   dW_out = d_zout hnew^T, db_out = sum d_zout  (apg_quad_lstm_gate_wgrad),
  *   dconv_w[ch][c][t] = sum_{hi,tau,n} G[ch][hi][tau][n] ref[n][4 hi + tau + t][c]
  *                       - (c < 3) sum_{k,n} P[ch][k][n] pos_k[n][c],
  *   dconv_b[ch] = sum_{k,n} P[ch][k][n]. */
@@ -276,6 +278,31 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               float *d_zout, float *d_conv, float *grad_state0,
                               float *grad_h0, float *grad_c0, float *workspace,
                               apg_stream_t stream);
+
+/* Round 6: the gate and head weight gradients of the LSTM unroll from the
+ * cotangent planes of the reverse sweep - what `loss.backward()` leaves in
+ * lstm.weight_ih / weight_hh / bias_ih and fc_out.weight / bias
+ * (scripts/train_base.py:200-204 for train_mode "LSTM") - without the conv
+ * outputs in memory: one kernel recomputes relu(conv(window)) per step on the
+ * matrix cores (operands swapped: trajectories in the registers) and multiplies
+ * it, the stored features / h_prev and a ones column with d_gates, h_new and
+ * ones with d_zout, trajectory-major; a second one sums the workgroups in index
+ * order (bit-reproducible).
+ *   state0 [12][B], states [H][12][B], in_ref [2H][9][B] as for the sweeps;
+ *   acts [39][N] = x (15) | hc (16) | hnew (8) of apg_quad_lstm_rollout_fwd as
+ *   ONE buffer; d_gates [32][N], d_zout [4][N] of apg_quad_lstm_rollout_bwd.
+ *   `policy` given: its forward tables are packed into `tables_fwd`
+ *   (apg_quad_lstm_workspace_floats() floats) first; NULL: `tables_fwd` holds them
+ *   (apg_quad_lstm_pack_tables / apg_quad_lstm_step_tail).
+ *   partials: apg_quad_lstm_gate_wgrad_partials_floats(B) floats of scratch.
+ * Outputs: ih_hh [32][183] = [dW_ih | dW_hh], b_ih [32] (= db_hh),
+ *   w_out [4][8], b_out [4]. */
+int apg_quad_lstm_gate_wgrad_partials_floats(int B);
+int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const float *in_ref,
+                             const float *acts, const float *d_gates, const float *d_zout,
+                             const ApgLstmPolicy *policy, float *tables_fwd, int B, int H,
+                             float *partials, float *ih_hh, float *b_ih, float *w_out,
+                             float *b_out, apg_stream_t stream);
 
 /* The LSTM training step without its small launches (round 6; the loop body of
  * scripts/train_base.py:198-214 for train_mode "LSTM": loss.backward() +
