@@ -935,6 +935,14 @@ constexpr int kGwPart = kGwBlocks * 16 * 64;      // one workgroup's partial: 5 
 constexpr int kGwTab = (hA + (nC + 2) * kBlock16) / 4;  // forward tables through the conv blocks
 constexpr int kGwActs = kNF + 3 * kNH;            // acts planes: 15 | 8 + 8 | 8
 constexpr int kGwNoExp = -100000;
+#if !defined(APG_EXPERIMENT_BUILD) && defined(APG_GW_KNOCKOUT)
+#error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
+#endif
+#ifndef APG_GW_KNOCKOUT
+#define APG_GW_KNOCKOUT 0   // timing experiments: 1 the trajectory-major block loads read one
+                            // 1 KB lane-linear, 2 no conv / product per position,
+                            // 4 a fixed block exponent (no wave maximum), 8 one step per group
+#endif
 
 struct GwArgs {
   const float *state0, *states, *in_ref;
@@ -953,6 +961,25 @@ __device__ __forceinline__ void mask_tail(float (&v)[16], int hi, int nvalid) {
     if (rrow(i) + 4 * hi >= nvalid) v[i] = 0.f;
 }
 
+// maximum of a wave's unsigned values on the VALU alone: DPP row shifts inside the
+// rows of 16, row broadcasts across them, the last lane holds it.  (policy_tm.h's
+// wave_umax goes through six ds_bpermute round trips: 0.95 us per step of this
+// kernel, tools/ab_gate_wgrad.sh.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_umax_dpp(unsigned v) {
+  v = dpp_umax<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_umax<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_umax<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_umax<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row: the row's maximum
+  v = dpp_umax<0x142, 0xa>(v);   // row_bcast:15 -> lanes 31, 63: two rows
+  v = dpp_umax<0x143, 0xc>(v);   // row_bcast:31 -> lane 63: the wave
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // running block exponent: e = exponent above this step's largest |v| in the wave;
 // the accumulators `acc[0..n)` follow when it grows.  Returns the exponent in use.
 template <int N>
@@ -960,9 +987,9 @@ __device__ __forceinline__ int block_exponent(const float (&v)[16], int &E, f32x
   unsigned m = 0u;
 #pragma unroll
   for (int i = 0; i < 16; ++i) m = umax_abs(m, v[i]);
-  m = wave_umax(m);
+  if (!(APG_GW_KNOCKOUT & 4)) m = wave_umax_dpp(m);
   bool bad = false;   // (a non-finite cotangent goes through the products as it is)
-  const int e = bits_exp(m, bad, false);
+  const int e = (APG_GW_KNOCKOUT & 4) ? 0 : bits_exp(m, bad, false);
   if (e > E) {
     if (E != kGwNoExp) {
       const int d = E - e;
@@ -1027,6 +1054,7 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
   int E = kGwNoExp, E2 = kGwNoExp;   // block exponents of d_gates / d_zout
+  const Op16 wc[2] = {L16.A(hA, nC), L16.A(hA, nC + 1)};   // the conv weights: B operand
 
 #pragma unroll 1
   for (int gi = 0; gi < kGwGroups; ++gi) {
@@ -1040,69 +1068,86 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
     // trajectory-major blocks: the lane's plane, trajectories b0 + 4 hi ..; the WHOLE
     // offset sits in the VGPR, so the buffer's range check covers the ragged tail
     const unsigned tcol = (unsigned)b0 * 4u + (unsigned)hi * 16u;
-    const unsigned vg = (unsigned)row * pitchN + tcol;
-    const unsigned va = (unsigned)(kAuxPlane0 + (aux_row ? row : 0)) * pitchN + tcol;
+    // (knock-out 1: lane-linear 16-byte loads - 8 cache lines per instruction, not 64)
+    const unsigned vg = (APG_GW_KNOCKOUT & 1) ? (unsigned)lane * 16u + tcol * 8u
+                                              : (unsigned)row * pitchN + tcol;
+    const unsigned va = (APG_GW_KNOCKOUT & 1)
+                            ? (unsigned)lane * 16u + tcol * 8u
+                            : (unsigned)(kAuxPlane0 + (aux_row ? row : 0)) * pitchN + tcol;
 
     // window row r (relative to 4 PH) -> its slot, straight into LDS
-    auto row_in = [&](int r, unsigned pB) {
+    auto row_in = [&](int r, unsigned pB, int j0, int j1) {
       const int slot = r % kGwSlots;
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
+      for (int j = j0; j < j1; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             Pin.rsrc, (lds_ptr_t)(win + ((slot * 5 + j) * kGwWaves + wave) * 64), 4, (int)vb_u,
             (int)(((r + 4 * PH) * kRD + j) * pB), 0, 0);
     };
     GwLoads ld;
-    auto issue = [&](int k) {   // the loads of step k (window: the row that slides in)
+    // the loads of step k in four parts: a block load is 64 cache-line accesses
+    // (16 bytes of a line per lane) and holds the wave at issue while the
+    // workgroup's others queue behind it - spread over the step, between the
+    // positions, the address unit works while the matrix pipe and the VALU do
+    auto issue = [&](int k, int part) {
       const unsigned pB = opaque(pitchB);
-      const unsigned kcol = (unsigned)k * pB;
-      ld.tg.load(Pdg, vg + kcol, 0u);
-      ld.ta.load(Pac, aux_row ? va + kcol : kDead, 0u);
-      if (PH == 1) ld.tz.load(Pdz, row < 4 ? vg + kcol : kDead, 0u);
+      const unsigned kcol = (APG_GW_KNOCKOUT & 1) ? 0u : (unsigned)k * pB;
+      const unsigned o = ((APG_GW_KNOCKOUT & 1) ? 1024u : 32u) * (unsigned)part;
+      ld.tg.q[part] = __builtin_amdgcn_raw_buffer_load_b128(Pdg.rsrc, (int)(vg + kcol), (int)o,
+                                                            APG_PLANES_LD_AUX);
+      ld.ta.q[part] = __builtin_amdgcn_raw_buffer_load_b128(
+          Pac.rsrc, (int)(aux_row ? va + kcol : kDead), (int)o, APG_PLANES_LD_AUX);
+      if (PH == 1)
+        ld.tz.q[part] = __builtin_amdgcn_raw_buffer_load_b128(
+            Pdz.rsrc, (int)(row < 4 ? vg + kcol : kDead), (int)o, APG_PLANES_LD_AUX);
+      if (part == 0) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j)   // the current position: the state BEFORE step k
-        ld.pos[j] = k > 0 ? Pst.ld(vb, ((k - 1) * 12 + j) * pB) : Ps0.ld(vb, j * pB);
-      if (k > 0) row_in(k + 5, pB);
+        for (int j = 0; j < 3; ++j)   // the current position: the state BEFORE step k
+          ld.pos[j] = k > 0 ? Pst.ld(vb, ((k - 1) * 12 + j) * pB) : Ps0.ld(vb, j * pB);
+      } else if (k > 0) {   // the window row that slides in: columns 0-1 | 2-3 | 4
+        row_in(k + 5, pB, 2 * (part - 1), part == 3 ? 5 : 2 * part);
+      }
     };
-    for (int r = 0; r < 6; ++r) row_in(r, pitchB);
-    issue(0);
+    for (int r = 0; r < 6; ++r) row_in(r, pitchB, 0, 5);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) issue(0, part);
 
     int s0 = 0;   // k % 7
 #pragma unroll 1
-    for (int k = 0; k < kH; ++k) {
+    for (int k = 0; k < ((APG_GW_KNOCKOUT & 8) ? 1 : kH); ++k) {
       // everything issued for this step has landed (registers and LDS)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      typedef const volatile __attribute__((address_space(3))) float *win_ptr_t;
-      win_ptr_t wr[6];
+      typedef const __attribute__((address_space(3))) float *win_ptr_t;
+      unsigned wo[6];   // LDS byte offset of window row r, column 0, this lane
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const int slot = s0 + r >= kGwSlots ? s0 + r - kGwSlots : s0 + r;
-        wr[r] = (win_ptr_t)(lds_ptr_t)lds + (kGwTab + (slot * 5 * kGwWaves + wave) * 64 + lane);
+        wo[r] = (unsigned)(kGwTab + (slot * 5 * kGwWaves + wave) * 64 + lane) * 4u;
       }
       s0 = s0 + 1 == kGwSlots ? 0 : s0 + 1;
       const float sub[3] = {hi ? 0.f : ld.pos[0], hi ? 0.f : ld.pos[1], hi ? 0.f : ld.pos[2]};
-      // d_gates of the step: scaled, split; the fifth block's operands
+      // the step's blocks out of the load registers, the next step's loads into
+      // them (a whole step ahead of their use), then: d_gates scaled and split,
+      // the fifth block's operands
       Op16 ad[2], bx[2], az[2];
       {
-        float dv[16];
+        float dv[16], av[16], zv[16];
         ld.tg.get(dv);
+        ld.ta.get(av);
+        if (PH == 1) ld.tz.get(zv);
+        if (k + 1 < kH) issue(k + 1, 0);
         if (nvalid < 32) mask_tail(dv, hi, nvalid);
         const int e = PH == 0 ? block_exponent<kGwBlocks>(dv, E, acc)
                               : block_exponent<kGwBlocks - 1>(dv, E, acc);
         split16(dv, e, ad);
-        float av[16];
-        ld.ta.get(av);
 #pragma unroll
         for (int i = 0; i < 16; ++i) av[i] = ones_row ? 1.f : av[i];
         split16(av, 0, bx);
         if (PH == 1) {
-          float zv[16];
-          ld.tz.get(zv);
           if (nvalid < 32) mask_tail(zv, hi, nvalid);
           split16(zv, block_exponent<1>(zv, E2, acc + 4), az);
         }
       }
-      if (k + 1 < kH) issue(k + 1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) acc[4] = mma3(PH == 0 ? ad[kk] : az[kk], bx[kk], acc[4]);
 
@@ -1110,6 +1155,18 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
       // (column s / 3, tap s % 3) of the lane's trajectory, relative to the
       // current position, split in pairs straight into the operand registers
       auto conv = [&](int e4) {
+        // the 15 window values of the position in one batch of LDS reads; the
+        // row offsets are made opaque per position: a value shared by three
+        // positions is read three times instead of being kept in a register
+        float wv[15];
+        {
+          unsigned o[3] = {wo[e4], wo[e4 + 1], wo[e4 + 2]};
+          asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));
+#pragma unroll
+          for (int s_ = 0; s_ < 15; ++s_)
+            wv[s_] = *(win_ptr_t)((const __attribute__((address_space(3))) char *)(lds_ptr_t)lds +
+                                  (o[s_ % 3] + (s_ / 3) * kGwThreads * 4));
+        }
         f32x16 cv;
 #pragma unroll
         for (int i = 0; i < 16; ++i) cv[i] = cb;
@@ -1118,28 +1175,21 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
           Op16 x;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
-            const int c0 = s0 / 3, c1 = s1 < 15 ? s1 / 3 : 0;
-            const float r0 = wr[e4 + s0 % 3][c0 * kGwThreads];
-            const float v0 = c0 < 3 ? r0 - sub[c0] : r0;
+            const int s0_ = kb * 8 + 2 * q, s1 = s0_ + 1;
+            const float v0 = s0_ / 3 < 3 ? wv[s0_] - sub[s0_ / 3] : wv[s0_];
             float v1 = 0.f;
-            if (s1 < 15) {
-              const float r1 = wr[e4 + s1 % 3][c1 * kGwThreads];
-              v1 = c1 < 3 ? r1 - sub[c1] : r1;
-            }
+            if (s1 < 15) v1 = s1 / 3 < 3 ? wv[s1] - sub[s1 / 3] : wv[s1];
             unsigned h, l;
             split_pair(v0, v1, h, l);
             x.h[q] = h, x.l[q] = l;
           }
-          cv = mma3(x, L16.A(hA, nC + kb), cv);   // [trajectory][channel]
+          cv = mma3(x, wc[kb], cv);   // [trajectory][channel]
         }
         return cv;
       };
-      f32x16 cv = conv(0);
 #pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) {
-        f32x16 nx;
-        if (e4 < 3) nx = conv(e4 + 1);   // on the matrix pipe while this one is split
+      for (int e4 = 0; e4 < ((APG_GW_KNOCKOUT & 2) ? 0 : 4); ++e4) {
+        const f32x16 cv = conv(e4);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           float v[8];
@@ -1147,7 +1197,7 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
           for (int j = 0; j < 8; ++j) v[j] = relu1(cv[8 * kk + j]);
           acc[e4] = mma3(ad[kk], split8(v), acc[e4]);
         }
-        if (e4 < 3) cv = nx;
+        if (e4 < 3 && k + 1 < kH) issue(k + 1, e4 + 1);
       }
     }
   }

@@ -10,7 +10,7 @@ KERNELS = {
     "concurrent": (("mlp_concurrent_bwd_tm_kernel", "bwd_tm"), ("mlp_concurrent_fwd_kernel", "fwd")),
     "autoregressive": (("mlp_rollout_bwd_tm_kernel", "ar_bwd_tm"), ("mlp_rollout_fwd_kernel", "ar_fwd")),
     "LSTM": (("lstm_rollout_bwd_kernel", "lstm_bwd"), ("lstm_rollout_fwd_kernel", "lstm_fwd"),
-             ("planes_gemm", "planes_gemm")),
+             ("lstm_gate_wgrad_kernel", "lstm_gate_wgrad"), ("planes_gemm", "planes_gemm")),
 }
 args = sys.argv[1:]
 mode = args.pop(0) if args and args[0] in KERNELS else "concurrent"
