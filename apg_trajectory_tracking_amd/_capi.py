@@ -184,7 +184,8 @@ SIGNATURES = {
     "apg_quad_lstm_rollout_bwd": [
         _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), ctypes.POINTER(ApgLstmPolicy),
-        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_cot_amax_floats": [_I],
     "apg_quad_lstm_tables_floats": [_I],
     "apg_quad_lstm_pack_tables": [ctypes.POINTER(ApgLstmPolicy), _P, _P, _P],
     "apg_quad_lstm_rollout_fwd_packed": [
@@ -193,11 +194,11 @@ SIGNATURES = {
     "apg_quad_lstm_rollout_bwd_packed": [
         _P, _P, _P, _P, _I, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgQuadLossWeights), _P,
-        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_quad_lstm_step_tail": [ctypes.POINTER(ApgLstmStepTail), _P],
     "apg_quad_lstm_gate_wgrad_partials_floats": [_I],
     "apg_quad_lstm_gate_wgrad": [
-        _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicy), _P, _I, _I,
+        _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicy), _P, _I, _I,
         _P, _P, _P, _P, _P, _P],
     "apg_quad_mlp_rollout_fwd": [
         _P, _P, _F, ctypes.POINTER(ApgQuadParams),

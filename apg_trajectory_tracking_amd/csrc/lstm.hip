@@ -684,6 +684,7 @@ struct BwdArgs {
   float *d_conv;   // [720][B] conv cotangents, summed along the window diagonals
                    // (see kConvG / kConvP below)
   float *grad_state0, *grad_h0, *grad_c0;
+  float *cot_amax;   // [groups of 32 trajectories][2]: largest |d_gates|, |d_zout| (or NULL)
   const float *tables;
   QuadConst c;
   ApgQuadLossWeights w;
@@ -716,6 +717,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) dh[r] = 0.f, dc[r] = 0.f;
   float loss = 0.f;
+  float run_g = 0.f, run_z = 0.f;   // largest |d_gates|, |d_zout| of the lane so far
   // sliding diagonal sums of the conv cotangents: dgn[ch][ii] = diagonal
   // tau = k + ii of this half-wave's positions (see kConvP)
   float dgn[kNC][4];
@@ -785,6 +787,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
     for (int j = 0; j < 4; ++j) {
       dz[j] = ga[j] * a[j] * (1.f - a[j]);
       Pdz.st(vn_lo, j * pN, dz[j]);
+      run_z = fmaxf(run_z, fabsf(dz[j]));
     }
     // LSTM cell, lane-local for the units r + 4 hi
     f32x16 dG;
@@ -813,6 +816,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
       float amax = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(dG[i]));
+      run_g = fmaxf(run_g, amax);
       ex = scale_exponent(amax);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -900,6 +904,16 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) A.grad_c0[(size_t)(r + 4 * hi) * B + b] = dc[r];
   write_wave_partial(A.loss_partials, st_lo ? loss : 0.f);
+  if (A.cot_amax) {   // what apg_quad_lstm_gate_wgrad scales its fp16 operands by
+    float mg = run_g, mz = run_z;
+#pragma unroll
+    for (int s_ = 32; s_ >= 1; s_ >>= 1) {
+      mg = fmaxf(mg, __shfl_xor(mg, s_, 64));
+      mz = fmaxf(mz, __shfl_xor(mz, s_, 64));
+    }
+    const int group = blockIdx.x * (kThreads / 64) + wave;
+    if (lane == 0 && group * 32 < B) A.cot_amax[2 * group] = mg, A.cot_amax[2 * group + 1] = mz;
+  }
 }
 
 // --------------------------------------------------- gate weight gradients
@@ -917,9 +931,13 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
 //     trajectories r(i) + 4 hi in its registers: after bias + relu it IS the
 //     B operand (k-slot = trajectory) of the product, no transposition;
 //   * d_gates as A operand: gate row (lane & 31), the trajectories as four
-//     16-byte loads of that plane (TBlock), scaled by the wave's running
-//     power of two (block floating point: the accumulators are rescaled when a
-//     step's largest |d_gates| exceeds it) and split into two fp16 terms.
+//     16-byte loads of that plane (TBlock), scaled by a power of two and split
+//     into two fp16 terms.  The scale is the largest |d_gates| of the wave's
+//     trajectories over the whole unroll, which the reverse sweep leaves per
+//     group of 32 (BwdArgs::cot_amax): ONE exponent per wave, so the
+//     accumulators are touched by matrix instructions only.  (A running
+//     exponent with a rescale branch made the compiler copy all 160
+//     accumulator registers between the two register files every step.)
 // A workgroup is 8 waves x 2 groups of 32 trajectories, all ten steps of each;
 // the window positions are shared between two workgroups (PH = blockIdx & 1:
 // positions 4 PH .. 4 PH + 3: four 32 x 32 accumulators per lane) so that two
@@ -927,27 +945,37 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
 // that ARE in memory: PH 0 [15 features | h_prev | 1] against d_gates (dW_ih's
 // first 15 columns, dW_hh, db), PH 1 [h_new | 1] against d_zout (the head's
 // dW_out, db_out - the product that was a launch of its own).  The waves of a
-// workgroup add up in wave order in LDS, lstm_gate_wgrad_reduce_kernel sums the
-// workgroups in index order: bit-reproducible.
+// workgroup put their accumulators side by side in LDS and the workgroup adds
+// them in wave order, lstm_gate_wgrad_reduce_kernel sums the workgroups in index
+// order: bit-reproducible.
+// What bounds it (tools/issue_probe3.hip, tools/ab_gate_wgrad.sh):
+// the fp16-split arithmetic - v_cvt_pk_f16_f32, v_fma_mix_f32, integer max, v_ldexp -
+// does NOT issue in the gaps of a second wave the way v_fma does: ~1 200 such
+// instructions per 32 trajectories and step at 4.3 cycles each; the matrix pipe
+// (108 instructions of 32 cycles) hides behind them.  A build with ONE wave per
+// SIMD doing all eight positions (d_gates split once, the window in registers,
+// matrix instructions spaced by hand with scheduling fences) ran no faster: the
+// compiler moves the matrix results between the two register files for the relu
+// (tools/patches/lstm_gate_wgrad_one_wave.patch).
 constexpr int kGwThreads = 512, kGwWaves = kGwThreads / 64, kGwGroups = 2;
 constexpr int kGwBlocks = 5;                      // accumulators per lane: 4 positions + 1
 constexpr int kGwPart = kGwBlocks * 16 * 64;      // one workgroup's partial: 5 120 floats
 constexpr int kGwTab = (hA + (nC + 2) * kBlock16) / 4;  // forward tables through the conv blocks
 constexpr int kGwActs = kNF + 3 * kNH;            // acts planes: 15 | 8 + 8 | 8
-constexpr int kGwNoExp = -100000;
 #if !defined(APG_EXPERIMENT_BUILD) && defined(APG_GW_KNOCKOUT)
 #error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
 #endif
 #ifndef APG_GW_KNOCKOUT
-#define APG_GW_KNOCKOUT 0   // timing experiments: 1 the trajectory-major block loads read one
-                            // 1 KB lane-linear, 2 no conv / product per position,
-                            // 4 a fixed block exponent (no wave maximum), 8 one step per group
+#define APG_GW_KNOCKOUT 0   // timing experiments: 1 the trajectory-major block loads read
+                            // 1 KB lane-linear (8 cache lines per instruction, not 64),
+                            // 2 no conv / product per position, 8 one step per group
 #endif
 
 struct GwArgs {
   const float *state0, *states, *in_ref;
   const float *acts;      // [39][N]: features | h_prev, c_prev | h_new
   const float *d_gates, *d_zout;
+  const float *cot_amax;  // [groups][2] (lstm_rollout_bwd_kernel)
   const float *tables;    // forward tables (lstm_pack_fwd16_kernel)
   float *partials;        // [workgroups][kGwPart]
   int B;
@@ -961,48 +989,6 @@ __device__ __forceinline__ void mask_tail(float (&v)[16], int hi, int nvalid) {
     if (rrow(i) + 4 * hi >= nvalid) v[i] = 0.f;
 }
 
-// maximum of a wave's unsigned values on the VALU alone: DPP row shifts inside the
-// rows of 16, row broadcasts across them, the last lane holds it.  (policy_tm.h's
-// wave_umax goes through six ds_bpermute round trips: 0.95 us per step of this
-// kernel, tools/ab_gate_wgrad.sh.)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
-  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-  return o > v ? o : v;
-}
-__device__ __forceinline__ unsigned wave_umax_dpp(unsigned v) {
-  v = dpp_umax<0x111, 0xf>(v);   // row_shr:1
-  v = dpp_umax<0x112, 0xf>(v);   // row_shr:2
-  v = dpp_umax<0x114, 0xf>(v);   // row_shr:4
-  v = dpp_umax<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row: the row's maximum
-  v = dpp_umax<0x142, 0xa>(v);   // row_bcast:15 -> lanes 31, 63: two rows
-  v = dpp_umax<0x143, 0xc>(v);   // row_bcast:31 -> lane 63: the wave
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// running block exponent: e = exponent above this step's largest |v| in the wave;
-// the accumulators `acc[0..n)` follow when it grows.  Returns the exponent in use.
-template <int N>
-__device__ __forceinline__ int block_exponent(const float (&v)[16], int &E, f32x16 *acc) {
-  unsigned m = 0u;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) m = umax_abs(m, v[i]);
-  if (!(APG_GW_KNOCKOUT & 4)) m = wave_umax_dpp(m);
-  bool bad = false;   // (a non-finite cotangent goes through the products as it is)
-  const int e = (APG_GW_KNOCKOUT & 4) ? 0 : bits_exp(m, bad, false);
-  if (e > E) {
-    if (E != kGwNoExp) {
-      const int d = E - e;
-#pragma unroll
-      for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[n][i] = __builtin_amdgcn_ldexpf(acc[n][i], d);
-    }
-    E = e;
-  }
-  return E;
-}
-
 // relu of a matrix-pipe result in ONE instruction: the signed-integer maximum of
 // the bit pattern and 0 (negative floats are negative integers).  fmaxf and
 // fmed3 canonicalise their input first (a second v_max per value); inline
@@ -1012,6 +998,11 @@ __device__ __forceinline__ int block_exponent(const float (&v)[16], int &E, f32x
 __device__ __forceinline__ float relu1(float v) {
   const int b = __builtin_bit_cast(int, v);
   return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// exponent above a (finite, non-negative) maximum; 0 for zero or non-finite
+__device__ __forceinline__ int amax_exponent(float m) {
+  return m > 0.f && m < __builtin_inff() ? __builtin_amdgcn_frexp_expf(m) : 0;
 }
 
 // what a step reads: issued one step ahead, right after the previous step's
@@ -1031,8 +1022,8 @@ constexpr int kGwWin = kGwSlots * 5 * kGwThreads;   // floats
 template <int PH>
 __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // tables | window | sum
-  float *const win = lds + kGwTab, *const red = lds + kGwTab + kGwWin;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // tables | window / sum
+  float *const win = lds + kGwTab;
   const int lane = threadIdx.x & 63, hi = lane >> 5, row = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const LdsView16 L16(lds, lane);
@@ -1046,19 +1037,32 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
   const float cb = lds[hTbc + 2 * ((row & 3) + 4 * (row >> 3)) + ((row >> 2) & 1)];
   // the fifth block's B operand: plane of column `row`, or the ones column
   constexpr int kAuxCols = PH == 0 ? kNF + kNH : kNH, kAuxPlane0 = PH == 0 ? 0 : kNF + 2 * kNH;
-  const bool aux_row = row < kAuxCols, ones_row = row == kAuxCols;
+  const bool aux_row = row < kAuxCols;
+  const float a_one = row == kAuxCols ? 1.f : 0.f;
 
   f32x16 acc[kGwBlocks];
 #pragma unroll
   for (int n = 0; n < kGwBlocks; ++n)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
-  int E = kGwNoExp, E2 = kGwNoExp;   // block exponents of d_gates / d_zout
+  // the wave's scales: 2^-E d_gates, 2^-E2 d_zout are at most 1
+  const int g0 = ((blockIdx.x >> 1) * kGwWaves + wave) * kGwGroups;
+  int E, E2;
+  {
+    float mg = 0.f, mz = 0.f;
+#pragma unroll
+    for (int gi = 0; gi < kGwGroups; ++gi)
+      if ((g0 + gi) * 32 < B) {
+        mg = fmaxf(mg, A.cot_amax[2 * (g0 + gi)]);
+        mz = fmaxf(mz, A.cot_amax[2 * (g0 + gi) + 1]);
+      }
+    E = amax_exponent(mg), E2 = amax_exponent(mz);
+  }
   const Op16 wc[2] = {L16.A(hA, nC), L16.A(hA, nC + 1)};   // the conv weights: B operand
 
 #pragma unroll 1
   for (int gi = 0; gi < kGwGroups; ++gi) {
-    const int b0 = (((blockIdx.x >> 1) * kGwWaves + wave) * kGwGroups + gi) * 32;
+    const int b0 = (g0 + gi) * 32;
     if (b0 >= B) break;   // (wave-uniform; the wave still takes part in the sum below)
     const int nvalid = B - b0;
     const int b = b0 + row;
@@ -1137,15 +1141,13 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
         if (PH == 1) ld.tz.get(zv);
         if (k + 1 < kH) issue(k + 1, 0);
         if (nvalid < 32) mask_tail(dv, hi, nvalid);
-        const int e = PH == 0 ? block_exponent<kGwBlocks>(dv, E, acc)
-                              : block_exponent<kGwBlocks - 1>(dv, E, acc);
-        split16(dv, e, ad);
+        split16(dv, E, ad);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) av[i] = ones_row ? 1.f : av[i];
+        for (int i = 0; i < 16; ++i) av[i] += a_one;   // (the ones column's plane reads 0)
         split16(av, 0, bx);
         if (PH == 1) {
           if (nvalid < 32) mask_tail(zv, hi, nvalid);
-          split16(zv, block_exponent<1>(zv, E2, acc + 4), az);
+          split16(zv, E2, az);
         }
       }
 #pragma unroll
@@ -1201,23 +1203,37 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
       }
     }
   }
-  // the workgroup's sum, waves in order, at true scale
-#pragma unroll 1
-  for (int wv = 0; wv < kGwWaves; ++wv) {
-    if (wave == wv) {
+  // the workgroup's sum at true scale, two accumulator blocks at a time: every
+  // wave puts them into its own LDS region (16-byte writes; the window is done
+  // with), then the 512 threads add the eight regions in wave order and write the
+  // partial
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 *const sum = reinterpret_cast<f32x4 *>(win);
+  f32x4 *dst = reinterpret_cast<f32x4 *>(A.partials + (size_t)blockIdx.x * kGwPart);
+  constexpr int kRound = 2, kQuads = kRound * 4 * 64;   // blocks / float4 per wave and round
+  static_assert(kGwWaves * kQuads * 4 <= kGwWin, "the sum regions fit the window's LDS");
 #pragma unroll
-      for (int n = 0; n < kGwBlocks; ++n)
+  for (int n0 = 0; n0 < kGwBlocks; n0 += kRound) {
+    __syncthreads();   // (the window / the previous round have been read)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float *p = red + (n * 16 + i) * 64 + lane;
-          const float v = __builtin_amdgcn_ldexpf(acc[n][i], (n == 4 && PH == 1) ? E2 : E);
-          *p = wv ? *p + v : v;
-        }
-    }
+    for (int n = n0; n < n0 + kRound && n < kGwBlocks; ++n)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int e = (n == 4 && PH == 1) ? E2 : E;
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_ldexpf(acc[n][4 * i4 + c], e);
+        sum[wave * kQuads + ((n - n0) * 4 + i4) * 64 + lane] = v;
+      }
     __syncthreads();
+    const int quads = (n0 + kRound <= kGwBlocks ? kRound : kGwBlocks - n0) * 4 * 64;
+    for (int idx = threadIdx.x; idx < quads; idx += kGwThreads) {
+      f32x4 v = sum[idx];
+#pragma unroll
+      for (int wv = 1; wv < kGwWaves; ++wv) v += sum[wv * kQuads + idx];
+      dst[n0 * 4 * 64 + idx] = v;
+    }
   }
-  float *dst = A.partials + (size_t)blockIdx.x * kGwPart;
-  for (int idx = threadIdx.x; idx < kGwPart; idx += kGwThreads) dst[idx] = red[idx];
 }
 
 __global__ __launch_bounds__(kGwThreads) void lstm_gate_wgrad_kernel(GwArgs A) {
@@ -1231,9 +1247,9 @@ __global__ __launch_bounds__(kGwThreads) void lstm_gate_wgrad_kernel(GwArgs A) {
 // (part, o) adds every 8th workgroup of output o's parity, part 0 adds the eight
 struct GwReduceArgs {
   const float *partials;
-  int chunks;          // workgroup pairs
-  float *ih_hh;        // [32][183]
-  float *b_ih;         // [32]
+  int chunks;            // workgroup pairs
+  float *ih_hh;          // [32][183]
+  float *b_ih;           // [32]
   float *w_out, *b_out;  // [4][8], [4]
 };
 __global__ __launch_bounds__(256) void lstm_gate_wgrad_reduce_kernel(GwReduceArgs A) {
@@ -1248,7 +1264,8 @@ __global__ __launch_bounds__(256) void lstm_gate_wgrad_reduce_kernel(GwReduceArg
   if (pt) return;
 #pragma unroll
   for (int q = 1; q < 8; ++q) s += part[q][ol];
-  const int n = r >> 10, i = (r >> 6) & 15, lane = r & 63;
+  // element r of a partial: block n, register 4 i4 + c of lane `lane`
+  const int n = r >> 10, i = 4 * ((r >> 8) & 3) + (r & 3), lane = (r >> 2) & 63;
   const int g = rrow(i) + 4 * (lane >> 5), col = lane & 31;
   if (n < 4) {
     if (col < kNC) A.ih_hh[g * (kNX + kNH) + kNF + col * kNP + 4 * ph + n] = s;
@@ -1364,8 +1381,8 @@ static int lstm_bwd(const float *state0, const float *states, const float *actio
                     const ApgQuadParams *params, const ApgQuadLossWeights *weights,
                     const ApgLstmPolicy *policy, int B, int H, float *loss_partials,
                     float *loss, float *d_gates, float *d_zout, float *d_conv,
-                    float *grad_state0, float *grad_h0, float *grad_c0, float *workspace,
-                    apg_stream_t stream) {
+                    float *grad_state0, float *grad_h0, float *grad_c0, float *cot_amax,
+                    float *workspace, apg_stream_t stream) {
   if (int e = check_lstm(params, policy, B, H, true)) return e;
   if (!weights) { set_error("weights is NULL"); return APG_ERR_ARG; }
   if (ref_cols != 9 && ref_cols != 6) {
@@ -1389,6 +1406,7 @@ static int lstm_bwd(const float *state0, const float *states, const float *actio
   A.loss_partials = loss_partials, A.d_gates = d_gates, A.d_zout = d_zout;
   A.d_conv = d_conv, A.grad_state0 = grad_state0, A.grad_h0 = grad_h0;
   A.grad_c0 = grad_c0;
+  A.cot_amax = cot_amax;
   A.tables = workspace;
   A.c = make_const(*params, dt);
   A.w = *weights;
@@ -1417,12 +1435,12 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const ApgLstmPolicy *policy, int B, int H,
                               float *loss_partials, float *loss, float *d_gates,
                               float *d_zout, float *d_conv, float *grad_state0,
-                              float *grad_h0, float *grad_c0, float *workspace,
-                              apg_stream_t stream) {
+                              float *grad_h0, float *grad_c0, float *cot_amax,
+                              float *workspace, apg_stream_t stream) {
   if (!policy) { set_error("policy is NULL"); return APG_ERR_ARG; }
   return lstm_bwd(state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt, params,
                   weights, policy, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
-                  grad_state0, grad_h0, grad_c0, workspace, stream);
+                  grad_state0, grad_h0, grad_c0, cot_amax, workspace, stream);
 }
 
 int apg_quad_lstm_rollout_bwd_packed(const float *state0, const float *states,
@@ -1433,10 +1451,11 @@ int apg_quad_lstm_rollout_bwd_packed(const float *state0, const float *states,
                                      const float *tables_bwd, int B, int H,
                                      float *loss_partials, float *loss, float *d_gates,
                                      float *d_zout, float *d_conv, float *grad_state0,
-                                     float *grad_h0, float *grad_c0, apg_stream_t stream) {
+                                     float *grad_h0, float *grad_c0, float *cot_amax,
+                                     apg_stream_t stream) {
   return lstm_bwd(state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt, params,
                   weights, nullptr, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
-                  grad_state0, grad_h0, grad_c0, const_cast<float *>(tables_bwd), stream);
+                  grad_state0, grad_h0, grad_c0, cot_amax, const_cast<float *>(tables_bwd), stream);
 }
 
 static int gw_blocks(int B) {
@@ -1444,13 +1463,16 @@ static int gw_blocks(int B) {
   return 2 * ((groups + per - 1) / per);
 }
 
+int apg_quad_lstm_cot_amax_floats(int B) { return B <= 0 ? 0 : 2 * ((B + 31) / 32); }
+
 int apg_quad_lstm_gate_wgrad_partials_floats(int B) {
   return B <= 0 ? 0 : gw_blocks(B) * kGwPart;
 }
 
 int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const float *in_ref,
                              const float *acts, const float *d_gates, const float *d_zout,
-                             const ApgLstmPolicy *policy, float *tables_fwd, int B, int H,
+                             const float *cot_amax, const ApgLstmPolicy *policy,
+                             float *tables_fwd, int B, int H,
                              float *partials, float *ih_hh, float *b_ih, float *w_out,
                              float *b_out, apg_stream_t stream) {
   if (H != kH) {
@@ -1474,8 +1496,8 @@ int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const flo
       return check_launch("memset(gate gradients)");
     return APG_OK;
   }
-  if (!state0 || !states || !in_ref || !acts || !d_gates || !d_zout || !tables_fwd ||
-      !partials) {
+  if (!state0 || !states || !in_ref || !acts || !d_gates || !d_zout || !cot_amax ||
+      !tables_fwd || !partials) {
     set_error("apg_quad_lstm_gate_wgrad: NULL buffer");
     return APG_ERR_ARG;
   }
@@ -1492,11 +1514,12 @@ int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const flo
   }
   GwArgs A;
   A.state0 = state0, A.states = states, A.in_ref = in_ref, A.acts = acts;
-  A.d_gates = d_gates, A.d_zout = d_zout, A.tables = tables_fwd, A.partials = partials;
+  A.d_gates = d_gates, A.d_zout = d_zout, A.cot_amax = cot_amax;
+  A.tables = tables_fwd, A.partials = partials;
   A.B = B;
   const int blocks = gw_blocks(B);
   hipLaunchKernelGGL(lstm_gate_wgrad_kernel, dim3(blocks), dim3(kGwThreads),
-                     (kGwTab + kGwWin + kGwPart) * sizeof(float), st, A);
+                     (kGwTab + kGwWin) * sizeof(float), st, A);
   if (int e = check_launch("quad_lstm_gate_wgrad")) return e;
   GwReduceArgs R;
   R.partials = partials, R.chunks = blocks / 2;

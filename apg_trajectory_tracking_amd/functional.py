@@ -1193,6 +1193,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         partials = new(max(1, lib().apg_quad_lstm_loss_partials_count(B)))
         loss = new(1)
         d_gates, d_zout, d_conv = new(32, N), new(4, N), new(_CONV_DIAG_PLANES, B)
+        cot_amax = new(max(1, lib().apg_quad_lstm_cot_amax_floats(B)))
         # optional input gradients (state0, h0, c0)
         g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
         g_h0 = new(8, B) if ctx.needs_input_grad[3] else None
@@ -1204,7 +1205,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
                 relu_mask.data_ptr(), ptr(gates), ptr(hc), float(dt),
                 ctypes.byref(params), ctypes.byref(weights), ptr(tables.bwd), B, H,
                 ptr(partials), None, ptr(d_gates), ptr(d_zout), ptr(d_conv), ptr(g_s0),
-                ptr(g_h0), ptr(g_c0), st), "apg_quad_lstm_rollout_bwd_packed")
+                ptr(g_h0), ptr(g_c0), ptr(cot_amax), st), "apg_quad_lstm_rollout_bwd_packed")
             ctx.lstm_tail = (partials, loss, pw)
         else:
             check(lib().apg_quad_lstm_rollout_bwd(
@@ -1213,8 +1214,8 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
                 ctypes.byref(params),
                 ctypes.byref(weights), ctypes.byref(pol), B, H, ptr(partials),
                 ptr(loss), ptr(d_gates), ptr(d_zout), ptr(d_conv), ptr(g_s0),
-                ptr(g_h0), ptr(g_c0), ptr(ws), st), "apg_quad_lstm_rollout_bwd")
-        ctx.save_for_backward(refbuf, acts, d_gates, d_zout, d_conv, *pw.values())
+                ptr(g_h0), ptr(g_c0), ptr(cot_amax), ptr(ws), st), "apg_quad_lstm_rollout_bwd")
+        ctx.save_for_backward(refbuf, acts, d_gates, d_zout, d_conv, cot_amax, *pw.values())
         ctx.input_grads = (g_s0, g_h0, g_c0)
         ctx.mark_non_differentiable(states, actions)
         ctx.dims = (B, H)
@@ -1293,7 +1294,7 @@ def _lstm_param_grads(saved, dims, tail=None):
     momentum SGD if `update` = (lr, momentum, {parameter name: buffer}), the next
     step's tables, the loss) instead of three elementwise launches, the
     optimizer's, the loss reduction and two table packs."""
-    refbuf, acts, d_gates, d_zout, d_conv = saved[:5]
+    refbuf, acts, d_gates, d_zout, d_conv, cot_amax = saved[:6]
     B, H = dims
     dev = acts.device
     flat, gr = _flat_grads(dev, {
@@ -1309,7 +1310,7 @@ def _lstm_param_grads(saved, dims, tail=None):
         pol, tab = None, tail[3].fwd          # resident tables (current: ensure())
     else:
         pw8 = dict(zip(("conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out",
-                        "b_out"), saved[5:13]))
+                        "b_out"), saved[6:14]))
         pol = ctypes.byref(_capi.ApgLstmPolicy(**{k: ptr(v) for k, v in pw8.items()}))
         tab = torch.empty(lib().apg_quad_lstm_workspace_floats(), dtype=torch.float32,
                           device=dev)
@@ -1317,7 +1318,8 @@ def _lstm_param_grads(saved, dims, tail=None):
                           dtype=torch.float32, device=dev)
     check(lib().apg_quad_lstm_gate_wgrad(
         ptr(st_all[:12]), ptr(st_all[12:]), ptr(refbuf[:2 * H * 9]), ptr(acts),
-        ptr(d_gates), ptr(d_zout), pol, ptr(tab), B, H, ptr(scratch), ptr(ih_hh),
+        ptr(d_gates), ptr(d_zout), ptr(cot_amax), pol, ptr(tab), B, H, ptr(scratch),
+        ptr(ih_hh),
         ptr(gr["lstm.bias_ih"]), ptr(gr["fc_out.weight"]), ptr(gr["fc_out.bias"]),
         stream_of(acts)), "apg_quad_lstm_gate_wgrad")
     conv, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.weight"],

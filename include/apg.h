@@ -260,13 +260,17 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
  *                        (hi = pos / 4: the half-wave that holds the position;
  *                        tau in [0, 13)), plane = ch * 26 + hi * 13 + tau
  *     planes [520, 720): P[ch][k] = sum_pos d[ch][pos][k], plane = 520 + ch*10 + k
- * optional grad_state0 [12][B], grad_h0 / grad_c0 [8][B].
+ * optional grad_state0 [12][B], grad_h0 / grad_c0 [8][B]; optional cot_amax
+ * [apg_quad_lstm_cot_amax_floats(B)] = per group of 32 trajectories the largest
+ * |d_gates| and |d_zout| of the unroll (apg_quad_lstm_gate_wgrad scales its fp16
+ * operands by them).
  *   dW_ih = d_gates x^T, dW_hh = d_gates h_prev^T, db_ih = db_hh = sum d_gates,
  *   dW_out = d_zout hnew^T, db_out = sum d_zout  (apg_quad_lstm_gate_wgrad),
  *   dconv_w[ch][c][t] = sum_{hi,tau,n} G[ch][hi][tau][n] ref[n][4 hi + tau + t][c]
  *                       - (c < 3) sum_{k,n} P[ch][k][n] pos_k[n][c],
  *   dconv_b[ch] = sum_{k,n} P[ch][k][n]. */
 int apg_quad_lstm_loss_partials_count(int B);
+int apg_quad_lstm_cot_amax_floats(int B);
 int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const float *actions, const float *ref,
                               int ref_cols, const unsigned *relu_mask,
@@ -276,8 +280,8 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               const ApgLstmPolicy *policy, int B, int H,
                               float *loss_partials, float *loss, float *d_gates,
                               float *d_zout, float *d_conv, float *grad_state0,
-                              float *grad_h0, float *grad_c0, float *workspace,
-                              apg_stream_t stream);
+                              float *grad_h0, float *grad_c0, float *cot_amax,
+                              float *workspace, apg_stream_t stream);
 
 /* Round 6: the gate and head weight gradients of the LSTM unroll from the
  * cotangent planes of the reverse sweep - what `loss.backward()` leaves in
@@ -286,11 +290,13 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
  * outputs in memory: one kernel recomputes relu(conv(window)) per step on the
  * matrix cores (operands swapped: trajectories in the registers) and multiplies
  * it, the stored features / h_prev and a ones column with d_gates, h_new and
- * ones with d_zout, trajectory-major; a second one sums the workgroups in index
- * order (bit-reproducible).
+ * ones with d_zout, trajectory-major (one wave per SIMD: all eight window
+ * positions of 64 trajectories); a second one sums the workgroups in index order
+ * (bit-reproducible).
  *   state0 [12][B], states [H][12][B], in_ref [2H][9][B] as for the sweeps;
  *   acts [39][N] = x (15) | hc (16) | hnew (8) of apg_quad_lstm_rollout_fwd as
- *   ONE buffer; d_gates [32][N], d_zout [4][N] of apg_quad_lstm_rollout_bwd.
+ *   ONE buffer; d_gates [32][N], d_zout [4][N], cot_amax of
+ *   apg_quad_lstm_rollout_bwd.
  *   `policy` given: its forward tables are packed into `tables_fwd`
  *   (apg_quad_lstm_workspace_floats() floats) first; NULL: `tables_fwd` holds them
  *   (apg_quad_lstm_pack_tables / apg_quad_lstm_step_tail).
@@ -300,7 +306,8 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
 int apg_quad_lstm_gate_wgrad_partials_floats(int B);
 int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const float *in_ref,
                              const float *acts, const float *d_gates, const float *d_zout,
-                             const ApgLstmPolicy *policy, float *tables_fwd, int B, int H,
+                             const float *cot_amax, const ApgLstmPolicy *policy,
+                             float *tables_fwd, int B, int H,
                              float *partials, float *ih_hh, float *b_ih, float *w_out,
                              float *b_out, apg_stream_t stream);
 
@@ -329,7 +336,8 @@ int apg_quad_lstm_rollout_bwd_packed(const float *state0, const float *states,
                                      const float *tables_bwd, int B, int H,
                                      float *loss_partials, float *loss, float *d_gates,
                                      float *d_zout, float *d_conv, float *grad_state0,
-                                     float *grad_h0, float *grad_c0, apg_stream_t stream);
+                                     float *grad_h0, float *grad_c0, float *cot_amax,
+                                     apg_stream_t stream);
 /* What follows the weight-gradient products of the step, in one launch of one
  * workgroup: the gradients into their tensors (conv_ref.weight = grad.conv_w as
  * the window product left it minus the position part conv_pos [20][3];
