@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
           mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
           // (round 6: relu(conv) is NOT stored - 160 of the 236 planes this
           // sweep wrote; lstm_gate_wgrad_kernel recomputes it from the window)
-          rv[e * 12 + i] = fmaxf(v, 0.f);
+          rv[e * 12 + i] = relu1(v);
         }
       }
 #pragma unroll
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void lstm_closed_loop_kernel(LoopArgs A) 
           cv = mma3(L16.A(hA, nC + kb), x, cv);
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) rv[e * 12 + i] = fmaxf(cv[i], 0.f);
+        for (int i = 0; i < 12; ++i) rv[e * 12 + i] = relu1(cv[i]);
       }
 #pragma unroll
       for (int kb = 0; kb < 3; ++kb) {
@@ -987,17 +987,6 @@ __device__ __forceinline__ void mask_tail(float (&v)[16], int hi, int nvalid) {
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     if (rrow(i) + 4 * hi >= nvalid) v[i] = 0.f;
-}
-
-// relu of a matrix-pipe result in ONE instruction: the signed-integer maximum of
-// the bit pattern and 0 (negative floats are negative integers).  fmaxf and
-// fmed3 canonicalise their input first (a second v_max per value); inline
-// assembly is no option: the compiler's hazard recognizer does not see a
-// matrix-pipe result read by an asm statement and leaves out the wait states
-// (measured: stale accumulators).
-__device__ __forceinline__ float relu1(float v) {
-  const int b = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
 // exponent above a (finite, non-negative) maximum; 0 for zero or non-finite

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
         float v = cv[i];
         mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
         xm_conv = umax(xm_conv, v);   // (before the relu: it would drop a NaN)
-        v = fmaxf(v, 0.f);
+        v = relu1(v);
         Px1.st(i < 8 ? vc : vb_lo, (kW + rrow(i) * kNP + pos) * pN, v);
         rv[e * 12 + i] = v;
       }

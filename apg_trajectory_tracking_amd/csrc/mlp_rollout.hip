@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
         for (int i = 0; i < 12; ++i) {  // rows r(i) + 4 hi < 20 are real channels
           float v = cv[i];
           mbits[i >> 2] |= (v > 0.f ? 1u : 0u) << ((i & 3) * 8 + pos);
-          v = fmaxf(v, 0.f);
+          v = relu1(v);
           if (XMAX) xm_c = fmaxf(xm_c, v);
           // plane 64 + (r(i) + 4 hi) * 8 + pos: the 4 hi * 8 rows are in vc
           Px1.st(i < 8 ? vc : vn_lo, (kW + rrow(i) * kNP + pos) * pN, v);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void mlp_closed_loop_kernel(LoopArgs A) {
           cv = mma3(L16.A(hA, nC + kb), x, cv);
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) rv[e * 12 + i] = fmaxf(cv[i], 0.f);
+        for (int i = 0; i < 12; ++i) rv[e * 12 + i] = relu1(cv[i]);
       }
 #pragma unroll
       for (int kb = 0; kb < 3; ++kb) {

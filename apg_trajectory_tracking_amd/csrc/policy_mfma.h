@@ -43,6 +43,17 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 
+// relu of a matrix-pipe result in ONE instruction: the signed-integer maximum of
+// the bit pattern and 0 (negative floats are negative integers).  fmaxf and
+// fmed3 canonicalise their input first (a second v_max per value); inline
+// assembly is no option: the compiler's hazard recognizer does not see a
+// matrix-pipe result read by an asm statement and leaves out the wait states
+// (measured: stale accumulators).
+__device__ __forceinline__ float relu1(float v) {
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) {
   return 1.0f / (1.0f + expf(-x));
 }
