@@ -196,6 +196,13 @@ SIGNATURES = {
         ctypes.POINTER(ApgQuadLossWeights), _P,
         _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_quad_lstm_step_tail": [ctypes.POINTER(ApgLstmStepTail), _P],
+    "apg_quad_lstm_rollout_fwd_rows": [
+        ctypes.POINTER(ApgBatchRows), _P, _P, _F, ctypes.POINTER(ApgQuadParams), _P, _I, _I,
+        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_rollout_bwd_rows": [
+        ctypes.POINTER(ApgBatchRows), _I, _P, _P, _P, _P, _P, _P, _F,
+        ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgQuadLossWeights), _P,
+        _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "apg_quad_lstm_gate_wgrad_partials_floats": [_I],
     "apg_quad_lstm_gate_wgrad": [
         _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicy), _P, _I, _I,

@@ -159,11 +159,20 @@ struct FwdArgs {
   const float *tables;   // packed operand tables (lstm_pack_fwd16_kernel)
   QuadConst c;
   int B;
+  // ROWS: the minibatch is named by row numbers of the whole data set's tensors
+  // (TrainBase.run_epoch's batch selection, scripts/train_base.py:191-194) and
+  // this sweep reads state0 [n][12] and in_ref [n][>= 2H][9] through them; it
+  // WRITES the state0 / in_ref planes its followers read (no gather pass)
+  const long long *index;
+  const float *r_state0, *r_in_ref;
+  unsigned bytes_state0, bytes_in_ref;   // n_rows x ld x 4
+  int ld_state0, ld_in_ref;
 };
 
+template <bool ROWS>
 __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  fill_lds(lds, A.tables, kFwd16Lds);
+  fill_lds_issue(lds, A.tables, kFwd16Lds);   // (waited for behind the first loads)
   const LdsView16 L16(lds, threadIdx.x & 63);
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const LdsView L(lds, lane);
@@ -184,9 +193,47 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   const unsigned vb_lo = st_lo ? vb : kDead;
   const unsigned vb_u = live ? vb + (hi ? 4u * pitchB : 0u) : kDead;  // unit r + 4 hi
 
+  // ROWS: the lane's data-set row (range-checked buffers: a row number beyond
+  // the data set reads zeros); the planes of what it reads are this sweep's output
+  const Planes Rs0(A.r_state0, 1, ROWS ? A.bytes_state0 : 0u);
+  const Planes Rin(A.r_in_ref, 1, ROWS ? A.bytes_in_ref : 0u);
+  unsigned vr_s = kDead, vr_in = kDead;
+  if (ROWS && live) {
+    const unsigned rown = (unsigned)A.index[b];
+    vr_s = rown * (unsigned)A.ld_state0 * 4u;
+    vr_in = rown * (unsigned)A.ld_in_ref * 4u + (hi ? 16u : 0u);   // column + 4 hi
+  }
+  // reference row r, columns 4 hi .. + 4 of the lane's trajectory (ROWS: 20
+  // contiguous bytes of its data-set row as 16 + 4, and their planes for the
+  // followers: the upper half's first column is the lower half's last)
+  auto window_row = [&](int r, unsigned pB, float (&v)[5]) {
+    if (!ROWS) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) v[j] = Pin.ld(vb_u, (r * kRD + j) * pB);
+      return;
+    }
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(Rin.rsrc, (int)vr_in, r * kRD * 4, 0);
+    const f32x4_ f = __builtin_bit_cast(f32x4_, q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = f[j];
+    v[4] = Rin.ld(vr_in, (r * kRD + 4) * 4);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) Pin.st(hi && j == 0 ? kDead : vb_u, (r * kRD + j) * pB, v[j]);
+  };
   float s[12], h[4], cell[4];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = Ps0.ld(vb, i * pitchB);
+  for (int i = 0; i < 12; ++i) {
+    if (!ROWS) {
+      s[i] = Ps0.ld(vb, i * pitchB);
+    } else if (i % 4 == 0) {   // 48 contiguous bytes: three 16-byte loads
+      const f32x4_ f = __builtin_bit_cast(
+          f32x4_, __builtin_amdgcn_raw_buffer_load_b128(Rs0.rsrc, (int)vr_s, i * 4, 0));
+      s[i] = f[0], s[i + 1] = f[1], s[i + 2] = f[2], s[i + 3] = f[3];
+    }
+  }
+  if (ROWS)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Ps0.st(vb_lo, i * pitchB, s[i]);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     h[r] = Ph0.ld(vb_u, r * pitchB);
@@ -196,9 +243,13 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   // 4..8 in the upper half (see fwd16_weight)
   float w[kH][5];
 #pragma unroll
-  for (int r = 0; r < kH; ++r)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) w[r][j] = Pin.ld(vb_u, (r * kRD + j) * pitchB);
+  for (int r = 0; r < kH; ++r) window_row(r, pitchB, w[r]);
+  if (ROWS) {   // (the last row: no step reads it, the planes are whole all the same)
+    float last[5];
+    window_row(2 * kH - 1, pitchB, last);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // the tables
 
 #pragma unroll 1
   for (int k = 0; k < kH; ++k) {
@@ -207,6 +258,10 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
     const unsigned vn_lo = st_lo ? col : kDead;
     const unsigned vr = live ? col + (hi ? 4u * pitchN : 0u) : kDead;   // + row 4 hi
     const unsigned vm = live ? col + (hi ? pitchN : 0u) : kDead;        // + mask word hi
+    // the row that slides in for the next step: requested first (ROWS: a scattered
+    // read through the index - a step of latency to hide)
+    float wn[5];
+    if (k + 1 < kH) window_row(k + kH, pB, wn);
     const Trig t = make_trig(&s[3]);
     float feat[kNF];
     quad_features(s, t, feat);
@@ -326,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) w[r][j] = w[r + 1][j];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) w[kH - 1][j] = Pin.ld(vb_u, ((k + kH) * kRD + j) * pB);
+      for (int j = 0; j < 5; ++j) w[kH - 1][j] = wn[j];
     }
   }
 }
@@ -689,8 +744,14 @@ struct BwdArgs {
   QuadConst c;
   ApgQuadLossWeights w;
   int B, ref_cols, vel_col;
+  // ROWS: ref [n][>= H][ref_cols] of the whole data set, read through `index`
+  const long long *index;
+  const float *r_ref;
+  unsigned bytes_ref;
+  int ld_ref;
 };
 
+template <bool ROWS>
 __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds(lds, A.tables, kBwd16Lds);
@@ -710,6 +771,9 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
   const Planes Pmk(A.mask, 5, pitchN), Pdg(A.d_gates, kNG, pitchN);
   const Planes Pdz(A.d_zout, 4, pitchN), Pdc(A.d_conv, kConvPlanes, pitchB);
   const unsigned vb = live ? (unsigned)b * 4u : kDead;
+  const Planes Rrf(A.r_ref, 1, ROWS ? A.bytes_ref : 0u);
+  const unsigned vr_ref =
+      ROWS && live ? (unsigned)A.index[b] * (unsigned)A.ld_ref * 4u : kDead;
 
   float lam[12], dh[4], dc[4];
 #pragma unroll
@@ -728,6 +792,9 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
   const unsigned vg = live ? (unsigned)b * 4u + (hi ? kTau * pitchB : 0u) : kDead;
   const unsigned vb_lo = st_lo ? (unsigned)b * 4u : kDead;
 
+  auto ref_value = [&](int k, int i, unsigned pB) {
+    return Prf.ld(vb, (k * A.ref_cols + i) * pB);
+  };
 #pragma unroll 1
   for (int k = kH - 1; k >= 0; --k) {
     const unsigned pB = opaque(pitchB), pN = opaque(pitchN);
@@ -743,10 +810,19 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_bwd_kernel(BwdArgs A) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] = Pac.ld(vb, (k * 4 + j) * pB);
+    if (ROWS) {   // 12 contiguous bytes each of the lane's data-set row
+      typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+      typedef float f32x3 __attribute__((ext_vector_type(3)));
+      const f32x3 p3 = __builtin_bit_cast(f32x3, (u32x3)__builtin_amdgcn_raw_buffer_load_b96(
+          Rrf.rsrc, (int)vr_ref, k * A.ref_cols * 4, 0));
+      const f32x3 v3 = __builtin_bit_cast(f32x3, (u32x3)__builtin_amdgcn_raw_buffer_load_b96(
+          Rrf.rsrc, (int)vr_ref, (k * A.ref_cols + A.vel_col) * 4, 0));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      rp[i] = Prf.ld(vb, (k * A.ref_cols + i) * pB);
-      rv[i] = Prf.ld(vb, (k * A.ref_cols + A.vel_col + i) * pB);
+      for (int i = 0; i < 3; ++i) rp[i] = p3[i], rv[i] = v3[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        rp[i] = ref_value(k, i, pB), rv[i] = ref_value(k, A.vel_col + i, pB);
     }
     unsigned mw[5];
 #pragma unroll
@@ -1308,12 +1384,36 @@ int apg_quad_lstm_loss_partials_count(int B) {
 
 // `policy` given: its tables are packed into `workspace` first; NULL: `workspace`
 // holds them already (apg_quad_lstm_pack_tables / apg_quad_lstm_step_tail)
-static int lstm_fwd(const float *state0, const float *in_ref, const float *h0,
+// rows given: the `_rows` entry points - state0 / in_ref (forward) and ref
+// (reverse) are read through rows->index; `state0`, `in_ref` are then OUTPUTS
+static int check_rows(const ApgBatchRows *rows, int B, int H, int ref_cols, bool reverse) {
+  if (B > 0 && (!rows->index || (reverse ? !rows->ref : (!rows->state0 || !rows->in_ref)))) {
+    set_error("rows: NULL index / tensor");
+    return APG_ERR_ARG;
+  }
+  const long long need = reverse ? (long long)H * ref_cols : 2ll * H * kRD;
+  const long long ld = reverse ? rows->ld_ref : rows->ld_in_ref;
+  if (rows->n_rows < 1 || ld < need || (!reverse && rows->ld_state0 < 12)) {
+    set_error("rows: need n_rows >= 1 and row strides of at least 12 / 2H x 9 / H x ref_cols");
+    return APG_ERR_ARG;
+  }
+  if (rows->n_rows * ld * 4 >= (1ll << 32) - 64 ||
+      (!reverse && rows->n_rows * (long long)rows->ld_state0 * 4 >= (1ll << 32) - 64)) {
+    set_error("rows: the data set's tensors must stay below 4 GiB (32-bit byte offsets)");
+    return APG_ERR_ARG;
+  }
+  return APG_OK;
+}
+
+static int lstm_fwd(const ApgBatchRows *rows, const float *state0, const float *in_ref,
+                    const float *h0,
                     const float *c0, float dt, const ApgQuadParams *params,
                     const ApgLstmPolicy *policy, int B, int H, float *states,
                     float *actions, float *x, float *gates, float *hc, float *hnew,
                     unsigned *relu_mask, float *workspace, apg_stream_t stream) {
   if (int e = check_lstm(params, policy, B, H, true)) return e;
+  if (rows)
+    if (int e = check_rows(rows, B, H, 0, false)) return e;
   if (B == 0) return APG_OK;
   if (!state0 || !in_ref || !h0 || !c0 || !states || !actions || !x || !gates ||
       !hc || !hnew || !relu_mask || !workspace) {
@@ -1328,6 +1428,14 @@ static int lstm_fwd(const float *state0, const float *in_ref, const float *h0,
   A.tables = workspace;
   A.c = make_const(*params, dt);
   A.B = B;
+  A.index = nullptr, A.r_state0 = A.r_in_ref = nullptr;
+  A.bytes_state0 = A.bytes_in_ref = 0u, A.ld_state0 = A.ld_in_ref = 0;
+  if (rows) {
+    A.index = rows->index, A.r_state0 = rows->state0, A.r_in_ref = rows->in_ref;
+    A.ld_state0 = rows->ld_state0, A.ld_in_ref = rows->ld_in_ref;
+    A.bytes_state0 = (unsigned)(rows->n_rows * (long long)rows->ld_state0 * 4);
+    A.bytes_in_ref = (unsigned)(rows->n_rows * (long long)rows->ld_in_ref * 4);
+  }
   hipStream_t st = (hipStream_t)stream;
   if (policy) {
     PackArgs P;
@@ -1335,9 +1443,13 @@ static int lstm_fwd(const float *state0, const float *in_ref, const float *h0,
     hipLaunchKernelGGL(lstm_pack_fwd16_kernel, dim3((kFwd16Lds + 255) / 256), dim3(256),
                        0, st, P);
   }
-  hipLaunchKernelGGL(lstm_rollout_fwd_kernel,
-                     dim3((B + kTrajPerBlock - 1) / kTrajPerBlock), dim3(kThreads),
-                     kFwd16Lds * sizeof(float), st, A);
+  const dim3 grid((B + kTrajPerBlock - 1) / kTrajPerBlock);
+  if (rows)
+    hipLaunchKernelGGL(lstm_rollout_fwd_kernel<true>, grid, dim3(kThreads),
+                       kFwd16Lds * sizeof(float), st, A);
+  else
+    hipLaunchKernelGGL(lstm_rollout_fwd_kernel<false>, grid, dim3(kThreads),
+                       kFwd16Lds * sizeof(float), st, A);
   return check_launch("quad_lstm_rollout_fwd");
 }
 
@@ -1350,7 +1462,8 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
                               unsigned *relu_mask, float *workspace,
                               apg_stream_t stream) {
   if (!policy) { set_error("policy is NULL"); return APG_ERR_ARG; }
-  return lstm_fwd(state0, in_ref, h0, c0, dt, params, policy, B, H, states, actions, x, gates,
+  return lstm_fwd(nullptr, state0, in_ref, h0, c0, dt, params, policy, B, H, states, actions, x,
+                  gates,
                   hc, hnew, relu_mask, workspace, stream);
 }
 
@@ -1360,11 +1473,13 @@ int apg_quad_lstm_rollout_fwd_packed(const float *state0, const float *in_ref,
                                      int B, int H, float *states, float *actions, float *x,
                                      float *gates, float *hc, float *hnew,
                                      unsigned *relu_mask, apg_stream_t stream) {
-  return lstm_fwd(state0, in_ref, h0, c0, dt, params, nullptr, B, H, states, actions, x, gates,
+  return lstm_fwd(nullptr, state0, in_ref, h0, c0, dt, params, nullptr, B, H, states, actions, x,
+                  gates,
                   hc, hnew, relu_mask, const_cast<float *>(tables_fwd), stream);
 }
 
-static int lstm_bwd(const float *state0, const float *states, const float *actions,
+static int lstm_bwd(const ApgBatchRows *rows, const float *state0, const float *states,
+                    const float *actions,
                     const float *ref, int ref_cols, const unsigned *relu_mask,
                     const float *gates, const float *hc, float dt,
                     const ApgQuadParams *params, const ApgQuadLossWeights *weights,
@@ -1378,13 +1493,15 @@ static int lstm_bwd(const float *state0, const float *states, const float *actio
     set_error("ref_cols must be 9 or 6");
     return APG_ERR_ARG;
   }
+  if (rows)
+    if (int e = check_rows(rows, B, H, ref_cols, true)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
     if (loss && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess)
       return check_launch("memset(loss)");
     return APG_OK;
   }
-  if (!state0 || !states || !actions || !ref || !relu_mask || !gates || !hc ||
+  if (!state0 || !states || !actions || (!ref && !rows) || !relu_mask || !gates || !hc ||
       !loss_partials || !d_gates || !d_zout || !d_conv || !workspace) {
     set_error("NULL buffer");
     return APG_ERR_ARG;
@@ -1400,6 +1517,11 @@ static int lstm_bwd(const float *state0, const float *states, const float *actio
   A.c = make_const(*params, dt);
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
+  A.index = nullptr, A.r_ref = nullptr, A.bytes_ref = 0u, A.ld_ref = 0;
+  if (rows) {
+    A.index = rows->index, A.r_ref = rows->ref, A.ld_ref = rows->ld_ref;
+    A.bytes_ref = (unsigned)(rows->n_rows * (long long)rows->ld_ref * 4);
+  }
   if (policy) {
     PackArgs P;
     P.pol = *policy, P.dst = workspace;
@@ -1407,8 +1529,12 @@ static int lstm_bwd(const float *state0, const float *states, const float *actio
                        0, st, P);
   }
   const int blocks = (B + kTrajPerBlock - 1) / kTrajPerBlock;
-  hipLaunchKernelGGL(lstm_rollout_bwd_kernel, dim3(blocks), dim3(kThreads),
-                     kBwd16Lds * sizeof(float), st, A);
+  if (rows)
+    hipLaunchKernelGGL(lstm_rollout_bwd_kernel<true>, dim3(blocks), dim3(kThreads),
+                       kBwd16Lds * sizeof(float), st, A);
+  else
+    hipLaunchKernelGGL(lstm_rollout_bwd_kernel<false>, dim3(blocks), dim3(kThreads),
+                       kBwd16Lds * sizeof(float), st, A);
   if (int e = check_launch("quad_lstm_rollout_bwd")) return e;
   if (loss)
     return launch_reduce_partials(loss_partials, blocks * (kThreads / kWave), loss, st);
@@ -1427,8 +1553,8 @@ int apg_quad_lstm_rollout_bwd(const float *state0, const float *states,
                               float *grad_h0, float *grad_c0, float *cot_amax,
                               float *workspace, apg_stream_t stream) {
   if (!policy) { set_error("policy is NULL"); return APG_ERR_ARG; }
-  return lstm_bwd(state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt, params,
-                  weights, policy, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
+  return lstm_bwd(nullptr, state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt,
+                  params, weights, policy, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
                   grad_state0, grad_h0, grad_c0, cot_amax, workspace, stream);
 }
 
@@ -1442,8 +1568,8 @@ int apg_quad_lstm_rollout_bwd_packed(const float *state0, const float *states,
                                      float *d_zout, float *d_conv, float *grad_state0,
                                      float *grad_h0, float *grad_c0, float *cot_amax,
                                      apg_stream_t stream) {
-  return lstm_bwd(state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt, params,
-                  weights, nullptr, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
+  return lstm_bwd(nullptr, state0, states, actions, ref, ref_cols, relu_mask, gates, hc, dt,
+                  params, weights, nullptr, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
                   grad_state0, grad_h0, grad_c0, cot_amax, const_cast<float *>(tables_bwd), stream);
 }
 
@@ -1515,6 +1641,33 @@ int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const flo
   R.ih_hh = ih_hh, R.b_ih = b_ih, R.w_out = w_out, R.b_out = b_out;
   hipLaunchKernelGGL(lstm_gate_wgrad_reduce_kernel, dim3(2 * kGwPart / 32), dim3(256), 0, st, R);
   return check_launch("quad_lstm_gate_wgrad_reduce");
+}
+
+int apg_quad_lstm_rollout_fwd_rows(const ApgBatchRows *rows, const float *h0, const float *c0,
+                                   float dt, const ApgQuadParams *params,
+                                   const float *tables_fwd, int B, int H, float *state0,
+                                   float *in_ref, float *states, float *actions, float *x,
+                                   float *gates, float *hc, float *hnew, unsigned *relu_mask,
+                                   apg_stream_t stream) {
+  if (!rows) { set_error("rows is NULL"); return APG_ERR_ARG; }
+  return lstm_fwd(rows, state0, in_ref, h0, c0, dt, params, nullptr, B, H, states, actions, x,
+                  gates, hc, hnew, relu_mask, const_cast<float *>(tables_fwd), stream);
+}
+
+int apg_quad_lstm_rollout_bwd_rows(const ApgBatchRows *rows, int ref_cols, const float *state0,
+                                   const float *states, const float *actions,
+                                   const unsigned *relu_mask, const float *gates,
+                                   const float *hc, float dt, const ApgQuadParams *params,
+                                   const ApgQuadLossWeights *weights, const float *tables_bwd,
+                                   int B, int H, float *loss_partials, float *loss,
+                                   float *d_gates, float *d_zout, float *d_conv,
+                                   float *grad_state0, float *grad_h0, float *grad_c0,
+                                   float *cot_amax, apg_stream_t stream) {
+  if (!rows) { set_error("rows is NULL"); return APG_ERR_ARG; }
+  return lstm_bwd(rows, state0, states, actions, nullptr, ref_cols, relu_mask, gates, hc, dt,
+                  params, weights, nullptr, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
+                  grad_state0, grad_h0, grad_c0, cot_amax, const_cast<float *>(tables_bwd),
+                  stream);
 }
 
 int apg_quad_lstm_tables_floats(int reverse) { return reverse ? kBwd16Lds : kFwd16Lds; }

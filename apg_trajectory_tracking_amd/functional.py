@@ -1118,6 +1118,32 @@ def _conv_diag_problems(cv, refbuf, B, H, w_out, b_out):
     return probs, finish
 
 
+# round 6: with resident tables and a row index the LSTM sweeps read the data
+# set's tensors through the index themselves (apg_quad_lstm_rollout_fwd_rows /
+# _bwd_rows) instead of a gather pass (a switch for A/B measurements and tests)
+LSTM_ROWS_IN_KERNEL = True
+
+
+def _lstm_batch_rows(state0, in_ref, ref, index, H):
+    """ApgBatchRows of an indexed LSTM minibatch, or None where the tensors are
+    not what the kernels read in place (then the gather pass runs)."""
+    ok = lambda t: (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                    and t.numel() * 4 < (1 << 32) - 64)
+    n = state0.shape[0]
+    if not (all(ok(t) for t in (state0, in_ref, ref)) and state0.dim() == 2
+            and state0.shape[1] == 12 and in_ref.dim() == 3 and in_ref.shape[0] == n
+            and in_ref.shape[1] >= 2 * H and in_ref.shape[2] == 9 and ref.dim() == 3
+            and ref.shape[0] == n and ref.shape[1] >= H and ref.shape[2] in (6, 9)
+            and index.is_cuda and index.dtype == torch.int64 and index.is_contiguous()):
+        return None
+    r = _capi.ApgBatchRows(index=index.data_ptr(), normed=None, state0=ptr(state0),
+                           in_ref=ptr(in_ref), ref=ptr(ref), ld_normed=0,
+                           ld_state0=state0.stride(0), ld_in_ref=in_ref.stride(0),
+                           ld_ref=ref.stride(0), n_rows=n, running_loss=None)
+    r._keep = (state0, in_ref, ref, index)
+    return r
+
+
 class _QuadLstmRolloutLoss(torch.autograd.Function):
     """loss of the LSTM-mode unroll with the policy inside the kernel.
 
@@ -1146,10 +1172,25 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             _guard_policy_inputs("fused LSTM unroll", state0=state0, in_ref=in_ref)
             src = getattr(ctx, "static_src", None) if index is None else None
             hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
-            refbuf, inr, s0, states, rf = hit or _ref_and_states(
-                _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
+            rows = None
+            if (index is not None and getattr(ctx, "lstm_tables", None) is not None
+                    and LSTM_ROWS_IN_KERNEL):
+                rows = _lstm_batch_rows(state0, in_ref, ref, index, H)
+            if rows is not None:
+                # round 6: the sweeps read the data set's rows through the index
+                # themselves; the forward sweep writes the planes its followers read
+                refbuf = torch.empty(2 * H * 9 + (H + 1) * 12, B, dtype=torch.float32,
+                                     device=state0.device)
+                inr = refbuf[:2 * H * 9].view(2 * H, 9, B)
+                st_all = refbuf[2 * H * 9:].view(H + 1, 12, B)
+                s0, states, rf = st_all[0], st_all[1:], None
+            else:
+                refbuf, inr, s0, states, rf = hit or _ref_and_states(
+                    _f32c(in_ref), _f32c(state0), B, H, index, also=(ref[:, :H],))
             if src and hit is None:
                 _STATIC_PLANES.store("recurrent", src, (refbuf, inr, s0, states, rf))
+        if prepared is not None:
+            rows = None
         dev = s0.device
         if all(_is_plane_view(t) for t in (h0, c0)):
             h0s, c0s = h0.detach().t(), c0.detach().t()   # already [8][B] planes
@@ -1160,7 +1201,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             w_hh=_f32c(w_hh), b_ih=_f32c(b_ih), b_hh=_f32c(b_hh),
             w_out=_f32c(w_out), b_out=_f32c(b_out))
         pw = {k: v.contiguous() for k, v in pw.items()}
-        require_device(s0, inr, rf, h0s, c0s, *pw.values())
+        require_device(s0, inr, *([] if rf is None else [rf]), h0s, c0s, *pw.values())
         pol = _capi.ApgLstmPolicy(**{k: ptr(v) for k, v in pw.items()})
         N = H * B
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -1178,6 +1219,13 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         tables = getattr(ctx, "lstm_tables", None)
         if tables is not None:
             tables.ensure(list(pw.values()), pol, st)
+        if rows is not None:
+            check(lib().apg_quad_lstm_rollout_fwd_rows(
+                ctypes.byref(rows), ptr(h0s), ptr(c0s), float(dt), ctypes.byref(params),
+                ptr(tables.fwd), B, H, ptr(s0), ptr(inr), ptr(states), ptr(actions), ptr(x),
+                ptr(gates), ptr(hc), ptr(hnew), relu_mask.data_ptr(), st),
+                "apg_quad_lstm_rollout_fwd_rows")
+        elif tables is not None:
             check(lib().apg_quad_lstm_rollout_fwd_packed(
                 ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt),
                 ctypes.byref(params), ptr(tables.fwd), B, H, ptr(states),
@@ -1198,7 +1246,15 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
         g_s0 = new(12, B) if ctx.needs_input_grad[0] else None
         g_h0 = new(8, B) if ctx.needs_input_grad[3] else None
         g_c0 = new(8, B) if ctx.needs_input_grad[4] else None
-        if tables is not None:
+        if rows is not None:
+            check(lib().apg_quad_lstm_rollout_bwd_rows(
+                ctypes.byref(rows), ref.shape[2], ptr(s0), ptr(states), ptr(actions),
+                relu_mask.data_ptr(), ptr(gates), ptr(hc), float(dt), ctypes.byref(params),
+                ctypes.byref(weights), ptr(tables.bwd), B, H, ptr(partials), None,
+                ptr(d_gates), ptr(d_zout), ptr(d_conv), ptr(g_s0), ptr(g_h0), ptr(g_c0),
+                ptr(cot_amax), st), "apg_quad_lstm_rollout_bwd_rows")
+            ctx.lstm_tail = (partials, loss, pw)
+        elif tables is not None:
             # (loss = NULL: the step's tail sums the partials)
             check(lib().apg_quad_lstm_rollout_bwd_packed(
                 ptr(s0), ptr(states), ptr(actions), ptr(rf), rf.shape[1],

@@ -304,12 +304,20 @@ STEP_MODELS = {
                            bytes_per_traj=48 + 2 * 20 * 36 + 10 * 36 * 2,
                            # state0 48 + in_ref 2H*36 + ref H*36
                            algo_bytes_per_traj=48 + 720 + 360),
-    "LSTM": dict(mfma_once=0, mfma_per_step=90 + 42,
-                 # x 700 + gates 128 + h/c 96 + states/actions 64 written and
-                 # re-read by the reverse sweep, cotangents 144 written, the
-                 # products read x, gates' cotangents and h once more
-                 bytes_per_step=(988 + 924 + 144) + (700 + 128 + 32),
-                 bytes_per_traj=288 * 2 + 48 + 20 * 72,
+    # Round 6: the gate / head weight gradients from lstm_gate_wgrad_kernel (conv
+    # recomputed trajectory-major: 108 fp16 matrix instructions per 32
+    # trajectories and step next to the sweeps' 90 + 42); the forward sweep no
+    # longer writes the 160 relu(conv) planes.  Per env-step: forward writes
+    # features 60 + h / c 64 + gates 128 + h_new 32 + relu mask 20 + states /
+    # actions 64; the reverse sweep reads 316 of them and writes the cotangents
+    # 144; the weight-gradient kernel reads cotangents 144 + features, h_prev,
+    # h_new 124 + position 12.  Per trajectory: inputs (state0, in_ref, ref, h0 /
+    # c0) by the three kernels 1 972, the conv cotangents' 720 diagonal planes
+    # written and read once 5 760, the window + position planes of the two conv
+    # products 840.  (Rounds 2-5: 2 916 per env-step, x alone 700 twice.)
+    "LSTM": dict(mfma_once=0, mfma_per_step=90 + 42 + 108, products_in_sweep=True,
+                 bytes_per_step=368 + 316 + 144 + 280,
+                 bytes_per_traj=1972 + 5760 + 840,
                  # state0 48 + in_ref 720 + ref 360 + h0 / c0 64
                  algo_bytes_per_traj=48 + 720 + 360 + 64),
 }

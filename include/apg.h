@@ -542,6 +542,32 @@ int apg_quad_mlp_concurrent_train_step_rows(
     const ApgMlpPolicyGrads *grads, float *states, float *workspace, float *partials,
     const ApgMlpSgdUpdate *update, const ApgStepEvents *events, apg_stream_t stream);
 
+/* Round 6: the LSTM sweeps on a minibatch named by ROW NUMBERS of the whole data
+ * set's tensors (TrainBase.run_epoch's batch selection,
+ * scripts/train_base.py:191-194: `batch = data[index]`) - no gather pass.  The
+ * forward sweep reads rows->state0 [n][ld >= 12] and rows->in_ref [n][ld >= 2H x 9]
+ * through rows->index [B] (range-checked: a row number beyond n_rows reads zeros)
+ * and WRITES their planes state0 [12][B], in_ref [2H][9][B] for its followers
+ * (the reverse sweep, apg_quad_lstm_gate_wgrad, the conv-weight products); the
+ * reverse sweep reads rows->ref [n][ld >= H x ref_cols] the same way.  Packed
+ * tables only; everything else as apg_quad_lstm_rollout_fwd_packed / _bwd_packed.
+ * (rows->normed, rows->running_loss are not used.) */
+int apg_quad_lstm_rollout_fwd_rows(const ApgBatchRows *rows, const float *h0, const float *c0,
+                                   float dt, const ApgQuadParams *params,
+                                   const float *tables_fwd, int B, int H, float *state0,
+                                   float *in_ref, float *states, float *actions, float *x,
+                                   float *gates, float *hc, float *hnew, unsigned *relu_mask,
+                                   apg_stream_t stream);
+int apg_quad_lstm_rollout_bwd_rows(const ApgBatchRows *rows, int ref_cols, const float *state0,
+                                   const float *states, const float *actions,
+                                   const unsigned *relu_mask, const float *gates,
+                                   const float *hc, float dt, const ApgQuadParams *params,
+                                   const ApgQuadLossWeights *weights, const float *tables_bwd,
+                                   int B, int H, float *loss_partials, float *loss,
+                                   float *d_gates, float *d_zout, float *d_conv,
+                                   float *grad_state0, float *grad_h0, float *grad_c0,
+                                   float *cot_amax, apg_stream_t stream);
+
 /* The AUTOREGRESSIVE training step in one call (round 5; configs[2] per rank):
  * TrainDrone.train_recurrent_model's unroll, loss and loss.backward()
  * (scripts/train_drone.py:113-173) for Net(15, 10, 9, 4, conv=1) - the forward

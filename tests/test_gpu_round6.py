@@ -316,3 +316,70 @@ def test_config2_eight_shards_summed_equal_the_whole_batch(dev):
         assert rel_err(got, want) < 1e-5, (k, rel_err(got, want))
         off += n
     assert off + 1 == flat_sum.numel()
+
+
+@pytest.mark.parametrize("B", [37, 1000, 4100])
+def test_lstm_gate_weight_gradients_recompute_the_conv_inputs(dev, B):
+    """apg_quad_lstm_gate_wgrad (round 6): [dW_ih | dW_hh], db, dW_out, db_out of
+    LSTM_NEW (neural_control/models/rnn.py:35-51; `loss.backward()` of
+    scripts/train_base.py:200-204) from the reverse sweep's cotangent planes with
+    the 160 relu(conv) inputs RECOMPUTED from the reference window - against the
+    same sums in float64 over x rebuilt on the host from the planes the sweeps
+    left (features, h_prev, h_new) and torch's own conv1d on the windows; ragged
+    batches (tail masks, one and several workgroups).  The reverse sweep's
+    cot_amax is the per-group maximum the kernel scales by, and two runs agree
+    to the bit (fixed summation order)."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    d = synthetic.quad_polynomial_batch(B, H, DT, seed=B, ref_length=20)
+    s0, in_ref, ref = (d[k].to(dev) for k in ("state0", "in_ref", "ref"))
+    g = torch.Generator().manual_seed(B)
+    h0, c0 = (torch.randn(B, 8, generator=g).to(dev) for _ in range(2))
+    torch.manual_seed(B)
+    net = LSTM_NEW(15, H, 9, 4, conv=1).to(dev)
+    dyn = FlightmareDynamics()
+    runs = []
+    for _ in range(2):
+        ctx = F._DirectCtx()
+        with torch.no_grad():
+            F._QuadLstmRolloutLoss.forward(
+                ctx, s0, in_ref, ref, h0, c0, *F._net_params(net, F._LSTM_PARAMS), DT,
+                dyn.params, F.quad_loss_weights())
+            flat, gr = F._lstm_param_grads(ctx.saved_tensors, ctx.dims)
+        runs.append((flat.clone(), {k: v.clone() for k, v in gr.items()}, ctx))
+    assert torch.equal(runs[0][0][:-1], runs[1][0][:-1])       # bit-reproducible
+    _, gr, ctx = runs[0]
+    refbuf, acts, d_gates, d_zout, _, cot_amax = ctx.saved_tensors[:6]
+    n = H * B
+    # the maxima the kernel scales by: per group of 32 trajectories over all steps
+    groups = (B + 31) // 32
+    dg = d_gates.view(32, H, B).abs().amax(dim=(0, 1))
+    dz = d_zout.view(4, H, B).abs().amax(dim=(0, 1))
+    pad = groups * 32 - B
+    dg, dz = (torch.nn.functional.pad(v, (0, pad)).view(groups, 32).amax(dim=1) for v in (dg, dz))
+    assert torch.equal(cot_amax.view(groups, 2)[:, 0], dg)
+    assert torch.equal(cot_amax.view(groups, 2)[:, 1], dz)
+    # x of every (step, trajectory) in float64: features | relu(conv1d(window)) | h_prev
+    inr = refbuf[:2 * H * 9].view(2 * H, 9, B).double()
+    st_all = refbuf[2 * H * 9:].view(H + 1, 12, B).double()
+    conv = torch.nn.Conv1d(9, 20, 3).double().to(dev)
+    conv.load_state_dict({k: v.double() for k, v in net.conv_ref.state_dict().items()})
+    xs = []
+    for k in range(H):
+        win = inr[k:k + H].clone()                      # [H, 9, B]
+        win[:, :3] -= st_all[k, :3]                     # relative to the current position
+        c = torch.relu(conv(win.permute(2, 1, 0)))      # [B, 20, 8]
+        xs.append(c.reshape(B, 160).t())
+    xc = torch.stack(xs, dim=1).reshape(160, n)         # column = step * B + trajectory
+    a = acts.double()
+    x = torch.cat([a[:15], xc, a[15:23]])               # 183 rows
+    want = {"lstm.weight_ih": (d_gates.double() @ x.t())[:, :175],
+            "lstm.weight_hh": (d_gates.double() @ x.t())[:, 175:],
+            "lstm.bias_ih": d_gates.double().sum(dim=1),
+            "fc_out.weight": d_zout.double() @ a[31:39].t(),
+            "fc_out.bias": d_zout.double().sum(dim=1)}
+    for k, w in want.items():
+        scale = w.abs().max().item() + 1e-300
+        assert (gr[k].double() - w).abs().max().item() / scale < 2e-6, k
