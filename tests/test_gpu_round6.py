@@ -383,3 +383,40 @@ def test_lstm_gate_weight_gradients_recompute_the_conv_inputs(dev, B):
     for k, w in want.items():
         scale = w.abs().max().item() + 1e-300
         assert (gr[k].double() - w).abs().max().item() / scale < 2e-6, k
+
+
+@pytest.mark.parametrize("B,ref_cols", [(1000, 9), (129, 6), (4096, 9)])
+def test_lstm_sweeps_read_the_batch_rows_through_the_index(dev, B, ref_cols):
+    """TrainBase.run_epoch's batch selection (scripts/train_base.py:191-194:
+    `batch = data[index]`) inside the LSTM sweeps (round 6:
+    apg_quad_lstm_rollout_fwd_rows / _bwd_rows): loss, every parameter gradient
+    and the rollout equal the gather pass + plane sweeps TO THE BIT - the same
+    numbers reach the same arithmetic - for a shuffled index with repeated rows
+    out of a larger data set, ragged batches, both reference layouts."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    n = 3 * B + 17
+    d = synthetic.quad_polynomial_batch(n, H, DT, seed=B, ref_length=24)
+    s0, in_ref = d["state0"].to(dev), d["in_ref"].to(dev)
+    ref = d["ref"][:, :, :ref_cols].contiguous().to(dev)
+    g = torch.Generator().manual_seed(B)
+    index = torch.randint(0, n, (B,), generator=g).to(dev)
+    index[1] = index[0]                                       # a repeated row
+    h0, c0 = (torch.randn(B, 8, generator=g).to(dev) for _ in range(2))
+    torch.manual_seed(B)
+    net = LSTM_NEW(15, H, 9, 4, conv=1).to(dev)
+    dyn = FlightmareDynamics()
+    out = []
+    for rows in (False, True):
+        F.LSTM_ROWS_IN_KERNEL = rows
+        try:
+            loss, gr, flat = F.quad_lstm_rollout_grads(net, s0, in_ref, ref, DT, dyn.params,
+                                                       h0, c0, index=index)
+        finally:
+            F.LSTM_ROWS_IN_KERNEL = True
+        out.append((loss.clone(), flat.clone()))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1][:-1], out[1][1][:-1])
+    assert torch.isfinite(out[1][1][:-1]).all() and out[1][1][:-1].abs().max() > 0
