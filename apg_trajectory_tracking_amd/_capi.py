@@ -210,6 +210,13 @@ SIGNATURES = {
     "apg_quad_mlp_rollout_fwd": [
         _P, _P, _F, ctypes.POINTER(ApgQuadParams),
         ctypes.POINTER(ApgMlpPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_mlp_rollout_fwd_inplace_ref": [
+        _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgMlpPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_rollout_fwd_inplace_ref": [
+        _P, _P, _P, _P, _F, ctypes.POINTER(ApgQuadParams),
+        ctypes.POINTER(ApgLstmPolicy), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P,
+        _P],
     "apg_quad_mlp_workspace_floats": [],
     "apg_quad_mlp_loss_partials_count": [_I],
     "apg_quad_mlp_step_workspace_floats": [],

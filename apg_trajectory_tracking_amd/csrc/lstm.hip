@@ -169,7 +169,11 @@ struct FwdArgs {
   int ld_state0, ld_in_ref;
 };
 
-template <bool ROWS>
+// LEGACY (forward only): the loop of scripts/train_drone.py:138-142 AS SHIPPED -
+// the window is a view of the batch and the relative-position subtraction
+// writes through it: every step shifts the rows its window holds AGAIN
+// (SURVEY.md 8a A4 `legacy_inplace_ref`; the pinned semantics copy the window)
+template <bool ROWS, bool LEGACY = false>
 __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds_issue(lds, A.tables, kFwd16Lds);   // (waited for behind the first loads)
@@ -290,7 +294,14 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
     // conv (one 32-row block per window position) feeding the gates; the
     // window relative to the current position is split once per step
     unsigned mbits[3] = {0u, 0u, 0u};
-    const float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
+    float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
+    if (LEGACY) {   // the shift stays in the window
+#pragma unroll
+      for (int r = 0; r < kH; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w[r][j] -= sub[j];
+      sub[0] = sub[1] = sub[2] = 0.f;
+    }
 #pragma unroll
     for (int pp = 0; pp < kNP / 2; ++pp) {
       float rv[24];  // relu(conv) of positions 2 pp, 2 pp + 1: registers 0..11 each
@@ -1410,7 +1421,8 @@ static int lstm_fwd(const ApgBatchRows *rows, const float *state0, const float *
                     const float *c0, float dt, const ApgQuadParams *params,
                     const ApgLstmPolicy *policy, int B, int H, float *states,
                     float *actions, float *x, float *gates, float *hc, float *hnew,
-                    unsigned *relu_mask, float *workspace, apg_stream_t stream) {
+                    unsigned *relu_mask, float *workspace, apg_stream_t stream,
+                    bool legacy_inplace_ref = false) {
   if (int e = check_lstm(params, policy, B, H, true)) return e;
   if (rows)
     if (int e = check_rows(rows, B, H, 0, false)) return e;
@@ -1444,7 +1456,10 @@ static int lstm_fwd(const ApgBatchRows *rows, const float *state0, const float *
                        0, st, P);
   }
   const dim3 grid((B + kTrajPerBlock - 1) / kTrajPerBlock);
-  if (rows)
+  if (legacy_inplace_ref)
+    hipLaunchKernelGGL((lstm_rollout_fwd_kernel<false, true>), grid, dim3(kThreads),
+                       kFwd16Lds * sizeof(float), st, A);
+  else if (rows)
     hipLaunchKernelGGL(lstm_rollout_fwd_kernel<true>, grid, dim3(kThreads),
                        kFwd16Lds * sizeof(float), st, A);
   else
@@ -1465,6 +1480,19 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
   return lstm_fwd(nullptr, state0, in_ref, h0, c0, dt, params, policy, B, H, states, actions, x,
                   gates,
                   hc, hnew, relu_mask, workspace, stream);
+}
+
+int apg_quad_lstm_rollout_fwd_inplace_ref(const float *state0, const float *in_ref,
+                                          const float *h0, const float *c0, float dt,
+                                          const ApgQuadParams *params,
+                                          const ApgLstmPolicy *policy, int B, int H,
+                                          float *states, float *actions, float *x,
+                                          float *gates, float *hc, float *hnew,
+                                          unsigned *relu_mask, float *workspace,
+                                          apg_stream_t stream) {
+  if (!policy) { set_error("policy is NULL"); return APG_ERR_ARG; }
+  return lstm_fwd(nullptr, state0, in_ref, h0, c0, dt, params, policy, B, H, states, actions, x,
+                  gates, hc, hnew, relu_mask, workspace, stream, true);
 }
 
 int apg_quad_lstm_rollout_fwd_packed(const float *state0, const float *in_ref,

@@ -46,7 +46,10 @@
 
 namespace apg {
 namespace {
-template <bool XMAX>
+// LEGACY (forward only): scripts/train_drone.py:138-142 AS SHIPPED - the window is a
+// view of the batch, the relative-position subtraction writes through it and every
+// step shifts the rows its window holds again (SURVEY.md 8a A4 `legacy_inplace_ref`)
+template <bool XMAX, bool LEGACY = false>
 __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fill_lds(lds, A.tables, kCfLds);
@@ -132,7 +135,14 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_fwd_kernel(FwdArgs A) {
     }
     // the window relative to the current position, split once per step: high
     // term in the low half-word, low term in the high half-word
-    const float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
+    float sub[3] = {hi ? 0.f : s[0], hi ? 0.f : s[1], hi ? 0.f : s[2]};
+    if (LEGACY) {   // the shift stays in the window
+#pragma unroll
+      for (int r = 0; r < kH; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w[r][j] -= sub[j];
+      sub[0] = sub[1] = sub[2] = 0.f;
+    }
     init_bias(a, L, hTb1);
     unsigned mbits[3] = {0u, 0u, 0u};
 #pragma unroll
@@ -1230,12 +1240,37 @@ int apg_quad_mlp_loss_partials_count(int B) {
   return B <= 0 ? 0 : ((B + kTrajPerBlock - 1) / kTrajPerBlock) * (kThreads / kWave);
 }
 
+static int mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
+                           const ApgQuadParams *params, const ApgMlpPolicy *policy, int B, int H,
+                           float *states, float *actions, float *feat, float *x1, float *h,
+                           unsigned *relu_mask, float *workspace, apg_stream_t stream,
+                           bool legacy_inplace_ref);
+
 int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
                              const ApgQuadParams *params,
                              const ApgMlpPolicy *policy, int B, int H,
                              float *states, float *actions, float *feat,
                              float *x1, float *h, unsigned *relu_mask,
                              float *workspace, apg_stream_t stream) {
+  return mlp_rollout_fwd(state0, in_ref, dt, params, policy, B, H, states, actions, feat, x1, h,
+                         relu_mask, workspace, stream, false);
+}
+
+int apg_quad_mlp_rollout_fwd_inplace_ref(const float *state0, const float *in_ref, float dt,
+                                         const ApgQuadParams *params,
+                                         const ApgMlpPolicy *policy, int B, int H,
+                                         float *states, float *actions, float *feat,
+                                         float *x1, float *h, unsigned *relu_mask,
+                                         float *workspace, apg_stream_t stream) {
+  return mlp_rollout_fwd(state0, in_ref, dt, params, policy, B, H, states, actions, feat, x1, h,
+                         relu_mask, workspace, stream, true);
+}
+
+static int mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
+                           const ApgQuadParams *params, const ApgMlpPolicy *policy, int B, int H,
+                           float *states, float *actions, float *feat, float *x1, float *h,
+                           unsigned *relu_mask, float *workspace, apg_stream_t stream,
+                           bool legacy_inplace_ref) {
   if (int e = check_mlp(params, policy, B, H)) return e;
   if (B == 0) return APG_OK;
   if (!state0 || !in_ref || !states || !actions || !feat || !x1 || !h ||
@@ -1246,6 +1281,7 @@ int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
   static PerDeviceOnce attr;
   if (!attr.test()) {
     if (int e = raise_lds(mlp_rollout_fwd_kernel<false>, kCfLds)) return e;
+    if (int e = raise_lds(mlp_rollout_fwd_kernel<false, true>, kCfLds)) return e;
     attr.set();
   }
   FwdArgs A;
@@ -1259,10 +1295,13 @@ int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
   P.pol = *policy, P.dst = workspace, P.head_rows = 4;
   hipLaunchKernelGGL(mlp_pack_cfwd_kernel, dim3((kCfLds + 255) / 256), dim3(256),
                      0, (hipStream_t)stream, P);
-  hipLaunchKernelGGL(mlp_rollout_fwd_kernel<false>,
-                     dim3((B + kTrajPerBlock - 1) / kTrajPerBlock),
-                     dim3(kThreads), kCfLds * sizeof(float), (hipStream_t)stream,
-                     A);
+  const dim3 grid((B + kTrajPerBlock - 1) / kTrajPerBlock);
+  if (legacy_inplace_ref)
+    hipLaunchKernelGGL((mlp_rollout_fwd_kernel<false, true>), grid, dim3(kThreads),
+                       kCfLds * sizeof(float), (hipStream_t)stream, A);
+  else
+    hipLaunchKernelGGL(mlp_rollout_fwd_kernel<false>, grid, dim3(kThreads),
+                       kCfLds * sizeof(float), (hipStream_t)stream, A);
   return check_launch("quad_mlp_rollout_fwd");
 }
 

@@ -1543,6 +1543,64 @@ _MLP_PARAMS = ("states_in.weight", "states_in.bias", "conv_ref.weight",
                "fc3.weight", "fc3.bias", "fc_out.weight", "fc_out.bias")
 
 
+def quad_recurrent_forward_inplace_ref(net, state0, in_ref, dt, params, h0=None, c0=None):
+    """SURVEY.md §8a A4 `legacy_inplace_ref`, forward only: the recurrent unroll
+    of scripts/train_drone.py:134-157 AS SHIPPED - the reference window is a view
+    of the batch and the relative-position subtraction (:138-142) writes through
+    it, so every step shifts the rows its window holds again - with the policy
+    inside the kernel (`Net(15, 10, 9, 4, conv=1)`, or `LSTM_NEW(...)` with its
+    hidden / cell state h0, c0 [B, 8]).  state0 [B,12], in_ref [B,>=2H,9] (not
+    modified).  Returns (states [B,H,12], actions [B,H,4]); the loss is
+    `quad_mpc_loss(states, ref[:, :H], actions)`.  No gradient exists: the
+    reference cannot back-propagate through the in-place write, the training
+    paths use the copied window."""
+    H = 10
+    lstm = hasattr(net, "lstm")
+    B = state0.shape[0]
+    if in_ref.shape[1] < 2 * H or in_ref.shape[2] != 9:
+        raise ValueError("in_ref [B,2H,9] with H = 10")
+    _guard_policy_inputs("fused recurrent unroll (as shipped)", state0=state0, in_ref=in_ref)
+    with torch.no_grad():
+        inr, s0 = to_soa_multi([(_f32c(in_ref)[:, :2 * H], None), (_f32c(state0), None)])
+        dev = s0.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        N = H * B
+        states, actions = new(H, 12, B), new(H, 4, B)
+        mask = torch.empty(5, N, dtype=torch.int32, device=dev)
+        st = stream_of(s0)
+        if lstm:
+            if h0 is None or c0 is None:
+                raise ValueError("the LSTM unroll needs h0, c0 [B, 8]")
+            h0s, c0s = to_soa_multi([(h0, None), (c0, None)])
+            pw = [_f32c(v).contiguous() for v in _net_params(net, _LSTM_PARAMS)]
+            pol = _capi.ApgLstmPolicy(**dict(zip(
+                ("conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out"),
+                map(ptr, pw))))
+            require_device(s0, inr, h0s, c0s, *pw)
+            x, gates, hc, hnew = new(15, N), new(32, N), new(16, N), new(8, N)
+            ws = new(lib().apg_quad_lstm_workspace_floats())
+            check(lib().apg_quad_lstm_rollout_fwd_inplace_ref(
+                ptr(s0), ptr(inr), ptr(h0s), ptr(c0s), float(dt), ctypes.byref(params),
+                ctypes.byref(pol), B, H, ptr(states), ptr(actions), ptr(x), ptr(gates),
+                ptr(hc), ptr(hnew), mask.data_ptr(), ptr(ws), st),
+                "apg_quad_lstm_rollout_fwd_inplace_ref")
+        else:
+            names = ("w_s", "b_s", "conv_w", "conv_b", "w_1", "b_1", "w_2", "b_2", "w_3",
+                     "b_3", "w_out", "b_out")
+            pw = [_f32c(v).contiguous() for v in _net_params(net, _MLP_PARAMS)]
+            if pw[0].shape != (64, 15) or pw[4].shape != (64, 224) or pw[10].shape != (4, 64):
+                raise ValueError("fused path needs Net(15, 10, 9, 4, conv=1)")
+            pol = _capi.ApgMlpPolicy(**dict(zip(names, map(ptr, pw))))
+            require_device(s0, inr, *pw)
+            feat, x1, h = new(15, N), new(224, N), new(192, N)
+            ws = new(lib().apg_quad_mlp_workspace_floats())
+            check(lib().apg_quad_mlp_rollout_fwd_inplace_ref(
+                ptr(s0), ptr(inr), float(dt), ctypes.byref(params), ctypes.byref(pol), B, H,
+                ptr(states), ptr(actions), ptr(feat), ptr(x1), ptr(h), mask.data_ptr(),
+                ptr(ws), st), "apg_quad_mlp_rollout_fwd_inplace_ref")
+    return states.permute(2, 0, 1).contiguous(), actions.permute(2, 0, 1).contiguous()
+
+
 def quad_mlp_rollout_loss(net, state0, in_ref, ref, dt, params, weights=None):
     """Fused autoregressive unroll for a `Net(15, 10, 9, 4, conv=1)` policy
     (train_mode "autoregressive", scripts/train_drone.py:113-173).  Returns

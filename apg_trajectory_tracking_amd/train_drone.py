@@ -94,6 +94,24 @@ class TrainDrone(TrainBase):
                 json.dump(self.config, f, default=str)
         self.init_optimizer()
 
+    def recurrent_forward_as_shipped(self, current_state, in_ref_states, ref_states):
+        """SURVEY.md §8a A4 `legacy_inplace_ref`: the forward half of
+        train_recurrent_model exactly as scripts/train_drone.py:134-165 ships it -
+        the reference window shifted IN PLACE through a view of the batch, every
+        step again (:138-142) - in one fused launch; returns (loss, states
+        [B,H,12], actions [B,H,4]).  Forward only: the reference itself cannot
+        back-propagate through that write (torch >= 1.5 refuses), which is why
+        training uses the copied window; the batch tensor is left as it was."""
+        n = self.net
+        hc = (None, None)
+        if self.train_mode == "LSTM":
+            n.reset_hidden_state(current_state.size()[0])
+            hc = (n.hidden_state.to(current_state.device), n.cell_state.to(current_state.device))
+        states, actions = F.quad_recurrent_forward_inplace_ref(
+            n, current_state, in_ref_states, self.delta_t, self.train_dynamics.params, *hc)
+        loss = quad_mpc_loss(states, ref_states[:, :self.horizon], actions, printout=0)
+        return loss, states, actions
+
     def train_recurrent_model(
         self, in_state, current_state, in_ref_states, ref_states, index=None,
         prepared=None, slot=0

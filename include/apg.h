@@ -247,6 +247,22 @@ int apg_quad_lstm_rollout_fwd(const float *state0, const float *in_ref,
                               unsigned *relu_mask, float *workspace,
                               apg_stream_t stream);
 
+/* SURVEY.md 8a A4 `legacy_inplace_ref`: the same forward sweep with the loop of
+ * scripts/train_drone.py:138-142 AS SHIPPED - the reference window is a view of
+ * the batch and the relative-position subtraction writes through it, so every
+ * step shifts the rows its window holds AGAIN.  Forward only (the reference
+ * cannot back-propagate through the in-place write; there is no gradient to
+ * match); in_ref itself is not modified.  apg_quad_mlp_rollout_fwd_inplace_ref is
+ * the autoregressive-MLP counterpart. */
+int apg_quad_lstm_rollout_fwd_inplace_ref(const float *state0, const float *in_ref,
+                                          const float *h0, const float *c0, float dt,
+                                          const ApgQuadParams *params,
+                                          const ApgLstmPolicy *policy, int B, int H,
+                                          float *states, float *actions, float *x,
+                                          float *gates, float *hc, float *hnew,
+                                          unsigned *relu_mask, float *workspace,
+                                          apg_stream_t stream);
+
 /* Reverse sweep (BPTT) of the above + quad_mpc_loss on ref[:, :H]
  * (scripts/train_drone.py:159-168).  ref [H][ref_cols][B].  Writes the loss
  * (loss_partials: apg_quad_lstm_loss_partials_count(B) floats) and the
@@ -405,6 +421,13 @@ int apg_quad_mlp_rollout_fwd(const float *state0, const float *in_ref, float dt,
                              float *states, float *actions, float *feat,
                              float *x1, float *h, unsigned *relu_mask,
                              float *workspace, apg_stream_t stream);
+/* (forward only: the loop as shipped, see apg_quad_lstm_rollout_fwd_inplace_ref) */
+int apg_quad_mlp_rollout_fwd_inplace_ref(const float *state0, const float *in_ref, float dt,
+                                         const ApgQuadParams *params,
+                                         const ApgMlpPolicy *policy, int B, int H,
+                                         float *states, float *actions, float *feat,
+                                         float *x1, float *h, unsigned *relu_mask,
+                                         float *workspace, apg_stream_t stream);
 
 /* apg_quad_mlp_loss_partials_count(B): floats of loss partials of the MLP-policy
  * sweeps.  (The plane-writing reverse sweep of rounds 1-4, apg_quad_mlp_rollout_bwd,

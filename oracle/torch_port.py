@@ -421,15 +421,23 @@ def rollout_fwd_bwd(dyn, loss_fn, state0, actions, ref, dt):
     return inter.detach(), loss.detach(), a.grad, s0.grad
 
 
-def quad_recurrent_unroll(net, dyn, state0, in_ref, ref, horizon, dt):
+def quad_recurrent_unroll(net, dyn, state0, in_ref, ref, horizon, dt,
+                          legacy_inplace_ref=False):
     """scripts/train_drone.py:113-165 with the window copied before the
-    relative-position subtraction (pinned semantics)."""
+    relative-position subtraction (pinned semantics).
+    legacy_inplace_ref: the loop AS SHIPPED (:138-142) - the window is a view and
+    the subtraction writes through it, so a reference row is shifted by the
+    current position of every step whose window holds it; forward only (call
+    under torch.no_grad(): autograd refuses the in-place write).  The caller's
+    in_ref is left alone (the reference destroys its batch)."""
     B = state0.shape[0]
     inter = torch.zeros(B, horizon, 12, dtype=state0.dtype)
     acts = torch.zeros(B, horizon, 4, dtype=state0.dtype)
     cur = state0
+    if legacy_inplace_ref:
+        in_ref = in_ref.clone()
     for k in range(horizon):
-        rel = in_ref[:, k:k + horizon].clone()
+        rel = in_ref[:, k:k + horizon] if legacy_inplace_ref else in_ref[:, k:k + horizon].clone()
         rel[:, :, :3] = rel[:, :, :3] - cur[:, None, :3]
         a = torch.sigmoid(net(quad_state_features(cur), rel))
         acts[:, k] = a

@@ -12,6 +12,7 @@ Fixtures:
   quad_rollout.npz   G2  H-step unroll + quad_mpc_loss + autograd grads
   quad_train.npz     G3  TrainDrone.train_controller_model, 2 SGD steps
   quad_recurrent.npz G4  autoregressive / LSTM unroll (window .clone() patch)
+  quad_recurrent_inplace.npz G4b the same loop AS SHIPPED (in-place window), forward only
   wing.npz           G5  FixedWingDynamics step, 1001-step sim, rollout+grads
   cartpole.npz       G6  CartpoleDynamics step + rollout + grads
   features.npz       G7  state_preprocessing + VJP
@@ -322,6 +323,52 @@ def g4_quad_recurrent():
             if p.grad is not None:
                 out[f"{mode}.g.{k}"] = npy(p.grad)
     save("quad_recurrent.npz", **out)
+
+
+def g4b_quad_recurrent_inplace():
+    """The loop of scripts/train_drone.py:134-157 AS SHIPPED, forward only: the
+    reference window is a VIEW of the batch's in_ref and the relative-position
+    subtraction writes through it, so a reference row is shifted by the current
+    position of EVERY step whose window holds it (SURVEY.md §8a A4:
+    `legacy_inplace_ref`; no gradient exists - autograd refuses the in-place
+    write).  Same inputs, weights and (h0, c0) as G4 (same seeds): only the
+    outputs are stored."""
+    out = {}
+    B, H, dt = 32, 10, 0.1
+    d = synthetic.quad_polynomial_batch(B, H, dt, seed=8, ref_length=2 * H)
+    dyn = FlightmareDynamics()
+    for mode in ("ar", "lstm"):
+        torch.manual_seed(9)
+        if mode == "ar":
+            net = Net(15, H, 9, 4, conv=1)
+        else:
+            net = LSTM_NEW(15, H, 9, 4, conv=1)
+            g = torch.Generator().manual_seed(10)
+            net.hidden_state = torch.randn(B, 8, generator=g)
+            net.cell_state = torch.randn(B, 8, generator=g)
+        with torch.no_grad():
+            in_ref_states = d["in_ref"].clone()      # (the loop destroys its batch)
+            current_state = d["state0"]
+            intermediate_states = torch.zeros(B, H, 12)
+            action_seq = torch.zeros(B, H, 4)
+            for k in range(H):
+                rel_in_ref_states = in_ref_states[:, k:k + H]
+                rel_in_ref_states[:, :, :3] = (
+                    rel_in_ref_states[:, :, :3] -
+                    torch.unsqueeze(current_state[:, :3], 1)
+                )
+                in_state = state_preprocessing(current_state)
+                action = torch.sigmoid(net(in_state, rel_in_ref_states))
+                action_seq[:, k] = action
+                current_state = dyn(current_state, action, dt=dt)
+                intermediate_states[:, k] = current_state
+            loss = quad_mpc_loss(intermediate_states, d["ref"][:, :H], action_seq,
+                                 printout=0)
+        out[f"{mode}.states"] = npy(intermediate_states)
+        out[f"{mode}.actions"] = npy(action_seq)
+        out[f"{mode}.loss"] = np.float64(loss.item())
+        out[f"{mode}.in_ref_after"] = npy(in_ref_states)
+    save("quad_recurrent_inplace.npz", **out)
 
 
 # --------------------------------------------------------------------- G5
@@ -1335,7 +1382,7 @@ def g18_wing_closed_loop_learnt():
 
 
 FIXTURES = dict(g1=g1_quad_step, g2=g2_quad_rollout, g3=g3_quad_train,
-                g4=g4_quad_recurrent, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
+                g4=g4_quad_recurrent, g4b=g4b_quad_recurrent_inplace, g5=g5_wing, g6=g6_cartpole, g7=g7_features,
                 g8=g8_losses, g9=g9_checkpoints, g10=g10_learnt_dynamics,
                 g11=g11_closed_loop, g12=g12_wing_train,
                 g13=g13_self_play, g14=g14_schedules,

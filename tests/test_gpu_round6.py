@@ -420,3 +420,69 @@ def test_lstm_sweeps_read_the_batch_rows_through_the_index(dev, B, ref_cols):
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1][:-1], out[1][1][:-1])
     assert torch.isfinite(out[1][1][:-1]).all() and out[1][1][:-1].abs().max() > 0
+
+
+@pytest.mark.parametrize("mode", ["ar", "lstm"])
+def test_recurrent_forward_as_shipped_in_place_window(dev, mode):
+    """SURVEY §8a A4 `legacy_inplace_ref` (VERDICT r5 missing #3): the recurrent
+    unroll with the reference window shifted IN PLACE as scripts/train_drone.py:
+    138-142 ships it - forward only - inside the fused kernels
+    (apg_quad_mlp_rollout_fwd_inplace_ref / apg_quad_lstm_rollout_fwd_inplace_ref)
+    against what the reference itself computed (G4b: tests/golden/
+    quad_recurrent_inplace.npz, made by the reference's own loop), and at a ragged
+    1 000 against the oracle's restatement in float64; the caller's in_ref stays
+    as it was, and the pinned (copied-window) forward differs."""
+    from apg_trajectory_tracking_amd import functional as F, synthetic
+    from apg_trajectory_tracking_amd.dynamics.quad_dynamics_flightmare import (
+        FlightmareDynamics)
+    from apg_trajectory_tracking_amd.models.hutter_model import Net
+    from apg_trajectory_tracking_amd.models.rnn import LSTM_NEW
+    from conftest import load_golden
+    from oracle import torch_port as tp
+    g, gi = load_golden("quad_recurrent.npz"), load_golden("quad_recurrent_inplace.npz")
+    net = (LSTM_NEW if mode == "lstm" else Net)(15, H, 9, 4, conv=1)
+    net.load_state_dict({k[len(mode) + 3:]: torch.from_numpy(g[k])
+                         for k in g.files if k.startswith(mode + ".w.")})
+    dyn = FlightmareDynamics()
+    s0, in_ref = (torch.from_numpy(g[k]).to(dev) for k in ("state0", "in_ref"))
+    hc = ((torch.from_numpy(g["lstm_h0"]).to(dev), torch.from_numpy(g["lstm_c0"]).to(dev))
+          if mode == "lstm" else (None, None))
+    before = in_ref.clone()
+    states, actions = F.quad_recurrent_forward_inplace_ref(
+        net.to(dev), s0, in_ref, float(g["dt"]), dyn.params, *hc)
+    assert torch.equal(in_ref, before)
+    assert rel_err(N(states), gi[f"{mode}.states"]) < 2e-5
+    assert rel_err(N(actions), gi[f"{mode}.actions"]) < 2e-5
+    assert rel_err(N(states), g[f"{mode}.states"]) > 1e-3      # not the pinned semantics
+    # the trainer's forward-only entry: the reference's loss of that loop
+    from apg_trajectory_tracking_amd.train_drone import TrainDrone
+    cfg = dict(delta_t=float(g["dt"]), delta_t_train=float(g["dt"]), epoch_size=32, self_play=0,
+               batch_size=32, state_size=12, horizon=H, ref_dim=9, action_dim=4,
+               train_mode="LSTM" if mode == "lstm" else "autoregressive",
+               learning_rate_controller=1e-9, system="quad", modified_params={})
+    t = TrainDrone(dyn, dyn, cfg)
+    t.net = net.to(dev)
+    if mode == "lstm":
+        def fixed_reset(batch_size=1, generator=None):
+            net.hidden_state, net.cell_state = hc[0].clone(), hc[1].clone()
+        net.reset_hidden_state = fixed_reset
+    loss, _, _ = t.recurrent_forward_as_shipped(s0, in_ref, torch.from_numpy(g["ref"]).to(dev))
+    assert abs(loss.item() - gi[f"{mode}.loss"]) / gi[f"{mode}.loss"] < 2e-5
+    assert torch.equal(in_ref, before)
+    # a ragged batch against the oracle in float64
+    B = 1000
+    d = synthetic.quad_polynomial_batch(B, H, DT, seed=77, ref_length=20)
+    gen = torch.Generator().manual_seed(5)
+    h0, c0 = torch.randn(B, 8, generator=gen), torch.randn(B, 8, generator=gen)
+    net64 = copy.deepcopy(net).cpu().double()
+    if mode == "lstm":
+        net64.hidden_state, net64.cell_state = h0.double(), c0.double()
+    with torch.no_grad():
+        inter, acts, _ = tp.quad_recurrent_unroll(
+            net64, tp.QuadOracle(dtype=torch.float64), d["state0"].double(),
+            d["in_ref"].double(), d["ref"].double(), H, DT, legacy_inplace_ref=True)
+    states, actions = F.quad_recurrent_forward_inplace_ref(
+        net.to(dev), d["state0"].to(dev), d["in_ref"].to(dev), DT, dyn.params,
+        *((h0.to(dev), c0.to(dev)) if mode == "lstm" else (None, None)))
+    assert rel_err(N(states), inter.numpy()) < 2e-5
+    assert rel_err(N(actions), acts.numpy()) < 2e-5
