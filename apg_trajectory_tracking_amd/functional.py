@@ -2035,15 +2035,19 @@ class QuadConcurrentStepPlan:
                 ld_in_ref=inr.shape[1] * 9, ld_ref=rfs.shape[1] * rfs.shape[2], n_rows=N,
                 running_loss=ptr(self.running))
             self._fn = lib().apg_quad_mlp_concurrent_train_step_rows
-            self._args = (ctypes.byref(self._rows), rfs.shape[2]) + tail
+            self._args = [ctypes.byref(self._rows), rfs.shape[2], *tail]
         else:
             self._rows = None
             self._fn = lib().apg_quad_mlp_concurrent_train_step
-            self._args = (ptr(s0), ptr(rf), rf.shape[1]) + tail
+            self._args = [ptr(s0), ptr(rf), rf.shape[1], *tail]
+        # every launch writes its loss into a tensor of its own (handed to the
+        # caller as it is: the clone a shared buffer needed was a 5 us copy
+        # kernel per step, 4 % of it)
+        self._loss_at = len(self._args) - len(tail) + 10
 
     def launch(self, events=None, index=None):
-        """Enqueue the step on the current stream; returns the loss (0-dim view
-        of the plan's loss buffer: overwritten by the next launch).  index (rows
+        """Enqueue the step on the current stream; returns the loss (0-dim, a
+        tensor of this launch's own).  index (rows
         plans): int64 [B] device tensor, contiguous - this batch's rows; the
         caller keeps it alive until the step has run."""
         if self._rows is not None:
@@ -2067,6 +2071,9 @@ class QuadConcurrentStepPlan:
                 k["upd"].resident = (2 if now == self._versions
                                      else 3 if self._map_built else 1)
                 self._versions, self._map_built = now, True
+        self.loss = torch.empty(1, dtype=torch.float32, device=self._dev)
+        self.loss0 = self.loss.reshape(())
+        self._args[self._loss_at] = ptr(self.loss)
         check(self._fn(*self._args, _step_events(events),
                        torch.cuda.current_stream(self._dev).cuda_stream),
               "apg_quad_mlp_concurrent_train_step")

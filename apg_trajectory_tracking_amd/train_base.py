@@ -270,7 +270,7 @@ class _PlannedStep:
                 else self.plan.launch(events, index=index))
         for p, g in self.grads:
             p.grad = g
-        return loss if borrow else loss.clone()
+        return loss      # (a tensor of this launch's own: nothing to clone)
 
 
 class _EpochLoss:
