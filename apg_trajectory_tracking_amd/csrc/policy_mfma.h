@@ -58,6 +58,9 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return 1.0f / (1.0f + expf(-x));
 }
 
+// the value of the lane 32 away.  (round 6: v_permlane32_swap + a select on the
+// VALU instead of this ds_bpermute measured no faster - LSTM sweeps 107-109 /
+// 116-121 us against 105-106 / 117 on the same box, tools/ab_gate_wgrad.sh.)
 __device__ __forceinline__ float other_half(float v) {
   return __shfl_xor(v, 32, 64);
 }
