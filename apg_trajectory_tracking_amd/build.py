@@ -33,7 +33,8 @@ def _headers():
 
 
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(
+            os.path.join(CSRC, "kernel_resources.json")):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
@@ -55,6 +56,28 @@ def _extra_flags():
     return flags
 
 
+RESOURCES = os.path.join(CSRC, "kernel_resources.json")
+
+
+def _kernel_resources(remarks):
+    """{demangled-ish kernel name: {vgprs, agprs, sgprs, scratch, occupancy}} out of
+    hipcc's -Rpass-analysis=kernel-resource-usage remarks."""
+    import re
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs",
+            "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "VGPRs Spill": "vgpr_spill"}
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][^:]*): (\d+) \[-Rpass-analysis", line)
+        if m and cur is not None and m.group(1) in keys:
+            cur[keys[m.group(1)]] = int(m.group(2))
+    return out
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source into one shared library; returns its path."""
     if not force and not _stale():
@@ -70,7 +93,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                *COMMON_FLAGS, *EXTRA_FLAGS.get(s, []),
-               *extra,
+               *extra, "-Rpass-analysis=kernel-resource-usage",
                "-I", os.path.join(REPO, "include"), "-I", CSRC, "-c", src,
                "-o", obj]
         if verbose:
@@ -78,10 +101,19 @@ def build(force=False, verbose=False):
         procs.append((s, subprocess.Popen(
             cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
+    resources = {}
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        resources.update(_kernel_resources(out))
+    # registers, scratch and waves per SIMD of every kernel as the compiler
+    # reports them: tests/test_host_cpu.py holds the kernels that are written for
+    # two waves per SIMD to that (five more live registers once cost the LSTM
+    # forward sweep its second wave: 94 -> 109 us)
+    import json
+    with open(RESOURCES, "w") as f:
+        json.dump(resources, f, indent=0, sort_keys=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True)

@@ -264,8 +264,10 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
     const unsigned vm = live ? col + (hi ? pitchN : 0u) : kDead;        // + mask word hi
     // the row that slides in for the next step: requested first (ROWS: a scattered
     // read through the index - a step of latency to hide)
+    // (the plane variant fetches it at the end of the step: five more live
+    // registers put that kernel over the 256 of two waves per SIMD)
     float wn[5];
-    if (k + 1 < kH) window_row(k + kH, pB, wn);
+    if (ROWS && k + 1 < kH) window_row(k + kH, pB, wn);
     const Trig t = make_trig(&s[3]);
     float feat[kNF];
     quad_features(s, t, feat);
@@ -393,6 +395,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
         for (int j = 0; j < 5; ++j) w[r][j] = w[r + 1][j];
 #pragma unroll
       for (int j = 0; j < 5; ++j) w[kH - 1][j] = wn[j];
+      if (!ROWS) window_row(k + kH, pB, w[kH - 1]);
     }
   }
 }

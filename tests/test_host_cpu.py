@@ -1121,3 +1121,35 @@ def test_planes_test_library_exports_its_header_and_the_product_does_not():
         assert plane_path.planes_lib() is not None
     finally:
         sys.path.remove(sys_path)
+
+
+def test_kernels_written_for_two_waves_per_simd_get_them():
+    """The policy sweeps are written for a register budget: two waves per SIMD
+    (256 registers) for the quadrotor sweeps and the LSTM weight-gradient kernel,
+    four for the fixed-wing policy.  The build records what the compiler reports
+    per kernel (`-Rpass-analysis=kernel-resource-usage` -> csrc/
+    kernel_resources.json); five more live registers once put the LSTM forward
+    sweep at ONE wave per SIMD - 94 -> 109 us, silently (round 6)."""
+    import json
+    from apg_trajectory_tracking_amd import build
+    build.build()
+    with open(build.RESOURCES) as f:
+        res = json.load(f)
+    want = {"23lstm_rollout_fwd_kernelILb0ELb0E": 2, "23lstm_rollout_fwd_kernelILb1ELb0E": 2,
+            "23lstm_rollout_fwd_kernelILb0ELb1E": 2, "23lstm_rollout_bwd_kernelILb0E": 2,
+            "23lstm_rollout_bwd_kernelILb1E": 2, "22lstm_gate_wgrad_kernelE": 2,
+            "22mlp_rollout_fwd_kernelILb0ELb0E": 2, "22mlp_rollout_fwd_kernelILb1ELb0E": 2,
+            "25mlp_rollout_bwd_tm_kernelE": 2, "25mlp_concurrent_fwd_kernelILb0E": 2,
+            "25mlp_concurrent_fwd_kernelILb1E": 2, "28mlp_concurrent_bwd_tm_kernelILb0E": 2,
+            "28mlp_concurrent_bwd_tm_kernelILb1E": 2, "22wing_policy_fwd_kernelE": 4,
+            "22wing_policy_bwd_kernelE": 4}
+    no_scratch = ("lstm_rollout_fwd_kernel", "lstm_rollout_bwd_kernel", "lstm_gate_wgrad_kernel",
+                  "quad_rollout_rows_kernel", "wing_rollout_pk_kernel")
+    assert len(res) > 100
+    for frag, occ in want.items():
+        hits = [v for k, v in res.items() if frag in k]
+        assert len(hits) == 1, (frag, len(hits))
+        assert hits[0]["occupancy"] >= occ, (frag, hits[0])
+    for k, v in res.items():
+        if any(n in k for n in no_scratch):
+            assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
