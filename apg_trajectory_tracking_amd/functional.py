@@ -1118,15 +1118,12 @@ def _conv_diag_problems(cv, refbuf, B, H, w_out, b_out):
     return probs, finish
 
 
-# round 6: with resident tables and a row index the LSTM sweeps read the data
-# set's tensors through the index themselves (apg_quad_lstm_rollout_fwd_rows /
-# _bwd_rows) instead of a gather pass (a switch for A/B measurements and tests)
-LSTM_ROWS_IN_KERNEL = True
-
-
 def _lstm_batch_rows(state0, in_ref, ref, index, H):
-    """ApgBatchRows of an indexed LSTM minibatch, or None where the tensors are
-    not what the kernels read in place (then the gather pass runs)."""
+    """Round 6: with resident tables and a row index the LSTM sweeps read the data
+    set's tensors through the index themselves (apg_quad_lstm_rollout_fwd_rows /
+    _bwd_rows) instead of a gather pass.  Returns the ApgBatchRows of an indexed
+    LSTM minibatch, or None where the tensors are not what the kernels read in
+    place (then the gather pass runs)."""
     ok = lambda t: (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
                     and t.numel() * 4 < (1 << 32) - 64)
     n = state0.shape[0]
@@ -1174,7 +1171,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
             hit = _STATIC_PLANES.lookup("recurrent", src) if src else None
             rows = None
             if (index is not None and getattr(ctx, "lstm_tables", None) is not None
-                    and LSTM_ROWS_IN_KERNEL):
+                    and getattr(ctx, "rows_in_kernel", True)):
                 rows = _lstm_batch_rows(state0, in_ref, ref, index, H)
             if rows is not None:
                 # round 6: the sweeps read the data set's rows through the index
@@ -2246,15 +2243,19 @@ _LSTM_PARAMS = ("conv_ref.weight", "conv_ref.bias", "lstm.weight_ih",
 
 def quad_lstm_rollout_grads(net, state0, in_ref, ref, dt, params, h0, c0,
                             weights=None, index=None, static_inputs=False,
-                            prepared=None, update=None, resident_tables=True):
+                            prepared=None, update=None, resident_tables=True,
+                            rows_in_kernel=True):
     """quad_lstm_rollout_loss + parameter gradients, without autograd.
     resident_tables (round 6): the sweeps read operand tables that stay packed
     between steps (LstmResidentTables) and ONE launch behind the products puts
     the gradients into place, reduces the loss and packs the next step's tables;
     `update` = (lr, momentum, {parameter name: momentum buffer}): that launch
     also applies torch.optim.SGD's momentum update (one process: the trainer
-    then skips optimizer.step())."""
+    then skips optimizer.step()).  rows_in_kernel (with `index` and resident
+    tables): the sweeps read the data set's rows through the index themselves;
+    False: the gather pass (the same numbers - what the tests compare with)."""
     ctx = _DirectCtx()
+    ctx.rows_in_kernel = rows_in_kernel
     if prepared is not None:     # quad_recurrent_prepare's result
         ctx.prepared = prepared
     elif static_inputs and index is None:

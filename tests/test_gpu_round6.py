@@ -410,12 +410,8 @@ def test_lstm_sweeps_read_the_batch_rows_through_the_index(dev, B, ref_cols):
     dyn = FlightmareDynamics()
     out = []
     for rows in (False, True):
-        F.LSTM_ROWS_IN_KERNEL = rows
-        try:
-            loss, gr, flat = F.quad_lstm_rollout_grads(net, s0, in_ref, ref, DT, dyn.params,
-                                                       h0, c0, index=index)
-        finally:
-            F.LSTM_ROWS_IN_KERNEL = True
+        loss, gr, flat = F.quad_lstm_rollout_grads(net, s0, in_ref, ref, DT, dyn.params,
+                                                   h0, c0, index=index, rows_in_kernel=rows)
         out.append((loss.clone(), flat.clone()))
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1][:-1], out[1][1][:-1])
