@@ -307,18 +307,6 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
 #pragma unroll
     for (int pp = 0; pp < kNP / 2; ++pp) {
       float rv[24];  // relu(conv) of positions 2 pp, 2 pp + 1: registers 0..11 each
-      // window rows 2 pp .. 2 pp + 3 relative to the current position, split:
-      // high term in the low half-word, low term in the high half-word
-      unsigned ws[4][5];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const float xv = j < 3 ? w[2 * pp + r][j] - sub[j] : w[2 * pp + r][j];
-          const _Float16 vh = (_Float16)xv, vl = (_Float16)(xv - (float)vh);
-          const h16x2 pr = {vh, vl};
-          ws[r][j] = __builtin_bit_cast(unsigned, pr);
-        }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int pos = 2 * pp + e;
@@ -327,14 +315,23 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
         for (int i = 0; i < 16; ++i) cv[i] = L.T(hTbc + i * 2);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+          // window slot s = (column s / 3, tap s % 3) relative to the current
+          // position, two slots per split: high and low terms land in the operand
+          // registers directly (round 6; rounds 3-5 split every window value on its
+          // own - five instructions - and paired the halves with two v_perm per
+          // slot pair: 66 instructions per position, now 41; the same numbers)
           Op16 x;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int s0 = kb * 8 + 2 * q, s1 = s0 + 1;
-            const unsigned r0 = ws[e + s0 % 3][s0 / 3];
-            const unsigned r1 = s1 < 15 ? ws[e + s1 % 3][s1 < 15 ? s1 / 3 : 0] : 0u;
-            x.h[q] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);  // low half-words
-            x.l[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);  // high half-words
+            const float v0 =
+                s0 / 3 < 3 ? w[pos + s0 % 3][s0 / 3] - sub[s0 / 3] : w[pos + s0 % 3][s0 / 3];
+            float v1 = 0.f;
+            if (s1 < 15)
+              v1 = s1 / 3 < 3 ? w[pos + s1 % 3][s1 / 3] - sub[s1 / 3] : w[pos + s1 % 3][s1 / 3];
+            unsigned h_, l_;
+            split_pair(v0, v1, h_, l_);
+            x.h[q] = h_, x.l[q] = l_;
           }
           cv = mma3(L16.A(hA, nC + kb), x, cv);
         }
