@@ -67,7 +67,8 @@ typedef int i32x4_ __attribute__((ext_vector_type(4)));
 #define APG_AR_KNOCKOUT 0   // timing experiments (recurrent sweeps): 1 no global atomics,
                             // 2 no weight-block products, 4 no LDS adds, 8 no conv-weight
                             // products, 16 no workgroup barriers, 32 the trajectory-major
-                            // block loads read one cache-resident 2 KB window, 64 the
+                            // block loads read one cache-resident 2 KB window, 128 the same
+                            // loads lane-linear (the block's bytes, coalesced), 64 the
                             // per-lane state / action / reference loads read cached planes
 #endif
 
@@ -80,6 +81,16 @@ struct TBlock {
     if (APG_AR_KNOCKOUT & 32) {
       voff = (threadIdx.x & 31u) * 64u + ((threadIdx.x & 32u) ? 16u : 0u);
       soff = 0u;
+    }
+    if (APG_AR_KNOCKOUT & 128) {   // lane-linear: 4 KB from the block's first plane on -
+      // the same bytes per block, 8 cache lines per instruction instead of 64 (what a
+      // tiled plane layout would give the sweep)
+      voff = voff == kDead ? kDead : (threadIdx.x & 63u) * 16u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        q[g] = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, (int)voff, (int)(soff + 1024 * g),
+                                                     APG_PLANES_LD_AUX);
+      return;
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
