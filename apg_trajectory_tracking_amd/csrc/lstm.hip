@@ -1053,9 +1053,8 @@ constexpr int kGwActs = kNF + 3 * kNH;            // acts planes: 15 | 8 + 8 | 8
 #error "experiment macro in a product build (variants: tools/build_policy_variant.sh)"
 #endif
 #ifndef APG_GW_KNOCKOUT
-#define APG_GW_KNOCKOUT 0   // timing experiments: 1 the trajectory-major block loads read
-                            // 1 KB lane-linear (8 cache lines per instruction, not 64),
-                            // 2 no conv / product per position, 8 one step per group
+#define APG_GW_KNOCKOUT 0   // timing experiments: 2 no conv / product per position,
+                            // 8 one step per group
 #endif
 
 struct GwArgs {
@@ -1094,6 +1093,13 @@ struct GwLoads {
 // (k + r) % 7.
 constexpr int kGwSlots = 7;
 constexpr int kGwWin = kGwSlots * 5 * kGwThreads;   // floats
+// Trajectory-major blocks (d_gates; PH 0: features + h_prev) reach the registers
+// THROUGH LDS: the plane layout makes a block load by lane 64 pieces of 16 bytes in 32
+// cache lines (tools/ab_gate_wgrad.sh: 12 us of this kernel); instead 64 lanes fetch
+// 16 consecutive bytes each - eight lanes a whole line of one plane - straight into
+// LDS (4 instructions, 8 lines each), the chunks of a line swizzled by its plane
+// number so that the 16-byte reads in block orientation hit no bank twice.
+constexpr int kGwBlk = kGwWaves * 2 * 1024;        // floats: [wave][d_gates | fifth][4 KB]
 
 template <int PH>
 __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
@@ -1103,6 +1109,17 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
   const int lane = threadIdx.x & 63, hi = lane >> 5, row = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const LdsView16 L16(lds, lane);
+  // this wave's two staged blocks; a lane's share of a staged load: line (plane)
+  // lane >> 3 of the instruction's eight, chunk (lane & 7) ^ (that plane & 7)
+  float *const blk = lds + kGwTab + kGwWin + wave * 2048;
+  const unsigned st_plane = (unsigned)lane >> 3, st_chunk = (((unsigned)lane & 7u) ^ st_plane) * 16u;
+  // ... and of a block read: chunk 2 g + hi of plane `row`
+  auto staged = [&](int which, TBlock &t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      t.q[g] = *reinterpret_cast<const u32x4 *>(
+          blk + which * 1024 + (row * 8 + ((2 * g + hi) ^ (row & 7))) * 4);
+  };
   const int B = A.B;
   const unsigned pitchB = (unsigned)B * 4u, pitchN = pitchB * kH;
   const Planes Ps0(A.state0, 12, pitchB), Pst(A.states, kH * 12, pitchB);
@@ -1148,12 +1165,10 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
     // trajectory-major blocks: the lane's plane, trajectories b0 + 4 hi ..; the WHOLE
     // offset sits in the VGPR, so the buffer's range check covers the ragged tail
     const unsigned tcol = (unsigned)b0 * 4u + (unsigned)hi * 16u;
-    // (knock-out 1: lane-linear 16-byte loads - 8 cache lines per instruction, not 64)
-    const unsigned vg = (APG_GW_KNOCKOUT & 1) ? (unsigned)lane * 16u + tcol * 8u
-                                              : (unsigned)row * pitchN + tcol;
-    const unsigned va = (APG_GW_KNOCKOUT & 1)
-                            ? (unsigned)lane * 16u + tcol * 8u
-                            : (unsigned)(kAuxPlane0 + (aux_row ? row : 0)) * pitchN + tcol;
+    const unsigned vg = (unsigned)row * pitchN + tcol;
+    const unsigned va = (unsigned)(kAuxPlane0 + (aux_row ? row : 0)) * pitchN + tcol;
+    // staged loads: plane (8 i + lane >> 3) of instruction i, this lane's chunk
+    const unsigned vs = st_plane * pitchN + (unsigned)b0 * 4u + st_chunk;
 
     // window row r (relative to 4 PH) -> its slot, straight into LDS
     auto row_in = [&](int r, unsigned pB, int j0, int j1) {
@@ -1170,16 +1185,23 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
     // workgroup's others queue behind it - spread over the step, between the
     // positions, the address unit works while the matrix pipe and the VALU do
     auto issue = [&](int k, int part) {
-      const unsigned pB = opaque(pitchB);
-      const unsigned kcol = (APG_GW_KNOCKOUT & 1) ? 0u : (unsigned)k * pB;
-      const unsigned o = ((APG_GW_KNOCKOUT & 1) ? 1024u : 32u) * (unsigned)part;
-      ld.tg.q[part] = __builtin_amdgcn_raw_buffer_load_b128(Pdg.rsrc, (int)(vg + kcol), (int)o,
-                                                            APG_PLANES_LD_AUX);
-      ld.ta.q[part] = __builtin_amdgcn_raw_buffer_load_b128(
-          Pac.rsrc, (int)(aux_row ? va + kcol : kDead), (int)o, APG_PLANES_LD_AUX);
-      if (PH == 1)
+      const unsigned pB = opaque(pitchB), pN8 = 8u * opaque(pitchN);
+      const unsigned kcol = (unsigned)k * pB;
+      // d_gates: planes 8 part .. + 7 into this wave's first staged block
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(Pdg.rsrc, (lds_ptr_t)(blk + part * 256), 16,
+                                               (int)(vs + kcol), (int)(part * pN8), 0, 0);
+      if (PH == 0) {   // features, h_prev: planes 0 .. 22
+        const bool on = 8 * part + (int)st_plane < kAuxCols;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Pac.rsrc, (lds_ptr_t)(blk + 1024 + part * 256),
+                                                 16, (int)(on ? vs + kcol : kDead),
+                                                 (int)(part * pN8), 0, 0);
+      } else {         // h_new, d_zout: a few planes - by lane
+        const unsigned o = 32u * (unsigned)part;
+        ld.ta.q[part] = __builtin_amdgcn_raw_buffer_load_b128(
+            Pac.rsrc, (int)(aux_row ? va + kcol : kDead), (int)o, APG_PLANES_LD_AUX);
         ld.tz.q[part] = __builtin_amdgcn_raw_buffer_load_b128(
             Pdz.rsrc, (int)(row < 4 ? vg + kcol : kDead), (int)o, APG_PLANES_LD_AUX);
+      }
       if (part == 0) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)   // the current position: the state BEFORE step k
@@ -1212,9 +1234,13 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
       Op16 ad[2], bx[2], az[2];
       {
         float dv[16], av[16], zv[16];
+        staged(0, ld.tg);
+        if (PH == 0) staged(1, ld.ta);
         ld.tg.get(dv);
         ld.ta.get(av);
         if (PH == 1) ld.tz.get(zv);
+        // (the staged blocks are in registers: the next step's may land)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (k + 1 < kH) issue(k + 1, 0);
         if (nvalid < 32) mask_tail(dv, hi, nvalid);
         split16(dv, E, ad);
@@ -1662,7 +1688,7 @@ int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const flo
   A.B = B;
   const int blocks = gw_blocks(B);
   hipLaunchKernelGGL(lstm_gate_wgrad_kernel, dim3(blocks), dim3(kGwThreads),
-                     (kGwTab + kGwWin) * sizeof(float), st, A);
+                     (kGwTab + kGwWin + kGwBlk) * sizeof(float), st, A);
   if (int e = check_launch("quad_lstm_gate_wgrad")) return e;
   GwReduceArgs R;
   R.partials = partials, R.chunks = blocks / 2;
