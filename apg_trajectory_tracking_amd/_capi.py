@@ -203,6 +203,8 @@ SIGNATURES = {
         ctypes.POINTER(ApgBatchRows), _I, _P, _P, _P, _P, _P, _P, _F,
         ctypes.POINTER(ApgQuadParams), ctypes.POINTER(ApgQuadLossWeights), _P,
         _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "apg_quad_lstm_conv_wgrad_partials_floats": [_I],
+    "apg_quad_lstm_conv_wgrad": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "apg_quad_lstm_gate_wgrad_partials_floats": [_I],
     "apg_quad_lstm_gate_wgrad": [
         _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicy), _P, _I, _I,

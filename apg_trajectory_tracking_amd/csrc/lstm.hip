@@ -1381,6 +1381,204 @@ __global__ __launch_bounds__(256) void lstm_gate_wgrad_reduce_kernel(GwReduceArg
   }
 }
 
+// --------------------------------------------------- conv weight gradient
+// Round 6.  dconv_w[ch][c][t] = sum G[ch][hi][tau] . R[4 hi + tau + t][c]
+//                               - (c < 3) sum_k P[ch][k] . pos_k[c],
+// dconv_b[ch] = sum_k P[ch][k]  (the diagonal sums the reverse sweep leaves, see
+// kConvP) were two segmented planes_gemm products + their reduce: 75-80 us for
+// 190 MB of cotangents, the LDS-tile kernel on the fp32 matrix instruction.  Here:
+// one wave per 32 trajectories walks the 26 diagonals and the 10 position sums;
+// both operands of a segment are 32 x 32 blocks straight out of planes - G / P
+// rows as A (channel in the lane), window rows / positions as B ((column, tap) in
+// the lane: plane (4 hi + tau + t) 9 + c) - fetched by coalesced direct-to-LDS loads
+// one segment ahead (chunks swizzled by plane, see kGwBlk), split into fp16 terms
+// (the cotangents scaled by a running power of two per wave: two accumulators to
+// rescale when it grows) and multiplied trajectory-major.  The waves of a workgroup
+// add up in LDS in wave order, lstm_conv_wgrad_reduce_kernel adds the workgroups in
+// index order: bit-reproducible.
+constexpr int kCwThreads = 512, kCwWaves = kCwThreads / 64;
+constexpr int kCwSegG = 2 * kTau, kCwSeg = kCwSegG + kH;   // 26 diagonals + 10 position sums
+constexpr int kCwPart = 2 * 16 * 64;                       // a workgroup's partial: 2 048 floats
+constexpr int kCwLds = kCwWaves * 4 * 1024;                // floats: [wave][2 buffers][A | B][4 KB]
+constexpr int kCwTaps = kRD * 3;                           // 27 (column, tap) pairs
+
+struct CwArgs {
+  const float *d_conv, *in_ref, *st_all;   // [720][B], [2H*9][B], [(H+1)*12][B]
+  float *partials;                         // [workgroups][kCwPart]
+  int B;
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return o > v ? o : v;
+}
+// maximum of a wave's unsigned values on the VALU alone (DPP row shifts, then row
+// broadcasts; policy_tm.h's wave_umax is six ds_bpermute round trips)
+__device__ __forceinline__ unsigned wave_umax_dpp(unsigned v) {
+  v = dpp_umax<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_umax<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_umax<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_umax<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row: the row's maximum
+  v = dpp_umax<0x142, 0xa>(v);   // row_bcast:15 -> lanes 31, 63: two rows
+  v = dpp_umax<0x143, 0xc>(v);   // row_bcast:31 -> lane 63: the wave
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(kCwThreads) void lstm_conv_wgrad_kernel(CwArgs A) {
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, hi = lane >> 5, row = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int B = A.B, b0 = (blockIdx.x * kCwWaves + wave) * 32;
+  const unsigned pitchB = (unsigned)B * 4u;
+  const Planes Pdc(A.d_conv, kConvPlanes, pitchB), Pin(A.in_ref, 2 * kH * kRD, pitchB);
+  const Planes Pst(A.st_all, (kH + 1) * 12, pitchB);
+  float *const buf = lds + wave * 4096;   // [buffer][A | B][1024]
+  // a lane's share of a staged load: line (plane) 8 i + lane >> 3 of instruction i,
+  // chunk (lane & 7) ^ (that plane's number & 7)
+  const unsigned sp = (unsigned)lane >> 3, sc = (((unsigned)lane & 7u) ^ sp) * 16u;
+  const unsigned col0 = (unsigned)b0 * 4u + sc;
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  int E[2] = {-100000, -100000};
+
+  if (b0 < B) {   // (wave-uniform; a dead wave still takes part in the sum below)
+    const int nvalid = B - b0;
+    // the two operands of segment s into buffer q (8 instructions)
+    auto issue = [&](int s, int q) {
+      const unsigned pB = opaque(pitchB);
+      const bool diag = s < kCwSegG;
+      const int shi = s >= kTau ? 1 : 0, tau = s - shi * kTau, k = s - kCwSegG;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned ch = 8u * i + sp;   // A: channel rows
+        const unsigned pa = diag ? ch * (unsigned)kCwSegG + (unsigned)s
+                                 : (unsigned)kConvP + ch * (unsigned)kH + (unsigned)k;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            Pdc.rsrc, (lds_ptr_t)(buf + q * 2048 + i * 256), 16,
+            (int)(ch < (unsigned)kNC ? pa * pB + col0 : kDead), 0, 0, 0);
+        const unsigned j = ch;             // B: (column, tap) = (j / 3, j % 3) | position j
+        if (diag) {
+          const unsigned pb = ((unsigned)(4 * shi + tau) + j % 3u) * (unsigned)kRD + j / 3u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              Pin.rsrc, (lds_ptr_t)(buf + q * 2048 + 1024 + i * 256), 16,
+              (int)(j < (unsigned)kCwTaps ? pb * pB + col0 : kDead), 0, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              Pst.rsrc, (lds_ptr_t)(buf + q * 2048 + 1024 + i * 256), 16,
+              (int)(j < 3u ? ((unsigned)k * 12u + j) * pB + col0 : kDead), 0, 0, 0);
+        }
+      }
+    };
+    auto staged = [&](int q, int which, float (&v)[16]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_ f = *reinterpret_cast<const f32x4_ *>(
+            buf + q * 2048 + which * 1024 + (row * 8 + ((2 * g + hi) ^ (row & 7))) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * g + c] = f[c];
+      }
+    };
+    // one segment: wait for its operands (the next one's are in flight), multiply
+    auto segment = [&](int s, f32x16 &acc_, int &E_, bool ones) {
+      const int q = s & 1;
+      if (s + 1 < kCwSeg) {
+        issue(s + 1, q ^ 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this segment's eight have landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      float av[16], bv[16];
+      staged(q, 0, av);
+      staged(q, 1, bv);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (before the buffer is refilled)
+      if (nvalid < 32) mask_tail(av, hi, nvalid);
+      // the cotangents' block exponent; the accumulator follows when it grows
+      unsigned m = 0u;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m = umax_abs(m, av[i]);
+      m = wave_umax_dpp(m);
+      bool bad = false;
+      const int e = bits_exp(m, bad, false);
+      if (e > E_) {
+        if (E_ > -100000) {
+          const int d = E_ - e;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc_[i] = __builtin_amdgcn_ldexpf(acc_[i], d);
+        }
+        E_ = e;
+      }
+      if (ones)   // the ones column of the position block: the bias gradient
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bv[i] += row == 3 ? 1.f : 0.f;
+      Op16 ad[2], bx[2];
+      split16(av, E_, ad);
+      split16(bv, 0, bx);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc_ = mma3(ad[kk], bx[kk], acc_);
+    };
+    issue(0, 0);
+#pragma unroll 1
+    for (int s = 0; s < kCwSegG; ++s) segment(s, acc[0], E[0], false);
+#pragma unroll 1
+    for (int s = kCwSegG; s < kCwSeg; ++s) segment(s, acc[1], E[1], true);
+  }
+  // the workgroup's sum at true scale: every wave into its own region, then all
+  // threads add the eight regions in wave order
+  f32x4_ *const sum = reinterpret_cast<f32x4_ *>(lds);
+  constexpr int kQuads = 2 * 4 * 64;
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      f32x4_ v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_ldexpf(acc[n][4 * i4 + c], E[n]);
+      sum[wave * kQuads + (n * 4 + i4) * 64 + lane] = v;
+    }
+  __syncthreads();
+  f32x4_ *dst = reinterpret_cast<f32x4_ *>(A.partials + (size_t)blockIdx.x * kCwPart);
+  for (int idx = threadIdx.x; idx < kQuads; idx += kCwThreads) {
+    f32x4_ v = sum[idx];
+#pragma unroll
+    for (int wv = 1; wv < kCwWaves; ++wv) v += sum[wv * kQuads + idx];
+    dst[idx] = v;
+  }
+}
+
+struct CwReduceArgs {
+  const float *partials;
+  int wgs;
+  float *conv_w, *conv_pos, *conv_b;   // [20][27], [20][3], [20]
+};
+// 620 of a partial's 2 048 floats are gradients (20 channels x 27 + 20 x 4): a thread
+// per (gradient, 1 of 32 slices of the workgroups), the slices added in a fixed tree
+constexpr int kCwOut = kNC * kCwTaps + kNC * 4;
+__global__ __launch_bounds__(256) void lstm_conv_wgrad_reduce_kernel(CwReduceArgs A) {
+  const int pt = threadIdx.x & 31, o = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool on = o < kCwOut;
+  const int oc = on ? o : 0;
+  const int n = oc < kNC * kCwTaps ? 0 : 1, q = n ? oc - kNC * kCwTaps : oc;
+  const int ch = n ? q >> 2 : q / kCwTaps, col = n ? q & 3 : q % kCwTaps;
+  // element of a partial: block n, register i of lane `lane` with ch = r(i) + 4 hi
+  const int hi = (ch >> 2) & 1, i = (ch & 3) + 4 * (ch >> 3), lane = hi * 32 + col;
+  const int r = ((n * 4 + (i >> 2)) * 64 + lane) * 4 + (i & 3);
+  float s = 0.f;
+  if (on)
+    for (int c = pt; c < A.wgs; c += 32) s += A.partials[(size_t)c * kCwPart + r];
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);   // (fixed order)
+  if (!on || pt) return;
+  if (n == 0) A.conv_w[ch * kCwTaps + col] = s;
+  else if (col < 3) A.conv_pos[ch * 3 + col] = s;
+  else A.conv_b[ch] = s;
+}
+
 // pol NULL: the caller holds packed tables instead of the parameters
 int check_lstm(const ApgQuadParams *params, const ApgLstmPolicy *pol, int B, int H,
                bool packed = false) {
@@ -1687,6 +1885,16 @@ int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const flo
   A.tables = tables_fwd, A.partials = partials;
   A.B = B;
   const int blocks = gw_blocks(B);
+  {   // (145 KB of dynamic LDS: above the 64 KB a kernel gets unasked)
+    static PerDeviceOnce attr;
+    if (!attr.test()) {
+      if (hipFuncSetAttribute((const void *)lstm_gate_wgrad_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((kGwTab + kGwWin + kGwBlk) * sizeof(float))) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(lstm_gate_wgrad)");
+      attr.set();
+    }
+  }
   hipLaunchKernelGGL(lstm_gate_wgrad_kernel, dim3(blocks), dim3(kGwThreads),
                      (kGwTab + kGwWin + kGwBlk) * sizeof(float), st, A);
   if (int e = check_launch("quad_lstm_gate_wgrad")) return e;
@@ -1722,6 +1930,60 @@ int apg_quad_lstm_rollout_bwd_rows(const ApgBatchRows *rows, int ref_cols, const
                   params, weights, nullptr, B, H, loss_partials, loss, d_gates, d_zout, d_conv,
                   grad_state0, grad_h0, grad_c0, cot_amax, const_cast<float *>(tables_bwd),
                   stream);
+}
+
+int apg_quad_lstm_conv_wgrad_partials_floats(int B) {
+  return B <= 0 ? 0 : ((B + 32 * kCwWaves - 1) / (32 * kCwWaves)) * kCwPart;
+}
+
+int apg_quad_lstm_conv_wgrad(const float *d_conv, const float *in_ref, const float *st_all, int B,
+                             int H, float *partials, float *conv_w, float *conv_pos,
+                             float *conv_b, apg_stream_t stream) {
+  if (H != kH) {
+    set_error("the fused LSTM rollout is built for horizon %d (got %d)", kH, H);
+    return APG_ERR_ARG;
+  }
+  if (B < 0 || (long long)B * 4 * kConvPlanes >= (1ll << 32) - 64) {
+    set_error("apg_quad_lstm_conv_wgrad: B out of range (%d)", B);
+    return APG_ERR_ARG;
+  }
+  if (!conv_w || !conv_pos || !conv_b) {
+    set_error("apg_quad_lstm_conv_wgrad: NULL gradient buffer");
+    return APG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (hipMemsetAsync(conv_w, 0, sizeof(float) * kNC * kCwTaps, st) != hipSuccess ||
+        hipMemsetAsync(conv_pos, 0, sizeof(float) * kNC * 3, st) != hipSuccess ||
+        hipMemsetAsync(conv_b, 0, sizeof(float) * kNC, st) != hipSuccess)
+      return check_launch("memset(conv gradients)");
+    return APG_OK;
+  }
+  if (!d_conv || !in_ref || !st_all || !partials) {
+    set_error("apg_quad_lstm_conv_wgrad: NULL buffer");
+    return APG_ERR_ARG;
+  }
+  {
+    static PerDeviceOnce attr;
+    if (!attr.test()) {
+      if (hipFuncSetAttribute((const void *)lstm_conv_wgrad_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(kCwLds * sizeof(float))) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(lstm_conv_wgrad)");
+      attr.set();
+    }
+  }
+  CwArgs A;
+  A.d_conv = d_conv, A.in_ref = in_ref, A.st_all = st_all, A.partials = partials, A.B = B;
+  const int wgs = (B + 32 * kCwWaves - 1) / (32 * kCwWaves);
+  hipLaunchKernelGGL(lstm_conv_wgrad_kernel, dim3(wgs), dim3(kCwThreads),
+                     kCwLds * sizeof(float), st, A);
+  if (int e = check_launch("quad_lstm_conv_wgrad")) return e;
+  CwReduceArgs R;
+  R.partials = partials, R.wgs = wgs;
+  R.conv_w = conv_w, R.conv_pos = conv_pos, R.conv_b = conv_b;
+  hipLaunchKernelGGL(lstm_conv_wgrad_reduce_kernel, dim3((kCwOut + 7) / 8), dim3(256), 0, st, R);
+  return check_launch("quad_lstm_conv_wgrad_reduce");
 }
 
 int apg_quad_lstm_tables_floats(int reverse) { return reverse ? kBwd16Lds : kFwd16Lds; }

@@ -1375,12 +1375,18 @@ def _lstm_param_grads(saved, dims, tail=None):
         ptr(ih_hh),
         ptr(gr["lstm.bias_ih"]), ptr(gr["fc_out.weight"]), ptr(gr["fc_out.bias"]),
         stream_of(acts)), "apg_quad_lstm_gate_wgrad")
-    conv, finish = _conv_diag_problems(d_conv, refbuf, B, H, gr["conv_ref.weight"],
-                                       gr["conv_ref.bias"])
-    _run_products(conv)
+    # the conv weights' gradient from the diagonal sums: one kernel over the planes
+    # (round 6; rounds 3-5: two segmented planes_gemm products, _conv_diag_problems)
+    conv_pos = torch.empty(20, 3, dtype=torch.float32, device=dev)
+    scratch_c = torch.empty(max(1, lib().apg_quad_lstm_conv_wgrad_partials_floats(B)),
+                            dtype=torch.float32, device=dev)
+    check(lib().apg_quad_lstm_conv_wgrad(
+        ptr(d_conv), ptr(refbuf[:2 * H * 9]), ptr(st_all), B, H, ptr(scratch_c),
+        ptr(gr["conv_ref.weight"]), ptr(conv_pos), ptr(gr["conv_ref.bias"]),
+        stream_of(acts)), "apg_quad_lstm_conv_wgrad")
     gr["lstm.bias_hh"] = gr["lstm.bias_ih"]
     if tail is None:
-        finish()
+        gr["conv_ref.weight"][:, :3].sub_(conv_pos[:, :, None])
         # contiguous per-parameter gradients (the fused optimizer path wants them)
         gr["lstm.weight_ih"].copy_(ih_hh[:, :175])
         gr["lstm.weight_hh"].copy_(ih_hh[:, 175:])
@@ -1391,7 +1397,7 @@ def _lstm_param_grads(saved, dims, tail=None):
                      _LSTM_PARAMS))
     t = _capi.ApgLstmStepTail(
         grad=G(**{c: ptr(gr[n]) for c, n in names.items()}),
-        ih_hh=ptr(ih_hh), conv_pos=ptr(conv[1]["out"]), update=int(update is not None),
+        ih_hh=ptr(ih_hh), conv_pos=ptr(conv_pos), update=int(update is not None),
         param=G(**{c: ptr(pw[c]) for c in names}),
         tables_fwd=ptr(tables.fwd), tables_bwd=ptr(tables.bwd),
         loss_partials=ptr(partials), n_partials=partials.numel(), loss=ptr(loss))

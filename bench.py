@@ -315,7 +315,8 @@ STEP_MODELS = {
     # c0) by the three kernels 1 972, the conv cotangents' 720 diagonal planes
     # written and read once 5 760, the window + position planes of the two conv
     # products 840.  (Rounds 2-5: 2 916 per env-step, x alone 700 twice.)
-    "LSTM": dict(mfma_once=0, mfma_per_step=90 + 42 + 108, products_in_sweep=True,
+    # (+ lstm_conv_wgrad_kernel: 36 segments x 6 per 32 trajectories, 22 per step)
+    "LSTM": dict(mfma_once=0, mfma_per_step=90 + 42 + 108 + 22, products_in_sweep=True,
                  bytes_per_step=368 + 316 + 144 + 280,
                  bytes_per_traj=1972 + 5760 + 840,
                  # state0 48 + in_ref 720 + ref 360 + h0 / c0 64

@@ -327,6 +327,22 @@ int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const flo
                              float *partials, float *ih_hh, float *b_ih, float *w_out,
                              float *b_out, apg_stream_t stream);
 
+/* Round 6: the conv weights' gradient of the LSTM unroll (what `loss.backward()`
+ * leaves in conv_ref.weight / bias, scripts/train_drone.py:168) from the diagonal
+ * sums d_conv [720][B] of apg_quad_lstm_rollout_bwd, the reference planes in_ref
+ * [2H][9][B] and st_all [(H + 1)][12][B] = [state0; states]: one kernel, both
+ * operands of a segment straight out of planes, trajectory-major products on
+ * fp16-split operands; a second one sums the workgroups in index order.
+ *   conv_w [20][27] = sum G . R (index c * 3 + t: conv_ref.weight's own layout,
+ *   BEFORE the position part is subtracted), conv_pos [20][3] = sum_k P . pos_k,
+ *   conv_b [20] = sum_k P;  dconv_w[ch][c][t] = conv_w[ch][c][t] - (c < 3) conv_pos[ch][c]
+ *   (apg_quad_lstm_step_tail does the subtraction).
+ *   partials: apg_quad_lstm_conv_wgrad_partials_floats(B) floats of scratch. */
+int apg_quad_lstm_conv_wgrad_partials_floats(int B);
+int apg_quad_lstm_conv_wgrad(const float *d_conv, const float *in_ref, const float *st_all, int B,
+                             int H, float *partials, float *conv_w, float *conv_pos,
+                             float *conv_b, apg_stream_t stream);
+
 /* The LSTM training step without its small launches (round 6; the loop body of
  * scripts/train_base.py:198-214 for train_mode "LSTM": loss.backward() +
  * optimizer.step()).  The operand tables of the two sweeps live in caller-owned

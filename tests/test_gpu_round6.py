@@ -380,6 +380,20 @@ def test_lstm_gate_weight_gradients_recompute_the_conv_inputs(dev, B):
             "lstm.bias_ih": d_gates.double().sum(dim=1),
             "fc_out.weight": d_zout.double() @ a[31:39].t(),
             "fc_out.bias": d_zout.double().sum(dim=1)}
+    # the conv weights' gradient (apg_quad_lstm_conv_wgrad) from the diagonal sums the
+    # reverse sweep left: G[ch][hi][tau] against window row 4 hi + tau + t, the
+    # position sums P[ch][k] against the current position (and ones: the bias)
+    d_conv = ctx.saved_tensors[4].double()
+    G = d_conv[:520].view(20, 2, 13, B)
+    P = d_conv[520:].view(20, H, B)
+    dw = torch.zeros(20, 9, 3, dtype=torch.float64, device=dev)
+    for hi_ in range(2):
+        for tau in range(13):
+            for t in range(3):
+                dw[:, :, t] += G[:, hi_, tau] @ inr[4 * hi_ + tau + t].t()
+    dw[:, :3] -= torch.einsum("ckb,kjb->cj", P, st_all[:H, :3])[:, :, None]
+    want["conv_ref.weight"] = dw
+    want["conv_ref.bias"] = P.sum(dim=(1, 2))
     for k, w in want.items():
         scale = w.abs().max().item() + 1e-300
         assert (gr[k].double() - w).abs().max().item() / scale < 2e-6, k
