@@ -1138,6 +1138,14 @@ __device__ __forceinline__ void gate_wgrad_body(const GwArgs &A) {
   for (int n = 0; n < kGwBlocks; ++n)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  // the two waves of a SIMD (w, w + 4) run the same instruction stream: started
+  // together they want the matrix pipe and the VALU at the same moments.  The
+  // second one starts ~770 cycles late (measured, same box: 104-105.5 us in step,
+  // 101-102 with a delay of 256 .. 2 560 cycles; tools/ab_gate_wgrad.sh ps<n>)
+#ifndef APG_GW_PHASE_SLEEP
+#define APG_GW_PHASE_SLEEP 12
+#endif
+  if (wave >= 4) __builtin_amdgcn_s_sleep(APG_GW_PHASE_SLEEP);
   // the wave's scales: 2^-E d_gates, 2^-E2 d_zout are at most 1
   const int g0 = ((blockIdx.x >> 1) * kGwWaves + wave) * kGwGroups;
   int E, E2;
