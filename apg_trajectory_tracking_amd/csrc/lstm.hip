@@ -28,8 +28,11 @@
 // next step's W_hh product: the recurrence needs no data movement at all.
 //
 // Weight gradients: the reverse sweep writes the per-(step, trajectory)
-// cotangent planes (gate / head / conv pre-activations) next to the forward's
-// saved inputs, all as [feature][H*B] planes; apg_planes_gemm reduces them.
+// cotangent planes of the gate and head pre-activations ([feature][H*B]) and the
+// conv cotangents summed along the window diagonals; rounds 1-5 reduced them
+// against the forward's saved inputs with apg_planes_gemm, since round 6 two
+// trajectory-major kernels below do (lstm_gate_wgrad_kernel - which recomputes the
+// conv inputs instead of reading 160 stored planes - and lstm_conv_wgrad_kernel).
 #include "apg_device.h"
 #include "policy_mfma.h"
 #include "policy_mfma16.h"

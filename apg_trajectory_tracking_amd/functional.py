@@ -1147,8 +1147,8 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
     forward : apg_quad_lstm_rollout_fwd then apg_quad_lstm_rollout_bwd (the
               reverse sweep runs right away - the loss only exists after it).
     backward: turns the saved per-(step, trajectory) cotangent planes into the
-              parameter gradients with three matrix-core reduction GEMMs over
-              the H*B rows (apg_planes_gemm).
+              parameter gradients with two trajectory-major kernels
+              (apg_quad_lstm_gate_wgrad, apg_quad_lstm_conv_wgrad; round 6).
     Inputs are the reference's tensors: state0 [B,12], in_ref [B,2H,9],
     ref [B,>=H,9], h0 / c0 [B,8] and the LSTM_NEW parameters."""
 
@@ -1339,9 +1339,10 @@ def lstm_resident_tables(net, dev):
 
 
 def _lstm_param_grads(saved, dims, tail=None):
-    """Weight gradients of the fused LSTM unroll from the saved planes: three
-    matrix-core products; every gradient is a contiguous view of one flat
-    buffer (returned first), keyed by LSTM_NEW parameter name.
+    """Weight gradients of the fused LSTM unroll from the saved planes: two
+    trajectory-major kernels (gate / head weights with the conv inputs recomputed,
+    conv weights from the diagonal sums); every gradient is a contiguous view of
+    one flat buffer (returned first), keyed by LSTM_NEW parameter name.
     tail = (partials, loss, {C name: parameter}, tables, update): what follows
     the products is ONE launch (apg_quad_lstm_step_tail: gradients into place,
     momentum SGD if `update` = (lr, momentum, {parameter name: buffer}), the next
