@@ -404,8 +404,9 @@ class TrainBase:
         # other way round on the builder's; LSTM 0.480 eager against 0.494
         # graphed) - so it is MEASURED, once per train mode: the first time a
         # step is captured, `launch_form_steps` replays are timed against as
-        # many stream-order steps (the training they do is undone), the faster
-        # form is kept and recorded in results_dict["launch_form"].
+        # many stream-order steps (behind 30 ms of untimed replays, alternately,
+        # twice; the training they do is undone), the faster form is kept and
+        # recorded in results_dict["launch_form"].
         # `launch_form[train_mode]` = "graph" | "eager" pins the answer.
         self.launch_form = {}
         self.measure_launch_form = type(self).MEASURE_LAUNCH_FORM
@@ -757,8 +758,18 @@ class TrainBase:
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
         try:
-            t_graph = timed(lambda: g(borrow=True))
-            t_eager = timed(eager)
+            # (the capture left the device idle and it clocks down: the form
+            # timed first paid the ramp - 12-20 ms, profiles/r06_step_ramp.txt -
+            # and lost.  Untimed replays take the ramp, then the two forms are
+            # timed alternately, twice, and each keeps its better time)
+            replay = lambda: g(borrow=True)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.03:
+                replay()
+            t_graph = t_eager = float("inf")
+            for _ in range(2):
+                t_graph = min(t_graph, timed(replay))
+                t_eager = min(t_eager, timed(eager))
         finally:
             with torch.no_grad():
                 for p, v in zip(params, saved):
@@ -1035,10 +1046,19 @@ class TrainBase:
         Returns (running_loss, last batch index)."""
         running, i = _EpochLoss(fresh=not self._graphable()), -1
         self._borrow_loss, self._epoch_sigs = True, {}
+        ld = self.trainloader
+        ahead = indices is None and hasattr(ld, "epoch_order")
         try:
             for i, index in enumerate(
-                    self.trainloader.iter_indices() if indices is None else indices, 0):
+                    (ld.iter_indices(ld.epoch_order()) if ahead else ld.iter_indices())
+                    if indices is None else indices, 0):
                 running.add(step(index).detach())
+            if ahead and i >= 0 and not getattr(self, "_in_epoch_capture", False):
+                # stream-order epochs (a step whose launch form was measured
+                # "eager" takes no epoch graph): the next epoch's permutation is
+                # issued behind the last batch - same order of draws as without
+                # it - and sorts while the device drains and the loss is read
+                self._prefetch_order(ld)
         finally:
             self._borrow_loss, self._epoch_sigs = False, None
         return running.total(), i
@@ -1105,8 +1125,17 @@ class TrainBase:
             eg.update(graph=graph, perm=perm, running=running, last=last)
         eg["perm"].copy_(order)
         eg["graph"].replay()
+        # the next epoch's permutation is drawn while this one runs (the host has
+        # nothing else to do behind the replay; the draw is 0.25 ms of sort kernels)
+        self._prefetch_order(ld)
         torch.autograd.graph.increment_version([p.detach() for p in self.net.parameters()])
         return eg["running"], eg["last"]
+
+    def _prefetch_order(self, ld):
+        if hasattr(ld, "prefetch_order"):
+            if "order_stream" not in self._prefetch:
+                self._prefetch["order_stream"] = torch.cuda.Stream()
+            ld.prefetch_order(self._prefetch["order_stream"])
 
     # ---- which loop an epoch runs: ONE table, built by init_optimizer --------
     # Hooks a system trainer may override (the quadrotor trainer does):
@@ -1190,12 +1219,14 @@ class TrainBase:
         fast, i, extra = {}, -1, None
         self._borrow_loss, self._epoch_sigs = True, {}
         order = ld.epoch_order() if hasattr(ld, "prefetch_order") else None
-        if order is not None:          # the next epoch's permutation, drawn beside this one
-            if "order_stream" not in self._prefetch:
-                self._prefetch["order_stream"] = torch.cuda.Stream()
-            ld.prefetch_order(self._prefetch["order_stream"])
         try:
             for i, index in enumerate(ld.iter_indices(order)):
+                if i == 2 and order is not None:
+                    # the next epoch's permutation, drawn beside this one - its
+                    # ~20 launches are 0.2 ms of HOST time: issued here, behind
+                    # two queued batches, not in front of the epoch's first
+                    # (profiles/r06_epoch_concurrent.txt)
+                    self._prefetch_order(ld)
                 plan = fast.get(index.numel())
                 if plan is not None:
                     plan.launch(index=index)
@@ -1210,6 +1241,8 @@ class TrainBase:
                     fast[index.numel()] = g.plan     # (its running sum has this step)
                 else:      # the step took another route: its loss is added here
                     extra = loss.detach().clone() if extra is None else extra + loss.detach()
+            if order is not None and i < 2:        # (an epoch of one or two batches)
+                self._prefetch_order(ld)
         finally:
             self._borrow_loss, self._epoch_sigs = False, None
         total = None if extra is None else extra.reshape(1)

@@ -364,7 +364,7 @@ def step_roofline(mode, B, H, n_params, ms):
     }
 
 
-def timed_steps(step, n, dist):
+def timed_steps(step, n, dist, ramp_ms=40.0):
     """(ms per step, last output, per-chunk ms) of `n` calls, each chunk
     bracketed by barrier + synchronize (so every rank sees the slowest rank).
     The calls are timed in four chunks and the MEDIAN chunk is reported: one
@@ -372,7 +372,9 @@ def timed_steps(step, n, dist):
     3.5 ms "per step") would otherwise be the number; every chunk's mean is in
     the line next to it.  Chunks of 100 steps by default (--train-steps 400): a
     chunk pays one pipeline fill and one synchronize, ~50 us - at 10 steps per
-    chunk that was 4 % of the concurrent step."""
+    chunk that was 4 % of the concurrent step.  `ramp_ms` of untimed steps run
+    right before every chunk's barrier + synchronize (round 6): a chunk starts
+    on a device at its working clocks, as a step inside an epoch does."""
     for _ in range(3):
         out = step()
     chunks = []
@@ -383,6 +385,14 @@ def timed_steps(step, n, dist):
         # loaded - is taken HERE, not wherever its allocation count happens to
         # trip inside a timed chunk: round 4's 0.75 ms outlier chunk)
         gc.collect()
+        # (the collection leaves the device idle for tens of ms and it clocks
+        # down: the first steps behind it ran slow enough to cost a 100-step
+        # chunk 2.3 ms - 6 % of the LSTM step; the ramp is 12-20 ms long,
+        # profiles/r06_step_ramp.txt.  Untimed steps take it; the synchronize
+        # below is microseconds)
+        r0 = time.perf_counter()
+        while time.perf_counter() - r0 < ramp_ms * 1e-3:
+            out = step()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -634,8 +644,19 @@ def run_epoch_probe(args, dev, dyn):
                     t._graphs.clear()
                     t.run_epoch("controller", 0)          # warm-up (eager epoch)
                     t.run_epoch("controller", 0)          # capture of the epoch graph
+                    # (the capture left the device idle; three epochs of the
+                    # concurrent mode are 12 ms, the length of the clock ramp
+                    # behind an idle device - profiles/r06_step_ramp.txt: 40 ms
+                    # of untimed epochs first, then >= 100 ms of timed ones)
                     torch.cuda.synchronize()
-                    epochs = 3
+                    r0, warm = time.perf_counter(), 0
+                    while time.perf_counter() - r0 < 0.04:
+                        t.run_epoch("controller", 0)
+                        warm += 1
+                    torch.cuda.synchronize()
+                    per_epoch = (time.perf_counter() - r0) / warm
+                    epochs = max(3, int(0.1 / per_epoch + 0.999))
+                    res["epochs_timed" if graphed else "epochs_timed_eager"] = epochs
                     t0 = time.perf_counter()
                     for e in range(epochs):
                         t.run_epoch("controller", e + 1)

@@ -38,6 +38,8 @@ with contextlib.redirect_stdout(sys.stderr):
     t.graph_epochs = epoch_graph
     if fork:
         t.gather_fork = fork
+    if os.environ.get("APG_EPOCH_NO_SHUFFLE"):   # experiment: batches of consecutive rows
+        t.trainloader.shuffle = False
     t.run_epoch("controller", 0)     # (graph_epochs: eager epoch, then the capture)
     t.run_epoch("controller", 0)
     torch.cuda.synchronize()
