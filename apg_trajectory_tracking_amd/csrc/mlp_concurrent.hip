@@ -711,7 +711,7 @@ int concurrent_train_step(
   A.c = make_const(*params, dt);
   A.w = *weights;
   A.B = B, A.ref_cols = ref_cols, A.vel_col = ref_cols == 9 ? 6 : 3;
-  A.index = nullptr, A.o_feat = A.o_in_ref = nullptr;
+  A.index = nullptr, A.o_feat = A.o_in_ref = nullptr, A.win16 = 0;
   if (rows) {
     A.index = rows->index;
     A.o_feat = acts + pFeat * plane, A.o_in_ref = acts + pInr * plane;
@@ -720,6 +720,7 @@ int concurrent_train_step(
     A.ld_state0 = rows->ld_state0, A.ld_ref = rows->ld_ref;
     const auto bytes = [&](int ld) { return (unsigned)(rows->n_rows * (long long)ld * 4); };
     A.bytes_feat = bytes(A.ld_feat), A.bytes_in_ref = bytes(A.ld_in_ref);
+    A.win16 = A.ld_in_ref % 4 == 0 && (reinterpret_cast<uintptr_t>(rows->in_ref) & 15) == 0;
     A.bytes_state0 = bytes(A.ld_state0), A.bytes_ref = bytes(A.ld_ref);
   }
   PackArgs P;

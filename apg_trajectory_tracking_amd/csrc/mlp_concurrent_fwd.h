@@ -40,23 +40,69 @@ struct ConcArgs {
   const long long *index;
   float *o_feat, *o_in_ref;
   int ld_feat, ld_in_ref, ld_state0, ld_ref;
+  int win16;   // the window rows start on 16-byte boundaries (gather_windows16_issue)
   unsigned bytes_feat, bytes_in_ref, bytes_state0, bytes_ref;
 };
 
 // ROWS: the minibatch gather folded into this kernel (VERDICT r4 next #4;
 // TrainBase.run_epoch's batch selection, scripts/train_base.py:191-194).  The
-// workgroup's rows are brought into LDS through the index (gather_rows_issue,
-// policy_mfma.h) before the operand tables - features + windows [256][15] /
-// [256][91] where the tables go afterwards, the start states [256][13] behind the
-// tables - and the reference rows [256][91] over the tables once the policy is
-// done with them, while the rollout runs.
+// workgroup's rows are brought into LDS through the index before the operand
+// tables are complete:
+//   windows  [256][92]  at the END of the table region (zWin): 23 chunks of 16
+//            bytes per row, lane-linear over (row, chunk) - 3 rows per
+//            instruction, i.e. whole cache lines (`win16`: row pitch and base
+//            are multiples of 16 bytes; else the same layout by dwords)
+//   features [256][15], start states [256][13], row numbers: behind the tables
+//   the first 32 KB of the tables (zWin floats: the small tables, states_in, conv,
+//            ten fc1 blocks) in the same batch of requests; the rest once every
+//            wave holds its rows in registers.
+// Round 6 (profiles/r06_rows_noshuffle.txt: 8 of the 13 us this kernel took over
+// the plane-reading one were its prologue, not DRAM): before, the windows were
+// staged under the WHOLE table region by 364 dword requests per workgroup and
+// read back with 4-way bank conflicts (row stride 91 was odd, but the half-waves'
+// columns 4 apart were not), and all 127 KB of tables followed the gather.
+// The reference rows [256][91] land over the tables once the policy is done with
+// them, while the rollout runs.
 constexpr int kRowPadW = kH * kRD + 1, kRowPadF = kNF, kRowPadS = 13;   // odd strides
-constexpr int zWin = 0, zFeat = kTrajPerBlock * kRowPadW,               // floats
+constexpr int kWinChunks = (kH * kRD + 3) / 4, kWinRow = 4 * kWinChunks;  // 23, 92
+constexpr int zRef = 0, zWin = kCfLds - kTrajPerBlock * kWinRow,        // floats
               zS0 = kCfLds, zRows = zS0 + kTrajPerBlock * kRowPadS,
-              kCfRowsLds = zRows + kTrajPerBlock;
-static_assert(zFeat + kTrajPerBlock * kRowPadF <= kCfLds, "staging under the tables");
+              zFeat = zRows + kTrajPerBlock,
+              kCfRowsLds = zFeat + kTrajPerBlock * kRowPadF;
+static_assert(zWin >= hA / 4 + 4 * kBlock16 / 4 && zWin % 256 == 0,
+              "states_in and conv blocks ahead of the window staging");
+static_assert(kTrajPerBlock * kRowPadW <= kCfLds, "reference rows over the tables");
 static_assert(kCfRowsLds * 4 <= 160 * 1024, "LDS");
 
+// the windows of the workgroup's 256 rows, 16 bytes per lane: element e = 64 n +
+// lane of [256][23] is chunk e % 23 of row e / 23
+__device__ __forceinline__ void gather_windows16_issue(float *dst, const int *rows,
+                                                       const float *base, unsigned bytes,
+                                                       int ld) {
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  const auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes,
+                                                   0x00020000);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves = blockDim.x >> 6;
+  for (int n = wave; n < kTrajPerBlock * kWinChunks / 64; n += waves) {
+    const int e = n * 64 + lane, t = e / kWinChunks, c = e - t * kWinChunks;
+    // (the last chunk of a row ends 2 floats past the window: the row's own next
+    // columns, or - last row of a data set whose rows are exactly the window -
+    // out of range: zeros)
+    const unsigned voff = ((unsigned)rows[t] * (unsigned)ld + 4u * (unsigned)c) * 4u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + n * 256), 16, (int)voff, 0,
+                                             0, 0);
+  }
+}
+
+// APG_CF_KNOCKOUT (experiment builds, tools/build_policy_variant.sh; results are
+// WRONG on purpose): 1 row numbers = batch positions (no index round trip), 2 no
+// wait for the second part of the tables, 4 no reference-row gather, 8 no row
+// gathers at all
+#ifndef APG_CF_KNOCKOUT
+#define APG_CF_KNOCKOUT 0
+#endif
 template <bool ROWS>
 __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -64,13 +110,20 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
     const int t = threadIdx.x, b_ = blockIdx.x * kTrajPerBlock + t;
     // (a dead trajectory reads the batch's last row: finite data, never stored)
     if (t < kTrajPerBlock)
-      reinterpret_cast<int *>(lds + zRows)[t] = (int)A.index[b_ < A.B ? b_ : A.B - 1];
+      reinterpret_cast<int *>(lds + zRows)[t] =
+          (APG_CF_KNOCKOUT & 1) ? (b_ < A.B ? b_ : A.B - 1) : (int)A.index[b_ < A.B ? b_ : A.B - 1];
     __syncthreads();
     const int *rows = reinterpret_cast<const int *>(lds + zRows);
-    gather_rows_issue<kRowPadW>(lds + zWin, rows, A.in_ref, A.bytes_in_ref, A.ld_in_ref,
-                                kH * kRD);
+    if (!(APG_CF_KNOCKOUT & 8)) {
+    if (A.win16)
+      gather_windows16_issue(lds + zWin, rows, A.in_ref, A.bytes_in_ref, A.ld_in_ref);
+    else
+      gather_rows_issue<kWinRow>(lds + zWin, rows, A.in_ref, A.bytes_in_ref, A.ld_in_ref,
+                                 kH * kRD);
     gather_rows_issue<kRowPadF>(lds + zFeat, rows, A.feat, A.bytes_feat, A.ld_feat, kNF);
     gather_rows_issue<kRowPadS>(lds + zS0, rows, A.state0, A.bytes_state0, A.ld_state0, 12);
+    }
+    fill_lds_issue(lds, A.tables, zWin);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else {
@@ -100,15 +153,27 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
   float w[kH][5];  // policy reference input, columns 0..4 / 4..8 per half
   const int tl = wave * 32 + (lane & 31);   // this lane's trajectory of the workgroup
   if (ROWS) {
-    const float *pf = lds + zFeat + tl * kRowPadF, *pw = lds + zWin + tl * kRowPadW + 4 * hi;
+    const float *pf = lds + zFeat + tl * kRowPadF;
 #pragma unroll
     for (int j = 0; j < kNF; ++j) feat[j] = pf[j];
+    // the lane's whole window row by 16-byte reads (row stride 23 chunks: 16
+    // consecutive rows start in 16 different bank quads), its half's columns
+    // picked in registers
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 *pw = reinterpret_cast<const f32x4 *>(lds + zWin + tl * kWinRow);
+    float wr[kWinRow];
+#pragma unroll
+    for (int cq = 0; cq < kWinChunks; ++cq) {
+      const f32x4 q = pw[cq];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wr[4 * cq + i] = q[i];
+    }
 #pragma unroll
     for (int r = 0; r < kH; ++r)
 #pragma unroll
-      for (int j = 0; j < 5; ++j) w[r][j] = pw[r * kRD + j];
+      for (int j = 0; j < 5; ++j) w[r][j] = hi ? wr[r * kRD + 4 + j] : wr[r * kRD + j];
     __syncthreads();                      // every wave has its rows: the tables may land
-    fill_lds_issue(lds, A.tables, kCfLds);
+    fill_lds_issue(lds + zWin, A.tables + zWin, kCfLds - zWin);
   } else {
 #pragma unroll
     for (int j = 0; j < kNF; ++j) feat[j] = Pfe.ld(vb, j * pN);
@@ -145,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
     }
   }
 
-  if (ROWS) {   // the table DMA issued above
+  if (ROWS && !(APG_CF_KNOCKOUT & 2)) {   // the table DMA issued above
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // (the reverse kernel reads the feature / window blocks of x^T from the data
@@ -272,7 +337,8 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
   if (ROWS) {
     // the tables are dead: the reference rows land over them while the rollout runs
     __syncthreads();
-    gather_rows_issue<kRowPadW>(lds + zWin, reinterpret_cast<const int *>(lds + zRows), A.ref,
+    if (!(APG_CF_KNOCKOUT & (4 | 8)))
+    gather_rows_issue<kRowPadW>(lds + zRef, reinterpret_cast<const int *>(lds + zRows), A.ref,
                                 A.bytes_ref, A.ld_ref, kH * A.ref_cols);
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = lds[zS0 + tl * kRowPadS + i];
@@ -299,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
 #pragma unroll
   for (int i = 0; i < 12; ++i) lam[i] = 0.f;
   float rp[3], rv[3];
-  const float *pr = lds + zWin + tl * kRowPadW;
+  const float *pr = lds + zRef + tl * kRowPadW;
   if (ROWS) {   // the reference rows (and every store so far) have landed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

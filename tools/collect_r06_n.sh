@@ -1,13 +1,15 @@
-# round 6: the rows-path kernels with shuffled rows and with consecutive rows (what the row
-# gather costs in DRAM line efficiency vs what its place in the kernel's prologue costs)
+# round 6 probe: rows of the next batch touched ahead (cache warm-up) - does the forward kernel's gather get cheaper?
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/r06n; mkdir -p $O
-for m in concurrent LSTM; do
-  k=lstm_rollout_fwd_kernel; [ $m = concurrent ] && k=mlp_concurrent_fwd_kernel
-  for ns in "" 1; do
-  rm -rf $O/re; APG_EPOCH_NO_SHUFFLE=$ns rocprofv3 --kernel-trace --output-format csv -d $O/re -- python tools/time_run_epoch.py $m graph 32 noprefetch > /dev/null 2>&1
-  echo "== $m no_shuffle=$ns"; python tools/trace_epoch.py $(ls $O/re/*/*kernel_trace.csv | head -1) $k 32 | grep "us/batch" | head -4
-  rm -rf $O/re
-  done
-done 2>&1 | tee $O/rows_noshuffle.txt
+for how in before beside none; do
+  timeout 120 python tools/touch_probe.py $how 2>&1 | tail -1
+  rm -rf $O/tp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/tp -- timeout 120 python tools/touch_probe.py $how > /dev/null 2>&1
+  python - $how <<'PY'
+import csv, glob, sys
+f = glob.glob("gpurun_out/r06n/tp/*/*kernel_stats.csv")[0]
+for r in list(csv.DictReader(open(f)))[:5]:
+    print("   ", sys.argv[1].ljust(8), r["Name"].replace("apg::(anonymous namespace)::", "")[:44].ljust(46), r["Calls"], round(float(r["AverageNs"]) / 1e3, 1))
+PY
+  rm -rf $O/tp
+done 2>&1 | tee $O/touch_probe.txt
