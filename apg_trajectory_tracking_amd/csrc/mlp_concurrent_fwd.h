@@ -99,7 +99,8 @@ __device__ __forceinline__ void gather_windows16_issue(float *dst, const int *ro
 // APG_CF_KNOCKOUT (experiment builds, tools/build_policy_variant.sh; results are
 // WRONG on purpose): 1 row numbers = batch positions (no index round trip), 2 no
 // wait for the second part of the tables, 4 no reference-row gather, 8 no row
-// gathers at all
+// gathers at all, 16 every workgroup reads rows 0..7 (same requests, eight rows'
+// cache lines)
 #ifndef APG_CF_KNOCKOUT
 #define APG_CF_KNOCKOUT 0
 #endif
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(kThreads) void mlp_concurrent_fwd_kernel(ConcArgs A
     // (a dead trajectory reads the batch's last row: finite data, never stored)
     if (t < kTrajPerBlock)
       reinterpret_cast<int *>(lds + zRows)[t] =
-          (APG_CF_KNOCKOUT & 1) ? (b_ < A.B ? b_ : A.B - 1) : (int)A.index[b_ < A.B ? b_ : A.B - 1];
+          (APG_CF_KNOCKOUT & 16) ? (t & 7)
+          : (APG_CF_KNOCKOUT & 1) ? (b_ < A.B ? b_ : A.B - 1) : (int)A.index[b_ < A.B ? b_ : A.B - 1];
     __syncthreads();
     const int *rows = reinterpret_cast<const int *>(lds + zRows);
     if (!(APG_CF_KNOCKOUT & 8)) {
