@@ -86,7 +86,8 @@ class ApgLstmStepTail(ctypes.Structure):
                 ("param", ApgLstmPolicyGrads), ("mom", ApgLstmPolicyGrads),
                 ("tables_fwd", ctypes.c_void_p), ("tables_bwd", ctypes.c_void_p),
                 ("loss_partials", ctypes.c_void_p), ("n_partials", ctypes.c_int),
-                ("loss", ctypes.c_void_p), ("loss_sum", ctypes.c_void_p)]
+                ("loss", ctypes.c_void_p), ("loss_sum", ctypes.c_void_p),
+                ("applied", ctypes.c_int)]
 
 
 class ApgMlpPolicy(ctypes.Structure):
@@ -206,6 +207,9 @@ SIGNATURES = {
     "apg_quad_lstm_conv_wgrad_partials_floats": [_I],
     "apg_quad_lstm_conv_wgrad": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "apg_quad_lstm_gate_wgrad_partials_floats": [_I],
+    "apg_quad_lstm_wgrads": [
+        _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicy), _P, _I, _I,
+        _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmStepTail), _P],
     "apg_quad_lstm_gate_wgrad": [
         _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(ApgLstmPolicy), _P, _I, _I,
         _P, _P, _P, _P, _P, _P],

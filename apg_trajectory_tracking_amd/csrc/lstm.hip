@@ -678,8 +678,13 @@ __global__ __launch_bounds__(kTailThreads) void lstm_step_tail_kernel(TailArgs A
   // other: 22 us for 6 516 parameters)
   constexpr int kTotal = kNC * 27 + kNC + kNG * kNX + kNG * kNH + kNG + kNG + 4 * kNH + 4;
   constexpr int kPer = (kTotal + kTailThreads - 1) / kTailThreads;
+  // the step's parameters as the pack below reads them: this workgroup's LDS (the
+  // pack read them back from global memory through ~10 dependent loads per thread:
+  // 14 us for the launch, profiles/r06_step_LSTM_timeline.txt)
+  __shared__ float sp[kTotal];
   int qs[kPer], es[kPer];
   float g[kPer], m_old[kPer], p_old[kPer];
+  const bool pack = t.tables_fwd && t.tables_bwd;
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     int e = tid + k * kTailThreads, q = 0;
@@ -702,18 +707,21 @@ __global__ __launch_bounds__(kTailThreads) void lstm_step_tail_kernel(TailArgs A
     } else {
       g[k] = grd[q][e];
     }
-    if (t.update) m_old[k] = mom[q][e], p_old[k] = par[q][e];
+    if (t.update) m_old[k] = mom[q][e];
+    if (t.update || pack) p_old[k] = par[q][e];
   }
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     const int q = qs[k], e = es[k];
     if (q < 0) continue;
     if (q == 0 || q == 2 || q == 3 || (q == 5 && grd[5] != grd[4])) grd[q][e] = g[k];
+    float p_new = p_old[k];
     if (t.update) {        // torch.optim.SGD in double, one rounding each (mlp_common.h)
       const float buf = (float)(t.momentum * (double)m_old[k] + (double)g[k]);
       mom[q][e] = buf;
-      par[q][e] = (float)((double)p_old[k] - t.lr * (double)buf);
+      par[q][e] = p_new = (float)((double)p_old[k] - t.lr * (double)buf);
     }
+    sp[tid + k * kTailThreads] = p_new;
   }
   if (t.loss) {              // fixed-shape sum of the loss partials
     __shared__ double sm[kTailThreads / 64];
@@ -730,16 +738,70 @@ __global__ __launch_bounds__(kTailThreads) void lstm_step_tail_kernel(TailArgs A
       if (t.loss_sum) *t.loss_sum += (float)tot;
     }
   }
-  if (t.tables_fwd && t.tables_bwd) {
-    __threadfence_block();
-    __syncthreads();         // every parameter of this step is written
+  if (pack) {
+    __syncthreads();         // every parameter of this step is in `sp`
     PackArgs P;
-    P.pol.conv_w = par[0], P.pol.conv_b = par[1], P.pol.w_ih = par[2], P.pol.w_hh = par[3];
-    P.pol.b_ih = par[4], P.pol.b_hh = par[5], P.pol.w_out = par[6], P.pol.b_out = par[7];
+    const float *q_ = sp;
+    const float *at[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) at[j] = q_, q_ += sizes[j];
+    P.pol.conv_w = at[0], P.pol.conv_b = at[1], P.pol.w_ih = at[2], P.pol.w_hh = at[3];
+    P.pol.b_ih = at[4], P.pol.b_hh = at[5], P.pol.w_out = at[6], P.pol.b_out = at[7];
     P.dst = t.tables_fwd;
     pack_fwd16(P, tid, kTailThreads);
     P.dst = t.tables_bwd;
     pack_bwd16(P, tid, kTailThreads);
+  }
+}
+
+// `applied` (apg_quad_lstm_wgrads finished the gradients and the update): what is
+// left of the tail - the next step's tables on as many workgroups as the pack
+// kernels use, the loss on one more
+__global__ __launch_bounds__(256) void lstm_tail_pack_kernel(TailArgs A, int fwd_blocks,
+                                                             int bwd_blocks) {
+  const ApgLstmStepTail &t = A.t;
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (blk < fwd_blocks + bwd_blocks) {
+    PackArgs P;
+    P.pol.conv_w = t.param.conv_w, P.pol.conv_b = t.param.conv_b;
+    P.pol.w_ih = t.param.w_ih, P.pol.w_hh = t.param.w_hh;
+    P.pol.b_ih = t.param.b_ih, P.pol.b_hh = t.param.b_hh;
+    P.pol.w_out = t.param.w_out, P.pol.b_out = t.param.b_out;
+    if (blk < fwd_blocks) {
+      P.dst = t.tables_fwd;
+      pack_fwd16(P, blk * 256 + tid, fwd_blocks * 256);
+    } else {
+      P.dst = t.tables_bwd;
+      pack_bwd16(P, (blk - fwd_blocks) * 256 + tid, bwd_blocks * 256);
+    }
+    return;
+  }
+  // fixed-shape sum of the loss partials (the same tree as lstm_step_tail_kernel's:
+  // 1024 strided sums, 64-lane butterflies, 16 wave sums in order)
+  __shared__ double sm[kTailThreads / 64];
+  double part[kTailThreads / 256];
+#pragma unroll
+  for (int j = 0; j < kTailThreads / 256; ++j) {
+    double acc = 0.0;
+    for (int k = tid + 256 * j; k < t.n_partials; k += kTailThreads)
+      acc += (double)t.loss_partials[k];
+    part[j] = acc;
+  }
+  // thread `tid + 256 j` of the 1024-thread form is lane tid & 63 of wave
+  // (tid >> 6) + 4 j
+#pragma unroll
+  for (int j = 0; j < kTailThreads / 256; ++j) {
+    double acc = part[j];
+#pragma unroll
+    for (int s_ = 32; s_ >= 1; s_ >>= 1) acc += __shfl_xor(acc, s_, 64);
+    if ((tid & 63) == 0) sm[(tid >> 6) + 4 * j] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < kTailThreads / 64; ++w) tot += sm[w];
+    *t.loss = (float)tot;
+    if (t.loss_sum) *t.loss_sum += (float)tot;
   }
 }
 
@@ -1356,6 +1418,24 @@ __global__ __launch_bounds__(kGwThreads) void lstm_gate_wgrad_kernel(GwArgs A) {
   else gate_wgrad_body<0>(A);
 }
 
+// The owner thread of a gradient element (the one that holds the final sum in
+// lstm_wgrad_reduce_kernel) can finish the step for it: the gradient into its
+// tensor and torch's momentum SGD (double, one rounding each: mlp_common.h) - what
+// lstm_step_tail_kernel did on ONE workgroup behind the sums (`applied`).
+struct FuseArgs {
+  int on, update;
+  double lr, momentum;
+  ApgLstmPolicyGrads grad, param, mom;
+};
+__device__ __forceinline__ void fuse_elem(const FuseArgs &U, float *grad, float *par,
+                                          float *mom, int e, float g) {
+  grad[e] = g;
+  if (!U.update) return;
+  const float buf = (float)(U.momentum * (double)mom[e] + (double)g);
+  mom[e] = buf;
+  par[e] = (float)((double)par[e] - U.lr * (double)buf);
+}
+
 // sum of the workgroups' partials (index order) into the gradients: thread
 // (part, o) adds every 8th workgroup of output o's parity, part 0 adds the eight
 struct GwReduceArgs {
@@ -1365,10 +1445,12 @@ struct GwReduceArgs {
   float *b_ih;           // [32]
   float *w_out, *b_out;  // [4][8], [4]
 };
-__global__ __launch_bounds__(256) void lstm_gate_wgrad_reduce_kernel(GwReduceArgs A) {
+template <bool FUSE>
+__device__ __forceinline__ void gate_wgrad_reduce_body(const GwReduceArgs &A, int block,
+                                                       const FuseArgs &U) {
   __shared__ float part[8][32];
   const int ol = threadIdx.x & 31, pt = threadIdx.x >> 5;
-  const int o = blockIdx.x * 32 + ol;          // < 2 kGwPart
+  const int o = block * 32 + ol;               // < 2 kGwPart
   const int ph = o / kGwPart, r = o - ph * kGwPart;
   float s = 0.f;
   for (int c = pt; c < A.chunks; c += 8) s += A.partials[(size_t)(2 * c + ph) * kGwPart + r];
@@ -1380,16 +1462,41 @@ __global__ __launch_bounds__(256) void lstm_gate_wgrad_reduce_kernel(GwReduceArg
   // element r of a partial: block n, register 4 i4 + c of lane `lane`
   const int n = r >> 10, i = 4 * ((r >> 8) & 3) + (r & 3), lane = (r >> 2) & 63;
   const int g = rrow(i) + 4 * (lane >> 5), col = lane & 31;
+  const bool fu = FUSE && U.on;
   if (n < 4) {
-    if (col < kNC) A.ih_hh[g * (kNX + kNH) + kNF + col * kNP + 4 * ph + n] = s;
+    if (col < kNC) {
+      const int x = kNF + col * kNP + 4 * ph + n;
+      A.ih_hh[g * (kNX + kNH) + x] = s;
+      if (fu) fuse_elem(U, U.grad.w_ih, U.param.w_ih, U.mom.w_ih, g * kNX + x, s);
+    }
   } else if (ph == 0) {
-    if (col < kNF) A.ih_hh[g * (kNX + kNH) + col] = s;
-    else if (col < kNF + kNH) A.ih_hh[g * (kNX + kNH) + kNX + col - kNF] = s;
-    else if (col == kNF + kNH) A.b_ih[g] = s;
+    if (col < kNF) {
+      A.ih_hh[g * (kNX + kNH) + col] = s;
+      if (fu) fuse_elem(U, U.grad.w_ih, U.param.w_ih, U.mom.w_ih, g * kNX + col, s);
+    } else if (col < kNF + kNH) {
+      A.ih_hh[g * (kNX + kNH) + kNX + col - kNF] = s;
+      if (fu)
+        fuse_elem(U, U.grad.w_hh, U.param.w_hh, U.mom.w_hh, g * kNH + col - kNF, s);
+    } else if (col == kNF + kNH) {
+      A.b_ih[g] = s;
+      if (fu) {   // lstm.bias_hh: the same sums as bias_ih (its gradient may alias it)
+        fuse_elem(U, U.grad.b_ih, U.param.b_ih, U.mom.b_ih, g, s);
+        fuse_elem(U, U.grad.b_hh, U.param.b_hh, U.mom.b_hh, g, s);
+      }
+    }
   } else if (g < 4) {
-    if (col < kNH) A.w_out[g * kNH + col] = s;
-    else if (col == kNH) A.b_out[g] = s;
+    if (col < kNH) {
+      A.w_out[g * kNH + col] = s;
+      if (fu) fuse_elem(U, U.grad.w_out, U.param.w_out, U.mom.w_out, g * kNH + col, s);
+    } else if (col == kNH) {
+      A.b_out[g] = s;
+      if (fu) fuse_elem(U, U.grad.b_out, U.param.b_out, U.mom.b_out, g, s);
+    }
   }
+}
+constexpr int kGwReduceBlocks = 2 * kGwPart / 32;
+__global__ __launch_bounds__(256) void lstm_gate_wgrad_reduce_kernel(GwReduceArgs A) {
+  gate_wgrad_reduce_body<false>(A, blockIdx.x, FuseArgs{});
 }
 
 // --------------------------------------------------- conv weight gradient
@@ -1570,8 +1677,10 @@ struct CwReduceArgs {
 // 620 of a partial's 2 048 floats are gradients (20 channels x 27 + 20 x 4): a thread
 // per (gradient, 1 of 32 slices of the workgroups), the slices added in a fixed tree
 constexpr int kCwOut = kNC * kCwTaps + kNC * 4;
-__global__ __launch_bounds__(256) void lstm_conv_wgrad_reduce_kernel(CwReduceArgs A) {
-  const int pt = threadIdx.x & 31, o = blockIdx.x * 8 + (threadIdx.x >> 5);
+template <bool FUSE>
+__device__ __forceinline__ void conv_wgrad_reduce_body(const CwReduceArgs &A, int block,
+                                                       const FuseArgs &U) {
+  const int pt = threadIdx.x & 31, o = block * 8 + (threadIdx.x >> 5);
   const bool on = o < kCwOut;
   const int oc = on ? o : 0;
   const int n = oc < kNC * kCwTaps ? 0 : 1, q = n ? oc - kNC * kCwTaps : oc;
@@ -1579,15 +1688,46 @@ __global__ __launch_bounds__(256) void lstm_conv_wgrad_reduce_kernel(CwReduceArg
   // element of a partial: block n, register i of lane `lane` with ch = r(i) + 4 hi
   const int hi = (ch >> 2) & 1, i = (ch & 3) + 4 * (ch >> 3), lane = hi * 32 + col;
   const int r = ((n * 4 + (i >> 2)) * 64 + lane) * 4 + (i & 3);
-  float s = 0.f;
+  // finishing the step here: a window weight of a position column (c < 3) also adds
+  // up its own copy of the position sum it is reduced by - the same slices in the
+  // same tree as that sum's owner, i.e. the same float
+  const bool fu = FUSE && U.on, pos = fu && n == 0 && col < 9;
+  const int r2 = ((4 + (i >> 2)) * 64 + hi * 32 + col / 3) * 4 + (i & 3);
+  float s = 0.f, s2 = 0.f;
   if (on)
-    for (int c = pt; c < A.wgs; c += 32) s += A.partials[(size_t)c * kCwPart + r];
+    for (int c = pt; c < A.wgs; c += 32) {
+      s += A.partials[(size_t)c * kCwPart + r];
+      if (pos) s2 += A.partials[(size_t)c * kCwPart + r2];
+    }
 #pragma unroll
-  for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);   // (fixed order)
+  for (int d = 16; d >= 1; d >>= 1) {   // (fixed order)
+    s += __shfl_xor(s, d, 32);
+    s2 += __shfl_xor(s2, d, 32);
+  }
   if (!on || pt) return;
-  if (n == 0) A.conv_w[ch * kCwTaps + col] = s;
-  else if (col < 3) A.conv_pos[ch * 3 + col] = s;
-  else A.conv_b[ch] = s;
+  if (n == 0) {
+    if (fu)   // (grad.conv_w may be A.conv_w: the final value is the one that stays)
+      fuse_elem(U, U.grad.conv_w, U.param.conv_w, U.mom.conv_w, ch * kCwTaps + col,
+                pos ? s - s2 : s);
+    else
+      A.conv_w[ch * kCwTaps + col] = s;
+  } else if (col < 3) {
+    A.conv_pos[ch * 3 + col] = s;
+  } else {
+    A.conv_b[ch] = s;
+    if (fu) fuse_elem(U, U.grad.conv_b, U.param.conv_b, U.mom.conv_b, ch, s);
+  }
+}
+constexpr int kCwReduceBlocks = (kCwOut + 7) / 8;
+__global__ __launch_bounds__(256) void lstm_conv_wgrad_reduce_kernel(CwReduceArgs A) {
+  conv_wgrad_reduce_body<false>(A, blockIdx.x, FuseArgs{});
+}
+// both sums in one launch (apg_quad_lstm_wgrads: the two product kernels run back to
+// back, their partials are added side by side)
+__global__ __launch_bounds__(256) void lstm_wgrad_reduce_kernel(GwReduceArgs G, CwReduceArgs C,
+                                                                FuseArgs U) {
+  if ((int)blockIdx.x < kGwReduceBlocks) gate_wgrad_reduce_body<true>(G, blockIdx.x, U);
+  else conv_wgrad_reduce_body<true>(C, blockIdx.x - kGwReduceBlocks, U);
 }
 
 // pol NULL: the caller holds packed tables instead of the parameters
@@ -1847,12 +1987,16 @@ int apg_quad_lstm_gate_wgrad_partials_floats(int B) {
   return B <= 0 ? 0 : gw_blocks(B) * kGwPart;
 }
 
-int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const float *in_ref,
-                             const float *acts, const float *d_gates, const float *d_zout,
-                             const float *cot_amax, const ApgLstmPolicy *policy,
-                             float *tables_fwd, int B, int H,
-                             float *partials, float *ih_hh, float *b_ih, float *w_out,
-                             float *b_out, apg_stream_t stream) {
+// `defer`: the sum of the partials is left to the caller (its arguments are handed
+// back, chunks 0: nothing to add up)
+static int gate_wgrad_impl(const float *state0, const float *states, const float *in_ref,
+                           const float *acts, const float *d_gates, const float *d_zout,
+                           const float *cot_amax, const ApgLstmPolicy *policy,
+                           float *tables_fwd, int B, int H,
+                           float *partials, float *ih_hh, float *b_ih, float *w_out,
+                           float *b_out, apg_stream_t stream, apg::GwReduceArgs *defer) {
+  using namespace apg;
+  if (defer) defer->chunks = 0;
   if (H != kH) {
     set_error("the fused LSTM rollout is built for horizon %d (got %d)", kH, H);
     return APG_ERR_ARG;
@@ -1912,8 +2056,20 @@ int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const flo
   GwReduceArgs R;
   R.partials = partials, R.chunks = blocks / 2;
   R.ih_hh = ih_hh, R.b_ih = b_ih, R.w_out = w_out, R.b_out = b_out;
-  hipLaunchKernelGGL(lstm_gate_wgrad_reduce_kernel, dim3(2 * kGwPart / 32), dim3(256), 0, st, R);
+  if (defer) { *defer = R; return APG_OK; }
+  hipLaunchKernelGGL(lstm_gate_wgrad_reduce_kernel, dim3(kGwReduceBlocks), dim3(256), 0, st, R);
   return check_launch("quad_lstm_gate_wgrad_reduce");
+}
+
+int apg_quad_lstm_gate_wgrad(const float *state0, const float *states, const float *in_ref,
+                             const float *acts, const float *d_gates, const float *d_zout,
+                             const float *cot_amax, const ApgLstmPolicy *policy,
+                             float *tables_fwd, int B, int H,
+                             float *partials, float *ih_hh, float *b_ih, float *w_out,
+                             float *b_out, apg_stream_t stream) {
+  return gate_wgrad_impl(state0, states, in_ref, acts, d_gates, d_zout, cot_amax, policy,
+                         tables_fwd, B, H, partials, ih_hh, b_ih, w_out, b_out, stream,
+                         nullptr);
 }
 
 int apg_quad_lstm_rollout_fwd_rows(const ApgBatchRows *rows, const float *h0, const float *c0,
@@ -1947,9 +2103,11 @@ int apg_quad_lstm_conv_wgrad_partials_floats(int B) {
   return B <= 0 ? 0 : ((B + 32 * kCwWaves - 1) / (32 * kCwWaves)) * kCwPart;
 }
 
-int apg_quad_lstm_conv_wgrad(const float *d_conv, const float *in_ref, const float *st_all, int B,
-                             int H, float *partials, float *conv_w, float *conv_pos,
-                             float *conv_b, apg_stream_t stream) {
+static int conv_wgrad_impl(const float *d_conv, const float *in_ref, const float *st_all, int B,
+                           int H, float *partials, float *conv_w, float *conv_pos,
+                           float *conv_b, apg_stream_t stream, apg::CwReduceArgs *defer) {
+  using namespace apg;
+  if (defer) defer->wgs = 0;
   if (H != kH) {
     set_error("the fused LSTM rollout is built for horizon %d (got %d)", kH, H);
     return APG_ERR_ARG;
@@ -1993,8 +2151,68 @@ int apg_quad_lstm_conv_wgrad(const float *d_conv, const float *in_ref, const flo
   CwReduceArgs R;
   R.partials = partials, R.wgs = wgs;
   R.conv_w = conv_w, R.conv_pos = conv_pos, R.conv_b = conv_b;
-  hipLaunchKernelGGL(lstm_conv_wgrad_reduce_kernel, dim3((kCwOut + 7) / 8), dim3(256), 0, st, R);
+  if (defer) { *defer = R; return APG_OK; }
+  hipLaunchKernelGGL(lstm_conv_wgrad_reduce_kernel, dim3(kCwReduceBlocks), dim3(256), 0, st, R);
   return check_launch("quad_lstm_conv_wgrad_reduce");
+}
+
+int apg_quad_lstm_conv_wgrad(const float *d_conv, const float *in_ref, const float *st_all, int B,
+                             int H, float *partials, float *conv_w, float *conv_pos,
+                             float *conv_b, apg_stream_t stream) {
+  return conv_wgrad_impl(d_conv, in_ref, st_all, B, H, partials, conv_w, conv_pos, conv_b, stream,
+                         nullptr);
+}
+
+int apg_quad_lstm_wgrads(const float *state0, const float *states, const float *in_ref,
+                         const float *acts, const float *d_gates, const float *d_zout,
+                         const float *cot_amax, const float *d_conv, const float *st_all,
+                         const ApgLstmPolicy *policy, float *tables_fwd, int B, int H,
+                         float *gate_partials, float *conv_partials, float *ih_hh, float *b_ih,
+                         float *w_out, float *b_out, float *conv_w, float *conv_pos,
+                         float *conv_b, const ApgLstmStepTail *finish, apg_stream_t stream) {
+  using namespace apg;
+  GwReduceArgs G;
+  CwReduceArgs C;
+  FuseArgs U;
+  U.on = U.update = 0, U.lr = U.momentum = 0.0;
+  U.grad = U.param = U.mom = ApgLstmPolicyGrads{};
+  if (finish) {
+    const ApgLstmStepTail &t = *finish;
+    const float *const need[] = {t.grad.conv_w, t.grad.conv_b, t.grad.w_ih, t.grad.w_hh,
+                                 t.grad.b_ih,   t.grad.b_hh,   t.grad.w_out, t.grad.b_out};
+    for (const float *q : need)
+      if (!q) { set_error("apg_quad_lstm_wgrads: finish: NULL gradient tensor"); return APG_ERR_ARG; }
+    if (t.update) {
+      const float *const pm[] = {t.param.conv_w, t.param.conv_b, t.param.w_ih, t.param.w_hh,
+                                 t.param.b_ih,   t.param.b_hh,   t.param.w_out, t.param.b_out,
+                                 t.mom.conv_w,   t.mom.conv_b,   t.mom.w_ih,   t.mom.w_hh,
+                                 t.mom.b_ih,     t.mom.b_hh,     t.mom.w_out,  t.mom.b_out};
+      for (const float *q : pm)
+        if (!q) {
+          set_error("apg_quad_lstm_wgrads: finish: NULL parameter / momentum buffer");
+          return APG_ERR_ARG;
+        }
+    }
+    U.on = 1, U.update = t.update != 0, U.lr = t.lr, U.momentum = t.momentum;
+    U.grad = t.grad, U.param = t.param, U.mom = t.mom;
+  }
+  if (int e = gate_wgrad_impl(state0, states, in_ref, acts, d_gates, d_zout, cot_amax, policy,
+                              tables_fwd, B, H, gate_partials, ih_hh, b_ih, w_out, b_out, stream,
+                              &G))
+    return e;
+  if (int e = conv_wgrad_impl(d_conv, in_ref, st_all, B, H, conv_partials, conv_w, conv_pos,
+                              conv_b, stream, &C))
+    return e;
+  if (!G.chunks || !C.wgs) {                   // (B = 0: the gradients were zeroed)
+    if (finish) {
+      set_error("apg_quad_lstm_wgrads: finish needs B > 0");
+      return APG_ERR_ARG;
+    }
+    return APG_OK;
+  }
+  hipLaunchKernelGGL(lstm_wgrad_reduce_kernel, dim3(kGwReduceBlocks + kCwReduceBlocks), dim3(256),
+                     0, (hipStream_t)stream, G, C, U);
+  return check_launch("quad_lstm_wgrad_reduce");
 }
 
 int apg_quad_lstm_tables_floats(int reverse) { return reverse ? kBwd16Lds : kFwd16Lds; }
@@ -2026,7 +2244,10 @@ int apg_quad_lstm_step_tail(const ApgLstmStepTail *tail, apg_stream_t stream) {
                                t.grad.b_ih, t.grad.b_hh, t.grad.w_out, t.grad.b_out,
                                t.ih_hh, t.conv_pos};
   for (const float *q : need)
-    if (!q) { set_error("apg_quad_lstm_step_tail: NULL gradient buffer"); return APG_ERR_ARG; }
+    if (!q && !t.applied) {
+      set_error("apg_quad_lstm_step_tail: NULL gradient buffer");
+      return APG_ERR_ARG;
+    }
   if (t.update || t.tables_fwd || t.tables_bwd) {
     const float *const pm[] = {t.param.conv_w, t.param.conv_b, t.param.w_ih, t.param.w_hh,
                                t.param.b_ih, t.param.b_hh, t.param.w_out, t.param.b_out};
@@ -2049,6 +2270,16 @@ int apg_quad_lstm_step_tail(const ApgLstmStepTail *tail, apg_stream_t stream) {
   }
   TailArgs A;
   A.t = t;
+  if (t.applied) {
+    const bool pack = t.tables_fwd != nullptr;
+    const int fwd_blocks = pack ? (kFwd16Lds + 255) / 256 : 0;
+    const int bwd_blocks = pack ? (kBwd16Lds + 255) / 256 : 0;
+    const int blocks = fwd_blocks + bwd_blocks + (t.loss ? 1 : 0);
+    if (!blocks) return APG_OK;
+    hipLaunchKernelGGL(lstm_tail_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       A, fwd_blocks, bwd_blocks);
+    return check_launch("quad_lstm_step_tail(applied)");
+  }
   hipLaunchKernelGGL(lstm_step_tail_kernel, dim3(1), dim3(kTailThreads), 0, (hipStream_t)stream,
                      A);
   return check_launch("quad_lstm_step_tail");

@@ -1148,7 +1148,7 @@ class _QuadLstmRolloutLoss(torch.autograd.Function):
               reverse sweep runs right away - the loss only exists after it).
     backward: turns the saved per-(step, trajectory) cotangent planes into the
               parameter gradients with two trajectory-major kernels
-              (apg_quad_lstm_gate_wgrad, apg_quad_lstm_conv_wgrad; round 6).
+              (apg_quad_lstm_wgrads = apg_quad_lstm_gate_wgrad + apg_quad_lstm_conv_wgrad; round 6).
     Inputs are the reference's tensors: state0 [B,12], in_ref [B,2H,9],
     ref [B,>=H,9], h0 / c0 [B,8] and the LSTM_NEW parameters."""
 
@@ -1370,42 +1370,47 @@ def _lstm_param_grads(saved, dims, tail=None):
                           device=dev)
     scratch = torch.empty(max(1, lib().apg_quad_lstm_gate_wgrad_partials_floats(B)),
                           dtype=torch.float32, device=dev)
-    check(lib().apg_quad_lstm_gate_wgrad(
-        ptr(st_all[:12]), ptr(st_all[12:]), ptr(refbuf[:2 * H * 9]), ptr(acts),
-        ptr(d_gates), ptr(d_zout), ptr(cot_amax), pol, ptr(tab), B, H, ptr(scratch),
-        ptr(ih_hh),
-        ptr(gr["lstm.bias_ih"]), ptr(gr["fc_out.weight"]), ptr(gr["fc_out.bias"]),
-        stream_of(acts)), "apg_quad_lstm_gate_wgrad")
     # the conv weights' gradient from the diagonal sums: one kernel over the planes
-    # (round 6; rounds 3-5: two segmented planes_gemm products, _conv_diag_problems)
+    # (round 6; rounds 3-5: two segmented planes_gemm products, _conv_diag_problems);
+    # both products' partials are added up by one launch (apg_quad_lstm_wgrads)
     conv_pos = torch.empty(20, 3, dtype=torch.float32, device=dev)
     scratch_c = torch.empty(max(1, lib().apg_quad_lstm_conv_wgrad_partials_floats(B)),
                             dtype=torch.float32, device=dev)
-    check(lib().apg_quad_lstm_conv_wgrad(
-        ptr(d_conv), ptr(refbuf[:2 * H * 9]), ptr(st_all), B, H, ptr(scratch_c),
-        ptr(gr["conv_ref.weight"]), ptr(conv_pos), ptr(gr["conv_ref.bias"]),
-        stream_of(acts)), "apg_quad_lstm_conv_wgrad")
     gr["lstm.bias_hh"] = gr["lstm.bias_ih"]
+    t = None
+    if tail is not None:
+        # the step's tail: with B > 0 the threads that hold the gradients' final sums
+        # put them in place and apply the update themselves (`finish`), and what is
+        # left for apg_quad_lstm_step_tail is the tables and the loss
+        partials, loss, pw, tables, update = tail
+        G = _capi.ApgLstmPolicyGrads
+        names = dict(zip(("conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out",
+                          "b_out"), _LSTM_PARAMS))
+        t = _capi.ApgLstmStepTail(
+            grad=G(**{c: ptr(gr[n]) for c, n in names.items()}),
+            ih_hh=ptr(ih_hh), conv_pos=ptr(conv_pos), update=int(update is not None),
+            param=G(**{c: ptr(pw[c]) for c in names}),
+            tables_fwd=ptr(tables.fwd), tables_bwd=ptr(tables.bwd),
+            loss_partials=ptr(partials), n_partials=partials.numel(), loss=ptr(loss),
+            applied=int(B > 0))
+        if update is not None:
+            lr, momentum, bufs = update
+            t.lr, t.momentum = float(lr), float(momentum)
+            t.mom = G(**{c: ptr(bufs[n]) for c, n in names.items()})
+    check(lib().apg_quad_lstm_wgrads(
+        ptr(st_all[:12]), ptr(st_all[12:]), ptr(refbuf[:2 * H * 9]), ptr(acts),
+        ptr(d_gates), ptr(d_zout), ptr(cot_amax), ptr(d_conv), ptr(st_all), pol, ptr(tab),
+        B, H, ptr(scratch), ptr(scratch_c), ptr(ih_hh),
+        ptr(gr["lstm.bias_ih"]), ptr(gr["fc_out.weight"]), ptr(gr["fc_out.bias"]),
+        ptr(gr["conv_ref.weight"]), ptr(conv_pos), ptr(gr["conv_ref.bias"]),
+        ctypes.byref(t) if t is not None and t.applied else None,
+        stream_of(acts)), "apg_quad_lstm_wgrads")
     if tail is None:
         gr["conv_ref.weight"][:, :3].sub_(conv_pos[:, :, None])
         # contiguous per-parameter gradients (the fused optimizer path wants them)
         gr["lstm.weight_ih"].copy_(ih_hh[:, :175])
         gr["lstm.weight_hh"].copy_(ih_hh[:, 175:])
         return flat, gr
-    partials, loss, pw, tables, update = tail
-    G = _capi.ApgLstmPolicyGrads
-    names = dict(zip(("conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out"),
-                     _LSTM_PARAMS))
-    t = _capi.ApgLstmStepTail(
-        grad=G(**{c: ptr(gr[n]) for c, n in names.items()}),
-        ih_hh=ptr(ih_hh), conv_pos=ptr(conv_pos), update=int(update is not None),
-        param=G(**{c: ptr(pw[c]) for c in names}),
-        tables_fwd=ptr(tables.fwd), tables_bwd=ptr(tables.bwd),
-        loss_partials=ptr(partials), n_partials=partials.numel(), loss=ptr(loss))
-    if update is not None:
-        lr, momentum, bufs = update
-        t.lr, t.momentum = float(lr), float(momentum)
-        t.mom = G(**{c: ptr(bufs[n]) for c, n in names.items()})
     check(lib().apg_quad_lstm_step_tail(ctypes.byref(t), stream_of(acts)),
           "apg_quad_lstm_step_tail")
     params8 = [pw[c] for c in names]

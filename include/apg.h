@@ -343,6 +343,28 @@ int apg_quad_lstm_conv_wgrad(const float *d_conv, const float *in_ref, const flo
                              int H, float *partials, float *conv_w, float *conv_pos,
                              float *conv_b, apg_stream_t stream);
 
+/* Both weight-gradient products of the LSTM unroll with ONE sum launch behind them
+ * (what the training step calls): apg_quad_lstm_gate_wgrad's and
+ * apg_quad_lstm_conv_wgrad's product kernels back to back, then one kernel that
+ * adds up both sets of partials side by side (the same fixed orders: results are
+ * bit-identical to the two calls).  Arguments as there; gate_partials /
+ * conv_partials: the two scratch buffers.
+ *   finish (or NULL): the step's ApgLstmStepTail (declared below).  The thread
+ *   that holds a gradient element's final sum then finishes the step for it: the
+ *   element into finish->grad (conv_ref.weight minus its position part,
+ *   lstm.weight_ih / weight_hh as their own tensors, bias_hh = bias_ih's) and - if
+ *   finish->update - momentum SGD on its parameter, the arithmetic of
+ *   apg_quad_lstm_step_tail; call that with `applied = 1` afterwards. */
+struct ApgLstmStepTail;
+int apg_quad_lstm_wgrads(const float *state0, const float *states, const float *in_ref,
+                         const float *acts, const float *d_gates, const float *d_zout,
+                         const float *cot_amax, const float *d_conv, const float *st_all,
+                         const ApgLstmPolicy *policy, float *tables_fwd, int B, int H,
+                         float *gate_partials, float *conv_partials, float *ih_hh, float *b_ih,
+                         float *w_out, float *b_out, float *conv_w, float *conv_pos,
+                         float *conv_b, const struct ApgLstmStepTail *finish,
+                         apg_stream_t stream);
+
 /* The LSTM training step without its small launches (round 6; the loop body of
  * scripts/train_base.py:198-214 for train_mode "LSTM": loss.backward() +
  * optimizer.step()).  The operand tables of the two sweeps live in caller-owned
@@ -393,6 +415,10 @@ typedef struct ApgLstmStepTail {
   const float *loss_partials;
   int n_partials;
   float *loss, *loss_sum;
+  /* 1: apg_quad_lstm_wgrads(finish = this) already put the gradients in place and
+   * applied the update: the tail packs the tables and sums the loss, nothing else
+   * (on ~60 workgroups instead of one) */
+  int applied;
 } ApgLstmStepTail;
 int apg_quad_lstm_step_tail(const ApgLstmStepTail *tail, apg_stream_t stream);
 

@@ -7,6 +7,7 @@
     neural_control/drone_loss.py:72-82);
   * `python bench.py --gpus N` as a plain command on a box with fewer GPUs:
     an explicit error, not a hang."""
+import ctypes
 import copy
 import os
 import subprocess
@@ -397,6 +398,33 @@ def test_lstm_gate_weight_gradients_recompute_the_conv_inputs(dev, B):
     for k, w in want.items():
         scale = w.abs().max().item() + 1e-300
         assert (gr[k].double() - w).abs().max().item() / scale < 2e-6, k
+    # apg_quad_lstm_wgrads (what _lstm_param_grads calls: both products, one sum
+    # launch) against the two entry points with a sum launch each: bit for bit
+    from apg_trajectory_tracking_amd._capi import ApgLstmPolicy, check, lib, ptr, stream_of
+    pw8 = dict(zip(("conv_w", "conv_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out"),
+                   ctx.saved_tensors[6:14]))
+    pol = ctypes.byref(ApgLstmPolicy(**{k: ptr(v) for k, v in pw8.items()}))
+    new = lambda *shape: torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
+    tab = new(lib().apg_quad_lstm_workspace_floats())
+    st = refbuf[2 * H * 9:]
+    ih_hh, b_ih, w_out, b_out = new(32, 183), new(32), new(4, 8), new(4)
+    conv_w, conv_pos, conv_b = new(20, 27), new(20, 3), new(20)
+    check(lib().apg_quad_lstm_gate_wgrad(
+        ptr(st[:12]), ptr(st[12:]), ptr(refbuf[:2 * H * 9]), ptr(acts), ptr(d_gates),
+        ptr(d_zout), ptr(cot_amax), pol, ptr(tab), B, H,
+        ptr(new(max(1, lib().apg_quad_lstm_gate_wgrad_partials_floats(B)))),
+        ptr(ih_hh), ptr(b_ih), ptr(w_out), ptr(b_out), stream_of(acts)), "gate_wgrad")
+    check(lib().apg_quad_lstm_conv_wgrad(
+        ptr(ctx.saved_tensors[4]), ptr(refbuf[:2 * H * 9]), ptr(st), B, H,
+        ptr(new(max(1, lib().apg_quad_lstm_conv_wgrad_partials_floats(B)))),
+        ptr(conv_w), ptr(conv_pos), ptr(conv_b), stream_of(acts)), "conv_wgrad")
+    assert torch.equal(ih_hh[:, :175], gr["lstm.weight_ih"])
+    assert torch.equal(ih_hh[:, 175:], gr["lstm.weight_hh"])
+    assert torch.equal(b_ih, gr["lstm.bias_ih"]) and torch.equal(b_out, gr["fc_out.bias"])
+    assert torch.equal(w_out, gr["fc_out.weight"]) and torch.equal(conv_b, gr["conv_ref.bias"])
+    cw = conv_w.view(20, 9, 3).clone()
+    cw[:, :3] -= conv_pos[:, :, None]
+    assert torch.equal(cw, gr["conv_ref.weight"])
 
 
 @pytest.mark.parametrize("B,ref_cols", [(1000, 9), (129, 6), (4096, 9)])
