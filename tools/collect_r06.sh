@@ -27,10 +27,17 @@ for m in concurrent autoregressive LSTM; do
   rocprofv3 --kernel-trace --output-format csv -d $O/re -- python tools/time_run_epoch.py $m graph 8 > /dev/null 2>&1
   python tools/trace_step.py $(ls $O/re/*/*kernel_trace.csv | head -1) $k > $O/run_epoch_${m}_timeline.txt; rm -rf $O/re
 done
-# 6. PMC of the concurrent and the autoregressive step at this commit (counters only)
+# 5b. whole epochs: per-batch kernel sums, idle gaps, what stands between two epochs
+for m in concurrent LSTM; do
+  k=mlp_concurrent_fwd_kernel; [ $m = LSTM ] && k=lstm_rollout_fwd_kernel
+  rocprofv3 --kernel-trace --output-format csv -d $O/re -- python tools/time_run_epoch.py $m graph 32 > /dev/null 2>&1
+  python tools/trace_epoch.py $(ls $O/re/*/*kernel_trace.csv | head -1) $k 32 > $O/epoch_${m}.txt; rm -rf $O/re
+done
+# 6. PMC of the three steps at this commit (counters only)
 bash tools/pmc_step.sh concurrent $O/pmc_conc > $O/pmc_conc.log 2>&1; cp $O/pmc_conc/report.txt $O/pmc_concurrent_step.txt
 bash tools/pmc_step.sh autoregressive $O/pmc_ar > $O/pmc_ar.log 2>&1; cp $O/pmc_ar/report.txt $O/pmc_ar_step.txt
-rm -rf $O/pmc_conc $O/pmc_ar
+bash tools/pmc_step.sh LSTM $O/pmc_lstm > $O/pmc_lstm.log 2>&1; cp $O/pmc_lstm/report.txt $O/pmc_lstm_step.txt
+rm -rf $O/pmc_conc $O/pmc_ar $O/pmc_lstm
 # 7. the GPU suite with the arbiter's statistics
 python -m pytest tests -m gpu -q -s > $O/pytest_all.log 2>&1; echo "rc_all=$?" >> $O/pytest_all.log
 grep "fp64 arbiter\|row arbiter" $O/pytest_all.log > $O/arbiter.txt

@@ -21,7 +21,9 @@ B, H, dt = 65536, 10, 0.1
 mode = sys.argv[1] if len(sys.argv) > 1 else "concurrent"
 graph = not (len(sys.argv) > 2 and sys.argv[2] == "eager")
 nb = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-prefetch = not (len(sys.argv) > 4 and sys.argv[4] == "noprefetch")
+# (the trainer's own default unless asked for: `prefetch` forces the gather pipeline
+# one batch ahead, which the LSTM / autoregressive rows paths replaced in round 6)
+prefetch = {"prefetch": True, "noprefetch": False}.get(sys.argv[4] if len(sys.argv) > 4 else "")
 epoch_graph = not (len(sys.argv) > 5 and sys.argv[5] == "noepoch")
 fork = sys.argv[6] if len(sys.argv) > 6 else None
 cfg = dict(delta_t=dt, delta_t_train=dt, epoch_size=nb * B, self_play=0, batch_size=B,
@@ -34,7 +36,8 @@ torch.manual_seed(0)
 with contextlib.redirect_stdout(sys.stderr):
     t.initialize_model(device=dev, seed=0)
     t.graph_steps = graph
-    t.prefetch_batches = prefetch
+    if prefetch is not None:
+        t.prefetch_batches = prefetch
     t.graph_epochs = epoch_graph
     if fork:
         t.gather_fork = fork
@@ -49,6 +52,6 @@ with contextlib.redirect_stdout(sys.stderr):
         t.run_epoch("controller", e + 1)
     torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / (epochs * nb) * 1e3
-print(f'{{"mode": "{mode}", "graphed": {str(graph).lower()}, "prefetch": {str(prefetch).lower()}, "epoch_graph": {str(epoch_graph and graph).lower()}, "batches_per_epoch": {nb}, '
+print(f'{{"mode": "{mode}", "graphed": {str(graph).lower()}, "prefetch": {str(bool(t.prefetch_batches)).lower()}, "epoch_graph": {str(epoch_graph and graph).lower()}, "batches_per_epoch": {nb}, '
       f'"gather_fork": "{t.gather_fork}", "ms_per_batch": {ms:.4f}, '
       f'"epoch_loop": "{t.last_epoch_loop}", "launch_form": "{t.launch_form.get(mode)}"}}')
