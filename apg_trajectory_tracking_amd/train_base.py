@@ -585,17 +585,19 @@ class TrainBase:
         if not (bool(self.graph_steps) and not self._in_epoch_capture
                 and (torch.cuda.is_available() or self.graph_emulation)):
             return False
+        # (a step whose kernels outlast the host's launch work may run faster in
+        # stream order: measured once, see launch_form.  Asked first: a step in
+        # stream order calls this three times, and the checks below walk the
+        # optimizer's state)
+        if self.launch_form.get(self.train_mode) == "eager":
+            return False
         # (a replayed graph runs no Python: step hooks would be skipped, and a
         # capture's warm-up steps would call them for steps that are undone)
         if self._step_hooks():
             return False
         # (the warm-up steps of a capture are undone by zeroing the state they
         # created: only where zero state IS fresh state)
-        if not _zero_state_is_fresh_state(self.optimizer_controller):
-            return False
-        # (a step whose kernels outlast the host's launch work may run faster in
-        # stream order: measured once, see launch_form)
-        return self.launch_form.get(self.train_mode) != "eager"
+        return _zero_state_is_fresh_state(self.optimizer_controller)
 
     def _reducing(self):
         """The step has an all-reduce slot (real or, when forced, empty)."""

@@ -979,18 +979,35 @@ def wing_eval_secondary(args, dev):
 
 # ----------------------------------------------------------------------------
 # Rank plumbing shared by the real run and --dry-run-cpu
-def _event_ms(fn, n, warm=3):
+def _event_ms(fn, n, warm=3, reps=3):
+    """ms per call of `fn`: the median of `reps` event-timed runs of `n` calls.
+    The interpreter's garbage is collected BEFORE the runs and not during them: a
+    full collection (~70 ms with torch loaded) that trips inside a 30-call run of a
+    host-launched step is 2 ms "per step" (round 6's last full run: the fixed-wing
+    step 2.58 ms instead of 0.37; `timed_steps` has collected up front since
+    round 5)."""
+    import gc
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        runs = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            runs.append(e0.elapsed_time(e1) / n)
+    finally:
+        if was_enabled:
+            gc.enable()
+    return sorted(runs)[len(runs) // 2]
 
 
 def more_secondaries(args, dev):

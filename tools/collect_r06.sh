@@ -25,7 +25,7 @@ for m in concurrent autoregressive LSTM; do
   python tools/time_run_epoch.py $m eager 32 >> $O/run_epoch.jsonl 2>/dev/null
   k=mlp_concurrent_fwd_kernel; [ $m = autoregressive ] && k=mlp_rollout_fwd_kernel; [ $m = LSTM ] && k=lstm_rollout_fwd_kernel
   rocprofv3 --kernel-trace --output-format csv -d $O/re -- python tools/time_run_epoch.py $m graph 8 > /dev/null 2>&1
-  python tools/trace_step.py $(ls $O/re/*/*kernel_trace.csv | head -1) $k > $O/run_epoch_${m}_timeline.txt; rm -rf $O/re
+  python tools/trace_step.py $(ls $O/re/*/*kernel_trace.csv | head -1) $k 4 > $O/run_epoch_${m}_timeline.txt; rm -rf $O/re
 done
 # 5b. whole epochs: per-batch kernel sums, idle gaps, what stands between two epochs
 for m in concurrent LSTM; do
