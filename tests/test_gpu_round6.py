@@ -427,6 +427,32 @@ def test_lstm_gate_weight_gradients_recompute_the_conv_inputs(dev, B):
     assert torch.equal(cw, gr["conv_ref.weight"])
 
 
+def test_lstm_wgrads_finish_argument_checks(dev):
+    """apg_quad_lstm_wgrads(finish = ...): the tensors the sum launch would write
+    are checked before anything is launched - gradients always, parameters and
+    momentum buffers when the update is asked for; a finish with B = 0 is an
+    error (nothing would be summed, the caller's tail would never run)."""
+    from apg_trajectory_tracking_amd import _capi
+    from apg_trajectory_tracking_amd._capi import lib, ptr
+    G = _capi.ApgLstmPolicyGrads
+    buf = torch.zeros(8192, device=dev)
+    full = G(**{n: ptr(buf) for n, _ in G._fields_})
+    part = G(**{n: ptr(buf) for n, _ in G._fields_ if n != "w_hh"})
+    call = lambda t, B=64: lib().apg_quad_lstm_wgrads(
+        *([None] * 9), None, None, B, 10, *([None] * 9), ctypes.byref(t), None)
+    err = lambda: lib().apg_last_error_string().decode()
+    assert call(_capi.ApgLstmStepTail(grad=part)) != 0 and "gradient" in err()
+    assert call(_capi.ApgLstmStepTail(grad=full, update=1, param=full)) != 0
+    assert "momentum" in err()
+    # complete finish, B = 0: the products zero the gradients, nothing to finish
+    t = _capi.ApgLstmStepTail(grad=full, update=1, param=full, mom=full)
+    out = [torch.zeros(32 * 183, device=dev) for _ in range(7)]
+    rc = lib().apg_quad_lstm_wgrads(
+        *([None] * 9), None, None, 0, 10, None, None, *[ptr(o) for o in out],
+        ctypes.byref(t), None)
+    assert rc != 0 and "B > 0" in err()
+
+
 @pytest.mark.parametrize("B,ref_cols", [(1000, 9), (129, 6), (4096, 9)])
 def test_lstm_sweeps_read_the_batch_rows_through_the_index(dev, B, ref_cols):
     """TrainBase.run_epoch's batch selection (scripts/train_base.py:191-194:
