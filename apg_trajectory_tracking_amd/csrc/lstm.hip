@@ -176,6 +176,12 @@ struct FwdArgs {
 // the window is a view of the batch and the relative-position subtraction
 // writes through it: every step shifts the rows its window holds AGAIN
 // (SURVEY.md 8a A4 `legacy_inplace_ref`; the pinned semantics copy the window)
+// APG_LF_KNOCKOUT (experiment builds only, results WRONG on purpose): 1 the rows
+// sweep does not store the state0 / in_ref planes its followers read, 2 its row
+// numbers are the batch positions (consecutive rows, no index load)
+#ifndef APG_LF_KNOCKOUT
+#define APG_LF_KNOCKOUT 0
+#endif
 template <bool ROWS, bool LEGACY = false>
 __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
   const Planes Rin(A.r_in_ref, 1, ROWS ? A.bytes_in_ref : 0u);
   unsigned vr_s = kDead, vr_in = kDead;
   if (ROWS && live) {
-    const unsigned rown = (unsigned)A.index[b];
+    const unsigned rown = (APG_LF_KNOCKOUT & 2) ? (unsigned)b : (unsigned)A.index[b];
     vr_s = rown * (unsigned)A.ld_state0 * 4u;
     vr_in = rown * (unsigned)A.ld_in_ref * 4u + (hi ? 16u : 0u);   // column + 4 hi
   }
@@ -224,8 +230,9 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = f[j];
     v[4] = Rin.ld(vr_in, (r * kRD + 4) * 4);
+    if (!(APG_LF_KNOCKOUT & 1))
 #pragma unroll
-    for (int j = 0; j < 5; ++j) Pin.st(hi && j == 0 ? kDead : vb_u, (r * kRD + j) * pB, v[j]);
+      for (int j = 0; j < 5; ++j) Pin.st(hi && j == 0 ? kDead : vb_u, (r * kRD + j) * pB, v[j]);
   };
   float s[12], h[4], cell[4];
 #pragma unroll
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void lstm_rollout_fwd_kernel(FwdArgs A) {
       s[i] = f[0], s[i + 1] = f[1], s[i + 2] = f[2], s[i + 3] = f[3];
     }
   }
-  if (ROWS)
+  if (ROWS && !(APG_LF_KNOCKOUT & 1))
 #pragma unroll
     for (int i = 0; i < 12; ++i) Ps0.st(vb_lo, i * pitchB, s[i]);
 #pragma unroll
