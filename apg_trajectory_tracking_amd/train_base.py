@@ -765,8 +765,14 @@ class TrainBase:
             # and lost.  Untimed replays take the ramp, then the two forms are
             # timed alternately, twice, and each keeps its better time)
             replay = lambda: g(borrow=True)
-            t0 = time.perf_counter()
-            while time.perf_counter() - t0 < 0.03:
+            # (30 ms worth, counted from one timed run - and the same count on
+            # every rank: a multi-rank step holds an all-reduce)
+            warm = int(0.03 / max(timed(replay), 1e-6)) + 1
+            if parallel.world_size() > 1:
+                agreed = torch.tensor([warm], dtype=torch.int64, device=params[0].device)
+                parallel.dist.all_reduce(agreed, op=parallel.dist.ReduceOp.MAX)
+                warm = int(agreed.item())
+            for _ in range(min(warm, 100 * n)):
                 replay()
             t_graph = t_eager = float("inf")
             for _ in range(2):

@@ -377,6 +377,20 @@ def timed_steps(step, n, dist, ramp_ms=40.0):
     on a device at its working clocks, as a step inside an epoch does."""
     for _ in range(3):
         out = step()
+    # how many steps `ramp_ms` are: from ten timed ones, and the SAME count on
+    # every rank (the largest) - a step of a multi-rank run holds an all-reduce,
+    # ranks that ran different numbers of them would wait for each other forever
+    torch.cuda.synchronize()
+    r0 = time.perf_counter()
+    for _ in range(10):
+        out = step()
+    torch.cuda.synchronize()
+    ramp = int(ramp_ms * 1e-3 / max((time.perf_counter() - r0) / 10, 1e-6)) + 1
+    if dist is not None:
+        agreed = torch.tensor([ramp], dtype=torch.int64, device="cuda")
+        dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
+        ramp = int(agreed.item())
+    ramp = min(ramp, 4 * max(n, 100))
     chunks = []
     sizes = [n // 4 + (1 if i < n % 4 else 0) for i in range(4)]
     import gc
@@ -390,8 +404,7 @@ def timed_steps(step, n, dist, ramp_ms=40.0):
         # chunk 2.3 ms - 6 % of the LSTM step; the ramp is 12-20 ms long,
         # profiles/r06_step_ramp.txt.  Untimed steps take it; the synchronize
         # below is microseconds)
-        r0 = time.perf_counter()
-        while time.perf_counter() - r0 < ramp_ms * 1e-3:
+        for _ in range(ramp):
             out = step()
         if dist is not None:
             dist.barrier()
